@@ -1,0 +1,1223 @@
+/*
+ * elph_oracle.c — CPU restatement (plain C) of the ElPhDynamics hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (parity oracle + CPU baseline); see elph_oracle.h.
+ * PARITY UNPINNED BY THE REFERENCE (no reference tests/golden vectors, no Julia here).
+ *
+ * Loop structure, pass structure and operation order follow the reference
+ * file:line cited at each function; nothing here is fused or reordered, so that
+ * the timed build (-O3 -march=native -ffast-math, the analogue of the reference's
+ * @fastmath @inbounds @simd) is a fair single-thread stand-in for the Julia code.
+ */
+#include "elph_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ====================================================================== */
+/* geometry                                                               */
+/* ====================================================================== */
+
+static int64_t jl_mod(int64_t a, int64_t m) { /* Julia mod(): result has sign of m */
+    int64_t r = a % m;
+    return (r < 0) ? r + m : r;
+}
+
+/* Lattices.jl:149-168, 384-391 */
+int64_t elpho_loc_to_site(int64_t norbits, int64_t L1, int64_t L2, int64_t L3, int64_t orbit,
+                          int64_t l1, int64_t l2, int64_t l3) {
+    int64_t l1p = jl_mod(l1, L1), l2p = jl_mod(l2, L2), l3p = jl_mod(l3, L3);
+    int64_t cell = l1p + l2p * L1 + l3p * L1 * L2 + 1; /* loc_to_cell, 1-based */
+    return norbits * (cell - 1) + orbit;
+}
+
+/* Lattices.jl:176-191 with site_to_cell / cell_loc as built at Lattices.jl:86-104 */
+int64_t elpho_site_to_site(int64_t norbits, int64_t L1, int64_t L2, int64_t L3, int64_t isite,
+                           const int64_t d[3], int64_t orbit) {
+    int64_t cell = (isite - 1) / norbits; /* 0-based cell */
+    int64_t l1 = cell % L1;
+    int64_t l2 = (cell / L1) % L2;
+    int64_t l3 = cell / (L1 * L2);
+    return elpho_loc_to_site(norbits, L1, L2, L3, orbit, l1 + d[0], l2 + d[1], l3 + d[2]);
+}
+
+/* Lattices.jl:265-316 */
+int64_t elpho_calc_neighbor_table(int64_t norbits, int64_t L1, int64_t L2, int64_t L3, int64_t o1,
+                                  int64_t o2, const int64_t d[3], int remove_duplicates,
+                                  int64_t *table) {
+    int64_t nsites = norbits * L1 * L2 * L3;
+    int64_t N = nsites / norbits;
+    int64_t cnt = 0;
+    for (int64_t isite = o1; isite <= nsites; isite += norbits) {
+        int64_t fsite = elpho_site_to_site(norbits, L1, L2, L3, isite, d, o2);
+        table[2 * cnt + 0] = isite;
+        table[2 * cnt + 1] = fsite;
+        cnt++;
+    }
+    if (!remove_duplicates) return N;
+    char *keep = (char *)malloc((size_t)N);
+    memset(keep, 1, (size_t)N);
+    for (int64_t i = 0; i < N - 1; i++) {
+        if (!keep[i]) continue;
+        int64_t a = table[2 * i], b = table[2 * i + 1];
+        for (int64_t j = i + 1; j < N; j++) {
+            int64_t a2 = table[2 * j], b2 = table[2 * j + 1];
+            if ((a == a2 && b == b2) || (a == b2 && b == a2)) keep[j] = 0;
+        }
+    }
+    int64_t out = 0;
+    for (int64_t i = 0; i < N; i++) {
+        if (keep[i]) {
+            table[2 * out] = table[2 * i];
+            table[2 * out + 1] = table[2 * i + 1];
+            out++;
+        }
+    }
+    free(keep);
+    return out;
+}
+
+/* stable merge sort of indices by key (Julia sortperm is stable) */
+static void msort_idx(const int64_t *keys, int64_t *idx, int64_t *tmp, int64_t lo, int64_t hi) {
+    if (hi - lo < 2) return;
+    int64_t mid = lo + (hi - lo) / 2;
+    msort_idx(keys, idx, tmp, lo, mid);
+    msort_idx(keys, idx, tmp, mid, hi);
+    int64_t a = lo, b = mid, k = lo;
+    while (a < mid && b < hi) {
+        if (keys[idx[b]] < keys[idx[a]]) tmp[k++] = idx[b++];
+        else tmp[k++] = idx[a++];
+    }
+    while (a < mid) tmp[k++] = idx[a++];
+    while (b < hi) tmp[k++] = idx[b++];
+    for (int64_t i = lo; i < hi; i++) idx[i] = tmp[i];
+}
+
+void elpho_sortperm(const int64_t *keys, int64_t n, int64_t *perm) {
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) perm[i] = i;
+    msort_idx(keys, perm, tmp, 0, n);
+    for (int64_t i = 0; i < n; i++) perm[i] += 1; /* 1-based like Julia */
+    free(tmp);
+}
+
+/* Lattices.jl:323-340 */
+void elpho_sorted_neighbor_table_perm(int64_t *table, int64_t nb, int64_t *perm) {
+    int64_t mx = 0;
+    for (int64_t i = 0; i < nb; i++) {
+        int64_t c1 = table[2 * i], c2 = table[2 * i + 1];
+        if (c1 > c2) {
+            table[2 * i] = c2;
+            table[2 * i + 1] = c1;
+        }
+        if (table[2 * i] > mx) mx = table[2 * i];
+        if (table[2 * i + 1] > mx) mx = table[2 * i + 1];
+    }
+    int64_t *vals = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nb > 0 ? nb : 1));
+    for (int64_t i = 0; i < nb; i++) vals[i] = mx * table[2 * i] + table[2 * i + 1];
+    elpho_sortperm(vals, nb, perm);
+    free(vals);
+}
+
+/* Checkerboard.jl:471-515 */
+int64_t elpho_checkerboard_groups(const int64_t *table, int64_t nb, int64_t *groups) {
+    for (int64_t i = 0; i < nb; i++) groups[i] = 0;
+    int64_t group = 0, nassigned = 0;
+    while (nassigned < nb) {
+        group += 1;
+        for (int64_t n = 0; n < nb; n++) {
+            if (groups[n] != 0) continue;
+            groups[n] = group;
+            nassigned += 1;
+            for (int64_t p = 0; p < n; p++) {
+                if (groups[p] != group) continue;
+                if (table[2 * n] == table[2 * p] || table[2 * n + 1] == table[2 * p + 1] ||
+                    table[2 * n] == table[2 * p + 1] || table[2 * n + 1] == table[2 * p]) {
+                    groups[n] = 0;
+                    nassigned -= 1;
+                    break;
+                }
+            }
+        }
+    }
+    return group;
+}
+
+static void permute_table(int64_t *table, int64_t nb, const int64_t *perm1) {
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)(nb > 0 ? nb : 1));
+    memcpy(tmp, table, sizeof(int64_t) * 2 * (size_t)nb);
+    for (int64_t i = 0; i < nb; i++) {
+        table[2 * i] = tmp[2 * (perm1[i] - 1)];
+        table[2 * i + 1] = tmp[2 * (perm1[i] - 1) + 1];
+    }
+    free(tmp);
+}
+static void permute_d(double *v, int64_t nb, const int64_t *perm1) {
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)(nb > 0 ? nb : 1));
+    memcpy(tmp, v, sizeof(double) * (size_t)nb);
+    for (int64_t i = 0; i < nb; i++) v[i] = tmp[perm1[i] - 1];
+    free(tmp);
+}
+
+/* HolsteinModels.jl:484-517 */
+int64_t elpho_holstein_initialize_model(int64_t *table, int64_t nb, const double *t, double dtau,
+                                        double *cosht, double *sinht, int64_t *cb_perm,
+                                        int64_t *groups_sorted) {
+    if (nb <= 0) return 0;
+    for (int64_t i = 0; i < nb; i++) {
+        cosht[i] = cosh(dtau * t[i]);
+        sinht[i] = sinh(dtau * t[i]);
+    }
+    int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+    int64_t *new_perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+    int64_t *groups = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+    int64_t *comp = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+    elpho_sorted_neighbor_table_perm(table, nb, perm);
+    permute_table(table, nb, perm);
+    permute_d(cosht, nb, perm);
+    permute_d(sinht, nb, perm);
+    int64_t ng = elpho_checkerboard_groups(table, nb, groups);
+    elpho_sortperm(groups, nb, new_perm); /* Checkerboard.jl:442-446 */
+    permute_table(table, nb, new_perm);
+    permute_d(cosht, nb, new_perm);
+    permute_d(sinht, nb, new_perm);
+    for (int64_t i = 0; i < nb; i++) comp[i] = perm[new_perm[i] - 1];
+    elpho_sortperm(comp, nb, cb_perm); /* checkerboard_perm = sortperm(perm[new_perm]) */
+    if (groups_sorted)
+        for (int64_t i = 0; i < nb; i++) groups_sorted[i] = groups[new_perm[i] - 1];
+    free(perm);
+    free(new_perm);
+    free(groups);
+    free(comp);
+    return ng;
+}
+
+/* SSHModels.jl:435-448 */
+int64_t elpho_ssh_initialize_table(int64_t *table, int64_t nb, int64_t *cb_perm,
+                                   int64_t *inv_cb_perm, int64_t *groups_sorted) {
+    if (nb <= 0) return 0;
+    int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+    int64_t *new_perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+    int64_t *groups = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+    elpho_sorted_neighbor_table_perm(table, nb, perm);
+    permute_table(table, nb, perm);
+    int64_t ng = elpho_checkerboard_groups(table, nb, groups);
+    elpho_sortperm(groups, nb, new_perm);
+    permute_table(table, nb, new_perm);
+    for (int64_t i = 0; i < nb; i++) inv_cb_perm[i] = perm[new_perm[i] - 1];
+    elpho_sortperm(inv_cb_perm, nb, cb_perm);
+    if (groups_sorted)
+        for (int64_t i = 0; i < nb; i++) groups_sorted[i] = groups[new_perm[i] - 1];
+    free(perm);
+    free(new_perm);
+    free(groups);
+    return ng;
+}
+
+/* HolsteinModels.jl:205 — Julia round(Int, x) rounds ties to even */
+int64_t elpho_ltau(double beta, double dtau) { return (int64_t)rint(beta / dtau); }
+
+/* ====================================================================== */
+/* model update                                                            */
+/* ====================================================================== */
+
+/* HolsteinModels.jl:526-549 */
+void elpho_update_model_holstein(int64_t N, int64_t L, double dtau, const double *x,
+                                 const double *lambda, const double *lambda2, const double *mu,
+                                 double *expV) {
+    for (int64_t i = 0; i < N; i++) {
+        for (int64_t tau = 0; tau < L; tau++) {
+            int64_t idx = i * L + tau;
+            expV[idx] = exp(-dtau * (lambda[i] * x[idx] + lambda2[i] * (x[idx] * x[idx]) + -mu[i]));
+        }
+    }
+}
+
+static double jl_sign(double x) { return (x > 0) ? 1.0 : ((x < 0) ? -1.0 : x); }
+
+/* SSHModels.jl:510-535 */
+void elpho_update_model_ssh(int64_t N, int64_t L, int64_t nb, int64_t Nph, double dtau,
+                            const double *x, const double *t, const double *alpha,
+                            const double *alpha2, const double *mu,
+                            const int64_t *phonon_to_bond, const int64_t *cb_perm, double *cosht,
+                            double *sinht, double *expDtauMu) {
+    (void)nb;
+    for (int64_t i = 0; i < N; i++) expDtauMu[i] = exp(dtau * mu[i]);
+    for (int64_t field = 0; field < Nph * L; field++) {
+        int64_t phonon = field / L; /* field_to_phonon = repeat(1:Nph, inner=L) */
+        int64_t tau = field % L;    /* field_to_tau    = repeat(1:L, outer=Nph) */
+        int64_t bond = phonon_to_bond[phonon] - 1;
+        int64_t index = cb_perm[bond] - 1;
+        double xt = x[field];
+        double v = alpha[phonon] * xt + jl_sign(xt) * alpha2[phonon] * (xt * xt);
+        double tp = t[bond] - v;
+        cosht[tau + L * index] = cosh(dtau * tp);
+        sinht[tau + L * index] = sinh(dtau * tp);
+    }
+}
+
+/* ====================================================================== */
+/* checkerboard products                                                   */
+/* ====================================================================== */
+
+/* Checkerboard.jl:57-83 */
+void elpho_checkerboard_mul(double *y, const int64_t *table, const double *c, const double *s,
+                            int64_t nb, int64_t L) {
+    for (int64_t n = 0; n < nb; n++) {
+        double cn = c[n], sn = s[n];
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double *yi = y + i * L, *yj = y + j * L;
+        for (int64_t tau = 0; tau < L; tau++) {
+            double t1 = yi[tau], t2 = yj[tau];
+            yi[tau] = cn * t1 + sn * t2;
+            yj[tau] = cn * t2 + sn * t1;
+        }
+    }
+}
+
+/* Checkerboard.jl:149-175 */
+void elpho_checkerboard_transpose_mul(double *y, const int64_t *table, const double *c,
+                                      const double *s, int64_t nb, int64_t L) {
+    for (int64_t n = nb - 1; n >= 0; n--) {
+        double cn = c[n], sn = s[n];
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double *yi = y + i * L, *yj = y + j * L;
+        for (int64_t tau = 0; tau < L; tau++) {
+            double t1 = yi[tau], t2 = yj[tau];
+            yi[tau] = cn * t1 + sn * t2;
+            yj[tau] = cn * t2 + sn * t1;
+        }
+    }
+}
+
+/* Checkerboard.jl:238-264 */
+void elpho_checkerboard_inverse_mul(double *y, const int64_t *table, const double *c,
+                                    const double *s, int64_t nb, int64_t L) {
+    for (int64_t n = nb - 1; n >= 0; n--) {
+        double cn = c[n], sn = s[n];
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double *yi = y + i * L, *yj = y + j * L;
+        for (int64_t tau = 0; tau < L; tau++) {
+            double t1 = yi[tau], t2 = yj[tau];
+            yi[tau] = cn * t1 - sn * t2;
+            yj[tau] = cn * t2 - sn * t1;
+        }
+    }
+}
+
+/* Checkerboard.jl:323-349 */
+void elpho_checkerboard_inverse_transpose_mul(double *y, const int64_t *table, const double *c,
+                                              const double *s, int64_t nb, int64_t L) {
+    for (int64_t n = 0; n < nb; n++) {
+        double cn = c[n], sn = s[n];
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double *yi = y + i * L, *yj = y + j * L;
+        for (int64_t tau = 0; tau < L; tau++) {
+            double t1 = yi[tau], t2 = yj[tau];
+            yi[tau] = cn * t1 - sn * t2;
+            yj[tau] = cn * t2 - sn * t1;
+        }
+    }
+}
+
+/* Checkerboard.jl:86-121 */
+void elpho_checkerboard_mul_mat(double *y, const int64_t *table, const double *c, const double *s,
+                                int64_t nb, int64_t L) {
+    for (int64_t n = 0; n < nb; n++) {
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double *yi = y + i * L, *yj = y + j * L;
+        const double *cn = c + n * L, *sn = s + n * L;
+        for (int64_t tau = 0; tau < L; tau++) {
+            double t1 = yi[tau], t2 = yj[tau];
+            yi[tau] = cn[tau] * t1 + sn[tau] * t2;
+            yj[tau] = cn[tau] * t2 + sn[tau] * t1;
+        }
+    }
+}
+
+/* Checkerboard.jl:177-210 */
+void elpho_checkerboard_transpose_mul_mat(double *y, const int64_t *table, const double *c,
+                                          const double *s, int64_t nb, int64_t L) {
+    for (int64_t n = nb - 1; n >= 0; n--) {
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double *yi = y + i * L, *yj = y + j * L;
+        const double *cn = c + n * L, *sn = s + n * L;
+        for (int64_t tau = 0; tau < L; tau++) {
+            double t1 = yi[tau], t2 = yj[tau];
+            yi[tau] = cn[tau] * t1 + sn[tau] * t2;
+            yj[tau] = cn[tau] * t2 + sn[tau] * t1;
+        }
+    }
+}
+
+/* Checkerboard.jl:123-141, complex y */
+void elpho_checkerboard_mul_nvec_z(double *y, const int64_t *table, const double *c,
+                                   const double *s, int64_t nb) {
+    for (int64_t n = 0; n < nb; n++) {
+        double cn = c[n], sn = s[n];
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double t1r = y[2 * i], t1i = y[2 * i + 1], t2r = y[2 * j], t2i = y[2 * j + 1];
+        y[2 * i] = cn * t1r + sn * t2r;
+        y[2 * i + 1] = cn * t1i + sn * t2i;
+        y[2 * j] = cn * t2r + sn * t1r;
+        y[2 * j + 1] = cn * t2i + sn * t1i;
+    }
+}
+
+/* Checkerboard.jl:212-230, complex y */
+void elpho_checkerboard_transpose_mul_nvec_z(double *y, const int64_t *table, const double *c,
+                                             const double *s, int64_t nb) {
+    for (int64_t n = nb - 1; n >= 0; n--) {
+        double cn = c[n], sn = s[n];
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double t1r = y[2 * i], t1i = y[2 * i + 1], t2r = y[2 * j], t2i = y[2 * j + 1];
+        y[2 * i] = cn * t1r + sn * t2r;
+        y[2 * i + 1] = cn * t1i + sn * t2i;
+        y[2 * j] = cn * t2r + sn * t1r;
+        y[2 * j + 1] = cn * t2i + sn * t1i;
+    }
+}
+
+/* Checkerboard.jl:123-141, real y */
+void elpho_checkerboard_mul_nvec(double *y, const int64_t *table, const double *c, const double *s,
+                                 int64_t nb) {
+    for (int64_t n = 0; n < nb; n++) {
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double t1 = y[i], t2 = y[j];
+        y[i] = c[n] * t1 + s[n] * t2;
+        y[j] = c[n] * t2 + s[n] * t1;
+    }
+}
+
+/* Checkerboard.jl:298-316, real y */
+void elpho_checkerboard_inverse_mul_nvec(double *y, const int64_t *table, const double *c,
+                                         const double *s, int64_t nb) {
+    for (int64_t n = nb - 1; n >= 0; n--) {
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        double t1 = y[i], t2 = y[j];
+        y[i] = c[n] * t1 - s[n] * t2;
+        y[j] = c[n] * t2 - s[n] * t1;
+    }
+}
+
+/* ====================================================================== */
+/* M, M^T, M^T M                                                           */
+/* ====================================================================== */
+
+/* HolsteinModels.jl:569-626 ; SSHModels.jl:581-640 */
+void elpho_mulM(double *y, const elpho_model *m, const double *v) {
+    const int64_t N = m->N, L = m->L;
+    /* pass 1: y(tau) = E .* v(tau-1)   (mod1 wrap) */
+    for (int64_t i = 0; i < N; i++) {
+        for (int64_t tau = 0; tau < L; tau++) {
+            int64_t taum1 = (tau == 0) ? L - 1 : tau - 1;
+            double e = (m->kind == 0) ? m->E[i * L + tau] : m->E[i];
+            y[i * L + tau] = e * v[i * L + taum1];
+        }
+    }
+    /* pass 2: checkerboard */
+    if (m->nb > 0) {
+        if (m->kind == 0) elpho_checkerboard_mul(y, m->table, m->c, m->s, m->nb, L);
+        else elpho_checkerboard_mul_mat(y, m->table, m->c, m->s, m->nb, L);
+    }
+    /* pass 3: combine */
+    for (int64_t i = 0; i < N; i++) {
+        y[i * L] = v[i * L] + y[i * L];
+        for (int64_t tau = 1; tau < L; tau++) y[i * L + tau] = v[i * L + tau] - y[i * L + tau];
+    }
+}
+
+/* HolsteinModels.jl:631-684 ; SSHModels.jl:646-701 */
+void elpho_mulMT(double *y, const elpho_model *m, const double *v) {
+    const int64_t N = m->N, L = m->L;
+    memcpy(y, v, sizeof(double) * (size_t)(N * L));
+    if (m->nb > 0) {
+        if (m->kind == 0) elpho_checkerboard_transpose_mul(y, m->table, m->c, m->s, m->nb, L);
+        else elpho_checkerboard_transpose_mul_mat(y, m->table, m->c, m->s, m->nb, L);
+    }
+    for (int64_t i = 0; i < N; i++) {
+        const double *Ei = (m->kind == 0) ? (m->E + i * L) : NULL;
+        double ei = (m->kind == 0) ? 0.0 : m->E[i];
+        double *yi = y + i * L;
+        const double *vi = v + i * L;
+        double y_iL = vi[L - 1] + ((m->kind == 0) ? Ei[0] : ei) * yi[0];
+        for (int64_t tau = 0; tau < L - 1; tau++)
+            yi[tau] = vi[tau] - ((m->kind == 0) ? Ei[tau + 1] : ei) * yi[tau + 1];
+        yi[L - 1] = y_iL;
+    }
+}
+
+/* Models.jl:215-224 */
+void elpho_mulMTM(double *y, const elpho_model *m, const double *v) {
+    elpho_mulM(m->vp, m, v);
+    elpho_mulMT(y, m, m->vp);
+}
+
+/* ====================================================================== */
+/* DFT along tau                                                           */
+/* ====================================================================== */
+
+/* FFTW.jl conventions (un-vendored dep FFTW.jl 1.3.2 / FFTW_jll 3.3.9):
+ * fft: X[k] = sum_t x[t] exp(-2 pi i k t / L); ifft: same with +, scaled 1/L.
+ * Restated as a direct O(L^2) sum with an exactly index-reduced twiddle table. */
+void elpho_dft_tau(double *out_z, const double *in_z, int64_t N, int64_t L, int sign) {
+    double *wr = (double *)malloc(sizeof(double) * (size_t)L);
+    double *wi = (double *)malloc(sizeof(double) * (size_t)L);
+    double *tmp = (double *)malloc(sizeof(double) * 2 * (size_t)L);
+    for (int64_t m = 0; m < L; m++) {
+        double a = 2.0 * M_PI * (double)m / (double)L;
+        wr[m] = cos(a);
+        wi[m] = (sign < 0) ? -sin(a) : sin(a);
+    }
+    double scale = (sign < 0) ? 1.0 : 1.0 / (double)L;
+    for (int64_t i = 0; i < N; i++) {
+        const double *x = in_z + 2 * i * L;
+        for (int64_t k = 0; k < L; k++) {
+            double sr = 0.0, si = 0.0;
+            int64_t m = 0;
+            for (int64_t t = 0; t < L; t++) {
+                double xr = x[2 * t], xi = x[2 * t + 1];
+                sr += xr * wr[m] - xi * wi[m];
+                si += xr * wi[m] + xi * wr[m];
+                m += k;
+                if (m >= L) m -= L;
+            }
+            tmp[2 * k] = sr * scale;
+            tmp[2 * k + 1] = si * scale;
+        }
+        memcpy(out_z + 2 * i * L, tmp, sizeof(double) * 2 * (size_t)L);
+    }
+    free(wr);
+    free(wi);
+    free(tmp);
+}
+
+/* TimeFreqFFTs.jl:37 (Theta), :55-73 */
+void elpho_tau_to_omega(double *out_z, const double *in, int64_t N, int64_t L) {
+    double *vtemp = (double *)malloc(sizeof(double) * 2 * (size_t)(N * L));
+    for (int64_t i = 0; i < N; i++) {
+        for (int64_t t = 0; t < L; t++) {
+            double a = -M_PI * (double)t / (double)L; /* Theta[t] = exp(-i pi t/L), t 0-based */
+            vtemp[2 * (i * L + t)] = cos(a) * in[i * L + t];
+            vtemp[2 * (i * L + t) + 1] = sin(a) * in[i * L + t];
+        }
+    }
+    elpho_dft_tau(out_z, vtemp, N, L, -1);
+    free(vtemp);
+}
+
+/* TimeFreqFFTs.jl:112-130 */
+void elpho_omega_to_tau(double *out, const double *in_z, int64_t N, int64_t L) {
+    double *vtemp = (double *)malloc(sizeof(double) * 2 * (size_t)(N * L));
+    elpho_dft_tau(vtemp, in_z, N, L, +1);
+    for (int64_t i = 0; i < N; i++) {
+        for (int64_t t = 0; t < L; t++) {
+            double a = -M_PI * (double)t / (double)L;
+            double cr = cos(a), ci = -sin(a); /* conj(Theta) */
+            double vr = vtemp[2 * (i * L + t)], vi = vtemp[2 * (i * L + t) + 1];
+            out[i * L + t] = cr * vr - ci * vi;
+        }
+    }
+    free(vtemp);
+}
+
+/* ====================================================================== */
+/* Fourier acceleration                                                    */
+/* ====================================================================== */
+
+/* FourierAcceleration.jl:260-266 */
+double elpho_element_Mi(int64_t k, double omega, double dtau, double m0, double c, int64_t L) {
+    int64_t kp = (k < L - k) ? k : L - k;
+    double q = c * (double)kp / (double)L;
+    double m = m0 * exp(-(q * q));
+    return dtau * (m * m + omega * omega + (2.0 - 2.0 * cos(2.0 * M_PI * (double)kp / (double)L)) / (dtau * dtau)) /
+           (m * m + omega * omega);
+}
+
+/* FourierAcceleration.jl:213-217 */
+double elpho_element_Qi(int64_t k, double omega, double dtau, double m, int64_t L) {
+    return (m * m + dtau * omega * omega + 4.0 / dtau) /
+           (m * m + dtau * omega * omega + (2.0 - 2.0 * cos(2.0 * M_PI * (double)k / (double)L)) / dtau);
+}
+
+/* FourierAcceleration.jl:222-240,245-255 */
+void elpho_update_M(double *Mdiag, int64_t Nph, int64_t L, double dtau, const double *omega,
+                    double wmin, double wmax, double m0, double c) {
+    for (int64_t ph = 0; ph < Nph; ph++)
+        if (wmin < omega[ph] && omega[ph] < wmax)
+            for (int64_t k = 0; k < L; k++) Mdiag[ph * L + k] = elpho_element_Mi(k, omega[ph], dtau, m0, c, L);
+}
+
+/* FourierAcceleration.jl:176-208 */
+void elpho_update_Q(double *Qdiag, int64_t Nph, int64_t L, double dtau, const double *omega,
+                    double wmin, double wmax, double m) {
+    for (int64_t ph = 0; ph < Nph; ph++)
+        if (wmin < omega[ph] && omega[ph] < wmax)
+            for (int64_t k = 0; k < L; k++) Qdiag[ph * L + k] = elpho_element_Qi(k, omega[ph], dtau, m, L);
+}
+
+/* FourierAcceleration.jl:91-114,137-143 */
+void elpho_fourier_accelerate(double *out, const double *in, const double *diag, double power,
+                              int64_t N, int64_t L) {
+    size_t n = (size_t)(N * L);
+    double *vin = (double *)malloc(sizeof(double) * 2 * n);
+    double *u = (double *)malloc(sizeof(double) * 2 * n);
+    for (size_t i = 0; i < n; i++) {
+        vin[2 * i] = in[i];
+        vin[2 * i + 1] = 0.0;
+    }
+    elpho_dft_tau(u, vin, N, L, -1);
+    for (size_t i = 0; i < n; i++) {
+        double f = pow(diag[i], power);
+        u[2 * i] *= f;
+        u[2 * i + 1] *= f;
+    }
+    elpho_dft_tau(vin, u, N, L, +1);
+    for (size_t i = 0; i < n; i++) out[i] = vin[2 * i];
+    free(vin);
+    free(u);
+}
+
+/* ====================================================================== */
+/* small dense eigenvalues (stand-in for LAPACK eigvals!, KPMPreconditioners.jl:891,935) */
+/* Hessenberg reduction + shifted QR (EISPACK elmhes/hqr algorithm).        */
+/* ====================================================================== */
+
+#define A_(i, j) a[(i) + (j) * n]
+
+static void elmhes(double *a, int64_t n) {
+    for (int64_t m = 1; m < n - 1; m++) {
+        double x = 0.0;
+        int64_t i = m;
+        for (int64_t j = m; j < n; j++) {
+            if (fabs(A_(j, m - 1)) > fabs(x)) {
+                x = A_(j, m - 1);
+                i = j;
+            }
+        }
+        if (i != m) {
+            for (int64_t j = m - 1; j < n; j++) {
+                double t = A_(i, j);
+                A_(i, j) = A_(m, j);
+                A_(m, j) = t;
+            }
+            for (int64_t j = 0; j < n; j++) {
+                double t = A_(j, i);
+                A_(j, i) = A_(j, m);
+                A_(j, m) = t;
+            }
+        }
+        if (x != 0.0) {
+            for (i = m + 1; i < n; i++) {
+                double y = A_(i, m - 1);
+                if (y != 0.0) {
+                    y /= x;
+                    A_(i, m - 1) = y;
+                    for (int64_t j = m; j < n; j++) A_(i, j) -= y * A_(m, j);
+                    for (int64_t j = 0; j < n; j++) A_(j, m) += y * A_(j, i);
+                }
+            }
+        }
+    }
+    for (int64_t j = 0; j < n; j++)
+        for (int64_t i = j + 2; i < n; i++) A_(i, j) = 0.0;
+}
+
+static double sign_of(double a, double b) { return (b >= 0.0) ? fabs(a) : -fabs(a); }
+
+static int hqr(double *a, int64_t n, double *wr, double *wi) {
+    int64_t nn, m, l, k, j, its, i, mmin;
+    double z, y, x, w, v, u, t, s, r = 0, q = 0, p = 0, anorm = 0.0;
+    for (i = 0; i < n; i++)
+        for (j = (i > 0 ? i - 1 : 0); j < n; j++) anorm += fabs(A_(i, j));
+    nn = n - 1;
+    t = 0.0;
+    while (nn >= 0) {
+        its = 0;
+        do {
+            for (l = nn; l >= 1; l--) {
+                s = fabs(A_(l - 1, l - 1)) + fabs(A_(l, l));
+                if (s == 0.0) s = anorm;
+                if (fabs(A_(l, l - 1)) + s == s) {
+                    A_(l, l - 1) = 0.0;
+                    break;
+                }
+            }
+            x = A_(nn, nn);
+            if (l == nn) {
+                wr[nn] = x + t;
+                wi[nn--] = 0.0;
+            } else {
+                y = A_(nn - 1, nn - 1);
+                w = A_(nn, nn - 1) * A_(nn - 1, nn);
+                if (l == nn - 1) {
+                    p = 0.5 * (y - x);
+                    q = p * p + w;
+                    z = sqrt(fabs(q));
+                    x += t;
+                    if (q >= 0.0) {
+                        z = p + sign_of(z, p);
+                        wr[nn - 1] = wr[nn] = x + z;
+                        if (z != 0.0) wr[nn] = x - w / z;
+                        wi[nn - 1] = wi[nn] = 0.0;
+                    } else {
+                        wr[nn - 1] = wr[nn] = x + p;
+                        wi[nn - 1] = -(wi[nn] = z);
+                    }
+                    nn -= 2;
+                } else {
+                    if (its == 60) return -1;
+                    if (its == 10 || its == 20) {
+                        t += x;
+                        for (i = 0; i <= nn; i++) A_(i, i) -= x;
+                        s = fabs(A_(nn, nn - 1)) + fabs(A_(nn - 1, nn - 2));
+                        y = x = 0.75 * s;
+                        w = -0.4375 * s * s;
+                    }
+                    ++its;
+                    for (m = nn - 2; m >= l; m--) {
+                        z = A_(m, m);
+                        r = x - z;
+                        s = y - z;
+                        p = (r * s - w) / A_(m + 1, m) + A_(m, m + 1);
+                        q = A_(m + 1, m + 1) - z - r - s;
+                        r = A_(m + 2, m + 1);
+                        s = fabs(p) + fabs(q) + fabs(r);
+                        p /= s;
+                        q /= s;
+                        r /= s;
+                        if (m == l) break;
+                        u = fabs(A_(m, m - 1)) * (fabs(q) + fabs(r));
+                        v = fabs(p) * (fabs(A_(m - 1, m - 1)) + fabs(z) + fabs(A_(m + 1, m + 1)));
+                        if (u + v == v) break;
+                    }
+                    for (i = m + 2; i <= nn; i++) {
+                        A_(i, i - 2) = 0.0;
+                        if (i != m + 2) A_(i, i - 3) = 0.0;
+                    }
+                    for (k = m; k <= nn - 1; k++) {
+                        if (k != m) {
+                            p = A_(k, k - 1);
+                            q = A_(k + 1, k - 1);
+                            r = 0.0;
+                            if (k != nn - 1) r = A_(k + 2, k - 1);
+                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) {
+                                p /= x;
+                                q /= x;
+                                r /= x;
+                            }
+                        }
+                        if ((s = sign_of(sqrt(p * p + q * q + r * r), p)) != 0.0) {
+                            if (k == m) {
+                                if (l != m) A_(k, k - 1) = -A_(k, k - 1);
+                            } else {
+                                A_(k, k - 1) = -s * x;
+                            }
+                            p += s;
+                            x = p / s;
+                            y = q / s;
+                            z = r / s;
+                            q /= p;
+                            r /= p;
+                            for (j = k; j <= nn; j++) {
+                                p = A_(k, j) + q * A_(k + 1, j);
+                                if (k != nn - 1) {
+                                    p += r * A_(k + 2, j);
+                                    A_(k + 2, j) -= p * z;
+                                }
+                                A_(k + 1, j) -= p * y;
+                                A_(k, j) -= p * x;
+                            }
+                            mmin = nn < k + 3 ? nn : k + 3;
+                            for (i = l; i <= mmin; i++) {
+                                p = x * A_(i, k) + y * A_(i, k + 1);
+                                if (k != nn - 1) {
+                                    p += z * A_(i, k + 2);
+                                    A_(i, k + 2) -= p * r;
+                                }
+                                A_(i, k + 1) -= p * q;
+                                A_(i, k) -= p;
+                            }
+                        }
+                    }
+                }
+            }
+        } while (l < nn - 1);
+    }
+    return 0;
+}
+#undef A_
+
+int elpho_eigvals(double *a, int64_t n, double *wr, double *wi) {
+    if (n <= 0) return 0;
+    if (n == 1) {
+        wr[0] = a[0];
+        wi[0] = 0.0;
+        return 0;
+    }
+    elmhes(a, n);
+    return hqr(a, n, wr, wi);
+}
+
+/* ====================================================================== */
+/* KPM preconditioner                                                      */
+/* ====================================================================== */
+
+/* KPMPreconditioners.jl:332-349 (Holstein), 355-381 (SSH) */
+void elpho_kpm_update_A(elpho_kpm *P, const elpho_model *m) {
+    int64_t N = m->N, L = m->L;
+    if (m->kind == 0) {
+        for (int64_t i = 0; i < N; i++) {
+            P->Ebar[i] = 0.0;
+            for (int64_t tau = 0; tau < L; tau++) P->Ebar[i] += m->E[i * L + tau];
+            P->Ebar[i] /= (double)L;
+        }
+        /* ctor, KPMPreconditioners.jl:124-126: cbar/sbar = model.cosht/sinht */
+        for (int64_t n = 0; n < m->nb; n++) {
+            P->cbar[n] = m->c[n];
+            P->sbar[n] = m->s[n];
+        }
+    } else {
+        for (int64_t n = 0; n < m->nb; n++) {
+            P->cbar[n] = 0.0;
+            P->sbar[n] = 0.0;
+            for (int64_t tau = 0; tau < L; tau++) {
+                P->cbar[n] += m->c[tau + L * n];
+                P->sbar[n] += m->s[tau + L * n];
+            }
+            P->cbar[n] /= (double)L;
+            P->sbar[n] /= (double)L;
+        }
+        for (int64_t i = 0; i < N; i++) P->Ebar[i] = m->E[i];
+    }
+}
+
+/* KPMPreconditioners.jl:789-839 with scalar_invM :948-951.
+ * The reference evaluates the sums with FFTW.dct! (unitary DCT-II) and undoes the
+ * normalisation; restated here as the direct DCT-II sum it equals:
+ *   c_m = (2 - delta_m0)/N_M * sum_{n<N_M} f(x_n) cos(pi m (n+1/2)/N_M),  N_M = 2*order. */
+void elpho_kpm_coefficients(double *c_z, int64_t order, double lam_lo, double lam_hi, double phi) {
+    int64_t M = order, NM = 2 * M;
+    double lam_avg = (lam_hi + lam_lo) / 2, lam_mag = (lam_hi - lam_lo) / 2;
+    double *fr = (double *)malloc(sizeof(double) * (size_t)NM);
+    double *fi = (double *)malloc(sizeof(double) * (size_t)NM);
+    double er = cos(phi), ei = -sin(phi); /* exp(-i phi) */
+    for (int64_t n = 0; n < NM; n++) {
+        double x = lam_mag * cos(M_PI * ((double)n + 0.5) / (double)NM) + lam_avg;
+        double dr = 1.0 - er * x, di = -ei * x; /* 1 - exp(-i phi) x */
+        double den = dr * dr + di * di;
+        fr[n] = dr / den;
+        fi[n] = -di / den;
+    }
+    for (int64_t m = 0; m < M; m++) {
+        double sr = 0.0, si = 0.0;
+        for (int64_t n = 0; n < NM; n++) {
+            double cs = cos(M_PI * (double)m * ((double)n + 0.5) / (double)NM);
+            sr += fr[n] * cs;
+            si += fi[n] * cs;
+        }
+        double f = ((m == 0) ? 1.0 : 2.0) / (double)NM;
+        c_z[2 * m] = f * sr;
+        c_z[2 * m + 1] = f * si;
+    }
+    free(fr);
+    free(fi);
+}
+
+/* A v = CBbar (Ebar .* v) — KPMPreconditioners.jl:387-401 (real arithmetic) */
+static void kpm_A_real(double *vp, const elpho_kpm *P, const double *v) {
+    for (int64_t i = 0; i < P->N; i++) vp[i] = P->Ebar[i] * v[i];
+    elpho_checkerboard_mul_nvec(vp, P->table, P->cbar, P->sbar, P->nb);
+}
+/* A^-1 v — KPMPreconditioners.jl:406-420 */
+static void kpm_Ainv_real(double *vp, const elpho_kpm *P, const double *v) {
+    for (int64_t i = 0; i < P->N; i++) vp[i] = v[i];
+    elpho_checkerboard_inverse_mul_nvec(vp, P->table, P->cbar, P->sbar, P->nb);
+    for (int64_t i = 0; i < P->N; i++) vp[i] /= P->Ebar[i];
+}
+
+static double arnoldi_max_ritz(const elpho_kpm *P, int64_t n, const double *b0, int inverse) {
+    int64_t m = P->N;
+    double *Q = (double *)calloc((size_t)(m * (n + 1)), sizeof(double));
+    double *h = (double *)calloc((size_t)((n + 1) * n), sizeof(double)); /* (n+1) x n col-major */
+    double *b = (double *)malloc(sizeof(double) * (size_t)m);
+    double *v = (double *)malloc(sizeof(double) * (size_t)m);
+    double nrm = 0.0;
+    for (int64_t i = 0; i < m; i++) nrm += b0[i] * b0[i];
+    nrm = sqrt(nrm);
+    for (int64_t i = 0; i < m; i++) {
+        b[i] = b0[i] / nrm;
+        Q[i] = b[i];
+    }
+    int64_t l = n;
+    for (int64_t k = 0; k < n; k++) {
+        if (inverse) kpm_Ainv_real(v, P, b);
+        else kpm_A_real(v, P, b);
+        for (int64_t j = 0; j <= k; j++) {
+            const double *Qj = Q + j * m;
+            double d = 0.0;
+            for (int64_t i = 0; i < m; i++) d += Qj[i] * v[i];
+            h[j + (n + 1) * k] = d;
+            for (int64_t i = 0; i < m; i++) v[i] -= d * Qj[i];
+        }
+        double nv = 0.0;
+        for (int64_t i = 0; i < m; i++) nv += v[i] * v[i];
+        nv = sqrt(nv);
+        h[(k + 1) + (n + 1) * k] = nv;
+        if (nv > 1e-12) {
+            for (int64_t i = 0; i < m; i++) {
+                b[i] = v[i] / nv;
+                Q[(k + 1) * m + i] = b[i];
+            }
+        } else {
+            l = k + 1;
+            break;
+        }
+    }
+    double *hp = (double *)malloc(sizeof(double) * (size_t)(l * l));
+    int finite = 1;
+    for (int64_t j = 0; j < l; j++)
+        for (int64_t i = 0; i < l; i++) {
+            hp[i + l * j] = h[i + (n + 1) * j];
+            if (!isfinite(hp[i + l * j])) finite = 0;
+        }
+    double res = INFINITY;
+    if (finite) {
+        double *wr = (double *)malloc(sizeof(double) * (size_t)l);
+        double *wi = (double *)malloc(sizeof(double) * (size_t)l);
+        if (elpho_eigvals(hp, l, wr, wi) == 0) {
+            res = wr[0];
+            for (int64_t i = 1; i < l; i++)
+                if (wr[i] > res) res = wr[i];
+        }
+        free(wr);
+        free(wi);
+    }
+    free(hp);
+    free(Q);
+    free(h);
+    free(b);
+    free(v);
+    return res;
+}
+
+/* KPMPreconditioners.jl:845-942 (random start vectors injected) */
+void elpho_kpm_arnoldi_bounds(const elpho_kpm *P, int64_t n, const double *b_max,
+                              const double *b_min, double *e_min, double *e_max) {
+    if (n > P->N) n = P->N; /* KPMPreconditioners.jl:136 */
+    double emax = arnoldi_max_ritz(P, n, b_max, 0);
+    double r = arnoldi_max_ritz(P, n, b_min, 1);
+    *e_max = emax;
+    *e_min = isfinite(r) ? 1.0 / r : -INFINITY;
+}
+
+static int jl_isapprox(double x, double y, double rtol) {
+    double ax = fabs(x), ay = fabs(y);
+    return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= rtol * (ax > ay ? ax : ay));
+}
+
+/* KPMPreconditioners.jl:269-321 */
+void elpho_kpm_setup_from_bounds(elpho_kpm *P, double e_min, double e_max) {
+    if ((0.0 < e_min && e_min < 1.0) && (1.0 < e_max) && (e_max - e_min) < 2.0) {
+        double lo = (1 - 2 * P->buf) * e_min;
+        if (lo < 0.0) lo = 0.0;
+        double hi = (1 + 2 * P->buf) * e_max;
+        if (!jl_isapprox(lo, P->lam_lo, P->buf) || !jl_isapprox(hi, P->lam_hi, P->buf)) {
+            P->lam_lo = lo;
+            P->lam_hi = hi;
+            P->lam_avg = (hi + lo) / 2;
+            P->lam_mag = (hi - lo) / 2;
+            int64_t off = 0;
+            for (int64_t w = 0; w < P->Lo2; w++) {
+                double phi = 2.0 * M_PI / (double)P->L * ((double)w + 0.5);
+                int64_t order = (int64_t)floor((hi - lo) * (P->c1 / phi + P->c2));
+                if (order < 1) order = 1;
+                P->order[w] = order;
+                P->coff[w] = off;
+                if (off + order <= P->coeff_cap)
+                    elpho_kpm_coefficients(P->coeff + 2 * off, order, lo, hi, phi);
+                off += order;
+            }
+            P->coff[P->Lo2] = off;
+        }
+        P->active = 1;
+    } else {
+        P->active = 0;
+    }
+}
+
+/* KPMPreconditioners.jl:758-778 (SymmetricKPMPreconditioner), complex vectors length N */
+static void kpm_mulA_z(double *vp, elpho_kpm *P, const double *v, int transposed) {
+    int64_t N = P->N;
+    if (transposed) {
+        memcpy(vp, v, sizeof(double) * 2 * (size_t)N);
+        elpho_checkerboard_transpose_mul_nvec_z(vp, P->table, P->cbar, P->sbar, P->nb);
+        for (int64_t i = 0; i < N; i++) {
+            vp[2 * i] *= P->Ebar[i];
+            vp[2 * i + 1] *= P->Ebar[i];
+        }
+    } else {
+        for (int64_t i = 0; i < N; i++) {
+            vp[2 * i] = P->Ebar[i] * v[2 * i];
+            vp[2 * i + 1] = P->Ebar[i] * v[2 * i + 1];
+        }
+        elpho_checkerboard_mul_nvec_z(vp, P->table, P->cbar, P->sbar, P->nb);
+    }
+    P->checkerboard_count += 1;
+}
+
+/* KPMPreconditioners.jl:685-693 */
+static void kpm_mulAprime_z(double *vp, elpho_kpm *P, const double *v, int transposed) {
+    kpm_mulA_z(vp, P, v, transposed);
+    double a = 1.0 / P->lam_mag, b = P->lam_avg / P->lam_mag;
+    for (int64_t i = 0; i < 2 * P->N; i++) vp[i] = a * vp[i] - b * v[i];
+}
+
+/* one Chebyshev series  vp = sum_m cc_m T_m(A') u1, with cc = conj(c) if conjc.
+ * KPMPreconditioners.jl:623-648 (first half) and :653-677 (second half) share this shape. */
+static void kpm_series(double *vp, elpho_kpm *P, const double *c, int64_t order, int conjc,
+                       int transposed, int from_vp, const double *v) {
+    int64_t N = P->N;
+    double *um1 = P->v3, *un = P->v4, *up1 = P->v5;
+    double c0r = c[0], c0i = conjc ? -c[1] : c[1];
+    if (from_vp) {
+        /* second half: u1 = v'; v' = c1 * v' */
+        if (order > 1) memcpy(un, vp, sizeof(double) * 2 * (size_t)N);
+        for (int64_t i = 0; i < N; i++) {
+            double xr = vp[2 * i], xi = vp[2 * i + 1];
+            vp[2 * i] = c0r * xr - c0i * xi;
+            vp[2 * i + 1] = c0r * xi + c0i * xr;
+        }
+    } else {
+        for (int64_t i = 0; i < N; i++) {
+            double xr = v[2 * i], xi = v[2 * i + 1];
+            vp[2 * i] = c0r * xr - c0i * xi;
+            vp[2 * i + 1] = c0r * xi + c0i * xr;
+        }
+        if (order > 1) memcpy(un, v, sizeof(double) * 2 * (size_t)N);
+    }
+    if (order > 1) {
+        int64_t n = 1;
+        kpm_mulAprime_z(up1, P, un, transposed);
+        for (;;) {
+            n += 1;
+            double *tmp = um1;
+            um1 = un;
+            un = up1;
+            up1 = tmp;
+            double cr = c[2 * (n - 1)], ci = conjc ? -c[2 * (n - 1) + 1] : c[2 * (n - 1) + 1];
+            for (int64_t i = 0; i < N; i++) {
+                double xr = un[2 * i], xi = un[2 * i + 1];
+                vp[2 * i] += cr * xr - ci * xi;
+                vp[2 * i + 1] += cr * xi + ci * xr;
+            }
+            if (n == order) break;
+            kpm_mulAprime_z(up1, P, un, transposed);
+            for (int64_t i = 0; i < 2 * N; i++) up1[i] = 2 * up1[i] - um1[i];
+        }
+    }
+}
+
+/* KPMPreconditioners.jl:606-679 */
+static void kpm_sym_mul(double *vp, elpho_kpm *P, const double *v, int64_t w) {
+    int64_t order = P->order[w];
+    const double *c = P->coeff + 2 * P->coff[w];
+    kpm_series(vp, P, c, order, 1, 1, 0, v);    /* M^-T[w,w], conj coefficients */
+    kpm_series(vp, P, c, order, 0, 0, 1, NULL); /* M^-1[w,w] */
+}
+
+/* KPMPreconditioners.jl:426-481 */
+void elpho_kpm_apply(double *out, elpho_kpm *P, const double *in) {
+    int64_t N = P->N, L = P->L;
+    P->checkerboard_count = 0;
+    if (!P->active) {
+        memcpy(out, in, sizeof(double) * (size_t)(N * L));
+        return;
+    }
+    double *v1 = P->v1, *v2 = P->v2;
+    elpho_tau_to_omega(v2, in, N, L);
+    /* transpose!(a1T, a2): a1T[i,w] = a2[w,i] */
+    for (int64_t i = 0; i < N; i++)
+        for (int64_t w = 0; w < L; w++) {
+            v1[2 * (i + N * w)] = v2[2 * (w + L * i)];
+            v1[2 * (i + N * w) + 1] = v2[2 * (w + L * i) + 1];
+        }
+    for (int64_t w = 0; w < P->Lo2; w++) {
+        const double *u1 = v1 + 2 * N * w;
+        double *u2 = v2 + 2 * N * w;
+        kpm_sym_mul(u2, P, u1, w);
+        double *u2c = v2 + 2 * N * (L - 1 - w);
+        for (int64_t i = 0; i < N; i++) {
+            double re = u2[2 * i], im = u2[2 * i + 1];
+            u2c[2 * i] = re;
+            u2c[2 * i + 1] = -im;
+        }
+    }
+    /* transpose!(a1, a2T): a1[w,i] = a2T[i,w] */
+    for (int64_t w = 0; w < L; w++)
+        for (int64_t i = 0; i < N; i++) {
+            v1[2 * (w + L * i)] = v2[2 * (i + N * w)];
+            v1[2 * (w + L * i) + 1] = v2[2 * (i + N * w) + 1];
+        }
+    elpho_omega_to_tau(out, v1, N, L);
+}
+
+/* ====================================================================== */
+/* conjugate gradient                                                      */
+/* ====================================================================== */
+
+static double dotp(const double *a, const double *b, int64_t n) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; i++) s += a[i] * b[i];
+    return s;
+}
+
+/* IterativeSolvers.jl:239-314 (no preconditioner) and :153-234 (preconditioner) */
+int64_t elpho_cg_solve(const elpho_model *m, double *x, const double *b, double tol,
+                       int64_t maxiter, double kmax, elpho_kpm *P, double *r, double *p, double *z,
+                       double *hist) {
+    const int64_t n = m->N * m->L;
+    double normb = sqrt(dotp(b, b, n));
+    /* r0 = b - A x0 */
+    elpho_mulMTM(r, m, x);
+    for (int64_t i = 0; i < n; i++) r[i] = 1.0 * b[i] + -1.0 * r[i]; /* axpby!(1,b,-1,r) */
+    double rdotz;
+    if (P) {
+        elpho_kpm_apply(z, P, r);
+        memcpy(p, z, sizeof(double) * (size_t)n);
+        rdotz = dotp(r, z, n);
+    } else {
+        memcpy(p, r, sizeof(double) * (size_t)n);
+        rdotz = dotp(r, r, n);
+    }
+    double eps0 = sqrt(dotp(r, r, n)) / normb;
+    double eps = eps0;
+    double kmin = 0.0;
+    if (hist) hist[0] = eps0;
+    for (int64_t j = 1; j <= maxiter; j++) {
+        elpho_mulMTM(z, m, p);
+        double alpha = rdotz / dotp(p, z, n);
+        for (int64_t i = 0; i < n; i++) x[i] += alpha * p[i];
+        for (int64_t i = 0; i < n; i++) r[i] += -alpha * z[i];
+        eps = sqrt(dotp(r, r, n)) / normb;
+        if (hist) hist[j] = eps;
+        double lg = log(2 * eps0 / eps);
+        double q = (2 * (double)j / lg);
+        double val = q * q;
+        kmin = (val > kmin) ? val : kmin; /* @fastmath max: NaN never wins */
+        if (eps < tol || kmin > kmax) return j;
+        double new_rdotz;
+        if (P) {
+            elpho_kpm_apply(z, P, r);
+            new_rdotz = dotp(r, z, n);
+        } else {
+            new_rdotz = dotp(r, r, n);
+        }
+        double beta = new_rdotz / rdotz;
+        rdotz = new_rdotz;
+        const double *zz = P ? z : r;
+        for (int64_t i = 0; i < n; i++) p[i] = 1.0 * zz[i] + beta * p[i]; /* axpby!(1,z,beta,p) */
+    }
+    return maxiter;
+}
+
+static void ldiv_noP(const elpho_model *m, double *x, const double *b, int64_t maxiter,
+                     double solver_tol, int64_t solver_maxiter, double kmax, double *r, double *p,
+                     double *z, int64_t *iters, double *resid, int64_t *flag) {
+    const int64_t n = m->N * m->L;
+    if (maxiter == 0) maxiter = solver_maxiter;
+    *iters = elpho_cg_solve(m, x, b, solver_tol, maxiter, kmax, NULL, r, p, z, NULL);
+    double *v = m->vppp;
+    elpho_mulMTM(v, m, x);
+    for (int64_t i = 0; i < n; i++) v[i] = v[i] - b[i];
+    *resid = sqrt(dotp(v, v, n)) / sqrt(dotp(b, b, n));
+    if (*resid > sqrt(solver_tol)) {
+        *flag = (*iters == solver_maxiter) ? 1 : 2; /* Models.jl:160 compares solver.maxiter */
+        memset(x, 0, sizeof(double) * (size_t)n);
+    } else {
+        *flag = 0;
+    }
+}
+
+/* Models.jl:74-137 (P != NULL), :139-186 (P == NULL) */
+void elpho_ldiv(const elpho_model *m, double *x, const double *b, elpho_kpm *P, int64_t maxiter,
+                double solver_tol, int64_t solver_maxiter, double kmax, double *r, double *p,
+                double *z, int64_t *iters, double *resid, int64_t *flag) {
+    const int64_t n = m->N * m->L;
+    if (maxiter == 0) maxiter = solver_maxiter;
+    if (!P) {
+        ldiv_noP(m, x, b, maxiter, solver_tol, solver_maxiter, kmax, r, p, z, iters, resid, flag);
+        return;
+    }
+    *iters = elpho_cg_solve(m, x, b, solver_tol, maxiter, kmax, P, r, p, z, NULL);
+    double *v = m->vppp;
+    elpho_mulMTM(v, m, x);
+    for (int64_t i = 0; i < n; i++) v[i] = v[i] - b[i];
+    *resid = sqrt(dotp(v, v, n)) / sqrt(dotp(b, b, n));
+    if (*resid > sqrt(solver_tol)) {
+        *flag = (*iters == maxiter) ? 1 : 2;
+        memset(x, 0, sizeof(double) * (size_t)n);
+    } else {
+        *flag = 0;
+    }
+    if (*flag > 0)
+        ldiv_noP(m, x, b, 10 * maxiter, solver_tol, solver_maxiter, kmax, r, p, z, iters, resid, flag);
+}
+
+/* ====================================================================== */
+/* callers' helpers                                                        */
+/* ====================================================================== */
+
+/* HMC.jl:921-941 */
+void elpho_update_Lambda(double *Lam, int64_t N, int64_t L, double dtau, const double *x,
+                         const double *lambda, const double *lambda2) {
+    for (int64_t i = 0; i < N; i++)
+        for (int64_t tau = 0; tau < L; tau++) {
+            double xt = x[i * L + tau];
+            Lam[i * L + tau] = exp(-dtau * (lambda[i] * xt + lambda2[i] * (xt * xt)) / 2);
+        }
+}
+
+/* HMC.jl:951-968 */
+void elpho_mulLambda(double *out, const double *in, const double *Lam, int64_t N, int64_t L) {
+    for (int64_t i = 0; i < N; i++) {
+        double u1 = in[i * L];
+        for (int64_t tau = 0; tau < L - 1; tau++)
+            out[i * L + tau] = -Lam[i * L + tau + 1] * in[i * L + tau + 1];
+        out[i * L + L - 1] = Lam[i * L] * u1;
+    }
+}
+
+/* HMC.jl:978-995 */
+void elpho_mulLambdaInv(double *out, const double *in, const double *Lam, int64_t N, int64_t L) {
+    for (int64_t i = 0; i < N; i++) {
+        double uL = in[i * L + L - 1];
+        for (int64_t tau = L - 1; tau >= 1; tau--)
+            out[i * L + tau] = -(1.0 / Lam[i * L + tau]) * in[i * L + tau - 1];
+        out[i * L] = (1.0 / Lam[i * L]) * uL;
+    }
+}
+
+/* HolsteinModels.jl:691-755 */
+void elpho_muldMdx_holstein(double *dMdx, const double *u, const elpho_model *m, const double *v,
+                            double dtau, const double *lambda, const double *lambda2,
+                            const double *x) {
+    const int64_t N = m->N, L = m->L;
+    double *y = m->vp;
+    for (int64_t i = 0; i < N; i++) {
+        int64_t i1 = i * L, iL = i * L + L - 1;
+        dMdx[i1] = -dtau * (lambda[i] + 2 * lambda2[i] * x[i1]) * m->E[i1] * v[iL];
+        for (int64_t tau = 1; tau < L; tau++) {
+            int64_t it = i * L + tau;
+            dMdx[it] = dtau * (lambda[i] + 2 * lambda2[i] * x[it]) * m->E[it] * v[it - 1];
+        }
+    }
+    memcpy(y, u, sizeof(double) * (size_t)(N * L));
+    if (m->nb > 0) elpho_checkerboard_transpose_mul(y, m->table, m->c, m->s, m->nb, L);
+    for (int64_t i = 0; i < N * L; i++) dMdx[i] = y[i] * dMdx[i];
+}

@@ -1,0 +1,259 @@
+"""ctypes binding of the CPU oracle (oracle/elph_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (elphdynamics_amd/) never
+imports this module.  PARITY UNPINNED BY THE REFERENCE (see elph_oracle.h).
+
+All arrays are numpy float64 / int64, flat, in the reference's layout
+(tau fastest; neighbor tables 2 x Nbonds column-major, 1-based).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+c_i64 = C.c_int64
+c_dbl = C.c_double
+P_i64 = C.POINTER(C.c_int64)
+P_dbl = C.POINTER(C.c_double)
+
+
+def build(fast=False):
+    """(Re)build the oracle shared library with gcc via oracle/Makefile."""
+    target = "fast" if fast else "all"
+    subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
+    return os.path.join(_BUILD, "libelph_oracle_fast.so" if fast else "libelph_oracle.so")
+
+
+def _ptr(a, ty):
+    if a is None:
+        return None
+    return a.ctypes.data_as(ty)
+
+
+def dp(a):
+    assert a is None or (a.dtype == np.float64 and a.flags["C_CONTIGUOUS"])
+    return _ptr(a, P_dbl)
+
+
+def ip(a):
+    assert a is None or (a.dtype == np.int64 and a.flags["C_CONTIGUOUS"])
+    return _ptr(a, P_i64)
+
+
+class Model(C.Structure):
+    _fields_ = [("kind", c_i64), ("N", c_i64), ("L", c_i64), ("nb", c_i64),
+                ("table", P_i64), ("c", P_dbl), ("s", P_dbl), ("E", P_dbl),
+                ("vp", P_dbl), ("vppp", P_dbl)]
+
+
+class KPM(C.Structure):
+    _fields_ = [("active", c_i64), ("N", c_i64), ("L", c_i64), ("nb", c_i64),
+                ("table", P_i64), ("Ebar", P_dbl), ("cbar", P_dbl), ("sbar", P_dbl),
+                ("lam_lo", c_dbl), ("lam_hi", c_dbl), ("lam_avg", c_dbl), ("lam_mag", c_dbl),
+                ("buf", c_dbl), ("c1", c_dbl), ("c2", c_dbl),
+                ("Lo2", c_i64), ("order", P_i64), ("coff", P_i64), ("coeff", P_dbl),
+                ("coeff_cap", c_i64), ("v1", P_dbl), ("v2", P_dbl),
+                ("v3", P_dbl), ("v4", P_dbl), ("v5", P_dbl), ("checkerboard_count", c_i64)]
+
+
+class Oracle:
+    """Loaded oracle library + thin numpy-level helpers."""
+
+    def __init__(self, fast=False):
+        path = build(fast=fast)
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.elpho_loc_to_site.restype = c_i64
+        L.elpho_loc_to_site.argtypes = [c_i64] * 8
+        L.elpho_site_to_site.restype = c_i64
+        L.elpho_site_to_site.argtypes = [c_i64, c_i64, c_i64, c_i64, c_i64, P_i64, c_i64]
+        L.elpho_calc_neighbor_table.restype = c_i64
+        L.elpho_calc_neighbor_table.argtypes = [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, P_i64, C.c_int, P_i64]
+        L.elpho_sortperm.argtypes = [P_i64, c_i64, P_i64]
+        L.elpho_sorted_neighbor_table_perm.argtypes = [P_i64, c_i64, P_i64]
+        L.elpho_checkerboard_groups.restype = c_i64
+        L.elpho_checkerboard_groups.argtypes = [P_i64, c_i64, P_i64]
+        L.elpho_holstein_initialize_model.restype = c_i64
+        L.elpho_holstein_initialize_model.argtypes = [P_i64, c_i64, P_dbl, c_dbl, P_dbl, P_dbl, P_i64, P_i64]
+        L.elpho_ssh_initialize_table.restype = c_i64
+        L.elpho_ssh_initialize_table.argtypes = [P_i64, c_i64, P_i64, P_i64, P_i64]
+        L.elpho_ltau.restype = c_i64
+        L.elpho_ltau.argtypes = [c_dbl, c_dbl]
+        L.elpho_update_model_holstein.argtypes = [c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_update_model_ssh.argtypes = [c_i64, c_i64, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl, P_dbl,
+                                             P_dbl, P_i64, P_i64, P_dbl, P_dbl, P_dbl]
+        for nm in ("elpho_checkerboard_mul", "elpho_checkerboard_transpose_mul",
+                   "elpho_checkerboard_inverse_mul", "elpho_checkerboard_inverse_transpose_mul",
+                   "elpho_checkerboard_mul_mat", "elpho_checkerboard_transpose_mul_mat"):
+            getattr(L, nm).argtypes = [P_dbl, P_i64, P_dbl, P_dbl, c_i64, c_i64]
+        for nm in ("elpho_checkerboard_mul_nvec_z", "elpho_checkerboard_transpose_mul_nvec_z",
+                   "elpho_checkerboard_mul_nvec", "elpho_checkerboard_inverse_mul_nvec"):
+            getattr(L, nm).argtypes = [P_dbl, P_i64, P_dbl, P_dbl, c_i64]
+        for nm in ("elpho_mulM", "elpho_mulMT", "elpho_mulMTM"):
+            getattr(L, nm).argtypes = [P_dbl, C.POINTER(Model), P_dbl]
+        L.elpho_tau_to_omega.argtypes = [P_dbl, P_dbl, c_i64, c_i64]
+        L.elpho_omega_to_tau.argtypes = [P_dbl, P_dbl, c_i64, c_i64]
+        L.elpho_dft_tau.argtypes = [P_dbl, P_dbl, c_i64, c_i64, C.c_int]
+        L.elpho_element_Mi.restype = c_dbl
+        L.elpho_element_Mi.argtypes = [c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_i64]
+        L.elpho_element_Qi.restype = c_dbl
+        L.elpho_element_Qi.argtypes = [c_i64, c_dbl, c_dbl, c_dbl, c_i64]
+        L.elpho_update_M.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, c_dbl, c_dbl, c_dbl, c_dbl]
+        L.elpho_update_Q.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, c_dbl, c_dbl, c_dbl]
+        L.elpho_fourier_accelerate.argtypes = [P_dbl, P_dbl, P_dbl, c_dbl, c_i64, c_i64]
+        L.elpho_kpm_update_A.argtypes = [C.POINTER(KPM), C.POINTER(Model)]
+        L.elpho_kpm_coefficients.argtypes = [P_dbl, c_i64, c_dbl, c_dbl, c_dbl]
+        L.elpho_kpm_arnoldi_bounds.argtypes = [C.POINTER(KPM), c_i64, P_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_kpm_setup_from_bounds.argtypes = [C.POINTER(KPM), c_dbl, c_dbl]
+        L.elpho_kpm_apply.argtypes = [P_dbl, C.POINTER(KPM), P_dbl]
+        L.elpho_eigvals.restype = C.c_int
+        L.elpho_eigvals.argtypes = [P_dbl, c_i64, P_dbl, P_dbl]
+        L.elpho_cg_solve.restype = c_i64
+        L.elpho_cg_solve.argtypes = [C.POINTER(Model), P_dbl, P_dbl, c_dbl, c_i64, c_dbl, C.POINTER(KPM),
+                                     P_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_ldiv.argtypes = [C.POINTER(Model), P_dbl, P_dbl, C.POINTER(KPM), c_i64, c_dbl, c_i64, c_dbl,
+                                 P_dbl, P_dbl, P_dbl, P_i64, P_dbl, P_i64]
+        L.elpho_update_Lambda.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_mulLambda.argtypes = [P_dbl, P_dbl, P_dbl, c_i64, c_i64]
+        L.elpho_mulLambdaInv.argtypes = [P_dbl, P_dbl, P_dbl, c_i64, c_i64]
+        L.elpho_muldMdx_holstein.argtypes = [P_dbl, P_dbl, C.POINTER(Model), P_dbl, c_dbl, P_dbl, P_dbl, P_dbl]
+
+    # ------------------------------------------------------------ geometry
+    def neighbor_table(self, norbits, L1, L2, L3, bonds):
+        """bonds: list of (o1, o2, (d1,d2,d3)) in deck order -> concatenated raw table (2 x nb, Fortran order
+        returned as int64 array shape (nb, 2), i.e. row n = bond n = Julia column n)."""
+        out = []
+        ncells = L1 * L2 * L3
+        for (o1, o2, d) in bonds:
+            tab = np.zeros(2 * ncells, dtype=np.int64)
+            dd = np.asarray(d, dtype=np.int64)
+            n = self.lib.elpho_calc_neighbor_table(norbits, L1, L2, L3, o1, o2, ip(dd), 1, ip(tab))
+            out.append(tab[:2 * n].reshape(n, 2).copy())
+        if not out:
+            return np.zeros((0, 2), dtype=np.int64)
+        return np.ascontiguousarray(np.concatenate(out, axis=0))
+
+    def holstein_initialize(self, table, t, dtau):
+        """Returns (table_cb (nb,2), cosht, sinht, cb_perm, colours, ncolours)."""
+        nb = table.shape[0]
+        tab = np.ascontiguousarray(table.copy())
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        c = np.zeros(nb)
+        s = np.zeros(nb)
+        perm = np.zeros(nb, dtype=np.int64)
+        grp = np.zeros(nb, dtype=np.int64)
+        ng = self.lib.elpho_holstein_initialize_model(ip(tab), nb, dp(t), dtau, dp(c), dp(s), ip(perm), ip(grp))
+        return tab, c, s, perm, grp, int(ng)
+
+    def ssh_initialize_table(self, table):
+        nb = table.shape[0]
+        tab = np.ascontiguousarray(table.copy())
+        perm = np.zeros(nb, dtype=np.int64)
+        iperm = np.zeros(nb, dtype=np.int64)
+        grp = np.zeros(nb, dtype=np.int64)
+        ng = self.lib.elpho_ssh_initialize_table(ip(tab), nb, ip(perm), ip(iperm), ip(grp))
+        return tab, perm, iperm, grp, int(ng)
+
+    # --------------------------------------------------------------- model
+    def make_model(self, kind, N, L, table, c, s, E):
+        """Bundle arrays into a Model struct; keeps references alive on the returned object."""
+        m = Model()
+        m.kind, m.N, m.L, m.nb = kind, N, L, table.shape[0]
+        keep = dict(table=np.ascontiguousarray(table, dtype=np.int64),
+                    c=np.ascontiguousarray(c, dtype=np.float64),
+                    s=np.ascontiguousarray(s, dtype=np.float64),
+                    E=np.ascontiguousarray(E, dtype=np.float64),
+                    vp=np.zeros(N * L), vppp=np.zeros(N * L))
+        m.table, m.c, m.s, m.E = ip(keep["table"]), dp(keep["c"]), dp(keep["s"]), dp(keep["E"])
+        m.vp, m.vppp = dp(keep["vp"]), dp(keep["vppp"])
+        m._keep = keep
+        return m
+
+    def update_model_holstein(self, N, L, dtau, x, lam, lam2, mu):
+        E = np.zeros(N * L)
+        self.lib.elpho_update_model_holstein(N, L, dtau, dp(x), dp(lam), dp(lam2), dp(mu), dp(E))
+        return E
+
+    def mulM(self, m, v):
+        y = np.zeros_like(v)
+        self.lib.elpho_mulM(dp(y), C.byref(m), dp(v))
+        return y
+
+    def mulMT(self, m, v):
+        y = np.zeros_like(v)
+        self.lib.elpho_mulMT(dp(y), C.byref(m), dp(v))
+        return y
+
+    def mulMTM(self, m, v):
+        y = np.zeros_like(v)
+        self.lib.elpho_mulMTM(dp(y), C.byref(m), dp(v))
+        return y
+
+    # ----------------------------------------------------------------- KPM
+    def make_kpm(self, m, n=20, buf=0.05, c1=1.0, c2=1.0, coeff_cap=None):
+        N, L, nb = m.N, m.L, m.nb
+        Lo2 = (L + 1) // 2
+        if coeff_cap is None:
+            coeff_cap = 64 * Lo2 + 4096
+        P = KPM()
+        keep = dict(Ebar=np.zeros(N), cbar=np.zeros(max(nb, 1)), sbar=np.zeros(max(nb, 1)),
+                    order=np.ones(Lo2, dtype=np.int64), coff=np.arange(Lo2 + 1, dtype=np.int64),
+                    coeff=np.zeros(2 * coeff_cap), v1=np.zeros(2 * N * L), v2=np.zeros(2 * N * L),
+                    v3=np.zeros(2 * N), v4=np.zeros(2 * N), v5=np.zeros(2 * N))
+        P.active, P.N, P.L, P.nb = 1, N, L, nb
+        P.table = m.table
+        P.Ebar, P.cbar, P.sbar = dp(keep["Ebar"]), dp(keep["cbar"]), dp(keep["sbar"])
+        P.lam_lo, P.lam_hi, P.lam_avg, P.lam_mag = 0.0, 2.0, 1.0, 1.0
+        P.buf, P.c1, P.c2 = buf, c1, c2
+        P.Lo2 = Lo2
+        P.order, P.coff, P.coeff, P.coeff_cap = ip(keep["order"]), ip(keep["coff"]), dp(keep["coeff"]), coeff_cap
+        P.v1, P.v2, P.v3, P.v4, P.v5 = (dp(keep[k]) for k in ("v1", "v2", "v3", "v4", "v5"))
+        P.checkerboard_count = 0
+        P._keep = keep
+        P._model = m
+        P._n = n
+        self.lib.elpho_kpm_update_A(C.byref(P), C.byref(m))
+        return P
+
+    def kpm_setup(self, P, e_min=None, e_max=None, b_max=None, b_min=None):
+        """setup!(P): either inject (e_min,e_max) or run the Arnoldi estimate from injected start vectors."""
+        self.lib.elpho_kpm_update_A(C.byref(P), C.byref(P._model))
+        if e_min is None:
+            em = C.c_double()
+            eM = C.c_double()
+            self.lib.elpho_kpm_arnoldi_bounds(C.byref(P), P._n, dp(b_max), dp(b_min), C.byref(em), C.byref(eM))
+            e_min, e_max = em.value, eM.value
+        self.lib.elpho_kpm_setup_from_bounds(C.byref(P), e_min, e_max)
+        return e_min, e_max
+
+    def kpm_apply(self, P, v):
+        out = np.zeros_like(v)
+        self.lib.elpho_kpm_apply(dp(out), C.byref(P), dp(v))
+        return out
+
+    # ------------------------------------------------------------------ CG
+    def cg_solve(self, m, b, x0=None, tol=1e-5, maxiter=10000, kmax=1e12, P=None, history=False):
+        n = m.N * m.L
+        x = np.zeros(n) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        r, p, z = np.zeros(n), np.zeros(n), np.zeros(n)
+        hist = np.full(maxiter + 1, np.nan) if history else None
+        it = self.lib.elpho_cg_solve(C.byref(m), dp(x), dp(b), tol, maxiter, kmax,
+                                     C.byref(P) if P is not None else None, dp(r), dp(p), dp(z), dp(hist))
+        if history:
+            return x, int(it), hist[:it + 1]
+        return x, int(it)
+
+    def ldiv(self, m, b, P=None, maxiter=0, solver_tol=1e-5, solver_maxiter=10000, kmax=1e12, x0=None):
+        n = m.N * m.L
+        x = np.zeros(n) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        r, p, z = np.zeros(n), np.zeros(n), np.zeros(n)
+        it, fl, res = C.c_int64(), C.c_int64(), C.c_double()
+        self.lib.elpho_ldiv(C.byref(m), dp(x), dp(b), C.byref(P) if P is not None else None, maxiter,
+                            solver_tol, solver_maxiter, kmax, dp(r), dp(p), dp(z),
+                            C.byref(it), C.byref(res), C.byref(fl))
+        return x, int(it.value), float(res.value), int(fl.value)
