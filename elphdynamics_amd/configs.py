@@ -1,0 +1,56 @@
+"""The BASELINE.json configurations (SURVEY.md §8 sizes table) as ready-made GPU models with the
+deterministic synthetic phonon fields of synth.py.  Parameters follow the example decks:
+t=1, omega=1, lambda=1, mu=0, dtau=0.1 (examples/holstein_hmc_square.toml:39-76);
+SSH: t=1, alpha=0.1, omega=0.1, dtau=0.05 (examples/ssh_hmc_square.toml:39-58)."""
+import numpy as np
+
+from . import lattice as lat
+from . import models, synth
+
+CONFIGS = {
+    # tag: (kind, norbits, Lspatial, bonds, beta, dtau)
+    "A": ("holstein", 1, 1, [], 2.0, 0.1),                          # holstein_hmc_single_site.toml
+    "B": ("holstein", 1, 8, lat.SQUARE_BONDS, 4.0, 0.1),
+    "C": ("holstein", 1, 16, lat.SQUARE_BONDS, 16.0, 0.1),
+    "D": ("holstein", 2, 12, lat.HONEYCOMB_BONDS, 12.0, 0.1),
+    "E": ("ssh", 1, 16, lat.SQUARE_BONDS, 8.0, 0.05),
+    # small variants for fast parity tests
+    "b": ("holstein", 1, 4, lat.SQUARE_BONDS, 2.0, 0.1),
+    "d": ("holstein", 2, 3, lat.HONEYCOMB_BONDS, 1.2, 0.1),
+    "e": ("ssh", 1, 4, lat.SQUARE_BONDS, 1.0, 0.05),
+    "t": ("holstein", 1, 3, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # odd L: ragged colours
+}
+
+
+def make_model(tag, tol=1e-5, maxiter=10000, rough=True, device=0, seed=synth.SEED_FIELDS):
+    kind, norb, Ls, bonds, beta, dtau = CONFIGS[tag]
+    L2 = Ls if Ls > 1 else 1
+    lattice = lat.Lattice(norb, Ls, L2, 1)
+    if kind == "holstein":
+        m = models.HolsteinModel(lattice, beta, dtau, tol=tol, maxiter=maxiter, device=device)
+        for (o1, o2, d) in bonds:
+            m.assign_t_(1.0, o1, o2, d)
+        m.assign_omega_(1.0)
+        m.assign_lambda_(1.0)
+        m.assign_mu_(0.0)
+        m.initialize_model_()
+        m.x[:] = synth.phonon_field(m.Nph, m.Ltau, beta, dtau, omega=1.0, lam=1.0, rough=rough, seed=seed)
+    else:
+        m = models.SSHModel(lattice, beta, dtau, tol=tol, maxiter=maxiter, device=device)
+        for (o1, o2, d) in bonds:
+            m.assign_hopping_(1.0, 0.1, 0.0, 0.1, o1, o2, d)
+        m.initialize_model_()
+        m.x[:] = synth.phonon_field(m.Nph, m.Ltau, beta, dtau, omega=0.1, lam=0.0, rough=rough, seed=seed)
+        # keep |alpha x| < t (SSHModels.jl:537-539 warns beyond that): the omega=0.1 QHO is wide
+        m.x *= 0.25
+    models.update_model_(m)
+    return m
+
+
+def rhs(model, nrhs=1, seed=synth.SEED_RHS):
+    """b = Mt R for i.i.d. N(0,1) R (GreensFunctions.jl:212-225); returns (R, b) as (nrhs, Ndim) arrays."""
+    R = np.stack([synth.rhs(model.Ndim, seed=seed + 7919 * i) for i in range(nrhs)])
+    B = np.empty_like(R)
+    for i in range(nrhs):
+        models.mulMt_(B[i], model, R[i])
+    return R, B

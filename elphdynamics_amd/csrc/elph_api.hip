@@ -1,0 +1,819 @@
+// elph_api.hip — extern "C" entry points of libelphgpu.so (include/elph_gpu.h).
+// Host orchestration only: argument checks, layout staging, the CG chunk loop and the ldiv!
+// flag logic (Models.jl:74-186).  All arithmetic on lattice vectors happens in kernels.hip.
+// There is NO CPU fallback: without a gfx950 device every compute entry point fails.
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <numeric>
+
+#include "elph_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+void elph_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *elph_last_error(void) { return g_err; }
+extern "C" int elph_abi_version(void) { return ELPH_ABI_VERSION; }
+
+extern "C" int elph_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+#define CHECK_H(h)                                    \
+    do {                                              \
+        if (!(h)) {                                   \
+            elph_set_error("null handle");            \
+            return ELPH_E_ARG;                        \
+        }                                             \
+        HIPCHK(hipSetDevice((h)->device));            \
+    } while (0)
+
+#define RC(call)                \
+    do {                        \
+        int _rc = (call);       \
+        if (_rc) return _rc;    \
+    } while (0)
+
+template <class T>
+static int dev_alloc(T **p, size_t n) {
+    if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+    return ELPH_OK;
+}
+
+static void drop_graphs(elph_handle_s *h) {
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+// life cycle
+// ------------------------------------------------------------------------------------------
+
+static int ensure_capacity(elph_handle_s *h, int nrhs) {
+    if (nrhs <= h->cap_rhs) return ELPH_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    const size_t nd = (size_t)h->ndim, c = (size_t)nrhs;
+    RC(dev_alloc(&h->d_stage_in, c * nd));
+    RC(dev_alloc(&h->d_stage_out, c * nd));
+    RC(dev_alloc(&h->d_b, c * nd));
+    RC(dev_alloc(&h->d_x, c * nd));
+    RC(dev_alloc(&h->d_r, c * nd));
+    RC(dev_alloc(&h->d_z, c * nd));
+    RC(dev_alloc(&h->d_zp, c * nd));
+    RC(dev_alloc(&h->d_tmp, c * nd));
+    RC(dev_alloc(&h->d_p, 2 * c * nd));
+    RC(dev_alloc(&h->d_part, 4 * c * (size_t)h->L * (size_t)h->npl));
+    RC(dev_alloc(&h->d_state, 2 * c));
+    RC(dev_alloc(&h->d_scal, 4 * c));
+    const size_t Lo2 = (size_t)(h->L + 1) / 2, Lh = (size_t)h->L / 2 + 1;
+    RC(dev_alloc(&h->d_nu, c * std::max(std::max(Lo2, Lh) * (size_t)h->N, nd)));
+    if (h->h_state) HIPCHK(hipHostFree(h->h_state));
+    if (h->h_scal) HIPCHK(hipHostFree(h->h_scal));
+    HIPCHK(hipHostMalloc((void **)&h->h_state, 2 * c * sizeof(CgState), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_scal, 4 * c * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(h->d_part, 0, 4 * c * (size_t)h->L * (size_t)h->npl * sizeof(double), h->stream));
+    h->cap_rhs = nrhs;
+    return ELPH_OK;
+}
+
+extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t ltau, int64_t nbonds,
+                           const int64_t *neighbor_table, const double *cosht, const double *sinht, int device) {
+    if (!out) { elph_set_error("out is null"); return ELPH_E_ARG; }
+    *out = nullptr;
+    if (kind != ELPH_MODEL_HOLSTEIN && kind != ELPH_MODEL_SSH) { elph_set_error("bad model kind %d", kind); return ELPH_E_ARG; }
+    if (nsites < 1 || ltau < 1 || nbonds < 0) { elph_set_error("bad sizes N=%lld L=%lld nb=%lld", (long long)nsites, (long long)ltau, (long long)nbonds); return ELPH_E_ARG; }
+    if (nsites > (int64_t)ELPH_MAX_NPL * ELPH_WAVE) {
+        elph_set_error("nsites=%lld exceeds the %d sites one wavefront-per-slice kernel supports", (long long)nsites, ELPH_MAX_NPL * ELPH_WAVE);
+        return ELPH_E_UNSUPPORTED;
+    }
+    if (nsites * ltau > (int64_t)1 << 30) { elph_set_error("ndim too large"); return ELPH_E_UNSUPPORTED; }
+    if (nbonds > 0 && !neighbor_table) { elph_set_error("neighbor_table is null"); return ELPH_E_ARG; }
+    if (kind == ELPH_MODEL_HOLSTEIN && nbonds > 0 && (!cosht || !sinht)) { elph_set_error("cosht/sinht null"); return ELPH_E_ARG; }
+    for (int64_t n = 0; n < nbonds; ++n) {
+        const int64_t i = neighbor_table[2 * n], j = neighbor_table[2 * n + 1];
+        if (i < 1 || i > nsites || j < 1 || j > nsites || i == j) {
+            elph_set_error("neighbor_table[:,%lld] = (%lld,%lld) out of range 1..%lld", (long long)n + 1, (long long)i, (long long)j, (long long)nsites);
+            return ELPH_E_ARG;
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { elph_set_error("no HIP device visible"); return ELPH_E_NOGPU; }
+    if (device < 0 || device >= ndev) { elph_set_error("device %d not in 0..%d", device, ndev - 1); return ELPH_E_ARG; }
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        elph_set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return ELPH_E_NOGPU;
+    }
+
+    elph_handle_s *h = new elph_handle_s();
+    h->kind = kind; h->device = device;
+    h->N = nsites; h->L = ltau; h->nb = nbonds; h->ndim = nsites * ltau;
+    h->npl = (int)((nsites + ELPH_WAVE - 1) / ELPH_WAVE);
+    h->maxiter = h->ndim;   // ConjugateGradient ctor default (IterativeSolvers.jl:49-51)
+    const char *ng = getenv("ELPH_NO_GRAPH");
+    h->use_graph = !(ng && ng[0] == '1');
+
+    // bond tables, 0-based; colours = maximal runs of site-disjoint bonds (reproduces the groups of
+    // checkerboard_groups!, Checkerboard.jl:471-515, for any table in checkerboard order, and stays
+    // correct — only slower — for an arbitrary bond order)
+    h->h_bi.resize(nbonds); h->h_bj.resize(nbonds);
+    h->h_coloff.clear(); h->h_coloff.push_back(0);
+    {
+        std::vector<char> used(nsites, 0);
+        for (int64_t n = 0; n < nbonds; ++n) {
+            const int i = (int)(neighbor_table[2 * n] - 1), j = (int)(neighbor_table[2 * n + 1] - 1);
+            if (used[i] || used[j]) {
+                h->h_coloff.push_back((int)n);
+                std::fill(used.begin(), used.end(), 0);
+            }
+            used[i] = used[j] = 1;
+            h->h_bi[n] = i; h->h_bj[n] = j;
+        }
+        if (nbonds > 0) h->h_coloff.push_back((int)nbonds);
+    }
+    h->ncol = (int)h->h_coloff.size() - 1;
+
+    int rc = ELPH_OK;
+    auto fail = [&](int code) { elph_destroy(h); return code; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { elph_set_error("stream create failed"); return fail(ELPH_E_HIP); }
+    h->own_stream = true;
+    if ((rc = dev_alloc(&h->d_bi, (size_t)nbonds))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_bj, (size_t)nbonds))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_coloff, h->h_coloff.size()))) return fail(rc);
+    const size_t ncs = (kind == ELPH_MODEL_SSH) ? (size_t)ltau * (size_t)nbonds : (size_t)nbonds;
+    if ((rc = dev_alloc(&h->d_c, ncs))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_s, ncs))) return fail(rc);
+    const size_t nE = (kind == ELPH_MODEL_SSH) ? (size_t)nsites : (size_t)h->ndim;
+    if ((rc = dev_alloc(&h->d_E, nE))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_lam, 3 * (size_t)nsites))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_params, 1))) return fail(rc);
+    if (nbonds > 0) {
+        if (hipMemcpy(h->d_bi, h->h_bi.data(), sizeof(int) * nbonds, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_bj, h->h_bj.data(), sizeof(int) * nbonds, hipMemcpyHostToDevice) != hipSuccess) {
+            elph_set_error("table upload failed");
+            return fail(ELPH_E_HIP);
+        }
+    }
+    if (hipMemcpy(h->d_coloff, h->h_coloff.data(), sizeof(int) * h->h_coloff.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        elph_set_error("table upload failed");
+        return fail(ELPH_E_HIP);
+    }
+    if (kind == ELPH_MODEL_HOLSTEIN && nbonds > 0) {
+        h->h_c.assign(cosht, cosht + nbonds);
+        h->h_s.assign(sinht, sinht + nbonds);
+        if (hipMemcpy(h->d_c, cosht, sizeof(double) * nbonds, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_s, sinht, sizeof(double) * nbonds, hipMemcpyHostToDevice) != hipSuccess) {
+            elph_set_error("cosh/sinh upload failed");
+            return fail(ELPH_E_HIP);
+        }
+    }
+    // twiddles: tw1[m] = exp(-2 pi i m/L), m<L ; tw2[m] = exp(-i pi m/L), m<2L (exact index reduction on host)
+    {
+        std::vector<double2> tw1((size_t)ltau), tw2((size_t)2 * ltau);
+        for (int64_t m = 0; m < ltau; ++m) {
+            const double a = 2.0 * M_PI * (double)m / (double)ltau;
+            tw1[m] = make_double2(cos(a), -sin(a));
+        }
+        for (int64_t m = 0; m < 2 * ltau; ++m) {
+            const double a = M_PI * (double)m / (double)ltau;
+            tw2[m] = make_double2(cos(a), -sin(a));
+        }
+        if ((rc = dev_alloc(&h->d_tw, (size_t)ltau))) return fail(rc);
+        if ((rc = dev_alloc(&h->d_theta, (size_t)2 * ltau))) return fail(rc);
+        if (hipMemcpy(h->d_tw, tw1.data(), sizeof(double2) * tw1.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_theta, tw2.data(), sizeof(double2) * tw2.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            elph_set_error("twiddle upload failed");
+            return fail(ELPH_E_HIP);
+        }
+    }
+    if ((rc = ensure_capacity(h, 1))) return fail(rc);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { elph_set_error("sync failed"); return fail(ELPH_E_HIP); }
+    *out = h;
+    return ELPH_OK;
+}
+
+extern "C" int elph_destroy(elph_handle h) {
+    if (!h) return ELPH_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+    void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
+                    h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_params,
+                    h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
+                    h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->h_scal) (void)hipHostFree(h->h_scal);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ELPH_OK;
+}
+
+extern "C" int elph_set_stream(elph_handle h, void *hip_stream) {
+    CHECK_H(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    if (hip_stream) {
+        if (h->own_stream) { HIPCHK(hipStreamDestroy(h->stream)); h->own_stream = false; }
+        h->stream = (hipStream_t)hip_stream;
+    } else if (!h->own_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return ELPH_OK;
+}
+
+extern "C" int elph_synchronize(elph_handle h) {
+    CHECK_H(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// update_model!
+// ------------------------------------------------------------------------------------------
+
+extern "C" int elph_update_model_holstein(elph_handle h, const double *x, const double *lambda, const double *lambda2,
+                                          const double *mu, double dtau) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
+    if (!x || !lambda || !lambda2 || !mu) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    const size_t N = (size_t)h->N;
+    HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, x, (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_expV(h, h->d_stage_in, dtau));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_E = true;
+    return ELPH_OK;
+}
+
+extern "C" int elph_set_expV(elph_handle h, const double *expnDtauV) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
+    if (!expnDtauV) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, expnDtauV, (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_E, h->d_stage_in, 1));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_E = true;
+    return ELPH_OK;
+}
+
+extern "C" int elph_update_model_ssh(elph_handle h, const double *cosht, const double *sinht, const double *expDtauMu) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    if (!expDtauMu || (h->nb > 0 && (!cosht || !sinht))) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    const size_t L = (size_t)h->L, nb = (size_t)h->nb;
+    // reference: (Ltau x Nbonds) column-major = [bond][tau]; device: tau-major [tau][bond]
+    h->h_c.resize(L * nb); h->h_s.resize(L * nb);
+    for (size_t n = 0; n < nb; ++n)
+        for (size_t t = 0; t < L; ++t) {
+            h->h_c[t * nb + n] = cosht[n * L + t];
+            h->h_s[t * nb + n] = sinht[n * L + t];
+        }
+    if (nb > 0) {
+        HIPCHK(hipMemcpy(h->d_c, h->h_c.data(), L * nb * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_s, h->h_s.data(), L * nb * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(h->d_E, expDtauMu, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
+    h->have_E = true;
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// mul! family
+// ------------------------------------------------------------------------------------------
+
+static int need_model(elph_handle_s *h) {
+    if (!h->have_E) { elph_set_error("update_model has not been called on this handle"); return ELPH_E_STATE; }
+    return ELPH_OK;
+}
+
+static int mul_dev(elph_handle_s *h, int which, double *y_dev, const double *v_dev) {
+    RC(need_model(h));
+    if (!y_dev || !v_dev) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(elph_launch_r2s(h, h->d_b, v_dev, 1));
+    RC(elph_launch_mul(h, which, h->d_x, h->d_b, 1));
+    RC(elph_launch_s2r(h, y_dev, h->d_x, 1));
+    return ELPH_OK;
+}
+
+static int mul_host(elph_handle_s *h, int which, double *y, const double *v) {
+    if (!y || !v) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, v, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(mul_dev(h, which, h->d_stage_out, h->d_stage_in));
+    HIPCHK(hipMemcpyAsync(y, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_mulM(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_host(h, 0, y, v); }
+extern "C" int elph_mulMT(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_host(h, 1, y, v); }
+extern "C" int elph_mulMTM(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_host(h, 2, y, v); }
+extern "C" int elph_mulM_dev(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_dev(h, 0, y, v); }
+extern "C" int elph_mulMT_dev(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_dev(h, 1, y, v); }
+extern "C" int elph_mulMTM_dev(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_dev(h, 2, y, v); }
+
+// ------------------------------------------------------------------------------------------
+// CG driver
+// ------------------------------------------------------------------------------------------
+
+extern "C" int elph_solver_set(elph_handle h, double tol, int64_t maxiter, double kappa_max) {
+    CHECK_H(h);
+    if (!(tol > 0.0) || maxiter < 0 || !(kappa_max > 0.0)) { elph_set_error("bad solver parameters"); return ELPH_E_ARG; }
+    h->tol = tol;
+    h->maxiter = (maxiter < 1) ? h->ndim : maxiter;   // IterativeSolvers.jl:49-51
+    h->kmax = kappa_max;
+    return ELPH_OK;
+}
+
+static int get_chunk_graph(elph_handle_s *h, int nrhs, int use_prec, hipGraphExec_t *out) {
+    for (auto &g : h->graphs)
+        if (g.nrhs == nrhs && g.use_prec == use_prec) { *out = g.exec; return ELPH_OK; }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = ELPH_OK;
+    for (int it = 0; it < ELPH_CG_CHUNK && rc == ELPH_OK; ++it) rc = elph_launch_cg_iteration(h, nrhs, use_prec);
+    if (rc == ELPH_OK) {
+        hipError_t e = hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream);
+        if (e != hipSuccess) { elph_set_error("capture memcpy: %s", hipGetErrorString(e)); rc = ELPH_E_HIP; }
+    }
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { elph_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { elph_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+    h->graphs.push_back({nrhs, use_prec, exec});
+    *out = exec;
+    return ELPH_OK;
+}
+
+// Runs CG on d_b / d_x (layout S) for nrhs right-hand sides.  Returns per-rhs iteration counts.
+static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t maxiter, double kmax, int64_t *iters,
+                  double *eps_hist /* host, optional, nrhs*(maxiter+1) */) {
+    if (use_prec && !h->kpm_ready) { elph_set_error("preconditioned solve requested before elph_kpm_setup"); return ELPH_E_STATE; }
+    CgParams P;
+    P.tol = tol; P.kmax = kmax; P.maxiter = maxiter; P.use_prec = use_prec;
+    P.record_hist = eps_hist ? 1 : 0;
+    P.hist_stride = maxiter + 1;
+    if (eps_hist) {
+        const int64_t need = (int64_t)nrhs * (maxiter + 1);
+        if (need > h->hist_cap) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            drop_graphs(h);
+            RC(dev_alloc(&h->d_hist, (size_t)need));
+            h->hist_cap = need;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(h->d_params, &P, sizeof(P), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // P is a stack object
+    RC(elph_launch_cg_init(h, nrhs, use_prec));
+
+    const int64_t max_chunks = (maxiter + 1 + ELPH_CG_CHUNK - 1) / ELPH_CG_CHUNK + 1;
+    bool all_done = false;
+    for (int64_t c = 0; c < max_chunks && !all_done; ++c) {
+        if (h->use_graph) {
+            hipGraphExec_t exec;
+            RC(get_chunk_graph(h, nrhs, use_prec, &exec));
+            HIPCHK(hipGraphLaunch(exec, h->stream));
+        } else {
+            for (int it = 0; it < ELPH_CG_CHUNK; ++it) RC(elph_launch_cg_iteration(h, nrhs, use_prec));
+            HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        all_done = true;
+        for (int r = 0; r < nrhs; ++r) {
+            const CgState &a = h->h_state[2 * r], &b = h->h_state[2 * r + 1];
+            const CgState &s = (b.seq > a.seq) ? b : a;
+            if (!s.done) all_done = false;
+            else iters[r] = s.iters;
+        }
+    }
+    if (!all_done) { elph_set_error("CG chunk loop ended without a terminal state (internal error)"); return ELPH_E_STATE; }
+    if (eps_hist) {
+        HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, sizeof(double) * (size_t)nrhs * (size_t)(maxiter + 1), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return ELPH_OK;
+}
+
+// residual + flag logic of ldiv! for rhs already solved into d_x; zeroes x where flag > 0
+static int residual_and_flags(elph_handle_s *h, int nrhs, const int64_t *iters, int64_t cmp_maxiter, double *resid, int *flag) {
+    RC(elph_launch_residual(h, nrhs));
+    HIPCHK(hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < nrhs; ++r) {
+        resid[r] = h->h_scal[r];
+        if (resid[r] > sqrt(h->tol)) {           // Models.jl:100,157 (NaN compares false, as in the reference)
+            flag[r] = (iters[r] == cmp_maxiter) ? 1 : 2;
+            RC(elph_launch_zero(h, h->d_x + (size_t)r * (size_t)h->ndim, h->ndim));   // fill!(x,0)
+        } else {
+            flag[r] = 0;
+        }
+    }
+    return ELPH_OK;
+}
+
+// ldiv! on device-resident layout-S d_b/d_x
+static int ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag) {
+    RC(need_model(h));
+    if (maxiter == 0) maxiter = h->maxiter;                                  // Models.jl:78-80,143-145
+    if (!use_prec) {
+        RC(run_cg(h, nrhs, 0, h->tol, maxiter, h->kmax, iters, nullptr));
+        RC(residual_and_flags(h, nrhs, iters, h->maxiter, resid, flag));     // Models.jl:160 compares solver.maxiter
+        return ELPH_OK;
+    }
+    RC(run_cg(h, nrhs, 1, h->tol, maxiter, h->kmax, iters, nullptr));
+    RC(residual_and_flags(h, nrhs, iters, maxiter, resid, flag));            // Models.jl:103 compares maxiter
+    // failed right-hand sides: retry without preconditioner, 10x maxiter, from x = 0 (Models.jl:129-133)
+    for (int r = 0; r < nrhs; ++r) {
+        if (flag[r] == 0) continue;
+        const size_t nd = (size_t)h->ndim;
+        if (r != 0) {
+            // park rhs 0, move rhs r into slot 0, solve single, move back
+            HIPCHK(hipMemcpyAsync(h->d_tmp, h->d_x, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_z, h->d_b, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_x, h->d_x + r * nd, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_b, h->d_b + r * nd, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_stage_out, h->d_tmp, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_stage_in, h->d_z, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+        int64_t it1 = 0; double rs1 = 0; int fl1 = 0;
+        RC(run_cg(h, 1, 0, h->tol, 10 * maxiter, h->kmax, &it1, nullptr));
+        RC(residual_and_flags(h, 1, &it1, h->maxiter, &rs1, &fl1));
+        iters[r] = it1; resid[r] = rs1; flag[r] = fl1;
+        if (r != 0) {
+            HIPCHK(hipMemcpyAsync(h->d_x + r * nd, h->d_x, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_x, h->d_stage_out, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_b, h->d_stage_in, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    return ELPH_OK;
+}
+
+static int stage_in_dev(elph_handle_s *h, int nrhs, const double *X_dev, const double *B_dev) {
+    RC(ensure_capacity(h, nrhs));
+    RC(elph_launch_r2s(h, h->d_b, B_dev, nrhs));
+    RC(elph_launch_r2s(h, h->d_x, X_dev, nrhs));
+    return ELPH_OK;
+}
+
+extern "C" int elph_ldiv_batched_dev(elph_handle h, int nrhs, double *X_dev, const double *B_dev, int use_prec,
+                                     int64_t maxiter, int64_t *iters, double *residual_error, int *flag) {
+    CHECK_H(h);
+    if (nrhs < 1 || !X_dev || !B_dev || !iters || !residual_error || !flag || maxiter < 0) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    RC(stage_in_dev(h, nrhs, X_dev, B_dev));
+    RC(ldiv_core(h, nrhs, use_prec, maxiter, iters, residual_error, flag));
+    RC(elph_launch_s2r(h, X_dev, h->d_x, nrhs));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_ldiv_dev(elph_handle h, double *x_dev, const double *b_dev, int use_prec, int64_t maxiter,
+                             int64_t *iters, double *residual_error, int *flag) {
+    return elph_ldiv_batched_dev(h, 1, x_dev, b_dev, use_prec, maxiter, iters, residual_error, flag);
+}
+
+extern "C" int elph_ldiv_batched(elph_handle h, int nrhs, double *X, const double *B, int use_prec, int64_t maxiter,
+                                 int64_t *iters, double *residual_error, int *flag) {
+    CHECK_H(h);
+    if (nrhs < 1 || !X || !B || !iters || !residual_error || !flag || maxiter < 0) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    RC(ensure_capacity(h, nrhs));
+    const size_t bytes = (size_t)nrhs * (size_t)h->ndim * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, B, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, nrhs));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, X, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, nrhs));
+    RC(ldiv_core(h, nrhs, use_prec, maxiter, iters, residual_error, flag));
+    RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, nrhs));
+    HIPCHK(hipMemcpyAsync(X, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_ldiv(elph_handle h, double *x, const double *b, int use_prec, int64_t maxiter, int64_t *iters,
+                         double *residual_error, int *flag) {
+    return elph_ldiv_batched(h, 1, x, b, use_prec, maxiter, iters, residual_error, flag);
+}
+
+extern "C" int elph_cg_solve(elph_handle h, double *x, const double *b, double tol, int64_t maxiter, double kappa_max,
+                             int use_precond, int64_t *iters, double *eps_hist) {
+    CHECK_H(h);
+    RC(need_model(h));
+    if (!x || !b || !iters || maxiter < 0) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (maxiter == 0) maxiter = h->maxiter;       // iszero() defaults, IterativeSolvers.jl:160-173
+    if (tol == 0.0) tol = h->tol;
+    if (kappa_max == 0.0) kappa_max = h->kmax;
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, b, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 1));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, x, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, 1));
+    RC(run_cg(h, 1, use_precond ? 1 : 0, tol, maxiter, kappa_max, iters, eps_hist));
+    RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, 1));
+    HIPCHK(hipMemcpyAsync(x, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// KPM preconditioner
+// ------------------------------------------------------------------------------------------
+
+extern "C" int elph_kpm_create(elph_handle h, int n, double buf, double c1, double c2) {
+    CHECK_H(h);
+    if (n < 1 || !(buf >= 0.0)) { elph_set_error("bad KPM parameters"); return ELPH_E_ARG; }
+    h->kpm_n = n; h->kpm_buf = buf; h->kpm_c1 = c1; h->kpm_c2 = c2;
+    // KPMExpansion ctor, KPMPreconditioners.jl:101-146
+    h->lam_lo = 0.0; h->lam_hi = 2.0; h->lam_avg = 1.0; h->lam_mag = 1.0;
+    const int Lo2 = (int)((h->L + 1) / 2);
+    h->h_order.assign(Lo2, 1);
+    h->h_coff.resize(Lo2 + 1);
+    std::iota(h->h_coff.begin(), h->h_coff.end(), 0);
+    h->h_coeff.assign(2 * (size_t)Lo2, 0.0);
+    h->h_wsched.resize(Lo2);
+    std::iota(h->h_wsched.begin(), h->h_wsched.end(), 0);
+    h->h_Ebar.assign((size_t)h->N, 0.0);
+    h->h_cbar.assign((size_t)h->nb, 0.0);
+    h->h_sbar.assign((size_t)h->nb, 0.0);
+    RC(dev_alloc(&h->d_Ebar, (size_t)h->N));
+    RC(dev_alloc(&h->d_cbar, (size_t)h->nb));
+    RC(dev_alloc(&h->d_sbar, (size_t)h->nb));
+    RC(dev_alloc(&h->d_order, (size_t)Lo2));
+    RC(dev_alloc(&h->d_coff, (size_t)Lo2 + 1));
+    RC(dev_alloc(&h->d_wsched, (size_t)Lo2));
+    h->kpm_created = true;
+    h->kpm_ready = false;
+    h->kpm_active = 1;
+    return ELPH_OK;
+}
+
+static int kpm_upload(elph_handle_s *h) {
+    const int Lo2 = (int)((h->L + 1) / 2);
+    const size_t ntot = (size_t)h->h_coff[Lo2];
+    if ((int64_t)ntot > h->coeff_cap) {
+        RC(dev_alloc(&h->d_coeff, ntot));
+        h->coeff_cap = (int64_t)ntot;
+    }
+    HIPCHK(hipMemcpy(h->d_coeff, h->h_coeff.data(), ntot * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_order, h->h_order.data(), sizeof(int) * Lo2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_coff, h->h_coff.data(), sizeof(int) * (Lo2 + 1), hipMemcpyHostToDevice));
+    // schedule: frequency blocks by decreasing order (the low frequencies carry the long recursions)
+    std::iota(h->h_wsched.begin(), h->h_wsched.end(), 0);
+    std::stable_sort(h->h_wsched.begin(), h->h_wsched.end(), [&](int a, int b) { return h->h_order[a] > h->h_order[b]; });
+    HIPCHK(hipMemcpy(h->d_wsched, h->h_wsched.data(), sizeof(int) * Lo2, hipMemcpyHostToDevice));
+    return ELPH_OK;
+}
+
+static bool jl_isapprox(double x, double y, double rtol) {
+    return x == y || (std::isfinite(x) && std::isfinite(y) && fabs(x - y) <= rtol * std::max(fabs(x), fabs(y)));
+}
+
+extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *b_min, double e_min, double e_max,
+                              int *active, double *lam_lo, double *lam_hi) {
+    CHECK_H(h);
+    if (!h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
+    RC(need_model(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+    // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)
+    if (h->kind == ELPH_MODEL_HOLSTEIN) {
+        RC(elph_launch_ebar(h));
+        HIPCHK(hipMemcpyAsync(h->h_Ebar.data(), h->d_Ebar, sizeof(double) * N, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->h_cbar = h->h_c;
+        h->h_sbar = h->h_s;
+    } else {
+        HIPCHK(hipMemcpy(h->h_Ebar.data(), h->d_E, sizeof(double) * N, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h->d_Ebar, h->d_E, sizeof(double) * N, hipMemcpyDeviceToDevice));
+        for (int64_t n = 0; n < h->nb; ++n) {
+            double c = 0.0, s = 0.0;
+            for (int t = 0; t < L; ++t) { c += h->h_c[(size_t)t * h->nb + n]; s += h->h_s[(size_t)t * h->nb + n]; }
+            h->h_cbar[n] = c / L;
+            h->h_sbar[n] = s / L;
+        }
+    }
+    if (h->nb > 0) {
+        HIPCHK(hipMemcpy(h->d_cbar, h->h_cbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sbar, h->h_sbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
+    }
+    // eigenvalue bounds (:272-273) — injected or Arnoldi with caller-supplied start vectors
+    if (!(std::isfinite(e_min) && std::isfinite(e_max))) {
+        if (!b_max || !b_min) { elph_set_error("Arnoldi start vectors required when bounds are not injected"); return ELPH_E_ARG; }
+        RC(elph_kpm_arnoldi(h, b_max, b_min, &e_min, &e_max));
+    }
+    const int was_active = h->kpm_active;
+    bool changed = !h->kpm_ready;
+    if ((0.0 < e_min && e_min < 1.0) && (1.0 < e_max) && (e_max - e_min) < 2.0) {       // :280
+        const double lo = std::max(0.0, (1 - 2 * h->kpm_buf) * e_min), hi = (1 + 2 * h->kpm_buf) * e_max;
+        if (!jl_isapprox(lo, h->lam_lo, h->kpm_buf) || !jl_isapprox(hi, h->lam_hi, h->kpm_buf)) {   // :288
+            h->lam_lo = lo; h->lam_hi = hi;
+            h->lam_avg = (hi + lo) / 2; h->lam_mag = (hi - lo) / 2;
+            int off = 0;
+            std::vector<double> coeff;
+            for (int w = 0; w < Lo2; ++w) {
+                const double phi = 2.0 * M_PI / (double)L * (w + 0.5);                   // ctor :117
+                int order = (int)floor((hi - lo) * (h->kpm_c1 / phi + h->kpm_c2));       // :300
+                order = std::max(1, order);
+                h->h_order[w] = order;
+                h->h_coff[w] = off;
+                coeff.resize(2 * (size_t)(off + order));
+                elph_kpm_coefficients(coeff.data() + 2 * (size_t)off, order, lo, hi, phi);
+                off += order;
+            }
+            h->h_coff[Lo2] = off;
+            h->h_coeff.swap(coeff);
+            changed = true;
+        }
+        h->kpm_active = 1;
+    } else {
+        h->kpm_active = 0;                                                               // :312-318
+    }
+    if (changed || was_active != h->kpm_active) {
+        RC(kpm_upload(h));
+        drop_graphs(h);   // KpmDev (lam_avg, lam_mag, active) is baked into captured kernel arguments
+    }
+    h->kpm_ready = true;
+    if (active) *active = h->kpm_active;
+    if (lam_lo) *lam_lo = h->lam_lo;
+    if (lam_hi) *lam_hi = h->lam_hi;
+    return ELPH_OK;
+}
+
+extern "C" int elph_kpm_orders(elph_handle h, int64_t *orders, int64_t *total) {
+    CHECK_H(h);
+    if (!h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
+    const int Lo2 = (int)((h->L + 1) / 2);
+    int64_t tot = 0;
+    for (int w = 0; w < Lo2; ++w) {
+        if (orders) orders[w] = h->h_order[w];
+        tot += h->h_order[w];
+    }
+    if (total) *total = tot;
+    return ELPH_OK;
+}
+
+extern "C" int elph_kpm_apply_dev(elph_handle h, double *z_dev, const double *r_dev) {
+    CHECK_H(h);
+    if (!h->kpm_ready) { elph_set_error("elph_kpm_setup has not been called"); return ELPH_E_STATE; }
+    if (!z_dev || !r_dev) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(elph_launch_r2s(h, h->d_r, r_dev, 1));
+    RC(elph_launch_kpm_apply(h, h->d_zp, h->d_r, 1, 0));
+    RC(elph_launch_s2r(h, z_dev, h->d_zp, 1));
+    return ELPH_OK;
+}
+
+extern "C" int elph_kpm_apply(elph_handle h, double *z, const double *r) {
+    CHECK_H(h);
+    if (!z || !r) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, r, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_kpm_apply_dev(h, h->d_stage_out, h->d_stage_in));
+    HIPCHK(hipMemcpyAsync(z, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fourier acceleration / twisted FFT
+// ------------------------------------------------------------------------------------------
+
+extern "C" int elph_fourier_accelerate(elph_handle h, double *vout, const double *vin, const double *diag, double power,
+                                       int64_t nph) {
+    CHECK_H(h);
+    if (!vout || !vin || !diag || nph < 1) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    const int64_t L = h->L, n = nph * L;
+    // scratch: 3 real vectors of n + complex half spectrum; grown on demand (nph may exceed nsites for SSH)
+    const int64_t need = 3 * n + 2 * (L / 2 + 1) * nph;
+    if (need > h->diag_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        RC(dev_alloc(&h->d_diag, (size_t)need));
+        h->diag_cap = need;
+    }
+    double *dR = h->d_diag, *aS = h->d_diag + n, *bS = h->d_diag + 2 * n;
+    double2 *u = reinterpret_cast<double2 *>(h->d_diag + 3 * n);
+    // stage (layout R -> S for "nph" columns): reuse the transpose kernel with rows = nph
+    elph_handle_s tmp = *h;   // shallow view with N := nph for the launch helpers
+    tmp.N = nph; tmp.ndim = n; tmp.npl = (int)((nph + ELPH_WAVE - 1) / ELPH_WAVE); tmp.d_nu = u;
+    tmp.graphs.clear();
+    HIPCHK(hipMemcpyAsync(dR, diag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(&tmp, bS, dR, 1));                 // bS = diag in layout S  (diag[k][s])
+    HIPCHK(hipMemcpyAsync(dR, vin, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(&tmp, aS, dR, 1));                 // aS = v in layout S
+    RC(elph_launch_fft_accel(&tmp, dR, aS, bS, power, nph));   // dR = result in layout S
+    RC(elph_launch_s2r(&tmp, aS, dR, 1));                 // aS = result in layout R
+    HIPCHK(hipMemcpyAsync(vout, aS, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    tmp.h_state = nullptr;   // the view owns nothing
+    return ELPH_OK;
+}
+
+extern "C" int elph_tau_to_omega(elph_handle h, double *nu_complex, const double *v) {
+    CHECK_H(h);
+    if (!nu_complex || !v) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    const size_t nd = (size_t)h->ndim;
+    RC(ensure_capacity(h, 2));   // complex scratch = 2 real vectors
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, v, nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 1));
+    double2 *fullS = reinterpret_cast<double2 *>(h->d_p);           // [L][N] complex
+    RC(elph_launch_tau_to_omega(h, fullS, h->d_b));
+    // complex layout S -> complex layout R: transpose re and im planes separately via a strided copy
+    // (API convenience path; the solver itself never leaves layout S)
+    std::vector<double> tmp(2 * nd);
+    HIPCHK(hipMemcpyAsync(tmp.data(), fullS, 2 * nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->N, L = (size_t)h->L;
+    for (size_t k = 0; k < L; ++k)
+        for (size_t s = 0; s < N; ++s) {
+            nu_complex[2 * (s * L + k)] = tmp[2 * (k * N + s)];
+            nu_complex[2 * (s * L + k) + 1] = tmp[2 * (k * N + s) + 1];
+        }
+    return ELPH_OK;
+}
+
+extern "C" int elph_omega_to_tau(elph_handle h, double *v, const double *nu_complex) {
+    CHECK_H(h);
+    if (!nu_complex || !v) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    const size_t nd = (size_t)h->ndim, N = (size_t)h->N, L = (size_t)h->L;
+    RC(ensure_capacity(h, 2));
+    std::vector<double> tmp(2 * nd);
+    for (size_t k = 0; k < L; ++k)
+        for (size_t s = 0; s < N; ++s) {
+            tmp[2 * (k * N + s)] = nu_complex[2 * (s * L + k)];
+            tmp[2 * (k * N + s) + 1] = nu_complex[2 * (s * L + k) + 1];
+        }
+    double2 *fullS = reinterpret_cast<double2 *>(h->d_p);
+    HIPCHK(hipMemcpy(fullS, tmp.data(), 2 * nd * sizeof(double), hipMemcpyHostToDevice));
+    RC(elph_launch_omega_to_tau(h, h->d_x, fullS));
+    RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, 1));
+    HIPCHK(hipMemcpyAsync(v, h->d_stage_out, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement hook
+// ------------------------------------------------------------------------------------------
+
+extern "C" int elph_time_unit(elph_handle h, int what, int nrhs, int reps, double *ms_per_rep) {
+    CHECK_H(h);
+    RC(need_model(h));
+    if (nrhs < 1 || reps < 1 || !ms_per_rep || what < 0 || what > 3) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if ((what == 2 || what == 3) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
+    RC(ensure_capacity(h, nrhs));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    int rc = ELPH_OK;
+    if (what == 1 || what == 3) {
+        // fixed-count CG iterations on whatever d_b/d_x hold: tol = 0 never converges, kmax = inf
+        CgParams P;
+        P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3); P.record_hist = 0; P.hist_stride = 0;
+        HIPCHK(hipMemcpy(h->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
+        // x0 = 0, b = whatever the last solve left in d_b (bench.py loads it with a real solve first)
+        HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
+        rc = elph_launch_cg_init(h, nrhs, P.use_prec);
+    }
+    if (rc == ELPH_OK) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipEventRecord(e0, h->stream));
+        for (int r = 0; r < reps && rc == ELPH_OK; ++r) {
+            if (what == 0) rc = elph_launch_mul(h, 2, h->d_z, h->d_b, nrhs);
+            else if (what == 2) rc = elph_launch_kpm_apply(h, h->d_zp, h->d_b, nrhs, 0);
+            else rc = elph_launch_cg_iteration(h, nrhs, what == 3);
+        }
+        HIPCHK(hipEventRecord(e1, h->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_rep = (double)ms / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

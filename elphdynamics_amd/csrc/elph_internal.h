@@ -1,0 +1,172 @@
+// elph_internal.h — internal declarations of libelphgpu (gfx950 only).
+//
+// Device-side data layout ("layout S", slice-major): a lattice vector is stored as
+//     v_S[tau * N + site]
+// i.e. one imaginary-time slice (all N sites) is contiguous.  The reference / C-ABI layout
+// ("layout R", Utilities.jl:12-15) is v_R[site * L + tau].  Host and `_dev` entry points
+// convert with a tiled transpose kernel; everything between (CG vectors, expV, KPM scratch)
+// stays in layout S, so that
+//   * one wavefront owns one tau-slice: its loads/stores are contiguous 8*N bytes,
+//   * the checkerboard sweep (couples sites at fixed tau) runs in that wave's LDS with no
+//     cross-wave synchronisation,
+//   * the tau-FFT output nu[omega][site] is already the omega-major layout the per-omega
+//     Chebyshev recursion of the KPM preconditioner wants (no transposes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/elph_gpu.h"
+
+#define ELPH_ABI_VERSION 1
+#define ELPH_WAVE 64
+#define ELPH_MAX_NPL 8          // sites per lane: N <= 512
+#define ELPH_CG_CHUNK 16        // CG iterations per captured graph launch
+
+void elph_set_error(const char *fmt, ...);
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            elph_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return ELPH_E_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+// Model description handed to kernels by value.
+struct ModelDev {
+    int N, L, nb, ncol;
+    int cs_tau_stride;   // 0 (Holstein: c,s per bond) or nb (SSH: c,s per (tau,bond))
+    int E_tau_stride;    // N (Holstein: E per (tau,site)) or 0 (SSH: E per site)
+    const int *bi;       // [nb] 0-based first site of bond, checkerboard order
+    const int *bj;       // [nb]
+    const int *coloff;   // [ncol+1] colour boundaries into the bond list
+    const double *c;     // cosh table
+    const double *s;     // sinh table
+    const double *E;     // exp(-dtau V) (Holstein, layout S) or exp(dtau mu) (SSH)
+};
+
+// CG state of one right-hand side; two copies, the newer one has the larger seq.
+struct CgState {
+    double rho;       // r.z (or r.r) belonging to the current search direction
+    double kmin;      // running lower bound of the condition number (IterativeSolvers.jl:289)
+    double eps0;      // |r0|/|b|
+    double normb;     // |b|
+    double eps;       // last evaluated |r|/|b|
+    long long seq;    // number of k_cg_ap launches that advanced this state
+    long long iters;  // completed CG iterations
+    int done;         // 0 running, 1 eps<tol, 2 kmin>kmax, 3 maxiter reached
+    int pad;
+};
+
+struct CgParams {
+    double tol, kmax;
+    long long maxiter;
+    int use_prec;
+    int record_hist;
+    long long hist_stride;
+};
+
+struct KpmDev {
+    int active;
+    int Lo2;
+    double lam_avg, lam_mag;
+    const double *Ebar;       // [N]
+    const double *cbar;       // [nb]
+    const double *sbar;       // [nb]
+    const int *order;         // [Lo2]
+    const int *coff;          // [Lo2+1]
+    const double2 *coeff;     // [sum order]
+    const int *wsched;        // [Lo2] omega indices sorted by decreasing order (longest first)
+};
+
+struct elph_handle_s {
+    int kind = 0, device = 0;
+    int64_t N = 0, L = 0, nb = 0, ndim = 0;
+    int npl = 0;               // ceil(N/64)
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // model
+    int ncol = 0;
+    std::vector<int> h_bi, h_bj, h_coloff;
+    std::vector<double> h_c, h_s;          // Holstein: [nb]; SSH: tau-major [L][nb]
+    int *d_bi = nullptr, *d_bj = nullptr, *d_coloff = nullptr;
+    double *d_c = nullptr, *d_s = nullptr, *d_E = nullptr;
+    bool have_E = false;
+    double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
+
+    // solver defaults (model.solver)
+    double tol = 1e-4, kmax = 1e12;
+    int64_t maxiter = 0;
+
+    // workspace
+    int cap_rhs = 0;
+    double *d_stage_in = nullptr, *d_stage_out = nullptr;  // layout R staging, cap_rhs*ndim
+    double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_zp = nullptr;
+    double *d_p = nullptr;                 // 2 * cap_rhs * ndim (ping-pong)
+    double *d_tmp = nullptr;               // cap_rhs*ndim scratch (v''')
+    double *d_part = nullptr;              // partial sums: 4 arrays of cap_rhs * L
+    CgState *d_state = nullptr;            // cap_rhs * 2
+    CgState *h_state = nullptr;            // pinned, cap_rhs * 2
+    CgParams *d_params = nullptr;
+    double *d_hist = nullptr;
+    int64_t hist_cap = 0;
+    double *d_scal = nullptr;              // small scalar scratch (residual norms), 4*cap_rhs
+    double *h_scal = nullptr;              // pinned
+
+    // captured CG chunk graphs, keyed by (nrhs, use_prec)
+    struct GraphEntry { int nrhs, use_prec; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    bool use_graph = true;
+
+    // KPM
+    bool kpm_created = false, kpm_ready = false;
+    int kpm_n = 20;
+    double kpm_buf = 0.05, kpm_c1 = 1.0, kpm_c2 = 1.0;
+    double lam_lo = 0.0, lam_hi = 2.0, lam_avg = 1.0, lam_mag = 1.0;
+    int kpm_active = 1;
+    std::vector<double> h_Ebar, h_cbar, h_sbar;
+    std::vector<int> h_order, h_coff, h_wsched;
+    std::vector<double> h_coeff;           // complex interleaved
+    double *d_Ebar = nullptr, *d_cbar = nullptr, *d_sbar = nullptr;
+    int *d_order = nullptr, *d_coff = nullptr, *d_wsched = nullptr;
+    double2 *d_coeff = nullptr;
+    int64_t coeff_cap = 0;
+    double2 *d_nu = nullptr;               // cap_rhs * Lo2 * N complex (half spectrum, omega-major)
+
+    // FFT twiddles
+    double2 *d_tw = nullptr;               // [L] exp(-2 pi i k / L)
+    double2 *d_theta = nullptr;            // [L] exp(-i pi t / L)
+    double *d_diag = nullptr;              // fourier-acceleration diagonal staging
+    int64_t diag_cap = 0;
+    std::vector<int> fft_radices;
+};
+
+// ---- launchers implemented in kernels.hip -------------------------------------------------
+ModelDev elph_model_dev(const elph_handle_s *h);
+KpmDev elph_kpm_dev(const elph_handle_s *h);
+
+int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec);
+int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec);
+int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau);
+int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
+int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec);
+int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec);
+int elph_launch_residual(elph_handle_s *h, int nrhs);
+int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode);
+int elph_launch_ebar(elph_handle_s *h);
+int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int64_t ncol);
+int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);
+int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS);
+int elph_launch_zero(elph_handle_s *h, double *p, int64_t n);
+
+// ---- host-side KPM setup (kpm_host.cpp) ---------------------------------------------------
+void elph_kpm_coefficients(double *c_z, int order, double lam_lo, double lam_hi, double phi);
+int elph_kpm_arnoldi(const elph_handle_s *h, const double *b_max, const double *b_min, double *e_min,
+                     double *e_max);
+int elph_hess_eigvals(std::vector<double> &a, int n, std::vector<double> &wr, std::vector<double> &wi);

@@ -1,0 +1,1035 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the fermion-force solver.
+//
+// Mapping (see elph_internal.h for layout S): one 64-lane wavefront == one workgroup owns one
+// imaginary-time slice tau of one right-hand side.  Lane l holds sites l, l+64, ... (NPL per lane)
+// in registers; the checkerboard sweep, which couples sites at fixed tau, goes through that wave's
+// private LDS slab, so the only synchronisation inside a kernel is the single-wave workgroup
+// barrier (which the compiler lowers to a wave barrier for 64-thread groups).
+// Grid = (L, nrhs) workgroups: >= 160 waves for the headline lattice, x nrhs when batched.
+//
+// Reference semantics: SURVEY.md Appendix A; file:line citations at each kernel.
+
+#include "elph_internal.h"
+
+#define WAVE ELPH_WAVE
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+    // xor butterfly: every lane ends with the bit-identical total (a+b == b+a at every level),
+    // and the tree is fixed => run-to-run deterministic.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double reduce_partials(const double *p, int n) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += WAVE) a += p[i];
+    return wave_sum(a);
+}
+
+__device__ __forceinline__ const CgState *newest_state(const CgState *st2) {
+    return (st2[1].seq > st2[0].seq) ? &st2[1] : &st2[0];
+}
+
+// One checkerboard sweep over an LDS slab holding one tau-slice (Checkerboard.jl:57-83 forward,
+// :149-175 transposed == colours in reverse order; bonds inside a colour are site-disjoint so
+// their order is irrelevant).  c,s point at this slice's coefficients.
+template <int NBUF, bool REVERSE>
+__device__ __forceinline__ void cb_sweep(double *buf0, double *buf1, const double *c0, const double *s0,
+                                         const double *c1, const double *s1, const ModelDev &m) {
+    for (int cc = 0; cc < m.ncol; ++cc) {
+        const int col = REVERSE ? (m.ncol - 1 - cc) : cc;
+        const int b0 = m.coloff[col], b1 = m.coloff[col + 1];
+        for (int n = b0 + threadIdx.x; n < b1; n += WAVE) {
+            const int i = m.bi[n], j = m.bj[n];
+            {
+                const double cn = c0[n], sn = s0[n];
+                const double t1 = buf0[i], t2 = buf0[j];
+                buf0[i] = cn * t1 + sn * t2;
+                buf0[j] = cn * t2 + sn * t1;
+            }
+            if (NBUF == 2) {
+                const double cn = c1[n], sn = s1[n];
+                const double t1 = buf1[i], t2 = buf1[j];
+                buf1[i] = cn * t1 + sn * t2;
+                buf1[j] = cn * t2 + sn * t1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// complex variant for the KPM recursion (Checkerboard.jl:123-141,212-230 on complex N-vectors)
+template <bool REVERSE>
+__device__ __forceinline__ void cb_sweep_z(double2 *buf, const double *c, const double *s, const ModelDev &m) {
+    for (int cc = 0; cc < m.ncol; ++cc) {
+        const int col = REVERSE ? (m.ncol - 1 - cc) : cc;
+        const int b0 = m.coloff[col], b1 = m.coloff[col + 1];
+        for (int n = b0 + threadIdx.x; n < b1; n += WAVE) {
+            const int i = m.bi[n], j = m.bj[n];
+            const double cn = c[n], sn = s[n];
+            const double2 t1 = buf[i], t2 = buf[j];
+            buf[i] = make_double2(cn * t1.x + sn * t2.x, cn * t1.y + sn * t2.y);
+            buf[j] = make_double2(cn * t2.x + sn * t1.x, cn * t2.y + sn * t1.y);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// layout conversion  R: v[site*L + tau]  <->  S: v[tau*N + site]
+// ------------------------------------------------------------------------------------------
+
+// out[c*rows + r] = in[r*cols + c]; 32x32 tiles through LDS (+1 pad), blockDim (32,8), z = vector
+__global__ void __launch_bounds__(256) k_transpose(double *__restrict__ out, const double *__restrict__ in,
+                                                   int rows, int cols) {
+    __shared__ double tile[32][33];
+    const size_t base = (size_t)blockIdx.z * (size_t)rows * (size_t)cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[k][threadIdx.x] = in[base + (size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[base + (size_t)c * rows + r] = tile[threadIdx.x][k];
+    }
+}
+
+// update_model!(holstein), HolsteinModels.jl:526-549, fused with the R->S conversion:
+// E_S[tau*N+i] = exp(-dtau*(lambda_i x + lambda2_i x^2 - mu_i)),  x in layout R.
+__global__ void __launch_bounds__(256) k_expV(double *__restrict__ ES, const double *__restrict__ xR,
+                                              const double *__restrict__ lam3, int N, int L, double dtau) {
+    __shared__ double tile[32][33];
+    const int t0 = blockIdx.x * 32, s0 = blockIdx.y * 32;   // in: rows = sites, cols = tau
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int s = s0 + k, t = t0 + threadIdx.x;
+        if (s < N && t < L) {
+            const double x = xR[(size_t)s * L + t];
+            tile[k][threadIdx.x] = exp(-dtau * (lam3[s] * x + lam3[N + s] * (x * x) + -lam3[2 * N + s]));
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int t = t0 + k, s = s0 + threadIdx.x;
+        if (s < N && t < L) ES[(size_t)t * N + s] = tile[threadIdx.x][k];
+    }
+}
+
+__global__ void k_zero(double *p, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// M v, M^T v, M^T M v   (HolsteinModels.jl:569-684, SSHModels.jl:581-701, Models.jl:215-224)
+//   (M v)(t)   = v(t) - sg(t)   CB(t) [E(t) .* v(t-1)],        sg(0) = -1 else +1
+//   (M^T v)(t) = v(t) - sg(t+1) E(t+1) .* [CB(t+1)^T v(t+1)]
+//   M^T M in ONE pass: a wave owning slice t rebuilds w(t) and w(t+1) (w = M v) from
+//   v(t-1..t+1) and applies the transposed sweep to w(t+1) — no v' round trip through memory.
+// ------------------------------------------------------------------------------------------
+
+template <int NPL, int WHICH>
+__global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const double *__restrict__ v, ModelDev m) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *bufA = lds, *bufB = lds + m.N;
+    const int N = m.N, L = m.L;
+    const int t = blockIdx.x;
+    const int tm1 = (t == 0) ? L - 1 : t - 1;
+    const int tp1 = (t == L - 1) ? 0 : t + 1;
+    const size_t vec = (size_t)blockIdx.y * (size_t)N * (size_t)L;
+    const double *vv = v + vec;
+    double *yy = y + vec;
+    const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
+    const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
+    const double *c1 = m.c + (size_t)tp1 * m.cs_tau_stride, *s1 = m.s + (size_t)tp1 * m.cs_tau_stride;
+    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+
+    if (WHICH == 0) {  // y = M v
+        double v0[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) {
+                v0[q] = vv[(size_t)t * N + s];
+                bufA[s] = E0[s] * vv[(size_t)tm1 * N + s];
+            }
+        }
+        __syncthreads();
+        cb_sweep<1, false>(bufA, nullptr, c0, s0, nullptr, nullptr, m);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) yy[(size_t)t * N + s] = v0[q] - sg0 * bufA[s];
+        }
+    } else if (WHICH == 1) {  // y = M^T v
+        double v0[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) {
+                v0[q] = vv[(size_t)t * N + s];
+                bufA[s] = vv[(size_t)tp1 * N + s];
+            }
+        }
+        __syncthreads();
+        cb_sweep<1, true>(bufA, nullptr, c1, s1, nullptr, nullptr, m);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) yy[(size_t)t * N + s] = v0[q] - sg1 * E1[s] * bufA[s];
+        }
+    } else {  // y = M^T M v
+        double v0[NPL], vp[NPL], w0[NPL], e1[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) {
+                const double vm = vv[(size_t)tm1 * N + s];
+                v0[q] = vv[(size_t)t * N + s];
+                vp[q] = vv[(size_t)tp1 * N + s];
+                e1[q] = E1[s];
+                bufA[s] = E0[s] * vm;
+                bufB[s] = e1[q] * v0[q];
+            }
+        }
+        __syncthreads();
+        cb_sweep<2, false>(bufA, bufB, c0, s0, c1, s1, m);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) {
+                w0[q] = v0[q] - sg0 * bufA[s];
+                bufB[s] = vp[q] - sg1 * bufB[s];
+            }
+        }
+        __syncthreads();
+        cb_sweep<1, true>(bufB, nullptr, c1, s1, nullptr, nullptr, m);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) yy[(size_t)t * N + s] = w0[q] - sg1 * e1[q] * bufB[s];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Conjugate gradient (IterativeSolvers.jl:153-234 with P, :239-314 without)
+// Two kernels per iteration, no host involvement, all control flow from device-resident state:
+//   k_cg_ap : [stop test of the previous iteration] beta; p = (z|r) + beta p; z = MtM p; partial p.z
+//   k_cg_xr : alpha; x += alpha p; r -= alpha z; partial r.r
+// Global reductions = per-slice partials written by one kernel and re-reduced, in a fixed order,
+// by every wave of the next kernel (deterministic; no atomics; no extra launch).
+// ------------------------------------------------------------------------------------------
+
+struct CgBufs {
+    double *x, *r, *z, *zp;     // [nrhs][ndim] layout S; zp = P^-1 r (preconditioned only)
+    double *p;                  // [2][nrhs][ndim] ping-pong by (seq & 1)
+    double *pap, *rr, *rz;      // partials [nrhs][npart]
+    CgState *state;             // [nrhs][2]
+    const CgParams *params;
+    double *hist;               // optional eps history
+    int nrz;                    // number of r.z partials per rhs
+    int nrhs;
+};
+
+template <int NPL>
+__global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *bufA = lds, *bufB = lds + m.N;
+    const int N = m.N, L = m.L;
+    const int t = blockIdx.x, rhs = blockIdx.y;
+    const size_t ndim = (size_t)N * L;
+    CgState *st2 = B.state + 2 * rhs;
+    const CgState S = *newest_state(st2);
+    if (S.done) return;
+    const CgParams P = *B.params;
+    const long long seq = S.seq;          // == completed iterations so far
+    const bool first = (seq == 0);
+    CgState *Sout = st2 + ((seq + 1) & 1);
+
+    double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
+    if (!first) {
+        // stop test of iteration `seq` (IterativeSolvers.jl:286-295 / :211-219)
+        const double rr = reduce_partials(B.rr + (size_t)rhs * L, L);
+        eps = sqrt(rr) / S.normb;
+        const double q = 2.0 * (double)seq / log(2.0 * S.eps0 / eps);
+        const double val = q * q;
+        kmin = (val > kmin) ? val : kmin;
+        int done = 0;
+        if (eps < P.tol) done = 1;
+        else if (kmin > P.kmax) done = 2;
+        else if (seq >= P.maxiter) done = 3;
+        if (t == 0 && threadIdx.x == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + seq] = eps;
+        if (done) {
+            if (t == 0 && threadIdx.x == 0) {
+                CgState o = S;
+                o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = done;
+                *Sout = o;
+            }
+            return;
+        }
+        const double rho_new = P.use_prec ? reduce_partials(B.rz + (size_t)rhs * B.nrz, B.nrz) : rr;
+        beta = rho_new / S.rho;            // :222-223 / :303-304
+        rho = rho_new;
+    }
+
+    const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
+    const double *pold = B.p + ((size_t)(seq & 1) * B.nrhs + rhs) * ndim;
+    double *pnew = B.p + ((size_t)((seq + 1) & 1) * B.nrhs + rhs) * ndim;
+    double *z = B.z + (size_t)rhs * ndim;
+
+    const int tm1 = (t == 0) ? L - 1 : t - 1;
+    const int tp1 = (t == L - 1) ? 0 : t + 1;
+    const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
+    const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
+    const double *c1 = m.c + (size_t)tp1 * m.cs_tau_stride, *s1 = m.s + (size_t)tp1 * m.cs_tau_stride;
+    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+
+    double p0[NPL], pp[NPL], w0[NPL], e1[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            const size_t im = (size_t)tm1 * N + s, i0 = (size_t)t * N + s, ip = (size_t)tp1 * N + s;
+            double pm;
+            if (first) {                       // p0 = z0|r0 was stored by the init kernel
+                pm = pold[im]; p0[q] = pold[i0]; pp[q] = pold[ip];
+            } else {                           // p = (z|r) + beta p   (:229-230 / :309-310)
+                pm = src[im] + beta * pold[im];
+                p0[q] = src[i0] + beta * pold[i0];
+                pp[q] = src[ip] + beta * pold[ip];
+            }
+            pnew[i0] = p0[q];
+            e1[q] = E1[s];
+            bufA[s] = E0[s] * pm;
+            bufB[s] = e1[q] * p0[q];
+        }
+    }
+    __syncthreads();
+    cb_sweep<2, false>(bufA, bufB, c0, s0, c1, s1, m);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            w0[q] = p0[q] - sg0 * bufA[s];
+            bufB[s] = pp[q] - sg1 * bufB[s];
+        }
+    }
+    __syncthreads();
+    cb_sweep<1, true>(bufB, nullptr, c1, s1, nullptr, nullptr, m);
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            const double zz = w0[q] - sg1 * e1[q] * bufB[s];
+            z[(size_t)t * N + s] = zz;
+            acc += p0[q] * zz;
+        }
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+        B.pap[(size_t)rhs * L + t] = acc;
+        if (t == 0) {
+            CgState o = S;
+            o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = 0;
+            *Sout = o;
+        }
+    }
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(WAVE) k_cg_xr(CgBufs B, int N, int L) {
+    const int t = blockIdx.x, rhs = blockIdx.y;
+    const size_t ndim = (size_t)N * L;
+    const CgState S = *newest_state(B.state + 2 * rhs);
+    if (S.done) return;
+    const double pap = reduce_partials(B.pap + (size_t)rhs * L, L);
+    const double alpha = S.rho / pap;                       // :202 / :279
+    const double *p = B.p + ((size_t)(S.seq & 1) * B.nrhs + rhs) * ndim;
+    const double *z = B.z + (size_t)rhs * ndim;
+    double *x = B.x + (size_t)rhs * ndim, *r = B.r + (size_t)rhs * ndim;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            const size_t i = (size_t)t * N + s;
+            x[i] += alpha * p[i];                           // :205 / :282
+            const double rn = r[i] - alpha * z[i];          // :208 / :285
+            r[i] = rn;
+            acc += rn * rn;
+        }
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) B.rr[(size_t)rhs * L + t] = acc;
+}
+
+// r0 = b - A x0 (A x0 precomputed into tmp), p0 = r0 (un-preconditioned), partial r.r and b.b
+__global__ void __launch_bounds__(WAVE) k_cg_init(CgBufs B, const double *__restrict__ b,
+                                                  const double *__restrict__ Ax, double *bb, int N, int L) {
+    const int t = blockIdx.x, rhs = blockIdx.y;
+    const size_t ndim = (size_t)N * L;
+    const double *bv = b + (size_t)rhs * ndim, *ax = Ax + (size_t)rhs * ndim;
+    double *r = B.r + (size_t)rhs * ndim;
+    double *p0 = B.p + (size_t)rhs * ndim;    // seq 0 reads p[0]
+    double a = 0.0, c = 0.0;
+    for (int s = threadIdx.x; s < N; s += WAVE) {
+        const size_t i = (size_t)t * N + s;
+        const double bi = bv[i];
+        const double ri = 1.0 * bi + -1.0 * ax[i];          // axpby!(1,b,-1,r), :179-180 / :262-263
+        r[i] = ri;
+        p0[i] = ri;
+        a += ri * ri;
+        c += bi * bi;
+    }
+    a = wave_sum(a);
+    c = wave_sum(c);
+    if (threadIdx.x == 0) {
+        B.rr[(size_t)rhs * L + t] = a;
+        bb[(size_t)rhs * L + t] = c;
+    }
+}
+
+// preconditioned start: p0 = z0 = P^-1 r0 (zp already computed, r.z partials in B.rz)
+__global__ void __launch_bounds__(WAVE) k_cg_init_prec(CgBufs B, int N, int L) {
+    const int t = blockIdx.x, rhs = blockIdx.y;
+    const size_t ndim = (size_t)N * L;
+    const double *zp = B.zp + (size_t)rhs * ndim;
+    double *p0 = B.p + (size_t)rhs * ndim;
+    for (int s = threadIdx.x; s < N; s += WAVE) {
+        const size_t i = (size_t)t * N + s;
+        p0[i] = zp[i];
+    }
+}
+
+// one wave per rhs: seed the state (normb, eps0, rho0) — IterativeSolvers.jl:176-195 / :259-274
+__global__ void __launch_bounds__(WAVE) k_cg_state0(CgBufs B, const double *bb, int L) {
+    const int rhs = blockIdx.x;
+    const CgParams P = *B.params;
+    const double rr = reduce_partials(B.rr + (size_t)rhs * L, L);
+    const double nb2 = reduce_partials(bb + (size_t)rhs * L, L);
+    const double rho = P.use_prec ? reduce_partials(B.rz + (size_t)rhs * B.nrz, B.nrz) : rr;
+    if (threadIdx.x == 0) {
+        CgState o;
+        o.normb = sqrt(nb2);
+        o.eps0 = sqrt(rr) / o.normb;
+        o.eps = o.eps0;
+        o.rho = rho;
+        o.kmin = 0.0;
+        o.seq = 0; o.iters = 0; o.done = 0; o.pad = 0;
+        B.state[2 * rhs] = o;
+        o.seq = -1;
+        B.state[2 * rhs + 1] = o;
+        if (P.record_hist) B.hist[(size_t)rhs * P.hist_stride] = o.eps0;
+    }
+}
+
+// true residual |A x - b| / |b| (Models.jl:94-97,150-154): partials of |Ax-b|^2 and |b|^2
+__global__ void __launch_bounds__(WAVE) k_resid_part(const double *__restrict__ Ax, const double *__restrict__ b,
+                                                     double *pa, double *pb, int N, int L) {
+    const int t = blockIdx.x, rhs = blockIdx.y;
+    const size_t ndim = (size_t)N * L;
+    double a = 0.0, c = 0.0;
+    for (int s = threadIdx.x; s < N; s += WAVE) {
+        const size_t i = (size_t)rhs * ndim + (size_t)t * N + s;
+        const double d = Ax[i] - b[i];
+        a += d * d;
+        c += b[i] * b[i];
+    }
+    a = wave_sum(a);
+    c = wave_sum(c);
+    if (threadIdx.x == 0) {
+        pa[(size_t)rhs * L + t] = a;
+        pb[(size_t)rhs * L + t] = c;
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_resid_final(const double *pa, const double *pb, double *out, int L) {
+    const int rhs = blockIdx.x;
+    const double a = reduce_partials(pa + (size_t)rhs * L, L);
+    const double c = reduce_partials(pb + (size_t)rhs * L, L);
+    if (threadIdx.x == 0) out[rhs] = sqrt(a) / sqrt(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// tau-axis transforms (TimeFreqFFTs.jl:55-73,112-130; FourierAcceleration.jl:91-143)
+//
+// Lengths are tiny (L = 40..160) and every site column is independent, so the transform is
+// evaluated as a direct twisted real DFT with wave-uniform twiddles:
+//   nu[k][s]  = sum_t exp(-i pi t (2k+1)/L) v[t][s]          (= FFT_t(Theta .* v)[k])
+// Real input => nu[L-1-k] = conj(nu[k]); only k < ceil(L/2) is produced, which is exactly the
+// half the KPM loop visits (KPMPreconditioners.jl:449-467).  Lane = site (coalesced), the twiddle
+// index depends only on (block, loop counter) => the compiler keeps it in SGPRs / scalar loads.
+// tw2[m] = exp(-i pi m / L), m in [0, 2L).
+// ------------------------------------------------------------------------------------------
+
+template <int KPT>
+__global__ void __launch_bounds__(WAVE) k_dft_fwd_twisted(double2 *__restrict__ nu, const double *__restrict__ v,
+                                                          const double2 *__restrict__ tw2, int N, int L, int Lo2,
+                                                          const CgState *state) {
+    const int rhs = blockIdx.z;
+    if (state && newest_state(state + 2 * rhs)->done) return;
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int k0 = blockIdx.y * KPT;
+    const double *vv = v + (size_t)rhs * N * L;
+    double2 acc[KPT];
+    int m[KPT];
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk) { acc[kk] = make_double2(0.0, 0.0); m[kk] = 0; }
+    const int twoL = 2 * L;
+    for (int t = 0; t < L; ++t) {
+        const double x = (s < N) ? vv[(size_t)t * N + s] : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk) {
+            const double2 w = tw2[m[kk]];
+            acc[kk].x += x * w.x;
+            acc[kk].y += x * w.y;
+            m[kk] += 2 * (k0 + kk) + 1;
+            if (m[kk] >= twoL) m[kk] -= twoL;
+        }
+    }
+    if (s < N) {
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk)
+            if (k0 + kk < Lo2) nu[((size_t)rhs * Lo2 + (k0 + kk)) * N + s] = acc[kk];
+    }
+}
+
+// v[t][s] = Re( conj(Theta_t) * (1/L) sum_k exp(+2 pi i k t/L) nu[k][s] ) using the conjugate symmetry:
+//         = (1/L) sum_{k<Lo2} wgt_k Re( exp(+i pi t (2k+1)/L) nu[k][s] ),  wgt = 2 (1 for the odd-L middle k)
+// Optionally fused: partial r.z for the CG (IterativeSolvers.jl:225).
+template <int TPT>
+__global__ void __launch_bounds__(WAVE) k_dft_inv_twisted(double *__restrict__ out, const double2 *__restrict__ nu,
+                                                          const double2 *__restrict__ tw2, int N, int L, int Lo2,
+                                                          const CgState *state, const double *__restrict__ rvec,
+                                                          double *__restrict__ rz_part, int nrz) {
+    const int rhs = blockIdx.z;
+    if (state && newest_state(state + 2 * rhs)->done) return;
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int t0 = blockIdx.y * TPT;
+    const double2 *nn = nu + (size_t)rhs * Lo2 * N;
+    double acc[TPT];
+    int m[TPT];
+    const int twoL = 2 * L;
+#pragma unroll
+    for (int tt = 0; tt < TPT; ++tt) { acc[tt] = 0.0; m[tt] = (t0 + tt) % twoL; }
+    const bool odd = (L & 1);
+    for (int k = 0; k < Lo2; ++k) {
+        const double2 x = (s < N) ? nn[(size_t)k * N + s] : make_double2(0.0, 0.0);
+        const double wgt = (odd && k == Lo2 - 1) ? 1.0 : 2.0;
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            const double2 w = tw2[m[tt]];          // exp(-i a): cos a = w.x, sin a = -w.y
+            acc[tt] += wgt * (w.x * x.x + w.y * x.y);
+            m[tt] += 2 * (t0 + tt);
+            if (m[tt] >= twoL) m[tt] -= twoL;
+            if (m[tt] >= twoL) m[tt] -= twoL;
+        }
+    }
+    const double invL = 1.0 / (double)L;
+    double dot = 0.0;
+#pragma unroll
+    for (int tt = 0; tt < TPT; ++tt) {
+        const int t = t0 + tt;
+        if (s < N && t < L) {
+            const double val = acc[tt] * invL;
+            const size_t i = (size_t)rhs * N * L + (size_t)t * N + s;
+            out[i] = val;
+            if (rz_part) dot += rvec[i] * val;
+        }
+    }
+    if (rz_part) {
+        dot = wave_sum(dot);
+        if (threadIdx.x == 0) rz_part[(size_t)rhs * nrz + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = dot;
+    }
+}
+
+// plain (untwisted) real DFT pair with a diagonal in between: fourier_accelerate!,
+// FourierAcceleration.jl:91-143:  out = Re iFFT( diag^power .* FFT(in) ).
+// Stage 1: u[k][s] = diag[k][s]^power * sum_t exp(-2 pi i k t/L) in[t][s]    for k <= L/2
+// Stage 2: out[t][s] = (1/L) sum_k wgt_k Re( exp(+2 pi i k t/L) u[k][s] )    (Hermitian symmetry;
+//          diag is symmetric under k -> L-k for M (k' = min(k,L-k)) and Q (cos), so the product
+//          keeps the symmetry of a real signal's spectrum).
+// tw1[m] = exp(-2 pi i m / L), m in [0, L).
+template <int KPT>
+__global__ void __launch_bounds__(WAVE) k_dft_fwd_plain(double2 *__restrict__ u, const double *__restrict__ v,
+                                                        const double *__restrict__ diag, double power,
+                                                        const double2 *__restrict__ tw1, int N, int L, int Lh) {
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int k0 = blockIdx.y * KPT;
+    double2 acc[KPT];
+    int m[KPT];
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk) { acc[kk] = make_double2(0.0, 0.0); m[kk] = 0; }
+    for (int t = 0; t < L; ++t) {
+        const double x = (s < N) ? v[(size_t)t * N + s] : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk) {
+            const double2 w = tw1[m[kk]];
+            acc[kk].x += x * w.x;
+            acc[kk].y += x * w.y;
+            m[kk] += (k0 + kk) % L;
+            if (m[kk] >= L) m[kk] -= L;
+        }
+    }
+    if (s < N) {
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk) {
+            const int k = k0 + kk;
+            if (k < Lh) {
+                // Re iFFT(D .* FFT(v)) of a real v only sees the symmetric part of D:
+                // mirror terms k and L-k combine to (D[k]+D[L-k])/2 * 2 Re(...)
+                const int km = (k == 0) ? 0 : L - k;
+                const double f = 0.5 * (pow(diag[(size_t)k * N + s], power) + pow(diag[(size_t)km * N + s], power));
+                u[(size_t)k * N + s] = make_double2(acc[kk].x * f, acc[kk].y * f);
+            }
+        }
+    }
+}
+
+template <int TPT>
+__global__ void __launch_bounds__(WAVE) k_dft_inv_plain(double *__restrict__ out, const double2 *__restrict__ u,
+                                                        const double2 *__restrict__ tw1, int N, int L, int Lh) {
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int t0 = blockIdx.y * TPT;
+    double acc[TPT];
+    int m[TPT];
+#pragma unroll
+    for (int tt = 0; tt < TPT; ++tt) { acc[tt] = 0.0; m[tt] = 0; }
+    for (int k = 0; k < Lh; ++k) {
+        const double2 x = (s < N) ? u[(size_t)k * N + s] : make_double2(0.0, 0.0);
+        // k = 0 and (even L) k = L/2 are their own mirror images
+        const double wgt = (k == 0 || 2 * k == L) ? 1.0 : 2.0;
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            const double2 w = tw1[m[tt]];
+            acc[tt] += wgt * (w.x * x.x + w.y * x.y);
+            m[tt] += (t0 + tt) % L;
+            if (m[tt] >= L) m[tt] -= L;
+        }
+    }
+    const double invL = 1.0 / (double)L;
+#pragma unroll
+    for (int tt = 0; tt < TPT; ++tt) {
+        const int t = t0 + tt;
+        if (s < N && t < L) out[(size_t)t * N + s] = acc[tt] * invL;
+    }
+}
+
+// full complex half-spectrum -> full spectrum expansion for the tau_to_omega API (complex output, layout S)
+__global__ void k_expand_spectrum(double2 *__restrict__ full, const double2 *__restrict__ half, int N, int L, int Lo2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * L) return;
+    const int k = (int)(i / N), s = (int)(i % N);
+    double2 vv;
+    if (k < Lo2) vv = half[(size_t)k * N + s];
+    else {
+        vv = half[(size_t)(L - 1 - k) * N + s];
+        vv.y = -vv.y;
+    }
+    full[i] = vv;
+}
+
+// generic complex inverse twisted transform for omega_to_tau on arbitrary (non-symmetric) spectra:
+// out[t][s] = Re( conj(Theta_t) (1/L) sum_k exp(2 pi i k t / L) nu[k][s] )
+__global__ void __launch_bounds__(WAVE) k_dft_inv_twisted_full(double *__restrict__ out, const double2 *__restrict__ nu,
+                                                               const double2 *__restrict__ tw2, int N, int L) {
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int t = blockIdx.y;
+    const int twoL = 2 * L;
+    double acc = 0.0;
+    int m = t % twoL;
+    for (int k = 0; k < L; ++k) {
+        const double2 x = (s < N) ? nu[(size_t)k * N + s] : make_double2(0.0, 0.0);
+        const double2 w = tw2[m];
+        acc += w.x * x.x + w.y * x.y;
+        m += 2 * t;
+        if (m >= twoL) m -= twoL;
+        if (m >= twoL) m -= twoL;
+    }
+    if (s < N) out[(size_t)t * N + s] = acc / (double)L;
+}
+
+// ------------------------------------------------------------------------------------------
+// KPM preconditioner, per-omega Chebyshev recursion (KPMPreconditioners.jl:606-693,758-778)
+// One wave per frequency block; u_{n-1}, u_n and the accumulator live in registers, the
+// checkerboard exchange goes through a complex LDS slab.  Blocks are scheduled longest-order first.
+// ------------------------------------------------------------------------------------------
+
+template <int NPL, bool TRANSPOSED>
+__device__ __forceinline__ void kpm_mulAprime(double2 (&out)[NPL], const double2 (&un)[NPL], double2 *buf,
+                                              const double (&eb)[NPL], double a, double b, const KpmDev &K,
+                                              const ModelDev &m) {
+    const int N = m.N;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) buf[s] = TRANSPOSED ? un[q] : make_double2(eb[q] * un[q].x, eb[q] * un[q].y);
+    }
+    __syncthreads();
+    cb_sweep_z<TRANSPOSED>(buf, K.cbar, K.sbar, m);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            double2 av = buf[s];
+            if (TRANSPOSED) { av.x *= eb[q]; av.y *= eb[q]; }
+            out[q] = make_double2(a * av.x - b * un[q].x, a * av.y - b * un[q].y);   // :685-693
+        }
+    }
+    __syncthreads();
+}
+
+template <int NPL, bool TRANSPOSED, bool CONJ>
+__device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&vin)[NPL], double2 *buf,
+                                           const double (&eb)[NPL], const double2 *c, int order, const KpmDev &K,
+                                           const ModelDev &m) {
+    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+    double2 um1[NPL], un[NPL], up1[NPL];
+    {
+        double2 c0 = c[0];
+        if (CONJ) c0.y = -c0.y;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            acc[q] = make_double2(c0.x * vin[q].x - c0.y * vin[q].y, c0.x * vin[q].y + c0.y * vin[q].x);
+            un[q] = vin[q];
+            um1[q] = make_double2(0.0, 0.0);
+        }
+    }
+    if (order > 1) {
+        kpm_mulAprime<NPL, TRANSPOSED>(up1, un, buf, eb, a, b, K, m);
+        for (int n = 2;; ++n) {
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) { um1[q] = un[q]; un[q] = up1[q]; }
+            double2 cn = c[n - 1];
+            if (CONJ) cn.y = -cn.y;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                acc[q].x += cn.x * un[q].x - cn.y * un[q].y;
+                acc[q].y += cn.x * un[q].y + cn.y * un[q].x;
+            }
+            if (n == order) break;
+            kpm_mulAprime<NPL, TRANSPOSED>(up1, un, buf, eb, a, b, K, m);
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                up1[q].x = 2.0 * up1[q].x - um1[q].x;
+                up1[q].y = 2.0 * up1[q].y - um1[q].y;
+            }
+        }
+    }
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(WAVE) k_kpm_cheb(double2 *__restrict__ nu, KpmDev K, ModelDev m, int Lo2,
+                                                   const CgState *state) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double2 *buf = reinterpret_cast<double2 *>(lds);
+    const int rhs = blockIdx.y;
+    if (state && newest_state(state + 2 * rhs)->done) return;
+    const int w = K.wsched[blockIdx.x];
+    const int N = m.N;
+    const int order = K.order[w];
+    const double2 *c = K.coeff + K.coff[w];
+    double2 *u = nu + ((size_t)rhs * Lo2 + w) * N;
+    double2 vin[NPL], mid[NPL], res[NPL];
+    double eb[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        vin[q] = (s < N) ? u[s] : make_double2(0.0, 0.0);
+        eb[q] = (s < N) ? K.Ebar[s] : 0.0;
+    }
+    kpm_series<NPL, true, true>(mid, vin, buf, eb, c, order, K, m);     // M^-T[w,w], conj coefficients (:621-648)
+    kpm_series<NPL, false, false>(res, mid, buf, eb, c, order, K, m);   // M^-1[w,w]                     (:650-677)
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) u[s] = res[q];
+    }
+}
+
+// Ebar[i] = mean_tau E[tau][i]  (update_A!, KPMPreconditioners.jl:332-349)
+__global__ void k_ebar(double *__restrict__ Ebar, const double *__restrict__ E, int N, int L) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    double a = 0.0;
+    for (int t = 0; t < L; ++t) a += E[(size_t)t * N + s];
+    Ebar[s] = a / (double)L;
+}
+
+__global__ void k_copy(double *__restrict__ dst, const double *__restrict__ src, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// partial r.z when the preconditioner is inactive (identity copy, KPMPreconditioners.jl:475-478)
+__global__ void __launch_bounds__(WAVE) k_copy_dot(double *__restrict__ zp, const double *__restrict__ r,
+                                                   double *__restrict__ rz_part, int nrz, int N, int L,
+                                                   const CgState *state) {
+    const int t = blockIdx.x, rhs = blockIdx.y;
+    if (state && newest_state(state + 2 * rhs)->done) return;
+    double a = 0.0;
+    for (int s = threadIdx.x; s < N; s += WAVE) {
+        const size_t i = (size_t)rhs * N * L + (size_t)t * N + s;
+        const double v = r[i];
+        zp[i] = v;
+        a += v * v;
+    }
+    a = wave_sum(a);
+    if (threadIdx.x == 0) {
+        // spread over the nrz slots: slot t gets the slice sum, the rest stay zero
+        rz_part[(size_t)rhs * nrz + t] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+
+ModelDev elph_model_dev(const elph_handle_s *h) {
+    ModelDev m;
+    m.N = (int)h->N; m.L = (int)h->L; m.nb = (int)h->nb; m.ncol = h->ncol;
+    m.cs_tau_stride = (h->kind == ELPH_MODEL_SSH) ? (int)h->nb : 0;
+    m.E_tau_stride = (h->kind == ELPH_MODEL_SSH) ? 0 : (int)h->N;
+    m.bi = h->d_bi; m.bj = h->d_bj; m.coloff = h->d_coloff;
+    m.c = h->d_c; m.s = h->d_s; m.E = h->d_E;
+    return m;
+}
+
+KpmDev elph_kpm_dev(const elph_handle_s *h) {
+    KpmDev K;
+    K.active = h->kpm_active;
+    K.Lo2 = (int)((h->L + 1) / 2);
+    K.lam_avg = h->lam_avg; K.lam_mag = h->lam_mag;
+    K.Ebar = h->d_Ebar; K.cbar = h->d_cbar; K.sbar = h->d_sbar;
+    K.order = h->d_order; K.coff = h->d_coff; K.coeff = h->d_coeff; K.wsched = h->d_wsched;
+    return K;
+}
+
+#define DISPATCH_NPL(npl, CALL)                                   \
+    switch (npl) {                                                \
+        case 1: { constexpr int NPL = 1; CALL; } break;           \
+        case 2: { constexpr int NPL = 2; CALL; } break;           \
+        case 3: { constexpr int NPL = 3; CALL; } break;           \
+        case 4: { constexpr int NPL = 4; CALL; } break;           \
+        case 5: { constexpr int NPL = 5; CALL; } break;           \
+        case 6: { constexpr int NPL = 6; CALL; } break;           \
+        case 7: { constexpr int NPL = 7; CALL; } break;           \
+        default: { constexpr int NPL = 8; CALL; } break;          \
+    }
+
+static int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        elph_set_error("launch %s failed: %s", what, hipGetErrorString(e));
+        return ELPH_E_HIP;
+    }
+    return ELPH_OK;
+}
+
+int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec) {
+    // in: rows = N sites, cols = L
+    dim3 grid((unsigned)((h->L + 31) / 32), (unsigned)((h->N + 31) / 32), (unsigned)nvec);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, h->stream, dstS, srcR, (int)h->N, (int)h->L);
+    return check_launch("k_transpose(r2s)");
+}
+
+int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec) {
+    // in: rows = L, cols = N
+    dim3 grid((unsigned)((h->N + 31) / 32), (unsigned)((h->L + 31) / 32), (unsigned)nvec);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, h->stream, dstR, srcS, (int)h->L, (int)h->N);
+    return check_launch("k_transpose(s2r)");
+}
+
+int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau) {
+    dim3 grid((unsigned)((h->L + 31) / 32), (unsigned)((h->N + 31) / 32), 1);
+    hipLaunchKernelGGL(k_expV, grid, dim3(32, 8), 0, h->stream, h->d_E, xR, h->d_lam, (int)h->N, (int)h->L, dtau);
+    return check_launch("k_expV");
+}
+
+int elph_launch_zero(elph_handle_s *h, double *p, int64_t n) {
+    if (n <= 0) return ELPH_OK;
+    hipLaunchKernelGGL(k_zero, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p, (long long)n);
+    return check_launch("k_zero");
+}
+
+int elph_launch_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec) {
+    ModelDev m = elph_model_dev(h);
+    dim3 grid((unsigned)h->L, (unsigned)nvec, 1);
+    const size_t shm = 2 * (size_t)h->N * sizeof(double);
+    DISPATCH_NPL(h->npl, {
+        if (which == 0) hipLaunchKernelGGL((k_mul<NPL, 0>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+        else if (which == 1) hipLaunchKernelGGL((k_mul<NPL, 1>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+        else hipLaunchKernelGGL((k_mul<NPL, 2>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+    });
+    return check_launch("k_mul");
+}
+
+static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
+    CgBufs B;
+    const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)(h->npl);  // partial stride per array
+    B.x = h->d_x; B.r = h->d_r; B.z = h->d_z; B.zp = h->d_zp; B.p = h->d_p;
+    B.pap = h->d_part; B.rr = h->d_part + P; B.rz = h->d_part + 2 * P;
+    B.state = h->d_state; B.params = h->d_params; B.hist = h->d_hist;
+    B.nrz = (int)(h->L * h->npl);
+    B.nrhs = nrhs;
+    return B;
+}
+
+int elph_launch_ebar(elph_handle_s *h) {
+    hipLaunchKernelGGL(k_ebar, dim3((unsigned)((h->N + 63) / 64)), dim3(64), 0, h->stream, h->d_Ebar, h->d_E,
+                       (int)h->N, (int)h->L);
+    return check_launch("k_ebar");
+}
+
+// z = P^-1 r on layout-S vectors.  cg_mode: 0 standalone; 1 inside CG (skip when done, fuse r.z partials)
+int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode) {
+    const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+    CgBufs B = make_bufs(h, nrhs);
+    const CgState *st = cg_mode ? h->d_state : nullptr;
+    if (!h->kpm_active) {
+        if (cg_mode) {
+            HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
+            hipLaunchKernelGGL(k_copy_dot, dim3((unsigned)L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, zS, rS, B.rz,
+                               B.nrz, N, L, st);
+        } else {
+            const long long n = (long long)nrhs * N * L;
+            hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, zS, rS, n);
+        }
+        return check_launch("kpm identity");
+    }
+    KpmDev K = elph_kpm_dev(h);
+    ModelDev m = elph_model_dev(h);
+    const int nst = (N + WAVE - 1) / WAVE;
+    constexpr int KPT = 2, TPT = 2;
+    hipLaunchKernelGGL((k_dft_fwd_twisted<KPT>), dim3((unsigned)nst, (unsigned)((Lo2 + KPT - 1) / KPT), (unsigned)nrhs),
+                       dim3(WAVE), 0, h->stream, h->d_nu, rS, h->d_theta /* tw2 */, N, L, Lo2, st);
+    const size_t shm = (size_t)N * sizeof(double2);
+    DISPATCH_NPL(h->npl, {
+        hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(WAVE), shm, h->stream, h->d_nu,
+                           K, m, Lo2, st);
+    });
+    // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz
+    if (cg_mode) HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
+    hipLaunchKernelGGL((k_dft_inv_twisted<TPT>), dim3((unsigned)nst, (unsigned)((L + TPT - 1) / TPT), (unsigned)nrhs),
+                       dim3(WAVE), 0, h->stream, zS, h->d_nu, h->d_theta, N, L, Lo2, st, cg_mode ? rS : nullptr,
+                       cg_mode ? B.rz : nullptr, B.nrz);
+    return check_launch("kpm apply");
+}
+
+int elph_launch_rz_partials(elph_handle_s *h, int nrhs);
+
+int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec) {
+    // expects d_b (layout S), d_x = initial guess; computes r0, p0 and seeds the state
+    CgBufs B = make_bufs(h, nrhs);
+    const int N = (int)h->N, L = (int)h->L;
+    int rc = elph_launch_mul(h, 2, h->d_tmp, h->d_x, nrhs);
+    if (rc) return rc;
+    const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
+    double *bb = h->d_part + 3 * P;
+    hipLaunchKernelGGL(k_cg_init, dim3((unsigned)L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, B, h->d_b, h->d_tmp, bb, N, L);
+    rc = check_launch("k_cg_init");
+    if (rc) return rc;
+    if (use_prec) {
+        // z0 = P^-1 r0, p0 = z0, rho0 = r0.z0 (IterativeSolvers.jl:182-189); once per solve
+        rc = elph_launch_kpm_apply(h, h->d_zp, h->d_r, nrhs, 0);
+        if (rc) return rc;
+        rc = elph_launch_rz_partials(h, nrhs);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_cg_init_prec, dim3((unsigned)L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, B, N, L);
+        rc = check_launch("k_cg_init_prec");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_cg_state0, dim3((unsigned)nrhs), dim3(WAVE), 0, h->stream, B, bb, L);
+    return check_launch("k_cg_state0");
+}
+
+// partial r.zp into B.rz (slot t = slice sum, rest zero)
+__global__ void __launch_bounds__(WAVE) k_rz_part(const double *__restrict__ r, const double *__restrict__ zp,
+                                                  double *__restrict__ rz_part, int nrz, int N, int L) {
+    const int t = blockIdx.x, rhs = blockIdx.y;
+    double a = 0.0;
+    for (int s = threadIdx.x; s < N; s += WAVE) {
+        const size_t i = (size_t)rhs * N * L + (size_t)t * N + s;
+        a += r[i] * zp[i];
+    }
+    a = wave_sum(a);
+    if (threadIdx.x == 0) rz_part[(size_t)rhs * nrz + t] = a;
+}
+
+int elph_launch_rz_partials(elph_handle_s *h, int nrhs) {
+    CgBufs B = make_bufs(h, nrhs);
+    HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
+    hipLaunchKernelGGL(k_rz_part, dim3((unsigned)h->L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, h->d_r, h->d_zp, B.rz,
+                       B.nrz, (int)h->N, (int)h->L);
+    return check_launch("k_rz_part");
+}
+
+// one CG iteration's kernels (graph-capturable: no syncs, no allocations, launch-invariant arguments)
+int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
+    CgBufs B = make_bufs(h, nrhs);
+    ModelDev m = elph_model_dev(h);
+    const int N = (int)h->N, L = (int)h->L;
+    dim3 grid((unsigned)L, (unsigned)nrhs, 1);
+    const size_t shm = 2 * (size_t)N * sizeof(double);
+    DISPATCH_NPL(h->npl, {
+        hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3(WAVE), shm, h->stream, B, m);
+        hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3(WAVE), 0, h->stream, B, N, L);
+    });
+    int rc = check_launch("cg iteration");
+    if (rc) return rc;
+    if (use_prec) rc = elph_launch_kpm_apply(h, h->d_zp, h->d_r, nrhs, 1);
+    return rc;
+}
+
+// true residual of d_x against d_b -> d_scal[rhs]
+int elph_launch_residual(elph_handle_s *h, int nrhs) {
+    int rc = elph_launch_mul(h, 2, h->d_tmp, h->d_x, nrhs);
+    if (rc) return rc;
+    const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
+    double *pa = h->d_part, *pb = h->d_part + P;
+    hipLaunchKernelGGL(k_resid_part, dim3((unsigned)h->L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, h->d_tmp, h->d_b, pa,
+                       pb, (int)h->N, (int)h->L);
+    hipLaunchKernelGGL(k_resid_final, dim3((unsigned)nrhs), dim3(WAVE), 0, h->stream, pa, pb, h->d_scal, (int)h->L);
+    return check_launch("residual");
+}
+
+int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS_full, const double *vS) {
+    const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+    const int nst = (N + WAVE - 1) / WAVE;
+    constexpr int KPT = 2;
+    hipLaunchKernelGGL((k_dft_fwd_twisted<KPT>), dim3((unsigned)nst, (unsigned)((Lo2 + KPT - 1) / KPT), 1), dim3(WAVE), 0,
+                       h->stream, h->d_nu, vS, h->d_theta, N, L, Lo2, (const CgState *)nullptr);
+    const long long n = (long long)N * L;
+    hipLaunchKernelGGL(k_expand_spectrum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, nuS_full, h->d_nu, N,
+                       L, Lo2);
+    return check_launch("tau_to_omega");
+}
+
+int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS_full) {
+    const int N = (int)h->N, L = (int)h->L;
+    const int nst = (N + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(k_dft_inv_twisted_full, dim3((unsigned)nst, (unsigned)L, 1), dim3(WAVE), 0, h->stream, vS, nuS_full,
+                       h->d_theta, N, L);
+    return check_launch("omega_to_tau");
+}
+
+int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power,
+                          int64_t ncol) {
+    const int N = (int)ncol, L = (int)h->L, Lh = L / 2 + 1;
+    const int nst = (N + WAVE - 1) / WAVE;
+    constexpr int KPT = 2, TPT = 2;
+    double2 *u = h->d_nu;   // capacity checked by the caller
+    hipLaunchKernelGGL((k_dft_fwd_plain<KPT>), dim3((unsigned)nst, (unsigned)((Lh + KPT - 1) / KPT), 1), dim3(WAVE), 0,
+                       h->stream, u, inS, diagS, power, h->d_tw, N, L, Lh);
+    hipLaunchKernelGGL((k_dft_inv_plain<TPT>), dim3((unsigned)nst, (unsigned)((L + TPT - 1) / TPT), 1), dim3(WAVE), 0,
+                       h->stream, outS, u, h->d_tw, N, L, Lh);
+    return check_launch("fourier_accelerate");
+}

@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's model / operator API for the hot path.
+
+The reference exposes the fermion matrix through Julia multiple dispatch on the model type
+(Models.jl:65-248, HolsteinModels.jl, SSHModels.jl, IterativeSolvers.jl:36-57).  These classes keep the
+same field names, argument order (output first, in place) and return conventions, and forward every
+operation to libelphgpu.so through its C ABI (include/elph_gpu.h).  Julia's `f!` is spelled `f_` here.
+
+    update_model_(model)                         HolsteinModels.jl:526 / SSHModels.jl:510
+    mul_(y, model, v)                            Models.jl:192   (honours model.mul_by_M / .transposed)
+    mulM_(y, model, v), mulMt_(y, model, v)      HolsteinModels.jl:569,631 / SSHModels.jl:581,646
+    mulMtM_(y, model, v)                         Models.jl:215
+    ldiv_(x, model, b, P=None, maxiter=0)        Models.jl:74,139  -> (iters, residual_error, flag)
+    solve_(x, model, b, cg, P=None, ...)         IterativeSolvers.jl:153,239 -> iters
+    transpose_(model)                            Models.jl:244
+
+All vectors are numpy float64, flat, reference layout (tau fastest, Utilities.jl:12-15).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import lattice as _lat
+from ._lib import check, dptr, iptr
+
+HOLSTEIN, SSH = 0, 1
+
+
+class ConjugateGradient:
+    """IterativeSolvers.jl:36-57 (tol, maxiter, kmax); the work vectors live on the GPU."""
+
+    def __init__(self, ndim, tol=1e-4, maxiter=0, kmax=1e12):
+        self.tol = float(tol)
+        self.maxiter = int(maxiter) if maxiter >= 1 else int(ndim)
+        self.kmax = float(kmax)
+        self.N = int(ndim)
+
+
+class AbstractModel:
+    """Common part of HolsteinModel / SSHModel (Models.jl:65): owns the GPU handle."""
+
+    kind = None
+
+    def _create(self, cosht=None, sinht=None, device=0):
+        lib = _lib.load()
+        h = _lib.Handle()
+        tab = np.ascontiguousarray(self.neighbor_table, dtype=np.int64)
+        check(lib.elph_create(C.byref(h), self.kind, self.Nsites, self.Ltau, self.Nbonds,
+                              iptr(tab) if self.Nbonds > 0 else None,
+                              dptr(cosht) if cosht is not None and self.Nbonds > 0 else None,
+                              dptr(sinht) if sinht is not None and self.Nbonds > 0 else None, device))
+        self._h = h
+        self._lib = lib
+        self._push_solver()
+
+    def _push_solver(self):
+        check(self._lib.elph_solver_set(self._h, self.solver.tol, self.solver.maxiter, self.solver.kmax))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.elph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # Base.length / size (Models.jl:262-284)
+    def __len__(self):
+        return self.Ndim
+
+    @property
+    def shape(self):
+        return (self.Ndim, self.Ndim)
+
+
+class HolsteinModel(AbstractModel):
+    """HolsteinModels.jl:22-314.  Build with the same incremental calls as ProcessInputFile.jl:216-326:
+    assign_t_ per bond definition, assign_mu_/lambda_/..., then initialize_model_()."""
+
+    kind = HOLSTEIN
+
+    def __init__(self, lattice, beta, dtau, tol=1e-4, maxiter=10000, device=0):
+        self.lattice = lattice
+        self.beta, self.dtau = float(beta), float(dtau)
+        self.Ltau = _lat.ltau_from_beta(beta, dtau)                 # HolsteinModels.jl:205
+        self.Nsites = lattice.nsites
+        self.Nph = self.Nsites
+        self.Ndof = self.Nph * self.Ltau
+        self.Ndim = self.Ndof
+        self.Nbonds = 0
+        self.nbonds = 0
+        self.x = np.zeros(self.Ndof)
+        self.expnDtauV = None                                       # lives on the GPU (layout S)
+        self.t = np.zeros(0)
+        self.neighbor_table = np.zeros((0, 2), dtype=np.int64)
+        self.cosht = np.zeros(0)
+        self.sinht = np.zeros(0)
+        self.checkerboard_perm = np.zeros(0, dtype=np.int64)
+        self.omega = np.zeros(self.Nph)
+        self.omega4 = np.zeros(self.Nph)
+        self.lam = np.zeros(self.Nph)
+        self.lam2 = np.zeros(self.Nph)
+        self.mu = np.zeros(self.Nsites)
+        self.mul_by_M = False                                       # CG works on MtM (HolsteinModels.jl:268-276)
+        self.transposed = False
+        self.solver = ConjugateGradient(self.Ndim, tol=tol, maxiter=maxiter)
+        self._device = device
+        self._h = None
+
+    # -- incremental specification (HolsteinModels.jl:323-444), deterministic part (stddev = 0)
+    def assign_t_(self, t, o1, o2, v):
+        new = self.lattice.calc_neighbor_table(o1, o2, v)
+        self.neighbor_table = np.concatenate([self.neighbor_table, new], axis=0)
+        self.t = np.concatenate([self.t, np.full(new.shape[0], float(t))])
+        self.nbonds += 1
+
+    def _assign(self, arr, val, orbit):
+        if orbit == 0:
+            arr[:] = val
+        else:
+            arr[orbit - 1::self.lattice.norbits] = val
+
+    def assign_mu_(self, val, orbit=0):
+        self._assign(self.mu, val, orbit)
+
+    def assign_lambda_(self, val, orbit=0):
+        self._assign(self.lam, val, orbit)
+
+    def assign_lambda2_(self, val, orbit=0):
+        self._assign(self.lam2, val, orbit)
+
+    def assign_omega_(self, val, orbit=0):
+        self._assign(self.omega, val, orbit)
+
+    def initialize_model_(self):
+        """HolsteinModels.jl:484-517, then create the GPU-side model."""
+        if len(self.t) > 0:
+            self.Nbonds = len(self.t)
+            cb = _lat.initialize_checkerboard(self.neighbor_table, self.t, self.dtau)
+            self.neighbor_table = cb["table"]
+            self.cosht, self.sinht = cb["cosht"], cb["sinht"]
+            self.checkerboard_perm = cb["cb_perm"]
+            self.colours = cb["colours"]
+        self._create(self.cosht, self.sinht, self._device)
+
+
+class SSHModel(AbstractModel):
+    """SSHModels.jl:79-314 reduced to what the path needs: bonds with optional bond phonons."""
+
+    kind = SSH
+
+    def __init__(self, lattice, beta, dtau, tol=1e-4, maxiter=10000, device=0):
+        self.lattice = lattice
+        self.beta, self.dtau = float(beta), float(dtau)
+        self.Ltau = _lat.ltau_from_beta(beta, dtau)
+        self.Nsites = lattice.nsites
+        self.Ndim = self.Nsites * self.Ltau
+        self.bond_definitions = []
+        self.mu = np.zeros(self.Nsites)
+        self.mul_by_M = False
+        self.transposed = False
+        self.solver = ConjugateGradient(self.Ndim, tol=tol, maxiter=maxiter)
+        self._device = device
+        self._h = None
+
+    def assign_hopping_(self, t, alpha, alpha2, omega, o1, o2, v, has_phonon=True):
+        self.bond_definitions.append(dict(t=float(t), alpha=float(alpha), alpha2=float(alpha2), omega=float(omega),
+                                          o1=o1, o2=o2, v=tuple(v), has_phonon=bool(has_phonon)))
+
+    def initialize_model_(self):
+        """SSHModels.jl:348-505 (deterministic part)."""
+        tabs, t, alpha, alpha2, omega, ph2b = [], [], [], [], [], []
+        nb_so_far = 0
+        for d in self.bond_definitions:
+            new = self.lattice.calc_neighbor_table(d["o1"], d["o2"], d["v"])
+            n = new.shape[0]
+            tabs.append(new)
+            t += [d["t"]] * n
+            if d["has_phonon"]:
+                alpha += [d["alpha"]] * n
+                alpha2 += [d["alpha2"]] * n
+                omega += [d["omega"]] * n
+                ph2b += list(range(nb_so_far + 1, nb_so_far + n + 1))      # 1-based bond of each phonon (:413)
+            nb_so_far += n
+        raw = np.concatenate(tabs, axis=0) if tabs else np.zeros((0, 2), dtype=np.int64)
+        cb = _lat.initialize_checkerboard(raw)
+        self.neighbor_table = cb["table"]
+        self.checkerboard_perm = cb["cb_perm"]
+        self.inv_checkerboard_perm = cb["inv_cb_perm"]
+        self.colours = cb["colours"]
+        self.Nbonds = raw.shape[0]
+        self.t = np.array(t)
+        self.alpha, self.alpha2, self.omega = np.array(alpha), np.array(alpha2), np.array(omega)
+        self.phonon_to_bond = np.array(ph2b, dtype=np.int64)
+        self.Nph = len(ph2b)
+        self.Ndof = self.Nph * self.Ltau
+        self.x = np.zeros(self.Ndof)
+        L, nb = self.Ltau, self.Nbonds
+        # cosht/sinht: Julia (Ltau x Nbonds) column-major == [bond][tau] here; bare values (:450-464)
+        self.cosht = np.zeros((nb, L))
+        self.sinht = np.zeros((nb, L))
+        for bond in range(nb):
+            idx = self.checkerboard_perm[bond] - 1
+            self.cosht[idx, :] = np.cosh(self.dtau * self.t[bond])
+            self.sinht[idx, :] = np.sinh(self.dtau * self.t[bond])
+        self.expDtauMu = np.exp(self.dtau * self.mu)
+        self._create(None, None, self._device)
+
+
+# ----------------------------------------------------------------------------------------------
+# update_model!
+# ----------------------------------------------------------------------------------------------
+
+def update_model_(model):
+    """HolsteinModels.jl:526-549 (exp on the GPU) / SSHModels.jl:510-562 (cosh/sinh gather on the host, upload)."""
+    if model.kind == HOLSTEIN:
+        check(model._lib.elph_update_model_holstein(model._h, dptr(np.ascontiguousarray(model.x)), dptr(model.lam),
+                                                    dptr(model.lam2), dptr(model.mu), model.dtau))
+    else:
+        model.expDtauMu = np.exp(model.dtau * model.mu)
+        X = model.x.reshape(model.Nph, model.Ltau)
+        v = model.alpha[:, None] * X + np.sign(X) * model.alpha2[:, None] * X ** 2
+        tp = model.t[model.phonon_to_bond - 1][:, None] - v
+        idx = model.checkerboard_perm[model.phonon_to_bond - 1] - 1
+        model.cosht[idx, :] = np.cosh(model.dtau * tp)
+        model.sinht[idx, :] = np.sinh(model.dtau * tp)
+        check(model._lib.elph_update_model_ssh(model._h, dptr(np.ascontiguousarray(model.cosht).reshape(-1)),
+                                               dptr(np.ascontiguousarray(model.sinht).reshape(-1)),
+                                               dptr(np.ascontiguousarray(model.expDtauMu))))
+
+
+# ----------------------------------------------------------------------------------------------
+# mul! family
+# ----------------------------------------------------------------------------------------------
+
+def _vec(a, n):
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.size == n, \
+        f"expected a contiguous float64 vector of length {n}"
+    return a
+
+
+def mulM_(y, model, v):
+    check(model._lib.elph_mulM(model._h, dptr(_vec(y, model.Ndim)), dptr(_vec(v, model.Ndim))))
+
+
+def mulMt_(y, model, v):
+    check(model._lib.elph_mulMT(model._h, dptr(_vec(y, model.Ndim)), dptr(_vec(v, model.Ndim))))
+
+
+def mulMtM_(y, model, v):
+    check(model._lib.elph_mulMTM(model._h, dptr(_vec(y, model.Ndim)), dptr(_vec(v, model.Ndim))))
+
+
+def mulMMt_(y, model, v):
+    """Models.jl:229-238 (two launches; not on the CG path, which always uses MtM)."""
+    tmp = np.empty_like(v)
+    mulMt_(tmp, model, v)
+    mulM_(y, model, tmp)
+
+
+def mul_(y, model, v):
+    """Models.jl:192-209."""
+    if model.mul_by_M:
+        (mulMt_ if model.transposed else mulM_)(y, model, v)
+    else:
+        (mulMMt_ if model.transposed else mulMtM_)(y, model, v)
+
+
+def transpose_(model):
+    """Models.jl:244-248."""
+    model.transposed = not model.transposed
+
+
+# ----------------------------------------------------------------------------------------------
+# solvers
+# ----------------------------------------------------------------------------------------------
+
+def _use_prec(P):
+    return 0 if P is None else 1
+
+
+def solve_(x, model, b, cg=None, P=None, maxiter=0, tol=0.0, kmax=0.0, history=False):
+    """solve!(x, A, b, cg[, P]; maxiter, tol, kmax) -> iters (IterativeSolvers.jl:153-234, 239-314).
+    With history=True also returns eps_0..eps_iters."""
+    cg = cg or model.solver
+    model._push_solver()
+    if P is not None:
+        assert P.model is model
+    mi = maxiter if maxiter else cg.maxiter
+    it = C.c_int64()
+    hist = np.full(mi + 1, np.nan) if history else None
+    check(model._lib.elph_cg_solve(model._h, dptr(_vec(x, model.Ndim)), dptr(_vec(b, model.Ndim)), tol or cg.tol, mi,
+                                   kmax or cg.kmax, _use_prec(P), C.byref(it), dptr(hist) if history else None))
+    if history:
+        return int(it.value), hist[:it.value + 1]
+    return int(it.value)
+
+
+def ldiv_(x, model, b, P=None, maxiter=0):
+    """ldiv!(x, model, b[, P]; maxiter) -> (iters, residual_error, flag)  (Models.jl:74-186)."""
+    assert not model.mul_by_M and not model.transposed, "the GPU path solves MtM x = b (CG), as the reference does"
+    model._push_solver()
+    it, fl, res = C.c_int64(), C.c_int(), C.c_double()
+    check(model._lib.elph_ldiv(model._h, dptr(_vec(x, model.Ndim)), dptr(_vec(b, model.Ndim)), _use_prec(P), maxiter,
+                               C.byref(it), C.byref(res), C.byref(fl)))
+    return int(it.value), float(res.value), int(fl.value)
+
+
+def ldiv_batched_(X, model, B, P=None, maxiter=0):
+    """nrhs independent solves of the same matrix advanced together; X, B: (nrhs, Ndim) arrays."""
+    model._push_solver()
+    nrhs = B.shape[0]
+    assert X.shape == B.shape == (nrhs, model.Ndim)
+    it = np.zeros(nrhs, dtype=np.int64)
+    res = np.zeros(nrhs)
+    fl = np.zeros(nrhs, dtype=np.int32)
+    check(model._lib.elph_ldiv_batched(model._h, nrhs, dptr(X), dptr(B), _use_prec(P), maxiter, iptr(it), dptr(res),
+                                       fl.ctypes.data_as(_lib.P_int)))
+    return it, res, fl

@@ -1,0 +1,187 @@
+/*
+ * elph_gpu.h — C ABI of libelphgpu.so, the MI355X (gfx950) fermion-force solver for ElPhDynamics.
+ *
+ * This is the drop-in boundary for the reference's operator API.  The reference has
+ * no FFI: its callers reach the path through Julia multiple dispatch on the model type
+ * (Models.jl / IterativeSolvers.jl / KPMPreconditioners.jl / FourierAcceleration.jl).  Each entry
+ * point below names the reference method it replaces (file:line under the reference's src/); the
+ * Julia-side binding (`ccall`) a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions across the boundary.
+ *   - Every function returns an int status: ELPH_OK (0) or a negative ELPH_E_* code.
+ *     Solver outcomes (iterations, residual, flag 0/1/2) are out-parameters, exactly the tuple
+ *     the reference's ldiv! returns (Models.jl:74,139) — non-convergence is NOT an error.
+ *   - Host entry points take host pointers in the REFERENCE layout: flat double[Nsites*Ltau],
+ *     tau fastest, idx = site*Ltau + tau (Utilities.jl:12-15); neighbour table int64[2*Nbonds],
+ *     column-major 2 x Nbonds, 1-based, already in checkerboard order (HolsteinModels.jl:484-517).
+ *     No host pointer is retained after return.
+ *   - `_dev` twins take device pointers in the same reference layout and run on the handle's stream.
+ *   - One handle = one model on one GPU; a handle is not reentrant (the reference's model is not
+ *     either: shared scratch v', v'', v''', Models.jl:218,94).
+ */
+#ifndef ELPH_GPU_H
+#define ELPH_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELPH_OK 0
+#define ELPH_E_ARG (-1)      /* bad argument / shape mismatch */
+#define ELPH_E_HIP (-2)      /* HIP runtime error (elph_last_error() has the text) */
+#define ELPH_E_STATE (-3)    /* call out of order (e.g. KPM apply before setup) */
+#define ELPH_E_NOGPU (-4)    /* no usable gfx950 device */
+#define ELPH_E_UNSUPPORTED (-5)
+
+#define ELPH_MODEL_HOLSTEIN 0
+#define ELPH_MODEL_SSH 1
+
+typedef struct elph_handle_s *elph_handle;
+
+/* Text of the last error on this thread (never NULL). */
+const char *elph_last_error(void);
+
+/* ABI version of the loaded library (for the Julia wrapper's sanity check). */
+int elph_abi_version(void);
+
+/* Number of visible HIP devices (0 if none); does not create a context. */
+int elph_device_count(void);
+
+/* ---------------------------------------------------------------- model life cycle */
+
+/* Replaces HolsteinModel / SSHModel construction + initialize_model!
+ * (HolsteinModels.jl:192-314,484-517; SSHModels.jl:348-505) for the fields the path uses.
+ *   kind            ELPH_MODEL_HOLSTEIN | ELPH_MODEL_SSH
+ *   nsites, ltau    Nsites, Ltau (Ndim = nsites*ltau)
+ *   nbonds          number of bonds (0 allowed: single-site deck, HolsteinModels.jl:486)
+ *   neighbor_table  int64[2*nbonds], 1-based, checkerboard order (model.neighbor_table)
+ *   cosht, sinht    Holstein: double[nbonds] (model.cosht/.sinht); may be NULL for SSH
+ *                   (SSH matrix elements arrive through elph_update_model_ssh)
+ *   device          HIP device ordinal
+ * The colour boundaries are recomputed from the table (maximal runs of site-disjoint bonds),
+ * which reproduces the reference's groups for any table produced by checkerboard_order!. */
+int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t ltau, int64_t nbonds,
+                const int64_t *neighbor_table, const double *cosht, const double *sinht, int device);
+
+/* Frees all device memory of the handle. */
+int elph_destroy(elph_handle h);
+
+/* Use an existing HIP stream (hipStream_t passed as void*; NULL = the handle's own stream). */
+int elph_set_stream(elph_handle h, void *hip_stream);
+
+/* Block until all work queued on the handle's stream has finished. */
+int elph_synchronize(elph_handle h);
+
+/* ---------------------------------------------------------------- update_model! */
+
+/* update_model!(holstein) — HolsteinModels.jl:526-549:
+ * expnDtauV[i,tau] = exp(-dtau*(lambda_i x + lambda2_i x^2 - mu_i)), computed on the device.
+ * x: double[nsites*ltau] (reference layout); lambda, lambda2, mu: double[nsites]. */
+int elph_update_model_holstein(elph_handle h, const double *x, const double *lambda,
+                               const double *lambda2, const double *mu, double dtau);
+
+/* Same, but hands over an already exponentiated model.expnDtauV (double[nsites*ltau]). */
+int elph_set_expV(elph_handle h, const double *expnDtauV);
+
+/* update_model!(ssh) matrix elements — SSHModels.jl:510-535 (computed by the caller):
+ * cosht, sinht: double[ltau*nbonds], Julia (Ltau x Nbonds) column-major (tau fastest),
+ * already in checkerboard column order; expDtauMu: double[nsites]. */
+int elph_update_model_ssh(elph_handle h, const double *cosht, const double *sinht,
+                          const double *expDtauMu);
+
+/* ---------------------------------------------------------------- mul! family */
+
+/* mulM!(y, model, v) — HolsteinModels.jl:569-626 / SSHModels.jl:581-640 */
+int elph_mulM(elph_handle h, double *y, const double *v);
+/* mulMᵀ!(y, model, v) — HolsteinModels.jl:631-684 / SSHModels.jl:646-701 */
+int elph_mulMT(elph_handle h, double *y, const double *v);
+/* mulMᵀM!(y, model, v) — Models.jl:215-224 (one fused kernel; no v' round trip) */
+int elph_mulMTM(elph_handle h, double *y, const double *v);
+/* device-pointer twins (reference layout, handle's stream, asynchronous) */
+int elph_mulM_dev(elph_handle h, double *y_dev, const double *v_dev);
+int elph_mulMT_dev(elph_handle h, double *y_dev, const double *v_dev);
+int elph_mulMTM_dev(elph_handle h, double *y_dev, const double *v_dev);
+
+/* ---------------------------------------------------------------- solver */
+
+/* ConjugateGradient fields — IterativeSolvers.jl:36-57 (model.solver.tol/.maxiter/.kmax). */
+int elph_solver_set(elph_handle h, double tol, int64_t maxiter, double kappa_max);
+
+/* solve!(x, model, b, cg[, P]; maxiter, tol, κmax) -> iters
+ * IterativeSolvers.jl:239-314 (use_precond=0) / :153-234 (use_precond=1, KPM must be set up).
+ * x is both the initial guess and the result (callers zero it: HMC.jl:854).
+ * tol/maxiter/kappa_max of 0 select the handle's solver defaults (as iszero() does there).
+ * eps_hist (optional, may be NULL): receives eps_0..eps_iters (needs maxiter+1 doubles). */
+int elph_cg_solve(elph_handle h, double *x, const double *b, double tol, int64_t maxiter,
+                  double kappa_max, int use_precond, int64_t *iters, double *eps_hist);
+
+/* ldiv!(x, model, b, P; maxiter=0) -> (iters, residual_error, flag) — Models.jl:74-137 (use_precond=1)
+ * and Models.jl:139-186 (use_precond=0): solve, true residual ‖Ax−b‖/‖b‖, flag 0/1/2 with x zeroed
+ * when flag>0, and the un-preconditioned retry with 10*maxiter. */
+int elph_ldiv(elph_handle h, double *x, const double *b, int use_precond, int64_t maxiter,
+              int64_t *iters, double *residual_error, int *flag);
+
+/* Batched ldiv!: nrhs independent right-hand sides of the same matrix advanced together
+ * (φ₊/φ₋ of calc_O⁻¹Λϕ!, HMC.jl:851-886; the nᵥ vectors of GreensFunctions.update!, :201-234).
+ * X, B: double[nrhs*ndim], RHS-major; iters/residual_error/flag: arrays of nrhs.
+ * Each RHS follows exactly the single-RHS recurrences and stop rule. */
+int elph_ldiv_batched(elph_handle h, int nrhs, double *X, const double *B, int use_precond,
+                      int64_t maxiter, int64_t *iters, double *residual_error, int *flag);
+
+/* device-pointer twins (reference layout) */
+int elph_ldiv_dev(elph_handle h, double *x_dev, const double *b_dev, int use_precond,
+                  int64_t maxiter, int64_t *iters, double *residual_error, int *flag);
+int elph_ldiv_batched_dev(elph_handle h, int nrhs, double *X_dev, const double *B_dev,
+                          int use_precond, int64_t maxiter, int64_t *iters,
+                          double *residual_error, int *flag);
+
+/* ---------------------------------------------------------------- KPM preconditioner */
+
+/* SymmetricKPMPreconditioner(model, n, buf, c1, c2) — KPMPreconditioners.jl:219-235, ctor :101-146 */
+int elph_kpm_create(elph_handle h, int n, double buf, double c1, double c2);
+
+/* KPMPreconditioners.setup!(P) — :259-321.  Averages expnDtauV over tau on the device
+ * (update_A!, :332-381), estimates the spectrum of A by Arnoldi (:845-942) and rebuilds the
+ * Chebyshev coefficients when the bounds moved by more than buf (:293-309).
+ *   b_max, b_min  the two random Arnoldi start vectors (double[nsites]); the reference draws
+ *                 them from model.rng (:859-861,902-904) — the caller supplies them.
+ *   e_min, e_max  if both finite, skip Arnoldi and use these eigenvalue bounds (parity runs);
+ *                 pass NaN to run Arnoldi.
+ * Out: active flag (P.expansion.active), and the bounds used. */
+int elph_kpm_setup(elph_handle h, const double *b_max, const double *b_min, double e_min,
+                   double e_max, int *active, double *lam_lo, double *lam_hi);
+
+/* Inspect the expansion: orders[cld(ltau,2)], total = sum(orders) (either pointer may be NULL). */
+int elph_kpm_orders(elph_handle h, int64_t *orders, int64_t *total);
+
+/* ldiv!(z, P, r) — KPMPreconditioners.jl:426-481 (identity copy when inactive, :475-478) */
+int elph_kpm_apply(elph_handle h, double *z, const double *r);
+int elph_kpm_apply_dev(elph_handle h, double *z_dev, const double *r_dev);
+
+/* ---------------------------------------------------------------- Fourier acceleration */
+
+/* fourier_accelerate!(v', fa, v, power; use_mass) — FourierAcceleration.jl:91-143, real in/out.
+ * diag: the accelerator's M (use_mass=true) or Q (false) vector, double[nph*ltau],
+ * frequency index fastest (update_M!/update_Q!, :149-167,176-266); nph = number of phonon
+ * columns (nsites for Holstein, Nph for SSH). */
+int elph_fourier_accelerate(elph_handle h, double *vout, const double *vin, const double *diag,
+                            double power, int64_t nph);
+
+/* τ_to_ω! / ω_to_τ! — TimeFreqFFTs.jl:55-73,112-130 (twisted FFT; complex interleaved re,im) */
+int elph_tau_to_omega(elph_handle h, double *nu_complex, const double *v);
+int elph_omega_to_tau(elph_handle h, double *v, const double *nu_complex);
+
+/* ---------------------------------------------------------------- measurement hooks (bench.py) */
+
+/* Timed repetition of one hot-path unit with inputs resident in HBM, bracketed by HIP events on
+ * the handle's stream.  what: 0 = MᵀM apply, 1 = one un-preconditioned CG iteration (fixed count,
+ * no early exit), 2 = KPM apply, 3 = one preconditioned CG iteration.  Returns average ms per rep. */
+int elph_time_unit(elph_handle h, int what, int nrhs, int reps, double *ms_per_rep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,423 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libelphgpu.so, against (i) the committed golden fixtures and (ii) the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star: 1e-10 relative on residuals / Green's-function elements):
+  * mat-vecs, preconditioner apply, FFTs: 1e-12 relative (observed ~1e-16) — only FMA contraction and
+    summation order differ from the oracle;
+  * CG: identical iteration count at the production tolerance (1e-5); eps history within 1e-10 relative
+    for the first 40 iterations (round-off then grows exponentially with the iteration index in ANY two
+    implementations that sum in different orders — SURVEY.md §7 "hard parts"); solution of a tol=1e-10..1e-12
+    solve within 1e-9 of the oracle / dense solve (Green's-function observable M^-1 R).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from elphdynamics_amd import _lib
+    L = _lib.load()
+    assert L.elph_device_count() >= 1, "no HIP device: the product has no CPU fallback"
+    return L
+
+
+class RawModel:
+    """Minimal driver of the raw C ABI (no Python mirror): what a Julia ccall wrapper would do."""
+
+    def __init__(self, lib, kind, N, L, table, c=None, s=None):
+        from elphdynamics_amd import _lib
+        self.lib, self.N, self.L, self.n = lib, N, L, N * L
+        self.h = _lib.Handle()
+        tab = np.ascontiguousarray(table, dtype=np.int64)
+        nb = tab.shape[0]
+        _lib.check(lib.elph_create(C.byref(self.h), kind, N, L, nb, _lib.iptr(tab) if nb else None,
+                                   _lib.dptr(np.ascontiguousarray(c)) if c is not None and nb else None,
+                                   _lib.dptr(np.ascontiguousarray(s)) if s is not None and nb else None, 0))
+
+    def close(self):
+        self.lib.elph_destroy(self.h)
+
+    def op(self, name, v):
+        from elphdynamics_amd import _lib
+        y = np.zeros(self.n)
+        _lib.check(getattr(self.lib, name)(self.h, _lib.dptr(y), _lib.dptr(np.ascontiguousarray(v))))
+        return y
+
+    def ldiv(self, b, tol, maxiter, use_prec=0, call_maxiter=0, x0=None):
+        from elphdynamics_amd import _lib
+        _lib.check(self.lib.elph_solver_set(self.h, tol, maxiter, 1e12))
+        x = np.zeros(self.n) if x0 is None else x0.copy()
+        it, fl, res = C.c_int64(), C.c_int(), C.c_double()
+        _lib.check(self.lib.elph_ldiv(self.h, _lib.dptr(x), _lib.dptr(np.ascontiguousarray(b)), use_prec, call_maxiter,
+                                      C.byref(it), C.byref(res), C.byref(fl)))
+        return x, it.value, res.value, fl.value
+
+
+# ------------------------------------------------------------------------------------------ golden fixtures
+
+@pytest.mark.parametrize("name", ["holstein_sq4_L8.npz", "holstein_hc3_L6.npz", "holstein_tri3_L5.npz",
+                                  "holstein_sq4_L40.npz"])
+def test_holstein_golden(lib, name):
+    from elphdynamics_amd import _lib
+    g = golden(name)
+    N, L = int(g["N"]), int(g["Ltau"])
+    m = RawModel(lib, 0, N, L, g["table"], g["cosht"], g["sinht"])
+    try:
+        # update_model! on the device vs the golden exp(-dtau V)
+        _lib.check(lib.elph_update_model_holstein(m.h, _lib.dptr(np.ascontiguousarray(g["x"])), _lib.dptr(g["lam"]),
+                                                  _lib.dptr(g["lam2"]), _lib.dptr(g["mu"]), float(g["dtau"])))
+        assert rel(m.op("elph_mulM", g["v"]), g["Mv"]) < 1e-13
+        assert rel(m.op("elph_mulMT", g["v"]), g["MTv"]) < 1e-13
+        assert rel(m.op("elph_mulMTM", g["v"]), g["MTMv"]) < 1e-13
+        # same through elph_set_expV (caller-supplied expnDtauV)
+        _lib.check(lib.elph_set_expV(m.h, _lib.dptr(np.ascontiguousarray(g["E"]))))
+        assert rel(m.op("elph_mulM", g["v"]), g["Mv"]) < 1e-13
+        x, it, res, flag = m.ldiv(g["b"], 1e-12, 5000)
+        assert flag == 0 and res < 1e-6
+        assert rel(x, g["xsol"]) < 1e-9 and rel(x, g["Minv_R"]) < 1e-9
+        # flag logic (Models.jl:157-180)
+        x, it, res, flag = m.ldiv(g["b"], 1e-14, 3)
+        assert it == 3 and flag == 1 and not x.any()
+        x, it, res, flag = m.ldiv(g["b"], 1e-14, 5000, call_maxiter=3)
+        assert it == 3 and flag == 2 and not x.any()
+    finally:
+        m.close()
+
+
+def test_single_site_golden(lib):
+    """config A (examples/holstein_hmc_single_site.toml): 1 site, no bonds, closed form."""
+    from elphdynamics_amd import _lib
+    g = golden("holstein_single_site.npz")
+    L = int(g["Ltau"])
+    m = RawModel(lib, 0, 1, L, np.zeros((0, 2), dtype=np.int64))
+    try:
+        _lib.check(lib.elph_update_model_holstein(m.h, _lib.dptr(np.ascontiguousarray(g["x"])), _lib.dptr(np.ones(1)),
+                                                  _lib.dptr(np.zeros(1)), _lib.dptr(np.zeros(1)), float(g["dtau"])))
+        assert rel(m.op("elph_mulM", g["b"]), g["Mb"]) < 1e-14
+        assert rel(m.op("elph_mulMT", g["b"]), g["MTb"]) < 1e-14
+        # M^-1 b via MtM x = Mt b
+        x, it, res, flag = m.ldiv(g["MTb"], 1e-13, 200)
+        assert flag == 0 and rel(x, g["Minv_b"]) < 1e-10
+    finally:
+        m.close()
+
+
+def test_ssh_golden(lib):
+    from elphdynamics_amd import _lib
+    g = golden("ssh_sq4_L8.npz")
+    N, L = int(g["N"]), int(g["Ltau"])
+    m = RawModel(lib, 1, N, L, g["table"])
+    try:
+        _lib.check(lib.elph_update_model_ssh(m.h, _lib.dptr(np.ascontiguousarray(g["cosht"])),
+                                             _lib.dptr(np.ascontiguousarray(g["sinht"])), _lib.dptr(g["expDtauMu"])))
+        assert rel(m.op("elph_mulM", g["v"]), g["Mv"]) < 1e-13
+        assert rel(m.op("elph_mulMT", g["v"]), g["MTv"]) < 1e-13
+        assert rel(m.op("elph_mulMTM", g["v"]), g["MTMv"]) < 1e-13
+        x, it, res, flag = m.ldiv(g["b"], 1e-12, 5000)
+        assert flag == 0 and rel(x, g["xsol"]) < 1e-9
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("L", [8, 20, 40, 120, 160, 7])
+def test_fft_golden(lib, L):
+    from elphdynamics_amd import _lib
+    g = golden("fft.npz")
+    N = 3
+    m = RawModel(lib, 0, N, L, np.zeros((0, 2), dtype=np.int64))
+    try:
+        v = np.ascontiguousarray(g[f"L{L}_v"])
+        nu = np.zeros(2 * N * L)
+        _lib.check(lib.elph_tau_to_omega(m.h, _lib.dptr(nu), _lib.dptr(v)))
+        assert rel(nu[0::2], g[f"L{L}_nu_re"]) < 1e-13 and rel(nu[1::2], g[f"L{L}_nu_im"]) < 1e-13
+        back = np.zeros(N * L)
+        _lib.check(lib.elph_omega_to_tau(m.h, _lib.dptr(back), _lib.dptr(nu)))
+        assert rel(back, v) < 1e-13
+        diag = np.tile(g[f"L{L}_Mi"], N)
+        for power in (-1.0, -0.5, 1.0):
+            out = np.zeros(N * L)
+            _lib.check(lib.elph_fourier_accelerate(m.h, _lib.dptr(out), _lib.dptr(v), _lib.dptr(diag), power, N))
+            assert rel(out, g[f"L{L}_fa_M_p{power}"]) < 1e-13
+        # a non-symmetric diagonal: the reference keeps only the real part, i.e. the symmetrised diagonal
+        rng = np.random.default_rng(L)
+        d2 = rng.uniform(0.5, 2.0, N * L)
+        out = np.zeros(N * L)
+        _lib.check(lib.elph_fourier_accelerate(m.h, _lib.dptr(out), _lib.dptr(v), _lib.dptr(d2), 1.0, N))
+        ref = np.real(np.fft.ifft(d2.reshape(N, L) * np.fft.fft(v.reshape(N, L), axis=1), axis=1)).reshape(-1)
+        assert rel(out, ref) < 1e-13
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("tag", ["sq4_L8", "sq4_L40"])
+def test_kpm_golden(lib, tag):
+    from elphdynamics_amd import _lib
+    g = golden(f"holstein_{tag}.npz")
+    k = golden(f"kpm_{tag}.npz")
+    N, L = int(g["N"]), int(g["Ltau"])
+    m = RawModel(lib, 0, N, L, g["table"], g["cosht"], g["sinht"])
+    try:
+        _lib.check(lib.elph_set_expV(m.h, _lib.dptr(np.ascontiguousarray(g["E"]))))
+        _lib.check(lib.elph_kpm_create(m.h, 20, float(k["buf"]), float(k["c1"]), float(k["c2"])))
+        act, lo, hi = C.c_int(), C.c_double(), C.c_double()
+        # own Arnoldi (n = min(20,N) = N steps => exact spectrum of the 16x16 A)
+        rng = np.random.default_rng(3)
+        _lib.check(lib.elph_kpm_setup(m.h, _lib.dptr(rng.standard_normal(N)), _lib.dptr(rng.standard_normal(N)),
+                                      float("nan"), float("nan"), C.byref(act), C.byref(lo), C.byref(hi)))
+        assert act.value == 1
+        assert abs(lo.value - float(k["lam_lo"])) < 1e-7 and abs(hi.value - float(k["lam_hi"])) < 1e-7
+        # injected bounds -> bit-identical lam_lo/hi; orders; apply
+        _lib.check(lib.elph_kpm_create(m.h, 20, float(k["buf"]), float(k["c1"]), float(k["c2"])))
+        _lib.check(lib.elph_kpm_setup(m.h, None, None, float(k["e_min"]), float(k["e_max"]), C.byref(act), C.byref(lo),
+                                      C.byref(hi)))
+        assert lo.value == float(k["lam_lo"]) and hi.value == float(k["lam_hi"])
+        orders = np.zeros((L + 1) // 2, dtype=np.int64)
+        tot = C.c_int64()
+        _lib.check(lib.elph_kpm_orders(m.h, _lib.iptr(orders), C.byref(tot)))
+        assert np.array_equal(orders, k["orders"]) and tot.value == k["orders"].sum()
+        assert rel(m.op("elph_kpm_apply", k["vin"]), k["vout"]) < 1e-12
+        # preconditioned ldiv! reaches the dense solution
+        x, it, res, flag = m.ldiv(g["b"], 1e-12, 5000, use_prec=1)
+        assert flag == 0 and rel(x, g["xsol"]) < 1e-9
+        x0, it0, *_ = m.ldiv(g["b"], 1e-12, 5000, use_prec=0)
+        if L >= 40:
+            assert it < it0
+        # implausible bounds deactivate -> identity (KPMPreconditioners.jl:312-318,475-478)
+        _lib.check(lib.elph_kpm_setup(m.h, None, None, 1.5, 1.2, C.byref(act), C.byref(lo), C.byref(hi)))
+        assert act.value == 0
+        assert np.array_equal(m.op("elph_kpm_apply", k["vin"]), k["vin"])
+        x, it2, res, flag = m.ldiv(g["b"], 1e-12, 5000, use_prec=1)
+        assert flag == 0 and rel(x, g["xsol"]) < 1e-9 and it2 == it0
+    finally:
+        m.close()
+
+
+# ------------------------------------------------------------------------------------------ oracle, same seeded inputs
+
+def _oracle_model(orc, m):
+    if m.kind == 0:
+        E = orc.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+        return orc.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+    return orc.make_model(1, m.Nsites, m.Ltau, m.neighbor_table, np.ascontiguousarray(m.cosht).reshape(-1),
+                          np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
+
+
+@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "e", "B", "C", "D", "E"])
+def test_matvec_vs_oracle(oracle, tag):
+    from elphdynamics_amd import configs, models, synth
+    m = configs.make_model(tag)
+    om = _oracle_model(oracle, m)
+    v = synth.randn(77, m.Ndim)
+    u = synth.randn(78, m.Ndim)
+    y = np.empty(m.Ndim)
+    for fn, ofn in ((models.mulM_, oracle.mulM), (models.mulMt_, oracle.mulMT), (models.mulMtM_, oracle.mulMTM)):
+        fn(y, m, v)
+        assert rel(y, ofn(om, v)) < 1e-13
+    # size-independent properties on the GPU results themselves
+    Mv, Mtu, a = np.empty(m.Ndim), np.empty(m.Ndim), np.empty(m.Ndim)
+    models.mulM_(Mv, m, v)
+    models.mulMt_(Mtu, m, u)
+    assert abs(u @ Mv - Mtu @ v) < 1e-11 * np.linalg.norm(u) * np.linalg.norm(v)          # adjointness
+    models.mulMt_(a, m, Mv)
+    models.mulMtM_(y, m, v)
+    assert rel(y, a) < 1e-14                                                                # fused MtM == Mt(M v)
+    models.mulM_(a, m, 2.0 * v - 3.0 * u)
+    Mu = np.empty(m.Ndim)
+    models.mulM_(Mu, m, u)
+    assert rel(a, 2.0 * Mv - 3.0 * Mu) < 1e-13                                              # linearity
+    m.close()
+
+
+@pytest.mark.parametrize("tag", ["b", "d", "t", "e", "B", "C", "D", "E"])
+def test_cg_vs_oracle(oracle, tag):
+    from elphdynamics_amd import configs, models
+    m = configs.make_model(tag, tol=1e-5)
+    om = _oracle_model(oracle, m)
+    R, B = configs.rhs(m, 1)
+    b = np.ascontiguousarray(B[0])
+    # production tolerance: same iteration count, same flags, early history to 1e-10
+    x = np.zeros(m.Ndim)
+    it, hist = models.solve_(x, m, b, tol=1e-5, history=True)
+    xo, ito, histo = oracle.cg_solve(om, b, tol=1e-5, maxiter=10000, history=True)
+    assert it == ito
+    n = min(41, it // 4 + 1)          # round-off grows with the iteration index; tiny systems converge in < 100
+    assert np.max(np.abs(hist[:n] - histo[:n]) / histo[:n]) < 1e-10
+    assert hist[-1] < 1e-5 <= hist[-2]
+    x2 = np.zeros(m.Ndim)
+    it2, res2, flag2 = models.ldiv_(x2, m, b)
+    xo2, ito2, reso2, flago2 = oracle.ldiv(om, b, solver_tol=1e-5, solver_maxiter=10000)
+    assert (it2, flag2) == (ito2, flago2) and flag2 == 0
+    # the true residual at exit carries the accumulated round-off of ~it iterations: same magnitude, not same digits
+    assert 0.5 * reso2 < res2 < 2.0 * reso2 and res2 <= np.sqrt(1e-5)
+    assert np.array_equal(x, x2)                                                            # deterministic re-run
+    # tight solve: Green's-function observable M^-1 R (GreensFunctions.jl:223-225, :334-346)
+    m.solver.tol = 1e-11
+    x3 = np.zeros(m.Ndim)
+    it3, res3, flag3 = models.ldiv_(x3, m, b)
+    xo3, ito3, *_ = oracle.ldiv(om, b, solver_tol=1e-11, solver_maxiter=10000)
+    assert flag3 == 0 and abs(it3 - ito3) <= max(3, ito3 // 100)
+    assert rel(x3, xo3) < 1e-9
+    Mx = np.empty(m.Ndim)
+    models.mulM_(Mx, m, x3)
+    assert rel(Mx, R[0]) < 1e-8                                                             # x = M^-1 R indeed
+    m.close()
+
+
+@pytest.mark.parametrize("tag", ["b", "C"])
+def test_batched_equals_single(tag):
+    """Batched right-hand sides follow the single-RHS recurrences exactly => bit-identical results."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model(tag, tol=1e-5)
+    nrhs = 3
+    R, B = configs.rhs(m, nrhs)
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    for i in range(nrhs):
+        x = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
+        assert it1 == it[i] and fl1 == fl[i] == 0 and res1 == res[i]
+        assert np.array_equal(x, X[i])
+    m.close()
+
+
+def test_nonzero_initial_guess_and_kappa_bailout(oracle):
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("b", tol=1e-8)
+    om = _oracle_model(oracle, m)
+    R, B = configs.rhs(m, 1)
+    b = np.ascontiguousarray(B[0])
+    x0 = 0.1 * R[0]
+    x = x0.copy()
+    it = models.solve_(x, m, b, tol=1e-8)
+    xo, ito = oracle.cg_solve(om, b, x0=x0, tol=1e-8, maxiter=10000)
+    assert it == ito and rel(x, xo) < 1e-7
+    # kappa_max bail-out (IterativeSolvers.jl:289-295): tiny kmax stops at the first iteration it is exceeded
+    x = np.zeros(m.Ndim)
+    it = models.solve_(x, m, b, tol=1e-12, kmax=50.0)
+    xo, ito = oracle.cg_solve(om, b, tol=1e-12, maxiter=10000, kmax=50.0)
+    assert it == ito and it < 60
+    m.close()
+
+
+@pytest.mark.parametrize("tag", ["b", "C", "D"])
+def test_kpm_vs_oracle(oracle, tag):
+    """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle."""
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    m = configs.make_model(tag, tol=1e-5)
+    om = _oracle_model(oracle, m)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    oP = oracle.make_kpm(om, n=20, buf=0.05, c1=1.0, c2=1.0)
+    rng = np.random.default_rng(11)
+    bmax, bmin = rng.standard_normal(m.Nsites), rng.standard_normal(m.Nsites)
+    e_min, e_max = oracle.kpm_setup(oP, b_max=bmax, b_min=bmin)
+    pc.setup_(P, b_max=bmax, b_min=bmin)                       # own Arnoldi (host C++), same start vectors
+    assert P.active and oP.active == 1
+    # 20 Arnoldi steps on N=256..288: Ritz values are reproducible to ~1e-7 across summation orders
+    assert abs(P.lam_lo - oP.lam_lo) < 1e-6 and abs(P.lam_hi - oP.lam_hi) < 1e-6
+    # parity of everything downstream: inject the oracle's bounds (parity runs take explicit inputs)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_(P, e_min=e_min, e_max=e_max)
+    assert P.lam_lo == oP.lam_lo and P.lam_hi == oP.lam_hi
+    Lo2 = (m.Ltau + 1) // 2
+    assert np.array_equal(P.orders, oP._keep["order"][:Lo2])
+    R, B = configs.rhs(m, 1)
+    r = np.ascontiguousarray(R[0])
+    z = np.empty(m.Ndim)
+    pc.kpm_ldiv_(z, P, r)
+    assert rel(z, oracle.kpm_apply(oP, r)) < 1e-11
+    b = np.ascontiguousarray(B[0])
+    x = np.zeros(m.Ndim)
+    it, hist = models.solve_(x, m, b, P=P, tol=1e-5, history=True)
+    xo, ito, histo = oracle.cg_solve(om, b, tol=1e-5, maxiter=10000, P=oP, history=True)
+    assert it == ito
+    n = min(21, it // 4 + 1)
+    assert np.max(np.abs(hist[:n] - histo[:n]) / histo[:n]) < 1e-10
+    x1 = np.zeros(m.Ndim)
+    it1, res1, fl1 = models.ldiv_(x1, m, b, P=P)
+    x0 = np.zeros(m.Ndim)
+    it0, res0, fl0 = models.ldiv_(x0, m, b)
+    assert fl1 == 0 and fl0 == 0 and it1 == it
+    assert it1 < it0                                             # the preconditioner reduces the iteration count
+    assert rel(x1, x0) < 1e-3                                    # both within tol of the same solution
+    m.close()
+
+
+def test_kpm_fallback_to_unpreconditioned(oracle):
+    """Models.jl:129-133: a preconditioned solve that fails (maxiter) is redone without P and 10x maxiter."""
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    m = configs.make_model("b", tol=1e-8, maxiter=40)
+    om = _oracle_model(oracle, m)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_(P, e_min=0.5, e_max=1.9)                           # deliberately poor bounds: weak preconditioner
+    oP = oracle.make_kpm(om)
+    oracle.kpm_setup(oP, e_min=0.5, e_max=1.9)
+    R, B = configs.rhs(m, 1)
+    b = np.ascontiguousarray(B[0])
+    x = np.zeros(m.Ndim)
+    it, res, fl = models.ldiv_(x, m, b, P=P, maxiter=5)
+    xo, ito, reso, flo = oracle.ldiv(om, b, P=oP, maxiter=5, solver_tol=1e-8, solver_maxiter=40)
+    assert (it, fl) == (ito, flo)
+    assert rel(x, xo) < 1e-6 if fl == 0 else not x.any()
+    m.close()
+
+
+def test_fourier_accelerate_full_size(oracle):
+    from elphdynamics_amd import configs, preconditioners as pc, synth
+    from oracle.oracle import dp
+    m = configs.make_model("C")
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, 10.0, 0.1, 2.0)
+    pc.update_Q_(fa, m, 0.0, 10.0, 0.5)
+    oM = np.zeros(m.Ndim)
+    oracle.lib.elpho_update_M(dp(oM), m.Nph, m.Ltau, m.dtau, dp(m.omega), 0.0, 10.0, 0.1, 2.0)
+    assert rel(fa.M, oM) < 1e-15
+    v = synth.randn(5, m.Ndim)
+    for power, use_mass in ((-1.0, True), (-0.5, True), (1.0, True), (1.0, False)):
+        out = np.empty(m.Ndim)
+        pc.fourier_accelerate_(out, fa, v, power, use_mass=use_mass)
+        ref = np.zeros(m.Ndim)
+        oracle.lib.elpho_fourier_accelerate(dp(ref), dp(v), dp(fa.M if use_mass else fa.Q), power, m.Nph, m.Ltau)
+        assert rel(out, ref) < 1e-12
+    back = np.empty(m.Ndim)
+    tmp = np.empty(m.Ndim)
+    pc.fourier_accelerate_(tmp, fa, v, -1.0, use_mass=True)
+    pc.fourier_accelerate_(back, fa, tmp, 1.0, use_mass=True)
+    assert rel(back, v) < 1e-12                                  # D^-1 then D is the identity
+    m.close()
+
+
+def test_error_paths(lib):
+    from elphdynamics_amd import _lib
+    h = _lib.Handle()
+    tab = np.array([[1, 2], [2, 9]], dtype=np.int64)
+    assert lib.elph_create(C.byref(h), 0, 4, 4, 2, _lib.iptr(tab), _lib.dptr(np.ones(2)), _lib.dptr(np.ones(2)), 0) == -1
+    assert b"out of range" in lib.elph_last_error()
+    assert lib.elph_create(C.byref(h), 7, 4, 4, 0, None, None, None, 0) == -1
+    assert lib.elph_create(C.byref(h), 0, 4, 4, 0, None, None, None, 99) == -1
+    m = RawModel(lib, 0, 4, 4, np.zeros((0, 2), dtype=np.int64))
+    y = np.zeros(16)
+    assert lib.elph_mulM(m.h, _lib.dptr(y), _lib.dptr(y)) == -3          # update_model not called yet
+    assert lib.elph_kpm_apply(m.h, _lib.dptr(y), _lib.dptr(y)) == -3
+    m.close()
+    # a table that is NOT in checkerboard order is still applied in the given sequential order
+    g = golden("holstein_sq4_L8.npz")
+    N, L = int(g["N"]), int(g["Ltau"])
+    perm = np.random.default_rng(0).permutation(g["table"].shape[0])
+    m2 = RawModel(lib, 0, N, L, g["table"][perm], g["cosht"][perm], g["sinht"][perm])
+    _lib.check(lib.elph_set_expV(m2.h, _lib.dptr(np.ascontiguousarray(g["E"]))))
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    om = orc.make_model(0, N, L, g["table"][perm], g["cosht"][perm], g["sinht"][perm], g["E"])
+    assert rel(m2.op("elph_mulM", g["v"]), orc.mulM(om, np.ascontiguousarray(g["v"]))) < 1e-13
+    assert rel(m2.op("elph_mulMTM", g["v"]), orc.mulMTM(om, np.ascontiguousarray(g["v"]))) < 1e-13
+    m2.close()

@@ -1,0 +1,99 @@
+"""CPU-side tests (no GPU): host set-up logic of the product against the golden integer tables, the
+C-ABI library loads and exports every symbol include/elph_gpu.h declares, and the product refuses to
+compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+from elphdynamics_amd import lattice as lat
+from elphdynamics_amd import synth
+
+CASES = [("sq2", 1, 2, 2, lat.SQUARE_BONDS), ("sq4", 1, 4, 4, lat.SQUARE_BONDS), ("sq8", 1, 8, 8, lat.SQUARE_BONDS),
+         ("sq16", 1, 16, 16, lat.SQUARE_BONDS), ("hc3", 2, 3, 3, lat.HONEYCOMB_BONDS),
+         ("hc12", 2, 12, 12, lat.HONEYCOMB_BONDS), ("tri3", 1, 3, 3, lat.TRIANGULAR_BONDS),
+         ("chain6", 1, 6, 1, [(1, 1, (1, 0, 0))])]
+
+
+@pytest.mark.parametrize("tag,norb,L1,L2,bonds", CASES)
+def test_product_tables_bit_exact(tag, norb, L1, L2, bonds):
+    """elphdynamics_amd.lattice reproduces the golden neighbour table / colouring / permutation bit-for-bit."""
+    g = golden("tables.npz")
+    la = lat.Lattice(norb, L1, L2, 1)
+    raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+    assert np.array_equal(raw, g[tag + "_raw"])
+    cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), 0.1)
+    assert np.array_equal(cb["table"], g[tag + "_table"])
+    assert np.array_equal(cb["colours"], g[tag + "_colour"])
+    assert np.array_equal(cb["cb_perm"], g[tag + "_cbperm"])
+    assert np.array_equal(cb["inv_cb_perm"][cb["cb_perm"] - 1], np.arange(1, raw.shape[0] + 1))
+
+
+def test_product_tables_match_oracle(oracle):
+    la = lat.Lattice(2, 4, 4, 1)
+    raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in lat.HONEYCOMB_BONDS], axis=0)
+    assert np.array_equal(raw, oracle.neighbor_table(2, 4, 4, 1, lat.HONEYCOMB_BONDS))
+    t = 1.0 + 0.1 * synth.randn(3, raw.shape[0])
+    cb = lat.initialize_checkerboard(raw, t, 0.1)
+    tab, c, s, perm, grp, ng = oracle.holstein_initialize(raw, t, 0.1)
+    assert np.array_equal(cb["table"], tab) and np.array_equal(cb["cb_perm"], perm)
+    assert np.allclose(cb["cosht"], c, rtol=4e-16, atol=0) and np.allclose(cb["sinht"], s, rtol=4e-16, atol=0)   # libm vs numpy: <= 1 ulp
+    assert cb["ncolours"] == ng
+
+
+def test_ltau_and_site_numbering():
+    assert lat.ltau_from_beta(16.0, 0.1) == 160 and lat.ltau_from_beta(2.5, 1.0) == 2 and lat.ltau_from_beta(3.5, 1.0) == 4
+    la = lat.Lattice(2, 3, 4, 1)
+    assert la.nsites == 24
+    assert la.loc_to_site(1, 0, 0) == 1 and la.loc_to_site(2, 0, 0) == 2 and la.loc_to_site(1, 1, 0) == 3
+    assert la.loc_to_site(1, -1, 0) == la.loc_to_site(1, 2, 0)
+    assert la.site_to_site(1, (0, -1, 0), 2) == la.loc_to_site(2, 0, 3)
+
+
+def test_synth_is_deterministic_and_sane():
+    a, b = synth.randn(5, 1001), synth.randn(5, 1001)
+    assert np.array_equal(a, b) and len(a) == 1001
+    g = synth.randn(1, 200000)
+    assert abs(g.mean()) < 0.01 and abs(g.std() - 1) < 0.01
+    x = synth.phonon_field(8, 10, 1.0, 0.1, rough=False)
+    assert np.all(x.reshape(8, 10) == x.reshape(8, 10)[:, :1])          # cold start: tau-constant per site
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """Every function declared in include/elph_gpu.h is exported by the built library and bound in _lib.SIGNATURES."""
+    from elphdynamics_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "elph_gpu.h")).read()
+    declared = set(re.findall(r"\b(elph_[a-z_0-9A-Z]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.elph_abi_version() == 1
+    assert isinstance(lib.elph_last_error(), bytes)
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a HIP device the product must fail loudly, never compute on the host."""
+    from elphdynamics_amd import _lib
+    lib = _lib.load()
+    if lib.elph_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    h = _lib.Handle()
+    rc = lib.elph_create(C.byref(h), 0, 4, 4, 0, None, None, None, 0)
+    assert rc == -4 and b"no HIP device" in lib.elph_last_error()
+    from elphdynamics_amd import configs
+    with pytest.raises(_lib.ElphError):
+        configs.make_model("b")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under elphdynamics_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "elphdynamics_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "elph_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
