@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — CG mat-vecs/s on the L=16, Ntau=160 Holstein square lattice (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--nrhs R] [--precond]
+
+A *step* is one conjugate-gradient iteration (1 MtM apply = 2 mat-vecs, + the vector updates and both
+reductions; + 1 KPM apply with --precond) advanced for a batch of `nrhs` independent right-hand sides of
+the same fermion matrix, with everything resident in HBM.  W untimed warm-up steps, then exactly K steps
+bracketed by barrier + device synchronise on both sides; the time is the MAX over ranks and
+value = (2 * nrhs * K * n_gpus) / time.  One JSON line on rank 0.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards over *independent chains*
+(one phonon configuration = one fermion matrix per rank, no data-path collective; "weak" scaling).  This is
+how the reference itself parallelises (independent run-IDs, ElPhDynamics.jl:90-95).  The spatially sharded
+single-solve mode with RCCL halo exchange is a strong-scaling anti-pattern at these sizes
+and is reported separately.
+
+Also in the JSON line:
+  roofline      the dominant kernel k_cg_ap timed ALONE with HIP events on the launch stream:
+                achieved = algorithmic bytes per launch / average launch duration  
+  cpu_baseline  the CPU oracle (oracle/elph_oracle.c, -O3 -march=native -ffast-math, 1 thread = the
+                reference's configuration, ElPhDynamics.jl:74-75) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+ALG_BYTES_PER_ELT = {          # SURVEY.md §8(d), f64, perfect fusion
+    "cg_iter": 120.0,          # 2 mat-vecs (48) + x, r, p updates (72)
+    "k_cg_ap": 72.0,           # p = r + beta p (24) + M p (24) + Mt (M p) (24)
+    "k_cg_xr": 48.0,           # x += alpha p (24) + r -= alpha z (24)
+    "kpm_apply": 16.0,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--nrhs", type=int, default=64, help="right-hand sides advanced per step (batch)")
+    ap.add_argument("--config", default="C", help="BASELINE config tag (C = Holstein square L=16 Ltau=160)")
+    ap.add_argument("--precond", action="store_true", help="KPM (tau-FFT) preconditioned CG iteration")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the secondary nrhs sweep")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # noqa: F811  (first: libelphgpu then shares torch's HIP runtime)
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    from elphdynamics_amd import _lib, configs, preconditioners as pc, synth
+    from elphdynamics_amd._lib import check
+
+    lib = _lib.load()
+    if lib.elph_device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libelphgpu has no CPU path")
+
+    # one independent chain (phonon configuration) per rank
+    m = configs.make_model(args.config, tol=1e-5, device=local_rank if world > 1 else 0,
+                           seed=synth.SEED_FIELDS + 1009 * rank)
+    nrhs = args.nrhs
+    R, B = configs.rhs(m, nrhs, seed=synth.SEED_RHS + 1009 * rank)
+    what = 3 if args.precond else 1
+    if args.precond:
+        P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+        pc.setup_(P, rng=np.random.default_rng(7 + rank))
+    Bc = np.ascontiguousarray(B)
+
+    def sync_all():
+        check(lib.elph_synchronize(m._h))
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def run(what_, nrhs_, reps, graph=1):
+        ms = C.c_double()
+        check(lib.elph_bench_run(m._h, what_, nrhs_, reps, graph, C.byref(ms)))
+        return ms.value
+
+    chunk = 16
+    K = max(chunk, (args.steps // chunk) * chunk)
+    W = max(chunk, (args.warmup // chunk) * chunk)
+
+    check(lib.elph_bench_prepare(m._h, what, nrhs, _lib.dptr(Bc)))
+    run(what, nrhs, W)                       # warm-up (also instantiates the graph path once)
+    check(lib.elph_bench_prepare(m._h, what, nrhs, None))
+    sync_all()
+    t0 = time.perf_counter()
+    ms_events = run(what, nrhs, K)           # exactly K steps; returns after the stream has drained
+    sync_all()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        ndim = m.Ndim
+        matvecs = 2.0 * nrhs * K * world
+        out = {
+            "metric": "cg_matvecs_per_sec",
+            "value": matvecs / elapsed,
+            "unit": "matvec/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config {args.config}: Holstein square L=16 Ntau=160 (N=256, Ndim=40960), "
+                            f"{'KPM-preconditioned' if args.precond else 'un-preconditioned'} CG iteration, "
+                            f"nrhs={nrhs} right-hand sides per chain, {world} independent chain(s) (1 per GPU)",
+                "nrhs": nrhs, "ndim": ndim, "preconditioned": bool(args.precond),
+                "parallelism": f"chains{world}",
+            },
+            "cg_iters_per_sec": nrhs * K * world / elapsed,
+            "cg_batch_steps_per_sec": K / elapsed,
+            "ms_per_step_events": ms_events / K,
+        }
+
+        # ---- roofline of the dominant kernel (k_cg_ap), timed alone with HIP events on its stream
+        reps = 2000
+        check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
+        run(4, nrhs, 320, graph=0)
+        ms_ap = run(4, nrhs, reps, graph=0) / reps
+        alg = ALG_BYTES_PER_ELT["k_cg_ap"] * ndim * nrhs
+        ach = alg / (ms_ap * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"k_cg_ap_nrhs{nrhs}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "k_cg_ap", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": ms_ap * 1e3,
+                           "algorithmic_bytes_per_launch": alg}
+        check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
+        run(5, nrhs, 320, graph=0)
+        ms_xr = run(5, nrhs, reps, graph=0) / reps
+        out["roofline"]["k_cg_xr_avg_launch_us"] = ms_xr * 1e3
+        out["roofline"]["whole_iteration"] = {
+            "algorithmic_bytes_per_step": ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs,
+            "achieved_GBs": ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs * K / (ms_events * 1e-3) / 1e9,
+        }
+        out["roofline"]["whole_iteration"]["frac"] = out["roofline"]["whole_iteration"]["achieved_GBs"] / HBM_PEAK_GBS
+
+        # ---- secondary: the same step at other batch sizes (short runs)
+        if not args.no_sweep:
+            sweep = {}
+            for nr in (1, 2, 10, 64, 256):
+                if nr == nrhs:
+                    sweep[str(nr)] = {"us_per_step": 1e3 * ms_events / K, "matvecs_per_sec": 2.0 * nr * K / (ms_events * 1e-3)}
+                    continue
+                _, Bs = configs.rhs(m, nr)
+                check(lib.elph_bench_prepare(m._h, what, nr, _lib.dptr(np.ascontiguousarray(Bs))))
+                run(what, nr, 160)
+                check(lib.elph_bench_prepare(m._h, what, nr, None))
+                ms = run(what, nr, 1600)
+                sweep[str(nr)] = {"us_per_step": 1e3 * ms / 1600, "matvecs_per_sec": 2.0 * nr * 1600 / (ms * 1e-3),
+                                  "alg_GBs": ALG_BYTES_PER_ELT["cg_iter"] * ndim * nr * 1600 / (ms * 1e-3) / 1e9}
+            out["by_nrhs"] = sweep
+
+        # ---- CPU baseline: the oracle, 1 thread, bounded sample of the same workload
+        if not args.no_cpu:
+            try:
+                from oracle.oracle import Oracle
+                orc = Oracle(fast=True)
+                E = orc.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+                om = orc.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+                b0 = np.ascontiguousarray(B[0])
+                tt = time.perf_counter()
+                orc.cg_solve(om, b0, tol=0.0, maxiter=200)
+                per_it = (time.perf_counter() - tt) / 200
+                n_it = int(max(200, min(200000, args.cpu_seconds / per_it)))
+                tt = time.perf_counter()
+                orc.cg_solve(om, b0, tol=0.0, maxiter=n_it)
+                dt = time.perf_counter() - tt
+                out["cpu_baseline"] = {"value": 2.0 * n_it / dt, "unit": "matvec/s", "cores": 1, "kind": "port",
+                                       "sample": f"{n_it} un-preconditioned CG iterations (tol=0) on right-hand side 0 of the same "
+                                                 f"config-{args.config} workload, oracle/elph_oracle.c built -O3 -march=native "
+                                                 f"-ffast-math, single thread ({os.cpu_count()} host cores present)",
+                                       "cg_iters_per_sec": n_it / dt, "seconds": dt}
+            except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    m.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,7 +50,8 @@ SIGNATURES = {
     "elph_fourier_accelerate": (c_int, [Handle, P_dbl, P_dbl, P_dbl, c_dbl, c_i64]),
     "elph_tau_to_omega": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_omega_to_tau": (c_int, [Handle, P_dbl, P_dbl]),
-    "elph_time_unit": (c_int, [Handle, c_int, c_int, c_int, P_dbl]),
+    "elph_bench_prepare": (c_int, [Handle, c_int, c_int, P_dbl]),
+    "elph_bench_run": (c_int, [Handle, c_int, c_int, c_int, c_int, P_dbl]),
 }
 
 

@@ -1,0 +1,539 @@
+// cg_fast.hip — latency-tuned gfx950 kernels for lattices whose checkerboard has <= 4 colours
+// (every even-L square and honeycomb lattice of the reference's example decks).
+//
+// What differs from the generic kernels in kernels.hip (same arithmetic, same results):
+//   * "lane program": the bond list is re-packed on the host per colour into [colour][pass][lane]
+//     so that every lane keeps ITS bonds (site pair + cosh + sinh) in registers for the whole kernel;
+//     a checkerboard colour is then  LDS read -> 4 FMAs -> LDS write -> wave barrier  with no
+//     dependent global load inside the sweep (the generic kernel pays one L2 round trip per colour);
+//   * every global load of the kernel (state, partial sums, vectors, exp(-dtau V), lane program)
+//     is independent of every other and issued up front: one memory round trip per kernel;
+//   * the p ping-pong index is a launch constant (launch parity) instead of device state;
+//   * XCD-aware 1-D grid: workgroups with equal (blockIdx.x % 8) share an XCD/L2, so they are given
+//     consecutive tau-slices — the tau+-1 halo re-reads of the fused MtM then hit the same L2.
+//
+// Reference semantics: see kernels.hip / SURVEY.md Appendix A.
+
+#include "elph_internal.h"
+
+#define WAVE ELPH_WAVE
+
+__device__ __forceinline__ double wave_sum2(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double reduce_partials2(const double *p, int n) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += WAVE) a += p[i];
+    return wave_sum2(a);
+}
+
+// XCD-aware mapping of a 1-D grid of 8*C*nrhs workgroups onto (tau, rhs); C = ceil(L/8)
+__device__ __forceinline__ bool xcd_map(int L, int &t, int &rhs) {
+    const int b = blockIdx.x;
+    const int C = (L + 7) >> 3;
+    const int xcd = b & 7, k = b >> 3;
+    rhs = k / C;
+    t = xcd * C + (k - rhs * C);
+    return t < L;
+}
+
+template <int NPL>
+struct LaneProg {
+    static constexpr int PP = (NPL + 1) / 2;     // passes per colour: ceil(N/2 / 64)
+    static constexpr int NE = 4 * PP;
+    unsigned ij[NE];
+};
+
+template <int NPL>
+__device__ __forceinline__ void lp_load_ij(unsigned (&ij)[4 * ((NPL + 1) / 2)], const ModelDev &m) {
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) ij[e] = m.lp_ij[e * WAVE + threadIdx.x];
+}
+
+template <int NPL>
+__device__ __forceinline__ void lp_load_cs(double (&c)[4 * ((NPL + 1) / 2)], double (&s)[4 * ((NPL + 1) / 2)],
+                                           const double *lc, const double *ls) {
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        c[e] = lc[e * WAVE + threadIdx.x];
+        s[e] = ls[e * WAVE + threadIdx.x];
+    }
+}
+
+// one checkerboard sweep with register-resident bonds (Checkerboard.jl:57-83 / :149-175)
+template <int NPL, int NBUF, bool REVERSE>
+__device__ __forceinline__ void lp_sweep(double *buf0, double *buf1, const unsigned (&ij)[4 * ((NPL + 1) / 2)],
+                                         const double (&c0)[4 * ((NPL + 1) / 2)], const double (&s0)[4 * ((NPL + 1) / 2)],
+                                         const double (&c1)[4 * ((NPL + 1) / 2)], const double (&s1)[4 * ((NPL + 1) / 2)],
+                                         int ncol) {
+    constexpr int PP = (NPL + 1) / 2;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int col = REVERSE ? 3 - cc : cc;
+        if (col < ncol) {
+            double a0[PP], a1[PP], b0[PP], b1[PP];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const unsigned w = ij[col * PP + pp];
+                if (w != 0xFFFFFFFFu) {
+                    const int i = w & 0xFFFF, j = w >> 16;
+                    a0[pp] = buf0[i]; a1[pp] = buf0[j];
+                    if (NBUF == 2) { b0[pp] = buf1[i]; b1[pp] = buf1[j]; }
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const int e = col * PP + pp;
+                const unsigned w = ij[e];
+                if (w != 0xFFFFFFFFu) {
+                    const int i = w & 0xFFFF, j = w >> 16;
+                    buf0[i] = c0[e] * a0[pp] + s0[e] * a1[pp];
+                    buf0[j] = c0[e] * a1[pp] + s0[e] * a0[pp];
+                    if (NBUF == 2) {
+                        buf1[i] = c1[e] * b0[pp] + s1[e] * b1[pp];
+                        buf1[j] = c1[e] * b1[pp] + s1[e] * b0[pp];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = M v | M^T v | M^T M v   (same maths as k_mul in kernels.hip)
+// ------------------------------------------------------------------------------------------
+
+template <int NPL, int WHICH, bool SSH>
+__global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const double *__restrict__ v, ModelDev m) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+    double *bufA = lds, *bufB = lds + m.N;
+    const int N = m.N, L = m.L;
+    int t, vecid;
+    if (!xcd_map(L, t, vecid)) return;
+    const int tm1 = (t == 0) ? L - 1 : t - 1;
+    const int tp1 = (t == L - 1) ? 0 : t + 1;
+    const size_t vec = (size_t)vecid * (size_t)N * (size_t)L;
+    const double *vv = v + vec;
+    double *yy = y + vec;
+    const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
+    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+
+    unsigned ij[NE];
+    double c0[NE], s0[NE], c1[NE], s1[NE];
+    lp_load_ij<NPL>(ij, m);
+    if (SSH) {
+        lp_load_cs<NPL>(c0, s0, m.lp_c + (size_t)t * m.lp_tau_stride, m.lp_s + (size_t)t * m.lp_tau_stride);
+        lp_load_cs<NPL>(c1, s1, m.lp_c + (size_t)tp1 * m.lp_tau_stride, m.lp_s + (size_t)tp1 * m.lp_tau_stride);
+    } else {
+        lp_load_cs<NPL>(c0, s0, m.lp_c, m.lp_s);
+    }
+    double vm[NPL], v0[NPL], vp[NPL], e0[NPL], e1[NPL], w0[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        const bool ok = s < N;
+        v0[q] = ok ? vv[(size_t)t * N + s] : 0.0;
+        if (WHICH != 1) { vm[q] = ok ? vv[(size_t)tm1 * N + s] : 0.0; e0[q] = ok ? E0[s] : 0.0; }
+        if (WHICH != 0) { vp[q] = ok ? vv[(size_t)tp1 * N + s] : 0.0; e1[q] = ok ? E1[s] : 0.0; }
+    }
+    if (WHICH == 0) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) bufA[s] = e0[q] * vm[q]; }
+        __syncthreads();
+        lp_sweep<NPL, 1, false>(bufA, nullptr, ij, c0, s0, c0, s0, m.ncol);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) yy[(size_t)t * N + s] = v0[q] - sg0 * bufA[s]; }
+    } else if (WHICH == 1) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) bufA[s] = vp[q]; }
+        __syncthreads();
+        if (SSH) lp_sweep<NPL, 1, true>(bufA, nullptr, ij, c1, s1, c1, s1, m.ncol);
+        else lp_sweep<NPL, 1, true>(bufA, nullptr, ij, c0, s0, c0, s0, m.ncol);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) yy[(size_t)t * N + s] = v0[q] - sg1 * e1[q] * bufA[s]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) { bufA[s] = e0[q] * vm[q]; bufB[s] = e1[q] * v0[q]; }
+        }
+        __syncthreads();
+        if (SSH) lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c1, s1, m.ncol);
+        else lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c0, s0, m.ncol);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) { w0[q] = v0[q] - sg0 * bufA[s]; bufB[s] = vp[q] - sg1 * bufB[s]; }
+        }
+        __syncthreads();
+        if (SSH) lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c1, s1, c1, s1, m.ncol);
+        else lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c0, s0, c0, s0, m.ncol);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) yy[(size_t)t * N + s] = w0[q] - sg1 * e1[q] * bufB[s]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// CG kernels (IterativeSolvers.jl:153-314); see kernels.hip for the protocol between them.
+// ------------------------------------------------------------------------------------------
+
+template <int NPL, bool SSH>
+__global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int parity) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+    double *bufA = lds, *bufB = lds + m.N;
+    const int N = m.N, L = m.L;
+    int t, rhs;
+    if (!xcd_map(L, t, rhs)) return;
+    const size_t ndim = (size_t)N * L;
+    const int tm1 = (t == 0) ? L - 1 : t - 1;
+    const int tp1 = (t == L - 1) ? 0 : t + 1;
+
+    // ---- every global load of the kernel, none depending on another ---------------------------
+    CgState *st2 = B.state + 2 * rhs;
+    const CgState Sa = st2[0], Sb = st2[1];
+    const CgParams P = *B.params;
+    const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
+    const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
+    double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
+    double *z = B.z + (size_t)rhs * ndim;
+    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+
+    double sm[NPL], s0v[NPL], sp[NPL], qm[NPL], q0[NPL], qp[NPL], e0[NPL], e1[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        const bool ok = s < N;
+        const size_t im = (size_t)tm1 * N + s, i0 = (size_t)t * N + s, ip = (size_t)tp1 * N + s;
+        sm[q] = ok ? src[im] : 0.0; s0v[q] = ok ? src[i0] : 0.0; sp[q] = ok ? src[ip] : 0.0;
+        qm[q] = ok ? pold[im] : 0.0; q0[q] = ok ? pold[i0] : 0.0; qp[q] = ok ? pold[ip] : 0.0;
+        e0[q] = ok ? E0[s] : 0.0; e1[q] = ok ? E1[s] : 0.0;
+    }
+    unsigned ij[NE];
+    double c0[NE], s0[NE], c1[NE], s1[NE];
+    lp_load_ij<NPL>(ij, m);
+    if (SSH) {
+        lp_load_cs<NPL>(c0, s0, m.lp_c + (size_t)t * m.lp_tau_stride, m.lp_s + (size_t)t * m.lp_tau_stride);
+        lp_load_cs<NPL>(c1, s1, m.lp_c + (size_t)tp1 * m.lp_tau_stride, m.lp_s + (size_t)tp1 * m.lp_tau_stride);
+    } else {
+        lp_load_cs<NPL>(c0, s0, m.lp_c, m.lp_s);
+    }
+    const double rr = reduce_partials2(B.rr + (size_t)rhs * L, L);
+    const double rz = P.use_prec ? reduce_partials2(B.rz + (size_t)rhs * B.nrz, B.nrz) : rr;
+
+    // ---- scalar control (identical in every wave of this rhs) ----------------------------------
+    const CgState S = (Sb.seq > Sa.seq) ? Sb : Sa;
+    if (S.done) return;
+    const long long seq = S.seq;
+    const bool first = (seq == 0);
+    CgState *Sout = st2 + ((seq + 1) & 1);
+    double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
+    if (!first) {
+        eps = sqrt(rr) / S.normb;
+        const double qq = 2.0 * (double)seq / log(2.0 * S.eps0 / eps);
+        const double val = qq * qq;
+        kmin = (val > kmin) ? val : kmin;
+        int done = 0;
+        if (eps < P.tol) done = 1;
+        else if (kmin > P.kmax) done = 2;
+        else if (seq >= P.maxiter) done = 3;
+        if (t == 0 && threadIdx.x == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + seq] = eps;
+        if (done) {
+            if (t == 0 && threadIdx.x == 0) {
+                CgState o = S;
+                o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = done;
+                *Sout = o;
+            }
+            return;
+        }
+        beta = rz / S.rho;
+        rho = rz;
+    }
+
+    // ---- p = (z|r) + beta p on slices t-1, t, t+1; stage E.*p into LDS ---------------------------
+    double p0[NPL], pp[NPL], w0[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        const double pm = first ? qm[q] : sm[q] + beta * qm[q];
+        p0[q] = first ? q0[q] : s0v[q] + beta * q0[q];
+        pp[q] = first ? qp[q] : sp[q] + beta * qp[q];
+        if (s < N) {
+            pnew[(size_t)t * N + s] = p0[q];
+            bufA[s] = e0[q] * pm;
+            bufB[s] = e1[q] * p0[q];
+        }
+    }
+    __syncthreads();
+    const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
+    if (SSH) lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c1, s1, m.ncol);
+    else lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c0, s0, m.ncol);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            w0[q] = p0[q] - sg0 * bufA[s];
+            bufB[s] = pp[q] - sg1 * bufB[s];
+        }
+    }
+    __syncthreads();
+    if (SSH) lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c1, s1, c1, s1, m.ncol);
+    else lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c0, s0, c0, s0, m.ncol);
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            const double zz = w0[q] - sg1 * e1[q] * bufB[s];
+            z[(size_t)t * N + s] = zz;
+            acc += p0[q] * zz;
+        }
+    }
+    acc = wave_sum2(acc);
+    if (threadIdx.x == 0) {
+        B.pap[(size_t)rhs * L + t] = acc;
+        if (t == 0) {
+            CgState o = S;
+            o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = 0;
+            *Sout = o;
+        }
+    }
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(WAVE) k_cg_xr_fast(CgBufs B, int N, int L, int parity) {
+    int t, rhs;
+    if (!xcd_map(L, t, rhs)) return;
+    const size_t ndim = (size_t)N * L;
+    const CgState *st2 = B.state + 2 * rhs;
+    const CgState Sa = st2[0], Sb = st2[1];
+    const double *p = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
+    const double *z = B.z + (size_t)rhs * ndim;
+    double *x = B.x + (size_t)rhs * ndim, *r = B.r + (size_t)rhs * ndim;
+    double xv[NPL], pv[NPL], rv[NPL], zv[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        const bool ok = s < N;
+        const size_t i = (size_t)t * N + s;
+        xv[q] = ok ? x[i] : 0.0; pv[q] = ok ? p[i] : 0.0; rv[q] = ok ? r[i] : 0.0; zv[q] = ok ? z[i] : 0.0;
+    }
+    const double pap = reduce_partials2(B.pap + (size_t)rhs * L, L);
+    const CgState S = (Sb.seq > Sa.seq) ? Sb : Sa;
+    if (S.done) return;
+    const double alpha = S.rho / pap;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) {
+            const size_t i = (size_t)t * N + s;
+            x[i] = xv[q] + alpha * pv[q];
+            const double rn = rv[q] - alpha * zv[q];
+            r[i] = rn;
+            acc += rn * rn;
+        }
+    }
+    acc = wave_sum2(acc);
+    if (threadIdx.x == 0) B.rr[(size_t)rhs * L + t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// KPM per-omega Chebyshev recursion with register-resident bonds (KPMPreconditioners.jl:606-693,758-778)
+// ------------------------------------------------------------------------------------------
+
+template <int NPL, bool REVERSE>
+__device__ __forceinline__ void lp_sweep_z(double2 *buf, const unsigned (&ij)[4 * ((NPL + 1) / 2)],
+                                           const double (&c)[4 * ((NPL + 1) / 2)], const double (&s)[4 * ((NPL + 1) / 2)],
+                                           int ncol) {
+    constexpr int PP = (NPL + 1) / 2;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int col = REVERSE ? 3 - cc : cc;
+        if (col < ncol) {
+            double2 a0[PP], a1[PP];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const unsigned w = ij[col * PP + pp];
+                if (w != 0xFFFFFFFFu) { a0[pp] = buf[w & 0xFFFF]; a1[pp] = buf[w >> 16]; }
+            }
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const int e = col * PP + pp;
+                const unsigned w = ij[e];
+                if (w != 0xFFFFFFFFu) {
+                    buf[w & 0xFFFF] = make_double2(c[e] * a0[pp].x + s[e] * a1[pp].x, c[e] * a0[pp].y + s[e] * a1[pp].y);
+                    buf[w >> 16] = make_double2(c[e] * a1[pp].x + s[e] * a0[pp].x, c[e] * a1[pp].y + s[e] * a0[pp].y);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NPL, bool TRANSPOSED, bool CONJ>
+__device__ __forceinline__ void kpm_series_fast(double2 (&acc)[NPL], const double2 (&vin)[NPL], double2 *buf,
+                                                const double (&eb)[NPL], const double2 *c, int order, double a, double b,
+                                                const unsigned (&ij)[4 * ((NPL + 1) / 2)], const double (&cb)[4 * ((NPL + 1) / 2)],
+                                                const double (&sb)[4 * ((NPL + 1) / 2)], int ncol, int N) {
+    double2 um1[NPL], un[NPL], up1[NPL];
+    double2 c0 = c[0];
+    if (CONJ) c0.y = -c0.y;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        acc[q] = make_double2(c0.x * vin[q].x - c0.y * vin[q].y, c0.x * vin[q].y + c0.y * vin[q].x);
+        un[q] = vin[q];
+        um1[q] = make_double2(0.0, 0.0);
+    }
+    for (int n = 2; n <= order; ++n) {
+        // up1 = A' un   (mulA'!, :685-693; A = CBbar diag(Ebar), A^T = diag(Ebar) CBbar^T, :758-778)
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) buf[s] = TRANSPOSED ? un[q] : make_double2(eb[q] * un[q].x, eb[q] * un[q].y);
+        }
+        __syncthreads();
+        lp_sweep_z<NPL, TRANSPOSED>(buf, ij, cb, sb, ncol);
+        const double2 cn0 = c[n - 1];
+        const double2 cn = make_double2(cn0.x, CONJ ? -cn0.y : cn0.y);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            double2 av = (s < N) ? buf[s] : make_double2(0.0, 0.0);
+            if (TRANSPOSED) { av.x *= eb[q]; av.y *= eb[q]; }
+            up1[q] = make_double2(a * av.x - b * un[q].x, a * av.y - b * un[q].y);
+            if (n > 2) {     // u_{n+1} = 2 A' u_n - u_{n-1}; the first step is u_2 = A' u_1
+                up1[q].x = 2.0 * up1[q].x - um1[q].x;
+                up1[q].y = 2.0 * up1[q].y - um1[q].y;
+            }
+            um1[q] = un[q];
+            un[q] = up1[q];
+            acc[q].x += cn.x * un[q].x - cn.y * un[q].y;
+            acc[q].y += cn.x * un[q].y + cn.y * un[q].x;
+        }
+        __syncthreads();
+    }
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(WAVE) k_kpm_cheb_fast(double2 *__restrict__ nu, KpmDev K, ModelDev m, int Lo2,
+                                                        const CgState *state) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+    double2 *buf = reinterpret_cast<double2 *>(lds);
+    const int rhs = blockIdx.y;
+    if (state) {
+        const CgState Sa = state[2 * rhs], Sb = state[2 * rhs + 1];
+        if (((Sb.seq > Sa.seq) ? Sb : Sa).done) return;
+    }
+    const int w = K.wsched[blockIdx.x];
+    const int N = m.N;
+    const int order = K.order[w];
+    const double2 *c = K.coeff + K.coff[w];
+    double2 *u = nu + ((size_t)rhs * Lo2 + w) * N;
+    unsigned ij[NE];
+    double cb[NE], sb[NE];
+    lp_load_ij<NPL>(ij, m);
+    lp_load_cs<NPL>(cb, sb, K.lp_cbar, K.lp_sbar);
+    double2 vin[NPL], mid[NPL], res[NPL];
+    double eb[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        vin[q] = (s < N) ? u[s] : make_double2(0.0, 0.0);
+        eb[q] = (s < N) ? K.Ebar[s] : 0.0;
+    }
+    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+    kpm_series_fast<NPL, true, true>(mid, vin, buf, eb, c, order, a, b, ij, cb, sb, m.ncol, N);
+    kpm_series_fast<NPL, false, false>(res, mid, buf, eb, c, order, a, b, ij, cb, sb, m.ncol, N);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        if (s < N) u[s] = res[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+
+#define DISPATCH_NPL_F(npl, CALL)                                 \
+    switch (npl) {                                                \
+        case 1: { constexpr int NPL = 1; CALL; } break;           \
+        case 2: { constexpr int NPL = 2; CALL; } break;           \
+        case 3: { constexpr int NPL = 3; CALL; } break;           \
+        case 4: { constexpr int NPL = 4; CALL; } break;           \
+        case 5: { constexpr int NPL = 5; CALL; } break;           \
+        case 6: { constexpr int NPL = 6; CALL; } break;           \
+        case 7: { constexpr int NPL = 7; CALL; } break;           \
+        default: { constexpr int NPL = 8; CALL; } break;          \
+    }
+
+static int check_launch_f(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        elph_set_error("launch %s failed: %s", what, hipGetErrorString(e));
+        return ELPH_E_HIP;
+    }
+    return ELPH_OK;
+}
+
+static unsigned xcd_grid(const elph_handle_s *h, int nvec) { return 8u * (unsigned)((h->L + 7) / 8) * (unsigned)nvec; }
+
+int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec) {
+    ModelDev m = elph_model_dev(h);
+    const size_t shm = 2 * (size_t)h->N * sizeof(double);
+    const dim3 grid(xcd_grid(h, nvec));
+    const bool ssh = (h->kind == ELPH_MODEL_SSH);
+    DISPATCH_NPL_F(h->npl, {
+        if (ssh) {
+            if (which == 0) hipLaunchKernelGGL((k_mul_fast<NPL, 0, true>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+            else if (which == 1) hipLaunchKernelGGL((k_mul_fast<NPL, 1, true>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+            else hipLaunchKernelGGL((k_mul_fast<NPL, 2, true>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+        } else {
+            if (which == 0) hipLaunchKernelGGL((k_mul_fast<NPL, 0, false>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+            else if (which == 1) hipLaunchKernelGGL((k_mul_fast<NPL, 1, false>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+            else hipLaunchKernelGGL((k_mul_fast<NPL, 2, false>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+        }
+    });
+    return check_launch_f("k_mul_fast");
+}
+
+int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
+    ModelDev m = elph_model_dev(h);
+    const size_t shm = 2 * (size_t)h->N * sizeof(double);
+    const dim3 grid(xcd_grid(h, nrhs));
+    const bool ssh = (h->kind == ELPH_MODEL_SSH);
+    DISPATCH_NPL_F(h->npl, {
+        if (ssh) hipLaunchKernelGGL((k_cg_ap_fast<NPL, true>), grid, dim3(WAVE), shm, h->stream, B, m, parity);
+        else hipLaunchKernelGGL((k_cg_ap_fast<NPL, false>), grid, dim3(WAVE), shm, h->stream, B, m, parity);
+    });
+    return check_launch_f("k_cg_ap_fast");
+}
+
+int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
+    const dim3 grid(xcd_grid(h, nrhs));
+    DISPATCH_NPL_F(h->npl, {
+        hipLaunchKernelGGL((k_cg_xr_fast<NPL>), grid, dim3(WAVE), 0, h->stream, B, (int)h->N, (int)h->L, parity);
+    });
+    return check_launch_f("k_cg_xr_fast");
+}
+
+int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
+    KpmDev K = elph_kpm_dev(h);
+    ModelDev m = elph_model_dev(h);
+    const int Lo2 = (int)((h->L + 1) / 2);
+    const size_t shm = (size_t)h->N * sizeof(double2);
+    DISPATCH_NPL_F(h->npl, {
+        hipLaunchKernelGGL((k_kpm_cheb_fast<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(WAVE), shm, h->stream, h->d_nu, K,
+                           m, Lo2, st);
+    });
+    return check_launch_f("k_kpm_cheb_fast");
+}

@@ -64,6 +64,65 @@ static void drop_graphs(elph_handle_s *h) {
 }
 
 // ------------------------------------------------------------------------------------------
+// lane program (cg_fast.hip): bonds re-packed [colour][pass][lane]
+// ------------------------------------------------------------------------------------------
+
+void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill) {
+    const int PP = (h->npl + 1) / 2, NE = 4 * PP;
+    for (int i = 0; i < NE * ELPH_WAVE; ++i) out[i] = fill;
+    for (int col = 0; col < h->ncol && col < 4; ++col) {
+        const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
+        for (int n = b0; n < b1; ++n) {
+            const int k = n - b0;
+            out[(col * PP + k / ELPH_WAVE) * ELPH_WAVE + (k % ELPH_WAVE)] = per_bond[n];
+        }
+    }
+}
+
+static int build_lane_program(elph_handle_s *h) {
+    const int PP = (h->npl + 1) / 2, NE = 4 * PP;
+    h->lp_ne = NE;
+    const char *nf = getenv("ELPH_NO_FAST");
+    h->fast = (h->ncol <= 4) && !(nf && nf[0] == '1');
+    h->h_lp_ij.assign((size_t)NE * ELPH_WAVE, 0xFFFFFFFFu);
+    if (h->fast) {
+        for (int col = 0; col < h->ncol; ++col) {
+            const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
+            if (b1 - b0 > PP * ELPH_WAVE) { h->fast = false; break; }
+            for (int n = b0; n < b1; ++n) {
+                const int k = n - b0;
+                h->h_lp_ij[(size_t)(col * PP + k / ELPH_WAVE) * ELPH_WAVE + (k % ELPH_WAVE)] =
+                    (unsigned)h->h_bi[n] | ((unsigned)h->h_bj[n] << 16);
+            }
+        }
+    }
+    RC(dev_alloc(&h->d_lp_ij, (size_t)NE * ELPH_WAVE));
+    HIPCHK(hipMemcpy(h->d_lp_ij, h->h_lp_ij.data(), sizeof(unsigned) * NE * ELPH_WAVE, hipMemcpyHostToDevice));
+    const size_t ntau = (h->kind == ELPH_MODEL_SSH) ? (size_t)h->L : 1;
+    RC(dev_alloc(&h->d_lp_c, ntau * NE * ELPH_WAVE));
+    RC(dev_alloc(&h->d_lp_s, ntau * NE * ELPH_WAVE));
+    RC(dev_alloc(&h->d_lp_cbar, (size_t)NE * ELPH_WAVE));
+    RC(dev_alloc(&h->d_lp_sbar, (size_t)NE * ELPH_WAVE));
+    return ELPH_OK;
+}
+
+// uploads the lane-program copy of the per-bond cosh/sinh tables (h_c/h_s)
+static int upload_lp_cs(elph_handle_s *h) {
+    if (!h->fast) return ELPH_OK;
+    const int NE = h->lp_ne;
+    const size_t ntau = (h->kind == ELPH_MODEL_SSH) ? (size_t)h->L : 1, per = (size_t)NE * ELPH_WAVE;
+    if (h->h_c.size() < ntau * (size_t)h->nb) return ELPH_OK;   // SSH before the first update_model
+    std::vector<double> c(ntau * per), s(ntau * per);
+    for (size_t t = 0; t < ntau; ++t) {
+        elph_lp_pack(h, h->h_c.data() + t * (size_t)h->nb, c.data() + t * per, 1.0);
+        elph_lp_pack(h, h->h_s.data() + t * (size_t)h->nb, s.data() + t * per, 0.0);
+    }
+    HIPCHK(hipMemcpy(h->d_lp_c, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_lp_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice));
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // life cycle
 // ------------------------------------------------------------------------------------------
 
@@ -207,6 +266,8 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
             return fail(ELPH_E_HIP);
         }
     }
+    if ((rc = build_lane_program(h))) return fail(rc);
+    if ((rc = upload_lp_cs(h))) return fail(rc);
     if ((rc = ensure_capacity(h, 1))) return fail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { elph_set_error("sync failed"); return fail(ELPH_E_HIP); }
     *out = h;
@@ -221,7 +282,8 @@ extern "C" int elph_destroy(elph_handle h) {
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_params,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
-                    h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag};
+                    h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
+                    h->d_lp_sbar};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -298,6 +360,7 @@ extern "C" int elph_update_model_ssh(elph_handle h, const double *cosht, const d
         HIPCHK(hipMemcpy(h->d_s, h->h_s.data(), L * nb * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemcpy(h->d_E, expDtauMu, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
+    RC(upload_lp_cs(h));
     h->have_E = true;
     return ELPH_OK;
 }
@@ -401,6 +464,7 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
             hipGraphExec_t exec;
             RC(get_chunk_graph(h, nrhs, use_prec, &exec));
             HIPCHK(hipGraphLaunch(exec, h->stream));
+            h->ap_count += ELPH_CG_CHUNK;   // even: the captured launch parities stay aligned with seq
         } else {
             for (int it = 0; it < ELPH_CG_CHUNK; ++it) RC(elph_launch_cg_iteration(h, nrhs, use_prec));
             HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
@@ -622,6 +686,13 @@ extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *
         HIPCHK(hipMemcpy(h->d_cbar, h->h_cbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sbar, h->h_sbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
     }
+    if (h->fast) {
+        std::vector<double> lc((size_t)h->lp_ne * ELPH_WAVE), ls((size_t)h->lp_ne * ELPH_WAVE);
+        elph_lp_pack(h, h->h_cbar.data(), lc.data(), 1.0);
+        elph_lp_pack(h, h->h_sbar.data(), ls.data(), 0.0);
+        HIPCHK(hipMemcpy(h->d_lp_cbar, lc.data(), sizeof(double) * lc.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_lp_sbar, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
+    }
     // eigenvalue bounds (:272-273) — injected or Arnoldi with caller-supplied start vectors
     if (!(std::isfinite(e_min) && std::isfinite(e_max))) {
         if (!b_max || !b_min) { elph_set_error("Arnoldi start vectors required when bounds are not injected"); return ELPH_E_ARG; }
@@ -777,42 +848,79 @@ extern "C" int elph_omega_to_tau(elph_handle h, double *v, const double *nu_comp
 }
 
 // ------------------------------------------------------------------------------------------
-// measurement hook
+// measurement hooks (bench.py)
 // ------------------------------------------------------------------------------------------
 
-extern "C" int elph_time_unit(elph_handle h, int what, int nrhs, int reps, double *ms_per_rep) {
+static int bench_launch_unit(elph_handle_s *h, int what, int nrhs) {
+    switch (what) {
+        case 0: return elph_launch_mul(h, 2, h->d_z, h->d_b, nrhs);
+        case 1: return elph_launch_cg_iteration(h, nrhs, 0);
+        case 2: return elph_launch_kpm_apply(h, h->d_zp, h->d_b, nrhs, 0);
+        case 3: return elph_launch_cg_iteration(h, nrhs, 1);
+        case 4: return elph_launch_cg_kernel(h, nrhs, 0);
+        default: return elph_launch_cg_kernel(h, nrhs, 1);
+    }
+}
+
+extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B) {
     CHECK_H(h);
     RC(need_model(h));
-    if (nrhs < 1 || reps < 1 || !ms_per_rep || what < 0 || what > 3) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (nrhs < 1 || what < 0 || what > 5) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     if ((what == 2 || what == 3) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
     RC(ensure_capacity(h, nrhs));
+    if (B) {
+        const size_t bytes = (size_t)nrhs * (size_t)h->ndim * sizeof(double);
+        HIPCHK(hipMemcpyAsync(h->d_stage_in, B, bytes, hipMemcpyHostToDevice, h->stream));
+        RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, nrhs));
+    }
+    // fixed-count CG: tol = 0 never converges, kmax = inf, x0 = 0
+    CgParams P;
+    P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3); P.record_hist = 0; P.hist_stride = 0;
+    HIPCHK(hipMemcpyAsync(h->d_params, &P, sizeof(P), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
+    RC(elph_launch_cg_init(h, nrhs, P.use_prec));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total) {
+    CHECK_H(h);
+    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 5) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     int rc = ELPH_OK;
-    if (what == 1 || what == 3) {
-        // fixed-count CG iterations on whatever d_b/d_x hold: tol = 0 never converges, kmax = inf
-        CgParams P;
-        P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3); P.record_hist = 0; P.hist_stride = 0;
-        HIPCHK(hipMemcpy(h->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
-        // x0 = 0, b = whatever the last solve left in d_b (bench.py loads it with a real solve first)
-        HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
-        rc = elph_launch_cg_init(h, nrhs, P.use_prec);
+    hipGraphExec_t exec = nullptr;
+    const int chunk = ELPH_CG_CHUNK;
+    if (use_graph && h->use_graph && reps % chunk == 0) {
+        // capture `chunk` units once (not cached: the bench owns it)
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < chunk && rc == ELPH_OK; ++i) rc = bench_launch_unit(h, what, nrhs);
+        hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (rc == ELPH_OK && e != hipSuccess) { elph_set_error("capture: %s", hipGetErrorString(e)); rc = ELPH_E_HIP; }
+        if (rc == ELPH_OK) {
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) { elph_set_error("instantiate: %s", hipGetErrorString(e)); rc = ELPH_E_HIP; }
+        }
+        if (graph) (void)hipGraphDestroy(graph);
     }
     if (rc == ELPH_OK) {
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipEventRecord(e0, h->stream));
-        for (int r = 0; r < reps && rc == ELPH_OK; ++r) {
-            if (what == 0) rc = elph_launch_mul(h, 2, h->d_z, h->d_b, nrhs);
-            else if (what == 2) rc = elph_launch_kpm_apply(h, h->d_zp, h->d_b, nrhs, 0);
-            else rc = elph_launch_cg_iteration(h, nrhs, what == 3);
+        if (exec) {
+            for (int r = 0; r < reps / chunk; ++r) HIPCHK(hipGraphLaunch(exec, h->stream));
+        } else {
+            for (int r = 0; r < reps && rc == ELPH_OK; ++r) rc = bench_launch_unit(h, what, nrhs);
         }
         HIPCHK(hipEventRecord(e1, h->stream));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        *ms_per_rep = (double)ms / reps;
+        *ms_total = (double)ms;
     }
+    if (exec) (void)hipGraphExecDestroy(exec);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;

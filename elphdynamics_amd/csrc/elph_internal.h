@@ -48,6 +48,26 @@ struct ModelDev {
     const double *c;     // cosh table
     const double *s;     // sinh table
     const double *E;     // exp(-dtau V) (Holstein, layout S) or exp(dtau mu) (SSH)
+    // "lane program" (cg_fast.hip): bonds re-packed [colour][pass][lane], PP = ceil(npl/2) passes per colour,
+    // NE = 4*PP entries; idle slots hold 0xFFFFFFFF.  Only valid when ncol <= 4.
+    const unsigned *lp_ij;   // [NE][64]  i | j << 16
+    const double *lp_c;      // [1 or L][NE][64]
+    const double *lp_s;
+    int lp_tau_stride;       // 0 (Holstein) or NE*64 (SSH)
+};
+
+// Buffers of the CG iteration kernels (all layout S).
+struct CgState;
+struct CgParams;
+struct CgBufs {
+    double *x, *r, *z, *zp;     // [nrhs][ndim]; zp = P^-1 r (preconditioned only)
+    double *p;                  // [2][nrhs][ndim] ping-pong by (seq & 1)
+    double *pap, *rr, *rz;      // partial sums [nrhs][npart]
+    CgState *state;             // [nrhs][2]
+    const CgParams *params;
+    double *hist;               // optional eps history
+    int nrz;                    // number of r.z partials per rhs
+    int nrhs;
 };
 
 // CG state of one right-hand side; two copies, the newer one has the larger seq.
@@ -82,6 +102,8 @@ struct KpmDev {
     const int *coff;          // [Lo2+1]
     const double2 *coeff;     // [sum order]
     const int *wsched;        // [Lo2] omega indices sorted by decreasing order (longest first)
+    const double *lp_cbar;    // lane-program copies of cbar/sbar [NE][64]
+    const double *lp_sbar;
 };
 
 struct elph_handle_s {
@@ -99,6 +121,13 @@ struct elph_handle_s {
     double *d_c = nullptr, *d_s = nullptr, *d_E = nullptr;
     bool have_E = false;
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
+    // lane program (fast path, ncol <= 4)
+    bool fast = false;
+    int lp_ne = 0;
+    std::vector<unsigned> h_lp_ij;
+    unsigned *d_lp_ij = nullptr;
+    double *d_lp_c = nullptr, *d_lp_s = nullptr, *d_lp_cbar = nullptr, *d_lp_sbar = nullptr;
+    long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
 
     // solver defaults (model.solver)
     double tol = 1e-4, kmax = 1e12;
@@ -157,6 +186,7 @@ int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau);
 int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
 int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec);
 int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec);
+int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which /*0 = k_cg_ap, 1 = k_cg_xr*/);
 int elph_launch_residual(elph_handle_s *h, int nrhs);
 int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode);
 int elph_launch_ebar(elph_handle_s *h);
@@ -164,6 +194,14 @@ int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, con
 int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);
 int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS);
 int elph_launch_zero(elph_handle_s *h, double *p, int64_t n);
+
+// ---- fast path (cg_fast.hip) ----------------------------------------------------------------
+int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
+int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
+// packs per-bond values (order of h_bi/h_bj) into the lane-program layout [NE][64] (idle slots = fill)
+void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill);
 
 // ---- host-side KPM setup (kpm_host.cpp) ---------------------------------------------------
 void elph_kpm_coefficients(double *c_z, int order, double lam_lo, double lam_hi, double phi);

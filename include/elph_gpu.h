@@ -176,10 +176,16 @@ int elph_omega_to_tau(elph_handle h, double *v, const double *nu_complex);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */
 
-/* Timed repetition of one hot-path unit with inputs resident in HBM, bracketed by HIP events on
- * the handle's stream.  what: 0 = MᵀM apply, 1 = one un-preconditioned CG iteration (fixed count,
- * no early exit), 2 = KPM apply, 3 = one preconditioned CG iteration.  Returns average ms per rep. */
-int elph_time_unit(elph_handle h, int what, int nrhs, int reps, double *ms_per_rep);
+/* Measurement of one hot-path unit with inputs resident in HBM (no host traffic in the timed region).
+ * what: 0 = MᵀM apply, 1 = one un-preconditioned CG iteration (k_cg_ap + k_cg_xr, stop test disabled),
+ *       2 = KPM apply, 3 = one preconditioned CG iteration, 4 = k_cg_ap alone, 5 = k_cg_xr alone.
+ * elph_bench_prepare: loads nrhs right-hand sides (B: host, reference layout, nrhs*ndim; NULL keeps what the
+ *   last solve left on the device), zeroes x, seeds the CG state with tol = 0 (never converges).
+ * elph_bench_run: launches `reps` units back-to-back on the handle's stream (captured graph chunks when
+ *   use_graph != 0 and reps is a multiple of the chunk), brackets them with HIP events recorded on that
+ *   stream, synchronises, and returns the event time in ms (total, not per rep). */
+int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B);
+int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total);
 
 #ifdef __cplusplus
 }

