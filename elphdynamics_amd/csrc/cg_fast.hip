@@ -65,7 +65,9 @@ __device__ __forceinline__ void lp_load_cs(double (&c)[4 * ((NPL + 1) / 2)], dou
     }
 }
 
-// one checkerboard sweep with register-resident bonds (Checkerboard.jl:57-83 / :149-175)
+// one checkerboard sweep with register-resident bonds (Checkerboard.jl:57-83 / :149-175).
+// Straight-line code: idle lanes of a ragged colour address two private padding slots of the slab with
+// (c,s) = (1,0), so there is no per-lane predicate and the compiler batches all LDS reads of a colour.
 template <int NPL, int NBUF, bool REVERSE>
 __device__ __forceinline__ void lp_sweep(double *buf0, double *buf1, const unsigned (&ij)[4 * ((NPL + 1) / 2)],
                                          const double (&c0)[4 * ((NPL + 1) / 2)], const double (&s0)[4 * ((NPL + 1) / 2)],
@@ -80,24 +82,20 @@ __device__ __forceinline__ void lp_sweep(double *buf0, double *buf1, const unsig
 #pragma unroll
             for (int pp = 0; pp < PP; ++pp) {
                 const unsigned w = ij[col * PP + pp];
-                if (w != 0xFFFFFFFFu) {
-                    const int i = w & 0xFFFF, j = w >> 16;
-                    a0[pp] = buf0[i]; a1[pp] = buf0[j];
-                    if (NBUF == 2) { b0[pp] = buf1[i]; b1[pp] = buf1[j]; }
-                }
+                const int i = w & 0xFFFF, j = w >> 16;
+                a0[pp] = buf0[i]; a1[pp] = buf0[j];
+                if (NBUF == 2) { b0[pp] = buf1[i]; b1[pp] = buf1[j]; }
             }
 #pragma unroll
             for (int pp = 0; pp < PP; ++pp) {
                 const int e = col * PP + pp;
                 const unsigned w = ij[e];
-                if (w != 0xFFFFFFFFu) {
-                    const int i = w & 0xFFFF, j = w >> 16;
-                    buf0[i] = c0[e] * a0[pp] + s0[e] * a1[pp];
-                    buf0[j] = c0[e] * a1[pp] + s0[e] * a0[pp];
-                    if (NBUF == 2) {
-                        buf1[i] = c1[e] * b0[pp] + s1[e] * b1[pp];
-                        buf1[j] = c1[e] * b1[pp] + s1[e] * b0[pp];
-                    }
+                const int i = w & 0xFFFF, j = w >> 16;
+                buf0[i] = c0[e] * a0[pp] + s0[e] * a1[pp];
+                buf0[j] = c0[e] * a1[pp] + s0[e] * a0[pp];
+                if (NBUF == 2) {
+                    buf1[i] = c1[e] * b0[pp] + s1[e] * b1[pp];
+                    buf1[j] = c1[e] * b1[pp] + s1[e] * b0[pp];
                 }
             }
             __syncthreads();
@@ -105,15 +103,21 @@ __device__ __forceinline__ void lp_sweep(double *buf0, double *buf1, const unsig
     }
 }
 
+// LDS slab of one tau-slice: NPL*64 site slots + 2 private padding slots per lane (idle lane-program entries)
+template <int NPL>
+__host__ __device__ constexpr int slab_len() { return NPL * WAVE + 2 * WAVE; }
+
 // ------------------------------------------------------------------------------------------
 // y = M v | M^T v | M^T M v   (same maths as k_mul in kernels.hip)
+// All global loads are unconditional (site index clamped to N-1 for the lanes past a ragged N); LDS
+// accesses need no predicate (slab padded to NPL*64); only global stores are guarded.
 // ------------------------------------------------------------------------------------------
 
 template <int NPL, int WHICH, bool SSH>
 __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const double *__restrict__ v, ModelDev m) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NE = 4 * ((NPL + 1) / 2);
-    double *bufA = lds, *bufB = lds + m.N;
+    double *bufA = lds, *bufB = lds + slab_len<NPL>();
     const int N = m.N, L = m.L;
     int t, vecid;
     if (!xcd_map(L, t, vecid)) return;
@@ -138,21 +142,21 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
-        const bool ok = s < N;
-        v0[q] = ok ? vv[(size_t)t * N + s] : 0.0;
-        if (WHICH != 1) { vm[q] = ok ? vv[(size_t)tm1 * N + s] : 0.0; e0[q] = ok ? E0[s] : 0.0; }
-        if (WHICH != 0) { vp[q] = ok ? vv[(size_t)tp1 * N + s] : 0.0; e1[q] = ok ? E1[s] : 0.0; }
+        const int sc = (s < N) ? s : N - 1;
+        v0[q] = vv[(size_t)t * N + sc];
+        if (WHICH != 1) { vm[q] = vv[(size_t)tm1 * N + sc]; e0[q] = E0[sc]; }
+        if (WHICH != 0) { vp[q] = vv[(size_t)tp1 * N + sc]; e1[q] = E1[sc]; }
     }
     if (WHICH == 0) {
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) bufA[s] = e0[q] * vm[q]; }
+        for (int q = 0; q < NPL; ++q) bufA[threadIdx.x + q * WAVE] = e0[q] * vm[q];
         __syncthreads();
         lp_sweep<NPL, 1, false>(bufA, nullptr, ij, c0, s0, c0, s0, m.ncol);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) yy[(size_t)t * N + s] = v0[q] - sg0 * bufA[s]; }
     } else if (WHICH == 1) {
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) bufA[s] = vp[q]; }
+        for (int q = 0; q < NPL; ++q) bufA[threadIdx.x + q * WAVE] = vp[q];
         __syncthreads();
         if (SSH) lp_sweep<NPL, 1, true>(bufA, nullptr, ij, c1, s1, c1, s1, m.ncol);
         else lp_sweep<NPL, 1, true>(bufA, nullptr, ij, c0, s0, c0, s0, m.ncol);
@@ -162,7 +166,8 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             const int s = threadIdx.x + q * WAVE;
-            if (s < N) { bufA[s] = e0[q] * vm[q]; bufB[s] = e1[q] * v0[q]; }
+            bufA[s] = e0[q] * vm[q];
+            bufB[s] = e1[q] * v0[q];
         }
         __syncthreads();
         if (SSH) lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c1, s1, m.ncol);
@@ -170,7 +175,8 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             const int s = threadIdx.x + q * WAVE;
-            if (s < N) { w0[q] = v0[q] - sg0 * bufA[s]; bufB[s] = vp[q] - sg1 * bufB[s]; }
+            w0[q] = v0[q] - sg0 * bufA[s];
+            bufB[s] = vp[q] - sg1 * bufB[s];
         }
         __syncthreads();
         if (SSH) lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c1, s1, c1, s1, m.ncol);
@@ -188,7 +194,7 @@ template <int NPL, bool SSH>
 __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int parity) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NE = 4 * ((NPL + 1) / 2);
-    double *bufA = lds, *bufB = lds + m.N;
+    double *bufA = lds, *bufB = lds + slab_len<NPL>();
     const int N = m.N, L = m.L;
     int t, rhs;
     if (!xcd_map(L, t, rhs)) return;
@@ -210,11 +216,11 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
-        const bool ok = s < N;
-        const size_t im = (size_t)tm1 * N + s, i0 = (size_t)t * N + s, ip = (size_t)tp1 * N + s;
-        sm[q] = ok ? src[im] : 0.0; s0v[q] = ok ? src[i0] : 0.0; sp[q] = ok ? src[ip] : 0.0;
-        qm[q] = ok ? pold[im] : 0.0; q0[q] = ok ? pold[i0] : 0.0; qp[q] = ok ? pold[ip] : 0.0;
-        e0[q] = ok ? E0[s] : 0.0; e1[q] = ok ? E1[s] : 0.0;
+        const int sc = (s < N) ? s : N - 1;
+        const size_t im = (size_t)tm1 * N + sc, i0 = (size_t)t * N + sc, ip = (size_t)tp1 * N + sc;
+        sm[q] = src[im]; s0v[q] = src[i0]; sp[q] = src[ip];
+        qm[q] = pold[im]; q0[q] = pold[i0]; qp[q] = pold[ip];
+        e0[q] = E0[sc]; e1[q] = E1[sc];
     }
     unsigned ij[NE];
     double c0[NE], s0[NE], c1[NE], s1[NE];
@@ -265,11 +271,9 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
         const double pm = first ? qm[q] : sm[q] + beta * qm[q];
         p0[q] = first ? q0[q] : s0v[q] + beta * q0[q];
         pp[q] = first ? qp[q] : sp[q] + beta * qp[q];
-        if (s < N) {
-            pnew[(size_t)t * N + s] = p0[q];
-            bufA[s] = e0[q] * pm;
-            bufB[s] = e1[q] * p0[q];
-        }
+        bufA[s] = e0[q] * pm;
+        bufB[s] = e1[q] * p0[q];
+        if (s < N) pnew[(size_t)t * N + s] = p0[q];
     }
     __syncthreads();
     const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
@@ -278,10 +282,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
-        if (s < N) {
-            w0[q] = p0[q] - sg0 * bufA[s];
-            bufB[s] = pp[q] - sg1 * bufB[s];
-        }
+        w0[q] = p0[q] - sg0 * bufA[s];
+        bufB[s] = pp[q] - sg1 * bufB[s];
     }
     __syncthreads();
     if (SSH) lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c1, s1, c1, s1, m.ncol);
@@ -290,8 +292,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
+        const double zz = w0[q] - sg1 * e1[q] * bufB[s];
         if (s < N) {
-            const double zz = w0[q] - sg1 * e1[q] * bufB[s];
             z[(size_t)t * N + s] = zz;
             acc += p0[q] * zz;
         }
@@ -321,9 +323,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_xr_fast(CgBufs B, int N, int L, int
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
-        const bool ok = s < N;
-        const size_t i = (size_t)t * N + s;
-        xv[q] = ok ? x[i] : 0.0; pv[q] = ok ? p[i] : 0.0; rv[q] = ok ? r[i] : 0.0; zv[q] = ok ? z[i] : 0.0;
+        const size_t i = (size_t)t * N + ((s < N) ? s : N - 1);
+        xv[q] = x[i]; pv[q] = p[i]; rv[q] = r[i]; zv[q] = z[i];
     }
     const double pap = reduce_partials2(B.pap + (size_t)rhs * L, L);
     const CgState S = (Sb.seq > Sa.seq) ? Sb : Sa;
@@ -362,16 +363,14 @@ __device__ __forceinline__ void lp_sweep_z(double2 *buf, const unsigned (&ij)[4 
 #pragma unroll
             for (int pp = 0; pp < PP; ++pp) {
                 const unsigned w = ij[col * PP + pp];
-                if (w != 0xFFFFFFFFu) { a0[pp] = buf[w & 0xFFFF]; a1[pp] = buf[w >> 16]; }
+                a0[pp] = buf[w & 0xFFFF]; a1[pp] = buf[w >> 16];
             }
 #pragma unroll
             for (int pp = 0; pp < PP; ++pp) {
                 const int e = col * PP + pp;
                 const unsigned w = ij[e];
-                if (w != 0xFFFFFFFFu) {
-                    buf[w & 0xFFFF] = make_double2(c[e] * a0[pp].x + s[e] * a1[pp].x, c[e] * a0[pp].y + s[e] * a1[pp].y);
-                    buf[w >> 16] = make_double2(c[e] * a1[pp].x + s[e] * a0[pp].x, c[e] * a1[pp].y + s[e] * a0[pp].y);
-                }
+                buf[w & 0xFFFF] = make_double2(c[e] * a0[pp].x + s[e] * a1[pp].x, c[e] * a0[pp].y + s[e] * a1[pp].y);
+                buf[w >> 16] = make_double2(c[e] * a1[pp].x + s[e] * a0[pp].x, c[e] * a1[pp].y + s[e] * a0[pp].y);
             }
             __syncthreads();
         }
@@ -395,18 +394,15 @@ __device__ __forceinline__ void kpm_series_fast(double2 (&acc)[NPL], const doubl
     for (int n = 2; n <= order; ++n) {
         // up1 = A' un   (mulA'!, :685-693; A = CBbar diag(Ebar), A^T = diag(Ebar) CBbar^T, :758-778)
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
-            if (s < N) buf[s] = TRANSPOSED ? un[q] : make_double2(eb[q] * un[q].x, eb[q] * un[q].y);
-        }
+        for (int q = 0; q < NPL; ++q)
+            buf[threadIdx.x + q * WAVE] = TRANSPOSED ? un[q] : make_double2(eb[q] * un[q].x, eb[q] * un[q].y);
         __syncthreads();
         lp_sweep_z<NPL, TRANSPOSED>(buf, ij, cb, sb, ncol);
         const double2 cn0 = c[n - 1];
         const double2 cn = make_double2(cn0.x, CONJ ? -cn0.y : cn0.y);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
-            double2 av = (s < N) ? buf[s] : make_double2(0.0, 0.0);
+            double2 av = buf[threadIdx.x + q * WAVE];
             if (TRANSPOSED) { av.x *= eb[q]; av.y *= eb[q]; }
             up1[q] = make_double2(a * av.x - b * un[q].x, a * av.y - b * un[q].y);
             if (n > 2) {     // u_{n+1} = 2 A' u_n - u_{n-1}; the first step is u_2 = A' u_1
@@ -447,8 +443,9 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb_fast(double2 *__restrict__ nu
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
-        vin[q] = (s < N) ? u[s] : make_double2(0.0, 0.0);
-        eb[q] = (s < N) ? K.Ebar[s] : 0.0;
+        const int sc = (s < N) ? s : N - 1;
+        vin[q] = u[sc];
+        eb[q] = K.Ebar[sc];
     }
     const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
     kpm_series_fast<NPL, true, true>(mid, vin, buf, eb, c, order, a, b, ij, cb, sb, m.ncol, N);
@@ -489,7 +486,7 @@ static unsigned xcd_grid(const elph_handle_s *h, int nvec) { return 8u * (unsign
 
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec) {
     ModelDev m = elph_model_dev(h);
-    const size_t shm = 2 * (size_t)h->N * sizeof(double);
+    const size_t shm = 2 * (size_t)(h->npl * WAVE + 2 * WAVE) * sizeof(double);
     const dim3 grid(xcd_grid(h, nvec));
     const bool ssh = (h->kind == ELPH_MODEL_SSH);
     DISPATCH_NPL_F(h->npl, {
@@ -508,7 +505,7 @@ int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int
 
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
     ModelDev m = elph_model_dev(h);
-    const size_t shm = 2 * (size_t)h->N * sizeof(double);
+    const size_t shm = 2 * (size_t)(h->npl * WAVE + 2 * WAVE) * sizeof(double);
     const dim3 grid(xcd_grid(h, nrhs));
     const bool ssh = (h->kind == ELPH_MODEL_SSH);
     DISPATCH_NPL_F(h->npl, {
@@ -530,7 +527,7 @@ int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     KpmDev K = elph_kpm_dev(h);
     ModelDev m = elph_model_dev(h);
     const int Lo2 = (int)((h->L + 1) / 2);
-    const size_t shm = (size_t)h->N * sizeof(double2);
+    const size_t shm = (size_t)(h->npl * WAVE + 2 * WAVE) * sizeof(double2);
     DISPATCH_NPL_F(h->npl, {
         hipLaunchKernelGGL((k_kpm_cheb_fast<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(WAVE), shm, h->stream, h->d_nu, K,
                            m, Lo2, st);

@@ -84,7 +84,14 @@ static int build_lane_program(elph_handle_s *h) {
     h->lp_ne = NE;
     const char *nf = getenv("ELPH_NO_FAST");
     h->fast = (h->ncol <= 4) && !(nf && nf[0] == '1');
-    h->h_lp_ij.assign((size_t)NE * ELPH_WAVE, 0xFFFFFFFFu);
+    // idle slots (ragged colours / fewer than 4 colours): each lane owns two padding slots of the LDS slab,
+    // paired with (cosh, sinh) = (1, 0) by elph_lp_pack => a no-op bond, no predicate in the kernels
+    h->h_lp_ij.resize((size_t)NE * ELPH_WAVE);
+    for (int e = 0; e < NE; ++e)
+        for (int l = 0; l < ELPH_WAVE; ++l) {
+            const unsigned i = (unsigned)(h->npl * ELPH_WAVE + 2 * l);
+            h->h_lp_ij[(size_t)e * ELPH_WAVE + l] = i | ((i + 1) << 16);
+        }
     if (h->fast) {
         for (int col = 0; col < h->ncol; ++col) {
             const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
@@ -165,6 +172,7 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
         return ELPH_E_UNSUPPORTED;
     }
     if (nsites * ltau > (int64_t)1 << 30) { elph_set_error("ndim too large"); return ELPH_E_UNSUPPORTED; }
+    if (ltau > 1024) { elph_set_error("ltau=%lld > 1024: the direct-DFT twiddle tables are O(L^2); a mixed-radix FFT is not built yet", (long long)ltau); return ELPH_E_UNSUPPORTED; }
     if (nbonds > 0 && !neighbor_table) { elph_set_error("neighbor_table is null"); return ELPH_E_ARG; }
     if (kind == ELPH_MODEL_HOLSTEIN && nbonds > 0 && (!cosht || !sinht)) { elph_set_error("cosht/sinht null"); return ELPH_E_ARG; }
     for (int64_t n = 0; n < nbonds; ++n) {
@@ -266,6 +274,7 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
             return fail(ELPH_E_HIP);
         }
     }
+    if ((rc = elph_dft_build_tables(h))) return fail(rc);
     if ((rc = build_lane_program(h))) return fail(rc);
     if ((rc = upload_lp_cs(h))) return fail(rc);
     if ((rc = ensure_capacity(h, 1))) return fail(rc);
@@ -283,7 +292,7 @@ extern "C" int elph_destroy(elph_handle h) {
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_params,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
-                    h->d_lp_sbar};
+                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);

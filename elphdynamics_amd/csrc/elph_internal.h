@@ -171,6 +171,8 @@ struct elph_handle_s {
     // FFT twiddles
     double2 *d_tw = nullptr;               // [L] exp(-2 pi i k / L)
     double2 *d_theta = nullptr;            // [L] exp(-i pi t / L)
+    double2 *d_Tk = nullptr, *d_Tt = nullptr;   // twisted DFT tables [Lo2][L] / [L][Lo2] (dft.hip)
+    double2 *d_Pk = nullptr, *d_Pt = nullptr;   // plain DFT tables   [Lh][L]  / [L][Lh]
     double *d_diag = nullptr;              // fourier-acceleration diagonal staging
     int64_t diag_cap = 0;
     std::vector<int> fft_radices;
@@ -202,6 +204,13 @@ int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
 // packs per-bond values (order of h_bi/h_bj) into the lane-program layout [NE][64] (idle slots = fill)
 void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill);
+
+// ---- tau-axis transforms (dft.hip) -------------------------------------------------------------
+int elph_dft_build_tables(elph_handle_s *h);
+int elph_dft_fwd_twisted(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st);
+int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,
+                         const double *rvec, double *rz_part, int nrz);
+int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u);
 
 // ---- host-side KPM setup (kpm_host.cpp) ---------------------------------------------------
 void elph_kpm_coefficients(double *c_z, int order, double lam_lo, double lam_hi, double phi);

@@ -746,12 +746,25 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb(double2 *__restrict__ nu, Kpm
 }
 
 // Ebar[i] = mean_tau E[tau][i]  (update_A!, KPMPreconditioners.jl:332-349)
-__global__ void k_ebar(double *__restrict__ Ebar, const double *__restrict__ E, int N, int L) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= N) return;
-    double a = 0.0;
-    for (int t = 0; t < L; ++t) a += E[(size_t)t * N + s];
-    Ebar[s] = a / (double)L;
+// block = 64 sites x 4 tau-phases; each thread sums every 4th slice with 4 independent accumulators
+// (loads in flight instead of one dependent chain), phases combined through LDS.
+__global__ void __launch_bounds__(256) k_ebar(double *__restrict__ Ebar, const double *__restrict__ E, int N, int L) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int s = blockIdx.x * 64 + lane;
+    const int sc = (s < N) ? s : N - 1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int t = ph;
+    for (; t + 12 < L; t += 16) {
+        a0 += E[(size_t)t * N + sc];
+        a1 += E[(size_t)(t + 4) * N + sc];
+        a2 += E[(size_t)(t + 8) * N + sc];
+        a3 += E[(size_t)(t + 12) * N + sc];
+    }
+    for (; t < L; t += 4) a0 += E[(size_t)t * N + sc];
+    part[ph][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ph == 0 && s < N) Ebar[s] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (double)L;
 }
 
 __global__ void k_copy(double *__restrict__ dst, const double *__restrict__ src, long long n) {
@@ -878,7 +891,7 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
 }
 
 int elph_launch_ebar(elph_handle_s *h) {
-    hipLaunchKernelGGL(k_ebar, dim3((unsigned)((h->N + 63) / 64)), dim3(64), 0, h->stream, h->d_Ebar, h->d_E,
+    hipLaunchKernelGGL(k_ebar, dim3((unsigned)((h->N + 63) / 64)), dim3(256), 0, h->stream, h->d_Ebar, h->d_E,
                        (int)h->N, (int)h->L);
     return check_launch("k_ebar");
 }
@@ -901,10 +914,11 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     }
     KpmDev K = elph_kpm_dev(h);
     ModelDev m = elph_model_dev(h);
-    const int nst = (N + WAVE - 1) / WAVE;
-    constexpr int KPT = 2, TPT = 2;
-    hipLaunchKernelGGL((k_dft_fwd_twisted<KPT>), dim3((unsigned)nst, (unsigned)((Lo2 + KPT - 1) / KPT), (unsigned)nrhs),
-                       dim3(WAVE), 0, h->stream, h->d_nu, rS, h->d_theta /* tw2 */, N, L, Lo2, st);
+
+    {
+        int rcd = elph_dft_fwd_twisted(h, h->d_nu, rS, N, nrhs, st);
+        if (rcd) return rcd;
+    }
     const size_t shm = (size_t)N * sizeof(double2);
     if (h->fast) {
         int rcf = elph_fast_kpm_cheb(h, nrhs, st);
@@ -917,9 +931,10 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     }
     // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz
     if (cg_mode) HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
-    hipLaunchKernelGGL((k_dft_inv_twisted<TPT>), dim3((unsigned)nst, (unsigned)((L + TPT - 1) / TPT), (unsigned)nrhs),
-                       dim3(WAVE), 0, h->stream, zS, h->d_nu, h->d_theta, N, L, Lo2, st, cg_mode ? rS : nullptr,
-                       cg_mode ? B.rz : nullptr, B.nrz);
+    {
+        int rcd = elph_dft_inv_twisted(h, zS, h->d_nu, N, nrhs, st, cg_mode ? rS : nullptr, cg_mode ? B.rz : nullptr, B.nrz);
+        if (rcd) return rcd;
+    }
     return check_launch("kpm apply");
 }
 
@@ -1036,10 +1051,11 @@ int elph_launch_residual(elph_handle_s *h, int nrhs) {
 
 int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS_full, const double *vS) {
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
-    const int nst = (N + WAVE - 1) / WAVE;
-    constexpr int KPT = 2;
-    hipLaunchKernelGGL((k_dft_fwd_twisted<KPT>), dim3((unsigned)nst, (unsigned)((Lo2 + KPT - 1) / KPT), 1), dim3(WAVE), 0,
-                       h->stream, h->d_nu, vS, h->d_theta, N, L, Lo2, (const CgState *)nullptr);
+
+    {
+        int rcd = elph_dft_fwd_twisted(h, h->d_nu, vS, N, 1, nullptr);
+        if (rcd) return rcd;
+    }
     const long long n = (long long)N * L;
     hipLaunchKernelGGL(k_expand_spectrum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, nuS_full, h->d_nu, N,
                        L, Lo2);
@@ -1056,13 +1072,5 @@ int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS_fu
 
 int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power,
                           int64_t ncol) {
-    const int N = (int)ncol, L = (int)h->L, Lh = L / 2 + 1;
-    const int nst = (N + WAVE - 1) / WAVE;
-    constexpr int KPT = 2, TPT = 2;
-    double2 *u = h->d_nu;   // capacity checked by the caller
-    hipLaunchKernelGGL((k_dft_fwd_plain<KPT>), dim3((unsigned)nst, (unsigned)((Lh + KPT - 1) / KPT), 1), dim3(WAVE), 0,
-                       h->stream, u, inS, diagS, power, h->d_tw, N, L, Lh);
-    hipLaunchKernelGGL((k_dft_inv_plain<TPT>), dim3((unsigned)nst, (unsigned)((L + TPT - 1) / TPT), 1), dim3(WAVE), 0,
-                       h->stream, outS, u, h->d_tw, N, L, Lh);
-    return check_launch("fourier_accelerate");
+    return elph_dft_accel(h, outS, inS, diagS, power, (int)ncol, h->d_nu);
 }

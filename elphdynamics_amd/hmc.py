@@ -1,0 +1,112 @@
+"""Immediate callers of the solve, mirrored on top of the GPU operator API.
+
+    update_Lambda_(Lam, model)                     HMC.jl:921-941
+    mulLambda_(out, v, Lam, model)                 HMC.jl:951-968
+    mulLambdaInv_(out, v, Lam, model)              HMC.jl:978-995
+    calc_OinvLambda_phi(model, phi_p, phi_m, ...)  HMC.jl:820-915   (the 2 CG solves of every force evaluation)
+    GreensEstimator.update_(model, P, rng)         GreensFunctions.jl:201-234
+    GreensEstimator.estimate(i, j, tau2, tau1)     GreensFunctions.jl:334-346
+
+The two pseudofermion solves (and the n_v measurement solves) share one fermion matrix, so they go to
+the GPU as ONE batched ldiv!; each right-hand side still follows the single-RHS recurrences and stop rule,
+so the results are bit-identical to the reference's sequential solves on the same inputs.
+The O(Ndim) diagonal Lambda operations stay on the host for now (SURVEY §8f-1 moves them to the device).
+"""
+import numpy as np
+
+from . import models
+from . import preconditioners as pc
+
+
+def update_Lambda_(Lam, model):
+    """Lambda[i,tau] = exp(-dtau (lambda_i x + lambda2_i x^2)/2); identity for SSH (HMC.jl:921-946)."""
+    if model.kind == models.SSH:
+        Lam[:] = 1.0
+        return
+    X = model.x.reshape(model.Nph, model.Ltau)
+    Lam[:] = np.exp(-model.dtau * (model.lam[:, None] * X + model.lam2[:, None] * X ** 2) / 2).reshape(-1)
+
+
+def mulLambda_(out, v, Lam, model):
+    """(Lambda v)[tau] = -Lambda[tau+1] v[tau+1], (Lambda v)[L] = Lambda[1] v[1]; no-op copy for SSH (HMC.jl:951-973)."""
+    if model.kind == models.SSH:
+        return
+    N, L = model.Nsites, model.Ltau
+    u, La, o = v.reshape(N, L), Lam.reshape(N, L), out.reshape(N, L)
+    u1 = u[:, 0].copy()
+    o[:, :L - 1] = -La[:, 1:] * u[:, 1:]
+    o[:, L - 1] = La[:, 0] * u1
+
+
+def mulLambdaInv_(out, v, Lam, model):
+    """HMC.jl:978-995."""
+    if model.kind == models.SSH:
+        return
+    N, L = model.Nsites, model.Ltau
+    u, La, o = v.reshape(N, L), Lam.reshape(N, L), out.reshape(N, L)
+    uL = u[:, L - 1].copy()
+    o[:, 1:] = -(1.0 / La[:, 1:]) * u[:, :L - 1]
+    o[:, 0] = (1.0 / La[:, 0]) * uL
+
+
+def calc_OinvLambda_phi(model, phi_p, phi_m, P=None, power=1.0, rng=None, setup_kwargs=None):
+    """calc_O⁻¹Λϕ!(hmc, model, P, power) -> (O⁻¹Λϕ₊, O⁻¹Λϕ₋, iters, flag)   (HMC.jl:820-915).
+
+    tol is raised to `power` for the duration of the call (:827-828, restored :912), setup!(P) runs first (:834),
+    the reported iteration count is cld(total, 2) when both solves converged (:907-909), and a failed first
+    solve suppresses the second (:880): its output stays zero."""
+    tol = model.solver.tol
+    model.solver.tol = tol ** power
+    try:
+        pc.setup_(P, rng=rng, **(setup_kwargs or {}))
+        Lam = np.empty(model.Ndim)
+        update_Lambda_(Lam, model)
+        B = np.empty((2, model.Ndim))
+        if model.kind == models.SSH:
+            B[0], B[1] = phi_p, phi_m        # mulΛ! is a no-op for SSH: Λϕ buffers hold what the caller put there
+        else:
+            mulLambda_(B[0], phi_p, Lam, model)
+            mulLambda_(B[1], phi_m, Lam, model)
+        X = np.zeros((2, model.Ndim))        # fill!(O⁻¹Λϕ, 0)  (:854, :883)
+        it, res, fl = models.ldiv_batched_(X, model, B, P=P)
+        flag = int(fl[0])
+        iters = int(it[0])
+        if flag == 0:
+            iters += int(it[1])
+            flag = int(fl[1])
+        else:
+            X[1] = 0.0
+        if flag == 0:
+            iters = -(-iters // 2)           # cld(iters, 2)
+        return X[0], X[1], iters, flag
+    finally:
+        model.solver.tol = tol
+
+
+class GreensEstimator:
+    """EstimateGreensFunction reduced to the solve it drives (GreensFunctions.jl:23-196 state, :201-234 update!)."""
+
+    def __init__(self, model, nv=10):
+        self.model, self.nv, self.L = model, int(nv), model.Ltau
+        self.R = np.zeros((self.nv, model.Ndim))
+        self.MinvR = np.zeros((self.nv, model.Ndim))
+
+    def update_(self, P=None, rng=None, R=None, setup_kwargs=None):
+        """n_v random vectors r, solve MtM x = Mt r  =>  x = M^-1 r, as one batch (GreensFunctions.jl:208-231)."""
+        m = self.model
+        pc.setup_(P, rng=rng, **(setup_kwargs or {}))
+        if R is None:
+            rng = rng or np.random.default_rng()
+            R = rng.standard_normal((self.nv, m.Ndim))
+        self.R[:] = R
+        B = np.empty_like(self.R)
+        for i in range(self.nv):
+            models.mulMt_(B[i], m, np.ascontiguousarray(self.R[i]))      # Mᵀr₁ (model.v″, :223-224)
+        self.MinvR[:] = 0.0
+        return models.ldiv_batched_(self.MinvR, m, B, P=P)
+
+    def estimate(self, i, j, tau2, tau1, n=0):
+        """G_ij(tau2, tau1) ~ (M^-1 r)[idx(tau2,i)] * r[idx(tau1,j)]  (1-based i, j, tau as in :334-346)."""
+        mm = (j - 1) * self.L + (tau1 - 1)
+        nn = (i - 1) * self.L + (tau2 - 1)
+        return self.MinvR[n, nn] * self.R[n, mm]

@@ -422,3 +422,63 @@ def test_error_paths(lib):
     assert rel(m2.op("elph_mulM", g["v"]), orc.mulM(om, np.ascontiguousarray(g["v"]))) < 1e-13
     assert rel(m2.op("elph_mulMTM", g["v"]), orc.mulMTM(om, np.ascontiguousarray(g["v"]))) < 1e-13
     m2.close()
+
+
+# ------------------------------------------------------------------------------------------ callers (a22, a23)
+
+def test_calc_OinvLambda_phi_vs_oracle(oracle):
+    """HMC.calc_O⁻¹Λϕ! (HMC.jl:820-915): Λ construction, the two solves as one batch, tol^power, cld(iters,2)."""
+    from elphdynamics_amd import configs, hmc, synth
+    from oracle.oracle import dp
+    m = configs.make_model("B", tol=1e-4)
+    om = _oracle_model(oracle, m)
+    N, L, n = m.Nsites, m.Ltau, m.Ndim
+    phi_p, phi_m = synth.randn(301, n), synth.randn(302, n)
+    Lam = np.zeros(n)
+    oracle.lib.elpho_update_Lambda(dp(Lam), N, L, m.dtau, dp(m.x), dp(m.lam), dp(m.lam2))
+    Lg = np.empty(n)
+    hmc.update_Lambda_(Lg, m)
+    assert rel(Lg, Lam) < 1e-15
+    tot, xs = 0, []
+    for phi in (phi_p, phi_m):
+        b = np.zeros(n)
+        oracle.lib.elpho_mulLambda(dp(b), dp(phi), dp(Lam), N, L)
+        bg = np.empty(n)
+        hmc.mulLambda_(bg, phi, Lg, m)
+        assert rel(bg, b) < 1e-15
+        back = np.empty(n)
+        hmc.mulLambdaInv_(back, bg, Lg, m)
+        assert rel(back, phi) < 1e-14
+        x, it, res, fl = oracle.ldiv(om, b, solver_tol=(1e-4) ** 2.0, solver_maxiter=10000)
+        assert fl == 0
+        tot += it
+        xs.append(x)
+    Xp, Xm, iters, flag = hmc.calc_OinvLambda_phi(m, phi_p, phi_m, None, power=2.0)
+    assert flag == 0 and abs(iters - (-(-tot // 2))) <= 1
+    assert rel(Xp, xs[0]) < 1e-6 and rel(Xm, xs[1]) < 1e-6        # both within tol^2 = 1e-8 of the same solution
+    assert m.solver.tol == 1e-4                                    # restored (HMC.jl:912)
+    m.close()
+
+
+def test_greens_estimator_vs_oracle(oracle):
+    """GreensFunctions.update!/estimate (:201-234,:334-346): M^-1 R for n_v vectors, G = (M^-1 r)[n] r[m]."""
+    from elphdynamics_amd import configs, hmc, synth
+    m = configs.make_model("b", tol=1e-11)
+    om = _oracle_model(oracle, m)
+    est = hmc.GreensEstimator(m, nv=3)
+    R = np.stack([synth.randn(900 + i, m.Ndim) for i in range(3)])
+    it, res, fl = est.update_(None, R=R)
+    assert not fl.any()
+    for i in range(3):
+        r = np.ascontiguousarray(R[i])
+        xo, ito, reso, flo = oracle.ldiv(om, oracle.mulMT(om, r), solver_tol=1e-11, solver_maxiter=10000)
+        assert rel(est.MinvR[i], xo) < 1e-9
+    g = est.estimate(2, 3, 4, 5, n=1)
+    L = m.Ltau
+    assert g == est.MinvR[1, (2 - 1) * L + 3] * R[1, (3 - 1) * L + 4]
+    # a Green's-function element averaged over vectors agrees with the oracle's to 1e-9 relative to its scale
+    go = np.mean([oracle.ldiv(om, oracle.mulMT(om, np.ascontiguousarray(R[i])), solver_tol=1e-11, solver_maxiter=10000)[0][(2 - 1) * L + 3]
+                  * R[i, (3 - 1) * L + 4] for i in range(3)])
+    gg = np.mean([est.estimate(2, 3, 4, 5, n=i) for i in range(3)])
+    assert abs(gg - go) < 1e-9 * max(1.0, abs(go))
+    m.close()
