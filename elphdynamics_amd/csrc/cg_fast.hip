@@ -14,9 +14,36 @@
 //
 // Reference semantics: see kernels.hip / SURVEY.md Appendix A.
 
+#include <cstdlib>
+
 #include "elph_internal.h"
 
 #define WAVE ELPH_WAVE
+
+// Ordering of LDS traffic inside ONE wavefront.  Every slab in this file is private to a wave, and the LDS
+// pipeline executes a wave's DS instructions in issue order, so a ds_read issued after a ds_write of the same
+// wave observes it without any s_waitcnt/s_barrier in between.  All that is needed is that the COMPILER keeps
+// the program order of possibly-aliasing LDS accesses: a pure compiler barrier, no instruction.
+// (Using __syncthreads() here costs an s_waitcnt lgkmcnt(0) per colour: one extra LDS round trip per stage.)
+#ifdef ELPH_LDS_SYNC
+#define WAVE_LDS_ORDER() __syncthreads()
+#else
+#define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
+#endif
+
+// device-coherent scalar traffic (experiment): agent-scope relaxed atomics => sc1 loads/stores that bypass L1/K$
+__device__ __forceinline__ double ld_coh(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ CgState ld_state(const CgState *p) {
+    CgState s;
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    unsigned long long w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_memcpy(&s, w, sizeof(CgState));
+    return s;
+}
 
 __device__ __forceinline__ double wave_sum2(double v) {
 #pragma unroll
@@ -26,7 +53,7 @@ __device__ __forceinline__ double wave_sum2(double v) {
 
 __device__ __forceinline__ double reduce_partials2(const double *p, int n) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += WAVE) a += p[i];
+    for (int i = threadIdx.x; i < n; i += WAVE) a += ld_coh(p + i);
     return wave_sum2(a);
 }
 
@@ -98,7 +125,7 @@ __device__ __forceinline__ void lp_sweep(double *buf0, double *buf1, const unsig
                     buf1[j] = c1[e] * b1[pp] + s1[e] * b0[pp];
                 }
             }
-            __syncthreads();
+            WAVE_LDS_ORDER();
         }
     }
 }
@@ -150,14 +177,14 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
     if (WHICH == 0) {
 #pragma unroll
         for (int q = 0; q < NPL; ++q) bufA[threadIdx.x + q * WAVE] = e0[q] * vm[q];
-        __syncthreads();
+        WAVE_LDS_ORDER();
         lp_sweep<NPL, 1, false>(bufA, nullptr, ij, c0, s0, c0, s0, m.ncol);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; if (s < N) yy[(size_t)t * N + s] = v0[q] - sg0 * bufA[s]; }
     } else if (WHICH == 1) {
 #pragma unroll
         for (int q = 0; q < NPL; ++q) bufA[threadIdx.x + q * WAVE] = vp[q];
-        __syncthreads();
+        WAVE_LDS_ORDER();
         if (SSH) lp_sweep<NPL, 1, true>(bufA, nullptr, ij, c1, s1, c1, s1, m.ncol);
         else lp_sweep<NPL, 1, true>(bufA, nullptr, ij, c0, s0, c0, s0, m.ncol);
 #pragma unroll
@@ -169,7 +196,7 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
             bufA[s] = e0[q] * vm[q];
             bufB[s] = e1[q] * v0[q];
         }
-        __syncthreads();
+        WAVE_LDS_ORDER();
         if (SSH) lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c1, s1, m.ncol);
         else lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c0, s0, m.ncol);
 #pragma unroll
@@ -178,7 +205,7 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
             w0[q] = v0[q] - sg0 * bufA[s];
             bufB[s] = vp[q] - sg1 * bufB[s];
         }
-        __syncthreads();
+        WAVE_LDS_ORDER();
         if (SSH) lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c1, s1, c1, s1, m.ncol);
         else lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c0, s0, c0, s0, m.ncol);
 #pragma unroll
@@ -190,6 +217,7 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
 // CG kernels (IterativeSolvers.jl:153-314); see kernels.hip for the protocol between them.
 // ------------------------------------------------------------------------------------------
 
+#define IS_LEADER (t == 0)
 template <int NPL, bool SSH>
 __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int parity) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -204,8 +232,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
 
     // ---- every global load of the kernel, none depending on another ---------------------------
     CgState *st2 = B.state + 2 * rhs;
-    const CgState Sa = st2[0], Sb = st2[1];
-    const CgParams P = *B.params;
+    const CgState S = ld_state(st2 + parity);        // this launch's copy; the other one is written below
+    const CgParams P = B.params;
     const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
     const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
     double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
@@ -235,11 +263,13 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
     const double rz = P.use_prec ? reduce_partials2(B.rz + (size_t)rhs * B.nrz, B.nrz) : rr;
 
     // ---- scalar control (identical in every wave of this rhs) ----------------------------------
-    const CgState S = (Sb.seq > Sa.seq) ? Sb : Sa;
-    if (S.done) return;
+    CgState *Sout = st2 + (parity ^ 1);
+    if (S.done) {                                     // keep both copies terminal: later launches alternate between them
+        if (IS_LEADER && threadIdx.x == 0) *Sout = S;
+        return;
+    }
     const long long seq = S.seq;
     const bool first = (seq == 0);
-    CgState *Sout = st2 + ((seq + 1) & 1);
     double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
     if (!first) {
         eps = sqrt(rr) / S.normb;
@@ -275,7 +305,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
         bufB[s] = e1[q] * p0[q];
         if (s < N) pnew[(size_t)t * N + s] = p0[q];
     }
-    __syncthreads();
+    WAVE_LDS_ORDER();
     const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
     if (SSH) lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c1, s1, m.ncol);
     else lp_sweep<NPL, 2, false>(bufA, bufB, ij, c0, s0, c0, s0, m.ncol);
@@ -285,7 +315,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
         w0[q] = p0[q] - sg0 * bufA[s];
         bufB[s] = pp[q] - sg1 * bufB[s];
     }
-    __syncthreads();
+    WAVE_LDS_ORDER();
     if (SSH) lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c1, s1, c1, s1, m.ncol);
     else lp_sweep<NPL, 1, true>(bufB, nullptr, ij, c0, s0, c0, s0, m.ncol);
     double acc = 0.0;
@@ -300,7 +330,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
     }
     acc = wave_sum2(acc);
     if (threadIdx.x == 0) {
-        B.pap[(size_t)rhs * L + t] = acc;
+        B.pap[(size_t)rhs * B.npap + t] = acc;
         if (t == 0) {
             CgState o = S;
             o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = 0;
@@ -309,13 +339,231 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
     }
 }
 
+#undef IS_LEADER
+#define IS_LEADER (ch == 0)
+// combined pass: forward sweep on bufA (slice tau+1) and reverse sweep on bufB (w(tau)) in the same 4 stages
+template <int NPL>
+__device__ __forceinline__ void lp_sweep_fr(double *bufA, double *bufB, const unsigned (&ij)[4 * ((NPL + 1) / 2)],
+                                            const double (&cA)[4 * ((NPL + 1) / 2)], const double (&sA)[4 * ((NPL + 1) / 2)],
+                                            const double (&cB)[4 * ((NPL + 1) / 2)], const double (&sB)[4 * ((NPL + 1) / 2)],
+                                            int ncol, bool doA) {
+    constexpr int PP = (NPL + 1) / 2;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int colA = cc, colB = 3 - cc;
+        const bool onA = doA && (colA < ncol), onB = (colB < ncol);
+        if (onA || onB) {
+            double a0[PP], a1[PP], b0[PP], b1[PP];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                if (onA) { const unsigned w = ij[colA * PP + pp]; a0[pp] = bufA[w & 0xFFFF]; a1[pp] = bufA[w >> 16]; }
+                if (onB) { const unsigned w = ij[colB * PP + pp]; b0[pp] = bufB[w & 0xFFFF]; b1[pp] = bufB[w >> 16]; }
+            }
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                if (onA) {
+                    const int e = colA * PP + pp; const unsigned w = ij[e];
+                    bufA[w & 0xFFFF] = cA[e] * a0[pp] + sA[e] * a1[pp];
+                    bufA[w >> 16] = cA[e] * a1[pp] + sA[e] * a0[pp];
+                }
+                if (onB) {
+                    const int e = colB * PP + pp; const unsigned w = ij[e];
+                    bufB[w & 0xFFFF] = cB[e] * b0[pp] + sB[e] * b1[pp];
+                    bufB[w >> 16] = cB[e] * b1[pp] + sB[e] * b0[pp];
+                }
+            }
+            WAVE_LDS_ORDER();
+        }
+    }
+}
+
+// Batched-throughput variant of k_cg_ap_fast: one wave owns T consecutive tau-slices of one right-hand side.
+//   w(t) = p(t) - sg(t) CB_t [E(t) .* p(t-1)]            needs T+1 forward sweeps  (t = t0 .. t0+T)
+//   z(t) = w(t) - sg(t+1) E(t+1) .* CB_{t+1}^T w(t+1)    needs T   reverse sweeps
+// The reverse sweep of w(t0+j) and the forward sweep of slice t0+j+1 run in the SAME four colour stages
+// (independent LDS slabs), so a slice costs 4 stages instead of 8 and ~3 slice loads instead of 8; the next
+// slice's loads are issued one stage ahead.  Results are bit-identical to the T=1 kernel (same operations per
+// element, same order), only the p.z partial sums are grouped per chunk instead of per slice.
+template <int NPL, int T, bool SSH>
+__global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int parity) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+    double *bufA = lds, *bufB = lds + slab_len<NPL>();
+    const int N = m.N, L = m.L;
+    const int nch = L / T;
+    const int rhs = blockIdx.x / nch, ch = blockIdx.x - rhs * nch;
+    const int t0 = ch * T;
+    const size_t ndim = (size_t)N * L;
+    auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
+
+    CgState *st2 = B.state + 2 * rhs;
+    const CgState S = ld_state(st2 + parity);        // this launch's copy; the other one is written below
+    const CgParams P = B.params;
+    const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
+    const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
+    double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
+    double *z = B.z + (size_t)rhs * ndim;
+
+    int sc[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; sc[q] = (s < N) ? s : N - 1; }
+    auto load_sq = [&](int t, double (&sv)[NPL], double (&qv)[NPL]) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const size_t i = (size_t)t * N + sc[q]; sv[q] = src[i]; qv[q] = pold[i]; }
+    };
+    auto load_e = [&](int t, double (&ev)[NPL]) {
+        const double *Et = m.E + (size_t)t * m.E_tau_stride;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) ev[q] = Et[sc[q]];
+    };
+
+    // ---- prologue loads (independent of everything) ----------------------------------------------
+    double Sm[NPL], Qm[NPL], S0[NPL], Q0[NPL], S1[NPL], Q1[NPL], E0[NPL], E1[NPL];
+    load_sq(wrap(t0 - 1), Sm, Qm);
+    load_sq(t0, S0, Q0);
+    load_sq(wrap(t0 + 1), S1, Q1);
+    load_e(t0, E0);
+    load_e(wrap(t0 + 1), E1);
+    unsigned ij[NE];
+    double cA[NE], sA[NE], cB[NE], sB[NE];
+    lp_load_ij<NPL>(ij, m);
+    if (SSH) {
+        lp_load_cs<NPL>(cA, sA, m.lp_c + (size_t)t0 * m.lp_tau_stride, m.lp_s + (size_t)t0 * m.lp_tau_stride);
+        lp_load_cs<NPL>(cB, sB, m.lp_c + (size_t)wrap(t0 + 1) * m.lp_tau_stride, m.lp_s + (size_t)wrap(t0 + 1) * m.lp_tau_stride);
+    } else {
+        lp_load_cs<NPL>(cA, sA, m.lp_c, m.lp_s);
+    }
+    const double rr = reduce_partials2(B.rr + (size_t)rhs * L, L);
+    const double rz = P.use_prec ? reduce_partials2(B.rz + (size_t)rhs * B.nrz, B.nrz) : rr;
+
+    // ---- scalar control (identical in every wave of this rhs; same code as k_cg_ap_fast) -----------
+    CgState *Sout = st2 + (parity ^ 1);
+    if (S.done) {                                     // keep both copies terminal: later launches alternate between them
+        if (IS_LEADER && threadIdx.x == 0) *Sout = S;
+        return;
+    }
+    const long long seq = S.seq;
+    const bool first = (seq == 0);
+    double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
+    if (!first) {
+        eps = sqrt(rr) / S.normb;
+        const double qq = 2.0 * (double)seq / log(2.0 * S.eps0 / eps);
+        const double val = qq * qq;
+        kmin = (val > kmin) ? val : kmin;
+        int done = 0;
+        if (eps < P.tol) done = 1;
+        else if (kmin > P.kmax) done = 2;
+        else if (seq >= P.maxiter) done = 3;
+        if (ch == 0 && threadIdx.x == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + seq] = eps;
+        if (done) {
+            if (ch == 0 && threadIdx.x == 0) {
+                CgState o = S;
+                o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = done;
+                *Sout = o;
+            }
+            return;
+        }
+        beta = rz / S.rho;
+        rho = rz;
+    }
+    auto pval = [&](double sv, double qv) { return first ? qv : sv + beta * qv; };
+    auto sgn = [](int t) { return (t == 0) ? -1.0 : 1.0; };
+
+    // ---- prologue: w(t0), w(t0+1) by one two-slab forward sweep --------------------------------------
+    double pprev[NPL], pcur[NPL], wprev[NPL], wcur[NPL], Ecur[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * WAVE;
+        const double pm = pval(Sm[q], Qm[q]);
+        pprev[q] = pval(S0[q], Q0[q]);
+        pcur[q] = pval(S1[q], Q1[q]);
+        bufA[s] = E0[q] * pm;
+        bufB[s] = E1[q] * pprev[q];
+        Ecur[q] = E1[q];
+        if (s < N) pnew[(size_t)t0 * N + s] = pprev[q];
+    }
+    WAVE_LDS_ORDER();
+    if (SSH) lp_sweep<NPL, 2, false>(bufA, bufB, ij, cA, sA, cB, sB, m.ncol);
+    else lp_sweep<NPL, 2, false>(bufA, bufB, ij, cA, sA, cA, sA, m.ncol);
+    {
+        const double sga = sgn(t0), sgb = sgn(wrap(t0 + 1));
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            wprev[q] = pprev[q] - sga * bufA[s];
+            wcur[q] = pcur[q] - sgb * bufB[s];
+        }
+    }
+    WAVE_LDS_ORDER();
+
+    // ---- pipelined stages: reverse sweep of w(t0+j)  ||  forward sweep of slice t0+j+1 ---------------
+    double acc = 0.0;
+    double Sn[NPL], Qn[NPL], En[NPL];
+    if (T > 1) { load_sq(wrap(t0 + 2), Sn, Qn); load_e(wrap(t0 + 2), En); }
+#pragma unroll
+    for (int j = 1; j <= T; ++j) {
+        const int tj = wrap(t0 + j);              // slice whose w is reverse-swept now
+        const int tn = wrap(t0 + j + 1);          // slice forward-swept now (if j < T)
+        const bool more = (j < T);
+        if (SSH) {
+            // B-side tables: slice tj (they were the A/B tables of the previous stage); A-side: slice tn
+            lp_load_cs<NPL>(cB, sB, m.lp_c + (size_t)tj * m.lp_tau_stride, m.lp_s + (size_t)tj * m.lp_tau_stride);
+            if (more) lp_load_cs<NPL>(cA, sA, m.lp_c + (size_t)tn * m.lp_tau_stride, m.lp_s + (size_t)tn * m.lp_tau_stride);
+        }
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            bufB[s] = wcur[q];
+            if (more) bufA[s] = En[q] * pcur[q];          // E(tn) .* p(tj)
+        }
+        WAVE_LDS_ORDER();
+        if (SSH) lp_sweep_fr<NPL>(bufA, bufB, ij, cA, sA, cB, sB, m.ncol, more);
+        else lp_sweep_fr<NPL>(bufA, bufB, ij, cA, sA, cA, sA, m.ncol, more);
+        const double sgj = sgn(tj), sgnn = sgn(tn);
+        double pnext[NPL], wnext[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            const double zz = wprev[q] - sgj * Ecur[q] * bufB[s];        // z(t0+j-1)
+            if (s < N) {
+                z[(size_t)wrap(t0 + j - 1) * N + s] = zz;
+                acc += pprev[q] * zz;
+            }
+            if (more) {
+                pnext[q] = pval(Sn[q], Qn[q]);                           // p(tn)
+                wnext[q] = pnext[q] - sgnn * bufA[s];                    // w(tn)
+                if (s < N) pnew[(size_t)tj * N + s] = pcur[q];
+            }
+        }
+        WAVE_LDS_ORDER();
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                wprev[q] = wcur[q]; wcur[q] = wnext[q];
+                pprev[q] = pcur[q]; pcur[q] = pnext[q];
+                Ecur[q] = En[q];
+            }
+            if (j + 1 < T) { load_sq(wrap(t0 + j + 2), Sn, Qn); load_e(wrap(t0 + j + 2), En); }
+        }
+    }
+    acc = wave_sum2(acc);
+    if (threadIdx.x == 0) {
+        B.pap[(size_t)rhs * B.npap + ch] = acc;
+        if (ch == 0) {
+            CgState o = S;
+            o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = 0;
+            *Sout = o;
+        }
+    }
+}
+
+#undef IS_LEADER
 template <int NPL>
 __global__ void __launch_bounds__(WAVE) k_cg_xr_fast(CgBufs B, int N, int L, int parity) {
     int t, rhs;
     if (!xcd_map(L, t, rhs)) return;
     const size_t ndim = (size_t)N * L;
-    const CgState *st2 = B.state + 2 * rhs;
-    const CgState Sa = st2[0], Sb = st2[1];
+    const CgState S = ld_state(B.state + 2 * rhs + parity);   // written by the k_cg_ap launch just before
     const double *p = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
     const double *z = B.z + (size_t)rhs * ndim;
     double *x = B.x + (size_t)rhs * ndim, *r = B.r + (size_t)rhs * ndim;
@@ -326,8 +574,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_xr_fast(CgBufs B, int N, int L, int
         const size_t i = (size_t)t * N + ((s < N) ? s : N - 1);
         xv[q] = x[i]; pv[q] = p[i]; rv[q] = r[i]; zv[q] = z[i];
     }
-    const double pap = reduce_partials2(B.pap + (size_t)rhs * L, L);
-    const CgState S = (Sb.seq > Sa.seq) ? Sb : Sa;
+    const double pap = reduce_partials2(B.pap + (size_t)rhs * B.npap, B.npap);
     if (S.done) return;
     const double alpha = S.rho / pap;
     double acc = 0.0;
@@ -372,7 +619,7 @@ __device__ __forceinline__ void lp_sweep_z(double2 *buf, const unsigned (&ij)[4 
                 buf[w & 0xFFFF] = make_double2(c[e] * a0[pp].x + s[e] * a1[pp].x, c[e] * a0[pp].y + s[e] * a1[pp].y);
                 buf[w >> 16] = make_double2(c[e] * a1[pp].x + s[e] * a0[pp].x, c[e] * a1[pp].y + s[e] * a0[pp].y);
             }
-            __syncthreads();
+            WAVE_LDS_ORDER();
         }
     }
 }
@@ -396,7 +643,7 @@ __device__ __forceinline__ void kpm_series_fast(double2 (&acc)[NPL], const doubl
 #pragma unroll
         for (int q = 0; q < NPL; ++q)
             buf[threadIdx.x + q * WAVE] = TRANSPOSED ? un[q] : make_double2(eb[q] * un[q].x, eb[q] * un[q].y);
-        __syncthreads();
+        WAVE_LDS_ORDER();
         lp_sweep_z<NPL, TRANSPOSED>(buf, ij, cb, sb, ncol);
         const double2 cn0 = c[n - 1];
         const double2 cn = make_double2(cn0.x, CONJ ? -cn0.y : cn0.y);
@@ -414,7 +661,7 @@ __device__ __forceinline__ void kpm_series_fast(double2 (&acc)[NPL], const doubl
             acc[q].x += cn.x * un[q].x - cn.y * un[q].y;
             acc[q].y += cn.x * un[q].y + cn.y * un[q].x;
         }
-        __syncthreads();
+        WAVE_LDS_ORDER();
     }
 }
 
@@ -425,10 +672,7 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb_fast(double2 *__restrict__ nu
     constexpr int NE = 4 * ((NPL + 1) / 2);
     double2 *buf = reinterpret_cast<double2 *>(lds);
     const int rhs = blockIdx.y;
-    if (state) {
-        const CgState Sa = state[2 * rhs], Sb = state[2 * rhs + 1];
-        if (((Sb.seq > Sa.seq) ? Sb : Sa).done) return;
-    }
+    if (state && ld_state(state + 2 * rhs).done) return;   // `state` points at the current copy (host adds the parity)
     const int w = K.wsched[blockIdx.x];
     const int N = m.N;
     const int order = K.order[w];
@@ -454,6 +698,140 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb_fast(double2 *__restrict__ nu
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
         if (s < N) u[s] = res[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// KPM Chebyshev recursion, re/im-split variant.
+// A' is real, so the real and the imaginary part of u_n obey the SAME real three-term recursion and never
+// mix; only the coefficient sums do.  One 128-thread workgroup per frequency block: wave 0 carries Re u,
+// wave 1 carries Im u, each in its own LDS slab (half the LDS bytes and half the instructions per wave of the
+// complex kernel), each accumulating P = sum cx_n u_n and Q = sum cy_n u_n; the halves are combined
+// through LDS once per series:
+//     conj coefficients (first series):  Re = P_re + Q_im,  Im = P_im - Q_re
+//     plain coefficients (second):       Re = P_re - Q_im,  Im = P_im + Q_re
+// LDS addresses of a lane's bonds are precomputed pointers (no per-access address arithmetic).
+// ------------------------------------------------------------------------------------------
+
+template <int NPL, bool REVERSE>
+__device__ __forceinline__ void lp_sweep_ptr(double *const (&pi)[4 * ((NPL + 1) / 2)], double *const (&pj)[4 * ((NPL + 1) / 2)],
+                                             const double (&c)[4 * ((NPL + 1) / 2)], const double (&s)[4 * ((NPL + 1) / 2)],
+                                             int ncol) {
+    constexpr int PP = (NPL + 1) / 2;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int col = REVERSE ? 3 - cc : cc;
+        if (col < ncol) {
+            double a0[PP], a1[PP];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) { a0[pp] = *pi[col * PP + pp]; a1[pp] = *pj[col * PP + pp]; }
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const int e = col * PP + pp;
+                *pi[e] = c[e] * a0[pp] + s[e] * a1[pp];
+                *pj[e] = c[e] * a1[pp] + s[e] * a0[pp];
+            }
+            WAVE_LDS_ORDER();
+        }
+    }
+}
+
+template <int NPL, bool TRANSPOSED>
+__device__ __forceinline__ void kpm_series_ri(double (&P)[NPL], double (&Q)[NPL], const double (&vin)[NPL], double *slab,
+                                              const double (&eb)[NPL], const double2 *c, int order, double a, double b,
+                                              double *const (&pi)[4 * ((NPL + 1) / 2)], double *const (&pj)[4 * ((NPL + 1) / 2)],
+                                              const double (&cb)[4 * ((NPL + 1) / 2)], const double (&sb)[4 * ((NPL + 1) / 2)],
+                                              int ncol) {
+    double um1[NPL], un[NPL];
+    const int lane = threadIdx.x & (WAVE - 1);
+    {
+        const double2 c0 = c[0];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            P[q] = c0.x * vin[q];
+            Q[q] = c0.y * vin[q];
+            un[q] = vin[q];
+            um1[q] = 0.0;
+        }
+    }
+    for (int n = 2; n <= order; ++n) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) slab[lane + q * WAVE] = TRANSPOSED ? un[q] : eb[q] * un[q];
+        WAVE_LDS_ORDER();
+        lp_sweep_ptr<NPL, TRANSPOSED>(pi, pj, cb, sb, ncol);
+        const double2 cn = c[n - 1];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            double av = slab[lane + q * WAVE];
+            if (TRANSPOSED) av *= eb[q];
+            double up = a * av - b * un[q];                    // A' u_n   (mulA'!, :685-693)
+            if (n > 2) up = 2.0 * up - um1[q];                 // u_{n+1} = 2 A' u_n - u_{n-1}
+            um1[q] = un[q];
+            un[q] = up;
+            P[q] += cn.x * up;
+            Q[q] += cn.y * up;
+        }
+        WAVE_LDS_ORDER();
+    }
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_ri(double2 *__restrict__ nu, KpmDev K, ModelDev m, int Lo2,
+                                                          const CgState *state) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+    constexpr int SL = slab_len<NPL>();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    double *slab = lds + wv * SL;                 // this wave's component slab
+    double *xch = lds + 2 * SL;                   // exchange area [2][NPL*64]
+    const int rhs = blockIdx.y;
+    if (state && ld_state(state + 2 * rhs).done) return;   // `state` points at the current copy (host adds the parity)
+    const int w = K.wsched[blockIdx.x];
+    const int N = m.N;
+    const int order = K.order[w];
+    const double2 *c = K.coeff + K.coff[w];
+    double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);    // interleaved re,im
+    double *pi[NE], *pj[NE];
+    double cb[NE], sb[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const unsigned ij = m.lp_ij[e * WAVE + lane];
+        pi[e] = slab + (ij & 0xFFFF);
+        pj[e] = slab + (ij >> 16);
+        cb[e] = K.lp_cbar[e * WAVE + lane];
+        sb[e] = K.lp_sbar[e * WAVE + lane];
+    }
+    double vin[NPL], eb[NPL], P[NPL], Q[NPL], mid[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = lane + q * WAVE;
+        const int sc = (s < N) ? s : N - 1;
+        vin[q] = u[2 * sc + wv];
+        eb[q] = K.Ebar[sc];
+    }
+    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+    // ---- first series: M^-T[w,w], conjugated coefficients (KPMPreconditioners.jl:621-648)
+    kpm_series_ri<NPL, true>(P, Q, vin, slab, eb, c, order, a, b, pi, pj, cb, sb, m.ncol);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) xch[wv * NPL * WAVE + lane + q * WAVE] = Q[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const double Qo = xch[(wv ^ 1) * NPL * WAVE + lane + q * WAVE];
+        mid[q] = (wv == 0) ? P[q] + Qo : P[q] - Qo;
+    }
+    __syncthreads();
+    // ---- second series: M^-1[w,w] (:650-677)
+    kpm_series_ri<NPL, false>(P, Q, mid, slab, eb, c, order, a, b, pi, pj, cb, sb, m.ncol);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) xch[wv * NPL * WAVE + lane + q * WAVE] = Q[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = lane + q * WAVE;
+        const double Qo = xch[(wv ^ 1) * NPL * WAVE + lane + q * WAVE];
+        const double res = (wv == 0) ? P[q] - Qo : P[q] + Qo;
+        if (s < N) u[2 * s + wv] = res;
     }
 }
 
@@ -503,11 +881,37 @@ int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int
     return check_launch_f("k_mul_fast");
 }
 
+// slices per wave for the batched kernel: the largest T in {8,4,2} dividing L that still leaves >= 1024 waves
+int elph_choose_T(const elph_handle_s *h, int nrhs) {
+    if (!h->fast || h->force_T == 1) return 1;
+    const int cand[3] = {8, 4, 2};
+    for (int T : cand) {
+        if (h->force_T > 1 && T != h->force_T) continue;
+        if (h->L % T) continue;
+        if (h->force_T > 1 || (int64_t)nrhs * (h->L / T) >= 1024) return T;
+    }
+    return 1;
+}
+
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
     ModelDev m = elph_model_dev(h);
     const size_t shm = 2 * (size_t)(h->npl * WAVE + 2 * WAVE) * sizeof(double);
-    const dim3 grid(xcd_grid(h, nrhs));
     const bool ssh = (h->kind == ELPH_MODEL_SSH);
+    const int T = (B.npap == (int)h->L) ? 1 : (int)(h->L / B.npap);
+    if (T > 1) {
+        const dim3 grid((unsigned)(nrhs * (h->L / T)));
+#define LAUNCH_CHUNK(TT)                                                                                           \
+        DISPATCH_NPL_F(h->npl, {                                                                                       \
+            if (ssh) hipLaunchKernelGGL((k_cg_ap_chunk<NPL, TT, true>), grid, dim3(WAVE), shm, h->stream, B, m, parity);  \
+            else hipLaunchKernelGGL((k_cg_ap_chunk<NPL, TT, false>), grid, dim3(WAVE), shm, h->stream, B, m, parity);     \
+        })
+        if (T == 8) { LAUNCH_CHUNK(8); }
+        else if (T == 4) { LAUNCH_CHUNK(4); }
+        else { LAUNCH_CHUNK(2); }
+#undef LAUNCH_CHUNK
+        return check_launch_f("k_cg_ap_chunk");
+    }
+    const dim3 grid(xcd_grid(h, nrhs));
     DISPATCH_NPL_F(h->npl, {
         if (ssh) hipLaunchKernelGGL((k_cg_ap_fast<NPL, true>), grid, dim3(WAVE), shm, h->stream, B, m, parity);
         else hipLaunchKernelGGL((k_cg_ap_fast<NPL, false>), grid, dim3(WAVE), shm, h->stream, B, m, parity);
@@ -527,10 +931,19 @@ int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     KpmDev K = elph_kpm_dev(h);
     ModelDev m = elph_model_dev(h);
     const int Lo2 = (int)((h->L + 1) / 2);
-    const size_t shm = (size_t)(h->npl * WAVE + 2 * WAVE) * sizeof(double2);
+    static const bool complex_variant = []() { const char *e = getenv("ELPH_CHEB_COMPLEX"); return e && e[0] == '1'; }();
+    if (complex_variant) {
+        const size_t shm = (size_t)(h->npl * WAVE + 2 * WAVE) * sizeof(double2);
+        DISPATCH_NPL_F(h->npl, {
+            hipLaunchKernelGGL((k_kpm_cheb_fast<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(WAVE), shm, h->stream, h->d_nu, K,
+                               m, Lo2, st);
+        });
+        return check_launch_f("k_kpm_cheb_fast");
+    }
+    const size_t shm = (size_t)(2 * (h->npl * WAVE + 2 * WAVE) + 2 * h->npl * WAVE) * sizeof(double);
     DISPATCH_NPL_F(h->npl, {
-        hipLaunchKernelGGL((k_kpm_cheb_fast<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(WAVE), shm, h->stream, h->d_nu, K,
-                           m, Lo2, st);
+        hipLaunchKernelGGL((k_kpm_cheb_ri<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(2 * WAVE), shm, h->stream, h->d_nu, K, m,
+                           Lo2, st);
     });
-    return check_launch_f("k_kpm_cheb_fast");
+    return check_launch_f("k_kpm_cheb_ri");
 }

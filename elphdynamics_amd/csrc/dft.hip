@@ -25,10 +25,10 @@ __device__ __forceinline__ double dft_wave_sum(double v) {
     return v;
 }
 
+// `state` (optional) points at the CURRENT copy of the CG state (the host adds the launch parity)
 __device__ __forceinline__ bool dft_done(const CgState *state, int rhs) {
     if (!state) return false;
-    const CgState a = state[2 * rhs], b = state[2 * rhs + 1];
-    return ((b.seq > a.seq) ? b : a).done != 0;
+    return __hip_atomic_load(&state[2 * rhs].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // out[k][s] = f(k,s) * sum_t Tk[k][t] * v[t][s]      k in [0,K), real v

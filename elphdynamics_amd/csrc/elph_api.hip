@@ -82,6 +82,13 @@ void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, d
 static int build_lane_program(elph_handle_s *h) {
     const int PP = (h->npl + 1) / 2, NE = 4 * PP;
     h->lp_ne = NE;
+    const char *ci = getenv("ELPH_CHUNK_ITERS");
+    h->chunk = ci ? atoi(ci) : ELPH_CG_CHUNK;
+    if (h->chunk < 2 || (h->chunk & 1)) h->chunk = ELPH_CG_CHUNK;   // must be even (ping-pong parity)
+    const char *co = getenv("ELPH_DBG_COPY_OUTSIDE");
+    h->dbg_copy_outside = (co && co[0] == '1');
+    const char *ct = getenv("ELPH_CHUNK_T");
+    h->force_T = ct ? atoi(ct) : 0;
     const char *nf = getenv("ELPH_NO_FAST");
     h->fast = (h->ncol <= 4) && !(nf && nf[0] == '1');
     // idle slots (ragged colours / fewer than 4 colours): each lane owns two padding slots of the LDS slab,
@@ -198,8 +205,11 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
     h->N = nsites; h->L = ltau; h->nb = nbonds; h->ndim = nsites * ltau;
     h->npl = (int)((nsites + ELPH_WAVE - 1) / ELPH_WAVE);
     h->maxiter = h->ndim;   // ConjugateGradient ctor default (IterativeSolvers.jl:49-51)
-    const char *ng = getenv("ELPH_NO_GRAPH");
-    h->use_graph = !(ng && ng[0] == '1');
+    // hipGraph replay of CG chunks is opt-in (ELPH_USE_GRAPH=1).  Eager launches are within ~3 % of the replay
+    // speed here (the stream stays queued ahead of the GPU: kernels take 3-6 us, a launch ~2 us), rocprofv3
+    // --kernel-trace cannot trace graph replays on this image, and eager keeps bench == profile.
+    const char *ug = getenv("ELPH_USE_GRAPH");
+    h->use_graph = (ug && ug[0] == '1');
 
     // bond tables, 0-based; colours = maximal runs of site-disjoint bonds (reproduces the groups of
     // checkerboard_groups!, Checkerboard.jl:471-515, for any table in checkerboard order, and stays
@@ -234,7 +244,6 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
     const size_t nE = (kind == ELPH_MODEL_SSH) ? (size_t)nsites : (size_t)h->ndim;
     if ((rc = dev_alloc(&h->d_E, nE))) return fail(rc);
     if ((rc = dev_alloc(&h->d_lam, 3 * (size_t)nsites))) return fail(rc);
-    if ((rc = dev_alloc(&h->d_params, 1))) return fail(rc);
     if (nbonds > 0) {
         if (hipMemcpy(h->d_bi, h->h_bi.data(), sizeof(int) * nbonds, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(h->d_bj, h->h_bj.data(), sizeof(int) * nbonds, hipMemcpyHostToDevice) != hipSuccess) {
@@ -289,7 +298,7 @@ extern "C" int elph_destroy(elph_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
-                    h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_params,
+                    h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
                     h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt};
@@ -426,10 +435,11 @@ static int get_chunk_graph(elph_handle_s *h, int nrhs, int use_prec, hipGraphExe
     for (auto &g : h->graphs)
         if (g.nrhs == nrhs && g.use_prec == use_prec) { *out = g.exec; return ELPH_OK; }
     hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamSynchronize(h->stream));   // drain the eager init kernels before the stream goes into capture mode
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = ELPH_OK;
-    for (int it = 0; it < ELPH_CG_CHUNK && rc == ELPH_OK; ++it) rc = elph_launch_cg_iteration(h, nrhs, use_prec);
-    if (rc == ELPH_OK) {
+    for (int it = 0; it < h->chunk && rc == ELPH_OK; ++it) rc = elph_launch_cg_iteration(h, nrhs, use_prec);
+    if (rc == ELPH_OK && !h->dbg_copy_outside) {
         hipError_t e = hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream);
         if (e != hipSuccess) { elph_set_error("capture memcpy: %s", hipGetErrorString(e)); rc = ELPH_E_HIP; }
     }
@@ -462,20 +472,22 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
             h->hist_cap = need;
         }
     }
-    HIPCHK(hipMemcpyAsync(h->d_params, &P, sizeof(P), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));   // P is a stack object
+    if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);   // parameters are baked into captured launches
+    h->cur_params = P;
     RC(elph_launch_cg_init(h, nrhs, use_prec));
 
-    const int64_t max_chunks = (maxiter + 1 + ELPH_CG_CHUNK - 1) / ELPH_CG_CHUNK + 1;
+    const int64_t max_chunks = (maxiter + 1 + h->chunk - 1) / h->chunk + 1;
     bool all_done = false;
     for (int64_t c = 0; c < max_chunks && !all_done; ++c) {
         if (h->use_graph) {
             hipGraphExec_t exec;
             RC(get_chunk_graph(h, nrhs, use_prec, &exec));
             HIPCHK(hipGraphLaunch(exec, h->stream));
-            h->ap_count += ELPH_CG_CHUNK;   // even: the captured launch parities stay aligned with seq
+            h->ap_count += h->chunk;   // even: the captured launch parities stay aligned with seq
+            if (h->dbg_copy_outside)
+                HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
         } else {
-            for (int it = 0; it < ELPH_CG_CHUNK; ++it) RC(elph_launch_cg_iteration(h, nrhs, use_prec));
+            for (int it = 0; it < h->chunk; ++it) RC(elph_launch_cg_iteration(h, nrhs, use_prec));
             HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
         }
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -885,8 +897,7 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
     // fixed-count CG: tol = 0 never converges, kmax = inf, x0 = 0
     CgParams P;
     P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3); P.record_hist = 0; P.hist_stride = 0;
-    HIPCHK(hipMemcpyAsync(h->d_params, &P, sizeof(P), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cur_params = P;
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
     RC(elph_launch_cg_init(h, nrhs, P.use_prec));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -56,17 +56,26 @@ struct ModelDev {
     int lp_tau_stride;       // 0 (Holstein) or NE*64 (SSH)
 };
 
+// Solver parameters travel BY VALUE in the kernel arguments (never through a small H2D copy + scalar load).
+struct CgParams {
+    double tol, kmax;
+    long long maxiter;
+    int use_prec;
+    int record_hist;
+    long long hist_stride;
+};
+
 // Buffers of the CG iteration kernels (all layout S).
 struct CgState;
-struct CgParams;
 struct CgBufs {
     double *x, *r, *z, *zp;     // [nrhs][ndim]; zp = P^-1 r (preconditioned only)
     double *p;                  // [2][nrhs][ndim] ping-pong by (seq & 1)
     double *pap, *rr, *rz;      // partial sums [nrhs][npart]
     CgState *state;             // [nrhs][2]
-    const CgParams *params;
+    CgParams params;
     double *hist;               // optional eps history
     int nrz;                    // number of r.z partials per rhs
+    int npap;                   // number of p.z partials per rhs (L, or L/T for the chunked kernel)
     int nrhs;
 };
 
@@ -83,13 +92,6 @@ struct CgState {
     int pad;
 };
 
-struct CgParams {
-    double tol, kmax;
-    long long maxiter;
-    int use_prec;
-    int record_hist;
-    long long hist_stride;
-};
 
 struct KpmDev {
     int active;
@@ -128,6 +130,7 @@ struct elph_handle_s {
     unsigned *d_lp_ij = nullptr;
     double *d_lp_c = nullptr, *d_lp_s = nullptr, *d_lp_cbar = nullptr, *d_lp_sbar = nullptr;
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
+    int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/8 force
 
     // solver defaults (model.solver)
     double tol = 1e-4, kmax = 1e12;
@@ -142,7 +145,7 @@ struct elph_handle_s {
     double *d_part = nullptr;              // partial sums: 4 arrays of cap_rhs * L
     CgState *d_state = nullptr;            // cap_rhs * 2
     CgState *h_state = nullptr;            // pinned, cap_rhs * 2
-    CgParams *d_params = nullptr;
+    CgParams cur_params;                   // parameters of the solve in progress (copied into every launch)
     double *d_hist = nullptr;
     int64_t hist_cap = 0;
     double *d_scal = nullptr;              // small scalar scratch (residual norms), 4*cap_rhs
@@ -151,7 +154,9 @@ struct elph_handle_s {
     // captured CG chunk graphs, keyed by (nrhs, use_prec)
     struct GraphEntry { int nrhs, use_prec; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
-    bool use_graph = true;
+    bool use_graph = false;                // hipGraph replay of CG chunks: opt-in (ELPH_USE_GRAPH=1), see DESIGN.md §3
+    int chunk = ELPH_CG_CHUNK;             // CG iterations per graph launch (even)
+    bool dbg_copy_outside = false;
 
     // KPM
     bool kpm_created = false, kpm_ready = false;
@@ -202,6 +207,7 @@ int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
+int elph_choose_T(const elph_handle_s *h, int nrhs);
 // packs per-bond values (order of h_bi/h_bj) into the lane-program layout [NE][64] (idle slots = fill)
 void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill);
 

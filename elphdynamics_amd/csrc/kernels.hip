@@ -31,9 +31,6 @@ __device__ __forceinline__ double reduce_partials(const double *p, int n) {
     return wave_sum(a);
 }
 
-__device__ __forceinline__ const CgState *newest_state(const CgState *st2) {
-    return (st2[1].seq > st2[0].seq) ? &st2[1] : &st2[0];
-}
 
 // One checkerboard sweep over an LDS slab holding one tau-slice (Checkerboard.jl:57-83 forward,
 // :149-175 transposed == colours in reverse order; bonds inside a colour are site-disjoint so
@@ -229,19 +226,23 @@ __global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const doub
 
 
 template <int NPL>
-__global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m) {
+__global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m, int parity) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bufA = lds, *bufB = lds + m.N;
     const int N = m.N, L = m.L;
     const int t = blockIdx.x, rhs = blockIdx.y;
     const size_t ndim = (size_t)N * L;
+    // state copy of this launch = st2[parity]; the other copy is written at the end (no same-kernel reader)
     CgState *st2 = B.state + 2 * rhs;
-    const CgState S = *newest_state(st2);
-    if (S.done) return;
-    const CgParams P = *B.params;
+    const CgState S = st2[parity];
+    CgState *Sout = st2 + (parity ^ 1);
+    if (S.done) {
+        if (t == 0 && threadIdx.x == 0) *Sout = S;
+        return;
+    }
+    const CgParams P = B.params;
     const long long seq = S.seq;          // == completed iterations so far
     const bool first = (seq == 0);
-    CgState *Sout = st2 + ((seq + 1) & 1);
 
     double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
     if (!first) {
@@ -270,8 +271,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m) {
     }
 
     const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
-    const double *pold = B.p + ((size_t)(seq & 1) * B.nrhs + rhs) * ndim;
-    double *pnew = B.p + ((size_t)((seq + 1) & 1) * B.nrhs + rhs) * ndim;
+    const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
+    double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
     double *z = B.z + (size_t)rhs * ndim;
 
     const int tm1 = (t == 0) ? L - 1 : t - 1;
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m) {
     }
     acc = wave_sum(acc);
     if (threadIdx.x == 0) {
-        B.pap[(size_t)rhs * L + t] = acc;
+        B.pap[(size_t)rhs * B.npap + t] = acc;
         if (t == 0) {
             CgState o = S;
             o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = 0;
@@ -335,14 +336,14 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m) {
 }
 
 template <int NPL>
-__global__ void __launch_bounds__(WAVE) k_cg_xr(CgBufs B, int N, int L) {
+__global__ void __launch_bounds__(WAVE) k_cg_xr(CgBufs B, int N, int L, int parity) {
     const int t = blockIdx.x, rhs = blockIdx.y;
     const size_t ndim = (size_t)N * L;
-    const CgState S = *newest_state(B.state + 2 * rhs);
+    const CgState S = B.state[2 * rhs + parity];
     if (S.done) return;
-    const double pap = reduce_partials(B.pap + (size_t)rhs * L, L);
+    const double pap = reduce_partials(B.pap + (size_t)rhs * B.npap, B.npap);
     const double alpha = S.rho / pap;                       // :202 / :279
-    const double *p = B.p + ((size_t)(S.seq & 1) * B.nrhs + rhs) * ndim;
+    const double *p = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
     const double *z = B.z + (size_t)rhs * ndim;
     double *x = B.x + (size_t)rhs * ndim, *r = B.r + (size_t)rhs * ndim;
     double acc = 0.0;
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_init_prec(CgBufs B, int N, int L) {
 // one wave per rhs: seed the state (normb, eps0, rho0) — IterativeSolvers.jl:176-195 / :259-274
 __global__ void __launch_bounds__(WAVE) k_cg_state0(CgBufs B, const double *bb, int L) {
     const int rhs = blockIdx.x;
-    const CgParams P = *B.params;
+    const CgParams P = B.params;
     const double rr = reduce_partials(B.rr + (size_t)rhs * L, L);
     const double nb2 = reduce_partials(bb + (size_t)rhs * L, L);
     const double rho = P.use_prec ? reduce_partials(B.rz + (size_t)rhs * B.nrz, B.nrz) : rr;
@@ -449,169 +450,9 @@ __global__ void __launch_bounds__(WAVE) k_resid_final(const double *pa, const do
 }
 
 // ------------------------------------------------------------------------------------------
-// tau-axis transforms (TimeFreqFFTs.jl:55-73,112-130; FourierAcceleration.jl:91-143)
-//
-// Lengths are tiny (L = 40..160) and every site column is independent, so the transform is
-// evaluated as a direct twisted real DFT with wave-uniform twiddles:
-//   nu[k][s]  = sum_t exp(-i pi t (2k+1)/L) v[t][s]          (= FFT_t(Theta .* v)[k])
-// Real input => nu[L-1-k] = conj(nu[k]); only k < ceil(L/2) is produced, which is exactly the
-// half the KPM loop visits (KPMPreconditioners.jl:449-467).  Lane = site (coalesced), the twiddle
-// index depends only on (block, loop counter) => the compiler keeps it in SGPRs / scalar loads.
-// tw2[m] = exp(-i pi m / L), m in [0, 2L).
+// tau-axis transforms: see dft.hip.  Only the two API helpers for the complex tau_to_omega!/omega_to_tau!
+// entry points live here (tw2[m] = exp(-i pi m / L), m in [0, 2L)).
 // ------------------------------------------------------------------------------------------
-
-template <int KPT>
-__global__ void __launch_bounds__(WAVE) k_dft_fwd_twisted(double2 *__restrict__ nu, const double *__restrict__ v,
-                                                          const double2 *__restrict__ tw2, int N, int L, int Lo2,
-                                                          const CgState *state) {
-    const int rhs = blockIdx.z;
-    if (state && newest_state(state + 2 * rhs)->done) return;
-    const int s = blockIdx.x * WAVE + threadIdx.x;
-    const int k0 = blockIdx.y * KPT;
-    const double *vv = v + (size_t)rhs * N * L;
-    double2 acc[KPT];
-    int m[KPT];
-#pragma unroll
-    for (int kk = 0; kk < KPT; ++kk) { acc[kk] = make_double2(0.0, 0.0); m[kk] = 0; }
-    const int twoL = 2 * L;
-    for (int t = 0; t < L; ++t) {
-        const double x = (s < N) ? vv[(size_t)t * N + s] : 0.0;
-#pragma unroll
-        for (int kk = 0; kk < KPT; ++kk) {
-            const double2 w = tw2[m[kk]];
-            acc[kk].x += x * w.x;
-            acc[kk].y += x * w.y;
-            m[kk] += 2 * (k0 + kk) + 1;
-            if (m[kk] >= twoL) m[kk] -= twoL;
-        }
-    }
-    if (s < N) {
-#pragma unroll
-        for (int kk = 0; kk < KPT; ++kk)
-            if (k0 + kk < Lo2) nu[((size_t)rhs * Lo2 + (k0 + kk)) * N + s] = acc[kk];
-    }
-}
-
-// v[t][s] = Re( conj(Theta_t) * (1/L) sum_k exp(+2 pi i k t/L) nu[k][s] ) using the conjugate symmetry:
-//         = (1/L) sum_{k<Lo2} wgt_k Re( exp(+i pi t (2k+1)/L) nu[k][s] ),  wgt = 2 (1 for the odd-L middle k)
-// Optionally fused: partial r.z for the CG (IterativeSolvers.jl:225).
-template <int TPT>
-__global__ void __launch_bounds__(WAVE) k_dft_inv_twisted(double *__restrict__ out, const double2 *__restrict__ nu,
-                                                          const double2 *__restrict__ tw2, int N, int L, int Lo2,
-                                                          const CgState *state, const double *__restrict__ rvec,
-                                                          double *__restrict__ rz_part, int nrz) {
-    const int rhs = blockIdx.z;
-    if (state && newest_state(state + 2 * rhs)->done) return;
-    const int s = blockIdx.x * WAVE + threadIdx.x;
-    const int t0 = blockIdx.y * TPT;
-    const double2 *nn = nu + (size_t)rhs * Lo2 * N;
-    double acc[TPT];
-    int m[TPT];
-    const int twoL = 2 * L;
-#pragma unroll
-    for (int tt = 0; tt < TPT; ++tt) { acc[tt] = 0.0; m[tt] = (t0 + tt) % twoL; }
-    const bool odd = (L & 1);
-    for (int k = 0; k < Lo2; ++k) {
-        const double2 x = (s < N) ? nn[(size_t)k * N + s] : make_double2(0.0, 0.0);
-        const double wgt = (odd && k == Lo2 - 1) ? 1.0 : 2.0;
-#pragma unroll
-        for (int tt = 0; tt < TPT; ++tt) {
-            const double2 w = tw2[m[tt]];          // exp(-i a): cos a = w.x, sin a = -w.y
-            acc[tt] += wgt * (w.x * x.x + w.y * x.y);
-            m[tt] += 2 * (t0 + tt);
-            if (m[tt] >= twoL) m[tt] -= twoL;
-            if (m[tt] >= twoL) m[tt] -= twoL;
-        }
-    }
-    const double invL = 1.0 / (double)L;
-    double dot = 0.0;
-#pragma unroll
-    for (int tt = 0; tt < TPT; ++tt) {
-        const int t = t0 + tt;
-        if (s < N && t < L) {
-            const double val = acc[tt] * invL;
-            const size_t i = (size_t)rhs * N * L + (size_t)t * N + s;
-            out[i] = val;
-            if (rz_part) dot += rvec[i] * val;
-        }
-    }
-    if (rz_part) {
-        dot = wave_sum(dot);
-        if (threadIdx.x == 0) rz_part[(size_t)rhs * nrz + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = dot;
-    }
-}
-
-// plain (untwisted) real DFT pair with a diagonal in between: fourier_accelerate!,
-// FourierAcceleration.jl:91-143:  out = Re iFFT( diag^power .* FFT(in) ).
-// Stage 1: u[k][s] = diag[k][s]^power * sum_t exp(-2 pi i k t/L) in[t][s]    for k <= L/2
-// Stage 2: out[t][s] = (1/L) sum_k wgt_k Re( exp(+2 pi i k t/L) u[k][s] )    (Hermitian symmetry;
-//          diag is symmetric under k -> L-k for M (k' = min(k,L-k)) and Q (cos), so the product
-//          keeps the symmetry of a real signal's spectrum).
-// tw1[m] = exp(-2 pi i m / L), m in [0, L).
-template <int KPT>
-__global__ void __launch_bounds__(WAVE) k_dft_fwd_plain(double2 *__restrict__ u, const double *__restrict__ v,
-                                                        const double *__restrict__ diag, double power,
-                                                        const double2 *__restrict__ tw1, int N, int L, int Lh) {
-    const int s = blockIdx.x * WAVE + threadIdx.x;
-    const int k0 = blockIdx.y * KPT;
-    double2 acc[KPT];
-    int m[KPT];
-#pragma unroll
-    for (int kk = 0; kk < KPT; ++kk) { acc[kk] = make_double2(0.0, 0.0); m[kk] = 0; }
-    for (int t = 0; t < L; ++t) {
-        const double x = (s < N) ? v[(size_t)t * N + s] : 0.0;
-#pragma unroll
-        for (int kk = 0; kk < KPT; ++kk) {
-            const double2 w = tw1[m[kk]];
-            acc[kk].x += x * w.x;
-            acc[kk].y += x * w.y;
-            m[kk] += (k0 + kk) % L;
-            if (m[kk] >= L) m[kk] -= L;
-        }
-    }
-    if (s < N) {
-#pragma unroll
-        for (int kk = 0; kk < KPT; ++kk) {
-            const int k = k0 + kk;
-            if (k < Lh) {
-                // Re iFFT(D .* FFT(v)) of a real v only sees the symmetric part of D:
-                // mirror terms k and L-k combine to (D[k]+D[L-k])/2 * 2 Re(...)
-                const int km = (k == 0) ? 0 : L - k;
-                const double f = 0.5 * (pow(diag[(size_t)k * N + s], power) + pow(diag[(size_t)km * N + s], power));
-                u[(size_t)k * N + s] = make_double2(acc[kk].x * f, acc[kk].y * f);
-            }
-        }
-    }
-}
-
-template <int TPT>
-__global__ void __launch_bounds__(WAVE) k_dft_inv_plain(double *__restrict__ out, const double2 *__restrict__ u,
-                                                        const double2 *__restrict__ tw1, int N, int L, int Lh) {
-    const int s = blockIdx.x * WAVE + threadIdx.x;
-    const int t0 = blockIdx.y * TPT;
-    double acc[TPT];
-    int m[TPT];
-#pragma unroll
-    for (int tt = 0; tt < TPT; ++tt) { acc[tt] = 0.0; m[tt] = 0; }
-    for (int k = 0; k < Lh; ++k) {
-        const double2 x = (s < N) ? u[(size_t)k * N + s] : make_double2(0.0, 0.0);
-        // k = 0 and (even L) k = L/2 are their own mirror images
-        const double wgt = (k == 0 || 2 * k == L) ? 1.0 : 2.0;
-#pragma unroll
-        for (int tt = 0; tt < TPT; ++tt) {
-            const double2 w = tw1[m[tt]];
-            acc[tt] += wgt * (w.x * x.x + w.y * x.y);
-            m[tt] += (t0 + tt) % L;
-            if (m[tt] >= L) m[tt] -= L;
-        }
-    }
-    const double invL = 1.0 / (double)L;
-#pragma unroll
-    for (int tt = 0; tt < TPT; ++tt) {
-        const int t = t0 + tt;
-        if (s < N && t < L) out[(size_t)t * N + s] = acc[tt] * invL;
-    }
-}
 
 // full complex half-spectrum -> full spectrum expansion for the tau_to_omega API (complex output, layout S)
 __global__ void k_expand_spectrum(double2 *__restrict__ full, const double2 *__restrict__ half, int N, int L, int Lo2) {
@@ -722,7 +563,7 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb(double2 *__restrict__ nu, Kpm
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double2 *buf = reinterpret_cast<double2 *>(lds);
     const int rhs = blockIdx.y;
-    if (state && newest_state(state + 2 * rhs)->done) return;
+    if (state && state[2 * rhs].done) return;   // `state` points at the current copy
     const int w = K.wsched[blockIdx.x];
     const int N = m.N;
     const int order = K.order[w];
@@ -777,7 +618,7 @@ __global__ void __launch_bounds__(WAVE) k_copy_dot(double *__restrict__ zp, cons
                                                    double *__restrict__ rz_part, int nrz, int N, int L,
                                                    const CgState *state) {
     const int t = blockIdx.x, rhs = blockIdx.y;
-    if (state && newest_state(state + 2 * rhs)->done) return;
+    if (state && state[2 * rhs].done) return;   // `state` points at the current copy
     double a = 0.0;
     for (int s = threadIdx.x; s < N; s += WAVE) {
         const size_t i = (size_t)rhs * N * L + (size_t)t * N + s;
@@ -884,8 +725,9 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)(h->npl);  // partial stride per array
     B.x = h->d_x; B.r = h->d_r; B.z = h->d_z; B.zp = h->d_zp; B.p = h->d_p;
     B.pap = h->d_part; B.rr = h->d_part + P; B.rz = h->d_part + 2 * P;
-    B.state = h->d_state; B.params = h->d_params; B.hist = h->d_hist;
+    B.state = h->d_state; B.params = h->cur_params; B.hist = h->d_hist;
     B.nrz = (int)(h->L * h->npl);
+    B.npap = (int)(h->L / elph_choose_T(h, nrhs));
     B.nrhs = nrhs;
     return B;
 }
@@ -900,7 +742,8 @@ int elph_launch_ebar(elph_handle_s *h) {
 int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode) {
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     CgBufs B = make_bufs(h, nrhs);
-    const CgState *st = cg_mode ? h->d_state : nullptr;
+    // kernels that skip finished right-hand sides read the state copy written by the latest k_cg_ap launch
+    const CgState *st = cg_mode ? h->d_state + (h->ap_count & 1) : nullptr;
     if (!h->kpm_active) {
         if (cg_mode) {
             HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
@@ -1003,8 +846,8 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
         dim3 grid((unsigned)L, (unsigned)nrhs, 1);
         const size_t shm = 2 * (size_t)N * sizeof(double);
         DISPATCH_NPL(h->npl, {
-            hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3(WAVE), shm, h->stream, B, m);
-            hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3(WAVE), 0, h->stream, B, N, L);
+            hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3(WAVE), shm, h->stream, B, m, (int)(h->ap_count & 1));
+            hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3(WAVE), 0, h->stream, B, N, L, (int)((h->ap_count + 1) & 1));
         });
         h->ap_count++;
         rc = check_launch("cg iteration");
@@ -1030,8 +873,8 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     dim3 grid((unsigned)L, (unsigned)nrhs, 1);
     const size_t shm = 2 * (size_t)N * sizeof(double);
     DISPATCH_NPL(h->npl, {
-        if (which == 0) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3(WAVE), shm, h->stream, B, m);
-        else hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3(WAVE), 0, h->stream, B, N, L);
+        if (which == 0) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3(WAVE), shm, h->stream, B, m, (int)(h->ap_count & 1));
+        else hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3(WAVE), 0, h->stream, B, N, L, (int)(h->ap_count & 1));
     });
     if (which == 0) h->ap_count++;
     return check_launch("cg kernel");
