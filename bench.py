@@ -56,21 +56,14 @@ def parse():
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from elphdynamics_amd import dist as edist
+    comm = edist.Comm()            # imports torch (and initialises RCCL) only when WORLD_SIZE > 1
+    rank, local_rank, world = comm.rank, comm.local_rank, comm.world
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    torch = None
-    if world > 1:
-        import torch  # noqa: F811  (first: libelphgpu then shares torch's HIP runtime)
-        import torch.distributed as dist  # noqa: F811
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
-    from elphdynamics_amd import _lib, configs, preconditioners as pc, synth
+    from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth
     from elphdynamics_amd._lib import check
 
     lib = _lib.load()
@@ -79,22 +72,17 @@ def main():
 
     # one independent chain (phonon configuration) per rank
     m = configs.make_model(args.config, tol=1e-5, device=local_rank if world > 1 else 0,
-                           seed=synth.SEED_FIELDS + 1009 * rank)
+                           seed=comm.chain_seed(synth.SEED_FIELDS))
     nrhs = args.nrhs
-    R, B = configs.rhs(m, nrhs, seed=synth.SEED_RHS + 1009 * rank)
+    R, B = configs.rhs(m, nrhs, seed=comm.chain_seed(synth.SEED_RHS))
     what = 3 if args.precond else 1
+    P = None
     if args.precond:
         P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
         pc.setup_(P, rng=np.random.default_rng(7 + rank))
     Bc = np.ascontiguousarray(B)
 
-    def sync_all():
-        check(lib.elph_synchronize(m._h))
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    def run(what_, nrhs_, reps, graph=1):
+    def run(what_, nrhs_, reps, graph=0):
         ms = C.c_double()
         check(lib.elph_bench_run(m._h, what_, nrhs_, reps, graph, C.byref(ms)))
         return ms.value
@@ -104,23 +92,22 @@ def main():
     W = max(chunk, (args.warmup // chunk) * chunk)
 
     check(lib.elph_bench_prepare(m._h, what, nrhs, _lib.dptr(Bc)))
-    run(what, nrhs, W)                       # warm-up (also instantiates the graph path once)
+    run(what, nrhs, W)                       # warm-up
     check(lib.elph_bench_prepare(m._h, what, nrhs, None))
-    sync_all()
-    t0 = time.perf_counter()
-    ms_events = run(what, nrhs, K)           # exactly K steps; returns after the stream has drained
-    sync_all()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    ev = {}
+
+    def run_steps(k):
+        ev["ms"] = run(what, nrhs, k)        # exactly k steps; returns after the stream has drained
+        check(lib.elph_synchronize(m._h))
+        return 2.0 * nrhs * k
+
+    check(lib.elph_synchronize(m._h))
+    elapsed, matvecs = edist.timed_steps(comm, run_steps, K)
+    ms_events = ev["ms"]
 
     out = None
     if rank == 0:
         ndim = m.Ndim
-        matvecs = 2.0 * nrhs * K * world
         out = {
             "metric": "cg_matvecs_per_sec",
             "value": matvecs / elapsed,
@@ -161,7 +148,10 @@ def main():
                 traffic = tj.get(f"k_cg_ap_nrhs{nrhs}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "k_cg_ap", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        Tsl = C.c_int()
+        check(lib.elph_bench_info(m._h, nrhs, C.byref(Tsl)))
+        kname = f"k_cg_ap_chunk<T={Tsl.value}>" if Tsl.value > 1 else "k_cg_ap_fast"
+        out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": ms_ap * 1e3,
                            "algorithmic_bytes_per_launch": alg}
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
@@ -190,6 +180,35 @@ def main():
                                   "alg_GBs": ALG_BYTES_PER_ELT["cg_iter"] * ndim * nr * 1600 / (ms * 1e-3) / 1e9}
             out["by_nrhs"] = sweep
 
+        # ---- secondary: time-to-solution of one ldiv! at tol=1e-5, plain vs KPM-preconditioned (BASELINE config 3)
+        if not args.no_sweep:
+            try:
+                P2 = P or pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+                pc.setup_(P2, rng=np.random.default_rng(7))
+                tts = {}
+                for nr in (1, 10):
+                    _, Bs = configs.rhs(m, nr)
+                    for label, PP in (("plain", None), ("kpm", P2)):
+                        X = np.zeros_like(Bs)
+                        models.ldiv_batched_(X, m, Bs, P=PP)                    # warm
+                        X[:] = 0.0
+                        tq = time.perf_counter()
+                        it, res, fl = models.ldiv_batched_(X, m, Bs, P=PP)
+                        dtq = time.perf_counter() - tq
+                        tts[f"{label}_nrhs{nr}"] = {"ms_per_batched_solve_incl_pcie": 1e3 * dtq, "iters_max": int(it.max()),
+                                                    "flags_ok": bool((fl == 0).all()), "max_residual": float(res.max())}
+                ms = C.c_double()
+                check(lib.elph_bench_prepare(m._h, 2, 1, None))
+                check(lib.elph_bench_run(m._h, 2, 1, 160, 0, C.byref(ms)))
+                tts["kpm_apply_us_nrhs1"] = 1e3 * ms.value / 160
+                check(lib.elph_bench_prepare(m._h, 3, 1, None))
+                check(lib.elph_bench_run(m._h, 3, 1, 160, 0, C.byref(ms)))
+                tts["preconditioned_cg_iter_us_nrhs1"] = 1e3 * ms.value / 160
+                tts["kpm_orders_sum"] = int(P2.orders.sum())
+                out["time_to_solution_tol1e-5"] = tts
+            except Exception as e:
+                out["time_to_solution_tol1e-5"] = {"error": str(e)}
+
         # ---- CPU baseline: the oracle, 1 thread, bounded sample of the same workload
         if not args.no_cpu:
             try:
@@ -214,9 +233,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out))
     m.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

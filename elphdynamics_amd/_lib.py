@@ -52,6 +52,7 @@ SIGNATURES = {
     "elph_omega_to_tau": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_bench_prepare": (c_int, [Handle, c_int, c_int, P_dbl]),
     "elph_bench_run": (c_int, [Handle, c_int, c_int, c_int, c_int, P_dbl]),
+    "elph_bench_info": (c_int, [Handle, c_int, P_int]),
 }
 
 

@@ -904,6 +904,13 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
     return ELPH_OK;
 }
 
+extern "C" int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave) {
+    CHECK_H(h);
+    if (nrhs < 1 || !slices_per_wave) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    *slices_per_wave = elph_choose_T(h, nrhs);
+    return ELPH_OK;
+}
+
 extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total) {
     CHECK_H(h);
     if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 5) { elph_set_error("bad argument"); return ELPH_E_ARG; }

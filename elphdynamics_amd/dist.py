@@ -1,0 +1,77 @@
+"""Multi-GPU plumbing for bench.py and multi-chain runs: one process per GPU, torch.distributed
+(backend "nccl" == RCCL on ROCm; "gloo" for the CPU tests).
+
+The hot path shards over INDEPENDENT CHAINS (one phonon configuration = one fermion matrix per rank): this
+is how the reference itself parallelises (independent run-IDs, ElPhDynamics.jl:90-95) and what SURVEY.md
+§8e recommends at these lattice sizes.  There is no data-path collective; the only communication is the
+barrier around the timed region, the MAX-reduction of the elapsed time and the SUM of the work counters.
+"""
+import os
+
+
+class Comm:
+    """Thin wrapper so that world_size == 1 needs no torch at all."""
+
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.torch = None
+        self.dist = None
+        self.device = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            self.backend = backend
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                self.device = torch.device("cuda", self.local_rank)
+                dist.init_process_group(backend="nccl", device_id=self.device)
+            else:
+                self.device = torch.device("cpu")
+                dist.init_process_group(backend=backend)
+
+    # one independent chain per rank: distinct, reproducible seeds
+    def chain_seed(self, base):
+        return int(base) + 1009 * self.rank
+
+    def barrier(self):
+        if self.dist is not None:
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
+            self.dist.barrier()
+
+    def max(self, value):
+        """MAX over ranks of a python float."""
+        if self.dist is None:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, value):
+        if self.dist is None:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(comm, run_steps, steps):
+    """The bench contract: barrier + synchronise, run exactly `steps` steps, synchronise + barrier, MAX over ranks.
+    `run_steps(k)` must return only after the device has finished the k steps.  Returns (elapsed_max, total_work)
+    where total_work sums the per-rank work counters run_steps returns (e.g. mat-vecs)."""
+    import time
+    comm.barrier()
+    t0 = time.perf_counter()
+    work = run_steps(steps)
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    return comm.max(elapsed), comm.sum(work)

@@ -186,6 +186,8 @@ int elph_omega_to_tau(elph_handle h, double *v, const double *nu_complex);
  *   stream, synchronises, and returns the event time in ms (total, not per rep). */
 int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B);
 int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total);
+/* Which k_cg_ap variant a batch of nrhs uses: *slices_per_wave = 1 (k_cg_ap_fast / generic) or T (k_cg_ap_chunk<T>). */
+int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave);
 
 #ifdef __cplusplus
 }
