@@ -19,6 +19,10 @@ CONFIGS = {
     "d": ("holstein", 2, 3, lat.HONEYCOMB_BONDS, 1.2, 0.1),
     "e": ("ssh", 1, 4, lat.SQUARE_BONDS, 1.0, 0.05),
     "t": ("holstein", 1, 3, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # odd L: ragged colours
+    # lattices beyond 512 sites: multi-wavefront workgroups of the generic kernels
+    "g": ("holstein", 1, 24, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 576  (2 wavefronts per slice)
+    "G": ("holstein", 1, 32, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 1024
+    "h": ("holstein", 2, 18, lat.HONEYCOMB_BONDS, 0.6, 0.1),        # N = 648 honeycomb
 }
 
 

@@ -90,7 +90,7 @@ static int build_lane_program(elph_handle_s *h) {
     const char *ct = getenv("ELPH_CHUNK_T");
     h->force_T = ct ? atoi(ct) : 0;
     const char *nf = getenv("ELPH_NO_FAST");
-    h->fast = (h->ncol <= 4) && !(nf && nf[0] == '1');
+    h->fast = (h->ncol <= 4) && (h->npl <= ELPH_MAX_NPL) && !(nf && nf[0] == '1');
     // idle slots (ragged colours / fewer than 4 colours): each lane owns two padding slots of the LDS slab,
     // paired with (cosh, sinh) = (1, 0) by elph_lp_pack => a no-op bond, no predicate in the kernels
     h->h_lp_ij.resize((size_t)NE * ELPH_WAVE);
@@ -174,8 +174,8 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
     *out = nullptr;
     if (kind != ELPH_MODEL_HOLSTEIN && kind != ELPH_MODEL_SSH) { elph_set_error("bad model kind %d", kind); return ELPH_E_ARG; }
     if (nsites < 1 || ltau < 1 || nbonds < 0) { elph_set_error("bad sizes N=%lld L=%lld nb=%lld", (long long)nsites, (long long)ltau, (long long)nbonds); return ELPH_E_ARG; }
-    if (nsites > (int64_t)ELPH_MAX_NPL * ELPH_WAVE) {
-        elph_set_error("nsites=%lld exceeds the %d sites one wavefront-per-slice kernel supports", (long long)nsites, ELPH_MAX_NPL * ELPH_WAVE);
+    if (nsites > (int64_t)ELPH_MAX_SITES) {
+        elph_set_error("nsites=%lld exceeds the %d sites a one-workgroup-per-slice kernel supports", (long long)nsites, ELPH_MAX_SITES);
         return ELPH_E_UNSUPPORTED;
     }
     if (nsites * ltau > (int64_t)1 << 30) { elph_set_error("ndim too large"); return ELPH_E_UNSUPPORTED; }

@@ -23,7 +23,8 @@
 
 #define ELPH_ABI_VERSION 1
 #define ELPH_WAVE 64
-#define ELPH_MAX_NPL 8          // sites per lane: N <= 512
+#define ELPH_MAX_NPL 8          // sites per thread
+#define ELPH_MAX_SITES 8192      // generic kernels: workgroups of up to 1024 threads x 8 sites
 #define ELPH_CG_CHUNK 16        // CG iterations per captured graph launch
 
 void elph_set_error(const char *fmt, ...);

@@ -1,11 +1,12 @@
 // kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the fermion-force solver.
 //
-// Mapping (see elph_internal.h for layout S): one 64-lane wavefront == one workgroup owns one
-// imaginary-time slice tau of one right-hand side.  Lane l holds sites l, l+64, ... (NPL per lane)
-// in registers; the checkerboard sweep, which couples sites at fixed tau, goes through that wave's
-// private LDS slab, so the only synchronisation inside a kernel is the single-wave workgroup
-// barrier (which the compiler lowers to a wave barrier for 64-thread groups).
-// Grid = (L, nrhs) workgroups: >= 160 waves for the headline lattice, x nrhs when batched.
+// These are the GENERIC kernels: any bond table (ragged colours, > 4 colours, arbitrary order) and any
+// lattice up to 8192 sites.  One workgroup of BS = 64*W threads (W = ceil(N/512) wavefronts) owns one
+// imaginary-time slice tau of one right-hand side.  Thread l holds sites l, l+BS, ... (NPL <= 8 per thread)
+// in registers; the checkerboard sweep, which couples sites at fixed tau, goes through the workgroup's LDS
+// slab with one barrier per colour (for W = 1 the compiler lowers it to a wave barrier).
+// Lattices with N <= 512 and <= 4 colours take the latency-tuned single-wave kernels of cg_fast.hip instead.
+// Grid = (L, nrhs) workgroups.
 //
 // Reference semantics: SURVEY.md Appendix A; file:line citations at each kernel.
 
@@ -25,10 +26,24 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// every wave of the workgroup reduces ALL partials itself: same loads, same tree => same bits in every wave
 __device__ __forceinline__ double reduce_partials(const double *p, int n) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += WAVE) a += p[i];
+    for (int i = (threadIdx.x & (WAVE - 1)); i < n; i += WAVE) a += p[i];
     return wave_sum(a);
+}
+
+// sum over the whole workgroup (fixed order: wave tree, then waves 0..W-1); result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *scratch /* LDS, >= 16 doubles */) {
+    v = wave_sum(v);
+    const int nw = (blockDim.x + WAVE - 1) / WAVE;
+    if (nw == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0) scratch[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += scratch[w];
+    return t;
 }
 
 
@@ -41,7 +56,7 @@ __device__ __forceinline__ void cb_sweep(double *buf0, double *buf1, const doubl
     for (int cc = 0; cc < m.ncol; ++cc) {
         const int col = REVERSE ? (m.ncol - 1 - cc) : cc;
         const int b0 = m.coloff[col], b1 = m.coloff[col + 1];
-        for (int n = b0 + threadIdx.x; n < b1; n += WAVE) {
+        for (int n = b0 + threadIdx.x; n < b1; n += blockDim.x) {
             const int i = m.bi[n], j = m.bj[n];
             {
                 const double cn = c0[n], sn = s0[n];
@@ -66,7 +81,7 @@ __device__ __forceinline__ void cb_sweep_z(double2 *buf, const double *c, const 
     for (int cc = 0; cc < m.ncol; ++cc) {
         const int col = REVERSE ? (m.ncol - 1 - cc) : cc;
         const int b0 = m.coloff[col], b1 = m.coloff[col + 1];
-        for (int n = b0 + threadIdx.x; n < b1; n += WAVE) {
+        for (int n = b0 + threadIdx.x; n < b1; n += blockDim.x) {
             const int i = m.bi[n], j = m.bj[n];
             const double cn = c[n], sn = s[n];
             const double2 t1 = buf[i], t2 = buf[j];
@@ -132,7 +147,7 @@ __global__ void k_zero(double *p, long long n) {
 // ------------------------------------------------------------------------------------------
 
 template <int NPL, int WHICH>
-__global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const double *__restrict__ v, ModelDev m) {
+__global__ void __launch_bounds__(1024) k_mul(double *__restrict__ y, const double *__restrict__ v, ModelDev m) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bufA = lds, *bufB = lds + m.N;
     const int N = m.N, L = m.L;
@@ -151,7 +166,7 @@ __global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const doub
         double v0[NPL];
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
+            const int s = threadIdx.x + q * blockDim.x;
             if (s < N) {
                 v0[q] = vv[(size_t)t * N + s];
                 bufA[s] = E0[s] * vv[(size_t)tm1 * N + s];
@@ -161,14 +176,14 @@ __global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const doub
         cb_sweep<1, false>(bufA, nullptr, c0, s0, nullptr, nullptr, m);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
+            const int s = threadIdx.x + q * blockDim.x;
             if (s < N) yy[(size_t)t * N + s] = v0[q] - sg0 * bufA[s];
         }
     } else if (WHICH == 1) {  // y = M^T v
         double v0[NPL];
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
+            const int s = threadIdx.x + q * blockDim.x;
             if (s < N) {
                 v0[q] = vv[(size_t)t * N + s];
                 bufA[s] = vv[(size_t)tp1 * N + s];
@@ -178,14 +193,14 @@ __global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const doub
         cb_sweep<1, true>(bufA, nullptr, c1, s1, nullptr, nullptr, m);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
+            const int s = threadIdx.x + q * blockDim.x;
             if (s < N) yy[(size_t)t * N + s] = v0[q] - sg1 * E1[s] * bufA[s];
         }
     } else {  // y = M^T M v
         double v0[NPL], vp[NPL], w0[NPL], e1[NPL];
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
+            const int s = threadIdx.x + q * blockDim.x;
             if (s < N) {
                 const double vm = vv[(size_t)tm1 * N + s];
                 v0[q] = vv[(size_t)t * N + s];
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const doub
         cb_sweep<2, false>(bufA, bufB, c0, s0, c1, s1, m);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
+            const int s = threadIdx.x + q * blockDim.x;
             if (s < N) {
                 w0[q] = v0[q] - sg0 * bufA[s];
                 bufB[s] = vp[q] - sg1 * bufB[s];
@@ -209,7 +224,7 @@ __global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const doub
         cb_sweep<1, true>(bufB, nullptr, c1, s1, nullptr, nullptr, m);
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = threadIdx.x + q * WAVE;
+            const int s = threadIdx.x + q * blockDim.x;
             if (s < N) yy[(size_t)t * N + s] = w0[q] - sg1 * e1[q] * bufB[s];
         }
     }
@@ -226,7 +241,7 @@ __global__ void __launch_bounds__(WAVE) k_mul(double *__restrict__ y, const doub
 
 
 template <int NPL>
-__global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m, int parity) {
+__global__ void __launch_bounds__(1024) k_cg_ap(CgBufs B, ModelDev m, int parity) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bufA = lds, *bufB = lds + m.N;
     const int N = m.N, L = m.L;
@@ -285,7 +300,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m, int parity
     double p0[NPL], pp[NPL], w0[NPL], e1[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         if (s < N) {
             const size_t im = (size_t)tm1 * N + s, i0 = (size_t)t * N + s, ip = (size_t)tp1 * N + s;
             double pm;
@@ -306,7 +321,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m, int parity
     cb_sweep<2, false>(bufA, bufB, c0, s0, c1, s1, m);
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         if (s < N) {
             w0[q] = p0[q] - sg0 * bufA[s];
             bufB[s] = pp[q] - sg1 * bufB[s];
@@ -317,14 +332,14 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m, int parity
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         if (s < N) {
             const double zz = w0[q] - sg1 * e1[q] * bufB[s];
             z[(size_t)t * N + s] = zz;
             acc += p0[q] * zz;
         }
     }
-    acc = wave_sum(acc);
+    acc = block_sum(acc, lds + 2 * (size_t)N);
     if (threadIdx.x == 0) {
         B.pap[(size_t)rhs * B.npap + t] = acc;
         if (t == 0) {
@@ -336,7 +351,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap(CgBufs B, ModelDev m, int parity
 }
 
 template <int NPL>
-__global__ void __launch_bounds__(WAVE) k_cg_xr(CgBufs B, int N, int L, int parity) {
+__global__ void __launch_bounds__(1024) k_cg_xr(CgBufs B, int N, int L, int parity) {
     const int t = blockIdx.x, rhs = blockIdx.y;
     const size_t ndim = (size_t)N * L;
     const CgState S = B.state[2 * rhs + parity];
@@ -349,7 +364,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_xr(CgBufs B, int N, int L, int pari
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         if (s < N) {
             const size_t i = (size_t)t * N + s;
             x[i] += alpha * p[i];                           // :205 / :282
@@ -358,7 +373,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_xr(CgBufs B, int N, int L, int pari
             acc += rn * rn;
         }
     }
-    acc = wave_sum(acc);
+    __shared__ double scratch[16];
+    acc = block_sum(acc, scratch);
     if (threadIdx.x == 0) B.rr[(size_t)rhs * L + t] = acc;
 }
 
@@ -501,14 +517,14 @@ __device__ __forceinline__ void kpm_mulAprime(double2 (&out)[NPL], const double2
     const int N = m.N;
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         if (s < N) buf[s] = TRANSPOSED ? un[q] : make_double2(eb[q] * un[q].x, eb[q] * un[q].y);
     }
     __syncthreads();
     cb_sweep_z<TRANSPOSED>(buf, K.cbar, K.sbar, m);
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         if (s < N) {
             double2 av = buf[s];
             if (TRANSPOSED) { av.x *= eb[q]; av.y *= eb[q]; }
@@ -558,7 +574,7 @@ __device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&
 }
 
 template <int NPL>
-__global__ void __launch_bounds__(WAVE) k_kpm_cheb(double2 *__restrict__ nu, KpmDev K, ModelDev m, int Lo2,
+__global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, KpmDev K, ModelDev m, int Lo2,
                                                    const CgState *state) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double2 *buf = reinterpret_cast<double2 *>(lds);
@@ -573,7 +589,7 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb(double2 *__restrict__ nu, Kpm
     double eb[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         vin[q] = (s < N) ? u[s] : make_double2(0.0, 0.0);
         eb[q] = (s < N) ? K.Ebar[s] : 0.0;
     }
@@ -581,7 +597,7 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb(double2 *__restrict__ nu, Kpm
     kpm_series<NPL, false, false>(res, mid, buf, eb, c, order, K, m);   // M^-1[w,w]                     (:650-677)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = threadIdx.x + q * WAVE;
+        const int s = threadIdx.x + q * blockDim.x;
         if (s < N) u[s] = res[q];
     }
 }
@@ -660,6 +676,10 @@ KpmDev elph_kpm_dev(const elph_handle_s *h) {
     return K;
 }
 
+// generic kernels: workgroup of BS = 64*W threads, W = ceil(N/512); NPL = ceil(N/BS) <= 8
+static inline int gen_bs(const elph_handle_s *h) { return ELPH_WAVE * (int)((h->N + 511) / 512); }
+static inline int gen_npl(const elph_handle_s *h) { const int bs = gen_bs(h); return (int)((h->N + bs - 1) / bs); }
+
 #define DISPATCH_NPL(npl, CALL)                                   \
     switch (npl) {                                                \
         case 1: { constexpr int NPL = 1; CALL; } break;           \
@@ -711,11 +731,11 @@ int elph_launch_mul(elph_handle_s *h, int which, double *yS, const double *vS, i
     if (h->fast) return elph_fast_mul(h, which, yS, vS, nvec);
     ModelDev m = elph_model_dev(h);
     dim3 grid((unsigned)h->L, (unsigned)nvec, 1);
-    const size_t shm = 2 * (size_t)h->N * sizeof(double);
-    DISPATCH_NPL(h->npl, {
-        if (which == 0) hipLaunchKernelGGL((k_mul<NPL, 0>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
-        else if (which == 1) hipLaunchKernelGGL((k_mul<NPL, 1>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
-        else hipLaunchKernelGGL((k_mul<NPL, 2>), grid, dim3(WAVE), shm, h->stream, yS, vS, m);
+    const size_t shm = (2 * (size_t)h->N + 16) * sizeof(double);
+    DISPATCH_NPL(gen_npl(h), {
+        if (which == 0) hipLaunchKernelGGL((k_mul<NPL, 0>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, yS, vS, m);
+        else if (which == 1) hipLaunchKernelGGL((k_mul<NPL, 1>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, yS, vS, m);
+        else hipLaunchKernelGGL((k_mul<NPL, 2>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, yS, vS, m);
     });
     return check_launch("k_mul");
 }
@@ -767,8 +787,8 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         int rcf = elph_fast_kpm_cheb(h, nrhs, st);
         if (rcf) return rcf;
     } else {
-        DISPATCH_NPL(h->npl, {
-            hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(WAVE), shm, h->stream, h->d_nu,
+        DISPATCH_NPL(gen_npl(h), {
+            hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3((unsigned)gen_bs(h)), shm, h->stream, h->d_nu,
                                K, m, Lo2, st);
         });
     }
@@ -844,10 +864,10 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
         ModelDev m = elph_model_dev(h);
         const int N = (int)h->N, L = (int)h->L;
         dim3 grid((unsigned)L, (unsigned)nrhs, 1);
-        const size_t shm = 2 * (size_t)N * sizeof(double);
-        DISPATCH_NPL(h->npl, {
-            hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3(WAVE), shm, h->stream, B, m, (int)(h->ap_count & 1));
-            hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3(WAVE), 0, h->stream, B, N, L, (int)((h->ap_count + 1) & 1));
+        const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
+        DISPATCH_NPL(gen_npl(h), {
+            hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
+            hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3((unsigned)gen_bs(h)), 0, h->stream, B, N, L, (int)((h->ap_count + 1) & 1));
         });
         h->ap_count++;
         rc = check_launch("cg iteration");
@@ -871,10 +891,10 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     ModelDev m = elph_model_dev(h);
     const int N = (int)h->N, L = (int)h->L;
     dim3 grid((unsigned)L, (unsigned)nrhs, 1);
-    const size_t shm = 2 * (size_t)N * sizeof(double);
-    DISPATCH_NPL(h->npl, {
-        if (which == 0) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3(WAVE), shm, h->stream, B, m, (int)(h->ap_count & 1));
-        else hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3(WAVE), 0, h->stream, B, N, L, (int)(h->ap_count & 1));
+    const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
+    DISPATCH_NPL(gen_npl(h), {
+        if (which == 0) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
+        else hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3((unsigned)gen_bs(h)), 0, h->stream, B, N, L, (int)(h->ap_count & 1));
     });
     if (which == 0) h->ap_count++;
     return check_launch("cg kernel");

@@ -212,7 +212,7 @@ def _oracle_model(orc, m):
                           np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
 
 
-@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "e", "B", "C", "D", "E"])
+@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "e", "B", "C", "D", "E", "g", "G", "h"])
 def test_matvec_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models, synth
     m = configs.make_model(tag)
@@ -238,7 +238,7 @@ def test_matvec_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "t", "e", "B", "C", "D", "E"])
+@pytest.mark.parametrize("tag", ["b", "d", "t", "e", "B", "C", "D", "E", "g", "h"])
 def test_cg_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models
     m = configs.make_model(tag, tol=1e-5)
@@ -310,7 +310,7 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "C", "D"])
+@pytest.mark.parametrize("tag", ["b", "C", "D", "g"])
 def test_kpm_vs_oracle(oracle, tag):
     """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle."""
     from elphdynamics_amd import configs, models, preconditioners as pc
