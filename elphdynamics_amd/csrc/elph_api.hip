@@ -154,6 +154,8 @@ static int ensure_capacity(elph_handle_s *h, int nrhs) {
     RC(dev_alloc(&h->d_zp, c * nd));
     RC(dev_alloc(&h->d_tmp, c * nd));
     RC(dev_alloc(&h->d_p, 2 * c * nd));
+    RC(dev_alloc(&h->d_phi, 2 * nd));
+    RC(dev_alloc(&h->d_xfield, nd));
     RC(dev_alloc(&h->d_part, 4 * c * (size_t)h->L * (size_t)h->npl));
     RC(dev_alloc(&h->d_state, 2 * c));
     RC(dev_alloc(&h->d_scal, 4 * c));
@@ -298,7 +300,7 @@ extern "C" int elph_destroy(elph_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
-                    h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state,
+                    h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
                     h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt};
@@ -623,6 +625,64 @@ extern "C" int elph_cg_solve(elph_handle h, double *x, const double *b, double t
     RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, 1));
     HIPCHK(hipMemcpyAsync(x, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fermion force: update_model! + calc_O⁻¹Λϕ! + calc_dSfdx! with x, phi± , X± resident
+// ------------------------------------------------------------------------------------------
+
+extern "C" int elph_fermion_force_holstein(elph_handle h, const double *x, const double *lambda, const double *lambda2,
+                                           const double *mu, double dtau, const double *phi_plus, const double *phi_minus,
+                                           int use_precond, double tol_power, double *dSfdx, double *Xp_out, double *Xm_out,
+                                           int64_t *iters, int *flag) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
+    if (!x || !lambda || !lambda2 || !mu || !phi_plus || !phi_minus || !dSfdx || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ensure_capacity(h, 2));
+    const size_t nd = (size_t)h->ndim, N = (size_t)h->N, bytes = nd * sizeof(double);
+    // update_model! (HolsteinModels.jl:526-549) and x in layout S
+    HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, x, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_expV(h, h->d_stage_in, dtau));
+    RC(elph_launch_r2s(h, h->d_xfield, h->d_stage_in, 1));
+    h->have_E = true;
+    // phi± -> layout S; b± = Λ phi± (HMC.jl:840-842)
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, phi_plus, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, phi_minus, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_phi, h->d_stage_in, 2));
+    RC(elph_launch_lambda_rhs(h, h->d_b, h->d_phi, h->d_xfield, dtau));
+    HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * bytes, h->stream));                      // fill!(O⁻¹Λϕ, 0)  (HMC.jl:854,883)
+    // the two solves as one batch at tol^power (HMC.jl:827-828, restored below as at :912)
+    const double tol0 = h->tol;
+    h->tol = pow(tol0, tol_power);
+    int64_t it2[2] = {0, 0};
+    double res2[2];
+    int fl2[2] = {0, 0};
+    int rc = ldiv_core(h, 2, use_precond, 0, it2, res2, fl2);
+    h->tol = tol0;
+    if (rc) return rc;
+    int64_t tot = it2[0];
+    int fl = fl2[0];
+    if (fl == 0) { tot += it2[1]; fl = fl2[1]; }                                  // a failed first solve suppresses the second (:880)
+    else RC(elph_launch_zero(h, h->d_x + nd, (int64_t)nd));
+    if (fl == 0) tot = (tot + 1) / 2;                                             // cld(iters, 2)  (:907-909)
+    *iters = tot;
+    *flag = fl;
+    // dSf/dx (HMC.jl:790-814)
+    RC(elph_launch_force_holstein(h, h->d_tmp, h->d_x, h->d_phi, h->d_xfield, dtau));
+    RC(elph_launch_s2r(h, h->d_stage_out, h->d_tmp, 1));
+    std::vector<double> F(nd);
+    HIPCHK(hipMemcpyAsync(F.data(), h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (Xp_out || Xm_out) {
+        RC(elph_launch_s2r(h, h->d_stage_in, h->d_x, 2));
+        if (Xp_out) HIPCHK(hipMemcpyAsync(Xp_out, h->d_stage_in, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (Xm_out) HIPCHK(hipMemcpyAsync(Xm_out, h->d_stage_in + nd, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < nd; ++i) dSfdx[i] += F[i];                             // "@. dSfdx += ..." accumulates (:803-811)
     return ELPH_OK;
 }
 

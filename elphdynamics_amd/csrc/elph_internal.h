@@ -143,6 +143,7 @@ struct elph_handle_s {
     double *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_zp = nullptr;
     double *d_p = nullptr;                 // 2 * cap_rhs * ndim (ping-pong)
     double *d_tmp = nullptr;               // cap_rhs*ndim scratch (v''')
+    double *d_phi = nullptr, *d_xfield = nullptr;   // force assembly: phi+- (2*ndim), x in layout S (ndim)
     double *d_part = nullptr;              // partial sums: 4 arrays of cap_rhs * L
     CgState *d_state = nullptr;            // cap_rhs * 2
     CgState *h_state = nullptr;            // pinned, cap_rhs * 2
@@ -202,6 +203,8 @@ int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, con
 int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);
 int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS);
 int elph_launch_zero(elph_handle_s *h, double *p, int64_t n);
+int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau);
+int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau);
 
 // ---- fast path (cg_fast.hip) ----------------------------------------------------------------
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);

@@ -110,3 +110,25 @@ class GreensEstimator:
         mm = (j - 1) * self.L + (tau1 - 1)
         nn = (i - 1) * self.L + (tau2 - 1)
         return self.MinvR[n, nn] * self.R[n, mm]
+
+
+def calc_dSfdx_(dSdx, model, phi_p, phi_m, P=None, power=1.0, return_solutions=False):
+    """Fermion force with everything resident on the GPU between the steps:
+    update_model! + calc_O⁻¹Λϕ!(…, P, power) + calc_dSfdx! (HMC.jl:790-915) in one C-ABI call.
+    dSdx is accumulated into, as the reference does.  Returns (iters, flag[, O⁻¹Λϕ₊, O⁻¹Λϕ₋]).
+    For a preconditioned force call update_model_ + setup_(P) on the current field first (HMC.jl:834)."""
+    import ctypes as C
+    from ._lib import check, dptr
+    assert model.kind == models.HOLSTEIN, "SSH force assembly is not on the device yet"
+    model._push_solver()
+    it, fl = C.c_int64(), C.c_int()
+    Xp = np.empty(model.Ndim) if return_solutions else None
+    Xm = np.empty(model.Ndim) if return_solutions else None
+    check(model._lib.elph_fermion_force_holstein(
+        model._h, dptr(np.ascontiguousarray(model.x)), dptr(model.lam), dptr(model.lam2), dptr(model.mu), model.dtau,
+        dptr(np.ascontiguousarray(phi_p)), dptr(np.ascontiguousarray(phi_m)), 0 if P is None else 1, float(power),
+        dptr(dSdx), dptr(Xp) if return_solutions else None, dptr(Xm) if return_solutions else None,
+        C.byref(it), C.byref(fl)))
+    if return_solutions:
+        return int(it.value), int(fl.value), Xp, Xm
+    return int(it.value), int(fl.value)

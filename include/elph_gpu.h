@@ -138,6 +138,23 @@ int elph_ldiv_batched_dev(elph_handle h, int nrhs, double *X_dev, const double *
                           int use_precond, int64_t maxiter, int64_t *iters,
                           double *residual_error, int *flag);
 
+/* ---------------------------------------------------------------- fermion force */
+
+/* One fermion-force evaluation of the Holstein model with the phonon field, both pseudofermion fields and both
+ * solutions resident on the device between the steps:
+ *   update_model!(model)                                   HolsteinModels.jl:526-549
+ *   calc_O⁻¹Λϕ!(hmc, model, P, power)                      HMC.jl:820-915  (Λ: :921-968; two solves as one batch,
+ *                                                          tolerance tol^power, iters = cld(total,2), flag)
+ *   calc_dSfdx!(hmc, model)                                HMC.jl:790-814  (mulM!, muldMdx! HolsteinModels.jl:691-755,
+ *                                                          muldΛdx! HMC.jl:1005-1025)
+ * dSfdx is ACCUMULATED into (the reference adds the fermionic force to hmc.dSdx).  Xp_out / Xm_out (optional)
+ * receive O⁻¹Λϕ₊ / O⁻¹Λϕ₋.  use_precond needs elph_kpm_setup on the *updated* field, so preconditioned callers
+ * call elph_update_model_holstein + elph_kpm_setup first (setup! runs inside calc_O⁻¹Λϕ!, HMC.jl:834). */
+int elph_fermion_force_holstein(elph_handle h, const double *x, const double *lambda, const double *lambda2,
+                                const double *mu, double dtau, const double *phi_plus, const double *phi_minus,
+                                int use_precond, double tol_power, double *dSfdx, double *Xp_out, double *Xm_out,
+                                int64_t *iters, int *flag);
+
 /* ---------------------------------------------------------------- KPM preconditioner */
 
 /* SymmetricKPMPreconditioner(model, n, buf, c1, c2) — KPMPreconditioners.jl:219-235, ctor :101-146 */

@@ -1221,3 +1221,35 @@ void elpho_muldMdx_holstein(double *dMdx, const double *u, const elpho_model *m,
     if (m->nb > 0) elpho_checkerboard_transpose_mul(y, m->table, m->c, m->s, m->nb, L);
     for (int64_t i = 0; i < N * L; i++) dMdx[i] = y[i] * dMdx[i];
 }
+
+/* HMC.jl:1005-1025: dLdx[n] += vl[n] * (sg dtau (lambda/2 + lambda2 x[n])) Lam[n] * vr[n'], n' = previous tau (wrapped),
+ * sg = -1 for tau = 1 (0-based 0), +1 otherwise */
+void elpho_muldLambdadx_holstein(double *dLdx, const double *vl, const double *vr, const double *Lam, int64_t N,
+                                 int64_t L, double dtau, const double *lambda, const double *lambda2, const double *x) {
+    for (int64_t i = 0; i < N; i++) {
+        int64_t n = i * L, np = i * L + L - 1;
+        dLdx[n] += vl[n] * (-dtau * (lambda[i] / 2 + lambda2[i] * x[n])) * Lam[n] * vr[np];
+        for (int64_t tau = 1; tau < L; tau++) {
+            n = i * L + tau;
+            np = n - 1;
+            dLdx[n] += vl[n] * (dtau * (lambda[i] / 2 + lambda2[i] * x[n])) * Lam[n] * vr[np];
+        }
+    }
+}
+
+/* HMC.jl:790-814: dSfdx += -dMdx(M X+, X+) - dMdx(M X-, X-) + dLdx(phi+, X+) + dLdx(phi-, X-).
+ * scratch: u[N*L], d[N*L] */
+void elpho_calc_dSfdx_holstein(double *dSfdx, const elpho_model *m, const double *Xp, const double *Xm,
+                               const double *phip, const double *phim, const double *Lam, double dtau,
+                               const double *lambda, const double *lambda2, const double *x, double *u, double *d) {
+    const int64_t n = m->N * m->L;
+    const double *X[2] = {Xp, Xm};
+    const double *phi[2] = {phip, phim};
+    for (int k = 0; k < 2; k++) {
+        elpho_mulM(u, m, X[k]);
+        elpho_muldMdx_holstein(d, u, m, X[k], dtau, lambda, lambda2, x);
+        for (int64_t i = 0; i < n; i++) dSfdx[i] += -d[i];
+    }
+    for (int k = 0; k < 2; k++)
+        elpho_muldLambdadx_holstein(dSfdx, phi[k], X[k], Lam, m->N, m->L, dtau, lambda, lambda2, x);
+}

@@ -215,6 +215,14 @@ void elpho_muldMdx_holstein(double *dMdx, const double *u, const elpho_model *m,
                             double dtau, const double *lambda, const double *lambda2,
                             const double *x);
 
+/* HMC.jl:1005-1025 */
+void elpho_muldLambdadx_holstein(double *dLdx, const double *vl, const double *vr, const double *Lam, int64_t N,
+                                 int64_t L, double dtau, const double *lambda, const double *lambda2, const double *x);
+/* HMC.jl:790-814 (accumulates into dSfdx; u, d: scratch [N*L]) */
+void elpho_calc_dSfdx_holstein(double *dSfdx, const elpho_model *m, const double *Xp, const double *Xm,
+                               const double *phip, const double *phim, const double *Lam, double dtau,
+                               const double *lambda, const double *lambda2, const double *x, double *u, double *d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -499,3 +499,70 @@ def test_repeated_solves_are_bit_identical():
             seen.add((tuple(it.tolist()), hashlib.md5(X.tobytes()).hexdigest()))
         assert len(seen) == 1, (tag, nrhs, len(seen))
         m.close()
+
+
+def _oracle_force(oracle, om, m, phi_p, phi_m, tol):
+    """calc_O⁻¹Λϕ! + calc_dSfdx! composed from the oracle's pieces; also returns S_f."""
+    from oracle.oracle import dp
+    import ctypes as C
+    N, L, n = m.Nsites, m.Ltau, m.Ndim
+    Lam = np.zeros(n)
+    oracle.lib.elpho_update_Lambda(dp(Lam), N, L, m.dtau, dp(np.ascontiguousarray(m.x)), dp(m.lam), dp(m.lam2))
+    X, Sf = [], 0.0
+    for phi in (phi_p, phi_m):
+        b = np.zeros(n)
+        oracle.lib.elpho_mulLambda(dp(b), dp(np.ascontiguousarray(phi)), dp(Lam), N, L)
+        x, it, res, fl = oracle.ldiv(om, b, solver_tol=tol, solver_maxiter=20000)
+        assert fl == 0
+        X.append(x)
+        Sf += 0.5 * (b @ x)
+    F = np.zeros(n)
+    u, d = np.zeros(n), np.zeros(n)
+    oracle.lib.elpho_calc_dSfdx_holstein(dp(F), C.byref(om), dp(X[0]), dp(X[1]), dp(np.ascontiguousarray(phi_p)),
+                                         dp(np.ascontiguousarray(phi_m)), dp(Lam), m.dtau, dp(m.lam), dp(m.lam2),
+                                         dp(np.ascontiguousarray(m.x)), dp(u), dp(d))
+    return F, X, Sf
+
+
+@pytest.mark.parametrize("tag", ["b", "B", "d", "g"])
+def test_fermion_force_vs_oracle(oracle, tag):
+    """update_model! + calc_O⁻¹Λϕ! + calc_dSfdx! on the device vs the oracle's composition."""
+    from elphdynamics_amd import configs, hmc, synth
+    m = configs.make_model(tag, tol=1e-11)
+    m.lam2[:] = 0.03 * synth.randn(5, m.Nsites)                 # exercise the lambda2 terms too
+    om_E = oracle.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+    om = oracle.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, om_E)
+    phi_p, phi_m = synth.randn(41, m.Ndim), synth.randn(42, m.Ndim)
+    Fo, Xo, _ = _oracle_force(oracle, om, m, phi_p, phi_m, 1e-11)
+    F = np.ones(m.Ndim)                                           # accumulation: starts from a non-zero array
+    it, fl, Xp, Xm = hmc.calc_dSfdx_(F, m, phi_p, phi_m, None, power=1.0, return_solutions=True)
+    assert fl == 0 and it > 0
+    assert rel(Xp, Xo[0]) < 1e-8 and rel(Xm, Xo[1]) < 1e-8
+    assert rel(F - 1.0, Fo) < 1e-8
+    m.close()
+
+
+def test_fermion_force_is_the_gradient_of_the_action(oracle):
+    """dS_f/dx_k from the device force equals a central finite difference of
+    S_f(x) = 1/2 sum_± (Λϕ±)ᵀ (MᵀM)⁻¹ (Λϕ±)  (HMC.jl:757-783) evaluated with the oracle."""
+    from elphdynamics_amd import configs, hmc, synth
+    m = configs.make_model("b", tol=1e-12)
+    m.lam2[:] = 0.02
+    phi_p, phi_m = synth.randn(51, m.Ndim), synth.randn(52, m.Ndim)
+    F = np.zeros(m.Ndim)
+    it, fl = hmc.calc_dSfdx_(F, m, phi_p, phi_m, None, power=1.0)
+    assert fl == 0
+    x0 = m.x.copy()
+    h = 1e-5
+    for k in (0, 7, m.Ltau, 5 * m.Ltau + 3, m.Ndim - 1):
+        S = []
+        for sgn in (+1, -1):
+            m.x[:] = x0
+            m.x[k] += sgn * h
+            E = oracle.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+            om = oracle.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+            S.append(_oracle_force(oracle, om, m, phi_p, phi_m, 1e-13)[2])
+        fd = (S[0] - S[1]) / (2 * h)
+        assert abs(fd - F[k]) < 2e-6 * max(1.0, abs(F[k])), (k, fd, F[k])
+    m.x[:] = x0
+    m.close()
