@@ -836,6 +836,152 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_ri(double2 *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// KPM Chebyshev recursion for the even-L square lattice (L = 8, 16): checkerboard exchange in REGISTERS.
+// The greedy colouring of the reference yields [x-even | x-odd | y-even | y-odd] (the
+// host verifies the bond table against exactly that pattern before enabling this kernel).  Each lane owns a
+// P x P patch of sites (P = L/8; lanes form an 8 x 8 grid of patches):
+//   * x-even / y-even bonds of a 2x2 patch connect two of the lane's own registers  -> no data movement,
+//   * x-odd / y-odd bonds connect to the neighbouring patch                          -> one wave shuffle per value,
+// so a checkerboard apply is 2 shuffle rounds + FMAs, with no LDS slab, no LDS round trip per colour.
+// Same re/im split as k_kpm_cheb_ri (wave 0 = Re, wave 1 = Im, one LDS exchange per series).
+// ------------------------------------------------------------------------------------------
+
+template <int P>
+struct SqLane {
+    static constexpr int NS = P * P;
+    double c[4][P * P], s[4][P * P];     // per colour, per own site: cosh/sinh of the bond touching it
+    int xp, xm, yp, ym, xe, ye;          // partner lanes: +x, -x, +y, -y neighbours; P == 1: x-even / y-even partner
+};
+
+template <int P, bool REVERSE>
+__device__ __forceinline__ void sq_cb_apply(double (&v)[P * P], const SqLane<P> &T) {
+    // slot index: dx + P*dy
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int col = REVERSE ? 3 - cc : cc;
+        if (P == 2) {
+            if (col == 0 || col == 2) {          // in-lane pairs: (0,d)-(1,d) along x, (d,0)-(d,1) along y
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int i = (col == 0) ? (0 + 2 * d) : (d + 0), j = (col == 0) ? (1 + 2 * d) : (d + 2);
+                    const double t0 = v[i], t1 = v[j];
+                    v[i] = T.c[col][i] * t0 + T.s[col][i] * t1;
+                    v[j] = T.c[col][j] * t1 + T.s[col][j] * t0;
+                }
+            } else {                             // cross-lane: my high-side sites pair with the +neighbour's low-side sites
+                const int up = (col == 1) ? T.xp : T.yp, dn = (col == 1) ? T.xm : T.ym;
+                double fromUp[2], fromDn[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int lo = (col == 1) ? (0 + 2 * d) : (d + 0), hi = (col == 1) ? (1 + 2 * d) : (d + 2);
+                    fromUp[d] = __shfl(v[lo], up, WAVE);      // neighbour's low-side value -> partner of my high-side site
+                    fromDn[d] = __shfl(v[hi], dn, WAVE);      // neighbour's high-side value -> partner of my low-side site
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int lo = (col == 1) ? (0 + 2 * d) : (d + 0), hi = (col == 1) ? (1 + 2 * d) : (d + 2);
+                    v[hi] = T.c[col][hi] * v[hi] + T.s[col][hi] * fromUp[d];
+                    v[lo] = T.c[col][lo] * v[lo] + T.s[col][lo] * fromDn[d];
+                }
+            }
+        } else {                                 // P == 1: one site per lane, every colour is a lane permutation
+            const int partner = (col == 0) ? T.xe : (col == 2) ? T.ye : (col == 1) ? T.xp : T.yp;   // xp/yp hold the odd-colour partner
+            const double t = __shfl(v[0], partner, WAVE);
+            v[0] = T.c[col][0] * v[0] + T.s[col][0] * t;
+        }
+    }
+}
+
+template <int P, bool TRANSPOSED>
+__device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qacc)[P * P], const double (&vin)[P * P],
+                                              const double (&eb)[P * P], const double2 *c, int order, double a, double b,
+                                              const SqLane<P> &T) {
+    constexpr int NS = P * P;
+    double um1[NS], un[NS];
+    {
+        const double2 c0 = c[0];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { Pacc[q] = c0.x * vin[q]; Qacc[q] = c0.y * vin[q]; un[q] = vin[q]; um1[q] = 0.0; }
+    }
+    for (int n = 2; n <= order; ++n) {
+        double w[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) w[q] = TRANSPOSED ? un[q] : eb[q] * un[q];
+        sq_cb_apply<P, TRANSPOSED>(w, T);
+        const double2 cn = c[n - 1];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            double av = w[q];
+            if (TRANSPOSED) av *= eb[q];
+            double up = a * av - b * un[q];
+            if (n > 2) up = 2.0 * up - um1[q];
+            um1[q] = un[q];
+            un[q] = up;
+            Pacc[q] += cn.x * up;
+            Qacc[q] += cn.y * up;
+        }
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_sq(double2 *__restrict__ nu, KpmDev K, const double *__restrict__ sqc,
+                                                          const double *__restrict__ sqs, int N, int Lo2,
+                                                          const CgState *state) {
+    constexpr int NS = P * P, LS = 8 * P;
+    __shared__ double xch[2][NS * WAVE];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int rhs = blockIdx.y;
+    if (state && ld_state(state + 2 * rhs).done) return;
+    const int w = K.wsched[blockIdx.x];
+    const int order = K.order[w];
+    const double2 *c = K.coeff + K.coff[w];
+    double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
+    const int pa = lane & 7, pb = lane >> 3;
+    SqLane<P> T;
+    T.xp = ((pa + 1) & 7) + 8 * pb; T.xm = ((pa + 7) & 7) + 8 * pb;
+    T.yp = pa + 8 * ((pb + 1) & 7); T.ym = pa + 8 * ((pb + 7) & 7);
+    T.xe = (pa ^ 1) + 8 * pb; T.ye = pa + 8 * (pb ^ 1);
+    if (P == 1) {   // odd colours pair (odd, odd+1): an odd coordinate looks up, an even one looks down
+        if (!(pa & 1)) T.xp = T.xm;
+        if (!(pb & 1)) T.yp = T.ym;
+    }
+    int site[NS];
+    double vin[NS], eb[NS], Pa[NS], Qa[NS], mid[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const int dx = q % P, dy = q / P;
+        site[q] = (pa * P + dx) + LS * (pb * P + dy);
+        vin[q] = u[2 * site[q] + wv];
+        eb[q] = K.Ebar[site[q]];
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            T.c[col][q] = sqc[(size_t)col * N + site[q]];
+            T.s[col][q] = sqs[(size_t)col * N + site[q]];
+        }
+    }
+    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+    kpm_series_sq<P, true>(Pa, Qa, vin, eb, c, order, a, b, T);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const double Qo = xch[wv ^ 1][q * WAVE + lane];
+        mid[q] = (wv == 0) ? Pa[q] + Qo : Pa[q] - Qo;
+    }
+    __syncthreads();
+    kpm_series_sq<P, false>(Pa, Qa, mid, eb, c, order, a, b, T);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const double Qo = xch[wv ^ 1][q * WAVE + lane];
+        u[2 * site[q] + wv] = (wv == 0) ? Pa[q] - Qo : Pa[q] + Qo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 
@@ -939,6 +1085,16 @@ int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
                                m, Lo2, st);
         });
         return check_launch_f("k_kpm_cheb_fast");
+    }
+    static const bool no_sq = []() { const char *e = getenv("ELPH_NO_SQ"); return e && e[0] == '1'; }();
+    if (h->sq_P > 0 && !no_sq) {
+        if (h->sq_P == 2)
+            hipLaunchKernelGGL((k_kpm_cheb_sq<2>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(2 * WAVE), 0, h->stream, h->d_nu, K,
+                               h->d_sq_cbar, h->d_sq_sbar, (int)h->N, Lo2, st);
+        else
+            hipLaunchKernelGGL((k_kpm_cheb_sq<1>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(2 * WAVE), 0, h->stream, h->d_nu, K,
+                               h->d_sq_cbar, h->d_sq_sbar, (int)h->N, Lo2, st);
+        return check_launch_f("k_kpm_cheb_sq");
     }
     const size_t shm = (size_t)(2 * (h->npl * WAVE + 2 * WAVE) + 2 * h->npl * WAVE) * sizeof(double);
     DISPATCH_NPL_F(h->npl, {

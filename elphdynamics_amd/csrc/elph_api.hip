@@ -79,6 +79,8 @@ void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, d
     }
 }
 
+static void detect_square(elph_handle_s *h);
+
 static int build_lane_program(elph_handle_s *h) {
     const int PP = (h->npl + 1) / 2, NE = 4 * PP;
     h->lp_ne = NE;
@@ -117,7 +119,41 @@ static int build_lane_program(elph_handle_s *h) {
     RC(dev_alloc(&h->d_lp_s, ntau * NE * ELPH_WAVE));
     RC(dev_alloc(&h->d_lp_cbar, (size_t)NE * ELPH_WAVE));
     RC(dev_alloc(&h->d_lp_sbar, (size_t)NE * ELPH_WAVE));
+    detect_square(h);
+    if (h->sq_P > 0) {
+        RC(dev_alloc(&h->d_sq_cbar, (size_t)4 * h->N));
+        RC(dev_alloc(&h->d_sq_sbar, (size_t)4 * h->N));
+    }
     return ELPH_OK;
+}
+
+// Recognise the even-L square lattice with the reference's colouring [x-even | x-odd | y-even | y-odd]
+// (L = 8 or 16, site = x + L*y).  Only then may the register-exchange Chebyshev kernel run; any deviation
+// (other lattice, other bond order, disordered table) leaves sq_P = 0 and the LDS kernels are used.
+static void detect_square(elph_handle_s *h) {
+    h->sq_P = 0;
+    int L = 0;
+    if (h->N == 64) L = 8; else if (h->N == 256) L = 16; else return;
+    if (h->ncol != 4 || h->nb != 2 * h->N) return;
+    h->sq_bond.assign((size_t)4 * h->N, -1);
+    for (int col = 0; col < 4; ++col) {
+        const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
+        if (b1 - b0 != h->N / 2) return;
+        for (int n = b0; n < b1; ++n) {
+            const int i = h->h_bi[n], j = h->h_bj[n];
+            const int xi = i % L, yi = i / L, xj = j % L, yj = j / L;
+            bool ok = false;
+            // expected partner of site (x,y): col 0: x^1 ; col 1: x odd -> x+1, even -> x-1 ; cols 2,3 the same along y
+            auto partner = [L](int x, int colpar) { return colpar == 0 ? (x ^ 1) : ((x & 1) ? (x + 1) % L : (x + L - 1) % L); };
+            if (col < 2) ok = (yi == yj) && (partner(xi, col) == xj) && (partner(xj, col) == xi);
+            else ok = (xi == xj) && (partner(yi, col - 2) == yj) && (partner(yj, col - 2) == yi);
+            if (!ok) return;
+            h->sq_bond[(size_t)col * h->N + i] = n;
+            h->sq_bond[(size_t)col * h->N + j] = n;
+        }
+    }
+    for (int v : h->sq_bond) if (v < 0) return;
+    h->sq_P = L / 8;
 }
 
 // uploads the lane-program copy of the per-bond cosh/sinh tables (h_c/h_s)
@@ -303,7 +339,7 @@ extern "C" int elph_destroy(elph_handle h) {
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
-                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt};
+                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -773,6 +809,12 @@ extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *
         elph_lp_pack(h, h->h_sbar.data(), ls.data(), 0.0);
         HIPCHK(hipMemcpy(h->d_lp_cbar, lc.data(), sizeof(double) * lc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_lp_sbar, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
+    }
+    if (h->sq_P > 0) {
+        std::vector<double> qc((size_t)4 * h->N), qs((size_t)4 * h->N);
+        for (size_t k = 0; k < qc.size(); ++k) { qc[k] = h->h_cbar[h->sq_bond[k]]; qs[k] = h->h_sbar[h->sq_bond[k]]; }
+        HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sq_sbar, qs.data(), sizeof(double) * qs.size(), hipMemcpyHostToDevice));
     }
     // eigenvalue bounds (:272-273) — injected or Arnoldi with caller-supplied start vectors
     if (!(std::isfinite(e_min) && std::isfinite(e_max))) {

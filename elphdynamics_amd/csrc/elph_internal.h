@@ -130,6 +130,10 @@ struct elph_handle_s {
     std::vector<unsigned> h_lp_ij;
     unsigned *d_lp_ij = nullptr;
     double *d_lp_c = nullptr, *d_lp_s = nullptr, *d_lp_cbar = nullptr, *d_lp_sbar = nullptr;
+    // even-L square lattice (L = 8 or 16) recognised in the bond table: P = L/8, per-site per-colour coefficients
+    int sq_P = 0;
+    std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
+    double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
     int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/8 force
 

@@ -310,7 +310,7 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "C", "D", "g"])
+@pytest.mark.parametrize("tag", ["b", "B", "C", "D", "g"])
 def test_kpm_vs_oracle(oracle, tag):
     """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle."""
     from elphdynamics_amd import configs, models, preconditioners as pc
