@@ -40,6 +40,10 @@ ALG_BYTES_PER_ELT = {          # SURVEY.md §8(d), f64, perfect fusion
 }
 
 
+DESCR = {"A": "Holstein single site (holstein_hmc_single_site.toml)", "B": "Holstein square L=8 Ntau=40",
+         "C": "Holstein square L=16 Ntau=160", "D": "Holstein honeycomb L=12 Ntau=120", "E": "optical SSH square L=16 Ntau=160"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +126,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE config {args.config}: Holstein square L=16 Ntau=160 (N=256, Ndim=40960), "
+                "workload": f"BASELINE config {args.config}: {DESCR.get(args.config, args.config)} "
+                            f"(N={m.Nsites}, Ltau={m.Ltau}, Ndim={m.Ndim}), "
                             f"{'KPM-preconditioned' if args.precond else 'un-preconditioned'} CG iteration, "
                             f"nrhs={nrhs} right-hand sides per chain, {world} independent chain(s) (1 per GPU)",
                 "nrhs": nrhs, "ndim": ndim, "preconditioned": bool(args.precond),
@@ -138,14 +143,19 @@ def main():
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
         run(4, nrhs, 320, graph=0)
         ms_ap = run(4, nrhs, reps, graph=0) / reps
-        alg = ALG_BYTES_PER_ELT["k_cg_ap"] * ndim * nrhs
+        if m.kind == 1:   # SSH mat-vec: 16 B x Ndim + 16 B x Ltau x Nbonds; p-update 24 B x Ndim
+            mv = 16.0 * ndim + 16.0 * m.Ltau * m.Nbonds
+            alg_ap, alg_it = (2 * mv + 24.0 * ndim) * nrhs, (2 * mv + 72.0 * ndim) * nrhs
+        else:
+            alg_ap, alg_it = ALG_BYTES_PER_ELT["k_cg_ap"] * ndim * nrhs, ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs
+        alg = alg_ap
         ach = alg / (ms_ap * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(f"k_cg_ap_nrhs{nrhs}", {}).get("hbm_bytes_per_launch")
+                traffic = tj.get(f"k_cg_ap_nrhs{nrhs}", {}).get("hbm_bytes_per_launch") if args.config == "C" else None
             except Exception:
                 traffic = None
         Tsl = C.c_int()
@@ -159,8 +169,8 @@ def main():
         ms_xr = run(5, nrhs, reps, graph=0) / reps
         out["roofline"]["k_cg_xr_avg_launch_us"] = ms_xr * 1e3
         out["roofline"]["whole_iteration"] = {
-            "algorithmic_bytes_per_step": ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs,
-            "achieved_GBs": ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs * K / (ms_events * 1e-3) / 1e9,
+            "algorithmic_bytes_per_step": alg_it,
+            "achieved_GBs": alg_it * K / (ms_events * 1e-3) / 1e9,
         }
         out["roofline"]["whole_iteration"]["frac"] = out["roofline"]["whole_iteration"]["achieved_GBs"] / HBM_PEAK_GBS
 
@@ -214,8 +224,12 @@ def main():
             try:
                 from oracle.oracle import Oracle
                 orc = Oracle(fast=True)
-                E = orc.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
-                om = orc.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+                if m.kind == 0:
+                    E = orc.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+                    om = orc.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+                else:
+                    om = orc.make_model(1, m.Nsites, m.Ltau, m.neighbor_table, np.ascontiguousarray(m.cosht).reshape(-1),
+                                        np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
                 b0 = np.ascontiguousarray(B[0])
                 tt = time.perf_counter()
                 orc.cg_solve(om, b0, tol=0.0, maxiter=200)
@@ -229,6 +243,23 @@ def main():
                                                  f"config-{args.config} workload, oracle/elph_oracle.c built -O3 -march=native "
                                                  f"-ffast-math, single thread ({os.cpu_count()} host cores present)",
                                        "cg_iters_per_sec": n_it / dt, "seconds": dt}
+                if m.kind == 0:
+                    try:     # all-host-cores variant: NOT the reference's configuration (it is single-threaded)
+                        from oracle import oracle as _om
+                        best = None
+                        for nt in sorted({min(8, os.cpu_count()), min(32, os.cpu_count()), min(64, os.cpu_count())}):
+                            secs, _ = _om.cg_iterations_omp(om, b0, 100, nt)          # warm-up + cost estimate
+                            n_omp = int(max(100, min(20000, 3.0 / max(secs / 100, 1e-7))))  # ~3 s per thread count
+                            secs, _ = _om.cg_iterations_omp(om, b0, n_omp, nt)
+                            rate = 2.0 * n_omp / secs
+                            if best is None or rate > best[0]:
+                                best = (rate, nt)
+                        out["cpu_baseline_all_cores"] = {"value": best[0], "unit": "matvec/s", "cores": best[1],
+                                                         "kind": "port", "note": "OpenMP over sites / bonds-within-colour / "
+                                                         "BLAS-1 reductions; best of 8/32/64 threads; NOT the reference's "
+                                                         "configuration (single-threaded, ElPhDynamics.jl:74-75)"}
+                    except Exception as e:
+                        out["cpu_baseline_all_cores"] = {"value": None, "note": f"failed: {e}"}
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out))

@@ -1253,3 +1253,113 @@ void elpho_calc_dSfdx_holstein(double *dSfdx, const elpho_model *m, const double
     for (int k = 0; k < 2; k++)
         elpho_muldLambdadx_holstein(dSfdx, phi[k], X[k], Lam, m->N, m->L, dtau, lambda, lambda2, x);
 }
+
+/* ====================================================================== */
+/* OpenMP variant of the un-preconditioned CG iteration (CPU baseline only) */
+/* ====================================================================== */
+/* NOT the reference's configuration: the reference pins BLAS and FFTW to one thread and has no threading
+ * (ElPhDynamics.jl:74-75).  This is the "what if the CPU path used all host cores" number BASELINE.md asks for:
+ * same passes as above, with  (i) the site loops of mulM!/mulMᵀ! split over threads, (ii) the bonds of one
+ * checkerboard colour (site-disjoint by construction) split over threads, (iii) BLAS-1 as parallel reductions.
+ * Built only into libelph_oracle_omp.so (-fopenmp). */
+#ifdef _OPENMP
+#include <omp.h>
+
+static int64_t omp_colours(const int64_t *table, int64_t nb, int64_t N, int64_t *off /* nb+1 */) {
+    char *used = (char *)calloc((size_t)N, 1);
+    int64_t nc = 0;
+    off[0] = 0;
+    for (int64_t n = 0; n < nb; n++) {
+        int64_t i = table[2 * n] - 1, j = table[2 * n + 1] - 1;
+        if (used[i] || used[j]) {
+            off[++nc] = n;
+            memset(used, 0, (size_t)N);
+        }
+        used[i] = used[j] = 1;
+    }
+    if (nb > 0) off[++nc] = nb;
+    free(used);
+    return nc;
+}
+
+static void omp_cb(double *y, const elpho_model *m, const int64_t *off, int64_t nc, int reverse) {
+    const int64_t L = m->L;
+    for (int64_t cc = 0; cc < nc; cc++) {
+        const int64_t col = reverse ? nc - 1 - cc : cc;
+#pragma omp for schedule(static)
+        for (int64_t n = off[col]; n < off[col + 1]; n++) {
+            const double cn = m->c[n], sn = m->s[n];
+            double *yi = y + (m->table[2 * n] - 1) * L, *yj = y + (m->table[2 * n + 1] - 1) * L;
+            for (int64_t tau = 0; tau < L; tau++) {
+                const double t1 = yi[tau], t2 = yj[tau];
+                yi[tau] = cn * t1 + sn * t2;
+                yj[tau] = cn * t2 + sn * t1;
+            }
+        }
+    }
+}
+
+/* Runs `niter` CG iterations (no stop test) on a Holstein model with `nthreads` threads; returns seconds. */
+double elpho_cg_iterations_omp(const elpho_model *m, double *x, const double *b, int64_t niter, int nthreads) {
+    const int64_t N = m->N, L = m->L, n = N * L;
+    if (m->kind != 0) return -1.0;
+    int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m->nb + 2));
+    const int64_t nc = omp_colours(m->table, m->nb, N, off);
+    double *r = (double *)malloc(sizeof(double) * (size_t)n), *p = (double *)malloc(sizeof(double) * (size_t)n);
+    double *z = (double *)malloc(sizeof(double) * (size_t)n), *w = (double *)malloc(sizeof(double) * (size_t)n);
+    memset(x, 0, sizeof(double) * (size_t)n);
+    memcpy(r, b, sizeof(double) * (size_t)n);
+    memcpy(p, b, sizeof(double) * (size_t)n);
+    double rho = 0.0, pap = 0.0, rr = 0.0;
+    for (int64_t i = 0; i < n; i++) rho += r[i] * r[i];
+    omp_set_num_threads(nthreads);
+    const double t0 = omp_get_wtime();
+#pragma omp parallel
+    {
+        for (int64_t it = 0; it < niter; it++) {
+            /* w = M p */
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < N; i++)
+                for (int64_t tau = 0; tau < L; tau++) w[i * L + tau] = m->E[i * L + tau] * p[i * L + (tau == 0 ? L - 1 : tau - 1)];
+            omp_cb(w, m, off, nc, 0);
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < N; i++) {
+                w[i * L] = p[i * L] + w[i * L];
+                for (int64_t tau = 1; tau < L; tau++) w[i * L + tau] = p[i * L + tau] - w[i * L + tau];
+            }
+            /* z = M^T w */
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < n; i++) z[i] = w[i];
+            omp_cb(z, m, off, nc, 1);
+#pragma omp single
+            pap = 0.0;
+#pragma omp for schedule(static) reduction(+ : pap)
+            for (int64_t i = 0; i < N; i++) {
+                double *zi = z + i * L;
+                const double *wi = w + i * L, *Ei = m->E + i * L;
+                const double zL = wi[L - 1] + Ei[0] * zi[0];
+                for (int64_t tau = 0; tau < L - 1; tau++) zi[tau] = wi[tau] - Ei[tau + 1] * zi[tau + 1];
+                zi[L - 1] = zL;
+                for (int64_t tau = 0; tau < L; tau++) pap += p[i * L + tau] * zi[tau];
+            }
+#pragma omp single
+            rr = 0.0;
+            const double alpha = rho / pap;
+#pragma omp for schedule(static) reduction(+ : rr)
+            for (int64_t i = 0; i < n; i++) {
+                x[i] += alpha * p[i];
+                r[i] -= alpha * z[i];
+                rr += r[i] * r[i];
+            }
+            const double beta = rr / rho;
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < n; i++) p[i] = r[i] + beta * p[i];
+#pragma omp single
+            rho = rr;
+        }
+    }
+    const double t1 = omp_get_wtime();
+    free(off); free(r); free(p); free(z); free(w);
+    return t1 - t0;
+}
+#endif

@@ -22,11 +22,21 @@ P_i64 = C.POINTER(C.c_int64)
 P_dbl = C.POINTER(C.c_double)
 
 
-def build(fast=False):
+def build(fast=False, omp=False):
     """(Re)build the oracle shared library with gcc via oracle/Makefile."""
-    target = "fast" if fast else "all"
+    target = "omp" if omp else ("fast" if fast else "all")
     subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
-    return os.path.join(_BUILD, "libelph_oracle_fast.so" if fast else "libelph_oracle.so")
+    return os.path.join(_BUILD, {"omp": "libelph_oracle_omp.so", "fast": "libelph_oracle_fast.so", "all": "libelph_oracle.so"}[target])
+
+
+def cg_iterations_omp(model, b, niter, nthreads):
+    """All-host-cores variant of the CG iteration (CPU baseline only; NOT the reference's configuration)."""
+    lib = C.CDLL(build(omp=True))
+    lib.elpho_cg_iterations_omp.restype = c_dbl
+    lib.elpho_cg_iterations_omp.argtypes = [C.POINTER(Model), P_dbl, P_dbl, c_i64, C.c_int]
+    x = np.zeros_like(b)
+    secs = lib.elpho_cg_iterations_omp(C.byref(model), dp(x), dp(b), niter, nthreads)
+    return secs, x
 
 
 def _ptr(a, ty):
