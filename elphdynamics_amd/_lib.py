@@ -28,6 +28,7 @@ SIGNATURES = {
     "elph_set_stream": (c_int, [Handle, C.c_void_p]),
     "elph_synchronize": (c_int, [Handle]),
     "elph_update_model_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl]),
+    "elph_update_model_holstein_chains": (c_int, [Handle, c_int, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl]),
     "elph_set_expV": (c_int, [Handle, P_dbl]),
     "elph_update_model_ssh": (c_int, [Handle, P_dbl, P_dbl, P_dbl]),
     "elph_mulM": (c_int, [Handle, P_dbl, P_dbl]),

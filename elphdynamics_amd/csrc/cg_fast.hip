@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(WAVE) k_mul_fast(double *__restrict__ y, const
     const double *vv = v + vec;
     double *yy = y + vec;
     const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
-    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+    const double *Ech = m.E + (size_t)(vecid % m.nchains) * m.E_chain_stride;
+    const double *E0 = Ech + (size_t)t * m.E_tau_stride, *E1 = Ech + (size_t)tp1 * m.E_tau_stride;
 
     unsigned ij[NE];
     double c0[NE], s0[NE], c1[NE], s1[NE];
@@ -238,7 +239,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
     const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
     double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
     double *z = B.z + (size_t)rhs * ndim;
-    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+    const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
+    const double *E0 = Ech + (size_t)t * m.E_tau_stride, *E1 = Ech + (size_t)tp1 * m.E_tau_stride;
 
     double sm[NPL], s0v[NPL], sp[NPL], qm[NPL], q0[NPL], qp[NPL], e0[NPL], e1[NPL];
 #pragma unroll
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
         for (int q = 0; q < NPL; ++q) { const size_t i = (size_t)t * N + sc[q]; sv[q] = src[i]; qv[q] = pold[i]; }
     };
     auto load_e = [&](int t, double (&ev)[NPL]) {
-        const double *Et = m.E + (size_t)t * m.E_tau_stride;
+        const double *Et = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride + (size_t)t * m.E_tau_stride;
 #pragma unroll
         for (int q = 0; q < NPL; ++q) ev[q] = Et[sc[q]];
     };

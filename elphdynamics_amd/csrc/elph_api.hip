@@ -281,6 +281,7 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
     if ((rc = dev_alloc(&h->d_s, ncs))) return fail(rc);
     const size_t nE = (kind == ELPH_MODEL_SSH) ? (size_t)nsites : (size_t)h->ndim;
     if ((rc = dev_alloc(&h->d_E, nE))) return fail(rc);
+    h->E_cap = (int64_t)nE;
     if ((rc = dev_alloc(&h->d_lam, 3 * (size_t)nsites))) return fail(rc);
     if (nbonds > 0) {
         if (hipMemcpy(h->d_bi, h->h_bi.data(), sizeof(int) * nbonds, hipMemcpyHostToDevice) != hipSuccess ||
@@ -382,9 +383,38 @@ extern "C" int elph_update_model_holstein(elph_handle h, const double *x, const 
     HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_stage_in, x, (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); }
     RC(elph_launch_expV(h, h->d_stage_in, dtau));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_E = true;
+    return ELPH_OK;
+}
+
+// several independent phonon configurations (chains) resident at once: right-hand side r of a batched solve
+// uses chain r % nchains.  X: nchains * ndim (reference layout, chain-major).
+extern "C" int elph_update_model_holstein_chains(elph_handle h, int nchains, const double *X, const double *lambda,
+                                                 const double *lambda2, const double *mu, double dtau) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
+    if (nchains < 1 || !X || !lambda || !lambda2 || !mu) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    const size_t N = (size_t)h->N, nd = (size_t)h->ndim;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((int64_t)nchains * (int64_t)nd > h->E_cap) {
+        RC(dev_alloc(&h->d_E, (size_t)nchains * nd));
+        h->E_cap = (int64_t)nchains * (int64_t)nd;
+    }
+    drop_graphs(h);
+    h->nchains = nchains;
+    HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int c = 0; c < nchains; ++c) {
+        HIPCHK(hipMemcpyAsync(h->d_stage_in, X + (size_t)c * nd, nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        RC(elph_launch_expV(h, h->d_stage_in, dtau, c));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->have_E = true;
+    h->kpm_ready = false;   // the preconditioner belongs to ONE configuration
     return ELPH_OK;
 }
 
@@ -393,6 +423,7 @@ extern "C" int elph_set_expV(elph_handle h, const double *expnDtauV) {
     if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
     if (!expnDtauV) { elph_set_error("null argument"); return ELPH_E_ARG; }
     HIPCHK(hipMemcpyAsync(h->d_stage_in, expnDtauV, (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); }
     RC(elph_launch_r2s(h, h->d_E, h->d_stage_in, 1));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_E = true;
@@ -676,6 +707,7 @@ extern "C" int elph_fermion_force_holstein(elph_handle h, const double *x, const
     if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
     if (!x || !lambda || !lambda2 || !mu || !phi_plus || !phi_minus || !dSfdx || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
     RC(ensure_capacity(h, 2));
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); }
     const size_t nd = (size_t)h->ndim, N = (size_t)h->N, bytes = nd * sizeof(double);
     // update_model! (HolsteinModels.jl:526-549) and x in layout S
     HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -780,6 +812,7 @@ extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *
     CHECK_H(h);
     if (!h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     RC(need_model(h));
+    if (h->nchains != 1) { elph_set_error("the KPM preconditioner is built for one phonon configuration; nchains = %d", h->nchains); return ELPH_E_UNSUPPORTED; }
     HIPCHK(hipStreamSynchronize(h->stream));
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)

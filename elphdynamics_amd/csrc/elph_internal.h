@@ -43,6 +43,8 @@ struct ModelDev {
     int N, L, nb, ncol;
     int cs_tau_stride;   // 0 (Holstein: c,s per bond) or nb (SSH: c,s per (tau,bond))
     int E_tau_stride;    // N (Holstein: E per (tau,site)) or 0 (SSH: E per site)
+    int nchains;         // independent phonon configurations resident in E (right-hand side r uses chain r % nchains)
+    long long E_chain_stride;   // ndim (Holstein) between chains; unused when nchains == 1
     const int *bi;       // [nb] 0-based first site of bond, checkerboard order
     const int *bj;       // [nb]
     const int *coloff;   // [ncol+1] colour boundaries into the bond list
@@ -123,6 +125,8 @@ struct elph_handle_s {
     int *d_bi = nullptr, *d_bj = nullptr, *d_coloff = nullptr;
     double *d_c = nullptr, *d_s = nullptr, *d_E = nullptr;
     bool have_E = false;
+    int nchains = 1;                       // Holstein: independent chains sharing one handle / one batch
+    int64_t E_cap = 0;                     // doubles allocated for d_E
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
     // lane program (fast path, ncol <= 4)
     bool fast = false;
@@ -195,7 +199,7 @@ KpmDev elph_kpm_dev(const elph_handle_s *h);
 
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec);
 int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec);
-int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau);
+int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain = 0);
 int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
 int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec);
 int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec);

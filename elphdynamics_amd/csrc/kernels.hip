@@ -10,6 +10,8 @@
 //
 // Reference semantics: SURVEY.md Appendix A; file:line citations at each kernel.
 
+#include <cstdlib>
+
 #include "elph_internal.h"
 
 #define WAVE ELPH_WAVE
@@ -160,7 +162,8 @@ __global__ void __launch_bounds__(1024) k_mul(double *__restrict__ y, const doub
     const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
     const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
     const double *c1 = m.c + (size_t)tp1 * m.cs_tau_stride, *s1 = m.s + (size_t)tp1 * m.cs_tau_stride;
-    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+    const double *Ech = m.E + (size_t)(blockIdx.y % m.nchains) * m.E_chain_stride;
+    const double *E0 = Ech + (size_t)t * m.E_tau_stride, *E1 = Ech + (size_t)tp1 * m.E_tau_stride;
 
     if (WHICH == 0) {  // y = M v
         double v0[NPL];
@@ -295,7 +298,8 @@ __global__ void __launch_bounds__(1024) k_cg_ap(CgBufs B, ModelDev m, int parity
     const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
     const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
     const double *c1 = m.c + (size_t)tp1 * m.cs_tau_stride, *s1 = m.s + (size_t)tp1 * m.cs_tau_stride;
-    const double *E0 = m.E + (size_t)t * m.E_tau_stride, *E1 = m.E + (size_t)tp1 * m.E_tau_stride;
+    const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
+    const double *E0 = Ech + (size_t)t * m.E_tau_stride, *E1 = Ech + (size_t)tp1 * m.E_tau_stride;
 
     double p0[NPL], pp[NPL], w0[NPL], e1[NPL];
 #pragma unroll
@@ -684,7 +688,7 @@ __global__ void __launch_bounds__(1024) k_force_holstein(double *__restrict__ F,
     const int tm1 = (t == 0) ? L - 1 : t - 1;
     const double sg = (t == 0) ? -1.0 : 1.0;
     const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
-    const double *E0 = m.E + (size_t)t * m.E_tau_stride;
+    const double *E0 = m.E + (size_t)t * m.E_tau_stride;   // force kernel: single chain
     double xmp[NPL], xmm[NPL], x0p[NPL], x0m[NPL], e[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
@@ -730,8 +734,11 @@ __global__ void __launch_bounds__(1024) k_force_holstein(double *__restrict__ F,
 ModelDev elph_model_dev(const elph_handle_s *h) {
     ModelDev m;
     m.N = (int)h->N; m.L = (int)h->L; m.nb = (int)h->nb; m.ncol = h->ncol;
+    { static const bool nosweep = []() { const char *e = getenv("ELPH_DBG_NOSWEEP"); return e && e[0] == '1'; }(); if (nosweep) m.ncol = 0; }   // timing experiments only
     m.cs_tau_stride = (h->kind == ELPH_MODEL_SSH) ? (int)h->nb : 0;
     m.E_tau_stride = (h->kind == ELPH_MODEL_SSH) ? 0 : (int)h->N;
+    m.nchains = h->nchains;
+    m.E_chain_stride = (long long)h->ndim;
     m.bi = h->d_bi; m.bj = h->d_bj; m.coloff = h->d_coloff;
     m.c = h->d_c; m.s = h->d_s; m.E = h->d_E;
     m.lp_ij = h->d_lp_ij; m.lp_c = h->d_lp_c; m.lp_s = h->d_lp_s;
@@ -789,9 +796,9 @@ int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec
     return check_launch("k_transpose(s2r)");
 }
 
-int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau) {
+int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain) {
     dim3 grid((unsigned)((h->L + 31) / 32), (unsigned)((h->N + 31) / 32), 1);
-    hipLaunchKernelGGL(k_expV, grid, dim3(32, 8), 0, h->stream, h->d_E, xR, h->d_lam, (int)h->N, (int)h->L, dtau);
+    hipLaunchKernelGGL(k_expV, grid, dim3(32, 8), 0, h->stream, h->d_E + (size_t)chain * (size_t)h->ndim, xR, h->d_lam, (int)h->N, (int)h->L, dtau);
     return check_launch("k_expV");
 }
 

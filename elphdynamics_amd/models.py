@@ -232,6 +232,17 @@ def update_model_(model):
                                                dptr(np.ascontiguousarray(model.expDtauMu))))
 
 
+def update_model_chains_(model, X):
+    """Several independent phonon configurations (chains) in one handle: X is (nchains, Ndof); in a batched call
+    right-hand side r then uses chain r % nchains (the reference runs chains as separate processes,
+    ElPhDynamics.jl:90-95).  model.x is left untouched."""
+    assert model.kind == HOLSTEIN
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    assert X.ndim == 2 and X.shape[1] == model.Ndof
+    check(model._lib.elph_update_model_holstein_chains(model._h, X.shape[0], dptr(X), dptr(model.lam), dptr(model.lam2),
+                                                       dptr(model.mu), model.dtau))
+
+
 # ----------------------------------------------------------------------------------------------
 # mul! family
 # ----------------------------------------------------------------------------------------------

@@ -83,6 +83,14 @@ int elph_synchronize(elph_handle h);
 int elph_update_model_holstein(elph_handle h, const double *x, const double *lambda,
                                const double *lambda2, const double *mu, double dtau);
 
+/* Several independent phonon configurations (Markov chains; the reference runs them as separate processes with
+ * run-IDs, ElPhDynamics.jl:90-95) resident in ONE handle: X is double[nchains*nsites*ltau], chain-major.  In a
+ * subsequent batched solve / mat-vec right-hand side r uses the fermion matrix of chain r % nchains, so e.g.
+ * nrhs = 2*nchains advances both pseudofermion solves of nchains HMC force evaluations together.  The KPM
+ * preconditioner and the force call are per-configuration and require nchains == 1. */
+int elph_update_model_holstein_chains(elph_handle h, int nchains, const double *X, const double *lambda,
+                                      const double *lambda2, const double *mu, double dtau);
+
 /* Same, but hands over an already exponentiated model.expnDtauV (double[nsites*ltau]). */
 int elph_set_expV(elph_handle h, const double *expnDtauV);
 

@@ -566,3 +566,38 @@ def test_fermion_force_is_the_gradient_of_the_action(oracle):
         assert abs(fd - F[k]) < 2e-6 * max(1.0, abs(F[k])), (k, fd, F[k])
     m.x[:] = x0
     m.close()
+
+
+@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("C", 4, 2), ("C", 32, 2)])
+def test_independent_chains_in_one_batch(tag, nchains, per):
+    """Several phonon configurations resident in one handle (the reference runs chains as separate processes,
+    ElPhDynamics.jl:90-95): right-hand side r of a batch uses the fermion matrix of chain r % nchains, and each
+    solve is bit-identical to the same solve done alone on a single-configuration model."""
+    from elphdynamics_amd import configs, models, synth
+    m = configs.make_model(tag, tol=1e-5)
+    X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=5000 + c) for c in range(nchains)])
+    nrhs = nchains * per
+    B = np.stack([synth.randn(7000 + r, m.Ndim) for r in range(nrhs)])
+    models.update_model_chains_(m, X)
+    Xs = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(Xs, m, B)
+    assert not fl.any()
+    check_r = range(nrhs) if nrhs <= 8 else (0, 1, nchains - 1, nchains, nrhs - 1)
+    for r in check_r:
+        m1 = configs.make_model(tag, tol=1e-5)
+        m1.x[:] = X[r % nchains]
+        models.update_model_(m1)
+        x1 = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x1, m1, np.ascontiguousarray(B[r]))
+        assert fl1 == 0
+        if nrhs * m.Ltau // 8 < 1024:        # same kernel variant as the single solve => same bits
+            assert it1 == it[r] and np.array_equal(x1, Xs[r])
+        else:                                 # large batches use k_cg_ap_chunk<T>: p.z partial sums grouped per chunk,
+            assert abs(it1 - it[r]) <= 5      # so round-off (not the arithmetic per element) differs from the T=1 kernel
+            assert rel(x1, Xs[r]) < 2e-4      # two tol=1e-5 solves of the same system
+        m1.close()
+    # going back to a single configuration resets the chain count
+    models.update_model_(m)
+    x = np.zeros(m.Ndim)
+    models.ldiv_(x, m, np.ascontiguousarray(B[0]))
+    m.close()
