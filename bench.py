@@ -4,16 +4,16 @@
     python bench.py --gpus N --steps K --warmup W [--nrhs R] [--precond]
 
 A *step* is one conjugate-gradient iteration (1 MtM apply = 2 mat-vecs, + the vector updates and both
-reductions; + 1 KPM apply with --precond) advanced for a batch of `nrhs` independent right-hand sides of
-the same fermion matrix, with everything resident in HBM.  W untimed warm-up steps, then exactly K steps
+reductions; + 1 KPM apply with --precond) advanced for a batch of `nrhs` right-hand sides resident in HBM.
+Default batch: 32 independent Markov chains per GPU (32 phonon configurations = 32 different fermion matrices,
+the reference runs them as separate processes, ElPhDynamics.jl:90-95) x the 2 pseudofermion solves of one HMC
+force evaluation each (HMC.jl:851-886) = 64 right-hand sides.  W untimed warm-up steps, then exactly K steps
 bracketed by barrier + device synchronise on both sides; the time is the MAX over ranks and
 value = (2 * nrhs * K * n_gpus) / time.  One JSON line on rank 0.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards over *independent chains*
-(one phonon configuration = one fermion matrix per rank, no data-path collective; "weak" scaling).  This is
-how the reference itself parallelises (independent run-IDs, ElPhDynamics.jl:90-95).  The spatially sharded
-single-solve mode with RCCL halo exchange is a strong-scaling anti-pattern at these sizes
-and is reported separately.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every GPU carries its own chains — no data-path
+collective, "weak" scaling (SURVEY.md §8e replica mode).  The spatially sharded single solve with RCCL halo
+exchange is a strong-scaling anti-pattern at these sizes and is not built.
 
 Also in the JSON line:
   roofline      the dominant kernel k_cg_ap timed ALONE with HIP events on the launch stream:
@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--nrhs", type=int, default=64, help="right-hand sides advanced per step (batch)")
+    ap.add_argument("--chains", type=int, default=32,
+                    help="independent phonon configurations (Markov chains) per GPU sharing the batch: right-hand side r "
+                         "uses the fermion matrix of chain r %% chains (nrhs = 2*chains = both pseudofermion solves of one "
+                         "HMC force evaluation per chain); 1 = all right-hand sides on one matrix")
     ap.add_argument("--config", default="C", help="BASELINE config tag (C = Holstein square L=16 Ltau=160)")
     ap.add_argument("--precond", action="store_true", help="KPM (tau-FFT) preconditioned CG iteration")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -78,7 +82,12 @@ def main():
     m = configs.make_model(args.config, tol=1e-5, device=local_rank if world > 1 else 0,
                            seed=comm.chain_seed(synth.SEED_FIELDS))
     nrhs = args.nrhs
+    nchains = 1 if (args.precond or m.kind != 0) else max(1, min(args.chains, nrhs))
     R, B = configs.rhs(m, nrhs, seed=comm.chain_seed(synth.SEED_RHS))
+    if nchains > 1:      # every chain its own phonon configuration (its own fermion matrix)
+        Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=comm.chain_seed(synth.SEED_FIELDS) + 17 * c)
+                       for c in range(nchains)])
+        models.update_model_chains_(m, Xc)
     what = 3 if args.precond else 1
     P = None
     if args.precond:
@@ -129,9 +138,11 @@ def main():
                 "workload": f"BASELINE config {args.config}: {DESCR.get(args.config, args.config)} "
                             f"(N={m.Nsites}, Ltau={m.Ltau}, Ndim={m.Ndim}), "
                             f"{'KPM-preconditioned' if args.precond else 'un-preconditioned'} CG iteration, "
-                            f"nrhs={nrhs} right-hand sides per chain, {world} independent chain(s) (1 per GPU)",
-                "nrhs": nrhs, "ndim": ndim, "preconditioned": bool(args.precond),
-                "parallelism": f"chains{world}",
+                            f"{nrhs} right-hand sides per step on each GPU = {nchains} independent Markov chain(s) x "
+                            f"{nrhs // nchains} solve(s) each (2 = the two pseudofermion solves of one HMC force evaluation), "
+                            f"{world} GPU(s) with their own chains",
+                "nrhs": nrhs, "chains_per_gpu": nchains, "ndim": ndim, "preconditioned": bool(args.precond),
+                "parallelism": f"gpus{world}xchains{nchains}",
             },
             "cg_iters_per_sec": nrhs * K * world / elapsed,
             "cg_batch_steps_per_sec": K / elapsed,
@@ -174,13 +185,12 @@ def main():
         }
         out["roofline"]["whole_iteration"]["frac"] = out["roofline"]["whole_iteration"]["achieved_GBs"] / HBM_PEAK_GBS
 
+        if nchains > 1:
+            models.update_model_(m)          # back to one configuration for the secondary single-matrix measurements
         # ---- secondary: the same step at other batch sizes (short runs)
         if not args.no_sweep:
             sweep = {}
             for nr in (1, 2, 10, 64, 256):
-                if nr == nrhs:
-                    sweep[str(nr)] = {"us_per_step": 1e3 * ms_events / K, "matvecs_per_sec": 2.0 * nr * K / (ms_events * 1e-3)}
-                    continue
                 _, Bs = configs.rhs(m, nr)
                 check(lib.elph_bench_prepare(m._h, what, nr, _lib.dptr(np.ascontiguousarray(Bs))))
                 run(what, nr, 160)
