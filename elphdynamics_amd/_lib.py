@@ -45,6 +45,7 @@ SIGNATURES = {
     "elph_ldiv_batched_dev": (c_int, [Handle, c_int, C.c_void_p, C.c_void_p, c_int, c_i64, P_i64, P_dbl, P_int]),
     "elph_fermion_force_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl,
                                             P_i64, P_int]),
+    "elph_fermion_force_ssh": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
     "elph_kpm_create": (c_int, [Handle, c_int, c_dbl, c_dbl, c_dbl]),
     "elph_kpm_setup": (c_int, [Handle, P_dbl, P_dbl, c_dbl, c_dbl, P_int, P_dbl, P_dbl]),
     "elph_kpm_orders": (c_int, [Handle, P_i64, P_i64]),

@@ -754,6 +754,52 @@ extern "C" int elph_fermion_force_holstein(elph_handle h, const double *x, const
     return ELPH_OK;
 }
 
+extern "C" int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
+                                      double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters,
+                                      int *flag) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    RC(need_model(h));
+    if (!rhs_plus || !rhs_minus || !q_out || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ensure_capacity(h, 2));
+    const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double), nq = (size_t)h->L * (size_t)h->nb;
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, rhs_plus, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, rhs_minus, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 2));
+    HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * bytes, h->stream));
+    const double tol0 = h->tol;
+    h->tol = pow(tol0, tol_power);
+    int64_t it2[2] = {0, 0};
+    double res2[2];
+    int fl2[2] = {0, 0};
+    int rc = ldiv_core(h, 2, use_precond, 0, it2, res2, fl2);
+    h->tol = tol0;
+    if (rc) return rc;
+    int64_t tot = it2[0];
+    int fl = fl2[0];
+    if (fl == 0) { tot += it2[1]; fl = fl2[1]; }
+    else RC(elph_launch_zero(h, h->d_x + nd, (int64_t)nd));
+    if (fl == 0) tot = (tot + 1) / 2;
+    *iters = tot;
+    *flag = fl;
+    // q[tau][n] on the device (tau-major) -> q_out[n*L + tau] (tau fastest, like the reference's (Ltau x Nbonds) arrays)
+    if (nq > 2 * nd) { elph_set_error("more bonds than 2*nsites: scratch too small"); return ELPH_E_UNSUPPORTED; }
+    double *dq = h->d_p;     // 2*cap*ndim doubles of scratch, free once the solves are done
+    RC(elph_launch_force_ssh(h, dq, h->d_x));
+    std::vector<double> qt(nq);
+    HIPCHK(hipMemcpyAsync(qt.data(), dq, nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (Xp_out || Xm_out) {
+        RC(elph_launch_s2r(h, h->d_stage_in, h->d_x, 2));
+        if (Xp_out) HIPCHK(hipMemcpyAsync(Xp_out, h->d_stage_in, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (Xm_out) HIPCHK(hipMemcpyAsync(Xm_out, h->d_stage_in + nd, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t L = (size_t)h->L, nb = (size_t)h->nb;
+    for (size_t t = 0; t < L; ++t)
+        for (size_t n = 0; n < nb; ++n) q_out[n * L + t] = qt[t * nb + n];
+    return ELPH_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // KPM preconditioner
 // ------------------------------------------------------------------------------------------

@@ -727,6 +727,72 @@ __global__ void __launch_bounds__(1024) k_force_holstein(double *__restrict__ F,
     }
 }
 
+// Fermion force of the SSH model: muldMdx! on bond phonons (SSHModels.jl:707-829) fused with mulM! (HMC.jl:797-806).
+// Per slice tau and per pseudofermion field X:
+//   b0 = E_mu .* X(tau-1);  u = X(tau) - sg CB_tau b0;  c0 = CB_tau^T u;
+//   then bond by bond in checkerboard order  b <- rot_n b,  c <- rot_n^-1 c,  q[tau][n] = c_j b_i + c_i b_j
+// (bonds of one colour are site-disjoint => one colour = one parallel step).  The kernel returns
+// q = q(X+) + q(X-); the caller multiplies by sg(tau) dtau dK_n/dx and scatters to the phonon fields.
+template <int NPL>
+__global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, const double *__restrict__ X, ModelDev m) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int N = m.N, L = m.L;
+    double *bP = lds, *cP = lds + N, *bM = lds + 2 * N, *cM = lds + 3 * N;
+    const size_t ndim = (size_t)N * L;
+    const int t = blockIdx.x;
+    const int tm1 = (t == 0) ? L - 1 : t - 1;
+    const double sg = (t == 0) ? -1.0 : 1.0;
+    const double *ct = m.c + (size_t)t * m.cs_tau_stride, *st = m.s + (size_t)t * m.cs_tau_stride;
+    double x0p[NPL], x0m[NPL], b0p[NPL], b0m[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int s = threadIdx.x + k * blockDim.x;
+        if (s < N) {
+            const double e = m.E[s];
+            x0p[k] = X[(size_t)t * N + s]; x0m[k] = X[ndim + (size_t)t * N + s];
+            b0p[k] = e * X[(size_t)tm1 * N + s]; b0m[k] = e * X[ndim + (size_t)tm1 * N + s];
+            cP[s] = b0p[k]; cM[s] = b0m[k];
+        }
+    }
+    __syncthreads();
+    cb_sweep<2, false>(cP, cM, ct, st, ct, st, m);                      // CB_tau b0
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int s = threadIdx.x + k * blockDim.x;
+        if (s < N) {
+            cP[s] = x0p[k] - sg * cP[s];                                 // u = (M X)(tau)
+            cM[s] = x0m[k] - sg * cM[s];
+            bP[s] = b0p[k]; bM[s] = b0m[k];
+        }
+    }
+    __syncthreads();
+    cb_sweep<2, true>(cP, cM, ct, st, ct, st, m);                       // c0 = CB_tau^T u
+    for (int col = 0; col < m.ncol; ++col) {
+        const int n0 = m.coloff[col], n1 = m.coloff[col + 1];
+        for (int n = n0 + threadIdx.x; n < n1; n += blockDim.x) {
+            const int i = m.bi[n], j = m.bj[n];
+            const double cn = ct[n], sn = st[n];
+            double acc = 0.0;
+            {
+                const double bi = bP[i], bj = bP[j], ci = cP[i], cj = cP[j];
+                const double nbi = cn * bi + sn * bj, nbj = cn * bj + sn * bi;
+                const double nci = cn * ci - sn * cj, ncj = cn * cj - sn * ci;
+                bP[i] = nbi; bP[j] = nbj; cP[i] = nci; cP[j] = ncj;
+                acc += ncj * nbi + nci * nbj;
+            }
+            {
+                const double bi = bM[i], bj = bM[j], ci = cM[i], cj = cM[j];
+                const double nbi = cn * bi + sn * bj, nbj = cn * bj + sn * bi;
+                const double nci = cn * ci - sn * cj, ncj = cn * cj - sn * ci;
+                bM[i] = nbi; bM[j] = nbj; cM[i] = nci; cM[j] = ncj;
+                acc += ncj * nbi + nci * nbj;
+            }
+            q[(size_t)t * m.nb + n] = acc;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
@@ -1033,4 +1099,13 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
                            xS, h->d_lam, m, dtau);
     });
     return check_launch("k_force_holstein");
+}
+
+int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS) {
+    ModelDev m = elph_model_dev(h);
+    const size_t shm = 4 * (size_t)h->N * sizeof(double);
+    DISPATCH_NPL(gen_npl(h), {
+        hipLaunchKernelGGL((k_force_ssh<NPL>), dim3((unsigned)h->L), dim3((unsigned)gen_bs(h)), shm, h->stream, q, XS, m);
+    });
+    return check_launch("k_force_ssh");
 }

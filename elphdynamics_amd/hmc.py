@@ -116,19 +116,38 @@ def calc_dSfdx_(dSdx, model, phi_p, phi_m, P=None, power=1.0, return_solutions=F
     """Fermion force with everything resident on the GPU between the steps:
     update_model! + calc_O⁻¹Λϕ!(…, P, power) + calc_dSfdx! (HMC.jl:790-915) in one C-ABI call.
     dSdx is accumulated into, as the reference does.  Returns (iters, flag[, O⁻¹Λϕ₊, O⁻¹Λϕ₋]).
+    SSH models: phi_p / phi_m are the right-hand sides Λϕ± (Λ = identity) and dSdx has Ndof = Nph*Ltau entries.
     For a preconditioned force call update_model_ + setup_(P) on the current field first (HMC.jl:834)."""
     import ctypes as C
     from ._lib import check, dptr
-    assert model.kind == models.HOLSTEIN, "SSH force assembly is not on the device yet"
     model._push_solver()
     it, fl = C.c_int64(), C.c_int()
     Xp = np.empty(model.Ndim) if return_solutions else None
     Xm = np.empty(model.Ndim) if return_solutions else None
-    check(model._lib.elph_fermion_force_holstein(
-        model._h, dptr(np.ascontiguousarray(model.x)), dptr(model.lam), dptr(model.lam2), dptr(model.mu), model.dtau,
-        dptr(np.ascontiguousarray(phi_p)), dptr(np.ascontiguousarray(phi_m)), 0 if P is None else 1, float(power),
-        dptr(dSdx), dptr(Xp) if return_solutions else None, dptr(Xm) if return_solutions else None,
-        C.byref(it), C.byref(fl)))
+    if model.kind == models.HOLSTEIN:
+        check(model._lib.elph_fermion_force_holstein(
+            model._h, dptr(np.ascontiguousarray(model.x)), dptr(model.lam), dptr(model.lam2), dptr(model.mu), model.dtau,
+            dptr(np.ascontiguousarray(phi_p)), dptr(np.ascontiguousarray(phi_m)), 0 if P is None else 1, float(power),
+            dptr(dSdx), dptr(Xp) if return_solutions else None, dptr(Xm) if return_solutions else None,
+            C.byref(it), C.byref(fl)))
+    else:
+        # SSH: Λ is the identity, phi_p / phi_m are the right-hand sides hmc.Λϕ± = MᵀR± (HMC.jl:680-686,943-973);
+        # the device returns the bond-local brackets q, the scatter to phonon fields is host bookkeeping
+        # (SSHModels.jl:809-823; equivalent fields / primary_field are not modelled here).
+        models.update_model_(model)
+        L, nb = model.Ltau, model.Nbonds
+        q = np.empty(nb * L)
+        check(model._lib.elph_fermion_force_ssh(
+            model._h, dptr(np.ascontiguousarray(phi_p)), dptr(np.ascontiguousarray(phi_m)), 0 if P is None else 1,
+            float(power), dptr(q), dptr(Xp) if return_solutions else None, dptr(Xm) if return_solutions else None,
+            C.byref(it), C.byref(fl)))
+        Q = q.reshape(nb, L)
+        X = model.x.reshape(model.Nph, L)
+        cbidx = model.checkerboard_perm[model.phonon_to_bond - 1] - 1        # checkerboard position of each phonon's bond
+        dKdx = model.alpha[:, None] + 2.0 * model.alpha2[:, None] * X       # ∂K_n/∂x_n  (SSHModels.jl:803)
+        sg = np.ones(L)
+        sg[0] = -1.0                                                         # "flip sign if τ=1" (:809-811)
+        dSdx -= (sg[None, :] * model.dtau * dKdx * Q[cbidx]).reshape(-1)      # dSfdx += -dMdx (HMC.jl:803,808)
     if return_solutions:
         return int(it.value), int(fl.value), Xp, Xm
     return int(it.value), int(fl.value)

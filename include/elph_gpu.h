@@ -163,6 +163,16 @@ int elph_fermion_force_holstein(elph_handle h, const double *x, const double *la
                                 int use_precond, double tol_power, double *dSfdx, double *Xp_out, double *Xm_out,
                                 int64_t *iters, int *flag);
 
+/* The same for the SSH model (bond phonons): the two solves of calc_O⁻¹Λϕ! on the given right-hand sides (Λ is the
+ * identity for SSH, HMC.jl:943-946,970-973, so the caller passes hmc.Λϕ₊/Λϕ₋ = MᵀR±) and the bond-local part of
+ * muldMdx! (SSHModels.jl:707-829) fused with mulM! (HMC.jl:797-806):
+ *   q_out[n*Ltau + tau] = sum_± ( c_j b_i + c_i b_j ) for checkerboard bond n (tau fastest), so that
+ *   dMdx[field(phonon(n), tau)] = sg(tau) * dtau * (alpha + 2 alpha2 x) * q_out[...],   sg(1) = -1, else +1,
+ * which the caller scatters to the phonon fields (primary_field bookkeeping stays on the host) and SUBTRACTS from
+ * dSdx (HMC.jl:803,808).  elph_update_model_ssh must have been called for the current field. */
+int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
+                           double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
+
 /* ---------------------------------------------------------------- KPM preconditioner */
 
 /* SymmetricKPMPreconditioner(model, n, buf, c1, c2) — KPMPreconditioners.jl:219-235, ctor :101-146 */

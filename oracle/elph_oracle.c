@@ -1254,6 +1254,43 @@ void elpho_calc_dSfdx_holstein(double *dSfdx, const elpho_model *m, const double
         elpho_muldLambdadx_holstein(dSfdx, phi[k], X[k], Lam, m->N, m->L, dtau, lambda, lambda2, x);
 }
 
+/* SSHModels.jl:707-829 without the equivalent-field bookkeeping (primary_field == identity):
+ * dMdx[field(phonon,tau)] = sg(tau) * <c_n(tau)| dtau dK_n/dx |b_n(tau)>, accumulated bond by bond in checkerboard order.
+ * bond_to_phonon_cb[n]: 1-based phonon living on checkerboard bond n (0 = none); x, alpha, alpha2 per phonon.
+ * Uses m->vp (b) and m->vppp (c) as scratch, like the reference uses v' and v''. */
+void elpho_muldMdx_ssh(double *dMdx, const double *u, const elpho_model *m, const double *v, double dtau,
+                       const int64_t *bond_to_phonon_cb, const double *alpha, const double *alpha2, const double *x,
+                       int64_t Nph) {
+    const int64_t N = m->N, L = m->L;
+    double *b = m->vp, *c = m->vppp;
+    for (int64_t i = 0; i < N; i++)
+        for (int64_t tau = 0; tau < L; tau++) b[i * L + tau] = m->E[i] * v[i * L + (tau == 0 ? L - 1 : tau - 1)];
+    memcpy(c, u, sizeof(double) * (size_t)(N * L));
+    elpho_checkerboard_transpose_mul_mat(c, m->table, m->c, m->s, m->nb, L);
+    for (int64_t k = 0; k < Nph * L; k++) dMdx[k] = 0.0;
+    for (int64_t n = 0; n < m->nb; n++) {
+        const int64_t ph = bond_to_phonon_cb[n];
+        const int64_t i = m->table[2 * n] - 1, j = m->table[2 * n + 1] - 1;
+        for (int64_t tau = 0; tau < L; tau++) {
+            const double ct = m->c[tau + L * n], st = m->s[tau + L * n];
+            const int64_t it = i * L + tau, jt = j * L + tau;
+            const double bi = b[it], bj = b[jt];
+            b[it] = ct * bi + st * bj;
+            b[jt] = ct * bj + st * bi;
+            const double ci = c[it], cj = c[jt];
+            c[it] = ct * ci - st * cj;
+            c[jt] = ct * cj - st * ci;
+            if (ph != 0) {
+                const int64_t field = (ph - 1) * L + tau;
+                const double dKdx = alpha[ph - 1] + 2 * alpha2[ph - 1] * x[field];
+                double dmdx = c[jt] * dtau * dKdx * b[it] + c[it] * dtau * dKdx * b[jt];
+                if (tau == 0) dmdx = -dmdx;
+                dMdx[field] += dmdx;
+            }
+        }
+    }
+}
+
 /* ====================================================================== */
 /* OpenMP variant of the un-preconditioned CG iteration (CPU baseline only) */
 /* ====================================================================== */

@@ -223,6 +223,11 @@ void elpho_calc_dSfdx_holstein(double *dSfdx, const elpho_model *m, const double
                                const double *phip, const double *phim, const double *Lam, double dtau,
                                const double *lambda, const double *lambda2, const double *x, double *u, double *d);
 
+/* SSHModels.jl:707-829 (no equivalent fields); dMdx[Nph*L] is overwritten */
+void elpho_muldMdx_ssh(double *dMdx, const double *u, const elpho_model *m, const double *v, double dtau,
+                       const int64_t *bond_to_phonon_cb, const double *alpha, const double *alpha2, const double *x,
+                       int64_t Nph);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,7 @@ class Oracle:
         L.elpho_mulLambda.argtypes = [P_dbl, P_dbl, P_dbl, c_i64, c_i64]
         L.elpho_mulLambdaInv.argtypes = [P_dbl, P_dbl, P_dbl, c_i64, c_i64]
         L.elpho_muldMdx_holstein.argtypes = [P_dbl, P_dbl, C.POINTER(Model), P_dbl, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_muldMdx_ssh.argtypes = [P_dbl, P_dbl, C.POINTER(Model), P_dbl, c_dbl, P_i64, P_dbl, P_dbl, P_dbl, c_i64]
         L.elpho_muldLambdadx_holstein.argtypes = [P_dbl, P_dbl, P_dbl, P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_calc_dSfdx_holstein.argtypes = [P_dbl, C.POINTER(Model), P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl]
 

@@ -601,3 +601,68 @@ def test_independent_chains_in_one_batch(tag, nchains, per):
     x = np.zeros(m.Ndim)
     models.ldiv_(x, m, np.ascontiguousarray(B[0]))
     m.close()
+
+
+def _ssh_oracle_bits(oracle, m):
+    om = oracle.make_model(1, m.Nsites, m.Ltau, m.neighbor_table, np.ascontiguousarray(m.cosht).reshape(-1),
+                           np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
+    b2p = np.zeros(m.Nbonds, dtype=np.int64)
+    b2p[m.checkerboard_perm[m.phonon_to_bond - 1] - 1] = np.arange(1, m.Nph + 1)
+    return om, b2p
+
+
+def _ssh_oracle_force(oracle, m, bp, bm, tol):
+    from oracle.oracle import dp, ip
+    import ctypes as C
+    om, b2p = _ssh_oracle_bits(oracle, m)
+    F = np.zeros(m.Ndof)
+    Sf = 0.0
+    for b in (bp, bm):
+        x, it, res, fl = oracle.ldiv(om, np.ascontiguousarray(b), solver_tol=tol, solver_maxiter=20000)
+        assert fl == 0
+        Sf += 0.5 * (b @ x)
+        u = oracle.mulM(om, x)
+        d = np.zeros(m.Ndof)
+        oracle.lib.elpho_muldMdx_ssh(dp(d), dp(u), C.byref(om), dp(x), m.dtau, ip(b2p), dp(m.alpha), dp(m.alpha2),
+                                     dp(np.ascontiguousarray(m.x)), m.Nph)
+        F -= d
+    return F, Sf
+
+
+@pytest.mark.parametrize("tag", ["e", "E"])
+def test_ssh_fermion_force_vs_oracle(oracle, tag):
+    """SURVEY §8f-1 for the SSH model: muldMdx! on bond phonons (SSHModels.jl:707-829) through the device path."""
+    from elphdynamics_amd import configs, hmc, models, synth
+    m = configs.make_model(tag, tol=1e-11)
+    m.alpha2[:] = 0.02
+    models.update_model_(m)
+    bp, bm = synth.randn(61, m.Ndim), synth.randn(62, m.Ndim)
+    Fo, _ = _ssh_oracle_force(oracle, m, bp, bm, 1e-11)
+    F = np.zeros(m.Ndof)
+    it, fl = hmc.calc_dSfdx_(F, m, bp, bm, None, power=1.0)
+    assert fl == 0 and rel(F, Fo) < 1e-8
+    m.close()
+
+
+def test_ssh_fermion_force_is_the_gradient_of_the_action(oracle):
+    """With alpha2 = 0 the reference's dK/dx = alpha + 2 alpha2 x (SSHModels.jl:803) is the exact derivative of
+    update_model!'s t' = t - (alpha x + sign(x) alpha2 x^2) (:528); for alpha2 != 0 and x < 0 the two differ by the
+    sign(x) factor — a reference quirk that the mirror reproduces (parity test above), not a gradient."""
+    from elphdynamics_amd import configs, hmc, models, synth
+    m = configs.make_model("e", tol=1e-12)
+    bp, bm = synth.randn(71, m.Ndim), synth.randn(72, m.Ndim)
+    F = np.zeros(m.Ndof)
+    it, fl = hmc.calc_dSfdx_(F, m, bp, bm, None, power=1.0)
+    assert fl == 0
+    x0 = m.x.copy()
+    h = 1e-5
+    for k in (0, 3, m.Ltau + 1, 7 * m.Ltau + 5, m.Ndof - 1):
+        S = []
+        for sgn in (+1, -1):
+            m.x[:] = x0
+            m.x[k] += sgn * h
+            models.update_model_(m)                      # host-side cosh/sinh of the perturbed field
+            S.append(_ssh_oracle_force(oracle, m, bp, bm, 1e-13)[1])
+        fd = (S[0] - S[1]) / (2 * h)
+        assert abs(fd - F[k]) < 2e-6 * max(1.0, abs(F[k])), (k, fd, F[k])
+    m.close()
