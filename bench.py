@@ -54,6 +54,10 @@ def parse():
                     help="independent phonon configurations (Markov chains) per GPU sharing the batch: right-hand side r "
                          "uses the fermion matrix of chain r %% chains (nrhs = 2*chains = both pseudofermion solves of one "
                          "HMC force evaluation per chain); 1 = all right-hand sides on one matrix")
+    ap.add_argument("--mode", default="chains", choices=["chains", "sharded"],
+                    help="chains (default): independent chains per GPU, no data-path collective (weak scaling). "
+                         "sharded: ONE solve, tau-slabs over the GPUs, RCCL halo exchange + all-gathers per iteration "
+                         "(strong scaling; latency-bound at these sizes, reported for completeness)")
     ap.add_argument("--config", default="C", help="BASELINE config tag (C = Holstein square L=16 Ltau=160)")
     ap.add_argument("--precond", action="store_true", help="KPM (tau-FFT) preconditioned CG iteration")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -71,6 +75,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import numpy as np
+    if args.mode == "sharded":
+        return main_sharded(args, comm)
     from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth
     from elphdynamics_amd._lib import check
 
@@ -274,6 +280,46 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out))
     m.close()
+    comm.close()
+
+
+def main_sharded(args, comm):
+    """ONE config solve sharded over the ranks (elphdynamics_amd/sharded.py): step = one CG iteration."""
+    import numpy as np
+    if comm.world == 1:
+        import torch                      # noqa: F401  (first, so that libelphgpu shares torch's HIP runtime)
+    from elphdynamics_amd import configs, lattice as lat, sharded, synth
+    kind, norb, Ls, bonds, beta, dtau = configs.CONFIGS[args.config]
+    assert kind == "holstein", "sharded mode: Holstein models"
+    la = lat.Lattice(norb, Ls, Ls if Ls > 1 else 1, 1)
+    raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+    cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), dtau)
+    N, Ltau = la.nsites, lat.ltau_from_beta(beta, dtau)
+    x = synth.phonon_field(N, Ltau, beta, dtau)
+    E = np.exp(-dtau * x)                                     # lambda = 1, mu = 0 (configs.py)
+    b = synth.rhs(N * Ltau)
+    s = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"])
+    s.update_model(E)
+    K, W = args.steps, args.warmup
+    s.prepare(b)
+    s.run_iterations(W)
+    s.prepare(b)
+    comm.barrier()
+    t0 = time.perf_counter()
+    s.run_iterations(K)
+    comm.barrier()
+    elapsed = comm.max(time.perf_counter() - t0)
+    if comm.rank == 0:
+        print(json.dumps({
+            "metric": "cg_matvecs_per_sec", "value": 2.0 * K / elapsed, "unit": "matvec/s", "n_gpus": comm.world, "steps": K,
+            "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: ONE un-preconditioned CG solve (N={N}, Ltau={Ltau}), tau-slabs "
+                                   f"over {comm.world} GPU(s), 1 r-halo exchange + 2 partial-sum all-gathers per iteration "
+                                   f"({'RCCL, device-resident' if s.dev is not None else 'host-staged'})",
+                       "parallelism": f"tau_slabs{comm.world}"},
+            "cg_iters_per_sec": K / elapsed}))
+    s.close()
     comm.close()
 
 

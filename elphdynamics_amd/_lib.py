@@ -43,6 +43,15 @@ SIGNATURES = {
     "elph_ldiv_batched": (c_int, [Handle, c_int, P_dbl, P_dbl, c_int, c_i64, P_i64, P_dbl, P_int]),
     "elph_ldiv_dev": (c_int, [Handle, C.c_void_p, C.c_void_p, c_int, c_i64, P_i64, P_dbl, P_int]),
     "elph_ldiv_batched_dev": (c_int, [Handle, c_int, C.c_void_p, C.c_void_p, c_int, c_i64, P_i64, P_dbl, P_int]),
+    "elph_cgstep_begin": (c_int, [Handle, P_dbl, c_dbl, c_i64, c_dbl]),
+    "elph_cgstep_state0": (c_int, [Handle]),
+    "elph_cgstep_ap": (c_int, [Handle]),
+    "elph_cgstep_xr": (c_int, [Handle]),
+    "elph_cgstep_status": (c_int, [Handle, P_i64, P_int, P_dbl]),
+    "elph_cgstep_result": (c_int, [Handle, P_dbl]),
+    "elph_dev_buffer": (c_int, [Handle, c_int, C.POINTER(C.c_void_p), P_i64]),
+    "elph_buffer_read": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
+    "elph_buffer_write": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
     "elph_fermion_force_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl,
                                             P_i64, P_int]),
     "elph_fermion_force_ssh": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),

@@ -696,6 +696,88 @@ extern "C" int elph_cg_solve(elph_handle h, double *x, const double *b, double t
 }
 
 // ------------------------------------------------------------------------------------------
+// step-wise CG for multi-GPU drivers (elphdynamics_amd/sharded.py): the same kernels as elph_cg_solve, one phase per
+// call, so the caller can exchange halo slices and combine partial sums across ranks between the phases
+// ------------------------------------------------------------------------------------------
+
+extern "C" int elph_cgstep_begin(elph_handle h, const double *b, double tol, int64_t maxiter, double kappa_max) {
+    CHECK_H(h);
+    RC(need_model(h));
+    if (!b || !(tol >= 0.0) || maxiter < 1) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    RC(ensure_capacity(h, 1));
+    CgParams P;
+    P.tol = tol; P.kmax = (kappa_max > 0.0) ? kappa_max : h->kmax; P.maxiter = maxiter; P.use_prec = 0; P.record_hist = 0; P.hist_stride = 0;
+    if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);
+    h->cur_params = P;
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, b, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 1));
+    HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_tmp, 0, bytes, h->stream));          // A x0 = 0
+    RC(elph_launch_cg_init_only(h, 1));                              // r0 = b, p0 = b, partial r.r and b.b
+    return ELPH_OK;
+}
+
+extern "C" int elph_cgstep_state0(elph_handle h) { CHECK_H(h); return elph_launch_cg_state0_only(h, 1); }
+extern "C" int elph_cgstep_ap(elph_handle h) { CHECK_H(h); return elph_launch_cg_kernel(h, 1, 0); }
+extern "C" int elph_cgstep_xr(elph_handle h) { CHECK_H(h); return elph_launch_cg_kernel(h, 1, 1); }
+
+extern "C" int elph_cgstep_status(elph_handle h, int64_t *iters, int *done, double *eps) {
+    CHECK_H(h);
+    HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const CgState &s = h->h_state[h->ap_count & 1];                  // the copy written by the latest k_cg_ap launch
+    if (iters) *iters = s.iters;
+    if (done) *done = s.done;
+    if (eps) *eps = s.eps;
+    return ELPH_OK;
+}
+
+extern "C" int elph_cgstep_result(elph_handle h, double *x) {
+    CHECK_H(h);
+    if (!x) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, 1));
+    HIPCHK(hipMemcpyAsync(x, h->d_stage_out, (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// device buffers of the step-wise solve (layout S: slice tau of a vector = N contiguous doubles at tau*N)
+extern "C" int elph_dev_buffer(elph_handle h, int which, void **ptr, int64_t *count) {
+    CHECK_H(h);
+    if (!ptr || !count) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ensure_capacity(h, 1));
+    const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
+    switch (which) {
+        case 0: *ptr = h->d_part; *count = h->L / elph_choose_T(h, 1); break;          // p.z partials of k_cg_ap
+        case 1: *ptr = h->d_part + P; *count = h->L; break;                            // r.r partials of k_cg_xr / init
+        case 2: *ptr = h->d_part + 3 * P; *count = h->L; break;                        // b.b partials of init
+        case 3: *ptr = h->d_r; *count = h->ndim; break;
+        case 4: *ptr = h->d_x; *count = h->ndim; break;
+        default: elph_set_error("unknown buffer %d", which); return ELPH_E_ARG;
+    }
+    return ELPH_OK;
+}
+
+extern "C" int elph_buffer_read(elph_handle h, int which, int64_t offset, int64_t count, double *host) {
+    void *p = nullptr; int64_t n = 0;
+    RC(elph_dev_buffer(h, which, &p, &n));
+    if (!host || offset < 0 || count < 0 || offset + count > n) { elph_set_error("bad range"); return ELPH_E_ARG; }
+    HIPCHK(hipMemcpyAsync(host, (double *)p + offset, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_buffer_write(elph_handle h, int which, int64_t offset, int64_t count, const double *host) {
+    void *p = nullptr; int64_t n = 0;
+    RC(elph_dev_buffer(h, which, &p, &n));
+    if (!host || offset < 0 || count < 0 || offset + count > n) { elph_set_error("bad range"); return ELPH_E_ARG; }
+    HIPCHK(hipMemcpyAsync((double *)p + offset, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // host buffer may be a temporary
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // fermion force: update_model! + calc_O⁻¹Λϕ! + calc_dSfdx! with x, phi± , X± resident
 // ------------------------------------------------------------------------------------------
 

@@ -1109,3 +1109,21 @@ int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS) {
     });
     return check_launch("k_force_ssh");
 }
+
+// pieces of elph_launch_cg_init for the step-wise API (A x0 expected in d_tmp)
+int elph_launch_cg_init_only(elph_handle_s *h, int nrhs) {
+    CgBufs B = make_bufs(h, nrhs);
+    h->ap_count = 0;
+    const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
+    double *bb = h->d_part + 3 * P;
+    hipLaunchKernelGGL(k_cg_init, dim3((unsigned)h->L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, B, h->d_b, h->d_tmp, bb,
+                       (int)h->N, (int)h->L);
+    return check_launch("k_cg_init");
+}
+
+int elph_launch_cg_state0_only(elph_handle_s *h, int nrhs) {
+    CgBufs B = make_bufs(h, nrhs);
+    const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
+    hipLaunchKernelGGL(k_cg_state0, dim3((unsigned)nrhs), dim3(WAVE), 0, h->stream, B, h->d_part + 3 * P, (int)h->L);
+    return check_launch("k_cg_state0");
+}

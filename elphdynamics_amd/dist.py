@@ -8,6 +8,8 @@ barrier around the timed region, the MAX-reduction of the elapsed time and the S
 """
 import os
 
+import numpy as np
+
 
 class Comm:
     """Thin wrapper so that world_size == 1 needs no torch at all."""
@@ -19,6 +21,7 @@ class Comm:
         self.torch = None
         self.dist = None
         self.device = None
+        self.backend = None
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -57,6 +60,39 @@ class Comm:
         t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    # ---- small numpy-level collectives (halo slices, partial sums): a few KB each, staged through torch tensors
+    def _to_tensor(self, a):
+        t = self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        return t.to(self.device) if self.backend == "nccl" else t
+
+    def allgather(self, vec):
+        """Concatenation over ranks of equally long float64 vectors (identical result on every rank)."""
+        import numpy as np
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        if self.dist is None:
+            return vec.copy()
+        t = self._to_tensor(vec)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return np.concatenate([o.cpu().numpy() for o in out])
+
+    def ring_exchange(self, send_to_prev, send_to_next):
+        """Periodic ring: returns (received from previous rank, received from next rank)."""
+        import numpy as np
+        if self.dist is None:
+            return np.array(send_to_next, copy=True), np.array(send_to_prev, copy=True)
+        prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        sp, sn = self._to_tensor(send_to_prev), self._to_tensor(send_to_next)
+        rp, rn = self.torch.empty_like(sn), self.torch.empty_like(sp)
+        ops = [self.dist.P2POp(self.dist.isend, sp, prev), self.dist.P2POp(self.dist.isend, sn, nxt),
+               self.dist.P2POp(self.dist.irecv, rp, prev), self.dist.P2POp(self.dist.irecv, rn, nxt)]
+        if self.world == 2:      # prev == next: order the two messages by tag-free pairing (send order = receive order)
+            ops = [self.dist.P2POp(self.dist.isend, sp, prev), self.dist.P2POp(self.dist.irecv, rn, nxt),
+                   self.dist.P2POp(self.dist.isend, sn, nxt), self.dist.P2POp(self.dist.irecv, rp, prev)]
+        for req in self.dist.batch_isend_irecv(ops):
+            req.wait()
+        return rp.cpu().numpy(), rn.cpu().numpy()
 
     def close(self):
         if self.dist is not None:

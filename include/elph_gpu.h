@@ -146,6 +146,29 @@ int elph_ldiv_batched_dev(elph_handle h, int nrhs, double *X_dev, const double *
                           int use_precond, int64_t maxiter, int64_t *iters,
                           double *residual_error, int *flag);
 
+/* ---------------------------------------------------------------- step-wise CG (multi-GPU drivers) */
+
+/* The kernels of elph_cg_solve (un-preconditioned, one right-hand side), one phase per call, for drivers that shard
+ * ONE solve over several GPUs (elphdynamics_amd/sharded.py): between the phases the caller exchanges
+ * halo slices of r and replaces the per-slice partial sums by cross-rank totals, through the device buffers below.
+ *   begin   : x0 = 0, r0 = p0 = b (host, reference layout), partial sums r.r and b.b   IterativeSolvers.jl:259-268
+ *   state0  : |b|, eps0, rho0 from the partial-sum buffers                                :262,271-274
+ *   ap      : stop test of the previous iteration, beta, p = r + beta p, z = MtM p, partial p.z   :277-279,286-310
+ *   xr      : alpha, x += alpha p, r -= alpha z, partial r.r                              :279-285
+ *   status  : (iterations completed, done flag 0/1/2/3, last eps)
+ * elph_dev_buffer: which = 0 p.z partials, 1 r.r partials, 2 b.b partials, 3 r, 4 x (vectors in the device layout:
+ * slice tau = nsites contiguous doubles at offset tau*nsites). */
+int elph_cgstep_begin(elph_handle h, const double *b, double tol, int64_t maxiter, double kappa_max);
+int elph_cgstep_state0(elph_handle h);
+int elph_cgstep_ap(elph_handle h);
+int elph_cgstep_xr(elph_handle h);
+int elph_cgstep_status(elph_handle h, int64_t *iters, int *done, double *eps);
+int elph_cgstep_result(elph_handle h, double *x);
+int elph_dev_buffer(elph_handle h, int which, void **ptr, int64_t *count);
+/* host <-> device copies of a range of one of those buffers (synchronous on the handle's stream) */
+int elph_buffer_read(elph_handle h, int which, int64_t offset, int64_t count, double *host);
+int elph_buffer_write(elph_handle h, int which, int64_t offset, int64_t count, const double *host);
+
 /* ---------------------------------------------------------------- fermion force */
 
 /* One fermion-force evaluation of the Holstein model with the phonon field, both pseudofermion fields and both

@@ -1,0 +1,134 @@
+"""Worker of the 2-rank sharded-CG tests (launched once per rank by tests/test_sharded_*.py).
+
+usage: sharded_worker.py {numpy|gpu} <out.npz>
+  numpy : local compute by a numpy/oracle stand-in backend (CPU, gloo) — TEST-ONLY code path
+  gpu   : local compute by libelphgpu (both ranks on device 0, collectives staged through gloo)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from elphdynamics_amd import dist, sharded, synth  # noqa: E402
+from elphdynamics_amd import lattice as lat  # noqa: E402
+
+
+class NumpyBackend:
+    """Stand-in for GpuBackend with the SAME phase semantics as k_cg_init / k_cg_state0 / k_cg_ap / k_cg_xr, local
+    operator applied by the CPU oracle.  Test infrastructure only."""
+
+    def __init__(self, N, L2, table, c, s):
+        from oracle.oracle import Oracle
+        self.orc = Oracle()
+        self.N, self.L, self.table, self.c, self.s = N, L2, table, c, s
+        self.buf = {k: np.zeros(L2) for k in (sharded.PAP, sharded.RR, sharded.BB)}
+
+    def set_expV(self, E_loc):
+        self.m = self.orc.make_model(0, self.N, self.L, self.table, self.c, self.s, np.ascontiguousarray(E_loc).reshape(-1))
+
+    def _slices(self, v):            # reference layout (N, L) -> per-slice view
+        return v.reshape(self.N, self.L)
+
+    def begin(self, b_loc, tol, maxiter, kmax):
+        self.tol, self.maxiter, self.kmax = tol, maxiter, kmax
+        self.b = np.ascontiguousarray(b_loc).reshape(-1).copy()
+        self.x = np.zeros_like(self.b)
+        self.r = self.b.copy()
+        self.p = self.b.copy()
+        self.buf[sharded.RR] = (self._slices(self.r) ** 2).sum(axis=0)
+        self.buf[sharded.BB] = (self._slices(self.b) ** 2).sum(axis=0)
+
+    def state0(self):
+        rr, bb = self.buf[sharded.RR].sum(), self.buf[sharded.BB].sum()
+        self.normb = np.sqrt(bb)
+        self.eps0 = self.eps = np.sqrt(rr) / self.normb
+        self.rho, self.kmin, self.seq, self.done = rr, 0.0, 0, 0
+
+    def ap(self):
+        if self.done:
+            return
+        if self.seq > 0:
+            rr = self.buf[sharded.RR].sum()
+            self.eps = np.sqrt(rr) / self.normb
+            q = 2.0 * self.seq / np.log(2.0 * self.eps0 / self.eps)
+            self.kmin = max(self.kmin, q * q)
+            if self.eps < self.tol:
+                self.done = 1
+            elif self.kmin > self.kmax:
+                self.done = 2
+            elif self.seq >= self.maxiter:
+                self.done = 3
+            if self.done:
+                return
+            beta = rr / self.rho
+            self.rho = rr
+            self.p = self.r + beta * self.p
+        self.z = self.orc.mulMTM(self.m, np.ascontiguousarray(self.p))
+        self.buf[sharded.PAP] = (self._slices(self.p) * self._slices(self.z)).sum(axis=0)
+        self.seq += 1
+
+    def xr(self):
+        if self.done:
+            return
+        alpha = self.rho / self.buf[sharded.PAP].sum()
+        self.x += alpha * self.p
+        self.r -= alpha * self.z
+        self.buf[sharded.RR] = (self._slices(self.r) ** 2).sum(axis=0)
+
+    def status(self):
+        return (self.seq if self.done else self.seq), self.done, float(self.eps)
+
+    def _vec(self, which):          # device layout (tau, site) flat view of r / x
+        return self.r if which == sharded.RVEC else self.x
+
+    def read(self, which, offset, count):
+        if which in self.buf:
+            return self.buf[which][offset:offset + count].copy()
+        S = self._slices(self._vec(which)).T.reshape(-1)            # (tau, site) order
+        return S[offset:offset + count].copy()
+
+    def write(self, which, offset, values):
+        values = np.asarray(values, dtype=np.float64)
+        if which in self.buf:
+            self.buf[which][offset:offset + values.size] = values
+            return
+        v = self._vec(which)
+        S = self._slices(v).T.copy().reshape(-1)
+        S[offset:offset + values.size] = values
+        v[:] = S.reshape(self.L, self.N).T.reshape(-1)
+
+    def close(self):
+        pass
+
+
+def main():
+    mode, out = sys.argv[1], sys.argv[2]
+    comm = dist.Comm(backend="gloo")
+    # Holstein square lattice, small enough for the CPU backend: L = 4, Ltau = 16
+    Ls, Ltau, dtau = 4, 16, 0.1
+    la = lat.Lattice(1, Ls, Ls, 1)
+    raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in lat.SQUARE_BONDS], axis=0)
+    cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), dtau)
+    N = la.nsites
+    x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
+    E = np.exp(-dtau * (1.0 * x - 0.0))
+    b = synth.randn(321, N * Ltau)
+    if mode == "numpy":
+        factory = lambda: NumpyBackend(N, Ltau // comm.world + 2, cb["table"], cb["cosht"], cb["sinht"])  # noqa: E731
+    else:
+        factory = None
+    solver = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"], backend_factory=factory, device=0)
+    solver.update_model(E)
+    xs, it, done = solver.solve(b, tol=1e-9, maxiter=2000, check_every=4)
+    np.savez(out + f".rank{comm.rank}", x=xs, it=it, done=done, E=E, b=b, table=cb["table"], c=cb["cosht"], s=cb["sinht"],
+             N=N, Ltau=Ltau)
+    solver.close()
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()
