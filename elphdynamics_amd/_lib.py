@@ -16,6 +16,7 @@ P_i64, P_dbl, P_int = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c
 Handle = C.c_void_p
 
 ELPH_OK = 0
+ELPH_E_ARG, ELPH_E_HIP, ELPH_E_STATE, ELPH_E_NOGPU, ELPH_E_UNSUPPORTED = -1, -2, -3, -4, -5
 ERRORS = {-1: "ELPH_E_ARG", -2: "ELPH_E_HIP", -3: "ELPH_E_STATE", -4: "ELPH_E_NOGPU", -5: "ELPH_E_UNSUPPORTED"}
 
 # every symbol include/elph_gpu.h declares: name -> (restype, argtypes)
@@ -55,6 +56,11 @@ SIGNATURES = {
     "elph_fermion_force_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl,
                                             P_i64, P_int]),
     "elph_fermion_force_ssh": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
+    "elph_hmc_create": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
+    "elph_hmc_set_state": (c_int, [Handle, P_dbl, P_dbl]),
+    "elph_hmc_get_state": (c_int, [Handle, P_dbl, P_dbl]),
+    "elph_hmc_update": (c_int, [Handle, c_dbl, c_i64, c_int, c_dbl, c_int, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_int, P_dbl, P_dbl,
+                                P_int]),
     "elph_kpm_create": (c_int, [Handle, c_int, c_dbl, c_dbl, c_dbl]),
     "elph_kpm_setup": (c_int, [Handle, P_dbl, P_dbl, c_dbl, c_dbl, P_int, P_dbl, P_dbl]),
     "elph_kpm_orders": (c_int, [Handle, P_i64, P_i64]),

@@ -336,6 +336,7 @@ extern "C" int elph_destroy(elph_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
+    elph_hmc_free(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
@@ -629,6 +630,12 @@ static int ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, 
     }
     return ELPH_OK;
 }
+
+int elph_i_ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag) {
+    return ldiv_core(h, nrhs, use_prec, maxiter, iters, resid, flag);
+}
+int elph_i_ensure_capacity(elph_handle_s *h, int nrhs) { return ensure_capacity(h, nrhs); }
+void elph_i_drop_graphs(elph_handle_s *h) { drop_graphs(h); }
 
 static int stage_in_dev(elph_handle_s *h, int nrhs, const double *X_dev, const double *B_dev) {
     RC(ensure_capacity(h, nrhs));

@@ -138,6 +138,7 @@ struct elph_handle_s {
     int sq_P = 0;
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
+    void *hmc = nullptr;                   // HmcState (hmc.hip), owned
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
     int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/8 force
 
@@ -197,6 +198,11 @@ struct elph_handle_s {
 ModelDev elph_model_dev(const elph_handle_s *h);
 KpmDev elph_kpm_dev(const elph_handle_s *h);
 
+// elph_api.hip internals used by hmc.hip
+int elph_i_ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag);
+int elph_i_ensure_capacity(elph_handle_s *h, int nrhs);
+void elph_i_drop_graphs(elph_handle_s *h);
+void elph_hmc_free(elph_handle_s *h);
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec);
 int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec);
 int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain = 0);

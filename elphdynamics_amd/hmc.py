@@ -6,6 +6,7 @@
     calc_OinvLambda_phi(model, phi_p, phi_m, ...)  HMC.jl:820-915   (the 2 CG solves of every force evaluation)
     GreensEstimator.update_(model, P, rng)         GreensFunctions.jl:201-234
     GreensEstimator.estimate(i, j, tau2, tau1)     GreensFunctions.jl:334-346
+    HybridMonteCarlo, update_(model, hmc, fa, P)   HMC.jl:20-337 (struct + update!): the whole trajectory on the device
 
 The two pseudofermion solves (and the n_v measurement solves) share one fermion matrix, so they go to
 the GPU as ONE batched ldiv!; each right-hand side still follows the single-RHS recurrences and stop rule,
@@ -151,3 +152,75 @@ def calc_dSfdx_(dSdx, model, phi_p, phi_m, P=None, power=1.0, return_solutions=F
     if return_solutions:
         return int(it.value), int(fl.value), Xp, Xm
     return int(it.value), int(fl.value)
+
+
+class HybridMonteCarlo:
+    """HybridMonteCarlo(model, Δt, tr, α, Nb) (HMC.jl:20-245), reduced to what the device-resident trajectory needs.
+    x, v, ϕ±, O⁻¹Λϕ± and dS/dx live on the GPU between updates; `model.x` / `hmc.v` on the host are refreshed by
+    `pull_()` (and pushed by `push_()` after the host changed them)."""
+
+    def __init__(self, model, fa, dt, tr, alpha=0.0, Nb=1):
+        assert 0.0 <= alpha < 1.0                                   # HMC.jl:182
+        if model.kind != models.HOLSTEIN:
+            raise NotImplementedError("device-resident HMC trajectory: Holstein models")
+        self.model, self.fa = model, fa
+        self.dt, self.tr, self.alpha, self.Nb = float(dt), float(tr), float(alpha), int(Nb)
+        self.Nt = int(round(tr / dt))                               # :206
+        self.dtp = self.dt / self.Nb                                # :209
+        self.Ndof, self.Ndim = model.Ndof, model.Ndim
+        self.v = np.zeros(model.Ndof)
+        self.updates, self.accepted, self.iters = 1, False, 0
+        self.H = self.S = self.K = 0.0
+        self.H0 = self.H1 = self.P_accept = 0.0
+        self.flag = 0
+        from ._lib import check, dptr
+        check(model._lib.elph_hmc_create(model._h, dptr(model.omega), dptr(model.omega4), dptr(model.lam), dptr(model.lam2),
+                                         dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.M))))
+        self.push_()
+
+    def push_(self):
+        from ._lib import check, dptr
+        check(self.model._lib.elph_hmc_set_state(self.model._h, dptr(np.ascontiguousarray(self.model.x)), dptr(self.v)))
+
+    def pull_(self):
+        from ._lib import check, dptr
+        check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self.model.x), dptr(self.v)))
+
+
+def draw_randoms(hmc, rng, with_kpm):
+    """The random numbers one update! consumes, in the order the reference draws them from model.rng
+    (refresh_v! :652, refresh_ϕ! :674-675, one pair of Arnoldi start vectors per setup!(P), rand :441)."""
+    m = hmc.model
+    R = rng.standard_normal(m.Ndof)
+    Rp = rng.standard_normal(m.Ndim)
+    Rm = rng.standard_normal(m.Ndim)
+    kpm = rng.standard_normal((hmc.Nt + 2, 2, m.Nsites)) if with_kpm else None
+    return dict(R=R, Rp=Rp, Rm=Rm, kpm_randn=kpm, u=float(rng.random()))
+
+
+def update_(model, hmc, fa=None, P=None, rng=None, randoms=None, pull=True):
+    """update!(model, hmc, fa, preconditioner) -> (accepted, iters)   (HMC.jl:313-337): one HMC update, the whole
+    trajectory (standard_update! for Nb == 1, multitimestep_update! otherwise) in ONE C-ABI call."""
+    import ctypes as C
+    from ._lib import check, dptr
+    if hmc.Ndof == 0:
+        return True, 0                                              # :333-335
+    if randoms is None:
+        randoms = draw_randoms(hmc, rng or np.random.default_rng(), P is not None)
+    model._push_solver()
+    acc, fl = C.c_int(), C.c_int()
+    its = C.c_double()
+    en = np.zeros(5)
+    kr = randoms.get("kpm_randn")
+    check(model._lib.elph_hmc_update(
+        model._h, hmc.dt, hmc.Nt, hmc.Nb, hmc.alpha, 0 if P is None else 1, dptr(np.ascontiguousarray(randoms["R"])),
+        dptr(np.ascontiguousarray(randoms["Rp"])), dptr(np.ascontiguousarray(randoms["Rm"])),
+        dptr(np.ascontiguousarray(kr)) if kr is not None else None, float(randoms["u"]), C.byref(acc), C.byref(its), dptr(en),
+        C.byref(fl)))
+    hmc.accepted, hmc.iters, hmc.flag = bool(acc.value), its.value, int(fl.value)
+    hmc.H0, hmc.H1, hmc.S, hmc.K, hmc.P_accept = (float(e) for e in en)
+    hmc.H = hmc.H1
+    hmc.updates += 1                                                # :329
+    if pull:
+        hmc.pull_()
+    return hmc.accepted, hmc.iters

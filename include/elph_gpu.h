@@ -196,6 +196,33 @@ int elph_fermion_force_holstein(elph_handle h, const double *x, const double *la
 int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
                            double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
 
+/* ---------------------------------------------------------------- HMC trajectory */
+
+/* One HMC update of the Holstein model, update!(model, hmc, fa, P) — HMC.jl:313-337 — i.e. standard_update!
+ * (:343-463, nb == 1) or multitimestep_update! (:469-638, nb > 1), with refresh_v!/refresh_ϕ! (:648-692), calc_H
+ * (:697-784), calc_Sb/calc_dSbdx! (PhononAction.jl:11-66,114-187), calc_O⁻¹Λϕ! and calc_dSfdx! inside.  The phonon
+ * field x, the velocity v, ϕ±, O⁻¹Λϕ± and dS/dx stay on the device for the whole trajectory and between updates.
+ *
+ * elph_hmc_create: per-site omega, omega4, lambda, lambda2, mu (double[nsites]), dtau, and FourierAccelerator.M
+ *   (fa_mass: double[nsites*ltau], frequency index fastest — FourierAcceleration.jl:222-240).  Dispersive phonon modes
+ *   are not supported (the reference's calc_Sb reads an undefined variable for them, PhononAction.jl:49).
+ * elph_hmc_set_state / get_state: model.x and hmc.v (double[nsites*ltau], tau fastest; NULL = leave / skip).
+ * elph_hmc_update: dt = hmc.Δt, nt = hmc.Nt, nb = hmc.Nb, alpha = partial momentum refresh.  The random numbers the
+ *   reference draws from model.rng are inputs: R[Ndof] (refresh_v!), Rp, Rm [Ndim] (refresh_ϕ!), kpm_randn[(nt+2)*2*nsites]
+ *   (the Arnoldi start vector pairs of the up to nt+2 setup!(P) calls, in call order; NULL without preconditioner) and
+ *   u_accept (the uniform of the Metropolis test, :441).  Solver settings are elph_solver_set's (tol^2 for the two
+ *   action evaluations, tol for the forces, :373,:398,:428).
+ *   Outputs: accepted (0/1); iters_per_solve = cld(iters, nt+2) as the reference returns; energies[5] = H0, H1,
+ *   S and K of the last calc_H, acceptance probability; flag = last linear-solve flag (> 0: trajectory killed, rejected).
+ *   On rejection x is restored, v = -v0 and exp(-dtau V) is rebuilt (:447-456). */
+int elph_hmc_create(elph_handle h, const double *omega, const double *omega4, const double *lambda, const double *lambda2,
+                    const double *mu, double dtau, const double *fa_mass);
+int elph_hmc_set_state(elph_handle h, const double *x, const double *v);
+int elph_hmc_get_state(elph_handle h, double *x, double *v);
+int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, double alpha, int use_precond, const double *R,
+                    const double *Rp, const double *Rm, const double *kpm_randn, double u_accept, int *accepted,
+                    double *iters_per_solve, double *energies, int *flag);
+
 /* ---------------------------------------------------------------- KPM preconditioner */
 
 /* SymmetricKPMPreconditioner(model, n, buf, c1, c2) — KPMPreconditioners.jl:219-235, ctor :101-146 */

@@ -1254,6 +1254,204 @@ void elpho_calc_dSfdx_holstein(double *dSfdx, const elpho_model *m, const double
         elpho_muldLambdadx_holstein(dSfdx, phi[k], X[k], Lam, m->N, m->L, dtau, lambda, lambda2, x);
 }
 
+/* ====================================================================== */
+/* HMC trajectory                                           */
+/* ====================================================================== */
+
+/* PhononAction.jl:11-66 (Holstein, shifted = false, no dispersive modes: the reference's loop over them reads an
+ * undefined variable `L`, :49, so a deck with dispersion cannot run through calc_Sb there) */
+double elpho_calc_Sb_holstein(int64_t N, int64_t L, double dtau, const double *x, const double *omega,
+                              const double *omega4) {
+    double Sb = 0.0;
+    for (int64_t i = 0; i < N; i++)
+        for (int64_t tau = 0; tau < L; tau++) {
+            int64_t tm1 = (tau + L - 1) % L;
+            double xt = x[i * L + tau], xm = x[i * L + tm1];
+            Sb += omega[i] * omega[i] * (xt * xt) / 2 + omega4[i] * (xt * xt * xt * xt);
+            Sb += (xt - xm) * (xt - xm) / (dtau * dtau) / 2;
+        }
+    return dtau * Sb;
+}
+
+/* PhononAction.jl:114-187 (accumulates) */
+void elpho_calc_dSbdx_holstein(double *dSbdx, int64_t N, int64_t L, double dtau, const double *x, const double *omega,
+                               const double *omega4) {
+    for (int64_t i = 0; i < N; i++) {
+        double a = dtau * omega[i] * omega[i], b = dtau * 4 * omega4[i];
+        for (int64_t tau = 0; tau < L; tau++) {
+            int64_t tp1 = (tau + 1) % L, tm1 = (tau + L - 1) % L, n = i * L + tau;
+            double xt = x[n];
+            dSbdx[n] += a * xt;
+            dSbdx[n] += b * xt * xt * xt;
+            dSbdx[n] -= (x[i * L + tp1] + x[i * L + tm1] - 2.0 * xt) / dtau;
+        }
+    }
+}
+
+typedef struct {
+    const elpho_hmc_params *hp;
+    elpho_model *m;
+    elpho_kpm *P;
+    double *x, *v;
+    double *phi[2], *Lphi[2], *X[2], *Lam, *u, *y, *dSdx, *r, *p, *z;
+    const double *kpm_randn;
+    int64_t kpm_calls;
+    double solver_iters;
+} hmc_ws;
+
+static void hmc_update_model(hmc_ws *w) {
+    const elpho_hmc_params *hp = w->hp;
+    elpho_update_model_holstein(hp->N, hp->L, hp->dtau, w->x, hp->lambda, hp->lambda2, hp->mu, (double *)w->m->E);
+}
+
+/* HMC.jl:820-915 (CG branch): returns iters, sets *flag */
+static int64_t hmc_calc_OinvLphi(hmc_ws *w, double power, int64_t *flag) {
+    const elpho_hmc_params *hp = w->hp;
+    const int64_t n = hp->N * hp->L;
+    const double tol = pow(hp->solver_tol, power);
+    if (w->P) {                                                   /* setup!(P), KPMPreconditioners.jl:259-321 */
+        const double *bmax = w->kpm_randn + (2 * w->kpm_calls) * hp->N, *bmin = bmax + hp->N;
+        double emin, emax;
+        w->kpm_calls++;
+        elpho_kpm_update_A(w->P, w->m);
+        elpho_kpm_arnoldi_bounds(w->P, hp->kpm_n, bmax, bmin, &emin, &emax);
+        elpho_kpm_setup_from_bounds(w->P, emin, emax);
+    }
+    elpho_update_Lambda(w->Lam, hp->N, hp->L, hp->dtau, w->x, hp->lambda, hp->lambda2);
+    elpho_mulLambda(w->Lphi[0], w->phi[0], w->Lam, hp->N, hp->L);
+    elpho_mulLambda(w->Lphi[1], w->phi[1], w->Lam, hp->N, hp->L);
+    int64_t iters = 0, it, fl = 0;
+    double res;
+    for (int k = 0; k < 2 && fl == 0; k++) {
+        memset(w->X[k], 0, sizeof(double) * (size_t)n);
+        elpho_ldiv(w->m, w->X[k], w->Lphi[k], w->P, 0, tol, hp->solver_maxiter, hp->kmax,
+                   w->r, w->p, w->z, &it, &res, &fl);
+        iters += it;
+    }
+    if (fl == 0) iters = (iters + 1) / 2;                          /* cld(iters, 2) */
+    *flag = fl;
+    return iters;
+}
+
+static double hmc_calc_Sf(hmc_ws *w) {                             /* HMC.jl:768-784 */
+    const int64_t n = w->hp->N * w->hp->L;
+    double Sf = dotp(w->Lphi[0], w->X[0], n) / 2;
+    Sf += dotp(w->Lphi[1], w->X[1], n) / 2;
+    return Sf;
+}
+
+static void hmc_calc_H(hmc_ws *w, double *H, double *S, double *K) {   /* HMC.jl:697-721,745-756 */
+    const elpho_hmc_params *hp = w->hp;
+    const int64_t n = hp->N * hp->L;
+    *S = hmc_calc_Sf(w);
+    *S += elpho_calc_Sb_holstein(hp->N, hp->L, hp->dtau, w->x, hp->omega, hp->omega4);
+    elpho_fourier_accelerate(w->y, w->v, hp->fa_M, 1.0, hp->N, hp->L);
+    *K = dotp(w->v, w->y, n) / 2;
+    *H = *S + *K;
+}
+
+static void hmc_calc_dSfdx(hmc_ws *w) {                            /* HMC.jl:790-814 */
+    const elpho_hmc_params *hp = w->hp;
+    elpho_calc_dSfdx_holstein(w->dSdx, w->m, w->X[0], w->X[1], w->phi[0], w->phi[1], w->Lam, hp->dtau, hp->lambda,
+                              hp->lambda2, w->x, w->u, w->y);
+}
+
+/* HMC.jl:343-463 (standard_update!, nb == 1) and :469-638 (multitimestep_update!, nb > 1); update! :313-337.
+ * The random numbers the reference draws from model.rng are inputs: R[Ndof] (refresh_v!, :648-659),
+ * Rp, Rm [Ndim] (refresh_ϕ!, :665-692), kpm_randn[(nt+2)*2*N] (one pair of Arnoldi start vectors per setup!,
+ * consumed in call order; may be NULL when P is NULL) and the uniform u of the accept/reject step (:441,:617).
+ * out[0..7] = H0, H1, S (last calc_H), K (last calc_H), returned iters = cld(iters, nt+2), flag, P_accept, solver calls. */
+int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, double *x, double *v,
+                                  const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
+                                  double *out) {
+    const int64_t N = hp->N, L = hp->L, n = N * L, nt = hp->nt, nb = hp->nb;
+    const double dt = hp->dt, dtp = hp->dt / (double)hp->nb;
+    double *buf = (double *)calloc((size_t)(16 * n), sizeof(double));
+    hmc_ws w;
+    memset(&w, 0, sizeof w);
+    w.hp = hp; w.m = m; w.P = P; w.x = x; w.v = v; w.kpm_randn = kpm_randn;
+    double *q = buf;
+    w.phi[0] = q; q += n; w.phi[1] = q; q += n; w.Lphi[0] = q; q += n; w.Lphi[1] = q; q += n;
+    w.X[0] = q; q += n; w.X[1] = q; q += n; w.Lam = q; q += n; w.u = q; q += n; w.y = q; q += n;
+    w.dSdx = q; q += n; w.r = q; q += n; w.p = q; q += n; w.z = q; q += n;
+    double *x0 = q; q += n;
+    double *v0 = q; q += n;
+    double *Q = w.dSdx;                                            /* QdSdx aliases dSdx (:349) */
+    int64_t flag = 0, iters = 0, itrs;
+    double H0 = 0, H1 = 0, S = 0, K = 0;
+
+    hmc_update_model(&w);
+    /* refresh_v! (:648-659) */
+    elpho_fourier_accelerate(w.y, R, hp->fa_M, -0.5, N, L);
+    for (int64_t i = 0; i < n; i++) v[i] = hp->alpha * v[i] + sqrt(1.0 - hp->alpha * hp->alpha) * w.y[i];
+    memcpy(x0, x, sizeof(double) * (size_t)n);
+    memcpy(v0, v, sizeof(double) * (size_t)n);
+    /* refresh_ϕ! (:665-692) */
+    elpho_update_Lambda(w.Lam, N, L, hp->dtau, x, hp->lambda, hp->lambda2);
+    elpho_mulMT(w.Lphi[0], m, Rp);
+    elpho_mulLambdaInv(w.phi[0], w.Lphi[0], w.Lam, N, L);
+    elpho_mulMT(w.Lphi[1], m, Rm);
+    elpho_mulLambdaInv(w.phi[1], w.Lphi[1], w.Lam, N, L);
+
+    itrs = hmc_calc_OinvLphi(&w, 2.0, &flag);
+    if (nb == 1) iters = itrs;                                     /* :373;  the multi-timestep variant has "iters += iters" (:507) */
+    if (flag == 0) {
+        hmc_calc_H(&w, &H0, &S, &K);
+        memset(w.dSdx, 0, sizeof(double) * (size_t)n);
+        hmc_calc_dSfdx(&w);
+        if (nb == 1) elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
+        elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
+        for (int64_t t = 1; t <= nt; t++) {
+            for (int64_t i = 0; i < n; i++) v[i] = v[i] - dt / 2 * Q[i];
+            if (nb == 1) {
+                for (int64_t i = 0; i < n; i++) x[i] = x[i] + dt * v[i];
+            } else {
+                memset(w.dSdx, 0, sizeof(double) * (size_t)n);
+                elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
+                elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
+                for (int64_t tp = 1; tp <= nb; tp++) {
+                    for (int64_t i = 0; i < n; i++) v[i] = v[i] - dtp / 2 * Q[i];
+                    for (int64_t i = 0; i < n; i++) x[i] = x[i] + dtp * v[i];
+                    memset(w.dSdx, 0, sizeof(double) * (size_t)n);
+                    elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
+                    elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
+                    for (int64_t i = 0; i < n; i++) v[i] = v[i] - dtp / 2 * Q[i];
+                }
+            }
+            hmc_update_model(&w);
+            itrs = hmc_calc_OinvLphi(&w, 1.0, &flag);
+            iters += itrs;
+            if (flag > 0) break;
+            memset(w.dSdx, 0, sizeof(double) * (size_t)n);
+            hmc_calc_dSfdx(&w);
+            if (nb == 1) elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
+            elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
+            for (int64_t i = 0; i < n; i++) v[i] = v[i] - dt / 2 * Q[i];
+        }
+    }
+    double Pacc = 0.0;
+    if (flag == 0) {
+        itrs = hmc_calc_OinvLphi(&w, 2.0, &flag);
+        iters += itrs;
+        if (flag == 0) {
+            hmc_calc_H(&w, &H1, &S, &K);
+            double dH = H1 - H0, e = exp(-dH);
+            Pacc = (1.0 < e) ? 1.0 : e;                            /* min(1, exp(-ΔH)) */
+        }
+    }
+    int64_t accepted = (u < Pacc && flag == 0) ? 1 : 0;
+    if (!accepted) {
+        memcpy(x, x0, sizeof(double) * (size_t)n);
+        for (int64_t i = 0; i < n; i++) v[i] = -v0[i];
+        hmc_update_model(&w);
+    }
+    out[0] = H0; out[1] = H1; out[2] = S; out[3] = K;
+    out[4] = (double)((iters + (nt + 2) - 1) / (nt + 2));          /* cld(iters, Nt+2) */
+    out[5] = (double)flag; out[6] = Pacc; out[7] = (double)w.kpm_calls;
+    free(buf);
+    return accepted;
+}
+
 /* SSHModels.jl:707-829 without the equivalent-field bookkeeping (primary_field == identity):
  * dMdx[field(phonon,tau)] = sg(tau) * <c_n(tau)| dtau dK_n/dx |b_n(tau)>, accumulated bond by bond in checkerboard order.
  * bond_to_phonon_cb[n]: 1-based phonon living on checkerboard bond n (0 = none); x, alpha, alpha2 per phonon.

@@ -223,6 +223,34 @@ void elpho_calc_dSfdx_holstein(double *dSfdx, const elpho_model *m, const double
                                const double *phip, const double *phim, const double *Lam, double dtau,
                                const double *lambda, const double *lambda2, const double *x, double *u, double *d);
 
+/* ------------------------------------------------ HMC trajectory */
+
+/* PhononAction.jl:11-66 / 114-187 (Holstein; shifted = false; no dispersive modes) */
+double elpho_calc_Sb_holstein(int64_t N, int64_t L, double dtau, const double *x, const double *omega,
+                              const double *omega4);
+void elpho_calc_dSbdx_holstein(double *dSbdx, int64_t N, int64_t L, double dtau, const double *x, const double *omega,
+                               const double *omega4);
+
+typedef struct {
+    int64_t N, L;
+    double dtau;
+    const double *omega, *omega4, *lambda, *lambda2, *mu;   /* per site */
+    const double *fa_M;                                     /* FourierAccelerator.M, [N*L] (omega fastest) */
+    double dt;                                              /* hmc.Δt */
+    int64_t nt, nb;                                         /* hmc.Nt, hmc.Nb */
+    double alpha;                                           /* partial momentum refresh */
+    double solver_tol;
+    int64_t solver_maxiter;
+    double kmax;
+    int64_t kpm_n;                                          /* Arnoldi dimension of setup!(P) */
+} elpho_hmc_params;
+
+/* HMC.jl:313-638 (update! -> standard_update! / multitimestep_update!) with the random numbers as inputs; see the
+ * definition for out[8].  m->E must be writable (update_model! writes it).  Returns accepted (0/1). */
+int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, double *x, double *v,
+                                  const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
+                                  double *out);
+
 /* SSHModels.jl:707-829 (no equivalent fields); dMdx[Nph*L] is overwritten */
 void elpho_muldMdx_ssh(double *dMdx, const double *u, const elpho_model *m, const double *v, double dtau,
                        const int64_t *bond_to_phonon_cb, const double *alpha, const double *alpha2, const double *x,

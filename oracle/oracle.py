@@ -71,6 +71,12 @@ class KPM(C.Structure):
                 ("v3", P_dbl), ("v4", P_dbl), ("v5", P_dbl), ("checkerboard_count", c_i64)]
 
 
+class HmcParams(C.Structure):
+    _fields_ = [("N", c_i64), ("L", c_i64), ("dtau", c_dbl), ("omega", P_dbl), ("omega4", P_dbl), ("lam", P_dbl),
+                ("lam2", P_dbl), ("mu", P_dbl), ("fa_M", P_dbl), ("dt", c_dbl), ("nt", c_i64), ("nb", c_i64),
+                ("alpha", c_dbl), ("solver_tol", c_dbl), ("solver_maxiter", c_i64), ("kmax", c_dbl), ("kpm_n", c_i64)]
+
+
 class Oracle:
     """Loaded oracle library + thin numpy-level helpers."""
 
@@ -135,6 +141,46 @@ class Oracle:
         L.elpho_muldMdx_ssh.argtypes = [P_dbl, P_dbl, C.POINTER(Model), P_dbl, c_dbl, P_i64, P_dbl, P_dbl, P_dbl, c_i64]
         L.elpho_muldLambdadx_holstein.argtypes = [P_dbl, P_dbl, P_dbl, P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_calc_dSfdx_holstein.argtypes = [P_dbl, C.POINTER(Model), P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl]
+
+        L.elpho_calc_Sb_holstein.restype = c_dbl
+        L.elpho_calc_Sb_holstein.argtypes = [c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_calc_dSbdx_holstein.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_hmc_update_holstein.restype = c_i64
+        L.elpho_hmc_update_holstein.argtypes = [C.POINTER(HmcParams), C.POINTER(Model), C.POINTER(KPM), P_dbl, P_dbl, P_dbl,
+                                                P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]
+
+    # ----------------------------------------------------------------- HMC
+    def calc_Sb_holstein(self, N, L, dtau, x, omega, omega4):
+        return float(self.lib.elpho_calc_Sb_holstein(N, L, dtau, dp(x), dp(omega), dp(omega4)))
+
+    def calc_dSbdx_holstein(self, N, L, dtau, x, omega, omega4):
+        d = np.zeros(N * L)
+        self.lib.elpho_calc_dSbdx_holstein(dp(d), N, L, dtau, dp(x), dp(omega), dp(omega4))
+        return d
+
+    def hmc_update_holstein(self, m, x, v, omega, omega4, lam, lam2, mu, dtau, fa_M, dt, nt, nb, alpha, randoms, P=None,
+                            tol=1e-5, maxiter=10000, kmax=1e12):
+        """update!(model, hmc, fa, P): returns (accepted, x', v', dict(H0, H1, S, K, iters, flag, P_accept, kpm_calls)).
+        m.E is overwritten (update_model!)."""
+        hp = HmcParams()
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (omega, omega4, lam, lam2, mu, fa_M)]
+        hp.N, hp.L, hp.dtau = m.N, m.L, dtau
+        hp.omega, hp.omega4, hp.lam, hp.lam2, hp.mu, hp.fa_M = (dp(a) for a in arrs)
+        hp.dt, hp.nt, hp.nb, hp.alpha = dt, nt, nb, alpha
+        hp.solver_tol, hp.solver_maxiter, hp.kmax = tol, maxiter, kmax
+        hp.kpm_n = P._n if P is not None else 0
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        v = np.ascontiguousarray(v, dtype=np.float64).copy()
+        out = np.zeros(8)
+        kr = randoms.get("kpm_randn")
+        kr = np.ascontiguousarray(kr, dtype=np.float64) if kr is not None else None
+        R, Rp, Rm = (np.ascontiguousarray(randoms[k], dtype=np.float64) for k in ("R", "Rp", "Rm"))
+        acc = self.lib.elpho_hmc_update_holstein(C.byref(hp), C.byref(m), C.byref(P) if P is not None else None, dp(x), dp(v),
+                                                 dp(R), dp(Rp), dp(Rm), dp(kr) if kr is not None else None, float(randoms["u"]),
+                                                 dp(out))
+        info = dict(H0=out[0], H1=out[1], S=out[2], K=out[3], iters=out[4], flag=int(out[5]), P_accept=out[6],
+                    kpm_calls=int(out[7]))
+        return bool(acc), x, v, info
 
     # ------------------------------------------------------------ geometry
     def neighbor_table(self, norbits, L1, L2, L3, bonds):

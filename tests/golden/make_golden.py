@@ -310,6 +310,118 @@ def gen_kpm(h, tag, buf=0.05, c1=1.0, c2=1.0):
          A=A)
 
 
+# ----------------------------------------------------------------------------- HMC trajectory (dense, exact solves)
+def gen_hmc(h, tag, seed, dt=0.05, nt=6, nb=1):
+    """One HMC trajectory from the DEFINITIONS (HMC.jl:343-463 / 469-638 for the order of the steps only):
+    action S(x) = Sb(x) + 1/2 sum_± (Λ(x)ϕ±)ᵀ (MᵀM)⁻¹ (Λ(x)ϕ±) with dense M and numpy.linalg.solve; the force is the
+    COMPLEX-STEP derivative of that dense action (no analytic force formula enters); Fourier acceleration with
+    scipy.fft.  Exact solves, so an iterative implementation agrees to its solver tolerance."""
+    N, L, dtau, CB = h["N"], h["Ltau"], h["dtau"], h["CB"]
+    n = N * L
+    g = np.load(os.path.join(HERE, f"holstein_{tag}.npz"))
+    lam, lam2, mu, x0 = g["lam"], g["lam2"], g["mu"], g["x"].copy()
+    omega = 1.0 + 0.1 * synth.randn(seed + 1, N)
+    omega4 = 0.05 * np.abs(synth.randn(seed + 2, N))
+    m0, cc = 1.0, 0.3
+    k = np.arange(L)
+    kp = np.minimum(k, L - k)
+    mreg = m0 * np.exp(-(cc * kp / L) ** 2)
+    faM = dtau * (mreg[None, :] ** 2 + omega[:, None] ** 2 + (2 - 2 * np.cos(2 * np.pi * kp / L))[None, :] / dtau ** 2) \
+        / (mreg[None, :] ** 2 + omega[:, None] ** 2)                            # [N, L]
+    R, Rp, Rm = synth.randn(seed + 3, n), synth.randn(seed + 4, n), synth.randn(seed + 5, n)
+
+    def accel(vec, power):
+        return np.real(scipy.fft.ifft(faM ** power * scipy.fft.fft(vec.reshape(N, L), axis=1), axis=1)).reshape(-1)
+
+    def lam_diag(x):
+        X = x.reshape(N, L)
+        return np.exp(-dtau * (lam[:, None] * X + lam2[:, None] * X ** 2) / 2)   # [N, L], complex-safe
+
+    def lam_mul(x, phi):
+        La, P = lam_diag(x), phi.reshape(N, L)
+        out = np.empty((N, L), dtype=np.result_type(La, P))
+        out[:, :L - 1] = -La[:, 1:] * P[:, 1:]
+        out[:, L - 1] = La[:, 0] * P[:, 0]
+        return out.reshape(-1)
+
+    def dense_M_of(x):
+        X = x.reshape(N, L)
+        E = np.exp(-dtau * (lam[:, None] * X + lam2[:, None] * X ** 2 - mu[:, None]))
+        M = np.eye(n, dtype=E.dtype)
+        for t in range(L):
+            B = CB @ np.diag(E[:, t])
+            tm1 = (t - 1) % L
+            sign = 1.0 if t == 0 else -1.0
+            M[np.ix_(np.arange(N) * L + t, np.arange(N) * L + tm1)] += sign * B
+        return M
+
+    def Sb(x):
+        X = x.reshape(N, L)
+        return dtau * np.sum(omega[:, None] ** 2 * X ** 2 / 2 + omega4[:, None] * X ** 4
+                             + (X - np.roll(X, 1, axis=1)) ** 2 / dtau ** 2 / 2)
+
+    def Sf(x, phis):
+        M = dense_M_of(x)
+        A = M.T @ M
+        tot = 0.0
+        for phi in phis:
+            b = lam_mul(x, phi)
+            tot = tot + 0.5 * (b @ np.linalg.solve(A, b))
+        return tot
+
+    def grad(fun, x):
+        hstep, out = 1e-30, np.empty(n)
+        for kk in range(n):
+            xc = x.astype(complex)
+            xc[kk] += 1j * hstep
+            out[kk] = np.imag(fun(xc)) / hstep
+        return out
+
+    x = x0.copy()
+    v = accel(R, -0.5)                                                     # alpha = 0: full refresh
+    v_init = v.copy()
+    M0 = dense_M_of(x)
+    La0 = lam_diag(x)
+
+    def lam_inv_mul(u):
+        U = u.reshape(N, L)
+        out = np.empty((N, L))
+        out[:, 1:] = -(1.0 / La0[:, 1:]) * U[:, :L - 1]
+        out[:, 0] = (1.0 / La0[:, 0]) * U[:, L - 1]
+        return out.reshape(-1)
+
+    phis = [lam_inv_mul(M0.T @ Rp), lam_inv_mul(M0.T @ Rm)]
+    H = lambda x, v: Sb(x) + Sf(x, phis) + 0.5 * (v @ accel(v, 1.0))
+    H0 = H(x, v)
+    dSf0 = grad(lambda z: Sf(z, phis), x)
+    dSb0 = grad(Sb, x)
+    if nb == 1:
+        Q = accel(dSf0 + dSb0, -1.0)
+        for _ in range(nt):
+            v = v - dt / 2 * Q
+            x = x + dt * v
+            Q = accel(grad(lambda z: Sf(z, phis) + Sb(z), x), -1.0)
+            v = v - dt / 2 * Q
+    else:
+        dtp = dt / nb
+        Qf = accel(dSf0, -1.0)
+        for _ in range(nt):
+            v = v - dt / 2 * Qf
+            Qb = accel(grad(Sb, x), -1.0)
+            for _ in range(nb):
+                v = v - dtp / 2 * Qb
+                x = x + dtp * v
+                Qb = accel(grad(Sb, x), -1.0)
+                v = v - dtp / 2 * Qb
+            Qf = accel(grad(lambda z: Sf(z, phis), x), -1.0)
+            v = v - dt / 2 * Qf
+    H1 = H(x, v)
+    save(f"hmc_{tag}_nb{nb}.npz", N=N, Ltau=L, dtau=dtau, omega=omega, omega4=omega4, lam=lam, lam2=lam2, mu=mu, x0=x0,
+         faM=faM.reshape(-1), R=R, Rp=Rp, Rm=Rm, dt=dt, nt=nt, nb=nb, v_init=v_init, phi_p=phis[0], phi_m=phis[1],
+         H0=H0, H1=H1, Sb0=Sb(x0), dSb0=dSb0, dSf0=dSf0, x1=x, v1=v,
+         H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0) + 0.5 * (v_init @ accel(v_init, 1.0)))
+
+
 if __name__ == "__main__":
     gen_tables()
     h1 = gen_holstein("sq4_L8", 1, 4, SQUARE, 8, 0.1, seed=11)
@@ -319,5 +431,7 @@ if __name__ == "__main__":
     gen_ssh("sq4_L8", 4, 8, 0.05, seed=44)
     gen_fft()
     gen_kpm(h1, "sq4_L8")
+    gen_hmc(h1, "sq4_L8", seed=66, nb=1)
+    gen_hmc(h1, "sq4_L8", seed=66, nb=3)
     h2 = gen_holstein("sq4_L40", 1, 4, SQUARE, 40, 0.1, seed=55)
     gen_kpm(h2, "sq4_L40")

@@ -1,0 +1,215 @@
+"""GPU (-m gpu): the device-resident HMC update (include/elph_gpu.h: elph_hmc_*) against the dense golden
+trajectory and against the CPU oracle on the same inputs (same random numbers handed to both).
+
+Tolerances: the force solves stop at the solver tolerance (1e-6 here; the two action evaluations at tol^2 = 1e-12).
+Two correct implementations whose stop test trips one iteration apart in one of the 2(nt+2) solves differ by that
+tolerance in the force, so end points agree to a few 1e-7 relative at worst (observed 2e-9 .. 2e-8; bound written
+below: 3e-7), H0 (tol^2 solves) to 1e-9, ΔH to 1e-7.  Against the exact-solve golden the bound is 1e-6 at tol 1e-7."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def _raw_update(lib, h, dt, nt, nb, alpha, use_prec, R, Rp, Rm, kpm, u):
+    from elphdynamics_amd._lib import check, dptr
+    acc, fl, its, en = C.c_int(), C.c_int(), C.c_double(), np.zeros(5)
+    check(lib.elph_hmc_update(h, dt, nt, nb, alpha, use_prec, dptr(np.ascontiguousarray(R)), dptr(np.ascontiguousarray(Rp)),
+                              dptr(np.ascontiguousarray(Rm)), dptr(np.ascontiguousarray(kpm)) if kpm is not None else None,
+                              u, C.byref(acc), C.byref(its), dptr(en), C.byref(fl)))
+    return bool(acc.value), its.value, en, fl.value
+
+
+@pytest.mark.parametrize("nb", [1, 3])
+def test_hmc_golden_through_the_raw_abi(nb):
+    """What a Julia ccall wrapper would do: elph_create from the reference-layout tables, elph_hmc_create,
+    elph_hmc_set_state, elph_hmc_update, elph_hmc_get_state — against the dense numpy trajectory."""
+    from elphdynamics_amd import _lib
+    from elphdynamics_amd._lib import check, dptr, iptr
+    lib = _lib.load()
+    g, hgold = golden(f"hmc_sq4_L8_nb{nb}.npz"), golden("holstein_sq4_L8.npz")
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    h = _lib.Handle()
+    tab = np.ascontiguousarray(hgold["table"], dtype=np.int64)
+    check(lib.elph_create(C.byref(h), 0, N, L, tab.shape[0], iptr(tab), dptr(np.ascontiguousarray(hgold["cosht"])),
+                          dptr(np.ascontiguousarray(hgold["sinht"])), 0))
+    try:
+        check(lib.elph_solver_set(h, 1e-7, 20000, 1e12))
+        arrs = [np.ascontiguousarray(g[k]) for k in ("omega", "omega4", "lam", "lam2", "mu")]
+        check(lib.elph_hmc_create(h, *(dptr(a) for a in arrs), dtau, dptr(np.ascontiguousarray(g["faM"]))))
+        x, v = g["x0"].copy(), np.zeros(N * L)
+        check(lib.elph_hmc_set_state(h, dptr(x), dptr(v)))
+        acc, its, en, fl = _raw_update(lib, h, float(g["dt"]), int(g["nt"]), nb, 0.0, 0, g["R"], g["Rp"], g["Rm"], None, 0.0)
+        check(lib.elph_hmc_get_state(h, dptr(x), dptr(v)))
+        assert acc and fl == 0 and its > 0
+        assert abs(en[0] - float(g["H0"])) < 1e-9 * abs(float(g["H0"]))
+        assert abs(en[0] - float(g["H0_closed"])) < 1e-9 * abs(float(g["H0"]))
+        assert abs(en[1] - float(g["H1"])) < 1e-6
+        assert rel(x, g["x1"]) < 1e-6 and rel(v, g["v1"]) < 1e-6
+    finally:
+        lib.elph_destroy(h)
+
+
+def _pair(oracle, tag, tol, lam2=0.0, seed=0):
+    from elphdynamics_amd import configs, preconditioners as pc, synth
+    m = configs.make_model(tag, tol=tol, maxiter=20000)
+    m.omega4[:] = 0.02
+    if lam2:
+        m.lam2[:] = lam2
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+    E = oracle.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+    om = oracle.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+    return m, fa, om
+
+
+def _randoms(m, nt, seed, with_kpm, u):
+    from elphdynamics_amd import synth
+    return dict(R=synth.randn(seed, m.Ndof), Rp=synth.randn(seed + 1, m.Ndim), Rm=synth.randn(seed + 2, m.Ndim),
+                kpm_randn=synth.randn(seed + 3, (nt + 2) * 2 * m.Nsites) if with_kpm else None, u=u)
+
+
+def _oracle_update(oracle, om, m, fa, x, v, dt, nt, nb, alpha, rnd, P=None):
+    return oracle.hmc_update_holstein(om, x, v, m.omega, m.omega4, m.lam, m.lam2, m.mu, m.dtau, fa.M, dt, nt, nb, alpha, rnd,
+                                      P=P, tol=m.solver.tol, maxiter=m.solver.maxiter)
+
+
+@pytest.mark.parametrize("tag,nb,nt", [("b", 1, 5), ("b", 3, 4), ("d", 1, 4), ("t", 1, 3), ("B", 1, 3), ("C", 1, 2), ("g", 1, 2)])
+def test_hmc_update_vs_oracle(oracle, tag, nb, nt):
+    from elphdynamics_amd import hmc
+    m, fa, om = _pair(oracle, tag, tol=1e-6, lam2=0.02)
+    dt = 0.05
+    H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt, alpha=0.0, Nb=nb)
+    assert H.Nt == nt
+    rnd = _randoms(m, nt, 500, False, 0.0)
+    x0 = m.x.copy()
+    acc_o, x_o, v_o, info = _oracle_update(oracle, om, m, fa, x0, np.zeros(m.Ndof), dt, nt, nb, 0.0, rnd)
+    acc, its = hmc.update_(m, H, fa, None, randoms=rnd)
+    assert acc == acc_o and H.flag == info["flag"] == 0
+    assert abs(H.H0 - info["H0"]) < 1e-9 * abs(info["H0"]) and abs(H.H1 - info["H1"]) < 1e-8 * abs(info["H1"])
+    # ΔH inherits the force-solve tolerance through the end point: absolute, grows with the system size
+    assert abs((H.H1 - H.H0) - (info["H1"] - info["H0"])) < max(5e-7, 1e-10 * abs(info["H0"]))
+    assert rel(m.x, x_o) < 3e-7 and rel(H.v, v_o) < 3e-7
+    assert abs(its - info["iters"]) <= 1                          # cld(iters, Nt+2): knife-edge stops can move it by one
+    assert abs(H.K - info["K"]) < 1e-8 * abs(info["K"]) and abs(H.S - info["S"]) < 1e-8 * abs(info["S"])
+    m.close()
+
+
+def test_hmc_two_updates_stay_on_the_device(oracle):
+    """State is resident between updates (no pull/push in between), partial momentum refresh uses the previous v."""
+    from elphdynamics_amd import hmc
+    m, fa, om = _pair(oracle, "b", tol=1e-7)
+    dt, nt, alpha = 0.04, 4, 0.4
+    H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt, alpha=alpha, Nb=1)
+    x, v = m.x.copy(), np.zeros(m.Ndof)
+    accs = []
+    for k, u in enumerate((0.0, 1.0, 0.0)):                       # accept, forced reject, accept
+        rnd = _randoms(m, nt, 700 + 10 * k, False, u)
+        acc_o, x, v, info = _oracle_update(oracle, om, m, fa, x, v, dt, nt, 1, alpha, rnd)
+        acc, _ = hmc.update_(m, H, fa, None, randoms=rnd, pull=False)
+        assert acc == acc_o
+        accs.append(acc)
+    assert accs == [True, False, True]
+    H.pull_()
+    assert rel(m.x, x) < 3e-7 and rel(H.v, v) < 3e-7
+    m.close()
+
+
+def test_hmc_reject_restores_bit_exactly_and_failed_solve_kills(oracle):
+    from elphdynamics_amd import hmc, models
+    m, fa, om = _pair(oracle, "b", tol=1e-6)
+    dt, nt = 0.05, 3
+    H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt)
+    x0 = m.x.copy()
+    rnd = _randoms(m, nt, 900, False, 1.0)
+    acc, _ = hmc.update_(m, H, fa, None, randoms=rnd)
+    assert not acc and H.flag == 0 and 0.0 < H.P_accept <= 1.0
+    assert np.array_equal(m.x, x0)                                 # copyto!(x, x0): bit-exact
+    # exp(-dtau V) was rebuilt for the restored field: a mat-vec equals the one of a fresh model
+    v = np.linspace(-1, 1, m.Ndim)
+    y1, y2 = np.empty(m.Ndim), np.empty(m.Ndim)
+    models.mulM_(y1, m, v)
+    models.update_model_(m)
+    models.mulM_(y2, m, v)
+    assert rel(y1, y2) < 1e-15
+    # a solve that cannot converge (maxiter = 3) kills the trajectory: flag 1, rejected, x restored
+    m.solver.maxiter = 3
+    acc, _ = hmc.update_(m, H, fa, None, randoms=_randoms(m, nt, 901, False, 0.0))
+    assert not acc and H.flag == 1 and H.P_accept == 0.0 and np.array_equal(m.x, x0)
+    m.close()
+
+
+@pytest.mark.parametrize("tag", ["b", "C"])
+def test_hmc_update_with_kpm_preconditioner(oracle, tag):
+    """setup!(P) once per force evaluation from the caller's Arnoldi start vectors; same end point as the oracle's
+    preconditioned trajectory (the two Arnoldi implementations agree to ~1e-7 on the bounds, which moves nothing by
+    more than the solver tolerance)."""
+    from elphdynamics_amd import hmc, preconditioners as pc
+    m, fa, om = _pair(oracle, tag, tol=1e-7)
+    dt, nt = 0.05, 2
+    H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt)
+    P = pc.SymmetricKPMPreconditioner(m, n=min(20, m.Nsites), buf=0.05, c1=1.0, c2=1.0)
+    Po = oracle.make_kpm(om, n=min(20, m.Nsites))
+    rnd = _randoms(m, nt, 1100, True, 0.0)
+    x0 = m.x.copy()
+    acc_o, x_o, v_o, info = _oracle_update(oracle, om, m, fa, x0, np.zeros(m.Ndof), dt, nt, 1, 0.0, rnd, P=Po)
+    acc, its = hmc.update_(m, H, fa, P, randoms=rnd)
+    assert acc == acc_o and H.flag == 0 and info["kpm_calls"] == nt + 2
+    assert abs(H.H0 - info["H0"]) < 1e-9 * abs(info["H0"])
+    assert rel(m.x, x_o) < 1e-6 and rel(H.v, v_o) < 1e-6
+    # and the unpreconditioned trajectory ends in the same place to solver tolerance
+    m2, fa2, om2 = _pair(oracle, tag, tol=1e-7)
+    H2 = hmc.HybridMonteCarlo(m2, fa2, dt, nt * dt)
+    hmc.update_(m2, H2, fa2, None, randoms=rnd)
+    assert rel(m.x, m2.x) < 1e-6 and its < H2.iters
+    m.close()
+    m2.close()
+
+
+def test_hmc_energy_error_scales_as_dt_squared():
+    """Size-independent property at the full config-C size: |ΔH| drops 4x when dt halves (same trajectory length)."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc
+    dH = []
+    for dt, nt in ((0.02, 2), (0.01, 4)):
+        m = configs.make_model("C", tol=1e-8, maxiter=40000)
+        fa = pc.FourierAccelerator(m)
+        pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+        H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt)
+        hmc.update_(m, H, fa, None, randoms=_randoms(m, nt, 1300, False, 0.0))
+        assert H.flag == 0
+        dH.append(H.H1 - H.H0)
+        m.close()
+    assert 3.0 < dH[0] / dH[1] < 5.0, dH
+
+
+def test_hmc_error_paths():
+    from elphdynamics_amd import _lib, configs
+    from elphdynamics_amd._lib import dptr
+    lib = _lib.load()
+    m = configs.make_model("b")
+    z = np.zeros(m.Ndim)
+    acc = C.c_int()
+    rc = lib.elph_hmc_update(m._h, 0.1, 2, 1, 0.0, 0, dptr(z), dptr(z), dptr(z), None, 0.0, C.byref(acc), None, None, None)
+    assert rc == _lib.ELPH_E_STATE                                  # elph_hmc_create missing
+    one = np.ones(m.Nsites)
+    _lib.check(lib.elph_hmc_create(m._h, dptr(one), dptr(one), dptr(one), dptr(one), dptr(one), m.dtau, dptr(np.ones(m.Ndim))))
+    rc = lib.elph_hmc_update(m._h, 0.1, 2, 1, 0.0, 0, dptr(z), dptr(z), dptr(z), None, 0.0, C.byref(acc), None, None, None)
+    assert rc == _lib.ELPH_E_STATE                                  # no state uploaded
+    _lib.check(lib.elph_hmc_set_state(m._h, dptr(z), None))
+    rc = lib.elph_hmc_update(m._h, 0.1, 2, 1, 1.0, 0, dptr(z), dptr(z), dptr(z), None, 0.0, C.byref(acc), None, None, None)
+    assert rc == _lib.ELPH_E_ARG                                    # alpha must be in [0, 1)   (HMC.jl:182)
+    rc = lib.elph_hmc_update(m._h, 0.1, 2, 1, 0.0, 1, dptr(z), dptr(z), dptr(z), None, 0.0, C.byref(acc), None, None, None)
+    assert rc == _lib.ELPH_E_ARG                                    # preconditioner without start vectors
+    m.close()
+    e = configs.make_model("e")
+    rc = lib.elph_hmc_create(e._h, dptr(one), dptr(one), dptr(one), dptr(one), dptr(one), e.dtau, dptr(np.ones(e.Ndim)))
+    assert rc == _lib.ELPH_E_UNSUPPORTED                            # SSH: not built
+    e.close()
