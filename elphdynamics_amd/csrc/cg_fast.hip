@@ -1105,3 +1105,340 @@ int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     });
     return check_launch_f("k_kpm_cheb_ri");
 }
+
+// ==========================================================================================
+// Resident CG: the whole un-preconditioned solve in ONE launch, vectors held in registers.
+// ==========================================================================================
+// A wave owns T consecutive tau-slices of one right-hand side for the entire solve and keeps x, r, p (own slices
+// plus one halo slice each side), z and exp(-dtau V) of those slices in registers; nothing of the Krylov vectors
+// goes back to HBM between iterations.  Waves of one right-hand side meet twice per iteration through L2:
+//   (1) p.z:  each wave publishes its partial, waits for all partials of its rhs, reduces them in the fixed order of
+//       reduce_partials2  =>  alpha identical in every wave;
+//   (2) r.r + halo:  each wave publishes the per-slice r.r partials of its slices AND its two boundary slices of the
+//       new r, waits for all  =>  eps, kappa, stop test, beta identical in every wave; the neighbours' boundary
+//       slices give p(t0-1), p(t0+T) of the next direction (p = r + beta p is pointwise, the old halo p is still in
+//       registers) — the same "recompute the halo" trick as k_cg_ap_fast, without re-reading anything else.
+// Everything the waves exchange (partials, boundary slices, flags) moves with device-scope (sc1) relaxed atomic
+// loads/stores, which are coherent at the device level by themselves on gfx942/950; the order "data before flag" /
+// "flag before data" is kept with s_waitcnt vmcnt(0) (a store is acknowledged once it is at the coherence point) —
+// NOT with agent-scope release/acquire fences, whose L2 write-back + invalidate per meeting cost 0.4 us per wave
+// (measured: 70 us per iteration at 160 waves).  Fast when the waves of a right-hand side share an XCD (their L2 is
+// the meeting point): block b runs on XCD b % 8, so right-hand side r is given the blocks with b % 8 == r % 8.
+// Arithmetic per element and the reduction trees are those of k_cg_ap_chunk<T> / k_cg_xr_fast: same iterates.
+// Every spin is bounded; a wave that times out raises `abort`, every other wave sees it within 64 polls and leaves,
+// and the host falls back to the two-kernel iteration (still on the GPU).
+struct ResidentCtl {
+    int *flagZ, *flagR;       // [nr][Wr] iteration counters (zeroed by the host before the launch)
+    double *pz;               // [2][nr][Wr]
+    double *rr;               // [2][nr][L]
+    double *halo;             // [2][nr][Wr][2][NPL*64]
+    int *abort;
+    int rhs0, nr;
+    long long spin_limit;
+};
+
+__device__ __forceinline__ int ld_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool wait_all(const int *flags, int n, int target, int *abort, long long limit) {
+    for (long long spin = 0;; ++spin) {
+        int ok = 1;
+        for (int i = threadIdx.x; i < n; i += WAVE) ok &= (ld_flag(flags + i) >= target);
+        if (__all(ok)) break;
+        if ((spin & 63) == 63 && ld_flag(abort) != 0) return false;
+        if (spin > limit) {
+            if (threadIdx.x == 0) __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return true;
+}
+
+__device__ __forceinline__ void st_coh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void publish(int *flag, int value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every sc1 store above has reached the coherence point
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NPL, int T>
+__global__ void __launch_bounds__(WAVE) k_cg_resident(CgBufs B, ModelDev m, ResidentCtl R) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NE = 4 * ((NPL + 1) / 2);
+    constexpr int HS = NPL * WAVE;                    // halo slice stride
+    double *bufA = lds, *bufB = lds + slab_len<NPL>();
+    const int N = m.N, L = m.L, Wr = L / T;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int rq = k / Wr, w = k - rq * Wr;
+    const int rl = rq * 8 + xcd;                      // right-hand side within this round
+    if (rl >= R.nr) return;
+    const int rhs = R.rhs0 + rl;
+    const int t0 = w * T;
+    const size_t ndim = (size_t)N * L;
+    auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
+    auto sgn = [](int t) { return (t == 0) ? -1.0 : 1.0; };
+    const CgParams P = B.params;
+    CgState *st2 = B.state + 2 * rhs;
+    const CgState S = ld_state(st2);
+    if (S.done || S.seq != 0) return;                 // only fresh solves (the host guarantees it)
+
+    int sc[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) { const int s = threadIdx.x + q * WAVE; sc[q] = (s < N) ? s : N - 1; }
+    double *xg = B.x + (size_t)rhs * ndim, *rg = B.r + (size_t)rhs * ndim;
+    const double *pg = B.p + (size_t)rhs * ndim;      // parity 0: p0 of k_cg_init
+    const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
+
+    double x[T][NPL], r[T][NPL], z[T][NPL], p[T + 2][NPL], E[T + 1][NPL];
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const size_t i = (size_t)(t0 + j) * N + sc[q];
+            x[j][q] = xg[i]; r[j][q] = rg[i];
+        }
+#pragma unroll
+    for (int j = 0; j < T + 2; ++j)
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) p[j][q] = pg[(size_t)wrap(t0 + j - 1) * N + sc[q]];
+#pragma unroll
+    for (int j = 0; j <= T; ++j)
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) E[j][q] = Ech[(size_t)wrap(t0 + j) * m.E_tau_stride + sc[q]];
+    unsigned ij[NE];
+    double cA[NE], sA[NE];
+    lp_load_ij<NPL>(ij, m);
+    lp_load_cs<NPL>(cA, sA, m.lp_c, m.lp_s);
+
+    int *fZ = R.flagZ + (size_t)rl * Wr, *fR = R.flagR + (size_t)rl * Wr;
+    const int wm = (w == 0) ? Wr - 1 : w - 1, wp = (w == Wr - 1) ? 0 : w + 1;
+    double rho = S.rho, kmin = S.kmin, eps = S.eps;
+    const double eps0 = S.eps0, normb = S.normb;
+
+    for (long long seq = 0;; ++seq) {
+        const int par = (int)(seq & 1);
+        // ---- z = MtM p on the own slices (pipeline of k_cg_ap_chunk, operands in registers) -------------------
+        double wprev[NPL], wcur[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            bufA[s] = E[0][q] * p[0][q];
+            bufB[s] = E[1][q] * p[1][q];
+        }
+        WAVE_LDS_ORDER();
+        lp_sweep<NPL, 2, false>(bufA, bufB, ij, cA, sA, cA, sA, m.ncol);
+        {
+            const double sga = sgn(t0), sgb = sgn(wrap(t0 + 1));
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int s = threadIdx.x + q * WAVE;
+                wprev[q] = p[1][q] - sga * bufA[s];
+                wcur[q] = p[2][q] - sgb * bufB[s];
+            }
+        }
+        WAVE_LDS_ORDER();
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 1; j <= T; ++j) {
+            const bool more = (j < T);
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int s = threadIdx.x + q * WAVE;
+                bufB[s] = wcur[q];
+                if (more) bufA[s] = E[(j + 1 <= T) ? j + 1 : T][q] * p[j + 1][q];      // E(t0+j+1) .* p(t0+j)
+            }
+            WAVE_LDS_ORDER();
+            lp_sweep_fr<NPL>(bufA, bufB, ij, cA, sA, cA, sA, m.ncol, more);
+            const double sgj = sgn(wrap(t0 + j)), sgnn = sgn(wrap(t0 + j + 1));
+            double wnext[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int s = threadIdx.x + q * WAVE;
+                const double zz = wprev[q] - sgj * E[j][q] * bufB[s];                   // z(t0+j-1)
+                z[j - 1][q] = zz;
+                if (s < N) acc += p[j][q] * zz;
+                if (more) wnext[q] = p[(j + 2 <= T + 1) ? j + 2 : T + 1][q] - sgnn * bufA[s];   // w(t0+j+1)
+            }
+            WAVE_LDS_ORDER();
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) { wprev[q] = wcur[q]; wcur[q] = wnext[q]; }
+            }
+        }
+        acc = wave_sum2(acc);
+        // ---- meeting 1: p.z --------------------------------------------------------------------------------
+        double *pzs = R.pz + ((size_t)par * R.nr + rl) * Wr;
+        if (threadIdx.x == 0) st_coh(pzs + w, acc);
+        publish(fZ + w, (int)seq + 1);
+        if (!wait_all(fZ, Wr, (int)seq + 1, R.abort, R.spin_limit)) return;
+        const double pap = reduce_partials2(pzs, Wr);
+        const double alpha = rho / pap;
+        // ---- x += alpha p, r -= alpha z, per-slice r.r; publish partials + boundary slices of r ----------------
+        double *rrs = R.rr + ((size_t)par * R.nr + rl) * L;
+        double *hal = R.halo + (((size_t)par * R.nr + rl) * Wr + w) * 2 * HS;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int s = threadIdx.x + q * WAVE;
+                x[j][q] = x[j][q] + alpha * p[j + 1][q];
+                const double rn = r[j][q] - alpha * z[j][q];
+                r[j][q] = rn;
+                if (s < N) a += rn * rn;
+                if (j == 0) st_coh(hal + s, rn);
+                if (T > 1 && j == T - 1) st_coh(hal + HS + s, rn);
+            }
+            a = wave_sum2(a);
+            if (threadIdx.x == 0) st_coh(rrs + t0 + j, a);
+        }
+        publish(fR + w, (int)seq + 1);
+        if (!wait_all(fR, Wr, (int)seq + 1, R.abort, R.spin_limit)) return;
+        const double rr = reduce_partials2(rrs, L);
+        // ---- stop test of iteration j = seq + 1 (IterativeSolvers.jl:286-295; same code as k_cg_ap_fast) -------
+        const long long it = seq + 1;
+        eps = sqrt(rr) / normb;
+        const double qq = 2.0 * (double)it / log(2.0 * eps0 / eps);
+        const double val = qq * qq;
+        kmin = (val > kmin) ? val : kmin;
+        int done = 0;
+        if (eps < P.tol) done = 1;
+        else if (kmin > P.kmax) done = 2;
+        else if (it >= P.maxiter) done = 3;
+        if (w == 0 && threadIdx.x == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + it] = eps;
+        if (done) {
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int s = threadIdx.x + q * WAVE;
+                    if (s < N) {
+                        const size_t i = (size_t)(t0 + j) * N + s;
+                        xg[i] = x[j][q]; rg[i] = r[j][q];
+                    }
+                }
+            if (w == 0 && threadIdx.x == 0) {
+                CgState o = S;
+                o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = it + 1; o.iters = it; o.done = done;
+                st2[0] = o;
+                st2[1] = o;
+            }
+            return;
+        }
+        const double beta = rr / rho;
+        rho = rr;
+        // ---- next direction on own slices and on the two halo slices ----------------------------------------
+        const double *hm = R.halo + (((size_t)par * R.nr + rl) * Wr + wm) * 2 * HS + ((T > 1) ? HS : 0);
+        const double *hp = R.halo + (((size_t)par * R.nr + rl) * Wr + wp) * 2 * HS;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            p[0][q] = ld_coh(hm + s) + beta * p[0][q];
+            p[T + 1][q] = ld_coh(hp + s) + beta * p[T + 1][q];
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) p[j + 1][q] = r[j][q] + beta * p[j + 1][q];
+    }
+}
+
+// rhs per round for a given T (0: this T cannot run), from the occupancy of the kernel on this device
+template <int NPL, int T>
+static int resident_capacity(elph_handle_s *h, size_t shm) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_cg_resident<NPL, T>, WAVE, shm) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int cus_per_xcd = prop.multiProcessorCount / 8;
+    if (cus_per_xcd < 1) return 0;
+    const long long per_xcd = (long long)occ * cus_per_xcd * 3 / 4;      // head-room: the dispatcher need not pack perfectly
+    const int Wr = (int)(h->L / T);
+    return (int)(8 * (per_xcd / Wr));
+}
+
+template <int NPL>
+static int res_cap_npl(elph_handle_s *h, size_t shm, int T) {
+    if (T == 1) return resident_capacity<NPL, 1>(h, shm);
+    if (T == 2) { if constexpr (NPL * 2 <= 8) return resident_capacity<NPL, 2>(h, shm); }
+    if (T == 4) { if constexpr (NPL * 4 <= 8) return resident_capacity<NPL, 4>(h, shm); }
+    return 0;
+}
+
+template <int NPL>
+static void res_launch_npl(elph_handle_s *h, dim3 grid, size_t shm, int T, const CgBufs &B, const ModelDev &m, const ResidentCtl &R) {
+    if (T == 1) hipLaunchKernelGGL((k_cg_resident<NPL, 1>), grid, dim3(WAVE), shm, h->stream, B, m, R);
+    else if (T == 2) { if constexpr (NPL * 2 <= 8) hipLaunchKernelGGL((k_cg_resident<NPL, 2>), grid, dim3(WAVE), shm, h->stream, B, m, R); }
+    else { if constexpr (NPL * 4 <= 8) hipLaunchKernelGGL((k_cg_resident<NPL, 4>), grid, dim3(WAVE), shm, h->stream, B, m, R); }
+}
+
+// Runs the whole un-preconditioned CG for rhs [0, nrhs) after elph_launch_cg_init.  *ran = false: not applicable
+// (the caller uses the two-kernel iteration); ELPH_E_HIP with "resident" in the message: timed out (same fallback).
+int elph_fast_cg_resident(elph_handle_s *h, const CgBufs &B, int nrhs, bool *ran) {
+    *ran = false;
+    // one-wave-per-slice-group variant: correct (bit-identical to the two-kernel path at equal T) but its 160-way
+    // meetings cost more than two kernel boundaries (19 vs 9.6 us per iteration at config C) => opt-in only
+    const char *eo = getenv("ELPH_RESIDENT_WAVES"), *et = getenv("ELPH_RESIDENT_T");     // read per solve: tests toggle them
+    const bool off = !(eo && eo[0] == '1');
+    const int forceT = et ? atoi(et) : 0;
+    if (off || h->resident_broken || !h->fast || h->kind != ELPH_MODEL_HOLSTEIN || B.params.use_prec) return ELPH_OK;
+    const int L = (int)h->L, npl = h->npl;
+    const size_t shm = 2 * (size_t)(npl * WAVE + 2 * WAVE) * sizeof(double);
+    int bestT = 0, bestCap = 0;
+    const int cand[3] = {1, 2, 4};
+    for (int T : cand) {
+        if (L % T || npl * T > 8 || L / T < 2) continue;
+        if (forceT && T != forceT) continue;
+        int cap = 0;
+        DISPATCH_NPL_F(npl, { cap = res_cap_npl<NPL>(h, shm, T); });
+        if (cap <= 0) continue;
+        if (bestT == 0 || (bestCap < nrhs && cap > bestCap)) { bestT = T; bestCap = cap; }
+        if (bestCap >= nrhs) break;                   // the smallest T that takes the whole batch in one round
+    }
+    if (bestT == 0) return ELPH_OK;
+    const int T = bestT, Wr = L / T, cap = bestCap;
+    // control block (grown on demand)
+    const int nr_max = std::min(nrhs, cap);
+    const size_t HS = (size_t)npl * WAVE;
+    const size_t n_flag = 2 * (size_t)nr_max * Wr, n_pz = 2 * (size_t)nr_max * Wr, n_rr = 2 * (size_t)nr_max * L,
+                 n_halo = 2 * (size_t)nr_max * Wr * 2 * HS;
+    const size_t need = (n_flag + 2) * sizeof(int) + (n_pz + n_rr + n_halo + 8) * sizeof(double);
+    if (need > h->res_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_res) HIPCHK(hipFree(h->d_res));
+        h->d_res = nullptr;
+        HIPCHK(hipMalloc(&h->d_res, need));
+        h->res_cap = need;
+    }
+    ModelDev m = elph_model_dev(h);
+    for (int rhs0 = 0; rhs0 < nrhs; rhs0 += cap) {
+        const int nr = std::min(cap, nrhs - rhs0);
+        ResidentCtl R;
+        char *base = static_cast<char *>(h->d_res);
+        R.pz = reinterpret_cast<double *>(base);
+        R.rr = R.pz + 2 * (size_t)nr * Wr;
+        R.halo = R.rr + 2 * (size_t)nr * L;
+        R.flagZ = reinterpret_cast<int *>(R.halo + 2 * (size_t)nr * Wr * 2 * HS);
+        R.flagR = R.flagZ + (size_t)nr * Wr;
+        R.abort = R.flagR + (size_t)nr * Wr;
+        R.rhs0 = rhs0; R.nr = nr;
+        R.spin_limit = 1LL << 21;
+        HIPCHK(hipMemsetAsync(R.flagZ, 0, (2 * (size_t)nr * Wr + 2) * sizeof(int), h->stream));
+        const dim3 grid((unsigned)(8 * ((nr + 7) / 8) * Wr));
+        DISPATCH_NPL_F(npl, { res_launch_npl<NPL>(h, grid, shm, T, B, m, R); });
+        int rc = check_launch_f("k_cg_resident");
+        if (rc) return rc;
+        int ab = 0;
+        HIPCHK(hipMemcpyAsync(&ab, R.abort, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (ab) {
+            h->resident_broken = true;
+            elph_set_error("resident CG kernel timed out waiting for its peer waves (T=%d, %d rhs); falling back", T, nr);
+            return ELPH_E_HIP;
+        }
+    }
+    h->resident_T = T;
+    *ran = true;
+    return ELPH_OK;
+}

@@ -341,7 +341,7 @@ extern "C" int elph_destroy(elph_handle h) {
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
-                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar};
+                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -545,6 +545,28 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
     if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);   // parameters are baked into captured launches
     h->cur_params = P;
     RC(elph_launch_cg_init(h, nrhs, use_prec));
+
+    // whole solve in one launch with the Krylov vectors in registers (cg_fast.hip: k_cg_resident) when it applies
+    if (h->fast && !use_prec && maxiter >= 1) {
+        bool ran = false;
+        CgBufs B = elph_make_bufs(h, nrhs);
+        B.params = P;
+        const int rc = elph_fast_cg_resident(h, B, nrhs, &ran);
+        if (rc == ELPH_OK && ran) {
+            HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int r = 0; r < nrhs; ++r) {
+                if (!h->h_state[2 * r].done) { elph_set_error("resident CG ended without a terminal state (internal error)"); return ELPH_E_STATE; }
+                iters[r] = h->h_state[2 * r].iters;
+            }
+            if (eps_hist) {
+                HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, sizeof(double) * (size_t)nrhs * (size_t)(maxiter + 1), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+            }
+            return ELPH_OK;
+        }
+        if (rc != ELPH_OK) RC(elph_launch_cg_init(h, nrhs, use_prec));   // timed out: redo the set-up, two-kernel iteration below
+    }
 
     const int64_t max_chunks = (maxiter + 1 + h->chunk - 1) / h->chunk + 1;
     bool all_done = false;

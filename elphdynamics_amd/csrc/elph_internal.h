@@ -139,6 +139,10 @@ struct elph_handle_s {
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     void *hmc = nullptr;                   // HmcState (hmc.hip), owned
+    void *d_res = nullptr;                 // resident-CG control block (flags, partials, halos)
+    size_t res_cap = 0;
+    bool resident_broken = false;          // a resident launch timed out once: do not try again on this handle
+    int resident_T = 0;                    // T of the last resident solve (0: none yet)
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
     int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/8 force
 
@@ -227,6 +231,8 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+int elph_fast_cg_resident(elph_handle_s *h, const CgBufs &B, int nrhs, bool *ran);
+CgBufs elph_make_bufs(elph_handle_s *h, int nrhs);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
 int elph_choose_T(const elph_handle_s *h, int nrhs);
 // packs per-bond values (order of h_bi/h_bj) into the lane-program layout [NE][64] (idle slots = fill)

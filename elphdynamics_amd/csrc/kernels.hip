@@ -1047,6 +1047,8 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     return check_launch("cg kernel");
 }
 
+CgBufs elph_make_bufs(elph_handle_s *h, int nrhs) { return make_bufs(h, nrhs); }
+
 // true residual of d_x against d_b -> d_scal[rhs]
 int elph_launch_residual(elph_handle_s *h, int nrhs) {
     int rc = elph_launch_mul(h, 2, h->d_tmp, h->d_x, nrhs);
