@@ -9,12 +9,12 @@ library and a gfx950 device.
 from . import lattice, synth  # noqa: F401
 from .lattice import Lattice  # noqa: F401
 
-__all__ = ["lattice", "synth", "Lattice", "models", "preconditioners", "configs"]
+__all__ = ["lattice", "synth", "Lattice", "models", "preconditioners", "configs", "hmc", "greens", "io"]
 
 
 def __getattr__(name):
     # models / preconditioners / configs pull in the ctypes binding lazily
-    if name in ("models", "preconditioners", "configs", "hmc"):
+    if name in ("models", "preconditioners", "configs", "hmc", "greens", "io", "sharded", "dist"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

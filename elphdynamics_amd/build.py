@@ -6,7 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("ELPH_LIB") or os.path.join(HERE, "libelphgpu.so")
-SOURCES = ["kernels.hip", "cg_fast.hip", "dft.hip", "elph_api.hip", "hmc.hip", "kpm_host.cpp"]
+SOURCES = ["kernels.hip", "cg_fast.hip", "dft.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
+OBJDIR = os.path.join(HERE, "build")
 HEADERS = [os.path.join(CSRC, "elph_internal.h"), os.path.join(HERE, "..", "include", "elph_gpu.h")]
 
 
@@ -26,12 +27,27 @@ def needs_build():
 
 
 def build_library(force=False, verbose=False):
-    """Compile the HIP kernels + C-ABI into elphdynamics_amd/libelphgpu.so. Returns the path."""
+    """Compile the HIP kernels + C-ABI into elphdynamics_amd/libelphgpu.so. Returns the path.
+    One object per source (rebuilt only when it or a header is newer), compiled side by side, then one link."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-x", "hip",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in HEADERS)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            cmd = [hipcc, *flags, "-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

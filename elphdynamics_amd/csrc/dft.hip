@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(WAVE) k_dft_fwd_tab(double2 *__restrict__ out,
             const int k = k0 + kk;
             if (k < K) {
                 double2 r = acc[kk];
-                if (PLAIN) {
+                if (PLAIN && diag) {
                     // Re iFFT(D .* FFT(v)) of a real v only sees the symmetric part of D: (D[k] + D[L-k])/2
                     const int km = (k == 0) ? 0 : L - k;
                     const double f = 0.5 * (pow(diag[(size_t)k * N + s], power) + pow(diag[(size_t)km * N + s], power));
@@ -201,6 +201,24 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
                        0, h->stream, outS, u, h->d_Pt, N, L, Lh, dft_pad(Lh, 2 * DFT_KC), (const CgState *)nullptr, (const double *)nullptr,
                        (double *)nullptr, 0);
     return dft_check("fourier_accelerate");
+}
+
+// nu[rhs][k][s] (half spectrum, k <= L/2) = FFT_t(v)[k]  — plain (untwisted) transform, no diagonal
+int elph_dft_fwd_plain(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs) {
+    const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, true>), dim3((unsigned)nst, (unsigned)((Lh + DFT_KPT - 1) / DFT_KPT), (unsigned)nrhs),
+                       dim3(WAVE), 0, h->stream, nu, vS, h->d_Pk, N, L, Lh, dft_pad(L, 2 * DFT_TC), (const CgState *)nullptr,
+                       (const double *)nullptr, 0.0);
+    return dft_check("k_dft_fwd_tab(plain)");
+}
+
+// out = Re iFFT(nu) from the half spectrum k <= L/2 (Hermitian weights and 1/L in the table)
+int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs) {
+    const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>), dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nrhs),
+                       dim3(WAVE), 0, h->stream, outS, nu, h->d_Pt, N, L, Lh, dft_pad(Lh, 2 * DFT_KC), (const CgState *)nullptr,
+                       (const double *)nullptr, (double *)nullptr, 0);
+    return dft_check("k_dft_inv_tab(plain)");
 }
 
 // host: build the four twiddle tables with exact index reduction

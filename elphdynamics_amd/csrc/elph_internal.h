@@ -139,6 +139,7 @@ struct elph_handle_s {
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     void *hmc = nullptr;                   // HmcState (hmc.hip), owned
+    void *greens = nullptr;                // GreensState (greens.hip), owned
     void *d_res = nullptr;                 // resident-CG control block (flags, partials, halos)
     size_t res_cap = 0;
     bool resident_broken = false;          // a resident launch timed out once: do not try again on this handle
@@ -207,6 +208,7 @@ int elph_i_ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, 
 int elph_i_ensure_capacity(elph_handle_s *h, int nrhs);
 void elph_i_drop_graphs(elph_handle_s *h);
 void elph_hmc_free(elph_handle_s *h);
+void elph_greens_free(elph_handle_s *h);
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec);
 int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec);
 int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain = 0);
@@ -243,6 +245,8 @@ int elph_dft_build_tables(elph_handle_s *h);
 int elph_dft_fwd_twisted(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st);
 int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,
                          const double *rvec, double *rz_part, int nrz);
+int elph_dft_fwd_plain(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs);
+int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs);
 int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u);
 
 // ---- host-side KPM setup (kpm_host.cpp) ---------------------------------------------------

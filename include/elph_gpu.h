@@ -223,6 +223,39 @@ int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, double alpha, 
                     const double *Rp, const double *Rm, const double *kpm_randn, double u_accept, int *accepted,
                     double *iters_per_solve, double *energies, int *flag);
 
+/* ---------------------------------------------------------------- Green's-function estimator */
+
+/* EstimateGreensFunction(model, n_v) — GreensFunctions.jl:155-195.  norbits*L1*L2*L3 must equal nsites
+ * (site = norbits*cell + orbit, cell = l1 + L1*(l2 + L2*l3), Lattices.jl:56-107).  n_v = max(2, nv) (:167). */
+int elph_greens_create(elph_handle h, int norbits, int L1, int L2, int L3, int nv);
+int elph_greens_nv(elph_handle h, int *nv);
+
+/* update!(estimator, model, P) — GreensFunctions.jl:201-234: for every noise vector r (R: double[n_v * ndim], the
+ * vectors the reference draws with randn!(model.rng, r₁), :212) solve MᵀM x = Mᵀ r from x = 0 with ldiv!'s semantics
+ * (Models.jl:74-186; flags, zero-fill, un-preconditioned retry) — the n_v solves run as ONE batched CG.  R and M⁻¹R
+ * stay on the device.  iters / residual_error / flag: per vector, each may be NULL.  With use_precond the caller has
+ * run elph_kpm_setup on the current field (setup!(preconditioner), :206). */
+int elph_greens_update(elph_handle h, const double *R, int use_precond, int64_t *iters, double *residual_error, int *flag);
+
+/* estimator.R / estimator.M⁻¹R (double[n_v * ndim], vector-major, tau fastest); NULL = skip.  set: replay of vectors
+ * produced elsewhere (both must have been given before elph_greens_setup). */
+int elph_greens_set_vectors(elph_handle h, const double *R, const double *MinvR);
+int elph_greens_get_vectors(elph_handle h, double *R, double *MinvR);
+
+/* setup!(estimator, n₁, n₂) — GreensFunctions.jl:239-288 with convolve! (:351-400), antiperiodic_copy! (:406-418),
+ * periodic_product! (:424-440); n₁, n₂ 1-based.  Outputs (NULL = not copied to the host), each
+ * Complex{Float64}[2L, n_s, n_s, L1, L2, L3] as interleaved (re, im) doubles, first index fastest:
+ *   GD0      G[Δ,0]            measure_GΔ0      (:293-298)  = array[mod1(τ+1,2L), o₂, o₁, l₁+1, l₂+1, l₃+1]
+ *   GD0_GD0  G[Δ,0]·G[Δ,0]     measure_GΔ0_GΔ0  (:303-308)
+ *   GDD_G00  G[Δ,Δ]·G[0,0]     measure_GΔΔ_G00  (:313-318)
+ *   GD0_G0D  G[Δ,0]·G[0,Δ]     measure_GΔ0_G0Δ  (:324-329)
+ * Imaginary parts are exact zeros (the reference's are FFT round-off, ~1e-17). */
+int elph_greens_setup(elph_handle h, int n1, int n2, double *GD0, double *GD0_GD0, double *GDD_G00, double *GD0_G0D);
+
+/* Device-resident results of the last elph_greens_setup: arrays[0..3] in the order above, `count` complex numbers each
+ * (valid until the next elph_greens_setup / elph_greens_create / elph_destroy). */
+int elph_greens_dev_arrays(elph_handle h, void **arrays, int64_t *count);
+
 /* ---------------------------------------------------------------- KPM preconditioner */
 
 /* SymmetricKPMPreconditioner(model, n, buf, c1, c2) — KPMPreconditioners.jl:219-235, ctor :101-146 */

@@ -422,10 +422,51 @@ def gen_hmc(h, tag, seed, dt=0.05, nt=6, nb=1):
          H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0) + 0.5 * (v_init @ accel(v_init, 1.0)))
 
 
+# ----------------------------------------------------------------------------- Green's-function estimator
+def gen_greens(h, tag, norb, Lsp, seed, nv=3):
+    """Stochastic Green's-function estimator (GreensFunctions.jl:201-288): the four translation-averaged products
+    written as what they ARE — plain cross-correlations over the antiperiodically (or periodically) doubled time
+    axis, summed directly (no FFT):
+        ab[dt, s2, s1, dl] = (1/V) sum_{t < 2L} sum_{cells l} a~[(t+dt) mod 2L, s2, l+dl] * b~[t, s1, l],  V = 2L*Ncells
+    with a~ = [a, -a] (antiperiodic_copy!) or [a*c, a*c] (periodic_product!).  M^-1 R from a dense solve."""
+    N, L, M = h["N"], h["Ltau"], h["M"]
+    L1 = L2 = Lsp
+    R = np.stack([synth.randn(seed + i, N * L) for i in range(nv)])
+    MinvR = np.stack([np.linalg.solve(M, R[i]) for i in range(nv)])
+    shape = (L, norb, L1, L2)
+
+    def grid(v):
+        return v.reshape(shape, order="F")
+
+    def corr(a2, b2):
+        V = a2.shape[0] * L1 * L2
+        out = np.zeros((2 * L, norb, norb, L1, L2))
+        for dt in range(2 * L):
+            for d1 in range(L1):
+                for d2 in range(L2):
+                    ash = np.roll(a2, (-dt, -d1, -d2), axis=(0, 2, 3))
+                    out[dt, :, :, d1, d2] = np.einsum("tsxy,tuxy->su", ash, b2) / V
+        return out
+
+    anti = lambda v: np.concatenate([grid(v), -grid(v)], axis=0)
+    peri = lambda u, v: np.concatenate([grid(u) * grid(v), grid(u) * grid(v)], axis=0)
+    out = dict(N=N, Ltau=L, norb=norb, L1=L1, L2=L2, R=R, MinvR=MinvR)
+    for (n1, n2) in [(0, 1), (0, 2), (1, 2)]:
+        x1, x2, r1, r2 = MinvR[n1], MinvR[n2], R[n1], R[n2]
+        key = f"_{n1 + 1}{n2 + 1}"
+        out["GD0" + key] = corr(anti((x1 + x2) / np.sqrt(2.0)), anti((r1 + r2) / np.sqrt(2.0))).reshape(-1, order="F")
+        out["GD0_GD0" + key] = corr(peri(x1, x2), peri(r1, r2)).reshape(-1, order="F")
+        out["GDD_G00" + key] = corr(peri(x2, r2), peri(x1, r1)).reshape(-1, order="F")
+        out["GD0_G0D" + key] = corr(peri(x1, r2), peri(x2, r1)).reshape(-1, order="F")
+    save(f"greens_{tag}.npz", **out)
+
+
 if __name__ == "__main__":
     gen_tables()
     h1 = gen_holstein("sq4_L8", 1, 4, SQUARE, 8, 0.1, seed=11)
-    gen_holstein("hc3_L6", 2, 3, HONEY, 6, 0.1, seed=22)
+    h3 = gen_holstein("hc3_L6", 2, 3, HONEY, 6, 0.1, seed=22)
+    gen_greens(h1, "sq4_L8", 1, 4, seed=77)
+    gen_greens(h3, "hc3_L6", 2, 3, seed=88)
     gen_holstein("tri3_L5", 1, 3, TRI, 5, 0.125, seed=33)
     gen_single_site()
     gen_ssh("sq4_L8", 4, 8, 0.05, seed=44)
