@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("ELPH_LIB") or os.path.join(HERE, "libelphgpu.so")
-SOURCES = ["kernels.hip", "cg_fast.hip", "dft.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
+SOURCES = ["kernels.hip", "cg_fast.hip", "dft.hip", "dft_mfma.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
 OBJDIR = os.path.join(HERE, "build")
 HEADERS = [os.path.join(CSRC, "elph_internal.h"), os.path.join(HERE, "..", "include", "elph_gpu.h")]
 

@@ -673,9 +673,9 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb_fast(double2 *__restrict__ nu
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NE = 4 * ((NPL + 1) / 2);
     double2 *buf = reinterpret_cast<double2 *>(lds);
-    const int rhs = blockIdx.y;
+    const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && ld_state(state + 2 * rhs).done) return;   // `state` points at the current copy (host adds the parity)
-    const int w = K.wsched[blockIdx.x];
+    const int w = K.wsched[blockIdx.y];
     const int N = m.N;
     const int order = K.order[w];
     const double2 *c = K.coeff + K.coff[w];
@@ -786,9 +786,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_ri(double2 *__restrict__ 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     double *slab = lds + wv * SL;                 // this wave's component slab
     double *xch = lds + 2 * SL;                   // exchange area [2][NPL*64]
-    const int rhs = blockIdx.y;
+    const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && ld_state(state + 2 * rhs).done) return;   // `state` points at the current copy (host adds the parity)
-    const int w = K.wsched[blockIdx.x];
+    const int w = K.wsched[blockIdx.y];
     const int N = m.N;
     const int order = K.order[w];
     const double2 *c = K.coeff + K.coff[w];
@@ -932,9 +932,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_sq(double2 *__restrict__ 
     constexpr int NS = P * P, LS = 8 * P;
     __shared__ double xch[2][NS * WAVE];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
-    const int rhs = blockIdx.y;
+    const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && ld_state(state + 2 * rhs).done) return;
-    const int w = K.wsched[blockIdx.x];
+    const int w = K.wsched[blockIdx.y];
     const int order = K.order[w];
     const double2 *c = K.coeff + K.coff[w];
     double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
@@ -1083,7 +1083,7 @@ int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     if (complex_variant) {
         const size_t shm = (size_t)(h->npl * WAVE + 2 * WAVE) * sizeof(double2);
         DISPATCH_NPL_F(h->npl, {
-            hipLaunchKernelGGL((k_kpm_cheb_fast<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(WAVE), shm, h->stream, h->d_nu, K,
+            hipLaunchKernelGGL((k_kpm_cheb_fast<NPL>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3(WAVE), shm, h->stream, h->d_nu, K,
                                m, Lo2, st);
         });
         return check_launch_f("k_kpm_cheb_fast");
@@ -1091,16 +1091,16 @@ int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     static const bool no_sq = []() { const char *e = getenv("ELPH_NO_SQ"); return e && e[0] == '1'; }();
     if (h->sq_P > 0 && !no_sq) {
         if (h->sq_P == 2)
-            hipLaunchKernelGGL((k_kpm_cheb_sq<2>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(2 * WAVE), 0, h->stream, h->d_nu, K,
+            hipLaunchKernelGGL((k_kpm_cheb_sq<2>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3(2 * WAVE), 0, h->stream, h->d_nu, K,
                                h->d_sq_cbar, h->d_sq_sbar, (int)h->N, Lo2, st);
         else
-            hipLaunchKernelGGL((k_kpm_cheb_sq<1>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(2 * WAVE), 0, h->stream, h->d_nu, K,
+            hipLaunchKernelGGL((k_kpm_cheb_sq<1>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3(2 * WAVE), 0, h->stream, h->d_nu, K,
                                h->d_sq_cbar, h->d_sq_sbar, (int)h->N, Lo2, st);
         return check_launch_f("k_kpm_cheb_sq");
     }
     const size_t shm = (size_t)(2 * (h->npl * WAVE + 2 * WAVE) + 2 * h->npl * WAVE) * sizeof(double);
     DISPATCH_NPL_F(h->npl, {
-        hipLaunchKernelGGL((k_kpm_cheb_ri<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3(2 * WAVE), shm, h->stream, h->d_nu, K, m,
+        hipLaunchKernelGGL((k_kpm_cheb_ri<NPL>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3(2 * WAVE), shm, h->stream, h->d_nu, K, m,
                            Lo2, st);
     });
     return check_launch_f("k_kpm_cheb_ri");

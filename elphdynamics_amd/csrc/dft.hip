@@ -15,6 +15,8 @@
 //     current chunk's FMAs (two named buffers), so a wave pays ~L/TC memory round trips, not L.
 // O(L^2) per column is deliberate at these lengths (13 MFLOP at config C); tables are O(L^2) bytes.
 
+#include <cstdlib>
+
 #include "elph_internal.h"
 
 #define WAVE ELPH_WAVE
@@ -157,7 +159,13 @@ __global__ void __launch_bounds__(WAVE) k_dft_inv_tab(double *__restrict__ out, 
     }
     if (rz_part) {
         dot = dft_wave_sum(dot);
-        if (threadIdx.x == 0) rz_part[(size_t)rhs * nrz + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = dot;
+        if (threadIdx.x == 0) {
+            // own slot, plus this block's share of the slots no block of this grid owns (the reducers read all nrz)
+            const int G = (int)(gridDim.x * gridDim.y), b = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+            double *slots = rz_part + (size_t)rhs * nrz;
+            slots[b] = dot;
+            for (int q = G + b; q < nrz; q += G) slots[q] = 0.0;
+        }
     }
 }
 
@@ -170,15 +178,18 @@ static int dft_check(const char *what) {
     return ELPH_OK;
 }
 
+// Single-solve shapes (2 outputs per wave: many waves for the latency-bound case).  These kernels are bound by the
+// scalar twiddle stream (106 SGPRs hold < 30 twiddles); a wider shape (8 outputs per wave) was measured ~15 % SLOWER in
+// a batch, so batches go to the matrix-core GEMM form in dft_mfma.hip instead.
 constexpr int DFT_KPT = 2, DFT_TC = 40, DFT_TPT = 2, DFT_KC = 20;
 static int dft_pad(int n, int m) { return ((n + m - 1) / m) * m; }
-
 // nu[rhs][k][s] (half spectrum, k < ceil(L/2)) = FFT_t(Theta .* v)[k]
 int elph_dft_fwd_twisted(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {
     const int L = (int)h->L, Lo2 = (L + 1) / 2, nst = (N + WAVE - 1) / WAVE;
+    if (elph_dft_mfma_usable(h, 0, false, N, nrhs)) return elph_dft_mfma_fwd(h, 0, nu, vS, N, nrhs, st);
     hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, false>),
-                       dim3((unsigned)nst, (unsigned)((Lo2 + DFT_KPT - 1) / DFT_KPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, nu,
-                       vS, h->d_Tk, N, L, Lo2, dft_pad(L, 2 * DFT_TC), st, (const double *)nullptr, 0.0);
+                           dim3((unsigned)nst, (unsigned)((Lo2 + DFT_KPT - 1) / DFT_KPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, nu,
+                           vS, h->d_Tk, N, L, Lo2, dft_pad(L, 2 * DFT_TC), st, (const double *)nullptr, 0.0);
     return dft_check("k_dft_fwd_tab(twisted)");
 }
 
@@ -186,9 +197,10 @@ int elph_dft_fwd_twisted(elph_handle_s *h, double2 *nu, const double *vS, int N,
 int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,
                          const double *rvec, double *rz_part, int nrz) {
     const int L = (int)h->L, Lo2 = (L + 1) / 2, nst = (N + WAVE - 1) / WAVE;
+    if (elph_dft_mfma_usable(h, 0, true, N, nrhs)) return elph_dft_mfma_inv(h, 0, outS, nu, N, nrhs, st, rvec, rz_part, nrz);
     hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>),
-                       dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, outS,
-                       nu, h->d_Tt, N, L, Lo2, dft_pad(Lo2, 2 * DFT_KC), st, rvec, rz_part, nrz);
+                           dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, outS,
+                           nu, h->d_Tt, N, L, Lo2, dft_pad(Lo2, 2 * DFT_KC), st, rvec, rz_part, nrz);
     return dft_check("k_dft_inv_tab(twisted)");
 }
 
@@ -206,18 +218,21 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
 // nu[rhs][k][s] (half spectrum, k <= L/2) = FFT_t(v)[k]  — plain (untwisted) transform, no diagonal
 int elph_dft_fwd_plain(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs) {
     const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, true>), dim3((unsigned)nst, (unsigned)((Lh + DFT_KPT - 1) / DFT_KPT), (unsigned)nrhs),
-                       dim3(WAVE), 0, h->stream, nu, vS, h->d_Pk, N, L, Lh, dft_pad(L, 2 * DFT_TC), (const CgState *)nullptr,
-                       (const double *)nullptr, 0.0);
+    if (elph_dft_mfma_usable(h, 1, false, N, nrhs)) return elph_dft_mfma_fwd(h, 1, nu, vS, N, nrhs, nullptr);
+    hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, true>),
+                           dim3((unsigned)nst, (unsigned)((Lh + DFT_KPT - 1) / DFT_KPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, nu, vS,
+                           h->d_Pk, N, L, Lh, dft_pad(L, 2 * DFT_TC), (const CgState *)nullptr, (const double *)nullptr, 0.0);
     return dft_check("k_dft_fwd_tab(plain)");
 }
 
 // out = Re iFFT(nu) from the half spectrum k <= L/2 (Hermitian weights and 1/L in the table)
 int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs) {
     const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>), dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nrhs),
-                       dim3(WAVE), 0, h->stream, outS, nu, h->d_Pt, N, L, Lh, dft_pad(Lh, 2 * DFT_KC), (const CgState *)nullptr,
-                       (const double *)nullptr, (double *)nullptr, 0);
+    if (elph_dft_mfma_usable(h, 1, true, N, nrhs)) return elph_dft_mfma_inv(h, 1, outS, nu, N, nrhs, nullptr, nullptr, nullptr, 0);
+    hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>),
+                           dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, outS,
+                           nu, h->d_Pt, N, L, Lh, dft_pad(Lh, 2 * DFT_KC), (const CgState *)nullptr, (const double *)nullptr,
+                           (double *)nullptr, 0);
     return dft_check("k_dft_inv_tab(plain)");
 }
 
@@ -253,5 +268,5 @@ int elph_dft_build_tables(elph_handle_s *h) {
         HIPCHK(hipMalloc((void **)tb.d, tb.v->size() * sizeof(double2)));
         HIPCHK(hipMemcpy(*tb.d, tb.v->data(), tb.v->size() * sizeof(double2), hipMemcpyHostToDevice));
     }
-    return ELPH_OK;
+    return elph_dft_mfma_build_tables(h);
 }

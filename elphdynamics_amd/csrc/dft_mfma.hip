@@ -1,0 +1,240 @@
+// dft_mfma.hip — batched tau-axis transforms as dense f64 GEMMs on the matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Same transforms as dft.hip (TimeFreqFFTs.jl:55-73,112-130 twisted; FourierAcceleration.jl:91-143 plain): for a batch
+// of right-hand sides the direct DFT  out[m][col] = sum_j W[m][j] * in[j][col]  is a (2K x L) x (L x N*nrhs) real GEMM
+// (forward: rows = (k, re/im), j = tau; inverse: rows = tau, j = (k, re/im) with Hermitian weights and 1/L folded in).
+// The scalar-twiddle kernels of dft.hip are SGPR-bound in a batch (each FMA pair needs a fresh 16-byte scalar load,
+// 106 SGPRs hold < 30 twiddles: ~8 TFLOP/s); here a wave keeps its 16 data columns in registers for the whole
+// reduction axis (one f64 per lane per 4x16 B tile), streams pre-swizzled 16x4 A tiles of W with one coalesced 512-byte
+// load each, and issues MG independent MFMAs per A-tile step.  The single-solve (latency-bound) case stays on dft.hip.
+//
+// MFMA operand maps (MI355X_MICROARCH.md, f64 16x16x4): A[row = lane&15][j = lane>>4], B[j = lane>>4][col = lane&15],
+// C/D reg r: [row = (lane>>4) + 4r][col = lane&15].  Forward tiles order their 16 rows so that a lane's four results are
+// (re, im) of two adjacent frequencies: row rho = r0 + 4r  <->  k = 8*mt + 2*r0 + (r>>1), part = r&1  -> 16-byte stores.
+
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "elph_internal.h"
+
+#define WAVE ELPH_WAVE
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int MG = 5;                 // row tiles (independent accumulators) per wave
+constexpr int CW = 4;                 // waves per workgroup = adjacent column tiles walking the SAME A-tile stream: their
+                                      // requests for a tile meet in the CU's L1 instead of each going to L2 (every wave
+                                      // of a row group reads the same table lines — single-wave workgroups hot-spot a
+                                      // few L2 channels)
+constexpr int NT_CAND[5] = {12, 20, 32, 44, 64};
+
+__device__ __forceinline__ bool mf_done(const CgState *state, int rhs) {
+    if (!state) return false;
+    return __hip_atomic_load(&state[2 * rhs].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// grid: x = column tile (16 columns), y = row-tile group (MG tiles), z = right-hand side
+template <int NT, bool INV>
+__global__ void __launch_bounds__(CW * WAVE) k_dft_mfma(double *__restrict__ out, const double *__restrict__ in,
+                                                   const double *__restrict__ W, int N, int L, int K, const CgState *state,
+                                                   const double *__restrict__ rvec, double *__restrict__ rz_part, int nrz) {
+    const int rhs = blockIdx.z;
+    if (mf_done(state, rhs)) return;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, col = lane & 15, jj = lane >> 4;
+    const int ctile = blockIdx.x * CW + wv;
+    if (ctile * 16 >= N) return;                                         // no block-level sync below
+    const int s = ctile * 16 + col;
+    const int sc = (s < N) ? s : N - 1;
+    // ---- the wave's 16 data columns over the whole reduction axis: b[tt] = in[j = 4 tt + jj][col]
+    double b[NT];
+    if (!INV) {
+        const double *v = in + (size_t)rhs * N * L;                       // real [tau][site]
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int t = 4 * tt + jj;
+            t = (t < L) ? t : L - 1;                                      // W is zero there; the clamp keeps the value finite
+            b[tt] = v[(size_t)t * N + sc];
+        }
+    } else {
+        const double *nu = in + (size_t)rhs * K * N * 2;                  // complex [k][site] as (re, im) doubles
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int k = 2 * tt + (jj >> 1);
+            k = (k < K) ? k : K - 1;
+            b[tt] = nu[((size_t)k * N + sc) * 2 + (jj & 1)];
+        }
+    }
+    const int mt0 = blockIdx.y * MG;
+    const double *Wg = W + ((size_t)mt0 * NT) * WAVE + lane;              // tile (mt, tt) at ((mt*NT + tt)*64 + lane)
+    double4_t acc[MG];
+#pragma unroll
+    for (int g = 0; g < MG; ++g) acc[g] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // A tiles come from L2 (the table is shared by every wave): a step's MFMAs last ~130 ns, an L2 round trip several times
+    // that, so the tile stream runs PF steps ahead in a register ring (indices are compile-time after unrolling).
+    constexpr int PF = 6;
+    double a[PF + 1][MG];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        if (p < NT) {
+#pragma unroll
+            for (int g = 0; g < MG; ++g) a[p][g] = Wg[(size_t)(g * NT + p) * WAVE];
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        if (tt + PF < NT) {
+#pragma unroll
+            for (int g = 0; g < MG; ++g) a[(tt + PF) % (PF + 1)][g] = Wg[(size_t)(g * NT + tt + PF) * WAVE];
+        }
+#pragma unroll
+        for (int g = 0; g < MG; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt % (PF + 1)][g], b[tt], acc[g], 0, 0, 0);
+    }
+    // ---- results
+    const int r0 = lane >> 4;
+    if (!INV) {
+        double2 *o = reinterpret_cast<double2 *>(out) + (size_t)rhs * K * N;
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+            const int k = 8 * (mt0 + g) + 2 * r0;
+            if (s < N) {
+                if (k < K) o[(size_t)k * N + s] = make_double2(acc[g].x, acc[g].y);
+                if (k + 1 < K) o[(size_t)(k + 1) * N + s] = make_double2(acc[g].z, acc[g].w);
+            }
+        }
+    } else {
+        double dot = 0.0;
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * (mt0 + g) + r0 + 4 * r;
+                if (s < N && t < L) {
+                    const size_t i = (size_t)rhs * N * L + (size_t)t * N + s;
+                    const double val = acc[g][r];
+                    out[i] = val;
+                    if (rz_part) dot += rvec[i] * val;
+                }
+            }
+        }
+        if (rz_part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, WAVE);
+            if (lane == 0) {
+                const int nct = (N + 15) / 16;
+                const int G = nct * (int)gridDim.y, bid = (int)blockIdx.y * nct + ctile;
+                double *slots = rz_part + (size_t)rhs * nrz;
+                slots[bid] = dot;
+                for (int q = G + bid; q < nrz; q += G) slots[q] = 0.0;
+            }
+        }
+    }
+}
+
+int pick_nt(int need) {
+    for (int c : NT_CAND) if (need <= c) return c;
+    return 0;
+}
+
+int mf_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { elph_set_error("launch %s failed: %s", what, hipGetErrorString(e)); return ELPH_E_HIP; }
+    return ELPH_OK;
+}
+
+template <bool INV>
+int launch(elph_handle_s *h, int nt, double *out, const double *in, const double *W, int N, int K, int groups, int nrhs,
+           const CgState *st, const double *rvec, double *rz_part, int nrz) {
+    const int nct = (N + 15) / 16;
+    const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)groups, (unsigned)nrhs), block(CW * WAVE);
+    const int L = (int)h->L;
+#define MF_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma<NTV, INV>), grid, block, 0, h->stream, out, in, W, N, L, K, st, rvec, rz_part, nrz); break;
+    switch (nt) {
+        MF_CASE(12) MF_CASE(20) MF_CASE(32) MF_CASE(44) MF_CASE(64)
+        default: elph_set_error("dft_mfma: no kernel for %d reduction tiles", nt); return ELPH_E_UNSUPPORTED;
+    }
+#undef MF_CASE
+    return mf_check(INV ? "k_dft_mfma(inverse)" : "k_dft_mfma(forward)");
+}
+
+}  // namespace
+
+// which: 0 twisted, 1 plain
+bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N, int nrhs) {
+    const char *e = getenv("ELPH_DFT_MFMA");       // read per call: tests switch both ways inside one process
+    const int force = e ? atoi(e) : -1;
+    if (force == 0) return false;
+    const elph_handle_s::MfmaTab &T = h->mf[which][inverse ? 1 : 0];
+    if (!T.W) return false;
+    if (force == 1) return true;
+    return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;
+}
+
+int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {
+    const elph_handle_s::MfmaTab &T = h->mf[which][0];
+    const int K = which == 0 ? (int)(h->L + 1) / 2 : (int)h->L / 2 + 1;
+    return launch<false>(h, T.nt, reinterpret_cast<double *>(nu), vS, T.W, N, K, T.groups, nrhs, st, nullptr, nullptr, 0);
+}
+
+int elph_dft_mfma_inv(elph_handle_s *h, int which, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,
+                      const double *rvec, double *rz_part, int nrz) {
+    const elph_handle_s::MfmaTab &T = h->mf[which][1];
+    const int K = which == 0 ? (int)(h->L + 1) / 2 : (int)h->L / 2 + 1;
+    if (rz_part && (int)((N + 15) / 16) * T.groups > nrz) { elph_set_error("dft_mfma: %d partial slots needed, %d available", ((N + 15) / 16) * T.groups, nrz); return ELPH_E_STATE; }
+    return launch<true>(h, T.nt, outS, reinterpret_cast<const double *>(nu), T.W, N, K, T.groups, nrhs, st, rvec, rz_part, nrz);
+}
+
+// host: the four W matrices in A-tile order (zero-padded to groups*MG row tiles x nt reduction tiles)
+int elph_dft_mfma_build_tables(elph_handle_s *h) {
+    const int L = (int)h->L;
+    for (int which = 0; which < 2; ++which) {
+        const int K = which == 0 ? (L + 1) / 2 : L / 2 + 1;
+        auto angle = [&](int k, int t) {   // exact index reduction, as in dft.hip
+            if (which == 0) { const long long m = ((long long)(2 * k + 1) * t) % (2LL * L); return M_PI * (double)m / (double)L; }
+            const long long m = ((long long)k * t) % L;
+            return 2.0 * M_PI * (double)m / (double)L;
+        };
+        auto weight = [&](int k) {
+            if (which == 0) return ((L & 1) && k == K - 1) ? 1.0 : 2.0;
+            return (k == 0 || 2 * k == L) ? 1.0 : 2.0;
+        };
+        for (int inv = 0; inv < 2; ++inv) {
+            elph_handle_s::MfmaTab &T = h->mf[which][inv];
+            if (T.W) { HIPCHK(hipFree(T.W)); T.W = nullptr; }
+            const int rows = inv ? L : 2 * K, red = inv ? 2 * K : L;
+            const int nmt = (rows + 15) / 16, ntt = (red + 3) / 4;
+            T.nt = pick_nt(ntt);
+            if (T.nt == 0) continue;                       // L > 256: scalar kernels only
+            T.groups = (nmt + MG - 1) / MG;
+            const int nmt_pad = T.groups * MG;
+            std::vector<double> W((size_t)nmt_pad * T.nt * WAVE, 0.0);
+            for (int mt = 0; mt < nmt; ++mt)
+                for (int tt = 0; tt < ntt; ++tt)
+                    for (int lane = 0; lane < WAVE; ++lane) {
+                        const int rho = lane & 15, jj = lane >> 4;
+                        double val = 0.0;
+                        if (!inv) {
+                            const int r0 = rho & 3, r = rho >> 2;
+                            const int k = 8 * mt + 2 * r0 + (r >> 1), part = r & 1, t = 4 * tt + jj;
+                            if (k < K && t < L) { const double a = angle(k, t); val = part == 0 ? cos(a) : -sin(a); }
+                        } else {
+                            const int t = 16 * mt + rho, k = 2 * tt + (jj >> 1), part = jj & 1;
+                            if (t < L && k < K) {
+                                const double a = angle(k, t), w = weight(k) / (double)L;
+                                val = part == 0 ? w * cos(a) : -(w * sin(a));     // Re((c + i s)(x + i y)) = c x - s y
+                            }
+                        }
+                        W[((size_t)mt * T.nt + tt) * WAVE + lane] = val;
+                    }
+            HIPCHK(hipMalloc((void **)&T.W, W.size() * sizeof(double)));
+            HIPCHK(hipMemcpy(T.W, W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    return ELPH_OK;
+}
+
+void elph_dft_mfma_free(elph_handle_s *h) {
+    for (auto &a : h->mf) for (auto &T : a) if (T.W) { (void)hipFree(T.W); T.W = nullptr; }
+}

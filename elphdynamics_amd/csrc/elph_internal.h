@@ -194,6 +194,9 @@ struct elph_handle_s {
     double2 *d_theta = nullptr;            // [L] exp(-i pi t / L)
     double2 *d_Tk = nullptr, *d_Tt = nullptr;   // twisted DFT tables [Lo2][L] / [L][Lo2] (dft.hip)
     double2 *d_Pk = nullptr, *d_Pt = nullptr;   // plain DFT tables   [Lh][L]  / [L][Lh]
+    // batched tau-DFT on the matrix cores (dft_mfma.hip): W in A-tile order, [which: twisted/plain][fwd/inv]
+    struct MfmaTab { double *W = nullptr; int nt = 0, groups = 0; };
+    MfmaTab mf[2][2];
     double *d_diag = nullptr;              // fourier-acceleration diagonal staging
     int64_t diag_cap = 0;
     std::vector<int> fft_radices;
@@ -248,6 +251,14 @@ int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int 
 int elph_dft_fwd_plain(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs);
 int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs);
 int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u);
+
+// ---- batched tau-axis transforms on the matrix cores (dft_mfma.hip); which: 0 twisted, 1 plain
+int elph_dft_mfma_build_tables(elph_handle_s *h);
+void elph_dft_mfma_free(elph_handle_s *h);
+bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N, int nrhs);
+int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS, int N, int nrhs, const CgState *st);
+int elph_dft_mfma_inv(elph_handle_s *h, int which, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,
+                      const double *rvec, double *rz_part, int nrz);
 
 // ---- host-side KPM setup (kpm_host.cpp) ---------------------------------------------------
 void elph_kpm_coefficients(double *c_z, int order, double lam_lo, double lam_hi, double phi);

@@ -582,9 +582,9 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
                                                    const CgState *state) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double2 *buf = reinterpret_cast<double2 *>(lds);
-    const int rhs = blockIdx.y;
+    const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && state[2 * rhs].done) return;   // `state` points at the current copy
-    const int w = K.wsched[blockIdx.x];
+    const int w = K.wsched[blockIdx.y];
     const int N = m.N;
     const int order = K.order[w];
     const double2 *c = K.coeff + K.coff[w];
@@ -648,8 +648,9 @@ __global__ void __launch_bounds__(WAVE) k_copy_dot(double *__restrict__ zp, cons
     }
     a = wave_sum(a);
     if (threadIdx.x == 0) {
-        // spread over the nrz slots: slot t gets the slice sum, the rest stay zero
+        // slot t gets the slice sum; this block also clears its share of the unused slots [L, nrz)
         rz_part[(size_t)rhs * nrz + t] = a;
+        for (int q = L + t; q < nrz; q += L) rz_part[(size_t)rhs * nrz + q] = 0.0;
     }
 }
 
@@ -913,7 +914,6 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     const CgState *st = cg_mode ? h->d_state + (h->ap_count & 1) : nullptr;
     if (!h->kpm_active) {
         if (cg_mode) {
-            HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
             hipLaunchKernelGGL(k_copy_dot, dim3((unsigned)L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, zS, rS, B.rz,
                                B.nrz, N, L, st);
         } else {
@@ -935,12 +935,11 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         if (rcf) return rcf;
     } else {
         DISPATCH_NPL(gen_npl(h), {
-            hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)Lo2, (unsigned)nrhs), dim3((unsigned)gen_bs(h)), shm, h->stream, h->d_nu,
+            hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3((unsigned)gen_bs(h)), shm, h->stream, h->d_nu,
                                K, m, Lo2, st);
         });
     }
-    // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz
-    if (cg_mode) HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
+    // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz; the kernel clears the rest
     {
         int rcd = elph_dft_inv_twisted(h, zS, h->d_nu, N, nrhs, st, cg_mode ? rS : nullptr, cg_mode ? B.rz : nullptr, B.nrz);
         if (rcd) return rcd;
@@ -986,12 +985,14 @@ __global__ void __launch_bounds__(WAVE) k_rz_part(const double *__restrict__ r, 
         a += r[i] * zp[i];
     }
     a = wave_sum(a);
-    if (threadIdx.x == 0) rz_part[(size_t)rhs * nrz + t] = a;
+    if (threadIdx.x == 0) {
+        rz_part[(size_t)rhs * nrz + t] = a;
+        for (int q = L + t; q < nrz; q += L) rz_part[(size_t)rhs * nrz + q] = 0.0;
+    }
 }
 
 int elph_launch_rz_partials(elph_handle_s *h, int nrhs) {
     CgBufs B = make_bufs(h, nrhs);
-    HIPCHK(hipMemsetAsync(B.rz, 0, sizeof(double) * (size_t)nrhs * B.nrz, h->stream));
     hipLaunchKernelGGL(k_rz_part, dim3((unsigned)h->L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, h->d_r, h->d_zp, B.rz,
                        B.nrz, (int)h->N, (int)h->L);
     return check_launch("k_rz_part");

@@ -2,27 +2,28 @@ import sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, '.')
 from elphdynamics_amd import configs, models, preconditioners as pc
-from elphdynamics_amd._lib import check
+from elphdynamics_amd._lib import check, dptr
 tag = sys.argv[1] if len(sys.argv) > 1 else "C"
 m = configs.make_model(tag, tol=1e-5)
 lib = m._lib
 P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
-t0=time.time(); pc.setup_(P, rng=np.random.default_rng(1)); t1=time.time()
-print("setup", t1-t0, "active", P.active, P.lam_lo, P.lam_hi, "orders sum", P.orders.sum(), "max", P.orders.max())
-t0=time.time(); pc.setup_(P, rng=np.random.default_rng(2)); t1=time.time(); print("setup again", t1-t0)
-R, B = configs.rhs(m, 1)
-b = np.ascontiguousarray(B[0])
-for tol in (1e-5, 1e-10):
-    m.solver.tol = tol
-    x = np.zeros(m.Ndim); t0=time.time(); it0, r0, f0 = models.ldiv_(x, m, b); t1=time.time()
-    x = np.zeros(m.Ndim); t2=time.time(); it1, r1, f1 = models.ldiv_(x, m, b, P=P); t3=time.time()
-    x = np.zeros(m.Ndim); t2=time.time(); it1, r1, f1 = models.ldiv_(x, m, b, P=P); t3=time.time()
-    print(f"tol={tol:g}: plain CG {it0} iters {1e3*(t1-t0):.2f} ms | KPM-CG {it1} iters {1e3*(t3-t2):.2f} ms  flags {f0} {f1}")
+pc.setup_(P, rng=np.random.default_rng(7))
+print("orders sum", int(P.orders.sum()), "max", int(P.orders.max()), "Lo2", len(P.orders))
 ms = C.c_double()
-for nrhs in (1, 16, 64):
+for nrhs in (1, 2, 10, 64):
     R, B = configs.rhs(m, nrhs)
-    for what, name in ((2, "kpm_apply"), (3, "prec_cg_iter"), (1, "cg_iter")):
-        check(lib.elph_bench_prepare(m._h, what, nrhs, np.ascontiguousarray(B).ctypes.data_as(C.POINTER(C.c_double))))
+    out = {}
+    for what, name in ((1, "cg_iter"), (2, "kpm_apply"), (3, "pcg_iter")):
+        check(lib.elph_bench_prepare(m._h, what, nrhs, dptr(np.ascontiguousarray(B))))
         check(lib.elph_bench_run(m._h, what, nrhs, 32, 0, C.byref(ms)))
-        check(lib.elph_bench_run(m._h, what, nrhs, 160, 0, C.byref(ms)))
-        print(f"nrhs={nrhs} {name}: {1e3*ms.value/160:.2f} us")
+        check(lib.elph_bench_prepare(m._h, what, nrhs, None))
+        check(lib.elph_bench_run(m._h, what, nrhs, 320, 0, C.byref(ms)))
+        out[name] = ms.value * 1e3 / 320
+    X = np.zeros_like(B)
+    models.ldiv_batched_(X, m, B, P=P); X[:] = 0
+    t0 = time.perf_counter(); it, res, fl = models.ldiv_batched_(X, m, B, P=P); t1 = time.perf_counter()
+    X[:] = 0
+    models.ldiv_batched_(X, m, B); X[:] = 0
+    t2 = time.perf_counter(); it0, res0, fl0 = models.ldiv_batched_(X, m, B); t3 = time.perf_counter()
+    print(f"{tag} nrhs={nrhs:3d} cg_iter {out['cg_iter']:.1f} us  kpm_apply {out['kpm_apply']:.1f} us  pcg_iter {out['pcg_iter']:.1f} us | "
+          f"solve kpm {1e3*(t1-t0):.2f} ms ({it.max()} it)  plain {1e3*(t3-t2):.2f} ms ({it0.max()} it)")

@@ -666,3 +666,51 @@ def test_ssh_fermion_force_is_the_gradient_of_the_action(oracle):
         fd = (S[0] - S[1]) / (2 * h)
         assert abs(fd - F[k]) < 2e-6 * max(1.0, abs(F[k])), (k, fd, F[k])
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ matrix-core DFT
+
+@pytest.mark.parametrize("L", [7, 8, 40, 120, 160])
+def test_mfma_dft_matches_golden_and_scalar_kernels(lib, L, monkeypatch):
+    """dft_mfma.hip (v_mfma_f64_16x16x4 GEMM form, used for batches) against the golden FFTs and against the
+    scalar-twiddle kernels of dft.hip on the same input — ragged N (3 and 70 sites: column clamps), odd L."""
+    from elphdynamics_amd import _lib
+    g = golden("fft.npz")
+    for N in (3, 70):
+        m = RawModel(lib, 0, N, L, np.zeros((0, 2), dtype=np.int64))
+        try:
+            v = np.ascontiguousarray(g[f"L{L}_v"]) if N == 3 else np.random.default_rng(L).standard_normal(N * L)
+            res = {}
+            for mode in ("0", "1"):
+                monkeypatch.setenv("ELPH_DFT_MFMA", mode)
+                nu = np.zeros(2 * N * L)
+                _lib.check(lib.elph_tau_to_omega(m.h, _lib.dptr(nu), _lib.dptr(v)))
+                back = np.zeros(N * L)
+                _lib.check(lib.elph_omega_to_tau(m.h, _lib.dptr(back), _lib.dptr(nu)))
+                res[mode] = (nu, back)
+                assert rel(back, v) < 1e-13
+                if N == 3:
+                    assert rel(nu[0::2], g[f"L{L}_nu_re"]) < 1e-13 and rel(nu[1::2], g[f"L{L}_nu_im"]) < 1e-13
+            assert rel(res["1"][0], res["0"][0]) < 1e-14 and rel(res["1"][1], res["0"][1]) < 1e-14
+        finally:
+            m.close()
+
+
+def test_mfma_dft_inside_batched_preconditioned_solve(monkeypatch):
+    """A 24-right-hand-side KPM-preconditioned solve at config B runs the GEMM-form DFTs (forward, and the inverse with
+    its fused r.z partial sums); same iteration counts and solutions as the scalar-kernel path."""
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    m = configs.make_model("B", tol=1e-8)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_(P, rng=np.random.default_rng(3))
+    _, B = configs.rhs(m, 24)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_DFT_MFMA", mode)
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B, P=P)
+        assert not fl.any()
+        out[mode] = (X, it)
+    assert np.array_equal(out["0"][1], out["1"][1])
+    assert rel(out["1"][0], out["0"][0]) < 1e-10
+    m.close()
