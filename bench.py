@@ -88,7 +88,7 @@ def main():
     m = configs.make_model(args.config, tol=1e-5, device=local_rank if world > 1 else 0,
                            seed=comm.chain_seed(synth.SEED_FIELDS))
     nrhs = args.nrhs
-    nchains = 1 if (args.precond or m.kind != 0) else max(1, min(args.chains, nrhs))
+    nchains = 1 if m.kind != 0 else max(1, min(args.chains, nrhs))
     R, B = configs.rhs(m, nrhs, seed=comm.chain_seed(synth.SEED_RHS))
     if nchains > 1:      # every chain its own phonon configuration (its own fermion matrix)
         Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=comm.chain_seed(synth.SEED_FIELDS) + 17 * c)
@@ -96,9 +96,12 @@ def main():
         models.update_model_chains_(m, Xc)
     what = 3 if args.precond else 1
     P = None
-    if args.precond:
+    if args.precond:      # one KPM expansion per chain (its own Ē, spectrum bounds, orders and coefficients)
         P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
-        pc.setup_(P, rng=np.random.default_rng(7 + rank))
+        if nchains > 1:
+            pc.setup_chains_(P, rng=np.random.default_rng(7 + rank))
+        else:
+            pc.setup_(P, rng=np.random.default_rng(7 + rank))
     Bc = np.ascontiguousarray(B)
 
     def run(what_, nrhs_, reps, graph=0):
@@ -191,6 +194,35 @@ def main():
         }
         out["roofline"]["whole_iteration"]["frac"] = out["roofline"]["whole_iteration"]["achieved_GBs"] / HBM_PEAK_GBS
 
+        # ---- secondary: time to solution of the whole default batch (every chain its own matrix), plain vs KPM
+        if not args.no_sweep and m.kind == 0:
+            try:
+                Pb = P or pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+                setup = pc.setup_chains_ if nchains > 1 else pc.setup_
+                setup(Pb, rng=np.random.default_rng(7))          # first call allocates the per-chain tables
+                tk = time.perf_counter()
+                setup(Pb, rng=np.random.default_rng(7))
+                t_setup = time.perf_counter() - tk
+                bt = {"kpm_setup_ms_all_chains": 1e3 * t_setup}
+                for label, PP in (("plain", None), ("kpm", Pb)):
+                    X = np.zeros_like(Bc)
+                    models.ldiv_batched_(X, m, Bc, P=PP)
+                    X[:] = 0.0
+                    tq = time.perf_counter()
+                    it, res, fl = models.ldiv_batched_(X, m, Bc, P=PP)
+                    dtq = time.perf_counter() - tq
+                    bt[label] = {"ms_per_batched_solve_incl_pcie": 1e3 * dtq, "solves_per_sec": nrhs / dtq,
+                                 "iters_max": int(it.max()), "iters_mean": float(it.mean()),
+                                 "flags_ok": bool((fl == 0).all()), "max_residual": float(res.max())}
+                ms = C.c_double()
+                for wh, nm in ((2, "kpm_apply_us"), (3, "preconditioned_cg_iter_us")):
+                    check(lib.elph_bench_prepare(m._h, wh, nrhs, None))
+                    check(lib.elph_bench_run(m._h, wh, nrhs, 32, 0, C.byref(ms)))
+                    check(lib.elph_bench_run(m._h, wh, nrhs, 320, 0, C.byref(ms)))
+                    bt[nm] = 1e3 * ms.value / 320
+                out[f"batch_time_to_solution_tol1e-5_nrhs{nrhs}_chains{nchains}"] = bt
+            except Exception as e:
+                out[f"batch_time_to_solution_tol1e-5_nrhs{nrhs}_chains{nchains}"] = {"error": str(e)}
         if nchains > 1:
             models.update_model_(m)          # back to one configuration for the secondary single-matrix measurements
         # ---- secondary: the same step at other batch sizes (short runs)

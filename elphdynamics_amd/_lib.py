@@ -70,6 +70,7 @@ SIGNATURES = {
     "elph_greens_dev_arrays": (c_int, [Handle, C.POINTER(C.c_void_p), P_i64]),
     "elph_kpm_create": (c_int, [Handle, c_int, c_dbl, c_dbl, c_dbl]),
     "elph_kpm_setup": (c_int, [Handle, P_dbl, P_dbl, c_dbl, c_dbl, P_int, P_dbl, P_dbl]),
+    "elph_kpm_setup_chains": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, P_int, P_dbl, P_dbl]),
     "elph_kpm_orders": (c_int, [Handle, P_i64, P_i64]),
     "elph_kpm_apply": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_kpm_apply_dev": (c_int, [Handle, C.c_void_p, C.c_void_p]),

@@ -675,10 +675,11 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb_fast(double2 *__restrict__ nu
     double2 *buf = reinterpret_cast<double2 *>(lds);
     const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && ld_state(state + 2 * rhs).done) return;   // `state` points at the current copy (host adds the parity)
-    const int w = K.wsched[blockIdx.y];
+    const KpmChainView V = kpm_chain_view(K, rhs, m.N);
+    const int w = V.wsched[blockIdx.y];
     const int N = m.N;
-    const int order = K.order[w];
-    const double2 *c = K.coeff + K.coff[w];
+    const int order = V.order[w];
+    const double2 *c = K.coeff + V.coff[w];
     double2 *u = nu + ((size_t)rhs * Lo2 + w) * N;
     unsigned ij[NE];
     double cb[NE], sb[NE];
@@ -691,9 +692,9 @@ __global__ void __launch_bounds__(WAVE) k_kpm_cheb_fast(double2 *__restrict__ nu
         const int s = threadIdx.x + q * WAVE;
         const int sc = (s < N) ? s : N - 1;
         vin[q] = u[sc];
-        eb[q] = K.Ebar[sc];
+        eb[q] = V.Ebar[sc];
     }
-    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+    const double a = V.a, b = V.b;
     kpm_series_fast<NPL, true, true>(mid, vin, buf, eb, c, order, a, b, ij, cb, sb, m.ncol, N);
     kpm_series_fast<NPL, false, false>(res, mid, buf, eb, c, order, a, b, ij, cb, sb, m.ncol, N);
 #pragma unroll
@@ -788,10 +789,11 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_ri(double2 *__restrict__ 
     double *xch = lds + 2 * SL;                   // exchange area [2][NPL*64]
     const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && ld_state(state + 2 * rhs).done) return;   // `state` points at the current copy (host adds the parity)
-    const int w = K.wsched[blockIdx.y];
+    const KpmChainView V = kpm_chain_view(K, rhs, m.N);
+    const int w = V.wsched[blockIdx.y];
     const int N = m.N;
-    const int order = K.order[w];
-    const double2 *c = K.coeff + K.coff[w];
+    const int order = V.order[w];
+    const double2 *c = K.coeff + V.coff[w];
     double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);    // interleaved re,im
     double *pi[NE], *pj[NE];
     double cb[NE], sb[NE];
@@ -809,9 +811,9 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_ri(double2 *__restrict__ 
         const int s = lane + q * WAVE;
         const int sc = (s < N) ? s : N - 1;
         vin[q] = u[2 * sc + wv];
-        eb[q] = K.Ebar[sc];
+        eb[q] = V.Ebar[sc];
     }
-    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+    const double a = V.a, b = V.b;
     // ---- first series: M^-T[w,w], conjugated coefficients (KPMPreconditioners.jl:621-648)
     kpm_series_ri<NPL, true>(P, Q, vin, slab, eb, c, order, a, b, pi, pj, cb, sb, m.ncol);
 #pragma unroll
@@ -934,9 +936,10 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_sq(double2 *__restrict__ 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && ld_state(state + 2 * rhs).done) return;
-    const int w = K.wsched[blockIdx.y];
-    const int order = K.order[w];
-    const double2 *c = K.coeff + K.coff[w];
+    const KpmChainView V = kpm_chain_view(K, rhs, N);
+    const int w = V.wsched[blockIdx.y];
+    const int order = V.order[w];
+    const double2 *c = K.coeff + V.coff[w];
     double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
     const int pa = lane & 7, pb = lane >> 3;
     SqLane<P> T;
@@ -954,14 +957,14 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_sq(double2 *__restrict__ 
         const int dx = q % P, dy = q / P;
         site[q] = (pa * P + dx) + LS * (pb * P + dy);
         vin[q] = u[2 * site[q] + wv];
-        eb[q] = K.Ebar[site[q]];
+        eb[q] = V.Ebar[site[q]];
 #pragma unroll
         for (int col = 0; col < 4; ++col) {
             T.c[col][q] = sqc[(size_t)col * N + site[q]];
             T.s[col][q] = sqs[(size_t)col * N + site[q]];
         }
     }
-    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+    const double a = V.a, b = V.b;
     kpm_series_sq<P, true>(Pa, Qa, vin, eb, c, order, a, b, T);
 #pragma unroll
     for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];

@@ -11,6 +11,9 @@
 #include <algorithm>
 #include <numeric>
 
+#include <atomic>
+#include <thread>
+
 #include "elph_internal.h"
 
 // ------------------------------------------------------------------------------------------
@@ -342,7 +345,7 @@ extern "C" int elph_destroy(elph_handle h) {
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
-                    h->d_coeff, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
+                    h->d_coeff, h->d_klam, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
                     h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -386,7 +389,7 @@ extern "C" int elph_update_model_holstein(elph_handle h, const double *x, const 
     HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_stage_in, x, (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); }
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }   // expansions were per chain
     RC(elph_launch_expV(h, h->d_stage_in, dtau));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_E = true;
@@ -426,7 +429,7 @@ extern "C" int elph_set_expV(elph_handle h, const double *expnDtauV) {
     if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
     if (!expnDtauV) { elph_set_error("null argument"); return ELPH_E_ARG; }
     HIPCHK(hipMemcpyAsync(h->d_stage_in, expnDtauV, (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); }
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }   // expansions were per chain
     RC(elph_launch_r2s(h, h->d_E, h->d_stage_in, 1));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_E = true;
@@ -643,8 +646,11 @@ static int ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, 
             HIPCHK(hipMemcpyAsync(h->d_stage_in, h->d_z, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         }
         int64_t it1 = 0; double rs1 = 0; int fl1 = 0;
-        RC(run_cg(h, 1, 0, h->tol, 10 * maxiter, h->kmax, &it1, nullptr));
-        RC(residual_and_flags(h, 1, &it1, h->maxiter, &rs1, &fl1));
+        if (h->nchains > 1) { h->solo_chain = r % h->nchains; drop_graphs(h); }   // slot 0 must keep rhs r's fermion matrix
+        int rc1 = run_cg(h, 1, 0, h->tol, 10 * maxiter, h->kmax, &it1, nullptr);
+        if (rc1 == ELPH_OK) rc1 = residual_and_flags(h, 1, &it1, h->maxiter, &rs1, &fl1);
+        if (h->solo_chain >= 0) { h->solo_chain = -1; drop_graphs(h); }
+        RC(rc1);
         iters[r] = it1; resid[r] = rs1; flag[r] = fl1;
         if (r != 0) {
             HIPCHK(hipMemcpyAsync(h->d_x + r * nd, h->d_x, nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -820,7 +826,7 @@ extern "C" int elph_fermion_force_holstein(elph_handle h, const double *x, const
     if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
     if (!x || !lambda || !lambda2 || !mu || !phi_plus || !phi_minus || !dSfdx || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
     RC(ensure_capacity(h, 2));
-    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); }
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }   // expansions were per chain
     const size_t nd = (size_t)h->ndim, N = (size_t)h->N, bytes = nd * sizeof(double);
     // update_model! (HolsteinModels.jl:526-549) and x in layout S
     HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -921,44 +927,89 @@ extern "C" int elph_kpm_create(elph_handle h, int n, double buf, double c1, doub
     CHECK_H(h);
     if (n < 1 || !(buf >= 0.0)) { elph_set_error("bad KPM parameters"); return ELPH_E_ARG; }
     h->kpm_n = n; h->kpm_buf = buf; h->kpm_c1 = c1; h->kpm_c2 = c2;
-    // KPMExpansion ctor, KPMPreconditioners.jl:101-146
+    // KPMExpansion ctor, KPMPreconditioners.jl:101-146: λ_lo = 0, λ_hi = 2, order 1 everywhere (one per chain, made on demand)
     h->lam_lo = 0.0; h->lam_hi = 2.0; h->lam_avg = 1.0; h->lam_mag = 1.0;
-    const int Lo2 = (int)((h->L + 1) / 2);
-    h->h_order.assign(Lo2, 1);
-    h->h_coff.resize(Lo2 + 1);
-    std::iota(h->h_coff.begin(), h->h_coff.end(), 0);
-    h->h_coeff.assign(2 * (size_t)Lo2, 0.0);
-    h->h_wsched.resize(Lo2);
-    std::iota(h->h_wsched.begin(), h->h_wsched.end(), 0);
-    h->h_Ebar.assign((size_t)h->N, 0.0);
+    h->kpm_chain.clear();
+    h->kpm_nch = 1;
     h->h_cbar.assign((size_t)h->nb, 0.0);
     h->h_sbar.assign((size_t)h->nb, 0.0);
-    RC(dev_alloc(&h->d_Ebar, (size_t)h->N));
     RC(dev_alloc(&h->d_cbar, (size_t)h->nb));
     RC(dev_alloc(&h->d_sbar, (size_t)h->nb));
-    RC(dev_alloc(&h->d_order, (size_t)Lo2));
-    RC(dev_alloc(&h->d_coff, (size_t)Lo2 + 1));
-    RC(dev_alloc(&h->d_wsched, (size_t)Lo2));
+    h->kpm_tab_cap = 0;
     h->kpm_created = true;
     h->kpm_ready = false;
     h->kpm_active = 1;
     return ELPH_OK;
 }
 
-static int kpm_upload(elph_handle_s *h) {
+// (re)size the per-chain host state and the device tables for nch chains
+static int kpm_reserve(elph_handle_s *h, int nch) {
     const int Lo2 = (int)((h->L + 1) / 2);
-    const size_t ntot = (size_t)h->h_coff[Lo2];
+    if ((int)h->kpm_chain.size() != nch) {
+        // a different number of configurations: every expansion starts from the constructor state again
+        h->kpm_chain.assign((size_t)nch, elph_handle_s::KpmChainHost());
+        for (auto &c : h->kpm_chain) { c.order.assign(Lo2, 1); c.coeff.assign(2 * (size_t)Lo2, 0.0); for (int w = 0; w < Lo2; ++w) c.coeff[2 * w] = 1.0; }
+    }
+    h->kpm_nch = nch;
+    h->h_Ebar.resize((size_t)nch * h->N);
+    if (nch > h->kpm_tab_cap) {
+        RC(dev_alloc(&h->d_Ebar, (size_t)nch * h->N));
+        RC(dev_alloc(&h->d_order, (size_t)nch * Lo2));
+        RC(dev_alloc(&h->d_coff, (size_t)nch * (Lo2 + 1)));
+        RC(dev_alloc(&h->d_wsched, (size_t)nch * Lo2));
+        RC(dev_alloc(&h->d_klam, (size_t)nch * 2));
+        h->kpm_tab_cap = nch;
+    }
+    return ELPH_OK;
+}
+
+// flatten the per-chain expansions into the device tables.  A chain whose expansion is inactive (while others are
+// active) gets the identity expansion: order 1, c₀ = 1 — ldiv! copies for it (KPMPreconditioners.jl:475-478).
+static int kpm_upload(elph_handle_s *h) {
+    const int Lo2 = (int)((h->L + 1) / 2), nch = h->kpm_nch;
+    h->h_order.assign((size_t)nch * Lo2, 1);
+    h->h_coff.assign((size_t)nch * (Lo2 + 1), 0);
+    h->h_wsched.assign((size_t)nch * Lo2, 0);
+    h->h_lam.assign((size_t)nch * 2, 1.0);
+    h->h_coeff.clear();
+    int off = 0;
+    for (int c = 0; c < nch; ++c) {
+        const auto &C = h->kpm_chain[(size_t)c];
+        int *ord = h->h_order.data() + (size_t)c * Lo2, *cof = h->h_coff.data() + (size_t)c * (Lo2 + 1);
+        int *ws = h->h_wsched.data() + (size_t)c * Lo2;
+        int loc = 0;
+        for (int w = 0; w < Lo2; ++w) {
+            const int o = C.active ? C.order[w] : 1;
+            ord[w] = o;
+            cof[w] = off;
+            if (C.active) {
+                h->h_coeff.insert(h->h_coeff.end(), C.coeff.begin() + 2 * (size_t)loc, C.coeff.begin() + 2 * (size_t)(loc + o));
+                loc += o;
+            } else {
+                h->h_coeff.push_back(1.0); h->h_coeff.push_back(0.0);
+                loc += C.order[w];
+            }
+            off += o;
+        }
+        cof[Lo2] = off;
+        // schedule: frequency blocks by decreasing order (the low frequencies carry the long recursions)
+        std::iota(ws, ws + Lo2, 0);
+        std::stable_sort(ws, ws + Lo2, [&](int a, int b) { return ord[a] > ord[b]; });
+        h->h_lam[2 * c] = (C.lam_hi + C.lam_lo) / 2;
+        h->h_lam[2 * c + 1] = (C.lam_hi - C.lam_lo) / 2;
+    }
+    const size_t ntot = (size_t)off;
     if ((int64_t)ntot > h->coeff_cap) {
         RC(dev_alloc(&h->d_coeff, ntot));
         h->coeff_cap = (int64_t)ntot;
     }
     HIPCHK(hipMemcpy(h->d_coeff, h->h_coeff.data(), ntot * sizeof(double2), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_order, h->h_order.data(), sizeof(int) * Lo2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_coff, h->h_coff.data(), sizeof(int) * (Lo2 + 1), hipMemcpyHostToDevice));
-    // schedule: frequency blocks by decreasing order (the low frequencies carry the long recursions)
-    std::iota(h->h_wsched.begin(), h->h_wsched.end(), 0);
-    std::stable_sort(h->h_wsched.begin(), h->h_wsched.end(), [&](int a, int b) { return h->h_order[a] > h->h_order[b]; });
-    HIPCHK(hipMemcpy(h->d_wsched, h->h_wsched.data(), sizeof(int) * Lo2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_order, h->h_order.data(), sizeof(int) * h->h_order.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_coff, h->h_coff.data(), sizeof(int) * h->h_coff.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_wsched, h->h_wsched.data(), sizeof(int) * h->h_wsched.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_klam, h->h_lam.data(), sizeof(double) * h->h_lam.size(), hipMemcpyHostToDevice));
+    h->lam_lo = h->kpm_chain[0].lam_lo; h->lam_hi = h->kpm_chain[0].lam_hi;
+    h->lam_avg = h->h_lam[0]; h->lam_mag = h->h_lam[1];
     return ELPH_OK;
 }
 
@@ -966,18 +1017,19 @@ static bool jl_isapprox(double x, double y, double rtol) {
     return x == y || (std::isfinite(x) && std::isfinite(y) && fabs(x - y) <= rtol * std::max(fabs(x), fabs(y)));
 }
 
-extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *b_min, double e_min, double e_max,
-                              int *active, double *lam_lo, double *lam_hi) {
-    CHECK_H(h);
+// setup!(P) for every chain resident in the handle (h->nchains of them).  All arrays are per chain.
+static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b_min, const double *e_min_in,
+                          const double *e_max_in, int *active, double *lam_lo, double *lam_hi) {
     if (!h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     RC(need_model(h));
-    if (h->nchains != 1) { elph_set_error("the KPM preconditioner is built for one phonon configuration; nchains = %d", h->nchains); return ELPH_E_UNSUPPORTED; }
     HIPCHK(hipStreamSynchronize(h->stream));
-    const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+    const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2, nch = h->nchains;
+    const bool resized = ((int)h->kpm_chain.size() != nch);
+    RC(kpm_reserve(h, nch));
     // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)
     if (h->kind == ELPH_MODEL_HOLSTEIN) {
-        RC(elph_launch_ebar(h));
-        HIPCHK(hipMemcpyAsync(h->h_Ebar.data(), h->d_Ebar, sizeof(double) * N, hipMemcpyDeviceToHost, h->stream));
+        for (int c = 0; c < nch; ++c) RC(elph_launch_ebar(h, c));
+        HIPCHK(hipMemcpyAsync(h->h_Ebar.data(), h->d_Ebar, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->h_cbar = h->h_c;
         h->h_sbar = h->h_s;
@@ -1008,47 +1060,90 @@ extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *
         HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sq_sbar, qs.data(), sizeof(double) * qs.size(), hipMemcpyHostToDevice));
     }
-    // eigenvalue bounds (:272-273) — injected or Arnoldi with caller-supplied start vectors
-    if (!(std::isfinite(e_min) && std::isfinite(e_max))) {
-        if (!b_max || !b_min) { elph_set_error("Arnoldi start vectors required when bounds are not injected"); return ELPH_E_ARG; }
-        RC(elph_kpm_arnoldi(h, b_max, b_min, &e_min, &e_max));
-    }
     const int was_active = h->kpm_active;
-    bool changed = !h->kpm_ready;
-    if ((0.0 < e_min && e_min < 1.0) && (1.0 < e_max) && (e_max - e_min) < 2.0) {       // :280
-        const double lo = std::max(0.0, (1 - 2 * h->kpm_buf) * e_min), hi = (1 + 2 * h->kpm_buf) * e_max;
-        if (!jl_isapprox(lo, h->lam_lo, h->kpm_buf) || !jl_isapprox(hi, h->lam_hi, h->kpm_buf)) {   // :288
-            h->lam_lo = lo; h->lam_hi = hi;
-            h->lam_avg = (hi + lo) / 2; h->lam_mag = (hi - lo) / 2;
-            int off = 0;
-            std::vector<double> coeff;
-            for (int w = 0; w < Lo2; ++w) {
-                const double phi = 2.0 * M_PI / (double)L * (w + 0.5);                   // ctor :117
-                int order = (int)floor((hi - lo) * (h->kpm_c1 / phi + h->kpm_c2));       // :300
-                order = std::max(1, order);
-                h->h_order[w] = order;
-                h->h_coff[w] = off;
-                coeff.resize(2 * (size_t)(off + order));
-                elph_kpm_coefficients(coeff.data() + 2 * (size_t)off, order, lo, hi, phi);
-                off += order;
+    bool changed = !h->kpm_ready || resized;
+    if (!(b_max && b_min))
+        for (int c = 0; c < nch; ++c)
+            if (!(e_min_in && e_max_in && std::isfinite(e_min_in[c]) && std::isfinite(e_max_in[c]))) {
+                elph_set_error("Arnoldi start vectors required when bounds are not injected");
+                return ELPH_E_ARG;
             }
-            h->h_coff[Lo2] = off;
-            h->h_coeff.swap(coeff);
-            changed = true;
+    // per chain, independent host work (no HIP calls): Arnoldi bounds, and new orders + coefficients when the bounds
+    // moved by more than buf — spread over host threads when there are several chains
+    std::vector<char> moved((size_t)nch, 0);
+    std::vector<int> was((size_t)nch, 0);
+    auto one_chain = [&](int c) {
+        auto &C = h->kpm_chain[(size_t)c];
+        was[(size_t)c] = C.active;
+        // eigenvalue bounds (:272-273) — injected or Arnoldi with caller-supplied start vectors
+        double e_min = e_min_in ? e_min_in[c] : NAN, e_max = e_max_in ? e_max_in[c] : NAN;
+        if (!(std::isfinite(e_min) && std::isfinite(e_max)))
+            (void)elph_kpm_arnoldi(h, c, b_max + (size_t)c * N, b_min + (size_t)c * N, &e_min, &e_max);
+        if ((0.0 < e_min && e_min < 1.0) && (1.0 < e_max) && (e_max - e_min) < 2.0) {       // :280
+            const double lo = std::max(0.0, (1 - 2 * h->kpm_buf) * e_min), hi = (1 + 2 * h->kpm_buf) * e_max;
+            if (!jl_isapprox(lo, C.lam_lo, h->kpm_buf) || !jl_isapprox(hi, C.lam_hi, h->kpm_buf)) {   // :288
+                C.lam_lo = lo; C.lam_hi = hi;
+                int off = 0;
+                std::vector<double> coeff;
+                for (int w = 0; w < Lo2; ++w) {
+                    const double phi = 2.0 * M_PI / (double)L * (w + 0.5);                   // ctor :117
+                    int order = (int)floor((hi - lo) * (h->kpm_c1 / phi + h->kpm_c2));       // :300
+                    order = std::max(1, order);
+                    C.order[w] = order;
+                    coeff.resize(2 * (size_t)(off + order));
+                    elph_kpm_coefficients(coeff.data() + 2 * (size_t)off, order, lo, hi, phi);
+                    off += order;
+                }
+                C.coeff.swap(coeff);
+                moved[(size_t)c] = 1;
+            }
+            C.active = 1;
+        } else {
+            C.active = 0;                                                                    // :312-318
         }
-        h->kpm_active = 1;
-    } else {
-        h->kpm_active = 0;                                                               // :312-318
+    };
+    {
+        const int nthr = std::max(1, std::min(nch, std::min(32, (int)std::thread::hardware_concurrency())));
+        if (nthr <= 1) {
+            for (int c = 0; c < nch; ++c) one_chain(c);
+        } else {
+            std::vector<std::thread> pool;
+            std::atomic<int> next(0);
+            for (int t = 0; t < nthr; ++t)
+                pool.emplace_back([&]() { for (int c; (c = next.fetch_add(1)) < nch;) one_chain(c); });
+            for (auto &th : pool) th.join();
+        }
     }
+    int any_active = 0;
+    for (int c = 0; c < nch; ++c) {
+        auto &C = h->kpm_chain[(size_t)c];
+        if (moved[(size_t)c] || was[(size_t)c] != C.active || C.fresh) changed = true;
+        C.fresh = false;
+        any_active |= C.active;
+        if (active) active[c] = C.active;
+        if (lam_lo) lam_lo[c] = C.lam_lo;
+        if (lam_hi) lam_hi[c] = C.lam_hi;
+    }
+    h->kpm_active = any_active;
     if (changed || was_active != h->kpm_active) {
         RC(kpm_upload(h));
         drop_graphs(h);   // KpmDev (lam_avg, lam_mag, active) is baked into captured kernel arguments
     }
     h->kpm_ready = true;
-    if (active) *active = h->kpm_active;
-    if (lam_lo) *lam_lo = h->lam_lo;
-    if (lam_hi) *lam_hi = h->lam_hi;
     return ELPH_OK;
+}
+
+extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *b_min, double e_min, double e_max,
+                              int *active, double *lam_lo, double *lam_hi) {
+    CHECK_H(h);
+    if (h->nchains != 1) { elph_set_error("%d phonon configurations are resident: use elph_kpm_setup_chains", h->nchains); return ELPH_E_STATE; }
+    return kpm_setup_core(h, b_max, b_min, &e_min, &e_max, active, lam_lo, lam_hi);
+}
+
+extern "C" int elph_kpm_setup_chains(elph_handle h, const double *b_max, const double *b_min, const double *e_min,
+                                     const double *e_max, int *active, double *lam_lo, double *lam_hi) {
+    CHECK_H(h);
+    return kpm_setup_core(h, b_max, b_min, e_min, e_max, active, lam_lo, lam_hi);
 }
 
 extern "C" int elph_kpm_orders(elph_handle h, int64_t *orders, int64_t *total) {
@@ -1057,8 +1152,9 @@ extern "C" int elph_kpm_orders(elph_handle h, int64_t *orders, int64_t *total) {
     const int Lo2 = (int)((h->L + 1) / 2);
     int64_t tot = 0;
     for (int w = 0; w < Lo2; ++w) {
-        if (orders) orders[w] = h->h_order[w];
-        tot += h->h_order[w];
+        const int o = h->kpm_chain.empty() ? 1 : h->kpm_chain[0].order[w];
+        if (orders) orders[w] = o;
+        tot += o;
     }
     if (total) *total = tot;
     return ELPH_OK;

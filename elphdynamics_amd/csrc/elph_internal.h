@@ -99,17 +99,46 @@ struct CgState {
 struct KpmDev {
     int active;
     int Lo2;
-    double lam_avg, lam_mag;
-    const double *Ebar;       // [N]
+    int nchains;              // one expansion per phonon configuration (chain); right-hand side r uses chain r % nchains
+    double lam_avg, lam_mag;  // chain 0 by value (the single-chain kernels never wait for a load of them)
+    const double *lam;        // [nchains][2] lam_avg, lam_mag
+    const double *Ebar;       // [nchains][N]
     const double *cbar;       // [nb]
     const double *sbar;       // [nb]
-    const int *order;         // [Lo2]
-    const int *coff;          // [Lo2+1]
-    const double2 *coeff;     // [sum order]
-    const int *wsched;        // [Lo2] omega indices sorted by decreasing order (longest first)
+    const int *order;         // [nchains][Lo2]
+    const int *coff;          // [nchains][Lo2+1] offsets into coeff (absolute: a chain's base is included)
+    const double2 *coeff;     // [sum over chains of sum order]
+    const int *wsched;        // [nchains][Lo2] omega indices sorted by decreasing order (longest first)
     const double *lp_cbar;    // lane-program copies of cbar/sbar [NE][64]
     const double *lp_sbar;
 };
+
+// One chain's view of the expansion (device side).
+struct KpmChainView {
+    const int *order, *coff, *wsched;
+    const double *Ebar;
+    double a, b;              // 1/lam_mag, lam_avg/lam_mag
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ KpmChainView kpm_chain_view(const KpmDev &K, int rhs, int N) {
+    KpmChainView V;
+    if (K.nchains > 1) {
+        const int c = rhs % K.nchains;
+        V.order = K.order + (size_t)c * K.Lo2;
+        V.coff = K.coff + (size_t)c * (K.Lo2 + 1);
+        V.wsched = K.wsched + (size_t)c * K.Lo2;
+        V.Ebar = K.Ebar + (size_t)c * N;
+        const double avg = K.lam[2 * c], mag = K.lam[2 * c + 1];
+        V.a = 1.0 / mag;
+        V.b = avg / mag;
+    } else {
+        V.order = K.order; V.coff = K.coff; V.wsched = K.wsched; V.Ebar = K.Ebar;
+        V.a = 1.0 / K.lam_mag;
+        V.b = K.lam_avg / K.lam_mag;
+    }
+    return V;
+}
+#endif
 
 struct elph_handle_s {
     int kind = 0, device = 0;
@@ -127,6 +156,7 @@ struct elph_handle_s {
     bool have_E = false;
     int nchains = 1;                       // Holstein: independent chains sharing one handle / one batch
     int64_t E_cap = 0;                     // doubles allocated for d_E
+    int solo_chain = -1;                   // >= 0: kernels see only this chain (single re-solve of one RHS of a chains batch)
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
     // lane program (fast path, ncol <= 4)
     bool fast = false;
@@ -179,10 +209,17 @@ struct elph_handle_s {
     int kpm_n = 20;
     double kpm_buf = 0.05, kpm_c1 = 1.0, kpm_c2 = 1.0;
     double lam_lo = 0.0, lam_hi = 2.0, lam_avg = 1.0, lam_mag = 1.0;
-    int kpm_active = 1;
-    std::vector<double> h_Ebar, h_cbar, h_sbar;
-    std::vector<int> h_order, h_coff, h_wsched;
-    std::vector<double> h_coeff;           // complex interleaved
+    int kpm_active = 1;                    // 0: every chain's expansion is inactive (identity copy path)
+    int kpm_nch = 1;                       // chains the expansion tables are built for
+    struct KpmChainHost { double lam_lo = 0.0, lam_hi = 2.0; int active = 1; bool fresh = true;
+                          std::vector<int> order; std::vector<double> coeff; };
+    std::vector<KpmChainHost> kpm_chain;   // per chain: bounds, orders, coefficients (complex interleaved)
+    std::vector<double> h_Ebar, h_cbar, h_sbar;   // h_Ebar: [kpm_nch][N]
+    std::vector<int> h_order, h_coff, h_wsched;   // flattened [kpm_nch][...] images of the device tables
+    std::vector<double> h_coeff;           // complex interleaved, all chains
+    std::vector<double> h_lam;             // [kpm_nch][2]
+    double *d_klam = nullptr;
+    int64_t kpm_tab_cap = 0;               // chains the device tables are allocated for
     double *d_Ebar = nullptr, *d_cbar = nullptr, *d_sbar = nullptr;
     int *d_order = nullptr, *d_coff = nullptr, *d_wsched = nullptr;
     double2 *d_coeff = nullptr;
@@ -223,7 +260,7 @@ int elph_launch_residual(elph_handle_s *h, int nrhs);
 int elph_launch_cg_init_only(elph_handle_s *h, int nrhs);
 int elph_launch_cg_state0_only(elph_handle_s *h, int nrhs);
 int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode);
-int elph_launch_ebar(elph_handle_s *h);
+int elph_launch_ebar(elph_handle_s *h, int chain = 0);
 int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int64_t ncol);
 int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);
 int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS);
@@ -262,6 +299,6 @@ int elph_dft_mfma_inv(elph_handle_s *h, int which, double *outS, const double2 *
 
 // ---- host-side KPM setup (kpm_host.cpp) ---------------------------------------------------
 void elph_kpm_coefficients(double *c_z, int order, double lam_lo, double lam_hi, double phi);
-int elph_kpm_arnoldi(const elph_handle_s *h, const double *b_max, const double *b_min, double *e_min,
+int elph_kpm_arnoldi(const elph_handle_s *h, int chain, const double *b_max, const double *b_min, double *e_min,
                      double *e_max);
 int elph_hess_eigvals(std::vector<double> &a, int n, std::vector<double> &wr, std::vector<double> &wi);

@@ -541,8 +541,7 @@ __device__ __forceinline__ void kpm_mulAprime(double2 (&out)[NPL], const double2
 template <int NPL, bool TRANSPOSED, bool CONJ>
 __device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&vin)[NPL], double2 *buf,
                                            const double (&eb)[NPL], const double2 *c, int order, const KpmDev &K,
-                                           const ModelDev &m) {
-    const double a = 1.0 / K.lam_mag, b = K.lam_avg / K.lam_mag;
+                                           const ModelDev &m, double a, double b) {
     double2 um1[NPL], un[NPL], up1[NPL];
     {
         double2 c0 = c[0];
@@ -584,10 +583,11 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
     double2 *buf = reinterpret_cast<double2 *>(lds);
     const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && state[2 * rhs].done) return;   // `state` points at the current copy
-    const int w = K.wsched[blockIdx.y];
+    const KpmChainView V = kpm_chain_view(K, rhs, m.N);
+    const int w = V.wsched[blockIdx.y];
     const int N = m.N;
-    const int order = K.order[w];
-    const double2 *c = K.coeff + K.coff[w];
+    const int order = V.order[w];
+    const double2 *c = K.coeff + V.coff[w];
     double2 *u = nu + ((size_t)rhs * Lo2 + w) * N;
     double2 vin[NPL], mid[NPL], res[NPL];
     double eb[NPL];
@@ -595,10 +595,10 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * blockDim.x;
         vin[q] = (s < N) ? u[s] : make_double2(0.0, 0.0);
-        eb[q] = (s < N) ? K.Ebar[s] : 0.0;
+        eb[q] = (s < N) ? V.Ebar[s] : 0.0;
     }
-    kpm_series<NPL, true, true>(mid, vin, buf, eb, c, order, K, m);     // M^-T[w,w], conj coefficients (:621-648)
-    kpm_series<NPL, false, false>(res, mid, buf, eb, c, order, K, m);   // M^-1[w,w]                     (:650-677)
+    kpm_series<NPL, true, true>(mid, vin, buf, eb, c, order, K, m, V.a, V.b);     // M^-T[w,w], conj coefficients (:621-648)
+    kpm_series<NPL, false, false>(res, mid, buf, eb, c, order, K, m, V.a, V.b);   // M^-1[w,w]                     (:650-677)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * blockDim.x;
@@ -808,6 +808,10 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.E_chain_stride = (long long)h->ndim;
     m.bi = h->d_bi; m.bj = h->d_bj; m.coloff = h->d_coloff;
     m.c = h->d_c; m.s = h->d_s; m.E = h->d_E;
+    if (h->solo_chain >= 0) {   // one right-hand side of a chains batch re-solved alone: present ITS configuration as the only one
+        m.nchains = 1;
+        m.E = h->d_E + (size_t)h->solo_chain * (size_t)h->ndim;
+    }
     m.lp_ij = h->d_lp_ij; m.lp_c = h->d_lp_c; m.lp_s = h->d_lp_s;
     m.lp_tau_stride = (h->kind == ELPH_MODEL_SSH) ? h->lp_ne * ELPH_WAVE : 0;
     return m;
@@ -818,9 +822,17 @@ KpmDev elph_kpm_dev(const elph_handle_s *h) {
     K.active = h->kpm_active;
     K.Lo2 = (int)((h->L + 1) / 2);
     K.lam_avg = h->lam_avg; K.lam_mag = h->lam_mag;
+    K.nchains = h->kpm_nch; K.lam = h->d_klam;
     K.Ebar = h->d_Ebar; K.cbar = h->d_cbar; K.sbar = h->d_sbar;
     K.order = h->d_order; K.coff = h->d_coff; K.coeff = h->d_coeff; K.wsched = h->d_wsched;
     K.lp_cbar = h->d_lp_cbar; K.lp_sbar = h->d_lp_sbar;
+    if (h->solo_chain >= 0 && h->kpm_nch > 1) {
+        const int c = h->solo_chain;
+        K.nchains = 1;
+        K.lam_avg = h->h_lam[2 * c]; K.lam_mag = h->h_lam[2 * c + 1];
+        K.Ebar += (size_t)c * h->N;
+        K.order += (size_t)c * K.Lo2; K.coff += (size_t)c * (K.Lo2 + 1); K.wsched += (size_t)c * K.Lo2;
+    }
     return K;
 }
 
@@ -900,9 +912,9 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     return B;
 }
 
-int elph_launch_ebar(elph_handle_s *h) {
-    hipLaunchKernelGGL(k_ebar, dim3((unsigned)((h->N + 63) / 64)), dim3(256), 0, h->stream, h->d_Ebar, h->d_E,
-                       (int)h->N, (int)h->L);
+int elph_launch_ebar(elph_handle_s *h, int chain) {
+    hipLaunchKernelGGL(k_ebar, dim3((unsigned)((h->N + 63) / 64)), dim3(256), 0, h->stream, h->d_Ebar + (size_t)chain * h->N,
+                       h->d_E + (size_t)chain * h->ndim, (int)h->N, (int)h->L);
     return check_launch("k_ebar");
 }
 

@@ -35,19 +35,19 @@ void cb_inv_mul(std::vector<double> &y, const elph_handle_s *h) {
     }
 }
 
-void apply_A(std::vector<double> &out, const std::vector<double> &in, const elph_handle_s *h, bool inverse) {
+void apply_A(std::vector<double> &out, const std::vector<double> &in, const elph_handle_s *h, const double *Ebar, bool inverse) {
     const int64_t N = h->N;
     if (!inverse) {  // A v = CBbar (Ebar .* v), :387-401
-        for (int64_t i = 0; i < N; ++i) out[i] = h->h_Ebar[i] * in[i];
+        for (int64_t i = 0; i < N; ++i) out[i] = Ebar[i] * in[i];
         cb_mul(out, h);
     } else {         // A^-1 v = (CBbar^-1 v) ./ Ebar, :406-420
         out = in;
         cb_inv_mul(out, h);
-        for (int64_t i = 0; i < N; ++i) out[i] /= h->h_Ebar[i];
+        for (int64_t i = 0; i < N; ++i) out[i] /= Ebar[i];
     }
 }
 
-double max_ritz(const elph_handle_s *h, int n, const double *b0, bool inverse) {
+double max_ritz(const elph_handle_s *h, const double *Ebar, int n, const double *b0, bool inverse) {
     const int64_t m = h->N;
     std::vector<double> Q((size_t)m * (n + 1), 0.0), H((size_t)(n + 1) * n, 0.0), b(m), v(m);
     double nrm = 0.0;
@@ -56,7 +56,7 @@ double max_ritz(const elph_handle_s *h, int n, const double *b0, bool inverse) {
     for (int64_t i = 0; i < m; ++i) { b[i] = b0[i] / nrm; Q[i] = b[i]; }
     int l = n;
     for (int k = 0; k < n; ++k) {
-        apply_A(v, b, h, inverse);
+        apply_A(v, b, h, Ebar, inverse);
         for (int j = 0; j <= k; ++j) {
             const double *Qj = &Q[(size_t)j * m];
             double d = 0.0;
@@ -194,12 +194,14 @@ int elph_hess_eigvals(std::vector<double> &a, int n, std::vector<double> &wr, st
 }
 
 // KPMPreconditioners.jl:845-942 with the random start vectors supplied by the caller.
-int elph_kpm_arnoldi(const elph_handle_s *h, const double *b_max, const double *b_min, double *e_min, double *e_max) {
+// `chain` selects the configuration's Ē in h->h_Ebar; re-entrant (chains are set up on parallel host threads).
+int elph_kpm_arnoldi(const elph_handle_s *h, int chain, const double *b_max, const double *b_min, double *e_min, double *e_max) {
+    const double *Ebar = h->h_Ebar.data() + (size_t)chain * (size_t)h->N;
     int n = h->kpm_n;
     if (n > h->N) n = (int)h->N;   // :136
     if (n < 1) n = 1;
-    const double emax = max_ritz(h, n, b_max, false);
-    const double r = max_ritz(h, n, b_min, true);
+    const double emax = max_ritz(h, Ebar, n, b_max, false);
+    const double r = max_ritz(h, Ebar, n, b_min, true);
     *e_max = emax;
     *e_min = std::isfinite(r) ? 1.0 / r : -INFINITY;
     return 0;

@@ -216,6 +216,7 @@ class SSHModel(AbstractModel):
 
 def update_model_(model):
     """HolsteinModels.jl:526-549 (exp on the GPU) / SSHModels.jl:510-562 (cosh/sinh gather on the host, upload)."""
+    model._nchains = 1
     if model.kind == HOLSTEIN:
         check(model._lib.elph_update_model_holstein(model._h, dptr(np.ascontiguousarray(model.x)), dptr(model.lam),
                                                     dptr(model.lam2), dptr(model.mu), model.dtau))
@@ -241,6 +242,7 @@ def update_model_chains_(model, X):
     assert X.ndim == 2 and X.shape[1] == model.Ndof
     check(model._lib.elph_update_model_holstein_chains(model._h, X.shape[0], dptr(X), dptr(model.lam), dptr(model.lam2),
                                                        dptr(model.mu), model.dtau))
+    model._nchains = X.shape[0]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -56,6 +56,30 @@ def setup_(P, rng=None, e_min=None, e_max=None, b_max=None, b_min=None):
     P.active, P.lam_lo, P.lam_hi = bool(act.value), lo.value, hi.value
 
 
+def setup_chains_(P, rng=None, e_min=None, e_max=None, b_max=None, b_min=None):
+    """setup!(P) for every chain resident after models.update_model_chains_: one expansion per phonon configuration
+    (the reference runs chains as separate processes, each with its own preconditioner).  Arrays are per chain:
+    b_max/b_min (nchains, Nsites), e_min/e_max (nchains,).  Returns (active, lam_lo, lam_hi) arrays."""
+    m = P.model
+    nch = int(m._nchains)
+    N = m.Nsites
+    if e_min is None or e_max is None:
+        e_min = e_max = None
+        if b_max is None:
+            rng = rng or np.random.default_rng()
+            b_max, b_min = rng.standard_normal((nch, N)), rng.standard_normal((nch, N))
+    else:
+        e_min = np.ascontiguousarray(np.broadcast_to(np.asarray(e_min, dtype=np.float64), (nch,)))
+        e_max = np.ascontiguousarray(np.broadcast_to(np.asarray(e_max, dtype=np.float64), (nch,)))
+    act = np.zeros(nch, dtype=np.int32)
+    lo, hi = np.zeros(nch), np.zeros(nch)
+    arr = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64)) if a is not None else None
+    check(m._lib.elph_kpm_setup_chains(m._h, arr(b_max), arr(b_min), arr(e_min), arr(e_max),
+                                       act.ctypes.data_as(C.POINTER(C.c_int)), dptr(lo), dptr(hi)))
+    P.active, P.lam_lo, P.lam_hi = bool(act.any()), float(lo[0]), float(hi[0])
+    return act, lo, hi
+
+
 def kpm_ldiv_(z, P, r):
     """ldiv!(z, P, r): z = P^-1 r; plain copy for the identity (IterativeSolvers.jl:14-17)."""
     if P is None:

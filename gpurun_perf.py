@@ -1,25 +1,24 @@
 import sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, '.')
-from elphdynamics_amd import configs, models
-from elphdynamics_amd._lib import check
-tag = sys.argv[1] if len(sys.argv) > 1 else "C"
-m = configs.make_model(tag, tol=1e-5)
-lib = m._lib
-for nrhs in (1, 2, 4, 16, 64):
-    R, B = configs.rhs(m, nrhs)
-    X = np.zeros_like(B)
-    t0 = time.time(); it, res, fl = models.ldiv_batched_(X, m, B); t1 = time.time()
-    X[:] = 0
-    t0 = time.time(); it, res, fl = models.ldiv_batched_(X, m, B); t1 = time.time()
-    ms = C.c_double()
-    out = {}
-    for what, name, g in ((0, "MtM", 0), (1, "cg_iter", 0), (1, "cg_iter_graph", 1), (4, "ap", 0), (5, "xr", 0)):
-        check(lib.elph_bench_prepare(m._h, what, nrhs, None))
-        check(lib.elph_bench_run(m._h, what, nrhs, 160, g, C.byref(ms)))
-        check(lib.elph_bench_run(m._h, what, nrhs, 800, g, C.byref(ms)))
-        out[name] = ms.value * 1e3 / 800
-    ndim = m.Ndim
-    print(f"{tag} nrhs={nrhs:3d} ldiv wall {1e3*(t1-t0):8.2f} ms iters={it.max()} ({1e6*(t1-t0)/it.max():.1f} us/iter)  "
-          f"MtM {out['MtM']:.2f} us  ap {out['ap']:.2f} xr {out['xr']:.2f}  cg_iter eager {out['cg_iter']:.2f} graph {out['cg_iter_graph']:.2f} us  -> {2*nrhs/out['cg_iter_graph']:.3f} M matvec/s, "
-          f"alg BW {120*ndim*nrhs/out['cg_iter_graph']/1e6:.3f} TB/s")
+from elphdynamics_amd import configs, models, preconditioners as pc, synth
+m = configs.make_model("C", tol=1e-5)
+nch = 32
+Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=100 + 17 * c) for c in range(nch)])
+t0 = time.perf_counter(); models.update_model_chains_(m, Xc); t1 = time.perf_counter()
+print("update_model_chains %.2f ms" % (1e3 * (t1 - t0)))
+P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+rng = np.random.default_rng(1)
+bmax, bmin = rng.standard_normal((nch, m.Nsites)), rng.standard_normal((nch, m.Nsites))
+for i in range(4):
+    t0 = time.perf_counter(); act, lo, hi = pc.setup_chains_(P, b_max=bmax, b_min=bmin); t1 = time.perf_counter()
+    print("setup_chains call %d: %.3f ms  (active %d)" % (i, 1e3 * (t1 - t0), act.sum()))
+# perturb fields slightly (as in HMC): bounds move < 5% -> no coefficient recompute
+models.update_model_chains_(m, Xc * 1.001)
+t0 = time.perf_counter(); act, lo, hi = pc.setup_chains_(P, b_max=bmax, b_min=bmin); t1 = time.perf_counter()
+print("setup_chains after small move: %.3f ms" % (1e3 * (t1 - t0)))
+models.update_model_(m)
+P1 = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+for i in range(3):
+    t0 = time.perf_counter(); pc.setup_(P1, b_max=bmax[0], b_min=bmin[0]); t1 = time.perf_counter()
+    print("single setup call %d: %.3f ms" % (i, 1e3 * (t1 - t0)))

@@ -272,7 +272,15 @@ int elph_kpm_create(elph_handle h, int n, double buf, double c1, double c2);
 int elph_kpm_setup(elph_handle h, const double *b_max, const double *b_min, double e_min,
                    double e_max, int *active, double *lam_lo, double *lam_hi);
 
-/* Inspect the expansion: orders[cld(ltau,2)], total = sum(orders) (either pointer may be NULL). */
+/* The same for every phonon configuration resident after elph_update_model_holstein_chains (nchains of them): one
+ * expansion per chain — its own Ē, eigenvalue bounds, orders and coefficients; in a batched solve right-hand side r is
+ * preconditioned with the expansion of chain r % nchains.  b_max, b_min: double[nchains * nsites] (chain-major);
+ * e_min, e_max: double[nchains] or NULL (NULL or non-finite entries: run Arnoldi for that chain); active, lam_lo,
+ * lam_hi: per chain, each may be NULL.  A chain whose bounds fail the test of :280 is preconditioned with the identity. */
+int elph_kpm_setup_chains(elph_handle h, const double *b_max, const double *b_min, const double *e_min,
+                          const double *e_max, int *active, double *lam_lo, double *lam_hi);
+
+/* Inspect the expansion (of chain 0): orders[cld(ltau,2)], total = sum(orders) (either pointer may be NULL). */
 int elph_kpm_orders(elph_handle h, int64_t *orders, int64_t *total);
 
 /* ldiv!(z, P, r) — KPMPreconditioners.jl:426-481 (identity copy when inactive, :475-478) */

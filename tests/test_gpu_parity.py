@@ -714,3 +714,64 @@ def test_mfma_dft_inside_batched_preconditioned_solve(monkeypatch):
     assert np.array_equal(out["0"][1], out["1"][1])
     assert rel(out["1"][0], out["0"][0]) < 1e-10
     m.close()
+
+
+@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2)])
+def test_kpm_preconditioner_per_chain(tag, nchains, per):
+    """One KPM expansion per resident phonon configuration (elph_kpm_setup_chains): every right-hand side of the batch
+    is preconditioned with ITS chain's Ē, eigenvalue bounds, orders and coefficients — same bounds, same iteration
+    count and the same solution as the single-configuration model given the same Arnoldi start vectors."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    m = configs.make_model(tag, tol=1e-8)
+    # chains with visibly different spectra: different seeds AND different roughness
+    X = np.stack([(0.6 + 0.25 * c) * synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=5100 + c) for c in range(nchains)])
+    nrhs = nchains * per
+    B = np.stack([synth.randn(7100 + r, m.Ndim) for r in range(nrhs)])
+    rng = np.random.default_rng(11)
+    bmax, bmin = rng.standard_normal((nchains, m.Nsites)), rng.standard_normal((nchains, m.Nsites))
+    models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    # the single-chain entry point refuses while several configurations are resident
+    with pytest.raises(Exception):
+        pc.setup_(P, b_max=bmax[0], b_min=bmin[0])
+    act, lo, hi = pc.setup_chains_(P, b_max=bmax, b_min=bmin)
+    assert act.all() and len(set(np.round(hi, 6))) > 1          # the chains really have different bounds
+    Xs = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+    assert not fl.any() and (res < 1e-7).all()
+    plain = np.zeros_like(B)
+    it0, _, fl0 = models.ldiv_batched_(plain, m, B)
+    assert not fl0.any() and (it < it0).all()                    # and they precondition: far fewer iterations
+    for r in range(nrhs) if nrhs <= 8 else (0, 1, nchains, nrhs - 1):
+        c = r % nchains
+        m1 = configs.make_model(tag, tol=1e-8)
+        m1.x[:] = X[c]
+        models.update_model_(m1)
+        P1 = pc.SymmetricKPMPreconditioner(m1, 20, 0.05, 1.0, 1.0)
+        pc.setup_(P1, b_max=bmax[c], b_min=bmin[c])
+        assert P1.lam_lo == lo[c] and P1.lam_hi == hi[c]
+        x1 = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x1, m1, np.ascontiguousarray(B[r]), P=P1)
+        assert fl1 == 0 and abs(it1 - it[r]) <= 1
+        assert rel(x1, Xs[r]) < 1e-6 and rel(plain[r], Xs[r]) < 1e-6
+        m1.close()
+    # injected bounds, one chain made inactive (e_max - e_min >= 2 fails the test of KPMPreconditioners.jl:280):
+    # that chain is preconditioned with the identity, the others keep their expansions
+    emin, emax = np.full(nchains, 0.5), np.full(nchains, 1.8)
+    emax[1] = 2.6
+    act, lo2, hi2 = pc.setup_chains_(P, e_min=emin, e_max=emax)
+    assert act.tolist() == [1, 0] + [1] * (nchains - 2)
+    Xi = np.zeros_like(B)
+    it2, res2, fl2 = models.ldiv_batched_(Xi, m, B, P=P)
+    assert not fl2.any()
+    assert abs(int(it2[1]) - int(it0[1])) <= 2                   # identity-preconditioned == plain CG
+    assert rel(Xi, plain) < 1e-6
+    # back to one configuration: the per-chain expansions are dropped, the single-chain set-up works again
+    models.update_model_(m)
+    with pytest.raises(Exception):
+        models.ldiv_(np.zeros(m.Ndim), m, np.ascontiguousarray(B[0]), P=P)
+    pc.setup_(P, rng=np.random.default_rng(5))
+    x = np.zeros(m.Ndim)
+    itx, _, flx = models.ldiv_(x, m, np.ascontiguousarray(B[0]), P=P)
+    assert flx == 0
+    m.close()
