@@ -12,8 +12,9 @@ bracketed by barrier + device synchronise on both sides; the time is the MAX ove
 value = (2 * nrhs * K * n_gpus) / time.  One JSON line on rank 0.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every GPU carries its own chains — no data-path
-collective, "weak" scaling (SURVEY.md §8e replica mode).  The spatially sharded single solve with RCCL halo
-exchange is a strong-scaling anti-pattern at these sizes and is not built.
+collective, "weak" scaling (SURVEY.md §8e replica mode).  ONE solve sharded over the GPUs (spatial slabs with ghost
+rows, or tau-slabs; RCCL halo exchange + partial-sum all-gathers per iteration) is --mode spatial / --mode sharded:
+strong scaling, latency-bound at these sizes.
 
 Also in the JSON line:
   roofline      the dominant kernel k_cg_ap timed ALONE with HIP events on the launch stream:
@@ -54,9 +55,10 @@ def parse():
                     help="independent phonon configurations (Markov chains) per GPU sharing the batch: right-hand side r "
                          "uses the fermion matrix of chain r %% chains (nrhs = 2*chains = both pseudofermion solves of one "
                          "HMC force evaluation per chain); 1 = all right-hand sides on one matrix")
-    ap.add_argument("--mode", default="chains", choices=["chains", "sharded"],
+    ap.add_argument("--mode", default="chains", choices=["chains", "sharded", "spatial"],
                     help="chains (default): independent chains per GPU, no data-path collective (weak scaling). "
-                         "sharded: ONE solve, tau-slabs over the GPUs, RCCL halo exchange + all-gathers per iteration "
+                         "sharded: ONE solve, tau-slabs over the GPUs; spatial: ONE solve, slabs of rows of cells + ghost "
+                         "rows (the north_star's decomposition) — RCCL halo exchange + all-gathers per iteration "
                          "(strong scaling; latency-bound at these sizes, reported for completeness)")
     ap.add_argument("--config", default="C", help="BASELINE config tag (C = Holstein square L=16 Ltau=160)")
     ap.add_argument("--precond", action="store_true", help="KPM (tau-FFT) preconditioned CG iteration")
@@ -75,7 +77,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import numpy as np
-    if args.mode == "sharded":
+    if args.mode in ("sharded", "spatial"):
         return main_sharded(args, comm)
     from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth
     from elphdynamics_amd._lib import check
@@ -330,7 +332,11 @@ def main_sharded(args, comm):
     x = synth.phonon_field(N, Ltau, beta, dtau)
     E = np.exp(-dtau * x)                                     # lambda = 1, mu = 0 (configs.py)
     b = synth.rhs(N * Ltau)
-    s = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"])
+    spatial = args.mode == "spatial"
+    if spatial:
+        s = sharded.SpatialShardedCG(comm, norb, la.L1, la.L2, Ltau, cb["table"], cb["cosht"], cb["sinht"])
+    else:
+        s = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"])
     s.update_model(E)
     K, W = args.steps, args.warmup
     s.prepare(b)
@@ -346,10 +352,11 @@ def main_sharded(args, comm):
             "metric": "cg_matvecs_per_sec", "value": 2.0 * K / elapsed, "unit": "matvec/s", "n_gpus": comm.world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config {args.config}: ONE un-preconditioned CG solve (N={N}, Ltau={Ltau}), tau-slabs "
-                                   f"over {comm.world} GPU(s), 1 r-halo exchange + 2 partial-sum all-gathers per iteration "
+            "config": {"workload": f"BASELINE config {args.config}: ONE un-preconditioned CG solve (N={N}, Ltau={Ltau}), "
+                                   + (f"slabs of rows of cells (+{s.sl['lo']}/{s.sl['hi']} ghost rows) " if spatial else "tau-slabs ")
+                                   + f"over {comm.world} GPU(s), 1 r-halo exchange + 2 partial-sum all-gathers per iteration "
                                    f"({'RCCL, device-resident' if s.dev is not None else 'host-staged'})",
-                       "parallelism": f"tau_slabs{comm.world}"},
+                       "parallelism": f"{'row_slabs' if spatial else 'tau_slabs'}{comm.world}"},
             "cg_iters_per_sec": K / elapsed}))
     s.close()
     comm.close()

@@ -53,6 +53,9 @@ SIGNATURES = {
     "elph_dev_buffer": (c_int, [Handle, c_int, C.POINTER(C.c_void_p), P_i64]),
     "elph_buffer_read": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
     "elph_buffer_write": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
+    "elph_set_dot_range": (c_int, [Handle, c_i64, c_i64]),
+    "elph_buffer_read_rows": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
+    "elph_buffer_write_rows": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
     "elph_fermion_force_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl,
                                             P_i64, P_int]),
     "elph_fermion_force_ssh": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),

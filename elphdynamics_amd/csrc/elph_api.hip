@@ -115,6 +115,7 @@ static int build_lane_program(elph_handle_s *h) {
             }
         }
     }
+    h->fast_capable = h->fast;
     RC(dev_alloc(&h->d_lp_ij, (size_t)NE * ELPH_WAVE));
     HIPCHK(hipMemcpy(h->d_lp_ij, h->h_lp_ij.data(), sizeof(unsigned) * NE * ELPH_WAVE, hipMemcpyHostToDevice));
     const size_t ntau = (h->kind == ELPH_MODEL_SSH) ? (size_t)h->L : 1;
@@ -777,6 +778,45 @@ extern "C" int elph_cgstep_result(elph_handle h, double *x) {
     HIPCHK(hipMemcpyAsync(x, h->d_stage_out, (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return ELPH_OK;
+}
+
+// Sites [site_lo, site_hi) (0-based) enter the inner products of the step-wise / full CG (p.z, r.r, b.b); the other sites
+// of the handle's lattice are ghost sites of a spatial shard: they take part in the mat-vec, their values come from the
+// neighbouring ranks.  A restricted range runs the generic kernel family.  (0, nsites) restores the default.
+extern "C" int elph_set_dot_range(elph_handle h, int64_t site_lo, int64_t site_hi) {
+    CHECK_H(h);
+    if (site_lo < 0 || site_hi > h->N || site_lo >= site_hi) { elph_set_error("bad site range [%lld, %lld)", (long long)site_lo, (long long)site_hi); return ELPH_E_ARG; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    const bool all = (site_lo == 0 && site_hi == h->N);
+    h->dot_lo = all ? 0 : (int)site_lo;
+    h->dot_hi = all ? 0 : (int)site_hi;
+    h->fast = all ? h->fast_capable : false;
+    return ELPH_OK;
+}
+
+// rows of a layout-S vector: for every tau the sites [site_lo, site_lo + nsites) -> host[tau * nsites + k]
+static int buffer_rows(elph_handle_s *h, int which, int64_t site_lo, int64_t nsites, double *host, bool write) {
+    if (which != 3 && which != 4) { elph_set_error("rows access is for the vectors r (3) and x (4)"); return ELPH_E_ARG; }
+    void *p = nullptr; int64_t n = 0;
+    RC(elph_dev_buffer(h, which, &p, &n));
+    if (!host || site_lo < 0 || nsites < 1 || site_lo + nsites > h->N) { elph_set_error("bad site range"); return ELPH_E_ARG; }
+    double *d = (double *)p + site_lo;
+    const size_t dpitch = (size_t)h->N * sizeof(double), hpitch = (size_t)nsites * sizeof(double);
+    if (write) HIPCHK(hipMemcpy2DAsync(d, dpitch, host, hpitch, hpitch, (size_t)h->L, hipMemcpyHostToDevice, h->stream));
+    else HIPCHK(hipMemcpy2DAsync(host, hpitch, d, dpitch, hpitch, (size_t)h->L, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_buffer_read_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, double *host) {
+    CHECK_H(h);
+    return buffer_rows(h, which, site_lo, nsites, host, false);
+}
+
+extern "C" int elph_buffer_write_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, const double *host) {
+    CHECK_H(h);
+    return buffer_rows(h, which, site_lo, nsites, const_cast<double *>(host), true);
 }
 
 // device buffers of the step-wise solve (layout S: slice tau of a vector = N contiguous doubles at tau*N)

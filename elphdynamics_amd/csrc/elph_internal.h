@@ -77,6 +77,7 @@ struct CgBufs {
     CgState *state;             // [nrhs][2]
     CgParams params;
     double *hist;               // optional eps history
+    int dot_lo, dot_hi;         // sites [dot_lo, dot_hi) enter the inner products (whole slice unless a spatial shard)
     int nrz;                    // number of r.z partials per rhs
     int npap;                   // number of p.z partials per rhs (L, or L/T for the chunked kernel)
     int nrhs;
@@ -156,6 +157,8 @@ struct elph_handle_s {
     bool have_E = false;
     int nchains = 1;                       // Holstein: independent chains sharing one handle / one batch
     int64_t E_cap = 0;                     // doubles allocated for d_E
+    int dot_lo = 0, dot_hi = 0;            // sites counted in the CG inner products (elph_set_dot_range); hi = 0: all
+    bool fast_capable = false;             // lane-program kernels possible for this bond table (fast may be switched off)
     int solo_chain = -1;                   // >= 0: kernels see only this chain (single re-solve of one RHS of a chains batch)
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
     // lane program (fast path, ncol <= 4)

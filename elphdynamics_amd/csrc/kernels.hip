@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(1024) k_cg_ap(CgBufs B, ModelDev m, int parity
         if (s < N) {
             const double zz = w0[q] - sg1 * e1[q] * bufB[s];
             z[(size_t)t * N + s] = zz;
-            acc += p0[q] * zz;
+            if (s >= B.dot_lo && s < B.dot_hi) acc += p0[q] * zz;
         }
     }
     acc = block_sum(acc, lds + 2 * (size_t)N);
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(1024) k_cg_xr(CgBufs B, int N, int L, int pari
             x[i] += alpha * p[i];                           // :205 / :282
             const double rn = r[i] - alpha * z[i];          // :208 / :285
             r[i] = rn;
-            acc += rn * rn;
+            if (s >= B.dot_lo && s < B.dot_hi) acc += rn * rn;
         }
     }
     __shared__ double scratch[16];
@@ -397,8 +397,10 @@ __global__ void __launch_bounds__(WAVE) k_cg_init(CgBufs B, const double *__rest
         const double ri = 1.0 * bi + -1.0 * ax[i];          // axpby!(1,b,-1,r), :179-180 / :262-263
         r[i] = ri;
         p0[i] = ri;
-        a += ri * ri;
-        c += bi * bi;
+        if (s >= B.dot_lo && s < B.dot_hi) {
+            a += ri * ri;
+            c += bi * bi;
+        }
     }
     a = wave_sum(a);
     c = wave_sum(c);
@@ -906,6 +908,8 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     B.x = h->d_x; B.r = h->d_r; B.z = h->d_z; B.zp = h->d_zp; B.p = h->d_p;
     B.pap = h->d_part; B.rr = h->d_part + P; B.rz = h->d_part + 2 * P;
     B.state = h->d_state; B.params = h->cur_params; B.hist = h->d_hist;
+    B.dot_lo = h->dot_hi > 0 ? h->dot_lo : 0;
+    B.dot_hi = h->dot_hi > 0 ? h->dot_hi : (int)h->N;
     B.nrz = (int)(h->L * h->npl);
     B.npap = (int)(h->L / elph_choose_T(h, nrhs));
     B.nrhs = nrhs;

@@ -77,14 +77,24 @@ class Comm:
         self.dist.all_gather(out, t)
         return np.concatenate([o.cpu().numpy() for o in out])
 
-    def ring_exchange(self, send_to_prev, send_to_next):
-        """Periodic ring: returns (received from previous rank, received from next rank)."""
+    def allgather_object(self, obj):
+        """List over ranks of arbitrary (picklable) objects — ragged pieces of a result, not a hot-path call."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def ring_exchange(self, send_to_prev, send_to_next, recv_prev_n=None, recv_next_n=None):
+        """Periodic ring: returns (received from previous rank, received from next rank).  The received lengths default
+        to the symmetric case (what comes from the previous rank is as long as what goes to the next one)."""
         import numpy as np
         if self.dist is None:
             return np.array(send_to_next, copy=True), np.array(send_to_prev, copy=True)
         prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
         sp, sn = self._to_tensor(send_to_prev), self._to_tensor(send_to_next)
-        rp, rn = self.torch.empty_like(sn), self.torch.empty_like(sp)
+        rp = self.torch.empty_like(sn) if recv_prev_n is None else self.torch.empty(int(recv_prev_n), dtype=sn.dtype, device=sn.device)
+        rn = self.torch.empty_like(sp) if recv_next_n is None else self.torch.empty(int(recv_next_n), dtype=sp.dtype, device=sp.device)
         ops = [self.dist.P2POp(self.dist.isend, sp, prev), self.dist.P2POp(self.dist.isend, sn, nxt),
                self.dist.P2POp(self.dist.irecv, rp, prev), self.dist.P2POp(self.dist.irecv, rn, nxt)]
         if self.world == 2:      # prev == next: order the two messages by tag-free pairing (send order = receive order)

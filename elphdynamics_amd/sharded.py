@@ -75,6 +75,20 @@ class GpuBackend:
         v = np.ascontiguousarray(values, dtype=np.float64)
         self._lib_mod.check(self.lib.elph_buffer_write(self.h, which, offset, v.size, self._lib_mod.dptr(v)))
 
+    # ---- spatial shards: inner products over the own sites only; rows (site ranges over all tau) of r / x
+    def set_dot_range(self, lo, hi):
+        self._lib_mod.check(self.lib.elph_set_dot_range(self.h, lo, hi))
+
+    def read_rows(self, which, site_lo, nsites):
+        out = np.empty((self.L, nsites))
+        self._lib_mod.check(self.lib.elph_buffer_read_rows(self.h, which, site_lo, nsites, self._lib_mod.dptr(out)))
+        return out
+
+    def write_rows(self, which, site_lo, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.shape[0] == self.L
+        self._lib_mod.check(self.lib.elph_buffer_write_rows(self.h, which, site_lo, v.shape[1], self._lib_mod.dptr(v)))
+
     # ---- zero-copy torch views of the device buffers (nccl path: collectives act on them directly, no host hop)
     def tensor(self, which, torch):
         ptr, cnt = C.c_void_p(), C.c_int64()
@@ -235,6 +249,237 @@ class ShardedCG:
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
+
+    def close(self):
+        self.be.close()
+
+
+# =====================================================================================================================
+# Spatial slabs (the decomposition SURVEY §8e / the north_star describe)
+# =====================================================================================================================
+
+def mtm_dependency_closure(own_sites, table0):
+    """Sites of p that  z = Mᵀ(M p)  on `own_sites` depends on, and the bonds that carry the dependency.
+
+    table0: (nb, 2) 0-based bonds in the order the checkerboard applies them (bond 0 first in M; Mᵀ applies them last
+    to first — Checkerboard.jl:57-141).  Walking the factors backwards from the output: a bond that touches the current
+    set pulls in its other end.  The τ-shift, exp(-ΔτV) and the ± are pointwise in the site index and add nothing."""
+    S = np.zeros(int(table0.max()) + 1 if table0.size else 0, dtype=bool)
+    S[np.asarray(own_sites)] = True
+    need = np.zeros(table0.shape[0], dtype=bool)
+    nb = table0.shape[0]
+    for n in list(range(nb)) + list(range(nb - 1, -1, -1)):      # Mᵀ backwards (bond 0 was applied last), then M backwards
+        i, j = table0[n]
+        if S[i] or S[j]:
+            S[i] = S[j] = True
+            need[n] = True
+    return S, need
+
+
+class SpatialSlabs:
+    """Row decomposition of a lattice (site = norbits*(l1 + L1*l2) + orbit, L3 = 1) over P ranks along l2, with the ghost
+    rows each rank's fused MᵀM needs.  Pure integer set-up, identical on every rank."""
+
+    def __init__(self, norbits, L1, L2, table, P):
+        self.ns, self.L1, self.L2, self.P = int(norbits), int(L1), int(L2), int(P)
+        self.row = self.ns * self.L1                              # sites per row of cells
+        self.N = self.row * self.L2
+        t0 = np.asarray(table, dtype=np.int64) - 1
+        self.starts = [(q * self.L2) // self.P for q in range(self.P + 1)]
+        if min(np.diff(self.starts)) < 1:
+            raise ValueError("more ranks than rows of cells")
+        self.slabs = [self._slab(q, t0) for q in range(self.P)]
+
+    def _slab(self, q, t0):
+        r0, r1 = self.starts[q], self.starts[q + 1]
+        R = r1 - r0
+        own_sites = np.arange(r0 * self.row, r1 * self.row)
+        if self.P == 1:
+            return dict(R=R, lo=0, hi=0, rows=np.arange(self.L2), bonds=np.arange(t0.shape[0]), r0=r0)
+        S, need = mtm_dependency_closure(own_sites, t0)
+        rows_needed = np.unique(np.nonzero(S)[0] // self.row)
+        lo = hi = 0
+        for g in rows_needed:
+            d = (g - r0) % self.L2
+            if d < R:
+                continue
+            up, down = d - (R - 1), self.L2 - d                  # distance above the last / below the first own row
+            if up <= down:
+                hi = max(hi, up)
+            else:
+                lo = max(lo, down)
+        if lo + R + hi > self.L2:
+            raise ValueError(f"rank {q}: own rows {R} + ghost rows {lo}+{hi} exceed the {self.L2} rows of the lattice")
+        rows = (np.arange(r0 - lo, r1 + hi)) % self.L2            # local row j -> global row
+        loc_of = -np.ones(self.L2, dtype=np.int64)
+        loc_of[rows] = np.arange(rows.size)
+        gi, gj = t0[:, 0] // self.row, t0[:, 1] // self.row
+        li, lj = loc_of[gi], loc_of[gj]
+        inc = (li >= 0) & (lj >= 0) & (np.abs(li - lj) <= 1)      # both ends in the slab, no wrap through its open ends
+        if (need & ~inc).any():
+            raise ValueError(f"rank {q}: a bond the own rows depend on leaves the slab")
+        return dict(R=R, lo=lo, hi=hi, rows=rows, bonds=np.nonzero(inc)[0], r0=r0)
+
+    def local_table(self, q, table):
+        """1-based local neighbour table of rank q's slab, bonds in the global checkerboard order."""
+        sl = self.slabs[q]
+        t0 = np.asarray(table, dtype=np.int64) - 1
+        loc_of = -np.ones(self.L2, dtype=np.int64)
+        loc_of[sl["rows"]] = np.arange(sl["rows"].size)
+        b = t0[sl["bonds"]]
+        loc = loc_of[b // self.row] * self.row + (b % self.row)
+        return loc + 1
+
+    def global_sites(self, q):
+        sl = self.slabs[q]
+        return (sl["rows"][:, None] * self.row + np.arange(self.row)[None, :]).reshape(-1)
+
+
+class SpatialShardedCG:
+    """Un-preconditioned CG on MᵀM x = b for ONE Holstein fermion matrix, slabs of rows of cells over comm.world ranks.
+
+    Rank q's handle lives on its slab: own rows + the ghost rows found by `mtm_dependency_closure` (2 below and 2 above
+    for the even-aligned square lattice, where only the last colour crosses the slab boundary — SURVEY §8e).  The fused
+    kernel then yields the exact z = MᵀM p on the own rows with NO exchange inside the mat-vec; per iteration the ranks
+    exchange the ghost rows of r once (the checkerboard boundary rows: 2 x L1 x Ltau doubles each way at config C =
+    41 KB) and rebuild p on the ghosts locally (p = r + βp is pointwise), and combine the two inner products from
+    per-slice partial sums over own sites (elph_set_dot_range) so every rank takes bit-identical α, β, stop decisions."""
+
+    def __init__(self, comm, norbits, L1, L2, ltau, table, cosht, sinht, backend_factory=None, device=None):
+        self.comm, self.P, self.rank = comm, comm.world, comm.rank
+        self.Ltau = int(ltau)
+        self.slabs = SpatialSlabs(norbits, L1, L2, table, self.P)
+        self.N = self.slabs.N
+        sl = self.slabs.slabs[self.rank]
+        self.sl = sl
+        self.row = self.slabs.row
+        self.Nloc = sl["rows"].size * self.row
+        self.own_lo, self.own_n = sl["lo"] * self.row, sl["R"] * self.row
+        ltab = self.slabs.local_table(self.rank, table)
+        c, s = np.asarray(cosht)[sl["bonds"]], np.asarray(sinht)[sl["bonds"]]
+        dev = comm.local_rank if device is None else device
+        factory = backend_factory or (lambda N, L, t, cc, ss: GpuBackend(N, L, t, cc, ss, dev))
+        self.be = factory(self.Nloc, self.Ltau, ltab, c, s)
+        self.gsites = self.slabs.global_sites(self.rank)
+        if self.P > 1:
+            self.be.set_dot_range(self.own_lo, self.own_lo + self.own_n)
+            prev, nxt = (self.rank - 1) % self.P, (self.rank + 1) % self.P
+            sp, sn = self.slabs.slabs[prev], self.slabs.slabs[nxt]
+            if sl["lo"] > sp["R"] or sl["hi"] > sn["R"]:
+                raise ValueError("ghost rows reach beyond the neighbouring rank: use fewer ranks")
+            # what the neighbours need from me: next wants my top sn.lo rows, prev wants my bottom sp.hi rows
+            self.n_to_next, self.n_to_prev = sn["lo"] * self.row, sp["hi"] * self.row
+            self.n_from_prev, self.n_from_next = sl["lo"] * self.row, sl["hi"] * self.row
+        self.dev = None
+        if getattr(comm, "backend", None) == "nccl" and isinstance(self.be, GpuBackend):
+            torch = comm.torch
+            stream = torch.cuda.Stream()
+            self.be.use_stream(stream.cuda_stream)
+            t = {k: self.be.tensor(k, torch) for k in (PAP, RR, BB, RVEC, XVEC)}
+            with torch.cuda.stream(stream):
+                gbuf = torch.empty(self.P * self.Ltau, dtype=torch.float64, device="cuda")
+            self.dev = dict(torch=torch, t=t, gbuf=gbuf, r=t[RVEC].view(self.Ltau, self.Nloc), stream=stream)
+
+    def update_model(self, expV_global):
+        Eg = np.asarray(expV_global).reshape(self.N, self.Ltau)
+        self.be.set_expV(Eg[self.gsites, :])
+
+    def _local(self, v_global):
+        return np.asarray(v_global).reshape(self.N, self.Ltau)[self.gsites, :]
+
+    def _combine(self, which):
+        if self.P == 1:
+            return
+        if self.dev is not None:
+            d = self.dev
+            t = d["t"][which]
+            self.comm.dist.all_gather_into_tensor(d["gbuf"], t.contiguous())
+            total = d["gbuf"].sum()
+            t.zero_()
+            t[0] = total
+            return
+        own = self.be.read(which, 0, self.Ltau)
+        total = float(np.sum(self.comm.allgather(own)))
+        buf = np.zeros(self.Ltau)
+        buf[0] = total
+        self.be.write(which, 0, buf)
+
+    def _exchange_r_halo(self):
+        if self.P == 1:
+            return
+        lo, n = self.own_lo, self.own_n
+        if self.dev is not None:
+            dist, r, torch = self.comm.dist, self.dev["r"], self.dev["torch"]
+            prev, nxt = (self.rank - 1) % self.P, (self.rank + 1) % self.P
+            to_prev = r[:, lo:lo + self.n_to_prev].contiguous()
+            to_next = r[:, lo + n - self.n_to_next:lo + n].contiguous()
+            from_prev = torch.empty((self.Ltau, self.n_from_prev), dtype=torch.float64, device="cuda")
+            from_next = torch.empty((self.Ltau, self.n_from_next), dtype=torch.float64, device="cuda")
+            if self.P == 2:
+                ops = [dist.P2POp(dist.isend, to_prev, prev), dist.P2POp(dist.irecv, from_next, nxt),
+                       dist.P2POp(dist.isend, to_next, nxt), dist.P2POp(dist.irecv, from_prev, prev)]
+            else:
+                ops = [dist.P2POp(dist.isend, to_prev, prev), dist.P2POp(dist.isend, to_next, nxt),
+                       dist.P2POp(dist.irecv, from_prev, prev), dist.P2POp(dist.irecv, from_next, nxt)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            r[:, :lo].copy_(from_prev)
+            r[:, lo + n:].copy_(from_next)
+            return
+        to_prev = self.be.read_rows(RVEC, lo, self.n_to_prev) if self.n_to_prev else np.zeros((self.Ltau, 0))
+        to_next = self.be.read_rows(RVEC, lo + n - self.n_to_next, self.n_to_next) if self.n_to_next else np.zeros((self.Ltau, 0))
+        from_prev, from_next = self.comm.ring_exchange(send_to_prev=to_prev.reshape(-1), send_to_next=to_next.reshape(-1),
+                                                       recv_prev_n=self.Ltau * self.n_from_prev,
+                                                       recv_next_n=self.Ltau * self.n_from_next)
+        if self.n_from_prev:
+            self.be.write_rows(RVEC, 0, np.asarray(from_prev).reshape(self.Ltau, self.n_from_prev))
+        if self.n_from_next:
+            self.be.write_rows(RVEC, lo + n, np.asarray(from_next).reshape(self.Ltau, self.n_from_next))
+
+    def _iteration(self):
+        self.be.ap()
+        self._combine(PAP)
+        self.be.xr()
+        self._combine(RR)
+        self._exchange_r_halo()
+
+    def _begin(self, b_global, tol, maxiter, kmax):
+        self.be.begin(self._local(b_global), tol, maxiter, kmax)
+        self._combine(RR)
+        self._combine(BB)
+        self.be.state0()
+
+    def _ctx(self):
+        import contextlib
+        return self.dev["torch"].cuda.stream(self.dev["stream"]) if self.dev is not None else contextlib.nullcontext()
+
+    def solve(self, b_global, tol=1e-5, maxiter=10000, kmax=1e12, check_every=8):
+        """Returns (x_global (N*Ltau,), iterations, done_flag) — identical on every rank."""
+        with self._ctx():
+            self._begin(b_global, tol, maxiter, kmax)
+            it, done, launched = 0, 0, 0
+            while not done and launched <= maxiter + 1:
+                for _ in range(check_every):
+                    self._iteration()
+                    launched += 1
+                it, done, _ = self.be.status()
+            x_own = self.be.read_rows(XVEC, self.own_lo, self.own_n)                   # (Ltau, own sites)
+        parts = self.comm.allgather_object(x_own) if self.P > 1 else [x_own]
+        x = np.concatenate(parts, axis=1)                                              # (Ltau, N): ranks own ascending rows
+        return np.ascontiguousarray(x.T).reshape(-1), it, done
+
+    def prepare(self, b_global, tol=0.0, maxiter=1 << 40):
+        with self._ctx():
+            self._begin(b_global, tol, maxiter, 1e300)
+
+    def run_iterations(self, k):
+        with self._ctx():
+            for _ in range(k):
+                self._iteration()
+            if self.dev is not None:
+                self.dev["stream"].synchronize()
+            else:
+                self.be.status()
 
     def close(self):
         self.be.close()

@@ -169,6 +169,17 @@ int elph_dev_buffer(elph_handle h, int which, void **ptr, int64_t *count);
 int elph_buffer_read(elph_handle h, int which, int64_t offset, int64_t count, double *host);
 int elph_buffer_write(elph_handle h, int which, int64_t offset, int64_t count, const double *host);
 
+/* Spatial shards (north_star "shards along the spatial axis with halo exchange of the checkerboard boundary"):
+ * a rank's handle is built on its slab of the lattice = its own rows of cells plus the ghost rows the fused MᵀM apply
+ * reads (elphdynamics_amd/sharded.py computes them from the bond table).  elph_set_dot_range: only sites
+ * [site_lo, site_hi) (0-based, the rank's own sites) enter the inner products p·z, r·r, b·b of the solver; the ghost
+ * sites take part in the mat-vec and are refreshed from the neighbouring ranks once per iteration
+ * (elph_buffer_read_rows / _write_rows: for every tau the sites [site_lo, site_lo + nsites) of r (which = 3) or
+ * x (which = 4), host[tau * nsites + k]).  A restricted range runs the generic kernel family. */
+int elph_set_dot_range(elph_handle h, int64_t site_lo, int64_t site_hi);
+int elph_buffer_read_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, double *host);
+int elph_buffer_write_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, const double *host);
+
 /* ---------------------------------------------------------------- fermion force */
 
 /* One fermion-force evaluation of the Holstein model with the phonon field, both pseudofermion fields and both

@@ -1,8 +1,9 @@
 """Worker of the 2-rank sharded-CG tests (launched once per rank by tests/test_sharded_*.py).
 
-usage: sharded_worker.py {numpy|gpu} <out.npz>
+usage: sharded_worker.py {numpy|gpu}[-spatial] <out.npz>
   numpy : local compute by a numpy/oracle stand-in backend (CPU, gloo) — TEST-ONLY code path
   gpu   : local compute by libelphgpu (both ranks on device 0, collectives staged through gloo)
+  -spatial : slabs of rows of cells (SpatialShardedCG) instead of tau-slabs (ShardedCG)
 """
 import os
 import sys
@@ -26,6 +27,20 @@ class NumpyBackend:
         self.orc = Oracle()
         self.N, self.L, self.table, self.c, self.s = N, L2, table, c, s
         self.buf = {k: np.zeros(L2) for k in (sharded.PAP, sharded.RR, sharded.BB)}
+        self.mask = np.ones(N)          # sites that enter the inner products (elph_set_dot_range)
+
+    def set_dot_range(self, lo, hi):
+        self.mask = np.zeros(self.N)
+        self.mask[lo:hi] = 1.0
+
+    def _dot(self, a, b):            # per-slice partial sums over the masked sites
+        return (self._slices(a) * self._slices(b) * self.mask[:, None]).sum(axis=0)
+
+    def read_rows(self, which, site_lo, nsites):
+        return self._slices(self._vec(which))[site_lo:site_lo + nsites, :].T.copy()
+
+    def write_rows(self, which, site_lo, values):
+        self._slices(self._vec(which))[site_lo:site_lo + values.shape[1], :] = np.asarray(values).T
 
     def set_expV(self, E_loc):
         self.m = self.orc.make_model(0, self.N, self.L, self.table, self.c, self.s, np.ascontiguousarray(E_loc).reshape(-1))
@@ -39,8 +54,8 @@ class NumpyBackend:
         self.x = np.zeros_like(self.b)
         self.r = self.b.copy()
         self.p = self.b.copy()
-        self.buf[sharded.RR] = (self._slices(self.r) ** 2).sum(axis=0)
-        self.buf[sharded.BB] = (self._slices(self.b) ** 2).sum(axis=0)
+        self.buf[sharded.RR] = self._dot(self.r, self.r)
+        self.buf[sharded.BB] = self._dot(self.b, self.b)
 
     def state0(self):
         rr, bb = self.buf[sharded.RR].sum(), self.buf[sharded.BB].sum()
@@ -68,7 +83,7 @@ class NumpyBackend:
             self.rho = rr
             self.p = self.r + beta * self.p
         self.z = self.orc.mulMTM(self.m, np.ascontiguousarray(self.p))
-        self.buf[sharded.PAP] = (self._slices(self.p) * self._slices(self.z)).sum(axis=0)
+        self.buf[sharded.PAP] = self._dot(self.p, self.z)
         self.seq += 1
 
     def xr(self):
@@ -77,7 +92,7 @@ class NumpyBackend:
         alpha = self.rho / self.buf[sharded.PAP].sum()
         self.x += alpha * self.p
         self.r -= alpha * self.z
-        self.buf[sharded.RR] = (self._slices(self.r) ** 2).sum(axis=0)
+        self.buf[sharded.RR] = self._dot(self.r, self.r)
 
     def status(self):
         return (self.seq if self.done else self.seq), self.done, float(self.eps)
@@ -105,9 +120,37 @@ class NumpyBackend:
         pass
 
 
+def main_spatial(mode, out, comm):
+    """Two lattices through SpatialShardedCG: square 8x8 (ghost rows 2+2) and honeycomb 4x4x2 (ghost rows 1+1)."""
+    res = {}
+    for tag, norb, Ls, bonds, Ltau in (("sq", 1, 8, lat.SQUARE_BONDS, 8), ("hc", 2, 4, lat.HONEYCOMB_BONDS, 6)):
+        dtau = 0.1
+        la = lat.Lattice(norb, Ls, Ls, 1)
+        raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+        tvals = 1.0 + 0.1 * synth.randn(5, raw.shape[0])             # disordered hoppings: every bond is distinguishable
+        cb = lat.initialize_checkerboard(raw, tvals, dtau)
+        N = la.nsites
+        x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
+        E = np.exp(-dtau * (1.0 * x - 0.0))
+        b = synth.randn(321, N * Ltau)
+        factory = (lambda n, l, t, c, s_: NumpyBackend(n, l, t, c, s_)) if mode == "numpy" else None
+        solver = sharded.SpatialShardedCG(comm, norb, Ls, Ls, Ltau, cb["table"], cb["cosht"], cb["sinht"], backend_factory=factory,
+                                          device=0)
+        solver.update_model(E)
+        xs, it, done = solver.solve(b, tol=1e-9, maxiter=2000, check_every=4)
+        res.update({f"{tag}_x": xs, f"{tag}_it": it, f"{tag}_done": done, f"{tag}_E": E, f"{tag}_b": b, f"{tag}_table": cb["table"],
+                    f"{tag}_c": cb["cosht"], f"{tag}_s": cb["sinht"], f"{tag}_N": N, f"{tag}_Ltau": Ltau,
+                    f"{tag}_halo": np.array([solver.sl["lo"], solver.sl["hi"]])})
+        solver.close()
+    np.savez(out + f".rank{comm.rank}", **res)
+    comm.close()
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     comm = dist.Comm(backend="gloo")
+    if mode.endswith("-spatial"):
+        return main_spatial(mode.split("-")[0], out, comm)
     # Holstein square lattice, small enough for the CPU backend: L = 4, Ltau = 16
     Ls, Ltau, dtau = 4, 16, 0.1
     la = lat.Lattice(1, Ls, Ls, 1)

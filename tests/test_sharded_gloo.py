@@ -74,3 +74,60 @@ def test_sharded_solver_device_resident_nccl_path(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sharded_nccl_worker.py")], env=env, capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+
+
+# ---------------------------------------------------------------------------------------------- spatial slabs
+
+def _check_spatial(res, oracle):
+    a, b = res[0], res[1]
+    for tag, halo in (("sq", [2, 2]), ("hc", [1, 1])):
+        assert a[f"{tag}_halo"].tolist() == halo                               # ghost rows found by the dependency closure
+        assert int(a[f"{tag}_it"]) == int(b[f"{tag}_it"]) and int(a[f"{tag}_done"]) == int(b[f"{tag}_done"]) == 1
+        assert np.array_equal(a[f"{tag}_x"], b[f"{tag}_x"])
+        N, L = int(a[f"{tag}_N"]), int(a[f"{tag}_Ltau"])
+        om = oracle.make_model(0, N, L, a[f"{tag}_table"], a[f"{tag}_c"], a[f"{tag}_s"], np.ascontiguousarray(a[f"{tag}_E"]))
+        bb = np.ascontiguousarray(a[f"{tag}_b"])
+        xo, ito = oracle.cg_solve(om, bb, tol=1e-9, maxiter=2000)
+        assert abs(int(a[f"{tag}_it"]) - ito) <= 2
+        assert np.linalg.norm(a[f"{tag}_x"] - xo) / np.linalg.norm(xo) < 1e-7
+        r = oracle.mulMTM(om, np.ascontiguousarray(a[f"{tag}_x"])) - bb
+        assert np.linalg.norm(r) / np.linalg.norm(bb) < 1e-8
+
+
+def test_spatial_sharded_protocol_two_ranks_cpu(tmp_path, oracle):
+    """Slabs of rows of cells + ghost rows (SpatialShardedCG): square 8x8 and honeycomb 4x4, 2 gloo ranks, numpy/oracle
+    stand-in for the local kernels — the slab tables, the masked inner products, the ghost-row exchange of r."""
+    _check_spatial(_run("numpy-spatial", tmp_path), oracle)
+
+
+@pytest.mark.gpu
+def test_spatial_sharded_solve_two_ranks_one_gpu(tmp_path, oracle):
+    _check_spatial(_run("gpu-spatial", tmp_path), oracle)
+
+
+def test_spatial_slab_tables():
+    """Integer set-up of the spatial decomposition on the BASELINE lattices: ghost rows from the dependency closure of
+    the fused MᵀM (2+2 for the even-aligned square lattice — only the last colour crosses the slab boundary, SURVEY §8e;
+    1+1 for honeycomb), uneven splits, and the too-many-ranks error."""
+    from elphdynamics_amd import lattice as lat
+    from elphdynamics_amd import sharded
+
+    def slabs(ns, L, bonds, P):
+        la = lat.Lattice(ns, L, L, 1)
+        raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+        cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), 0.1)
+        return sharded.SpatialSlabs(ns, L, L, cb["table"], P), cb["table"]
+
+    S, tab = slabs(1, 16, lat.SQUARE_BONDS, 8)
+    assert [(s["R"], int(s["lo"]), int(s["hi"])) for s in S.slabs] == [(2, 2, 2)] * 8
+    lt = S.local_table(3, tab)
+    assert lt.min() == 1 and lt.max() == 6 * 16 and lt.shape[0] == 6 * 16 + 5 * 16      # 6 rows of x-bonds, 5 row-pairs of y-bonds
+    assert np.array_equal(S.global_sites(0)[:32], np.arange(14 * 16, 16 * 16))         # rank 0's ghosts wrap to rows 14, 15
+    S, _ = slabs(2, 12, lat.HONEYCOMB_BONDS, 8)
+    assert [s["R"] for s in S.slabs] == [1, 2, 1, 2, 1, 2, 1, 2] and all(s["lo"] == 1 and s["hi"] == 1 for s in S.slabs)
+    S, _ = slabs(1, 16, lat.SQUARE_BONDS, 3)
+    assert [(s["R"], int(s["lo"]), int(s["hi"])) for s in S.slabs] == [(5, 2, 3), (5, 3, 2), (6, 2, 2)]
+    with pytest.raises(ValueError):
+        slabs(1, 8, lat.SQUARE_BONDS, 16)           # more ranks than rows of cells
+    S1, tab1 = slabs(1, 8, lat.SQUARE_BONDS, 1)
+    assert S1.slabs[0]["lo"] == 0 and len(S1.slabs[0]["bonds"]) == tab1.shape[0]
