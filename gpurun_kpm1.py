@@ -1,15 +1,17 @@
-import sys, ctypes as C
+import sys, time
 import numpy as np
 sys.path.insert(0, '.')
-from elphdynamics_amd import configs, models, preconditioners as pc
-from elphdynamics_amd._lib import check
-m = configs.make_model("C", tol=1e-5)
-lib = m._lib
-P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
-pc.setup_(P, rng=np.random.default_rng(1))
-nrhs = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-R, B = configs.rhs(m, nrhs)
-ms = C.c_double()
-check(lib.elph_bench_prepare(m._h, 2, nrhs, np.ascontiguousarray(B).ctypes.data_as(C.POINTER(C.c_double))))
-check(lib.elph_bench_run(m._h, 2, nrhs, 200, 0, C.byref(ms)))
-print("kpm_apply us", 1e3*ms.value/200)
+from elphdynamics_amd import configs, models, hmc, preconditioners as pc, synth
+m = configs.make_model("C", tol=1e-5, maxiter=20000)
+fa = pc.FourierAccelerator(m)
+pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.1)
+for with_kpm in (False, True):
+    for nb in (1, 10):
+        H = hmc.HybridMonteCarlo(m, fa, dt=0.01, tr=0.2, alpha=0.0, Nb=nb)
+        P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0) if with_kpm else None
+        rng = np.random.default_rng(3)
+        hmc.update_(m, H, fa, P, rng=rng)
+        t0 = time.perf_counter()
+        acc, its = hmc.update_(m, H, fa, P, rng=rng)
+        t1 = time.perf_counter()
+        print(f"kpm={with_kpm} Nb={nb} Nt={H.Nt}: update {1e3*(t1-t0):.1f} ms = {1e3*(t1-t0)/(H.Nt+2):.2f} ms per force/action evaluation; iters/solve {its:.1f} accepted {acc} dH {H.H1-H.H0:.3e}")
