@@ -204,14 +204,37 @@ int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int 
     return dft_check("k_dft_inv_tab(twisted)");
 }
 
-// out = Re iFFT( diag^power .* FFT(in) ), N columns
-int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u) {
+// u[rhs][k][s] *= (D[k][s]^p + D[L-k][s]^p)/2  — the symmetrised diagonal of fourier_accelerate! between the two GEMM-form
+// transforms of a batch (the scalar forward kernel applies it in its epilogue)
+__global__ void __launch_bounds__(256) k_dft_diag(double2 *__restrict__ u, const double *__restrict__ diag, double power, int N,
+                                                  int L, int K, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int s = (int)(i % N), k = (int)((i / N) % K);
+    const int km = (k == 0) ? 0 : L - k;
+    const double f = 0.5 * (pow(diag[(size_t)k * N + s], power) + pow(diag[(size_t)km * N + s], power));
+    double2 v = u[i];
+    v.x *= f; v.y *= f;
+    u[i] = v;
+}
+
+// out = Re iFFT( diag^power .* FFT(in) ), N columns, nvec vectors sharing one diagonal
+int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u, int nvec) {
     const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, true>), dim3((unsigned)nst, (unsigned)((Lh + DFT_KPT - 1) / DFT_KPT), 1),
+    if (elph_dft_mfma_usable(h, 1, false, N, nvec) && elph_dft_mfma_usable(h, 1, true, N, nvec)) {
+        int rc = elph_dft_mfma_fwd(h, 1, u, inS, N, nvec, nullptr);
+        if (rc) return rc;
+        const long long total = (long long)nvec * Lh * N;
+        hipLaunchKernelGGL(k_dft_diag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, u, diagS, power, N, L, Lh, total);
+        rc = dft_check("k_dft_diag");
+        if (rc) return rc;
+        return elph_dft_mfma_inv(h, 1, outS, u, N, nvec, nullptr, nullptr, nullptr, 0);
+    }
+    hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, true>), dim3((unsigned)nst, (unsigned)((Lh + DFT_KPT - 1) / DFT_KPT), (unsigned)nvec),
                        dim3(WAVE), 0, h->stream, u, inS, h->d_Pk, N, L, Lh, dft_pad(L, 2 * DFT_TC), (const CgState *)nullptr, diagS, power);
-    hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>), dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), 1), dim3(WAVE),
-                       0, h->stream, outS, u, h->d_Pt, N, L, Lh, dft_pad(Lh, 2 * DFT_KC), (const CgState *)nullptr, (const double *)nullptr,
-                       (double *)nullptr, 0);
+    hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>), dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nvec),
+                       dim3(WAVE), 0, h->stream, outS, u, h->d_Pt, N, L, Lh, dft_pad(Lh, 2 * DFT_KC), (const CgState *)nullptr,
+                       (const double *)nullptr, (double *)nullptr, 0);
     return dft_check("fourier_accelerate");
 }
 

@@ -666,6 +666,18 @@ int elph_i_ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, 
     return ldiv_core(h, nrhs, use_prec, maxiter, iters, resid, flag);
 }
 int elph_i_ensure_capacity(elph_handle_s *h, int nrhs) { return ensure_capacity(h, nrhs); }
+int elph_i_reserve_chains(elph_handle_s *h, int nchains) {
+    if (nchains < 1) { elph_set_error("nchains < 1"); return ELPH_E_ARG; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t need = (int64_t)nchains * h->ndim;
+    if (need > h->E_cap) {
+        RC(dev_alloc(&h->d_E, (size_t)need));
+        h->E_cap = need;
+        h->have_E = false;
+    }
+    if (h->nchains != nchains) { h->nchains = nchains; drop_graphs(h); h->kpm_ready = false; }
+    return ELPH_OK;
+}
 void elph_i_drop_graphs(elph_handle_s *h) { drop_graphs(h); }
 
 static int stage_in_dev(elph_handle_s *h, int nrhs, const double *X_dev, const double *B_dev) {

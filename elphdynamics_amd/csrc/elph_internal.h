@@ -249,6 +249,7 @@ KpmDev elph_kpm_dev(const elph_handle_s *h);
 // elph_api.hip internals used by hmc.hip
 int elph_i_ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag);
 int elph_i_ensure_capacity(elph_handle_s *h, int nrhs);
+int elph_i_reserve_chains(elph_handle_s *h, int nchains);   // d_E for nchains configurations, h->nchains = nchains
 void elph_i_drop_graphs(elph_handle_s *h);
 void elph_hmc_free(elph_handle_s *h);
 void elph_greens_free(elph_handle_s *h);
@@ -264,13 +265,15 @@ int elph_launch_cg_init_only(elph_handle_s *h, int nrhs);
 int elph_launch_cg_state0_only(elph_handle_s *h, int nrhs);
 int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode);
 int elph_launch_ebar(elph_handle_s *h, int chain = 0);
-int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int64_t ncol);
+int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int64_t ncol,
+                          int nvec = 1);
 int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);
 int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS);
 int elph_launch_zero(elph_handle_s *h, double *p, int64_t n);
-int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau);
+int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau, int nch = 1);
 int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS);
-int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau);
+int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau,
+                               int nch = 1);
 
 // ---- fast path (cg_fast.hip) ----------------------------------------------------------------
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
@@ -290,7 +293,8 @@ int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int 
                          const double *rvec, double *rz_part, int nrz);
 int elph_dft_fwd_plain(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs);
 int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs);
-int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u);
+int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u,
+                   int nvec = 1);
 
 // ---- batched tau-axis transforms on the matrix cores (dft_mfma.hip); which: 0 twisted, 1 plain
 int elph_dft_mfma_build_tables(elph_handle_s *h);

@@ -25,12 +25,14 @@ namespace {
 constexpr int TPB = 256;
 
 struct HmcState {
+    int nch = 1;                 // chains advanced in lockstep (one phonon configuration, one trajectory each)
+    // per chain: [nch][ndim], layout S inside a chain
     double *x = nullptr, *v = nullptr, *x0 = nullptr, *v0 = nullptr, *dS = nullptr, *y = nullptr;
-    double *R2 = nullptr;        // [2 ndim] R±
-    double *phi = nullptr;       // [2 ndim] ϕ±
-    double *faM = nullptr;       // FourierAccelerator.M in layout S ([k][site])
+    double *R2 = nullptr;        // [2][nch][ndim] R±
+    double *phi = nullptr;       // [2][nch][ndim] ϕ±
+    double *faM = nullptr;       // FourierAccelerator.M in layout S ([k][site]), shared by the chains
     double *par = nullptr;       // [2N] ω, ω₄   (λ, λ₂, μ are h->d_lam)
-    double *part = nullptr;      // [3 L] partial sums
+    double *part = nullptr;      // [2 nch][L] partial sums
     double dtau = 0.0;
     bool have_state = false;
 };
@@ -71,31 +73,35 @@ __global__ void __launch_bounds__(TPB) k_hmc_neg(double *__restrict__ v, const d
 // ϕ = Λ⁻¹ (MᵀR):  ϕ(τ) = -(1/Λ(τ)) u(τ-1),  ϕ(0) = +(1/Λ(0)) u(L-1)   (mulΛ⁻¹!, HMC.jl:978-995; Λ: :921-941)
 __global__ void __launch_bounds__(TPB) k_hmc_phi(double *__restrict__ phi, const double *__restrict__ u,
                                                  const double *__restrict__ x, const double *__restrict__ lam3, int N, int L,
-                                                 double dtau) {
-    const long long n = (long long)N * L, i = (long long)blockIdx.x * TPB + threadIdx.x;
+                                                 double dtau, int nch) {
+    // i runs over [chain][ndim]; blockIdx.y = sign; u, phi are [sign][chain][ndim]
+    const long long nd = (long long)N * L, n = nd * nch, i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
-    const int s = (int)(i % N), t = (int)(i / N);
+    const long long base = (i / nd) * nd;
+    const int s = (int)(i % N), t = (int)((i % nd) / N);
     const int tm1 = (t == 0) ? L - 1 : t - 1;
     const double sg = (t == 0) ? 1.0 : -1.0;
     const double xi = x[i];
     const double Lam = exp(-dtau * (lam3[s] * xi + lam3[N + s] * (xi * xi)) / 2);
     const size_t o = (size_t)blockIdx.y * (size_t)n;
-    phi[o + i] = sg * (1.0 / Lam) * u[o + (size_t)tm1 * N + s];
+    phi[o + i] = sg * (1.0 / Lam) * u[o + (size_t)base + (size_t)tm1 * N + s];
 }
 
 // dS/dx (+)= dSb/dx   (calc_dSbdx!, PhononAction.jl:114-187, no dispersive modes)
 __global__ void __launch_bounds__(TPB) k_hmc_dsb(double *__restrict__ dS, const double *__restrict__ x,
-                                                 const double *__restrict__ par, int N, int L, double dtau, int accumulate) {
-    const long long n = (long long)N * L, i = (long long)blockIdx.x * TPB + threadIdx.x;
+                                                 const double *__restrict__ par, int N, int L, double dtau, int accumulate,
+                                                 int nch) {
+    const long long nd = (long long)N * L, n = nd * nch, i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
-    const int s = (int)(i % N), t = (int)(i / N);
+    const size_t base = (size_t)((i / nd) * nd);
+    const int s = (int)(i % N), t = (int)((i % nd) / N);
     const int tp1 = (t == L - 1) ? 0 : t + 1, tm1 = (t == 0) ? L - 1 : t - 1;
     const double w = par[s], w4 = par[N + s];
     const double xt = x[i];
     double d = accumulate ? dS[i] : 0.0;
     d += (dtau * w * w) * xt;
     d += (dtau * 4 * w4) * xt * xt * xt;
-    d -= (x[(size_t)tp1 * N + s] + x[(size_t)tm1 * N + s] - 2.0 * xt) / dtau;
+    d -= (x[base + (size_t)tp1 * N + s] + x[base + (size_t)tm1 * N + s] - 2.0 * xt) / dtau;
     dS[i] = d;
 }
 
@@ -115,6 +121,8 @@ __global__ void __launch_bounds__(TPB) k_hmc_sb_part(double *__restrict__ part, 
                                                      const double *__restrict__ par, int N, int L, double dtau) {
     __shared__ double sc[8];
     const int t = blockIdx.x, tm1 = (t == 0) ? L - 1 : t - 1;
+    x += (size_t)blockIdx.y * (size_t)N * L;                   // blockIdx.y = chain
+    part += (size_t)blockIdx.y * L;
     double acc = 0.0;
     for (int s = threadIdx.x; s < N; s += TPB) {
         const double xt = x[(size_t)t * N + s], xm = x[(size_t)tm1 * N + s], w = par[s], w4 = par[N + s];
@@ -125,10 +133,12 @@ __global__ void __launch_bounds__(TPB) k_hmc_sb_part(double *__restrict__ part, 
     if (threadIdx.x == 0) part[t] = acc;
 }
 
-// partial dot products: part[b] = sum over block b's range of a·b
+// partial dot products of vector blockIdx.y (n elements each): part[y][b] = sum over block b's range of a·b
 __global__ void __launch_bounds__(TPB) k_hmc_dot_part(double *__restrict__ part, const double *__restrict__ a,
                                                       const double *__restrict__ b, long long n, long long per_block) {
     __shared__ double sc[8];
+    a += (size_t)blockIdx.y * (size_t)n; b += (size_t)blockIdx.y * (size_t)n;
+    part += (size_t)blockIdx.y * gridDim.x;
     const long long lo = (long long)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
     double acc = 0.0;
     for (long long i = lo + threadIdx.x; i < hi; i += TPB) acc += a[i] * b[i];
@@ -144,109 +154,131 @@ int chk(const char *what) {
     return ELPH_OK;
 }
 
-int dot_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, long long n, double *out) {
+// out[k] = a_k · b_k for `count` consecutive vectors of n elements (count <= 2 nch)
+int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, long long n, int count, double *out) {
     const int nb = (int)h->L;
     const long long per = (n + nb - 1) / nb;
-    hipLaunchKernelGGL(k_hmc_dot_part, dim3((unsigned)nb), dim3(TPB), 0, h->stream, st->part, a, b, n, per);
+    hipLaunchKernelGGL(k_hmc_dot_part, dim3((unsigned)nb, (unsigned)count), dim3(TPB), 0, h->stream, st->part, a, b, n, per);
     RC(chk("k_hmc_dot_part"));
-    std::vector<double> p((size_t)nb);
-    HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> p((size_t)nb * count);
+    HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    double s = 0.0;
-    for (double q : p) s += q;
-    *out = s;
+    for (int k = 0; k < count; ++k) {
+        double s = 0.0;
+        for (int q = 0; q < nb; ++q) s += p[(size_t)k * nb + q];
+        out[k] = s;
+    }
     return ELPH_OK;
 }
 
 int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
-    const int L = (int)h->L;
-    hipLaunchKernelGGL(k_hmc_sb_part, dim3((unsigned)L), dim3(TPB), 0, h->stream, st->part, st->x, st->par, (int)h->N, L, st->dtau);
+    const int L = (int)h->L, nch = st->nch;
+    hipLaunchKernelGGL(k_hmc_sb_part, dim3((unsigned)L, (unsigned)nch), dim3(TPB), 0, h->stream, st->part, st->x, st->par, (int)h->N, L,
+                       st->dtau);
     RC(chk("k_hmc_sb_part"));
-    std::vector<double> p((size_t)L);
-    HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * L, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> p((size_t)L * nch);
+    HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    double s = 0.0;
-    for (double q : p) s += q;
-    *out = st->dtau * s;
+    for (int c = 0; c < nch; ++c) {
+        double s = 0.0;
+        for (int q = 0; q < L; ++q) s += p[(size_t)c * L + q];
+        out[c] = st->dtau * s;
+    }
     return ELPH_OK;
 }
 
 int update_model(elph_handle_s *h, HmcState *st) {
-    hipLaunchKernelGGL(k_hmc_expV, dim3(nblk(h->ndim)), dim3(TPB), 0, h->stream, h->d_E, st->x, h->d_lam, (int)h->N,
-                       (long long)h->ndim, st->dtau);
+    const long long n = (long long)h->ndim * st->nch;
+    hipLaunchKernelGGL(k_hmc_expV, dim3(nblk(n)), dim3(TPB), 0, h->stream, h->d_E, st->x, h->d_lam, (int)h->N, n, st->dtau);
     h->have_E = true;
     return chk("k_hmc_expV");
 }
 
-// calc_O⁻¹Λϕ!(hmc, model, P, power)  (HMC.jl:820-915): setup!(P), Λϕ±, both solves as one batch, iters = cld(total, 2)
+// calc_O⁻¹Λϕ!(hmc, model, P, power)  (HMC.jl:820-915) for every chain: setup!(P) per chain, Λϕ±, all 2·nch solves as one
+// batch (right-hand side v·nch + c belongs to chain c), per chain iters = cld(total, 2) and flag
 int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power, const double *kpm_randn, int64_t *kpm_calls,
                   int64_t *iters, int *flag) {
     const size_t nd = (size_t)h->ndim;
+    const int nch = st->nch;
     int use = 0;
     if (use_precond) {
-        const double *bmax = kpm_randn + (size_t)(2 * *kpm_calls) * (size_t)h->N, *bmin = bmax + h->N;
+        // start vectors of this set-up call: [b_max | b_min][chain][N]
+        const double *bmax = kpm_randn + (size_t)(2 * *kpm_calls) * (size_t)nch * (size_t)h->N, *bmin = bmax + (size_t)nch * h->N;
         ++*kpm_calls;
-        int act = 0;
-        RC(elph_kpm_setup(h, bmax, bmin, NAN, NAN, &act, nullptr, nullptr));
+        RC(elph_kpm_setup_chains(h, bmax, bmin, nullptr, nullptr, nullptr, nullptr, nullptr));
         use = 1;                      // an inactive preconditioner is the identity inside the preconditioned recurrence
     }
-    RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau));
-    HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * nd * sizeof(double), h->stream));
+    RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
+    HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * (size_t)nch * nd * sizeof(double), h->stream));
     const double tol0 = h->tol;
     h->tol = pow(tol0, power);
-    int64_t it2[2] = {0, 0};
-    double res2[2];
-    int fl2[2] = {0, 0};
-    const int rc = elph_i_ldiv_core(h, 2, use, 0, it2, res2, fl2);
+    std::vector<int64_t> it2((size_t)2 * nch, 0);
+    std::vector<double> res2((size_t)2 * nch);
+    std::vector<int> fl2((size_t)2 * nch, 0);
+    const int rc = elph_i_ldiv_core(h, 2 * nch, use, 0, it2.data(), res2.data(), fl2.data());
     h->tol = tol0;
     if (rc) return rc;
-    int64_t tot = it2[0];
-    int fl = fl2[0];
-    if (fl == 0) { tot += it2[1]; fl = fl2[1]; }
-    if (fl == 0) tot = (tot + 1) / 2;
-    *iters = tot;
-    *flag = fl;
+    for (int c = 0; c < nch; ++c) {
+        int64_t tot = it2[(size_t)c];
+        int fl = fl2[(size_t)c];
+        if (fl == 0) { tot += it2[(size_t)nch + c]; fl = fl2[(size_t)nch + c]; }
+        if (fl == 0) tot = (tot + 1) / 2;
+        iters[c] = tot;
+        flag[c] = fl;
+    }
     return ELPH_OK;
 }
 
 int fa(elph_handle_s *h, HmcState *st, double *out, const double *in, double power) {
-    return elph_launch_fft_accel(h, out, in, st->faM, power, h->N);
+    return elph_launch_fft_accel(h, out, in, st->faM, power, h->N, st->nch);
 }
 
-// calc_H (HMC.jl:697-705): S = Sf + Sb (:745-756,768-784), K = v·(M v)/2 (:711-719)
+// calc_H (HMC.jl:697-705) per chain: S = Sf + Sb (:745-756,768-784), K = v·(M v)/2 (:711-719)
 int calc_H(elph_handle_s *h, HmcState *st, double *H, double *S, double *K) {
-    double sf = 0, sb = 0, k = 0;
-    RC(dot_host(h, st, h->d_b, h->d_x, 2 * (long long)h->ndim, &sf));
-    RC(calc_Sb(h, st, &sb));
+    const int nch = st->nch;
+    std::vector<double> sf((size_t)2 * nch), sb((size_t)nch), k((size_t)nch);
+    RC(dots_host(h, st, h->d_b, h->d_x, (long long)h->ndim, 2 * nch, sf.data()));
+    RC(calc_Sb(h, st, sb.data()));
     RC(fa(h, st, st->y, st->v, 1.0));
-    RC(dot_host(h, st, st->v, st->y, (long long)h->ndim, &k));
-    *S = sf / 2 + sb;
-    *K = k / 2;
-    *H = *S + *K;
+    RC(dots_host(h, st, st->v, st->y, (long long)h->ndim, nch, k.data()));
+    for (int c = 0; c < nch; ++c) {
+        S[c] = (sf[(size_t)c] + sf[(size_t)nch + c]) / 2 + sb[(size_t)c];
+        K[c] = k[(size_t)c] / 2;
+        H[c] = S[c] + K[c];
+    }
     return ELPH_OK;
 }
 
 // dS/dx = dSf/dx [+ dSb/dx]; Q = M^-1 dS/dx in place  (HMC.jl:379-384)
 int force(elph_handle_s *h, HmcState *st, bool with_Sb) {
-    RC(elph_launch_force_holstein(h, st->dS, h->d_x, st->phi, st->x, st->dtau));
+    const long long n = (long long)h->ndim * st->nch;
+    RC(elph_launch_force_holstein(h, st->dS, h->d_x, st->phi, st->x, st->dtau, st->nch));
     if (with_Sb) {
-        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(h->ndim)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, (int)h->N, (int)h->L,
-                           st->dtau, 1);
+        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 1,
+                           st->nch);
         RC(chk("k_hmc_dsb"));
     }
     return fa(h, st, st->dS, st->dS, -1.0);
 }
 
 int boson_force(elph_handle_s *h, HmcState *st) {
-    hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(h->ndim)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, (int)h->N, (int)h->L,
-                       st->dtau, 0);
+    const long long n = (long long)h->ndim * st->nch;
+    hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 0,
+                       st->nch);
     RC(chk("k_hmc_dsb"));
     return fa(h, st, st->dS, st->dS, -1.0);
 }
 
 int leap(elph_handle_s *h, HmcState *st, double cv, double cx) {
-    hipLaunchKernelGGL(k_hmc_leap, dim3(nblk(h->ndim)), dim3(TPB), 0, h->stream, st->v, st->x, st->dS, cv, cx, (long long)h->ndim);
+    const long long n = (long long)h->ndim * st->nch;
+    hipLaunchKernelGGL(k_hmc_leap, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->v, st->x, st->dS, cv, cx, n);
     return chk("k_hmc_leap");
+}
+
+// host [nvec][ndim] (reference layout) -> device layout S, staged through the handle's staging buffer (cap = 2 nch vectors)
+int upload_vectors(elph_handle_s *h, double *dstS, const double *host, int nvec) {
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, host, (size_t)nvec * (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return elph_launch_r2s(h, dstS, h->d_stage_in, nvec);
 }
 
 HmcState *state_of(elph_handle_s *h) { return static_cast<HmcState *>(h->hmc); }
@@ -271,51 +303,55 @@ void elph_hmc_free(elph_handle_s *h) {
         HIPCHK(hipSetDevice((h)->device));            \
     } while (0)
 
-extern "C" int elph_hmc_create(elph_handle h, const double *omega, const double *omega4, const double *lambda,
-                               const double *lambda2, const double *mu, double dtau, const double *fa_mass) {
+extern "C" int elph_hmc_create_chains(elph_handle h, int nchains, const double *omega, const double *omega4, const double *lambda,
+                                      const double *lambda2, const double *mu, double dtau, const double *fa_mass) {
     CHECK_H(h);
     if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("HMC trajectory: Holstein handles only"); return ELPH_E_UNSUPPORTED; }
-    if (!omega || !omega4 || !lambda || !lambda2 || !mu || !fa_mass || !(dtau > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    RC(elph_i_ensure_capacity(h, 2));
-    if (h->nchains != 1) { h->nchains = 1; elph_i_drop_graphs(h); }
+    if (nchains < 1 || !omega || !omega4 || !lambda || !lambda2 || !mu || !fa_mass || !(dtau > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    RC(elph_i_ensure_capacity(h, 2 * nchains));
+    RC(elph_i_reserve_chains(h, nchains));
     elph_hmc_free(h);
     HmcState *st = new HmcState();
     h->hmc = st;
-    const size_t nd = (size_t)h->ndim, N = (size_t)h->N;
-    double **vecs[] = {&st->x, &st->v, &st->x0, &st->v0, &st->dS, &st->y, &st->faM};
-    for (double **p : vecs) HIPCHK(hipMalloc((void **)p, nd * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&st->R2, 2 * nd * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&st->phi, 2 * nd * sizeof(double)));
+    st->nch = nchains;
+    const size_t nd = (size_t)h->ndim, N = (size_t)h->N, nc = (size_t)nchains;
+    double **vecs[] = {&st->x, &st->v, &st->x0, &st->v0, &st->dS, &st->y};
+    for (double **p : vecs) HIPCHK(hipMalloc((void **)p, nc * nd * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&st->faM, nd * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&st->R2, 2 * nc * nd * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&st->phi, 2 * nc * nd * sizeof(double)));
     HIPCHK(hipMalloc((void **)&st->par, 2 * N * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&st->part, 3 * (size_t)h->L * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&st->part, 2 * nc * (size_t)h->L * sizeof(double)));
     st->dtau = dtau;
     HIPCHK(hipMemcpyAsync(st->par, omega, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(st->par + N, omega4, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_stage_in, fa_mass, nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(h, st->faM, h->d_stage_in, 1));
-    HIPCHK(hipMemsetAsync(st->v, 0, nd * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(st->x, 0, nd * sizeof(double), h->stream));
+    RC(upload_vectors(h, st->faM, fa_mass, 1));
+    HIPCHK(hipMemsetAsync(st->v, 0, nc * nd * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st->x, 0, nc * nd * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return ELPH_OK;
 }
 
+extern "C" int elph_hmc_create(elph_handle h, const double *omega, const double *omega4, const double *lambda,
+                               const double *lambda2, const double *mu, double dtau, const double *fa_mass) {
+    return elph_hmc_create_chains(h, 1, omega, omega4, lambda, lambda2, mu, dtau, fa_mass);
+}
+
+// x, v: double[nchains * ndim] (chain-major, reference layout inside a chain); NULL = leave
 extern "C" int elph_hmc_set_state(elph_handle h, const double *x, const double *v) {
     CHECK_H(h);
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
-    const size_t bytes = (size_t)h->ndim * sizeof(double);
     if (x) {
-        HIPCHK(hipMemcpyAsync(h->d_stage_in, x, bytes, hipMemcpyHostToDevice, h->stream));
-        RC(elph_launch_r2s(h, st->x, h->d_stage_in, 1));
+        RC(upload_vectors(h, st->x, x, st->nch));
         HIPCHK(hipStreamSynchronize(h->stream));
         st->have_state = true;
     }
     if (v) {
-        HIPCHK(hipMemcpyAsync(h->d_stage_in, v, bytes, hipMemcpyHostToDevice, h->stream));
-        RC(elph_launch_r2s(h, st->v, h->d_stage_in, 1));
+        RC(upload_vectors(h, st->v, v, st->nch));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return ELPH_OK;
@@ -325,64 +361,79 @@ extern "C" int elph_hmc_get_state(elph_handle h, double *x, double *v) {
     CHECK_H(h);
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
-    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    const size_t bytes = (size_t)st->nch * (size_t)h->ndim * sizeof(double);
     if (x) {
-        RC(elph_launch_s2r(h, h->d_stage_out, st->x, 1));
+        RC(elph_launch_s2r(h, h->d_stage_out, st->x, st->nch));
         HIPCHK(hipMemcpyAsync(x, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     if (v) {
-        RC(elph_launch_s2r(h, h->d_stage_out, st->v, 1));
+        RC(elph_launch_s2r(h, h->d_stage_out, st->v, st->nch));
         HIPCHK(hipMemcpyAsync(v, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return ELPH_OK;
 }
 
-extern "C" int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, double alpha, int use_precond, const double *R,
-                               const double *Rp, const double *Rm, const double *kpm_randn, double u_accept, int *accepted,
-                               double *iters_per_solve, double *energies, int *flag_out) {
+// One HMC update of every chain, in lockstep: the leapfrog schedule is common, each chain has its own field, momenta,
+// pseudofermions, energies, Metropolis test and failure flag.  A chain whose solve fails (flag > 0, HMC.jl:405-408) is
+// dead for this update: its field is put back to x0 at once (so that its remaining — ignored — solves stay cheap) and
+// it is rejected at the end.
+extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double alpha, int use_precond, const double *R,
+                                      const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept,
+                                      int *accepted, double *iters_per_solve, double *energies, int *flag_out) {
     CHECK_H(h);
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
     if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
-    if (!R || !Rp || !Rm || !accepted || nt < 0 || nb < 1 || !(alpha >= 0.0 && alpha < 1.0) || !(dt > 0.0)) {
+    if (!R || !Rp || !Rm || !u_accept || !accepted || nt < 0 || nb < 1 || !(alpha >= 0.0 && alpha < 1.0) || !(dt > 0.0)) {
         elph_set_error("bad argument");
         return ELPH_E_ARG;
     }
     if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
-    RC(elph_i_ensure_capacity(h, 2));
-    if (h->nchains != 1) { h->nchains = 1; elph_i_drop_graphs(h); }
-    const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double);
-    const long long n = (long long)nd;
+    const int nch = st->nch;
+    RC(elph_i_ensure_capacity(h, 2 * nch));
+    RC(elph_i_reserve_chains(h, nch));
+    const size_t nd = (size_t)h->ndim, cbytes = nd * sizeof(double), bytes = (size_t)nch * cbytes;
+    const long long n = (long long)nd * nch;
     const double dtp = dt / (double)nb;
-    int64_t iters = 0, itrs = 0, kpm_calls = 0;
-    int flag = 0;
-    double H0 = 0, H1 = 0, S = 0, K = 0;
+    int64_t kpm_calls = 0;
+    std::vector<int64_t> iters((size_t)nch, 0), itrs((size_t)nch, 0);
+    std::vector<int> flag((size_t)nch, 0), dead((size_t)nch, 0);
+    std::vector<double> H0((size_t)nch, 0.0), H1((size_t)nch, 0.0), S((size_t)nch, 0.0), K((size_t)nch, 0.0), P((size_t)nch, 0.0);
+    auto bury = [&]() -> int {              // chains that just failed: remember the flag, restore their field
+        for (int c = 0; c < nch; ++c)
+            if (flag[(size_t)c] > 0 && !dead[(size_t)c]) {
+                dead[(size_t)c] = flag[(size_t)c];
+                HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nd, st->x0 + (size_t)c * nd, cbytes, hipMemcpyDeviceToDevice, h->stream));
+            }
+        return ELPH_OK;
+    };
+    auto all_dead = [&]() { for (int c = 0; c < nch; ++c) if (!dead[(size_t)c]) return false; return true; };
 
     RC(update_model(h, st));
     // refresh_v!  (HMC.jl:648-659)
-    HIPCHK(hipMemcpyAsync(h->d_stage_in, R, bytes, hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(h, st->y, h->d_stage_in, 1));
+    RC(upload_vectors(h, st->y, R, nch));
     RC(fa(h, st, st->y, st->y, -0.5));
     hipLaunchKernelGGL(k_hmc_refresh_v, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->v, st->y, alpha, n);
     RC(chk("k_hmc_refresh_v"));
     HIPCHK(hipMemcpyAsync(st->x0, st->x, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(st->v0, st->v, bytes, hipMemcpyDeviceToDevice, h->stream));
-    // refresh_ϕ!  (HMC.jl:665-692): ϕ± = Λ⁻¹ Mᵀ R±
-    HIPCHK(hipMemcpyAsync(h->d_stage_in, Rp, bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, Rm, bytes, hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(h, st->R2, h->d_stage_in, 2));
-    RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2));
+    // refresh_ϕ!  (HMC.jl:665-692): ϕ± = Λ⁻¹ Mᵀ R±      (R2, ϕ: [sign][chain][ndim])
+    RC(upload_vectors(h, st->R2, Rp, nch));
+    RC(upload_vectors(h, st->R2 + (size_t)nch * nd, Rm, nch));
+    RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2 * nch));
     hipLaunchKernelGGL(k_hmc_phi, dim3(nblk(n), 2), dim3(TPB), 0, h->stream, st->phi, h->d_b, st->x, h->d_lam, (int)h->N, (int)h->L,
-                       st->dtau);
+                       st->dtau, nch);
     RC(chk("k_hmc_phi"));
 
-    RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, &itrs, &flag));
-    if (nb == 1) iters = itrs;        // standard_update! :373.  multitimestep_update! :507 has "iters += iters": not counted
-    if (flag == 0) {
-        RC(calc_H(h, st, &H0, &S, &K));
+    RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, itrs.data(), flag.data()));
+    // standard_update! :373 counts these iterations;  multitimestep_update! :507 has "iters += iters": not counted
+    if (nb == 1) for (int c = 0; c < nch; ++c) iters[(size_t)c] = itrs[(size_t)c];
+    RC(bury());
+    if (!all_dead()) {
+        RC(calc_H(h, st, H0.data(), S.data(), K.data()));
         RC(force(h, st, nb == 1));
         for (int64_t t = 1; t <= nt; ++t) {
             if (nb == 1) {
@@ -396,35 +447,62 @@ extern "C" int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, dou
                     RC(leap(h, st, dtp / 2, 0.0));
                 }
             }
+            for (int c = 0; c < nch; ++c)       // a dead chain idles at its old field
+                if (dead[(size_t)c])
+                    HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nd, st->x0 + (size_t)c * nd, cbytes, hipMemcpyDeviceToDevice, h->stream));
             RC(update_model(h, st));
-            RC(calc_OinvLphi(h, st, use_precond, 1.0, kpm_randn, &kpm_calls, &itrs, &flag));
-            iters += itrs;
-            if (flag > 0) break;                                               // :405-408
+            RC(calc_OinvLphi(h, st, use_precond, 1.0, kpm_randn, &kpm_calls, itrs.data(), flag.data()));
+            for (int c = 0; c < nch; ++c) if (!dead[(size_t)c]) iters[(size_t)c] += itrs[(size_t)c];
+            RC(bury());
+            if (all_dead()) break;                                             // :405-408
             RC(force(h, st, nb == 1));
             RC(leap(h, st, dt / 2, 0.0));                                      // :418
         }
     }
-    double P = 0.0;
-    if (flag == 0) {
-        RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, &itrs, &flag));
-        iters += itrs;
-        if (flag == 0) {
-            RC(calc_H(h, st, &H1, &S, &K));
-            const double e = exp(-(H1 - H0));
-            P = (1.0 < e) ? 1.0 : e;                                           // min(1, exp(-ΔH)); NaN -> NaN -> reject, like Julia
+    if (!all_dead()) {
+        RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, itrs.data(), flag.data()));
+        for (int c = 0; c < nch; ++c) if (!dead[(size_t)c]) iters[(size_t)c] += itrs[(size_t)c];
+        RC(bury());
+        if (!all_dead()) {
+            RC(calc_H(h, st, H1.data(), S.data(), K.data()));
+            for (int c = 0; c < nch; ++c) {
+                if (dead[(size_t)c]) continue;
+                const double e = exp(-(H1[(size_t)c] - H0[(size_t)c]));
+                P[(size_t)c] = (1.0 < e) ? 1.0 : e;                            // min(1, exp(-ΔH)); NaN -> NaN -> reject, like Julia
+            }
         }
     }
-    const int acc = (u_accept < P && flag == 0) ? 1 : 0;                       // :441
-    if (!acc) {
-        HIPCHK(hipMemcpyAsync(st->x, st->x0, bytes, hipMemcpyDeviceToDevice, h->stream));
-        hipLaunchKernelGGL(k_hmc_neg, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->v, st->v0, n);
-        RC(chk("k_hmc_neg"));
-        RC(update_model(h, st));
+    bool any_reject = false;
+    for (int c = 0; c < nch; ++c) {
+        const int acc = (!dead[(size_t)c] && u_accept[c] < P[(size_t)c]) ? 1 : 0;      // :441
+        accepted[c] = acc;
+        if (!acc) {
+            any_reject = true;
+            HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nd, st->x0 + (size_t)c * nd, cbytes, hipMemcpyDeviceToDevice, h->stream));
+            hipLaunchKernelGGL(k_hmc_neg, dim3(nblk((long long)nd)), dim3(TPB), 0, h->stream, st->v + (size_t)c * nd,
+                               st->v0 + (size_t)c * nd, (long long)nd);
+            RC(chk("k_hmc_neg"));
+        }
     }
+    if (any_reject) RC(update_model(h, st));
     HIPCHK(hipStreamSynchronize(h->stream));
-    *accepted = acc;
-    if (iters_per_solve) *iters_per_solve = (double)((iters + (nt + 2) - 1) / (nt + 2));   // T1(cld(iters, Nt+2))
-    if (energies) { energies[0] = H0; energies[1] = H1; energies[2] = S; energies[3] = K; energies[4] = P; }
-    if (flag_out) *flag_out = flag;
+    for (int c = 0; c < nch; ++c) {
+        if (iters_per_solve) iters_per_solve[c] = (double)((iters[(size_t)c] + (nt + 2) - 1) / (nt + 2));   // T1(cld(iters, Nt+2))
+        if (energies) {
+            double *e = energies + 5 * (size_t)c;
+            e[0] = H0[(size_t)c]; e[1] = H1[(size_t)c]; e[2] = S[(size_t)c]; e[3] = K[(size_t)c]; e[4] = P[(size_t)c];
+        }
+        if (flag_out) flag_out[c] = dead[(size_t)c];
+    }
     return ELPH_OK;
+}
+
+extern "C" int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, double alpha, int use_precond, const double *R,
+                               const double *Rp, const double *Rm, const double *kpm_randn, double u_accept, int *accepted,
+                               double *iters_per_solve, double *energies, int *flag_out) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (st && st->nch != 1) { elph_set_error("%d chains: use elph_hmc_update_chains", st->nch); return ELPH_E_STATE; }
+    return elph_hmc_update_chains(h, dt, nt, nb, alpha, use_precond, R, Rp, Rm, kpm_randn, &u_accept, accepted, iters_per_solve,
+                                  energies, flag_out);
 }

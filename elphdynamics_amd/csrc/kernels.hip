@@ -669,13 +669,15 @@ __global__ void __launch_bounds__(WAVE) k_copy_dot(double *__restrict__ zp, cons
 __global__ void __launch_bounds__(WAVE) k_lambda_rhs(double *__restrict__ b, const double *__restrict__ phi,
                                                      const double *__restrict__ xS, const double *__restrict__ lam3,
                                                      int N, int L, double dtau) {
-    const int t = blockIdx.x, v = blockIdx.y;
+    // vectors are laid out [sign v][chain c][ndim]; x is [chain][ndim]   (one chain: gridDim.z == 1)
+    const int t = blockIdx.x, v = blockIdx.y, c = blockIdx.z, nch = gridDim.z;
+    const size_t ndim = (size_t)N * L, vo = ((size_t)v * nch + c) * ndim;
     const int tp1 = (t == L - 1) ? 0 : t + 1;
     const double sg = (t == L - 1) ? 1.0 : -1.0;            // (Λϕ)[τ] = -Λ[τ+1]ϕ[τ+1];  (Λϕ)[Lτ] = +Λ[1]ϕ[1]
     for (int s = threadIdx.x; s < N; s += WAVE) {
-        const double x = xS[(size_t)tp1 * N + s];
+        const double x = xS[(size_t)c * ndim + (size_t)tp1 * N + s];
         const double Lam = exp(-dtau * (lam3[s] * x + lam3[N + s] * (x * x)) / 2);
-        b[(size_t)v * N * L + (size_t)t * N + s] = sg * Lam * phi[(size_t)v * N * L + (size_t)tp1 * N + s];
+        b[vo + (size_t)t * N + s] = sg * Lam * phi[vo + (size_t)tp1 * N + s];
     }
 }
 
@@ -687,18 +689,20 @@ __global__ void __launch_bounds__(1024) k_force_holstein(double *__restrict__ F,
     double *bufA = lds, *bufB = lds + m.N;
     const int N = m.N, L = m.L;
     const size_t ndim = (size_t)N * L;
-    const int t = blockIdx.x;
+    const int t = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;          // X, phi: [sign][chain][ndim]; F, x: [chain][ndim]
+    const size_t minus = (size_t)nch * ndim;                             // offset of the "-" pseudofermion block
+    X += (size_t)ch * ndim; phi += (size_t)ch * ndim; xS += (size_t)ch * ndim; F += (size_t)ch * ndim;
     const int tm1 = (t == 0) ? L - 1 : t - 1;
     const double sg = (t == 0) ? -1.0 : 1.0;
     const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
-    const double *E0 = m.E + (size_t)t * m.E_tau_stride;   // force kernel: single chain
+    const double *E0 = m.E + (size_t)(ch % m.nchains) * m.E_chain_stride + (size_t)t * m.E_tau_stride;
     double xmp[NPL], xmm[NPL], x0p[NPL], x0m[NPL], e[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * blockDim.x;
         if (s < N) {
-            xmp[q] = X[(size_t)tm1 * N + s]; xmm[q] = X[ndim + (size_t)tm1 * N + s];
-            x0p[q] = X[(size_t)t * N + s]; x0m[q] = X[ndim + (size_t)t * N + s];
+            xmp[q] = X[(size_t)tm1 * N + s]; xmm[q] = X[minus + (size_t)tm1 * N + s];
+            x0p[q] = X[(size_t)t * N + s]; x0m[q] = X[minus + (size_t)t * N + s];
             e[q] = E0[s];
             bufA[s] = e[q] * xmp[q];
             bufB[s] = e[q] * xmm[q];
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(1024) k_force_holstein(double *__restrict__ F,
             const double Lam = exp(-dtau * (lam * x + lam2 * (x * x)) / 2);
             const double gM = sg * dtau * (lam + 2 * lam2 * x) * e[q];        // muldMdx! (HolsteinModels.jl:727-741)
             const double gL = sg * dtau * (lam / 2 + lam2 * x) * Lam;         // muldΛdx! (HMC.jl:1015-1022)
-            F[i] = -(bufA[s] * (gM * xmp[q])) - (bufB[s] * (gM * xmm[q])) + phi[i] * (gL * xmp[q]) + phi[ndim + i] * (gL * xmm[q]);
+            F[i] = -(bufA[s] * (gM * xmp[q])) - (bufB[s] * (gM * xmm[q])) + phi[i] * (gL * xmp[q]) + phi[minus + i] * (gL * xmm[q]);
         }
     }
 }
@@ -1100,22 +1104,24 @@ int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS_fu
 }
 
 int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power,
-                          int64_t ncol) {
-    return elph_dft_accel(h, outS, inS, diagS, power, (int)ncol, h->d_nu);
+                          int64_t ncol, int nvec) {
+    return elph_dft_accel(h, outS, inS, diagS, power, (int)ncol, h->d_nu, nvec);
 }
 
-int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau) {
-    hipLaunchKernelGGL(k_lambda_rhs, dim3((unsigned)h->L, 2), dim3(WAVE), 0, h->stream, bS, phiS, xS, h->d_lam, (int)h->N,
-                       (int)h->L, dtau);
+// nch chains: b, phi laid out [sign][chain][ndim], x [chain][ndim]
+int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau, int nch) {
+    hipLaunchKernelGGL(k_lambda_rhs, dim3((unsigned)h->L, 2, (unsigned)nch), dim3(WAVE), 0, h->stream, bS, phiS, xS, h->d_lam,
+                       (int)h->N, (int)h->L, dtau);
     return check_launch("k_lambda_rhs");
 }
 
-int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau) {
+int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau,
+                               int nch) {
     ModelDev m = elph_model_dev(h);
     const size_t shm = 2 * (size_t)h->N * sizeof(double);
     DISPATCH_NPL(gen_npl(h), {
-        hipLaunchKernelGGL((k_force_holstein<NPL>), dim3((unsigned)h->L), dim3((unsigned)gen_bs(h)), shm, h->stream, FS, XS, phiS,
-                           xS, h->d_lam, m, dtau);
+        hipLaunchKernelGGL((k_force_holstein<NPL>), dim3((unsigned)h->L, (unsigned)nch), dim3((unsigned)gen_bs(h)), shm, h->stream, FS,
+                           XS, phiS, xS, h->d_lam, m, dtau);
     });
     return check_launch("k_force_holstein");
 }

@@ -159,7 +159,10 @@ class HybridMonteCarlo:
     x, v, ϕ±, O⁻¹Λϕ± and dS/dx live on the GPU between updates; `model.x` / `hmc.v` on the host are refreshed by
     `pull_()` (and pushed by `push_()` after the host changed them)."""
 
-    def __init__(self, model, fa, dt, tr, alpha=0.0, Nb=1):
+    def __init__(self, model, fa, dt, tr, alpha=0.0, Nb=1, nchains=1):
+        """nchains > 1: that many Markov chains of the same deck advance in lockstep on this handle (every force
+        evaluation is one batched solve of 2*nchains right-hand sides); their fields / momenta are self.X / self.V
+        (nchains, Ndof) and model.x / hmc.v are not used."""
         assert 0.0 <= alpha < 1.0                                   # HMC.jl:182
         if model.kind != models.HOLSTEIN:
             raise NotImplementedError("device-resident HMC trajectory: Holstein models")
@@ -168,23 +171,34 @@ class HybridMonteCarlo:
         self.Nt = int(round(tr / dt))                               # :206
         self.dtp = self.dt / self.Nb                                # :209
         self.Ndof, self.Ndim = model.Ndof, model.Ndim
+        self.nchains = int(nchains)
         self.v = np.zeros(model.Ndof)
+        self.X = np.zeros((self.nchains, model.Ndof)) if self.nchains > 1 else None
+        self.V = np.zeros((self.nchains, model.Ndof)) if self.nchains > 1 else None
         self.updates, self.accepted, self.iters = 1, False, 0
         self.H = self.S = self.K = 0.0
         self.H0 = self.H1 = self.P_accept = 0.0
         self.flag = 0
         from ._lib import check, dptr
-        check(model._lib.elph_hmc_create(model._h, dptr(model.omega), dptr(model.omega4), dptr(model.lam), dptr(model.lam2),
-                                         dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.M))))
-        self.push_()
+        check(model._lib.elph_hmc_create_chains(model._h, self.nchains, dptr(model.omega), dptr(model.omega4), dptr(model.lam),
+                                                dptr(model.lam2), dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.M))))
+        model._nchains = self.nchains
+        if self.nchains == 1:
+            self.push_()
 
     def push_(self):
         from ._lib import check, dptr
-        check(self.model._lib.elph_hmc_set_state(self.model._h, dptr(np.ascontiguousarray(self.model.x)), dptr(self.v)))
+        if self.nchains > 1:
+            check(self.model._lib.elph_hmc_set_state(self.model._h, dptr(np.ascontiguousarray(self.X)), dptr(np.ascontiguousarray(self.V))))
+        else:
+            check(self.model._lib.elph_hmc_set_state(self.model._h, dptr(np.ascontiguousarray(self.model.x)), dptr(self.v)))
 
     def pull_(self):
         from ._lib import check, dptr
-        check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self.model.x), dptr(self.v)))
+        if self.nchains > 1:
+            check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self.X), dptr(self.V)))
+        else:
+            check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self.model.x), dptr(self.v)))
 
 
 def draw_randoms(hmc, rng, with_kpm):
@@ -221,6 +235,38 @@ def update_(model, hmc, fa=None, P=None, rng=None, randoms=None, pull=True):
     hmc.H0, hmc.H1, hmc.S, hmc.K, hmc.P_accept = (float(e) for e in en)
     hmc.H = hmc.H1
     hmc.updates += 1                                                # :329
+    if pull:
+        hmc.pull_()
+    return hmc.accepted, hmc.iters
+
+
+def draw_randoms_chains(hmc, rng, with_kpm):
+    """Per chain what draw_randoms draws for one; kpm_randn is [(Nt+2)][b_max|b_min][chain][Nsites]."""
+    m, nch = hmc.model, hmc.nchains
+    return dict(R=rng.standard_normal((nch, m.Ndof)), Rp=rng.standard_normal((nch, m.Ndim)), Rm=rng.standard_normal((nch, m.Ndim)),
+                kpm_randn=rng.standard_normal((hmc.Nt + 2, 2, nch, m.Nsites)) if with_kpm else None, u=rng.random(nch))
+
+
+def update_chains_(model, hmc, fa=None, P=None, rng=None, randoms=None, pull=False):
+    """One HMC update of every chain of `hmc` (nchains Markov chains in lockstep, one batched solve per force / action
+    evaluation).  Returns (accepted[nchains] bool, iters[nchains]); per-chain energies in hmc.energies (nchains, 5) =
+    H0, H1, S, K, acceptance probability; hmc.flags[nchains] > 0 marks chains rejected because a solve failed."""
+    import ctypes as C
+    from ._lib import P_int, check, dptr
+    nch = hmc.nchains
+    if randoms is None:
+        randoms = draw_randoms_chains(hmc, rng or np.random.default_rng(), P is not None)
+    model._push_solver()
+    acc = np.zeros(nch, dtype=np.int32)
+    fl = np.zeros(nch, dtype=np.int32)
+    its, en = np.zeros(nch), np.zeros((nch, 5))
+    c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
+    kr = randoms.get("kpm_randn")
+    check(model._lib.elph_hmc_update_chains(
+        model._h, hmc.dt, hmc.Nt, hmc.Nb, hmc.alpha, 0 if P is None else 1, c(randoms["R"]), c(randoms["Rp"]), c(randoms["Rm"]),
+        c(kr) if kr is not None else None, c(randoms["u"]), acc.ctypes.data_as(P_int), dptr(its), dptr(en), fl.ctypes.data_as(P_int)))
+    hmc.accepted, hmc.iters, hmc.flags, hmc.energies = acc.astype(bool), its, fl, en
+    hmc.updates += 1
     if pull:
         hmc.pull_()
     return hmc.accepted, hmc.iters

@@ -234,6 +234,20 @@ int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, double alpha, 
                     const double *Rp, const double *Rm, const double *kpm_randn, double u_accept, int *accepted,
                     double *iters_per_solve, double *energies, int *flag);
 
+/* Several Markov chains (same deck, independent phonon fields — the reference runs them as separate processes,
+ * ElPhDynamics.jl:90-95) advanced in LOCKSTEP by one handle: the leapfrog schedule is common, every chain has its own
+ * x, v, ϕ±, energies, Metropolis test and failure flag, and all 2·nchains pseudofermion solves of a force / action
+ * evaluation run as ONE batched CG (with use_precond: one KPM expansion per chain, elph_kpm_setup_chains).
+ * elph_hmc_create_chains replaces elph_hmc_create; elph_hmc_set_state / _get_state then move double[nchains * ndim]
+ * (chain-major).  elph_hmc_update_chains: R [nchains*Ndof], Rp, Rm [nchains*Ndim] chain-major;
+ * kpm_randn [(nt+2)][2 (b_max, b_min)][nchains][nsites]; u_accept, accepted, iters_per_solve, flag [nchains];
+ * energies [nchains][5].  A chain whose linear solve fails is rejected (flag > 0) without stopping the others. */
+int elph_hmc_create_chains(elph_handle h, int nchains, const double *omega, const double *omega4, const double *lambda,
+                           const double *lambda2, const double *mu, double dtau, const double *fa_mass);
+int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double alpha, int use_precond, const double *R,
+                           const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept, int *accepted,
+                           double *iters_per_solve, double *energies, int *flag);
+
 /* ---------------------------------------------------------------- Green's-function estimator */
 
 /* EstimateGreensFunction(model, n_v) — GreensFunctions.jl:155-195.  norbits*L1*L2*L3 must equal nsites

@@ -213,3 +213,52 @@ def test_hmc_error_paths():
     rc = lib.elph_hmc_create(e._h, dptr(one), dptr(one), dptr(one), dptr(one), dptr(one), e.dtau, dptr(np.ones(e.Ndim)))
     assert rc == _lib.ELPH_E_UNSUPPORTED                            # SSH: not built
     e.close()
+
+
+@pytest.mark.parametrize("tag,nch,nb,with_kpm", [("b", 3, 1, False), ("B", 4, 3, True), ("d", 2, 1, True)])
+def test_hmc_chains_in_lockstep_equal_single_chain_updates(tag, nch, nb, with_kpm):
+    """elph_hmc_update_chains: nch Markov chains advanced in lockstep by one handle (all 2*nch pseudofermion solves of an
+    evaluation as one batch, one KPM expansion per chain) — every chain ends where the single-chain update ends when it
+    is given the same field, momenta and random numbers; accept/reject is taken per chain."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc, synth
+    nt, dt = 4, 0.05
+    m = configs.make_model(tag, tol=1e-9, maxiter=20000)
+    m.omega4[:] = 0.02
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+    X0 = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=900 + c) for c in range(nch)])
+    V0 = np.stack([0.3 * synth.randn(950 + c, m.Ndof) for c in range(nch)])
+    rnd = dict(R=np.stack([synth.randn(1000 + c, m.Ndof) for c in range(nch)]),
+               Rp=np.stack([synth.randn(1100 + c, m.Ndim) for c in range(nch)]),
+               Rm=np.stack([synth.randn(1200 + c, m.Ndim) for c in range(nch)]),
+               kpm_randn=synth.randn(1300, (nt + 2) * 2 * nch * m.Nsites).reshape(nt + 2, 2, nch, m.Nsites) if with_kpm else None,
+               u=np.array([0.0 if c % 2 == 0 else 1.5 for c in range(nch)]))     # even chains accept; u > 1 forces the odd ones to reject
+    H = hmc.HybridMonteCarlo(m, fa, dt=dt, tr=nt * dt, alpha=0.2, Nb=nb, nchains=nch)
+    H.X[:], H.V[:] = X0, V0
+    H.push_()
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0) if with_kpm else None
+    acc, its = hmc.update_chains_(m, H, fa, P, randoms=rnd, pull=True)
+    assert not H.flags.any()
+    Xb, Vb, Eb = H.X.copy(), H.V.copy(), H.energies.copy()
+    m.close()
+    for c in range(nch):
+        m1 = configs.make_model(tag, tol=1e-9, maxiter=20000)
+        m1.omega4[:] = 0.02
+        fa1 = pc.FourierAccelerator(m1)
+        pc.update_M_(fa1, m1, 0.0, np.inf, 1.0, 0.3)
+        m1.x[:] = X0[c]
+        H1 = hmc.HybridMonteCarlo(m1, fa1, dt=dt, tr=nt * dt, alpha=0.2, Nb=nb)
+        H1.v[:] = V0[c]
+        H1.push_()
+        P1 = pc.SymmetricKPMPreconditioner(m1, 20, 0.05, 1.0, 1.0) if with_kpm else None
+        r1 = dict(R=rnd["R"][c], Rp=rnd["Rp"][c], Rm=rnd["Rm"][c],
+                  kpm_randn=np.ascontiguousarray(rnd["kpm_randn"][:, :, c, :]) if with_kpm else None, u=float(rnd["u"][c]))
+        a1, i1 = hmc.update_(m1, H1, fa1, P1, randoms=r1)
+        assert a1 == bool(acc[c]) and H1.flag == 0
+        assert abs(i1 - its[c]) <= 1
+        assert abs(H1.H0 - Eb[c, 0]) < 1e-8 * abs(H1.H0) and abs(H1.H1 - Eb[c, 1]) < 1e-8 * abs(H1.H1)
+        assert np.abs(m1.x - Xb[c]).max() < 1e-7 * np.abs(m1.x).max() and np.abs(H1.v - Vb[c]).max() < 1e-7 * max(np.abs(H1.v).max(), 1.0)
+        if not a1:      # rejected: field restored bit-exactly, momenta flipped (HMC.jl:447-456)
+            assert np.array_equal(Xb[c], X0[c])
+        m1.close()
+    assert acc[0] and (nch < 2 or not acc[1])
