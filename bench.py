@@ -269,6 +269,56 @@ def main():
             except Exception as e:
                 out["time_to_solution_tol1e-5"] = {"error": str(e)}
 
+        # ---- secondary: whole HMC updates (the caller of the path): chains in lockstep on the GPU vs the CPU
+        # oracle's single chain (the reference's configuration), KPM-preconditioned, same deck
+        if not args.no_sweep and m.kind == 0:
+            try:
+                from elphdynamics_amd import hmc as ehmc
+                nt_g, dt_h = 10, 0.01
+                hm = {}
+                for nch_h in (1, args.chains):
+                    mh = configs.make_model(args.config, tol=1e-5, maxiter=20000, device=local_rank if world > 1 else 0)
+                    fah = pc.FourierAccelerator(mh)
+                    pc.update_M_(fah, mh, 0.0, np.inf, 1.0, 0.1)
+                    Hh = ehmc.HybridMonteCarlo(mh, fah, dt=dt_h, tr=nt_g * dt_h, alpha=0.0, Nb=1, nchains=nch_h)
+                    if nch_h > 1:
+                        Hh.X[:] = np.stack([synth.phonon_field(mh.Nph, mh.Ltau, mh.beta, mh.dtau, seed=100 + 17 * c) for c in range(nch_h)])
+                        Hh.push_()
+                    Ph = pc.SymmetricKPMPreconditioner(mh, 20, 0.05, 1.0, 1.0)
+                    rngh = np.random.default_rng(3)
+                    upd = (lambda: ehmc.update_chains_(mh, Hh, fah, Ph, rng=rngh)) if nch_h > 1 else (lambda: ehmc.update_(mh, Hh, fah, Ph, rng=rngh, pull=False))
+                    upd()
+                    tq = time.perf_counter()
+                    acc_h, its_h = upd()
+                    dth = time.perf_counter() - tq
+                    hm[f"gpu_chains{nch_h}"] = {"nt": nt_g, "ms_per_update": 1e3 * dth, "ms_per_chain_update": 1e3 * dth / nch_h,
+                                               "chain_evaluations_per_sec": nch_h * (nt_g + 2) / dth,
+                                               "iters_per_solve": float(np.mean(its_h)), "accepted": float(np.mean(acc_h))}
+                    mh.close()
+                if not args.no_cpu:
+                    from oracle.oracle import Oracle
+                    orc_h = Oracle(fast=True)
+                    mo = configs.make_model(args.config, tol=1e-5, maxiter=20000, device=local_rank if world > 1 else 0)
+                    fao = pc.FourierAccelerator(mo)
+                    pc.update_M_(fao, mo, 0.0, np.inf, 1.0, 0.1)
+                    Eo = orc_h.update_model_holstein(mo.Nsites, mo.Ltau, mo.dtau, mo.x, mo.lam, mo.lam2, mo.mu)
+                    omo = orc_h.make_model(0, mo.Nsites, mo.Ltau, mo.neighbor_table, mo.cosht, mo.sinht, Eo)
+                    Po = orc_h.make_kpm(omo, n=20)
+                    nt_c = 1
+                    rngc = np.random.default_rng(3)
+                    rnd = dict(R=rngc.standard_normal(mo.Ndof), Rp=rngc.standard_normal(mo.Ndim), Rm=rngc.standard_normal(mo.Ndim),
+                               kpm_randn=rngc.standard_normal((nt_c + 2) * 2 * mo.Nsites), u=0.5)
+                    tq = time.perf_counter()
+                    orc_h.hmc_update_holstein(omo, mo.x.copy(), np.zeros(mo.Ndof), mo.omega, mo.omega4, mo.lam, mo.lam2, mo.mu, mo.dtau,
+                                              fao.M, dt_h, nt_c, 1, 0.0, rnd, P=Po, tol=1e-5, maxiter=20000)
+                    dtc = time.perf_counter() - tq
+                    hm["cpu_oracle_1core"] = {"nt": nt_c, "s_per_update": dtc, "chain_evaluations_per_sec": (nt_c + 2) / dtc}
+                    hm["gpu_over_cpu_chain_evaluations"] = hm[f"gpu_chains{args.chains}"]["chain_evaluations_per_sec"] / hm["cpu_oracle_1core"]["chain_evaluations_per_sec"]
+                    mo.close()
+                out["hmc_update_kpm"] = hm
+            except Exception as e:
+                out["hmc_update_kpm"] = {"error": repr(e)}
+
         # ---- CPU baseline: the oracle, 1 thread, bounded sample of the same workload
         if not args.no_cpu:
             try:

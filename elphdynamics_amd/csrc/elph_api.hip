@@ -983,6 +983,7 @@ extern "C" int elph_kpm_create(elph_handle h, int n, double buf, double c1, doub
     h->lam_lo = 0.0; h->lam_hi = 2.0; h->lam_avg = 1.0; h->lam_mag = 1.0;
     h->kpm_chain.clear();
     h->kpm_nch = 1;
+    h->kpm_hop_uploaded = false;
     h->h_cbar.assign((size_t)h->nb, 0.0);
     h->h_sbar.assign((size_t)h->nb, 0.0);
     RC(dev_alloc(&h->d_cbar, (size_t)h->nb));
@@ -1080,7 +1081,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     RC(kpm_reserve(h, nch));
     // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)
     if (h->kind == ELPH_MODEL_HOLSTEIN) {
-        for (int c = 0; c < nch; ++c) RC(elph_launch_ebar(h, c));
+        RC(elph_launch_ebar(h, nch));
         HIPCHK(hipMemcpyAsync(h->h_Ebar.data(), h->d_Ebar, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->h_cbar = h->h_c;
@@ -1095,23 +1096,26 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
             h->h_sbar[n] = s / L;
         }
     }
-    if (h->nb > 0) {
+    // Holstein: c̄ = cosh(Δτ t), s̄ = sinh(Δτ t) never change after elph_create — upload their three device images once
+    const bool hop_fresh = !(h->kind == ELPH_MODEL_HOLSTEIN && h->kpm_hop_uploaded);
+    if (hop_fresh && h->nb > 0) {
         HIPCHK(hipMemcpy(h->d_cbar, h->h_cbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sbar, h->h_sbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
     }
-    if (h->fast) {
+    if (hop_fresh && h->fast_capable) {
         std::vector<double> lc((size_t)h->lp_ne * ELPH_WAVE), ls((size_t)h->lp_ne * ELPH_WAVE);
         elph_lp_pack(h, h->h_cbar.data(), lc.data(), 1.0);
         elph_lp_pack(h, h->h_sbar.data(), ls.data(), 0.0);
         HIPCHK(hipMemcpy(h->d_lp_cbar, lc.data(), sizeof(double) * lc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_lp_sbar, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
     }
-    if (h->sq_P > 0) {
+    if (hop_fresh && h->sq_P > 0) {
         std::vector<double> qc((size_t)4 * h->N), qs((size_t)4 * h->N);
         for (size_t k = 0; k < qc.size(); ++k) { qc[k] = h->h_cbar[h->sq_bond[k]]; qs[k] = h->h_sbar[h->sq_bond[k]]; }
         HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sq_sbar, qs.data(), sizeof(double) * qs.size(), hipMemcpyHostToDevice));
     }
+    h->kpm_hop_uploaded = true;
     const int was_active = h->kpm_active;
     bool changed = !h->kpm_ready || resized;
     if (!(b_max && b_min))
@@ -1155,7 +1159,8 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         }
     };
     {
-        const int nthr = std::max(1, std::min(nch, std::min(32, (int)std::thread::hardware_concurrency())));
+        // ~0.1 ms of scalar work per chain; a thread costs ~30 us to start: one thread per 4 chains, at most 8
+        const int nthr = std::max(1, std::min(std::min(nch / 4, 8), (int)std::thread::hardware_concurrency()));
         if (nthr <= 1) {
             for (int c = 0; c < nch; ++c) one_chain(c);
         } else {

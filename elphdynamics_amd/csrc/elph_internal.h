@@ -214,6 +214,7 @@ struct elph_handle_s {
     double lam_lo = 0.0, lam_hi = 2.0, lam_avg = 1.0, lam_mag = 1.0;
     int kpm_active = 1;                    // 0: every chain's expansion is inactive (identity copy path)
     int kpm_nch = 1;                       // chains the expansion tables are built for
+    bool kpm_hop_uploaded = false;         // Holstein: c̄, s̄ (= cosh, sinh of the fixed hoppings) are on the device already
     struct KpmChainHost { double lam_lo = 0.0, lam_hi = 2.0; int active = 1; bool fresh = true;
                           std::vector<int> order; std::vector<double> coeff; };
     std::vector<KpmChainHost> kpm_chain;   // per chain: bounds, orders, coefficients (complex interleaved)
@@ -264,7 +265,7 @@ int elph_launch_residual(elph_handle_s *h, int nrhs);
 int elph_launch_cg_init_only(elph_handle_s *h, int nrhs);
 int elph_launch_cg_state0_only(elph_handle_s *h, int nrhs);
 int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode);
-int elph_launch_ebar(elph_handle_s *h, int chain = 0);
+int elph_launch_ebar(elph_handle_s *h, int nch = 1);
 int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int64_t ncol,
                           int nvec = 1);
 int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);

@@ -613,6 +613,8 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
 // (loads in flight instead of one dependent chain), phases combined through LDS.
 __global__ void __launch_bounds__(256) k_ebar(double *__restrict__ Ebar, const double *__restrict__ E, int N, int L) {
     __shared__ double part[4][64];
+    Ebar += (size_t)blockIdx.y * N;                    // blockIdx.y = chain
+    E += (size_t)blockIdx.y * (size_t)N * L;
     const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int s = blockIdx.x * 64 + lane;
     const int sc = (s < N) ? s : N - 1;
@@ -920,9 +922,10 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     return B;
 }
 
-int elph_launch_ebar(elph_handle_s *h, int chain) {
-    hipLaunchKernelGGL(k_ebar, dim3((unsigned)((h->N + 63) / 64)), dim3(256), 0, h->stream, h->d_Ebar + (size_t)chain * h->N,
-                       h->d_E + (size_t)chain * h->ndim, (int)h->N, (int)h->L);
+// Ē of the first `nch` resident chains in one launch
+int elph_launch_ebar(elph_handle_s *h, int nch) {
+    hipLaunchKernelGGL(k_ebar, dim3((unsigned)((h->N + 63) / 64), (unsigned)nch), dim3(256), 0, h->stream, h->d_Ebar, h->d_E,
+                       (int)h->N, (int)h->L);
     return check_launch("k_ebar");
 }
 
