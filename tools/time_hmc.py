@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from elphdynamics_amd import configs, models, hmc, preconditioners as pc, synth
 nt, dt = 20, 0.01
 for nch in ([int(a) for a in sys.argv[1:]] or [1, 8, 32]):

@@ -1,6 +1,6 @@
 import sys, time, ctypes as C
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from elphdynamics_amd import configs, models, preconditioners as pc
 from elphdynamics_amd._lib import check, dptr
 tag = sys.argv[1] if len(sys.argv) > 1 else "C"
