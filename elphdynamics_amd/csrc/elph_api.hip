@@ -346,7 +346,7 @@ extern "C" int elph_destroy(elph_handle h) {
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
-                    h->d_coeff, h->d_klam, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
+                    h->d_coeff, h->d_klam, h->d_ssh_x, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_cb, h->d_ssh_slot, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
                     h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -455,7 +455,90 @@ extern "C" int elph_update_model_ssh(elph_handle h, const double *cosht, const d
     }
     HIPCHK(hipMemcpy(h->d_E, expDtauMu, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
     RC(upload_lp_cs(h));
+    h->cs_host_stale = false;
     h->have_E = true;
+    return ELPH_OK;
+}
+
+// update_model!(ssh) computed ON THE DEVICE from the phonon fields (SSHModels.jl:510-562): no cosh/sinh on the host, no
+// (Ltau x Nbonds) tables over PCIe.
+//   x          double[nph * ltau]   ssh.x, field = (phonon-1) Ltau + tau
+//   cb_index   int64[nph]           1-based checkerboard position of each phonon's bond = checkerboard_perm[phonon_to_bond[p]]
+//   t_ph, alpha, alpha2  double[nph] bare hopping of that bond (ssh.t[bond]) and the couplings
+//   t_bare_cb  double[nbonds]       bare hopping of EVERY bond in checkerboard order (bonds without a phonon keep it)
+//   mu         double[nsites]
+// A bond is driven by at most one field per tau (equivalent fields carry equal x, :548-558).
+extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int64_t nph, const int64_t *cb_index, const double *t_ph,
+                                            const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu,
+                                            double dtau) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    if (nph < 0 || !mu || (h->nb > 0 && !t_bare_cb) || (nph > 0 && (!x || !cb_index || !t_ph || !alpha || !alpha2))) {
+        elph_set_error("null argument");
+        return ELPH_E_ARG;
+    }
+    const size_t L = (size_t)h->L, nb = (size_t)h->nb, np = (size_t)nph;
+    std::vector<int> cb0(np);
+    for (size_t p = 0; p < np; ++p) {
+        if (cb_index[p] < 1 || cb_index[p] > (int64_t)nb) { elph_set_error("cb_index[%zu] = %lld outside 1..%zu", p, (long long)cb_index[p], nb); return ELPH_E_ARG; }
+        cb0[p] = (int)(cb_index[p] - 1);
+    }
+    if (!h->d_ssh_slot) {     // once: lane-program slot of each checkerboard bond (the layout of elph_lp_pack)
+        std::vector<int> slot(std::max<size_t>(nb, 1), -1);
+        if (h->fast_capable) {
+            const int PP = (h->npl + 1) / 2;
+            for (int col = 0; col < h->ncol && col < 4; ++col)
+                for (int n = h->h_coloff[col]; n < h->h_coloff[col + 1]; ++n) {
+                    const int k = n - h->h_coloff[col];
+                    slot[(size_t)n] = (col * PP + k / ELPH_WAVE) * ELPH_WAVE + (k % ELPH_WAVE);
+                }
+            // idle lane-program slots: the identity bond (cosh, sinh) = (1, 0) on every slice
+            const size_t per = (size_t)h->lp_ne * ELPH_WAVE;
+            std::vector<double> one(L * per, 1.0), zero(L * per, 0.0);
+            HIPCHK(hipMemcpy(h->d_lp_c, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->d_lp_s, zero.data(), zero.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        RC(dev_alloc(&h->d_ssh_slot, slot.size()));
+        HIPCHK(hipMemcpy(h->d_ssh_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+        RC(dev_alloc(&h->d_ssh_tbare, std::max<size_t>(nb, 1)));
+    }
+    if ((int64_t)np > h->ssh_nph_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        RC(dev_alloc(&h->d_ssh_x, std::max<size_t>(np * L, 1)));
+        RC(dev_alloc(&h->d_ssh_par, std::max<size_t>(3 * np, 1)));
+        RC(dev_alloc(&h->d_ssh_cb, std::max<size_t>(np, 1)));
+        h->ssh_nph_cap = (int64_t)np;
+    }
+    if (np > 0) {
+        HIPCHK(hipMemcpyAsync(h->d_ssh_x, x, np * L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ssh_par, t_ph, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ssh_par + np, alpha, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ssh_par + 2 * np, alpha2, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ssh_cb, cb0.data(), np * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    if (nb > 0) HIPCHK(hipMemcpyAsync(h->d_ssh_tbare, t_bare_cb, nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam, mu, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_ssh_update(h, h->d_ssh_x, (int)np, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, dtau));
+    HIPCHK(hipStreamSynchronize(h->stream));       // cb0 / the caller's arrays may go away
+    h->cs_host_stale = true;
+    h->have_E = true;
+    return ELPH_OK;
+}
+
+// model.cosht / model.sinht as the reference stores them, (Ltau x Nbonds) column-major = [bond][tau] — for callers that
+// reach into those fields (KPMPreconditioners.jl:362-378) after a device-side update
+extern "C" int elph_get_cosh_sinh(elph_handle h, double *cosht, double *sinht) {
+    CHECK_H(h);
+    if (!cosht || !sinht) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    const size_t L = (h->kind == ELPH_MODEL_SSH) ? (size_t)h->L : 1, nb = (size_t)h->nb;
+    std::vector<double> c(L * nb), s(L * nb);
+    if (nb > 0) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(c.data(), h->d_c, c.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(s.data(), h->d_s, s.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    for (size_t n = 0; n < nb; ++n)
+        for (size_t t = 0; t < L; ++t) { cosht[n * L + t] = c[t * nb + n]; sinht[n * L + t] = s[t * nb + n]; }
     return ELPH_OK;
 }
 
@@ -1089,11 +1172,11 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     } else {
         HIPCHK(hipMemcpy(h->h_Ebar.data(), h->d_E, sizeof(double) * N, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(h->d_Ebar, h->d_E, sizeof(double) * N, hipMemcpyDeviceToDevice));
-        for (int64_t n = 0; n < h->nb; ++n) {
-            double c = 0.0, s = 0.0;
-            for (int t = 0; t < L; ++t) { c += h->h_c[(size_t)t * h->nb + n]; s += h->h_s[(size_t)t * h->nb + n]; }
-            h->h_cbar[n] = c / L;
-            h->h_sbar[n] = s / L;
+        if (h->nb > 0) {   // tau-means of cosht, sinht from the device tables (they may have been produced there)
+            RC(elph_launch_cs_bar(h, h->d_cbar, h->d_sbar));
+            HIPCHK(hipMemcpyAsync(h->h_cbar.data(), h->d_cbar, sizeof(double) * h->nb, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_sbar.data(), h->d_sbar, sizeof(double) * h->nb, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
         }
     }
     // Holstein: c̄ = cosh(Δτ t), s̄ = sinh(Δτ t) never change after elph_create — upload their three device images once

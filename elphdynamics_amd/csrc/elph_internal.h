@@ -161,6 +161,11 @@ struct elph_handle_s {
     bool fast_capable = false;             // lane-program kernels possible for this bond table (fast may be switched off)
     int solo_chain = -1;                   // >= 0: kernels see only this chain (single re-solve of one RHS of a chains batch)
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
+    // SSH update_model! on the device (elph_update_model_ssh_fields): staging of x, per-phonon tables, slot map
+    double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
+    int *d_ssh_cb = nullptr, *d_ssh_slot = nullptr;
+    int64_t ssh_nph_cap = 0;
+    bool cs_host_stale = false;            // SSH: d_c/d_s were produced on the device; h_c/h_s are not current
     // lane program (fast path, ncol <= 4)
     bool fast = false;
     int lp_ne = 0;
@@ -257,6 +262,9 @@ void elph_greens_free(elph_handle_s *h);
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec);
 int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec);
 int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain = 0);
+int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
+                           const double *tbare_dev, const int *slot_dev, double dtau);
+int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev);
 int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
 int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec);
 int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec);

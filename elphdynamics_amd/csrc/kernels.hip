@@ -609,6 +609,56 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
 }
 
 // Ebar[i] = mean_tau E[tau][i]  (update_A!, KPMPreconditioners.jl:332-349)
+// update_model! of the SSH model on the device (SSHModels.jl:510-562).
+//   pass 1 (fill):   every (tau, bond) gets cosh/sinh of its bare hopping  (bonds without a phonon keep that)
+//   pass 2 (fields): phonon field (p, tau):  t' = t - (alpha x + sign(x) alpha2 x^2),  cosh/sinh(dtau t') at the bond's
+//                    checkerboard position — in the tau-major table AND in the lane-program copy of the fast kernels
+// par = [t | alpha | alpha2] per phonon; cb0 = 0-based checkerboard position of each phonon's bond; slot = lane-program
+// slot of each checkerboard bond (-1: generic kernels only); x in the reference's field order (tau fastest).
+__global__ void __launch_bounds__(256) k_ssh_fill(double *__restrict__ c, double *__restrict__ s, double *__restrict__ lpc,
+                                                  double *__restrict__ lps, const double *__restrict__ tbare,
+                                                  const int *__restrict__ slot, int nb, int L, int lp_stride, double dtau) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)nb * L) return;
+    const int n = (int)(i % nb), t = (int)(i / nb);
+    const double a = dtau * tbare[n], cc = cosh(a), ss = sinh(a);
+    c[i] = cc; s[i] = ss;
+    if (slot && slot[n] >= 0) { lpc[(size_t)t * lp_stride + slot[n]] = cc; lps[(size_t)t * lp_stride + slot[n]] = ss; }
+}
+
+__global__ void __launch_bounds__(256) k_ssh_fields(double *__restrict__ c, double *__restrict__ s, double *__restrict__ lpc,
+                                                    double *__restrict__ lps, const double *__restrict__ x,
+                                                    const double *__restrict__ par, const int *__restrict__ cb0,
+                                                    const int *__restrict__ slot, int nph, int nb, int L, int lp_stride,
+                                                    double dtau) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)nph * L) return;
+    const int t = (int)(i % L), p = (int)(i / L);           // field index = (phonon - 1) Ltau + tau  (Utilities.jl:12-15)
+    const double xt = x[i];
+    const double sg = (xt > 0.0) ? 1.0 : ((xt < 0.0) ? -1.0 : 0.0);
+    const double v = par[nph + p] * xt + sg * par[2 * nph + p] * (xt * xt);
+    const double a = dtau * (par[p] - v), cc = cosh(a), ss = sinh(a);
+    const int n = cb0[p];
+    c[(size_t)t * nb + n] = cc; s[(size_t)t * nb + n] = ss;
+    if (slot && slot[n] >= 0) { lpc[(size_t)t * lp_stride + slot[n]] = cc; lps[(size_t)t * lp_stride + slot[n]] = ss; }
+}
+
+__global__ void __launch_bounds__(256) k_ssh_expmu(double *__restrict__ E, const double *__restrict__ mu, int N, double dtau) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) E[i] = exp(dtau * mu[i]);
+}
+
+// tau-means of the SSH cosh/sinh tables (update_A!, KPMPreconditioners.jl:355-381): one thread per bond
+__global__ void __launch_bounds__(256) k_cs_bar(double *__restrict__ cbar, double *__restrict__ sbar, const double *__restrict__ c,
+                                                const double *__restrict__ s, int nb, int L) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= nb) return;
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < L; ++t) { a += c[(size_t)t * nb + n]; b += s[(size_t)t * nb + n]; }
+    cbar[n] = a / L;
+    sbar[n] = b / L;
+}
+
 // block = 64 sites x 4 tau-phases; each thread sums every 4th slice with 4 independent accumulators
 // (loads in flight instead of one dependent chain), phases combined through LDS.
 __global__ void __launch_bounds__(256) k_ebar(double *__restrict__ Ebar, const double *__restrict__ E, int N, int L) {
@@ -920,6 +970,30 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     B.npap = (int)(h->L / elph_choose_T(h, nrhs));
     B.nrhs = nrhs;
     return B;
+}
+
+int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
+                           const double *tbare_dev, const int *slot_dev, double dtau) {
+    const int nb = (int)h->nb, L = (int)h->L, lp_stride = h->lp_ne * ELPH_WAVE;
+    const int *slot = h->fast_capable ? slot_dev : nullptr;
+    if (nb > 0) {
+        const long long n1 = (long long)nb * L;
+        hipLaunchKernelGGL(k_ssh_fill, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, h->d_c, h->d_s, h->d_lp_c, h->d_lp_s,
+                           tbare_dev, slot, nb, L, lp_stride, dtau);
+        if (nph > 0) {
+            const long long n2 = (long long)nph * L;
+            hipLaunchKernelGGL(k_ssh_fields, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, h->d_c, h->d_s, h->d_lp_c,
+                               h->d_lp_s, x_dev, par_dev, cb0_dev, slot, nph, nb, L, lp_stride, dtau);
+        }
+    }
+    hipLaunchKernelGGL(k_ssh_expmu, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->d_E, h->d_lam, (int)h->N, dtau);
+    return check_launch("ssh update_model");
+}
+
+int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev) {
+    hipLaunchKernelGGL(k_cs_bar, dim3((unsigned)((h->nb + 255) / 256)), dim3(256), 0, h->stream, cbar_dev, sbar_dev, h->d_c, h->d_s,
+                       (int)h->nb, (int)h->L);
+    return check_launch("k_cs_bar");
 }
 
 // Ē of the first `nch` resident chains in one launch

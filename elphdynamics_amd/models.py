@@ -148,9 +148,21 @@ class HolsteinModel(AbstractModel):
 
 
 class SSHModel(AbstractModel):
-    """SSHModels.jl:79-314 reduced to what the path needs: bonds with optional bond phonons."""
+    """SSHModels.jl:79-314 reduced to what the path needs: bonds with optional bond phonons.
+
+    update_model_ computes cosht / sinht on the GPU; the host-visible `model.cosht`, `model.sinht` ((Nbonds, Ltau), i.e.
+    Julia's (Ltau x Nbonds) column-major) are fetched from the device on first access after an update."""
 
     kind = SSH
+
+    def _cs(self, name):
+        if getattr(self, "_cs_stale", False) and getattr(self, "_h", None):
+            check(self._lib.elph_get_cosh_sinh(self._h, dptr(self._cosht.reshape(-1)), dptr(self._sinht.reshape(-1))))
+            self._cs_stale = False
+        return getattr(self, name)
+
+    cosht = property(lambda self: self._cs("_cosht"), lambda self, v: setattr(self, "_cosht", v))
+    sinht = property(lambda self: self._cs("_sinht"), lambda self, v: setattr(self, "_sinht", v))
 
     def __init__(self, lattice, beta, dtau, tol=1e-4, maxiter=10000, device=0):
         self.lattice = lattice
@@ -200,12 +212,11 @@ class SSHModel(AbstractModel):
         self.x = np.zeros(self.Ndof)
         L, nb = self.Ltau, self.Nbonds
         # cosht/sinht: Julia (Ltau x Nbonds) column-major == [bond][tau] here; bare values (:450-464)
+        self._cs_stale = False
         self.cosht = np.zeros((nb, L))
         self.sinht = np.zeros((nb, L))
-        for bond in range(nb):
-            idx = self.checkerboard_perm[bond] - 1
-            self.cosht[idx, :] = np.cosh(self.dtau * self.t[bond])
-            self.sinht[idx, :] = np.sinh(self.dtau * self.t[bond])
+        self.t_bare_cb = np.zeros(nb)                                # bare hopping in checkerboard order
+        self.t_bare_cb[self.checkerboard_perm - 1] = self.t
         self.expDtauMu = np.exp(self.dtau * self.mu)
         self._create(None, None, self._device)
 
@@ -221,16 +232,16 @@ def update_model_(model):
         check(model._lib.elph_update_model_holstein(model._h, dptr(np.ascontiguousarray(model.x)), dptr(model.lam),
                                                     dptr(model.lam2), dptr(model.mu), model.dtau))
     else:
-        model.expDtauMu = np.exp(model.dtau * model.mu)
-        X = model.x.reshape(model.Nph, model.Ltau)
-        v = model.alpha[:, None] * X + np.sign(X) * model.alpha2[:, None] * X ** 2
-        tp = model.t[model.phonon_to_bond - 1][:, None] - v
-        idx = model.checkerboard_perm[model.phonon_to_bond - 1] - 1
-        model.cosht[idx, :] = np.cosh(model.dtau * tp)
-        model.sinht[idx, :] = np.sinh(model.dtau * tp)
-        check(model._lib.elph_update_model_ssh(model._h, dptr(np.ascontiguousarray(model.cosht).reshape(-1)),
-                                               dptr(np.ascontiguousarray(model.sinht).reshape(-1)),
-                                               dptr(np.ascontiguousarray(model.expDtauMu))))
+        # cosh/sinh of t' = t - (alpha x + sign(x) alpha2 x^2) and exp(dtau mu) are computed on the GPU (SSHModels.jl:510-562)
+        model.expDtauMu = np.exp(model.dtau * model.mu)             # host-visible field only; the device computes its own
+        cb_index = np.ascontiguousarray(model.checkerboard_perm[model.phonon_to_bond - 1], dtype=np.int64)
+        t_ph = np.ascontiguousarray(model.t[model.phonon_to_bond - 1], dtype=np.float64)
+        check(model._lib.elph_update_model_ssh_fields(
+            model._h, dptr(np.ascontiguousarray(model.x)) if model.Nph else None, model.Nph, iptr(cb_index) if model.Nph else None,
+            dptr(t_ph) if model.Nph else None, dptr(np.ascontiguousarray(model.alpha)) if model.Nph else None,
+            dptr(np.ascontiguousarray(model.alpha2)) if model.Nph else None,
+            dptr(model.t_bare_cb) if model.Nbonds else None, dptr(np.ascontiguousarray(model.mu)), model.dtau))
+        model._cs_stale = True
 
 
 def update_model_chains_(model, X):

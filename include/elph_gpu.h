@@ -100,6 +100,19 @@ int elph_set_expV(elph_handle h, const double *expnDtauV);
 int elph_update_model_ssh(elph_handle h, const double *cosht, const double *sinht,
                           const double *expDtauMu);
 
+/* update_model!(ssh) computed on the device from the phonon fields — SSHModels.jl:510-562: expΔτμ = exp(Δτ μ); per field
+ * t′ = t − (α x + sign(x) α₂ x²), cosht[τ, index] = cosh(Δτ t′), sinht likewise (no host cosh/sinh, no tables over PCIe).
+ *   x         double[nph * ltau]  ssh.x (field = (phonon−1)·Lτ + τ)
+ *   cb_index  int64[nph]          1-based checkerboard position of each phonon's bond: checkerboard_perm[phonon_to_bond[p]]
+ *   t_ph, alpha, alpha2  double[nph]   ssh.t[bond of p], ssh.α, ssh.α₂
+ *   t_bare_cb double[nbonds]      bare hopping of every bond in checkerboard order (bonds without a phonon keep cosh/sinh(Δτ t))
+ *   mu        double[nsites]
+ * elph_get_cosh_sinh: model.cosht / model.sinht as the reference stores them ((Lτ × Nbonds) column-major), for callers that
+ * read those fields after a device-side update (Holstein handles: Nbonds values each). */
+int elph_update_model_ssh_fields(elph_handle h, const double *x, int64_t nph, const int64_t *cb_index, const double *t_ph,
+                                 const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu, double dtau);
+int elph_get_cosh_sinh(elph_handle h, double *cosht, double *sinht);
+
 /* ---------------------------------------------------------------- mul! family */
 
 /* mulM!(y, model, v) — HolsteinModels.jl:569-626 / SSHModels.jl:581-640 */

@@ -775,3 +775,77 @@ def test_kpm_preconditioner_per_chain(tag, nchains, per):
     itx, _, flx = models.ldiv_(x, m, np.ascontiguousarray(B[0]), P=P)
     assert flx == 0
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ SSH update_model! on the device
+
+def test_ssh_update_model_on_device_matches_golden(lib):
+    """elph_update_model_ssh_fields (SSHModels.jl:510-562 computed on the GPU: cosh/sinh of t' per (tau, bond), exp(dtau mu))
+    against the golden tables and against the host-table entry point — both kernel families see the same matrix."""
+    from elphdynamics_amd import _lib
+    g = golden("ssh_sq4_L8.npz")
+    N, L = int(g["N"]), int(g["Ltau"])
+    nb = g["table"].shape[0]
+    nph = g["phonon_to_bond"].shape[0]
+    cbperm = g["cbperm"]
+    cb_index = np.ascontiguousarray(cbperm[g["phonon_to_bond"] - 1], dtype=np.int64)
+    t_ph = np.ascontiguousarray(g["t"][g["phonon_to_bond"] - 1])
+    t_cb = np.zeros(nb)
+    t_cb[cbperm - 1] = g["t"]
+    mu, dtau = np.ascontiguousarray(g["mu"]), float(g["dtau"])
+    m = RawModel(lib, 1, N, L, g["table"])
+    try:
+        _lib.check(lib.elph_update_model_ssh_fields(m.h, _lib.dptr(np.ascontiguousarray(g["x"])), nph, _lib.iptr(cb_index),
+                                                    _lib.dptr(t_ph), _lib.dptr(np.ascontiguousarray(g["alpha"])),
+                                                    _lib.dptr(np.ascontiguousarray(g["alpha2"])), _lib.dptr(t_cb), _lib.dptr(mu), dtau))
+        c, s = np.zeros(nb * L), np.zeros(nb * L)
+        _lib.check(lib.elph_get_cosh_sinh(m.h, _lib.dptr(c), _lib.dptr(s)))
+        assert rel(c, g["cosht"]) < 1e-15 and rel(s, g["sinht"]) < 1e-14        # libm vs device cosh/sinh: last-bit differences
+        for name in ("Mv", "MTv", "MTMv"):
+            op = {"Mv": "elph_mulM", "MTv": "elph_mulMT", "MTMv": "elph_mulMTM"}[name]
+            assert rel(m.op(op, g["v"]), g[name]) < 1e-13
+        x, it, res, flag = m.ldiv(g["b"], 1e-12, 5000)
+        assert flag == 0 and rel(x, g["xsol"]) < 1e-9
+        # the KPM set-up reads its tau-averaged cosh/sinh from the device tables now
+        _lib.check(lib.elph_kpm_create(m.h, 8, 0.05, 1.0, 1.0))
+        rng = np.random.default_rng(0)
+        act = C.c_int()
+        _lib.check(lib.elph_kpm_setup(m.h, _lib.dptr(rng.standard_normal(N)), _lib.dptr(rng.standard_normal(N)), float("nan"),
+                                      float("nan"), C.byref(act), None, None))
+        xk, itk, resk, flagk = m.ldiv(g["b"], 1e-12, 5000, use_prec=1)
+        assert flagk == 0 and rel(xk, g["xsol"]) < 1e-9
+        # bad checkerboard position
+        bad = cb_index.copy(); bad[0] = nb + 1
+        assert lib.elph_update_model_ssh_fields(m.h, _lib.dptr(np.ascontiguousarray(g["x"])), nph, _lib.iptr(bad), _lib.dptr(t_ph),
+                                                _lib.dptr(np.ascontiguousarray(g["alpha"])), _lib.dptr(np.ascontiguousarray(g["alpha2"])),
+                                                _lib.dptr(t_cb), _lib.dptr(mu), dtau) == _lib.ELPH_E_ARG
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("no_fast", ["0", "1"])
+def test_ssh_device_update_equals_host_tables_at_config_E(no_fast, monkeypatch):
+    """Config E (OSSH square L=16, Ltau=160, alpha2 = 0.02 switched on): the model built by the device-side update_model!
+    applies the same operator as one fed with numpy cosh/sinh tables through elph_update_model_ssh — lane-program (fast)
+    and generic kernels."""
+    monkeypatch.setenv("ELPH_NO_FAST", no_fast)
+    from elphdynamics_amd import _lib, configs, models
+    m = configs.make_model("E")
+    m.alpha2[:] = 0.02
+    models.update_model_(m)                                    # device path
+    v = np.cos(0.3 * np.arange(m.Ndim))
+    y_dev = np.zeros(m.Ndim)
+    models.mulMtM_(y_dev, m, v)
+    X = m.x.reshape(m.Nph, m.Ltau)
+    tp = m.t[m.phonon_to_bond - 1][:, None] - (m.alpha[:, None] * X + np.sign(X) * m.alpha2[:, None] * X ** 2)
+    idx = m.checkerboard_perm[m.phonon_to_bond - 1] - 1
+    c = np.tile(np.cosh(m.dtau * m.t_bare_cb)[:, None], (1, m.Ltau))
+    s = np.tile(np.sinh(m.dtau * m.t_bare_cb)[:, None], (1, m.Ltau))
+    c[idx, :], s[idx, :] = np.cosh(m.dtau * tp), np.sinh(m.dtau * tp)
+    assert rel(m.cosht, c) < 1e-15 and rel(m.sinht, s) < 1e-14            # lazily fetched from the device
+    _lib.check(m._lib.elph_update_model_ssh(m._h, _lib.dptr(np.ascontiguousarray(c).reshape(-1)),
+                                            _lib.dptr(np.ascontiguousarray(s).reshape(-1)), _lib.dptr(np.exp(m.dtau * m.mu))))
+    y_host = np.zeros(m.Ndim)
+    models.mulMtM_(y_host, m, v)
+    assert rel(y_dev, y_host) < 1e-13
+    m.close()
