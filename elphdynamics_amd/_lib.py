@@ -61,6 +61,7 @@ SIGNATURES = {
     "elph_fermion_force_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl,
                                             P_i64, P_int]),
     "elph_fermion_force_ssh": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
+    "elph_fermion_force_ssh_fields": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
     "elph_hmc_create": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
     "elph_hmc_set_state": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_hmc_get_state": (c_int, [Handle, P_dbl, P_dbl]),

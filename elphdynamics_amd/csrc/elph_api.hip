@@ -520,6 +520,8 @@ extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int6
     HIPCHK(hipMemcpyAsync(h->d_lam, mu, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_ssh_update(h, h->d_ssh_x, (int)np, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, dtau));
     HIPCHK(hipStreamSynchronize(h->stream));       // cb0 / the caller's arrays may go away
+    h->ssh_nph = (int)np;
+    h->ssh_dtau = dtau;
     h->cs_host_stale = true;
     h->have_E = true;
     return ELPH_OK;
@@ -1008,13 +1010,9 @@ extern "C" int elph_fermion_force_holstein(elph_handle h, const double *x, const
     return ELPH_OK;
 }
 
-extern "C" int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
-                                      double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters,
-                                      int *flag) {
-    CHECK_H(h);
-    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
-    RC(need_model(h));
-    if (!rhs_plus || !rhs_minus || !q_out || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
+// the two solves of calc_O⁻¹Λϕ! for an SSH handle (Λ = identity) + the bond brackets q[tau][n] left in h->d_p
+static int ssh_force_core(elph_handle_s *h, const double *rhs_plus, const double *rhs_minus, int use_precond, double tol_power,
+                          int64_t *iters, int *flag) {
     RC(ensure_capacity(h, 2));
     const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double), nq = (size_t)h->L * (size_t)h->nb;
     HIPCHK(hipMemcpyAsync(h->d_stage_in, rhs_plus, bytes, hipMemcpyHostToDevice, h->stream));
@@ -1036,21 +1034,60 @@ extern "C" int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, con
     if (fl == 0) tot = (tot + 1) / 2;
     *iters = tot;
     *flag = fl;
-    // q[tau][n] on the device (tau-major) -> q_out[n*L + tau] (tau fastest, like the reference's (Ltau x Nbonds) arrays)
     if (nq > 2 * nd) { elph_set_error("more bonds than 2*nsites: scratch too small"); return ELPH_E_UNSUPPORTED; }
-    double *dq = h->d_p;     // 2*cap*ndim doubles of scratch, free once the solves are done
-    RC(elph_launch_force_ssh(h, dq, h->d_x));
-    std::vector<double> qt(nq);
-    HIPCHK(hipMemcpyAsync(qt.data(), dq, nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return elph_launch_force_ssh(h, h->d_p, h->d_x);     // d_p: 2*cap*ndim doubles of scratch, free once the solves are done
+}
+
+static int ssh_solutions_out(elph_handle_s *h, double *Xp_out, double *Xm_out) {
+    const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double);
     if (Xp_out || Xm_out) {
         RC(elph_launch_s2r(h, h->d_stage_in, h->d_x, 2));
         if (Xp_out) HIPCHK(hipMemcpyAsync(Xp_out, h->d_stage_in, bytes, hipMemcpyDeviceToHost, h->stream));
         if (Xm_out) HIPCHK(hipMemcpyAsync(Xm_out, h->d_stage_in + nd, bytes, hipMemcpyDeviceToHost, h->stream));
     }
+    return ELPH_OK;
+}
+
+extern "C" int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
+                                      double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters,
+                                      int *flag) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    RC(need_model(h));
+    if (!rhs_plus || !rhs_minus || !q_out || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ssh_force_core(h, rhs_plus, rhs_minus, use_precond, tol_power, iters, flag));
+    // q[tau][n] on the device (tau-major) -> q_out[n*L + tau] (tau fastest, like the reference's (Ltau x Nbonds) arrays)
+    const size_t L = (size_t)h->L, nb = (size_t)h->nb, nq = L * nb;
+    std::vector<double> qt(nq);
+    HIPCHK(hipMemcpyAsync(qt.data(), h->d_p, nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC(ssh_solutions_out(h, Xp_out, Xm_out));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const size_t L = (size_t)h->L, nb = (size_t)h->nb;
     for (size_t t = 0; t < L; ++t)
         for (size_t n = 0; n < nb; ++n) q_out[n * L + t] = qt[t * nb + n];
+    return ELPH_OK;
+}
+
+// The same with the scatter onto the phonon fields done on the device (SSHModels.jl:797-823 with one field per bond):
+//   dSdx[(p-1) Ltau + tau] -= sg(tau) dtau (alpha_p + 2 alpha2_p x) q[tau][bond(p)],   sg(1) = -1   (HMC.jl:803,808)
+// for the fields, couplings and checkerboard positions given to the last elph_update_model_ssh_fields call.
+extern "C" int elph_fermion_force_ssh_fields(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
+                                             double tol_power, double *dSdx, double *Xp_out, double *Xm_out, int64_t *iters,
+                                             int *flag) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    RC(need_model(h));
+    if (!rhs_plus || !rhs_minus || !dSdx || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    if (!h->cs_host_stale || h->ssh_nph < 0) { elph_set_error("elph_update_model_ssh_fields has not been called for the current field"); return ELPH_E_STATE; }
+    RC(ssh_force_core(h, rhs_plus, rhs_minus, use_precond, tol_power, iters, flag));
+    const size_t nf = (size_t)h->ssh_nph * (size_t)h->L;
+    double *dF = h->d_tmp;                                   // cap*ndim doubles
+    if (nf > (size_t)h->cap_rhs * (size_t)h->ndim) { elph_set_error("more phonon fields than scratch"); return ELPH_E_UNSUPPORTED; }
+    RC(elph_launch_ssh_scatter(h, dF, h->d_p, h->d_ssh_x, h->d_ssh_par, h->d_ssh_cb, h->ssh_nph, h->ssh_dtau));
+    std::vector<double> F(nf);
+    if (nf) HIPCHK(hipMemcpyAsync(F.data(), dF, nf * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RC(ssh_solutions_out(h, Xp_out, Xm_out));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < nf; ++i) dSdx[i] -= F[i];         // the reference accumulates into hmc.dSdx (HMC.jl:808)
     return ELPH_OK;
 }
 

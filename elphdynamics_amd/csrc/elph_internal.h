@@ -165,6 +165,8 @@ struct elph_handle_s {
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
     int *d_ssh_cb = nullptr, *d_ssh_slot = nullptr;
     int64_t ssh_nph_cap = 0;
+    int ssh_nph = -1;                      // fields of the last device-side update_model!
+    double ssh_dtau = 0.0;
     bool cs_host_stale = false;            // SSH: d_c/d_s were produced on the device; h_c/h_s are not current
     // lane program (fast path, ncol <= 4)
     bool fast = false;
@@ -265,6 +267,8 @@ int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain 
 int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
                            const double *tbare_dev, const int *slot_dev, double dtau);
 int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev);
+int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
+                            const int *cb0_dev, int nph, double dtau);
 int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
 int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec);
 int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec);

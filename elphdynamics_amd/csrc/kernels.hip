@@ -648,6 +648,18 @@ __global__ void __launch_bounds__(256) k_ssh_expmu(double *__restrict__ E, const
     if (i < N) E[i] = exp(dtau * mu[i]);
 }
 
+// F[(p, tau)] = sg(tau) dtau (alpha_p + 2 alpha2_p x) q[tau][bond(p)]  — dMdx of the bond-phonon fields (SSHModels.jl:797-823)
+__global__ void __launch_bounds__(256) k_ssh_scatter(double *__restrict__ F, const double *__restrict__ q, const double *__restrict__ x,
+                                                     const double *__restrict__ par, const int *__restrict__ cb0, int nph, int nb,
+                                                     int L, double dtau) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)nph * L) return;
+    const int t = (int)(i % L), p = (int)(i / L);
+    const double sg = (t == 0) ? -1.0 : 1.0;                                  // "flip sign if τ=1" (:809-811)
+    const double dKdx = par[nph + p] + 2.0 * par[2 * nph + p] * x[i];         // ∂K/∂x as the reference takes it (:803)
+    F[i] = sg * dtau * dKdx * q[(size_t)t * nb + cb0[p]];
+}
+
 // tau-means of the SSH cosh/sinh tables (update_A!, KPMPreconditioners.jl:355-381): one thread per bond
 __global__ void __launch_bounds__(256) k_cs_bar(double *__restrict__ cbar, double *__restrict__ sbar, const double *__restrict__ c,
                                                 const double *__restrict__ s, int nb, int L) {
@@ -988,6 +1000,15 @@ int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const
     }
     hipLaunchKernelGGL(k_ssh_expmu, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->d_E, h->d_lam, (int)h->N, dtau);
     return check_launch("ssh update_model");
+}
+
+int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
+                            const int *cb0_dev, int nph, double dtau) {
+    const long long n = (long long)nph * h->L;
+    if (n == 0) return ELPH_OK;
+    hipLaunchKernelGGL(k_ssh_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, F_dev, q_dev, x_dev, par_dev, cb0_dev,
+                       nph, (int)h->nb, (int)h->L, dtau);
+    return check_launch("k_ssh_scatter");
 }
 
 int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev) {

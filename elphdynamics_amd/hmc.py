@@ -11,7 +11,8 @@
 The two pseudofermion solves (and the n_v measurement solves) share one fermion matrix, so they go to
 the GPU as ONE batched ldiv!; each right-hand side still follows the single-RHS recurrences and stop rule,
 so the results are bit-identical to the reference's sequential solves on the same inputs.
-The O(Ndim) diagonal Lambda operations stay on the host for now (SURVEY §8f-1 moves them to the device).
+update_Lambda_/mulLambda_/mulLambdaInv_ are host utilities for building test inputs; inside calc_OinvLambda_phi and
+calc_dSfdx_ the Λ operations run on the device (k_lambda_rhs, k_force_holstein).
 """
 import numpy as np
 
@@ -56,18 +57,18 @@ def calc_OinvLambda_phi(model, phi_p, phi_m, P=None, power=1.0, rng=None, setup_
     tol is raised to `power` for the duration of the call (:827-828, restored :912), setup!(P) runs first (:834),
     the reported iteration count is cld(total, 2) when both solves converged (:907-909), and a failed first
     solve suppresses the second (:880): its output stays zero."""
+    if model.kind == models.HOLSTEIN:
+        # Λ (update_Λ!, mulΛ!, :921-968), both solves and the bookkeeping below run inside one device call; the force it
+        # also assembles is discarded here
+        pc.setup_(P, rng=rng, **(setup_kwargs or {}))
+        it, fl, Xp, Xm = calc_dSfdx_(np.zeros(model.Ndof), model, phi_p, phi_m, P=P, power=power, return_solutions=True)
+        return Xp, Xm, it, fl
     tol = model.solver.tol
     model.solver.tol = tol ** power
     try:
         pc.setup_(P, rng=rng, **(setup_kwargs or {}))
-        Lam = np.empty(model.Ndim)
-        update_Lambda_(Lam, model)
         B = np.empty((2, model.Ndim))
-        if model.kind == models.SSH:
-            B[0], B[1] = phi_p, phi_m        # mulΛ! is a no-op for SSH: Λϕ buffers hold what the caller put there
-        else:
-            mulLambda_(B[0], phi_p, Lam, model)
-            mulLambda_(B[1], phi_m, Lam, model)
+        B[0], B[1] = phi_p, phi_m            # mulΛ! is a no-op for SSH: Λϕ buffers hold what the caller put there
         X = np.zeros((2, model.Ndim))        # fill!(O⁻¹Λϕ, 0)  (:854, :883)
         it, res, fl = models.ldiv_batched_(X, model, B, P=P)
         flag = int(fl[0])
@@ -133,22 +134,13 @@ def calc_dSfdx_(dSdx, model, phi_p, phi_m, P=None, power=1.0, return_solutions=F
             C.byref(it), C.byref(fl)))
     else:
         # SSH: Λ is the identity, phi_p / phi_m are the right-hand sides hmc.Λϕ± = MᵀR± (HMC.jl:680-686,943-973);
-        # the device returns the bond-local brackets q, the scatter to phonon fields is host bookkeeping
-        # (SSHModels.jl:809-823; equivalent fields / primary_field are not modelled here).
+        # update_model!, the two solves, the bond brackets and their scatter onto the phonon fields all run on the device
+        # (SSHModels.jl:797-823; equivalent fields / primary_field are not modelled here).
         models.update_model_(model)
-        L, nb = model.Ltau, model.Nbonds
-        q = np.empty(nb * L)
-        check(model._lib.elph_fermion_force_ssh(
+        check(model._lib.elph_fermion_force_ssh_fields(
             model._h, dptr(np.ascontiguousarray(phi_p)), dptr(np.ascontiguousarray(phi_m)), 0 if P is None else 1,
-            float(power), dptr(q), dptr(Xp) if return_solutions else None, dptr(Xm) if return_solutions else None,
+            float(power), dptr(dSdx), dptr(Xp) if return_solutions else None, dptr(Xm) if return_solutions else None,
             C.byref(it), C.byref(fl)))
-        Q = q.reshape(nb, L)
-        X = model.x.reshape(model.Nph, L)
-        cbidx = model.checkerboard_perm[model.phonon_to_bond - 1] - 1        # checkerboard position of each phonon's bond
-        dKdx = model.alpha[:, None] + 2.0 * model.alpha2[:, None] * X       # ∂K_n/∂x_n  (SSHModels.jl:803)
-        sg = np.ones(L)
-        sg[0] = -1.0                                                         # "flip sign if τ=1" (:809-811)
-        dSdx -= (sg[None, :] * model.dtau * dKdx * Q[cbidx]).reshape(-1)      # dSfdx += -dMdx (HMC.jl:803,808)
     if return_solutions:
         return int(it.value), int(fl.value), Xp, Xm
     return int(it.value), int(fl.value)

@@ -220,6 +220,14 @@ int elph_fermion_force_holstein(elph_handle h, const double *x, const double *la
 int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
                            double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
 
+/* As elph_fermion_force_ssh, with the scatter onto the phonon fields done on the device as well:
+ *   dSdx[(p−1)·Lτ + τ] −= sg(τ)·Δτ·(α_p + 2 α₂_p x)·q[τ][bond(p)]      (SSHModels.jl:797-823, HMC.jl:803,808)
+ * for the fields x, couplings and checkerboard positions of the last elph_update_model_ssh_fields call (one field per
+ * bond and τ; the reference's primary_field aliasing of equivalent fields stays with the caller).  dSdx: double[nph·Lτ],
+ * accumulated into. */
+int elph_fermion_force_ssh_fields(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
+                                  double tol_power, double *dSdx, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
+
 /* ---------------------------------------------------------------- HMC trajectory */
 
 /* One HMC update of the Holstein model, update!(model, hmc, fa, P) — HMC.jl:313-337 — i.e. standard_update!
