@@ -500,13 +500,21 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
 
     // ---- pipelined stages: reverse sweep of w(t0+j)  ||  forward sweep of slice t0+j+1 ---------------
     double acc = 0.0;
-    double Sn[NPL], Qn[NPL], En[NPL];
-    if (T > 1) { load_sq(wrap(t0 + 2), Sn, Qn); load_e(wrap(t0 + 2), En); }
+    // Slices t0+2 … t0+T stream through a register ring PF stages deep: a stage (four colour sweeps) lasts ~0.3 us, an HBM
+    // round trip under load several times that, and at ~1.25 waves per SIMD nothing else hides it — the registers are free.
+    constexpr int PF = (T >= 4) ? 2 : 1;
+    double Sr[PF][NPL], Qr[PF][NPL], Er[PF][NPL];
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+        if (k + 2 <= T) { load_sq(wrap(t0 + 2 + k), Sr[k], Qr[k]); load_e(wrap(t0 + 2 + k), Er[k]); }
 #pragma unroll
     for (int j = 1; j <= T; ++j) {
         const int tj = wrap(t0 + j);              // slice whose w is reverse-swept now
         const int tn = wrap(t0 + j + 1);          // slice forward-swept now (if j < T)
         const bool more = (j < T);
+        double (&Sn)[NPL] = Sr[(j - 1) % PF];     // slice tn in the ring (compile-time slot: the loop is unrolled)
+        double (&Qn)[NPL] = Qr[(j - 1) % PF];
+        double (&En)[NPL] = Er[(j - 1) % PF];
         if (SSH) {
             // B-side tables: slice tj (they were the A/B tables of the previous stage); A-side: slice tn
             lp_load_cs<NPL>(cB, sB, m.lp_c + (size_t)tj * m.lp_tau_stride, m.lp_s + (size_t)tj * m.lp_tau_stride);
@@ -545,7 +553,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
                 pprev[q] = pcur[q]; pcur[q] = pnext[q];
                 Ecur[q] = En[q];
             }
-            if (j + 1 < T) { load_sq(wrap(t0 + j + 2), Sn, Qn); load_e(wrap(t0 + j + 2), En); }
+            if (j + 1 + PF <= T) { load_sq(wrap(t0 + j + 1 + PF), Sn, Qn); load_e(wrap(t0 + j + 1 + PF), En); }   // refill this slot
         }
     }
     acc = wave_sum2(acc);
