@@ -5,9 +5,9 @@
 
 A *step* is one conjugate-gradient iteration (1 MtM apply = 2 mat-vecs, + the vector updates and both
 reductions; + 1 KPM apply with --precond) advanced for a batch of `nrhs` right-hand sides resident in HBM.
-Default batch: 32 independent Markov chains per GPU (32 phonon configurations = 32 different fermion matrices,
+Default batch: 64 independent Markov chains per GPU (64 phonon configurations = 64 different fermion matrices,
 the reference runs them as separate processes, ElPhDynamics.jl:90-95) x the 2 pseudofermion solves of one HMC
-force evaluation each (HMC.jl:851-886) = 64 right-hand sides.  W untimed warm-up steps, then exactly K steps
+force evaluation each (HMC.jl:851-886) = 128 right-hand sides (315 MB of solver vectors: the batch is what fills the GPU).  W untimed warm-up steps, then exactly K steps
 bracketed by barrier + device synchronise on both sides; the time is the MAX over ranks and
 value = (2 * nrhs * K * n_gpus) / time.  One JSON line on rank 0.
 
@@ -35,8 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 ALG_BYTES_PER_ELT = {          # SURVEY.md §8(d), f64, perfect fusion
     "cg_iter": 120.0,          # 2 mat-vecs (48) + x, r, p updates (72)
-    "k_cg_ap": 72.0,           # p = r + beta p (24) + M p (24) + Mt (M p) (24)
-    "k_cg_xr": 48.0,           # x += alpha p (24) + r -= alpha z (24)
+    "k_cg_ap": 96.0,           # x += alpha p of the previous iteration (24) + p = r + beta p (24) + M p (24) + Mt (M p) (24)
+    "k_cg_xr": 24.0,           # r -= alpha z (24)   [x += alpha p rides in the next k_cg_ap, which reads that p anyway]
     "kpm_apply": 16.0,
 }
 
@@ -50,8 +50,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=400)
-    ap.add_argument("--nrhs", type=int, default=64, help="right-hand sides advanced per step (batch)")
-    ap.add_argument("--chains", type=int, default=32,
+    ap.add_argument("--nrhs", type=int, default=128, help="right-hand sides advanced per step (batch)")
+    ap.add_argument("--chains", type=int, default=64,
                     help="independent phonon configurations (Markov chains) per GPU sharing the batch: right-hand side r "
                          "uses the fermion matrix of chain r %% chains (nrhs = 2*chains = both pseudofermion solves of one "
                          "HMC force evaluation per chain); 1 = all right-hand sides on one matrix")
@@ -165,9 +165,9 @@ def main():
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
         run(4, nrhs, 320, graph=0)
         ms_ap = run(4, nrhs, reps, graph=0) / reps
-        if m.kind == 1:   # SSH mat-vec: 16 B x Ndim + 16 B x Ltau x Nbonds; p-update 24 B x Ndim
+        if m.kind == 1:   # SSH mat-vec: 16 B x Ndim + 16 B x Ltau x Nbonds; p- and x-update 24 B x Ndim each
             mv = 16.0 * ndim + 16.0 * m.Ltau * m.Nbonds
-            alg_ap, alg_it = (2 * mv + 24.0 * ndim) * nrhs, (2 * mv + 72.0 * ndim) * nrhs
+            alg_ap, alg_it = (2 * mv + 48.0 * ndim) * nrhs, (2 * mv + 72.0 * ndim) * nrhs
         else:
             alg_ap, alg_it = ALG_BYTES_PER_ELT["k_cg_ap"] * ndim * nrhs, ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs
         alg = alg_ap
@@ -230,7 +230,7 @@ def main():
         # ---- secondary: the same step at other batch sizes (short runs)
         if not args.no_sweep:
             sweep = {}
-            for nr in (1, 2, 10, 64, 256):
+            for nr in (1, 2, 10, 64, 128, 256):
                 _, Bs = configs.rhs(m, nr)
                 check(lib.elph_bench_prepare(m._h, what, nr, _lib.dptr(np.ascontiguousarray(Bs))))
                 run(what, nr, 160)

@@ -242,7 +242,9 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
     const double *E0 = Ech + (size_t)t * m.E_tau_stride, *E1 = Ech + (size_t)tp1 * m.E_tau_stride;
 
-    double sm[NPL], s0v[NPL], sp[NPL], qm[NPL], q0[NPL], qp[NPL], e0[NPL], e1[NPL];
+    double *x = B.x + (size_t)rhs * ndim;
+    const double alpha_prev = B.alpha[rhs];          // step length of the previous iteration (unused when seq == 0)
+    double sm[NPL], s0v[NPL], sp[NPL], qm[NPL], q0[NPL], qp[NPL], e0[NPL], e1[NPL], xv[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
@@ -251,6 +253,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
         sm[q] = src[im]; s0v[q] = src[i0]; sp[q] = src[ip];
         qm[q] = pold[im]; q0[q] = pold[i0]; qp[q] = pold[ip];
         e0[q] = E0[sc]; e1[q] = E1[sc];
+        xv[q] = x[i0];
     }
     unsigned ij[NE];
     double c0[NE], s0[NE], c1[NE], s1[NE];
@@ -274,6 +277,12 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_fast(CgBufs B, ModelDev m, int p
     const bool first = (seq == 0);
     double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
     if (!first) {
+        // x += alpha p of the iteration whose stop test follows (IterativeSolvers.jl:205/282), with the p this launch reads anyway
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) x[(size_t)t * N + s] = xv[q] + alpha_prev * q0[q];
+        }
         eps = sqrt(rr) / S.normb;
         const double qq = 2.0 * (double)seq / log(2.0 * S.eps0 / eps);
         const double val = qq * qq;
@@ -405,6 +414,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
     const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
     double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
     double *z = B.z + (size_t)rhs * ndim;
+    double *x = B.x + (size_t)rhs * ndim;
+    const double alpha_prev = B.alpha[rhs];          // step length of the previous iteration (unused when seq == 0)
 
     int sc[NPL];
 #pragma unroll
@@ -418,14 +429,28 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
 #pragma unroll
         for (int q = 0; q < NPL; ++q) ev[q] = Et[sc[q]];
     };
+    auto load_x = [&](int t, double (&xv)[NPL]) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) xv[q] = x[(size_t)t * N + sc[q]];
+    };
+    // x(t) += alpha_prev p_old(t) for an OWN slice (t0 <= t < t0+T), with the p_old values this launch has in registers
+    auto update_x = [&](int t, const double (&xv)[NPL], const double (&qv)[NPL]) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = threadIdx.x + q * WAVE;
+            if (s < N) x[(size_t)t * N + s] = xv[q] + alpha_prev * qv[q];
+        }
+    };
 
     // ---- prologue loads (independent of everything) ----------------------------------------------
-    double Sm[NPL], Qm[NPL], S0[NPL], Q0[NPL], S1[NPL], Q1[NPL], E0[NPL], E1[NPL];
+    double Sm[NPL], Qm[NPL], S0[NPL], Q0[NPL], S1[NPL], Q1[NPL], E0[NPL], E1[NPL], X0[NPL], X1[NPL];
     load_sq(wrap(t0 - 1), Sm, Qm);
     load_sq(t0, S0, Q0);
     load_sq(wrap(t0 + 1), S1, Q1);
     load_e(t0, E0);
     load_e(wrap(t0 + 1), E1);
+    load_x(t0, X0);
+    if (T > 1) load_x(t0 + 1, X1);                   // t0 + 1 <= L - 1 whenever T > 1 (T divides L)
     unsigned ij[NE];
     double cA[NE], sA[NE], cB[NE], sB[NE];
     lp_load_ij<NPL>(ij, m);
@@ -458,6 +483,15 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
         else if (seq >= P.maxiter) done = 3;
         if (ch == 0 && threadIdx.x == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + seq] = eps;
         if (done) {
+            // the solve ends here: apply the pending x += alpha p of the last iteration to all own slices, then leave
+            update_x(t0, X0, Q0);
+            if (T > 1) update_x(t0 + 1, X1, Q1);
+            for (int j = 2; j < T; ++j) {
+                double xv[NPL], qv[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) { const size_t i = (size_t)(t0 + j) * N + sc[q]; xv[q] = x[i]; qv[q] = pold[i]; }
+                update_x(t0 + j, xv, qv);
+            }
             if (ch == 0 && threadIdx.x == 0) {
                 CgState o = S;
                 o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = done;
@@ -465,6 +499,8 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
             }
             return;
         }
+        update_x(t0, X0, Q0);
+        if (T > 1) update_x(t0 + 1, X1, Q1);
         beta = rz / S.rho;
         rho = rz;
     }
@@ -503,10 +539,14 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
     // Slices t0+2 … t0+T stream through a register ring PF stages deep: a stage (four colour sweeps) lasts ~0.3 us, an HBM
     // round trip under load several times that, and at ~1.25 waves per SIMD nothing else hides it — the registers are free.
     constexpr int PF = (T >= 4) ? 2 : 1;
-    double Sr[PF][NPL], Qr[PF][NPL], Er[PF][NPL];
+    double Sr[PF][NPL], Qr[PF][NPL], Er[PF][NPL], Xr[PF][NPL];
 #pragma unroll
     for (int k = 0; k < PF; ++k)
-        if (k + 2 <= T) { load_sq(wrap(t0 + 2 + k), Sr[k], Qr[k]); load_e(wrap(t0 + 2 + k), Er[k]); }
+        if (k + 2 <= T) {
+            load_sq(wrap(t0 + 2 + k), Sr[k], Qr[k]);
+            load_e(wrap(t0 + 2 + k), Er[k]);
+            if (k + 2 < T) load_x(t0 + 2 + k, Xr[k]);          // own slices only (the last ring slice, t0+T, is halo)
+        }
 #pragma unroll
     for (int j = 1; j <= T; ++j) {
         const int tj = wrap(t0 + j);              // slice whose w is reverse-swept now
@@ -515,6 +555,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
         double (&Sn)[NPL] = Sr[(j - 1) % PF];     // slice tn in the ring (compile-time slot: the loop is unrolled)
         double (&Qn)[NPL] = Qr[(j - 1) % PF];
         double (&En)[NPL] = Er[(j - 1) % PF];
+        double (&Xn)[NPL] = Xr[(j - 1) % PF];
         if (SSH) {
             // B-side tables: slice tj (they were the A/B tables of the previous stage); A-side: slice tn
             lp_load_cs<NPL>(cB, sB, m.lp_c + (size_t)tj * m.lp_tau_stride, m.lp_s + (size_t)tj * m.lp_tau_stride);
@@ -545,6 +586,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
                 if (s < N) pnew[(size_t)tj * N + s] = pcur[q];
             }
         }
+        if (!first && j + 1 < T) update_x(t0 + j + 1, Xn, Qn);           // tn = t0+j+1 is an own slice
         WAVE_LDS_ORDER();
         if (more) {
 #pragma unroll
@@ -553,7 +595,11 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
                 pprev[q] = pcur[q]; pcur[q] = pnext[q];
                 Ecur[q] = En[q];
             }
-            if (j + 1 + PF <= T) { load_sq(wrap(t0 + j + 1 + PF), Sn, Qn); load_e(wrap(t0 + j + 1 + PF), En); }   // refill this slot
+            if (j + 1 + PF <= T) {                                        // refill this slot
+                load_sq(wrap(t0 + j + 1 + PF), Sn, Qn);
+                load_e(wrap(t0 + j + 1 + PF), En);
+                if (j + 1 + PF < T) load_x(t0 + j + 1 + PF, Xn);
+            }
         }
     }
     acc = wave_sum2(acc);
@@ -570,19 +616,20 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_chunk(CgBufs B, ModelDev m, int 
 #undef IS_LEADER
 template <int NPL>
 __global__ void __launch_bounds__(WAVE) k_cg_xr_fast(CgBufs B, int N, int L, int parity) {
+    // r -= alpha z and the partial r.r.  x += alpha p is NOT done here: the next k_cg_ap reads this p anyway (as its p_old),
+    // so it applies the update there and this kernel moves 24 B per element instead of 48 (alpha travels in B.alpha).
     int t, rhs;
     if (!xcd_map(L, t, rhs)) return;
     const size_t ndim = (size_t)N * L;
     const CgState S = ld_state(B.state + 2 * rhs + parity);   // written by the k_cg_ap launch just before
-    const double *p = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
     const double *z = B.z + (size_t)rhs * ndim;
-    double *x = B.x + (size_t)rhs * ndim, *r = B.r + (size_t)rhs * ndim;
-    double xv[NPL], pv[NPL], rv[NPL], zv[NPL];
+    double *r = B.r + (size_t)rhs * ndim;
+    double rv[NPL], zv[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * WAVE;
         const size_t i = (size_t)t * N + ((s < N) ? s : N - 1);
-        xv[q] = x[i]; pv[q] = p[i]; rv[q] = r[i]; zv[q] = z[i];
+        rv[q] = r[i]; zv[q] = z[i];
     }
     const double pap = reduce_partials2(B.pap + (size_t)rhs * B.npap, B.npap);
     if (S.done) return;
@@ -593,14 +640,16 @@ __global__ void __launch_bounds__(WAVE) k_cg_xr_fast(CgBufs B, int N, int L, int
         const int s = threadIdx.x + q * WAVE;
         if (s < N) {
             const size_t i = (size_t)t * N + s;
-            x[i] = xv[q] + alpha * pv[q];
             const double rn = rv[q] - alpha * zv[q];
             r[i] = rn;
             acc += rn * rn;
         }
     }
     acc = wave_sum2(acc);
-    if (threadIdx.x == 0) B.rr[(size_t)rhs * L + t] = acc;
+    if (threadIdx.x == 0) {
+        B.rr[(size_t)rhs * L + t] = acc;
+        if (t == 0) B.alpha[rhs] = alpha;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

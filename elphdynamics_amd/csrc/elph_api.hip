@@ -199,6 +199,7 @@ static int ensure_capacity(elph_handle_s *h, int nrhs) {
     RC(dev_alloc(&h->d_part, 4 * c * (size_t)h->L * (size_t)h->npl));
     RC(dev_alloc(&h->d_state, 2 * c));
     RC(dev_alloc(&h->d_scal, 4 * c));
+    RC(dev_alloc(&h->d_alpha, c));
     const size_t Lo2 = (size_t)(h->L + 1) / 2, Lh = (size_t)h->L / 2 + 1;
     RC(dev_alloc(&h->d_nu, c * std::max(std::max(Lo2, Lh) * (size_t)h->N, nd)));
     if (h->h_state) HIPCHK(hipHostFree(h->h_state));
@@ -345,7 +346,7 @@ extern "C" int elph_destroy(elph_handle h) {
     elph_dft_mfma_free(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
-                    h->d_hist, h->d_scal, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
+                    h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_klam, h->d_ssh_x, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_cb, h->d_ssh_slot, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
                     h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -74,6 +74,7 @@ struct CgBufs {
     double *x, *r, *z, *zp;     // [nrhs][ndim]; zp = P^-1 r (preconditioned only)
     double *p;                  // [2][nrhs][ndim] ping-pong by (seq & 1)
     double *pap, *rr, *rz;      // partial sums [nrhs][npart]
+    double *alpha;              // [nrhs] step length of the last k_cg_xr (fast family: x += alpha p is applied by the NEXT k_cg_ap)
     CgState *state;             // [nrhs][2]
     CgParams params;
     double *hist;               // optional eps history
@@ -205,6 +206,7 @@ struct elph_handle_s {
     double *d_hist = nullptr;
     int64_t hist_cap = 0;
     double *d_scal = nullptr;              // small scalar scratch (residual norms), 4*cap_rhs
+    double *d_alpha = nullptr;             // cap_rhs: CG step length handed from k_cg_xr to the next k_cg_ap
     double *h_scal = nullptr;              // pinned
 
     // captured CG chunk graphs, keyed by (nrhs, use_prec)

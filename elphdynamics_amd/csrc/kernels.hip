@@ -976,6 +976,7 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     B.x = h->d_x; B.r = h->d_r; B.z = h->d_z; B.zp = h->d_zp; B.p = h->d_p;
     B.pap = h->d_part; B.rr = h->d_part + P; B.rz = h->d_part + 2 * P;
     B.state = h->d_state; B.params = h->cur_params; B.hist = h->d_hist;
+    B.alpha = h->d_alpha;
     B.dot_lo = h->dot_hi > 0 ? h->dot_lo : 0;
     B.dot_hi = h->dot_hi > 0 ? h->dot_hi : (int)h->N;
     B.nrz = (int)(h->L * h->npl);
