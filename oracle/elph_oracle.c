@@ -1290,17 +1290,25 @@ void elpho_calc_dSbdx_holstein(double *dSbdx, int64_t N, int64_t L, double dtau,
 
 typedef struct {
     const elpho_hmc_params *hp;
+    const elpho_hmc_ssh *ssh;       /* NULL: Holstein */
     elpho_model *m;
     elpho_kpm *P;
     double *x, *v;
     double *phi[2], *Lphi[2], *X[2], *Lam, *u, *y, *dSdx, *r, *p, *z;
     const double *kpm_randn;
     int64_t kpm_calls;
+    int64_t nf;                     /* phonon columns: Nsites (Holstein) or Nph (SSH) */
     double solver_iters;
 } hmc_ws;
 
 static void hmc_update_model(hmc_ws *w) {
     const elpho_hmc_params *hp = w->hp;
+    if (w->ssh) {                                                 /* SSHModels.jl:510-562 */
+        const elpho_hmc_ssh *q = w->ssh;
+        elpho_update_model_ssh(hp->N, hp->L, w->m->nb, q->Nph, hp->dtau, w->x, q->t, q->alpha, q->alpha2, hp->mu,
+                               q->phonon_to_bond, q->cb_perm, (double *)w->m->c, (double *)w->m->s, (double *)w->m->E);
+        return;
+    }
     elpho_update_model_holstein(hp->N, hp->L, hp->dtau, w->x, hp->lambda, hp->lambda2, hp->mu, (double *)w->m->E);
 }
 
@@ -1317,9 +1325,14 @@ static int64_t hmc_calc_OinvLphi(hmc_ws *w, double power, int64_t *flag) {
         elpho_kpm_arnoldi_bounds(w->P, hp->kpm_n, bmax, bmin, &emin, &emax);
         elpho_kpm_setup_from_bounds(w->P, emin, emax);
     }
-    elpho_update_Lambda(w->Lam, hp->N, hp->L, hp->dtau, w->x, hp->lambda, hp->lambda2);
-    elpho_mulLambda(w->Lphi[0], w->phi[0], w->Lam, hp->N, hp->L);
-    elpho_mulLambda(w->Lphi[1], w->phi[1], w->Lam, hp->N, hp->L);
+    if (w->ssh) {                                                 /* Λ ≡ 1: update_Λ!/mulΛ! are no-ops (HMC.jl:943-946,970-973) */
+        memcpy(w->Lphi[0], w->phi[0], sizeof(double) * (size_t)n);
+        memcpy(w->Lphi[1], w->phi[1], sizeof(double) * (size_t)n);
+    } else {
+        elpho_update_Lambda(w->Lam, hp->N, hp->L, hp->dtau, w->x, hp->lambda, hp->lambda2);
+        elpho_mulLambda(w->Lphi[0], w->phi[0], w->Lam, hp->N, hp->L);
+        elpho_mulLambda(w->Lphi[1], w->phi[1], w->Lam, hp->N, hp->L);
+    }
     int64_t iters = 0, it, fl = 0;
     double res;
     for (int k = 0; k < 2 && fl == 0; k++) {
@@ -1342,16 +1355,27 @@ static double hmc_calc_Sf(hmc_ws *w) {                             /* HMC.jl:768
 
 static void hmc_calc_H(hmc_ws *w, double *H, double *S, double *K) {   /* HMC.jl:697-721,745-756 */
     const elpho_hmc_params *hp = w->hp;
-    const int64_t n = hp->N * hp->L;
+    const int64_t nfl = w->nf * hp->L;
     *S = hmc_calc_Sf(w);
-    *S += elpho_calc_Sb_holstein(hp->N, hp->L, hp->dtau, w->x, hp->omega, hp->omega4);
-    elpho_fourier_accelerate(w->y, w->v, hp->fa_M, 1.0, hp->N, hp->L);
-    *K = dotp(w->v, w->y, n) / 2;
+    /* calc_Sb: the SSH version (PhononAction.jl:68-97, every field its own primary field) is the Holstein sum over Nph columns */
+    *S += elpho_calc_Sb_holstein(w->nf, hp->L, hp->dtau, w->x, hp->omega, hp->omega4);
+    elpho_fourier_accelerate(w->y, w->v, hp->fa_M, 1.0, w->nf, hp->L);
+    *K = dotp(w->v, w->y, nfl) / 2;
     *H = *S + *K;
 }
 
 static void hmc_calc_dSfdx(hmc_ws *w) {                            /* HMC.jl:790-814 */
     const elpho_hmc_params *hp = w->hp;
+    if (w->ssh) {                                                  /* dSf/dx += -dMdx(M X±, X±); muldΛdx! is a no-op (:1027-1030) */
+        const elpho_hmc_ssh *q = w->ssh;
+        const int64_t nfl = w->nf * hp->L;
+        for (int k = 0; k < 2; k++) {
+            elpho_mulM(w->u, w->m, w->X[k]);
+            elpho_muldMdx_ssh(w->y, w->u, w->m, w->X[k], hp->dtau, q->bond_to_phonon_cb, q->alpha, q->alpha2, w->x, q->Nph);
+            for (int64_t i = 0; i < nfl; i++) w->dSdx[i] += -w->y[i];
+        }
+        return;
+    }
     elpho_calc_dSfdx_holstein(w->dSdx, w->m, w->X[0], w->X[1], w->phi[0], w->phi[1], w->Lam, hp->dtau, hp->lambda,
                               hp->lambda2, w->x, w->u, w->y);
 }
@@ -1360,73 +1384,81 @@ static void hmc_calc_dSfdx(hmc_ws *w) {                            /* HMC.jl:790
  * The random numbers the reference draws from model.rng are inputs: R[Ndof] (refresh_v!, :648-659),
  * Rp, Rm [Ndim] (refresh_ϕ!, :665-692), kpm_randn[(nt+2)*2*N] (one pair of Arnoldi start vectors per setup!,
  * consumed in call order; may be NULL when P is NULL) and the uniform u of the accept/reject step (:441,:617).
- * out[0..7] = H0, H1, S (last calc_H), K (last calc_H), returned iters = cld(iters, nt+2), flag, P_accept, solver calls. */
-int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, double *x, double *v,
-                                  const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
-                                  double *out) {
+ * out[0..7] = H0, H1, S (last calc_H), K (last calc_H), returned iters = cld(iters, nt+2), flag, P_accept, solver calls.
+ * ssh == NULL: Holstein (fields on sites, Λ from x); ssh != NULL: SSH (Nph bond-phonon columns, Λ ≡ 1, hp->omega,
+ * omega4, fa_M per phonon; hp->lambda, lambda2 unused). */
+static int64_t hmc_update_generic(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x,
+                                  double *v, const double *R, const double *Rp, const double *Rm, const double *kpm_randn,
+                                  double u, double *out) {
     const int64_t N = hp->N, L = hp->L, n = N * L, nt = hp->nt, nb = hp->nb;
+    const int64_t nf = ssh ? ssh->Nph : N, nfl = nf * L, nmax = (nfl > n) ? nfl : n;
     const double dt = hp->dt, dtp = hp->dt / (double)hp->nb;
-    double *buf = (double *)calloc((size_t)(16 * n), sizeof(double));
+    double *buf = (double *)calloc((size_t)(16 * nmax), sizeof(double));
     hmc_ws w;
     memset(&w, 0, sizeof w);
-    w.hp = hp; w.m = m; w.P = P; w.x = x; w.v = v; w.kpm_randn = kpm_randn;
+    w.hp = hp; w.ssh = ssh; w.m = m; w.P = P; w.x = x; w.v = v; w.kpm_randn = kpm_randn; w.nf = nf;
     double *q = buf;
-    w.phi[0] = q; q += n; w.phi[1] = q; q += n; w.Lphi[0] = q; q += n; w.Lphi[1] = q; q += n;
-    w.X[0] = q; q += n; w.X[1] = q; q += n; w.Lam = q; q += n; w.u = q; q += n; w.y = q; q += n;
-    w.dSdx = q; q += n; w.r = q; q += n; w.p = q; q += n; w.z = q; q += n;
-    double *x0 = q; q += n;
-    double *v0 = q; q += n;
+    w.phi[0] = q; q += nmax; w.phi[1] = q; q += nmax; w.Lphi[0] = q; q += nmax; w.Lphi[1] = q; q += nmax;
+    w.X[0] = q; q += nmax; w.X[1] = q; q += nmax; w.Lam = q; q += nmax; w.u = q; q += nmax; w.y = q; q += nmax;
+    w.dSdx = q; q += nmax; w.r = q; q += nmax; w.p = q; q += nmax; w.z = q; q += nmax;
+    double *x0 = q; q += nmax;
+    double *v0 = q; q += nmax;
     double *Q = w.dSdx;                                            /* QdSdx aliases dSdx (:349) */
     int64_t flag = 0, iters = 0, itrs;
     double H0 = 0, H1 = 0, S = 0, K = 0;
 
     hmc_update_model(&w);
     /* refresh_v! (:648-659) */
-    elpho_fourier_accelerate(w.y, R, hp->fa_M, -0.5, N, L);
-    for (int64_t i = 0; i < n; i++) v[i] = hp->alpha * v[i] + sqrt(1.0 - hp->alpha * hp->alpha) * w.y[i];
-    memcpy(x0, x, sizeof(double) * (size_t)n);
-    memcpy(v0, v, sizeof(double) * (size_t)n);
-    /* refresh_ϕ! (:665-692) */
-    elpho_update_Lambda(w.Lam, N, L, hp->dtau, x, hp->lambda, hp->lambda2);
-    elpho_mulMT(w.Lphi[0], m, Rp);
-    elpho_mulLambdaInv(w.phi[0], w.Lphi[0], w.Lam, N, L);
-    elpho_mulMT(w.Lphi[1], m, Rm);
-    elpho_mulLambdaInv(w.phi[1], w.Lphi[1], w.Lam, N, L);
+    elpho_fourier_accelerate(w.y, R, hp->fa_M, -0.5, nf, L);
+    for (int64_t i = 0; i < nfl; i++) v[i] = hp->alpha * v[i] + sqrt(1.0 - hp->alpha * hp->alpha) * w.y[i];
+    memcpy(x0, x, sizeof(double) * (size_t)nfl);
+    memcpy(v0, v, sizeof(double) * (size_t)nfl);
+    /* refresh_ϕ! (:665-692): ϕ± = Λ⁻¹ Mᵀ R± */
+    if (ssh) {
+        elpho_mulMT(w.phi[0], m, Rp);
+        elpho_mulMT(w.phi[1], m, Rm);
+    } else {
+        elpho_update_Lambda(w.Lam, N, L, hp->dtau, x, hp->lambda, hp->lambda2);
+        elpho_mulMT(w.Lphi[0], m, Rp);
+        elpho_mulLambdaInv(w.phi[0], w.Lphi[0], w.Lam, N, L);
+        elpho_mulMT(w.Lphi[1], m, Rm);
+        elpho_mulLambdaInv(w.phi[1], w.Lphi[1], w.Lam, N, L);
+    }
 
     itrs = hmc_calc_OinvLphi(&w, 2.0, &flag);
     if (nb == 1) iters = itrs;                                     /* :373;  the multi-timestep variant has "iters += iters" (:507) */
     if (flag == 0) {
         hmc_calc_H(&w, &H0, &S, &K);
-        memset(w.dSdx, 0, sizeof(double) * (size_t)n);
+        memset(w.dSdx, 0, sizeof(double) * (size_t)nfl);
         hmc_calc_dSfdx(&w);
-        if (nb == 1) elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
-        elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
+        if (nb == 1) elpho_calc_dSbdx_holstein(w.dSdx, nf, L, hp->dtau, x, hp->omega, hp->omega4);
+        elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, nf, L);
         for (int64_t t = 1; t <= nt; t++) {
-            for (int64_t i = 0; i < n; i++) v[i] = v[i] - dt / 2 * Q[i];
+            for (int64_t i = 0; i < nfl; i++) v[i] = v[i] - dt / 2 * Q[i];
             if (nb == 1) {
-                for (int64_t i = 0; i < n; i++) x[i] = x[i] + dt * v[i];
+                for (int64_t i = 0; i < nfl; i++) x[i] = x[i] + dt * v[i];
             } else {
-                memset(w.dSdx, 0, sizeof(double) * (size_t)n);
-                elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
-                elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
+                memset(w.dSdx, 0, sizeof(double) * (size_t)nfl);
+                elpho_calc_dSbdx_holstein(w.dSdx, nf, L, hp->dtau, x, hp->omega, hp->omega4);
+                elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, nf, L);
                 for (int64_t tp = 1; tp <= nb; tp++) {
-                    for (int64_t i = 0; i < n; i++) v[i] = v[i] - dtp / 2 * Q[i];
-                    for (int64_t i = 0; i < n; i++) x[i] = x[i] + dtp * v[i];
-                    memset(w.dSdx, 0, sizeof(double) * (size_t)n);
-                    elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
-                    elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
-                    for (int64_t i = 0; i < n; i++) v[i] = v[i] - dtp / 2 * Q[i];
+                    for (int64_t i = 0; i < nfl; i++) v[i] = v[i] - dtp / 2 * Q[i];
+                    for (int64_t i = 0; i < nfl; i++) x[i] = x[i] + dtp * v[i];
+                    memset(w.dSdx, 0, sizeof(double) * (size_t)nfl);
+                    elpho_calc_dSbdx_holstein(w.dSdx, nf, L, hp->dtau, x, hp->omega, hp->omega4);
+                    elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, nf, L);
+                    for (int64_t i = 0; i < nfl; i++) v[i] = v[i] - dtp / 2 * Q[i];
                 }
             }
             hmc_update_model(&w);
             itrs = hmc_calc_OinvLphi(&w, 1.0, &flag);
             iters += itrs;
             if (flag > 0) break;
-            memset(w.dSdx, 0, sizeof(double) * (size_t)n);
+            memset(w.dSdx, 0, sizeof(double) * (size_t)nfl);
             hmc_calc_dSfdx(&w);
-            if (nb == 1) elpho_calc_dSbdx_holstein(w.dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4);
-            elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, N, L);
-            for (int64_t i = 0; i < n; i++) v[i] = v[i] - dt / 2 * Q[i];
+            if (nb == 1) elpho_calc_dSbdx_holstein(w.dSdx, nf, L, hp->dtau, x, hp->omega, hp->omega4);
+            elpho_fourier_accelerate(Q, w.dSdx, hp->fa_M, -1.0, nf, L);
+            for (int64_t i = 0; i < nfl; i++) v[i] = v[i] - dt / 2 * Q[i];
         }
     }
     double Pacc = 0.0;
@@ -1441,8 +1473,8 @@ int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, el
     }
     int64_t accepted = (u < Pacc && flag == 0) ? 1 : 0;
     if (!accepted) {
-        memcpy(x, x0, sizeof(double) * (size_t)n);
-        for (int64_t i = 0; i < n; i++) v[i] = -v0[i];
+        memcpy(x, x0, sizeof(double) * (size_t)nfl);
+        for (int64_t i = 0; i < nfl; i++) v[i] = -v0[i];
         hmc_update_model(&w);
     }
     out[0] = H0; out[1] = H1; out[2] = S; out[3] = K;
@@ -1450,6 +1482,19 @@ int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, el
     out[5] = (double)flag; out[6] = Pacc; out[7] = (double)w.kpm_calls;
     free(buf);
     return accepted;
+}
+
+int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, double *x, double *v,
+                                  const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
+                                  double *out) {
+    return hmc_update_generic(hp, NULL, m, P, x, v, R, Rp, Rm, kpm_randn, u, out);
+}
+
+/* The same update for the SSH model (bond phonons): x, v, R have Nph*L entries, Rp, Rm N*L; m->c, m->s, m->E writable. */
+int64_t elpho_hmc_update_ssh(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x,
+                             double *v, const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
+                             double *out) {
+    return hmc_update_generic(hp, ssh, m, P, x, v, R, Rp, Rm, kpm_randn, u, out);
 }
 
 /* SSHModels.jl:707-829 without the equivalent-field bookkeeping (primary_field == identity):

@@ -251,6 +251,20 @@ int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, el
                                   const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
                                   double *out);
 
+/* SSH extras of the HMC update (bond phonons, SSHModels.jl:79-314): per phonon t is indexed by RAW bond as in ssh.t */
+typedef struct {
+    int64_t Nph;
+    const double *t;                 /* [nbonds] bare hopping, raw bond order (ssh.t) */
+    const double *alpha, *alpha2;    /* [Nph] */
+    const int64_t *phonon_to_bond;   /* [Nph] 1-based raw bond of each phonon */
+    const int64_t *cb_perm;          /* [nbonds] checkerboard_perm */
+    const int64_t *bond_to_phonon_cb;/* [nbonds] 1-based phonon on checkerboard bond n, 0 = none */
+} elpho_hmc_ssh;
+
+int64_t elpho_hmc_update_ssh(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x,
+                             double *v, const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
+                             double *out);
+
 /* SSHModels.jl:707-829 (no equivalent fields); dMdx[Nph*L] is overwritten */
 void elpho_muldMdx_ssh(double *dMdx, const double *u, const elpho_model *m, const double *v, double dtau,
                        const int64_t *bond_to_phonon_cb, const double *alpha, const double *alpha2, const double *x,

@@ -77,6 +77,11 @@ class HmcParams(C.Structure):
                 ("alpha", c_dbl), ("solver_tol", c_dbl), ("solver_maxiter", c_i64), ("kmax", c_dbl), ("kpm_n", c_i64)]
 
 
+class HmcSsh(C.Structure):
+    _fields_ = [("Nph", c_i64), ("t", P_dbl), ("alpha", P_dbl), ("alpha2", P_dbl), ("phonon_to_bond", P_i64), ("cb_perm", P_i64),
+                ("bond_to_phonon_cb", P_i64)]
+
+
 class Oracle:
     """Loaded oracle library + thin numpy-level helpers."""
 
@@ -145,6 +150,9 @@ class Oracle:
         L.elpho_calc_Sb_holstein.restype = c_dbl
         L.elpho_calc_Sb_holstein.argtypes = [c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_calc_dSbdx_holstein.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_hmc_update_ssh.restype = c_i64
+        L.elpho_hmc_update_ssh.argtypes = [C.POINTER(HmcParams), C.POINTER(HmcSsh), C.POINTER(Model), C.POINTER(KPM), P_dbl, P_dbl,
+                                           P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]
         L.elpho_hmc_update_holstein.restype = c_i64
         L.elpho_hmc_update_holstein.argtypes = [C.POINTER(HmcParams), C.POINTER(Model), C.POINTER(KPM), P_dbl, P_dbl, P_dbl,
                                                 P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]
@@ -178,6 +186,38 @@ class Oracle:
         acc = self.lib.elpho_hmc_update_holstein(C.byref(hp), C.byref(m), C.byref(P) if P is not None else None, dp(x), dp(v),
                                                  dp(R), dp(Rp), dp(Rm), dp(kr) if kr is not None else None, float(randoms["u"]),
                                                  dp(out))
+        info = dict(H0=out[0], H1=out[1], S=out[2], K=out[3], iters=out[4], flag=int(out[5]), P_accept=out[6],
+                    kpm_calls=int(out[7]))
+        return bool(acc), x, v, info
+
+    def hmc_update_ssh(self, m, x, v, omega, omega4, mu, dtau, fa_M, t, alpha, alpha2, phonon_to_bond, cb_perm, dt, nt, nb,
+                       alpha_mom, randoms, P=None, tol=1e-5, maxiter=10000, kmax=1e12):
+        """update!(model, hmc, fa, P) for an SSH model (bond phonons): x, v, R are (Nph*L,), Rp/Rm (N*L,).  m.c, m.s, m.E are
+        overwritten (update_model!).  Same return convention as hmc_update_holstein."""
+        hp, sp = HmcParams(), HmcSsh()
+        Nph = len(alpha)
+        zeros = np.zeros(max(m.N, Nph))
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (omega, omega4, zeros, zeros, mu, fa_M, t, alpha, alpha2)]
+        iarrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (phonon_to_bond, cb_perm)]
+        b2p = np.zeros(m.nb, dtype=np.int64)
+        b2p[iarrs[1][iarrs[0] - 1] - 1] = np.arange(1, Nph + 1)
+        hp.N, hp.L, hp.dtau = m.N, m.L, dtau
+        hp.omega, hp.omega4, hp.lam, hp.lam2, hp.mu, hp.fa_M = (dp(a) for a in arrs[:6])
+        hp.dt, hp.nt, hp.nb, hp.alpha = dt, nt, nb, alpha_mom
+        hp.solver_tol, hp.solver_maxiter, hp.kmax = tol, maxiter, kmax
+        hp.kpm_n = P._n if P is not None else 0
+        sp.Nph = Nph
+        sp.t, sp.alpha, sp.alpha2 = dp(arrs[6]), dp(arrs[7]), dp(arrs[8])
+        sp.phonon_to_bond, sp.cb_perm, sp.bond_to_phonon_cb = ip(iarrs[0]), ip(iarrs[1]), ip(b2p)
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        v = np.ascontiguousarray(v, dtype=np.float64).copy()
+        out = np.zeros(8)
+        kr = randoms.get("kpm_randn")
+        kr = np.ascontiguousarray(kr, dtype=np.float64) if kr is not None else None
+        R, Rp, Rm = (np.ascontiguousarray(randoms[k], dtype=np.float64) for k in ("R", "Rp", "Rm"))
+        acc = self.lib.elpho_hmc_update_ssh(C.byref(hp), C.byref(sp), C.byref(m), C.byref(P) if P is not None else None, dp(x),
+                                            dp(v), dp(R), dp(Rp), dp(Rm), dp(kr) if kr is not None else None,
+                                            float(randoms["u"]), dp(out))
         info = dict(H0=out[0], H1=out[1], S=out[2], K=out[3], iters=out[4], flag=int(out[5]), P_accept=out[6],
                     kpm_calls=int(out[7]))
         return bool(acc), x, v, info

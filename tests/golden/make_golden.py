@@ -181,7 +181,7 @@ def gen_single_site():
 
 
 # ----------------------------------------------------------------------------- SSH small case
-def gen_ssh(tag, Lsp, Ltau, dtau, seed):
+def gen_ssh(tag, Lsp, Ltau, dtau, seed, with_alpha2=True):
     N = Lsp * Lsp
     raw = raw_table(1, Lsp, Lsp, 1, SQUARE)
     nb = raw.shape[0]
@@ -189,7 +189,7 @@ def gen_ssh(tag, Lsp, Ltau, dtau, seed):
     inv_cbp = perm[new_perm] + 1
     tb = np.ones(nb)                                   # bare hopping per raw bond
     alpha = np.full(nb, 0.1)
-    alpha2 = 0.03 * synth.randn(seed + 2, nb)
+    alpha2 = 0.03 * synth.randn(seed + 2, nb) if with_alpha2 else np.zeros(nb)
     mu = 0.1 * synth.randn(seed + 3, N)
     Nph = nb                                           # both bond types carry a phonon (ssh_hmc_square.toml)
     phonon_to_bond = np.arange(1, nb + 1, dtype=np.int64)
@@ -422,6 +422,109 @@ def gen_hmc(h, tag, seed, dt=0.05, nt=6, nb=1):
          H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0) + 0.5 * (v_init @ accel(v_init, 1.0)))
 
 
+def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
+    """One HMC trajectory of the SSH model (bond phonons, alpha2 = 0 so that M(x) is analytic) from the definitions:
+    S(x) = Sb(x) + 1/2 sum_± ϕ±ᵀ (MᵀM)⁻¹ ϕ± (Λ ≡ 1), dense M(x) with B(τ) = CB_τ(x) diag(exp(Δτ μ)),
+    cosh/sinh(Δτ (t - α x)) on the bonds; the force is the complex-step derivative of the dense action."""
+    g = np.load(os.path.join(HERE, f"ssh_{tag}.npz"))
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    table, cbp = g["table"], g["cbperm"]
+    nbd = table.shape[0]
+    tb, alpha, mu, p2b = g["t"], g["alpha"], g["mu"], g["phonon_to_bond"]
+    Nph = p2b.shape[0]
+    n, nf = N * L, Nph * L
+    x0 = g["x"].copy()
+    omega = 0.5 + 0.05 * synth.randn(seed + 1, Nph)
+    omega4 = 0.05 * np.abs(synth.randn(seed + 2, Nph))
+    m0, cc = 1.0, 0.3
+    k = np.arange(L)
+    kp = np.minimum(k, L - k)
+    mreg = m0 * np.exp(-(cc * kp / L) ** 2)
+    faM = dtau * (mreg[None, :] ** 2 + omega[:, None] ** 2 + (2 - 2 * np.cos(2 * np.pi * kp / L))[None, :] / dtau ** 2) \
+        / (mreg[None, :] ** 2 + omega[:, None] ** 2)                            # [Nph, L]
+    R, Rp, Rm = synth.randn(seed + 3, nf), synth.randn(seed + 4, n), synth.randn(seed + 5, n)
+    Emu = np.exp(dtau * mu)
+    cbidx = cbp[p2b - 1] - 1                                                    # checkerboard position of each phonon's bond
+
+    def accel(vec, power):
+        return np.real(scipy.fft.ifft(faM ** power * scipy.fft.fft(vec.reshape(Nph, L), axis=1), axis=1)).reshape(-1)
+
+    def dense_M_of(x):
+        X = x.reshape(Nph, L)
+        tp = np.empty((nbd, L), dtype=X.dtype)
+        tp[:] = tb[np.argsort(cbp)][:, None]                                    # bare hopping at each checkerboard position
+        tp[cbidx] = tb[p2b - 1][:, None] - alpha[:, None] * X
+        M = np.eye(n, dtype=X.dtype)
+        for t in range(L):
+            c, s_ = np.cosh(dtau * tp[:, t]), np.sinh(dtau * tp[:, t])
+            CB = np.eye(N, dtype=X.dtype)
+            for b in range(nbd):
+                i, j = table[b, 0] - 1, table[b, 1] - 1
+                ri, rj = CB[i].copy(), CB[j].copy()
+                CB[i] = c[b] * ri + s_[b] * rj
+                CB[j] = c[b] * rj + s_[b] * ri
+            B = CB * Emu[None, :]
+            tm1 = (t - 1) % L
+            sign = 1.0 if t == 0 else -1.0
+            M[np.ix_(np.arange(N) * L + t, np.arange(N) * L + tm1)] += sign * B
+        return M
+
+    def Sb(x):
+        X = x.reshape(Nph, L)
+        return dtau * np.sum(omega[:, None] ** 2 * X ** 2 / 2 + omega4[:, None] * X ** 4
+                             + (X - np.roll(X, 1, axis=1)) ** 2 / dtau ** 2 / 2)
+
+    def Sf(x, phis):
+        M = dense_M_of(x)
+        A = M.T @ M
+        tot = 0.0
+        for phi in phis:
+            tot = tot + 0.5 * (phi @ np.linalg.solve(A, phi))
+        return tot
+
+    def grad(fun, x):
+        hstep, out = 1e-30, np.empty(nf)
+        for kk in range(nf):
+            xc = x.astype(complex)
+            xc[kk] += 1j * hstep
+            out[kk] = np.imag(fun(xc)) / hstep
+        return out
+
+    x = x0.copy()
+    v = accel(R, -0.5)
+    v_init = v.copy()
+    M0 = dense_M_of(x)
+    phis = [M0.T @ Rp, M0.T @ Rm]
+    H = lambda x, v: Sb(x) + Sf(x, phis) + 0.5 * (v @ accel(v, 1.0))
+    H0 = H(x, v)
+    dSf0 = grad(lambda z: Sf(z, phis), x)
+    dSb0 = grad(Sb, x)
+    if nb == 1:
+        Q = accel(dSf0 + dSb0, -1.0)
+        for _ in range(nt):
+            v = v - dt / 2 * Q
+            x = x + dt * v
+            Q = accel(grad(lambda z: Sf(z, phis) + Sb(z), x), -1.0)
+            v = v - dt / 2 * Q
+    else:
+        dtp = dt / nb
+        Qf = accel(dSf0, -1.0)
+        for _ in range(nt):
+            v = v - dt / 2 * Qf
+            Qb = accel(grad(Sb, x), -1.0)
+            for _ in range(nb):
+                v = v - dtp / 2 * Qb
+                x = x + dtp * v
+                Qb = accel(grad(Sb, x), -1.0)
+                v = v - dtp / 2 * Qb
+            Qf = accel(grad(lambda z: Sf(z, phis), x), -1.0)
+            v = v - dt / 2 * Qf
+    H1 = H(x, v)
+    save(f"hmc_ssh_{tag}_nb{nb}.npz", N=N, Ltau=L, dtau=dtau, Nph=Nph, omega=omega, omega4=omega4, x0=x0, faM=faM.reshape(-1), R=R,
+         Rp=Rp, Rm=Rm, dt=dt, nt=nt, nb=nb, v_init=v_init, phi_p=phis[0], phi_m=phis[1], H0=H0, H1=H1, Sb0=Sb(x0), dSb0=dSb0,
+         dSf0=dSf0, x1=x, v1=v, H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0) + 0.5 * (v_init @ accel(v_init, 1.0)))
+
+
 # ----------------------------------------------------------------------------- Green's-function estimator
 def gen_greens(h, tag, norb, Lsp, seed, nv=3):
     """Stochastic Green's-function estimator (GreensFunctions.jl:201-288): the four translation-averaged products
@@ -470,6 +573,9 @@ if __name__ == "__main__":
     gen_holstein("tri3_L5", 1, 3, TRI, 5, 0.125, seed=33)
     gen_single_site()
     gen_ssh("sq4_L8", 4, 8, 0.05, seed=44)
+    gen_ssh("sq4_L8_a", 4, 8, 0.05, seed=45, with_alpha2=False)        # alpha2 = 0: analytic in x (complex-step HMC golden)
+    gen_hmc_ssh("sq4_L8_a", seed=67, nb=1)
+    gen_hmc_ssh("sq4_L8_a", seed=67, nb=3)
     gen_fft()
     gen_kpm(h1, "sq4_L8")
     gen_hmc(h1, "sq4_L8", seed=66, nb=1)
