@@ -469,12 +469,11 @@ extern "C" int elph_update_model_ssh(elph_handle h, const double *cosht, const d
 //   t_bare_cb  double[nbonds]       bare hopping of EVERY bond in checkerboard order (bonds without a phonon keep it)
 //   mu         double[nsites]
 // A bond is driven by at most one field per tau (equivalent fields carry equal x, :548-558).
-extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int64_t nph, const int64_t *cb_index, const double *t_ph,
-                                            const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu,
-                                            double dtau) {
-    CHECK_H(h);
+// per-phonon tables, bare hoppings, lane-program slot map and mu of an SSH handle -> device (d_ssh_*, d_lam)
+int elph_i_ssh_upload_params(elph_handle_s *h, int64_t nph, const int64_t *cb_index, const double *t_ph, const double *alpha,
+                             const double *alpha2, const double *t_bare_cb, const double *mu) {
     if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
-    if (nph < 0 || !mu || (h->nb > 0 && !t_bare_cb) || (nph > 0 && (!x || !cb_index || !t_ph || !alpha || !alpha2))) {
+    if (nph < 0 || !mu || (h->nb > 0 && !t_bare_cb) || (nph > 0 && (!cb_index || !t_ph || !alpha || !alpha2))) {
         elph_set_error("null argument");
         return ELPH_E_ARG;
     }
@@ -511,7 +510,6 @@ extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int6
         h->ssh_nph_cap = (int64_t)np;
     }
     if (np > 0) {
-        HIPCHK(hipMemcpyAsync(h->d_ssh_x, x, np * L * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_ssh_par, t_ph, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_ssh_par + np, alpha, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_ssh_par + 2 * np, alpha2, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -519,9 +517,21 @@ extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int6
     }
     if (nb > 0) HIPCHK(hipMemcpyAsync(h->d_ssh_tbare, t_bare_cb, nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam, mu, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_ssh_update(h, h->d_ssh_x, (int)np, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, dtau));
     HIPCHK(hipStreamSynchronize(h->stream));       // cb0 / the caller's arrays may go away
     h->ssh_nph = (int)np;
+    return ELPH_OK;
+}
+
+extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int64_t nph, const int64_t *cb_index, const double *t_ph,
+                                            const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu,
+                                            double dtau) {
+    CHECK_H(h);
+    if (nph > 0 && !x) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(elph_i_ssh_upload_params(h, nph, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu));
+    const size_t np = (size_t)nph;
+    if (np > 0) HIPCHK(hipMemcpyAsync(h->d_ssh_x, x, np * (size_t)h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_ssh_update(h, h->d_ssh_x, (int)np, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, dtau));
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->ssh_dtau = dtau;
     h->cs_host_stale = true;
     h->have_E = true;

@@ -263,14 +263,16 @@ int elph_i_reserve_chains(elph_handle_s *h, int nchains);   // d_E for nchains c
 void elph_i_drop_graphs(elph_handle_s *h);
 void elph_hmc_free(elph_handle_s *h);
 void elph_greens_free(elph_handle_s *h);
-int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec);
-int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec);
+int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec, int ncols = 0);
+int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec, int ncols = 0);
 int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain = 0);
 int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
-                           const double *tbare_dev, const int *slot_dev, double dtau);
+                           const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major = 0);
 int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev);
 int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
-                            const int *cb0_dev, int nph, double dtau);
+                            const int *cb0_dev, int nph, double dtau, int tau_major = 0, double scale = 1.0);
+int elph_i_ssh_upload_params(elph_handle_s *h, int64_t nph, const int64_t *cb_index, const double *t_ph, const double *alpha,
+                             const double *alpha2, const double *t_bare_cb, const double *mu);
 int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
 int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec);
 int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec);

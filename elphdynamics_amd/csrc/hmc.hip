@@ -26,7 +26,9 @@ constexpr int TPB = 256;
 
 struct HmcState {
     int nch = 1;                 // chains advanced in lockstep (one phonon configuration, one trajectory each)
-    // per chain: [nch][ndim], layout S inside a chain
+    bool ssh = false;            // SSH: the fields are bond phonons (nf = Nph columns), Λ ≡ 1
+    int nf = 0;                  // phonon columns: nsites (Holstein) or Nph (SSH); field vectors are [tau][column]
+    // per chain: [nch][nf*L], layout S (tau-major) inside a chain
     double *x = nullptr, *v = nullptr, *x0 = nullptr, *v0 = nullptr, *dS = nullptr, *y = nullptr;
     double *R2 = nullptr;        // [2][nch][ndim] R±
     double *phi = nullptr;       // [2][nch][ndim] ϕ±
@@ -173,7 +175,7 @@ int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, 
 
 int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
     const int L = (int)h->L, nch = st->nch;
-    hipLaunchKernelGGL(k_hmc_sb_part, dim3((unsigned)L, (unsigned)nch), dim3(TPB), 0, h->stream, st->part, st->x, st->par, (int)h->N, L,
+    hipLaunchKernelGGL(k_hmc_sb_part, dim3((unsigned)L, (unsigned)nch), dim3(TPB), 0, h->stream, st->part, st->x, st->par, st->nf, L,
                        st->dtau);
     RC(chk("k_hmc_sb_part"));
     std::vector<double> p((size_t)L * nch);
@@ -188,6 +190,13 @@ int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
 }
 
 int update_model(elph_handle_s *h, HmcState *st) {
+    if (st->ssh) {      // SSHModels.jl:510-562 from the device-resident fields (tau-major)
+        RC(elph_launch_ssh_update(h, st->x, st->nf, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, st->dtau, 1));
+        h->ssh_dtau = st->dtau;
+        h->cs_host_stale = true;
+        h->have_E = true;
+        return ELPH_OK;
+    }
     const long long n = (long long)h->ndim * st->nch;
     hipLaunchKernelGGL(k_hmc_expV, dim3(nblk(n)), dim3(TPB), 0, h->stream, h->d_E, st->x, h->d_lam, (int)h->N, n, st->dtau);
     h->have_E = true;
@@ -208,7 +217,10 @@ int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power,
         RC(elph_kpm_setup_chains(h, bmax, bmin, nullptr, nullptr, nullptr, nullptr, nullptr));
         use = 1;                      // an inactive preconditioner is the identity inside the preconditioned recurrence
     }
-    RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
+    if (st->ssh)        // Λ ≡ 1 (HMC.jl:943-946,970-973): the right-hand sides are ϕ± themselves
+        HIPCHK(hipMemcpyAsync(h->d_b, st->phi, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    else
+        RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
     HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * (size_t)nch * nd * sizeof(double), h->stream));
     const double tol0 = h->tol;
     h->tol = pow(tol0, power);
@@ -230,7 +242,7 @@ int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power,
 }
 
 int fa(elph_handle_s *h, HmcState *st, double *out, const double *in, double power) {
-    return elph_launch_fft_accel(h, out, in, st->faM, power, h->N, st->nch);
+    return elph_launch_fft_accel(h, out, in, st->faM, power, st->nf, st->nch);
 }
 
 // calc_H (HMC.jl:697-705) per chain: S = Sf + Sb (:745-756,768-784), K = v·(M v)/2 (:711-719)
@@ -240,7 +252,7 @@ int calc_H(elph_handle_s *h, HmcState *st, double *H, double *S, double *K) {
     RC(dots_host(h, st, h->d_b, h->d_x, (long long)h->ndim, 2 * nch, sf.data()));
     RC(calc_Sb(h, st, sb.data()));
     RC(fa(h, st, st->y, st->v, 1.0));
-    RC(dots_host(h, st, st->v, st->y, (long long)h->ndim, nch, k.data()));
+    RC(dots_host(h, st, st->v, st->y, (long long)st->nf * h->L, nch, k.data()));
     for (int c = 0; c < nch; ++c) {
         S[c] = (sf[(size_t)c] + sf[(size_t)nch + c]) / 2 + sb[(size_t)c];
         K[c] = k[(size_t)c] / 2;
@@ -251,10 +263,15 @@ int calc_H(elph_handle_s *h, HmcState *st, double *H, double *S, double *K) {
 
 // dS/dx = dSf/dx [+ dSb/dx]; Q = M^-1 dS/dx in place  (HMC.jl:379-384)
 int force(elph_handle_s *h, HmcState *st, bool with_Sb) {
-    const long long n = (long long)h->ndim * st->nch;
-    RC(elph_launch_force_holstein(h, st->dS, h->d_x, st->phi, st->x, st->dtau, st->nch));
+    const long long n = (long long)st->nf * h->L * st->nch;
+    if (st->ssh) {      // dSf/dx = -dMdx(M X₊, X₊) - dMdx(M X₋, X₋)  (HMC.jl:797-808; muldΛdx! is a no-op)
+        RC(elph_launch_force_ssh(h, h->d_p, h->d_x));                          // bond brackets q[tau][bond] (d_p is free here)
+        RC(elph_launch_ssh_scatter(h, st->dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -1.0));
+    } else {
+        RC(elph_launch_force_holstein(h, st->dS, h->d_x, st->phi, st->x, st->dtau, st->nch));
+    }
     if (with_Sb) {
-        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 1,
+        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1,
                            st->nch);
         RC(chk("k_hmc_dsb"));
     }
@@ -262,23 +279,25 @@ int force(elph_handle_s *h, HmcState *st, bool with_Sb) {
 }
 
 int boson_force(elph_handle_s *h, HmcState *st) {
-    const long long n = (long long)h->ndim * st->nch;
-    hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 0,
+    const long long n = (long long)st->nf * h->L * st->nch;
+    hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 0,
                        st->nch);
     RC(chk("k_hmc_dsb"));
     return fa(h, st, st->dS, st->dS, -1.0);
 }
 
 int leap(elph_handle_s *h, HmcState *st, double cv, double cx) {
-    const long long n = (long long)h->ndim * st->nch;
+    const long long n = (long long)st->nf * h->L * st->nch;
     hipLaunchKernelGGL(k_hmc_leap, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->v, st->x, st->dS, cv, cx, n);
     return chk("k_hmc_leap");
 }
 
 // host [nvec][ndim] (reference layout) -> device layout S, staged through the handle's staging buffer (cap = 2 nch vectors)
-int upload_vectors(elph_handle_s *h, double *dstS, const double *host, int nvec) {
-    HIPCHK(hipMemcpyAsync(h->d_stage_in, host, (size_t)nvec * (size_t)h->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    return elph_launch_r2s(h, dstS, h->d_stage_in, nvec);
+// ncols = 0: site vectors (ndim); otherwise field vectors with that many columns
+int upload_vectors(elph_handle_s *h, double *dstS, const double *host, int nvec, int ncols = 0) {
+    const size_t per = (size_t)(ncols > 0 ? ncols : h->N) * (size_t)h->L;
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, host, (size_t)nvec * per * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return elph_launch_r2s(h, dstS, h->d_stage_in, nvec, ncols);
 }
 
 HmcState *state_of(elph_handle_s *h) { return static_cast<HmcState *>(h->hmc); }
@@ -303,41 +322,64 @@ void elph_hmc_free(elph_handle_s *h) {
         HIPCHK(hipSetDevice((h)->device));            \
     } while (0)
 
-extern "C" int elph_hmc_create_chains(elph_handle h, int nchains, const double *omega, const double *omega4, const double *lambda,
-                                      const double *lambda2, const double *mu, double dtau, const double *fa_mass) {
-    CHECK_H(h);
-    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("HMC trajectory: Holstein handles only"); return ELPH_E_UNSUPPORTED; }
-    if (nchains < 1 || !omega || !omega4 || !lambda || !lambda2 || !mu || !fa_mass || !(dtau > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    RC(elph_i_ensure_capacity(h, 2 * nchains));
-    RC(elph_i_reserve_chains(h, nchains));
+static int hmc_create_core(elph_handle_s *h, int nchains, int nf, bool ssh, const double *omega, const double *omega4, double dtau,
+                           const double *fa_mass) {
+    // staging / scratch must hold the field vectors too (SSH: Nph columns may exceed the number of sites)
+    const int per_field = (int)(((int64_t)nf + h->N - 1) / h->N);
+    RC(elph_i_ensure_capacity(h, std::max(2 * nchains, 2 * per_field + 1)));
     elph_hmc_free(h);
     HmcState *st = new HmcState();
     h->hmc = st;
-    st->nch = nchains;
-    const size_t nd = (size_t)h->ndim, N = (size_t)h->N, nc = (size_t)nchains;
+    st->nch = nchains; st->nf = nf; st->ssh = ssh;
+    const size_t nd = (size_t)h->ndim, nfd = (size_t)nf * (size_t)h->L, nc = (size_t)nchains;
     double **vecs[] = {&st->x, &st->v, &st->x0, &st->v0, &st->dS, &st->y};
-    for (double **p : vecs) HIPCHK(hipMalloc((void **)p, nc * nd * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&st->faM, nd * sizeof(double)));
+    for (double **p : vecs) HIPCHK(hipMalloc((void **)p, nc * nfd * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&st->faM, nfd * sizeof(double)));
     HIPCHK(hipMalloc((void **)&st->R2, 2 * nc * nd * sizeof(double)));
     HIPCHK(hipMalloc((void **)&st->phi, 2 * nc * nd * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&st->par, 2 * N * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&st->par, 2 * (size_t)nf * sizeof(double)));
     HIPCHK(hipMalloc((void **)&st->part, 2 * nc * (size_t)h->L * sizeof(double)));
     st->dtau = dtau;
-    HIPCHK(hipMemcpyAsync(st->par, omega, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(st->par + N, omega4, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(st->par, omega, (size_t)nf * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(st->par + nf, omega4, (size_t)nf * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(upload_vectors(h, st->faM, fa_mass, 1, nf));
+    HIPCHK(hipMemsetAsync(st->v, 0, nc * nfd * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st->x, 0, nc * nfd * sizeof(double), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_hmc_create_chains(elph_handle h, int nchains, const double *omega, const double *omega4, const double *lambda,
+                                      const double *lambda2, const double *mu, double dtau, const double *fa_mass) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("elph_hmc_create[_chains]: Holstein handles (SSH: elph_hmc_create_ssh)"); return ELPH_E_UNSUPPORTED; }
+    if (nchains < 1 || !omega || !omega4 || !lambda || !lambda2 || !mu || !fa_mass || !(dtau > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    RC(elph_i_ensure_capacity(h, 2 * nchains));
+    RC(elph_i_reserve_chains(h, nchains));
+    const size_t N = (size_t)h->N;
     HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    RC(upload_vectors(h, st->faM, fa_mass, 1));
-    HIPCHK(hipMemsetAsync(st->v, 0, nc * nd * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(st->x, 0, nc * nd * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return ELPH_OK;
+    return hmc_create_core(h, nchains, (int)h->N, false, omega, omega4, dtau, fa_mass);
 }
 
 extern "C" int elph_hmc_create(elph_handle h, const double *omega, const double *omega4, const double *lambda,
                                const double *lambda2, const double *mu, double dtau, const double *fa_mass) {
     return elph_hmc_create_chains(h, 1, omega, omega4, lambda, lambda2, mu, dtau, fa_mass);
+}
+
+// HybridMonteCarlo for an SSH model (bond phonons): omega, omega4 per phonon (double[nph]), fa_mass double[nph * ltau]; the
+// remaining arguments are those of elph_update_model_ssh_fields (couplings, checkerboard positions, bare hoppings, mu).
+extern "C" int elph_hmc_create_ssh(elph_handle h, int64_t nph, const double *omega, const double *omega4, const int64_t *cb_index,
+                                   const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb,
+                                   const double *mu, double dtau, const double *fa_mass) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("elph_hmc_create_ssh: SSH handles only"); return ELPH_E_UNSUPPORTED; }
+    if (nph < 1 || !omega || !omega4 || !fa_mass || !(dtau > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if ((size_t)h->L * (size_t)h->nb > 2 * (size_t)h->ndim) { elph_set_error("more bonds than 2*nsites: scratch too small"); return ELPH_E_UNSUPPORTED; }
+    RC(elph_i_ssh_upload_params(h, nph, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu));
+    return hmc_create_core(h, 1, (int)nph, true, omega, omega4, dtau, fa_mass);
 }
 
 // x, v: double[nchains * ndim] (chain-major, reference layout inside a chain); NULL = leave
@@ -346,12 +388,12 @@ extern "C" int elph_hmc_set_state(elph_handle h, const double *x, const double *
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
     if (x) {
-        RC(upload_vectors(h, st->x, x, st->nch));
+        RC(upload_vectors(h, st->x, x, st->nch, st->nf));
         HIPCHK(hipStreamSynchronize(h->stream));
         st->have_state = true;
     }
     if (v) {
-        RC(upload_vectors(h, st->v, v, st->nch));
+        RC(upload_vectors(h, st->v, v, st->nch, st->nf));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return ELPH_OK;
@@ -361,14 +403,14 @@ extern "C" int elph_hmc_get_state(elph_handle h, double *x, double *v) {
     CHECK_H(h);
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
-    const size_t bytes = (size_t)st->nch * (size_t)h->ndim * sizeof(double);
+    const size_t bytes = (size_t)st->nch * (size_t)st->nf * (size_t)h->L * sizeof(double);
     if (x) {
-        RC(elph_launch_s2r(h, h->d_stage_out, st->x, st->nch));
+        RC(elph_launch_s2r(h, h->d_stage_out, st->x, st->nch, st->nf));
         HIPCHK(hipMemcpyAsync(x, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     if (v) {
-        RC(elph_launch_s2r(h, h->d_stage_out, st->v, st->nch));
+        RC(elph_launch_s2r(h, h->d_stage_out, st->v, st->nch, st->nf));
         HIPCHK(hipMemcpyAsync(v, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -394,9 +436,10 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     const int nch = st->nch;
     RC(elph_i_ensure_capacity(h, 2 * nch));
-    RC(elph_i_reserve_chains(h, nch));
-    const size_t nd = (size_t)h->ndim, cbytes = nd * sizeof(double), bytes = (size_t)nch * cbytes;
-    const long long n = (long long)nd * nch;
+    if (!st->ssh) RC(elph_i_reserve_chains(h, nch));
+    // nd: site vectors (ϕ±, R±, solutions); nfd: field vectors (x, v, dS/dx) of one chain
+    const size_t nd = (size_t)h->ndim, nfd = (size_t)st->nf * (size_t)h->L, cbytes = nfd * sizeof(double), bytes = (size_t)nch * cbytes;
+    const long long n = (long long)nfd * nch;
     const double dtp = dt / (double)nb;
     int64_t kpm_calls = 0;
     std::vector<int64_t> iters((size_t)nch, 0), itrs((size_t)nch, 0);
@@ -406,7 +449,7 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
         for (int c = 0; c < nch; ++c)
             if (flag[(size_t)c] > 0 && !dead[(size_t)c]) {
                 dead[(size_t)c] = flag[(size_t)c];
-                HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nd, st->x0 + (size_t)c * nd, cbytes, hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nfd, st->x0 + (size_t)c * nfd, cbytes, hipMemcpyDeviceToDevice, h->stream));
             }
         return ELPH_OK;
     };
@@ -414,7 +457,7 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
 
     RC(update_model(h, st));
     // refresh_v!  (HMC.jl:648-659)
-    RC(upload_vectors(h, st->y, R, nch));
+    RC(upload_vectors(h, st->y, R, nch, st->nf));
     RC(fa(h, st, st->y, st->y, -0.5));
     hipLaunchKernelGGL(k_hmc_refresh_v, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->v, st->y, alpha, n);
     RC(chk("k_hmc_refresh_v"));
@@ -424,9 +467,13 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     RC(upload_vectors(h, st->R2, Rp, nch));
     RC(upload_vectors(h, st->R2 + (size_t)nch * nd, Rm, nch));
     RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2 * nch));
-    hipLaunchKernelGGL(k_hmc_phi, dim3(nblk(n), 2), dim3(TPB), 0, h->stream, st->phi, h->d_b, st->x, h->d_lam, (int)h->N, (int)h->L,
-                       st->dtau, nch);
-    RC(chk("k_hmc_phi"));
+    if (st->ssh) {      // Λ⁻¹ ≡ 1: ϕ± = MᵀR±
+        HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        hipLaunchKernelGGL(k_hmc_phi, dim3(nblk((long long)nd * nch), 2), dim3(TPB), 0, h->stream, st->phi, h->d_b, st->x, h->d_lam,
+                           (int)h->N, (int)h->L, st->dtau, nch);
+        RC(chk("k_hmc_phi"));
+    }
 
     RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, itrs.data(), flag.data()));
     // standard_update! :373 counts these iterations;  multitimestep_update! :507 has "iters += iters": not counted
@@ -449,7 +496,7 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
             }
             for (int c = 0; c < nch; ++c)       // a dead chain idles at its old field
                 if (dead[(size_t)c])
-                    HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nd, st->x0 + (size_t)c * nd, cbytes, hipMemcpyDeviceToDevice, h->stream));
+                    HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nfd, st->x0 + (size_t)c * nfd, cbytes, hipMemcpyDeviceToDevice, h->stream));
             RC(update_model(h, st));
             RC(calc_OinvLphi(h, st, use_precond, 1.0, kpm_randn, &kpm_calls, itrs.data(), flag.data()));
             for (int c = 0; c < nch; ++c) if (!dead[(size_t)c]) iters[(size_t)c] += itrs[(size_t)c];
@@ -478,9 +525,9 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
         accepted[c] = acc;
         if (!acc) {
             any_reject = true;
-            HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nd, st->x0 + (size_t)c * nd, cbytes, hipMemcpyDeviceToDevice, h->stream));
-            hipLaunchKernelGGL(k_hmc_neg, dim3(nblk((long long)nd)), dim3(TPB), 0, h->stream, st->v + (size_t)c * nd,
-                               st->v0 + (size_t)c * nd, (long long)nd);
+            HIPCHK(hipMemcpyAsync(st->x + (size_t)c * nfd, st->x0 + (size_t)c * nfd, cbytes, hipMemcpyDeviceToDevice, h->stream));
+            hipLaunchKernelGGL(k_hmc_neg, dim3(nblk((long long)nfd)), dim3(TPB), 0, h->stream, st->v + (size_t)c * nfd,
+                               st->v0 + (size_t)c * nfd, (long long)nfd);
             RC(chk("k_hmc_neg"));
         }
     }

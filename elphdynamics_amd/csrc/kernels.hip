@@ -630,11 +630,11 @@ __global__ void __launch_bounds__(256) k_ssh_fields(double *__restrict__ c, doub
                                                     double *__restrict__ lps, const double *__restrict__ x,
                                                     const double *__restrict__ par, const int *__restrict__ cb0,
                                                     const int *__restrict__ slot, int nph, int nb, int L, int lp_stride,
-                                                    double dtau) {
+                                                    double dtau, int x_tau_major) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)nph * L) return;
     const int t = (int)(i % L), p = (int)(i / L);           // field index = (phonon - 1) Ltau + tau  (Utilities.jl:12-15)
-    const double xt = x[i];
+    const double xt = x_tau_major ? x[(size_t)t * nph + p] : x[i];   // tau-major: the HMC trajectory's device layout
     const double sg = (xt > 0.0) ? 1.0 : ((xt < 0.0) ? -1.0 : 0.0);
     const double v = par[nph + p] * xt + sg * par[2 * nph + p] * (xt * xt);
     const double a = dtau * (par[p] - v), cc = cosh(a), ss = sinh(a);
@@ -651,13 +651,14 @@ __global__ void __launch_bounds__(256) k_ssh_expmu(double *__restrict__ E, const
 // F[(p, tau)] = sg(tau) dtau (alpha_p + 2 alpha2_p x) q[tau][bond(p)]  — dMdx of the bond-phonon fields (SSHModels.jl:797-823)
 __global__ void __launch_bounds__(256) k_ssh_scatter(double *__restrict__ F, const double *__restrict__ q, const double *__restrict__ x,
                                                      const double *__restrict__ par, const int *__restrict__ cb0, int nph, int nb,
-                                                     int L, double dtau) {
+                                                     int L, double dtau, int tau_major, double scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)nph * L) return;
     const int t = (int)(i % L), p = (int)(i / L);
+    const size_t k = tau_major ? (size_t)t * nph + p : (size_t)i;             // x and F share one layout
     const double sg = (t == 0) ? -1.0 : 1.0;                                  // "flip sign if τ=1" (:809-811)
-    const double dKdx = par[nph + p] + 2.0 * par[2 * nph + p] * x[i];         // ∂K/∂x as the reference takes it (:803)
-    F[i] = sg * dtau * dKdx * q[(size_t)t * nb + cb0[p]];
+    const double dKdx = par[nph + p] + 2.0 * par[2 * nph + p] * x[k];         // ∂K/∂x as the reference takes it (:803)
+    F[k] = scale * sg * dtau * dKdx * q[(size_t)t * nb + cb0[p]];
 }
 
 // tau-means of the SSH cosh/sinh tables (update_A!, KPMPreconditioners.jl:355-381): one thread per bond
@@ -931,17 +932,20 @@ static int check_launch(const char *what) {
     return ELPH_OK;
 }
 
-int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec) {
+// ncols: columns of the vectors (0 = the lattice sites; SSH phonon fields have Nph columns)
+int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec, int ncols) {
     // in: rows = N sites, cols = L
-    dim3 grid((unsigned)((h->L + 31) / 32), (unsigned)((h->N + 31) / 32), (unsigned)nvec);
-    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, h->stream, dstS, srcR, (int)h->N, (int)h->L);
+    const int N = ncols > 0 ? ncols : (int)h->N;
+    dim3 grid((unsigned)((h->L + 31) / 32), (unsigned)((N + 31) / 32), (unsigned)nvec);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, h->stream, dstS, srcR, N, (int)h->L);
     return check_launch("k_transpose(r2s)");
 }
 
-int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec) {
+int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec, int ncols) {
     // in: rows = L, cols = N
-    dim3 grid((unsigned)((h->N + 31) / 32), (unsigned)((h->L + 31) / 32), (unsigned)nvec);
-    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, h->stream, dstR, srcS, (int)h->L, (int)h->N);
+    const int N = ncols > 0 ? ncols : (int)h->N;
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((h->L + 31) / 32), (unsigned)nvec);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, h->stream, dstR, srcS, (int)h->L, N);
     return check_launch("k_transpose(s2r)");
 }
 
@@ -986,7 +990,7 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
 }
 
 int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
-                           const double *tbare_dev, const int *slot_dev, double dtau) {
+                           const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major) {
     const int nb = (int)h->nb, L = (int)h->L, lp_stride = h->lp_ne * ELPH_WAVE;
     const int *slot = h->fast_capable ? slot_dev : nullptr;
     if (nb > 0) {
@@ -996,7 +1000,7 @@ int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const
         if (nph > 0) {
             const long long n2 = (long long)nph * L;
             hipLaunchKernelGGL(k_ssh_fields, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, h->d_c, h->d_s, h->d_lp_c,
-                               h->d_lp_s, x_dev, par_dev, cb0_dev, slot, nph, nb, L, lp_stride, dtau);
+                               h->d_lp_s, x_dev, par_dev, cb0_dev, slot, nph, nb, L, lp_stride, dtau, x_tau_major);
         }
     }
     hipLaunchKernelGGL(k_ssh_expmu, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->d_E, h->d_lam, (int)h->N, dtau);
@@ -1004,11 +1008,11 @@ int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const
 }
 
 int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
-                            const int *cb0_dev, int nph, double dtau) {
+                            const int *cb0_dev, int nph, double dtau, int tau_major, double scale) {
     const long long n = (long long)nph * h->L;
     if (n == 0) return ELPH_OK;
     hipLaunchKernelGGL(k_ssh_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, F_dev, q_dev, x_dev, par_dev, cb0_dev,
-                       nph, (int)h->nb, (int)h->L, dtau);
+                       nph, (int)h->nb, (int)h->L, dtau, tau_major, scale);
     return check_launch("k_ssh_scatter");
 }
 

@@ -156,8 +156,8 @@ class HybridMonteCarlo:
         evaluation is one batched solve of 2*nchains right-hand sides); their fields / momenta are self.X / self.V
         (nchains, Ndof) and model.x / hmc.v are not used."""
         assert 0.0 <= alpha < 1.0                                   # HMC.jl:182
-        if model.kind != models.HOLSTEIN:
-            raise NotImplementedError("device-resident HMC trajectory: Holstein models")
+        if model.kind != models.HOLSTEIN and nchains != 1:
+            raise NotImplementedError("chains in lockstep: Holstein models")
         self.model, self.fa = model, fa
         self.dt, self.tr, self.alpha, self.Nb = float(dt), float(tr), float(alpha), int(Nb)
         self.Nt = int(round(tr / dt))                               # :206
@@ -171,9 +171,21 @@ class HybridMonteCarlo:
         self.H = self.S = self.K = 0.0
         self.H0 = self.H1 = self.P_accept = 0.0
         self.flag = 0
-        from ._lib import check, dptr
-        check(model._lib.elph_hmc_create_chains(model._h, self.nchains, dptr(model.omega), dptr(model.omega4), dptr(model.lam),
-                                                dptr(model.lam2), dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.M))))
+        from ._lib import check, dptr, iptr
+        if model.kind == models.SSH:      # bond phonons: omega, omega4 and fa.M per phonon
+            self.omega4 = getattr(model, "omega4", None)
+            if self.omega4 is None:
+                self.omega4 = model.omega4 = np.zeros(model.Nph)
+            cb_index = np.ascontiguousarray(model.checkerboard_perm[model.phonon_to_bond - 1], dtype=np.int64)
+            t_ph = np.ascontiguousarray(model.t[model.phonon_to_bond - 1], dtype=np.float64)
+            check(model._lib.elph_hmc_create_ssh(
+                model._h, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
+                dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)), dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb),
+                dptr(np.ascontiguousarray(model.mu)), model.dtau, dptr(np.ascontiguousarray(fa.M))))
+            model._cs_stale = True
+        else:
+            check(model._lib.elph_hmc_create_chains(model._h, self.nchains, dptr(model.omega), dptr(model.omega4), dptr(model.lam),
+                                                    dptr(model.lam2), dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.M))))
         model._nchains = self.nchains
         if self.nchains == 1:
             self.push_()

@@ -255,6 +255,17 @@ int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, double alpha, 
                     const double *Rp, const double *Rm, const double *kpm_randn, double u_accept, int *accepted,
                     double *iters_per_solve, double *energies, int *flag);
 
+/* The same trajectory for an SSH model (bond phonons; SURVEY config E): the fields are the Nph·Lτ bond-phonon displacements,
+ * update_model! is the device-side cosh/sinh of t′ = t − (αx + sign(x)α₂x²) (SSHModels.jl:510-562), Λ ≡ 1
+ * (HMC.jl:943-946), the force is −dMdx(M X±, X±) scattered from the bond brackets (SSHModels.jl:707-829), calc_Sb /
+ * calc_dSbdx! are PhononAction.jl:68-112,189-234 with every field its own primary field.  elph_hmc_create_ssh replaces
+ * elph_hmc_create (omega, omega4: double[nph]; fa_mass: double[nph·Lτ]; the other arguments as in
+ * elph_update_model_ssh_fields); elph_hmc_set_state / _get_state / elph_hmc_update then work on double[nph·Lτ] fields
+ * (R: [nph·Lτ]; Rp, Rm: [Ndim]). */
+int elph_hmc_create_ssh(elph_handle h, int64_t nph, const double *omega, const double *omega4, const int64_t *cb_index,
+                        const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu,
+                        double dtau, const double *fa_mass);
+
 /* Several Markov chains (same deck, independent phonon fields — the reference runs them as separate processes,
  * ElPhDynamics.jl:90-95) advanced in LOCKSTEP by one handle: the leapfrog schedule is common, every chain has its own
  * x, v, ϕ±, energies, Metropolis test and failure flag, and all 2·nchains pseudofermion solves of a force / action

@@ -262,3 +262,87 @@ def test_hmc_chains_in_lockstep_equal_single_chain_updates(tag, nch, nb, with_kp
             assert np.array_equal(Xb[c], X0[c])
         m1.close()
     assert acc[0] and (nch < 2 or not acc[1])
+
+
+# ---------------------------------------------------------------------------------------------- SSH (bond phonons)
+
+def _ssh_golden_model(nb):
+    from elphdynamics_amd import lattice as lat
+    from elphdynamics_amd import models
+    g, hgold = golden(f"hmc_ssh_sq4_L8_a_nb{nb}.npz"), golden("ssh_sq4_L8_a.npz")
+    la = lat.Lattice(1, 4, 4, 1)
+    L, dtau = int(g["Ltau"]), float(g["dtau"])
+    m = models.SSHModel(la, L * dtau, dtau, tol=1e-7, maxiter=20000)
+    for (o1, o2, d) in lat.SQUARE_BONDS:
+        m.assign_hopping_(1.0, 0.1, 0.0, 0.5, o1, o2, d)
+    m.initialize_model_()
+    assert np.array_equal(m.neighbor_table, hgold["table"]) and np.array_equal(m.checkerboard_perm, hgold["cbperm"])
+    m.alpha[:], m.alpha2[:], m.mu[:] = hgold["alpha"], hgold["alpha2"], hgold["mu"]
+    m.omega = np.array(g["omega"])
+    m.omega4 = np.array(g["omega4"])
+    m.x[:] = g["x0"]
+    models.update_model_(m)
+    return g, hgold, m
+
+
+@pytest.mark.parametrize("nb", [1, 3])
+def test_ssh_hmc_update_matches_dense_golden(nb):
+    """elph_hmc_create_ssh + elph_hmc_update on the SSH model: the whole trajectory (device-side update_model! of the bond
+    hoppings every step, Λ ≡ 1, bond-phonon force, multi-timestep variant) against the dense complex-step golden."""
+    from elphdynamics_amd import hmc, preconditioners as pc
+    g, hgold, m = _ssh_golden_model(nb)
+    fa = pc.FourierAccelerator(m)
+    fa.M[:] = g["faM"]
+    H = hmc.HybridMonteCarlo(m, fa, float(g["dt"]), int(g["nt"]) * float(g["dt"]), alpha=0.0, Nb=nb)
+    rnd = dict(R=g["R"], Rp=g["Rp"], Rm=g["Rm"], kpm_randn=None, u=0.0)
+    acc, its = hmc.update_(m, H, fa, None, randoms=rnd)
+    assert acc and H.flag == 0
+    assert abs(H.H0 - float(g["H0"])) < 1e-9 * abs(float(g["H0"])) and abs(H.H0 - float(g["H0_closed"])) < 1e-9 * abs(float(g["H0"]))
+    assert abs(H.H1 - float(g["H1"])) < 1e-6
+    assert rel(m.x, g["x1"]) < 1e-6 and rel(H.v, g["v1"]) < 1e-6
+    # the hopping tables on the device belong to the final field
+    X = m.x.reshape(m.Nph, m.Ltau)
+    idx = m.checkerboard_perm[m.phonon_to_bond - 1] - 1
+    c = np.zeros((m.Nbonds, m.Ltau))
+    c[idx] = np.cosh(m.dtau * (m.t[m.phonon_to_bond - 1][:, None] - m.alpha[:, None] * X))
+    assert rel(m.cosht, c) < 1e-14
+    m.close()
+
+
+@pytest.mark.parametrize("tag,with_kpm,nb", [("e", False, 1), ("e", True, 2), ("E", True, 1)])
+def test_ssh_hmc_update_vs_oracle(oracle, tag, with_kpm, nb):
+    """Configs e / E (optical SSH square L = 4 / 16): device trajectory vs the oracle's, with alpha2 != 0 and the KPM
+    preconditioner (tau-averaged cosh/sinh from the device tables), accept and reject."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc, synth
+    m = configs.make_model(tag, tol=1e-7, maxiter=20000)
+    m.alpha2[:] = 0.01
+    m.omega4 = np.full(m.Nph, 0.02)
+    models_update = __import__("elphdynamics_amd.models", fromlist=["update_model_"]).update_model_
+    models_update(m)
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+    nt, dt = 2, 0.05
+    x0 = m.x.copy()
+    om = oracle.make_model(1, m.Nsites, m.Ltau, m.neighbor_table, np.ascontiguousarray(m.cosht).reshape(-1).copy(),
+                           np.ascontiguousarray(m.sinht).reshape(-1).copy(), np.exp(m.dtau * m.mu))
+    n_arn = min(20, m.Nsites)
+    Po = oracle.make_kpm(om, n=n_arn) if with_kpm else None
+    P = pc.SymmetricKPMPreconditioner(m, n=n_arn, buf=0.05, c1=1.0, c2=1.0) if with_kpm else None
+    H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt, alpha=0.3, Nb=nb)
+    v0 = 0.2 * synth.randn(77, m.Ndof)
+    H.v[:] = v0
+    H.push_()
+    for u in (0.0, 1.5):      # accepted, then (u > 1) rejected
+        rnd = dict(R=synth.randn(1500, m.Ndof), Rp=synth.randn(1501, m.Ndim), Rm=synth.randn(1502, m.Ndim),
+                   kpm_randn=synth.randn(1503, (nt + 2) * 2 * m.Nsites) if with_kpm else None, u=u)
+        x_in, v_in = m.x.copy(), H.v.copy()
+        acc_o, x_o, v_o, info = oracle.hmc_update_ssh(om, x_in, v_in, m.omega, m.omega4, m.mu, m.dtau, fa.M, m.t, m.alpha, m.alpha2,
+                                                      m.phonon_to_bond, m.checkerboard_perm, dt, nt, nb, 0.3, rnd, P=Po, tol=1e-7,
+                                                      maxiter=20000)
+        acc, its = hmc.update_(m, H, fa, P, randoms=rnd)
+        assert acc == acc_o == (u == 0.0) and H.flag == 0 and info["flag"] == 0
+        assert abs(H.H0 - info["H0"]) < 1e-8 * abs(info["H0"]) and abs(H.H1 - info["H1"]) < 1e-6 * abs(info["H1"])
+        assert rel(m.x, x_o) < 1e-6 and rel(H.v, v_o) < 1e-6
+        if not acc:
+            assert np.array_equal(m.x, x_in)
+    m.close()
