@@ -1387,19 +1387,15 @@ extern "C" int elph_fourier_accelerate(elph_handle h, double *vout, const double
     }
     double *dR = h->d_diag, *aS = h->d_diag + n, *bS = h->d_diag + 2 * n;
     double2 *u = reinterpret_cast<double2 *>(h->d_diag + 3 * n);
-    // stage (layout R -> S for "nph" columns): reuse the transpose kernel with rows = nph
-    elph_handle_s tmp = *h;   // shallow view with N := nph for the launch helpers
-    tmp.N = nph; tmp.ndim = n; tmp.npl = (int)((nph + ELPH_WAVE - 1) / ELPH_WAVE); tmp.d_nu = u;
-    tmp.graphs.clear();
+    // stage (layout R -> S for "nph" columns), transform with the handle's tables, stage back
     HIPCHK(hipMemcpyAsync(dR, diag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(&tmp, bS, dR, 1));                 // bS = diag in layout S  (diag[k][s])
+    RC(elph_launch_r2s(h, bS, dR, 1, (int)nph));          // bS = diag in layout S  (diag[k][s])
     HIPCHK(hipMemcpyAsync(dR, vin, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(&tmp, aS, dR, 1));                 // aS = v in layout S
-    RC(elph_launch_fft_accel(&tmp, dR, aS, bS, power, nph));   // dR = result in layout S
-    RC(elph_launch_s2r(&tmp, aS, dR, 1));                 // aS = result in layout R
+    RC(elph_launch_r2s(h, aS, dR, 1, (int)nph));          // aS = v in layout S
+    RC(elph_dft_accel(h, dR, aS, bS, power, (int)nph, u, 1));   // dR = result in layout S
+    RC(elph_launch_s2r(h, aS, dR, 1, (int)nph));          // aS = result in layout R
     HIPCHK(hipMemcpyAsync(vout, aS, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    tmp.h_state = nullptr;   // the view owns nothing
     return ELPH_OK;
 }
 
