@@ -849,3 +849,52 @@ def test_ssh_device_update_equals_host_tables_at_config_E(no_fast, monkeypatch):
     models.mulMtM_(y_host, m, v)
     assert rel(y_dev, y_host) < 1e-13
     m.close()
+
+
+# ------------------------------------------------------------------------------------------ odd shapes
+
+@pytest.mark.parametrize("norb,L1,L2,bonds,Ltau", [
+    (1, 2, 1, [(1, 1, (1, 0, 0))], 1),        # two sites, one bond, ONE time slice (tau-1 wraps onto tau)
+    (1, 2, 1, [(1, 1, (1, 0, 0))], 2),
+    (1, 5, 1, [(1, 1, (1, 0, 0))], 3),        # odd ring: three ragged colours
+    (1, 3, 3, "tri", 7),                      # 9 colours (generic kernels), prime Ltau
+    (2, 2, 2, "hc", 5),                       # honeycomb 2x2: wrap bonds coincide
+    (1, 6, 4, "sq", 161),                     # Ltau not divisible by 2, 4 or 8: no chunk kernel
+    (1, 10, 10, "sq", 12),                    # N = 100: ragged last lane group
+])
+def test_odd_lattices_and_time_extents_vs_oracle(oracle, norb, L1, L2, bonds, Ltau):
+    """Shapes the decks never use but the kernels must not trip over: a single time slice, odd rings, prime Ltau, ragged
+    site counts — mat-vecs, a batched solve of 3 right-hand sides and the KPM-preconditioned solve against the oracle."""
+    from elphdynamics_amd import lattice as lat
+    from elphdynamics_amd import models, preconditioners as pc, synth
+    if isinstance(bonds, str):
+        bonds = {"tri": lat.TRIANGULAR_BONDS, "hc": lat.HONEYCOMB_BONDS, "sq": lat.SQUARE_BONDS}[bonds]
+    la = lat.Lattice(norb, L1, L2, 1)
+    dtau = 0.1
+    m = models.HolsteinModel(la, Ltau * dtau, dtau, tol=1e-9, maxiter=20000)
+    assert m.Ltau == Ltau
+    for (o1, o2, d) in bonds:
+        m.assign_t_(1.0, o1, o2, d)
+    m.assign_omega_(1.0); m.assign_lambda_(1.0); m.assign_mu_(0.1)
+    m.initialize_model_()
+    m.x[:] = synth.phonon_field(m.Nph, Ltau, Ltau * dtau, dtau, seed=4242)
+    models.update_model_(m)
+    om = _oracle_model(oracle, m)
+    v = synth.randn(1, m.Ndim)
+    for f_gpu, f_orc in ((models.mulM_, oracle.mulM), (models.mulMt_, oracle.mulMT), (models.mulMtM_, oracle.mulMTM)):
+        y = np.zeros(m.Ndim)
+        f_gpu(y, m, v)
+        assert rel(y, f_orc(om, v)) < 1e-13
+    B = np.stack([oracle.mulMT(om, synth.randn(10 + r, m.Ndim)) for r in range(3)])
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    assert not fl.any()
+    for r in range(3):
+        xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(B[r]), solver_tol=1e-9, solver_maxiter=20000)
+        assert flo == 0 and abs(int(it[r]) - ito) <= 2 and rel(X[r], xo) < 1e-6
+    P = pc.SymmetricKPMPreconditioner(m, n=min(20, m.Nsites), buf=0.05, c1=1.0, c2=1.0)
+    pc.setup_(P, rng=np.random.default_rng(2))
+    xk = np.zeros(m.Ndim)
+    itk, resk, flk = models.ldiv_(xk, m, np.ascontiguousarray(B[0]), P=P)
+    assert flk == 0 and rel(xk, X[0]) < 1e-6
+    m.close()
