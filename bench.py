@@ -87,7 +87,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libelphgpu has no CPU path")
 
     # one independent chain (phonon configuration) per rank
-    m = configs.make_model(args.config, tol=1e-5, device=local_rank if world > 1 else 0,
+    m = configs.make_model(args.config, tol=1e-5, device=comm.device_index(),
                            seed=comm.chain_seed(synth.SEED_FIELDS))
     nrhs = args.nrhs
     nchains = 1 if m.kind != 0 else max(1, min(args.chains, nrhs))
@@ -277,7 +277,7 @@ def main():
                 nt_g, dt_h = 10, 0.01
                 hm = {}
                 for nch_h in (1, args.chains):
-                    mh = configs.make_model(args.config, tol=1e-5, maxiter=20000, device=local_rank if world > 1 else 0)
+                    mh = configs.make_model(args.config, tol=1e-5, maxiter=20000, device=comm.device_index())
                     fah = pc.FourierAccelerator(mh)
                     pc.update_M_(fah, mh, 0.0, np.inf, 1.0, 0.1)
                     Hh = ehmc.HybridMonteCarlo(mh, fah, dt=dt_h, tr=nt_g * dt_h, alpha=0.0, Nb=1, nchains=nch_h)
@@ -298,7 +298,7 @@ def main():
                 if not args.no_cpu:
                     from oracle.oracle import Oracle
                     orc_h = Oracle(fast=True)
-                    mo = configs.make_model(args.config, tol=1e-5, maxiter=20000, device=local_rank if world > 1 else 0)
+                    mo = configs.make_model(args.config, tol=1e-5, maxiter=20000, device=comm.device_index())
                     fao = pc.FourierAccelerator(mo)
                     pc.update_M_(fao, mo, 0.0, np.inf, 1.0, 0.1)
                     Eo = orc_h.update_model_holstein(mo.Nsites, mo.Ltau, mo.dtau, mo.x, mo.lam, mo.lam2, mo.mu)

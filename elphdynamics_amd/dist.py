@@ -26,7 +26,8 @@ class Comm:
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            # ELPH_DIST_BACKEND=gloo: rehearsal of the multi-rank driver on a box with fewer GPUs than ranks
+            backend = backend or os.environ.get("ELPH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             self.backend = backend
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
@@ -35,6 +36,13 @@ class Comm:
             else:
                 self.device = torch.device("cpu")
                 dist.init_process_group(backend=backend)
+
+    def device_index(self):
+        """GPU of this rank: LOCAL_RANK, unless ELPH_FORCE_DEVICE pins every rank to one device (rehearsals on a 1-GPU box)."""
+        forced = os.environ.get("ELPH_FORCE_DEVICE")
+        if forced is not None:
+            return int(forced)
+        return self.local_rank if self.world > 1 else 0
 
     # one independent chain per rank: distinct, reproducible seeds
     def chain_seed(self, base):
