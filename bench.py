@@ -76,6 +76,9 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if world > 1:        # the CPU baseline and the secondary measurements belong to the N = 1 run (rank 0 only, contract ④)
+        args.no_cpu = True
+        args.no_sweep = True
     import numpy as np
     if args.mode in ("sharded", "spatial"):
         return main_sharded(args, comm)
