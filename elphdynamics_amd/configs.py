@@ -18,7 +18,9 @@ CONFIGS = {
     "b": ("holstein", 1, 4, lat.SQUARE_BONDS, 2.0, 0.1),
     "d": ("holstein", 2, 3, lat.HONEYCOMB_BONDS, 1.2, 0.1),
     "e": ("ssh", 1, 4, lat.SQUARE_BONDS, 1.0, 0.05),
-    "t": ("holstein", 1, 3, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # odd L: ragged colours
+    "t": ("holstein", 1, 3, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # odd L: 9 ragged colours (generic kernels)
+    "u": ("holstein", 1, 4, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # even-L triangular: 6 colours (lane program lp6)
+    "T": ("holstein", 1, 16, lat.TRIANGULAR_BONDS, 16.0, 0.1),      # holstein_hmc_triangular.toml geometry at config-C size
     # lattices beyond 512 sites: multi-wavefront workgroups of the generic kernels
     "g": ("holstein", 1, 24, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 576  (2 wavefronts per slice)
     "G": ("holstein", 1, 32, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 1024

@@ -71,9 +71,9 @@ static void drop_graphs(elph_handle_s *h) {
 // ------------------------------------------------------------------------------------------
 
 void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill) {
-    const int PP = (h->npl + 1) / 2, NE = 4 * PP;
+    const int PP = (h->npl + 1) / 2, NE = h->lp_mc * PP;
     for (int i = 0; i < NE * ELPH_WAVE; ++i) out[i] = fill;
-    for (int col = 0; col < h->ncol && col < 4; ++col) {
+    for (int col = 0; col < h->ncol && col < h->lp_mc; ++col) {
         const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
         for (int n = b0; n < b1; ++n) {
             const int k = n - b0;
@@ -85,7 +85,8 @@ void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, d
 static void detect_square(elph_handle_s *h);
 
 static int build_lane_program(elph_handle_s *h) {
-    const int PP = (h->npl + 1) / 2, NE = 4 * PP;
+    h->lp_mc = (h->ncol <= 4) ? 4 : 6;      // kernels exist for 4-colour (square, honeycomb, chain) and 6-colour (triangular) programs
+    const int PP = (h->npl + 1) / 2, NE = h->lp_mc * PP;
     h->lp_ne = NE;
     const char *ci = getenv("ELPH_CHUNK_ITERS");
     h->chunk = ci ? atoi(ci) : ELPH_CG_CHUNK;
@@ -95,7 +96,7 @@ static int build_lane_program(elph_handle_s *h) {
     const char *ct = getenv("ELPH_CHUNK_T");
     h->force_T = ct ? atoi(ct) : 0;
     const char *nf = getenv("ELPH_NO_FAST");
-    h->fast = (h->ncol <= 4) && (h->npl <= ELPH_MAX_NPL) && !(nf && nf[0] == '1');
+    h->fast = (h->ncol <= 6) && (h->npl <= ELPH_MAX_NPL) && !(nf && nf[0] == '1');
     // idle slots (ragged colours / fewer than 4 colours): each lane owns two padding slots of the LDS slab,
     // paired with (cosh, sinh) = (1, 0) by elph_lp_pack => a no-op bond, no predicate in the kernels
     h->h_lp_ij.resize((size_t)NE * ELPH_WAVE);
@@ -487,7 +488,7 @@ int elph_i_ssh_upload_params(elph_handle_s *h, int64_t nph, const int64_t *cb_in
         std::vector<int> slot(std::max<size_t>(nb, 1), -1);
         if (h->fast_capable) {
             const int PP = (h->npl + 1) / 2;
-            for (int col = 0; col < h->ncol && col < 4; ++col)
+            for (int col = 0; col < h->ncol && col < h->lp_mc; ++col)
                 for (int n = h->h_coloff[col]; n < h->h_coloff[col + 1]; ++n) {
                     const int k = n - h->h_coloff[col];
                     slot[(size_t)n] = (col * PP + k / ELPH_WAVE) * ELPH_WAVE + (k % ELPH_WAVE);

@@ -52,7 +52,7 @@ struct ModelDev {
     const double *s;     // sinh table
     const double *E;     // exp(-dtau V) (Holstein, layout S) or exp(dtau mu) (SSH)
     // "lane program" (cg_fast.hip): bonds re-packed [colour][pass][lane], PP = ceil(npl/2) passes per colour,
-    // NE = 4*PP entries; idle slots hold 0xFFFFFFFF.  Only valid when ncol <= 4.
+    // NE = MC*PP entries (MC = 4 or 6 colours); idle slots point at the lane's padding pair.  Only valid when ncol <= 6.
     const unsigned *lp_ij;   // [NE][64]  i | j << 16
     const double *lp_c;      // [1 or L][NE][64]
     const double *lp_s;
@@ -171,6 +171,7 @@ struct elph_handle_s {
     bool cs_host_stale = false;            // SSH: d_c/d_s were produced on the device; h_c/h_s are not current
     // lane program (fast path, ncol <= 4)
     bool fast = false;
+    int lp_mc = 4;                         // colours of the lane program the kernels were compiled for: 4 (lp4) or 6 (lp6)
     int lp_ne = 0;
     std::vector<unsigned> h_lp_ij;
     unsigned *d_lp_ij = nullptr;
