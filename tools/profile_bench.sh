@@ -13,4 +13,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $B -
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_kpm -- python3 $B --precond --steps 320 --warmup 32 --no-cpu --no-sweep > $OUT/bench_trace_kpm.json 2> $OUT/bench_trace_kpm.err
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json
+python3 tools/pmc_traffic.py $OUT --traffic-json 128 40960 > $OUT/traffic.json
 ls -R $OUT | head -40
