@@ -346,3 +346,51 @@ def test_ssh_hmc_update_vs_oracle(oracle, tag, with_kpm, nb):
         if not acc:
             assert np.array_equal(m.x, x_in)
     m.close()
+
+
+def test_hmc_chains_failed_solve_kills_only_that_chain():
+    """A chain whose linear solve fails (flag > 0, HMC.jl:405-408) is rejected and restored bit-exactly while the other
+    chains of the lockstep update go on and end where they would have ended alone."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc, synth
+    tag, nch, nt, dt = "b", 3, 3, 0.05
+    m = configs.make_model(tag, tol=1e-7, maxiter=400)
+    m.omega4[:] = 0.02
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+    X0 = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=900 + c) for c in range(nch)])
+    X0[1] *= 40.0                               # chain 1: exp(-dtau V) spans hundreds of orders of magnitude: CG cannot converge in 400 iterations
+    V0 = np.zeros((nch, m.Ndof))
+    rnd = dict(R=np.stack([synth.randn(1000 + c, m.Ndof) for c in range(nch)]),
+               Rp=np.stack([synth.randn(1100 + c, m.Ndim) for c in range(nch)]),
+               Rm=np.stack([synth.randn(1200 + c, m.Ndim) for c in range(nch)]), kpm_randn=None, u=np.zeros(nch))
+    H = hmc.HybridMonteCarlo(m, fa, dt=dt, tr=nt * dt, alpha=0.0, Nb=1, nchains=nch)
+    H.X[:], H.V[:] = X0, V0
+    H.push_()
+    acc, its = hmc.update_chains_(m, H, fa, None, randoms=rnd, pull=True)
+    assert H.flags[1] > 0 and not acc[1] and H.flags[0] == 0 and H.flags[2] == 0 and acc[0] and acc[2]
+    assert np.array_equal(H.X[1], X0[1])                                  # dead chain: field restored bit-exactly
+    assert H.energies[1, 4] == 0.0                                        # acceptance probability of a killed trajectory
+    Xb, Vb = H.X.copy(), H.V.copy()
+    m.close()
+    for c in (0, 2):
+        m1 = configs.make_model(tag, tol=1e-7, maxiter=400)
+        m1.omega4[:] = 0.02
+        fa1 = pc.FourierAccelerator(m1)
+        pc.update_M_(fa1, m1, 0.0, np.inf, 1.0, 0.3)
+        m1.x[:] = X0[c]
+        H1 = hmc.HybridMonteCarlo(m1, fa1, dt=dt, tr=nt * dt, alpha=0.0, Nb=1)
+        r1 = dict(R=rnd["R"][c], Rp=rnd["Rp"][c], Rm=rnd["Rm"][c], kpm_randn=None, u=0.0)
+        a1, i1 = hmc.update_(m1, H1, fa1, None, randoms=r1)
+        assert a1 and np.abs(m1.x - Xb[c]).max() < 1e-6 * np.abs(m1.x).max() and np.abs(H1.v - Vb[c]).max() < 1e-6 * np.abs(H1.v).max()
+        m1.close()
+    # every chain failing: the update returns at once, all rejected, nothing moved
+    m = configs.make_model(tag, tol=1e-12, maxiter=3)
+    m.omega4[:] = 0.02
+    H = hmc.HybridMonteCarlo(m, fa, dt=dt, tr=nt * dt, alpha=0.0, Nb=1, nchains=2)
+    H.X[:] = X0[[0, 2]]
+    H.push_()
+    rnd2 = {k: (v[[0, 2]] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in rnd.items()}
+    rnd2["u"] = np.zeros(2)
+    acc, its = hmc.update_chains_(m, H, fa, None, randoms=rnd2, pull=True)
+    assert not acc.any() and (H.flags > 0).all() and np.array_equal(H.X, X0[[0, 2]])
+    m.close()
