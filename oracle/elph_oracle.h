@@ -251,6 +251,13 @@ int64_t elpho_hmc_update_holstein(const elpho_hmc_params *hp, elpho_model *m, el
                                   const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
                                   double *out);
 
+/* LangevinDynamics.jl:334-384 (calc_dSdx!) and :81-328 (evolve! for Euler / Runge-Kutta / Heun dynamics), Holstein; the
+ * random vectors are inputs.  See the definitions. */
+int64_t elpho_langevin_dSdx(double *dSdx, const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, const double *x, const double *g,
+                            const double *b_max, const double *b_min, double *Minv_g, double *work);
+int64_t elpho_langevin_evolve(int scheme, const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, double *x, const double *fa_Q,
+                              double dt, const double *eta, const double *g1, const double *g2, const double *kpm_randn);
+
 /* SSH extras of the HMC update (bond phonons, SSHModels.jl:79-314): per phonon t is indexed by RAW bond as in ssh.t */
 typedef struct {
     int64_t Nph;

@@ -150,6 +150,12 @@ class Oracle:
         L.elpho_calc_Sb_holstein.restype = c_dbl
         L.elpho_calc_Sb_holstein.argtypes = [c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_calc_dSbdx_holstein.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_langevin_dSdx.restype = c_i64
+        L.elpho_langevin_dSdx.argtypes = [P_dbl, C.POINTER(HmcParams), C.POINTER(Model), C.POINTER(KPM), P_dbl, P_dbl, P_dbl, P_dbl,
+                                          P_dbl, P_dbl]
+        L.elpho_langevin_evolve.restype = c_i64
+        L.elpho_langevin_evolve.argtypes = [C.c_int, C.POINTER(HmcParams), C.POINTER(Model), C.POINTER(KPM), P_dbl, P_dbl, c_dbl,
+                                            P_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_hmc_update_ssh.restype = c_i64
         L.elpho_hmc_update_ssh.argtypes = [C.POINTER(HmcParams), C.POINTER(HmcSsh), C.POINTER(Model), C.POINTER(KPM), P_dbl, P_dbl,
                                            P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]
@@ -189,6 +195,38 @@ class Oracle:
         info = dict(H0=out[0], H1=out[1], S=out[2], K=out[3], iters=out[4], flag=int(out[5]), P_accept=out[6],
                     kpm_calls=int(out[7]))
         return bool(acc), x, v, info
+
+    def _langevin_params(self, m, omega, omega4, lam, lam2, mu, dtau, P, tol, maxiter, kmax):
+        hp = HmcParams()
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (omega, omega4, lam, lam2, mu)]
+        hp.N, hp.L, hp.dtau = m.N, m.L, dtau
+        hp.omega, hp.omega4, hp.lam, hp.lam2, hp.mu = (dp(a) for a in arrs)
+        hp.solver_tol, hp.solver_maxiter, hp.kmax = tol, maxiter, kmax
+        hp.kpm_n = P._n if P is not None else 0
+        return hp, arrs
+
+    def langevin_dSdx(self, m, x, g, omega, omega4, lam, lam2, mu, dtau, P=None, b_max=None, b_min=None, tol=1e-5,
+                      maxiter=10000, kmax=1e12):
+        """calc_dSdx!(dSdx, g, M⁻¹g, model, P) of LangevinDynamics.jl -> (dSdx, M⁻¹g, iters); m.E must hold update_model!(x)."""
+        hp, keep = self._langevin_params(m, omega, omega4, lam, lam2, mu, dtau, P, tol, maxiter, kmax)
+        n = m.N * m.L
+        dS, Mg, work = np.zeros(n), np.zeros(n), np.zeros(5 * n)
+        it = self.lib.elpho_langevin_dSdx(dp(dS), C.byref(hp), C.byref(m), C.byref(P) if P is not None else None,
+                                          dp(np.ascontiguousarray(x, dtype=np.float64)), dp(np.ascontiguousarray(g, dtype=np.float64)),
+                                          dp(np.ascontiguousarray(b_max)) if b_max is not None else None,
+                                          dp(np.ascontiguousarray(b_min)) if b_min is not None else None, dp(Mg), dp(work))
+        return dS, Mg, int(it)
+
+    def langevin_evolve(self, scheme, m, x, fa_Q, dt, eta, g1, g2, omega, omega4, lam, lam2, mu, dtau, P=None, kpm_randn=None,
+                        tol=1e-5, maxiter=10000, kmax=1e12):
+        """evolve!(model, dyn, fa, P): scheme 0 Euler, 1 Runge-Kutta, 2 Heun -> (x', iters).  m.E is overwritten."""
+        hp, keep = self._langevin_params(m, omega, omega4, lam, lam2, mu, dtau, P, tol, maxiter, kmax)
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        c = lambda a: dp(np.ascontiguousarray(a, dtype=np.float64)) if a is not None else None
+        fq, e, a1, a2, kr = (np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (fa_Q, eta, g1, g2, kpm_randn))
+        it = self.lib.elpho_langevin_evolve(int(scheme), C.byref(hp), C.byref(m), C.byref(P) if P is not None else None, dp(x), dp(fq),
+                                            float(dt), dp(e), dp(a1), dp(a2) if a2 is not None else dp(a1), dp(kr) if kr is not None else None)
+        return x, int(it)
 
     def hmc_update_ssh(self, m, x, v, omega, omega4, mu, dtau, fa_M, t, alpha, alpha2, phonon_to_bond, cb_perm, dt, nt, nb,
                        alpha_mom, randoms, P=None, tol=1e-5, maxiter=10000, kmax=1e12):

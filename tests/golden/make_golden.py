@@ -525,6 +525,67 @@ def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
          dSf0=dSf0, x1=x, v1=v, H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0) + 0.5 * (v_init @ accel(v_init, 1.0)))
 
 
+def gen_langevin(h, tag, seed, dt=0.02):
+    """One Langevin step of each scheme (LangevinDynamics.jl:81-328 for the ORDER of the stages only) from the definitions:
+    drift dS/dx = dSb_shifted/dx - 2 d/dx [gᵀ M(x) v]_{v = M(x)⁻¹ g held fixed} with dense M, exact solves and the COMPLEX-STEP
+    derivative of the bilinear form (no analytic force formula enters); Fourier acceleration with scipy.fft and the Q table."""
+    N, L, dtau = h["N"], h["Ltau"], h["dtau"]
+    n = N * L
+    g = np.load(os.path.join(HERE, f"holstein_{tag}.npz"))
+    lam, lam2, mu, x0, CB = g["lam"], g["lam2"], g["mu"], g["x"].copy(), h["CB"]
+    omega = 1.0 + 0.1 * synth.randn(seed + 1, N)
+    omega4 = 0.05 * np.abs(synth.randn(seed + 2, N))
+    mreg = 0.7
+    k = np.arange(L)
+    faQ = (mreg ** 2 + dtau * omega[:, None] ** 2 + 4.0 / dtau) \
+        / (mreg ** 2 + dtau * omega[:, None] ** 2 + (2 - 2 * np.cos(2 * np.pi * k / L))[None, :] / dtau)     # element_Qi, [N, L]
+    eta, g1, g2 = synth.randn(seed + 3, n), synth.randn(seed + 4, n), synth.randn(seed + 5, n)
+
+    def accel(vec, power):
+        return np.real(scipy.fft.ifft(faQ ** power * scipy.fft.fft(vec.reshape(N, L), axis=1), axis=1)).reshape(-1)
+
+    def dense_M_of(x):
+        X = x.reshape(N, L)
+        E = np.exp(-dtau * (lam[:, None] * X + lam2[:, None] * X ** 2 - mu[:, None]))
+        M = np.eye(n, dtype=E.dtype)
+        for t in range(L):
+            B = CB @ np.diag(E[:, t])
+            tm1 = (t - 1) % L
+            sign = 1.0 if t == 0 else -1.0
+            M[np.ix_(np.arange(N) * L + t, np.arange(N) * L + tm1)] += sign * B
+        return M
+
+    def Sb_shifted(x):
+        X = x.reshape(N, L)
+        return dtau * np.sum(omega[:, None] ** 2 * X ** 2 / 2 + omega4[:, None] * X ** 4 - lam[:, None] * X
+                             + (X - np.roll(X, 1, axis=1)) ** 2 / dtau ** 2 / 2)
+
+    def grad(fun, x):
+        hstep, out = 1e-30, np.empty(n)
+        for kk in range(n):
+            xc = x.astype(complex)
+            xc[kk] += 1j * hstep
+            out[kk] = np.imag(fun(xc)) / hstep
+        return out
+
+    def drift(x, gvec):
+        v = np.linalg.solve(dense_M_of(x), gvec)
+        return grad(Sb_shifted, x) - 2.0 * grad(lambda z: gvec @ (dense_M_of(z) @ v), x), v
+
+    F1, v1 = drift(x0, g1)
+    x_euler = x0 + np.sqrt(2 * dt) * accel(eta, 0.5) - dt * accel(F1, 1.0)
+    xp = x0 + np.sqrt(2 * dt) * eta - dt * F1                                   # Runge-Kutta predictor: no acceleration
+    F2, _ = drift(xp, g2)
+    x_rk = x0 + np.sqrt(2 * dt) * accel(eta, 0.5) - dt * accel((F1 + F2) / 2, 1.0)
+    xi = accel(eta, 0.5)
+    G1 = accel(F1, 1.0)
+    xh = x0 + np.sqrt(2 * dt) * xi - dt * G1
+    F2h, _ = drift(xh, g2)
+    x_heun = x0 + np.sqrt(2 * dt) * xi - dt * (G1 + accel(F2h, 1.0)) / 2
+    save(f"langevin_{tag}.npz", N=N, Ltau=L, dtau=dtau, omega=omega, omega4=omega4, faQ=faQ.reshape(-1), eta=eta, g1=g1, g2=g2, dt=dt,
+         F1=F1, Minv_g1=v1, x_euler=x_euler, x_rk=x_rk, x_heun=x_heun)
+
+
 # ----------------------------------------------------------------------------- Green's-function estimator
 def gen_greens(h, tag, norb, Lsp, seed, nv=3):
     """Stochastic Green's-function estimator (GreensFunctions.jl:201-288): the four translation-averaged products
@@ -580,5 +641,6 @@ if __name__ == "__main__":
     gen_kpm(h1, "sq4_L8")
     gen_hmc(h1, "sq4_L8", seed=66, nb=1)
     gen_hmc(h1, "sq4_L8", seed=66, nb=3)
+    gen_langevin(h1, "sq4_L8", seed=71)
     h2 = gen_holstein("sq4_L40", 1, 4, SQUARE, 40, 0.1, seed=55)
     gen_kpm(h2, "sq4_L40")

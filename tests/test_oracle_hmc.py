@@ -140,3 +140,40 @@ def test_ssh_trajectory_with_kpm_preconditioner(oracle):
     acc, x1, v1, info = _run_ssh(oracle, g, h, om, dtau, float(g["dt"]), nt, 1, P=P, kpm_randn=kr)
     assert acc and info["kpm_calls"] == nt + 2
     assert rel(x1, g["x1"]) < 1e-6 and abs(info["H1"] - float(g["H1"])) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- Langevin dynamics
+
+def _setup_langevin(oracle):
+    g, h = golden("langevin_sq4_L8.npz"), golden("holstein_sq4_L8.npz")
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    E = oracle.update_model_holstein(N, L, dtau, h["x"], h["lam"], h["lam2"], h["mu"])
+    om = oracle.make_model(0, N, L, h["table"], h["cosht"], h["sinht"], E)
+    return g, h, om, N, L, dtau
+
+
+def test_langevin_drift_matches_dense_golden(oracle):
+    """calc_dSdx! of LangevinDynamics.jl (:334-384): -2 gᵀ(∂M/∂x)M⁻¹g + shifted boson force vs the dense complex-step value."""
+    g, h, om, N, L, dtau = _setup_langevin(oracle)
+    dS, Mg, it = oracle.langevin_dSdx(om, h["x"], g["g1"], g["omega"], g["omega4"], h["lam"], h["lam2"], h["mu"], dtau, tol=1e-10,
+                                      maxiter=20000)
+    assert rel(Mg, g["Minv_g1"]) < 1e-8 and rel(dS, g["F1"]) < 1e-8
+
+
+@pytest.mark.parametrize("scheme,key", [(0, "x_euler"), (1, "x_rk"), (2, "x_heun")])
+def test_langevin_step_matches_dense_golden(oracle, scheme, key):
+    g, h, om, N, L, dtau = _setup_langevin(oracle)
+    x1, it = oracle.langevin_evolve(scheme, om, h["x"], g["faQ"], float(g["dt"]), g["eta"], g["g1"], g["g2"], g["omega"], g["omega4"],
+                                    h["lam"], h["lam2"], h["mu"], dtau, tol=1e-10, maxiter=20000)
+    assert rel(x1 - h["x"], g[key] - h["x"]) < 1e-7              # compare the displacement, not x itself
+    E1 = oracle.update_model_holstein(N, L, dtau, x1, h["lam"], h["lam2"], h["mu"])
+    assert np.array_equal(np.ctypeslib.as_array(om.E, shape=(N * L,)), E1)     # update_model! ran for the new field
+
+
+def test_langevin_step_with_kpm_preconditioner(oracle):
+    g, h, om, N, L, dtau = _setup_langevin(oracle)
+    from elphdynamics_amd import synth
+    P = oracle.make_kpm(om, n=min(20, N))
+    x1, it = oracle.langevin_evolve(2, om, h["x"], g["faQ"], float(g["dt"]), g["eta"], g["g1"], g["g2"], g["omega"], g["omega4"],
+                                    h["lam"], h["lam2"], h["mu"], dtau, P=P, kpm_randn=synth.randn(5, 4 * N), tol=1e-10, maxiter=20000)
+    assert rel(x1 - h["x"], g["x_heun"] - h["x"]) < 1e-7
