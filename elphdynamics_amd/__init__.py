@@ -14,7 +14,7 @@ __all__ = ["lattice", "synth", "Lattice", "models", "preconditioners", "configs"
 
 def __getattr__(name):
     # models / preconditioners / configs pull in the ctypes binding lazily
-    if name in ("models", "preconditioners", "configs", "hmc", "greens", "io", "sharded", "dist"):
+    if name in ("models", "preconditioners", "configs", "hmc", "langevin", "greens", "io", "sharded", "dist"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

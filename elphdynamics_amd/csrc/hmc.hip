@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(TPB) k_hmc_phi(double *__restrict__ phi, const
 // dS/dx (+)= dSb/dx   (calc_dSbdx!, PhononAction.jl:114-187, no dispersive modes)
 __global__ void __launch_bounds__(TPB) k_hmc_dsb(double *__restrict__ dS, const double *__restrict__ x,
                                                  const double *__restrict__ par, int N, int L, double dtau, int accumulate,
-                                                 int nch) {
+                                                 int nch, const double *__restrict__ lam_shift = nullptr) {
     const long long nd = (long long)N * L, n = nd * nch, i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     const size_t base = (size_t)((i / nd) * nd);
@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(TPB) k_hmc_dsb(double *__restrict__ dS, const 
     d += (dtau * w * w) * xt;
     d += (dtau * 4 * w4) * xt * xt * xt;
     d -= (x[base + (size_t)tp1 * N + s] + x[base + (size_t)tm1 * N + s] - 2.0 * xt) / dtau;
+    if (lam_shift) d -= dtau * lam_shift[s];         // calc_dSbdx!(…, shifted = true): the particle-hole shifted action (Langevin)
     dS[i] = d;
 }
 
@@ -552,4 +553,121 @@ extern "C" int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, dou
     if (st && st->nch != 1) { elph_set_error("%d chains: use elph_hmc_update_chains", st->nch); return ELPH_E_STATE; }
     return elph_hmc_update_chains(h, dt, nt, nb, alpha, use_precond, R, Rp, Rm, kpm_randn, &u_accept, accepted, iters_per_solve,
                                   energies, flag_out);
+}
+
+
+// ==========================================================================================
+// Langevin dynamics (LangevinDynamics.jl) on the device — Holstein.  Shares the HMC state (x, scratch vectors, ω, ω₄,
+// the accelerator table, here FourierAccelerator.Q) and its helpers.
+//   calc_dSdx! = calc_dSfdx! (:350-384: one solve MᵀM x = Mᵀg, dSf/dx = -2 gᵀ(∂M/∂x)M⁻¹g, the flag is ignored) + shifted
+//                calc_dSbdx! (:334-344)
+//   evolve!    = EulerDynamics (:81-130), RungeKuttaDynamics (:162-232), HeunsDynamics (:272-328)
+// ==========================================================================================
+
+namespace {
+
+__global__ void __launch_bounds__(TPB) k_lv_axpby(double *__restrict__ out, double a, const double *__restrict__ x, double b,
+                                                  const double *__restrict__ y, double c, const double *__restrict__ z, long long n) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i] + (z ? c * z[i] : 0.0);
+}
+
+int axpby(elph_handle_s *h, double *out, double a, const double *x, double b, const double *y, double c, const double *z, long long n) {
+    hipLaunchKernelGGL(k_lv_axpby, dim3(nblk(n)), dim3(TPB), 0, h->stream, out, a, x, b, y, c, z, n);
+    return chk("k_lv_axpby");
+}
+
+// dS (layout S) = calc_dSdx!(x; g); returns the iteration count of the solve
+int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_host, int use_precond, const double *bmax,
+                   const double *bmin, int64_t *iters, int *flag) {
+    const size_t nd = (size_t)h->ndim;
+    RC(upload_vectors(h, st->R2, g_host, 1));                                   // g in layout S
+    if (use_precond) RC(elph_kpm_setup_chains(h, bmax, bmin, nullptr, nullptr, nullptr, nullptr, nullptr));   // setup!(P), :366
+    RC(elph_launch_mul(h, 1, h->d_b, st->R2, 1));                               // Mᵀg (model.v″, :378)
+    HIPCHK(hipMemsetAsync(h->d_x, 0, nd * sizeof(double), h->stream));          // fill!(M⁻¹g, 0), :367
+    int64_t it = 0;
+    double res = 0.0;
+    int fl = 0;
+    RC(elph_i_ldiv_core(h, 1, use_precond ? 1 : 0, 0, &it, &res, &fl));
+    RC(elph_launch_dmdx_holstein(h, dS, st->R2, h->d_x, st->x, st->dtau, -2.0));   // -2 gᵀ(∂M/∂x)M⁻¹g, :381-384
+    const long long n = (long long)nd;
+    hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 1, 1,
+                       (const double *)h->d_lam);                               // calc_dSbdx!(dSdx, model, true), :341
+    RC(chk("k_hmc_dsb(shifted)"));
+    *iters = it;
+    *flag = fl;
+    return ELPH_OK;
+}
+
+}  // namespace
+
+// LangevinDynamics on a Holstein handle: same arguments as elph_hmc_create, with fa_Q = FourierAccelerator.Q (evolve! calls
+// fourier_accelerate! without use_mass).  elph_hmc_set_state / elph_hmc_get_state move the field x.
+extern "C" int elph_langevin_create(elph_handle h, const double *omega, const double *omega4, const double *lambda,
+                                    const double *lambda2, const double *mu, double dtau, const double *fa_Q) {
+    return elph_hmc_create_chains(h, 1, omega, omega4, lambda, lambda2, mu, dtau, fa_Q);
+}
+
+// evolve!(model, dyn, fa, P): scheme 0 Euler, 1 Runge-Kutta, 2 Heun.  The random numbers the reference draws are inputs:
+// eta [Ndof] (randn!(η, model)), g1, g2 [Ndim] (the noise vectors of the first / second force estimate; g2 unused by Euler),
+// kpm_randn [2][2][nsites] (b_max, b_min of the first and second setup!(P); NULL without preconditioner).
+// iters: the count evolve! returns (Euler: the solve; RK: the second solve; Heun: div(it1 + it2, 2)); flag: last ldiv! flag
+// (the reference ignores it: a failed solve contributes M⁻¹g = 0).
+extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int use_precond, const double *eta, const double *g1,
+                                    const double *g2, const double *kpm_randn, int64_t *iters, int *flag) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st || st->ssh || st->nch != 1) { elph_set_error("elph_langevin_create has not been called on this (Holstein, single-chain) handle"); return ELPH_E_STATE; }
+    if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
+    if (scheme < 0 || scheme > 2 || !(dt > 0.0) || !eta || !g1 || (scheme > 0 && !g2)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
+    if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
+    RC(elph_i_ensure_capacity(h, 2));
+    RC(elph_i_reserve_chains(h, 1));
+    const size_t nd = (size_t)h->ndim, N = (size_t)h->N;
+    const long long n = (long long)nd;
+    const double s2 = sqrt(2.0 * dt);
+    const double *bm1 = kpm_randn, *bn1 = kpm_randn ? kpm_randn + N : nullptr;
+    const double *bm2 = kpm_randn ? kpm_randn + 2 * N : nullptr, *bn2 = kpm_randn ? kpm_randn + 3 * N : nullptr;
+    double *F1 = st->dS, *F2 = st->y, *xi = st->v, *dx = st->v0;      // the momentum buffers are free: Langevin has none
+    int64_t it1 = 0, it2 = 0;
+    int fl = 0;
+    RC(update_model(h, st));
+    RC(upload_vectors(h, xi, eta, 1, st->nf));
+    if (scheme == 0) {
+        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, &it1, &fl));
+        RC(fa(h, st, F1, F1, 1.0));
+        RC(fa(h, st, xi, xi, 0.5));
+        RC(axpby(h, st->x, 1.0, st->x, s2, xi, -dt, F1, n));                       // x += √(2Δt) Q^½η − Δt Q dS/dx
+    } else if (scheme == 1) {
+        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, &it1, &fl));
+        RC(axpby(h, dx, s2, xi, -dt, F1, 0.0, nullptr, n));                        // Δx = √(2Δt) η − Δt dS/dx   (no acceleration)
+        RC(axpby(h, st->x, 1.0, st->x, 1.0, dx, 0.0, nullptr, n));
+        RC(update_model(h, st));
+        RC(langevin_force(h, st, F2, g2, use_precond, bm2, bn2, &it2, &fl));
+        RC(axpby(h, st->x, 1.0, st->x, -1.0, dx, 0.0, nullptr, n));                // x = x′ − Δx
+        RC(axpby(h, F1, 0.5, F2, 0.5, F1, 0.0, nullptr, n));                       // (dSdx′ + dSdx)/2
+        RC(fa(h, st, F1, F1, 1.0));
+        RC(fa(h, st, xi, xi, 0.5));
+        RC(axpby(h, st->x, 1.0, st->x, s2, xi, -dt, F1, n));
+        it1 = it2;
+    } else {
+        RC(fa(h, st, xi, xi, 0.5));                                                // ξ = Q^½η
+        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, &it1, &fl));
+        RC(fa(h, st, F1, F1, 1.0));                                                // dΓ/dx
+        RC(axpby(h, dx, s2, xi, -dt, F1, 0.0, nullptr, n));
+        RC(axpby(h, st->x, 1.0, st->x, 1.0, dx, 0.0, nullptr, n));
+        RC(update_model(h, st));
+        RC(langevin_force(h, st, F2, g2, use_precond, bm2, bn2, &it2, &fl));
+        RC(fa(h, st, F2, F2, 1.0));
+        RC(axpby(h, st->x, 1.0, st->x, -1.0, dx, 0.0, nullptr, n));                // x = x′ − Δx
+        RC(axpby(h, F1, 0.5, F1, 0.5, F2, 0.0, nullptr, n));                       // (dΓ + dΓ′)/2
+        RC(axpby(h, st->x, 1.0, st->x, s2, xi, -dt, F1, n));
+        it1 = (it1 + it2) / 2;
+    }
+    RC(update_model(h, st));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (iters) *iters = it1;
+    if (flag) *flag = fl;
+    return ELPH_OK;
 }

@@ -799,6 +799,38 @@ __global__ void __launch_bounds__(1024) k_force_holstein(double *__restrict__ F,
     }
 }
 
+// muldMdx!(dMdx, u, holstein, v) for given u, v (HolsteinModels.jl:691-755) — the Langevin force -2 gᵀ(∂M/∂x)M⁻¹g
+// (LangevinDynamics.jl:350-384):  F(tau) = scale * [CBᵀ u](tau) .* sg(tau) dtau (lambda + 2 lambda2 x) E(tau) .* v(tau-1)
+template <int NPL>
+__global__ void __launch_bounds__(1024) k_dmdx_holstein(double *__restrict__ F, const double *__restrict__ u,
+                                                        const double *__restrict__ v, const double *__restrict__ xS,
+                                                        const double *__restrict__ lam3, ModelDev m, double dtau, double scale) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *buf = lds;
+    const int N = m.N, L = m.L;
+    const int t = blockIdx.x;
+    const int tm1 = (t == 0) ? L - 1 : t - 1;
+    const double sg = (t == 0) ? -1.0 : 1.0;
+    const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
+    const double *E0 = m.E + (size_t)t * m.E_tau_stride;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * blockDim.x;
+        if (s < N) buf[s] = u[(size_t)t * N + s];
+    }
+    __syncthreads();
+    cb_sweep<1, true>(buf, nullptr, c0, s0, nullptr, nullptr, m);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int s = threadIdx.x + q * blockDim.x;
+        if (s < N) {
+            const size_t i = (size_t)t * N + s;
+            const double x = xS[i];
+            F[i] = scale * buf[s] * (sg * dtau * (lam3[s] + 2 * lam3[N + s] * x) * E0[s] * v[(size_t)tm1 * N + s]);
+        }
+    }
+}
+
 // Fermion force of the SSH model: muldMdx! on bond phonons (SSHModels.jl:707-829) fused with mulM! (HMC.jl:797-806).
 // Per slice tau and per pseudofermion field X:
 //   b0 = E_mu .* X(tau-1);  u = X(tau) - sg CB_tau b0;  c0 = CB_tau^T u;
@@ -1227,6 +1259,17 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
                            XS, phiS, xS, h->d_lam, m, dtau);
     });
     return check_launch("k_force_holstein");
+}
+
+int elph_launch_dmdx_holstein(elph_handle_s *h, double *FS, const double *uS, const double *vS, const double *xS, double dtau,
+                              double scale) {
+    ModelDev m = elph_model_dev(h);
+    const size_t shm = 2 * (size_t)h->N * sizeof(double);
+    DISPATCH_NPL(gen_npl(h), {
+        hipLaunchKernelGGL((k_dmdx_holstein<NPL>), dim3((unsigned)h->L), dim3((unsigned)gen_bs(h)), shm, h->stream, FS, uS, vS, xS,
+                           h->d_lam, m, dtau, scale);
+    });
+    return check_launch("k_dmdx_holstein");
 }
 
 int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS) {

@@ -280,6 +280,21 @@ int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double 
                            const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept, int *accepted,
                            double *iters_per_solve, double *energies, int *flag);
 
+/* ---------------------------------------------------------------- Langevin dynamics (caller of the path) */
+
+/* LangevinDynamics.jl on a Holstein handle.  elph_langevin_create: the arguments of elph_hmc_create with
+ * fa_Q = FourierAccelerator.Q (evolve! calls fourier_accelerate! without use_mass); the field moves through
+ * elph_hmc_set_state / elph_hmc_get_state (v = NULL).
+ * elph_langevin_evolve = evolve!(model, dyn, fa, P): scheme 0 EulerDynamics (:81-130), 1 RungeKuttaDynamics (:162-232),
+ * 2 HeunsDynamics (:272-328), with calc_dSdx! (:334-384: one solve MᵀM x = Mᵀg, dSf/dx = −2 gᵀ(∂M/∂x)M⁻¹g via muldMdx!
+ * HolsteinModels.jl:691-755, plus the shifted calc_dSbdx!) on the device.  The random numbers are inputs: eta [Ndof], g1, g2
+ * [Ndim] (g2 unused by Euler), kpm_randn [2][2][nsites] (b_max, b_min per setup!(P)).  iters: what evolve! returns; flag:
+ * the last ldiv! flag (the reference ignores it). */
+int elph_langevin_create(elph_handle h, const double *omega, const double *omega4, const double *lambda, const double *lambda2,
+                         const double *mu, double dtau, const double *fa_Q);
+int elph_langevin_evolve(elph_handle h, int scheme, double dt, int use_precond, const double *eta, const double *g1, const double *g2,
+                         const double *kpm_randn, int64_t *iters, int *flag);
+
 /* ---------------------------------------------------------------- Green's-function estimator */
 
 /* EstimateGreensFunction(model, n_v) — GreensFunctions.jl:155-195.  norbits*L1*L2*L3 must equal nsites

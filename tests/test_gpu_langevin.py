@@ -1,0 +1,82 @@
+"""GPU parity of the Langevin dynamics step (LangevinDynamics.jl: calc_dSdx!, evolve! for Euler / Runge-Kutta / Heun) —
+elph_langevin_* through the C ABI vs the dense golden steps and vs the oracle at the BASELINE sizes."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def _golden_model(tol=1e-10):
+    from elphdynamics_amd import lattice as lat
+    from elphdynamics_amd import models, preconditioners as pc
+    g, h = golden("langevin_sq4_L8.npz"), golden("holstein_sq4_L8.npz")
+    la = lat.Lattice(1, 4, 4, 1)
+    m = models.HolsteinModel(la, int(g["Ltau"]) * float(g["dtau"]), float(g["dtau"]), tol=tol, maxiter=20000)
+    m.neighbor_table, m.t = np.array(h["raw"]), np.array(h["t_raw"])
+    m.initialize_model_()
+    m.lam[:], m.lam2[:], m.mu[:] = h["lam"], h["lam2"], h["mu"]
+    m.omega[:], m.omega4[:] = g["omega"], g["omega4"]
+    m.x[:] = h["x"]
+    models.update_model_(m)
+    fa = pc.FourierAccelerator(m)
+    fa.Q[:] = g["faQ"]
+    return g, h, m, fa
+
+
+@pytest.mark.parametrize("cls,key", [("EulerDynamics", "x_euler"), ("RungeKuttaDynamics", "x_rk"), ("HeunsDynamics", "x_heun")])
+def test_langevin_step_matches_dense_golden(cls, key):
+    from elphdynamics_amd import langevin
+    g, h, m, fa = _golden_model()
+    dyn = getattr(langevin, cls)(m, fa, float(g["dt"]))
+    it = langevin.evolve_(m, dyn, fa, None, randoms=dict(eta=g["eta"], g1=g["g1"], g2=g["g2"], kpm_randn=None))
+    assert dyn.flag == 0 and it > 0
+    assert rel(m.x - h["x"], g[key] - h["x"]) < 1e-7
+    m.close()
+
+
+@pytest.mark.parametrize("tag,scheme,with_kpm", [("b", 0, False), ("d", 1, True), ("B", 2, True), ("C", 2, True)])
+def test_langevin_step_vs_oracle(oracle, tag, scheme, with_kpm):
+    """Two consecutive steps (the field stays on the device between them) vs the oracle, with the KPM preconditioner set up
+    from the same Arnoldi start vectors; also the reference's iteration-count conventions."""
+    from elphdynamics_amd import configs, langevin, preconditioners as pc, synth
+    m = configs.make_model(tag, tol=1e-8, maxiter=20000)
+    m.omega4[:] = 0.02
+    fa = pc.FourierAccelerator(m)
+    pc.update_Q_(fa, m, 0.0, np.inf, 0.7)
+    E = oracle.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+    om = oracle.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+    n_arn = min(20, m.Nsites)
+    Po = oracle.make_kpm(om, n=n_arn) if with_kpm else None
+    P = pc.SymmetricKPMPreconditioner(m, n=n_arn, buf=0.05, c1=1.0, c2=1.0) if with_kpm else None
+    dyn = [langevin.EulerDynamics, langevin.RungeKuttaDynamics, langevin.HeunsDynamics][scheme](m, fa, 0.01)
+    x_o = m.x.copy()
+    for step in range(2):
+        rnd = dict(eta=synth.randn(2000 + step, m.Ndof), g1=synth.randn(2100 + step, m.Ndim), g2=synth.randn(2200 + step, m.Ndim),
+                   kpm_randn=synth.randn(2300 + step, 4 * m.Nsites) if with_kpm else None)
+        x_prev = x_o
+        x_o, it_o = oracle.langevin_evolve(scheme, om, x_o, fa.Q, 0.01, rnd["eta"], rnd["g1"], rnd["g2"], m.omega, m.omega4, m.lam,
+                                           m.lam2, m.mu, m.dtau, P=Po, kpm_randn=rnd["kpm_randn"], tol=1e-8, maxiter=20000)
+        it = langevin.evolve_(m, dyn, fa, P, randoms=rnd)
+        assert dyn.flag == 0 and abs(it - it_o) <= 1
+        assert rel(m.x - x_prev, x_o - x_prev) < 1e-6
+    m.close()
+
+
+def test_langevin_error_paths():
+    from elphdynamics_amd import _lib, configs
+    m = configs.make_model("b")
+    lib = m._lib
+    z = np.zeros(m.Ndim)
+    assert lib.elph_langevin_evolve(m._h, 0, 0.01, 0, _lib.dptr(z), _lib.dptr(z), None, None, None, None) == _lib.ELPH_E_STATE
+    m.close()
+    e = configs.make_model("e")
+    assert e._lib.elph_langevin_create(e._h, _lib.dptr(np.zeros(e.Nsites)), _lib.dptr(np.zeros(e.Nsites)), _lib.dptr(np.zeros(e.Nsites)),
+                                       _lib.dptr(np.zeros(e.Nsites)), _lib.dptr(np.zeros(e.Nsites)), 0.05,
+                                       _lib.dptr(np.zeros(e.Ndim))) == _lib.ELPH_E_UNSUPPORTED
+    e.close()
