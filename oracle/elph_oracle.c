@@ -1498,6 +1498,61 @@ int64_t elpho_hmc_update_ssh(const elpho_hmc_params *hp, const elpho_hmc_ssh *ss
 }
 
 /* ====================================================================== */
+/* Special updates (SpecialUpdates.jl): one proposed move                   */
+/* ====================================================================== */
+
+/* The body of the loops of special_update! — ReflectionUpdate (SpecialUpdates.jl:103-136: x_i(τ) → −x_i(τ) on one site) and
+ * SwapUpdate (:205-236 Holstein, :241-275 SSH: two phonon columns exchange their world lines):
+ *   S₀ = refresh_ϕ!(hmc, model, sample_R = true)      fresh pseudofermions for the CURRENT field, S₀ = (R₊² + R₋²)/2 + S_b
+ *   apply the move, update_model!, calc_O⁻¹Λϕ!(…, 2.0), S₁ = calc_S, accept iff u < min(1, e^{−(S₁−S₀)}) and flag == 0,
+ *   otherwise undo the move and update_model! again.
+ * kind 0: reflect column ci; kind 1: swap columns ci, cj (0-based phonon columns).  ssh == NULL: Holstein.
+ * out[0..4] = S₀, S₁, iters, flag, acceptance probability.  Returns accepted. */
+int64_t elpho_special_move(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x, int kind,
+                           int64_t ci, int64_t cj, const double *Rp, const double *Rm, const double *kpm_randn, double u,
+                           double *out) {
+    const int64_t N = hp->N, L = hp->L, n = N * L;
+    const int64_t nf = ssh ? ssh->Nph : N, nfl = nf * L, nmax = (nfl > n) ? nfl : n;
+    double *buf = (double *)calloc((size_t)(13 * nmax), sizeof(double));
+    hmc_ws w;
+    memset(&w, 0, sizeof w);
+    w.hp = hp; w.ssh = ssh; w.m = m; w.P = P; w.x = x; w.kpm_randn = kpm_randn; w.nf = nf;
+    double *q = buf;
+    w.phi[0] = q; q += nmax; w.phi[1] = q; q += nmax; w.Lphi[0] = q; q += nmax; w.Lphi[1] = q; q += nmax;
+    w.X[0] = q; q += nmax; w.X[1] = q; q += nmax; w.Lam = q; q += nmax; w.u = q; q += nmax; w.y = q; q += nmax;
+    w.dSdx = q; q += nmax; w.r = q; q += nmax; w.p = q; q += nmax; w.z = q; q += nmax;
+    hmc_update_model(&w);
+    /* refresh_ϕ!(…, sample_R = true), HMC.jl:665-692 */
+    if (ssh) {
+        elpho_mulMT(w.phi[0], m, Rp);
+        elpho_mulMT(w.phi[1], m, Rm);
+    } else {
+        elpho_update_Lambda(w.Lam, N, L, hp->dtau, x, hp->lambda, hp->lambda2);
+        elpho_mulMT(w.Lphi[0], m, Rp);
+        elpho_mulLambdaInv(w.phi[0], w.Lphi[0], w.Lam, N, L);
+        elpho_mulMT(w.Lphi[1], m, Rm);
+        elpho_mulLambdaInv(w.phi[1], w.Lphi[1], w.Lam, N, L);
+    }
+    const double S0 = dotp(Rp, Rp, n) / 2 + dotp(Rm, Rm, n) / 2 + elpho_calc_Sb_holstein(nf, L, hp->dtau, x, hp->omega, hp->omega4);
+    for (int rep = 0; rep < 2; rep++) {                            /* rep 0: the move; rep 1: its undo when rejected */
+        for (int64_t t = 0; t < L; t++) {
+            if (kind == 0) x[ci * L + t] = -x[ci * L + t];
+            else { const double a = x[ci * L + t]; x[ci * L + t] = x[cj * L + t]; x[cj * L + t] = a; }
+        }
+        hmc_update_model(&w);
+        if (rep == 1) break;
+        int64_t flag = 0;
+        const int64_t iters = hmc_calc_OinvLphi(&w, 2.0, &flag);
+        const double S1 = hmc_calc_Sf(&w) + elpho_calc_Sb_holstein(nf, L, hp->dtau, x, hp->omega, hp->omega4);
+        const double e = exp(-(S1 - S0)), Pf = (1.0 < e) ? 1.0 : e;
+        out[0] = S0; out[1] = S1; out[2] = (double)iters; out[3] = (double)flag; out[4] = Pf;
+        if (u < Pf && flag == 0) { free(buf); return 1; }
+    }
+    free(buf);
+    return 0;
+}
+
+/* ====================================================================== */
 /* Langevin dynamics (LangevinDynamics.jl) — Holstein                      */
 /* ====================================================================== */
 

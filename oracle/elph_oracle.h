@@ -272,6 +272,12 @@ int64_t elpho_hmc_update_ssh(const elpho_hmc_params *hp, const elpho_hmc_ssh *ss
                              double *v, const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
                              double *out);
 
+/* SpecialUpdates.jl:103-136,205-275: one proposed reflection (kind 0) or swap (kind 1) move; see the definition */
+int64_t elpho_special_move(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x, int kind,
+                           int64_t ci, int64_t cj, const double *Rp, const double *Rm, const double *kpm_randn, double u,
+                           double *out);
+
+
 /* SSHModels.jl:707-829 (no equivalent fields); dMdx[Nph*L] is overwritten */
 void elpho_muldMdx_ssh(double *dMdx, const double *u, const elpho_model *m, const double *v, double dtau,
                        const int64_t *bond_to_phonon_cb, const double *alpha, const double *alpha2, const double *x,

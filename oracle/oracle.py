@@ -150,6 +150,9 @@ class Oracle:
         L.elpho_calc_Sb_holstein.restype = c_dbl
         L.elpho_calc_Sb_holstein.argtypes = [c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_calc_dSbdx_holstein.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_special_move.restype = c_i64
+        L.elpho_special_move.argtypes = [C.POINTER(HmcParams), C.POINTER(HmcSsh), C.POINTER(Model), C.POINTER(KPM), P_dbl, C.c_int, c_i64,
+                                         c_i64, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]
         L.elpho_langevin_dSdx.restype = c_i64
         L.elpho_langevin_dSdx.argtypes = [P_dbl, C.POINTER(HmcParams), C.POINTER(Model), C.POINTER(KPM), P_dbl, P_dbl, P_dbl, P_dbl,
                                           P_dbl, P_dbl]
@@ -195,6 +198,32 @@ class Oracle:
         info = dict(H0=out[0], H1=out[1], S=out[2], K=out[3], iters=out[4], flag=int(out[5]), P_accept=out[6],
                     kpm_calls=int(out[7]))
         return bool(acc), x, v, info
+
+    def special_move(self, m, x, kind, ci, cj, Rp, Rm, u, omega, omega4, lam, lam2, mu, dtau, P=None, kpm_randn=None, tol=1e-5,
+                     maxiter=10000, kmax=1e12, ssh=None):
+        """One proposed reflection (kind 0) / swap (kind 1) move of SpecialUpdates.jl on phonon columns ci, cj (0-based).
+        ssh: None (Holstein) or dict(t, alpha, alpha2, phonon_to_bond, cb_perm).  -> (accepted, x', dict(S0, S1, iters, flag, P))"""
+        hp, keep = self._langevin_params(m, omega, omega4, lam, lam2, mu, dtau, P, tol, maxiter, kmax)
+        sp = None
+        if ssh is not None:
+            sp = HmcSsh()
+            Nph = len(ssh["alpha"])
+            fa_ = [np.ascontiguousarray(ssh[k], dtype=np.float64) for k in ("t", "alpha", "alpha2")]
+            ia_ = [np.ascontiguousarray(ssh[k], dtype=np.int64) for k in ("phonon_to_bond", "cb_perm")]
+            b2p = np.zeros(m.nb, dtype=np.int64)
+            b2p[ia_[1][ia_[0] - 1] - 1] = np.arange(1, Nph + 1)
+            sp.Nph = Nph
+            sp.t, sp.alpha, sp.alpha2 = (dp(a) for a in fa_)
+            sp.phonon_to_bond, sp.cb_perm, sp.bond_to_phonon_cb = ip(ia_[0]), ip(ia_[1]), ip(b2p)
+            keep += fa_ + ia_ + [b2p]
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        out = np.zeros(5)
+        kr = np.ascontiguousarray(kpm_randn, dtype=np.float64) if kpm_randn is not None else None
+        acc = self.lib.elpho_special_move(C.byref(hp), C.byref(sp) if sp is not None else None, C.byref(m),
+                                          C.byref(P) if P is not None else None, dp(x), int(kind), int(ci), int(cj),
+                                          dp(np.ascontiguousarray(Rp, dtype=np.float64)), dp(np.ascontiguousarray(Rm, dtype=np.float64)),
+                                          dp(kr) if kr is not None else None, float(u), dp(out))
+        return bool(acc), x, dict(S0=out[0], S1=out[1], iters=int(out[2]), flag=int(out[3]), P=out[4])
 
     def _langevin_params(self, m, omega, omega4, lam, lam2, mu, dtau, P, tol, maxiter, kmax):
         hp = HmcParams()

@@ -586,6 +586,65 @@ def gen_langevin(h, tag, seed, dt=0.02):
          F1=F1, Minv_g1=v1, x_euler=x_euler, x_rk=x_rk, x_heun=x_heun)
 
 
+def gen_special(h, tag, seed):
+    """Actions before / after a proposed special update (SpecialUpdates.jl:103-136,205-236) from the definitions: fresh
+    pseudofermions ϕ± = Λ(x)⁻¹ M(x)ᵀ R± for the current field, S₀ = (R₊² + R₋²)/2 + S_b(x); after the move x → x′,
+    S₁ = S_b(x′) + 1/2 Σ± (Λ(x′)ϕ±)ᵀ (M(x′)ᵀM(x′))⁻¹ (Λ(x′)ϕ±) with dense matrices and exact solves."""
+    N, L, dtau, CB = h["N"], h["Ltau"], h["dtau"], h["CB"]
+    n = N * L
+    g = np.load(os.path.join(HERE, f"holstein_{tag}.npz"))
+    lam, lam2, mu, x0 = g["lam"], g["lam2"], g["mu"], g["x"].copy()
+    omega = 1.0 + 0.1 * synth.randn(seed + 1, N)
+    omega4 = 0.05 * np.abs(synth.randn(seed + 2, N))
+    Rp, Rm = synth.randn(seed + 4, n), synth.randn(seed + 5, n)
+
+    def lam_diag(x):
+        X = x.reshape(N, L)
+        return np.exp(-dtau * (lam[:, None] * X + lam2[:, None] * X ** 2) / 2)
+
+    def lam_mul(x, phi):
+        La, P = lam_diag(x), phi.reshape(N, L)
+        out = np.empty((N, L))
+        out[:, :L - 1] = -La[:, 1:] * P[:, 1:]
+        out[:, L - 1] = La[:, 0] * P[:, 0]
+        return out.reshape(-1)
+
+    def lam_inv_mul(x, u):
+        La, U = lam_diag(x), u.reshape(N, L)
+        out = np.empty((N, L))
+        out[:, 1:] = -(1.0 / La[:, 1:]) * U[:, :L - 1]
+        out[:, 0] = (1.0 / La[:, 0]) * U[:, L - 1]
+        return out.reshape(-1)
+
+    def dense_M_of(x):
+        X = x.reshape(N, L)
+        E = np.exp(-dtau * (lam[:, None] * X + lam2[:, None] * X ** 2 - mu[:, None]))
+        return dense_M(N, L, lambda t: CB, E)
+
+    def Sb(x):
+        X = x.reshape(N, L)
+        return dtau * np.sum(omega[:, None] ** 2 * X ** 2 / 2 + omega4[:, None] * X ** 4 + (X - np.roll(X, 1, axis=1)) ** 2 / dtau ** 2 / 2)
+
+    M0 = dense_M_of(x0)
+    phis = [lam_inv_mul(x0, M0.T @ Rp), lam_inv_mul(x0, M0.T @ Rm)]
+    S0 = 0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0)
+
+    def S_after(x):
+        M = dense_M_of(x)
+        A = M.T @ M
+        return Sb(x) + sum(0.5 * (lam_mul(x, p) @ np.linalg.solve(A, lam_mul(x, p))) for p in phis)
+
+    out = dict(N=N, Ltau=L, omega=omega, omega4=omega4, Rp=Rp, Rm=Rm, S0=S0)
+    X0 = x0.reshape(N, L)
+    for site in (2, 7):
+        X = X0.copy(); X[site] = -X[site]
+        out[f"S1_reflect{site}"] = S_after(X.reshape(-1))
+    for (i, j) in ((0, 1), (5, 9)):
+        X = X0.copy(); X[[i, j]] = X[[j, i]]
+        out[f"S1_swap{i}_{j}"] = S_after(X.reshape(-1))
+    save(f"special_{tag}.npz", **out)
+
+
 # ----------------------------------------------------------------------------- Green's-function estimator
 def gen_greens(h, tag, norb, Lsp, seed, nv=3):
     """Stochastic Green's-function estimator (GreensFunctions.jl:201-288): the four translation-averaged products
@@ -642,5 +701,6 @@ if __name__ == "__main__":
     gen_hmc(h1, "sq4_L8", seed=66, nb=1)
     gen_hmc(h1, "sq4_L8", seed=66, nb=3)
     gen_langevin(h1, "sq4_L8", seed=71)
+    gen_special(h1, "sq4_L8", seed=81)
     h2 = gen_holstein("sq4_L40", 1, 4, SQUARE, 40, 0.1, seed=55)
     gen_kpm(h2, "sq4_L40")

@@ -177,3 +177,35 @@ def test_langevin_step_with_kpm_preconditioner(oracle):
     x1, it = oracle.langevin_evolve(2, om, h["x"], g["faQ"], float(g["dt"]), g["eta"], g["g1"], g["g2"], g["omega"], g["omega4"],
                                     h["lam"], h["lam2"], h["mu"], dtau, P=P, kpm_randn=synth.randn(5, 4 * N), tol=1e-10, maxiter=20000)
     assert rel(x1 - h["x"], g["x_heun"] - h["x"]) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------- special updates
+
+def test_special_moves_match_dense_golden(oracle):
+    """One proposed reflection / swap move (SpecialUpdates.jl): the actions S₀, S₁ vs the dense golden, the accept / reject
+    bookkeeping (field changed or restored, update_model! for the final field)."""
+    g, h = golden("special_sq4_L8.npz"), golden("holstein_sq4_L8.npz")
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(h["dtau"])
+    E = oracle.update_model_holstein(N, L, dtau, h["x"], h["lam"], h["lam2"], h["mu"])
+    om = oracle.make_model(0, N, L, h["table"], h["cosht"], h["sinht"], E)
+    X0 = h["x"].reshape(N, L)
+    for kind, ci, cj, key in ((0, 2, 0, "S1_reflect2"), (0, 7, 0, "S1_reflect7"), (1, 0, 1, "S1_swap0_1"), (1, 5, 9, "S1_swap5_9")):
+        for u, want in ((0.0, True), (1.5, False)):
+            acc, x1, info = oracle.special_move(om, h["x"], kind, ci, cj, g["Rp"], g["Rm"], u, g["omega"], g["omega4"], h["lam"], h["lam2"],
+                                                h["mu"], dtau, tol=1e-6, maxiter=20000)
+            assert info["flag"] == 0 and acc == want
+            assert abs(info["S0"] - float(g["S0"])) < 1e-11 * abs(float(g["S0"]))
+            assert abs(info["S1"] - float(g[key])) < 1e-8 * abs(float(g[key]))         # action at tol^2 = 1e-12
+            X = X0.copy()
+            if want:
+                if kind == 0:
+                    X[ci] = -X[ci]
+                else:
+                    X[[ci, cj]] = X[[cj, ci]]
+            assert np.array_equal(x1, X.reshape(-1))
+            assert np.array_equal(np.ctypeslib.as_array(om.E, shape=(N * L,)),
+                                  oracle.update_model_holstein(N, L, dtau, x1, h["lam"], h["lam2"], h["mu"]))
+    # a failed solve rejects whatever the Metropolis test says
+    acc, x1, info = oracle.special_move(om, h["x"], 0, 2, 0, g["Rp"], g["Rm"], 0.0, g["omega"], g["omega4"], h["lam"], h["lam2"], h["mu"], dtau,
+                                        tol=1e-6, maxiter=2)
+    assert not acc and info["flag"] > 0 and np.array_equal(x1, h["x"])
