@@ -671,3 +671,87 @@ extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int us
     if (flag) *flag = fl;
     return ELPH_OK;
 }
+
+
+// ==========================================================================================
+// Special updates (SpecialUpdates.jl): one proposed move on the device-resident field of the HMC state
+// ==========================================================================================
+
+namespace {
+
+// reflect column ci (kind 0) or swap columns ci, cj (kind 1) of a tau-major field vector x[t * nf + column]
+__global__ void __launch_bounds__(TPB) k_hmc_colop(double *__restrict__ x, int nf, int L, int kind, int ci, int cj) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= L) return;
+    double *row = x + (size_t)t * nf;
+    if (kind == 0) row[ci] = -row[ci];
+    else { const double a = row[ci]; row[ci] = row[cj]; row[cj] = a; }
+}
+
+}  // namespace
+
+// The body of the loops of special_update! (SpecialUpdates.jl:103-136 reflection, :205-275 swap) for the single chain of an
+// HMC state created with elph_hmc_create / elph_hmc_create_ssh:
+//   S₀ = refresh_ϕ!(hmc, model, sample_R = true) — Rp, Rm are the fresh R± (HMC.jl:665-692), S₀ = (R₊² + R₋²)/2 + S_b;
+//   the move (kind 0: x_col(τ) → −x_col(τ) on column col_i; kind 1: columns col_i, col_j exchange their world lines; 0-based
+//   phonon columns = sites for Holstein), update_model!, calc_O⁻¹Λϕ!(…, 2.0), S₁ = calc_S;
+//   accepted iff u < min(1, e^{−(S₁−S₀)}) and flag == 0, otherwise the move is undone and update_model! runs again.
+// kpm_randn: b_max, b_min [2][nsites] of the one setup!(P) (NULL without preconditioner).  The choice of sites / bonds
+// (sample!(model.rng, …)) stays with the caller.  out: accepted, S₀, S₁, iterations, flag.
+extern "C" int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int64_t col_j, const double *Rp, const double *Rm,
+                                     int use_precond, const double *kpm_randn, double u_accept, int *accepted, double *S0_out,
+                                     double *S1_out, int64_t *iters_out, int *flag_out) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st || st->nch != 1) { elph_set_error("elph_hmc_create / elph_hmc_create_ssh (single chain) has not been called"); return ELPH_E_STATE; }
+    if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
+    if (!Rp || !Rm || !accepted || kind < 0 || kind > 1 || col_i < 0 || col_i >= st->nf || (kind == 1 && (col_j < 0 || col_j >= st->nf))) {
+        elph_set_error("bad argument");
+        return ELPH_E_ARG;
+    }
+    if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
+    if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
+    RC(elph_i_ensure_capacity(h, 2));
+    if (!st->ssh) RC(elph_i_reserve_chains(h, 1));
+    const size_t nd = (size_t)h->ndim;
+    const int L = (int)h->L;
+    RC(update_model(h, st));
+    // refresh_ϕ!(…, sample_R = true)
+    RC(upload_vectors(h, st->R2, Rp, 1));
+    RC(upload_vectors(h, st->R2 + nd, Rm, 1));
+    RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2));
+    if (st->ssh) {
+        HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        hipLaunchKernelGGL(k_hmc_phi, dim3(nblk((long long)nd), 2), dim3(TPB), 0, h->stream, st->phi, h->d_b, st->x, h->d_lam, (int)h->N, L,
+                           st->dtau, 1);
+        RC(chk("k_hmc_phi"));
+    }
+    double rr[2], sb0 = 0.0, sb1 = 0.0, sf[2];
+    RC(dots_host(h, st, st->R2, st->R2, (long long)nd, 2, rr));
+    RC(calc_Sb(h, st, &sb0));
+    const double S0 = rr[0] / 2 + rr[1] / 2 + sb0;
+    auto move = [&]() -> int {
+        hipLaunchKernelGGL(k_hmc_colop, dim3((unsigned)((L + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, st->x, st->nf, L, kind, (int)col_i,
+                           (int)col_j);
+        RC(chk("k_hmc_colop"));
+        return update_model(h, st);
+    };
+    RC(move());
+    int64_t kpm_calls = 0, iters = 0;
+    int flag = 0;
+    RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, &iters, &flag));
+    RC(dots_host(h, st, h->d_b, h->d_x, (long long)nd, 2, sf));
+    RC(calc_Sb(h, st, &sb1));
+    const double S1 = sf[0] / 2 + sf[1] / 2 + sb1;
+    const double e = exp(-(S1 - S0)), P = (1.0 < e) ? 1.0 : e;
+    const int acc = (u_accept < P && flag == 0) ? 1 : 0;
+    if (!acc) RC(move());                                  // both moves are involutions
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *accepted = acc;
+    if (S0_out) *S0_out = S0;
+    if (S1_out) *S1_out = S1;
+    if (iters_out) *iters_out = iters;
+    if (flag_out) *flag_out = flag;
+    return ELPH_OK;
+}

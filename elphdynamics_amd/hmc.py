@@ -274,3 +274,52 @@ def update_chains_(model, hmc, fa=None, P=None, rng=None, randoms=None, pull=Fal
     if pull:
         hmc.pull_()
     return hmc.accepted, hmc.iters
+
+
+# ---------------------------------------------------------------------------------------------- special updates
+
+REFLECT, SWAP = 0, 1
+
+
+def special_move_(model, hmc, kind, col_i, col_j=0, P=None, rng=None, randoms=None):
+    """One proposed move of special_update! (SpecialUpdates.jl:103-136 reflection, :205-275 swap) on the device-resident field:
+    fresh pseudofermions, the move on phonon column(s) col_i[, col_j] (0-based), Metropolis test on S₁ − S₀.
+    -> (accepted, S0, S1, iters, flag).  randoms: dict(Rp, Rm, kpm_randn (2, Nsites) or None, u)."""
+    import ctypes as C
+    from ._lib import check, dptr
+    if randoms is None:
+        rng = rng or np.random.default_rng()
+        randoms = dict(Rp=rng.standard_normal(model.Ndim), Rm=rng.standard_normal(model.Ndim),
+                       kpm_randn=rng.standard_normal((2, model.Nsites)) if P is not None else None, u=float(rng.random()))
+    model._push_solver()
+    acc, fl, it = C.c_int(), C.c_int(), C.c_int64()
+    s0, s1 = C.c_double(), C.c_double()
+    kr = randoms.get("kpm_randn")
+    check(model._lib.elph_hmc_special_move(model._h, int(kind), int(col_i), int(col_j), dptr(np.ascontiguousarray(randoms["Rp"])),
+                                           dptr(np.ascontiguousarray(randoms["Rm"])), 0 if P is None else 1,
+                                           dptr(np.ascontiguousarray(kr, dtype=np.float64).reshape(-1)) if kr is not None else None,
+                                           float(randoms["u"]), C.byref(acc), C.byref(s0), C.byref(s1), C.byref(it), C.byref(fl)))
+    if model.kind == models.SSH:
+        model._cs_stale = True
+    return bool(acc.value), s0.value, s1.value, int(it.value), int(fl.value)
+
+
+def reflection_update_(model, hmc, nsites, P=None, rng=None):
+    """special_update!(model, hmc, ru::ReflectionUpdate, P) (SpecialUpdates.jl:103-136): nsites sites drawn with replacement,
+    one move each; returns the accepted fraction.  Holstein only (null operation otherwise, :138-141)."""
+    if model.kind != models.HOLSTEIN or nsites < 1:
+        return 0.0
+    rng = rng or np.random.default_rng()
+    sites = rng.integers(0, model.Nph, size=min(model.Nph, nsites))
+    return sum(special_move_(model, hmc, REFLECT, int(i), P=P, rng=rng)[0] for i in sites) / len(sites)
+
+
+def swap_update_(model, hmc, nbonds, P=None, rng=None):
+    """special_update!(model, hmc, su::SwapUpdate, P): Holstein (:205-236) — the two sites of nbonds randomly drawn bonds swap
+    their phonon world lines."""
+    if model.kind != models.HOLSTEIN or model.Nbonds == 0 or nbonds < 1:
+        return 0.0
+    rng = rng or np.random.default_rng()
+    bonds = rng.integers(0, model.Nbonds, size=min(model.Nbonds, nbonds))
+    tab = model.neighbor_table
+    return sum(special_move_(model, hmc, SWAP, int(tab[b, 0]) - 1, int(tab[b, 1]) - 1, P=P, rng=rng)[0] for b in bonds) / len(bonds)

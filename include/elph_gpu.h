@@ -280,6 +280,15 @@ int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double 
                            const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept, int *accepted,
                            double *iters_per_solve, double *energies, int *flag);
 
+/* One proposed move of special_update! (SpecialUpdates.jl:103-136 ReflectionUpdate, :205-275 SwapUpdate) on the device-resident
+ * field of the (single-chain) HMC state:  S₀ = refresh_ϕ!(…, sample_R = true) with the fresh R± = Rp, Rm (HMC.jl:665-692);
+ * kind 0: x_col(τ) → −x_col(τ) on phonon column col_i; kind 1: columns col_i, col_j exchange their world lines (0-based; sites
+ * for Holstein, bond phonons for SSH); update_model!, calc_O⁻¹Λϕ!(…, 2.0), S₁ = calc_S; accepted iff u_accept <
+ * min(1, e^{−(S₁−S₀)}) and flag == 0, else the move is undone.  kpm_randn: [2][nsites] or NULL.  Which sites / bonds are tried
+ * (sample!(model.rng, …)) is the caller's bookkeeping. */
+int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int64_t col_j, const double *Rp, const double *Rm, int use_precond,
+                          const double *kpm_randn, double u_accept, int *accepted, double *S0, double *S1, int64_t *iters, int *flag);
+
 /* ---------------------------------------------------------------- Langevin dynamics (caller of the path) */
 
 /* LangevinDynamics.jl on a Holstein handle.  elph_langevin_create: the arguments of elph_hmc_create with

@@ -394,3 +394,72 @@ def test_hmc_chains_failed_solve_kills_only_that_chain():
     acc, its = hmc.update_chains_(m, H, fa, None, randoms=rnd2, pull=True)
     assert not acc.any() and (H.flags > 0).all() and np.array_equal(H.X, X0[[0, 2]])
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------- special updates
+
+def test_special_moves_match_golden_and_oracle(oracle):
+    """elph_hmc_special_move (SpecialUpdates.jl reflection / swap moves) vs the dense golden actions and the oracle: S₀, S₁,
+    accept / reject, the field after the move, on the Holstein golden case; then SSH swaps and a KPM run vs the oracle."""
+    from elphdynamics_amd import hmc, lattice as lat, models, preconditioners as pc, synth
+    g, hg = golden("special_sq4_L8.npz"), golden("holstein_sq4_L8.npz")
+    la = lat.Lattice(1, 4, 4, 1)
+    m = models.HolsteinModel(la, int(g["Ltau"]) * float(hg["dtau"]), float(hg["dtau"]), tol=1e-6, maxiter=20000)
+    m.neighbor_table, m.t = np.array(hg["raw"]), np.array(hg["t_raw"])
+    m.initialize_model_()
+    m.lam[:], m.lam2[:], m.mu[:] = hg["lam"], hg["lam2"], hg["mu"]
+    m.omega[:], m.omega4[:] = g["omega"], g["omega4"]
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+    N, L = m.Nsites, m.Ltau
+    X0 = hg["x"].reshape(N, L)
+    for kind, ci, cj, key in ((0, 2, 0, "S1_reflect2"), (0, 7, 0, "S1_reflect7"), (1, 0, 1, "S1_swap0_1"), (1, 5, 9, "S1_swap5_9")):
+        for u, want in ((0.0, True), (1.5, False)):
+            m.x[:] = hg["x"]
+            H = hmc.HybridMonteCarlo(m, fa, 0.05, 0.1)
+            acc, S0, S1, it, fl = hmc.special_move_(m, H, kind, ci, cj, randoms=dict(Rp=g["Rp"], Rm=g["Rm"], kpm_randn=None, u=u))
+            H.pull_()
+            assert fl == 0 and acc == want
+            assert abs(S0 - float(g["S0"])) < 1e-11 * abs(float(g["S0"])) and abs(S1 - float(g[key])) < 1e-8 * abs(float(g[key]))
+            X = X0.copy()
+            if want:
+                if kind == 0:
+                    X[ci] = -X[ci]
+                else:
+                    X[[ci, cj]] = X[[cj, ci]]
+            assert np.array_equal(m.x, X.reshape(-1))
+    # the drivers: accepted fractions are fractions, the field stays a permutation / sign flip of world lines
+    m.x[:] = hg["x"]
+    H = hmc.HybridMonteCarlo(m, fa, 0.05, 0.1)
+    rng = np.random.default_rng(5)
+    f1 = hmc.reflection_update_(m, H, 3, rng=rng)
+    f2 = hmc.swap_update_(m, H, 3, rng=rng)
+    H.pull_()
+    assert 0.0 <= f1 <= 1.0 and 0.0 <= f2 <= 1.0
+    assert np.allclose(np.sort(np.abs(m.x.reshape(N, L)).sum(axis=1)), np.sort(np.abs(X0).sum(axis=1)), rtol=1e-13)
+    m.close()
+    # SSH swap of two bond-phonon columns, with the KPM preconditioner, vs the oracle
+    from elphdynamics_amd import configs
+    e = configs.make_model("e", tol=1e-6, maxiter=20000)
+    e.alpha2[:] = 0.01
+    e.omega4 = np.full(e.Nph, 0.02)
+    models.update_model_(e)
+    fae = pc.FourierAccelerator(e)
+    pc.update_M_(fae, e, 0.0, np.inf, 1.0, 0.3)
+    om = oracle.make_model(1, e.Nsites, e.Ltau, e.neighbor_table, np.ascontiguousarray(e.cosht).reshape(-1).copy(),
+                           np.ascontiguousarray(e.sinht).reshape(-1).copy(), np.exp(e.dtau * e.mu))
+    Po = oracle.make_kpm(om, n=min(20, e.Nsites))
+    Pe = pc.SymmetricKPMPreconditioner(e, n=min(20, e.Nsites), buf=0.05, c1=1.0, c2=1.0)
+    He = hmc.HybridMonteCarlo(e, fae, 0.05, 0.1)
+    rnd = dict(Rp=synth.randn(3100, e.Ndim), Rm=synth.randn(3101, e.Ndim), kpm_randn=synth.randn(3102, 2 * e.Nsites), u=0.3)
+    x_in = e.x.copy()
+    acc_o, x_o, info = oracle.special_move(om, x_in, 1, 3, 17, rnd["Rp"], rnd["Rm"], rnd["u"], e.omega, e.omega4, np.zeros(e.Nsites),
+                                           np.zeros(e.Nsites), e.mu, e.dtau, P=Po, kpm_randn=rnd["kpm_randn"], tol=1e-6, maxiter=20000,
+                                           ssh=dict(t=e.t, alpha=e.alpha, alpha2=e.alpha2, phonon_to_bond=e.phonon_to_bond,
+                                                    cb_perm=e.checkerboard_perm))
+    acc, S0, S1, it, fl = hmc.special_move_(e, He, 1, 3, 17, P=Pe, randoms=rnd)
+    He.pull_()
+    assert fl == 0 and info["flag"] == 0 and acc == acc_o
+    assert abs(S0 - info["S0"]) < 1e-10 * abs(info["S0"]) and abs(S1 - info["S1"]) < 1e-7 * abs(info["S1"])
+    assert np.array_equal(e.x, x_o)
+    e.close()
