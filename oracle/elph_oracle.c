@@ -1565,12 +1565,14 @@ static void calc_dSbdx_holstein_shifted(double *dSbdx, int64_t N, int64_t L, dou
 }
 
 /* calc_dSdx! = calc_dSfdx! + calc_dSbdx!(…, true)  (LangevinDynamics.jl:334-384): g is the noise vector the reference draws
- * with randn!(model.rng, g); solve MᵀM x = Mᵀg; dSf/dx = -2 gᵀ (∂M/∂x) M⁻¹g.  The flag of ldiv! is ignored there (a failed
- * solve leaves M⁻¹g = 0).  Returns the iteration count.  work: 5 N L doubles. */
-int64_t elpho_langevin_dSdx(double *dSdx, const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, const double *x, const double *g,
-                            const double *b_max, const double *b_min, double *Minv_g, double *work) {
+ * with randn!(model.rng, g); solve MᵀM x = Mᵀg; dSf/dx = -2 gᵀ (∂M/∂x) M⁻¹g (muldMdx! of the model).  The flag of ldiv! is
+ * ignored there (a failed solve leaves M⁻¹g = 0).  ssh == NULL: Holstein; otherwise bond phonons (dSdx has Nph*L entries, the
+ * shifted flag changes nothing, PhononAction.jl:189-234).  Returns the iteration count.  work: 5 max(N, Nph) L doubles. */
+static int64_t langevin_dSdx(double *dSdx, const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P,
+                             const double *x, const double *g, const double *b_max, const double *b_min, double *Minv_g, double *work) {
     const int64_t N = hp->N, L = hp->L, n = N * L;
-    double *b = work, *r = work + n, *p = work + 2 * n, *z = work + 3 * n, *d = work + 4 * n;
+    const int64_t nf = ssh ? ssh->Nph : N, nfl = nf * L, nmax = (nfl > n) ? nfl : n;
+    double *b = work, *r = work + nmax, *p = work + 2 * nmax, *z = work + 3 * nmax, *d = work + 4 * nmax;
     int64_t it = 0, fl = 0;
     double res;
     if (P) {                                                       /* setup!(preconditioner), :366 */
@@ -1582,56 +1584,89 @@ int64_t elpho_langevin_dSdx(double *dSdx, const elpho_hmc_params *hp, elpho_mode
     memset(Minv_g, 0, sizeof(double) * (size_t)n);
     elpho_mulMT(b, m, g);
     elpho_ldiv(m, Minv_g, b, P, 0, hp->solver_tol, hp->solver_maxiter, hp->kmax, r, p, z, &it, &res, &fl);
-    elpho_muldMdx_holstein(d, g, m, Minv_g, hp->dtau, hp->lambda, hp->lambda2, x);
-    for (int64_t i = 0; i < n; i++) dSdx[i] = -2.0 * d[i];
-    calc_dSbdx_holstein_shifted(dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4, hp->lambda);
+    if (ssh) {
+        elpho_muldMdx_ssh(d, g, m, Minv_g, hp->dtau, ssh->bond_to_phonon_cb, ssh->alpha, ssh->alpha2, x, ssh->Nph);
+        for (int64_t i = 0; i < nfl; i++) dSdx[i] = -2.0 * d[i];
+        elpho_calc_dSbdx_holstein(dSdx, nf, L, hp->dtau, x, hp->omega, hp->omega4);
+    } else {
+        elpho_muldMdx_holstein(d, g, m, Minv_g, hp->dtau, hp->lambda, hp->lambda2, x);
+        for (int64_t i = 0; i < n; i++) dSdx[i] = -2.0 * d[i];
+        calc_dSbdx_holstein_shifted(dSdx, N, L, hp->dtau, x, hp->omega, hp->omega4, hp->lambda);
+    }
     return it;
 }
 
+int64_t elpho_langevin_dSdx(double *dSdx, const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, const double *x, const double *g,
+                            const double *b_max, const double *b_min, double *Minv_g, double *work) {
+    return langevin_dSdx(dSdx, hp, NULL, m, P, x, g, b_max, b_min, Minv_g, work);
+}
+
+static void langevin_update_model(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, const double *x) {
+    if (ssh)
+        elpho_update_model_ssh(hp->N, hp->L, m->nb, ssh->Nph, hp->dtau, x, ssh->t, ssh->alpha, ssh->alpha2, hp->mu, ssh->phonon_to_bond,
+                               ssh->cb_perm, (double *)m->c, (double *)m->s, (double *)m->E);
+    else
+        elpho_update_model_holstein(hp->N, hp->L, hp->dtau, x, hp->lambda, hp->lambda2, hp->mu, (double *)m->E);
+}
+
 /* evolve!(model, dyn, fa, P) — scheme 0: EulerDynamics (:81-130), 1: RungeKuttaDynamics (:162-232), 2: HeunsDynamics
- * (:272-328).  fa_Q = FourierAccelerator.Q (fourier_accelerate! without use_mass).  eta [N L], g1, g2 [N L] (the second
+ * (:272-328).  fa_Q = FourierAccelerator.Q (fourier_accelerate! without use_mass).  eta [Ndof], g1, g2 [N L] (the second
  * noise vector of the two-stage schemes), kpm_randn: b_max, b_min of the first and of the second set-up (4 N doubles).
- * x is advanced in place; m->E follows (update_model!).  Returns the reference's iteration count. */
-int64_t elpho_langevin_evolve(int scheme, const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, double *x, const double *fa_Q,
-                              double dt, const double *eta, const double *g1, const double *g2, const double *kpm_randn) {
-    const int64_t N = hp->N, L = hp->L, n = N * L;
-    double *buf = (double *)calloc((size_t)(12 * n), sizeof(double));
-    double *F1 = buf, *F2 = buf + n, *xi = buf + 2 * n, *dx = buf + 3 * n, *Mg = buf + 4 * n, *Q = buf + 5 * n, *work = buf + 6 * n;
+ * x is advanced in place; the model tables follow (update_model!).  Returns the reference's iteration count. */
+static int64_t langevin_evolve(int scheme, const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x,
+                               const double *fa_Q, double dt, const double *eta, const double *g1, const double *g2,
+                               const double *kpm_randn) {
+    const int64_t N = hp->N, L = hp->L;
+    const int64_t nf = ssh ? ssh->Nph : N, n = nf * L, nmax = (n > N * L) ? n : N * L;
+    double *buf = (double *)calloc((size_t)(12 * nmax), sizeof(double));
+    double *F1 = buf, *F2 = buf + nmax, *xi = buf + 2 * nmax, *dx = buf + 3 * nmax, *Mg = buf + 4 * nmax, *Q = buf + 5 * nmax,
+           *work = buf + 6 * nmax;
     const double *bm1 = kpm_randn, *bn1 = kpm_randn ? kpm_randn + N : NULL;
     const double *bm2 = kpm_randn ? kpm_randn + 2 * N : NULL, *bn2 = kpm_randn ? kpm_randn + 3 * N : NULL;
     int64_t iters = 0;
-    elpho_update_model_holstein(N, L, hp->dtau, x, hp->lambda, hp->lambda2, hp->mu, (double *)m->E);
+    langevin_update_model(hp, ssh, m, x);
     if (scheme == 0) {
-        iters = elpho_langevin_dSdx(F1, hp, m, P, x, g1, bm1, bn1, Mg, work);
-        elpho_fourier_accelerate(Q, F1, fa_Q, 1.0, N, L);
-        elpho_fourier_accelerate(xi, eta, fa_Q, 0.5, N, L);
+        iters = langevin_dSdx(F1, hp, ssh, m, P, x, g1, bm1, bn1, Mg, work);
+        elpho_fourier_accelerate(Q, F1, fa_Q, 1.0, nf, L);
+        elpho_fourier_accelerate(xi, eta, fa_Q, 0.5, nf, L);
         for (int64_t i = 0; i < n; i++) x[i] += sqrt(2.0 * dt) * xi[i] - dt * Q[i];
     } else if (scheme == 1) {
-        (void)elpho_langevin_dSdx(F1, hp, m, P, x, g1, bm1, bn1, Mg, work);
+        (void)langevin_dSdx(F1, hp, ssh, m, P, x, g1, bm1, bn1, Mg, work);
         for (int64_t i = 0; i < n; i++) { dx[i] = sqrt(2 * dt) * eta[i] - dt * F1[i]; x[i] = x[i] + dx[i]; }
-        elpho_update_model_holstein(N, L, hp->dtau, x, hp->lambda, hp->lambda2, hp->mu, (double *)m->E);
-        iters = elpho_langevin_dSdx(F2, hp, m, P, x, g2, bm2, bn2, Mg, work);
+        langevin_update_model(hp, ssh, m, x);
+        iters = langevin_dSdx(F2, hp, ssh, m, P, x, g2, bm2, bn2, Mg, work);
         for (int64_t i = 0; i < n; i++) { x[i] = x[i] - dx[i]; F1[i] = (F2[i] + F1[i]) / 2.0; }
-        elpho_fourier_accelerate(Q, F1, fa_Q, 1.0, N, L);
-        elpho_fourier_accelerate(xi, eta, fa_Q, 0.5, N, L);
+        elpho_fourier_accelerate(Q, F1, fa_Q, 1.0, nf, L);
+        elpho_fourier_accelerate(xi, eta, fa_Q, 0.5, nf, L);
         for (int64_t i = 0; i < n; i++) x[i] = x[i] + (sqrt(2.0 * dt) * xi[i] - dt * Q[i]);
     } else {
-        elpho_fourier_accelerate(xi, eta, fa_Q, 0.5, N, L);
-        const int64_t it1 = elpho_langevin_dSdx(F1, hp, m, P, x, g1, bm1, bn1, Mg, work);
-        elpho_fourier_accelerate(F1, F1, fa_Q, 1.0, N, L);           /* dΓdx aliases dSdx */
+        elpho_fourier_accelerate(xi, eta, fa_Q, 0.5, nf, L);
+        const int64_t it1 = langevin_dSdx(F1, hp, ssh, m, P, x, g1, bm1, bn1, Mg, work);
+        elpho_fourier_accelerate(F1, F1, fa_Q, 1.0, nf, L);          /* dΓdx aliases dSdx */
         for (int64_t i = 0; i < n; i++) { dx[i] = sqrt(2 * dt) * xi[i] - dt * F1[i]; x[i] = x[i] + dx[i]; }
-        elpho_update_model_holstein(N, L, hp->dtau, x, hp->lambda, hp->lambda2, hp->mu, (double *)m->E);
-        const int64_t it2 = elpho_langevin_dSdx(F2, hp, m, P, x, g2, bm2, bn2, Mg, work);
-        elpho_fourier_accelerate(F2, F2, fa_Q, 1.0, N, L);
+        langevin_update_model(hp, ssh, m, x);
+        const int64_t it2 = langevin_dSdx(F2, hp, ssh, m, P, x, g2, bm2, bn2, Mg, work);
+        elpho_fourier_accelerate(F2, F2, fa_Q, 1.0, nf, L);
         for (int64_t i = 0; i < n; i++) {
             x[i] = x[i] - dx[i];
             x[i] = x[i] + sqrt(2 * dt) * xi[i] - dt * (F1[i] + F2[i]) / 2;
         }
         iters = (it1 + it2) / 2;
     }
-    elpho_update_model_holstein(N, L, hp->dtau, x, hp->lambda, hp->lambda2, hp->mu, (double *)m->E);
+    langevin_update_model(hp, ssh, m, x);
     free(buf);
     return iters;
+}
+
+int64_t elpho_langevin_evolve(int scheme, const elpho_hmc_params *hp, elpho_model *m, elpho_kpm *P, double *x, const double *fa_Q,
+                              double dt, const double *eta, const double *g1, const double *g2, const double *kpm_randn) {
+    return langevin_evolve(scheme, hp, NULL, m, P, x, fa_Q, dt, eta, g1, g2, kpm_randn);
+}
+
+int64_t elpho_langevin_evolve_ssh(int scheme, const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P,
+                                  double *x, const double *fa_Q, double dt, const double *eta, const double *g1, const double *g2,
+                                  const double *kpm_randn) {
+    return langevin_evolve(scheme, hp, ssh, m, P, x, fa_Q, dt, eta, g1, g2, kpm_randn);
 }
 
 /* SSHModels.jl:707-829 without the equivalent-field bookkeeping (primary_field == identity):

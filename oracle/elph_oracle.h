@@ -272,6 +272,11 @@ int64_t elpho_hmc_update_ssh(const elpho_hmc_params *hp, const elpho_hmc_ssh *ss
                              double *v, const double *R, const double *Rp, const double *Rm, const double *kpm_randn, double u,
                              double *out);
 
+/* evolve! of LangevinDynamics.jl for the SSH model (x, eta: Nph*L; g1, g2: N*L; fa_Q per phonon) */
+int64_t elpho_langevin_evolve_ssh(int scheme, const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P,
+                                  double *x, const double *fa_Q, double dt, const double *eta, const double *g1, const double *g2,
+                                  const double *kpm_randn);
+
 /* SpecialUpdates.jl:103-136,205-275: one proposed reflection (kind 0) or swap (kind 1) move; see the definition */
 int64_t elpho_special_move(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x, int kind,
                            int64_t ci, int64_t cj, const double *Rp, const double *Rm, const double *kpm_randn, double u,

@@ -150,6 +150,9 @@ class Oracle:
         L.elpho_calc_Sb_holstein.restype = c_dbl
         L.elpho_calc_Sb_holstein.argtypes = [c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_calc_dSbdx_holstein.argtypes = [P_dbl, c_i64, c_i64, c_dbl, P_dbl, P_dbl, P_dbl]
+        L.elpho_langevin_evolve_ssh.restype = c_i64
+        L.elpho_langevin_evolve_ssh.argtypes = [C.c_int, C.POINTER(HmcParams), C.POINTER(HmcSsh), C.POINTER(Model), C.POINTER(KPM), P_dbl,
+                                                P_dbl, c_dbl, P_dbl, P_dbl, P_dbl, P_dbl]
         L.elpho_special_move.restype = c_i64
         L.elpho_special_move.argtypes = [C.POINTER(HmcParams), C.POINTER(HmcSsh), C.POINTER(Model), C.POINTER(KPM), P_dbl, C.c_int, c_i64,
                                          c_i64, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]
@@ -255,6 +258,27 @@ class Oracle:
         fq, e, a1, a2, kr = (np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (fa_Q, eta, g1, g2, kpm_randn))
         it = self.lib.elpho_langevin_evolve(int(scheme), C.byref(hp), C.byref(m), C.byref(P) if P is not None else None, dp(x), dp(fq),
                                             float(dt), dp(e), dp(a1), dp(a2) if a2 is not None else dp(a1), dp(kr) if kr is not None else None)
+        return x, int(it)
+
+    def langevin_evolve_ssh(self, scheme, m, x, fa_Q, dt, eta, g1, g2, omega, omega4, mu, dtau, ssh, P=None, kpm_randn=None, tol=1e-5,
+                            maxiter=10000, kmax=1e12):
+        """evolve! for an SSH model: ssh = dict(t, alpha, alpha2, phonon_to_bond, cb_perm) -> (x', iters)."""
+        Nph = len(ssh["alpha"])
+        zeros = np.zeros(max(m.N, Nph))
+        hp, keep = self._langevin_params(m, omega, omega4, zeros, zeros, mu, dtau, P, tol, maxiter, kmax)
+        sp = HmcSsh()
+        fa_ = [np.ascontiguousarray(ssh[k], dtype=np.float64) for k in ("t", "alpha", "alpha2")]
+        ia_ = [np.ascontiguousarray(ssh[k], dtype=np.int64) for k in ("phonon_to_bond", "cb_perm")]
+        b2p = np.zeros(m.nb, dtype=np.int64)
+        b2p[ia_[1][ia_[0] - 1] - 1] = np.arange(1, Nph + 1)
+        sp.Nph = Nph
+        sp.t, sp.alpha, sp.alpha2 = (dp(a) for a in fa_)
+        sp.phonon_to_bond, sp.cb_perm, sp.bond_to_phonon_cb = ip(ia_[0]), ip(ia_[1]), ip(b2p)
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        fq, e, a1, a2, kr = (np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (fa_Q, eta, g1, g2, kpm_randn))
+        it = self.lib.elpho_langevin_evolve_ssh(int(scheme), C.byref(hp), C.byref(sp), C.byref(m), C.byref(P) if P is not None else None,
+                                                dp(x), dp(fq), float(dt), dp(e), dp(a1), dp(a2) if a2 is not None else dp(a1),
+                                                dp(kr) if kr is not None else None)
         return x, int(it)
 
     def hmc_update_ssh(self, m, x, v, omega, omega4, mu, dtau, fa_M, t, alpha, alpha2, phonon_to_bond, cb_perm, dt, nt, nb,

@@ -645,6 +645,76 @@ def gen_special(h, tag, seed):
     save(f"special_{tag}.npz", **out)
 
 
+def gen_langevin_ssh(tag, seed, dt=0.02):
+    """One Langevin step of each scheme for the SSH model (alpha2 = 0: M(x) analytic) from the definitions — drift
+    dSb/dx - 2 d/dx [gᵀ M(x) v]_{v = M(x)⁻¹ g fixed}, dense M, exact solves, complex-step derivative."""
+    g = np.load(os.path.join(HERE, f"ssh_{tag}.npz"))
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    table, cbp = g["table"], g["cbperm"]
+    nbd = table.shape[0]
+    tb, alpha, mu, p2b = g["t"], g["alpha"], g["mu"], g["phonon_to_bond"]
+    Nph = p2b.shape[0]
+    n, nf = N * L, Nph * L
+    x0 = g["x"].copy()
+    omega = 0.5 + 0.05 * synth.randn(seed + 1, Nph)
+    omega4 = 0.05 * np.abs(synth.randn(seed + 2, Nph))
+    mreg = 0.7
+    k = np.arange(L)
+    faQ = (mreg ** 2 + dtau * omega[:, None] ** 2 + 4.0 / dtau) \
+        / (mreg ** 2 + dtau * omega[:, None] ** 2 + (2 - 2 * np.cos(2 * np.pi * k / L))[None, :] / dtau)
+    eta, g1, g2 = synth.randn(seed + 3, nf), synth.randn(seed + 4, n), synth.randn(seed + 5, n)
+    Emu = np.exp(dtau * mu)
+    cbidx = cbp[p2b - 1] - 1
+
+    def accel(vec, power):
+        return np.real(scipy.fft.ifft(faQ ** power * scipy.fft.fft(vec.reshape(Nph, L), axis=1), axis=1)).reshape(-1)
+
+    def dense_M_of(x):
+        X = x.reshape(Nph, L)
+        tp = np.empty((nbd, L), dtype=X.dtype)
+        tp[:] = tb[np.argsort(cbp)][:, None]
+        tp[cbidx] = tb[p2b - 1][:, None] - alpha[:, None] * X
+        M = np.eye(n, dtype=X.dtype)
+        for t in range(L):
+            c, s_ = np.cosh(dtau * tp[:, t]), np.sinh(dtau * tp[:, t])
+            CB = np.eye(N, dtype=X.dtype)
+            for b in range(nbd):
+                i, j = table[b, 0] - 1, table[b, 1] - 1
+                ri, rj = CB[i].copy(), CB[j].copy()
+                CB[i] = c[b] * ri + s_[b] * rj
+                CB[j] = c[b] * rj + s_[b] * ri
+            tm1 = (t - 1) % L
+            sign = 1.0 if t == 0 else -1.0
+            M[np.ix_(np.arange(N) * L + t, np.arange(N) * L + tm1)] += sign * (CB * Emu[None, :])
+        return M
+
+    def Sb(x):
+        X = x.reshape(Nph, L)
+        return dtau * np.sum(omega[:, None] ** 2 * X ** 2 / 2 + omega4[:, None] * X ** 4 + (X - np.roll(X, 1, axis=1)) ** 2 / dtau ** 2 / 2)
+
+    def grad(fun, x):
+        hstep, out = 1e-30, np.empty(nf)
+        for kk in range(nf):
+            xc = x.astype(complex)
+            xc[kk] += 1j * hstep
+            out[kk] = np.imag(fun(xc)) / hstep
+        return out
+
+    def drift(x, gvec):
+        v = np.linalg.solve(dense_M_of(x), gvec)
+        return grad(Sb, x) - 2.0 * grad(lambda z: gvec @ (dense_M_of(z) @ v), x)
+
+    F1 = drift(x0, g1)
+    x_euler = x0 + np.sqrt(2 * dt) * accel(eta, 0.5) - dt * accel(F1, 1.0)
+    xp = x0 + np.sqrt(2 * dt) * eta - dt * F1
+    x_rk = x0 + np.sqrt(2 * dt) * accel(eta, 0.5) - dt * accel((F1 + drift(xp, g2)) / 2, 1.0)
+    xi, G1 = accel(eta, 0.5), accel(F1, 1.0)
+    xh = x0 + np.sqrt(2 * dt) * xi - dt * G1
+    x_heun = x0 + np.sqrt(2 * dt) * xi - dt * (G1 + accel(drift(xh, g2), 1.0)) / 2
+    save(f"langevin_ssh_{tag}.npz", N=N, Ltau=L, dtau=dtau, Nph=Nph, omega=omega, omega4=omega4, faQ=faQ.reshape(-1), eta=eta, g1=g1,
+         g2=g2, dt=dt, F1=F1, x_euler=x_euler, x_rk=x_rk, x_heun=x_heun)
+
+
 # ----------------------------------------------------------------------------- Green's-function estimator
 def gen_greens(h, tag, norb, Lsp, seed, nv=3):
     """Stochastic Green's-function estimator (GreensFunctions.jl:201-288): the four translation-averaged products
@@ -696,6 +766,7 @@ if __name__ == "__main__":
     gen_ssh("sq4_L8_a", 4, 8, 0.05, seed=45, with_alpha2=False)        # alpha2 = 0: analytic in x (complex-step HMC golden)
     gen_hmc_ssh("sq4_L8_a", seed=67, nb=1)
     gen_hmc_ssh("sq4_L8_a", seed=67, nb=3)
+    gen_langevin_ssh("sq4_L8_a", seed=73)
     gen_fft()
     gen_kpm(h1, "sq4_L8")
     gen_hmc(h1, "sq4_L8", seed=66, nb=1)

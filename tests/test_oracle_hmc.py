@@ -209,3 +209,15 @@ def test_special_moves_match_dense_golden(oracle):
     acc, x1, info = oracle.special_move(om, h["x"], 0, 2, 0, g["Rp"], g["Rm"], 0.0, g["omega"], g["omega4"], h["lam"], h["lam2"], h["mu"], dtau,
                                         tol=1e-6, maxiter=2)
     assert not acc and info["flag"] > 0 and np.array_equal(x1, h["x"])
+
+
+@pytest.mark.parametrize("scheme,key", [(0, "x_euler"), (1, "x_rk"), (2, "x_heun")])
+def test_ssh_langevin_step_matches_dense_golden(oracle, scheme, key):
+    g, h = golden("langevin_ssh_sq4_L8_a.npz"), golden("ssh_sq4_L8_a.npz")
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    om = oracle.make_model(1, N, L, h["table"], np.ascontiguousarray(h["cosht"]).copy(), np.ascontiguousarray(h["sinht"]).copy(),
+                           np.ascontiguousarray(h["expDtauMu"]).copy())
+    ssh = dict(t=h["t"], alpha=h["alpha"], alpha2=h["alpha2"], phonon_to_bond=h["phonon_to_bond"], cb_perm=h["cbperm"])
+    x1, it = oracle.langevin_evolve_ssh(scheme, om, h["x"], g["faQ"], float(g["dt"]), g["eta"], g["g1"], g["g2"], g["omega"], g["omega4"],
+                                        h["mu"], dtau, ssh, tol=1e-10, maxiter=20000)
+    assert rel(x1 - h["x"], g[key] - h["x"]) < 1e-7
