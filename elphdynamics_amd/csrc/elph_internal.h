@@ -289,7 +289,7 @@ int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);
 int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS);
 int elph_launch_zero(elph_handle_s *h, double *p, int64_t n);
 int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau, int nch = 1);
-int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS);
+int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS, const double *US = nullptr);
 int elph_launch_dmdx_holstein(elph_handle_s *h, double *FS, const double *uS, const double *vS, const double *xS, double dtau,
                               double scale);
 int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau,

@@ -589,11 +589,18 @@ int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_h
     double res = 0.0;
     int fl = 0;
     RC(elph_i_ldiv_core(h, 1, use_precond ? 1 : 0, 0, &it, &res, &fl));
-    RC(elph_launch_dmdx_holstein(h, dS, st->R2, h->d_x, st->x, st->dtau, -2.0));   // -2 gᵀ(∂M/∂x)M⁻¹g, :381-384
-    const long long n = (long long)nd;
-    hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 1, 1,
-                       (const double *)h->d_lam);                               // calc_dSbdx!(dSdx, model, true), :341
-    RC(chk("k_hmc_dsb(shifted)"));
+    const long long n = (long long)st->nf * h->L;
+    if (st->ssh) {      // muldMdx!(dSfdx, g, ssh, M⁻¹g) (SSHModels.jl:707-829) with u = g given; no shifted term for bond phonons
+        RC(elph_launch_force_ssh(h, h->d_p, h->d_x, st->R2));
+        RC(elph_launch_ssh_scatter(h, dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -2.0));
+        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1, 1,
+                           (const double *)nullptr);
+    } else {
+        RC(elph_launch_dmdx_holstein(h, dS, st->R2, h->d_x, st->x, st->dtau, -2.0));   // -2 gᵀ(∂M/∂x)M⁻¹g, :381-384
+        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 1, 1,
+                           (const double *)h->d_lam);                           // calc_dSbdx!(dSdx, model, true), :341
+    }
+    RC(chk("k_hmc_dsb(langevin)"));
     *iters = it;
     *flag = fl;
     return ELPH_OK;
@@ -608,6 +615,13 @@ extern "C" int elph_langevin_create(elph_handle h, const double *omega, const do
     return elph_hmc_create_chains(h, 1, omega, omega4, lambda, lambda2, mu, dtau, fa_Q);
 }
 
+// The same for an SSH handle: the arguments of elph_hmc_create_ssh with fa_Q (per phonon) in place of the mass table.
+extern "C" int elph_langevin_create_ssh(elph_handle h, int64_t nph, const double *omega, const double *omega4, const int64_t *cb_index,
+                                        const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb,
+                                        const double *mu, double dtau, const double *fa_Q) {
+    return elph_hmc_create_ssh(h, nph, omega, omega4, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu, dtau, fa_Q);
+}
+
 // evolve!(model, dyn, fa, P): scheme 0 Euler, 1 Runge-Kutta, 2 Heun.  The random numbers the reference draws are inputs:
 // eta [Ndof] (randn!(η, model)), g1, g2 [Ndim] (the noise vectors of the first / second force estimate; g2 unused by Euler),
 // kpm_randn [2][2][nsites] (b_max, b_min of the first and second setup!(P); NULL without preconditioner).
@@ -617,15 +631,15 @@ extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int us
                                     const double *g2, const double *kpm_randn, int64_t *iters, int *flag) {
     CHECK_H(h);
     HmcState *st = state_of(h);
-    if (!st || st->ssh || st->nch != 1) { elph_set_error("elph_langevin_create has not been called on this (Holstein, single-chain) handle"); return ELPH_E_STATE; }
+    if (!st || st->nch != 1) { elph_set_error("elph_langevin_create[_ssh] has not been called on this handle"); return ELPH_E_STATE; }
     if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
     if (scheme < 0 || scheme > 2 || !(dt > 0.0) || !eta || !g1 || (scheme > 0 && !g2)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     RC(elph_i_ensure_capacity(h, 2));
-    RC(elph_i_reserve_chains(h, 1));
-    const size_t nd = (size_t)h->ndim, N = (size_t)h->N;
-    const long long n = (long long)nd;
+    if (!st->ssh) RC(elph_i_reserve_chains(h, 1));
+    const size_t N = (size_t)h->N;
+    const long long n = (long long)st->nf * h->L;            // field vectors (Holstein: = ndim)
     const double s2 = sqrt(2.0 * dt);
     const double *bm1 = kpm_randn, *bn1 = kpm_randn ? kpm_randn + N : nullptr;
     const double *bm2 = kpm_randn ? kpm_randn + 2 * N : nullptr, *bn2 = kpm_randn ? kpm_randn + 3 * N : nullptr;

@@ -838,7 +838,10 @@ __global__ void __launch_bounds__(1024) k_dmdx_holstein(double *__restrict__ F, 
 // (bonds of one colour are site-disjoint => one colour = one parallel step).  The kernel returns
 // q = q(X+) + q(X-); the caller multiplies by sg(tau) dtau dK_n/dx and scatters to the phonon fields.
 template <int NPL>
-__global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, const double *__restrict__ X, ModelDev m) {
+// U (optional): muldMdx!(·, u, ssh, v) for a GIVEN u (Langevin: u = g, v = X = M⁻¹g, one field): c₀ = CBᵀ U instead of CBᵀ(M X),
+// the second slab carries zeros.
+__global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, const double *__restrict__ X, ModelDev m,
+                                                    const double *__restrict__ U) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int N = m.N, L = m.L;
     double *bP = lds, *cP = lds + N, *bM = lds + 2 * N, *cM = lds + 3 * N;
@@ -853,8 +856,8 @@ __global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, cons
         const int s = threadIdx.x + k * blockDim.x;
         if (s < N) {
             const double e = m.E[s];
-            x0p[k] = X[(size_t)t * N + s]; x0m[k] = X[ndim + (size_t)t * N + s];
-            b0p[k] = e * X[(size_t)tm1 * N + s]; b0m[k] = e * X[ndim + (size_t)tm1 * N + s];
+            x0p[k] = X[(size_t)t * N + s]; x0m[k] = U ? 0.0 : X[ndim + (size_t)t * N + s];
+            b0p[k] = e * X[(size_t)tm1 * N + s]; b0m[k] = U ? 0.0 : e * X[ndim + (size_t)tm1 * N + s];
             cP[s] = b0p[k]; cM[s] = b0m[k];
         }
     }
@@ -864,7 +867,7 @@ __global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, cons
     for (int k = 0; k < NPL; ++k) {
         const int s = threadIdx.x + k * blockDim.x;
         if (s < N) {
-            cP[s] = x0p[k] - sg * cP[s];                                 // u = (M X)(tau)
+            cP[s] = U ? U[(size_t)t * N + s] : x0p[k] - sg * cP[s];      // u = (M X)(tau), or the caller's u
             cM[s] = x0m[k] - sg * cM[s];
             bP[s] = b0p[k]; bM[s] = b0m[k];
         }
@@ -1272,11 +1275,11 @@ int elph_launch_dmdx_holstein(elph_handle_s *h, double *FS, const double *uS, co
     return check_launch("k_dmdx_holstein");
 }
 
-int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS) {
+int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS, const double *US) {
     ModelDev m = elph_model_dev(h);
     const size_t shm = 4 * (size_t)h->N * sizeof(double);
     DISPATCH_NPL(gen_npl(h), {
-        hipLaunchKernelGGL((k_force_ssh<NPL>), dim3((unsigned)h->L), dim3((unsigned)gen_bs(h)), shm, h->stream, q, XS, m);
+        hipLaunchKernelGGL((k_force_ssh<NPL>), dim3((unsigned)h->L), dim3((unsigned)gen_bs(h)), shm, h->stream, q, XS, m, US);
     });
     return check_launch("k_force_ssh");
 }

@@ -21,13 +21,23 @@ class _Dynamics:
     scheme = None
 
     def __init__(self, model, fa, dt):
-        if model.kind != models.HOLSTEIN:
-            raise NotImplementedError("device-resident Langevin step: Holstein models")
         self.model, self.fa, self.dt = model, fa, float(dt)
         self.Ndof, self.Ndim = model.Ndof, model.Ndim
         self.flag = 0
-        check(model._lib.elph_langevin_create(model._h, dptr(model.omega), dptr(model.omega4), dptr(model.lam), dptr(model.lam2),
-                                              dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
+        if model.kind == models.SSH:
+            from ._lib import iptr
+            if getattr(model, "omega4", None) is None:
+                model.omega4 = np.zeros(model.Nph)
+            cb_index = np.ascontiguousarray(model.checkerboard_perm[model.phonon_to_bond - 1], dtype=np.int64)
+            t_ph = np.ascontiguousarray(model.t[model.phonon_to_bond - 1], dtype=np.float64)
+            check(model._lib.elph_langevin_create_ssh(
+                model._h, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
+                dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)), dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb),
+                dptr(np.ascontiguousarray(model.mu)), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
+            model._cs_stale = True
+        else:
+            check(model._lib.elph_langevin_create(model._h, dptr(model.omega), dptr(model.omega4), dptr(model.lam), dptr(model.lam2),
+                                                  dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
         model._nchains = 1
         self.push_()
 
@@ -68,6 +78,8 @@ def evolve_(model, dyn, fa=None, P=None, rng=None, randoms=None, pull=True):
     check(model._lib.elph_langevin_evolve(model._h, dyn.scheme, dyn.dt, 0 if P is None else 1, c(randoms["eta"]), c(randoms["g1"]),
                                           c(randoms.get("g2")), c(randoms.get("kpm_randn")), C.byref(it), C.byref(fl)))
     dyn.flag = int(fl.value)
+    if model.kind == models.SSH:
+        model._cs_stale = True
     if pull:
         dyn.pull_()
     return int(it.value)

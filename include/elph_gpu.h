@@ -301,6 +301,11 @@ int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int64_t col_j,
  * the last ldiv! flag (the reference ignores it). */
 int elph_langevin_create(elph_handle h, const double *omega, const double *omega4, const double *lambda, const double *lambda2,
                          const double *mu, double dtau, const double *fa_Q);
+/* SSH handles (examples/ssh_langevin_square.toml): the arguments of elph_hmc_create_ssh with fa_Q per phonon; eta has
+ * nph·Lτ entries, calc_dSfdx! uses muldMdx! of SSHModels.jl:707-829 with u = g, and the shifted flag changes nothing. */
+int elph_langevin_create_ssh(elph_handle h, int64_t nph, const double *omega, const double *omega4, const int64_t *cb_index,
+                             const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu,
+                             double dtau, const double *fa_Q);
 int elph_langevin_evolve(elph_handle h, int scheme, double dt, int use_precond, const double *eta, const double *g1, const double *g2,
                          const double *kpm_randn, int64_t *iters, int *flag);
 

@@ -68,6 +68,55 @@ def test_langevin_step_vs_oracle(oracle, tag, scheme, with_kpm):
     m.close()
 
 
+@pytest.mark.parametrize("cls,key", [("EulerDynamics", "x_euler"), ("RungeKuttaDynamics", "x_rk"), ("HeunsDynamics", "x_heun")])
+def test_ssh_langevin_step_matches_dense_golden(cls, key):
+    """Bond-phonon Langevin step (examples/ssh_langevin_square.toml geometry at 4x4): device vs the dense golden."""
+    from elphdynamics_amd import langevin, lattice as lat, models, preconditioners as pc
+    g, hg = golden("langevin_ssh_sq4_L8_a.npz"), golden("ssh_sq4_L8_a.npz")
+    la = lat.Lattice(1, 4, 4, 1)
+    L, dtau = int(g["Ltau"]), float(g["dtau"])
+    m = models.SSHModel(la, L * dtau, dtau, tol=1e-10, maxiter=20000)
+    for (o1, o2, d) in lat.SQUARE_BONDS:
+        m.assign_hopping_(1.0, 0.1, 0.0, 0.5, o1, o2, d)
+    m.initialize_model_()
+    m.alpha[:], m.alpha2[:], m.mu[:] = hg["alpha"], hg["alpha2"], hg["mu"]
+    m.omega, m.omega4 = np.array(g["omega"]), np.array(g["omega4"])
+    m.x[:] = hg["x"]
+    models.update_model_(m)
+    fa = pc.FourierAccelerator(m)
+    fa.Q[:] = g["faQ"]
+    dyn = getattr(langevin, cls)(m, fa, float(g["dt"]))
+    it = langevin.evolve_(m, dyn, fa, None, randoms=dict(eta=g["eta"], g1=g["g1"], g2=g["g2"], kpm_randn=None))
+    assert dyn.flag == 0 and it > 0
+    assert rel(m.x - hg["x"], g[key] - hg["x"]) < 1e-7
+    m.close()
+
+
+def test_ssh_langevin_step_vs_oracle_at_config_E(oracle):
+    """Config E (optical SSH square L = 16, Ltau = 160) with alpha2 != 0 and the KPM preconditioner: Heun step vs the oracle."""
+    from elphdynamics_amd import configs, langevin, models, preconditioners as pc, synth
+    m = configs.make_model("E", tol=1e-8, maxiter=20000)
+    m.alpha2[:] = 0.01
+    m.omega4 = np.full(m.Nph, 0.02)
+    models.update_model_(m)
+    fa = pc.FourierAccelerator(m)
+    pc.update_Q_(fa, m, 0.0, np.inf, 0.7)
+    om = oracle.make_model(1, m.Nsites, m.Ltau, m.neighbor_table, np.ascontiguousarray(m.cosht).reshape(-1).copy(),
+                           np.ascontiguousarray(m.sinht).reshape(-1).copy(), np.exp(m.dtau * m.mu))
+    Po = oracle.make_kpm(om, n=20)
+    P = pc.SymmetricKPMPreconditioner(m, n=20, buf=0.05, c1=1.0, c2=1.0)
+    dyn = langevin.HeunsDynamics(m, fa, 0.01)
+    rnd = dict(eta=synth.randn(2000, m.Ndof), g1=synth.randn(2100, m.Ndim), g2=synth.randn(2200, m.Ndim), kpm_randn=synth.randn(2300, 4 * m.Nsites))
+    x_in = m.x.copy()
+    ssh = dict(t=m.t, alpha=m.alpha, alpha2=m.alpha2, phonon_to_bond=m.phonon_to_bond, cb_perm=m.checkerboard_perm)
+    x_o, it_o = oracle.langevin_evolve_ssh(2, om, x_in, fa.Q, 0.01, rnd["eta"], rnd["g1"], rnd["g2"], m.omega, m.omega4, m.mu, m.dtau, ssh,
+                                           P=Po, kpm_randn=rnd["kpm_randn"], tol=1e-8, maxiter=20000)
+    it = langevin.evolve_(m, dyn, fa, P, randoms=rnd)
+    assert dyn.flag == 0 and abs(it - it_o) <= 1
+    assert rel(m.x - x_in, x_o - x_in) < 1e-6
+    m.close()
+
+
 def test_langevin_error_paths():
     from elphdynamics_amd import _lib, configs
     m = configs.make_model("b")
@@ -75,7 +124,7 @@ def test_langevin_error_paths():
     z = np.zeros(m.Ndim)
     assert lib.elph_langevin_evolve(m._h, 0, 0.01, 0, _lib.dptr(z), _lib.dptr(z), None, None, None, None) == _lib.ELPH_E_STATE
     m.close()
-    e = configs.make_model("e")
+    e = configs.make_model("e")     # the Holstein entry point refuses an SSH handle
     assert e._lib.elph_langevin_create(e._h, _lib.dptr(np.zeros(e.Nsites)), _lib.dptr(np.zeros(e.Nsites)), _lib.dptr(np.zeros(e.Nsites)),
                                        _lib.dptr(np.zeros(e.Nsites)), _lib.dptr(np.zeros(e.Nsites)), 0.05,
                                        _lib.dptr(np.zeros(e.Ndim))) == _lib.ELPH_E_UNSUPPORTED
