@@ -70,6 +70,7 @@ SIGNATURES = {
     "elph_hmc_special_move": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl, P_dbl, c_int, P_dbl, c_dbl, P_int, P_dbl, P_dbl, P_i64, P_int]),
     "elph_langevin_create": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
     "elph_langevin_create_ssh": (c_int, [Handle, c_i64, P_dbl, P_dbl, P_i64, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
+    "elph_langevin_create_chains": (c_int, [Handle, c_int, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
     "elph_langevin_evolve": (c_int, [Handle, c_int, c_dbl, c_int, P_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
     "elph_greens_create": (c_int, [Handle, c_int, c_int, c_int, c_int, c_int]),
     "elph_greens_nv": (c_int, [Handle, P_int]),

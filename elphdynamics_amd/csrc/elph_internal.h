@@ -291,7 +291,7 @@ int elph_launch_zero(elph_handle_s *h, double *p, int64_t n);
 int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau, int nch = 1);
 int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS, const double *US = nullptr);
 int elph_launch_dmdx_holstein(elph_handle_s *h, double *FS, const double *uS, const double *vS, const double *xS, double dtau,
-                              double scale);
+                              double scale, int nch = 1);
 int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau,
                                int nch = 1);
 

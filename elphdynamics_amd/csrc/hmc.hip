@@ -577,32 +577,29 @@ int axpby(elph_handle_s *h, double *out, double a, const double *x, double b, co
     return chk("k_lv_axpby");
 }
 
-// dS (layout S) = calc_dSdx!(x; g); returns the iteration count of the solve
+// dS (layout S) = calc_dSdx!(x; g) for every chain (g: [nch][Ndim] on the host); per-chain iteration counts and flags
 int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_host, int use_precond, const double *bmax,
                    const double *bmin, int64_t *iters, int *flag) {
     const size_t nd = (size_t)h->ndim;
-    RC(upload_vectors(h, st->R2, g_host, 1));                                   // g in layout S
+    const int nch = st->nch;
+    RC(upload_vectors(h, st->R2, g_host, nch));                                 // g in layout S
     if (use_precond) RC(elph_kpm_setup_chains(h, bmax, bmin, nullptr, nullptr, nullptr, nullptr, nullptr));   // setup!(P), :366
-    RC(elph_launch_mul(h, 1, h->d_b, st->R2, 1));                               // Mᵀg (model.v″, :378)
-    HIPCHK(hipMemsetAsync(h->d_x, 0, nd * sizeof(double), h->stream));          // fill!(M⁻¹g, 0), :367
-    int64_t it = 0;
-    double res = 0.0;
-    int fl = 0;
-    RC(elph_i_ldiv_core(h, 1, use_precond ? 1 : 0, 0, &it, &res, &fl));
-    const long long n = (long long)st->nf * h->L;
+    RC(elph_launch_mul(h, 1, h->d_b, st->R2, nch));                             // Mᵀg (model.v″, :378)
+    HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nch * nd * sizeof(double), h->stream));   // fill!(M⁻¹g, 0), :367
+    std::vector<double> res((size_t)nch);
+    RC(elph_i_ldiv_core(h, nch, use_precond ? 1 : 0, 0, iters, res.data(), flag));
+    const long long n = (long long)st->nf * h->L * nch;
     if (st->ssh) {      // muldMdx!(dSfdx, g, ssh, M⁻¹g) (SSHModels.jl:707-829) with u = g given; no shifted term for bond phonons
         RC(elph_launch_force_ssh(h, h->d_p, h->d_x, st->R2));
         RC(elph_launch_ssh_scatter(h, dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -2.0));
         hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1, 1,
                            (const double *)nullptr);
     } else {
-        RC(elph_launch_dmdx_holstein(h, dS, st->R2, h->d_x, st->x, st->dtau, -2.0));   // -2 gᵀ(∂M/∂x)M⁻¹g, :381-384
-        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 1, 1,
+        RC(elph_launch_dmdx_holstein(h, dS, st->R2, h->d_x, st->x, st->dtau, -2.0, nch));   // -2 gᵀ(∂M/∂x)M⁻¹g, :381-384
+        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, (int)h->N, (int)h->L, st->dtau, 1, nch,
                            (const double *)h->d_lam);                           // calc_dSbdx!(dSdx, model, true), :341
     }
     RC(chk("k_hmc_dsb(langevin)"));
-    *iters = it;
-    *flag = fl;
     return ELPH_OK;
 }
 
@@ -613,6 +610,14 @@ int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_h
 extern "C" int elph_langevin_create(elph_handle h, const double *omega, const double *omega4, const double *lambda,
                                     const double *lambda2, const double *mu, double dtau, const double *fa_Q) {
     return elph_hmc_create_chains(h, 1, omega, omega4, lambda, lambda2, mu, dtau, fa_Q);
+}
+
+// nchains independent Langevin trajectories of one deck in lockstep (every step one batched solve of nchains right-hand sides,
+// one KPM expansion per chain); state and random vectors are chain-major: x, eta [nchains*Ndof], g1, g2 [nchains*Ndim],
+// kpm_randn [2 set-ups][b_max|b_min][nchains][nsites]; iters, flag [nchains].
+extern "C" int elph_langevin_create_chains(elph_handle h, int nchains, const double *omega, const double *omega4, const double *lambda,
+                                           const double *lambda2, const double *mu, double dtau, const double *fa_Q) {
+    return elph_hmc_create_chains(h, nchains, omega, omega4, lambda, lambda2, mu, dtau, fa_Q);
 }
 
 // The same for an SSH handle: the arguments of elph_hmc_create_ssh with fa_Q (per phonon) in place of the mass table.
@@ -631,34 +636,36 @@ extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int us
                                     const double *g2, const double *kpm_randn, int64_t *iters, int *flag) {
     CHECK_H(h);
     HmcState *st = state_of(h);
-    if (!st || st->nch != 1) { elph_set_error("elph_langevin_create[_ssh] has not been called on this handle"); return ELPH_E_STATE; }
+    if (!st) { elph_set_error("elph_langevin_create[_ssh|_chains] has not been called on this handle"); return ELPH_E_STATE; }
     if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
     if (scheme < 0 || scheme > 2 || !(dt > 0.0) || !eta || !g1 || (scheme > 0 && !g2)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
-    RC(elph_i_ensure_capacity(h, 2));
-    if (!st->ssh) RC(elph_i_reserve_chains(h, 1));
+    const int nch = st->nch;
+    RC(elph_i_ensure_capacity(h, std::max(2, 2 * nch)));
+    if (!st->ssh) RC(elph_i_reserve_chains(h, nch));
     const size_t N = (size_t)h->N;
-    const long long n = (long long)st->nf * h->L;            // field vectors (Holstein: = ndim)
+    const long long n = (long long)st->nf * h->L * nch;      // field vectors of all chains (Holstein: nch * ndim)
     const double s2 = sqrt(2.0 * dt);
-    const double *bm1 = kpm_randn, *bn1 = kpm_randn ? kpm_randn + N : nullptr;
-    const double *bm2 = kpm_randn ? kpm_randn + 2 * N : nullptr, *bn2 = kpm_randn ? kpm_randn + 3 * N : nullptr;
+    // start vectors of the two set-ups: [set-up][b_max | b_min][chain][N]
+    const double *bm1 = kpm_randn, *bn1 = kpm_randn ? kpm_randn + (size_t)nch * N : nullptr;
+    const double *bm2 = kpm_randn ? kpm_randn + 2 * (size_t)nch * N : nullptr, *bn2 = kpm_randn ? kpm_randn + 3 * (size_t)nch * N : nullptr;
     double *F1 = st->dS, *F2 = st->y, *xi = st->v, *dx = st->v0;      // the momentum buffers are free: Langevin has none
-    int64_t it1 = 0, it2 = 0;
-    int fl = 0;
+    std::vector<int64_t> it1((size_t)nch, 0), it2((size_t)nch, 0);
+    std::vector<int> fl((size_t)nch, 0);
     RC(update_model(h, st));
-    RC(upload_vectors(h, xi, eta, 1, st->nf));
+    RC(upload_vectors(h, xi, eta, nch, st->nf));
     if (scheme == 0) {
-        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, &it1, &fl));
+        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, it1.data(), fl.data()));
         RC(fa(h, st, F1, F1, 1.0));
         RC(fa(h, st, xi, xi, 0.5));
         RC(axpby(h, st->x, 1.0, st->x, s2, xi, -dt, F1, n));                       // x += √(2Δt) Q^½η − Δt Q dS/dx
     } else if (scheme == 1) {
-        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, &it1, &fl));
+        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, it1.data(), fl.data()));
         RC(axpby(h, dx, s2, xi, -dt, F1, 0.0, nullptr, n));                        // Δx = √(2Δt) η − Δt dS/dx   (no acceleration)
         RC(axpby(h, st->x, 1.0, st->x, 1.0, dx, 0.0, nullptr, n));
         RC(update_model(h, st));
-        RC(langevin_force(h, st, F2, g2, use_precond, bm2, bn2, &it2, &fl));
+        RC(langevin_force(h, st, F2, g2, use_precond, bm2, bn2, it2.data(), fl.data()));
         RC(axpby(h, st->x, 1.0, st->x, -1.0, dx, 0.0, nullptr, n));                // x = x′ − Δx
         RC(axpby(h, F1, 0.5, F2, 0.5, F1, 0.0, nullptr, n));                       // (dSdx′ + dSdx)/2
         RC(fa(h, st, F1, F1, 1.0));
@@ -667,22 +674,24 @@ extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int us
         it1 = it2;
     } else {
         RC(fa(h, st, xi, xi, 0.5));                                                // ξ = Q^½η
-        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, &it1, &fl));
+        RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, it1.data(), fl.data()));
         RC(fa(h, st, F1, F1, 1.0));                                                // dΓ/dx
         RC(axpby(h, dx, s2, xi, -dt, F1, 0.0, nullptr, n));
         RC(axpby(h, st->x, 1.0, st->x, 1.0, dx, 0.0, nullptr, n));
         RC(update_model(h, st));
-        RC(langevin_force(h, st, F2, g2, use_precond, bm2, bn2, &it2, &fl));
+        RC(langevin_force(h, st, F2, g2, use_precond, bm2, bn2, it2.data(), fl.data()));
         RC(fa(h, st, F2, F2, 1.0));
         RC(axpby(h, st->x, 1.0, st->x, -1.0, dx, 0.0, nullptr, n));                // x = x′ − Δx
         RC(axpby(h, F1, 0.5, F1, 0.5, F2, 0.0, nullptr, n));                       // (dΓ + dΓ′)/2
         RC(axpby(h, st->x, 1.0, st->x, s2, xi, -dt, F1, n));
-        it1 = (it1 + it2) / 2;
+        for (int c = 0; c < nch; ++c) it1[(size_t)c] = (it1[(size_t)c] + it2[(size_t)c]) / 2;
     }
     RC(update_model(h, st));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (iters) *iters = it1;
-    if (flag) *flag = fl;
+    for (int c = 0; c < nch; ++c) {
+        if (iters) iters[c] = it1[(size_t)c];
+        if (flag) flag[c] = fl[(size_t)c];
+    }
     return ELPH_OK;
 }
 

@@ -808,11 +808,13 @@ __global__ void __launch_bounds__(1024) k_dmdx_holstein(double *__restrict__ F, 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *buf = lds;
     const int N = m.N, L = m.L;
-    const int t = blockIdx.x;
+    const int t = blockIdx.x, ch = blockIdx.y;                            // blockIdx.y = chain: all vectors are [chain][ndim]
+    const size_t co = (size_t)ch * (size_t)N * L;
+    F += co; u += co; v += co; xS += co;
     const int tm1 = (t == 0) ? L - 1 : t - 1;
     const double sg = (t == 0) ? -1.0 : 1.0;
     const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
-    const double *E0 = m.E + (size_t)t * m.E_tau_stride;
+    const double *E0 = m.E + (size_t)(ch % m.nchains) * m.E_chain_stride + (size_t)t * m.E_tau_stride;
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * blockDim.x;
@@ -1265,11 +1267,11 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
 }
 
 int elph_launch_dmdx_holstein(elph_handle_s *h, double *FS, const double *uS, const double *vS, const double *xS, double dtau,
-                              double scale) {
+                              double scale, int nch) {
     ModelDev m = elph_model_dev(h);
     const size_t shm = 2 * (size_t)h->N * sizeof(double);
     DISPATCH_NPL(gen_npl(h), {
-        hipLaunchKernelGGL((k_dmdx_holstein<NPL>), dim3((unsigned)h->L), dim3((unsigned)gen_bs(h)), shm, h->stream, FS, uS, vS, xS,
+        hipLaunchKernelGGL((k_dmdx_holstein<NPL>), dim3((unsigned)h->L, (unsigned)nch), dim3((unsigned)gen_bs(h)), shm, h->stream, FS, uS, vS, xS,
                            h->d_lam, m, dtau, scale);
     });
     return check_launch("k_dmdx_holstein");

@@ -20,10 +20,18 @@ EULER, RUNGE_KUTTA, HEUN = 0, 1, 2
 class _Dynamics:
     scheme = None
 
-    def __init__(self, model, fa, dt):
+    def __init__(self, model, fa, dt, nchains=1):
+        """nchains > 1 (Holstein): that many independent trajectories of the same deck advance in lockstep on this handle
+        (every step one batched solve of nchains right-hand sides, one KPM expansion per chain); their fields are
+        self.X (nchains, Ndof) and model.x is not used."""
         self.model, self.fa, self.dt = model, fa, float(dt)
         self.Ndof, self.Ndim = model.Ndof, model.Ndim
         self.flag = 0
+        self.nchains = int(nchains)
+        if self.nchains < 1 or (self.nchains > 1 and model.kind != models.HOLSTEIN):
+            raise ValueError("chains in lockstep are built for the Holstein model")
+        self.X = np.tile(model.x, (self.nchains, 1)) if self.nchains > 1 else None
+        self.flags = np.zeros(self.nchains, dtype=np.int32)
         if model.kind == models.SSH:
             from ._lib import iptr
             if getattr(model, "omega4", None) is None:
@@ -35,17 +43,23 @@ class _Dynamics:
                 dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)), dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb),
                 dptr(np.ascontiguousarray(model.mu)), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
             model._cs_stale = True
+        elif self.nchains > 1:
+            check(model._lib.elph_langevin_create_chains(model._h, self.nchains, dptr(model.omega), dptr(model.omega4), dptr(model.lam),
+                                                         dptr(model.lam2), dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
         else:
             check(model._lib.elph_langevin_create(model._h, dptr(model.omega), dptr(model.omega4), dptr(model.lam), dptr(model.lam2),
                                                   dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
-        model._nchains = 1
+        model._nchains = self.nchains
         self.push_()
 
+    def _field(self):
+        return self.X if self.nchains > 1 else self.model.x
+
     def push_(self):
-        check(self.model._lib.elph_hmc_set_state(self.model._h, dptr(np.ascontiguousarray(self.model.x)), None))
+        check(self.model._lib.elph_hmc_set_state(self.model._h, dptr(np.ascontiguousarray(self._field()).reshape(-1)), None))
 
     def pull_(self):
-        check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self.model.x), None))
+        check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self._field().reshape(-1)), None))
 
 
 class EulerDynamics(_Dynamics):
@@ -61,25 +75,29 @@ class HeunsDynamics(_Dynamics):
 
 
 def draw_randoms(dyn, rng, with_kpm):
-    m = dyn.model
-    out = dict(eta=rng.standard_normal(m.Ndof), g1=rng.standard_normal(m.Ndim))
-    out["g2"] = rng.standard_normal(m.Ndim) if dyn.scheme != EULER else None
-    out["kpm_randn"] = rng.standard_normal((2, 2, m.Nsites)) if with_kpm else None
+    m, nch = dyn.model, dyn.nchains
+    out = dict(eta=rng.standard_normal((nch, m.Ndof)), g1=rng.standard_normal((nch, m.Ndim)))
+    out["g2"] = rng.standard_normal((nch, m.Ndim)) if dyn.scheme != EULER else None
+    out["kpm_randn"] = rng.standard_normal((2, 2, nch, m.Nsites)) if with_kpm else None     # [set-up][b_max|b_min][chain][site]
     return out
 
 
 def evolve_(model, dyn, fa=None, P=None, rng=None, randoms=None, pull=True):
-    """evolve!(model, dyn, fa, preconditioner) -> iters: one Langevin step, entirely on the device."""
+    """evolve!(model, dyn, fa, preconditioner) -> iters: one Langevin step, entirely on the device.  With dyn.nchains > 1 the
+    random vectors are chain-major (see draw_randoms) and the return value is iters[nchains]; dyn.flags holds the solver flag
+    of every chain."""
     if randoms is None:
         randoms = draw_randoms(dyn, rng or np.random.default_rng(), P is not None)
     model._push_solver()
-    it, fl = C.c_int64(), C.c_int()
+    nch = dyn.nchains
+    it, fl = (C.c_int64 * nch)(), (C.c_int * nch)()
     c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1)) if a is not None else None
     check(model._lib.elph_langevin_evolve(model._h, dyn.scheme, dyn.dt, 0 if P is None else 1, c(randoms["eta"]), c(randoms["g1"]),
-                                          c(randoms.get("g2")), c(randoms.get("kpm_randn")), C.byref(it), C.byref(fl)))
-    dyn.flag = int(fl.value)
+                                          c(randoms.get("g2")), c(randoms.get("kpm_randn")), it, fl))
+    dyn.flags = np.array(fl[:], dtype=np.int32)
+    dyn.flag = int(dyn.flags.max())
     if model.kind == models.SSH:
         model._cs_stale = True
     if pull:
         dyn.pull_()
-    return int(it.value)
+    return int(it[0]) if nch == 1 else np.array(it[:], dtype=np.int64)

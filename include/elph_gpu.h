@@ -306,6 +306,12 @@ int elph_langevin_create(elph_handle h, const double *omega, const double *omega
 int elph_langevin_create_ssh(elph_handle h, int64_t nph, const double *omega, const double *omega4, const int64_t *cb_index,
                              const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu,
                              double dtau, const double *fa_Q);
+/* nchains independent Langevin trajectories of one (Holstein) deck in lockstep: every step is one batched solve of nchains
+ * right-hand sides with one KPM expansion per chain.  State and random vectors are chain-major (x, eta: [nchains·Ndof];
+ * g1, g2: [nchains·Ndim]; kpm_randn: [2 set-ups][b_max | b_min][nchains][nsites]); elph_langevin_evolve then returns
+ * iters and flag per chain ([nchains]). */
+int elph_langevin_create_chains(elph_handle h, int nchains, const double *omega, const double *omega4, const double *lambda,
+                                const double *lambda2, const double *mu, double dtau, const double *fa_Q);
 int elph_langevin_evolve(elph_handle h, int scheme, double dt, int use_precond, const double *eta, const double *g1, const double *g2,
                          const double *kpm_randn, int64_t *iters, int *flag);
 

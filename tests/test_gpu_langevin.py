@@ -129,3 +129,57 @@ def test_langevin_error_paths():
                                        _lib.dptr(np.zeros(e.Nsites)), _lib.dptr(np.zeros(e.Nsites)), 0.05,
                                        _lib.dptr(np.zeros(e.Ndim))) == _lib.ELPH_E_UNSUPPORTED
     e.close()
+
+
+@pytest.mark.parametrize("tag,scheme,with_kpm", [("b", 0, False), ("d", 1, True), ("B", 2, True)])
+def test_langevin_chains_match_single_trajectories(tag, scheme, with_kpm):
+    """nchains trajectories in lockstep (one batched solve per force, one KPM expansion per chain) == each trajectory run alone
+    with its own random numbers; two steps so that the fields differ between chains at the second."""
+    from elphdynamics_amd import configs, langevin, preconditioners as pc, synth
+    nch = 3
+    cls = [langevin.EulerDynamics, langevin.RungeKuttaDynamics, langevin.HeunsDynamics][scheme]
+
+    def make():
+        m = configs.make_model(tag, tol=1e-9, maxiter=20000)
+        m.omega4[:] = 0.02
+        fa = pc.FourierAccelerator(m)
+        pc.update_Q_(fa, m, 0.0, np.inf, 0.7)
+        P = pc.SymmetricKPMPreconditioner(m, n=min(20, m.Nsites), buf=0.05, c1=1.0, c2=1.0) if with_kpm else None
+        return m, fa, P
+
+    def rnd(step, c, m):
+        return dict(eta=synth.randn(3000 + 10 * step + c, m.Ndof), g1=synth.randn(3100 + 10 * step + c, m.Ndim),
+                    g2=synth.randn(3200 + 10 * step + c, m.Ndim), kpm_randn=synth.randn(3300 + 10 * step + c, 4 * m.Nsites))
+
+    m, fa, P = make()
+    x0 = m.x.copy()
+    singles, its = [], []
+    for c in range(nch):
+        m.x[:] = x0 + 0.05 * synth.randn(3400 + c, m.Ndof)
+        dyn = cls(m, fa, 0.01)
+        it_c = []
+        for step in range(2):
+            r = rnd(step, c, m)
+            if not with_kpm:
+                r["kpm_randn"] = None
+            it_c.append(langevin.evolve_(m, dyn, fa, P, randoms=r))
+            assert dyn.flag == 0
+        singles.append(m.x.copy())
+        its.append(it_c)
+    m.close()
+
+    m, fa, P = make()
+    dyn = cls(m, fa, 0.01, nchains=nch)
+    for c in range(nch):
+        dyn.X[c] = x0 + 0.05 * synth.randn(3400 + c, m.Ndof)
+    dyn.push_()
+    for step in range(2):
+        rs = [rnd(step, c, m) for c in range(nch)]
+        kr = np.stack([r["kpm_randn"].reshape(2, 2, m.Nsites) for r in rs], axis=2) if with_kpm else None   # [2][2][chain][site]
+        it = langevin.evolve_(m, dyn, fa, P, randoms=dict(eta=np.stack([r["eta"] for r in rs]), g1=np.stack([r["g1"] for r in rs]),
+                                                          g2=np.stack([r["g2"] for r in rs]), kpm_randn=kr))
+        assert (dyn.flags == 0).all()
+        assert np.all(np.abs(it - np.array([its[c][step] for c in range(nch)])) <= 1)
+    for c in range(nch):
+        assert rel(dyn.X[c] - x0, singles[c] - x0) < 1e-7
+    m.close()
