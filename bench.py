@@ -288,15 +288,16 @@ def main():
                         Hh.X[:] = np.stack([synth.phonon_field(mh.Nph, mh.Ltau, mh.beta, mh.dtau, seed=100 + 17 * c) for c in range(nch_h)])
                         Hh.push_()
                     Ph = pc.SymmetricKPMPreconditioner(mh, 20, 0.05, 1.0, 1.0)
-                    rngh = np.random.default_rng(3)
-                    upd = (lambda: ehmc.update_chains_(mh, Hh, fah, Ph, rng=rngh)) if nch_h > 1 else (lambda: ehmc.update_(mh, Hh, fah, Ph, rng=rngh, pull=False))
+                    Hh.device_rng_(3)      # random inputs drawn inside the library (on the GPU), as a production run would
+                    upd = (lambda: ehmc.update_chains_(mh, Hh, fah, Ph)) if nch_h > 1 else (lambda: ehmc.update_(mh, Hh, fah, Ph, pull=False))
                     upd()
                     tq = time.perf_counter()
                     acc_h, its_h = upd()
                     dth = time.perf_counter() - tq
                     hm[f"gpu_chains{nch_h}"] = {"nt": nt_g, "ms_per_update": 1e3 * dth, "ms_per_chain_update": 1e3 * dth / nch_h,
                                                "chain_evaluations_per_sec": nch_h * (nt_g + 2) / dth,
-                                               "iters_per_solve": float(np.mean(its_h)), "accepted": float(np.mean(acc_h))}
+                                               "iters_per_solve": float(np.mean(its_h)), "accepted": float(np.mean(acc_h)),
+                                               "random_numbers": "library generator (elph_hmc_set_rng)"}
                     mh.close()
                 if not args.no_cpu:
                     from oracle.oracle import Oracle

@@ -37,7 +37,42 @@ struct HmcState {
     double *part = nullptr;      // [2 nch][L] partial sums
     double dtau = 0.0;
     bool have_state = false;
+    // optional generator for the random inputs the caller leaves NULL (elph_hmc_set_rng)
+    bool rng_on = false;
+    uint64_t rng_seed = 0, rng_batches = 0;
 };
+
+// The build's counter-based generator (elphdynamics_amd/synth.py): SplitMix64 -> uniform(0,1) -> Box-Muller.  Element i of a
+// batch of n normals uses uniforms i/2 and ceil(n/2) + i/2; even i takes the cosine, odd i the sine.
+__host__ __device__ inline uint64_t sm64(uint64_t seed, uint64_t idx1) {
+    uint64_t z = seed + idx1 * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline double u01(uint64_t seed, uint64_t i) {
+    return ((double)(sm64(seed, i + 1) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// nvec vectors of ncols*L standard normals, written in layout S ([vec][tau][col]); the batch is numbered in the reference
+// layout ([vec][col][tau]) so that it equals synth.randn(seed, nvec*ncols*L) handed over by the host
+__global__ void __launch_bounds__(TPB) k_randn_S(double *__restrict__ dst, uint64_t seed, long long n, int ncols, int L) {
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;        // pair index
+    const long long m = (n + 1) / 2;
+    if (k >= m) return;
+    const double r = sqrt(-2.0 * log(u01(seed, (uint64_t)k)));
+    double sn, cs;
+    sincos(6.283185307179586476925 * u01(seed, (uint64_t)(m + k)), &sn, &cs);
+    const long long per = (long long)ncols * L;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const long long i = 2 * k + e;
+        if (i >= n) break;
+        const long long vec = i / per, w = i - vec * per;
+        const int col = (int)(w / L), t = (int)(w - (long long)col * L);
+        dst[vec * per + (long long)t * ncols + col] = r * (e ? sn : cs);
+    }
+}
 
 // E(τ,s) = exp(-Δτ (λ x + λ₂ x² - μ)), x already in layout S  (update_model!, HolsteinModels.jl:526-549)
 __global__ void __launch_bounds__(TPB) k_hmc_expV(double *__restrict__ E, const double *__restrict__ x,
@@ -303,6 +338,40 @@ int upload_vectors(elph_handle_s *h, double *dstS, const double *host, int nvec,
 
 HmcState *state_of(elph_handle_s *h) { return static_cast<HmcState *>(h->hmc); }
 
+// seed of the next batch: output number (batches drawn so far + 1) of SplitMix64 started at the handle's seed
+uint64_t next_batch_seed(HmcState *st) { return sm64(st->rng_seed, ++st->rng_batches); }
+
+// a random input vector set: uploaded when the caller gives it, otherwise drawn on the device (no PCIe, no host generator)
+int randn_vectors(elph_handle_s *h, HmcState *st, double *dstS, const double *host, int nvec, int ncols = 0) {
+    if (host) return upload_vectors(h, dstS, host, nvec, ncols);
+    if (!st->rng_on) { elph_set_error("a random input is NULL and elph_hmc_set_rng has not been called"); return ELPH_E_ARG; }
+    const int nc = ncols > 0 ? ncols : (int)h->N;
+    const long long n = (long long)nvec * nc * h->L;
+    hipLaunchKernelGGL(k_randn_S, dim3(nblk((n + 1) / 2)), dim3(TPB), 0, h->stream, dstS, next_batch_seed(st), n, nc, (int)h->L);
+    return chk("k_randn_S");
+}
+
+// host-side batches of the same generator: Arnoldi start vectors and Metropolis uniforms the caller leaves NULL
+int randn_host(HmcState *st, std::vector<double> &out, size_t n) {
+    if (!st->rng_on) { elph_set_error("a random input is NULL and elph_hmc_set_rng has not been called"); return ELPH_E_ARG; }
+    const uint64_t seed = next_batch_seed(st);
+    const size_t m = (n + 1) / 2;
+    out.resize(n);
+    for (size_t k = 0; k < m; ++k) {
+        const double r = sqrt(-2.0 * log(u01(seed, k))), th = 6.283185307179586476925 * u01(seed, m + k);
+        out[2 * k] = r * cos(th);
+        if (2 * k + 1 < n) out[2 * k + 1] = r * sin(th);
+    }
+    return ELPH_OK;
+}
+int uniform_host(HmcState *st, std::vector<double> &out, size_t n) {
+    if (!st->rng_on) { elph_set_error("a random input is NULL and elph_hmc_set_rng has not been called"); return ELPH_E_ARG; }
+    const uint64_t seed = next_batch_seed(st);
+    out.resize(n);
+    for (size_t k = 0; k < n; ++k) out[k] = u01(seed, k);
+    return ELPH_OK;
+}
+
 }  // namespace
 
 void elph_hmc_free(elph_handle_s *h) {
@@ -422,6 +491,24 @@ extern "C" int elph_hmc_get_state(elph_handle h, double *x, double *v) {
 // pseudofermions, energies, Metropolis test and failure flag.  A chain whose solve fails (flag > 0, HMC.jl:405-408) is
 // dead for this update: its field is put back to x0 at once (so that its remaining — ignored — solves stay cheap) and
 // it is rejected at the end.
+extern "C" int elph_hmc_set_rng(elph_handle h, uint64_t seed) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st) { elph_set_error("elph_hmc_create / elph_langevin_create has not been called"); return ELPH_E_STATE; }
+    st->rng_on = true;
+    st->rng_seed = seed;
+    st->rng_batches = 0;
+    return ELPH_OK;
+}
+
+extern "C" int elph_hmc_rng_batches(elph_handle h, uint64_t *batches) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st || !batches) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    *batches = st->rng_batches;
+    return ELPH_OK;
+}
+
 extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double alpha, int use_precond, const double *R,
                                       const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept,
                                       int *accepted, double *iters_per_solve, double *energies, int *flag_out) {
@@ -429,11 +516,14 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
     if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
-    if (!R || !Rp || !Rm || !u_accept || !accepted || nt < 0 || nb < 1 || !(alpha >= 0.0 && alpha < 1.0) || !(dt > 0.0)) {
+    if (!accepted || nt < 0 || nb < 1 || !(alpha >= 0.0 && alpha < 1.0) || !(dt > 0.0)) {
         elph_set_error("bad argument");
         return ELPH_E_ARG;
     }
-    if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
+    if ((!R || !Rp || !Rm || !u_accept || (use_precond && !kpm_randn)) && !st->rng_on) {
+        elph_set_error("R, Rp, Rm, u_accept (and kpm_randn with a preconditioner) are required unless elph_hmc_set_rng was called");
+        return ELPH_E_ARG;
+    }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     const int nch = st->nch;
     RC(elph_i_ensure_capacity(h, 2 * nch));
@@ -458,15 +548,24 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
 
     RC(update_model(h, st));
     // refresh_v!  (HMC.jl:648-659)
-    RC(upload_vectors(h, st->y, R, nch, st->nf));
+    RC(randn_vectors(h, st, st->y, R, nch, st->nf));
     RC(fa(h, st, st->y, st->y, -0.5));
     hipLaunchKernelGGL(k_hmc_refresh_v, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->v, st->y, alpha, n);
     RC(chk("k_hmc_refresh_v"));
     HIPCHK(hipMemcpyAsync(st->x0, st->x, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(st->v0, st->v, bytes, hipMemcpyDeviceToDevice, h->stream));
     // refresh_ϕ!  (HMC.jl:665-692): ϕ± = Λ⁻¹ Mᵀ R±      (R2, ϕ: [sign][chain][ndim])
-    RC(upload_vectors(h, st->R2, Rp, nch));
-    RC(upload_vectors(h, st->R2 + (size_t)nch * nd, Rm, nch));
+    RC(randn_vectors(h, st, st->R2, Rp, nch));
+    RC(randn_vectors(h, st, st->R2 + (size_t)nch * nd, Rm, nch));
+    std::vector<double> kpm_own, u_own;      // generated in this order after R, R₊, R₋ when the caller left them NULL
+    if (use_precond && !kpm_randn) {
+        RC(randn_host(st, kpm_own, (size_t)(nt + 2) * 2 * (size_t)nch * (size_t)h->N));
+        kpm_randn = kpm_own.data();
+    }
+    if (!u_accept) {
+        RC(uniform_host(st, u_own, (size_t)nch));
+        u_accept = u_own.data();
+    }
     RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2 * nch));
     if (st->ssh) {      // Λ⁻¹ ≡ 1: ϕ± = MᵀR±
         HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -551,7 +650,7 @@ extern "C" int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, dou
     CHECK_H(h);
     HmcState *st = state_of(h);
     if (st && st->nch != 1) { elph_set_error("%d chains: use elph_hmc_update_chains", st->nch); return ELPH_E_STATE; }
-    return elph_hmc_update_chains(h, dt, nt, nb, alpha, use_precond, R, Rp, Rm, kpm_randn, &u_accept, accepted, iters_per_solve,
+    return elph_hmc_update_chains(h, dt, nt, nb, alpha, use_precond, R, Rp, Rm, kpm_randn, u_accept >= 0.0 ? &u_accept : nullptr, accepted, iters_per_solve,
                                   energies, flag_out);
 }
 
@@ -582,7 +681,7 @@ int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_h
                    const double *bmin, int64_t *iters, int *flag) {
     const size_t nd = (size_t)h->ndim;
     const int nch = st->nch;
-    RC(upload_vectors(h, st->R2, g_host, nch));                                 // g in layout S
+    RC(randn_vectors(h, st, st->R2, g_host, nch));                              // g in layout S
     if (use_precond) RC(elph_kpm_setup_chains(h, bmax, bmin, nullptr, nullptr, nullptr, nullptr, nullptr));   // setup!(P), :366
     RC(elph_launch_mul(h, 1, h->d_b, st->R2, nch));                             // Mᵀg (model.v″, :378)
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nch * nd * sizeof(double), h->stream));   // fill!(M⁻¹g, 0), :367
@@ -638,8 +737,11 @@ extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int us
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_langevin_create[_ssh|_chains] has not been called on this handle"); return ELPH_E_STATE; }
     if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
-    if (scheme < 0 || scheme > 2 || !(dt > 0.0) || !eta || !g1 || (scheme > 0 && !g2)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
+    if (scheme < 0 || scheme > 2 || !(dt > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if ((!eta || !g1 || (scheme > 0 && !g2) || (use_precond && !kpm_randn)) && !st->rng_on) {
+        elph_set_error("eta, g1 (g2 beyond Euler, kpm_randn with a preconditioner) are required unless elph_hmc_set_rng was called");
+        return ELPH_E_ARG;
+    }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     const int nch = st->nch;
     RC(elph_i_ensure_capacity(h, std::max(2, 2 * nch)));
@@ -647,14 +749,19 @@ extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int us
     const size_t N = (size_t)h->N;
     const long long n = (long long)st->nf * h->L * nch;      // field vectors of all chains (Holstein: nch * ndim)
     const double s2 = sqrt(2.0 * dt);
+    std::vector<double> kpm_own;             // batches are drawn in the order eta, kpm_randn, g1, g2
+    RC(update_model(h, st));
+    RC(randn_vectors(h, st, st->v, eta, nch, st->nf));
+    if (use_precond && !kpm_randn) {
+        RC(randn_host(st, kpm_own, 4 * (size_t)nch * N));
+        kpm_randn = kpm_own.data();
+    }
     // start vectors of the two set-ups: [set-up][b_max | b_min][chain][N]
     const double *bm1 = kpm_randn, *bn1 = kpm_randn ? kpm_randn + (size_t)nch * N : nullptr;
     const double *bm2 = kpm_randn ? kpm_randn + 2 * (size_t)nch * N : nullptr, *bn2 = kpm_randn ? kpm_randn + 3 * (size_t)nch * N : nullptr;
     double *F1 = st->dS, *F2 = st->y, *xi = st->v, *dx = st->v0;      // the momentum buffers are free: Langevin has none
     std::vector<int64_t> it1((size_t)nch, 0), it2((size_t)nch, 0);
     std::vector<int> fl((size_t)nch, 0);
-    RC(update_model(h, st));
-    RC(upload_vectors(h, xi, eta, nch, st->nf));
     if (scheme == 0) {
         RC(langevin_force(h, st, F1, g1, use_precond, bm1, bn1, it1.data(), fl.data()));
         RC(fa(h, st, F1, F1, 1.0));
@@ -728,11 +835,14 @@ extern "C" int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int
     HmcState *st = state_of(h);
     if (!st || st->nch != 1) { elph_set_error("elph_hmc_create / elph_hmc_create_ssh (single chain) has not been called"); return ELPH_E_STATE; }
     if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
-    if (!Rp || !Rm || !accepted || kind < 0 || kind > 1 || col_i < 0 || col_i >= st->nf || (kind == 1 && (col_j < 0 || col_j >= st->nf))) {
+    if (!accepted || kind < 0 || kind > 1 || col_i < 0 || col_i >= st->nf || (kind == 1 && (col_j < 0 || col_j >= st->nf))) {
         elph_set_error("bad argument");
         return ELPH_E_ARG;
     }
-    if (use_precond && !kpm_randn) { elph_set_error("kpm_randn required with a preconditioner"); return ELPH_E_ARG; }
+    if ((!Rp || !Rm || !(u_accept >= 0.0) || (use_precond && !kpm_randn)) && !st->rng_on) {
+        elph_set_error("Rp, Rm, u_accept >= 0 (kpm_randn with a preconditioner) are required unless elph_hmc_set_rng was called");
+        return ELPH_E_ARG;
+    }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     RC(elph_i_ensure_capacity(h, 2));
     if (!st->ssh) RC(elph_i_reserve_chains(h, 1));
@@ -740,8 +850,17 @@ extern "C" int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int
     const int L = (int)h->L;
     RC(update_model(h, st));
     // refresh_ϕ!(…, sample_R = true)
-    RC(upload_vectors(h, st->R2, Rp, 1));
-    RC(upload_vectors(h, st->R2 + nd, Rm, 1));
+    RC(randn_vectors(h, st, st->R2, Rp, 1));
+    RC(randn_vectors(h, st, st->R2 + nd, Rm, 1));
+    std::vector<double> kpm_own, u_own;      // batches in the order Rp, Rm, kpm_randn, u_accept
+    if (use_precond && !kpm_randn) {
+        RC(randn_host(st, kpm_own, 2 * (size_t)h->N));
+        kpm_randn = kpm_own.data();
+    }
+    if (!(u_accept >= 0.0)) {
+        RC(uniform_host(st, u_own, 1));
+        u_accept = u_own[0];
+    }
     RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2));
     if (st->ssh) {
         HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));

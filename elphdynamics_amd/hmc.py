@@ -171,6 +171,7 @@ class HybridMonteCarlo:
         self.H = self.S = self.K = 0.0
         self.H0 = self.H1 = self.P_accept = 0.0
         self.flag = 0
+        self.device_rng = False
         from ._lib import check, dptr, iptr
         if model.kind == models.SSH:      # bond phonons: omega, omega4 and fa.M per phonon
             self.omega4 = getattr(model, "omega4", None)
@@ -190,6 +191,14 @@ class HybridMonteCarlo:
         if self.nchains == 1:
             self.push_()
 
+    def device_rng_(self, seed):
+        """Draw the random inputs of every later update / special move on the GPU (elph_hmc_set_rng) instead of taking them from
+        the host: batch b of the run is synth.randn(batch_seed(seed, b), n), see synth.batch_seed."""
+        import ctypes as C
+        from ._lib import check
+        check(self.model._lib.elph_hmc_set_rng(self.model._h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+        self.device_rng = True
+
     def push_(self):
         from ._lib import check, dptr
         if self.nchains > 1:
@@ -203,6 +212,9 @@ class HybridMonteCarlo:
             check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self.X), dptr(self.V)))
         else:
             check(self.model._lib.elph_hmc_get_state(self.model._h, dptr(self.model.x), dptr(self.v)))
+
+
+_NO_RANDOMS = {}          # every input NULL: drawn by the handle's own generator (HybridMonteCarlo.device_rng_)
 
 
 def draw_randoms(hmc, rng, with_kpm):
@@ -224,16 +236,16 @@ def update_(model, hmc, fa=None, P=None, rng=None, randoms=None, pull=True):
     if hmc.Ndof == 0:
         return True, 0                                              # :333-335
     if randoms is None:
-        randoms = draw_randoms(hmc, rng or np.random.default_rng(), P is not None)
+        randoms = _NO_RANDOMS if hmc.device_rng else draw_randoms(hmc, rng or np.random.default_rng(), P is not None)
     model._push_solver()
     acc, fl = C.c_int(), C.c_int()
     its = C.c_double()
     en = np.zeros(5)
-    kr = randoms.get("kpm_randn")
+    c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1)) if a is not None else None
+    u = randoms.get("u")
     check(model._lib.elph_hmc_update(
-        model._h, hmc.dt, hmc.Nt, hmc.Nb, hmc.alpha, 0 if P is None else 1, dptr(np.ascontiguousarray(randoms["R"])),
-        dptr(np.ascontiguousarray(randoms["Rp"])), dptr(np.ascontiguousarray(randoms["Rm"])),
-        dptr(np.ascontiguousarray(kr)) if kr is not None else None, float(randoms["u"]), C.byref(acc), C.byref(its), dptr(en),
+        model._h, hmc.dt, hmc.Nt, hmc.Nb, hmc.alpha, 0 if P is None else 1, c(randoms.get("R")), c(randoms.get("Rp")),
+        c(randoms.get("Rm")), c(randoms.get("kpm_randn")), float(u) if u is not None else -1.0, C.byref(acc), C.byref(its), dptr(en),
         C.byref(fl)))
     hmc.accepted, hmc.iters, hmc.flag = bool(acc.value), its.value, int(fl.value)
     hmc.H0, hmc.H1, hmc.S, hmc.K, hmc.P_accept = (float(e) for e in en)
@@ -259,16 +271,16 @@ def update_chains_(model, hmc, fa=None, P=None, rng=None, randoms=None, pull=Fal
     from ._lib import P_int, check, dptr
     nch = hmc.nchains
     if randoms is None:
-        randoms = draw_randoms_chains(hmc, rng or np.random.default_rng(), P is not None)
+        randoms = _NO_RANDOMS if hmc.device_rng else draw_randoms_chains(hmc, rng or np.random.default_rng(), P is not None)
     model._push_solver()
     acc = np.zeros(nch, dtype=np.int32)
     fl = np.zeros(nch, dtype=np.int32)
     its, en = np.zeros(nch), np.zeros((nch, 5))
-    c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
-    kr = randoms.get("kpm_randn")
+    c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1)) if a is not None else None
     check(model._lib.elph_hmc_update_chains(
-        model._h, hmc.dt, hmc.Nt, hmc.Nb, hmc.alpha, 0 if P is None else 1, c(randoms["R"]), c(randoms["Rp"]), c(randoms["Rm"]),
-        c(kr) if kr is not None else None, c(randoms["u"]), acc.ctypes.data_as(P_int), dptr(its), dptr(en), fl.ctypes.data_as(P_int)))
+        model._h, hmc.dt, hmc.Nt, hmc.Nb, hmc.alpha, 0 if P is None else 1, c(randoms.get("R")), c(randoms.get("Rp")),
+        c(randoms.get("Rm")), c(randoms.get("kpm_randn")), c(randoms.get("u")), acc.ctypes.data_as(P_int), dptr(its), dptr(en),
+        fl.ctypes.data_as(P_int)))
     hmc.accepted, hmc.iters, hmc.flags, hmc.energies = acc.astype(bool), its, fl, en
     hmc.updates += 1
     if pull:
@@ -287,6 +299,8 @@ def special_move_(model, hmc, kind, col_i, col_j=0, P=None, rng=None, randoms=No
     -> (accepted, S0, S1, iters, flag).  randoms: dict(Rp, Rm, kpm_randn (2, Nsites) or None, u)."""
     import ctypes as C
     from ._lib import check, dptr
+    if randoms is None and hmc.device_rng:
+        randoms = _NO_RANDOMS
     if randoms is None:
         rng = rng or np.random.default_rng()
         randoms = dict(Rp=rng.standard_normal(model.Ndim), Rm=rng.standard_normal(model.Ndim),
@@ -294,11 +308,11 @@ def special_move_(model, hmc, kind, col_i, col_j=0, P=None, rng=None, randoms=No
     model._push_solver()
     acc, fl, it = C.c_int(), C.c_int(), C.c_int64()
     s0, s1 = C.c_double(), C.c_double()
-    kr = randoms.get("kpm_randn")
-    check(model._lib.elph_hmc_special_move(model._h, int(kind), int(col_i), int(col_j), dptr(np.ascontiguousarray(randoms["Rp"])),
-                                           dptr(np.ascontiguousarray(randoms["Rm"])), 0 if P is None else 1,
-                                           dptr(np.ascontiguousarray(kr, dtype=np.float64).reshape(-1)) if kr is not None else None,
-                                           float(randoms["u"]), C.byref(acc), C.byref(s0), C.byref(s1), C.byref(it), C.byref(fl)))
+    c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1)) if a is not None else None
+    u = randoms.get("u")
+    check(model._lib.elph_hmc_special_move(model._h, int(kind), int(col_i), int(col_j), c(randoms.get("Rp")), c(randoms.get("Rm")),
+                                           0 if P is None else 1, c(randoms.get("kpm_randn")), float(u) if u is not None else -1.0,
+                                           C.byref(acc), C.byref(s0), C.byref(s1), C.byref(it), C.byref(fl)))
     if model.kind == models.SSH:
         model._cs_stale = True
     return bool(acc.value), s0.value, s1.value, int(it.value), int(fl.value)

@@ -32,6 +32,7 @@ class _Dynamics:
             raise ValueError("chains in lockstep are built for the Holstein model")
         self.X = np.tile(model.x, (self.nchains, 1)) if self.nchains > 1 else None
         self.flags = np.zeros(self.nchains, dtype=np.int32)
+        self.device_rng = False
         if model.kind == models.SSH:
             from ._lib import iptr
             if getattr(model, "omega4", None) is None:
@@ -51,6 +52,11 @@ class _Dynamics:
                                                   dptr(model.mu), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
         model._nchains = self.nchains
         self.push_()
+
+    def device_rng_(self, seed):
+        """Draw eta, g1, g2 (and the Arnoldi start vectors) of every later step inside the library (elph_hmc_set_rng)."""
+        check(self.model._lib.elph_hmc_set_rng(self.model._h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+        self.device_rng = True
 
     def _field(self):
         return self.X if self.nchains > 1 else self.model.x
@@ -87,12 +93,12 @@ def evolve_(model, dyn, fa=None, P=None, rng=None, randoms=None, pull=True):
     random vectors are chain-major (see draw_randoms) and the return value is iters[nchains]; dyn.flags holds the solver flag
     of every chain."""
     if randoms is None:
-        randoms = draw_randoms(dyn, rng or np.random.default_rng(), P is not None)
+        randoms = {} if dyn.device_rng else draw_randoms(dyn, rng or np.random.default_rng(), P is not None)
     model._push_solver()
     nch = dyn.nchains
     it, fl = (C.c_int64 * nch)(), (C.c_int * nch)()
     c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1)) if a is not None else None
-    check(model._lib.elph_langevin_evolve(model._h, dyn.scheme, dyn.dt, 0 if P is None else 1, c(randoms["eta"]), c(randoms["g1"]),
+    check(model._lib.elph_langevin_evolve(model._h, dyn.scheme, dyn.dt, 0 if P is None else 1, c(randoms.get("eta")), c(randoms.get("g1")),
                                           c(randoms.get("g2")), c(randoms.get("kpm_randn")), it, fl))
     dyn.flags = np.array(fl[:], dtype=np.int32)
     dyn.flag = int(dyn.flags.max())

@@ -26,6 +26,12 @@ from ._lib import check, dptr, iptr
 HOLSTEIN, SSH = 0, 1
 
 
+def _rng(rng):
+    if rng is None:
+        raise ValueError("a disorder width (stddev) needs rng=numpy.random.Generator")
+    return rng
+
+
 class ConjugateGradient:
     """IterativeSolvers.jl:36-57 (tol, maxiter, kmax); the work vectors live on the GPU."""
 
@@ -110,30 +116,38 @@ class HolsteinModel(AbstractModel):
         self._device = device
         self._h = None
 
-    # -- incremental specification (HolsteinModels.jl:323-444), deterministic part (stddev = 0)
-    def assign_t_(self, t, o1, o2, v):
+    # -- incremental specification (HolsteinModels.jl:323-444).  Disorder (stddev != 0) draws standard normals from `rng`
+    #    (a numpy Generator) in the reference's order; Julia's Xoshiro stream itself is not reproducible here.
+    def assign_t_(self, t, o1, o2, v, stddev=0.0, rng=None):
         new = self.lattice.calc_neighbor_table(o1, o2, v)
         self.neighbor_table = np.concatenate([self.neighbor_table, new], axis=0)
-        self.t = np.concatenate([self.t, np.full(new.shape[0], float(t))])
+        n = new.shape[0]
+        phase = t / abs(t)                                          # :437 (t = 0 is NaN in the reference too)
+        t_new = np.full(n, abs(float(t)))
+        if stddev != 0.0:
+            t_new = t_new + stddev * _rng(rng).standard_normal(n)
+        self.t = np.concatenate([self.t, phase * t_new])
         self.nbonds += 1
 
-    def _assign(self, arr, val, orbit):
-        if orbit == 0:
-            arr[:] = val
-        else:
-            arr[orbit - 1::self.lattice.norbits] = val
+    def _assign(self, arr, val, orbit, stddev=0.0, rng=None):
+        sel = slice(None) if orbit == 0 else slice(orbit - 1, None, self.lattice.norbits)
+        n = len(arr[sel])
+        arr[sel] = val + (stddev * _rng(rng).standard_normal(n) if stddev != 0.0 else 0.0)
 
-    def assign_mu_(self, val, orbit=0):
-        self._assign(self.mu, val, orbit)
+    def assign_mu_(self, val, orbit=0, stddev=0.0, rng=None):
+        self._assign(self.mu, val, orbit, stddev, rng)
 
-    def assign_lambda_(self, val, orbit=0):
-        self._assign(self.lam, val, orbit)
+    def assign_lambda_(self, val, orbit=0, stddev=0.0, rng=None):
+        self._assign(self.lam, val, orbit, stddev, rng)
 
-    def assign_lambda2_(self, val, orbit=0):
-        self._assign(self.lam2, val, orbit)
+    def assign_lambda2_(self, val, orbit=0, stddev=0.0, rng=None):
+        self._assign(self.lam2, val, orbit, stddev, rng)
 
-    def assign_omega_(self, val, orbit=0):
-        self._assign(self.omega, val, orbit)
+    def assign_omega_(self, val, orbit=0, stddev=0.0, rng=None):
+        self._assign(self.omega, val, orbit, stddev, rng)
+
+    def assign_omega4_(self, val, orbit=0, stddev=0.0, rng=None):
+        self._assign(self.omega4, val, orbit, stddev, rng)
 
     def initialize_model_(self):
         """HolsteinModels.jl:484-517, then create the GPU-side model."""
@@ -178,25 +192,45 @@ class SSHModel(AbstractModel):
         self._device = device
         self._h = None
 
-    def assign_hopping_(self, t, alpha, alpha2, omega, o1, o2, v, has_phonon=True):
-        self.bond_definitions.append(dict(t=float(t), alpha=float(alpha), alpha2=float(alpha2), omega=float(omega),
-                                          o1=o1, o2=o2, v=tuple(v), has_phonon=bool(has_phonon)))
+    def assign_hopping_(self, t, alpha, alpha2, omega, o1, o2, v, has_phonon=None, omega4=0.0, name="", t_std=0.0,
+                        omega_std=0.0, omega4_std=0.0, alpha_std=0.0, alpha2_std=0.0):
+        """assign_hopping!(ssh, t, σt, ω, σω, ω₄, σω₄, α, σα, α₂, σα₂, o₁, o₂, dL, name) (SSHModels.jl:319-342); a bond
+        definition carries a phonon iff ω or σω is non-zero (:74) unless has_phonon is given."""
+        if has_phonon is None:
+            has_phonon = (omega != 0.0) or (omega_std != 0.0)
+        v = tuple(v) + (0,) * (3 - len(v))
+        self.bond_definitions.append(dict(t=float(t), alpha=float(alpha), alpha2=float(alpha2), omega=float(omega), omega4=float(omega4),
+                                          o1=o1, o2=o2, v=v, has_phonon=bool(has_phonon), name=str(name), t_std=float(t_std),
+                                          omega_std=float(omega_std), omega4_std=float(omega4_std), alpha_std=float(alpha_std),
+                                          alpha2_std=float(alpha2_std)))
 
-    def initialize_model_(self):
-        """SSHModels.jl:348-505 (deterministic part)."""
-        tabs, t, alpha, alpha2, omega, ph2b = [], [], [], [], [], []
+    def initialize_model_(self, rng=None):
+        """SSHModels.jl:348-505.  Disorder widths draw from `rng` (numpy Generator) in the reference's order (:381-411)."""
+        tabs, t, alpha, alpha2, omega, omega4, ph2b, names = [], [], [], [], [], [], [], []
         nb_so_far = 0
+
+        def spread(mean, std, n, signed):
+            ph = 1.0 if (not signed or mean == 0.0) else mean / abs(mean)
+            base = np.full(n, abs(mean) if signed else mean)
+            if std != 0.0:
+                base = base + std * _rng(rng).standard_normal(n)
+            return list(ph * base)
+
         for d in self.bond_definitions:
             new = self.lattice.calc_neighbor_table(d["o1"], d["o2"], d["v"])
             n = new.shape[0]
             tabs.append(new)
-            t += [d["t"]] * n
+            t += spread(d["t"], d.get("t_std", 0.0), n, True)
             if d["has_phonon"]:
-                alpha += [d["alpha"]] * n
-                alpha2 += [d["alpha2"]] * n
-                omega += [d["omega"]] * n
+                names.append(d.get("name", ""))
+                omega += spread(d["omega"], d.get("omega_std", 0.0), n, False)
+                omega4 += spread(d.get("omega4", 0.0), d.get("omega4_std", 0.0), n, False)
+                alpha += spread(d["alpha"], d.get("alpha_std", 0.0), n, True)
+                alpha2 += spread(d["alpha2"], d.get("alpha2_std", 0.0), n, True)
                 ph2b += list(range(nb_so_far + 1, nb_so_far + n + 1))      # 1-based bond of each phonon (:413)
             nb_so_far += n
+        self.nph = len(names)                                              # number of phonon types
+        self.phonon_names = names
         raw = np.concatenate(tabs, axis=0) if tabs else np.zeros((0, 2), dtype=np.int64)
         cb = _lat.initialize_checkerboard(raw)
         self.neighbor_table = cb["table"]
@@ -205,11 +239,24 @@ class SSHModel(AbstractModel):
         self.colours = cb["colours"]
         self.Nbonds = raw.shape[0]
         self.t = np.array(t)
-        self.alpha, self.alpha2, self.omega = np.array(alpha), np.array(alpha2), np.array(omega)
+        self.alpha, self.alpha2, self.omega, self.omega4 = np.array(alpha), np.array(alpha2), np.array(omega), np.array(omega4)
         self.phonon_to_bond = np.array(ph2b, dtype=np.int64)
         self.Nph = len(ph2b)
         self.Ndof = self.Nph * self.Ltau
         self.x = np.zeros(self.Ndof)
+        # phonon types with the same name share their fields: primary_field (:480-502), 0-based here; the reference's
+        # tabulation assumes equally many phonons per type (reshape to (Ndof/nph, nph))
+        self.primary_field = np.arange(self.Ndof, dtype=np.int64)
+        if self.nph > 1 and len(set(names)) < self.nph:
+            if self.Ndof % self.nph:
+                raise ValueError("phonon types of unequal size cannot share fields (SSHModels.jl:482)")
+            per = self.Ndof // self.nph
+            pf = self.primary_field.reshape(self.nph, per)
+            for a in range(self.nph):
+                for b in range(a + 1, self.nph):
+                    if names[a] == names[b] and pf[b, 0] > a * per:
+                        pf[b, :] = np.arange(a * per, (a + 1) * per)
+        self.has_shared_fields = bool(np.any(self.primary_field != np.arange(self.Ndof)))
         L, nb = self.Ltau, self.Nbonds
         # cosht/sinht: Julia (Ltau x Nbonds) column-major == [bond][tau] here; bare values (:450-464)
         self._cs_stale = False

@@ -47,6 +47,11 @@ def randn(seed, n):
     return np.ascontiguousarray(out[:n])
 
 
+def batch_seed(seed, b):
+    """Seed of batch b (1-based) of the library's generator (elph_hmc_set_rng): output b of SplitMix64(seed)."""
+    return int(splitmix64(seed, b)[b - 1])
+
+
 def phonon_field(nph, ltau, beta, dtau, omega=1.0, lam=1.0, rough=True, seed=SEED_FIELDS):
     """Flat x[nph*ltau], tau fastest (Utilities.jl:12-15)."""
     u = (splitmix64(seed ^ 0x5151, nph) % np.uint64(3)).astype(np.int64) - 1

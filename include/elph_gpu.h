@@ -280,6 +280,20 @@ int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double 
                            const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept, int *accepted,
                            double *iters_per_solve, double *energies, int *flag);
 
+/* Optional on-device generator for the random inputs of elph_hmc_update[_chains], elph_hmc_special_move and
+ * elph_langevin_evolve (the reference draws them from model.rng on the CPU: randn! HMC.jl:655,675-676, LangevinDynamics.jl:97,360,
+ * KPMPreconditioners.jl:860,903; with 64 chains the host generator and the PCIe transfer of 3 x nchains vectors per update cost
+ * a quarter of the update).  After elph_hmc_set_rng(h, seed) any of R, Rp, Rm, eta, g1, g2, kpm_randn, u_accept may be NULL
+ * (u_accept < 0 where it is passed by value): each missing input is one batch of the build's counter-based generator
+ * (SplitMix64 -> uniform(0,1) -> Box-Muller, elphdynamics_amd/synth.py), batch b (1-based, counted per handle since
+ * elph_hmc_set_rng) seeded with output b of SplitMix64(seed), numbered in the layout the host array would have had — so a run
+ * is reproducible from (seed, batch count) and equals the run that is handed synth.randn(batch seed, n) explicitly.  Field and
+ * site vectors are generated on the device; Arnoldi start vectors and Metropolis uniforms (small) on the host.  Order of the
+ * batches within a call: HMC update R, Rp, Rm, kpm_randn, u_accept; special move Rp, Rm, kpm_randn, u_accept; Langevin step eta,
+ * kpm_randn, g1, g2. */
+int elph_hmc_set_rng(elph_handle h, uint64_t seed);
+int elph_hmc_rng_batches(elph_handle h, uint64_t *batches);
+
 /* One proposed move of special_update! (SpecialUpdates.jl:103-136 ReflectionUpdate, :205-275 SwapUpdate) on the device-resident
  * field of the (single-chain) HMC state:  S₀ = refresh_ϕ!(…, sample_R = true) with the fresh R± = Rp, Rm (HMC.jl:665-692);
  * kind 0: x_col(τ) → −x_col(τ) on phonon column col_i; kind 1: columns col_i, col_j exchange their world lines (0-based; sites

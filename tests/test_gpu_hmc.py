@@ -463,3 +463,91 @@ def test_special_moves_match_golden_and_oracle(oracle):
     assert abs(S0 - info["S0"]) < 1e-10 * abs(info["S0"]) and abs(S1 - info["S1"]) < 1e-7 * abs(info["S1"])
     assert np.array_equal(e.x, x_o)
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------- the library's own generator
+
+@pytest.mark.parametrize("tag,nch,with_kpm", [("b", 1, False), ("B", 3, True)])
+def test_device_rng_equals_explicit_batches(tag, nch, with_kpm):
+    """elph_hmc_set_rng: the random inputs left NULL are drawn inside the library (field / site vectors on the GPU) — the run
+    equals the one that is handed synth.randn(batch seed, n) explicitly, batch by batch, over two updates and a special move."""
+    import ctypes as C
+    from elphdynamics_amd import configs, hmc, preconditioners as pc, synth
+    nt, dt, seed = 3, 0.05, 0xC0FFEE
+
+    def make():
+        m = configs.make_model(tag, tol=1e-9, maxiter=20000)
+        fa = pc.FourierAccelerator(m)
+        pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+        H = hmc.HybridMonteCarlo(m, fa, dt=dt, tr=nt * dt, alpha=0.1, Nb=2, nchains=nch)
+        if nch > 1:
+            H.X[:] = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=900 + c) for c in range(nch)])
+            H.push_()
+        P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0) if with_kpm else None
+        return m, fa, H, P
+
+    upd = (lambda m, H, fa, P, r: hmc.update_chains_(m, H, fa, P, randoms=r, pull=True)) if nch > 1 else \
+          (lambda m, H, fa, P, r: hmc.update_(m, H, fa, P, randoms=r))
+    # a) the library draws
+    m, fa, H, P = make()
+    H.device_rng_(seed)
+    res_a = [upd(m, H, fa, P, None) for _ in range(2)]
+    Ea = np.array(H.energies if nch > 1 else [H.H0, H.H1, H.S, H.K, H.P_accept])
+    if nch == 1:
+        mv_a = hmc.special_move_(m, H, hmc.REFLECT, 3, P=P)
+        H.pull_()
+    nb_batches = C.c_uint64()
+    assert m._lib.elph_hmc_rng_batches(m._h, C.byref(nb_batches)) == 0
+    Xa = (H.X if nch > 1 else m.x).copy()
+    m.close()
+    # b) the same batches handed over
+    m, fa, H, P = make()
+    b = [0]
+
+    def batch(n, uniform=False):
+        b[0] += 1
+        s = synth.batch_seed(seed, b[0])
+        return synth.uniform01(s, n) if uniform else synth.randn(s, n)
+
+    res_b = []
+    for _ in range(2):
+        r = dict(R=batch(nch * m.Ndof), Rp=batch(nch * m.Ndim), Rm=batch(nch * m.Ndim))
+        r["kpm_randn"] = batch((nt + 2) * 2 * nch * m.Nsites) if with_kpm else None
+        u = batch(nch, uniform=True)
+        r["u"] = u if nch > 1 else float(u[0])
+        res_b.append(upd(m, H, fa, P, r))
+    Eb = np.array(H.energies if nch > 1 else [H.H0, H.H1, H.S, H.K, H.P_accept])
+    if nch == 1:
+        r = dict(Rp=batch(m.Ndim), Rm=batch(m.Ndim), kpm_randn=batch(2 * m.Nsites) if with_kpm else None)
+        r["u"] = float(batch(1, uniform=True)[0])
+        mv_b = hmc.special_move_(m, H, hmc.REFLECT, 3, P=P, randoms=r)
+        H.pull_()
+        assert mv_a[0] == mv_b[0] and abs(mv_a[1] - mv_b[1]) < 1e-8 * abs(mv_b[1]) and abs(mv_a[2] - mv_b[2]) < 1e-8 * abs(mv_b[2])
+    assert nb_batches.value == b[0]
+    Xb = (H.X if nch > 1 else m.x).copy()
+    for (aa, ia), (ab, ib) in zip(res_a, res_b):
+        assert np.array_equal(np.atleast_1d(aa), np.atleast_1d(ab)) and np.all(np.abs(np.atleast_1d(ia) - np.atleast_1d(ib)) <= 1)
+    assert np.allclose(Ea, Eb, rtol=1e-8, atol=1e-8)
+    assert np.abs(Xa - Xb).max() < 1e-8 * np.abs(Xb).max()
+    m.close()
+
+
+def test_device_rng_normals_have_the_right_moments():
+    """The device generator itself: mean, variance, fourth moment and lag-1 correlation of 2.6M normals drawn as R of one
+    update (read back through the momenta: alpha = 0, no accelerator mass => v = R after refresh_v!, and nt = 0 keeps it)."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc, synth
+    m = configs.make_model("C", tol=1e-5)
+    fa = pc.FourierAccelerator(m)
+    fa.M[:] = 1.0
+    nch = 8
+    H = hmc.HybridMonteCarlo(m, fa, dt=0.01, tr=0.0, alpha=0.0, Nb=1, nchains=nch)
+    H.X[:] = synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau)
+    H.push_()
+    H.device_rng_(12345)
+    hmc.update_chains_(m, H, fa, None, pull=True)
+    v = H.V.reshape(-1) * np.where(H.accepted, 1.0, -1.0).repeat(m.Ndof)
+    assert np.allclose(v, synth.randn(synth.batch_seed(12345, 1), nch * m.Ndof), rtol=0, atol=1e-12)
+    n = v.size
+    assert abs(v.mean()) < 5 / np.sqrt(n) and abs(v.var() - 1) < 5 * np.sqrt(2 / n) and abs((v ** 4).mean() - 3) < 5 * np.sqrt(96 / n)
+    assert abs(np.mean(v[1:] * v[:-1])) < 5 / np.sqrt(n)
+    m.close()

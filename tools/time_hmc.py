@@ -15,6 +15,8 @@ for nch in ([int(a) for a in sys.argv[1:]] or [1, 8, 32]):
                 H.push_()
             P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0) if with_kpm else None
             rng = np.random.default_rng(3)
+            if not __import__('os').environ.get("HOST_RNG"):
+                H.device_rng_(3)
             upd = (lambda: hmc.update_chains_(m, H, fa, P, rng=rng)) if nch > 1 else (lambda: hmc.update_(m, H, fa, P, rng=rng))
             upd()
             t0 = time.perf_counter(); acc, its = upd(); t1 = time.perf_counter()
