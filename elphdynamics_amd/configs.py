@@ -44,7 +44,7 @@ def make_model(tag, tol=1e-5, maxiter=10000, rough=True, device=0, seed=synth.SE
     else:
         m = models.SSHModel(lattice, beta, dtau, tol=tol, maxiter=maxiter, device=device)
         for (o1, o2, d) in bonds:
-            m.assign_hopping_(1.0, 0.1, 0.0, 0.1, o1, o2, d)
+            m.assign_hopping_(1.0, 0.1, 0.0, 0.1, o1, o2, d, name="xyz"[d.index(1)])     # names "x", "y" as in the deck (:46,:62)
         m.initialize_model_()
         m.x[:] = synth.phonon_field(m.Nph, m.Ltau, beta, dtau, omega=0.1, lam=0.0, rough=rough, seed=seed)
         # keep |alpha x| < t (SSHModels.jl:537-539 warns beyond that): the omega=0.1 QHO is wide

@@ -37,6 +37,12 @@ struct HmcState {
     double *part = nullptr;      // [2 nch][L] partial sums
     double dtau = 0.0;
     bool have_state = false;
+    // SSH phonon types of the same name share their fields (SSHModels.jl:480-502): primary column of each column, the next
+    // member of its class (-1 ends the list) and the weight 1 (primary) / 0 of each column in Sb and K
+    bool shared = false;
+    int *prim = nullptr, *next = nullptr;
+    double *wcol = nullptr;
+    std::vector<int> prim_host;
     // optional generator for the random inputs the caller leaves NULL (elph_hmc_set_rng)
     bool rng_on = false;
     uint64_t rng_seed = 0, rng_batches = 0;
@@ -156,13 +162,15 @@ __device__ __forceinline__ double blk_sum(double v, double *sc) {
 
 // per-slice partial of Sb/Δτ   (calc_Sb, PhononAction.jl:11-66)
 __global__ void __launch_bounds__(TPB) k_hmc_sb_part(double *__restrict__ part, const double *__restrict__ x,
-                                                     const double *__restrict__ par, int N, int L, double dtau) {
+                                                     const double *__restrict__ par, int N, int L, double dtau,
+                                                     const double *__restrict__ wcol) {
     __shared__ double sc[8];
     const int t = blockIdx.x, tm1 = (t == 0) ? L - 1 : t - 1;
     x += (size_t)blockIdx.y * (size_t)N * L;                   // blockIdx.y = chain
     part += (size_t)blockIdx.y * L;
     double acc = 0.0;
     for (int s = threadIdx.x; s < N; s += TPB) {
+        if (wcol && wcol[s] == 0.0) continue;                  // only primary phonons count (PhononAction.jl:83)
         const double xt = x[(size_t)t * N + s], xm = x[(size_t)tm1 * N + s], w = par[s], w4 = par[N + s];
         acc += w * w * (xt * xt) / 2 + w4 * (xt * xt * xt * xt);
         acc += (xt - xm) * (xt - xm) / (dtau * dtau) / 2;
@@ -193,6 +201,31 @@ int chk(const char *what) {
 }
 
 // out[k] = a_k · b_k for `count` consecutive vectors of n elements (count <= 2 nch)
+// Shared fields (layout S: index = tau*nf + column).  k_alias_sum: every member of a class gets the class sum (muldMdx!,
+// SSHModels.jl:820-826); k_alias_copy: every column takes its primary's value (randn!, :568-575); k_mask_cols: v *= wcol.
+__global__ void __launch_bounds__(TPB) k_alias_sum(double *__restrict__ F, const int *__restrict__ prim, const int *__restrict__ next,
+                                                   int nf, long long n) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int col = (int)(i % nf);
+    if (prim[col] != col || next[col] < 0) return;
+    const long long base = i - col;
+    double sum = F[i];
+    for (int c = next[col]; c >= 0; c = next[c]) sum += F[base + c];
+    F[i] = sum;
+    for (int c = next[col]; c >= 0; c = next[c]) F[base + c] = sum;
+}
+__global__ void __launch_bounds__(TPB) k_alias_copy(double *__restrict__ F, const int *__restrict__ prim, int nf, long long n) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int col = (int)(i % nf);
+    if (prim[col] != col) F[i] = F[i - col + prim[col]];       // primaries are never written: no race
+}
+__global__ void __launch_bounds__(TPB) k_mask_cols(double *__restrict__ F, const double *__restrict__ wcol, int nf, long long n) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) F[i] *= wcol[i % nf];
+}
+
 int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, long long n, int count, double *out) {
     const int nb = (int)h->L;
     const long long per = (n + nb - 1) / nb;
@@ -209,10 +242,17 @@ int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, 
     return ELPH_OK;
 }
 
+int alias_sum(elph_handle_s *h, HmcState *st, double *F) {
+    if (!st->shared) return ELPH_OK;
+    const long long n = (long long)st->nf * h->L * st->nch;
+    hipLaunchKernelGGL(k_alias_sum, dim3(nblk(n)), dim3(TPB), 0, h->stream, F, (const int *)st->prim, (const int *)st->next, st->nf, n);
+    return chk("k_alias_sum");
+}
+
 int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
     const int L = (int)h->L, nch = st->nch;
     hipLaunchKernelGGL(k_hmc_sb_part, dim3((unsigned)L, (unsigned)nch), dim3(TPB), 0, h->stream, st->part, st->x, st->par, st->nf, L,
-                       st->dtau);
+                       st->dtau, (const double *)(st->shared ? st->wcol : nullptr));
     RC(chk("k_hmc_sb_part"));
     std::vector<double> p((size_t)L * nch);
     HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
@@ -288,6 +328,11 @@ int calc_H(elph_handle_s *h, HmcState *st, double *H, double *S, double *K) {
     RC(dots_host(h, st, h->d_b, h->d_x, (long long)h->ndim, 2 * nch, sf.data()));
     RC(calc_Sb(h, st, sb.data()));
     RC(fa(h, st, st->y, st->v, 1.0));
+    if (st->shared) {       // calc_K of the SSH model counts primary fields only (HMC.jl:720-738)
+        const long long nn = (long long)st->nf * h->L * nch;
+        hipLaunchKernelGGL(k_mask_cols, dim3(nblk(nn)), dim3(TPB), 0, h->stream, st->y, (const double *)st->wcol, st->nf, nn);
+        RC(chk("k_mask_cols"));
+    }
     RC(dots_host(h, st, st->v, st->y, (long long)st->nf * h->L, nch, k.data()));
     for (int c = 0; c < nch; ++c) {
         S[c] = (sf[(size_t)c] + sf[(size_t)nch + c]) / 2 + sb[(size_t)c];
@@ -303,6 +348,7 @@ int force(elph_handle_s *h, HmcState *st, bool with_Sb) {
     if (st->ssh) {      // dSf/dx = -dMdx(M X₊, X₊) - dMdx(M X₋, X₋)  (HMC.jl:797-808; muldΛdx! is a no-op)
         RC(elph_launch_force_ssh(h, h->d_p, h->d_x));                          // bond brackets q[tau][bond] (d_p is free here)
         RC(elph_launch_ssh_scatter(h, st->dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -1.0));
+        RC(alias_sum(h, st, st->dS));
     } else {
         RC(elph_launch_force_holstein(h, st->dS, h->d_x, st->phi, st->x, st->dtau, st->nch));
     }
@@ -348,7 +394,12 @@ int randn_vectors(elph_handle_s *h, HmcState *st, double *dstS, const double *ho
     const int nc = ncols > 0 ? ncols : (int)h->N;
     const long long n = (long long)nvec * nc * h->L;
     hipLaunchKernelGGL(k_randn_S, dim3(nblk((n + 1) / 2)), dim3(TPB), 0, h->stream, dstS, next_batch_seed(st), n, nc, (int)h->L);
-    return chk("k_randn_S");
+    RC(chk("k_randn_S"));
+    if (ncols > 0 && st->shared) {      // randn!(v, ssh): v = v[primary_field]  (SSHModels.jl:568-575)
+        hipLaunchKernelGGL(k_alias_copy, dim3(nblk(n)), dim3(TPB), 0, h->stream, dstS, (const int *)st->prim, nc, n);
+        RC(chk("k_alias_copy"));
+    }
+    return ELPH_OK;
 }
 
 // host-side batches of the same generator: Arnoldi start vectors and Metropolis uniforms the caller leaves NULL
@@ -379,6 +430,9 @@ void elph_hmc_free(elph_handle_s *h) {
     if (!st) return;
     double *ptrs[] = {st->x, st->v, st->x0, st->v0, st->dS, st->y, st->R2, st->phi, st->faM, st->par, st->part};
     for (double *p : ptrs) if (p) (void)hipFree(p);
+    if (st->prim) (void)hipFree(st->prim);
+    if (st->next) (void)hipFree(st->next);
+    if (st->wcol) (void)hipFree(st->wcol);
     delete st;
     h->hmc = nullptr;
 }
@@ -457,6 +511,21 @@ extern "C" int elph_hmc_set_state(elph_handle h, const double *x, const double *
     CHECK_H(h);
     HmcState *st = state_of(h);
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
+    if (x && st->shared) {      // update_model! refuses fields that differ from their primary (SSHModels.jl:549-559; isapprox)
+        const size_t L = (size_t)h->L;
+        for (int c = 0; c < st->nf; ++c) {
+            const int pc = st->prim_host[(size_t)c];
+            if (pc == c) continue;
+            for (size_t t = 0; t < L; ++t) {
+                const double a = x[(size_t)c * L + t], b = x[(size_t)pc * L + t];
+                if (!(fabs(a - b) <= 1.4901161193847656e-08 * fmax(fabs(a), fabs(b)))) {
+                    elph_set_error("(x[%zu]=%g) != (x[%zu]=%g): fields that share a primary field must be equal", (size_t)c * L + t + 1, a,
+                                   (size_t)pc * L + t + 1, b);
+                    return ELPH_E_ARG;
+                }
+            }
+        }
+    }
     if (x) {
         RC(upload_vectors(h, st->x, x, st->nch, st->nf));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -491,6 +560,43 @@ extern "C" int elph_hmc_get_state(elph_handle h, double *x, double *v) {
 // pseudofermions, energies, Metropolis test and failure flag.  A chain whose solve fails (flag > 0, HMC.jl:405-408) is
 // dead for this update: its field is put back to x0 at once (so that its remaining — ignored — solves stay cheap) and
 // it is rejected at the end.
+extern "C" int elph_hmc_set_shared_fields(elph_handle h, const int64_t *primary_column) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st || !st->ssh) { elph_set_error("elph_hmc_create_ssh / elph_langevin_create_ssh has not been called"); return ELPH_E_STATE; }
+    if (!primary_column) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    const int nf = st->nf;
+    std::vector<int> prim((size_t)nf), next((size_t)nf, -1), last((size_t)nf);
+    std::vector<double> w((size_t)nf);
+    bool any = false;
+    for (int c = 0; c < nf; ++c) {
+        const int64_t p = primary_column[c];
+        if (p < 0 || p > c || primary_column[p] != p) {
+            elph_set_error("primary_column[%d] = %lld: a primary is an earlier (or the same) column that is its own primary", c, (long long)p);
+            return ELPH_E_ARG;
+        }
+        prim[(size_t)c] = (int)p;
+        last[(size_t)c] = c;
+        w[(size_t)c] = (p == c) ? 1.0 : 0.0;
+        if (p != c) {       // append to the class list of p, in column order
+            next[(size_t)last[(size_t)p]] = c;
+            last[(size_t)p] = c;
+            any = true;
+        }
+    }
+    if (!st->prim) {
+        HIPCHK(hipMalloc((void **)&st->prim, (size_t)nf * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&st->next, (size_t)nf * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&st->wcol, (size_t)nf * sizeof(double)));
+    }
+    HIPCHK(hipMemcpy(st->prim, prim.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(st->next, next.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(st->wcol, w.data(), (size_t)nf * sizeof(double), hipMemcpyHostToDevice));
+    st->prim_host = prim;
+    st->shared = any;
+    return ELPH_OK;
+}
+
 extern "C" int elph_hmc_set_rng(elph_handle h, uint64_t seed) {
     CHECK_H(h);
     HmcState *st = state_of(h);
@@ -691,6 +797,7 @@ int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_h
     if (st->ssh) {      // muldMdx!(dSfdx, g, ssh, M⁻¹g) (SSHModels.jl:707-829) with u = g given; no shifted term for bond phonons
         RC(elph_launch_force_ssh(h, h->d_p, h->d_x, st->R2));
         RC(elph_launch_ssh_scatter(h, dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -2.0));
+        RC(alias_sum(h, st, dS));
         hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1, 1,
                            (const double *)nullptr);
     } else {
@@ -838,6 +945,10 @@ extern "C" int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int
     if (!accepted || kind < 0 || kind > 1 || col_i < 0 || col_i >= st->nf || (kind == 1 && (col_j < 0 || col_j >= st->nf))) {
         elph_set_error("bad argument");
         return ELPH_E_ARG;
+    }
+    if (st->shared) {
+        elph_set_error("special moves on shared fields: the reference's swap leaves the fields unequal and then stops in update_model!");
+        return ELPH_E_UNSUPPORTED;
     }
     if ((!Rp || !Rm || !(u_accept >= 0.0) || (use_precond && !kpm_randn)) && !st->rng_on) {
         elph_set_error("Rp, Rm, u_accept >= 0 (kpm_randn with a preconditioner) are required unless elph_hmc_set_rng was called");

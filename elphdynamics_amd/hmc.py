@@ -146,6 +146,15 @@ def calc_dSfdx_(dSdx, model, phi_p, phi_m, P=None, power=1.0, return_solutions=F
     return int(it.value), int(fl.value)
 
 
+def set_shared_fields_(model):
+    """Tell the device which bond phonons share their fields (model.primary_field, SSHModels.jl:480-502)."""
+    from ._lib import check, iptr
+    if getattr(model, "has_shared_fields", False):
+        L = model.Ltau
+        prim_col = np.ascontiguousarray(model.primary_field[::L] // L, dtype=np.int64)
+        check(model._lib.elph_hmc_set_shared_fields(model._h, iptr(prim_col)))
+
+
 class HybridMonteCarlo:
     """HybridMonteCarlo(model, Δt, tr, α, Nb) (HMC.jl:20-245), reduced to what the device-resident trajectory needs.
     x, v, ϕ±, O⁻¹Λϕ± and dS/dx live on the GPU between updates; `model.x` / `hmc.v` on the host are refreshed by
@@ -183,6 +192,7 @@ class HybridMonteCarlo:
                 model._h, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
                 dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)), dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb),
                 dptr(np.ascontiguousarray(model.mu)), model.dtau, dptr(np.ascontiguousarray(fa.M))))
+            set_shared_fields_(model)
             model._cs_stale = True
         else:
             check(model._lib.elph_hmc_create_chains(model._h, self.nchains, dptr(model.omega), dptr(model.omega4), dptr(model.lam),
@@ -190,6 +200,17 @@ class HybridMonteCarlo:
         model._nchains = self.nchains
         if self.nchains == 1:
             self.push_()
+
+    def sharing(self, dt, tr, alpha, Nb):
+        """HybridMonteCarlo(hmc, Δt, tr, α, Nb) (HMC.jl:225-245): a second parameter set (burn-in) on the same arrays — here the
+        same device state; dt, Nt, Nb and α travel with every update call."""
+        import copy
+        assert 0.0 <= alpha < 1.0
+        other = copy.copy(self)
+        other.dt, other.tr, other.alpha, other.Nb = float(dt), float(tr), float(alpha), int(Nb)
+        other.Nt = int(round(other.tr / other.dt))
+        other.dtp = other.dt / other.Nb
+        return other
 
     def device_rng_(self, seed):
         """Draw the random inputs of every later update / special move on the GPU (elph_hmc_set_rng) instead of taking them from
@@ -222,6 +243,8 @@ def draw_randoms(hmc, rng, with_kpm):
     (refresh_v! :652, refresh_ϕ! :674-675, one pair of Arnoldi start vectors per setup!(P), rand :441)."""
     m = hmc.model
     R = rng.standard_normal(m.Ndof)
+    if getattr(m, "has_shared_fields", False):
+        R = R[m.primary_field]                                      # randn!(R, ssh), SSHModels.jl:568-575
     Rp = rng.standard_normal(m.Ndim)
     Rm = rng.standard_normal(m.Ndim)
     kpm = rng.standard_normal((hmc.Nt + 2, 2, m.Nsites)) if with_kpm else None
@@ -318,6 +341,11 @@ def special_move_(model, hmc, kind, col_i, col_j=0, P=None, rng=None, randoms=No
     return bool(acc.value), s0.value, s1.value, int(it.value), int(fl.value)
 
 
+def _isapprox(a, b):
+    """Julia's a ≈ b for vectors: ‖a − b‖ ≤ √eps · max(‖a‖, ‖b‖)."""
+    return np.linalg.norm(a - b) <= 1.4901161193847656e-08 * max(np.linalg.norm(a), np.linalg.norm(b))
+
+
 def reflection_update_(model, hmc, nsites, P=None, rng=None):
     """special_update!(model, hmc, ru::ReflectionUpdate, P) (SpecialUpdates.jl:103-136): nsites sites drawn with replacement,
     one move each; returns the accepted fraction.  Holstein only (null operation otherwise, :138-141)."""
@@ -330,10 +358,27 @@ def reflection_update_(model, hmc, nsites, P=None, rng=None):
 
 def swap_update_(model, hmc, nbonds, P=None, rng=None):
     """special_update!(model, hmc, su::SwapUpdate, P): Holstein (:205-236) — the two sites of nbonds randomly drawn bonds swap
-    their phonon world lines."""
-    if model.kind != models.HOLSTEIN or model.Nbonds == 0 or nbonds < 1:
+    their phonon world lines; SSH (:302-362) — two randomly drawn bond phonons with different world lines swap them."""
+    if nbonds < 1:
         return 0.0
     rng = rng or np.random.default_rng()
+    if model.kind == models.SSH:
+        if model.Nph < 2:
+            return 0.0
+        acc, L = 0, model.Ltau
+        for _ in range(nbonds):
+            hmc.pull_()                                             # the draw compares world lines (while xᵢ ≈ xⱼ, :325-327)
+            x = model.x.reshape(model.Nph, L)
+            if np.allclose(x, x[0], rtol=1e-8, atol=0):
+                return acc / nbonds                                 # every phonon the same: the reference would loop forever
+            i = int(rng.integers(0, model.Nph))
+            j = int(rng.integers(0, model.Nph))
+            while _isapprox(x[i], x[j]):
+                j = int(rng.integers(0, model.Nph))
+            acc += special_move_(model, hmc, SWAP, i, j, P=P, rng=rng)[0]
+        return acc / nbonds
+    if model.Nbonds == 0:
+        return 0.0
     bonds = rng.integers(0, model.Nbonds, size=min(model.Nbonds, nbonds))
     tab = model.neighbor_table
     return sum(special_move_(model, hmc, SWAP, int(tab[b, 0]) - 1, int(tab[b, 1]) - 1, P=P, rng=rng)[0] for b in bonds) / len(bonds)

@@ -43,6 +43,8 @@ class _Dynamics:
                 model._h, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
                 dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)), dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb),
                 dptr(np.ascontiguousarray(model.mu)), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
+            from .hmc import set_shared_fields_
+            set_shared_fields_(model)
             model._cs_stale = True
         elif self.nchains > 1:
             check(model._lib.elph_langevin_create_chains(model._h, self.nchains, dptr(model.omega), dptr(model.omega4), dptr(model.lam),
@@ -83,6 +85,8 @@ class HeunsDynamics(_Dynamics):
 def draw_randoms(dyn, rng, with_kpm):
     m, nch = dyn.model, dyn.nchains
     out = dict(eta=rng.standard_normal((nch, m.Ndof)), g1=rng.standard_normal((nch, m.Ndim)))
+    if getattr(m, "has_shared_fields", False):
+        out["eta"] = out["eta"][:, m.primary_field]                  # randn!(η, model), LangevinDynamics.jl:97
     out["g2"] = rng.standard_normal((nch, m.Ndim)) if dyn.scheme != EULER else None
     out["kpm_randn"] = rng.standard_normal((2, 2, nch, m.Nsites)) if with_kpm else None     # [set-up][b_max|b_min][chain][site]
     return out

@@ -280,6 +280,15 @@ int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double 
                            const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept, int *accepted,
                            double *iters_per_solve, double *energies, int *flag);
 
+/* SSH phonon types of the same name (the default "" included) share their fields: primary_field of initialize_model!
+ * (SSHModels.jl:480-502).  primary_column[Nph]: 0-based column of the primary phonon of every phonon (itself for a primary; the
+ * sharing is the same on every time slice).  Call after elph_hmc_create_ssh / elph_langevin_create_ssh.  Then, as in the
+ * reference: the fermion force of a class is summed over its members and given to each (muldMdx!, :820-826), calc_Sb and
+ * calc_K count primary fields only (PhononAction.jl:83, HMC.jl:720-738), elph_hmc_set_state refuses fields that differ
+ * from their primary (update_model!, :549-559), generated random field vectors are copied from their primaries (randn!,
+ * :568-575; host-supplied R / eta must already be v[primary_field]); elph_hmc_special_move returns ELPH_E_UNSUPPORTED. */
+int elph_hmc_set_shared_fields(elph_handle h, const int64_t *primary_column);
+
 /* Optional on-device generator for the random inputs of elph_hmc_update[_chains], elph_hmc_special_move and
  * elph_langevin_evolve (the reference draws them from model.rng on the CPU: randn! HMC.jl:655,675-676, LangevinDynamics.jl:97,360,
  * KPMPreconditioners.jl:860,903; with 64 chains the host generator and the PCIe transfer of 3 x nchains vectors per update cost

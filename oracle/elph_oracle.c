@@ -1353,14 +1353,32 @@ static double hmc_calc_Sf(hmc_ws *w) {                             /* HMC.jl:768
     return Sf;
 }
 
+/* dMdx[primary_field[f]] += dMdx[f] for the secondary fields, then dMdx = dMdx[primary_field]  (muldMdx!, SSHModels.jl:820-826) */
+static void ssh_share_force(double *d, const int64_t *pf, int64_t nfl) {
+    if (!pf) return;
+    for (int64_t f = 0; f < nfl; f++)
+        if (pf[f] != f) d[pf[f]] += d[f];
+    for (int64_t f = 0; f < nfl; f++) d[f] = d[pf[f]];
+}
+
 static void hmc_calc_H(hmc_ws *w, double *H, double *S, double *K) {   /* HMC.jl:697-721,745-756 */
     const elpho_hmc_params *hp = w->hp;
-    const int64_t nfl = w->nf * hp->L;
+    const int64_t nfl = w->nf * hp->L, L = hp->L;
+    const int64_t *pf = w->ssh ? w->ssh->primary_field : NULL;
     *S = hmc_calc_Sf(w);
-    /* calc_Sb: the SSH version (PhononAction.jl:68-97, every field its own primary field) is the Holstein sum over Nph columns */
-    *S += elpho_calc_Sb_holstein(w->nf, hp->L, hp->dtau, w->x, hp->omega, hp->omega4);
     elpho_fourier_accelerate(w->y, w->v, hp->fa_M, 1.0, w->nf, hp->L);
-    *K = dotp(w->v, w->y, nfl) / 2;
+    if (pf) {      /* SSH with shared fields: calc_Sb (PhononAction.jl:68-97) and calc_K (HMC.jl:720-738) over primary fields */
+        double k = 0.0;
+        for (int64_t i = 0; i < w->nf; i++)
+            if (pf[i * L] == i * L) *S += elpho_calc_Sb_holstein(1, L, hp->dtau, w->x + i * L, hp->omega + i, hp->omega4 + i);
+        for (int64_t f = 0; f < nfl; f++)
+            if (pf[f] == f) k += w->v[f] * w->y[f] / 2;
+        *K = k;
+    } else {
+        /* calc_Sb: the SSH version with every field its own primary field is the Holstein sum over Nph columns */
+        *S += elpho_calc_Sb_holstein(w->nf, hp->L, hp->dtau, w->x, hp->omega, hp->omega4);
+        *K = dotp(w->v, w->y, nfl) / 2;
+    }
     *H = *S + *K;
 }
 
@@ -1372,6 +1390,7 @@ static void hmc_calc_dSfdx(hmc_ws *w) {                            /* HMC.jl:790
         for (int k = 0; k < 2; k++) {
             elpho_mulM(w->u, w->m, w->X[k]);
             elpho_muldMdx_ssh(w->y, w->u, w->m, w->X[k], hp->dtau, q->bond_to_phonon_cb, q->alpha, q->alpha2, w->x, q->Nph);
+            ssh_share_force(w->y, q->primary_field, nfl);
             for (int64_t i = 0; i < nfl; i++) w->dSdx[i] += -w->y[i];
         }
         return;
@@ -1586,6 +1605,7 @@ static int64_t langevin_dSdx(double *dSdx, const elpho_hmc_params *hp, const elp
     elpho_ldiv(m, Minv_g, b, P, 0, hp->solver_tol, hp->solver_maxiter, hp->kmax, r, p, z, &it, &res, &fl);
     if (ssh) {
         elpho_muldMdx_ssh(d, g, m, Minv_g, hp->dtau, ssh->bond_to_phonon_cb, ssh->alpha, ssh->alpha2, x, ssh->Nph);
+        ssh_share_force(d, ssh->primary_field, nfl);
         for (int64_t i = 0; i < nfl; i++) dSdx[i] = -2.0 * d[i];
         elpho_calc_dSbdx_holstein(dSdx, nf, L, hp->dtau, x, hp->omega, hp->omega4);
     } else {

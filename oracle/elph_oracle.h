@@ -266,6 +266,7 @@ typedef struct {
     const int64_t *phonon_to_bond;   /* [Nph] 1-based raw bond of each phonon */
     const int64_t *cb_perm;          /* [nbonds] checkerboard_perm */
     const int64_t *bond_to_phonon_cb;/* [nbonds] 1-based phonon on checkerboard bond n, 0 = none */
+    const int64_t *primary_field;    /* [Nph*L] 0-based ssh.primary_field (SSHModels.jl:480-502); NULL: every field its own */
 } elpho_hmc_ssh;
 
 int64_t elpho_hmc_update_ssh(const elpho_hmc_params *hp, const elpho_hmc_ssh *ssh, elpho_model *m, elpho_kpm *P, double *x,

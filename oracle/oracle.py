@@ -79,7 +79,7 @@ class HmcParams(C.Structure):
 
 class HmcSsh(C.Structure):
     _fields_ = [("Nph", c_i64), ("t", P_dbl), ("alpha", P_dbl), ("alpha2", P_dbl), ("phonon_to_bond", P_i64), ("cb_perm", P_i64),
-                ("bond_to_phonon_cb", P_i64)]
+                ("bond_to_phonon_cb", P_i64), ("primary_field", P_i64)]
 
 
 class Oracle:
@@ -218,6 +218,7 @@ class Oracle:
             sp.Nph = Nph
             sp.t, sp.alpha, sp.alpha2 = (dp(a) for a in fa_)
             sp.phonon_to_bond, sp.cb_perm, sp.bond_to_phonon_cb = ip(ia_[0]), ip(ia_[1]), ip(b2p)
+            sp.primary_field = None
             keep += fa_ + ia_ + [b2p]
         x = np.ascontiguousarray(x, dtype=np.float64).copy()
         out = np.zeros(5)
@@ -274,6 +275,8 @@ class Oracle:
         sp.Nph = Nph
         sp.t, sp.alpha, sp.alpha2 = (dp(a) for a in fa_)
         sp.phonon_to_bond, sp.cb_perm, sp.bond_to_phonon_cb = ip(ia_[0]), ip(ia_[1]), ip(b2p)
+        pf = np.ascontiguousarray(ssh["primary_field"], dtype=np.int64) if ssh.get("primary_field") is not None else None
+        sp.primary_field = ip(pf) if pf is not None else None
         x = np.ascontiguousarray(x, dtype=np.float64).copy()
         fq, e, a1, a2, kr = (np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (fa_Q, eta, g1, g2, kpm_randn))
         it = self.lib.elpho_langevin_evolve_ssh(int(scheme), C.byref(hp), C.byref(sp), C.byref(m), C.byref(P) if P is not None else None,
@@ -282,7 +285,7 @@ class Oracle:
         return x, int(it)
 
     def hmc_update_ssh(self, m, x, v, omega, omega4, mu, dtau, fa_M, t, alpha, alpha2, phonon_to_bond, cb_perm, dt, nt, nb,
-                       alpha_mom, randoms, P=None, tol=1e-5, maxiter=10000, kmax=1e12):
+                       alpha_mom, randoms, P=None, tol=1e-5, maxiter=10000, kmax=1e12, primary_field=None):
         """update!(model, hmc, fa, P) for an SSH model (bond phonons): x, v, R are (Nph*L,), Rp/Rm (N*L,).  m.c, m.s, m.E are
         overwritten (update_model!).  Same return convention as hmc_update_holstein."""
         hp, sp = HmcParams(), HmcSsh()
@@ -300,6 +303,8 @@ class Oracle:
         sp.Nph = Nph
         sp.t, sp.alpha, sp.alpha2 = dp(arrs[6]), dp(arrs[7]), dp(arrs[8])
         sp.phonon_to_bond, sp.cb_perm, sp.bond_to_phonon_cb = ip(iarrs[0]), ip(iarrs[1]), ip(b2p)
+        pf = np.ascontiguousarray(primary_field, dtype=np.int64) if primary_field is not None else None     # 0-based, [Nph*L]
+        sp.primary_field = ip(pf) if pf is not None else None
         x = np.ascontiguousarray(x, dtype=np.float64).copy()
         v = np.ascontiguousarray(v, dtype=np.float64).copy()
         out = np.zeros(8)

@@ -422,10 +422,14 @@ def gen_hmc(h, tag, seed, dt=0.05, nt=6, nb=1):
          H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0) + 0.5 * (v_init @ accel(v_init, 1.0)))
 
 
-def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
+def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1, shared=False):
     """One HMC trajectory of the SSH model (bond phonons, alpha2 = 0 so that M(x) is analytic) from the definitions:
     S(x) = Sb(x) + 1/2 sum_± ϕ±ᵀ (MᵀM)⁻¹ ϕ± (Λ ≡ 1), dense M(x) with B(τ) = CB_τ(x) diag(exp(Δτ μ)),
-    cosh/sinh(Δτ (t - α x)) on the bonds; the force is the complex-step derivative of the dense action."""
+    cosh/sinh(Δτ (t - α x)) on the bonds; the force is the complex-step derivative of the dense action.
+    shared: the two phonon types carry the same name, so phonon k of the second type shares the fields of phonon k of the first
+    (primary_field, SSHModels.jl:480-502).  The golden trajectory is then that of the INDEPENDENT variables y (the primary
+    fields) with x = (y, y): S(y) = Sb(y) + Sf(x(y)), K = v_y·M⁻¹v_y / 2 — which is what the reference's rules (class-summed
+    fermion force, Sb and K over primaries, randn! copied from primaries) amount to when ω and the accelerator agree in a class."""
     g = np.load(os.path.join(HERE, f"ssh_{tag}.npz"))
     N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
     table, cbp = g["table"], g["cbperm"]
@@ -436,6 +440,10 @@ def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
     x0 = g["x"].copy()
     omega = 0.5 + 0.05 * synth.randn(seed + 1, Nph)
     omega4 = 0.05 * np.abs(synth.randn(seed + 2, Nph))
+    Npr = Nph // 2 if shared else Nph                                          # independent phonons
+    ex = (lambda y: np.concatenate([y, y])) if shared else (lambda y: y)       # x(y), phonon-major
+    if shared:
+        omega, omega4 = ex(omega[:Npr]), ex(omega4[:Npr])
     m0, cc = 1.0, 0.3
     k = np.arange(L)
     kp = np.minimum(k, L - k)
@@ -443,14 +451,16 @@ def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
     faM = dtau * (mreg[None, :] ** 2 + omega[:, None] ** 2 + (2 - 2 * np.cos(2 * np.pi * kp / L))[None, :] / dtau ** 2) \
         / (mreg[None, :] ** 2 + omega[:, None] ** 2)                            # [Nph, L]
     R, Rp, Rm = synth.randn(seed + 3, nf), synth.randn(seed + 4, n), synth.randn(seed + 5, n)
+    nfr = Npr * L
+    faMr, omr, om4r = faM[:Npr], omega[:Npr], omega4[:Npr]
     Emu = np.exp(dtau * mu)
     cbidx = cbp[p2b - 1] - 1                                                    # checkerboard position of each phonon's bond
 
     def accel(vec, power):
-        return np.real(scipy.fft.ifft(faM ** power * scipy.fft.fft(vec.reshape(Nph, L), axis=1), axis=1)).reshape(-1)
+        return np.real(scipy.fft.ifft(faMr ** power * scipy.fft.fft(vec.reshape(Npr, L), axis=1), axis=1)).reshape(-1)
 
-    def dense_M_of(x):
-        X = x.reshape(Nph, L)
+    def dense_M_of(y):
+        X = ex(y).reshape(Nph, L)
         tp = np.empty((nbd, L), dtype=X.dtype)
         tp[:] = tb[np.argsort(cbp)][:, None]                                    # bare hopping at each checkerboard position
         tp[cbidx] = tb[p2b - 1][:, None] - alpha[:, None] * X
@@ -470,8 +480,8 @@ def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
         return M
 
     def Sb(x):
-        X = x.reshape(Nph, L)
-        return dtau * np.sum(omega[:, None] ** 2 * X ** 2 / 2 + omega4[:, None] * X ** 4
+        X = x.reshape(Npr, L)
+        return dtau * np.sum(omr[:, None] ** 2 * X ** 2 / 2 + om4r[:, None] * X ** 4
                              + (X - np.roll(X, 1, axis=1)) ** 2 / dtau ** 2 / 2)
 
     def Sf(x, phis):
@@ -483,15 +493,17 @@ def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
         return tot
 
     def grad(fun, x):
-        hstep, out = 1e-30, np.empty(nf)
-        for kk in range(nf):
+        hstep, out = 1e-30, np.empty(nfr)
+        for kk in range(nfr):
             xc = x.astype(complex)
             xc[kk] += 1j * hstep
             out[kk] = np.imag(fun(xc)) / hstep
         return out
 
-    x = x0.copy()
-    v = accel(R, -0.5)
+    x = x0[:nfr].copy()
+    x0 = ex(x)
+    R = ex(R[:nfr])
+    v = accel(R[:nfr], -0.5)
     v_init = v.copy()
     M0 = dense_M_of(x)
     phis = [M0.T @ Rp, M0.T @ Rm]
@@ -520,9 +532,12 @@ def gen_hmc_ssh(tag, seed, dt=0.05, nt=4, nb=1):
             Qf = accel(grad(lambda z: Sf(z, phis), x), -1.0)
             v = v - dt / 2 * Qf
     H1 = H(x, v)
-    save(f"hmc_ssh_{tag}_nb{nb}.npz", N=N, Ltau=L, dtau=dtau, Nph=Nph, omega=omega, omega4=omega4, x0=x0, faM=faM.reshape(-1), R=R,
-         Rp=Rp, Rm=Rm, dt=dt, nt=nt, nb=nb, v_init=v_init, phi_p=phis[0], phi_m=phis[1], H0=H0, H1=H1, Sb0=Sb(x0), dSb0=dSb0,
-         dSf0=dSf0, x1=x, v1=v, H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0) + 0.5 * (v_init @ accel(v_init, 1.0)))
+    fam_full = np.concatenate([faMr, faMr]) if shared else faM
+    save(f"hmc_ssh_{tag}_nb{nb}{'_shared' if shared else ''}.npz", N=N, Ltau=L, dtau=dtau, Nph=Nph, omega=omega, omega4=omega4, x0=x0,
+         faM=fam_full.reshape(-1), R=R, Rp=Rp, Rm=Rm, dt=dt, nt=nt, nb=nb, v_init=ex(v_init), phi_p=phis[0], phi_m=phis[1], H0=H0,
+         H1=H1, Sb0=Sb(x0[:nfr]), dSb0=ex(dSb0), dSf0=ex(dSf0), x1=ex(x), v1=ex(v),
+         H0_closed=0.5 * (Rp @ Rp + Rm @ Rm) + Sb(x0[:nfr]) + 0.5 * (v_init @ accel(v_init, 1.0)),
+         primary_column=np.concatenate([np.arange(Npr), np.arange(Npr)]) if shared else np.arange(Nph))
 
 
 def gen_langevin(h, tag, seed, dt=0.02):
@@ -766,6 +781,8 @@ if __name__ == "__main__":
     gen_ssh("sq4_L8_a", 4, 8, 0.05, seed=45, with_alpha2=False)        # alpha2 = 0: analytic in x (complex-step HMC golden)
     gen_hmc_ssh("sq4_L8_a", seed=67, nb=1)
     gen_hmc_ssh("sq4_L8_a", seed=67, nb=3)
+    gen_hmc_ssh("sq4_L8_a", seed=68, nb=1, shared=True)
+    gen_hmc_ssh("sq4_L8_a", seed=68, nb=3, shared=True)
     gen_langevin_ssh("sq4_L8_a", seed=73)
     gen_fft()
     gen_kpm(h1, "sq4_L8")

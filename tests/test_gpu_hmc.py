@@ -266,15 +266,15 @@ def test_hmc_chains_in_lockstep_equal_single_chain_updates(tag, nch, nb, with_kp
 
 # ---------------------------------------------------------------------------------------------- SSH (bond phonons)
 
-def _ssh_golden_model(nb):
+def _ssh_golden_model(nb, shared=False):
     from elphdynamics_amd import lattice as lat
     from elphdynamics_amd import models
-    g, hgold = golden(f"hmc_ssh_sq4_L8_a_nb{nb}.npz"), golden("ssh_sq4_L8_a.npz")
+    g, hgold = golden(f"hmc_ssh_sq4_L8_a_nb{nb}{'_shared' if shared else ''}.npz"), golden("ssh_sq4_L8_a.npz")
     la = lat.Lattice(1, 4, 4, 1)
     L, dtau = int(g["Ltau"]), float(g["dtau"])
     m = models.SSHModel(la, L * dtau, dtau, tol=1e-7, maxiter=20000)
-    for (o1, o2, d) in lat.SQUARE_BONDS:
-        m.assign_hopping_(1.0, 0.1, 0.0, 0.5, o1, o2, d)
+    for (o1, o2, d), name in zip(lat.SQUARE_BONDS, ("", "") if shared else ("x", "y")):
+        m.assign_hopping_(1.0, 0.1, 0.0, 0.5, o1, o2, d, name=name)
     m.initialize_model_()
     assert np.array_equal(m.neighbor_table, hgold["table"]) and np.array_equal(m.checkerboard_perm, hgold["cbperm"])
     m.alpha[:], m.alpha2[:], m.mu[:] = hgold["alpha"], hgold["alpha2"], hgold["mu"]
@@ -306,6 +306,39 @@ def test_ssh_hmc_update_matches_dense_golden(nb):
     c = np.zeros((m.Nbonds, m.Ltau))
     c[idx] = np.cosh(m.dtau * (m.t[m.phonon_to_bond - 1][:, None] - m.alpha[:, None] * X))
     assert rel(m.cosht, c) < 1e-14
+    m.close()
+
+
+@pytest.mark.parametrize("nb", [1, 3])
+def test_ssh_hmc_shared_fields_match_dense_golden(nb):
+    """Two phonon types of the same name share their fields (primary_field, SSHModels.jl:480-502): class-summed fermion force,
+    Sb and K over primary fields — against the dense golden trajectory of the independent variables alone."""
+    from elphdynamics_amd import hmc, preconditioners as pc
+    g, hgold, m = _ssh_golden_model(nb, shared=True)
+    assert m.has_shared_fields and np.array_equal(m.primary_field[::m.Ltau] // m.Ltau, g["primary_column"])
+    fa = pc.FourierAccelerator(m)
+    fa.M[:] = g["faM"]
+    H = hmc.HybridMonteCarlo(m, fa, float(g["dt"]), int(g["nt"]) * float(g["dt"]), alpha=0.0, Nb=nb)
+    rnd = dict(R=g["R"], Rp=g["Rp"], Rm=g["Rm"], kpm_randn=None, u=0.0)
+    acc, its = hmc.update_(m, H, fa, None, randoms=rnd)
+    assert acc and H.flag == 0
+    assert abs(H.H0 - float(g["H0"])) < 1e-9 * abs(float(g["H0"])) and abs(H.H0 - float(g["H0_closed"])) < 1e-9 * abs(float(g["H0"]))
+    assert abs(H.H1 - float(g["H1"])) < 1e-6
+    assert rel(m.x, g["x1"]) < 1e-6 and rel(H.v, g["v1"]) < 1e-6
+    half = m.Ndof // 2
+    assert np.array_equal(m.x[:half], m.x[half:]) and np.array_equal(H.v[:half], H.v[half:])      # the classes stay together exactly
+    # fields that differ from their primary are refused, like update_model! (SSHModels.jl:549-559)
+    m.x[half] += 1e-3
+    with pytest.raises(Exception, match="primary"):
+        H.push_()
+    m.x[half] -= 1e-3
+    H.push_()
+    # generated momenta respect the sharing too
+    H.device_rng_(5)
+    acc, its = hmc.update_(m, H, fa, None)
+    assert H.flag == 0 and np.array_equal(m.x[:half], m.x[half:]) and np.array_equal(H.v[:half], H.v[half:])
+    with pytest.raises(Exception):
+        hmc.special_move_(m, H, hmc.SWAP, 0, 1)
     m.close()
 
 

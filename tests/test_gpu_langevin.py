@@ -77,7 +77,7 @@ def test_ssh_langevin_step_matches_dense_golden(cls, key):
     L, dtau = int(g["Ltau"]), float(g["dtau"])
     m = models.SSHModel(la, L * dtau, dtau, tol=1e-10, maxiter=20000)
     for (o1, o2, d) in lat.SQUARE_BONDS:
-        m.assign_hopping_(1.0, 0.1, 0.0, 0.5, o1, o2, d)
+        m.assign_hopping_(1.0, 0.1, 0.0, 0.5, o1, o2, d, name="xy"[d.index(1)])
     m.initialize_model_()
     m.alpha[:], m.alpha2[:], m.mu[:] = hg["alpha"], hg["alpha2"], hg["mu"]
     m.omega, m.omega4 = np.array(g["omega"]), np.array(g["omega4"])
@@ -182,4 +182,43 @@ def test_langevin_chains_match_single_trajectories(tag, scheme, with_kpm):
         assert np.all(np.abs(it - np.array([its[c][step] for c in range(nch)])) <= 1)
     for c in range(nch):
         assert rel(dyn.X[c] - x0, singles[c] - x0) < 1e-7
+    m.close()
+
+
+@pytest.mark.parametrize("scheme", [0, 2])
+def test_ssh_langevin_shared_fields_vs_oracle(oracle, scheme):
+    """The reference's ssh_langevin_square deck leaves both phonon types unnamed, so the x- and y-bond phonons share their
+    fields (primary_field, SSHModels.jl:480-502): two device steps vs the oracle's restatement of the sharing rules."""
+    from elphdynamics_amd import langevin, lattice as lat, models, preconditioners as pc, synth
+    la = lat.Lattice(1, 8, 8, 1)
+    m = models.SSHModel(la, 2.0, 0.05, tol=1e-9, maxiter=20000)
+    for (o1, o2, d) in lat.SQUARE_BONDS:
+        m.assign_hopping_(1.0, 0.1, 0.01, 0.5, o1, o2, d, omega4=0.02)            # no names, like the deck
+    m.initialize_model_()
+    assert m.has_shared_fields
+    half = m.Ndof // 2
+    y = 0.8 * synth.randn(41, half)
+    m.x[:] = np.concatenate([y, y])
+    models.update_model_(m)
+    fa = pc.FourierAccelerator(m)
+    pc.update_Q_(fa, m, 0.0, np.inf, 0.7)
+    om = oracle.make_model(1, m.Nsites, m.Ltau, m.neighbor_table, np.ascontiguousarray(m.cosht).reshape(-1).copy(),
+                           np.ascontiguousarray(m.sinht).reshape(-1).copy(), np.exp(m.dtau * m.mu))
+    Po = oracle.make_kpm(om, n=20)
+    P = pc.SymmetricKPMPreconditioner(m, n=20, buf=0.05, c1=1.0, c2=1.0)
+    dyn = [langevin.EulerDynamics, langevin.RungeKuttaDynamics, langevin.HeunsDynamics][scheme](m, fa, 0.01)
+    ssh = dict(t=m.t, alpha=m.alpha, alpha2=m.alpha2, phonon_to_bond=m.phonon_to_bond, cb_perm=m.checkerboard_perm,
+               primary_field=m.primary_field)
+    x_o = m.x.copy()
+    for step in range(2):
+        eta = synth.randn(2000 + step, m.Ndof)[m.primary_field]
+        rnd = dict(eta=eta, g1=synth.randn(2100 + step, m.Ndim), g2=synth.randn(2200 + step, m.Ndim),
+                   kpm_randn=synth.randn(2300 + step, 4 * m.Nsites))
+        x_prev = x_o
+        x_o, it_o = oracle.langevin_evolve_ssh(scheme, om, x_o, fa.Q, 0.01, rnd["eta"], rnd["g1"], rnd["g2"], m.omega, m.omega4, m.mu,
+                                               m.dtau, ssh, P=Po, kpm_randn=rnd["kpm_randn"], tol=1e-9, maxiter=20000)
+        it = langevin.evolve_(m, dyn, fa, P, randoms=rnd)
+        assert dyn.flag == 0 and abs(it - it_o) <= 1
+        assert rel(m.x - x_prev, x_o - x_prev) < 1e-6
+        assert np.array_equal(m.x[:half], m.x[half:])
     m.close()

@@ -92,8 +92,8 @@ def test_trajectory_with_kpm_preconditioner(oracle):
 
 # ---------------------------------------------------------------------------------------------- SSH (bond phonons)
 
-def _setup_ssh(oracle, nb):
-    g = golden(f"hmc_ssh_sq4_L8_a_nb{nb}.npz")
+def _setup_ssh(oracle, nb, shared=False):
+    g = golden(f"hmc_ssh_sq4_L8_a_nb{nb}{'_shared' if shared else ''}.npz")
     h = golden("ssh_sq4_L8_a.npz")
     N, L = int(g["N"]), int(g["Ltau"])
     om = oracle.make_model(1, N, L, h["table"], np.ascontiguousarray(h["cosht"]).copy(), np.ascontiguousarray(h["sinht"]).copy(),
@@ -101,11 +101,29 @@ def _setup_ssh(oracle, nb):
     return g, h, om, N, L, float(g["dtau"])
 
 
-def _run_ssh(oracle, g, h, om, dtau, dt, nt, nb, u=0.0, tol=1e-7, alpha=0.0, v=None, P=None, kpm_randn=None, maxiter=20000):
+def _run_ssh(oracle, g, h, om, dtau, dt, nt, nb, u=0.0, tol=1e-7, alpha=0.0, v=None, P=None, kpm_randn=None, maxiter=20000,
+             primary_field=None):
     rnd = dict(R=g["R"], Rp=g["Rp"], Rm=g["Rm"], u=u, kpm_randn=kpm_randn)
     v = np.zeros(g["x0"].size) if v is None else v
     return oracle.hmc_update_ssh(om, g["x0"], v, g["omega"], g["omega4"], h["mu"], dtau, g["faM"], h["t"], h["alpha"], h["alpha2"],
-                                 h["phonon_to_bond"], h["cbperm"], dt, nt, nb, alpha, rnd, P=P, tol=tol, maxiter=maxiter)
+                                 h["phonon_to_bond"], h["cbperm"], dt, nt, nb, alpha, rnd, P=P, tol=tol, maxiter=maxiter,
+                                 primary_field=primary_field)
+
+
+@pytest.mark.parametrize("nb", [1, 3])
+def test_ssh_shared_fields_match_dense_golden(oracle, nb):
+    """primary_field (SSHModels.jl:480-502, muldMdx! :820-826, calc_Sb PhononAction.jl:83, calc_K HMC.jl:720-738): the restated
+    rules reproduce the dense trajectory of the independent variables (make_golden.py::gen_hmc_ssh(shared=True))."""
+    g, h, om, N, L, dtau = _setup_ssh(oracle, nb, shared=True)
+    pf = (np.asarray(g["primary_column"])[:, None] * L + np.arange(L)[None, :]).reshape(-1)
+    acc, x1, v1, info = _run_ssh(oracle, g, h, om, dtau, float(g["dt"]), int(g["nt"]), nb, primary_field=pf)
+    assert acc and info["flag"] == 0
+    assert abs(info["H0"] - float(g["H0"])) < 1e-9 * abs(float(g["H0"]))
+    assert abs(info["H0"] - float(g["H0_closed"])) < 1e-9 * abs(float(g["H0"]))
+    assert abs(info["H1"] - float(g["H1"])) < 1e-6
+    assert rel(x1, g["x1"]) < 1e-6 and rel(v1, g["v1"]) < 1e-6
+    half = x1.size // 2
+    assert np.array_equal(x1[:half], x1[half:])
 
 
 @pytest.mark.parametrize("nb", [1, 3])
