@@ -29,7 +29,7 @@ constexpr int CW = 4;                 // waves per workgroup = adjacent column t
                                       // requests for a tile meet in the CU's L1 instead of each going to L2 (every wave
                                       // of a row group reads the same table lines — single-wave workgroups hot-spot a
                                       // few L2 channels)
-constexpr int NT_CAND[5] = {12, 20, 32, 44, 64};
+constexpr int NT_CAND[6] = {12, 20, 32, 40, 44, 64};
 
 __device__ __forceinline__ bool mf_done(const CgState *state, int rhs) {
     if (!state) return false;
@@ -133,6 +133,140 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma(double *__restrict__ out
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Twisted transform, one even/odd-tau split (L % 4 == 0; H = L/2, Q = L/4):
+//   forward   nu_k = A_k + w_k B_k,  A (B) = half-length twisted DFT of the even (odd) time slices, w_k = e^{-i pi (2k+1)/L};
+//             A_{H-1-k} = conj(A_k) for real data, so only k < Q is transformed: two (H x H) real GEMMs that share every A tile
+//             instead of one (L x L) — half the MFMAs, half the table traffic, and a wave produces all frequencies of its 16
+//             columns (the input is read once, not once per row group).
+//   inverse   v_{2j+p} = (2/L) Re sum_{k<Q} d^p_k e^{i pi (2k+1) j / H},  d^p_k = c_k + conj(c_{H-1-k}),  c_k = nu_k conj(w_k)^p
+// Row / reduction orderings are those of k_dft_mfma with K -> Q, L -> H.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int R2_NT_CAND[5] = {5, 10, 15, 20, 32};
+
+template <int NT, bool INV>
+__global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ out, const double *__restrict__ in,
+                                                      const double *__restrict__ W, const double2 *__restrict__ tw, int N, int L,
+                                                      const CgState *state, const double *__restrict__ rvec,
+                                                      double *__restrict__ rz_part, int nrz) {
+    const int rhs = blockIdx.z;
+    if (mf_done(state, rhs)) return;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, col = lane & 15, jj = lane >> 4;
+    const int ctile = blockIdx.x * CW + wv;
+    if (ctile * 16 >= N) return;
+    const int s = ctile * 16 + col;
+    const int sc = (s < N) ? s : N - 1;
+    const int H = L >> 1, Q = L >> 2;
+    double b0[NT], b1[NT];
+    if (!INV) {
+        const double *v = in + (size_t)rhs * N * L;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int j = 4 * tt + jj;
+            j = (j < H) ? j : H - 1;                                      // W is zero there
+            b0[tt] = v[(size_t)(2 * j) * N + sc];
+            b1[tt] = v[(size_t)(2 * j + 1) * N + sc];
+        }
+    } else {
+        const double2 *nu = reinterpret_cast<const double2 *>(in) + (size_t)rhs * H * N;
+        const int part = jj & 1;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int k = 2 * tt + (jj >> 1);
+            k = (k < Q) ? k : Q - 1;
+            const int kc = H - 1 - k;
+            const double2 a = nu[(size_t)k * N + sc], c = nu[(size_t)kc * N + sc], wk = tw[k], wc = tw[kc];
+            // p = 0: d = a + conj(c);   p = 1: d = a conj(w_k) + conj(c conj(w_kc)),  conj(w) = (w.x, -w.y)
+            const double a1x = a.x * wk.x + a.y * wk.y, a1y = a.y * wk.x - a.x * wk.y;
+            const double c1x = c.x * wc.x + c.y * wc.y, c1y = c.y * wc.x - c.x * wc.y;
+            b0[tt] = part ? (a.y - c.y) : (a.x + c.x);
+            b1[tt] = part ? (a1y - c1y) : (a1x + c1x);
+        }
+    }
+    const int mt0 = blockIdx.y * MG;
+    const double *Wg = W + ((size_t)mt0 * NT) * WAVE + lane;
+    double4_t acc0[MG], acc1[MG];
+#pragma unroll
+    for (int g = 0; g < MG; ++g) { acc0[g] = (double4_t){0.0, 0.0, 0.0, 0.0}; acc1[g] = (double4_t){0.0, 0.0, 0.0, 0.0}; }
+    constexpr int PF = (NT < 4) ? NT : 4;
+    double a[PF + 1][MG];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+#pragma unroll
+        for (int g = 0; g < MG; ++g) a[p][g] = Wg[(size_t)(g * NT + p) * WAVE];
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        if (tt + PF < NT) {
+#pragma unroll
+            for (int g = 0; g < MG; ++g) a[(tt + PF) % (PF + 1)][g] = Wg[(size_t)(g * NT + tt + PF) * WAVE];
+        }
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+            acc0[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt % (PF + 1)][g], b0[tt], acc0[g], 0, 0, 0);
+            acc1[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt % (PF + 1)][g], b1[tt], acc1[g], 0, 0, 0);
+        }
+    }
+    const int r0 = lane >> 4;
+    if (!INV) {
+        double2 *o = reinterpret_cast<double2 *>(out) + (size_t)rhs * H * N;
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 8 * (mt0 + g) + 2 * r0 + e;
+                if (s < N && k < Q) {
+                    const double ax = e ? acc0[g].z : acc0[g].x, ay = e ? acc0[g].w : acc0[g].y;
+                    const double bx = e ? acc1[g].z : acc1[g].x, by = e ? acc1[g].w : acc1[g].y;
+                    const int kc = H - 1 - k;
+                    const double2 wk = tw[k], wc = tw[kc];
+                    o[(size_t)k * N + s] = make_double2(ax + (wk.x * bx - wk.y * by), ay + (wk.x * by + wk.y * bx));
+                    // conj(A) + w_kc conj(B)
+                    o[(size_t)kc * N + s] = make_double2(ax + (wc.x * bx + wc.y * by), -ay + (wc.y * bx - wc.x * by));
+                }
+            }
+        }
+    } else {
+        double dot = 0.0;
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * (mt0 + g) + r0 + 4 * r;
+                if (s < N && j < H) {
+                    const size_t i = (size_t)rhs * N * L + (size_t)(2 * j) * N + s;
+                    const double v0 = acc0[g][r], v1 = acc1[g][r];
+                    out[i] = v0;
+                    out[i + N] = v1;
+                    if (rz_part) dot += rvec[i] * v0 + rvec[i + N] * v1;
+                }
+            }
+        }
+        if (rz_part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, WAVE);
+            if (lane == 0) {
+                const int nct = (N + 15) / 16;
+                const int G = nct * (int)gridDim.y, bid = (int)blockIdx.y * nct + ctile;
+                double *slots = rz_part + (size_t)rhs * nrz;
+                slots[bid] = dot;
+                for (int q = G + bid; q < nrz; q += G) slots[q] = 0.0;
+            }
+        }
+    }
+}
+
+int pick_nt_r2(int need) {
+    for (int c : R2_NT_CAND) if (need <= c) return c;
+    return 0;
+}
+
+bool r2_enabled() {
+    const char *e = getenv("ELPH_DFT_R2");         // read per call (tests compare both forms)
+    return !(e && atoi(e) == 0);
+}
+
 int pick_nt(int need) {
     for (int c : NT_CAND) if (need <= c) return c;
     return 0;
@@ -152,11 +286,27 @@ int launch(elph_handle_s *h, int nt, double *out, const double *in, const double
     const int L = (int)h->L;
 #define MF_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma<NTV, INV>), grid, block, 0, h->stream, out, in, W, N, L, K, st, rvec, rz_part, nrz); break;
     switch (nt) {
-        MF_CASE(12) MF_CASE(20) MF_CASE(32) MF_CASE(44) MF_CASE(64)
+        MF_CASE(12) MF_CASE(20) MF_CASE(32) MF_CASE(40) MF_CASE(44) MF_CASE(64)
         default: elph_set_error("dft_mfma: no kernel for %d reduction tiles", nt); return ELPH_E_UNSUPPORTED;
     }
 #undef MF_CASE
     return mf_check(INV ? "k_dft_mfma(inverse)" : "k_dft_mfma(forward)");
+}
+
+template <bool INV>
+int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, const double *in, int N, int nrhs, const CgState *st,
+              const double *rvec, double *rz_part, int nrz) {
+    const int nct = (N + 15) / 16;
+    const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)T.groups, (unsigned)nrhs), block(CW * WAVE);
+    const int L = (int)h->L;
+    const double2 *tw = reinterpret_cast<const double2 *>(h->d_r2_tw);
+#define R2_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2<NTV, INV>), grid, block, 0, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz); break;
+    switch (T.nt) {
+        R2_CASE(5) R2_CASE(10) R2_CASE(15) R2_CASE(20) R2_CASE(32)
+        default: elph_set_error("dft_mfma_r2: no kernel for %d reduction tiles", T.nt); return ELPH_E_UNSUPPORTED;
+    }
+#undef R2_CASE
+    return mf_check(INV ? "k_dft_mfma_r2(inverse)" : "k_dft_mfma_r2(forward)");
 }
 
 }  // namespace
@@ -169,10 +319,12 @@ bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N
     const elph_handle_s::MfmaTab &T = h->mf[which][inverse ? 1 : 0];
     if (!T.W) return false;
     if (force == 1) return true;
-    return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;
+    return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;        // (the split form has half the row groups, twice the work each)
 }
 
 int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {
+    if (which == 0 && h->mf_r2[0].W && r2_enabled())
+        return launch_r2<false>(h, h->mf_r2[0], reinterpret_cast<double *>(nu), vS, N, nrhs, st, nullptr, nullptr, 0);
     const elph_handle_s::MfmaTab &T = h->mf[which][0];
     const int K = which == 0 ? (int)(h->L + 1) / 2 : (int)h->L / 2 + 1;
     return launch<false>(h, T.nt, reinterpret_cast<double *>(nu), vS, T.W, N, K, T.groups, nrhs, st, nullptr, nullptr, 0);
@@ -180,6 +332,11 @@ int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS
 
 int elph_dft_mfma_inv(elph_handle_s *h, int which, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,
                       const double *rvec, double *rz_part, int nrz) {
+    if (which == 0 && h->mf_r2[1].W && r2_enabled()) {
+        const elph_handle_s::MfmaTab &T2 = h->mf_r2[1];
+        if (rz_part && (int)((N + 15) / 16) * T2.groups > nrz) { elph_set_error("dft_mfma_r2: %d partial slots needed, %d available", ((N + 15) / 16) * T2.groups, nrz); return ELPH_E_STATE; }
+        return launch_r2<true>(h, T2, outS, reinterpret_cast<const double *>(nu), N, nrhs, st, rvec, rz_part, nrz);
+    }
     const elph_handle_s::MfmaTab &T = h->mf[which][1];
     const int K = which == 0 ? (int)(h->L + 1) / 2 : (int)h->L / 2 + 1;
     if (rz_part && (int)((N + 15) / 16) * T.groups > nrz) { elph_set_error("dft_mfma: %d partial slots needed, %d available", ((N + 15) / 16) * T.groups, nrz); return ELPH_E_STATE; }
@@ -232,9 +389,55 @@ int elph_dft_mfma_build_tables(elph_handle_s *h) {
             HIPCHK(hipMemcpy(T.W, W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
+    // ---- the even/odd split of the twisted transform (L % 4 == 0): half-length tables and the twiddles
+    for (auto &T : h->mf_r2) if (T.W) { HIPCHK(hipFree(T.W)); T.W = nullptr; }
+    if (h->d_r2_tw) { HIPCHK(hipFree(h->d_r2_tw)); h->d_r2_tw = nullptr; }
+    if (L % 4 == 0 && L >= 8) {
+        const int H = L / 2, Q = L / 4;
+        auto angle = [&](int k, int j) { const long long m = ((long long)(2 * k + 1) * j) % (2LL * H); return M_PI * (double)m / (double)H; };
+        for (int inv = 0; inv < 2; ++inv) {
+            elph_handle_s::MfmaTab &T = h->mf_r2[inv];
+            const int nmt = (H + 15) / 16, ntt = (H + 3) / 4;          // rows: (k < Q, re/im) or j < H; reduction: j < H or (k < Q, re/im)
+            T.nt = pick_nt_r2(ntt);
+            if (T.nt == 0) continue;
+            T.groups = (nmt + MG - 1) / MG;
+            const int nmt_pad = T.groups * MG;
+            std::vector<double> W((size_t)nmt_pad * T.nt * WAVE, 0.0);
+            for (int mt = 0; mt < nmt; ++mt)
+                for (int tt = 0; tt < ntt; ++tt)
+                    for (int lane = 0; lane < WAVE; ++lane) {
+                        const int rho = lane & 15, jj = lane >> 4;
+                        double val = 0.0;
+                        if (!inv) {
+                            const int r0 = rho & 3, r = rho >> 2;
+                            const int k = 8 * mt + 2 * r0 + (r >> 1), part = r & 1, j = 4 * tt + jj;
+                            if (k < Q && j < H) { const double a = angle(k, j); val = part == 0 ? cos(a) : -sin(a); }
+                        } else {
+                            const int j = 16 * mt + rho, k = 2 * tt + (jj >> 1), part = jj & 1;
+                            if (j < H && k < Q) {
+                                const double a = angle(k, j), w = 2.0 / (double)L;
+                                val = part == 0 ? w * cos(a) : -(w * sin(a));
+                            }
+                        }
+                        W[((size_t)mt * T.nt + tt) * WAVE + lane] = val;
+                    }
+            HIPCHK(hipMalloc((void **)&T.W, W.size() * sizeof(double)));
+            HIPCHK(hipMemcpy(T.W, W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        std::vector<double> tw((size_t)2 * H);
+        for (int k = 0; k < H; ++k) {
+            const double a = M_PI * (double)(2 * k + 1) / (double)L;
+            tw[2 * (size_t)k] = cos(a);
+            tw[2 * (size_t)k + 1] = -sin(a);
+        }
+        HIPCHK(hipMalloc((void **)&h->d_r2_tw, tw.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(h->d_r2_tw, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return ELPH_OK;
 }
 
 void elph_dft_mfma_free(elph_handle_s *h) {
     for (auto &a : h->mf) for (auto &T : a) if (T.W) { (void)hipFree(T.W); T.W = nullptr; }
+    for (auto &T : h->mf_r2) if (T.W) { (void)hipFree(T.W); T.W = nullptr; }
+    if (h->d_r2_tw) { (void)hipFree(h->d_r2_tw); h->d_r2_tw = nullptr; }
 }

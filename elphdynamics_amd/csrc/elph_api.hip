@@ -1291,8 +1291,8 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         }
     };
     {
-        // ~0.1 ms of scalar work per chain; a thread costs ~30 us to start: one thread per 4 chains, at most 8
-        const int nthr = std::max(1, std::min(std::min(nch / 4, 8), (int)std::thread::hardware_concurrency()));
+        // ~0.15 ms of scalar work per chain; a thread costs ~30 us to start: one thread per 4 chains, at most 16
+        const int nthr = std::max(1, std::min(std::min(nch / 4, 16), (int)std::thread::hardware_concurrency()));
         if (nthr <= 1) {
             for (int c = 0; c < nch; ++c) one_chain(c);
         } else {

@@ -248,6 +248,9 @@ struct elph_handle_s {
     // batched tau-DFT on the matrix cores (dft_mfma.hip): W in A-tile order, [which: twisted/plain][fwd/inv]
     struct MfmaTab { double *W = nullptr; int nt = 0, groups = 0; };
     MfmaTab mf[2][2];
+    // twisted transform split once over even/odd tau (L % 4 == 0): half-length tables [fwd/inv] + the L/2 twiddles
+    MfmaTab mf_r2[2];
+    double *d_r2_tw = nullptr;             // [L/2] (cos, -sin) of pi (2k+1) / L
     double *d_diag = nullptr;              // fourier-acceleration diagonal staging
     int64_t diag_cap = 0;
     std::vector<int> fft_radices;
