@@ -145,11 +145,24 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma(double *__restrict__ out
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int R2_NT_CAND[5] = {5, 10, 15, 20, 32};
 
-template <int NT, bool INV>
+// XR (forward only): the CG residual update is done on the way in — r <- r - alpha (A p), alpha = rho / sum(p.Ap partials), the
+// r.r partials of the stop test and alpha[rhs] for the next k_cg_ap — i.e. k_cg_xr folded into the transform that reads r anyway
+// (one pass over r less and one launch less per preconditioned iteration).  Same arithmetic as k_cg_xr_fast; the r.r partials
+// are per column tile instead of per time slice.
+struct XrFuse {
+    const double *z;          // A p
+    double *r;                // residual, updated in place (the transform's input)
+    const double *pap;        // p.Ap partials [nrhs][npap]
+    double *rr;               // r.r partial slots [nrhs][rr_slots]
+    double *alpha;            // [nrhs]
+    int npap, rr_slots;
+};
+
+template <int NT, bool INV, bool XR>
 __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ out, const double *__restrict__ in,
                                                       const double *__restrict__ W, const double2 *__restrict__ tw, int N, int L,
                                                       const CgState *state, const double *__restrict__ rvec,
-                                                      double *__restrict__ rz_part, int nrz) {
+                                                      double *__restrict__ rz_part, int nrz, XrFuse X) {
     const int rhs = blockIdx.z;
     if (mf_done(state, rhs)) return;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, col = lane & 15, jj = lane >> 4;
@@ -159,7 +172,40 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ 
     const int sc = (s < N) ? s : N - 1;
     const int H = L >> 1, Q = L >> 2;
     double b0[NT], b1[NT];
-    if (!INV) {
+    if (!INV && XR) {
+        double a = 0.0;
+        for (int i = lane; i < X.npap; i += WAVE)
+            a += __hip_atomic_load(X.pap + (size_t)rhs * X.npap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+        const double rho = __hip_atomic_load(&state[2 * rhs].rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double alpha = rho / a;
+        double *rw = X.r + (size_t)rhs * N * L;
+        const double *zz = X.z + (size_t)rhs * N * L;
+        double acc = 0.0;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int j = 4 * tt + jj;
+            b0[tt] = 0.0; b1[tt] = 0.0;
+            if (j < H && s < N) {                                         // each element is touched by exactly one lane
+                const size_t i0 = (size_t)(2 * j) * N + s, i1 = i0 + N;
+                const double n0 = rw[i0] - alpha * zz[i0], n1 = rw[i1] - alpha * zz[i1];
+                rw[i0] = n0; rw[i1] = n1;
+                acc += n0 * n0;
+                acc += n1 * n1;
+                b0[tt] = n0; b1[tt] = n1;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+        if (lane == 0) {
+            const int nct = (N + 15) / 16;
+            double *slots = X.rr + (size_t)rhs * X.rr_slots;
+            slots[ctile] = acc;
+            for (int q = nct + ctile; q < X.rr_slots; q += nct) slots[q] = 0.0;
+            if (ctile == 0) X.alpha[rhs] = alpha;
+        }
+    } else if (!INV) {
         const double *v = in + (size_t)rhs * N * L;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
@@ -293,14 +339,14 @@ int launch(elph_handle_s *h, int nt, double *out, const double *in, const double
     return mf_check(INV ? "k_dft_mfma(inverse)" : "k_dft_mfma(forward)");
 }
 
-template <bool INV>
+template <bool INV, bool XR = false>
 int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, const double *in, int N, int nrhs, const CgState *st,
-              const double *rvec, double *rz_part, int nrz) {
+              const double *rvec, double *rz_part, int nrz, XrFuse X = XrFuse{}) {
     const int nct = (N + 15) / 16;
     const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)T.groups, (unsigned)nrhs), block(CW * WAVE);
     const int L = (int)h->L;
     const double2 *tw = reinterpret_cast<const double2 *>(h->d_r2_tw);
-#define R2_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2<NTV, INV>), grid, block, 0, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz); break;
+#define R2_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2<NTV, INV, XR>), grid, block, 0, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); break;
     switch (T.nt) {
         R2_CASE(5) R2_CASE(10) R2_CASE(15) R2_CASE(20) R2_CASE(32)
         default: elph_set_error("dft_mfma_r2: no kernel for %d reduction tiles", T.nt); return ELPH_E_UNSUPPORTED;
@@ -328,6 +374,20 @@ int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS
     const elph_handle_s::MfmaTab &T = h->mf[which][0];
     const int K = which == 0 ? (int)(h->L + 1) / 2 : (int)h->L / 2 + 1;
     return launch<false>(h, T.nt, reinterpret_cast<double *>(nu), vS, T.W, N, K, T.groups, nrhs, st, nullptr, nullptr, 0);
+}
+
+// forward twisted transform of r - alpha z with the residual update of k_cg_xr folded in (see XrFuse); usable: see below
+bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs) {
+    const char *e = getenv("ELPH_FUSE_XR");
+    if (e && atoi(e) == 0) return false;
+    return h->mf_r2[0].W && r2_enabled() && elph_dft_mfma_usable(h, 0, false, N, nrhs) && (N + 15) / 16 <= (int)h->L &&
+           h->mf_r2[0].groups == 1;           // one row group: every element of r belongs to exactly one wave
+}
+
+int elph_dft_mfma_fwd_xr(elph_handle_s *h, double2 *nu, double *rS, const double *zS, const double *pap, int npap, double *rr,
+                         double *alpha, int N, int nrhs, const CgState *st) {
+    XrFuse X{zS, rS, pap, rr, alpha, npap, (int)h->L};
+    return launch_r2<false, true>(h, h->mf_r2[0], reinterpret_cast<double *>(nu), rS, N, nrhs, st, nullptr, nullptr, 0, X);
 }
 
 int elph_dft_mfma_inv(elph_handle_s *h, int which, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,

@@ -1244,6 +1244,10 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     if (hop_fresh && h->sq_P > 0) {
         std::vector<double> qc((size_t)4 * h->N), qs((size_t)4 * h->N);
         for (size_t k = 0; k < qc.size(); ++k) { qc[k] = h->h_cbar[h->sq_bond[k]]; qs[k] = h->h_sbar[h->sq_bond[k]]; }
+        bool uni = true;
+        for (size_t k = 1; k < qc.size(); ++k) uni = uni && qc[k] == qc[0] && qs[k] == qs[0];
+        if (uni != h->sq_uniform) drop_graphs(h);
+        h->sq_uniform = uni;
         HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sq_sbar, qs.data(), sizeof(double) * qs.size(), hipMemcpyHostToDevice));
     }

@@ -178,6 +178,7 @@ struct elph_handle_s {
     double *d_lp_c = nullptr, *d_lp_s = nullptr, *d_lp_cbar = nullptr, *d_lp_sbar = nullptr;
     // even-L square lattice (L = 8 or 16) recognised in the bond table: P = L/8, per-site per-colour coefficients
     int sq_P = 0;
+    bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     void *hmc = nullptr;                   // HmcState (hmc.hip), owned
@@ -321,6 +322,9 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
 
 // ---- batched tau-axis transforms on the matrix cores (dft_mfma.hip); which: 0 twisted, 1 plain
 int elph_dft_mfma_build_tables(elph_handle_s *h);
+bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs);
+int elph_dft_mfma_fwd_xr(elph_handle_s *h, double2 *nu, double *rS, const double *zS, const double *pap, int npap, double *rr,
+                         double *alpha, int N, int nrhs, const CgState *st);
 void elph_dft_mfma_free(elph_handle_s *h);
 bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N, int nrhs);
 int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS, int N, int nrhs, const CgState *st);

@@ -1066,7 +1066,8 @@ int elph_launch_ebar(elph_handle_s *h, int nch) {
     return check_launch("k_ebar");
 }
 
-// z = P^-1 r on layout-S vectors.  cg_mode: 0 standalone; 1 inside CG (skip when done, fuse r.z partials)
+// z = P^-1 r on layout-S vectors.  cg_mode: 0 standalone; 1 inside CG (skip when done, fuse r.z partials); 2 as 1 with the
+// residual update r -= alpha A p (k_cg_xr) folded into the forward transform (rS is then written)
 int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode) {
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     CgBufs B = make_bufs(h, nrhs);
@@ -1085,7 +1086,10 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     KpmDev K = elph_kpm_dev(h);
     ModelDev m = elph_model_dev(h);
 
-    {
+    if (cg_mode == 2) {
+        int rcd = elph_dft_mfma_fwd_xr(h, h->d_nu, const_cast<double *>(rS), B.z, B.pap, B.npap, B.rr, B.alpha, N, nrhs, st);
+        if (rcd) return rcd;
+    } else {
         int rcd = elph_dft_fwd_twisted(h, h->d_nu, rS, N, nrhs, st);
         if (rcd) return rcd;
     }
@@ -1166,6 +1170,8 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
         rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1));
         h->ap_count++;
         if (rc) return rc;
+        if (use_prec && h->kpm_active && B.dot_lo == 0 && B.dot_hi == (int)h->N && elph_dft_mfma_xr_usable(h, (int)h->N, nrhs))
+            return elph_launch_kpm_apply(h, h->d_zp, h->d_r, nrhs, 2);      // k_cg_xr rides on the forward transform
         rc = elph_fast_cg_xr(h, B, nrhs, (int)(h->ap_count & 1));
         if (rc) return rc;
     } else {

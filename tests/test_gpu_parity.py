@@ -705,14 +705,21 @@ def test_mfma_dft_inside_batched_preconditioned_solve(monkeypatch):
     pc.setup_(P, rng=np.random.default_rng(3))
     _, B = configs.rhs(m, 24)
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("ELPH_DFT_MFMA", mode)
+    # scalar kernels | GEMM form with the even/odd split and k_cg_xr folded into the forward transform | split, separate k_cg_xr |
+    # direct GEMM form
+    for mode, env in (("0", {"ELPH_DFT_MFMA": "0"}), ("1", {"ELPH_DFT_MFMA": "1"}), ("nofuse", {"ELPH_DFT_MFMA": "1", "ELPH_FUSE_XR": "0"}),
+                      ("direct", {"ELPH_DFT_MFMA": "1", "ELPH_DFT_R2": "0"})):
+        for k in ("ELPH_DFT_MFMA", "ELPH_FUSE_XR", "ELPH_DFT_R2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         X = np.zeros_like(B)
         it, res, fl = models.ldiv_batched_(X, m, B, P=P)
         assert not fl.any()
         out[mode] = (X, it)
-    assert np.array_equal(out["0"][1], out["1"][1])
-    assert rel(out["1"][0], out["0"][0]) < 1e-10
+    for mode in ("1", "nofuse", "direct"):
+        assert np.array_equal(out["0"][1], out[mode][1]), mode
+        assert rel(out[mode][0], out["0"][0]) < 1e-10, mode
     m.close()
 
 
