@@ -1,0 +1,60 @@
+"""Host-side mirror of RunSimulation.jl's driver loops (run_simulation!, :25-144 Langevin, :149-300 HMC) around the GPU path:
+burn-in and simulation updates, reflection / swap updates at their frequencies, and at every meas_freq-th simulation update a
+fresh Green's-function estimate handed to the caller's `measure(sim, n_meas)` — the measurement containers, binning, files,
+checkpoints and the chemical-potential tuner of the reference are control plane and stay with the caller.
+
+    sim = process_input.process_input_file("deck.toml")
+    stats = run_simulation_(sim, measure=lambda sim, n: ...)
+    -> dict(iters, acceptance_rate, reflect_acceptance_rate, swap_acceptance_rate, simulation_time, measurement_time)   (:130-141, :283-297)
+"""
+import time
+
+from . import greens, hmc, langevin
+
+
+def _special(sim, dyn, n, reflect, swap, stats, P, rng):
+    m = sim.model
+    if reflect is not None and n % reflect.freq == 0:                                   # :188-191
+        stats["reflect_acceptance_rate"] += hmc.reflection_update_(m, dyn, reflect.nsites, P, rng=rng)
+    if swap is not None and n % swap.freq == 0:                                         # :194-197
+        stats["swap_acceptance_rate"] += hmc.swap_update_(m, dyn, swap.nbonds, P, rng=rng)
+
+
+def run_simulation_(sim, measure=None, rng=None):
+    m, fa, P, sp = sim.model, sim.fa, sim.preconditioner, sim.sim_params
+    rng = rng or getattr(m, "rng", None)
+    stats = dict(simulation_time=0.0, measurement_time=0.0, write_time=0.0, iters=0.0, acceptance_rate=0.0,
+                 reflect_acceptance_rate=0.0, swap_acceptance_rate=0.0)
+    is_hmc = isinstance(sim.simulation_dynamics, hmc.HybridMonteCarlo)
+    phases = ((sim.burnin_dynamics, sp.burnin, sim.burnin_reflect_update, sim.burnin_swap_update, False),
+              (sim.simulation_dynamics, sp.nsteps, sim.sim_reflect_update, sim.sim_swap_update, True))
+    for dyn, nsteps, reflect, swap, measuring in phases:
+        for n in range(1, nsteps + 1):
+            t0 = time.perf_counter()
+            if is_hmc:
+                acc, it = hmc.update_(m, dyn, fa, P, rng=rng, pull=False)
+                stats["iters"] += it
+                stats["acceptance_rate"] += float(acc)
+                _special(sim, dyn, n, reflect, swap, stats, P, rng)
+            else:
+                stats["iters"] += langevin.evolve_(m, dyn, fa, P, rng=rng, pull=False)
+            stats["simulation_time"] += time.perf_counter() - t0
+            if measuring and n % sp.meas_freq == 0:                                     # :91-95 / :250-254
+                t0 = time.perf_counter()
+                dyn.pull_()                                                             # model.x for the caller's observables
+                greens.update_(sim.Gr, m, P, rng=rng)                                   # make_measurements! starts with update!(Gr, …)
+                if measure is not None:
+                    measure(sim, n // sp.meas_freq)
+                stats["measurement_time"] += time.perf_counter() - t0
+    total = sp.nsteps + sp.burnin
+    stats["iters"] /= max(total, 1)                                                     # :131 / :284
+    if is_hmc:
+        stats["acceptance_rate"] /= max(total, 1)                                       # :287-289
+        nref = sum(nst // r.freq for r, nst in ((sim.burnin_reflect_update, sp.burnin), (sim.sim_reflect_update, sp.nsteps)) if r)
+        nswp = sum(nst // s.freq for s, nst in ((sim.burnin_swap_update, sp.burnin), (sim.sim_swap_update, sp.nsteps)) if s)
+        stats["reflect_acceptance_rate"] /= max(nref, 1)
+        stats["swap_acceptance_rate"] /= max(nswp, 1)
+    else:
+        stats["acceptance_rate"] = 1.0                                                  # :137
+    sim.simulation_dynamics.pull_()
+    return stats
