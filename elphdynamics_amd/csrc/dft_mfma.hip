@@ -303,6 +303,187 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming form of k_dft_mfma_r2: the W panel of the row group (MG x NT tiles, 51 KB at L = 160) is staged ONCE per workgroup in
+// LDS and the data tiles are prefetched PFB reduction steps ahead in a small register ring instead of being held for the whole
+// axis.  In the form above a wave runs load phase -> MFMA phase -> store phase and only other waves overlap them (2 waves per
+// SIMD: transform time = memory time + MFMA time); here the vector-memory queue carries nothing but the data stream, the
+// A operands come from LDS (ds_read, lgkmcnt), so loads run under the MFMAs of the same wave, and the smaller register
+// footprint admits a third wave per SIMD.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, bool INV, bool XR>
+__global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__ out, const double *__restrict__ in,
+                                                       const double *__restrict__ W, const double2 *__restrict__ tw, int N, int L,
+                                                       const CgState *state, const double *__restrict__ rvec,
+                                                       double *__restrict__ rz_part, int nrz, XrFuse X) {
+    extern __shared__ double Wl[];                                       // [MG][NT][64]
+    const int rhs = blockIdx.z;
+    if (mf_done(state, rhs)) return;                                     // uniform over the workgroup
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, col = lane & 15, jj = lane >> 4;
+    const int ctile = blockIdx.x * CW + wv;
+    const bool active = ctile * 16 < N;
+    const int s = ctile * 16 + col;
+    const int sc = (s < N) ? s : N - 1;
+    const int H = L >> 1, Q = L >> 2;
+    const int mt0 = blockIdx.y * MG;
+    constexpr int PFB = INV ? ((NT < 4) ? NT : 4) : ((NT < 8) ? NT : 8);   // the inverse also holds its r slice (below)
+    constexpr int RAW = (INV || XR) ? 4 : 2;
+    double raw[PFB + 1][RAW];
+    double2 twr[PFB + 1];
+
+    const double *v = in + (size_t)rhs * N * L;                                            // forward: real [tau][site]
+    const double2 *nu = reinterpret_cast<const double2 *>(in) + (size_t)rhs * H * N;       // inverse: complex [k][site]
+    double *rw = XR ? X.r + (size_t)rhs * N * L : nullptr;
+    const double *zz = XR ? X.z + (size_t)rhs * N * L : nullptr;
+    auto issue = [&](int tt, double (&dst)[RAW], double2 &twd) {
+        if (!INV) {
+            int j = 4 * tt + jj;
+            j = (j < H) ? j : H - 1;
+            const size_t i0 = (size_t)(2 * j) * N + sc;
+            if (XR) { dst[0] = rw[i0]; dst[1] = rw[i0 + N]; dst[2] = zz[i0]; dst[3] = zz[i0 + N]; }
+            else    { dst[0] = v[i0]; dst[1] = v[i0 + N]; }
+        } else {
+            int k = 2 * tt + (jj >> 1);
+            k = (k < Q) ? k : Q - 1;
+            const double2 a = nu[(size_t)k * N + sc], c = nu[(size_t)(H - 1 - k) * N + sc];
+            dst[0] = a.x; dst[1] = a.y; dst[2] = c.x; dst[3] = c.y;
+            twd = tw[k];
+        }
+    };
+    if (active) {
+#pragma unroll
+        for (int p = 0; p < PFB; ++p) issue(p, raw[p], twr[p]);
+    }
+    // ---- the W panel of this row group -> LDS (all waves, also those without a column tile: they pass the barrier)
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(W + (size_t)mt0 * NT * WAVE);
+        double2 *dst = reinterpret_cast<double2 *>(Wl);
+        for (int i = threadIdx.x; i < MG * NT * WAVE / 2; i += CW * WAVE) dst[i] = src[i];
+    }
+    double alpha = 0.0, acc = 0.0;
+    if (!INV && XR) {
+        double a = 0.0;
+        for (int i = lane; i < X.npap; i += WAVE)
+            a += __hip_atomic_load(X.pap + (size_t)rhs * X.npap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+        alpha = __hip_atomic_load(&state[2 * rhs].rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / a;
+    }
+    __syncthreads();
+    if (!active) return;
+    const double *Al = Wl + lane;
+    // inverse with the fused r.z: this lane's r values (the rows its accumulators will hold) are fetched now, under the MFMAs,
+    // instead of in the epilogue where nothing hides them
+    double rv0[INV ? MG * 4 : 1], rv1[INV ? MG * 4 : 1];
+    if (INV && rz_part) {
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int j = 16 * (mt0 + g) + (lane >> 4) + 4 * r;
+                j = (j < H) ? j : H - 1;
+                const size_t i = (size_t)rhs * N * L + (size_t)(2 * j) * N + sc;
+                rv0[g * 4 + r] = rvec[i];
+                rv1[g * 4 + r] = rvec[i + N];
+            }
+        }
+    }
+    double4_t acc0[MG], acc1[MG];
+#pragma unroll
+    for (int g = 0; g < MG; ++g) { acc0[g] = (double4_t){0.0, 0.0, 0.0, 0.0}; acc1[g] = (double4_t){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        if (tt + PFB < NT) issue(tt + PFB, raw[(tt + PFB) % (PFB + 1)], twr[(tt + PFB) % (PFB + 1)]);
+        const double (&q)[RAW] = raw[tt % (PFB + 1)];
+        double b0, b1;
+        if (!INV && XR) {
+            const int j = 4 * tt + jj;
+            const bool valid = (j < H) && (s < N);                       // each element of r belongs to exactly one lane
+            const double n0 = q[0] - alpha * q[2], n1 = q[1] - alpha * q[3];
+            if (valid) {
+                const size_t i0 = (size_t)(2 * j) * N + s;
+                rw[i0] = n0; rw[i0 + N] = n1;
+                acc += n0 * n0;
+                acc += n1 * n1;
+            }
+            b0 = valid ? n0 : 0.0; b1 = valid ? n1 : 0.0;
+        } else if (!INV) {
+            b0 = q[0]; b1 = q[1];
+        } else {
+            // d0 = nu_k + conj(nu_kc);  d1 = conj(w_k) (nu_k - conj(nu_kc))   (w_kc = -conj(w_k))
+            const double2 wk = twr[tt % (PFB + 1)];
+            const double sx = q[0] + q[2], sy = q[1] - q[3], ex = q[0] - q[2], ey = q[1] + q[3];
+            const double d1x = ex * wk.x + ey * wk.y, d1y = ey * wk.x - ex * wk.y;
+            b0 = (jj & 1) ? sy : sx;
+            b1 = (jj & 1) ? d1y : d1x;
+        }
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+            const double a = Al[(size_t)(g * NT + tt) * WAVE];
+            acc0[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0[g], 0, 0, 0);
+            acc1[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1[g], 0, 0, 0);
+        }
+    }
+    const int r0 = lane >> 4;
+    if (!INV) {
+        if (XR) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+            if (lane == 0) {
+                const int nct = (N + 15) / 16;
+                double *slots = X.rr + (size_t)rhs * X.rr_slots;
+                slots[ctile] = acc;
+                for (int qq = nct + ctile; qq < X.rr_slots; qq += nct) slots[qq] = 0.0;
+                if (ctile == 0) X.alpha[rhs] = alpha;
+            }
+        }
+        double2 *o = reinterpret_cast<double2 *>(out) + (size_t)rhs * H * N;
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 8 * (mt0 + g) + 2 * r0 + e;
+                if (s < N && k < Q) {
+                    const double ax = e ? acc0[g].z : acc0[g].x, ay = e ? acc0[g].w : acc0[g].y;
+                    const double bx = e ? acc1[g].z : acc1[g].x, by = e ? acc1[g].w : acc1[g].y;
+                    const double2 wk = tw[k];
+                    const double tx = wk.x * bx - wk.y * by, ty = wk.x * by + wk.y * bx;          // t = w_k B
+                    o[(size_t)k * N + s] = make_double2(ax + tx, ay + ty);                        // nu_k = A + t
+                    o[(size_t)(H - 1 - k) * N + s] = make_double2(ax - tx, -(ay - ty));           // nu_kc = conj(A - t)
+                }
+            }
+        }
+    } else {
+        double dot = 0.0;
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * (mt0 + g) + r0 + 4 * r;
+                if (s < N && j < H) {
+                    const size_t i = (size_t)rhs * N * L + (size_t)(2 * j) * N + s;
+                    const double v0 = acc0[g][r], v1 = acc1[g][r];
+                    out[i] = v0;
+                    out[i + N] = v1;
+                    if (rz_part) dot += rv0[g * 4 + r] * v0 + rv1[g * 4 + r] * v1;
+                }
+            }
+        }
+        if (rz_part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, WAVE);
+            if (lane == 0) {
+                const int nct = (N + 15) / 16;
+                const int G = nct * (int)gridDim.y, bid = (int)blockIdx.y * nct + ctile;
+                double *slots = rz_part + (size_t)rhs * nrz;
+                slots[bid] = dot;
+                for (int qq = G + bid; qq < nrz; qq += G) slots[qq] = 0.0;
+            }
+        }
+    }
+}
+
 int pick_nt_r2(int need) {
     for (int c : R2_NT_CAND) if (need <= c) return c;
     return 0;
@@ -346,6 +527,17 @@ int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, co
     const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)T.groups, (unsigned)nrhs), block(CW * WAVE);
     const int L = (int)h->L;
     const double2 *tw = reinterpret_cast<const double2 *>(h->d_r2_tw);
+    const size_t panel = (size_t)MG * T.nt * WAVE * sizeof(double);
+    const char *es = getenv("ELPH_DFT_STREAM");
+    if (panel <= 64 * 1024 && !(es && atoi(es) == 0)) {
+#define R2S_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2s<NTV, INV, XR>), grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); break;
+        switch (T.nt) {
+            R2S_CASE(5) R2S_CASE(10) R2S_CASE(15) R2S_CASE(20)
+            default: elph_set_error("dft_mfma_r2s: no kernel for %d reduction tiles", T.nt); return ELPH_E_UNSUPPORTED;
+        }
+#undef R2S_CASE
+        return mf_check(INV ? "k_dft_mfma_r2s(inverse)" : "k_dft_mfma_r2s(forward)");
+    }
 #define R2_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2<NTV, INV, XR>), grid, block, 0, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); break;
     switch (T.nt) {
         R2_CASE(5) R2_CASE(10) R2_CASE(15) R2_CASE(20) R2_CASE(32)
