@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
+from elphdynamics_amd import synth
 from oracle.oracle import dp, ip
 
 SQUARE = [(1, 1, (1, 0, 0)), (1, 1, (0, 1, 0))]
@@ -257,3 +258,39 @@ def test_muldMdx_finite_difference(oracle):
             mm = oracle.make_model(0, N, L, m._keep["table"], m._keep["c"], m._keep["s"], E)
             f.append(u @ oracle.mulM(mm, v))
         assert abs((f[0] - f[1]) / (2 * h) - out[k]) < 1e-6 * max(1.0, abs(out[k]))
+
+
+# ---------------------------------------------------------------------------------------------- kinetic-matrix aid
+
+@pytest.mark.parametrize("norb,Lsp,bonds", [(1, 4, [(1, 1, (1, 0, 0)), (1, 1, (0, 1, 0))]),
+                                            (2, 3, [(1, 2, (0, 0, 0)), (1, 2, (-1, 0, 0)), (1, 2, (0, -1, 0))])])
+def test_checkerboard_product_approximates_expm_of_kinetic_matrix(oracle, norb, Lsp, bonds):
+    """The reference's SSH kinetic-matrix dump (SSHModels.jl:915-944) exists to compare exp(-dtau K) with the checkerboard product:
+    the product of the 2x2 bond blocks equals exp(-dtau K(tau)) up to the O(dtau^2) Trotter error of non-commuting colours —
+    here with hoppings that differ on every bond and time slice (the SSH form), B(tau) read off mulM on unit vectors."""
+    import scipy.linalg
+    raw = oracle.neighbor_table(norb, Lsp, Lsp, 1, bonds)
+    tab, perm, iperm, grp, ng = oracle.ssh_initialize_table(raw)
+    N, L, nb = norb * Lsp * Lsp, 3, tab.shape[0]
+    tp = 1.0 + 0.3 * synth.randn(99, nb * L).reshape(nb, L)                  # t'[bond (checkerboard order)][tau]
+    errs = []
+    for dtau in (0.1, 0.05, 0.025):
+        c, s = np.cosh(dtau * tp), np.sinh(dtau * tp)
+        om = oracle.make_model(1, N, L, tab, c.reshape(-1), s.reshape(-1), np.ones(N))
+        err = 0.0
+        for t in range(L):
+            B = np.zeros((N, N))
+            for j in range(N):                                               # column j of B(t): y(t) = v(t) -/+ B(t) v(t-1)
+                v = np.zeros(N * L)
+                v[j * L + (t - 1) % L] = 1.0
+                y = oracle.mulM(om, v).reshape(N, L)[:, t]
+                B[:, j] = y if t == 0 else -y
+            K = np.zeros((N, N))
+            for n in range(nb):
+                i, jn = tab[n, 0] - 1, tab[n, 1] - 1
+                K[i, jn] -= tp[n, t]
+                K[jn, i] -= tp[n, t]
+            err = max(err, np.abs(B - scipy.linalg.expm(-dtau * K)).max())
+            assert abs(np.linalg.det(B) - 1.0) < 1e-12                        # every block has cosh^2 - sinh^2 = 1
+        errs.append(err)
+    assert errs[0] < 0.05 and 3.0 < errs[0] / errs[1] < 5.0 and 3.0 < errs[1] / errs[2] < 5.0      # O(dtau^2)
