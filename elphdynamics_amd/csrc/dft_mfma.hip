@@ -557,7 +557,10 @@ bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N
     const elph_handle_s::MfmaTab &T = h->mf[which][inverse ? 1 : 0];
     if (!T.W) return false;
     if (force == 1) return true;
-    return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;        // (the split form has half the row groups, twice the work each)
+    // measured crossover against the scalar-twiddle kernels (tools/time_dft_crossover.py, configs C and D): the split form wins
+    // from ~100 column-tile waves (8 right-hand sides at N = 256), the direct form from ~512 waves
+    if (which == 0 && h->mf_r2[inverse ? 1 : 0].W && r2_enabled()) return (long long)((N + 15) / 16) * nrhs >= 100;
+    return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;
 }
 
 int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {
