@@ -569,6 +569,21 @@ extern "C" int elph_hmc_get_state(elph_handle h, double *x, double *v) {
 // pseudofermions, energies, Metropolis test and failure flag.  A chain whose solve fails (flag > 0, HMC.jl:405-408) is
 // dead for this update: its field is put back to x0 at once (so that its remaining — ignored — solves stay cheap) and
 // it is rejected at the end.
+// model.μ changed (the chemical-potential tuner, MuFinder.jl:68-107: μ += Δμ on every site): refresh the device copy and the model
+extern "C" int elph_hmc_set_mu(elph_handle h, const double *mu) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st || !mu) { elph_set_error(st ? "null argument" : "elph_hmc_create / elph_langevin_create has not been called"); return st ? ELPH_E_ARG : ELPH_E_STATE; }
+    const size_t N = (size_t)h->N;
+    HIPCHK(hipMemcpyAsync(h->d_lam + (st->ssh ? 0 : 2 * N), mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (st->have_state) {
+        RC(update_model(h, st));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return ELPH_OK;
+}
+
 extern "C" int elph_hmc_set_shared_fields(elph_handle h, const int64_t *primary_column) {
     CHECK_H(h);
     HmcState *st = state_of(h);

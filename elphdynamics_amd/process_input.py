@@ -3,13 +3,13 @@ special updates of a run from one of the reference's TOML decks (examples/*.toml
 drives the GPU path unchanged.
 
     sim = process_input_file("holstein_hmc_square.toml")      ProcessInputFile.jl:34-121
-    sim.model, sim.Gr, sim.sim_params, sim.simulation_dynamics, sim.burnin_dynamics, sim.burnin_reflect_update,
+    sim.model, sim.Gr, sim.mu_tuner, sim.sim_params, sim.simulation_dynamics, sim.burnin_dynamics, sim.burnin_reflect_update,
     sim.sim_reflect_update, sim.burnin_swap_update, sim.sim_swap_update, sim.fa, sim.preconditioner
 
 What is read: [lattice], [holstein] / [ssh] (all tables, disorder widths included), [solver] (+ [solver.preconditioner]),
 [[fourier_acceleration]], [hmc] (+ [hmc.burnin], [hmc.reflection_update], [hmc.swap_update]) / [langevin],
 [measurements].num_random_vectors, [simulation] (seed, counts, names — kept in sim.sim_params, nothing is created on disk).
-What is not: the measurement container and its folders, the chemical-potential tuner, logging, checkpoints — the reference's
+[tune_density] (mu_tuner.py).  What is not: the measurement container and its folders, logging, checkpoints — the reference's
 control plane (SURVEY §8 "out of scope"); sim.input keeps the whole parsed deck for a driver that wants them.
 
 Only solver.type = "CG" exists on the GPU (the path of BASELINE.json); GMRES / BiCGStab decks raise.
@@ -150,6 +150,17 @@ def initialize_simulation_params(inp):
                            foldername=sim.get("foldername", ""), datafolder=sim["datafolder"])
 
 
+def initialize_mutuner(inp, model):
+    """ProcessInputFile.jl:611-624 (the tuner's log file is not created)."""
+    from .mu_tuner import MuTuner
+    mu0 = float(np.mean(model.mu))
+    td = inp.get("tune_density")
+    if td is None:
+        return MuTuner(False, mu0, 1.0 * model.Nsites, model.Nsites, model.beta, model.dtau, 0.75, 0.1)
+    return MuTuner(True, mu0, td["density"] * model.Nsites, model.Nsites, model.beta, model.dtau, td["memory"],
+                   td["kappa_min"] * model.Nsites)
+
+
 def initialize_dynamics(inp, model, fa, nchains=1):
     """ProcessInputFile.jl:626-700 -> (burnin_dynamics, simulation_dynamics).  The burn-in HybridMonteCarlo shares the
     device state of the simulation one (HybridMonteCarlo(simulation_dynamics, Δt, tr, α, Nb), HMC.jl:225-245)."""
@@ -190,12 +201,13 @@ def process_input_file(deck, device=0, nchains=1, rng=None):
     sim_params = initialize_simulation_params(inp)
     model = initialize_model(inp, rng, device)
     initialize_phonon_fields_(inp, model)
+    mu_tuner = initialize_mutuner(inp, model)
     P = initialize_preconditioner(inp, model)
     fa = initialize_fourieraccelerator(inp, model)
     burn, sim = initialize_dynamics(inp, model, fa, nchains)
     b_ref, s_ref = initialize_reflect_update(inp, model)
     b_swap, s_swap = initialize_swap_update(inp, model)
     Gr = greens.EstimateGreensFunction(model, int(inp.get("measurements", {}).get("num_random_vectors", 2)))
-    return SimpleNamespace(model=model, Gr=Gr, sim_params=sim_params, simulation_dynamics=sim, burnin_dynamics=burn,
+    return SimpleNamespace(model=model, Gr=Gr, mu_tuner=mu_tuner, sim_params=sim_params, simulation_dynamics=sim, burnin_dynamics=burn,
                            burnin_reflect_update=b_ref, sim_reflect_update=s_ref, burnin_swap_update=b_swap, sim_swap_update=s_swap,
                            fa=fa, preconditioner=P, input=inp)

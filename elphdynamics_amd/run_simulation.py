@@ -1,7 +1,8 @@
 """Host-side mirror of RunSimulation.jl's driver loops (run_simulation!, :25-144 Langevin, :149-300 HMC) around the GPU path:
 burn-in and simulation updates, reflection / swap updates at their frequencies, and at every meas_freq-th simulation update a
 fresh Green's-function estimate handed to the caller's `measure(sim, n_meas)` — the measurement containers, binning, files,
-checkpoints and the chemical-potential tuner of the reference are control plane and stay with the caller.
+checkpoints of the reference are control plane and stay with the caller; the chemical-potential tuner (mu_tuner.py)
+runs where the reference runs it.
 
     sim = process_input.process_input_file("deck.toml")
     stats = run_simulation_(sim, measure=lambda sim, n: ...)
@@ -10,6 +11,7 @@ checkpoints and the chemical-potential tuner of the reference are control plane 
 import time
 
 from . import greens, hmc, langevin
+from .mu_tuner import update_mu_
 
 
 def _special(sim, dyn, n, reflect, swap, stats, P, rng):
@@ -28,6 +30,9 @@ def run_simulation_(sim, measure=None, rng=None):
     is_hmc = isinstance(sim.simulation_dynamics, hmc.HybridMonteCarlo)
     phases = ((sim.burnin_dynamics, sp.burnin, sim.burnin_reflect_update, sim.burnin_swap_update, False),
               (sim.simulation_dynamics, sp.nsteps, sim.sim_reflect_update, sim.sim_swap_update, True))
+    tuner = getattr(sim, "mu_tuner", None)
+    tuning = tuner is not None and tuner.active
+    mu_freq = max(sp.meas_freq, 1)                                                      # :47
     for dyn, nsteps, reflect, swap, measuring in phases:
         for n in range(1, nsteps + 1):
             t0 = time.perf_counter()
@@ -38,6 +43,9 @@ def run_simulation_(sim, measure=None, rng=None):
                 _special(sim, dyn, n, reflect, swap, stats, P, rng)
             else:
                 stats["iters"] += langevin.evolve_(m, dyn, fa, P, rng=rng, pull=False)
+            if tuning and not measuring and (is_hmc or n % mu_freq == 0):               # burn-in: :65-68 (Langevin), :198-201 (HMC)
+                greens.update_(sim.Gr, m, P, rng=rng)
+                update_mu_(m, tuner, sim.Gr, dyn)
             stats["simulation_time"] += time.perf_counter() - t0
             if measuring and n % sp.meas_freq == 0:                                     # :91-95 / :250-254
                 t0 = time.perf_counter()
@@ -45,6 +53,8 @@ def run_simulation_(sim, measure=None, rng=None):
                 greens.update_(sim.Gr, m, P, rng=rng)                                   # make_measurements! starts with update!(Gr, …)
                 if measure is not None:
                     measure(sim, n // sp.meas_freq)
+                if tuning:                                                              # :98-100 / :255-257
+                    update_mu_(m, tuner, sim.Gr, dyn)
                 stats["measurement_time"] += time.perf_counter() - t0
     total = sp.nsteps + sp.burnin
     stats["iters"] /= max(total, 1)                                                     # :131 / :284

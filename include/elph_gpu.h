@@ -280,6 +280,10 @@ int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double 
                            const double *Rp, const double *Rm, const double *kpm_randn, const double *u_accept, int *accepted,
                            double *iters_per_solve, double *energies, int *flag);
 
+/* model.μ changed while the field lives on the device (the chemical-potential tuner, MuFinder.jl:68-107 adds Δμ to every site):
+ * new μ[nsites] for the HMC / Langevin state, followed by update_model!. */
+int elph_hmc_set_mu(elph_handle h, const double *mu);
+
 /* SSH phonon types of the same name (the default "" included) share their fields: primary_field of initialize_model!
  * (SSHModels.jl:480-502).  primary_column[Nph]: 0-based column of the primary phonon of every phonon (itself for a primary; the
  * sharing is the same on every time slice).  Call after elph_hmc_create_ssh / elph_langevin_create_ssh.  Then, as in the
