@@ -93,8 +93,9 @@ int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
     return h->lp_mc == 4 ? lp4::elph_fast_cg_xr(h, B, nrhs, parity) : lp6::elph_fast_cg_xr(h, B, nrhs, parity);
 }
-int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
-    return h->lp_mc == 4 ? lp4::elph_fast_kpm_cheb(h, nrhs, st) : lp6::elph_fast_kpm_cheb(h, nrhs, st);
+int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, bool *did_rz, const double *rr_part) {
+    return h->lp_mc == 4 ? lp4::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part)
+                         : lp6::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part);
 }
 int elph_fast_cg_resident(elph_handle_s *h, const CgBufs &B, int nrhs, bool *ran) {
     if (h->lp_mc != 4) { *ran = false; return ELPH_OK; }

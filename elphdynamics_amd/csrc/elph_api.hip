@@ -1181,7 +1181,7 @@ static int kpm_upload(elph_handle_s *h) {
         std::iota(ws, ws + Lo2, 0);
         std::stable_sort(ws, ws + Lo2, [&](int a, int b) { return ord[a] > ord[b]; });
         h->h_lam[2 * c] = (C.lam_hi + C.lam_lo) / 2;
-        h->h_lam[2 * c + 1] = (C.lam_hi - C.lam_lo) / 2;
+        h->h_lam[2 * c + 1] = C.active ? (C.lam_hi - C.lam_lo) / 2 : -1.0;      // < 0 marks the identity (KpmChainView::active)
     }
     const size_t ntot = (size_t)off;
     if ((int64_t)ntot > h->coeff_cap) {

@@ -120,6 +120,7 @@ struct KpmChainView {
     const int *order, *coff, *wsched;
     const double *Ebar;
     double a, b;              // 1/lam_mag, lam_avg/lam_mag
+    bool active;              // false: this chain's preconditioner is the identity (order 1, coefficient 1 everywhere)
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ KpmChainView kpm_chain_view(const KpmDev &K, int rhs, int N) {
@@ -133,10 +134,12 @@ __device__ __forceinline__ KpmChainView kpm_chain_view(const KpmDev &K, int rhs,
         const double avg = K.lam[2 * c], mag = K.lam[2 * c + 1];
         V.a = 1.0 / mag;
         V.b = avg / mag;
+        V.active = mag > 0.0;                                  // the host uploads a negative magnitude for an inactive chain
     } else {
         V.order = K.order; V.coff = K.coff; V.wsched = K.wsched; V.Ebar = K.Ebar;
         V.a = 1.0 / K.lam_mag;
         V.b = K.lam_avg / K.lam_mag;
+        V.active = K.active != 0;
     }
     return V;
 }
@@ -305,7 +308,8 @@ int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_resident(elph_handle_s *h, const CgBufs &B, int nrhs, bool *ran);
 CgBufs elph_make_bufs(elph_handle_s *h, int nrhs);
-int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
+int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part = nullptr, int nrz = 0, bool *did_rz = nullptr,
+                       const double *rr_part = nullptr);
 int elph_choose_T(const elph_handle_s *h, int nrhs);
 // packs per-bond values (order of h_bi/h_bj) into the lane-program layout [NE][64] (idle slots = fill)
 void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill);

@@ -1094,8 +1094,11 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         if (rcd) return rcd;
     }
     const size_t shm = (size_t)N * sizeof(double2);
+    bool rz_done = false;     // r.z partials already produced in frequency space by the Chebyshev kernel
     if (h->fast) {
-        int rcf = elph_fast_kpm_cheb(h, nrhs, st);
+        static const bool freq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
+        const bool want = cg_mode && freq_rz && 2 * Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N;
+        int rcf = elph_fast_kpm_cheb(h, nrhs, st, want ? B.rz : nullptr, B.nrz, &rz_done, B.rr);
         if (rcf) return rcf;
     } else {
         DISPATCH_NPL(gen_npl(h), {
@@ -1105,7 +1108,8 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     }
     // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz; the kernel clears the rest
     {
-        int rcd = elph_dft_inv_twisted(h, zS, h->d_nu, N, nrhs, st, cg_mode ? rS : nullptr, cg_mode ? B.rz : nullptr, B.nrz);
+        const bool fuse = cg_mode && !rz_done;
+        int rcd = elph_dft_inv_twisted(h, zS, h->d_nu, N, nrhs, st, fuse ? rS : nullptr, fuse ? B.rz : nullptr, B.nrz);
         if (rcd) return rcd;
     }
     return check_launch("kpm apply");
