@@ -312,7 +312,9 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ 
 // A operands come from LDS (ds_read, lgkmcnt), so loads run under the MFMAs of the same wave, and the smaller register
 // footprint admits a third wave per SIMD.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, bool INV, bool XR>
+// RZ (inverse only): fuse the time-domain r.z partial sums (needs this lane's slice of r); without it the inverse is a pure
+// transform (the Chebyshev kernel delivered r.z in frequency space) and runs with a deeper prefetch ring
+template <int NT, bool INV, bool XR, bool RZ>
 __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__ out, const double *__restrict__ in,
                                                        const double *__restrict__ W, const double2 *__restrict__ tw, int N, int L,
                                                        const CgState *state, const double *__restrict__ rvec,
@@ -327,7 +329,8 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
     const int sc = (s < N) ? s : N - 1;
     const int H = L >> 1, Q = L >> 2;
     const int mt0 = blockIdx.y * MG;
-    constexpr int PFB = INV ? ((NT < 4) ? NT : 4) : ((NT < 8) ? NT : 8);   // the inverse also holds its r slice (below)
+    constexpr int PFW = INV ? 4 : 8;                                                         // with RZ the inverse also holds its r slice (below)
+    constexpr int PFB = (NT < PFW) ? NT : PFW;
     constexpr int RAW = (INV || XR) ? 4 : 2;
     double raw[PFB + 1][RAW];
     double2 twr[PFB + 1];
@@ -375,8 +378,8 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
     const double *Al = Wl + lane;
     // inverse with the fused r.z: this lane's r values (the rows its accumulators will hold) are fetched now, under the MFMAs,
     // instead of in the epilogue where nothing hides them
-    double rv0[INV ? MG * 4 : 1], rv1[INV ? MG * 4 : 1];
-    if (INV && rz_part) {
+    double rv0[(INV && RZ) ? MG * 4 : 1], rv1[(INV && RZ) ? MG * 4 : 1];
+    if (INV && RZ) {
 #pragma unroll
         for (int g = 0; g < MG; ++g) {
 #pragma unroll
@@ -466,11 +469,11 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
                     const double v0 = acc0[g][r], v1 = acc1[g][r];
                     out[i] = v0;
                     out[i + N] = v1;
-                    if (rz_part) dot += rv0[g * 4 + r] * v0 + rv1[g * 4 + r] * v1;
+                    if (RZ) dot += rv0[g * 4 + r] * v0 + rv1[g * 4 + r] * v1;
                 }
             }
         }
-        if (rz_part) {
+        if (RZ) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, WAVE);
             if (lane == 0) {
@@ -530,7 +533,10 @@ int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, co
     const size_t panel = (size_t)MG * T.nt * WAVE * sizeof(double);
     const char *es = getenv("ELPH_DFT_STREAM");
     if (panel <= 64 * 1024 && !(es && atoi(es) == 0)) {
-#define R2S_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2s<NTV, INV, XR>), grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); break;
+#define R2S_CASE(NTV) case NTV: \
+        if (INV && rz_part) hipLaunchKernelGGL((k_dft_mfma_r2s<NTV, INV, XR, INV>), grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
+        else hipLaunchKernelGGL((k_dft_mfma_r2s<NTV, INV, XR, false>), grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
+        break;
         switch (T.nt) {
             R2S_CASE(5) R2S_CASE(10) R2S_CASE(15) R2S_CASE(20)
             default: elph_set_error("dft_mfma_r2s: no kernel for %d reduction tiles", T.nt); return ELPH_E_UNSUPPORTED;
