@@ -77,6 +77,26 @@ __device__ __forceinline__ void cb_sweep(double *buf0, double *buf1, const doubl
     }
 }
 
+// the same with the bond program (i | j << 16, cosh, sinh per bond) resident in LDS: the recursion applies it order_w times, and
+// reading four table entries per bond from global memory (L2 latency, every colour of every apply) was what the generic
+// Chebyshev kernel spent its time on (2.5 - 5 us per apply at N = 576 ... 1024)
+template <bool REVERSE>
+__device__ __forceinline__ void cb_sweep_z_lds(double2 *buf, const unsigned *ij, const double *c, const double *s, const ModelDev &m) {
+    for (int cc = 0; cc < m.ncol; ++cc) {
+        const int col = REVERSE ? (m.ncol - 1 - cc) : cc;
+        const int b0 = m.coloff[col], b1 = m.coloff[col + 1];
+        for (int n = b0 + threadIdx.x; n < b1; n += blockDim.x) {
+            const unsigned w = ij[n];
+            const int i = (int)(w & 0xFFFFu), j = (int)(w >> 16);
+            const double cn = c[n], sn = s[n];
+            const double2 t1 = buf[i], t2 = buf[j];
+            buf[i] = make_double2(cn * t1.x + sn * t2.x, cn * t1.y + sn * t2.y);
+            buf[j] = make_double2(cn * t2.x + sn * t1.x, cn * t2.y + sn * t1.y);
+        }
+        __syncthreads();
+    }
+}
+
 // complex variant for the KPM recursion (Checkerboard.jl:123-141,212-230 on complex N-vectors)
 template <bool REVERSE>
 __device__ __forceinline__ void cb_sweep_z(double2 *buf, const double *c, const double *s, const ModelDev &m) {
@@ -519,7 +539,8 @@ __global__ void __launch_bounds__(WAVE) k_dft_inv_twisted_full(double *__restric
 template <int NPL, bool TRANSPOSED>
 __device__ __forceinline__ void kpm_mulAprime(double2 (&out)[NPL], const double2 (&un)[NPL], double2 *buf,
                                               const double (&eb)[NPL], double a, double b, const KpmDev &K,
-                                              const ModelDev &m) {
+                                              const ModelDev &m, const unsigned *K_lds_ij, const double *K_lds_c,
+                                              const double *K_lds_s) {
     const int N = m.N;
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
@@ -527,7 +548,8 @@ __device__ __forceinline__ void kpm_mulAprime(double2 (&out)[NPL], const double2
         if (s < N) buf[s] = TRANSPOSED ? un[q] : make_double2(eb[q] * un[q].x, eb[q] * un[q].y);
     }
     __syncthreads();
-    cb_sweep_z<TRANSPOSED>(buf, K.cbar, K.sbar, m);
+    if (K_lds_ij) cb_sweep_z_lds<TRANSPOSED>(buf, K_lds_ij, K_lds_c, K_lds_s, m);
+    else cb_sweep_z<TRANSPOSED>(buf, K.cbar, K.sbar, m);
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * blockDim.x;
@@ -543,7 +565,8 @@ __device__ __forceinline__ void kpm_mulAprime(double2 (&out)[NPL], const double2
 template <int NPL, bool TRANSPOSED, bool CONJ>
 __device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&vin)[NPL], double2 *buf,
                                            const double (&eb)[NPL], const double2 *c, int order, const KpmDev &K,
-                                           const ModelDev &m, double a, double b) {
+                                           const ModelDev &m, double a, double b, const unsigned *lij, const double *lc,
+                                           const double *ls) {
     double2 um1[NPL], un[NPL], up1[NPL];
     {
         double2 c0 = c[0];
@@ -556,7 +579,7 @@ __device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&
         }
     }
     if (order > 1) {
-        kpm_mulAprime<NPL, TRANSPOSED>(up1, un, buf, eb, a, b, K, m);
+        kpm_mulAprime<NPL, TRANSPOSED>(up1, un, buf, eb, a, b, K, m, lij, lc, ls);
         for (int n = 2;; ++n) {
 #pragma unroll
             for (int q = 0; q < NPL; ++q) { um1[q] = un[q]; un[q] = up1[q]; }
@@ -568,7 +591,7 @@ __device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&
                 acc[q].y += cn.x * un[q].y + cn.y * un[q].x;
             }
             if (n == order) break;
-            kpm_mulAprime<NPL, TRANSPOSED>(up1, un, buf, eb, a, b, K, m);
+            kpm_mulAprime<NPL, TRANSPOSED>(up1, un, buf, eb, a, b, K, m, lij, lc, ls);
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 up1[q].x = 2.0 * up1[q].x - um1[q].x;
@@ -580,11 +603,23 @@ __device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&
 
 template <int NPL>
 __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, KpmDev K, ModelDev m, int Lo2,
-                                                   const CgState *state) {
+                                                   const CgState *state, int lds_tables) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double2 *buf = reinterpret_cast<double2 *>(lds);
     const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
     if (state && state[2 * rhs].done) return;   // `state` points at the current copy
+    // bond program -> LDS (after the slab: [N] double2 | [nb] cosh | [nb] sinh | [nb] i | j << 16)
+    const unsigned *lij = nullptr;
+    const double *lc = nullptr, *ls = nullptr;
+    if (lds_tables) {
+        double *tc = lds + 2 * (size_t)m.N, *ts = tc + m.nb;
+        unsigned *tij = reinterpret_cast<unsigned *>(ts + m.nb);
+        for (int n = threadIdx.x; n < m.nb; n += blockDim.x) {
+            tc[n] = K.cbar[n]; ts[n] = K.sbar[n];
+            tij[n] = (unsigned)m.bi[n] | ((unsigned)m.bj[n] << 16);
+        }
+        lij = tij; lc = tc; ls = ts;                               // the first barrier inside kpm_mulAprime publishes them
+    }
     const KpmChainView V = kpm_chain_view(K, rhs, m.N);
     const int w = V.wsched[blockIdx.y];
     const int N = m.N;
@@ -599,8 +634,8 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
         vin[q] = (s < N) ? u[s] : make_double2(0.0, 0.0);
         eb[q] = (s < N) ? V.Ebar[s] : 0.0;
     }
-    kpm_series<NPL, true, true>(mid, vin, buf, eb, c, order, K, m, V.a, V.b);     // M^-T[w,w], conj coefficients (:621-648)
-    kpm_series<NPL, false, false>(res, mid, buf, eb, c, order, K, m, V.a, V.b);   // M^-1[w,w]                     (:650-677)
+    kpm_series<NPL, true, true>(mid, vin, buf, eb, c, order, K, m, V.a, V.b, lij, lc, ls);     // M^-T[w,w], conj coefficients (:621-648)
+    kpm_series<NPL, false, false>(res, mid, buf, eb, c, order, K, m, V.a, V.b, lij, lc, ls);   // M^-1[w,w]                     (:650-677)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * blockDim.x;
@@ -1101,9 +1136,17 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         int rcf = elph_fast_kpm_cheb(h, nrhs, st, want ? B.rz : nullptr, B.nrz, &rz_done, B.rr);
         if (rcf) return rcf;
     } else {
-        DISPATCH_NPL(gen_npl(h), {
-            hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3((unsigned)gen_bs(h)), shm, h->stream, h->d_nu,
-                               K, m, Lo2, st);
+        // one thread per bond of the largest colour (up to 1024): a colour is then one LDS round trip per thread; the bond
+        // program rides in LDS when it fits next to the slab
+        int maxcol = 1;
+        for (int cidx = 0; cidx < h->ncol; ++cidx) maxcol = std::max(maxcol, h->h_coloff[(size_t)cidx + 1] - h->h_coloff[(size_t)cidx]);
+        const int cbs = std::min(1024, std::max(gen_bs(h), ELPH_WAVE * ((maxcol + ELPH_WAVE - 1) / ELPH_WAVE)));
+        const int cnpl = (N + cbs - 1) / cbs;
+        const size_t tab = (size_t)h->nb * (2 * sizeof(double) + sizeof(unsigned));
+        const int lds_tables = (N <= 65535 && shm + tab <= 64 * 1024) ? 1 : 0;
+        DISPATCH_NPL(cnpl, {
+            hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3((unsigned)cbs), shm + (lds_tables ? tab : 0),
+                               h->stream, h->d_nu, K, m, Lo2, st, lds_tables);
         });
     }
     // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz; the kernel clears the rest
