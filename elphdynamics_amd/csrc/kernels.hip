@@ -980,7 +980,12 @@ KpmDev elph_kpm_dev(const elph_handle_s *h) {
 }
 
 // generic kernels: workgroup of BS = 64*W threads, W = ceil(N/512); NPL = ceil(N/BS) <= 8
-static inline int gen_bs(const elph_handle_s *h) { return ELPH_WAVE * (int)((h->N + 511) / 512); }
+// block size of the generic (LDS-slab) kernels: one wave up to 512 sites; beyond that one thread per two sites (= per bond of a
+// full colour), so that a colour sweep is one table read + one LDS round trip per thread instead of four in sequence
+static inline int gen_bs(const elph_handle_s *h) {
+    if (h->N <= 512) return ELPH_WAVE;
+    return std::min(1024, ELPH_WAVE * (int)((h->N / 2 + ELPH_WAVE - 1) / ELPH_WAVE));
+}
 static inline int gen_npl(const elph_handle_s *h) { const int bs = gen_bs(h); return (int)((h->N + bs - 1) / bs); }
 
 #define DISPATCH_NPL(npl, CALL)                                   \
