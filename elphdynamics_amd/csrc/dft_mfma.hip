@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma(double *__restrict__ out
 //   inverse   v_{2j+p} = (2/L) Re sum_{k<Q} d^p_k e^{i pi (2k+1) j / H},  d^p_k = c_k + conj(c_{H-1-k}),  c_k = nu_k conj(w_k)^p
 // Row / reduction orderings are those of k_dft_mfma with K -> Q, L -> H.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int R2_NT_CAND[5] = {5, 10, 15, 20, 32};
+constexpr int R2_NT_CAND[8] = {5, 10, 15, 20, 25, 32, 40, 50};       // reduction tiles: L/8 rounded up (L <= 400)
 
 // XR (forward only): the CG residual update is done on the way in — r <- r - alpha (A p), alpha = rho / sum(p.Ap partials), the
 // r.r partials of the stop test and alpha[rhs] for the next k_cg_ap — i.e. k_cg_xr folded into the transform that reads r anyway
@@ -530,24 +530,34 @@ int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, co
     const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)T.groups, (unsigned)nrhs), block(CW * WAVE);
     const int L = (int)h->L;
     const double2 *tw = reinterpret_cast<const double2 *>(h->d_r2_tw);
+    // streaming form: W panel of a row group in LDS.  Up to 64 KB is the default dynamic-LDS limit; the long time axes
+    // (L = 256 ... 400: 80 ... 128 KB of the CU's 160 KB) ask for it explicitly, once per kernel instantiation
     const size_t panel = (size_t)MG * T.nt * WAVE * sizeof(double);
     const char *es = getenv("ELPH_DFT_STREAM");
-    if (panel <= 64 * 1024 && !(es && atoi(es) == 0)) {
-#define R2S_CASE(NTV) case NTV: \
-        if (INV && rz_part) hipLaunchKernelGGL((k_dft_mfma_r2s<NTV, INV, XR, INV>), grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
-        else hipLaunchKernelGGL((k_dft_mfma_r2s<NTV, INV, XR, false>), grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
-        break;
+    if (panel <= 144 * 1024 && !(es && atoi(es) == 0)) {
+        hipError_t attr_rc = hipSuccess;
+#define R2S_LAUNCH(NTV, RZV) do {                                                                                              \
+            auto kfn = k_dft_mfma_r2s<NTV, INV, XR, RZV>;                                                                       \
+            if (panel > 64 * 1024) {                                                                                            \
+                static bool raised = false;                                                                                     \
+                if (!raised) { attr_rc = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel); raised = (attr_rc == hipSuccess); } \
+            }                                                                                                                   \
+            if (attr_rc == hipSuccess) hipLaunchKernelGGL(kfn, grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
+        } while (0)
+#define R2S_CASE(NTV) case NTV: if (INV && rz_part) R2S_LAUNCH(NTV, INV); else R2S_LAUNCH(NTV, false); break;
         switch (T.nt) {
-            R2S_CASE(5) R2S_CASE(10) R2S_CASE(15) R2S_CASE(20)
+            R2S_CASE(5) R2S_CASE(10) R2S_CASE(15) R2S_CASE(20) R2S_CASE(25) R2S_CASE(32) R2S_CASE(40) R2S_CASE(50)
             default: elph_set_error("dft_mfma_r2s: no kernel for %d reduction tiles", T.nt); return ELPH_E_UNSUPPORTED;
         }
 #undef R2S_CASE
+#undef R2S_LAUNCH
+        if (attr_rc != hipSuccess) { elph_set_error("hipFuncSetAttribute(dynamic LDS %zu B) failed: %s", panel, hipGetErrorString(attr_rc)); return ELPH_E_HIP; }
         return mf_check(INV ? "k_dft_mfma_r2s(inverse)" : "k_dft_mfma_r2s(forward)");
     }
 #define R2_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2<NTV, INV, XR>), grid, block, 0, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); break;
     switch (T.nt) {
-        R2_CASE(5) R2_CASE(10) R2_CASE(15) R2_CASE(20) R2_CASE(32)
-        default: elph_set_error("dft_mfma_r2: no kernel for %d reduction tiles", T.nt); return ELPH_E_UNSUPPORTED;
+        R2_CASE(5) R2_CASE(10) R2_CASE(15) R2_CASE(20) R2_CASE(25) R2_CASE(32)
+        default: elph_set_error("dft_mfma_r2: no register-resident kernel for %d reduction tiles (ELPH_DFT_STREAM=0 needs L <= 256)", T.nt); return ELPH_E_UNSUPPORTED;
     }
 #undef R2_CASE
     return mf_check(INV ? "k_dft_mfma_r2(inverse)" : "k_dft_mfma_r2(forward)");
@@ -561,11 +571,12 @@ bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N
     const int force = e ? atoi(e) : -1;
     if (force == 0) return false;
     const elph_handle_s::MfmaTab &T = h->mf[which][inverse ? 1 : 0];
-    if (!T.W) return false;
+    const bool split = which == 0 && h->mf_r2[inverse ? 1 : 0].W && r2_enabled();      // exists up to L = 400, the direct form to 256
+    if (!T.W && !split) return false;
     if (force == 1) return true;
     // measured crossover against the scalar-twiddle kernels (tools/time_dft_crossover.py, configs C and D): the split form wins
     // from ~100 column-tile waves (8 right-hand sides at N = 256), the direct form from ~512 waves
-    if (which == 0 && h->mf_r2[inverse ? 1 : 0].W && r2_enabled()) return (long long)((N + 15) / 16) * nrhs >= 100;
+    if (split) return (long long)((N + 15) / 16) * nrhs >= 100;
     return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;
 }
 

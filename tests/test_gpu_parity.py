@@ -905,3 +905,30 @@ def test_odd_lattices_and_time_extents_vs_oracle(oracle, norb, L1, L2, bonds, Lt
     itk, resk, flk = models.ldiv_(xk, m, np.ascontiguousarray(B[0]), P=P)
     assert flk == 0 and rel(xk, X[0]) < 1e-6
     m.close()
+
+
+@pytest.mark.parametrize("L", [200, 256, 320, 400])
+def test_mfma_dft_long_time_axes(lib, L, monkeypatch):
+    """The split GEMM form of the twisted transform on long time axes (W panel of 64 ... 128 KB in LDS, several row groups for
+    L > 320): against numpy's FFT of the twisted sequence (TimeFreqFFTs.jl:55-73,112-130) and against the scalar kernels."""
+    from elphdynamics_amd import _lib
+    N = 37
+    m = RawModel(lib, 0, N, L, np.zeros((0, 2), dtype=np.int64))
+    try:
+        v = np.random.default_rng(L).standard_normal(N * L)
+        V = v.reshape(N, L)
+        ref = np.fft.fft(V * np.exp(-1j * np.pi * np.arange(L) / L)[None, :], axis=1)            # nu[site, omega]
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("ELPH_DFT_MFMA", mode)
+            nu = np.zeros(2 * N * L)
+            _lib.check(lib.elph_tau_to_omega(m.h, _lib.dptr(nu), _lib.dptr(v)))
+            back = np.zeros(N * L)
+            _lib.check(lib.elph_omega_to_tau(m.h, _lib.dptr(back), _lib.dptr(nu)))
+            z = (nu[0::2] + 1j * nu[1::2]).reshape(N, L)
+            assert np.abs(z - ref).max() < 1e-12 * np.abs(ref).max(), mode
+            assert rel(back, v) < 1e-13, mode
+            res[mode] = nu
+        assert rel(res["1"], res["0"]) < 1e-13
+    finally:
+        m.close()
