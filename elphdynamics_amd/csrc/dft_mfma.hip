@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma(double *__restrict__ out
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Twisted transform, one even/odd-tau split (L % 4 == 0; H = L/2, Q = L/4):
+// Twisted transform, one even/odd-tau split (L even; H = L/2, Q = ceil(H/2) independent frequencies):
 //   forward   nu_k = A_k + w_k B_k,  A (B) = half-length twisted DFT of the even (odd) time slices, w_k = e^{-i pi (2k+1)/L};
 //             A_{H-1-k} = conj(A_k) for real data, so only k < Q is transformed: two (H x H) real GEMMs that share every A tile
 //             instead of one (L x L) — half the MFMAs, half the table traffic, and a wave produces all frequencies of its 16
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ 
     if (ctile * 16 >= N) return;
     const int s = ctile * 16 + col;
     const int sc = (s < N) ? s : N - 1;
-    const int H = L >> 1, Q = L >> 2;
+    const int H = L >> 1, Q = (H + 1) >> 1;      // Q independent frequencies; H odd: the middle one is its own mirror
     double b0[NT], b1[NT];
     if (!INV && XR) {
         double a = 0.0;
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
     const bool active = ctile * 16 < N;
     const int s = ctile * 16 + col;
     const int sc = (s < N) ? s : N - 1;
-    const int H = L >> 1, Q = L >> 2;
+    const int H = L >> 1, Q = (H + 1) >> 1;      // Q independent frequencies; H odd: the middle one is its own mirror
     const int mt0 = blockIdx.y * MG;
     constexpr int PFW = INV ? 4 : 8;                                                         // with RZ the inverse also holds its r slice (below)
     constexpr int PFB = (NT < PFW) ? NT : PFW;
@@ -661,15 +661,16 @@ int elph_dft_mfma_build_tables(elph_handle_s *h) {
             HIPCHK(hipMemcpy(T.W, W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
-    // ---- the even/odd split of the twisted transform (L % 4 == 0): half-length tables and the twiddles
+    // ---- the even/odd split of the twisted transform (L even): half-length tables and the twiddles
     for (auto &T : h->mf_r2) if (T.W) { HIPCHK(hipFree(T.W)); T.W = nullptr; }
     if (h->d_r2_tw) { HIPCHK(hipFree(h->d_r2_tw)); h->d_r2_tw = nullptr; }
-    if (L % 4 == 0 && L >= 8) {
-        const int H = L / 2, Q = L / 4;
+    if (L % 2 == 0 && L >= 8) {
+        const int H = L / 2, Q = (H + 1) / 2;
         auto angle = [&](int k, int j) { const long long m = ((long long)(2 * k + 1) * j) % (2LL * H); return M_PI * (double)m / (double)H; };
         for (int inv = 0; inv < 2; ++inv) {
             elph_handle_s::MfmaTab &T = h->mf_r2[inv];
-            const int nmt = (H + 15) / 16, ntt = (H + 3) / 4;          // rows: (k < Q, re/im) or j < H; reduction: j < H or (k < Q, re/im)
+            // forward: rows (k < Q, re/im), 8 frequencies per row tile, reduction j < H; inverse: rows j < H, reduction (k < Q, re/im)
+            const int nmt = inv ? (H + 15) / 16 : (Q + 7) / 8, ntt = inv ? (Q + 1) / 2 : (H + 3) / 4;
             T.nt = pick_nt_r2(ntt);
             if (T.nt == 0) continue;
             T.groups = (nmt + MG - 1) / MG;
@@ -687,7 +688,8 @@ int elph_dft_mfma_build_tables(elph_handle_s *h) {
                         } else {
                             const int j = 16 * mt + rho, k = 2 * tt + (jj >> 1), part = jj & 1;
                             if (j < H && k < Q) {
-                                const double a = angle(k, j), w = 2.0 / (double)L;
+                                // H odd: k = (H-1)/2 is its own mirror, its folded pair d = c + conj(c) counts the term twice
+                                const double a = angle(k, j), w = ((H & 1) && k == Q - 1 ? 1.0 : 2.0) / (double)L;
                                 val = part == 0 ? w * cos(a) : -(w * sin(a));
                             }
                         }

@@ -907,10 +907,10 @@ def test_odd_lattices_and_time_extents_vs_oracle(oracle, norb, L1, L2, bonds, Lt
     m.close()
 
 
-@pytest.mark.parametrize("L", [200, 256, 320, 400])
+@pytest.mark.parametrize("L", [10, 18, 50, 90, 150, 200, 256, 320, 400])
 def test_mfma_dft_long_time_axes(lib, L, monkeypatch):
-    """The split GEMM form of the twisted transform on long time axes (W panel of 64 ... 128 KB in LDS, several row groups for
-    L > 320): against numpy's FFT of the twisted sequence (TimeFreqFFTs.jl:55-73,112-130) and against the scalar kernels."""
+    """The split GEMM form of the twisted transform on time axes with L = 2 (mod 4) (odd half length: the middle frequency is
+    its own mirror) and on long ones (W panel of 64 ... 128 KB in LDS, several row groups for L > 320): against numpy's FFT of the twisted sequence (TimeFreqFFTs.jl:55-73,112-130) and against the scalar kernels."""
     from elphdynamics_amd import _lib
     N = 37
     m = RawModel(lib, 0, N, L, np.zeros((0, 2), dtype=np.int64))
@@ -932,3 +932,39 @@ def test_mfma_dft_long_time_axes(lib, L, monkeypatch):
         assert rel(res["1"], res["0"]) < 1e-13
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("Lt", [30, 50])
+def test_batched_preconditioned_solve_with_odd_half_length(Lt, monkeypatch):
+    """Ltau = 2 (mod 4): the split transforms (odd half length), the folded residual update and the frequency-space r.z inside a
+    batched KPM-preconditioned solve — same iteration counts and solutions as the scalar-kernel path, and as the oracle."""
+    from elphdynamics_amd import lattice as lat, models, preconditioners as pc, synth
+    from oracle.oracle import Oracle
+    la = lat.Lattice(1, 8, 8, 1)
+    m = models.HolsteinModel(la, Lt * 0.1, 0.1, tol=1e-8, maxiter=20000)
+    for (o1, o2, d) in lat.SQUARE_BONDS:
+        m.assign_t_(1.0, o1, o2, d)
+    m.assign_omega_(1.0), m.assign_lambda_(1.0), m.assign_mu_(0.0)
+    m.initialize_model_()
+    m.x[:] = synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau)
+    models.update_model_(m)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    bmax, bmin = synth.randn(1, m.Nsites), synth.randn(2, m.Nsites)
+    pc.setup_(P, b_max=bmax, b_min=bmin)
+    B = np.stack([synth.randn(300 + r, m.Ndim) for r in range(24)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_DFT_MFMA", mode)
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B, P=P)
+        assert not fl.any()
+        out[mode] = (X, it)
+    assert np.array_equal(out["0"][1], out["1"][1]) and rel(out["1"][0], out["0"][0]) < 1e-10
+    orc = Oracle()
+    E = orc.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+    om = orc.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+    Po = orc.make_kpm(om, n=20)
+    orc.kpm_setup(Po, b_max=bmax, b_min=bmin)
+    xo, ito, reso, flo = orc.ldiv(om, B[0], P=Po, solver_tol=1e-8, solver_maxiter=20000)
+    assert flo == 0 and abs(int(out["1"][1][0]) - ito) <= 1 and rel(out["1"][0][0], xo) < 1e-6
+    m.close()
