@@ -17,71 +17,21 @@
 //
 // Reference semantics: see kernels.hip / SURVEY.md Appendix A.
 
-#include <cstdlib>
-
-#include "elph_internal.h"
-
-#define WAVE ELPH_WAVE
-
-// Ordering of LDS traffic inside ONE wavefront.  Every slab in this file is private to a wave, and the LDS
-// pipeline executes a wave's DS instructions in issue order, so a ds_read issued after a ds_write of the same
-// wave observes it without any s_waitcnt/s_barrier in between.  All that is needed is that the COMPILER keeps
-// the program order of possibly-aliasing LDS accesses: a pure compiler barrier, no instruction.
-// (Using __syncthreads() here costs an s_waitcnt lgkmcnt(0) per colour: one extra LDS round trip per stage.)
-#ifdef ELPH_LDS_SYNC
-#define WAVE_LDS_ORDER() __syncthreads()
-#else
-#define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
-#endif
-
-// device-coherent scalar traffic (experiment): agent-scope relaxed atomics => sc1 loads/stores that bypass L1/K$
-__device__ __forceinline__ double ld_coh(const double *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ CgState ld_state(const CgState *p) {
-    CgState s;
-    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-    unsigned long long w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_memcpy(&s, w, sizeof(CgState));
-    return s;
-}
-
-__device__ __forceinline__ double wave_sum2(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-
-__device__ __forceinline__ double reduce_partials2(const double *p, int n) {
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += WAVE) a += ld_coh(p + i);
-    return wave_sum2(a);
-}
-
-// XCD-aware mapping of a 1-D grid of 8*C*nrhs workgroups onto (tau, rhs); C = ceil(L/8)
-__device__ __forceinline__ bool xcd_map(int L, int &t, int &rhs) {
-    const int b = blockIdx.x;
-    const int C = (L + 7) >> 3;
-    const int xcd = b & 7, k = b >> 3;
-    rhs = k / C;
-    t = xcd * C + (k - rhs * C);
-    return t < L;
-}
-
+#include "cg_fast_common.h"
 
 #define ELPH_LP_MC 4
 #define LPNS lp4
 #include "cg_fast_impl.inc"
 #undef ELPH_LP_MC
 #undef LPNS
-#define ELPH_LP_MC 6
-#define LPNS lp6
-#include "cg_fast_impl.inc"
-#undef ELPH_LP_MC
-#undef LPNS
 
+// the 6-colour instantiation lives in cg_fast6.hip
+namespace lp6 {
+int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
+int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, bool *did_rz, const double *rr_part);
+}  // namespace lp6
 // ---- dispatch on the handle's lane-program width ------------------------------------------------------------
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec) {
     return h->lp_mc == 4 ? lp4::elph_fast_mul(h, which, yS, vS, nvec) : lp6::elph_fast_mul(h, which, yS, vS, nvec);
