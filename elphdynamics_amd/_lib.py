@@ -33,6 +33,7 @@ SIGNATURES = {
     "elph_set_expV": (c_int, [Handle, P_dbl]),
     "elph_update_model_ssh": (c_int, [Handle, P_dbl, P_dbl, P_dbl]),
     "elph_update_model_ssh_fields": (c_int, [Handle, P_dbl, c_i64, P_i64, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl]),
+    "elph_update_model_ssh_fields_chains": (c_int, [Handle, c_int, P_dbl, c_i64, P_i64, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl]),
     "elph_get_cosh_sinh": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_mulM": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_mulMT": (c_int, [Handle, P_dbl, P_dbl]),

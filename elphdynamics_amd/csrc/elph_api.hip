@@ -505,7 +505,7 @@ int elph_i_ssh_upload_params(elph_handle_s *h, int64_t nph, const int64_t *cb_in
     }
     if ((int64_t)np > h->ssh_nph_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        RC(dev_alloc(&h->d_ssh_x, std::max<size_t>(np * L, 1)));
+        RC(dev_alloc(&h->d_ssh_x, std::max<size_t>((size_t)h->ssh_chain_cap * np * L, 1)));
         RC(dev_alloc(&h->d_ssh_par, std::max<size_t>(3 * np, 1)));
         RC(dev_alloc(&h->d_ssh_cb, std::max<size_t>(np, 1)));
         h->ssh_nph_cap = (int64_t)np;
@@ -529,6 +529,7 @@ extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int6
     CHECK_H(h);
     if (nph > 0 && !x) { elph_set_error("null argument"); return ELPH_E_ARG; }
     RC(elph_i_ssh_upload_params(h, nph, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu));
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }
     const size_t np = (size_t)nph;
     if (np > 0) HIPCHK(hipMemcpyAsync(h->d_ssh_x, x, np * (size_t)h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_ssh_update(h, h->d_ssh_x, (int)np, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, dtau));
@@ -536,6 +537,27 @@ extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int6
     h->ssh_dtau = dtau;
     h->cs_host_stale = true;
     h->have_E = true;
+    return ELPH_OK;
+}
+
+// Several independent phonon configurations (chains) of one SSH deck in one handle: X[nchains][nph*ltau]; in a batched call
+// right-hand side r then uses the hopping tables of chain r % nchains (exp(dtau mu) and the couplings are the deck's, shared).
+extern "C" int elph_update_model_ssh_fields_chains(elph_handle h, int nchains, const double *X, int64_t nph, const int64_t *cb_index,
+                                                   const double *t_ph, const double *alpha, const double *alpha2,
+                                                   const double *t_bare_cb, const double *mu, double dtau) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    if (nchains < 1 || (nph > 0 && !X)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    RC(elph_i_reserve_chains(h, nchains));
+    RC(elph_i_ssh_upload_params(h, nph, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu));
+    const size_t np = (size_t)nph;
+    if (np > 0) HIPCHK(hipMemcpyAsync(h->d_ssh_x, X, (size_t)nchains * np * (size_t)h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_ssh_update(h, h->d_ssh_x, (int)np, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, dtau, 0, nchains));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->ssh_dtau = dtau;
+    h->cs_host_stale = true;
+    h->have_E = true;
+    h->kpm_ready = false;
     return ELPH_OK;
 }
 
@@ -763,9 +785,37 @@ int elph_i_ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, 
     return ldiv_core(h, nrhs, use_prec, maxiter, iters, resid, flag);
 }
 int elph_i_ensure_capacity(elph_handle_s *h, int nrhs) { return ensure_capacity(h, nrhs); }
+// SSH: one set of hopping tables (tau-major cosh/sinh + their lane-program copies) and one field buffer per chain
+static int ssh_reserve_chains(elph_handle_s *h, int nchains) {
+    if (nchains <= h->ssh_chain_cap) return ELPH_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    const size_t L = (size_t)h->L, nb = (size_t)h->nb, per = (size_t)h->lp_ne * ELPH_WAVE, nc = (size_t)nchains;
+    RC(dev_alloc(&h->d_c, nc * L * nb));
+    RC(dev_alloc(&h->d_s, nc * L * nb));
+    if (h->fast_capable) {
+        RC(dev_alloc(&h->d_lp_c, nc * L * per));
+        RC(dev_alloc(&h->d_lp_s, nc * L * per));
+        // idle lane-program slots: the identity bond (cosh, sinh) = (1, 0) on every slice of every chain
+        std::vector<double> one(nc * L * per, 1.0);
+        HIPCHK(hipMemcpy(h->d_lp_c, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(h->d_lp_s, 0, one.size() * sizeof(double)));
+    }
+    if (h->ssh_nph_cap > 0) RC(dev_alloc(&h->d_ssh_x, nc * (size_t)h->ssh_nph_cap * L));
+    h->ssh_chain_cap = nchains;
+    h->have_E = false;          // the tables are empty until the next update_model!
+    h->cs_host_stale = true;
+    return ELPH_OK;
+}
+
 int elph_i_reserve_chains(elph_handle_s *h, int nchains) {
     if (nchains < 1) { elph_set_error("nchains < 1"); return ELPH_E_ARG; }
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->kind == ELPH_MODEL_SSH) {
+        RC(ssh_reserve_chains(h, nchains));
+        if (h->nchains != nchains) { h->nchains = nchains; drop_graphs(h); h->kpm_ready = false; }
+        return ELPH_OK;
+    }
     const int64_t need = (int64_t)nchains * h->ndim;
     if (need > h->E_cap) {
         RC(dev_alloc(&h->d_E, (size_t)need));
@@ -1209,6 +1259,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     RC(need_model(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2, nch = h->nchains;
+    if (h->kind == ELPH_MODEL_SSH && nch > 1) { elph_set_error("KPM preconditioner for SSH chains: not built"); return ELPH_E_UNSUPPORTED; }
     const bool resized = ((int)h->kpm_chain.size() != nch);
     RC(kpm_reserve(h, nch));
     // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)

@@ -57,7 +57,19 @@ struct ModelDev {
     const double *lp_c;      // [1 or L][NE][64]
     const double *lp_s;
     int lp_tau_stride;       // 0 (Holstein) or NE*64 (SSH)
+    // SSH with several resident phonon configurations: one set of hopping tables per chain (0: shared tables)
+    long long cs_chain_stride, lp_chain_stride;
 };
+#ifdef __HIPCC__
+// the hopping tables of the chain right-hand side `rhs` belongs to (SSH chains; no-op otherwise)
+__device__ __forceinline__ void ssh_chain_select(ModelDev &m, int rhs) {
+    if (m.cs_chain_stride) {
+        const long long c = rhs % m.nchains;
+        m.c += c * m.cs_chain_stride; m.s += c * m.cs_chain_stride;
+        m.lp_c += c * m.lp_chain_stride; m.lp_s += c * m.lp_chain_stride;
+    }
+}
+#endif
 
 // Solver parameters travel BY VALUE in the kernel arguments (never through a small H2D copy + scalar load).
 struct CgParams {
@@ -169,6 +181,7 @@ struct elph_handle_s {
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
     int *d_ssh_cb = nullptr, *d_ssh_slot = nullptr;
     int64_t ssh_nph_cap = 0;
+    int ssh_chain_cap = 1;                 // SSH: chains whose hopping tables (d_c, d_s, d_lp_c, d_lp_s) and fields (d_ssh_x) are allocated
     int ssh_nph = -1;                      // fields of the last device-side update_model!
     double ssh_dtau = 0.0;
     bool cs_host_stale = false;            // SSH: d_c/d_s were produced on the device; h_c/h_s are not current
@@ -275,7 +288,7 @@ int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec
 int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec, int ncols = 0);
 int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain = 0);
 int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
-                           const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major = 0);
+                           const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major = 0, int nch = 1);
 int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev);
 int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
                             const int *cb0_dev, int nph, double dtau, int tau_major = 0, double scale = 1.0);

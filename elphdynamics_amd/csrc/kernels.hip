@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(1024) k_mul(double *__restrict__ y, const doub
     const double *vv = v + vec;
     double *yy = y + vec;
     const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
+    ssh_chain_select(m, (int)blockIdx.y);
     const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
     const double *c1 = m.c + (size_t)tp1 * m.cs_tau_stride, *s1 = m.s + (size_t)tp1 * m.cs_tau_stride;
     const double *Ech = m.E + (size_t)(blockIdx.y % m.nchains) * m.E_chain_stride;
@@ -316,6 +317,7 @@ __global__ void __launch_bounds__(1024) k_cg_ap(CgBufs B, ModelDev m, int parity
     const int tm1 = (t == 0) ? L - 1 : t - 1;
     const int tp1 = (t == L - 1) ? 0 : t + 1;
     const double sg0 = (t == 0) ? -1.0 : 1.0, sg1 = (tp1 == 0) ? -1.0 : 1.0;
+    ssh_chain_select(m, rhs);
     const double *c0 = m.c + (size_t)t * m.cs_tau_stride, *s0 = m.s + (size_t)t * m.cs_tau_stride;
     const double *c1 = m.c + (size_t)tp1 * m.cs_tau_stride, *s1 = m.s + (size_t)tp1 * m.cs_tau_stride;
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
@@ -655,6 +657,7 @@ __global__ void __launch_bounds__(256) k_ssh_fill(double *__restrict__ c, double
                                                   const int *__restrict__ slot, int nb, int L, int lp_stride, double dtau) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)nb * L) return;
+    { const size_t ch = blockIdx.y; c += ch * (size_t)nb * L; s += ch * (size_t)nb * L; lpc += ch * (size_t)L * lp_stride; lps += ch * (size_t)L * lp_stride; }
     const int n = (int)(i % nb), t = (int)(i / nb);
     const double a = dtau * tbare[n], cc = cosh(a), ss = sinh(a);
     c[i] = cc; s[i] = ss;
@@ -668,6 +671,8 @@ __global__ void __launch_bounds__(256) k_ssh_fields(double *__restrict__ c, doub
                                                     double dtau, int x_tau_major) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)nph * L) return;
+    { const size_t ch = blockIdx.y; c += ch * (size_t)nb * L; s += ch * (size_t)nb * L; lpc += ch * (size_t)L * lp_stride; lps += ch * (size_t)L * lp_stride;
+      x += ch * (size_t)nph * L; }
     const int t = (int)(i % L), p = (int)(i / L);           // field index = (phonon - 1) Ltau + tau  (Utilities.jl:12-15)
     const double xt = x_tau_major ? x[(size_t)t * nph + p] : x[i];   // tau-major: the HMC trajectory's device layout
     const double sg = (xt > 0.0) ? 1.0 : ((xt < 0.0) ? -1.0 : 0.0);
@@ -948,7 +953,7 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.cs_tau_stride = (h->kind == ELPH_MODEL_SSH) ? (int)h->nb : 0;
     m.E_tau_stride = (h->kind == ELPH_MODEL_SSH) ? 0 : (int)h->N;
     m.nchains = h->nchains;
-    m.E_chain_stride = (long long)h->ndim;
+    m.E_chain_stride = (h->kind == ELPH_MODEL_SSH) ? 0 : (long long)h->ndim;      // SSH: exp(dtau mu) is one per-site vector for all chains
     m.bi = h->d_bi; m.bj = h->d_bj; m.coloff = h->d_coloff;
     m.c = h->d_c; m.s = h->d_s; m.E = h->d_E;
     if (h->solo_chain >= 0) {   // one right-hand side of a chains batch re-solved alone: present ITS configuration as the only one
@@ -957,6 +962,17 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     }
     m.lp_ij = h->d_lp_ij; m.lp_c = h->d_lp_c; m.lp_s = h->d_lp_s;
     m.lp_tau_stride = (h->kind == ELPH_MODEL_SSH) ? h->lp_ne * ELPH_WAVE : 0;
+    m.cs_chain_stride = m.lp_chain_stride = 0;
+    if (h->kind == ELPH_MODEL_SSH && h->nchains > 1) {
+        const long long cs = (long long)h->L * h->nb, lp = (long long)h->L * h->lp_ne * ELPH_WAVE;
+        if (h->solo_chain >= 0) {
+            m.c += (size_t)h->solo_chain * cs; m.s += (size_t)h->solo_chain * cs;
+            m.lp_c += (size_t)h->solo_chain * lp; m.lp_s += (size_t)h->solo_chain * lp;
+            m.E = h->d_E;                         // exp(dtau mu) is shared by the chains
+        } else {
+            m.cs_chain_stride = cs; m.lp_chain_stride = lp;
+        }
+    }
     return m;
 }
 
@@ -1067,16 +1083,17 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
 }
 
 int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
-                           const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major) {
+                           const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major, int nch) {
     const int nb = (int)h->nb, L = (int)h->L, lp_stride = h->lp_ne * ELPH_WAVE;
     const int *slot = h->fast_capable ? slot_dev : nullptr;
+    if (nch > h->ssh_chain_cap) { elph_set_error("%d chains, tables for %d", nch, h->ssh_chain_cap); return ELPH_E_STATE; }
     if (nb > 0) {
         const long long n1 = (long long)nb * L;
-        hipLaunchKernelGGL(k_ssh_fill, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, h->d_c, h->d_s, h->d_lp_c, h->d_lp_s,
+        hipLaunchKernelGGL(k_ssh_fill, dim3((unsigned)((n1 + 255) / 256), (unsigned)nch), dim3(256), 0, h->stream, h->d_c, h->d_s, h->d_lp_c, h->d_lp_s,
                            tbare_dev, slot, nb, L, lp_stride, dtau);
         if (nph > 0) {
             const long long n2 = (long long)nph * L;
-            hipLaunchKernelGGL(k_ssh_fields, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, h->d_c, h->d_s, h->d_lp_c,
+            hipLaunchKernelGGL(k_ssh_fields, dim3((unsigned)((n2 + 255) / 256), (unsigned)nch), dim3(256), 0, h->stream, h->d_c, h->d_s, h->d_lp_c,
                                h->d_lp_s, x_dev, par_dev, cb0_dev, slot, nph, nb, L, lp_stride, dtau, x_tau_major);
         }
     }

@@ -295,9 +295,17 @@ def update_model_chains_(model, X):
     """Several independent phonon configurations (chains) in one handle: X is (nchains, Ndof); in a batched call
     right-hand side r then uses chain r % nchains (the reference runs chains as separate processes,
     ElPhDynamics.jl:90-95).  model.x is left untouched."""
-    assert model.kind == HOLSTEIN
     X = np.ascontiguousarray(X, dtype=np.float64)
     assert X.ndim == 2 and X.shape[1] == model.Ndof
+    if model.kind == SSH:
+        cb_index = np.ascontiguousarray(model.checkerboard_perm[model.phonon_to_bond - 1], dtype=np.int64)
+        t_ph = np.ascontiguousarray(model.t[model.phonon_to_bond - 1], dtype=np.float64)
+        check(model._lib.elph_update_model_ssh_fields_chains(
+            model._h, X.shape[0], dptr(X), model.Nph, iptr(cb_index), dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)),
+            dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb), dptr(np.ascontiguousarray(model.mu)), model.dtau))
+        model._cs_stale = True
+        model._nchains = X.shape[0]
+        return
     check(model._lib.elph_update_model_holstein_chains(model._h, X.shape[0], dptr(X), dptr(model.lam), dptr(model.lam2),
                                                        dptr(model.mu), model.dtau))
     model._nchains = X.shape[0]

@@ -100,6 +100,13 @@ int elph_set_expV(elph_handle h, const double *expnDtauV);
 int elph_update_model_ssh(elph_handle h, const double *cosht, const double *sinht,
                           const double *expDtauMu);
 
+/* Several independent phonon configurations (chains) of one SSH deck in one handle (the reference runs chains as separate
+ * processes, ElPhDynamics.jl:90-95): X[nchains][nph*ltau]; the other arguments as elph_update_model_ssh_fields.  In a batched
+ * call right-hand side r then uses the hopping tables of chain r % nchains. */
+int elph_update_model_ssh_fields_chains(elph_handle h, int nchains, const double *X, int64_t nph, const int64_t *cb_index,
+                                        const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb,
+                                        const double *mu, double dtau);
+
 /* update_model!(ssh) computed on the device from the phonon fields — SSHModels.jl:510-562: expΔτμ = exp(Δτ μ); per field
  * t′ = t − (α x + sign(x) α₂ x²), cosht[τ, index] = cosh(Δτ t′), sinht likewise (no host cosh/sinh, no tables over PCIe).
  *   x         double[nph * ltau]  ssh.x (field = (phonon−1)·Lτ + τ)

@@ -568,14 +568,17 @@ def test_fermion_force_is_the_gradient_of_the_action(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("C", 4, 2), ("C", 32, 2)])
+@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("C", 4, 2), ("C", 32, 2), ("e", 3, 2), ("E", 4, 2), ("E", 16, 2)])
 def test_independent_chains_in_one_batch(tag, nchains, per):
     """Several phonon configurations resident in one handle (the reference runs chains as separate processes,
     ElPhDynamics.jl:90-95): right-hand side r of a batch uses the fermion matrix of chain r % nchains, and each
     solve is bit-identical to the same solve done alone on a single-configuration model."""
     from elphdynamics_amd import configs, models, synth
     m = configs.make_model(tag, tol=1e-5)
-    X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=5000 + c) for c in range(nchains)])
+    if m.kind == models.SSH:      # bond phonons: every chain its own hopping tables (cosh/sinh per bond and time slice)
+        X = np.stack([m.x * (0.55 + 0.9 * c / nchains) * (1.0 + 0.2 * synth.randn(5000 + c, m.Ndof)) for c in range(nchains)])
+    else:
+        X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=5000 + c) for c in range(nchains)])
     nrhs = nchains * per
     B = np.stack([synth.randn(7000 + r, m.Ndim) for r in range(nrhs)])
     models.update_model_chains_(m, X)
@@ -590,7 +593,7 @@ def test_independent_chains_in_one_batch(tag, nchains, per):
         x1 = np.zeros(m.Ndim)
         it1, res1, fl1 = models.ldiv_(x1, m1, np.ascontiguousarray(B[r]))
         assert fl1 == 0
-        if nrhs * m.Ltau // 8 < 1024:        # same kernel variant as the single solve => same bits
+        if nrhs * m.Ltau // 5 < 1024:        # same kernel variant (one slice per wave) as the single solve => same bits
             assert it1 == it[r] and np.array_equal(x1, Xs[r])
         else:                                 # large batches use k_cg_ap_chunk<T>: p.z partial sums grouped per chunk,
             assert abs(it1 - it[r]) <= 5      # so round-off (not the arithmetic per element) differs from the T=1 kernel
