@@ -1259,7 +1259,6 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     RC(need_model(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2, nch = h->nchains;
-    if (h->kind == ELPH_MODEL_SSH && nch > 1) { elph_set_error("KPM preconditioner for SSH chains: not built"); return ELPH_E_UNSUPPORTED; }
     const bool resized = ((int)h->kpm_chain.size() != nch);
     RC(kpm_reserve(h, nch));
     // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)
@@ -1269,34 +1268,61 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         HIPCHK(hipStreamSynchronize(h->stream));
         h->h_cbar = h->h_c;
         h->h_sbar = h->h_s;
+        h->kpm_hop_per_chain = false;
     } else {
+        // Ebar = exp(dtau mu): the same for every chain (replicated so that chain views need no special case)
         HIPCHK(hipMemcpy(h->h_Ebar.data(), h->d_E, sizeof(double) * N, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(h->d_Ebar, h->d_E, sizeof(double) * N, hipMemcpyDeviceToDevice));
+        for (int c = 1; c < nch; ++c) std::copy(h->h_Ebar.begin(), h->h_Ebar.begin() + N, h->h_Ebar.begin() + (size_t)c * N);
+        HIPCHK(hipMemcpy(h->d_Ebar, h->h_Ebar.data(), sizeof(double) * (size_t)nch * N, hipMemcpyHostToDevice));
+        h->kpm_hop_per_chain = nch > 1;
+        if (nch > h->kpm_hop_cap) {          // averaged hopping tables per chain (and their lane-program / register-exchange images)
+            RC(dev_alloc(&h->d_cbar, (size_t)nch * h->nb));
+            RC(dev_alloc(&h->d_sbar, (size_t)nch * h->nb));
+            if (h->fast_capable) {
+                RC(dev_alloc(&h->d_lp_cbar, (size_t)nch * h->lp_ne * ELPH_WAVE));
+                RC(dev_alloc(&h->d_lp_sbar, (size_t)nch * h->lp_ne * ELPH_WAVE));
+            }
+            if (h->sq_P > 0) {
+                RC(dev_alloc(&h->d_sq_cbar, (size_t)nch * 4 * h->N));
+                RC(dev_alloc(&h->d_sq_sbar, (size_t)nch * 4 * h->N));
+            }
+            h->kpm_hop_cap = nch;
+        }
+        h->h_cbar.resize((size_t)nch * h->nb);
+        h->h_sbar.resize((size_t)nch * h->nb);
         if (h->nb > 0) {   // tau-means of cosht, sinht from the device tables (they may have been produced there)
-            RC(elph_launch_cs_bar(h, h->d_cbar, h->d_sbar));
-            HIPCHK(hipMemcpyAsync(h->h_cbar.data(), h->d_cbar, sizeof(double) * h->nb, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_sbar.data(), h->d_sbar, sizeof(double) * h->nb, hipMemcpyDeviceToHost, h->stream));
+            RC(elph_launch_cs_bar(h, h->d_cbar, h->d_sbar, nch));
+            HIPCHK(hipMemcpyAsync(h->h_cbar.data(), h->d_cbar, sizeof(double) * (size_t)nch * h->nb, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_sbar.data(), h->d_sbar, sizeof(double) * (size_t)nch * h->nb, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
     }
     // Holstein: c̄ = cosh(Δτ t), s̄ = sinh(Δτ t) never change after elph_create — upload their three device images once
     const bool hop_fresh = !(h->kind == ELPH_MODEL_HOLSTEIN && h->kpm_hop_uploaded);
-    if (hop_fresh && h->nb > 0) {
+    const int hch = h->kpm_hop_per_chain ? nch : 1;                       // hopping tables: one per chain (SSH chains) or shared
+    if (hop_fresh && h->nb > 0 && h->kind == ELPH_MODEL_HOLSTEIN) {
         HIPCHK(hipMemcpy(h->d_cbar, h->h_cbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sbar, h->h_sbar.data(), sizeof(double) * h->nb, hipMemcpyHostToDevice));
     }
     if (hop_fresh && h->fast_capable) {
-        std::vector<double> lc((size_t)h->lp_ne * ELPH_WAVE), ls((size_t)h->lp_ne * ELPH_WAVE);
-        elph_lp_pack(h, h->h_cbar.data(), lc.data(), 1.0);
-        elph_lp_pack(h, h->h_sbar.data(), ls.data(), 0.0);
+        const size_t per = (size_t)h->lp_ne * ELPH_WAVE;
+        std::vector<double> lc((size_t)hch * per), ls((size_t)hch * per);
+        for (int c = 0; c < hch; ++c) {
+            elph_lp_pack(h, h->h_cbar.data() + (size_t)c * h->nb, lc.data() + (size_t)c * per, 1.0);
+            elph_lp_pack(h, h->h_sbar.data() + (size_t)c * h->nb, ls.data() + (size_t)c * per, 0.0);
+        }
         HIPCHK(hipMemcpy(h->d_lp_cbar, lc.data(), sizeof(double) * lc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_lp_sbar, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
     }
     if (hop_fresh && h->sq_P > 0) {
-        std::vector<double> qc((size_t)4 * h->N), qs((size_t)4 * h->N);
-        for (size_t k = 0; k < qc.size(); ++k) { qc[k] = h->h_cbar[h->sq_bond[k]]; qs[k] = h->h_sbar[h->sq_bond[k]]; }
+        const size_t per = (size_t)4 * h->N;
+        std::vector<double> qc((size_t)hch * per), qs((size_t)hch * per);
         bool uni = true;
-        for (size_t k = 1; k < qc.size(); ++k) uni = uni && qc[k] == qc[0] && qs[k] == qs[0];
+        for (int c = 0; c < hch; ++c) {
+            double *q0 = qc.data() + (size_t)c * per, *q1 = qs.data() + (size_t)c * per;
+            for (size_t k = 0; k < per; ++k) { q0[k] = h->h_cbar[(size_t)c * h->nb + h->sq_bond[k]]; q1[k] = h->h_sbar[(size_t)c * h->nb + h->sq_bond[k]]; }
+            for (size_t k = 1; k < per; ++k) uni = uni && q0[k] == q0[0] && q1[k] == q1[0];       // uniform within the chain
+        }
         if (uni != h->sq_uniform) drop_graphs(h);
         h->sq_uniform = uni;
         HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));

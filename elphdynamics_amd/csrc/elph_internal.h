@@ -125,6 +125,8 @@ struct KpmDev {
     const int *wsched;        // [nchains][Lo2] omega indices sorted by decreasing order (longest first)
     const double *lp_cbar;    // lane-program copies of cbar/sbar [NE][64]
     const double *lp_sbar;
+    // SSH chains: every chain has its own tau-averaged hopping (cbar, sbar) — strides between chains, 0 when shared (Holstein)
+    long long hop_stride, lp_hop_stride, sq_stride;
 };
 
 // One chain's view of the expansion (device side).
@@ -132,6 +134,7 @@ struct KpmChainView {
     const int *order, *coff, *wsched;
     const double *Ebar;
     double a, b;              // 1/lam_mag, lam_avg/lam_mag
+    const double *cbar, *sbar, *lp_cbar, *lp_sbar;    // this chain's averaged hopping tables
     bool active;              // false: this chain's preconditioner is the identity (order 1, coefficient 1 everywhere)
 };
 #ifdef __HIPCC__
@@ -147,7 +150,10 @@ __device__ __forceinline__ KpmChainView kpm_chain_view(const KpmDev &K, int rhs,
         V.a = 1.0 / mag;
         V.b = avg / mag;
         V.active = mag > 0.0;                                  // the host uploads a negative magnitude for an inactive chain
+        V.cbar = K.cbar + c * K.hop_stride; V.sbar = K.sbar + c * K.hop_stride;
+        V.lp_cbar = K.lp_cbar + c * K.lp_hop_stride; V.lp_sbar = K.lp_sbar + c * K.lp_hop_stride;
     } else {
+        V.cbar = K.cbar; V.sbar = K.sbar; V.lp_cbar = K.lp_cbar; V.lp_sbar = K.lp_sbar;
         V.order = K.order; V.coff = K.coff; V.wsched = K.wsched; V.Ebar = K.Ebar;
         V.a = 1.0 / K.lam_mag;
         V.b = K.lam_avg / K.lam_mag;
@@ -245,7 +251,9 @@ struct elph_handle_s {
     struct KpmChainHost { double lam_lo = 0.0, lam_hi = 2.0; int active = 1; bool fresh = true;
                           std::vector<int> order; std::vector<double> coeff; };
     std::vector<KpmChainHost> kpm_chain;   // per chain: bounds, orders, coefficients (complex interleaved)
-    std::vector<double> h_Ebar, h_cbar, h_sbar;   // h_Ebar: [kpm_nch][N]
+    std::vector<double> h_Ebar, h_cbar, h_sbar;   // h_Ebar: [kpm_nch][N]; h_cbar, h_sbar: [nb], or [kpm_nch][nb] for SSH chains
+    bool kpm_hop_per_chain = false;        // SSH with several chains: averaged hopping tables per chain
+    int kpm_hop_cap = 1;                   // chains the device copies of the averaged hopping tables are allocated for
     std::vector<int> h_order, h_coff, h_wsched;   // flattened [kpm_nch][...] images of the device tables
     std::vector<double> h_coeff;           // complex interleaved, all chains
     std::vector<double> h_lam;             // [kpm_nch][2]
@@ -289,7 +297,7 @@ int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec
 int elph_launch_expV(elph_handle_s *h, const double *xR, double dtau, int chain = 0);
 int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const int *cb0_dev, const double *par_dev,
                            const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major = 0, int nch = 1);
-int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev);
+int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev, int nch = 1);
 int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
                             const int *cb0_dev, int nph, double dtau, int tau_major = 0, double scale = 1.0);
 int elph_i_ssh_upload_params(elph_handle_s *h, int64_t nph, const int64_t *cb_index, const double *t_ph, const double *alpha,

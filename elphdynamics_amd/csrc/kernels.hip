@@ -623,6 +623,7 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
         lij = tij; lc = tc; ls = ts;                               // the first barrier inside kpm_mulAprime publishes them
     }
     const KpmChainView V = kpm_chain_view(K, rhs, m.N);
+    K.cbar = V.cbar; K.sbar = V.sbar;                               // this chain's averaged hopping (SSH chains)
     const int w = V.wsched[blockIdx.y];
     const int N = m.N;
     const int order = V.order[w];
@@ -706,6 +707,7 @@ __global__ void __launch_bounds__(256) k_cs_bar(double *__restrict__ cbar, doubl
                                                 const double *__restrict__ s, int nb, int L) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= nb) return;
+    { const size_t ch = blockIdx.y; c += ch * (size_t)L * nb; s += ch * (size_t)L * nb; cbar += ch * (size_t)nb; sbar += ch * (size_t)nb; }
     double a = 0.0, b = 0.0;
     for (int t = 0; t < L; ++t) { a += c[(size_t)t * nb + n]; b += s[(size_t)t * nb + n]; }
     cbar[n] = a / L;
@@ -985,8 +987,14 @@ KpmDev elph_kpm_dev(const elph_handle_s *h) {
     K.Ebar = h->d_Ebar; K.cbar = h->d_cbar; K.sbar = h->d_sbar;
     K.order = h->d_order; K.coff = h->d_coff; K.coeff = h->d_coeff; K.wsched = h->d_wsched;
     K.lp_cbar = h->d_lp_cbar; K.lp_sbar = h->d_lp_sbar;
+    const bool hop_per_chain = (h->kind == ELPH_MODEL_SSH && h->kpm_nch > 1);
+    K.hop_stride = hop_per_chain ? (long long)h->nb : 0;
+    K.lp_hop_stride = hop_per_chain ? (long long)h->lp_ne * ELPH_WAVE : 0;
+    K.sq_stride = hop_per_chain ? 4LL * h->N : 0;
     if (h->solo_chain >= 0 && h->kpm_nch > 1) {
         const int c = h->solo_chain;
+        K.cbar += (size_t)c * K.hop_stride; K.sbar += (size_t)c * K.hop_stride;
+        K.lp_cbar += (size_t)c * K.lp_hop_stride; K.lp_sbar += (size_t)c * K.lp_hop_stride;
         K.nchains = 1;
         K.lam_avg = h->h_lam[2 * c]; K.lam_mag = h->h_lam[2 * c + 1];
         K.Ebar += (size_t)c * h->N;
@@ -1110,8 +1118,8 @@ int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev
     return check_launch("k_ssh_scatter");
 }
 
-int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev) {
-    hipLaunchKernelGGL(k_cs_bar, dim3((unsigned)((h->nb + 255) / 256)), dim3(256), 0, h->stream, cbar_dev, sbar_dev, h->d_c, h->d_s,
+int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev, int nch) {
+    hipLaunchKernelGGL(k_cs_bar, dim3((unsigned)((h->nb + 255) / 256), (unsigned)nch), dim3(256), 0, h->stream, cbar_dev, sbar_dev, h->d_c, h->d_s,
                        (int)h->nb, (int)h->L);
     return check_launch("k_cs_bar");
 }

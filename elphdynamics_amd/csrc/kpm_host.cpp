@@ -15,39 +15,41 @@ namespace {
 
 // bonds are stored in checkerboard order; the sequential product over n = 0..nb-1 is the
 // reference's checkerboard_mul! (Checkerboard.jl:123-141), reversed with -s its inverse (:298-316).
-void cb_mul(std::vector<double> &y, const elph_handle_s *h) {
+void cb_mul(std::vector<double> &y, const elph_handle_s *h, const double *cbar, const double *sbar) {
     for (int64_t n = 0; n < h->nb; ++n) {
         const int i = h->h_bi[n], j = h->h_bj[n];
-        const double c = h->h_cbar[n], s = h->h_sbar[n];
+        const double c = cbar[n], s = sbar[n];
         const double t1 = y[i], t2 = y[j];
         y[i] = c * t1 + s * t2;
         y[j] = c * t2 + s * t1;
     }
 }
 
-void cb_inv_mul(std::vector<double> &y, const elph_handle_s *h) {
+void cb_inv_mul(std::vector<double> &y, const elph_handle_s *h, const double *cbar, const double *sbar) {
     for (int64_t n = h->nb - 1; n >= 0; --n) {
         const int i = h->h_bi[n], j = h->h_bj[n];
-        const double c = h->h_cbar[n], s = h->h_sbar[n];
+        const double c = cbar[n], s = sbar[n];
         const double t1 = y[i], t2 = y[j];
         y[i] = c * t1 - s * t2;
         y[j] = c * t2 - s * t1;
     }
 }
 
-void apply_A(std::vector<double> &out, const std::vector<double> &in, const elph_handle_s *h, const double *Ebar, bool inverse) {
+void apply_A(std::vector<double> &out, const std::vector<double> &in, const elph_handle_s *h, const double *Ebar, bool inverse,
+             const double *cbar, const double *sbar) {
     const int64_t N = h->N;
     if (!inverse) {  // A v = CBbar (Ebar .* v), :387-401
         for (int64_t i = 0; i < N; ++i) out[i] = Ebar[i] * in[i];
-        cb_mul(out, h);
+        cb_mul(out, h, cbar, sbar);
     } else {         // A^-1 v = (CBbar^-1 v) ./ Ebar, :406-420
         out = in;
-        cb_inv_mul(out, h);
+        cb_inv_mul(out, h, cbar, sbar);
         for (int64_t i = 0; i < N; ++i) out[i] /= Ebar[i];
     }
 }
 
-double max_ritz(const elph_handle_s *h, const double *Ebar, int n, const double *b0, bool inverse) {
+double max_ritz(const elph_handle_s *h, const double *Ebar, int n, const double *b0, bool inverse, const double *cbar,
+                const double *sbar) {
     const int64_t m = h->N;
     std::vector<double> Q((size_t)m * (n + 1), 0.0), H((size_t)(n + 1) * n, 0.0), b(m), v(m);
     double nrm = 0.0;
@@ -56,7 +58,7 @@ double max_ritz(const elph_handle_s *h, const double *Ebar, int n, const double 
     for (int64_t i = 0; i < m; ++i) { b[i] = b0[i] / nrm; Q[i] = b[i]; }
     int l = n;
     for (int k = 0; k < n; ++k) {
-        apply_A(v, b, h, Ebar, inverse);
+        apply_A(v, b, h, Ebar, inverse, cbar, sbar);
         for (int j = 0; j <= k; ++j) {
             const double *Qj = &Q[(size_t)j * m];
             double d = 0.0;
@@ -200,8 +202,11 @@ int elph_kpm_arnoldi(const elph_handle_s *h, int chain, const double *b_max, con
     int n = h->kpm_n;
     if (n > h->N) n = (int)h->N;   // :136
     if (n < 1) n = 1;
-    const double emax = max_ritz(h, Ebar, n, b_max, false);
-    const double r = max_ritz(h, Ebar, n, b_min, true);
+    // averaged hopping of this chain: one table per chain for SSH chains, one shared table otherwise
+    const size_t hop = (h->h_cbar.size() >= (size_t)(chain + 1) * (size_t)h->nb && h->kpm_hop_per_chain) ? (size_t)chain * (size_t)h->nb : 0;
+    const double *cbar = h->h_cbar.data() + hop, *sbar = h->h_sbar.data() + hop;
+    const double emax = max_ritz(h, Ebar, n, b_max, false, cbar, sbar);
+    const double r = max_ritz(h, Ebar, n, b_min, true, cbar, sbar);
     *e_max = emax;
     *e_min = std::isfinite(r) ? 1.0 / r : -INFINITY;
     return 0;

@@ -726,7 +726,7 @@ def test_mfma_dft_inside_batched_preconditioned_solve(monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2)])
+@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2)])
 def test_kpm_preconditioner_per_chain(tag, nchains, per):
     """One KPM expansion per resident phonon configuration (elph_kpm_setup_chains): every right-hand side of the batch
     is preconditioned with ITS chain's Ē, eigenvalue bounds, orders and coefficients — same bounds, same iteration
@@ -734,7 +734,10 @@ def test_kpm_preconditioner_per_chain(tag, nchains, per):
     from elphdynamics_amd import configs, models, preconditioners as pc, synth
     m = configs.make_model(tag, tol=1e-8)
     # chains with visibly different spectra: different seeds AND different roughness
-    X = np.stack([(0.6 + 0.25 * c) * synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=5100 + c) for c in range(nchains)])
+    if m.kind == models.SSH:      # bond phonons: per-chain averaged hopping tables (cbar, sbar) in every Chebyshev kernel
+        X = np.stack([m.x * (0.4 + 1.2 * c / nchains) * (1.0 + 0.3 * synth.randn(5100 + c, m.Ndof)) for c in range(nchains)])
+    else:
+        X = np.stack([(0.6 + 0.25 * c) * synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=5100 + c) for c in range(nchains)])
     nrhs = nchains * per
     B = np.stack([synth.randn(7100 + r, m.Ndim) for r in range(nrhs)])
     rng = np.random.default_rng(11)
