@@ -85,6 +85,7 @@ SIGNATURES = {
     "elph_greens_setup": (c_int, [Handle, c_int, c_int, P_dbl, P_dbl, P_dbl, P_dbl]),
     "elph_greens_dev_arrays": (c_int, [Handle, C.POINTER(C.c_void_p), P_i64]),
     "elph_hmc_create_ssh": (c_int, [Handle, c_i64, P_dbl, P_dbl, P_i64, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
+    "elph_hmc_create_ssh_chains": (c_int, [Handle, c_int, c_i64, P_dbl, P_dbl, P_i64, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
     "elph_hmc_create_chains": (c_int, [Handle, c_int, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
     "elph_hmc_update_chains": (c_int, [Handle, c_dbl, c_i64, c_int, c_dbl, c_int, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, P_int, P_dbl, P_dbl,
                                        P_int]),

@@ -299,7 +299,7 @@ int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const
                            const double *tbare_dev, const int *slot_dev, double dtau, int x_tau_major = 0, int nch = 1);
 int elph_launch_cs_bar(elph_handle_s *h, double *cbar_dev, double *sbar_dev, int nch = 1);
 int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
-                            const int *cb0_dev, int nph, double dtau, int tau_major = 0, double scale = 1.0);
+                            const int *cb0_dev, int nph, double dtau, int tau_major = 0, double scale = 1.0, int nch = 1);
 int elph_i_ssh_upload_params(elph_handle_s *h, int64_t nph, const int64_t *cb_index, const double *t_ph, const double *alpha,
                              const double *alpha2, const double *t_bare_cb, const double *mu);
 int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
@@ -317,7 +317,7 @@ int elph_launch_tau_to_omega(elph_handle_s *h, double2 *nuS, const double *vS);
 int elph_launch_omega_to_tau(elph_handle_s *h, double *vS, const double2 *nuS);
 int elph_launch_zero(elph_handle_s *h, double *p, int64_t n);
 int elph_launch_lambda_rhs(elph_handle_s *h, double *bS, const double *phiS, const double *xS, double dtau, int nch = 1);
-int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS, const double *US = nullptr);
+int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS, const double *US = nullptr, int nch = 1);
 int elph_launch_dmdx_holstein(elph_handle_s *h, double *FS, const double *uS, const double *vS, const double *xS, double dtau,
                               double scale, int nch = 1);
 int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, const double *phiS, const double *xS, double dtau,

@@ -268,7 +268,7 @@ int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
 
 int update_model(elph_handle_s *h, HmcState *st) {
     if (st->ssh) {      // SSHModels.jl:510-562 from the device-resident fields (tau-major)
-        RC(elph_launch_ssh_update(h, st->x, st->nf, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, st->dtau, 1));
+        RC(elph_launch_ssh_update(h, st->x, st->nf, h->d_ssh_cb, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_slot, st->dtau, 1, st->nch));
         h->ssh_dtau = st->dtau;
         h->cs_host_stale = true;
         h->have_E = true;
@@ -295,7 +295,7 @@ int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power,
         use = 1;                      // an inactive preconditioner is the identity inside the preconditioned recurrence
     }
     if (st->ssh)        // Λ ≡ 1 (HMC.jl:943-946,970-973): the right-hand sides are ϕ± themselves
-        HIPCHK(hipMemcpyAsync(h->d_b, st->phi, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_b, st->phi, 2 * (size_t)nch * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     else
         RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
     HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * (size_t)nch * nd * sizeof(double), h->stream));
@@ -347,8 +347,8 @@ int calc_H(elph_handle_s *h, HmcState *st, double *H, double *S, double *K) {
 int force(elph_handle_s *h, HmcState *st, bool with_Sb) {
     const long long n = (long long)st->nf * h->L * st->nch;
     if (st->ssh) {      // dSf/dx = -dMdx(M X₊, X₊) - dMdx(M X₋, X₋)  (HMC.jl:797-808; muldΛdx! is a no-op)
-        RC(elph_launch_force_ssh(h, h->d_p, h->d_x));                          // bond brackets q[tau][bond] (d_p is free here)
-        RC(elph_launch_ssh_scatter(h, st->dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -1.0));
+        RC(elph_launch_force_ssh(h, h->d_p, h->d_x, nullptr, st->nch));        // bond brackets q[chain][tau][bond] (d_p is free here)
+        RC(elph_launch_ssh_scatter(h, st->dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -1.0, st->nch));
         RC(alias_sum(h, st, st->dS));
     } else {
         RC(elph_launch_force_holstein(h, st->dS, h->d_x, st->phi, st->x, st->dtau, st->nch));
@@ -504,15 +504,22 @@ extern "C" int elph_hmc_create(elph_handle h, const double *omega, const double 
 
 // HybridMonteCarlo for an SSH model (bond phonons): omega, omega4 per phonon (double[nph]), fa_mass double[nph * ltau]; the
 // remaining arguments are those of elph_update_model_ssh_fields (couplings, checkerboard positions, bare hoppings, mu).
+extern "C" int elph_hmc_create_ssh_chains(elph_handle h, int nchains, int64_t nph, const double *omega, const double *omega4,
+                                          const int64_t *cb_index, const double *t_ph, const double *alpha, const double *alpha2,
+                                          const double *t_bare_cb, const double *mu, double dtau, const double *fa_mass) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("elph_hmc_create_ssh: SSH handles only"); return ELPH_E_UNSUPPORTED; }
+    if (nchains < 1 || nph < 1 || !omega || !omega4 || !fa_mass || !(dtau > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if ((size_t)h->L * (size_t)h->nb > 2 * (size_t)h->ndim) { elph_set_error("more bonds than 2*nsites: scratch too small"); return ELPH_E_UNSUPPORTED; }
+    RC(elph_i_reserve_chains(h, nchains));
+    RC(elph_i_ssh_upload_params(h, nph, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu));
+    return hmc_create_core(h, nchains, (int)nph, true, omega, omega4, dtau, fa_mass);
+}
+
 extern "C" int elph_hmc_create_ssh(elph_handle h, int64_t nph, const double *omega, const double *omega4, const int64_t *cb_index,
                                    const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb,
                                    const double *mu, double dtau, const double *fa_mass) {
-    CHECK_H(h);
-    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("elph_hmc_create_ssh: SSH handles only"); return ELPH_E_UNSUPPORTED; }
-    if (nph < 1 || !omega || !omega4 || !fa_mass || !(dtau > 0.0)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    if ((size_t)h->L * (size_t)h->nb > 2 * (size_t)h->ndim) { elph_set_error("more bonds than 2*nsites: scratch too small"); return ELPH_E_UNSUPPORTED; }
-    RC(elph_i_ssh_upload_params(h, nph, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu));
-    return hmc_create_core(h, 1, (int)nph, true, omega, omega4, dtau, fa_mass);
+    return elph_hmc_create_ssh_chains(h, 1, nph, omega, omega4, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu, dtau, fa_mass);
 }
 
 // x, v: double[nchains * ndim] (chain-major, reference layout inside a chain); NULL = leave
@@ -522,11 +529,13 @@ extern "C" int elph_hmc_set_state(elph_handle h, const double *x, const double *
     if (!st) { elph_set_error("elph_hmc_create has not been called"); return ELPH_E_STATE; }
     if (x && st->shared) {      // update_model! refuses fields that differ from their primary (SSHModels.jl:549-559; isapprox)
         const size_t L = (size_t)h->L;
+        for (int ch = 0; ch < st->nch; ++ch)
         for (int c = 0; c < st->nf; ++c) {
             const int pc = st->prim_host[(size_t)c];
             if (pc == c) continue;
+            const size_t co = (size_t)ch * (size_t)st->nf * L;
             for (size_t t = 0; t < L; ++t) {
-                const double a = x[(size_t)c * L + t], b = x[(size_t)pc * L + t];
+                const double a = x[co + (size_t)c * L + t], b = x[co + (size_t)pc * L + t];
                 if (!(fabs(a - b) <= 1.4901161193847656e-08 * fmax(fabs(a), fabs(b)))) {
                     elph_set_error("(x[%zu]=%g) != (x[%zu]=%g): fields that share a primary field must be equal", (size_t)c * L + t + 1, a,
                                    (size_t)pc * L + t + 1, b);
@@ -657,7 +666,7 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     const int nch = st->nch;
     RC(elph_i_ensure_capacity(h, 2 * nch));
-    if (!st->ssh) RC(elph_i_reserve_chains(h, nch));
+    RC(elph_i_reserve_chains(h, nch));
     // nd: site vectors (ϕ±, R±, solutions); nfd: field vectors (x, v, dS/dx) of one chain
     const size_t nd = (size_t)h->ndim, nfd = (size_t)st->nf * (size_t)h->L, cbytes = nfd * sizeof(double), bytes = (size_t)nch * cbytes;
     const long long n = (long long)nfd * nch;
@@ -698,7 +707,7 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     }
     RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2 * nch));
     if (st->ssh) {      // Λ⁻¹ ≡ 1: ϕ± = MᵀR±
-        HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * (size_t)nch * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     } else {
         hipLaunchKernelGGL(k_hmc_phi, dim3(nblk((long long)nd * nch), 2), dim3(TPB), 0, h->stream, st->phi, h->d_b, st->x, h->d_lam,
                            (int)h->N, (int)h->L, st->dtau, nch);
@@ -819,10 +828,10 @@ int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_h
     RC(elph_i_ldiv_core(h, nch, use_precond ? 1 : 0, 0, iters, res.data(), flag));
     const long long n = (long long)st->nf * h->L * nch;
     if (st->ssh) {      // muldMdx!(dSfdx, g, ssh, M⁻¹g) (SSHModels.jl:707-829) with u = g given; no shifted term for bond phonons
-        RC(elph_launch_force_ssh(h, h->d_p, h->d_x, st->R2));
-        RC(elph_launch_ssh_scatter(h, dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -2.0));
+        RC(elph_launch_force_ssh(h, h->d_p, h->d_x, st->R2, nch));
+        RC(elph_launch_ssh_scatter(h, dS, h->d_p, st->x, h->d_ssh_par, h->d_ssh_cb, st->nf, st->dtau, 1, -2.0, nch));
         RC(alias_sum(h, st, dS));
-        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1, 1,
+        hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1, nch,
                            (const double *)nullptr);
     } else {
         RC(elph_launch_dmdx_holstein(h, dS, st->R2, h->d_x, st->x, st->dtau, -2.0, nch));   // -2 gᵀ(∂M/∂x)M⁻¹g, :381-384
@@ -876,7 +885,7 @@ extern "C" int elph_langevin_evolve(elph_handle h, int scheme, double dt, int us
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     const int nch = st->nch;
     RC(elph_i_ensure_capacity(h, std::max(2, 2 * nch)));
-    if (!st->ssh) RC(elph_i_reserve_chains(h, nch));
+    RC(elph_i_reserve_chains(h, nch));
     const size_t N = (size_t)h->N;
     const long long n = (long long)st->nf * h->L * nch;      // field vectors of all chains (Holstein: nch * ndim)
     const double s2 = sqrt(2.0 * dt);
@@ -980,7 +989,7 @@ extern "C" int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int
     }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     RC(elph_i_ensure_capacity(h, 2));
-    if (!st->ssh) RC(elph_i_reserve_chains(h, 1));
+    RC(elph_i_reserve_chains(h, 1));
     const size_t nd = (size_t)h->ndim;
     const int L = (int)h->L;
     RC(update_model(h, st));

@@ -695,6 +695,7 @@ __global__ void __launch_bounds__(256) k_ssh_scatter(double *__restrict__ F, con
                                                      int L, double dtau, int tau_major, double scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)nph * L) return;
+    { const size_t ch = blockIdx.y; F += ch * (size_t)nph * L; x += ch * (size_t)nph * L; q += ch * (size_t)L * nb; }   // chain
     const int t = (int)(i % L), p = (int)(i / L);
     const size_t k = tau_major ? (size_t)t * nph + p : (size_t)i;             // x and F share one layout
     const double sg = (t == 0) ? -1.0 : 1.0;                                  // "flip sign if τ=1" (:809-811)
@@ -885,12 +886,15 @@ template <int NPL>
 // U (optional): muldMdx!(·, u, ssh, v) for a GIVEN u (Langevin: u = g, v = X = M⁻¹g, one field): c₀ = CBᵀ U instead of CBᵀ(M X),
 // the second slab carries zeros.
 __global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, const double *__restrict__ X, ModelDev m,
-                                                    const double *__restrict__ U) {
+                                                    const double *__restrict__ U, int nch) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int N = m.N, L = m.L;
     double *bP = lds, *cP = lds + N, *bM = lds + 2 * N, *cM = lds + 3 * N;
     const size_t ndim = (size_t)N * L;
     const int t = blockIdx.x;
+    // blockIdx.y = chain: X = [sign][chain][ndim] (X+ of chain c, then X- at +nch*ndim), q = [chain][tau][bond], U = [chain][ndim]
+    const size_t xm_off = (size_t)nch * ndim;
+    { const int ch = blockIdx.y; ssh_chain_select(m, ch); X += (size_t)ch * ndim; q += (size_t)ch * L * m.nb; if (U) U += (size_t)ch * ndim; }
     const int tm1 = (t == 0) ? L - 1 : t - 1;
     const double sg = (t == 0) ? -1.0 : 1.0;
     const double *ct = m.c + (size_t)t * m.cs_tau_stride, *st = m.s + (size_t)t * m.cs_tau_stride;
@@ -900,8 +904,8 @@ __global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, cons
         const int s = threadIdx.x + k * blockDim.x;
         if (s < N) {
             const double e = m.E[s];
-            x0p[k] = X[(size_t)t * N + s]; x0m[k] = U ? 0.0 : X[ndim + (size_t)t * N + s];
-            b0p[k] = e * X[(size_t)tm1 * N + s]; b0m[k] = U ? 0.0 : e * X[ndim + (size_t)tm1 * N + s];
+            x0p[k] = X[(size_t)t * N + s]; x0m[k] = U ? 0.0 : X[xm_off + (size_t)t * N + s];
+            b0p[k] = e * X[(size_t)tm1 * N + s]; b0m[k] = U ? 0.0 : e * X[xm_off + (size_t)tm1 * N + s];
             cP[s] = b0p[k]; cM[s] = b0m[k];
         }
     }
@@ -1110,10 +1114,10 @@ int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const
 }
 
 int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev, const double *x_dev, const double *par_dev,
-                            const int *cb0_dev, int nph, double dtau, int tau_major, double scale) {
+                            const int *cb0_dev, int nph, double dtau, int tau_major, double scale, int nch) {
     const long long n = (long long)nph * h->L;
     if (n == 0) return ELPH_OK;
-    hipLaunchKernelGGL(k_ssh_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, F_dev, q_dev, x_dev, par_dev, cb0_dev,
+    hipLaunchKernelGGL(k_ssh_scatter, dim3((unsigned)((n + 255) / 256), (unsigned)nch), dim3(256), 0, h->stream, F_dev, q_dev, x_dev, par_dev, cb0_dev,
                        nph, (int)h->nb, (int)h->L, dtau, tau_major, scale);
     return check_launch("k_ssh_scatter");
 }
@@ -1360,11 +1364,11 @@ int elph_launch_dmdx_holstein(elph_handle_s *h, double *FS, const double *uS, co
     return check_launch("k_dmdx_holstein");
 }
 
-int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS, const double *US) {
+int elph_launch_force_ssh(elph_handle_s *h, double *q, const double *XS, const double *US, int nch) {
     ModelDev m = elph_model_dev(h);
     const size_t shm = 4 * (size_t)h->N * sizeof(double);
     DISPATCH_NPL(gen_npl(h), {
-        hipLaunchKernelGGL((k_force_ssh<NPL>), dim3((unsigned)h->L), dim3((unsigned)gen_bs(h)), shm, h->stream, q, XS, m, US);
+        hipLaunchKernelGGL((k_force_ssh<NPL>), dim3((unsigned)h->L, (unsigned)nch), dim3((unsigned)gen_bs(h)), shm, h->stream, q, XS, m, US, nch);
     });
     return check_launch("k_force_ssh");
 }

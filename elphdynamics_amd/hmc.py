@@ -165,8 +165,6 @@ class HybridMonteCarlo:
         evaluation is one batched solve of 2*nchains right-hand sides); their fields / momenta are self.X / self.V
         (nchains, Ndof) and model.x / hmc.v are not used."""
         assert 0.0 <= alpha < 1.0                                   # HMC.jl:182
-        if model.kind != models.HOLSTEIN and nchains != 1:
-            raise NotImplementedError("chains in lockstep: Holstein models")
         self.model, self.fa = model, fa
         self.dt, self.tr, self.alpha, self.Nb = float(dt), float(tr), float(alpha), int(Nb)
         self.Nt = int(round(tr / dt))                               # :206
@@ -188,8 +186,8 @@ class HybridMonteCarlo:
                 self.omega4 = model.omega4 = np.zeros(model.Nph)
             cb_index = np.ascontiguousarray(model.checkerboard_perm[model.phonon_to_bond - 1], dtype=np.int64)
             t_ph = np.ascontiguousarray(model.t[model.phonon_to_bond - 1], dtype=np.float64)
-            check(model._lib.elph_hmc_create_ssh(
-                model._h, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
+            check(model._lib.elph_hmc_create_ssh_chains(
+                model._h, self.nchains, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
                 dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)), dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb),
                 dptr(np.ascontiguousarray(model.mu)), model.dtau, dptr(np.ascontiguousarray(fa.M))))
             set_shared_fields_(model)

@@ -28,8 +28,8 @@ class _Dynamics:
         self.Ndof, self.Ndim = model.Ndof, model.Ndim
         self.flag = 0
         self.nchains = int(nchains)
-        if self.nchains < 1 or (self.nchains > 1 and model.kind != models.HOLSTEIN):
-            raise ValueError("chains in lockstep are built for the Holstein model")
+        if self.nchains < 1:
+            raise ValueError("nchains < 1")
         self.X = np.tile(model.x, (self.nchains, 1)) if self.nchains > 1 else None
         self.flags = np.zeros(self.nchains, dtype=np.int32)
         self.device_rng = False
@@ -39,8 +39,8 @@ class _Dynamics:
                 model.omega4 = np.zeros(model.Nph)
             cb_index = np.ascontiguousarray(model.checkerboard_perm[model.phonon_to_bond - 1], dtype=np.int64)
             t_ph = np.ascontiguousarray(model.t[model.phonon_to_bond - 1], dtype=np.float64)
-            check(model._lib.elph_langevin_create_ssh(
-                model._h, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
+            check(model._lib.elph_hmc_create_ssh_chains(      # the Langevin state is the HMC state with fa.Q in place of fa.M
+                model._h, self.nchains, model.Nph, dptr(np.ascontiguousarray(model.omega)), dptr(np.ascontiguousarray(model.omega4)), iptr(cb_index),
                 dptr(t_ph), dptr(np.ascontiguousarray(model.alpha)), dptr(np.ascontiguousarray(model.alpha2)), dptr(model.t_bare_cb),
                 dptr(np.ascontiguousarray(model.mu)), model.dtau, dptr(np.ascontiguousarray(fa.Q))))
             from .hmc import set_shared_fields_

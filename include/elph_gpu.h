@@ -272,6 +272,11 @@ int elph_hmc_update(elph_handle h, double dt, int64_t nt, int nb, double alpha, 
 int elph_hmc_create_ssh(elph_handle h, int64_t nph, const double *omega, const double *omega4, const int64_t *cb_index,
                         const double *t_ph, const double *alpha, const double *alpha2, const double *t_bare_cb, const double *mu,
                         double dtau, const double *fa_mass);
+/* The same for nchains independent chains of one SSH deck in lockstep (x, v, R chain-major as for elph_hmc_create_chains;
+ * elph_hmc_update_chains / elph_langevin_evolve then act on all of them; special moves stay single-chain). */
+int elph_hmc_create_ssh_chains(elph_handle h, int nchains, int64_t nph, const double *omega, const double *omega4,
+                               const int64_t *cb_index, const double *t_ph, const double *alpha, const double *alpha2,
+                               const double *t_bare_cb, const double *mu, double dtau, const double *fa_mass);
 
 /* Several Markov chains (same deck, independent phonon fields — the reference runs them as separate processes,
  * ElPhDynamics.jl:90-95) advanced in LOCKSTEP by one handle: the leapfrog schedule is common, every chain has its own

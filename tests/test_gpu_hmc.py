@@ -584,3 +584,99 @@ def test_device_rng_normals_have_the_right_moments():
     assert abs(v.mean()) < 5 / np.sqrt(n) and abs(v.var() - 1) < 5 * np.sqrt(2 / n) and abs((v ** 4).mean() - 3) < 5 * np.sqrt(96 / n)
     assert abs(np.mean(v[1:] * v[:-1])) < 5 / np.sqrt(n)
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------- SSH chains in lockstep
+
+@pytest.mark.parametrize("tag,nch,nb,with_kpm", [("e", 3, 1, False), ("e", 2, 2, True), ("E", 4, 1, True)])
+def test_ssh_hmc_chains_in_lockstep_equal_single_chain_updates(tag, nch, nb, with_kpm):
+    """Bond-phonon chains: per-chain hopping tables in every kernel of the path, per-chain KPM expansions, per-chain bond-bracket
+    force — every chain ends where the single-chain SSH update ends given the same field, momenta and random numbers."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc, synth
+    nt, dt = 3, 0.05
+
+    def make():
+        m = configs.make_model(tag, tol=1e-9, maxiter=20000)
+        m.alpha2[:] = 0.01
+        m.omega4 = np.full(m.Nph, 0.02)
+        fa = pc.FourierAccelerator(m)
+        pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+        return m, fa
+
+    m, fa = make()
+    X0 = np.stack([m.x * (0.6 + 0.5 * c / nch) * (1.0 + 0.2 * synth.randn(900 + c, m.Ndof)) for c in range(nch)])
+    V0 = np.stack([0.3 * synth.randn(950 + c, m.Ndof) for c in range(nch)])
+    rnd = dict(R=np.stack([synth.randn(1000 + c, m.Ndof) for c in range(nch)]),
+               Rp=np.stack([synth.randn(1100 + c, m.Ndim) for c in range(nch)]),
+               Rm=np.stack([synth.randn(1200 + c, m.Ndim) for c in range(nch)]),
+               kpm_randn=synth.randn(1300, (nt + 2) * 2 * nch * m.Nsites).reshape(nt + 2, 2, nch, m.Nsites) if with_kpm else None,
+               u=np.array([0.0 if c % 2 == 0 else 1.5 for c in range(nch)]))
+    H = hmc.HybridMonteCarlo(m, fa, dt=dt, tr=nt * dt, alpha=0.2, Nb=nb, nchains=nch)
+    H.X[:], H.V[:] = X0, V0
+    H.push_()
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0) if with_kpm else None
+    acc, its = hmc.update_chains_(m, H, fa, P, randoms=rnd, pull=True)
+    assert not H.flags.any()
+    Xb, Vb, Eb = H.X.copy(), H.V.copy(), H.energies.copy()
+    m.close()
+    for c in range(nch):
+        m1, fa1 = make()
+        m1.x[:] = X0[c]
+        H1 = hmc.HybridMonteCarlo(m1, fa1, dt=dt, tr=nt * dt, alpha=0.2, Nb=nb)
+        H1.v[:] = V0[c]
+        H1.push_()
+        P1 = pc.SymmetricKPMPreconditioner(m1, 20, 0.05, 1.0, 1.0) if with_kpm else None
+        r1 = dict(R=rnd["R"][c], Rp=rnd["Rp"][c], Rm=rnd["Rm"][c],
+                  kpm_randn=np.ascontiguousarray(rnd["kpm_randn"][:, :, c, :]) if with_kpm else None, u=float(rnd["u"][c]))
+        a1, i1 = hmc.update_(m1, H1, fa1, P1, randoms=r1)
+        assert a1 == bool(acc[c]) and H1.flag == 0 and abs(i1 - its[c]) <= 1
+        assert abs(H1.H0 - Eb[c, 0]) < 1e-8 * abs(H1.H0) and abs(H1.H1 - Eb[c, 1]) < 1e-8 * abs(H1.H1)
+        assert np.abs(m1.x - Xb[c]).max() < 1e-7 * np.abs(m1.x).max() and np.abs(H1.v - Vb[c]).max() < 1e-7 * max(np.abs(H1.v).max(), 1.0)
+        if not a1:
+            assert np.array_equal(Xb[c], X0[c])
+        m1.close()
+    assert acc[0] and not acc[1]
+
+
+def test_ssh_langevin_chains_match_single_trajectories():
+    from elphdynamics_amd import configs, langevin, preconditioners as pc, synth
+    nch = 3
+
+    def make():
+        m = configs.make_model("e", tol=1e-9, maxiter=20000)
+        m.alpha2[:] = 0.01
+        m.omega4 = np.full(m.Nph, 0.02)
+        fa = pc.FourierAccelerator(m)
+        pc.update_Q_(fa, m, 0.0, np.inf, 0.7)
+        return m, fa, pc.SymmetricKPMPreconditioner(m, n=min(20, m.Nsites), buf=0.05, c1=1.0, c2=1.0)
+
+    def rnd(step, c, m):
+        return dict(eta=synth.randn(3000 + 10 * step + c, m.Ndof), g1=synth.randn(3100 + 10 * step + c, m.Ndim),
+                    g2=synth.randn(3200 + 10 * step + c, m.Ndim), kpm_randn=synth.randn(3300 + 10 * step + c, 4 * m.Nsites))
+
+    m, fa, P = make()
+    x0 = m.x.copy()
+    starts = [x0 * (0.7 + 0.2 * c) for c in range(nch)]
+    singles = []
+    for c in range(nch):
+        m.x[:] = starts[c]
+        dyn = langevin.HeunsDynamics(m, fa, 0.01)
+        for step in range(2):
+            langevin.evolve_(m, dyn, fa, P, randoms=rnd(step, c, m))
+            assert dyn.flag == 0
+        singles.append(m.x.copy())
+    m.close()
+    m, fa, P = make()
+    dyn = langevin.HeunsDynamics(m, fa, 0.01, nchains=nch)
+    for c in range(nch):
+        dyn.X[c] = starts[c]
+    dyn.push_()
+    for step in range(2):
+        rs = [rnd(step, c, m) for c in range(nch)]
+        kr = np.stack([r["kpm_randn"].reshape(2, 2, m.Nsites) for r in rs], axis=2)
+        langevin.evolve_(m, dyn, fa, P, randoms=dict(eta=np.stack([r["eta"] for r in rs]), g1=np.stack([r["g1"] for r in rs]),
+                                                     g2=np.stack([r["g2"] for r in rs]), kpm_randn=kr))
+        assert (dyn.flags == 0).all()
+    for c in range(nch):
+        assert rel(dyn.X[c] - starts[c], singles[c] - starts[c]) < 1e-7
+    m.close()
