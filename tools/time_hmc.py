@@ -3,15 +3,19 @@ import numpy as np
 sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from elphdynamics_amd import configs, models, hmc, preconditioners as pc, synth
 nt, dt = 20, 0.01
+TAG = __import__('os').environ.get("TAG", "C")       # TAG=E: the optical SSH square lattice (bond phonons)
 for nch in ([int(a) for a in sys.argv[1:]] or [1, 8, 32]):
     for with_kpm in (True,):
         for nb in (1,):
-            m = configs.make_model("C", tol=1e-5, maxiter=20000)
+            m = configs.make_model(TAG, tol=1e-5, maxiter=20000)
             fa = pc.FourierAccelerator(m)
             pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.1)
             H = hmc.HybridMonteCarlo(m, fa, dt=dt, tr=nt * dt, alpha=0.0, Nb=nb, nchains=nch)
             if nch > 1:
-                H.X[:] = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=100 + 17 * c) for c in range(nch)])
+                if m.kind == models.SSH:
+                    H.X[:] = np.stack([m.x * (0.7 + 0.5 * c / nch) for c in range(nch)])
+                else:
+                    H.X[:] = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=100 + 17 * c) for c in range(nch)])
                 H.push_()
             P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0) if with_kpm else None
             rng = np.random.default_rng(3)
