@@ -161,3 +161,22 @@ def test_holstein_deck_in_lockstep_chains():
     acc2, its2 = hmc.update_chains_(m, H, sim.fa, sim.preconditioner, pull=True)
     assert not H.flags.any() and its.min() > 0 and its2.min() > 0 and np.all(np.isfinite(H.X))
     m.close()
+
+
+@pytest.mark.gpu
+def test_ssh_deck_in_lockstep_chains():
+    """process_input_file(..., nchains) for a bond-phonon deck: Langevin trajectories of several chains on one GPU."""
+    from elphdynamics_amd import langevin, process_input as pi
+    sim = pi.process_input_file(os.path.join(DECKS, "ssh_langevin_square_L4.toml"), nchains=3)
+    dyn, m = sim.simulation_dynamics, sim.model
+    assert dyn.nchains == 3 and dyn.X.shape == (3, m.Ndof)
+    for c in range(3):
+        dyn.X[c] = m.x * (0.8 + 0.1 * c)
+    dyn.push_()
+    X0 = dyn.X.copy()
+    dyn.device_rng_(11)
+    it = langevin.evolve_(m, dyn, sim.fa, sim.preconditioner)
+    assert (dyn.flags == 0).all() and it.min() > 0
+    d = np.abs(dyn.X - X0).max(axis=1)
+    assert np.all(d > 0) and np.all(d < 1.0) and len(set(np.round(d, 12))) == 3       # every chain moved, each its own way
+    m.close()
