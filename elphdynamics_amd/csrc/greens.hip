@@ -254,9 +254,14 @@ extern "C" int elph_greens_update(elph_handle h, const double *R, int use_precon
     CHECK_H(h);
     RC(need_greens(h));
     if (!R) { elph_set_error("R is null"); return ELPH_E_ARG; }
-    if (h->nchains != 1) { elph_set_error("the estimator works on one phonon configuration; nchains = %d", h->nchains); return ELPH_E_UNSUPPORTED; }
     GreensState *g = gs_of(h);
     const int nv = g->nv;
+    // several chains resident: right-hand side r of the batch belongs to chain r % nchains, so vector v of chain c is row
+    // v * nchains + c of R — the estimator must then hold a multiple of nchains vectors
+    if (h->nchains != 1 && nv % h->nchains) {
+        elph_set_error("%d chains are resident: the estimator needs a multiple of that many vectors (it has %d)", h->nchains, nv);
+        return ELPH_E_ARG;
+    }
     const size_t nd = (size_t)h->ndim;
     RC(elph_i_ensure_capacity(h, nv));
     HIPCHK(hipMemcpyAsync(h->d_stage_in, R, (size_t)nv * nd * sizeof(double), hipMemcpyHostToDevice, h->stream));

@@ -59,7 +59,15 @@ def update_(est, model, P=None, rng=None, R=None, setup_kwargs=None):
     Returns (iters, residual_error, flag) per vector (the reference discards them)."""
     m = est.model
     assert model is m
-    pc.setup_(P, rng=rng, **(setup_kwargs or {}))                          # :206
+    if getattr(m, "_nchains", 1) > 1:
+        # chains in lockstep: right-hand side r of the batch belongs to chain r % nchains, so an estimator made with
+        # nv = n_v * nchains vectors holds vector v of chain c at index v * nchains + c (chain_vector below)
+        if est.nv % m._nchains:
+            raise ValueError("with chains resident the estimator needs a multiple of nchains vectors")
+        if P is not None:
+            pc.setup_chains_(P, rng=rng, **(setup_kwargs or {}))
+    else:
+        pc.setup_(P, rng=rng, **(setup_kwargs or {}))                      # :206
     if R is None:
         rng = rng or np.random.default_rng()
         R = rng.standard_normal((est.nv, m.Ndim))
@@ -71,6 +79,14 @@ def update_(est, model, P=None, rng=None, R=None, setup_kwargs=None):
     check(m._lib.elph_greens_update(m._h, dptr(est.R), use_prec, it.ctypes.data_as(P_i64), dptr(res), fl.ctypes.data_as(P_int)))
     check(m._lib.elph_greens_get_vectors(m._h, None, dptr(est.MinvR)))
     return it, res, fl
+
+
+def chain_vector(est, chain, v):
+    """1-based index (for setup_ / estimate) of noise vector v (1-based, v <= est.nv // nchains) of chain `chain` (0-based) in an
+    estimator that serves several resident chains: setup_(est, chain_vector(est, c, 1), chain_vector(est, c, 2)) selects the
+    first pair of chain c."""
+    nch = int(est.model._nchains)
+    return (int(v) - 1) * nch + int(chain) + 1
 
 
 def set_vectors_(est, R, MinvR):

@@ -207,7 +207,8 @@ def process_input_file(deck, device=0, nchains=1, rng=None):
     burn, sim = initialize_dynamics(inp, model, fa, nchains)
     b_ref, s_ref = initialize_reflect_update(inp, model)
     b_swap, s_swap = initialize_swap_update(inp, model)
-    Gr = greens.EstimateGreensFunction(model, int(inp.get("measurements", {}).get("num_random_vectors", 2)))
+    # chains in lockstep: n_v vectors per chain in one estimator (vector v of chain c at greens.chain_vector(est, c, v))
+    Gr = greens.EstimateGreensFunction(model, max(2, int(inp.get("measurements", {}).get("num_random_vectors", 2))) * max(1, int(nchains)))
     return SimpleNamespace(model=model, Gr=Gr, mu_tuner=mu_tuner, sim_params=sim_params, simulation_dynamics=sim, burnin_dynamics=burn,
                            burnin_reflect_update=b_ref, sim_reflect_update=s_ref, burnin_swap_update=b_swap, sim_swap_update=s_swap,
                            fa=fa, preconditioner=P, input=inp)

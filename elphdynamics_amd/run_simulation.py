@@ -10,6 +10,8 @@ runs where the reference runs it.
 """
 import time
 
+import numpy as np
+
 from . import greens, hmc, langevin
 from .mu_tuner import update_mu_
 
@@ -28,6 +30,9 @@ def run_simulation_(sim, measure=None, rng=None):
     stats = dict(simulation_time=0.0, measurement_time=0.0, write_time=0.0, iters=0.0, acceptance_rate=0.0,
                  reflect_acceptance_rate=0.0, swap_acceptance_rate=0.0)
     is_hmc = isinstance(sim.simulation_dynamics, hmc.HybridMonteCarlo)
+    nch = int(getattr(sim.simulation_dynamics, "nchains", 1))
+    if nch > 1 and getattr(sim, "mu_tuner", None) is not None and sim.mu_tuner.active:
+        raise NotImplementedError("tune_density with chains in lockstep: every chain would need its own chemical potential")
     phases = ((sim.burnin_dynamics, sp.burnin, sim.burnin_reflect_update, sim.burnin_swap_update, False),
               (sim.simulation_dynamics, sp.nsteps, sim.sim_reflect_update, sim.sim_swap_update, True))
     tuner = getattr(sim, "mu_tuner", None)
@@ -36,13 +41,17 @@ def run_simulation_(sim, measure=None, rng=None):
     for dyn, nsteps, reflect, swap, measuring in phases:
         for n in range(1, nsteps + 1):
             t0 = time.perf_counter()
-            if is_hmc:
+            if is_hmc and nch > 1:                                                      # chains in lockstep: means over the chains;
+                acc, it = hmc.update_chains_(m, dyn, fa, P, rng=rng, pull=False)        # special updates are single-chain moves
+                stats["iters"] += float(it.mean())
+                stats["acceptance_rate"] += float(acc.mean())
+            elif is_hmc:
                 acc, it = hmc.update_(m, dyn, fa, P, rng=rng, pull=False)
                 stats["iters"] += it
                 stats["acceptance_rate"] += float(acc)
                 _special(sim, dyn, n, reflect, swap, stats, P, rng)
             else:
-                stats["iters"] += langevin.evolve_(m, dyn, fa, P, rng=rng, pull=False)
+                stats["iters"] += float(np.mean(langevin.evolve_(m, dyn, fa, P, rng=rng, pull=False)))
             if tuning and not measuring and (is_hmc or n % mu_freq == 0):               # burn-in: :65-68 (Langevin), :198-201 (HMC)
                 greens.update_(sim.Gr, m, P, rng=rng)
                 update_mu_(m, tuner, sim.Gr, dyn)

@@ -365,7 +365,9 @@ int elph_greens_nv(elph_handle h, int *nv);
  * vectors the reference draws with randn!(model.rng, r₁), :212) solve MᵀM x = Mᵀ r from x = 0 with ldiv!'s semantics
  * (Models.jl:74-186; flags, zero-fill, un-preconditioned retry) — the n_v solves run as ONE batched CG.  R and M⁻¹R
  * stay on the device.  iters / residual_error / flag: per vector, each may be NULL.  With use_precond the caller has
- * run elph_kpm_setup on the current field (setup!(preconditioner), :206). */
+ * run elph_kpm_setup on the current field (setup!(preconditioner), :206).  With several chains resident (elph_update_model_*_chains /
+ * elph_hmc_create_*chains) row r of R belongs to chain r % nchains: create the estimator with n_v * nchains vectors and find
+ * vector v of chain c at row v * nchains + c (elph_greens_setup then takes those 1-based indices). */
 int elph_greens_update(elph_handle h, const double *R, int use_precond, int64_t *iters, double *residual_error, int *flag);
 
 /* estimator.R / estimator.M⁻¹R (double[n_v * ndim], vector-major, tau fastest); NULL = skip.  set: replay of vectors

@@ -9,6 +9,10 @@ import pytest
 
 from conftest import golden
 
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
 pytestmark = pytest.mark.gpu
 
 NAMES = ["GD0", "GD0_GD0", "GDD_G00", "GD0_G0D"]
@@ -105,3 +109,36 @@ def test_estimator_argument_checks():
     assert lib.elph_greens_setup(m._h, 1, 3, None, None, None, None) == _lib.ELPH_E_ARG
     assert lib.elph_greens_setup(m._h, 1, 2, None, None, None, None) == 0
     m.close()
+
+
+def test_greens_estimator_serves_chains_in_lockstep():
+    """One estimator for several resident chains: vector v of chain c lives at index v * nchains + c (right-hand side r of the
+    batched solve uses chain r % nchains), its M⁻¹R and its translation-averaged tables equal those of the single-chain
+    estimator on that chain's configuration."""
+    from elphdynamics_amd import configs, greens, models, preconditioners as pc, synth
+    nch, nv = 3, 2
+    m = configs.make_model("b", tol=1e-9)
+    X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=400 + c) for c in range(nch)])
+    R = np.stack([synth.randn(500 + r, m.Ndim) for r in range(nv * nch)])
+    models.update_model_chains_(m, X)
+    est = greens.EstimateGreensFunction(m, nv * nch)
+    P = pc.SymmetricKPMPreconditioner(m, 16, 0.05, 1.0, 1.0)
+    bmax, bmin = synth.randn(1, nch * m.Nsites).reshape(nch, -1), synth.randn(2, nch * m.Nsites).reshape(nch, -1)
+    it, res, fl = greens.update_(est, m, P, R=R, setup_kwargs=dict(b_max=bmax, b_min=bmin))
+    assert not fl.any()
+    tabs = {}
+    for c in range(nch):
+        greens.setup_(est, greens.chain_vector(est, c, 1), greens.chain_vector(est, c, 2))
+        tabs[c] = (est.GD0.copy(), est.GD0_G0D.copy(), est.MinvR[[c, nch + c]].copy())
+    m.close()
+    for c in range(nch):
+        m1 = configs.make_model("b", tol=1e-9)
+        m1.x[:] = X[c]
+        models.update_model_(m1)
+        e1 = greens.EstimateGreensFunction(m1, nv)
+        P1 = pc.SymmetricKPMPreconditioner(m1, 16, 0.05, 1.0, 1.0)
+        greens.update_(e1, m1, P1, R=R[[c, nch + c]], setup_kwargs=dict(b_max=bmax[c], b_min=bmin[c]))
+        greens.setup_(e1, 1, 2)
+        assert rel(tabs[c][2], e1.MinvR) < 1e-7
+        assert rel(tabs[c][0], e1.GD0) < 1e-7 and rel(tabs[c][1], e1.GD0_G0D) < 1e-7
+        m1.close()

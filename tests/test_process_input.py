@@ -160,6 +160,19 @@ def test_holstein_deck_in_lockstep_chains():
     acc, its = hmc.update_chains_(m, sim.burnin_dynamics, sim.fa, sim.preconditioner, pull=True)
     acc2, its2 = hmc.update_chains_(m, H, sim.fa, sim.preconditioner, pull=True)
     assert not H.flags.any() and its.min() > 0 and its2.min() > 0 and np.all(np.isfinite(H.X))
+    # the driver loop with chains: one estimator serves all of them (3 vectors per chain in this deck)
+    from elphdynamics_amd import greens, run_simulation as rs
+    assert sim.Gr.nv == 3 * 4
+    dens = []
+
+    def measure(sim, n):
+        for c in range(4):
+            greens.setup_(sim.Gr, greens.chain_vector(sim.Gr, c, 1), greens.chain_vector(sim.Gr, c, 2))
+            dens.append(1.0 - float(np.real(greens.measure_GD0(sim.Gr, 0, 0, 0, 1, 1, 0))))
+
+    stats = rs.run_simulation_(sim, measure=measure)
+    assert len(dens) == 4 * (sim.sim_params.nsteps // sim.sim_params.meas_freq) and all(-0.5 < d < 1.5 for d in dens)
+    assert 0.0 <= stats["acceptance_rate"] <= 1.0 and stats["iters"] > 0
     m.close()
 
 
