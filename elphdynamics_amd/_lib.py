@@ -72,6 +72,7 @@ SIGNATURES = {
     "elph_hmc_set_shared_fields": (c_int, [Handle, P_i64]),
     "elph_hmc_set_rng": (c_int, [Handle, C.c_uint64]),
     "elph_hmc_rng_batches": (c_int, [Handle, C.POINTER(C.c_uint64)]),
+    "elph_hmc_special_move_chains": (c_int, [Handle, c_int, P_i64, P_i64, P_dbl, P_dbl, c_int, P_dbl, P_dbl, P_int, P_dbl, P_dbl, P_i64, P_int]),
     "elph_hmc_special_move": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl, P_dbl, c_int, P_dbl, c_dbl, P_int, P_dbl, P_dbl, P_i64, P_int]),
     "elph_langevin_create": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
     "elph_langevin_create_ssh": (c_int, [Handle, c_i64, P_dbl, P_dbl, P_i64, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),

@@ -968,76 +968,98 @@ __global__ void __launch_bounds__(TPB) k_hmc_colop(double *__restrict__ x, int n
 //   accepted iff u < min(1, e^{−(S₁−S₀)}) and flag == 0, otherwise the move is undone and update_model! runs again.
 // kpm_randn: b_max, b_min [2][nsites] of the one setup!(P) (NULL without preconditioner).  The choice of sites / bonds
 // (sample!(model.rng, …)) stays with the caller.  out: accepted, S₀, S₁, iterations, flag.
+extern "C" int elph_hmc_special_move_chains(elph_handle h, int kind, const int64_t *col_i, const int64_t *col_j, const double *Rp,
+                                            const double *Rm, int use_precond, const double *kpm_randn, const double *u_accept,
+                                            int *accepted, double *S0_out, double *S1_out, int64_t *iters_out, int *flag_out) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st) { elph_set_error("elph_hmc_create[_ssh][_chains] has not been called"); return ELPH_E_STATE; }
+    if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
+    const int nch = st->nch;
+    if (!accepted || !col_i || kind < 0 || kind > 1 || (kind == 1 && !col_j)) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    for (int c = 0; c < nch; ++c)
+        if (col_i[c] < 0 || col_i[c] >= st->nf || (kind == 1 && (col_j[c] < 0 || col_j[c] >= st->nf))) {
+            elph_set_error("chain %d: column outside 0..%d", c, st->nf - 1);
+            return ELPH_E_ARG;
+        }
+    if (st->shared) {
+        elph_set_error("special moves on shared fields: the reference's swap leaves the fields unequal and then stops in update_model!");
+        return ELPH_E_UNSUPPORTED;
+    }
+    if ((!Rp || !Rm || !u_accept || (use_precond && !kpm_randn)) && !st->rng_on) {
+        elph_set_error("Rp, Rm, u_accept (kpm_randn with a preconditioner) are required unless elph_hmc_set_rng was called");
+        return ELPH_E_ARG;
+    }
+    if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
+    RC(elph_i_ensure_capacity(h, 2 * nch));
+    RC(elph_i_reserve_chains(h, nch));
+    const size_t nd = (size_t)h->ndim, nfd = (size_t)st->nf * (size_t)h->L;
+    const int L = (int)h->L;
+    RC(update_model(h, st));
+    // refresh_ϕ!(…, sample_R = true) for every chain   (R2, ϕ: [sign][chain][ndim])
+    RC(randn_vectors(h, st, st->R2, Rp, nch));
+    RC(randn_vectors(h, st, st->R2 + (size_t)nch * nd, Rm, nch));
+    std::vector<double> kpm_own, u_own;      // batches in the order Rp, Rm, kpm_randn, u_accept
+    if (use_precond && !kpm_randn) {
+        RC(randn_host(st, kpm_own, 2 * (size_t)nch * (size_t)h->N));
+        kpm_randn = kpm_own.data();
+    }
+    if (!u_accept) {
+        RC(uniform_host(st, u_own, (size_t)nch));
+        u_accept = u_own.data();
+    }
+    RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2 * nch));
+    if (st->ssh) {
+        HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * (size_t)nch * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        hipLaunchKernelGGL(k_hmc_phi, dim3(nblk((long long)nd * nch), 2), dim3(TPB), 0, h->stream, st->phi, h->d_b, st->x, h->d_lam, (int)h->N, L,
+                           st->dtau, nch);
+        RC(chk("k_hmc_phi"));
+    }
+    std::vector<double> rr((size_t)2 * nch), sf((size_t)2 * nch), sb0((size_t)nch), sb1((size_t)nch);
+    RC(dots_host(h, st, st->R2, st->R2, (long long)nd, 2 * nch, rr.data()));
+    RC(calc_Sb(h, st, sb0.data()));
+    auto move = [&](const std::vector<int> &which) -> int {       // both moves are involutions: the same call undoes them
+        for (int c = 0; c < nch; ++c) {
+            if (!which[(size_t)c]) continue;
+            hipLaunchKernelGGL(k_hmc_colop, dim3((unsigned)((L + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, st->x + (size_t)c * nfd, st->nf, L,
+                               kind, (int)col_i[c], (int)(col_j ? col_j[c] : 0));
+            RC(chk("k_hmc_colop"));
+        }
+        return update_model(h, st);
+    };
+    RC(move(std::vector<int>((size_t)nch, 1)));
+    int64_t kpm_calls = 0;
+    std::vector<int64_t> iters((size_t)nch, 0);
+    std::vector<int> flag((size_t)nch, 0), undo((size_t)nch, 0);
+    RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, iters.data(), flag.data()));
+    RC(dots_host(h, st, h->d_b, h->d_x, (long long)nd, 2 * nch, sf.data()));
+    RC(calc_Sb(h, st, sb1.data()));
+    bool any_undo = false;
+    for (int c = 0; c < nch; ++c) {
+        const double S0 = rr[(size_t)c] / 2 + rr[(size_t)nch + c] / 2 + sb0[(size_t)c];
+        const double S1 = sf[(size_t)c] / 2 + sf[(size_t)nch + c] / 2 + sb1[(size_t)c];
+        const double e = exp(-(S1 - S0)), P = (1.0 < e) ? 1.0 : e;
+        const int acc = (u_accept[c] < P && flag[(size_t)c] == 0) ? 1 : 0;
+        accepted[c] = acc;
+        undo[(size_t)c] = !acc;
+        any_undo = any_undo || !acc;
+        if (S0_out) S0_out[c] = S0;
+        if (S1_out) S1_out[c] = S1;
+        if (iters_out) iters_out[c] = iters[(size_t)c];
+        if (flag_out) flag_out[c] = flag[(size_t)c];
+    }
+    if (any_undo) RC(move(undo));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
 extern "C" int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int64_t col_j, const double *Rp, const double *Rm,
                                      int use_precond, const double *kpm_randn, double u_accept, int *accepted, double *S0_out,
                                      double *S1_out, int64_t *iters_out, int *flag_out) {
     CHECK_H(h);
     HmcState *st = state_of(h);
     if (!st || st->nch != 1) { elph_set_error("elph_hmc_create / elph_hmc_create_ssh (single chain) has not been called"); return ELPH_E_STATE; }
-    if (!st->have_state) { elph_set_error("elph_hmc_set_state(x) has not been called"); return ELPH_E_STATE; }
-    if (!accepted || kind < 0 || kind > 1 || col_i < 0 || col_i >= st->nf || (kind == 1 && (col_j < 0 || col_j >= st->nf))) {
-        elph_set_error("bad argument");
-        return ELPH_E_ARG;
-    }
-    if (st->shared) {
-        elph_set_error("special moves on shared fields: the reference's swap leaves the fields unequal and then stops in update_model!");
-        return ELPH_E_UNSUPPORTED;
-    }
-    if ((!Rp || !Rm || !(u_accept >= 0.0) || (use_precond && !kpm_randn)) && !st->rng_on) {
-        elph_set_error("Rp, Rm, u_accept >= 0 (kpm_randn with a preconditioner) are required unless elph_hmc_set_rng was called");
-        return ELPH_E_ARG;
-    }
-    if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
-    RC(elph_i_ensure_capacity(h, 2));
-    RC(elph_i_reserve_chains(h, 1));
-    const size_t nd = (size_t)h->ndim;
-    const int L = (int)h->L;
-    RC(update_model(h, st));
-    // refresh_ϕ!(…, sample_R = true)
-    RC(randn_vectors(h, st, st->R2, Rp, 1));
-    RC(randn_vectors(h, st, st->R2 + nd, Rm, 1));
-    std::vector<double> kpm_own, u_own;      // batches in the order Rp, Rm, kpm_randn, u_accept
-    if (use_precond && !kpm_randn) {
-        RC(randn_host(st, kpm_own, 2 * (size_t)h->N));
-        kpm_randn = kpm_own.data();
-    }
-    if (!(u_accept >= 0.0)) {
-        RC(uniform_host(st, u_own, 1));
-        u_accept = u_own[0];
-    }
-    RC(elph_launch_mul(h, 1, h->d_b, st->R2, 2));
-    if (st->ssh) {
-        HIPCHK(hipMemcpyAsync(st->phi, h->d_b, 2 * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    } else {
-        hipLaunchKernelGGL(k_hmc_phi, dim3(nblk((long long)nd), 2), dim3(TPB), 0, h->stream, st->phi, h->d_b, st->x, h->d_lam, (int)h->N, L,
-                           st->dtau, 1);
-        RC(chk("k_hmc_phi"));
-    }
-    double rr[2], sb0 = 0.0, sb1 = 0.0, sf[2];
-    RC(dots_host(h, st, st->R2, st->R2, (long long)nd, 2, rr));
-    RC(calc_Sb(h, st, &sb0));
-    const double S0 = rr[0] / 2 + rr[1] / 2 + sb0;
-    auto move = [&]() -> int {
-        hipLaunchKernelGGL(k_hmc_colop, dim3((unsigned)((L + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, st->x, st->nf, L, kind, (int)col_i,
-                           (int)col_j);
-        RC(chk("k_hmc_colop"));
-        return update_model(h, st);
-    };
-    RC(move());
-    int64_t kpm_calls = 0, iters = 0;
-    int flag = 0;
-    RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, &iters, &flag));
-    RC(dots_host(h, st, h->d_b, h->d_x, (long long)nd, 2, sf));
-    RC(calc_Sb(h, st, &sb1));
-    const double S1 = sf[0] / 2 + sf[1] / 2 + sb1;
-    const double e = exp(-(S1 - S0)), P = (1.0 < e) ? 1.0 : e;
-    const int acc = (u_accept < P && flag == 0) ? 1 : 0;
-    if (!acc) RC(move());                                  // both moves are involutions
-    HIPCHK(hipStreamSynchronize(h->stream));
-    *accepted = acc;
-    if (S0_out) *S0_out = S0;
-    if (S1_out) *S1_out = S1;
-    if (iters_out) *iters_out = iters;
-    if (flag_out) *flag_out = flag;
-    return ELPH_OK;
+    return elph_hmc_special_move_chains(h, kind, &col_i, &col_j, Rp, Rm, use_precond, kpm_randn, u_accept >= 0.0 ? &u_accept : nullptr,
+                                        accepted, S0_out, S1_out, iters_out, flag_out);
 }

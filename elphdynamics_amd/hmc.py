@@ -339,6 +339,35 @@ def special_move_(model, hmc, kind, col_i, col_j=0, P=None, rng=None, randoms=No
     return bool(acc.value), s0.value, s1.value, int(it.value), int(fl.value)
 
 
+def special_move_chains_(model, hmc, kind, cols_i, cols_j=None, P=None, rng=None, randoms=None):
+    """special_move_ for every chain of `hmc` at once: chain c proposes the move on ITS columns cols_i[c] (, cols_j[c]); one
+    batched action evaluation, acceptance per chain.  -> (accepted[nch] bool, S0[nch], S1[nch], iters[nch], flag[nch]).
+    randoms: dict(Rp (nch, Ndim), Rm, kpm_randn (2, nch, Nsites) or None, u (nch,)); None: drawn from rng / by the library."""
+    import ctypes as C
+    from ._lib import P_i64, P_int, check, dptr
+    nch = hmc.nchains
+    if randoms is None and hmc.device_rng:
+        randoms = _NO_RANDOMS
+    if randoms is None:
+        rng = rng or np.random.default_rng()
+        randoms = dict(Rp=rng.standard_normal((nch, model.Ndim)), Rm=rng.standard_normal((nch, model.Ndim)),
+                       kpm_randn=rng.standard_normal((2, nch, model.Nsites)) if P is not None else None, u=rng.random(nch))
+    model._push_solver()
+    ci = np.ascontiguousarray(cols_i, dtype=np.int64)
+    cj = np.ascontiguousarray(cols_j if cols_j is not None else np.zeros(nch), dtype=np.int64)
+    acc, fl = np.zeros(nch, dtype=np.int32), np.zeros(nch, dtype=np.int32)
+    it = np.zeros(nch, dtype=np.int64)
+    s0, s1 = np.zeros(nch), np.zeros(nch)
+    c = lambda a: dptr(np.ascontiguousarray(a, dtype=np.float64).reshape(-1)) if a is not None else None
+    check(model._lib.elph_hmc_special_move_chains(
+        model._h, int(kind), ci.ctypes.data_as(P_i64), cj.ctypes.data_as(P_i64), c(randoms.get("Rp")), c(randoms.get("Rm")),
+        0 if P is None else 1, c(randoms.get("kpm_randn")), c(randoms.get("u")), acc.ctypes.data_as(P_int), dptr(s0), dptr(s1),
+        it.ctypes.data_as(P_i64), fl.ctypes.data_as(P_int)))
+    if model.kind == models.SSH:
+        model._cs_stale = True
+    return acc.astype(bool), s0, s1, it, fl
+
+
 def _isapprox(a, b):
     """Julia's a ≈ b for vectors: ‖a − b‖ ≤ √eps · max(‖a‖, ‖b‖)."""
     return np.linalg.norm(a - b) <= 1.4901161193847656e-08 * max(np.linalg.norm(a), np.linalg.norm(b))
@@ -350,6 +379,10 @@ def reflection_update_(model, hmc, nsites, P=None, rng=None):
     if model.kind != models.HOLSTEIN or nsites < 1:
         return 0.0
     rng = rng or np.random.default_rng()
+    if hmc.nchains > 1:      # every chain draws its own sites; move k of all chains is one batched action evaluation
+        nmv = min(model.Nph, nsites)
+        sites = rng.integers(0, model.Nph, size=(nmv, hmc.nchains))
+        return float(np.mean([special_move_chains_(model, hmc, REFLECT, sites[k], P=P, rng=rng)[0] for k in range(nmv)]))
     sites = rng.integers(0, model.Nph, size=min(model.Nph, nsites))
     return sum(special_move_(model, hmc, REFLECT, int(i), P=P, rng=rng)[0] for i in sites) / len(sites)
 
@@ -377,6 +410,12 @@ def swap_update_(model, hmc, nbonds, P=None, rng=None):
         return acc / nbonds
     if model.Nbonds == 0:
         return 0.0
+    if hmc.nchains > 1:
+        nmv = min(model.Nbonds, nbonds)
+        bonds = rng.integers(0, model.Nbonds, size=(nmv, hmc.nchains))
+        tab = model.neighbor_table
+        return float(np.mean([special_move_chains_(model, hmc, SWAP, tab[bonds[k], 0] - 1, tab[bonds[k], 1] - 1, P=P, rng=rng)[0]
+                              for k in range(nmv)]))
     bonds = rng.integers(0, model.Nbonds, size=min(model.Nbonds, nbonds))
     tab = model.neighbor_table
     return sum(special_move_(model, hmc, SWAP, int(tab[b, 0]) - 1, int(tab[b, 1]) - 1, P=P, rng=rng)[0] for b in bonds) / len(bonds)

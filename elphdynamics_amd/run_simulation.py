@@ -41,10 +41,12 @@ def run_simulation_(sim, measure=None, rng=None):
     for dyn, nsteps, reflect, swap, measuring in phases:
         for n in range(1, nsteps + 1):
             t0 = time.perf_counter()
-            if is_hmc and nch > 1:                                                      # chains in lockstep: means over the chains;
-                acc, it = hmc.update_chains_(m, dyn, fa, P, rng=rng, pull=False)        # special updates are single-chain moves
+            if is_hmc and nch > 1:                                                      # chains in lockstep: means over the chains
+                acc, it = hmc.update_chains_(m, dyn, fa, P, rng=rng, pull=False)
                 stats["iters"] += float(it.mean())
                 stats["acceptance_rate"] += float(acc.mean())
+                if m.kind == 0:                                                         # (SSH swap moves compare world lines: single chain)
+                    _special(sim, dyn, n, reflect, swap, stats, P, rng)
             elif is_hmc:
                 acc, it = hmc.update_(m, dyn, fa, P, rng=rng, pull=False)
                 stats["iters"] += it

@@ -327,6 +327,12 @@ int elph_hmc_rng_batches(elph_handle h, uint64_t *batches);
  * (sample!(model.rng, …)) is the caller's bookkeeping. */
 int elph_hmc_special_move(elph_handle h, int kind, int64_t col_i, int64_t col_j, const double *Rp, const double *Rm, int use_precond,
                           const double *kpm_randn, double u_accept, int *accepted, double *S0, double *S1, int64_t *iters, int *flag);
+/* The same for chains in lockstep: every chain proposes its own move (col_i[c], col_j[c]) on its own field, one batched action
+ * evaluation serves all of them, acceptance is per chain (all arrays [nchains]; Rp, Rm chain-major like elph_hmc_update_chains;
+ * kpm_randn [2][nchains][nsites]). */
+int elph_hmc_special_move_chains(elph_handle h, int kind, const int64_t *col_i, const int64_t *col_j, const double *Rp,
+                                 const double *Rm, int use_precond, const double *kpm_randn, const double *u_accept,
+                                 int *accepted, double *S0, double *S1, int64_t *iters, int *flag);
 
 /* ---------------------------------------------------------------- Langevin dynamics (caller of the path) */
 

@@ -680,3 +680,50 @@ def test_ssh_langevin_chains_match_single_trajectories():
     for c in range(nch):
         assert rel(dyn.X[c] - starts[c], singles[c] - starts[c]) < 1e-7
     m.close()
+
+
+@pytest.mark.parametrize("with_kpm", [False, True])
+def test_special_moves_of_chains_equal_single_chain_moves(with_kpm):
+    """elph_hmc_special_move_chains: every chain proposes its own reflection / swap; S0, S1 and the decision of each chain equal
+    the single-chain move on that chain's field with the same random numbers; rejected chains get their field back."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc, synth
+    nch, tag = 3, "b"
+
+    def make(nchains):
+        m = configs.make_model(tag, tol=1e-9, maxiter=20000)
+        fa = pc.FourierAccelerator(m)
+        pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+        H = hmc.HybridMonteCarlo(m, fa, dt=0.05, tr=0.1, alpha=0.0, Nb=1, nchains=nchains)
+        P = pc.SymmetricKPMPreconditioner(m, 16, 0.05, 1.0, 1.0) if with_kpm else None
+        return m, fa, H, P
+
+    m, fa, H, P = make(nch)
+    X0 = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=900 + c) for c in range(nch)])
+    H.X[:] = X0
+    H.push_()
+    for kind, ci, cj in ((hmc.REFLECT, [1, 5, 9], None), (hmc.SWAP, [0, 3, 7], [1, 4, 11])):
+        rnd = dict(Rp=np.stack([synth.randn(1100 + c, m.Ndim) for c in range(nch)]), Rm=np.stack([synth.randn(1200 + c, m.Ndim) for c in range(nch)]),
+                   kpm_randn=synth.randn(1300, 2 * nch * m.Nsites).reshape(2, nch, m.Nsites) if with_kpm else None,
+                   u=np.array([0.0, 1.5, 0.0]))                      # chain 1 is forced to reject
+        H.X[:] = X0
+        H.push_()
+        acc, s0, s1, it, fl = hmc.special_move_chains_(m, H, kind, ci, cj, P=P, randoms=rnd)
+        H.pull_()
+        assert not fl.any() and acc[0] and not acc[1] and acc[2]
+        assert np.array_equal(H.X[1], X0[1])                       # undone bit-exactly
+        for c in range(nch):
+            m1, fa1, H1, P1 = make(1)
+            m1.x[:] = X0[c]
+            H1.push_()
+            r1 = dict(Rp=rnd["Rp"][c], Rm=rnd["Rm"][c], kpm_randn=np.ascontiguousarray(rnd["kpm_randn"][:, c, :]) if with_kpm else None,
+                      u=float(rnd["u"][c]))
+            a1, S0, S1, i1, f1 = hmc.special_move_(m1, H1, kind, ci[c], cj[c] if cj else 0, P=P1, randoms=r1)
+            H1.pull_()
+            assert a1 == bool(acc[c]) and abs(S0 - s0[c]) < 1e-9 * abs(S0) and abs(S1 - s1[c]) < 1e-8 * abs(S1)
+            assert np.abs(m1.x - H.X[c]).max() < 1e-12
+            m1.close()
+    # the frequency-driven helpers run per chain too
+    r = hmc.reflection_update_(m, H, 2, P, rng=np.random.default_rng(1))
+    s = hmc.swap_update_(m, H, 2, P, rng=np.random.default_rng(2))
+    assert 0.0 <= r <= 1.0 and 0.0 <= s <= 1.0
+    m.close()
