@@ -69,6 +69,7 @@ SIGNATURES = {
     "elph_hmc_update": (c_int, [Handle, c_dbl, c_i64, c_int, c_dbl, c_int, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_int, P_dbl, P_dbl,
                                 P_int]),
     "elph_hmc_set_mu": (c_int, [Handle, P_dbl]),
+    "elph_hmc_set_mu_chains": (c_int, [Handle, P_dbl]),
     "elph_hmc_set_shared_fields": (c_int, [Handle, P_i64]),
     "elph_hmc_set_rng": (c_int, [Handle, C.c_uint64]),
     "elph_hmc_rng_batches": (c_int, [Handle, C.POINTER(C.c_uint64)]),

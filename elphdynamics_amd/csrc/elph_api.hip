@@ -349,7 +349,7 @@ extern "C" int elph_destroy(elph_handle h) {
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_klam, h->d_ssh_x, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_cb, h->d_ssh_slot, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
-                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res};
+                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res, h->d_mu_ch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -529,6 +529,7 @@ extern "C" int elph_update_model_ssh_fields(elph_handle h, const double *x, int6
     CHECK_H(h);
     if (nph > 0 && !x) { elph_set_error("null argument"); return ELPH_E_ARG; }
     RC(elph_i_ssh_upload_params(h, nph, cb_index, t_ph, alpha, alpha2, t_bare_cb, mu));
+    h->mu_per_chain = false;
     if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }
     const size_t np = (size_t)nph;
     if (np > 0) HIPCHK(hipMemcpyAsync(h->d_ssh_x, x, np * (size_t)h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -802,6 +803,8 @@ static int ssh_reserve_chains(elph_handle_s *h, int nchains) {
         HIPCHK(hipMemset(h->d_lp_s, 0, one.size() * sizeof(double)));
     }
     if (h->ssh_nph_cap > 0) RC(dev_alloc(&h->d_ssh_x, nc * (size_t)h->ssh_nph_cap * L));
+    RC(dev_alloc(&h->d_E, nc * (size_t)h->N));          // exp(dtau mu) per chain
+    h->E_cap = (int64_t)(nc * (size_t)h->N);
     h->ssh_chain_cap = nchains;
     h->have_E = false;          // the tables are empty until the next update_model!
     h->cs_host_stale = true;
@@ -1270,10 +1273,9 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         h->h_sbar = h->h_s;
         h->kpm_hop_per_chain = false;
     } else {
-        // Ebar = exp(dtau mu): the same for every chain (replicated so that chain views need no special case)
-        HIPCHK(hipMemcpy(h->h_Ebar.data(), h->d_E, sizeof(double) * N, hipMemcpyDeviceToHost));
-        for (int c = 1; c < nch; ++c) std::copy(h->h_Ebar.begin(), h->h_Ebar.begin() + N, h->h_Ebar.begin() + (size_t)c * N);
-        HIPCHK(hipMemcpy(h->d_Ebar, h->h_Ebar.data(), sizeof(double) * (size_t)nch * N, hipMemcpyHostToDevice));
+        // Ebar = exp(dtau mu), held per chain (equal unless the chemical potential is tuned per chain)
+        HIPCHK(hipMemcpy(h->h_Ebar.data(), h->d_E, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h->d_Ebar, h->d_E, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToDevice));
         h->kpm_hop_per_chain = nch > 1;
         if (nch > h->kpm_hop_cap) {          // averaged hopping tables per chain (and their lane-program / register-exchange images)
             RC(dev_alloc(&h->d_cbar, (size_t)nch * h->nb));

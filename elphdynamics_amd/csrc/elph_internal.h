@@ -187,6 +187,9 @@ struct elph_handle_s {
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
     int *d_ssh_cb = nullptr, *d_ssh_slot = nullptr;
     int64_t ssh_nph_cap = 0;
+    double *d_mu_ch = nullptr;             // [mu_ch_cap][N] chemical potential per chain (the tuner with chains in lockstep)
+    int mu_ch_cap = 0;
+    bool mu_per_chain = false;
     int ssh_chain_cap = 1;                 // SSH: chains whose hopping tables (d_c, d_s, d_lp_c, d_lp_s) and fields (d_ssh_x) are allocated
     int ssh_nph = -1;                      // fields of the last device-side update_model!
     double ssh_dtau = 0.0;

@@ -83,12 +83,14 @@ __global__ void __launch_bounds__(TPB) k_randn_S(double *__restrict__ dst, uint6
 
 // E(τ,s) = exp(-Δτ (λ x + λ₂ x² - μ)), x already in layout S  (update_model!, HolsteinModels.jl:526-549)
 __global__ void __launch_bounds__(TPB) k_hmc_expV(double *__restrict__ E, const double *__restrict__ x,
-                                                  const double *__restrict__ lam3, int N, long long n, double dtau) {
+                                                  const double *__restrict__ lam3, int N, long long n, double dtau,
+                                                  const double *__restrict__ mu_ch, long long ndim) {
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     const int s = (int)(i % N);
     const double xi = x[i];
-    E[i] = exp(-dtau * (lam3[s] * xi + lam3[N + s] * (xi * xi) + -lam3[2 * N + s]));
+    const double mu = mu_ch ? mu_ch[(i / ndim) * N + s] : lam3[2 * N + s];      // per chain when the tuner runs per chain
+    E[i] = exp(-dtau * (lam3[s] * xi + lam3[N + s] * (xi * xi) + -mu));
 }
 
 // v = α v + sqrt(1-α²) y   (refresh_v!, HMC.jl:656)
@@ -275,7 +277,8 @@ int update_model(elph_handle_s *h, HmcState *st) {
         return ELPH_OK;
     }
     const long long n = (long long)h->ndim * st->nch;
-    hipLaunchKernelGGL(k_hmc_expV, dim3(nblk(n)), dim3(TPB), 0, h->stream, h->d_E, st->x, h->d_lam, (int)h->N, n, st->dtau);
+    hipLaunchKernelGGL(k_hmc_expV, dim3(nblk(n)), dim3(TPB), 0, h->stream, h->d_E, st->x, h->d_lam, (int)h->N, n, st->dtau,
+                       (const double *)((h->mu_per_chain && st->nch <= h->mu_ch_cap) ? h->d_mu_ch : nullptr), (long long)h->ndim);
     h->have_E = true;
     return chk("k_hmc_expV");
 }
@@ -464,6 +467,7 @@ static int hmc_create_core(elph_handle_s *h, int nchains, int nf, bool ssh, cons
     HmcState *st = new HmcState();
     h->hmc = st;
     st->nch = nchains; st->nf = nf; st->ssh = ssh;
+    h->mu_per_chain = false;                 // a new dynamics state starts from the deck's one chemical potential
     const size_t nd = (size_t)h->ndim, nfd = (size_t)nf * (size_t)h->L, nc = (size_t)nchains;
     double **vecs[] = {&st->x, &st->v, &st->x0, &st->v0, &st->dS, &st->y};
     for (double **p : vecs) HIPCHK(hipMalloc((void **)p, nc * nfd * sizeof(double)));
@@ -584,8 +588,30 @@ extern "C" int elph_hmc_set_mu(elph_handle h, const double *mu) {
     HmcState *st = state_of(h);
     if (!st || !mu) { elph_set_error(st ? "null argument" : "elph_hmc_create / elph_langevin_create has not been called"); return st ? ELPH_E_ARG : ELPH_E_STATE; }
     const size_t N = (size_t)h->N;
+    h->mu_per_chain = false;
     HIPCHK(hipMemcpyAsync(h->d_lam + (st->ssh ? 0 : 2 * N), mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (st->have_state) {
+        RC(update_model(h, st));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return ELPH_OK;
+}
+
+// the tuner with chains in lockstep: every chain its own chemical potential, mu[nchains][nsites]
+extern "C" int elph_hmc_set_mu_chains(elph_handle h, const double *mu) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st || !mu) { elph_set_error(st ? "null argument" : "elph_hmc_create / elph_langevin_create has not been called"); return st ? ELPH_E_ARG : ELPH_E_STATE; }
+    const size_t N = (size_t)h->N, nch = (size_t)st->nch;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((int)nch > h->mu_ch_cap) {
+        if (h->d_mu_ch) { HIPCHK(hipFree(h->d_mu_ch)); h->d_mu_ch = nullptr; }
+        HIPCHK(hipMalloc((void **)&h->d_mu_ch, nch * N * sizeof(double)));
+        h->mu_ch_cap = (int)nch;
+    }
+    HIPCHK(hipMemcpy(h->d_mu_ch, mu, nch * N * sizeof(double), hipMemcpyHostToDevice));
+    h->mu_per_chain = true;
     if (st->have_state) {
         RC(update_model(h, st));
         HIPCHK(hipStreamSynchronize(h->stream));

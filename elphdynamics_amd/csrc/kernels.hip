@@ -684,9 +684,11 @@ __global__ void __launch_bounds__(256) k_ssh_fields(double *__restrict__ c, doub
     if (slot && slot[n] >= 0) { lpc[(size_t)t * lp_stride + slot[n]] = cc; lps[(size_t)t * lp_stride + slot[n]] = ss; }
 }
 
-__global__ void __launch_bounds__(256) k_ssh_expmu(double *__restrict__ E, const double *__restrict__ mu, int N, double dtau) {
+// blockIdx.y = chain: every chain has its own exp(dtau mu) (the same values unless the chemical potential is tuned per chain)
+__global__ void __launch_bounds__(256) k_ssh_expmu(double *__restrict__ E, const double *__restrict__ mu, int N, double dtau,
+                                                   int mu_stride) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < N) E[i] = exp(dtau * mu[i]);
+    if (i < N) E[(size_t)blockIdx.y * N + i] = exp(dtau * mu[(size_t)blockIdx.y * mu_stride + i]);
 }
 
 // F[(p, tau)] = sg(tau) dtau (alpha_p + 2 alpha2_p x) q[tau][bond(p)]  — dMdx of the bond-phonon fields (SSHModels.jl:797-823)
@@ -894,7 +896,8 @@ __global__ void __launch_bounds__(1024) k_force_ssh(double *__restrict__ q, cons
     const int t = blockIdx.x;
     // blockIdx.y = chain: X = [sign][chain][ndim] (X+ of chain c, then X- at +nch*ndim), q = [chain][tau][bond], U = [chain][ndim]
     const size_t xm_off = (size_t)nch * ndim;
-    { const int ch = blockIdx.y; ssh_chain_select(m, ch); X += (size_t)ch * ndim; q += (size_t)ch * L * m.nb; if (U) U += (size_t)ch * ndim; }
+    { const int ch = blockIdx.y; ssh_chain_select(m, ch); X += (size_t)ch * ndim; q += (size_t)ch * L * m.nb; if (U) U += (size_t)ch * ndim;
+      m.E += (size_t)(ch % m.nchains) * (size_t)m.E_chain_stride; }
     const int tm1 = (t == 0) ? L - 1 : t - 1;
     const double sg = (t == 0) ? -1.0 : 1.0;
     const double *ct = m.c + (size_t)t * m.cs_tau_stride, *st = m.s + (size_t)t * m.cs_tau_stride;
@@ -959,7 +962,7 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.cs_tau_stride = (h->kind == ELPH_MODEL_SSH) ? (int)h->nb : 0;
     m.E_tau_stride = (h->kind == ELPH_MODEL_SSH) ? 0 : (int)h->N;
     m.nchains = h->nchains;
-    m.E_chain_stride = (h->kind == ELPH_MODEL_SSH) ? 0 : (long long)h->ndim;      // SSH: exp(dtau mu) is one per-site vector for all chains
+    m.E_chain_stride = (h->kind == ELPH_MODEL_SSH) ? (long long)h->N : (long long)h->ndim;   // SSH: exp(dtau mu), one per-site vector per chain
     m.bi = h->d_bi; m.bj = h->d_bj; m.coloff = h->d_coloff;
     m.c = h->d_c; m.s = h->d_s; m.E = h->d_E;
     if (h->solo_chain >= 0) {   // one right-hand side of a chains batch re-solved alone: present ITS configuration as the only one
@@ -974,7 +977,7 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
         if (h->solo_chain >= 0) {
             m.c += (size_t)h->solo_chain * cs; m.s += (size_t)h->solo_chain * cs;
             m.lp_c += (size_t)h->solo_chain * lp; m.lp_s += (size_t)h->solo_chain * lp;
-            m.E = h->d_E;                         // exp(dtau mu) is shared by the chains
+            m.E = h->d_E + (size_t)h->solo_chain * (size_t)h->N;
         } else {
             m.cs_chain_stride = cs; m.lp_chain_stride = lp;
         }
@@ -1109,7 +1112,11 @@ int elph_launch_ssh_update(elph_handle_s *h, const double *x_dev, int nph, const
                                h->d_lp_s, x_dev, par_dev, cb0_dev, slot, nph, nb, L, lp_stride, dtau, x_tau_major);
         }
     }
-    hipLaunchKernelGGL(k_ssh_expmu, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->d_E, h->d_lam, (int)h->N, dtau);
+    {
+        const bool per = h->mu_per_chain && h->d_mu_ch && nch <= h->mu_ch_cap;
+        hipLaunchKernelGGL(k_ssh_expmu, dim3((unsigned)((h->N + 255) / 256), (unsigned)nch), dim3(256), 0, h->stream, h->d_E,
+                           per ? h->d_mu_ch : h->d_lam, (int)h->N, dtau, per ? (int)h->N : 0);
+    }
     return check_launch("ssh update_model");
 }
 

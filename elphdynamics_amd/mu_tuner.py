@@ -153,3 +153,40 @@ def update_mu_(model, tuner, est, dyn=None):
     else:
         models.update_model_(model)
     return mu1
+
+
+def make_chain_tuners(tuner, nchains):
+    """One tuner per chain for a deck run as chains in lockstep (copies of the deck's tuner, advanced independently)."""
+    import copy
+    return [copy.deepcopy(tuner) for _ in range(int(nchains))]
+
+
+def update_mu_chains_(model, tuners, est, dyn):
+    """update_μ! for every chain of a lockstep run: chain c's ⟨N⟩, ⟨N²⟩ come from ITS noise vectors in the shared estimator
+    (greens.chain_vector), its tuner moves ITS chemical potential; the per-chain μ (dyn.mu_chains, (nchains, Nsites)) goes to the
+    device state with elph_hmc_set_mu_chains.  model.mu keeps the deck's value.  -> array of the new chain means of μ."""
+    nch = len(tuners)
+    nvc = est.nv // nch
+    if getattr(dyn, "mu_chains", None) is None:
+        dyn.mu_chains = np.tile(np.asarray(model.mu, dtype=np.float64), (nch, 1))
+    out = np.zeros(nch)
+    for c, tuner in enumerate(tuners):
+        mu0 = float(np.mean(dyn.mu_chains[c]))
+        if not tuner.active:
+            tuner.mu = out[c] = mu0
+            continue
+        Nsum = N2sum = 0.0
+        npairs = 0
+        for i in range(1, nvc):
+            for j in range(i + 1, nvc + 1):
+                greens.setup_(est, greens.chain_vector(est, c, i), greens.chain_vector(est, c, j))
+                Nsum += model.Nsites * measure_density(est)
+                N2sum += measure_N2(model, est)
+                npairs += 1
+        mu1 = tuner.update(Nsum / npairs, N2sum / npairs)
+        dyn.mu_chains[c] += mu1 - mu0
+        tuner.mu = out[c] = mu1
+    check(model._lib.elph_hmc_set_mu_chains(model._h, dptr(np.ascontiguousarray(dyn.mu_chains).reshape(-1))))
+    if model.kind == models.SSH:
+        model._cs_stale = True
+    return out

@@ -13,7 +13,7 @@ import time
 import numpy as np
 
 from . import greens, hmc, langevin
-from .mu_tuner import update_mu_
+from .mu_tuner import make_chain_tuners, update_mu_, update_mu_chains_
 
 
 def _special(sim, dyn, n, reflect, swap, stats, P, rng):
@@ -31,8 +31,8 @@ def run_simulation_(sim, measure=None, rng=None):
                  reflect_acceptance_rate=0.0, swap_acceptance_rate=0.0)
     is_hmc = isinstance(sim.simulation_dynamics, hmc.HybridMonteCarlo)
     nch = int(getattr(sim.simulation_dynamics, "nchains", 1))
-    if nch > 1 and getattr(sim, "mu_tuner", None) is not None and sim.mu_tuner.active:
-        raise NotImplementedError("tune_density with chains in lockstep: every chain would need its own chemical potential")
+    if nch > 1 and getattr(sim, "mu_tuner", None) is not None and sim.mu_tuner.active and getattr(sim, "mu_tuners", None) is None:
+        sim.mu_tuners = make_chain_tuners(sim.mu_tuner, nch)            # every chain tunes its own chemical potential
     phases = ((sim.burnin_dynamics, sp.burnin, sim.burnin_reflect_update, sim.burnin_swap_update, False),
               (sim.simulation_dynamics, sp.nsteps, sim.sim_reflect_update, sim.sim_swap_update, True))
     tuner = getattr(sim, "mu_tuner", None)
@@ -56,7 +56,10 @@ def run_simulation_(sim, measure=None, rng=None):
                 stats["iters"] += float(np.mean(langevin.evolve_(m, dyn, fa, P, rng=rng, pull=False)))
             if tuning and not measuring and (is_hmc or n % mu_freq == 0):               # burn-in: :65-68 (Langevin), :198-201 (HMC)
                 greens.update_(sim.Gr, m, P, rng=rng)
-                update_mu_(m, tuner, sim.Gr, dyn)
+                if nch > 1:
+                    update_mu_chains_(m, sim.mu_tuners, sim.Gr, dyn)
+                else:
+                    update_mu_(m, tuner, sim.Gr, dyn)
             stats["simulation_time"] += time.perf_counter() - t0
             if measuring and n % sp.meas_freq == 0:                                     # :91-95 / :250-254
                 t0 = time.perf_counter()
@@ -64,7 +67,9 @@ def run_simulation_(sim, measure=None, rng=None):
                 greens.update_(sim.Gr, m, P, rng=rng)                                   # make_measurements! starts with update!(Gr, …)
                 if measure is not None:
                     measure(sim, n // sp.meas_freq)
-                if tuning:                                                              # :98-100 / :255-257
+                if tuning and nch > 1:
+                    update_mu_chains_(m, sim.mu_tuners, sim.Gr, dyn)
+                elif tuning:                                                            # :98-100 / :255-257
                     update_mu_(m, tuner, sim.Gr, dyn)
                 stats["measurement_time"] += time.perf_counter() - t0
     total = sp.nsteps + sp.burnin

@@ -295,6 +295,8 @@ int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int nb, double 
 /* model.μ changed while the field lives on the device (the chemical-potential tuner, MuFinder.jl:68-107 adds Δμ to every site):
  * new μ[nsites] for the HMC / Langevin state, followed by update_model!. */
 int elph_hmc_set_mu(elph_handle h, const double *mu);
+/* chains in lockstep, each with its own tuner: mu[nchains][nsites] (elph_hmc_set_mu / a new elph_hmc_create* return to one μ) */
+int elph_hmc_set_mu_chains(elph_handle h, const double *mu);
 
 /* SSH phonon types of the same name (the default "" included) share their fields: primary_field of initialize_model!
  * (SSHModels.jl:480-502).  primary_column[Nph]: 0-based column of the primary phonon of every phonon (itself for a primary; the

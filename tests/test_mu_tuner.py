@@ -78,3 +78,49 @@ def test_tune_density_deck_runs_and_mu_reaches_the_device():
     g00 = np.mean([np.real(greens.measure_GD0(sim.Gr, 0, 0, 0, o, o, 0)) for o in (1, 2)])
     assert abs(n - 2.0 * (1.0 - g00)) < 0.3
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deck", ["holstein_hmc_honeycomb_L3.toml", "ssh_langevin_square_L4.toml"])
+def test_tune_density_with_chains_in_lockstep(deck):
+    """Chains in lockstep with [tune_density]: one tuner and one chemical potential per chain (elph_hmc_set_mu_chains); the
+    device model of every chain carries ITS μ."""
+    from elphdynamics_amd import models, process_input as pi, run_simulation as rs
+    nch = 3
+    inp = pi.read_deck(os.path.join(DECKS, deck))
+    inp["tune_density"] = dict(density=0.9, memory=0.75, kappa_min=0.1)
+    if "hmc" in inp:
+        inp["hmc"]["burnin_updates"], inp["hmc"]["simulation_updates"] = 3, 2
+    else:
+        inp["langevin"]["burnin_timesteps"], inp["langevin"]["simulation_timesteps"], inp["langevin"]["meas_freq"] = 2, 2, 1
+        inp["measurements"]["num_random_vectors"] = 3
+    sim = pi.process_input_file(inp, nchains=nch)
+    m, dyn = sim.model, sim.simulation_dynamics
+    rng = np.random.default_rng(2)
+    for c in range(nch):
+        dyn.X[c] = m.x * (1.0 + 0.05 * c) + 0.02 * rng.standard_normal(m.Ndof)
+    dyn.push_()
+    mu_deck = m.mu.copy()
+    stats = rs.run_simulation_(sim)
+    tuners = sim.mu_tuners
+    assert len(tuners) == nch and all(len(t.N_traj) >= 4 for t in tuners)
+    mus = np.array([t.mu for t in tuners])
+    assert len(set(np.round(mus, 10))) == nch and np.array_equal(m.mu, mu_deck)            # each chain went its own way
+    assert np.allclose(dyn.mu_chains.mean(axis=1), mus)
+    # chain c of the device model = a single model with chain c's field and chain c's μ: same solution of MᵀM x = b
+    dyn.pull_()
+    B = rng.standard_normal((nch, m.Ndim))
+    Xs = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(Xs, m, B)
+    assert not fl.any()
+    for c in range(nch):
+        s1 = pi.process_input_file(pi.read_deck(os.path.join(DECKS, deck)))
+        m1 = s1.model
+        m1.x[:] = dyn.X[c]
+        m1.mu[:] = dyn.mu_chains[c]
+        models.update_model_(m1)
+        x1 = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x1, m1, np.ascontiguousarray(B[c]))
+        assert fl1 == 0 and np.linalg.norm(x1 - Xs[c]) < 1e-6 * np.linalg.norm(x1)
+        m1.close()
+    m.close()
