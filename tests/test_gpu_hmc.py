@@ -727,3 +727,43 @@ def test_special_moves_of_chains_equal_single_chain_moves(with_kpm):
     s = hmc.swap_update_(m, H, 2, P, rng=np.random.default_rng(2))
     assert 0.0 <= r <= 1.0 and 0.0 <= s <= 1.0
     m.close()
+
+
+@pytest.mark.parametrize("mu", [0.0, -0.3])
+def test_hmc_samples_the_exactly_solvable_single_site_model(mu):
+    """End-to-end physics, independent of the restatement: the reference's single-site deck (holstein_hmc_single_site.toml:
+    one site, no hopping) is exactly solvable.  The pseudofermion weight det(Λ⁻¹MᵀMΛ⁻¹) = det(M)² e^{Δτ λ Σx} is the
+    particle-hole symmetric coupling H = p²/2 + ω²x²/2 + λ x (n − 1) − μ n, so E_n = −μ n − λ²(n−1)²/(2ω²) and
+    <x> = −λ(<n> − 1)/ω²,  <x²> = Σ_n p_n x_n² + coth(βω/2)/(2ω).  64 chains in lockstep supply the statistics."""
+    from elphdynamics_amd import hmc, lattice as lat, models, preconditioners as pc
+    beta, dtau, w, lam, nch, nup = 2.0, 0.1, 1.0, 1.0, 64, 700
+    E = [-mu * n - lam ** 2 * (n - 1) ** 2 / (2 * w ** 2) for n in (0, 1, 2)]
+    wgt = np.array([1, 2, 1]) * np.exp(-beta * np.array(E))
+    p = wgt / wgt.sum()
+    n_exact = float(p @ np.array([0, 1, 2]))
+    x_exact = -lam * (n_exact - 1) / w ** 2
+    x2_exact = float(p @ (lam * (np.array([0, 1, 2]) - 1) / w ** 2) ** 2) + 1.0 / (2 * w * np.tanh(beta * w / 2))
+    m = models.HolsteinModel(lat.Lattice(1, 1, 1, 1), beta, dtau, tol=1e-10, maxiter=1000)
+    m.assign_omega_(w), m.assign_lambda_(lam), m.assign_mu_(mu)
+    m.initialize_model_()
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.0)
+    H = hmc.HybridMonteCarlo(m, fa, dt=0.1, tr=1.0, alpha=0.0, Nb=1, nchains=nch)
+    H.X[:] = 0.5 * np.random.default_rng(5).standard_normal((nch, 1))
+    H.push_()
+    H.device_rng_(20260131)
+    xs, x2s, acc = [], [], 0.0
+    for k in range(nup):
+        a, it = hmc.update_chains_(m, H, fa, None, pull=True)
+        acc += a.mean()
+        if k >= 100:
+            xs.append(H.X.mean())
+            x2s.append(np.mean(H.X ** 2))
+    xs, x2s = np.array(xs), np.array(x2s)
+    nb = 20
+    err = lambda v: v[:len(v) // nb * nb].reshape(nb, -1).mean(axis=1).std(ddof=1) / np.sqrt(nb)
+    assert acc / nup > 0.9
+    assert err(xs) < 0.03 and err(x2s) < 0.03                                  # the statistics are what they should be
+    assert abs(xs.mean() - x_exact) < 4 * err(xs) + 0.01, (xs.mean(), x_exact, err(xs))
+    assert abs(x2s.mean() - x2_exact) < 4 * err(x2s) + 0.015, (x2s.mean(), x2_exact, err(x2s))    # + O(Δτ²) of the discretised path
+    m.close()
