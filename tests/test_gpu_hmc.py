@@ -767,3 +767,47 @@ def test_hmc_samples_the_exactly_solvable_single_site_model(mu):
     assert abs(xs.mean() - x_exact) < 4 * err(xs) + 0.01, (xs.mean(), x_exact, err(xs))
     assert abs(x2s.mean() - x2_exact) < 4 * err(x2s) + 0.015, (x2s.mean(), x2_exact, err(x2s))    # + O(Δτ²) of the discretised path
     m.close()
+
+
+@pytest.mark.parametrize("mu", [0.0, -0.5])
+def test_ssh_hmc_samples_the_exactly_solvable_two_site_model(mu):
+    """The same for bond phonons (the reference's ssh_hmc_two_site deck): K = Σ_σ (c†₁σ c₂σ + h.c.) commutes with
+    H = −(t − α x) K − μ N + p²/2 + ω² x²/2, every (N, k) sector is a displaced oscillator:
+    E = −t k − μ N − α² k²/(2ω²),  <x> = −α <k>/ω²,  <x²> = α² <k²>/ω⁴ + coth(βω/2)/(2ω).  SSH chains in lockstep."""
+    import itertools
+    from elphdynamics_amd import hmc, lattice as lat, models, preconditioners as pc
+    beta, dtau, w, t, alpha, nch, nup = 2.0, 0.1, 1.0, 1.0, 0.8, 64, 700
+    one = [(0, 0), (1, 1), (1, -1), (2, 0)]                   # (N, k) of one spin species: empty, bonding, antibonding, full
+    Z = k_av = k2_av = 0.0
+    for (N1, k1), (N2, k2) in itertools.product(one, one):
+        N, k = N1 + N2, k1 + k2
+        wgt = np.exp(-beta * (-t * k - mu * N - alpha ** 2 * k ** 2 / (2 * w ** 2)))
+        Z += wgt; k_av += k * wgt; k2_av += k * k * wgt
+    x_exact = -alpha * (k_av / Z) / w ** 2
+    x2_exact = alpha ** 2 * (k2_av / Z) / w ** 4 + 1.0 / (2 * w * np.tanh(beta * w / 2))
+    m = models.SSHModel(lat.Lattice(1, 2, 1, 1), beta, dtau, tol=1e-10, maxiter=1000)
+    m.assign_hopping_(t, alpha, 0.0, w, 1, 1, (1, 0, 0), name="b")
+    m.initialize_model_()
+    m.mu[:] = mu
+    assert m.Nbonds == 1 and m.Nph == 1
+    models.update_model_(m)
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.0)
+    H = hmc.HybridMonteCarlo(m, fa, dt=0.1, tr=1.0, alpha=0.0, Nb=1, nchains=nch)
+    H.X[:] = 0.3 * np.random.default_rng(5).standard_normal((nch, 1))
+    H.push_()
+    H.device_rng_(20260132)
+    xs, x2s, acc = [], [], 0.0
+    for kk in range(nup):
+        a, it = hmc.update_chains_(m, H, fa, None, pull=True)
+        acc += a.mean()
+        if kk >= 100:
+            xs.append(H.X.mean())
+            x2s.append(np.mean(H.X ** 2))
+    xs, x2s = np.array(xs), np.array(x2s)
+    nb = 20
+    err = lambda v: v[:len(v) // nb * nb].reshape(nb, -1).mean(axis=1).std(ddof=1) / np.sqrt(nb)
+    assert acc / nup > 0.9 and err(xs) < 0.02 and err(x2s) < 0.05
+    assert abs(xs.mean() - x_exact) < 4 * err(xs) + 0.01, (xs.mean(), x_exact, err(xs))
+    assert abs(x2s.mean() - x2_exact) < 4 * err(x2s) + 0.03, (x2s.mean(), x2_exact, err(x2s))
+    m.close()
