@@ -222,3 +222,37 @@ def test_ssh_langevin_shared_fields_vs_oracle(oracle, scheme):
         assert rel(m.x - x_prev, x_o - x_prev) < 1e-6
         assert np.array_equal(m.x[:half], m.x[half:])
     m.close()
+
+
+def test_langevin_samples_the_exactly_solvable_single_site_model():
+    """Heun's dynamics (64 chains in lockstep, Δt = 0.02) on the single-site Holstein model: <x>, <x²> of
+    H = p²/2 + ω²x²/2 + λx(n − 1) − μn within the statistical error plus the O(Δt²) and stochastic-force bias of the scheme."""
+    from elphdynamics_amd import langevin, lattice as lat, models, preconditioners as pc
+    beta, dtau, w, lam, mu, nch, nst = 2.0, 0.1, 1.0, 1.0, -0.3, 64, 5000
+    E = [-mu * n - lam ** 2 * (n - 1) ** 2 / (2 * w ** 2) for n in (0, 1, 2)]
+    wgt = np.array([1, 2, 1]) * np.exp(-beta * np.array(E))
+    p = wgt / wgt.sum()
+    x_exact = -lam * (float(p @ np.array([0, 1, 2])) - 1) / w ** 2
+    x2_exact = float(p @ (lam * (np.array([0, 1, 2]) - 1) / w ** 2) ** 2) + 1.0 / (2 * w * np.tanh(beta * w / 2))
+    m = models.HolsteinModel(lat.Lattice(1, 1, 1, 1), beta, dtau, tol=1e-10, maxiter=1000)
+    m.assign_omega_(w), m.assign_lambda_(lam), m.assign_mu_(mu)
+    m.initialize_model_()
+    fa = pc.FourierAccelerator(m)
+    pc.update_Q_(fa, m, 0.0, np.inf, 1.0)
+    dyn = langevin.HeunsDynamics(m, fa, 0.02, nchains=nch)
+    dyn.X[:] = 0.5 * np.random.default_rng(5).standard_normal((nch, 1))
+    dyn.push_()
+    dyn.device_rng_(20260133)
+    xs, x2s = [], []
+    for k in range(nst):
+        langevin.evolve_(m, dyn, fa, None, pull=(k % 10 == 9))
+        if k % 10 == 9 and k >= 500:
+            xs.append(dyn.X.mean())
+            x2s.append(np.mean(dyn.X ** 2))
+    xs, x2s = np.array(xs), np.array(x2s)
+    nb = 20
+    err = lambda v: v[:len(v) // nb * nb].reshape(nb, -1).mean(axis=1).std(ddof=1) / np.sqrt(nb)
+    assert err(xs) < 0.03 and err(x2s) < 0.03
+    assert abs(xs.mean() - x_exact) < 4 * err(xs) + 0.02, (xs.mean(), x_exact, err(xs))
+    assert abs(x2s.mean() - x2_exact) < 4 * err(x2s) + 0.03, (x2s.mean(), x2_exact, err(x2s))
+    m.close()
