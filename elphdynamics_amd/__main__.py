@@ -1,0 +1,61 @@
+"""python -m elphdynamics_amd deck.toml [--chains N] [--device D] [--out phonon_config.out]
+
+Runs one of the reference's TOML decks on the GPU the way `julia -e "using ElPhDynamics; simulate(ARGS)" -- deck.toml` runs it
+(ElPhDynamics.jl:80-130): burn-in and simulation updates with the deck's dynamics, special updates, μ-tuning and, at every
+measurement, the correlation functions of measurements.py averaged over the run.  Prints the run statistics as one JSON line and
+optionally writes the final phonon configuration in the reference's text format.  The reference's measurement files, bins,
+checkpoints and logs are not produced (control plane)."""
+import argparse
+import json
+import sys
+
+import numpy as np
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m elphdynamics_amd")
+    ap.add_argument("deck")
+    ap.add_argument("--chains", type=int, default=1, help="independent runs of the deck advanced in lockstep on this GPU")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--out", default=None, help="write the final phonon configuration (chain 0) here")
+    args = ap.parse_args(argv)
+    from . import io, measurements, process_input, run_simulation
+    sim = process_input.process_input_file(args.deck, device=args.device, nchains=args.chains)
+    m = sim.model
+    acc = measurements.new_accumulator(m) if args.chains == 1 else None
+
+    def measure(sim, n):
+        if acc is not None:
+            # the Green's estimate of this measurement is fresh (run_simulation_ called update!); add every pair's contribution
+            from . import greens
+            for i in range(1, sim.Gr.nv):
+                for j in range(i + 1, sim.Gr.nv + 1):
+                    greens.setup_(sim.Gr, i, j)
+                    g = measurements.global_measurements(m, sim.Gr)
+                    for k in acc["glob"]:
+                        acc["glob"][k] += g[k]
+                    for kind in measurements.KINDS:
+                        measurements.correlation_(acc["corr"][kind], acc["pairs"], m, sim.Gr, kind)
+                    acc["n"] += 1
+
+    stats = run_simulation.run_simulation_(sim, measure=measure)
+    out = dict(deck=args.deck, chains=args.chains, nsites=m.Nsites, ltau=m.Ltau, **{k: float(v) for k, v in stats.items()})
+    if acc is not None and acc["n"]:
+        out["density"] = acc["glob"]["density"] / acc["n"]
+        out["mu"] = acc["glob"]["mu"] / acc["n"]
+        out["G_r0_tau0"] = float(np.real(acc["corr"]["Greens"][0, 0, 0, 0, 0]) / acc["n"])
+    if sim.mu_tuner.active and args.chains == 1:
+        from .mu_tuner import estimate_mu
+        estimate_mu(sim.mu_tuner)
+        out["mu_avg"], out["mu_err"] = sim.mu_tuner.mu_avg, sim.mu_tuner.mu_err
+    if args.out:
+        if args.chains > 1:
+            m.x[:] = sim.simulation_dynamics.X[0]
+        io.write_phonons_(m, args.out)
+    print(json.dumps(out))
+    m.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
