@@ -93,11 +93,15 @@ def main():
     m = configs.make_model(args.config, tol=1e-5, device=comm.device_index(),
                            seed=comm.chain_seed(synth.SEED_FIELDS))
     nrhs = args.nrhs
-    nchains = 1 if m.kind != 0 else max(1, min(args.chains, nrhs))
+    nchains = max(1, min(args.chains, nrhs))
     R, B = configs.rhs(m, nrhs, seed=comm.chain_seed(synth.SEED_RHS))
     if nchains > 1:      # every chain its own phonon configuration (its own fermion matrix)
-        Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=comm.chain_seed(synth.SEED_FIELDS) + 17 * c)
-                       for c in range(nchains)])
+        if m.kind == 0:
+            Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=comm.chain_seed(synth.SEED_FIELDS) + 17 * c)
+                           for c in range(nchains)])
+        else:            # bond phonons: the deck's field rescaled and roughened per chain (|alpha x| stays below t)
+            Xc = np.stack([m.x * (0.6 + 0.8 * c / nchains) * (1.0 + 0.2 * synth.randn(comm.chain_seed(synth.SEED_FIELDS) + 17 * c, m.Ndof))
+                           for c in range(nchains)])
         models.update_model_chains_(m, Xc)
     what = 3 if args.precond else 1
     P = None
