@@ -18,6 +18,7 @@ def main(argv=None):
     ap.add_argument("--chains", type=int, default=1, help="independent runs of the deck advanced in lockstep on this GPU")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default=None, help="write the final phonon configuration (chain 0) here")
+    ap.add_argument("--checkpoint", default=None, help="checkpoint file: written periodically, resumed from when it exists")
     args = ap.parse_args(argv)
     from . import io, measurements, process_input, run_simulation
     sim = process_input.process_input_file(args.deck, device=args.device, nchains=args.chains)
@@ -38,7 +39,8 @@ def main(argv=None):
                         measurements.correlation_(acc["corr"][kind], acc["pairs"], m, sim.Gr, kind)
                     acc["n"] += 1
 
-    stats = run_simulation.run_simulation_(sim, measure=measure)
+    stats = run_simulation.run_simulation_(sim, measure=measure, checkpoint=args.checkpoint, resume=args.checkpoint is not None,
+                                           checkpoint_every=60.0 * float(sim.sim_params.checkpoint_freq))
     out = dict(deck=args.deck, chains=args.chains, nsites=m.Nsites, ltau=m.Ltau, **{k: float(v) for k, v in stats.items()})
     if acc is not None and acc["n"]:
         out["density"] = acc["glob"]["density"] / acc["n"]

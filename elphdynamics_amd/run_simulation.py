@@ -24,13 +24,70 @@ def _special(sim, dyn, n, reflect, swap, stats, P, rng):
         stats["swap_acceptance_rate"] += hmc.swap_update_(m, dyn, swap.nbonds, P, rng=rng)
 
 
-def run_simulation_(sim, measure=None, rng=None):
+def save_checkpoint(path, sim, phase, n, stats, rng):
+    """Checkpoint of a run (the reference serialises (model, μ_tuner, container, burnin_start, sim_start, sim_stats) to
+    checkpoint.jls, RunSimulation.jl:54-59,120-126,175-180; dynamics, accelerator, preconditioner and estimator are rebuilt from
+    the deck on resume, ProcessInputFile.jl:122-177 — the same split here): field(s), momenta, chemical potential(s), tuner(s),
+    generator state, position in the run, statistics."""
+    import pickle
+    dyn = sim.simulation_dynamics
+    dyn.pull_()
+    state = dict(phase=phase, n=n, stats=dict(stats), x=sim.model.x.copy(), mu=sim.model.mu.copy(),
+                 X=None if getattr(dyn, "X", None) is None else dyn.X.copy(), V=None if getattr(dyn, "V", None) is None else dyn.V.copy(),
+                 v=None if getattr(dyn, "v", None) is None else np.array(dyn.v).copy(), mu_chains=getattr(dyn, "mu_chains", None),
+                 mu_tuner=getattr(sim, "mu_tuner", None), mu_tuners=getattr(sim, "mu_tuners", None),
+                 rng=None if rng is None else rng.bit_generator.state)
+    tmp = str(path) + ".tmp"
+    with open(tmp, "wb") as f:
+        pickle.dump(state, f)
+    import os
+    os.replace(tmp, path)
+
+
+def load_checkpoint(path, sim, rng):
+    """Put a run built from the same deck (process_input_file) back where save_checkpoint left it -> (phase, n, stats)."""
+    import pickle
+    from ._lib import check, dptr
+    with open(path, "rb") as f:
+        st = pickle.load(f)
+    m, dyn = sim.model, sim.simulation_dynamics
+    m.x[:], m.mu[:] = st["x"], st["mu"]
+    if st["X"] is not None:
+        dyn.X[:] = st["X"]
+        if st["V"] is not None and getattr(dyn, "V", None) is not None:
+            dyn.V[:] = st["V"]
+    elif st["v"] is not None and getattr(dyn, "v", None) is not None:
+        dyn.v[:] = st["v"]
+    sim.mu_tuner = st["mu_tuner"] if st["mu_tuner"] is not None else sim.mu_tuner
+    if st["mu_tuners"] is not None:
+        sim.mu_tuners = st["mu_tuners"]
+    dyn.push_()
+    if st["mu_chains"] is not None:
+        dyn.mu_chains = st["mu_chains"]
+        check(m._lib.elph_hmc_set_mu_chains(m._h, dptr(np.ascontiguousarray(dyn.mu_chains).reshape(-1))))
+    else:
+        check(m._lib.elph_hmc_set_mu(m._h, dptr(np.ascontiguousarray(m.mu))))
+    if rng is not None and st["rng"] is not None:
+        rng.bit_generator.state = st["rng"]
+    return st["phase"], st["n"], st["stats"]
+
+
+def run_simulation_(sim, measure=None, rng=None, checkpoint=None, checkpoint_every=600.0, resume=False):
+    """checkpoint: file written every `checkpoint_every` seconds (sim_params.checkpoint_freq is in minutes in the decks) and at
+    the end of every phase; resume=True continues from it when it exists (the reference resumes when the data folder exists,
+    ElPhDynamics.jl:102-107)."""
+    import os
     m, fa, P, sp = sim.model, sim.fa, sim.preconditioner, sim.sim_params
     rng = rng or getattr(m, "rng", None)
     stats = dict(simulation_time=0.0, measurement_time=0.0, write_time=0.0, iters=0.0, acceptance_rate=0.0,
                  reflect_acceptance_rate=0.0, swap_acceptance_rate=0.0)
     is_hmc = isinstance(sim.simulation_dynamics, hmc.HybridMonteCarlo)
     nch = int(getattr(sim.simulation_dynamics, "nchains", 1))
+    start_phase, start_n = 0, 1
+    if checkpoint and resume and os.path.exists(checkpoint):
+        start_phase, last_n, stats = load_checkpoint(checkpoint, sim, rng)
+        start_n = last_n + 1
+    t_ckpt = time.perf_counter()
     if nch > 1 and getattr(sim, "mu_tuner", None) is not None and sim.mu_tuner.active and getattr(sim, "mu_tuners", None) is None:
         sim.mu_tuners = make_chain_tuners(sim.mu_tuner, nch)            # every chain tunes its own chemical potential
     phases = ((sim.burnin_dynamics, sp.burnin, sim.burnin_reflect_update, sim.burnin_swap_update, False),
@@ -38,8 +95,10 @@ def run_simulation_(sim, measure=None, rng=None):
     tuner = getattr(sim, "mu_tuner", None)
     tuning = tuner is not None and tuner.active
     mu_freq = max(sp.meas_freq, 1)                                                      # :47
-    for dyn, nsteps, reflect, swap, measuring in phases:
-        for n in range(1, nsteps + 1):
+    for iphase, (dyn, nsteps, reflect, swap, measuring) in enumerate(phases):
+        if iphase < start_phase:
+            continue
+        for n in range(start_n if iphase == start_phase else 1, nsteps + 1):
             t0 = time.perf_counter()
             if is_hmc and nch > 1:                                                      # chains in lockstep: means over the chains
                 acc, it = hmc.update_chains_(m, dyn, fa, P, rng=rng, pull=False)
@@ -72,6 +131,11 @@ def run_simulation_(sim, measure=None, rng=None):
                 elif tuning:                                                            # :98-100 / :255-257
                     update_mu_(m, tuner, sim.Gr, dyn)
                 stats["measurement_time"] += time.perf_counter() - t0
+            if checkpoint and (time.perf_counter() - t_ckpt > checkpoint_every or n == nsteps):
+                t0 = time.perf_counter()
+                save_checkpoint(checkpoint, sim, iphase, n, stats, rng)
+                t_ckpt = time.perf_counter()
+                stats["write_time"] += t_ckpt - t0
     total = sp.nsteps + sp.burnin
     stats["iters"] /= max(total, 1)                                                     # :131 / :284
     if is_hmc:

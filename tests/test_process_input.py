@@ -193,3 +193,35 @@ def test_ssh_deck_in_lockstep_chains():
     d = np.abs(dyn.X - X0).max(axis=1)
     assert np.all(d > 0) and np.all(d < 1.0) and len(set(np.round(d, 12))) == 3       # every chain moved, each its own way
     m.close()
+
+
+@pytest.mark.gpu
+def test_checkpoint_and_resume_continue_the_same_run(tmp_path):
+    """A run interrupted after the burn-in phase and resumed from its checkpoint ends where the uninterrupted run ends: field,
+    momenta, μ, tuner and generator state travel in the checkpoint; dynamics, accelerator, preconditioner and estimator are
+    rebuilt, as in the reference — the rebuilt preconditioner starts its bound hysteresis afresh, so solves agree to the solver
+    tolerance rather than bit for bit."""
+    from elphdynamics_amd import process_input as pi, run_simulation as rs
+    deck = os.path.join(DECKS, "holstein_hmc_honeycomb_L3.toml")
+
+    def build():
+        inp = pi.read_deck(deck)
+        inp["tune_density"] = dict(density=0.9, memory=0.75, kappa_min=0.1)
+        inp["hmc"]["burnin_updates"], inp["hmc"]["simulation_updates"] = 3, 3
+        return pi.process_input_file(inp)
+
+    a = build()
+    stats_a = rs.run_simulation_(a)
+    xa, mua = a.model.x.copy(), a.model.mu.copy()
+    a.model.close()
+    ck = str(tmp_path / "checkpoint.pkl")
+    b = build()
+    b.sim_params.nsteps = 0                                     # "crash" at the end of the burn-in (checkpoint written there)
+    rs.run_simulation_(b, checkpoint=ck)
+    b.model.close()
+    c = build()
+    stats_c = rs.run_simulation_(c, checkpoint=ck, resume=True)
+    assert np.abs(c.model.x - xa).max() < 1e-5 * np.abs(xa).max() and np.abs(c.model.mu - mua).max() < 1e-5
+    assert stats_c["acceptance_rate"] == stats_a["acceptance_rate"] and abs(stats_c["iters"] - stats_a["iters"]) < 1.0
+    assert len(c.mu_tuner.N_traj) == len(a.mu_tuner.N_traj)
+    c.model.close()
