@@ -393,6 +393,23 @@ def swap_update_(model, hmc, nbonds, P=None, rng=None):
     if nbonds < 1:
         return 0.0
     rng = rng or np.random.default_rng()
+    if model.kind == models.SSH and hmc.nchains > 1:      # every chain draws its own pair of different world lines
+        if model.Nph < 2:
+            return 0.0
+        acc, L, nch = 0.0, model.Ltau, hmc.nchains
+        for _ in range(nbonds):
+            hmc.pull_()
+            ci, cj = np.zeros(nch, dtype=np.int64), np.zeros(nch, dtype=np.int64)
+            for c in range(nch):
+                x = hmc.X[c].reshape(model.Nph, L)
+                i = j = int(rng.integers(0, model.Nph))
+                if not np.allclose(x, x[0], rtol=1e-8, atol=0):
+                    j = int(rng.integers(0, model.Nph))
+                    while _isapprox(x[i], x[j]):
+                        j = int(rng.integers(0, model.Nph))
+                ci[c], cj[c] = i, j                                 # i == j (all world lines equal): the swap is the identity
+            acc += float(np.mean(special_move_chains_(model, hmc, SWAP, ci, cj, P=P, rng=rng)[0]))
+        return acc / nbonds
     if model.kind == models.SSH:
         if model.Nph < 2:
             return 0.0

@@ -104,8 +104,7 @@ def run_simulation_(sim, measure=None, rng=None, checkpoint=None, checkpoint_eve
                 acc, it = hmc.update_chains_(m, dyn, fa, P, rng=rng, pull=False)
                 stats["iters"] += float(it.mean())
                 stats["acceptance_rate"] += float(acc.mean())
-                if m.kind == 0:                                                         # (SSH swap moves compare world lines: single chain)
-                    _special(sim, dyn, n, reflect, swap, stats, P, rng)
+                _special(sim, dyn, n, reflect, swap, stats, P, rng)
             elif is_hmc:
                 acc, it = hmc.update_(m, dyn, fa, P, rng=rng, pull=False)
                 stats["iters"] += it

@@ -811,3 +811,36 @@ def test_ssh_hmc_samples_the_exactly_solvable_two_site_model(mu):
     assert abs(xs.mean() - x_exact) < 4 * err(xs) + 0.01, (xs.mean(), x_exact, err(xs))
     assert abs(x2s.mean() - x2_exact) < 4 * err(x2s) + 0.03, (x2s.mean(), x2_exact, err(x2s))
     m.close()
+
+
+def test_ssh_swap_update_of_chains():
+    """swap_update_ for bond-phonon chains: every chain swaps two of ITS phonon world lines; with a forced acceptance the two
+    columns are exchanged exactly, with a forced rejection the field comes back bit for bit."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc
+    nch = 3
+    m = configs.make_model("e", tol=1e-9, maxiter=20000)
+    m.omega4 = np.full(m.Nph, 0.0)
+    fa = pc.FourierAccelerator(m)
+    pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+    H = hmc.HybridMonteCarlo(m, fa, dt=0.05, tr=0.1, alpha=0.0, Nb=1, nchains=nch)
+    rng = np.random.default_rng(3)
+    X0 = np.stack([m.x * (0.8 + 0.1 * c) * (1.0 + 0.1 * rng.standard_normal(m.Ndof)) for c in range(nch)])
+    H.X[:] = X0
+    H.push_()
+    L = m.Ltau
+    ci, cj = np.array([0, 3, 5]), np.array([2, 4, 9])
+    rnd = dict(Rp=rng.standard_normal((nch, m.Ndim)), Rm=rng.standard_normal((nch, m.Ndim)), kpm_randn=None, u=np.array([0.0, 1.5, 0.0]))
+    acc, s0, s1, it, fl = hmc.special_move_chains_(m, H, hmc.SWAP, ci, cj, randoms=rnd)
+    H.pull_()
+    assert not fl.any() and acc.tolist() == [True, False, True]
+    for c in range(nch):
+        x0, x1 = X0[c].reshape(m.Nph, L), H.X[c].reshape(m.Nph, L)
+        if acc[c]:
+            assert np.array_equal(x1[ci[c]], x0[cj[c]]) and np.array_equal(x1[cj[c]], x0[ci[c]])
+            rest = np.setdiff1d(np.arange(m.Nph), [ci[c], cj[c]])
+            assert np.array_equal(x1[rest], x0[rest])
+        else:
+            assert np.array_equal(x1, x0)
+    frac = hmc.swap_update_(m, H, 2, None, rng=rng)
+    assert 0.0 <= frac <= 1.0
+    m.close()
