@@ -20,8 +20,22 @@ def main(argv=None):
     ap.add_argument("--out", default=None, help="write the final phonon configuration (chain 0) here")
     ap.add_argument("--checkpoint", default=None, help="checkpoint file: written periodically, resumed from when it exists")
     args = ap.parse_args(argv)
-    from . import io, measurements, process_input, run_simulation
-    sim = process_input.process_input_file(args.deck, device=args.device, nchains=args.chains)
+    from . import dist, io, measurements, process_input, run_simulation
+    # several GPUs (python -m torch.distributed.run --nproc-per-node N -m elphdynamics_amd deck.toml …): every rank runs its own
+    # chains of the deck on its own GPU with its own seed — the reference's independent run-IDs (ElPhDynamics.jl:90-95); no
+    # data-path communication, rank 0 prints the gathered statistics
+    comm = dist.Comm()
+    inp = process_input.read_deck(args.deck)
+    if comm.world > 1:
+        seed = inp.setdefault("simulation", {}).get("random_seed")
+        if seed is not None:
+            inp["simulation"]["random_seed"] = comm.chain_seed(seed)
+        args.device = comm.device_index()
+        if args.checkpoint:
+            args.checkpoint = f"{args.checkpoint}.rank{comm.rank}"
+        if args.out:
+            args.out = f"{args.out}.rank{comm.rank}"
+    sim = process_input.process_input_file(inp, device=args.device, nchains=args.chains)
     m = sim.model
     acc = measurements.new_accumulator(m) if args.chains == 1 else None
 
@@ -54,8 +68,15 @@ def main(argv=None):
         if args.chains > 1:
             m.x[:] = sim.simulation_dynamics.X[0]
         io.write_phonons_(m, args.out)
-    print(json.dumps(out))
+    out["rank"], out["world"] = comm.rank, comm.world
+    if comm.world > 1:
+        allout = comm.allgather_object(out)
+        if comm.rank == 0:
+            print(json.dumps(dict(world=comm.world, ranks=allout)))
+    else:
+        print(json.dumps(out))
     m.close()
+    comm.close()
     return 0
 
 

@@ -205,6 +205,14 @@ def process_input_file(deck, device=0, nchains=1, rng=None):
     P = initialize_preconditioner(inp, model)
     fa = initialize_fourieraccelerator(inp, model)
     burn, sim = initialize_dynamics(inp, model, fa, nchains)
+    if nchains > 1:      # every chain its own start configuration (a file gives all chains the same one, as separate runs would get)
+        d = inp["holstein" if "holstein" in inp else "ssh"]
+        for c in range(nchains):
+            if c > 0 and not d.get("read_phonon_config", False):
+                initialize_phonons.init_phonons_half_filled_(model, model.rng)
+            sim.X[c] = model.x
+        sim.push_()
+        model._nchains = int(nchains)                # (init_phonons' update_model! was a single-configuration one)
     b_ref, s_ref = initialize_reflect_update(inp, model)
     b_swap, s_swap = initialize_swap_update(inp, model)
     # chains in lockstep: n_v vectors per chain in one estimator (vector v of chain c at greens.chain_vector(est, c, v))
