@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ 
 // footprint admits a third wave per SIMD.
 // ---------------------------------------------------------------------------------------------------------------------
 // RZ (inverse only): fuse the time-domain r.z partial sums (needs this lane's slice of r); without it the inverse is a pure
-// transform (the Chebyshev kernel delivered r.z in frequency space) and runs with a deeper prefetch ring
+// transform (the Chebyshev kernel delivered r.z in frequency space) and fits a third wave per SIMD
 template <int NT, bool INV, bool XR, bool RZ>
 __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__ out, const double *__restrict__ in,
                                                        const double *__restrict__ W, const double2 *__restrict__ tw, int N, int L,
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
     const int sc = (s < N) ? s : N - 1;
     const int H = L >> 1, Q = (H + 1) >> 1;      // Q independent frequencies; H odd: the middle one is its own mirror
     const int mt0 = blockIdx.y * MG;
-    constexpr int PFW = INV ? 4 : 8;                                                         // with RZ the inverse also holds its r slice (below)
+    constexpr int PFW = INV ? 4 : 8;     // prefetch depth in reduction steps; 4 keeps the inverse at 3 waves per SIMD (4 doubles + a twiddle per slot)
     constexpr int PFB = (NT < PFW) ? NT : PFW;
     constexpr int RAW = (INV || XR) ? 4 : 2;
     double raw[PFB + 1][RAW];
