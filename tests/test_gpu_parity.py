@@ -974,3 +974,45 @@ def test_batched_preconditioned_solve_with_odd_half_length(Lt, monkeypatch):
     xo, ito, reso, flo = orc.ldiv(om, B[0], P=Po, solver_tol=1e-8, solver_maxiter=20000)
     assert flo == 0 and abs(int(out["1"][1][0]) - ito) <= 1 and rel(out["1"][0][0], xo) < 1e-6
     m.close()
+
+
+def test_lattice_beyond_the_register_resident_family(oracle):
+    """N = 576 sites (square L = 24, > 512): the generic LDS-slab kernels with one thread per two sites and the Chebyshev kernel
+    with its bond program in LDS — mat-vec, plain and KPM-preconditioned solves (single and batched) against the oracle."""
+    from elphdynamics_amd import lattice as lat, models, preconditioners as pc, synth
+    la = lat.Lattice(1, 24, 24, 1)
+    m = models.HolsteinModel(la, 24 * 0.1, 0.1, tol=1e-8, maxiter=20000)
+    for (o1, o2, d) in lat.SQUARE_BONDS:
+        m.assign_t_(1.0, o1, o2, d)
+    m.assign_omega_(1.0), m.assign_lambda_(1.0), m.assign_mu_(0.0)
+    m.initialize_model_()
+    m.x[:] = synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau)
+    models.update_model_(m)
+    E = oracle.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
+    om = oracle.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+    v = synth.randn(5, m.Ndim)
+    y = np.zeros(m.Ndim)
+    models.mulMtM_(y, m, v)
+    assert rel(y, oracle.mulMTM(om, v)) < 1e-13
+    b = np.zeros(m.Ndim)
+    models.mulMt_(b, m, v)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    bmax, bmin = synth.randn(1, m.Nsites), synth.randn(2, m.Nsites)
+    pc.setup_(P, b_max=bmax, b_min=bmin)
+    x = np.zeros(m.Ndim)
+    it, res, fl = models.ldiv_(x, m, b, P=P)
+    Po = oracle.make_kpm(om, n=20)
+    oracle.kpm_setup(Po, b_max=bmax, b_min=bmin)
+    xo, ito, reso, flo = oracle.ldiv(om, b, P=Po, solver_tol=1e-8, solver_maxiter=20000)
+    assert fl == 0 and flo == 0 and abs(it - ito) <= 1 and rel(x, xo) < 1e-6
+    Mx = np.zeros(m.Ndim)
+    models.mulM_(Mx, m, x)
+    assert rel(Mx, v) < 1e-6                                   # b = Mᵀv, so x = M⁻¹v
+    x2 = np.zeros(m.Ndim)
+    it2, res2, fl2 = models.ldiv_(x2, m, b)
+    assert fl2 == 0 and it2 > 5 * it and rel(x2, x) < 1e-5
+    B = np.stack([b, 2 * b, synth.randn(6, m.Ndim)])
+    X = np.zeros_like(B)
+    itb, resb, flb = models.ldiv_batched_(X, m, B, P=P)
+    assert not flb.any() and rel(X[0], x) < 1e-10 and rel(X[1], 2 * x) < 1e-6
+    m.close()
