@@ -940,10 +940,11 @@ def test_mfma_dft_long_time_axes(lib, L, monkeypatch):
         m.close()
 
 
-@pytest.mark.parametrize("Lt", [30, 50])
+@pytest.mark.parametrize("Lt", [30, 50, 400])
 def test_batched_preconditioned_solve_with_odd_half_length(Lt, monkeypatch):
     """Ltau = 2 (mod 4): the split transforms (odd half length), the folded residual update and the frequency-space r.z inside a
-    batched KPM-preconditioned solve — same iteration counts and solutions as the scalar-kernel path, and as the oracle."""
+    batched KPM-preconditioned solve — same iteration counts and solutions as the scalar-kernel path, and as the oracle.
+    Ltau = 400: the long-axis form (three row groups, 128 KB W panel in LDS, residual update NOT folded)."""
     from elphdynamics_amd import lattice as lat, models, preconditioners as pc, synth
     from oracle.oracle import Oracle
     la = lat.Lattice(1, 8, 8, 1)
@@ -965,14 +966,17 @@ def test_batched_preconditioned_solve_with_odd_half_length(Lt, monkeypatch):
         it, res, fl = models.ldiv_batched_(X, m, B, P=P)
         assert not fl.any()
         out[mode] = (X, it)
-    assert np.array_equal(out["0"][1], out["1"][1]) and rel(out["1"][0], out["0"][0]) < 1e-10
+    if Lt <= 100:
+        assert np.array_equal(out["0"][1], out["1"][1]) and rel(out["1"][0], out["0"][0]) < 1e-10
+    else:      # beta = 40: > 100 iterations even preconditioned — round-off moves the crossing of the tolerance by an iteration or two
+        assert np.abs(out["0"][1] - out["1"][1]).max() <= 3 and rel(out["1"][0], out["0"][0]) < 1e-6
     orc = Oracle()
     E = orc.update_model_holstein(m.Nsites, m.Ltau, m.dtau, m.x, m.lam, m.lam2, m.mu)
     om = orc.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
     Po = orc.make_kpm(om, n=20)
     orc.kpm_setup(Po, b_max=bmax, b_min=bmin)
     xo, ito, reso, flo = orc.ldiv(om, B[0], P=Po, solver_tol=1e-8, solver_maxiter=20000)
-    assert flo == 0 and abs(int(out["1"][1][0]) - ito) <= 1 and rel(out["1"][0][0], xo) < 1e-6
+    assert flo == 0 and abs(int(out["1"][1][0]) - ito) <= (1 if Lt <= 100 else 3) and rel(out["1"][0][0], xo) < 1e-6
     m.close()
 
 
