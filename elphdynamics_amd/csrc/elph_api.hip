@@ -457,6 +457,8 @@ extern "C" int elph_update_model_ssh(elph_handle h, const double *cosht, const d
     }
     HIPCHK(hipMemcpy(h->d_E, expDtauMu, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
     RC(upload_lp_cs(h));
+    h->mu_per_chain = false;
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }      // host tables describe ONE configuration
     h->cs_host_stale = false;
     h->have_E = true;
     return ELPH_OK;
