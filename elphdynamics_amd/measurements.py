@@ -6,7 +6,7 @@ file formats of the reference's measurement container are not restated (control 
     scalar, literal restatements (one displacement):       measure_Greens / _DenDen / _SpinSpin / _PairGreens       Measurements.jl:1469-1558
     whole tables at once (what measure_X! accumulates):    correlation_(container, pairs, est, kind)                :1561-1593
     measure_PhononGreens_(container, pairs, model)                                                                  :1598-1653
-    global_measurements(model, est), onsite_measurements_holstein(model, est)                                       :845-862, :916-973
+    global_measurements(model, est), onsite_measurements_holstein / _ssh(model, est)                                :845-862, :916-1023
     make_measurements_(acc, model, est, P, rng=None, R=None, kinds=…)                                               :545-569
 
 Containers are complex arrays (L+1, L1, L2, L3, n_pairs): time displacement 0..β, cell displacement, orbital pair — the
@@ -157,6 +157,15 @@ def onsite_measurements_holstein(model, est):
     return out
 
 
+def onsite_measurements_ssh(model, est):
+    """make_onsite_measurements! for the SSH model (:978-1023): density, double occupancy and μ per orbital type."""
+    lat, L, N = model.lattice, model.Ltau, model.Nsites
+    R1, R2, X1, X2 = (a.reshape(N, L) for a in (est.r1, est.r2, est.Minvr1, est.Minvr2))
+    G1, G2 = X1 * R1, X2 * R2
+    per_site = dict(density=(1 - G1) + (1 - G2), double_occ=(1 - G1) * (1 - G2), mu=np.repeat(model.mu[:, None], L, axis=1))
+    return {k: np.array([v[o::lat.norbits].mean() for o in range(lat.norbits)]) for k, v in per_site.items()}
+
+
 def new_accumulator(model, kinds=KINDS, pairs=None, phonon_greens=True):
     lat = model.lattice
     pairs = pairs or [(o1, o2) for o1 in range(1, lat.norbits + 1) for o2 in range(o1, lat.norbits + 1)]
@@ -183,8 +192,7 @@ def make_measurements_(acc, model, est, P=None, rng=None, R=None):
                     correlation_(acc["corr"][kind], acc["pairs"], model, est, kind)
             if "PhononGreens" in acc["corr"]:
                 measure_PhononGreens_(acc["corr"]["PhononGreens"], acc["pairs"], model)
-            if model.kind == models.HOLSTEIN:
-                o = onsite_measurements_holstein(model, est)
-                acc["onsite"] = o if acc["onsite"] is None else {k: acc["onsite"][k] + o[k] for k in o}
+            o = onsite_measurements_holstein(model, est) if model.kind == models.HOLSTEIN else onsite_measurements_ssh(model, est)
+            acc["onsite"] = o if acc["onsite"] is None else {k: acc["onsite"][k] + o[k] for k in o}
             acc["n"] += 1
     return acc

@@ -77,3 +77,20 @@ def test_measurements_of_a_deck_run():
     assert abs(2 * (1 - g00) - acc["glob"]["density"] / n) < 0.3
     assert all(np.all(np.isfinite(v)) for v in acc["corr"].values())
     m.close()
+
+
+@pytest.mark.gpu
+def test_measurements_of_a_bond_phonon_deck():
+    from elphdynamics_amd import measurements as M, process_input as pi
+    sim = pi.process_input_file(os.path.join(DECKS, "ssh_langevin_square_L4.toml"))
+    m = sim.model
+    acc = M.new_accumulator(m)
+    M.make_measurements_(acc, m, sim.Gr, sim.preconditioner, rng=m.rng)
+    n = acc["n"]
+    assert n == sim.Gr.nv * (sim.Gr.nv - 1) // 2 and "PhononGreens" not in acc["corr"]
+    on = {k: v / n for k, v in acc["onsite"].items()}
+    assert abs(on["density"].mean() - acc["glob"]["density"] / n) < 1e-12 and abs(on["mu"][0] - 0.05) < 1e-14
+    G = acc["corr"]["Greens"] / n
+    assert abs(G[m.Ltau, 0, 0, 0, 0] - (1.0 - G[0, 0, 0, 0, 0])) < 1e-13
+    assert all(np.all(np.isfinite(v)) for v in acc["corr"].values())
+    m.close()
