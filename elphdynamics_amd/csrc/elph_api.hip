@@ -417,11 +417,11 @@ extern "C" int elph_update_model_holstein_chains(elph_handle h, int nchains, con
     HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    for (int c = 0; c < nchains; ++c) {
-        HIPCHK(hipMemcpyAsync(h->d_stage_in, X + (size_t)c * nd, nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        RC(elph_launch_expV(h, h->d_stage_in, dtau, c));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
+    // all configurations in one transfer (the staging buffer holds cap_rhs vectors), one exp kernel per chain, one sync
+    RC(ensure_capacity(h, nchains));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, X, (size_t)nchains * nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int c = 0; c < nchains; ++c) RC(elph_launch_expV(h, h->d_stage_in + (size_t)c * nd, dtau, c));
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->have_E = true;
     h->kpm_ready = false;   // the preconditioner belongs to ONE configuration
     return ELPH_OK;
