@@ -118,12 +118,12 @@ def main():
         check(lib.elph_bench_run(m._h, what_, nrhs_, reps, graph, C.byref(ms)))
         return ms.value
 
-    chunk = 16
-    K = max(chunk, (args.steps // chunk) * chunk)
-    W = max(chunk, (args.warmup // chunk) * chunk)
+    K = max(1, args.steps)                   # exactly the K and W asked for (every step is its own pair of launches)
+    W = max(0, args.warmup)
 
     check(lib.elph_bench_prepare(m._h, what, nrhs, _lib.dptr(Bc)))
-    run(what, nrhs, W)                       # warm-up
+    if W:
+        run(what, nrhs, W)                   # warm-up
     check(lib.elph_bench_prepare(m._h, what, nrhs, None))
     ev = {}
 
