@@ -344,6 +344,8 @@ extern "C" int elph_destroy(elph_handle h) {
     drop_graphs(h);
     elph_hmc_free(h);
     elph_greens_free(h);
+    delete h->host_pool;
+    h->host_pool = nullptr;
     elph_dft_mfma_free(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
@@ -1377,15 +1379,15 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     };
     {
         // ~0.15 ms of scalar work per chain; a thread costs ~30 us to start: one thread per 4 chains, at most 16
-        const int nthr = std::max(1, std::min(std::min(nch / 4, 16), (int)std::thread::hardware_concurrency()));
+        // (threads are parked in the handle between calls, host_pool.h; the calling thread works too)
+        int nthr = std::max(1, std::min(std::min(nch / 4, 16), (int)std::thread::hardware_concurrency()));
+        if (const char *e = getenv("ELPH_KPM_THREADS")) nthr = std::max(1, std::min(atoi(e), 64));
         if (nthr <= 1) {
             for (int c = 0; c < nch; ++c) one_chain(c);
         } else {
-            std::vector<std::thread> pool;
-            std::atomic<int> next(0);
-            for (int t = 0; t < nthr; ++t)
-                pool.emplace_back([&]() { for (int c; (c = next.fetch_add(1)) < nch;) one_chain(c); });
-            for (auto &th : pool) th.join();
+            if (h->host_pool && h->host_pool->workers() != nthr - 1) { delete h->host_pool; h->host_pool = nullptr; }
+            if (!h->host_pool) h->host_pool = new ElphHostPool(nthr - 1);
+            h->host_pool->run(nch, one_chain);
         }
     }
     int any_active = 0;

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/elph_gpu.h"
+#include "host_pool.h"
 
 #define ELPH_ABI_VERSION 1
 #define ELPH_WAVE 64
@@ -254,6 +255,7 @@ struct elph_handle_s {
     struct KpmChainHost { double lam_lo = 0.0, lam_hi = 2.0; int active = 1; bool fresh = true;
                           std::vector<int> order; std::vector<double> coeff; };
     std::vector<KpmChainHost> kpm_chain;   // per chain: bounds, orders, coefficients (complex interleaved)
+    ElphHostPool *host_pool = nullptr;     // parked host threads for the per-chain set-up work (created on first use)
     std::vector<double> h_Ebar, h_cbar, h_sbar;   // h_Ebar: [kpm_nch][N]; h_cbar, h_sbar: [nb], or [kpm_nch][nb] for SSH chains
     bool kpm_hop_per_chain = false;        // SSH with several chains: averaged hopping tables per chain
     int kpm_hop_cap = 1;                   // chains the device copies of the averaged hopping tables are allocated for

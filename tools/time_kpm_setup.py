@@ -1,24 +1,26 @@
-import sys, time, ctypes as C
+"""Time setup!(P) for the chains resident in one handle (config C) against the number of host threads.
+usage: python tools/time_kpm_setup.py [nchains]"""
+import os
+import sys
+import time
+
 import numpy as np
-sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
-from elphdynamics_amd import configs, models, preconditioners as pc, synth
-m = configs.make_model("C", tol=1e-5)
-nch = 32
-Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=100 + 17 * c) for c in range(nch)])
-t0 = time.perf_counter(); models.update_model_chains_(m, Xc); t1 = time.perf_counter()
-print("update_model_chains %.2f ms" % (1e3 * (t1 - t0)))
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from elphdynamics_amd import configs, models, synth          # noqa: E402
+from elphdynamics_amd import preconditioners as pc           # noqa: E402
+
+nch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+m = configs.make_model("C")
+Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=synth.SEED_FIELDS + 17 * c) for c in range(nch)])
+models.update_model_chains_(m, Xc)
 P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
-rng = np.random.default_rng(1)
-bmax, bmin = rng.standard_normal((nch, m.Nsites)), rng.standard_normal((nch, m.Nsites))
-for i in range(4):
-    t0 = time.perf_counter(); act, lo, hi = pc.setup_chains_(P, b_max=bmax, b_min=bmin); t1 = time.perf_counter()
-    print("setup_chains call %d: %.3f ms  (active %d)" % (i, 1e3 * (t1 - t0), act.sum()))
-# perturb fields slightly (as in HMC): bounds move < 5% -> no coefficient recompute
-models.update_model_chains_(m, Xc * 1.001)
-t0 = time.perf_counter(); act, lo, hi = pc.setup_chains_(P, b_max=bmax, b_min=bmin); t1 = time.perf_counter()
-print("setup_chains after small move: %.3f ms" % (1e3 * (t1 - t0)))
-models.update_model_(m)
-P1 = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
-for i in range(3):
-    t0 = time.perf_counter(); pc.setup_(P1, b_max=bmax[0], b_min=bmin[0]); t1 = time.perf_counter()
-    print("single setup call %d: %.3f ms" % (i, 1e3 * (t1 - t0)))
+for thr in ("1", "2", "4", "8", "16", "32"):
+    os.environ["ELPH_KPM_THREADS"] = thr
+    pc.setup_chains_(P, rng=np.random.default_rng(7))
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        pc.setup_chains_(P, rng=np.random.default_rng(7))
+        ts.append(time.perf_counter() - t0)
+    print(f"threads {thr:>2}: setup of {nch} chains  min {1e3 * min(ts):.3f} ms  median {1e3 * sorted(ts)[10]:.3f} ms", flush=True)
