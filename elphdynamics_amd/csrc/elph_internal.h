@@ -214,7 +214,7 @@ struct elph_handle_s {
     bool resident_broken = false;          // a resident launch timed out once: do not try again on this handle
     int resident_T = 0;                    // T of the last resident solve (0: none yet)
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
-    int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/8 force
+    int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/5/8/10/16/20 force
 
     // solver defaults (model.solver)
     double tol = 1e-4, kmax = 1e12;
