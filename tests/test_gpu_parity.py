@@ -568,7 +568,8 @@ def test_fermion_force_is_the_gradient_of_the_action(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("C", 4, 2), ("C", 32, 2), ("e", 3, 2), ("E", 4, 2), ("E", 16, 2)])
+@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("C", 4, 2), ("C", 32, 2), ("e", 3, 2), ("E", 4, 2), ("E", 16, 2),
+                                             ("C", 64, 2), ("E", 64, 2)])    # 128 right-hand sides: 20 slices per wave
 def test_independent_chains_in_one_batch(tag, nchains, per):
     """Several phonon configurations resident in one handle (the reference runs chains as separate processes,
     ElPhDynamics.jl:90-95): right-hand side r of a batch uses the fermion matrix of chain r % nchains, and each
