@@ -33,12 +33,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-ALG_BYTES_PER_ELT = {          # SURVEY.md §8(d), f64, perfect fusion
+HMC_CHAINS = 64                # lockstep chains of the secondary whole-HMC-update measurement
+F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64, dense (same guide: f64 matrix = f64 vector peak)
+ALG_BYTES_PER_ELT = {          # the UNFUSED pass count of the algorithm, f64 (reported as algorithmic_GBs only)
     "cg_iter": 120.0,          # 2 mat-vecs (48) + x, r, p updates (72)
     "k_cg_ap": 96.0,           # x += alpha p of the previous iteration (24) + p = r + beta p (24) + M p (24) + Mt (M p) (24)
     "k_cg_xr": 24.0,           # r -= alpha z (24)   [x += alpha p rides in the next k_cg_ap, which reads that p anyway]
     "kpm_apply": 16.0,
 }
+# COMPULSORY bytes of each kernel AS BUILT (what roofline.frac is priced on): every vector the kernel must read or write
+# once, 8 B per element per right-hand side; tables that are shared by right-hand sides are counted once per launch.
+#   k_cg_ap     reads src (r | P^-1 r), p_old, x; writes p, z, x                     -> 48 B/elt/rhs  (+ E once per chain; SSH:
+#               + the per-slice hopping tables once per chain).  M p never leaves LDS, x += alpha p shares the read of p.
+#   k_cg_xr     reads r, z; writes r                                                  -> 24 B/elt/rhs
+#   KPM apply as three kernels: forward transform with the residual update folded in (reads r, z; writes r, nu) 32;
+#               Chebyshev recursion in place on nu (read + write) 16; inverse transform (reads nu, writes P^-1 r) 16
+BUILT_BYTES_PER_ELT = {"k_cg_ap": 48.0, "k_cg_xr": 24.0, "kpm_fwd_xr": 32.0, "kpm_fwd": 16.0, "kpm_cheb": 16.0, "kpm_inv": 16.0}
 
 
 DESCR = {"A": "Holstein single site (holstein_hmc_single_site.toml)", "B": "Holstein square L=8 Ntau=40",
@@ -50,8 +60,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=400)
-    ap.add_argument("--nrhs", type=int, default=128, help="right-hand sides advanced per step (batch)")
-    ap.add_argument("--chains", type=int, default=64,
+    ap.add_argument("--nrhs", type=int, default=256, help="right-hand sides advanced per step (batch)")
+    ap.add_argument("--chains", type=int, default=128,
                     help="independent phonon configurations (Markov chains) per GPU sharing the batch: right-hand side r "
                          "uses the fermion matrix of chain r %% chains (nrhs = 2*chains = both pseudofermion solves of one "
                          "HMC force evaluation per chain); 1 = all right-hand sides on one matrix")
@@ -172,39 +182,89 @@ def main():
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
         run(4, nrhs, 320, graph=0)
         ms_ap = run(4, nrhs, reps, graph=0) / reps
-        if m.kind == 1:   # SSH mat-vec: 16 B x Ndim + 16 B x Ltau x Nbonds; p- and x-update 24 B x Ndim each
-            mv = 16.0 * ndim + 16.0 * m.Ltau * m.Nbonds
-            alg_ap, alg_it = (2 * mv + 48.0 * ndim) * nrhs, (2 * mv + 72.0 * ndim) * nrhs
-        else:
-            alg_ap, alg_it = ALG_BYTES_PER_ELT["k_cg_ap"] * ndim * nrhs, ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs
-        alg = alg_ap
-        ach = alg / (ms_ap * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"k_cg_ap_nrhs{nrhs}", {}).get("hbm_bytes_per_launch") if args.config == "C" else None
-            except Exception:
-                traffic = None
         Tsl = C.c_int()
         check(lib.elph_bench_info(m._h, nrhs, C.byref(Tsl)))
+        vec = 8.0 * ndim * nrhs                                   # one solver vector of the batch, bytes
+        if m.kind == 1:   # SSH: E = exp(dtau mu) per site (negligible); the per-slice cosh/sinh tables once per chain
+            tab = 16.0 * m.Ltau * m.Nbonds * nchains
+            mv = 16.0 * ndim + 16.0 * m.Ltau * m.Nbonds           # SURVEY §8d mat-vec
+            alg_ap, alg_it = (2 * mv + 48.0 * ndim) * nrhs, (2 * mv + 72.0 * ndim) * nrhs
+        else:             # Holstein: E = exp(-dtau V) per (site, tau), once per chain
+            tab = 8.0 * ndim * nchains
+            alg_ap, alg_it = ALG_BYTES_PER_ELT["k_cg_ap"] * ndim * nrhs, ALG_BYTES_PER_ELT["cg_iter"] * ndim * nrhs
+        built_ap = 6.0 * vec + tab                                # BUILT_BYTES_PER_ELT["k_cg_ap"] x elements + tables
+        built_xr = 3.0 * vec
+        ach = built_ap / (ms_ap * 1e-3) / 1e9
         kname = f"k_cg_ap_chunk<T={Tsl.value}>" if Tsl.value > 1 else "k_cg_ap_fast"
+        tkey = f"{kname}|config={args.config}|nrhs={nrhs}|chains={nchains}"
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        try:                  # PMC bytes are only valid for the exact kernel / batch / slices-per-wave they were collected on
+            ent = json.load(open(tpath)).get("kernels", {}).get(tkey)
+            if ent is not None:
+                traffic = ent["hbm_bytes_per_launch"]
+            else:
+                traffic_note = f"profiles/traffic.json holds no PMC pass for '{tkey}' (tools/profile_bench.sh re-collects it)"
+        except Exception as e:
+            traffic_note = f"profiles/traffic.json unreadable: {e}"
         out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": ms_ap * 1e3,
-                           "algorithmic_bytes_per_launch": alg}
-        if traffic:      # the fused kernel moves fewer bytes than the algorithmic count: the rate it really sustains
+                           "bytes_per_launch": built_ap,
+                           "bytes_model": "compulsory bytes of the kernel as built: 6 vectors (reads r|P^-1 r, p_old, x; writes p, z, x) "
+                                          "x 8 B x Ndim x nrhs + exp(-dtau V) (SSH: the per-slice hopping tables) once per chain",
+                           "traffic_key": tkey,
+                           "algorithmic_GBs": alg_ap / (ms_ap * 1e-3) / 1e9,
+                           "algorithmic_note": "SURVEY.md 8(d) counts the unfused passes (96 B x Ndim x nrhs for this kernel); the fused "
+                                               "kernel does not move them, so this figure may exceed the HBM peak and is NOT the roofline fraction"}
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
+        if traffic:      # what the memory-side counters saw per launch, and the rate that is
             out["roofline"]["traffic_GBs"] = traffic / (ms_ap * 1e-3) / 1e9
             out["roofline"]["traffic_frac"] = out["roofline"]["traffic_GBs"] / HBM_PEAK_GBS
+            out["roofline"]["traffic_over_bytes"] = traffic / built_ap
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
         run(5, nrhs, 320, graph=0)
         ms_xr = run(5, nrhs, reps, graph=0) / reps
-        out["roofline"]["k_cg_xr_avg_launch_us"] = ms_xr * 1e3
+        out["roofline"]["k_cg_xr"] = {"avg_launch_us": ms_xr * 1e3, "bytes_per_launch": built_xr,
+                                      "achieved": built_xr / (ms_xr * 1e-3) / 1e9, "frac": built_xr / (ms_xr * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        it_bytes = built_ap + built_xr
+        it_GBs = it_bytes * K / (ms_events * 1e-3) / 1e9
         out["roofline"]["whole_iteration"] = {
-            "algorithmic_bytes_per_step": alg_it,
-            "achieved_GBs": alg_it * K / (ms_events * 1e-3) / 1e9,
+            "bytes_per_step": it_bytes, "achieved_GBs": it_GBs, "frac": it_GBs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_step": alg_it, "algorithmic_GBs": alg_it * K / (ms_events * 1e-3) / 1e9,
         }
-        out["roofline"]["whole_iteration"]["frac"] = out["roofline"]["whole_iteration"]["achieved_GBs"] / HBM_PEAK_GBS
+
+        # ---- the preconditioned iteration (BASELINE config C "with tau-FFT FourierAcceleration precond"): every kernel of it
+        # timed alone with HIP events, its compulsory bytes, and the matrix-core rate of the two tau-transforms
+        if not args.no_sweep and m.kind == 0:
+            try:
+                Pr = P or pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+                (pc.setup_chains_ if nchains > 1 else pc.setup_)(Pr, rng=np.random.default_rng(7))
+                rp = {}
+                names = {4: "k_cg_ap", 6: "kpm_forward_transform(+residual update)", 7: "kpm_chebyshev", 8: "kpm_inverse_transform", 3: "whole_iteration"}
+                Hh, Qq = m.Ltau // 2, (m.Ltau // 2 + 1) // 2
+                gemm_flops = 2.0 * (2.0 * (2 * Qq) * Hh) * m.Nsites * nrhs if m.Ltau % 2 == 0 else None   # two half-length f64 GEMMs (even / odd slices)
+                byts = {4: built_ap, 6: 4.0 * vec, 7: 2.0 * vec, 8: 2.0 * vec, 3: built_ap + 8.0 * vec}
+                for wh in (4, 6, 7, 8, 3):
+                    check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
+                    run(3, nrhs, 2)                           # sane p.z partials / states for the kernels timed alone
+                    run(wh, nrhs, 64)
+                    us = 1e3 * run(wh, nrhs, 640) / 640
+                    e = {"avg_launch_us": us, "bytes_per_launch": byts[wh], "achieved_GBs": byts[wh] / (us * 1e-6) / 1e9,
+                         "hbm_frac": byts[wh] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                    if wh in (6, 8) and gemm_flops:
+                        e["mfma_f64_TFLOPs"] = gemm_flops / (us * 1e-6) / 1e12
+                        e["mfma_frac"] = e["mfma_f64_TFLOPs"] / F64_MFMA_PEAK_TFLOPS
+                        e["flops_per_launch"] = gemm_flops
+                    rp[names[wh]] = e
+                rp["note"] = ("bytes: k_cg_ap as above (src = P^-1 r); forward transform reads r, z and writes r, nu (4 vectors; the half "
+                              "spectrum nu is one vector of bytes); Chebyshev reads and writes nu; inverse reads nu, writes P^-1 r.  "
+                              "SURVEY 8(d)'s 16 B x Ndim per KPM apply assumes the three kernels fused into one.  The Chebyshev kernel is "
+                              "latency-bound by its longest recursion, not by bytes.  mfma: two (L/2 x L/2) real f64 GEMMs per transform "
+                              f"on v_mfma_f64_16x16x4_f64, peak {F64_MFMA_PEAK_TFLOPS} TFLOP/s")
+                out["roofline_preconditioned"] = rp
+            except Exception as e:
+                out["roofline_preconditioned"] = {"error": repr(e)}
 
         # ---- secondary: time to solution of the whole default batch (every chain its own matrix), plain vs KPM
         if not args.no_sweep and m.kind == 0:
@@ -286,7 +346,7 @@ def main():
                 from elphdynamics_amd import hmc as ehmc
                 nt_g, dt_h = 10, 0.01
                 hm = {}
-                for nch_h in (1, args.chains):
+                for nch_h in (1, HMC_CHAINS):
                     mh = configs.make_model(args.config, tol=1e-5, maxiter=20000, device=comm.device_index())
                     fah = pc.FourierAccelerator(mh)
                     pc.update_M_(fah, mh, 0.0, np.inf, 1.0, 0.1)
@@ -324,7 +384,7 @@ def main():
                                               fao.M, dt_h, nt_c, 1, 0.0, rnd, P=Po, tol=1e-5, maxiter=20000)
                     dtc = time.perf_counter() - tq
                     hm["cpu_oracle_1core"] = {"nt": nt_c, "s_per_update": dtc, "chain_evaluations_per_sec": (nt_c + 2) / dtc}
-                    hm["gpu_over_cpu_chain_evaluations"] = hm[f"gpu_chains{args.chains}"]["chain_evaluations_per_sec"] / hm["cpu_oracle_1core"]["chain_evaluations_per_sec"]
+                    hm["gpu_over_cpu_chain_evaluations"] = hm[f"gpu_chains{HMC_CHAINS}"]["chain_evaluations_per_sec"] / hm["cpu_oracle_1core"]["chain_evaluations_per_sec"]
                     mo.close()
                 out["hmc_update_kpm"] = hm
             except Exception as e:

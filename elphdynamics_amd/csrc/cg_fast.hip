@@ -47,7 +47,4 @@ int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz
     return h->lp_mc == 4 ? lp4::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part)
                          : lp6::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part);
 }
-int elph_fast_cg_resident(elph_handle_s *h, const CgBufs &B, int nrhs, bool *ran) {
-    if (h->lp_mc != 4) { *ran = false; return ELPH_OK; }
-    return lp4::elph_fast_cg_resident(h, B, nrhs, ran);
-}
+

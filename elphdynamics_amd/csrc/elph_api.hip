@@ -676,26 +676,35 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
     h->cur_params = P;
     RC(elph_launch_cg_init(h, nrhs, use_prec));
 
-    // whole solve in one launch with the Krylov vectors in registers (cg_fast.hip: k_cg_resident) when it applies
-    if (h->fast && !use_prec && maxiter >= 1) {
+    // whole solve in one launch with the Krylov vectors in registers (cg_wg.hip: k_cg_wg) when it applies
+    if (h->fast && !use_prec && maxiter >= 1 && !h->wg_broken && elph_wg_usable(h, nullptr, nullptr, nullptr)) {
         bool ran = false;
         CgBufs B = elph_make_bufs(h, nrhs);
         B.params = P;
-        const int rc = elph_fast_cg_resident(h, B, nrhs, &ran);
-        if (rc == ELPH_OK && ran) {
+        // the caller's initial guess survives in d_zp (unused by an un-preconditioned solve) for the fallback below
+        HIPCHK(hipMemcpyAsync(h->d_zp, h->d_x, (size_t)nrhs * (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        RC(elph_wg_cg(h, B, nrhs, 0, &ran));
+        if (ran) {
             HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            for (int r = 0; r < nrhs; ++r) {
-                if (!h->h_state[2 * r].done) { elph_set_error("resident CG ended without a terminal state (internal error)"); return ELPH_E_STATE; }
-                iters[r] = h->h_state[2 * r].iters;
+            bool aborted = false;
+            RC(elph_wg_aborted(h, &aborted));
+            if (!aborted) {
+                for (int r = 0; r < nrhs; ++r) {
+                    if (!h->h_state[2 * r].done) { elph_set_error("workgroup-resident CG ended without a terminal state (internal error)"); return ELPH_E_STATE; }
+                    iters[r] = h->h_state[2 * r].iters;
+                }
+                if (eps_hist) {
+                    HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, sizeof(double) * (size_t)nrhs * (size_t)(maxiter + 1), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(hipStreamSynchronize(h->stream));
+                }
+                return ELPH_OK;
             }
-            if (eps_hist) {
-                HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, sizeof(double) * (size_t)nrhs * (size_t)(maxiter + 1), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
-            }
-            return ELPH_OK;
+            // a team gave up (x, r of the right-hand sides that had finished were overwritten): start every right-hand side again
+            // from the caller's initial guess; the two-kernel iteration below does the work
+            HIPCHK(hipMemcpyAsync(h->d_x, h->d_zp, (size_t)nrhs * (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            RC(elph_launch_cg_init(h, nrhs, use_prec));
         }
-        if (rc != ELPH_OK) RC(elph_launch_cg_init(h, nrhs, use_prec));   // timed out: redo the set-up, two-kernel iteration below
     }
 
     const int64_t max_chunks = (maxiter + 1 + h->chunk - 1) / h->chunk + 1;
@@ -1541,15 +1550,20 @@ static int bench_launch_unit(elph_handle_s *h, int what, int nrhs) {
         case 2: return elph_launch_kpm_apply(h, h->d_zp, h->d_b, nrhs, 0);
         case 3: return elph_launch_cg_iteration(h, nrhs, 1);
         case 4: return elph_launch_cg_kernel(h, nrhs, 0);
-        default: return elph_launch_cg_kernel(h, nrhs, 1);
+        case 5: return elph_launch_cg_kernel(h, nrhs, 1);
+        default: {
+            // 6, 7, 8: the three kernels of the KPM apply as the preconditioned iteration (case 3) launches them, one at a time
+            const bool xr_fused = h->fast && h->kpm_active && h->dot_hi == 0 && elph_dft_mfma_xr_usable(h, (int)h->N, nrhs);
+            return elph_launch_kpm_apply(h, h->d_zp, h->d_r, nrhs, xr_fused ? 2 : 1, 1 << (what - 6));
+        }
     }
 }
 
 extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B) {
     CHECK_H(h);
     RC(need_model(h));
-    if (nrhs < 1 || what < 0 || what > 5) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    if ((what == 2 || what == 3) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
+    if (nrhs < 1 || what < 0 || what > 9) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if ((what == 2 || what == 3 || (what >= 6 && what <= 8)) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
     RC(ensure_capacity(h, nrhs));
     if (B) {
         const size_t bytes = (size_t)nrhs * (size_t)h->ndim * sizeof(double);
@@ -1558,7 +1572,7 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
     }
     // fixed-count CG: tol = 0 never converges, kmax = inf, x0 = 0
     CgParams P;
-    P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3); P.record_hist = 0; P.hist_stride = 0;
+    P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3 || (what >= 6 && what <= 8)); P.record_hist = 0; P.hist_stride = 0;
     h->cur_params = P;
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
     RC(elph_launch_cg_init(h, nrhs, P.use_prec));
@@ -1573,13 +1587,47 @@ extern "C" int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave) {
     return ELPH_OK;
 }
 
+extern "C" int elph_bench_wg_info(elph_handle h, int *usable, int *T, int *W, int *G) {
+    CHECK_H(h);
+    if (!usable) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    int t = 0, w = 0, g = 0;
+    *usable = (!h->wg_broken && elph_wg_usable(h, &t, &w, &g)) ? 1 : 0;
+    if (T) *T = t;
+    if (W) *W = w;
+    if (G) *G = g;
+    return ELPH_OK;
+}
+
 extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total) {
     CHECK_H(h);
-    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 5) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 9) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     int rc = ELPH_OK;
+    if (what == 9) {        // `reps` iterations of the whole batch in one launch of the workgroup-resident kernel
+        bool ran = false, aborted = false;
+        CgBufs B = elph_make_bufs(h, nrhs);
+        B.params = h->cur_params;
+        hipError_t er = hipStreamSynchronize(h->stream);
+        if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
+        if (er == hipSuccess) {
+            rc = elph_wg_cg(h, B, nrhs, reps, &ran);
+            if (rc == ELPH_OK && !ran) { elph_set_error("the workgroup-resident kernel does not apply to this handle"); rc = ELPH_E_UNSUPPORTED; }
+        }
+        if (er == hipSuccess && rc == ELPH_OK) er = hipEventRecord(e1, h->stream);
+        if (er == hipSuccess && rc == ELPH_OK) er = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (er == hipSuccess && rc == ELPH_OK) er = hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (er != hipSuccess) { elph_set_error("bench (workgroup-resident): %s", hipGetErrorString(er)); return ELPH_E_HIP; }
+        if (rc) return rc;
+        RC(elph_wg_aborted(h, &aborted));
+        if (aborted) return ELPH_E_HIP;
+        *ms_total = (double)ms;
+        return ELPH_OK;
+    }
     hipGraphExec_t exec = nullptr;
     const int chunk = ELPH_CG_CHUNK;
     if (use_graph && h->use_graph && reps % chunk == 0) {

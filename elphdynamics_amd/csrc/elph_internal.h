@@ -60,6 +60,9 @@ struct ModelDev {
     int lp_tau_stride;       // 0 (Holstein) or NE*64 (SSH)
     // SSH with several resident phonon configurations: one set of hopping tables per chain (0: shared tables)
     long long cs_chain_stride, lp_chain_stride;
+    // every bond carries the same (cosh, sinh) (Holstein without hopping disorder): kernels may keep them in two scalars
+    int uniform;
+    double c_uni, s_uni;
 };
 #ifdef __HIPCC__
 // the hopping tables of the chain right-hand side `rhs` belongs to (SSH chains; no-op otherwise)
@@ -209,10 +212,11 @@ struct elph_handle_s {
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     void *hmc = nullptr;                   // HmcState (hmc.hip), owned
     void *greens = nullptr;                // GreensState (greens.hip), owned
-    void *d_res = nullptr;                 // resident-CG control block (flags, partials, halos)
+    void *d_res = nullptr;                 // control block of the workgroup-resident CG (cg_wg.hip): meeting records, abort word, boundary slices
     size_t res_cap = 0;
-    bool resident_broken = false;          // a resident launch timed out once: do not try again on this handle
-    int resident_T = 0;                    // T of the last resident solve (0: none yet)
+    bool wg_broken = false;                // a workgroup-resident launch timed out once: do not try again on this handle
+    size_t wg_abort_off = 0;               // byte offset of the abort word in d_res
+    int wg_T = 0, wg_W = 0, wg_G = 0;      // shape of the last workgroup-resident solve (0: none yet)
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
     int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/5/8/10/16/20 force
 
@@ -314,7 +318,7 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which /*0 = k_cg_ap, 1
 int elph_launch_residual(elph_handle_s *h, int nrhs);
 int elph_launch_cg_init_only(elph_handle_s *h, int nrhs);
 int elph_launch_cg_state0_only(elph_handle_s *h, int nrhs);
-int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode);
+int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode, int parts = 7);
 int elph_launch_ebar(elph_handle_s *h, int nch = 1);
 int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int64_t ncol,
                           int nvec = 1);
@@ -332,7 +336,10 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
-int elph_fast_cg_resident(elph_handle_s *h, const CgBufs &B, int nrhs, bool *ran);
+// ---- workgroup-resident CG (cg_wg.hip): the whole un-preconditioned solve in one launch
+bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G);
+int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
+int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream has drained
 CgBufs elph_make_bufs(elph_handle_s *h, int nrhs);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part = nullptr, int nrz = 0, bool *did_rz = nullptr,
                        const double *rr_part = nullptr);

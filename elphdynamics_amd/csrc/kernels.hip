@@ -972,6 +972,12 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.lp_ij = h->d_lp_ij; m.lp_c = h->d_lp_c; m.lp_s = h->d_lp_s;
     m.lp_tau_stride = (h->kind == ELPH_MODEL_SSH) ? h->lp_ne * ELPH_WAVE : 0;
     m.cs_chain_stride = m.lp_chain_stride = 0;
+    m.uniform = 0; m.c_uni = 1.0; m.s_uni = 0.0;
+    if (h->kind == ELPH_MODEL_HOLSTEIN && h->nb > 0) {
+        bool uni = true;
+        for (int64_t n = 1; n < h->nb && uni; ++n) uni = (h->h_c[(size_t)n] == h->h_c[0] && h->h_s[(size_t)n] == h->h_s[0]);
+        if (uni) { m.uniform = 1; m.c_uni = h->h_c[0]; m.s_uni = h->h_s[0]; }
+    }
     if (h->kind == ELPH_MODEL_SSH && h->nchains > 1) {
         const long long cs = (long long)h->L * h->nb, lp = (long long)h->L * h->lp_ne * ELPH_WAVE;
         if (h->solo_chain >= 0) {
@@ -1144,7 +1150,8 @@ int elph_launch_ebar(elph_handle_s *h, int nch) {
 
 // z = P^-1 r on layout-S vectors.  cg_mode: 0 standalone; 1 inside CG (skip when done, fuse r.z partials); 2 as 1 with the
 // residual update r -= alpha A p (k_cg_xr) folded into the forward transform (rS is then written)
-int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode) {
+// parts (measurement only, bench.py's per-kernel times): bit 0 forward transform, bit 1 Chebyshev recursion, bit 2 inverse transform
+int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode, int parts) {
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     CgBufs B = make_bufs(h, nrhs);
     // kernels that skip finished right-hand sides read the state copy written by the latest k_cg_ap launch
@@ -1162,7 +1169,8 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     KpmDev K = elph_kpm_dev(h);
     ModelDev m = elph_model_dev(h);
 
-    if (cg_mode == 2) {
+    if (!(parts & 1)) {
+    } else if (cg_mode == 2) {
         int rcd = elph_dft_mfma_fwd_xr(h, h->d_nu, const_cast<double *>(rS), B.z, B.pap, B.npap, B.rr, B.alpha, N, nrhs, st);
         if (rcd) return rcd;
     } else {
@@ -1171,7 +1179,9 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     }
     const size_t shm = (size_t)N * sizeof(double2);
     bool rz_done = false;     // r.z partials already produced in frequency space by the Chebyshev kernel
-    if (h->fast) {
+    if (!(parts & 2)) {
+        rz_done = h->fast && h->sq_P > 0 && cg_mode;      // (timing the inverse transform alone: the form that follows the register-exchange kernel)
+    } else if (h->fast) {
         static const bool freq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
         const bool want = cg_mode && freq_rz && 2 * Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N;
         int rcf = elph_fast_kpm_cheb(h, nrhs, st, want ? B.rz : nullptr, B.nrz, &rz_done, B.rr);
@@ -1191,7 +1201,7 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         });
     }
     // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz; the kernel clears the rest
-    {
+    if (parts & 4) {
         const bool fuse = cg_mode && !rz_done;
         int rcd = elph_dft_inv_twisted(h, zS, h->d_nu, N, nrhs, st, fuse ? rS : nullptr, fuse ? B.rz : nullptr, B.nrz);
         if (rcd) return rcd;

@@ -24,7 +24,7 @@ def _golden_model(name):
     g = golden(name)
     norb, Lsp = (1, 4) if "sq4" in name else (2, 3)
     la = lat.Lattice(norb, Lsp, Lsp, 1)
-    m = models.HolsteinModel(la, int(g["Ltau"]) * float(g["dtau"]), float(g["dtau"]), tol=1e-11)
+    m = models.HolsteinModel(la, int(g["Ltau"]) * float(g["dtau"]), float(g["dtau"]), tol=1e-13)
     assert m.Ltau == int(g["Ltau"])
     m.neighbor_table, m.t = np.array(g["raw"]), np.array(g["t_raw"])
     m.initialize_model_()
@@ -51,17 +51,18 @@ def test_setup_matches_golden_direct_correlations(hname, gname):
     # update!: the device's own batched solves reproduce the dense M⁻¹R, then the whole chain end to end
     it, res, fl = greens.update_(est, m, R=g["R"])
     assert not fl.any() and (res < 1e-9).all()
-    assert np.abs(est.MinvR - g["MinvR"]).max() < 1e-9 * np.abs(g["MinvR"]).max()
+    # Green's-function elements within the north_star's 1e-10 (solve to 1e-13 against the dense M⁻¹R of the fixture)
+    assert np.abs(est.MinvR - g["MinvR"]).max() < 1e-10 * np.abs(g["MinvR"]).max()
     greens.setup_(est, 2, 3)
     for nm in NAMES:
         ref = g["%s_23" % nm]
-        assert np.abs(getattr(est, nm).reshape(-1, order="F").real - ref).max() < 1e-9 * np.abs(ref).max()
+        assert np.abs(getattr(est, nm).reshape(-1, order="F").real - ref).max() < 1e-10 * np.abs(ref).max()
     # measure_* indexing (GreensFunctions.jl:293-329) and estimate (:334-346)
     L = m.Ltau
     G = g["GD0_23"].reshape(est.GD0.shape, order="F")
     o = est.ns
-    assert abs(greens.measure_GD0(est, 2, 1, 0, 1, o, 3) - G[3, o - 1, 0, 2, 1, 0]) < 1e-9
-    assert abs(greens.measure_GD0(est, 0, 0, 0, o, o, 2 * L) - G[0, o - 1, o - 1, 0, 0, 0]) < 1e-9
+    assert abs(greens.measure_GD0(est, 2, 1, 0, 1, o, 3) - G[3, o - 1, 0, 2, 1, 0]) < 1e-10 * np.abs(G).max()
+    assert abs(greens.measure_GD0(est, 0, 0, 0, o, o, 2 * L) - G[0, o - 1, o - 1, 0, 0, 0]) < 1e-10 * np.abs(G).max()
     assert greens.estimate(est, 2, 3, 4, 1, 2) == est.MinvR[2][(2 - 1) * L + 3] * est.R[2][(3 - 1) * L + 0]
     m.close()
 
