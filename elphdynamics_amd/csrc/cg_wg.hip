@@ -37,8 +37,8 @@ template <int NPL>
 __host__ __device__ constexpr int slab_len() { return NPL * WAVE + 2 * WAVE; }
 
 struct WgCtl {
-    u64 *slots;          // [nrhs][2 meetings][Gmax = 32][2 granules]; zeroed by the host before every launch
-    double *bnd;         // [nrhs][G][2][NPL*64]: first / last slice of r of every workgroup (G > 1 only)
+    u64 *slots;          // [nrhs][p.z | r.r][Gmax = 32][2 granules]; zeroed by the host before every launch
+    u64 *bnd;            // [nrhs][G][2][NPL*64][2 granules]: first / last slice of r of every workgroup (G > 1 only); zeroed like slots
     int *abort;
     int G, W;
     long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
@@ -68,116 +68,220 @@ __device__ __forceinline__ void load_tab(Tab<NE, UNI> &t, const double *lc, cons
     for (int e = 0; e < (UNI ? 1 : NE); ++e) { t.c[e] = lc[e * WAVE + lane]; t.s[e] = ls[e * WAVE + lane]; }
 }
 
-// forward checkerboard sweep on two independent slabs (Checkerboard.jl:57-83), bonds in registers
-template <int NPL, bool UNI>
-__device__ __forceinline__ void sweep2(double *bufA, double *bufB, const unsigned (&ij)[MC * ((NPL + 1) / 2)],
-                                       const Tab<MC * ((NPL + 1) / 2), UNI> &tA, const Tab<MC * ((NPL + 1) / 2), UNI> &tB, int ncol) {
-    constexpr int PP = (NPL + 1) / 2;
-#pragma unroll
-    for (int col = 0; col < MC; ++col) {
-        if (col < ncol) {
-            double a0[PP], a1[PP], b0[PP], b1[PP];
-#pragma unroll
-            for (int pp = 0; pp < PP; ++pp) {
-                const unsigned w = ij[col * PP + pp];
-                a0[pp] = bufA[w & 0xFFFF]; a1[pp] = bufA[w >> 16];
-                b0[pp] = bufB[w & 0xFFFF]; b1[pp] = bufB[w >> 16];
-            }
-#pragma unroll
-            for (int pp = 0; pp < PP; ++pp) {
-                const int e = col * PP + pp;
-                const unsigned w = ij[e];
-                bufA[w & 0xFFFF] = tA.C(e) * a0[pp] + tA.S(e) * a1[pp];
-                bufA[w >> 16] = tA.C(e) * a1[pp] + tA.S(e) * a0[pp];
-                bufB[w & 0xFFFF] = tB.C(e) * b0[pp] + tB.S(e) * b1[pp];
-                bufB[w >> 16] = tB.C(e) * b1[pp] + tB.S(e) * b0[pp];
-            }
-            WAVE_LDS_ORDER();
-        }
-    }
-}
-
-// forward sweep on bufA (tables A) and reverse sweep on bufB (tables B) in the same four colour stages
-template <int NPL, bool UNI>
-__device__ __forceinline__ void sweep_fr(double *bufA, double *bufB, const unsigned (&ij)[MC * ((NPL + 1) / 2)],
-                                         const Tab<MC * ((NPL + 1) / 2), UNI> &tA, const Tab<MC * ((NPL + 1) / 2), UNI> &tB, int ncol,
-                                         bool doA) {
-    constexpr int PP = (NPL + 1) / 2;
+// Checkerboard sweep (Checkerboard.jl:57-83 forward / :149-175 reverse) on NS independent slabs at once, bonds in registers:
+// the slabs' colour stages interleave, so NS sweeps cost the latency of one.  Slab k lives at buf + k * SL and uses the hopping
+// tables tabs[TSTRIDE * k + T0] (SSH: one table set per slice; otherwise TSTRIDE = 0).
+template <int NPL, int NS, bool REVERSE, bool UNI, int NT, int TSTRIDE, int T0>
+__device__ __forceinline__ void sweepN(double *buf, const unsigned (&ij)[MC * ((NPL + 1) / 2)],
+                                       const Tab<MC * ((NPL + 1) / 2), UNI> (&tabs)[NT], int ncol) {
+    constexpr int PP = (NPL + 1) / 2, SL = slab_len<NPL>();
 #pragma unroll
     for (int cc = 0; cc < MC; ++cc) {
-        const int colA = cc, colB = MC - 1 - cc;
-        const bool onA = doA && (colA < ncol), onB = (colB < ncol);
-        if (onA || onB) {
-            double a0[PP], a1[PP], b0[PP], b1[PP];
+        const int col = REVERSE ? MC - 1 - cc : cc;
+        if (col < ncol) {
+            double a0[NS][PP], a1[NS][PP];
 #pragma unroll
-            for (int pp = 0; pp < PP; ++pp) {
-                if (onA) { const unsigned w = ij[colA * PP + pp]; a0[pp] = bufA[w & 0xFFFF]; a1[pp] = bufA[w >> 16]; }
-                if (onB) { const unsigned w = ij[colB * PP + pp]; b0[pp] = bufB[w & 0xFFFF]; b1[pp] = bufB[w >> 16]; }
-            }
+            for (int k = 0; k < NS; ++k)
 #pragma unroll
-            for (int pp = 0; pp < PP; ++pp) {
-                if (onA) {
-                    const int e = colA * PP + pp; const unsigned w = ij[e];
-                    bufA[w & 0xFFFF] = tA.C(e) * a0[pp] + tA.S(e) * a1[pp];
-                    bufA[w >> 16] = tA.C(e) * a1[pp] + tA.S(e) * a0[pp];
+                for (int pp = 0; pp < PP; ++pp) {
+                    const unsigned w = ij[col * PP + pp];
+                    a0[k][pp] = buf[k * SL + (w & 0xFFFF)]; a1[k][pp] = buf[k * SL + (w >> 16)];
                 }
-                if (onB) {
-                    const int e = colB * PP + pp; const unsigned w = ij[e];
-                    bufB[w & 0xFFFF] = tB.C(e) * b0[pp] + tB.S(e) * b1[pp];
-                    bufB[w >> 16] = tB.C(e) * b1[pp] + tB.S(e) * b0[pp];
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int pp = 0; pp < PP; ++pp) {
+                    const int e = col * PP + pp;
+                    const unsigned w = ij[e];
+                    const Tab<MC * ((NPL + 1) / 2), UNI> &t = tabs[TSTRIDE * k + T0];
+                    buf[k * SL + (w & 0xFFFF)] = t.C(e) * a0[k][pp] + t.S(e) * a1[k][pp];
+                    buf[k * SL + (w >> 16)] = t.C(e) * a1[k][pp] + t.S(e) * a0[k][pp];
                 }
-            }
             WAVE_LDS_ORDER();
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The 16 x 16 square lattice with the reference's colouring [x-even | x-odd | y-even | y-odd] (verified on the host:
+// detect_square) and one hopping for all bonds: the checkerboard WITHOUT LDS.  Lane l holds the four sites
+//     x = l & 15,  y = 4 (l >> 4) + k,  k = 0..3        (a column segment; a 16-lane DPP row is a row of the lattice)
+// so that   x-bonds  pair neighbouring lanes of one DPP row:  colour 0 = quad_perm [1,0,3,2], colour 1 = row rotate by +-1,
+//           y-bonds  pair registers of one lane (k, k+1), except (k = 3, next row group's k = 0): one wave shuffle each way.
+// A sweep is ~50 VALU instructions and 4 ds_bpermute; the lane-program form is 4 LDS round trips of 16 reads + 16 writes.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct SqCtx { double c, s; bool xodd; int up, dn; };    // partner lanes of the y-odd colour: (l + 16) & 63, (l - 16) & 63
+
+template <int NS, bool REVERSE>
+__device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx &X) {
+    const double c = X.c, s = X.s;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int col = REVERSE ? 3 - cc : cc;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            if (col == 0) {                                      // x even <-> x + 1: lane ^ 1
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const double t = dpp_f64<0xB1>(v[n][k]); v[n][k] = c * v[n][k] + s * t; }
+            } else if (col == 1) {                               // x odd <-> x + 1 (mod 16): odd lanes look up, even lanes look down
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double a = dpp_f64<0x12F>(v[n][k]);    // row_ror:15 = value of lane + 1 (mod 16)
+                    const double b = dpp_f64<0x121>(v[n][k]);    // row_ror:1  = value of lane - 1 (mod 16)
+                    v[n][k] = c * v[n][k] + s * (X.xodd ? a : b);
+                }
+            } else if (col == 2) {                               // y even <-> y + 1: (k0,k1), (k2,k3) of the lane itself
+                const double n0 = c * v[n][0] + s * v[n][1], n1 = c * v[n][1] + s * v[n][0];
+                const double n2 = c * v[n][2] + s * v[n][3], n3 = c * v[n][3] + s * v[n][2];
+                v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
+            } else {                                             // y odd <-> y + 1 (mod 16): (k1,k2) in the lane, k3 <-> next row group's k0
+                const double t3 = __shfl(v[n][0], X.up, WAVE), t0 = __shfl(v[n][3], X.dn, WAVE);
+                const double n1 = c * v[n][1] + s * v[n][2], n2 = c * v[n][2] + s * v[n][1];
+                v[n][0] = c * v[n][0] + s * t0; v[n][3] = c * v[n][3] + s * t3;
+                v[n][1] = n1; v[n][2] = n2;
+            }
+        }
+    }
+}
+
+// Diagnostic build (-DELPH_WG_STAMPS, tools/time_wg_phases.py): wave 0 of workgroup 0 of right-hand side 0 adds the wall-clock
+// ticks (100 MHz) it spends in each phase of an iteration to a buffer no kernel reads.  Never compiled into the product.
+#ifdef ELPH_WG_STAMPS
+__device__ unsigned long long g_wg_stamps[16];
+#define STAMP_DECL long long _ts = wall_clock64(); unsigned long long _acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(k) do { const long long _n = wall_clock64(); _acc[k] += (unsigned long long)(_n - _ts); _ts = _n; } while (0)
+#define STAMP_OUT(iters) do { if (rhs == 0 && g == 0 && wv == 0 && lane == 0) { for (int _k = 0; _k < 10; ++_k) g_wg_stamps[_k] = _acc[_k]; g_wg_stamps[10] = (unsigned long long)(iters); } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_OUT(iters)
+#endif
+
+// One 8-byte record granule, write-through (sc1): correct under any placement of the team's workgroups.  (Measured alternative
+// for teams that find themselves on one XCD — plain stores that stay in that XCD's L2, polled with the same sc1 loads — is
+// SLOWER, 9.3 vs 6.7 us per iteration at config C: a plain store is in no hurry to leave the CU.)
 __device__ __forceinline__ void st_gran(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 ld_gran(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Team meeting through L2.  Called by EVERY wave of every workgroup of the team with the workgroup's value `mine` (identical
-// in all its waves); the `publisher` wave stores the workgroup's record.  On return every wave holds the sum of the G
-// records taken in index order.  false: timed out or aborted.
-__device__ __forceinline__ bool team_sum(u64 *slots, int g, int G, double mine, unsigned epoch, bool publisher, int lane,
-                                         const WgCtl &R, double &total) {
-    if (publisher && lane < 2) {
-        const u64 bits = (u64)__double_as_longlong(mine);
-        const unsigned half = lane ? (unsigned)(bits >> 32) : (unsigned)bits;
-        st_gran(slots + 2 * g + lane, ((u64)epoch << 32) | half);
+// Poll loops of the meetings: lanes < 2G watch the team's record granules, every lane of a boundary wave watches its 2 NPL boundary
+// granules, until all carry `epoch`.  A poll is a ~0.5 us round trip to the memory side (write-through lines do not stay in L2),
+// so the record poll keeps THREE loads in flight, a fresh one issued as the oldest returns: a record is noticed ~0.15 us after
+// it lands instead of up to a round trip later — and the workgroups of a team stay that much closer in step.
+// Bounded by the wall clock; false = gave up (abort raised) or saw abort.
+template <int NPL>
+__device__ __forceinline__ bool poll_bail(int spin, long long &t_start, int lane, const WgCtl &R) {
+    if ((spin & 31) != 31) return false;
+    if (__hip_atomic_load(R.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    const long long now = wall_clock64();
+    if (t_start == 0) { t_start = now; return false; }
+    if (now - t_start > R.timeout_ticks) {
+        if (lane == 0) __hip_atomic_store(R.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
     }
-    u64 v = 0;
+    return false;
+}
+
+// records only (lanes < 2G): three polls in flight
+__device__ __forceinline__ bool poll_records(const u64 *rec, int G, unsigned epoch, int lane, const WgCtl &R, u64 &v) {
+    const bool mine = lane < 2 * G;
+    u64 a = 0, b = 0, c = 0;
+    if (mine) a = ld_gran(rec + lane);
+    __builtin_amdgcn_s_sleep(2);
+    if (mine) b = ld_gran(rec + lane);
+    __builtin_amdgcn_s_sleep(2);
+    if (mine) c = ld_gran(rec + lane);
+    long long t_start = 0;
+    for (int spin = 0;; ++spin) {
+        if (__all(!mine || (unsigned)(a >> 32) == epoch)) { v = a; return true; }
+        if (mine) a = ld_gran(rec + lane);
+        if (__all(!mine || (unsigned)(b >> 32) == epoch)) { v = b; return true; }
+        if (mine) b = ld_gran(rec + lane);
+        if (__all(!mine || (unsigned)(c >> 32) == epoch)) { v = c; return true; }
+        if (mine) c = ld_gran(rec + lane);
+        if (poll_bail<1>(spin, t_start, lane, R)) return false;
+    }
+}
+
+// records (optional) + the 2 NPL boundary granules of every lane; one poll at a time (a second poll set in flight costs 4 NPL + 2
+// registers next to the Krylov vectors: measured as spills)
+template <int NPL>
+__device__ __forceinline__ bool poll_granules(const u64 *rec, int G, const u64 *bh, unsigned epoch, int lane, const WgCtl &R, u64 &v,
+                                              u64 (&gh)[NPL][2]) {
     long long t_start = 0;
     for (int spin = 0;; ++spin) {
         bool ok = true;
-        if (lane < 2 * G) { v = ld_gran(slots + lane); ok = ((unsigned)(v >> 32) == epoch); }
-        if (__all(ok)) break;
-        if ((spin & 63) == 63) {
-            if (__hip_atomic_load(R.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            const long long now = wall_clock64();
-            if (t_start == 0) t_start = now;
-            else if (now - t_start > R.timeout_ticks) {
-                if (lane == 0) __hip_atomic_store(R.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
+        if (rec && lane < 2 * G) v = ld_gran(rec + lane);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { gh[q][0] = ld_gran(bh + 2 * (lane + q * WAVE)); gh[q][1] = ld_gran(bh + 2 * (lane + q * WAVE) + 1); }
+        if (rec && lane < 2 * G) ok = ((unsigned)(v >> 32) == epoch);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) ok = ok && (unsigned)(gh[q][0] >> 32) == epoch && (unsigned)(gh[q][1] >> 32) == epoch;
+        if (__all(ok)) return true;
+        if (poll_bail<NPL>(spin, t_start, lane, R)) return false;
         __builtin_amdgcn_s_sleep(1);
     }
-    const unsigned lo = (unsigned)v;
-    const unsigned hi = (unsigned)__shfl((int)lo, lane | 1, WAVE);             // even lane 2k: the high half sits in lane 2k+1
-    const double val = __longlong_as_double((long long)(((u64)hi << 32) | lo));
-    total = 0.0;
-    for (int k = 0; k < G; ++k) total += __shfl(val, 2 * k, WAVE);
-    return true;
 }
 
-template <int NPL, int T, bool SSH, bool UNI>
+__device__ __forceinline__ void st_f64_gran(u64 *g2, double v, unsigned epoch) {
+    const u64 bits = (u64)__double_as_longlong(v), tag = (u64)epoch << 32;
+    st_gran(g2, tag | (bits & 0xFFFFFFFFull));
+    st_gran(g2 + 1, tag | (bits >> 32));
+}
+
+// wave-wide sum without LDS: quad swaps and row mirrors (DPP) give every lane the sum of its 16-lane row, then the four row sums
+// are added in a fixed order through scalar registers.  Same tree in every wave and every run.
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);         // row_half_mirror
+    v += dpp_f64<0x140>(v);         // row_mirror
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// sum of the W wave partials of a workgroup in index order (every wave gets the same bits)
+__device__ __forceinline__ double wg_sum(const double *part, int W, int lane) {
+    const double mine = (lane < W) ? part[lane] : 0.0;
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < W) tot += readlane_f64(mine, i);
+    return tot;
+}
+
+// wait for this wave's LDS traffic, then the workgroup barrier — NOT __syncthreads(): that would also drain the vector-memory
+// queue (the x loads / stores in flight ride across the meetings on purpose)
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// SQ: the DPP form for the uniform 16 x 16 square lattice (NPL = 4, no LDS slabs); otherwise the lane-program form
+template <int NPL, int T, bool SSH, bool UNI, bool SQ>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    static_assert(!SQ || (NPL == 4 && UNI && !SSH), "DPP form: uniform 16 x 16 square lattice");
     constexpr int NE = MC * ((NPL + 1) / 2);
     constexpr int HS = NPL * WAVE, SL = slab_len<NPL>();
-    constexpr int NH = (T == 1) ? 1 : 2;               // boundary slices a wave shows its neighbours (T = 1: first == last)
+    constexpr int NSLAB = SQ ? 0 : T + 1;              // LDS slabs per wave (lane-program form)
     constexpr int NT = SSH ? T + 1 : 1;                // hopping-table sets (SSH: one per slice t0 .. t0+T)
     constexpr int NEJ = SSH ? 1 : T + 1;               // exp(-dtau V) slices (SSH: exp(dtau mu), per site only)
     const int W = R.W, G = R.G;
@@ -189,9 +293,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
     const int N = m.N, L = m.L;
     const int t0 = (g * W + wv) * T;
     const size_t ndim = (size_t)N * L;
-    double *bufA = lds + (size_t)wv * 2 * SL, *bufB = bufA + SL;
-    double *hal = lds + (size_t)W * 2 * SL;            // [W][NH][HS]
-    double *partA = hal + (size_t)W * NH * HS, *partB = partA + W;
+    double *slab = lds + (size_t)wv * NSLAB * SL;
+    double *rall = lds + (size_t)W * NSLAB * SL;       // [W][T][HS]: r of every wave's slices — neighbours read their halo slices here
+    double *rl = rall + (size_t)wv * T * HS;
+    double *xl = rall + (size_t)W * T * HS + (size_t)wv * T * HS;      // [W][T][HS]: this wave's slices of x
+    double *partA = rall + 2 * (size_t)W * T * HS, *partB = partA + 8, *bc = partA + 16;     // bc: p.z total, r.r total, 0.0 = a poller gave up
     auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
     auto sgn = [](int t) { return (t == 0) ? -1.0 : 1.0; };
     const CgParams P = B.params;
@@ -199,20 +305,30 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
     const CgState S = ld_state(st2);
     if (S.done || S.seq != 0) return;                  // fresh solves only (the host guarantees it)
 
+    // site of register q of this lane: lane + 64 q (layout S order), or the column segments of the DPP form
     int sc[NPL];
+    bool live[NPL];
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) { const int s = lane + q * WAVE; sc[q] = (s < N) ? s : N - 1; }
+    for (int q = 0; q < NPL; ++q) {
+        const int s = SQ ? ((lane & 15) + 64 * (lane >> 4) + 16 * q) : lane + q * WAVE;
+        live[q] = s < N;
+        sc[q] = live[q] ? s : N - 1;
+    }
     double *xg = B.x + (size_t)rhs * ndim, *rg = B.r + (size_t)rhs * ndim;
     const double *pg = B.p + (size_t)rhs * ndim;       // parity 0: p0 of k_cg_init
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
 
-    // x lives in memory: it is only ever updated (x += alpha p), never an input of the iteration — its load-add-store rides under
-    // the second meeting and costs no register across the mat-vec
-    double r[T][NPL], z[T][NPL], p[T + 2][NPL], E[NEJ][NPL];
+    // x and r live in this wave's LDS (lane-linear, conflict-free): both are only touched by the two vector updates, never by the
+    // mat-vec — no register across the mat-vec, no vector-memory traffic inside the loop that a meeting's poll would wait behind,
+    // and the neighbouring waves read their halo slices of r straight from here
+    double z[T][NPL], p[T + 2][NPL], E[NEJ][NPL];
 #pragma unroll
     for (int j = 0; j < T; ++j)
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) r[j][q] = rg[(size_t)(t0 + j) * N + sc[q]];
+        for (int q = 0; q < NPL; ++q) {
+            rl[j * HS + lane + q * WAVE] = rg[(size_t)(t0 + j) * N + sc[q]];
+            xl[j * HS + lane + q * WAVE] = xg[(size_t)(t0 + j) * N + sc[q]];
+        }
 #pragma unroll
     for (int j = 0; j < T + 2; ++j)
 #pragma unroll
@@ -223,131 +339,191 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
         for (int q = 0; q < NPL; ++q) E[j][q] = Ech[(size_t)wrap(t0 + j) * m.E_tau_stride + sc[q]];
     unsigned ij[NE];
     Tab<NE, UNI> tab[NT];
-    load_ij<NPL>(ij, m, lane);
-    if (SSH) {
-        ssh_chain_select(m, rhs);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            load_tab<NE, UNI>(tab[j], m.lp_c + (size_t)wrap(t0 + j) * m.lp_tau_stride, m.lp_s + (size_t)wrap(t0 + j) * m.lp_tau_stride, lane, m);
+    SqCtx X;
+    if constexpr (SQ) {
+        X.c = m.c_uni; X.s = m.s_uni; X.xodd = (lane & 1) != 0; X.up = (lane + 16) & 63; X.dn = (lane + 48) & 63;
     } else {
-        load_tab<NE, UNI>(tab[0], m.lp_c, m.lp_s, lane, m);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ij[e] = m.lp_ij[e * WAVE + lane];
+        if (SSH) {
+            ssh_chain_select(m, rhs);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                load_tab<NE, UNI>(tab[j], m.lp_c + (size_t)wrap(t0 + j) * m.lp_tau_stride, m.lp_s + (size_t)wrap(t0 + j) * m.lp_tau_stride, lane, m);
+        } else {
+            load_tab<NE, UNI>(tab[0], m.lp_c, m.lp_s, lane, m);
+        }
     }
-#define TAB(j) tab[SSH ? (j) : 0]
 #define EXPV(j) E[SSH ? 0 : (j)]
 
     u64 *slotsA = R.slots + (size_t)rhs * 2 * 64, *slotsB = slotsA + 64;
-    double *bnd = R.bnd + (size_t)rhs * G * 2 * HS;
+    u64 *bnd = R.bnd + (size_t)rhs * G * 2 * HS * 2;     // [G][first | last slice][HS][2 granules]
     const int gm = (g == 0) ? G - 1 : g - 1, gp = (g == G - 1) ? 0 : g + 1;
     double rho = S.rho, kmin = S.kmin, eps = S.eps;
     const double eps0 = S.eps0, normb = S.normb;
 
+    if (threadIdx.x == 0) bc[2] = 1.0;                 // (ordered before its first reader by the barriers of iteration 0)
+    STAMP_DECL;
     for (long long seq = 0;; ++seq) {
         const unsigned epoch = (unsigned)seq + 1u;
-        // ---- z = M^T M p on the own slices: w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)],  z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)
-        double wprev[NPL], wcur[NPL];
+        STAMP(9);
+        // ---- z = M^T M p on the own slices:  w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)]  for t = t0 .. t0+T  (T+1 forward sweeps at once),
+        //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
+        double w[T + 1][NPL];
+        if constexpr (SQ) {
+            double f[T + 1][4];
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int s = lane + q * WAVE;
-            bufA[s] = EXPV(0)[q] * p[0][q];
-            bufB[s] = EXPV(1)[q] * p[1][q];
-        }
-        WAVE_LDS_ORDER();
-        sweep2<NPL, UNI>(bufA, bufB, ij, TAB(0), TAB(1), m.ncol);
-        {
-            const double sga = sgn(t0), sgb = sgn(wrap(t0 + 1));
+            for (int k = 0; k <= T; ++k)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const int s = lane + q * WAVE;
-                wprev[q] = p[1][q] - sga * bufA[s];
-                wcur[q] = p[2][q] - sgb * bufB[s];
+                for (int q = 0; q < 4; ++q) f[k][q] = EXPV(k)[q] * p[k][q];
+            sq_sweepN<T + 1, false>(f, X);
+#pragma unroll
+            for (int k = 0; k <= T; ++k) {
+                const double sg = sgn(wrap(t0 + k));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[k][q] = p[k + 1][q] - sg * f[k][q];
             }
+            double gq[T][4];
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gq[j][q] = w[j + 1][q];
+            sq_sweepN<T, true>(gq, X);
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const double sg = sgn(wrap(t0 + j + 1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[j][q] = w[j][q] - sg * EXPV(j + 1)[q] * gq[j][q];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k <= T; ++k)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) slab[k * SL + lane + q * WAVE] = EXPV(k)[q] * p[k][q];
+            WAVE_LDS_ORDER();
+            sweepN<NPL, T + 1, false, UNI, NT, SSH ? 1 : 0, 0>(slab, ij, tab, m.ncol);
+#pragma unroll
+            for (int k = 0; k <= T; ++k) {
+                const double sg = sgn(wrap(t0 + k));
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) w[k][q] = p[k + 1][q] - sg * slab[k * SL + lane + q * WAVE];
+            }
+            WAVE_LDS_ORDER();
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) slab[j * SL + lane + q * WAVE] = w[j + 1][q];
+            WAVE_LDS_ORDER();
+            sweepN<NPL, T, true, UNI, NT, SSH ? 1 : 0, SSH ? 1 : 0>(slab, ij, tab, m.ncol);
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const double sg = sgn(wrap(t0 + j + 1));
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) z[j][q] = w[j][q] - sg * EXPV(j + 1)[q] * slab[j * SL + lane + q * WAVE];
+            }
+            WAVE_LDS_ORDER();
         }
-        WAVE_LDS_ORDER();
         double acc = 0.0;
 #pragma unroll
-        for (int j = 1; j <= T; ++j) {
-            const bool more = (j < T);
+        for (int j = 0; j < T; ++j)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const int s = lane + q * WAVE;
-                bufB[s] = wcur[q];
-                if (more) bufA[s] = EXPV((j + 1 <= T) ? j + 1 : T)[q] * p[j + 1][q];        // E(t0+j+1) .* p(t0+j)
-            }
-            WAVE_LDS_ORDER();
-            sweep_fr<NPL, UNI>(bufA, bufB, ij, TAB((j + 1 <= T) ? j + 1 : T), TAB(j), m.ncol, more);
-            const double sgj = sgn(wrap(t0 + j)), sgnn = sgn(wrap(t0 + j + 1));
-            double wnext[NPL];
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const int s = lane + q * WAVE;
-                const double zz = wprev[q] - sgj * EXPV(j)[q] * bufB[s];                      // z(t0+j-1)
-                z[j - 1][q] = zz;
-                if (s < N) acc += p[j][q] * zz;
-                if (more) wnext[q] = p[(j + 2 <= T + 1) ? j + 2 : T + 1][q] - sgnn * bufA[s];  // w(t0+j+1)
-            }
-            WAVE_LDS_ORDER();
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) { wprev[q] = wcur[q]; wcur[q] = wnext[q]; }
-            }
-        }
-        acc = wave_sum2(acc);
+            for (int q = 0; q < NPL; ++q) if (live[q]) acc += p[j + 1][q] * z[j][q];
+        acc = wave_sum_dpp(acc);
+        // (x of the own slices lives in LDS)
+        STAMP(0);
         // ---- meeting 1: p.z ---------------------------------------------------------------------------------------
+        // wave partials -> LDS -> barrier; with a team of several workgroups ONE wave per workgroup publishes the workgroup's
+        // record and polls the team's (80 waves polling one line serialise at the memory side: 1.5 -> ~0.7 us per meeting),
+        // then hands the total to its workgroup through LDS
         if (lane == 0) partA[wv] = acc;
-        __syncthreads();
-        double pap = 0.0;
-        for (int i = 0; i < W; ++i) pap += partA[i];
-        if (G > 1) {
-            double tot;
-            if (!team_sum(slotsA, g, G, pap, epoch, wv == 0, lane, R, tot)) return;
-            pap = tot;
+        wg_barrier();
+        double pap;
+        if (G == 1) {
+            pap = wg_sum(partA, W, lane);
+        } else {
+            if (wv == 0) {
+                const double mine = wg_sum(partA, W, lane);
+                if (lane < 2) {
+                    const u64 bits = (u64)__double_as_longlong(mine);
+                    st_gran(slotsA + 2 * g + lane, ((u64)epoch << 32) | (lane ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+                }
+                u64 v = 0;
+                const bool ok = poll_records(slotsA, G, epoch, lane, R, v);
+                const int half = (int)(unsigned)v;
+                double tot = 0.0;
+                for (int k = 0; k < G; ++k)
+                    tot += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * k + 1), __builtin_amdgcn_readlane(half, 2 * k));
+                if (lane == 0) { bc[0] = tot; if (!ok) bc[2] = 0.0; }
+            }
+            wg_barrier();
+            if (bc[2] == 0.0) return;
+            pap = bc[0];
         }
+        STAMP(1);
+        STAMP(2);
         const double alpha = rho / pap;
-        // ---- r -= alpha z, r.r; show the boundary slices of the new r; x += alpha p goes to memory under the second meeting ---
-        double a = 0.0;
+        // ---- x += alpha p (to memory), r -= alpha z, r.r; show the boundary slices of the new r ---------------------------
+        double a = 0.0, rn[T][NPL];
 #pragma unroll
         for (int j = 0; j < T; ++j)
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const int s = lane + q * WAVE;
-                const double rn = r[j][q] - alpha * z[j][q];
-                r[j][q] = rn;
-                if (s < N) a += rn * rn;
+                rn[j][q] = rl[j * HS + lane + q * WAVE] - alpha * z[j][q];                         // :285
+                rl[j * HS + lane + q * WAVE] = rn[j][q];
+                if (live[q]) a += rn[j][q] * rn[j][q];
+                xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];                               // :282
             }
-        a = wave_sum2(a);
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int s = lane + q * WAVE;
-            hal[((size_t)wv * NH + 0) * HS + s] = r[0][q];
-            if (NH == 2) hal[((size_t)wv * NH + 1) * HS + s] = r[T - 1][q];
-        }
+        a = wave_sum_dpp(a);
+        // slices that cross a workgroup boundary travel as granules too ({iteration, half of the f64}: the data is its own flag —
+        // no drain here, no flag there; the neighbour polls them together with the r.r records)
         if (G > 1) {
             if (wv == 0) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) st_sc1(bnd + ((size_t)g * 2 + 0) * HS + lane + q * WAVE, r[0][q]);
+                for (int q = 0; q < NPL; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 0) * HS + lane + q * WAVE) * 2, rn[0][q], epoch);
             }
             if (wv == W - 1) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) st_sc1(bnd + ((size_t)g * 2 + 1) * HS + lane + q * WAVE, r[T - 1][q]);
+                for (int q = 0; q < NPL; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 1) * HS + lane + q * WAVE) * 2, rn[T - 1][q], epoch);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the barrier; the record after it is the flag
         }
         if (lane == 0) partB[wv] = a;
-        __syncthreads();
+        STAMP(3);
+        wg_barrier();
+        STAMP(4);
+        // ---- meeting 2: r.r and the halo slices of the new r ------------------------------------------------------------------
+        double rr, hx[NPL];                                   // hx: the halo slice that comes from another workgroup (waves 0 and W-1)
+        if (G == 1) {
+            rr = wg_sum(partB, W, lane);
+        } else {
+            if (wv == 0 || wv == W - 1) {
+                u64 v = 0, gh[NPL][2];
+                const u64 *bh = (wv == 0) ? bnd + (((size_t)gm * 2 + 1) * HS) * 2                  // left halo: last slice of workgroup g - 1
+                                          : bnd + (((size_t)gp * 2 + 0) * HS) * 2;                 // right halo: first slice of workgroup g + 1
+                if (wv == 0) {
+                    const double mine = wg_sum(partB, W, lane);
+                    if (lane < 2) {
+                        const u64 bits = (u64)__double_as_longlong(mine);
+                        st_gran(slotsB + 2 * g + lane, ((u64)epoch << 32) | (lane ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+                    }
+                }
+                const bool ok = poll_granules<NPL>(wv == 0 ? slotsB : nullptr, G, bh, epoch, lane, R, v, gh);
 #pragma unroll
-        for (int j = 0; j < T; ++j)
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const int s = lane + q * WAVE;
-                if (s < N) { const size_t i = (size_t)(t0 + j) * N + s; xg[i] = xg[i] + alpha * p[j + 1][q]; }     // IterativeSolvers.jl:282
+                for (int q = 0; q < NPL; ++q) hx[q] = __hiloint2double((int)(unsigned)gh[q][1], (int)(unsigned)gh[q][0]);
+                if (wv == 0) {
+                    const int half = (int)(unsigned)v;
+                    double tot = 0.0;
+                    for (int k = 0; k < G; ++k)
+                        tot += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * k + 1), __builtin_amdgcn_readlane(half, 2 * k));
+                    if (lane == 0) bc[1] = tot;
+                }
+                if (!ok && lane == 0) bc[2] = 0.0;
             }
-        double rr = 0.0;
-        for (int i = 0; i < W; ++i) rr += partB[i];
-        if (G > 1) {
-            double tot;
-            if (!team_sum(slotsB, g, G, rr, epoch, wv == 0, lane, R, tot)) return;
-            rr = tot;
+            wg_barrier();
+            if (bc[2] == 0.0) return;
+            rr = bc[1];
         }
+        STAMP(5);
+        STAMP(6);
         // ---- stop test of iteration it = seq + 1 (IterativeSolvers.jl:286-295) ---------------------------------------------
         const long long it = seq + 1;
         int done = 0;
@@ -363,14 +539,17 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
             else if (it >= P.maxiter) done = 3;
             if (g == 0 && wv == 0 && lane == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + it] = eps;
         }
+        STAMP(7);
         if (done) {
+            STAMP_OUT(it);
 #pragma unroll
             for (int j = 0; j < T; ++j)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int s = lane + q * WAVE;
-                    if (s < N) rg[(size_t)(t0 + j) * N + s] = r[j][q];
-                }
+                for (int q = 0; q < NPL; ++q)
+                    if (live[q]) {
+                        rg[(size_t)(t0 + j) * N + sc[q]] = rl[j * HS + lane + q * WAVE];
+                        xg[(size_t)(t0 + j) * N + sc[q]] = xl[j * HS + lane + q * WAVE];
+                    }
             if (g == 0 && wv == 0 && lane == 0) {
                 CgState o = S;
                 o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = it + 1; o.iters = it; o.done = done;
@@ -382,36 +561,23 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
         const double beta = rr / rho;
         rho = rr;
         // ---- next direction on the own slices and on the two halo slices (p = r + beta p is pointwise) --------------------
-        double hl[NPL], hr[NPL];
-        if (wv > 0 || G == 1) {
-            const double *src = hal + ((size_t)((wv > 0) ? wv - 1 : W - 1) * NH + (NH - 1)) * HS;
+        {
+            const bool lx = (G > 1 && wv == 0), rx = (G > 1 && wv == W - 1);
+            const double *sl = rall + ((size_t)((wv > 0) ? wv - 1 : W - 1) * T + (T - 1)) * HS;     // last slice of the wave below
+            const double *sr = rall + ((size_t)((wv < W - 1) ? wv + 1 : 0) * T + 0) * HS;          // first slice of the wave above
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) hl[q] = src[lane + q * WAVE];
-        } else {
-            const double *src = bnd + ((size_t)gm * 2 + 1) * HS;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) hl[q] = ld_sc1(src + lane + q * WAVE);
-        }
-        if (wv < W - 1 || G == 1) {
-            const double *src = hal + ((size_t)((wv < W - 1) ? wv + 1 : 0) * NH + 0) * HS;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) hr[q] = src[lane + q * WAVE];
-        } else {
-            const double *src = bnd + ((size_t)gp * 2 + 0) * HS;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) hr[q] = ld_sc1(src + lane + q * WAVE);
-        }
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            p[0][q] = hl[q] + beta * p[0][q];
-            p[T + 1][q] = hr[q] + beta * p[T + 1][q];
+            for (int q = 0; q < NPL; ++q) {
+                const double hl = lx ? hx[q] : sl[lane + q * WAVE], hr = rx ? hx[q] : sr[lane + q * WAVE];
+                p[0][q] = hl + beta * p[0][q];
+                p[T + 1][q] = hr + beta * p[T + 1][q];
+            }
         }
 #pragma unroll
         for (int j = 0; j < T; ++j)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) p[j + 1][q] = r[j][q] + beta * p[j + 1][q];
+            for (int q = 0; q < NPL; ++q) p[j + 1][q] = rl[j * HS + lane + q * WAVE] + beta * p[j + 1][q];
+        STAMP(8);
     }
-#undef TAB
 #undef EXPV
 }
 
@@ -419,58 +585,75 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
 // host side
 // ------------------------------------------------------------------------------------------
 
-struct Shape { int T, W, G; size_t shm; };
+struct Shape { int T, W, G; size_t shm; bool sq; };
 
-// T = 2 slices per wave where the register file takes it (site phonons, <= 4 sites per lane: no spills at 256 VGPRs), else 1;
-// W = the largest divisor of Ltau / T that is <= 8 waves (two per SIMD), G = workgroups per right-hand side
-static bool pick_shape(const elph_handle_s *h, int forceT, Shape *out) {
+// DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square), one hopping for all bonds
+static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
+    const char *e = getenv("ELPH_WG_NO_DPP");
+    return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 2 && h->N == 256 && m.uniform && !(e && e[0] == '1');
+}
+
+// T slices per wave: as many as the register file takes without spilling at two waves per SIMD (DPP form 4, lane-program form 2
+// for site phonons with <= 4 sites per lane, else 1); W = the largest divisor of Ltau / T that is <= 8 waves; G = workgroups per
+// right-hand side (<= 32: the 2G record granules of a meeting are polled by one wave instruction)
+static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, Shape *out) {
     const int L = (int)h->L;
-    const bool ssh = (h->kind == ELPH_MODEL_SSH);
-    const int cand[2] = {2, 1};
+    const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m);
+    const int cand[3] = {4, 2, 1};
     for (int T : cand) {
         if (forceT && T != forceT) continue;
-        if (T == 2 && (ssh || h->npl > 4)) continue;
+        if (T == 4 && (!sq || forceT != 4)) continue;       // (4 slices per wave spill at 256 registers: experiments only)
+        if (T == 2 && !sq && (ssh || h->npl > 4 || (h->npl == 4 && !m.uniform))) continue;
         if (L % T) continue;
         const int Wt = L / T;
         int W = 0;
         for (int w = std::min(8, Wt); w >= 1; --w) if (Wt % w == 0) { W = w; break; }
         const int G = Wt / W;
-        if (G > 32) continue;                            // the 2G record granules of a meeting must fit one wave's poll
-        const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE, NH = (T == 1) ? 1 : 2;
-        const size_t shm = ((size_t)W * 2 * SL + (size_t)W * NH * HS + 2 * (size_t)W + 2) * sizeof(double);
+        if (G > 32) continue;
+        if (G > 1 && W < 2) continue;                    // (a wave polls at most ONE neighbouring workgroup's boundary slice)
+        const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
+        const size_t shm = ((size_t)W * (sq ? 0 : T + 1) * SL + 2 * (size_t)W * T * HS + 24) * sizeof(double);
         if (shm > 160 * 1024) continue;
-        out->T = T; out->W = W; out->G = G; out->shm = shm;
+        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq;
         return true;
     }
     return false;
 }
 
-template <int NPL, int T, bool SSH, bool UNI>
+template <int NPL, int T, bool SSH, bool UNI, bool SQ>
 static hipError_t launch_k(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
+    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R);
+    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI, SQ>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R);
     return hipGetLastError();
 }
 
 template <int NPL>
 static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R) {
-    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false>(h, sh, grid, B, m, R);
-    if constexpr (NPL <= 4) {
-        if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false>(h, sh, grid, B, m, R);
+    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, false>(h, sh, grid, B, m, R);
+    if constexpr (NPL == 4) {
+        if (sh.sq) {
+            if (sh.T == 4) return launch_k<4, 4, false, true, true>(h, sh, grid, B, m, R);
+            if (sh.T == 2) return launch_k<4, 2, false, true, true>(h, sh, grid, B, m, R);
+            return launch_k<4, 1, false, true, true>(h, sh, grid, B, m, R);
+        }
     }
-    return m.uniform ? launch_k<NPL, 1, false, true>(h, sh, grid, B, m, R) : launch_k<NPL, 1, false, false>(h, sh, grid, B, m, R);
+    if constexpr (NPL <= 4) {
+        if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false, false>(h, sh, grid, B, m, R);
+    }
+    return m.uniform ? launch_k<NPL, 1, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 1, false, false, false>(h, sh, grid, B, m, R);
 }
 
 }  // namespace wg
 
 // Whether the workgroup-resident kernel can run this handle's un-preconditioned solves (and with which shape).
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G) {
-    static const bool off = []() { const char *e = getenv("ELPH_NO_WG"); return e && e[0] == '1'; }();
+    const char *eo = getenv("ELPH_NO_WG");                 // read per call: the tests switch between the two forms
+    const bool off = eo && eo[0] == '1';
     if (off || !h->fast || h->lp_mc != 4 || h->npl > 5 || h->dot_hi != 0 || h->solo_chain >= 0) return false;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
-    if (!wg::pick_shape(h, et ? atoi(et) : 0, &sh)) return false;
+    if (!wg::pick_shape(h, elph_model_dev(h), et ? atoi(et) : 0, &sh)) return false;
     if (T) *T = sh.T;
     if (W) *W = sh.W;
     if (G) *G = sh.G;
@@ -486,10 +669,11 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     if (!elph_wg_usable(h, nullptr, nullptr, nullptr)) return ELPH_OK;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
-    if (!wg::pick_shape(h, et ? atoi(et) : 0, &sh)) return ELPH_OK;
+    ModelDev m = elph_model_dev(h);
+    if (!wg::pick_shape(h, m, et ? atoi(et) : 0, &sh)) return ELPH_OK;
     const size_t HS = (size_t)h->npl * WAVE;
-    const size_t n_slots = (size_t)nrhs * 2 * 64, n_bnd = (size_t)nrhs * sh.G * 2 * HS;
-    const size_t need = n_slots * sizeof(wg::u64) + 64 + n_bnd * sizeof(double);
+    const size_t n_slots = (size_t)nrhs * 2 * 64, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
+    const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
     if (need > h->res_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->d_res) HIPCHK(hipFree(h->d_res));
@@ -500,14 +684,13 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     wg::WgCtl R;
     char *base = static_cast<char *>(h->d_res);
     R.slots = reinterpret_cast<wg::u64 *>(base);
-    R.abort = reinterpret_cast<int *>(base + n_slots * sizeof(wg::u64));
-    R.bnd = reinterpret_cast<double *>(base + n_slots * sizeof(wg::u64) + 64);
+    R.bnd = R.slots + n_slots;
+    R.abort = reinterpret_cast<int *>(base + (n_slots + n_bnd) * sizeof(wg::u64));
     R.G = sh.G; R.W = sh.W;
     const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
     R.timeout_ticks = (long long)(eto ? atoll(eto) : 20000) * 100000LL;     // wall_clock64 runs at 100 MHz
     R.fixed_iters = fixed_iters;
-    HIPCHK(hipMemsetAsync(base, 0, n_slots * sizeof(wg::u64) + 64, h->stream));   // every polled word, every launch
-    ModelDev m = elph_model_dev(h);
+    HIPCHK(hipMemsetAsync(base, 0, (n_slots + n_bnd) * sizeof(wg::u64) + 64, h->stream));   // every polled word, every launch
     const dim3 grid((unsigned)(8 * ((nrhs + 7) / 8) * sh.G));
     hipError_t e = hipSuccess;
     switch (h->npl) {
@@ -519,7 +702,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     }
     if (e != hipSuccess) { elph_set_error("launch k_cg_wg failed: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
     h->wg_T = sh.T; h->wg_W = sh.W; h->wg_G = sh.G;
-    h->wg_abort_off = n_slots * sizeof(wg::u64);
+    h->wg_abort_off = (n_slots + n_bnd) * sizeof(wg::u64);
     *ran = true;
     return ELPH_OK;
 }
@@ -538,3 +721,9 @@ int elph_wg_aborted(elph_handle_s *h, bool *aborted) {
     }
     return ELPH_OK;
 }
+
+#ifdef ELPH_WG_STAMPS
+extern "C" int elph_debug_wg_stamps(unsigned long long *out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(wg::g_wg_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1046,3 +1046,88 @@ def test_lds_sync_build_is_bit_identical():
     assert outs[0]["lib"] == "libelphgpu.so" and outs[1]["lib"] == "libelphgpu_ldssync.so"
     for tag in tags:
         assert outs[0][tag] == outs[1][tag], (tag, outs[0][tag], outs[1][tag])
+
+
+# ------------------------------------------------------------------------------------------ workgroup-resident CG (cg_wg.hip)
+
+def _wg_info(m):
+    from elphdynamics_amd import _lib
+    us, T, W, G = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _lib.check(_lib.load().elph_bench_wg_info(m._h, C.byref(us), C.byref(T), C.byref(W), C.byref(G)))
+    return us.value, T.value, W.value, G.value
+
+
+@pytest.mark.parametrize("tag", ["b", "d", "e", "B", "C", "D", "E"])
+def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
+    """The whole solve in one launch (Krylov vectors in registers / LDS, teams of workgroups meeting through L2) against the
+    streaming two-kernel iteration: same algorithm, different summation trees for p.z and r.r — same iteration count up to
+    the knife edge, solutions equal to the solver tolerance at 1e-5 and to 1e-11 when both solve to 1e-13; both slices-per-wave
+    shapes and, on the 16 x 16 square lattice, both forms of the checkerboard (DPP exchange / lane program in LDS)."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model(tag, tol=1e-5)
+    usable, T, W, G = _wg_info(m)
+    assert usable == 1, tag
+    R, B = configs.rhs(m, 3)
+
+    def solve(env, tol):
+        for k in ("ELPH_NO_WG", "ELPH_WG_T", "ELPH_WG_NO_DPP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m.solver.tol = tol
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B)
+        assert not fl.any()
+        return X, it
+
+    Xs, its = solve({"ELPH_NO_WG": "1"}, 1e-5)
+    variants = [{}, {"ELPH_WG_T": "1"}]
+    if tag == "C":
+        variants += [{"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
+    for env in variants:
+        Xw, itw = solve(env, 1e-5)
+        assert np.max(np.abs(itw - its)) <= 1, (tag, env, itw, its)
+        assert rel(Xw, Xs) < 5e-5, (tag, env)
+    Xs13, _ = solve({"ELPH_NO_WG": "1"}, 1e-13)
+    for env in variants:
+        Xw13, _ = solve(env, 1e-13)
+        assert rel(Xw13, Xs13) < 1e-11, (tag, env, rel(Xw13, Xs13))
+    m.close()
+
+
+def test_wg_resident_cg_with_more_teams_than_the_chip_holds():
+    """40 right-hand sides of config C = 400 workgroups for 256 CUs: teams at the dispatch frontier wait for their members; every
+    solution equals the single solve of that right-hand side bit for bit."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("C", tol=1e-5)
+    assert _wg_info(m)[0] == 1
+    nrhs = 40
+    R, B = configs.rhs(m, nrhs)
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    assert not fl.any() and (res < 1e-4).all()
+    for i in (0, 7, 25, 26, 39):
+        x = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
+        assert it1 == it[i] and np.array_equal(x, X[i]), i
+    m.close()
+
+
+def test_wg_resident_cg_maxiter_history_and_initial_guess(oracle):
+    """Stop rule details through the resident kernel: maxiter exhaustion (flag 1), eps history, non-zero initial guess."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("B", tol=1e-8)
+    assert _wg_info(m)[0] == 1
+    om = _oracle_model(oracle, m)
+    R, B = configs.rhs(m, 1)
+    b = np.ascontiguousarray(B[0])
+    x = 0.1 * R[0].copy()
+    it, hist = models.solve_(x, m, b, tol=1e-8, history=True)
+    xo, ito, histo = oracle.cg_solve(om, b, tol=1e-8, maxiter=10000, history=True, x0=0.1 * R[0])
+    assert abs(it - ito) <= 1 and rel(x, xo) < 1e-7
+    n = min(41, it // 4 + 1)
+    assert np.max(np.abs(hist[:n] - histo[:n]) / histo[:n]) < 1e-10
+    x = np.zeros(m.Ndim)
+    it2 = models.solve_(x, m, b, tol=1e-30, maxiter=17)
+    assert it2 == 17
+    m.close()
