@@ -72,6 +72,7 @@ def parse():
                          "(strong scaling; latency-bound at these sizes, reported for completeness)")
     ap.add_argument("--config", default="C", help="BASELINE config tag (C = Holstein square L=16 Ltau=160)")
     ap.add_argument("--precond", action="store_true", help="KPM (tau-FFT) preconditioned CG iteration")
+    ap.add_argument("--streaming", action="store_true", help="time the two-kernel (HBM-streaming) iteration instead of the workgroup-resident kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary nrhs sweep")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -113,7 +114,14 @@ def main():
             Xc = np.stack([m.x * (0.6 + 0.8 * c / nchains) * (1.0 + 0.2 * synth.randn(comm.chain_seed(synth.SEED_FIELDS) + 17 * c, m.Ndof))
                            for c in range(nchains)])
         models.update_model_chains_(m, Xc)
-    what = 3 if args.precond else 1
+    # un-preconditioned solves run as the workgroup-resident kernel (cg_wg.hip: the whole solve in one launch) wherever it applies —
+    # that is what elph_ldiv / elph_cg_solve launch — so that is what the headline times: K iterations of every right-hand side of
+    # the batch = ONE launch (what = 9).  --streaming times the two-kernel iteration instead (the form used for preconditioned
+    # solves and for lattices the resident kernel does not take), one pair of launches per step.
+    wg_us, wg_T, wg_W, wg_G = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(lib.elph_bench_wg_info(m._h, C.byref(wg_us), C.byref(wg_T), C.byref(wg_W), C.byref(wg_G)))
+    resident = bool(wg_us.value) and not args.precond and not args.streaming
+    what = 3 if args.precond else (9 if resident else 1)
     P = None
     if args.precond:      # one KPM expansion per chain (its own Ē, spectrum bounds, orders and coefficients)
         P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
@@ -131,10 +139,11 @@ def main():
     K = max(1, args.steps)                   # exactly the K and W asked for (every step is its own pair of launches)
     W = max(0, args.warmup)
 
-    check(lib.elph_bench_prepare(m._h, what, nrhs, _lib.dptr(Bc)))
+    prep = 1 if what == 9 else what
+    check(lib.elph_bench_prepare(m._h, prep, nrhs, _lib.dptr(Bc)))
     if W:
         run(what, nrhs, W)                   # warm-up
-    check(lib.elph_bench_prepare(m._h, what, nrhs, None))
+    check(lib.elph_bench_prepare(m._h, prep, nrhs, None))
     ev = {}
 
     def run_steps(k):
@@ -170,6 +179,8 @@ def main():
                             f"{nrhs // nchains} solve(s) each (2 = the two pseudofermion solves of one HMC force evaluation), "
                             f"{world} GPU(s) with their own chains",
                 "nrhs": nrhs, "chains_per_gpu": nchains, "ndim": ndim, "preconditioned": bool(args.precond),
+                "form": ("workgroup-resident: K iterations of the whole batch in one launch (k_cg_wg)" if resident else
+                         "two-kernel iteration, one pair of launches per step (k_cg_ap + k_cg_xr%s)" % (" + KPM apply" if args.precond else "")),
                 "parallelism": f"gpus{world}xchains{nchains}",
             },
             "cg_iters_per_sec": nrhs * K * world / elapsed,
@@ -177,8 +188,8 @@ def main():
             "ms_per_step_events": ms_events / K,
         }
 
-        # ---- roofline of the dominant kernel (k_cg_ap), timed alone with HIP events on its stream
-        reps = 2000
+        # ---- roofline of the dominant kernel of the STREAMING form (k_cg_ap), timed alone with HIP events on its stream
+        reps = 2000 if not resident else 400
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
         run(4, nrhs, 320, graph=0)
         ms_ap = run(4, nrhs, reps, graph=0) / reps
@@ -228,11 +239,55 @@ def main():
         out["roofline"]["k_cg_xr"] = {"avg_launch_us": ms_xr * 1e3, "bytes_per_launch": built_xr,
                                       "achieved": built_xr / (ms_xr * 1e-3) / 1e9, "frac": built_xr / (ms_xr * 1e-3) / 1e9 / HBM_PEAK_GBS}
         it_bytes = built_ap + built_xr
-        it_GBs = it_bytes * K / (ms_events * 1e-3) / 1e9
+        if resident:
+            check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
+            run(1, nrhs, 40)
+            ms_stream = run(1, nrhs, 400) / 400
+        else:
+            ms_stream = ms_events / K
+        it_GBs = it_bytes / (ms_stream * 1e-3) / 1e9
         out["roofline"]["whole_iteration"] = {
-            "bytes_per_step": it_bytes, "achieved_GBs": it_GBs, "frac": it_GBs / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_step": alg_it, "algorithmic_GBs": alg_it * K / (ms_events * 1e-3) / 1e9,
+            "us_per_step": ms_stream * 1e3, "bytes_per_step": it_bytes, "achieved_GBs": it_GBs, "frac": it_GBs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_step": alg_it, "algorithmic_GBs": alg_it / (ms_stream * 1e-3) / 1e9,
+            "matvecs_per_sec": 2.0 * nrhs / (ms_stream * 1e-3),
         }
+        if resident:
+            # The timed region above is ONE launch of k_cg_wg (K iterations of all right-hand sides).  Its Krylov vectors never leave the
+            # chip: per launch it reads r0, p0, x0 and exp(-dtau V) once and writes x and r once.  HBM is not what bounds it — the two
+            # team meetings per iteration are (profiles/r02/wg_phase_stamps.log) — so the HBM fraction is small BY DESIGN;
+            # the number to hold against the roofline of the streaming form is hbm_streaming_equivalent: what an implementation that
+            # streams the algorithm's vectors per iteration (120 B x Ndim) would have to sustain to match this rate.
+            us_launch = ms_events * 1e3
+            built_wg = 5.0 * vec + tab                        # reads r0, p0, x0 + tables; writes x, r
+            ach_wg = built_wg / (us_launch * 1e-6) / 1e9
+            equiv = alg_it * K / (us_launch * 1e-6) / 1e9
+            stream = out["roofline"]
+            stream["note"] = ("two-kernel streaming form: what preconditioned solves and lattices outside the resident kernel's reach run; "
+                              "timed here at the same batch for comparison")
+            out["roofline_streaming"] = stream
+            wkey = f"k_cg_wg<T={wg_T.value},W={wg_W.value},G={wg_G.value}>|config={args.config}|nrhs={nrhs}|chains={nchains}|iters={K}"
+            wtraffic = None
+            try:
+                went = json.load(open(tpath)).get("kernels", {}).get(wkey)
+                wtraffic = went["hbm_bytes_per_launch"] if went else None
+            except Exception:
+                wtraffic = None
+            out["roofline"] = {
+                "bound": "hbm", "kernel": f"k_cg_wg<T={wg_T.value},W={wg_W.value},G={wg_G.value}>", "traffic_key": wkey,
+                "achieved": ach_wg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_wg / HBM_PEAK_GBS, "traffic": wtraffic,
+                "avg_launch_us": us_launch, "iterations_per_launch": K, "us_per_iteration_of_the_batch": us_launch / K,
+                "bytes_per_launch": built_wg,
+                "bytes_model": "compulsory bytes of the kernel as built: r0, p0, x0 in, x, r out (5 vectors x 8 B x Ndim x nrhs) + "
+                               "exp(-dtau V) once per chain, per LAUNCH of K iterations — the Krylov vectors stay in registers / LDS",
+                "binding_resource": "on-chip latency: two team meetings through L2 per iteration (~1.2 us each) + the checkerboard sweeps; "
+                                    "not HBM (fraction small by design)",
+                "hbm_streaming_equivalent_GBs": equiv,
+                "x_hbm_peak_of_a_streaming_implementation": equiv / HBM_PEAK_GBS,
+                "streaming_form_same_batch": {"us_per_step": ms_stream * 1e3, "matvecs_per_sec": 2.0 * nrhs / (ms_stream * 1e-3),
+                                              "speedup_of_resident": (ms_stream * 1e3) / (us_launch / K)},
+                "teams": {"slices_per_wave": wg_T.value, "waves_per_workgroup": wg_W.value, "workgroups_per_rhs": wg_G.value,
+                          "workgroups_in_grid": 8 * ((nrhs + 7) // 8) * wg_G.value},
+            }
 
         # ---- the preconditioned iteration (BASELINE config C "with tau-FFT FourierAcceleration precond"): every kernel of it
         # timed alone with HIP events, its compulsory bytes, and the matrix-core rate of the two tau-transforms
@@ -300,14 +355,19 @@ def main():
         # ---- secondary: the same step at other batch sizes (short runs)
         if not args.no_sweep:
             sweep = {}
-            for nr in (1, 2, 10, 64, 128, 256):
+            for nr in (1, 2, 10, 24, 64, 128, 256):
                 _, Bs = configs.rhs(m, nr)
-                check(lib.elph_bench_prepare(m._h, what, nr, _lib.dptr(np.ascontiguousarray(Bs))))
-                run(what, nr, 160)
-                check(lib.elph_bench_prepare(m._h, what, nr, None))
-                ms = run(what, nr, 1600)
-                sweep[str(nr)] = {"us_per_step": 1e3 * ms / 1600, "matvecs_per_sec": 2.0 * nr * 1600 / (ms * 1e-3),
-                                  "alg_GBs": ALG_BYTES_PER_ELT["cg_iter"] * ndim * nr * 1600 / (ms * 1e-3) / 1e9}
+                row = {}
+                for form, wh in ((("resident", 9),) if resident else ()) + (("streaming", 3 if args.precond else 1),):
+                    pw = 1 if wh == 9 else wh
+                    check(lib.elph_bench_prepare(m._h, pw, nr, _lib.dptr(np.ascontiguousarray(Bs))))
+                    run(wh, nr, 160)
+                    check(lib.elph_bench_prepare(m._h, pw, nr, None))
+                    ms = run(wh, nr, 1600)
+                    row[form] = {"us_per_step": 1e3 * ms / 1600, "matvecs_per_sec": 2.0 * nr * 1600 / (ms * 1e-3)}
+                best = max(row.values(), key=lambda e: e["matvecs_per_sec"])
+                sweep[str(nr)] = {"us_per_step": best["us_per_step"], "matvecs_per_sec": best["matvecs_per_sec"],
+                                  "alg_GBs": ALG_BYTES_PER_ELT["cg_iter"] * ndim * best["matvecs_per_sec"] / 2.0 / 1e9, **row}
             out["by_nrhs"] = sweep
 
         # ---- secondary: time-to-solution of one ldiv! at tol=1e-5, plain vs KPM-preconditioned (BASELINE config 3)

@@ -56,6 +56,9 @@ def main():
         line = [ln for ln in open(os.path.join(root, "bench_pmc.json")) if ln.startswith("{")][-1]
         bench = json.loads(line)
         rl, cfg = bench["roofline"], bench["config"]
+        wg = None
+        if "roofline_streaming" in bench:          # headline = workgroup-resident kernel: record it too, then the streaming pair
+            wg, rl = rl, bench["roofline_streaming"]
         key, nrhs, ndim = rl["traffic_key"], cfg["nrhs"], cfg["ndim"]
         T = key.split("<T=")[1].split(">")[0] if "<T=" in key else None
 
@@ -86,6 +89,15 @@ def main():
                                     "write_expected": vec, "write_measured": xr["hbm_write_bytes"]},
             "k_cg_xr_hbm_bytes_per_launch": xr["hbm_bytes_per_launch"],
         }
+        if wg is not None:
+            kw = find("k_cg_wg")
+            tj["kernels"][wg["traffic_key"]] = {
+                "rocprof_kernel": kw["kernel"], "hbm_bytes_per_launch": kw["hbm_bytes_per_launch"], "read": kw["hbm_read_bytes_corrected"],
+                "write": kw["hbm_write_bytes"], "dispatches": kw["dispatches"], "nrhs": nrhs, "ndim": ndim,
+                "iterations_per_launch": wg["iterations_per_launch"],
+                "note": "one launch = iterations_per_launch CG iterations of all right-hand sides; the Krylov vectors stay on chip",
+            }
+            print(json.dumps(tj["kernels"][wg["traffic_key"]], indent=1))
         json.dump(tj, open(dst, "w"), indent=1)
         print(json.dumps(tj["kernels"][key], indent=1))
         return
