@@ -274,9 +274,89 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// One solve over several GPUs (slabs of rows of cells along l2, one process per GPU).  The rank's handle lives on
+// its slab = own rows + the ghost rows the fused M^T M needs (the dependency closure of the checkerboard, computed by the
+// caller); the SAME resident kernel runs on it, with three differences:
+//   * the two inner products count own sites only, and a team's records come from the workgroups of ALL ranks: every
+//     workgroup stores its record into every rank's MAILBOX (device memory of that rank, mapped here through hipIpc — a
+//     device-initiated store over xGMI, no collective, no host) and polls its own mailbox; all ranks add the same P G
+//     records in the same order, so alpha, beta and the stop decision are bit-identical everywhere;
+//   * after the residual update every wave stores the values of its slice on the rows its neighbours hold as ghosts into
+//     the neighbour's mailbox (granules: the data is its own flag) and takes its own ghost rows of r from its mailbox
+//     together with the second meeting — ONE exchange of the checkerboard boundary rows per iteration;
+//   * the solve starts from x = 0 inside the kernel (r0 = p0 = b, |b|^2 by a first meeting): no host-side combination.
+// Mailbox (identical layout on every rank): [2 meetings][128 records][2 granules] then ghost rows from below / from above
+// [Ltau][cap_ghost][2 granules] each.  It is zeroed by elph_shard_prepare; the caller's barrier between prepare and solve
+// keeps a fast rank's first stores from being wiped.
+// ------------------------------------------------------------------------------------------------------------------------
+using ShardCtl = ElphShardCtl;                   // elph_internal.h
+constexpr int SH_MAXREC = ELPH_SHARD_MAXREC;                              // P * G records at most
+constexpr size_t SH_REC_WORDS = 2 * (size_t)SH_MAXREC * 2;
+
+__device__ __forceinline__ void st_sys(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64 ld_sys(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64 *sh_ghost(u64 *mail, int region, int L, int cap, int t, int k) {
+    return mail + SH_REC_WORDS + (((size_t)region * L + t) * cap + k) * 2;
+}
+
+// wave 0 of a workgroup: store this workgroup's record of meeting m into every rank's mailbox
+__device__ __forceinline__ void sh_publish(const ShardCtl &Sh, int m, int g, int G, double mine, unsigned epoch, int lane) {
+    if (lane < 2 * Sh.P) {
+        const u64 bits = (u64)__double_as_longlong(mine);
+        const int dest = lane >> 1, half = lane & 1;
+        st_sys(Sh.mail[dest] + ((size_t)m * SH_MAXREC + (size_t)Sh.rank * G + g) * 2 + half,
+               ((u64)epoch << 32) | (half ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+    }
+}
+
+// poll the P G records of meeting m in the own mailbox (wave 0: rec = true) and this lane's ghost granules (gaddr[q] != nullptr);
+// on success `total` = sum of the records in (rank, workgroup) order and gv[q] = the ghost values
+template <int NPL>
+__device__ __forceinline__ bool sh_poll(const ShardCtl &Sh, bool rec, int m, int G, const u64 *const (&gaddr)[NPL], unsigned epoch,
+                                        int lane, const WgCtl &R, double &total, double (&gv)[NPL]) {
+    const int nrec2 = 2 * Sh.P * G;
+    const u64 *rbase = Sh.mail[Sh.rank] + (size_t)m * SH_MAXREC * 2;
+    u64 v[4] = {0, 0, 0, 0}, g0[NPL], g1[NPL];
+    long long t_start = 0;
+    for (int spin = 0;; ++spin) {
+        bool ok = true;
+        if (rec) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) if (lane + 64 * s < nrec2) v[s] = ld_sys(rbase + lane + 64 * s);
+        }
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) if (gaddr[q]) { g0[q] = ld_sys(gaddr[q]); g1[q] = ld_sys(gaddr[q] + 1); }
+        if (rec) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) if (lane + 64 * s < nrec2) ok = ok && (unsigned)(v[s] >> 32) == epoch;
+        }
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) if (gaddr[q]) ok = ok && (unsigned)(g0[q] >> 32) == epoch && (unsigned)(g1[q] >> 32) == epoch;
+        if (__all(ok)) break;
+        if (poll_bail<NPL>(spin, t_start, lane, R)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    total = 0.0;
+    if (rec) {
+        const int nr = Sh.P * G;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int half = (int)(unsigned)v[s];
+            for (int k = 0; k < 32; ++k)
+                if (s * 32 + k < nr) total += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * k + 1), __builtin_amdgcn_readlane(half, 2 * k));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) gv[q] = gaddr[q] ? __hiloint2double((int)(unsigned)g1[q], (int)(unsigned)g0[q]) : 0.0;
+    return true;
+}
+
 // SQ: the DPP form for the uniform 16 x 16 square lattice (NPL = 4, no LDS slabs); otherwise the lane-program form
-template <int NPL, int T, bool SSH, bool UNI, bool SQ>
-__global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
+// SHARD: this launch is one rank's part of a solve over several GPUs (T = 1, lane-program form)
+template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD>
+__global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
+    static_assert(!SHARD || (T == 1 && !SQ), "sharded solves: one slice per wave, lane-program form");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(!SQ || (NPL == 4 && UNI && !SSH), "DPP form: uniform 16 x 16 square lattice");
     constexpr int NE = MC * ((NPL + 1) / 2);
@@ -303,15 +383,16 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
     const CgParams P = B.params;
     CgState *st2 = B.state + 2 * rhs;
     const CgState S = ld_state(st2);
-    if (S.done || S.seq != 0) return;                  // fresh solves only (the host guarantees it)
+    if (!SHARD && (S.done || S.seq != 0)) return;      // fresh solves only (the host guarantees it); a shard seeds its state below
 
     // site of register q of this lane: lane + 64 q (layout S order), or the column segments of the DPP form
     int sc[NPL];
-    bool live[NPL];
+    bool live[NPL], own[NPL];                          // own: the site enters the inner products (a shard counts its own rows only)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = SQ ? ((lane & 15) + 64 * (lane >> 4) + 16 * q) : lane + q * WAVE;
         live[q] = s < N;
+        own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : live[q];
         sc[q] = live[q] ? s : N - 1;
     }
     double *xg = B.x + (size_t)rhs * ndim, *rg = B.r + (size_t)rhs * ndim;
@@ -360,12 +441,45 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
     u64 *bnd = R.bnd + (size_t)rhs * G * 2 * HS * 2;     // [G][first | last slice][HS][2 granules]
     const int gm = (g == 0) ? G - 1 : g - 1, gp = (g == G - 1) ? 0 : g + 1;
     double rho = S.rho, kmin = S.kmin, eps = S.eps;
-    const double eps0 = S.eps0, normb = S.normb;
+    double eps0 = S.eps0, normb = S.normb;
 
     if (threadIdx.x == 0) bc[2] = 1.0;                 // (ordered before its first reader by the barriers of iteration 0)
+    // ghost sites of this lane: where their values arrive in the own mailbox (nullptr: not a ghost site), slice t0
+    const u64 *gaddr[NPL];
+    if constexpr (SHARD) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int s = lane + q * WAVE;
+            gaddr[q] = (s < Sh.own_lo) ? sh_ghost(Sh.mail[Sh.rank], 0, L, Sh.cap_ghost, t0, s)
+                     : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, t0, s - Sh.own_hi) : nullptr;
+        }
+        // x0 = 0, r0 = p0 = b (the host put b into r and p): |b|^2 over the own sites of all ranks seeds the state
+        // (IterativeSolvers.jl:259-274 with x = 0: eps0 = 1, rho0 = |b|^2)
+        double a0 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) if (own[q]) a0 += p[1][q] * p[1][q];
+        a0 = wave_sum_dpp(a0);
+        if (lane == 0) partA[wv] = a0;
+        wg_barrier();
+        if (wv == 0) {
+            const double mine = wg_sum(partA, W, lane);
+            sh_publish(Sh, 0, g, G, mine, 1u, lane);
+            const u64 *none[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) none[q] = nullptr;
+            double tot = 0.0, dummy[NPL];
+            const bool ok = sh_poll<NPL>(Sh, true, 0, G, none, 1u, lane, R, tot, dummy);
+            if (lane == 0) { bc[0] = tot; if (!ok) bc[2] = 0.0; }
+        }
+        wg_barrier();
+        if (bc[2] == 0.0) return;
+        const double bb = bc[0];
+        normb = sqrt(bb); eps0 = 1.0; eps = 1.0; rho = bb; kmin = 0.0;
+        wg_barrier();                                   // bc[0] is rewritten by the first meeting of the loop
+    }
     STAMP_DECL;
     for (long long seq = 0;; ++seq) {
-        const unsigned epoch = (unsigned)seq + 1u;
+        const unsigned epoch = (unsigned)seq + (SHARD ? 2u : 1u);
         STAMP(9);
         // ---- z = M^T M p on the own slices:  w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)]  for t = t0 .. t0+T  (T+1 forward sweeps at once),
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
@@ -427,7 +541,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
 #pragma unroll
         for (int j = 0; j < T; ++j)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) if (live[q]) acc += p[j + 1][q] * z[j][q];
+            for (int q = 0; q < NPL; ++q) if (own[q]) acc += p[j + 1][q] * z[j][q];
         acc = wave_sum_dpp(acc);
         // (x of the own slices lives in LDS)
         STAMP(0);
@@ -438,7 +552,21 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
         if (lane == 0) partA[wv] = acc;
         wg_barrier();
         double pap;
-        if (G == 1) {
+        if constexpr (SHARD) {
+            if (wv == 0) {
+                const double mine = wg_sum(partA, W, lane);
+                sh_publish(Sh, 0, g, G, mine, epoch, lane);
+                const u64 *none[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) none[q] = nullptr;
+                double tot = 0.0, dummy[NPL];
+                const bool ok = sh_poll<NPL>(Sh, true, 0, G, none, epoch, lane, R, tot, dummy);
+                if (lane == 0) { bc[0] = tot; if (!ok) bc[2] = 0.0; }
+            }
+            wg_barrier();
+            if (bc[2] == 0.0) return;
+            pap = bc[0];
+        } else if (G == 1) {
             pap = wg_sum(partA, W, lane);
         } else {
             if (wv == 0) {
@@ -470,10 +598,27 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
             for (int q = 0; q < NPL; ++q) {
                 rn[j][q] = rl[j * HS + lane + q * WAVE] - alpha * z[j][q];                         // :285
                 rl[j * HS + lane + q * WAVE] = rn[j][q];
-                if (live[q]) a += rn[j][q] * rn[j][q];
+                if (own[q]) a += rn[j][q] * rn[j][q];
                 xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];                               // :282
             }
         a = wave_sum_dpp(a);
+        if constexpr (SHARD) {
+            // the rows my neighbours hold as ghosts: straight into their mailboxes (device-initiated stores over xGMI)
+            const int prev = (Sh.rank + Sh.P - 1) % Sh.P, next = (Sh.rank + 1) % Sh.P;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int s = lane + q * WAVE;
+                const u64 bits = (u64)__double_as_longlong(rn[0][q]), tag = (u64)epoch << 32;
+                if (s >= Sh.own_lo && s < Sh.own_lo + Sh.n_to_prev) {              // bottom rows -> previous rank's ghosts above its own rows
+                    u64 *d = sh_ghost(Sh.mail[prev], 1, L, Sh.cap_ghost, t0, s - Sh.own_lo);
+                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                }
+                if (s >= Sh.own_hi - Sh.n_to_next && s < Sh.own_hi) {              // top rows -> next rank's ghosts below its own rows
+                    u64 *d = sh_ghost(Sh.mail[next], 0, L, Sh.cap_ghost, t0, s - (Sh.own_hi - Sh.n_to_next));
+                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                }
+            }
+        }
         // slices that cross a workgroup boundary travel as granules too ({iteration, half of the f64}: the data is its own flag —
         // no drain here, no flag there; the neighbour polls them together with the r.r records)
         if (G > 1) {
@@ -492,7 +637,38 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R) {
         STAMP(4);
         // ---- meeting 2: r.r and the halo slices of the new r ------------------------------------------------------------------
         double rr, hx[NPL];                                   // hx: the halo slice that comes from another workgroup (waves 0 and W-1)
-        if (G == 1) {
+        if constexpr (SHARD) {
+            // every wave takes the ghost rows of its slice from the mailbox; wave 0 also trades the r.r records of all ranks
+            double tot = 0.0, gv[NPL];
+            if (wv == 0) sh_publish(Sh, 1, g, G, wg_sum(partB, W, lane), epoch, lane);
+            bool ok = sh_poll<NPL>(Sh, wv == 0, 1, G, gaddr, epoch, lane, R, tot, gv);
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) if (gaddr[q]) rl[lane + q * WAVE] = gv[q];
+            if (G > 1 && (wv == 0 || wv == W - 1)) {          // the tau-neighbour workgroup of this rank: its boundary slice (own rows; ghosts follow below)
+                u64 v = 0, gh[NPL][2];
+                const u64 *bh = (wv == 0) ? bnd + (((size_t)gm * 2 + 1) * HS) * 2 : bnd + (((size_t)gp * 2 + 0) * HS) * 2;
+                ok = poll_granules<NPL>(nullptr, G, bh, epoch, lane, R, v, gh) && ok;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) hx[q] = __hiloint2double((int)(unsigned)gh[q][1], (int)(unsigned)gh[q][0]);
+                // ... whose ghost rows are as stale as mine were: the neighbour slice's ghost values come from the mailbox too
+                const int th = (wv == 0) ? wrap(t0 - 1) : wrap(t0 + T);
+                const u64 *ga2[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int s = lane + q * WAVE;
+                    ga2[q] = (s < Sh.own_lo) ? sh_ghost(Sh.mail[Sh.rank], 0, L, Sh.cap_ghost, th, s)
+                           : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, th, s - Sh.own_hi) : nullptr;
+                }
+                double t2 = 0.0, gv2[NPL];
+                ok = sh_poll<NPL>(Sh, false, 1, G, ga2, epoch, lane, R, t2, gv2) && ok;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) if (ga2[q]) hx[q] = gv2[q];
+            }
+            if (lane == 0) { if (wv == 0) bc[1] = tot; if (!ok) bc[2] = 0.0; }
+            wg_barrier();
+            if (bc[2] == 0.0) return;
+            rr = bc[1];
+        } else if (G == 1) {
             rr = wg_sum(partB, W, lane);
         } else {
             if (wv == 0 || wv == W - 1) {
@@ -620,12 +796,21 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, Sh
     return false;
 }
 
-template <int NPL, int T, bool SSH, bool UNI, bool SQ>
-static hipError_t launch_k(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
+template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD = false>
+static hipError_t launch_k(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R,
+                           const ShardCtl &Sh = ShardCtl()) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI, SQ>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R);
+    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R, Sh);
     return hipGetLastError();
+}
+
+template <int NPL>
+static hipError_t launch_shard_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R,
+                                   const ShardCtl &Sh) {
+    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, false, true>(h, sh, grid, B, m, R, Sh);
+    return m.uniform ? launch_k<NPL, 1, false, true, false, true>(h, sh, grid, B, m, R, Sh)
+                     : launch_k<NPL, 1, false, false, false, true>(h, sh, grid, B, m, R, Sh);
 }
 
 template <int NPL>
@@ -727,3 +912,57 @@ extern "C" int elph_debug_wg_stamps(unsigned long long *out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(wg::g_wg_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// One rank's launch of a solve over several GPUs (shard.hip holds the mailbox and calls this).  x0 = 0, b in B.r and B.p.
+int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out) {
+    if (!h->fast_capable || h->lp_mc != 4 || h->npl > 5) {
+        elph_set_error("sharded solve: the slab needs a 4-colour lane program and <= 320 sites (N = %lld)", (long long)h->N);
+        return ELPH_E_UNSUPPORTED;
+    }
+    ModelDev m = elph_model_dev(h);
+    wg::Shape sh;
+    {   // one slice per wave on every rank (slab sizes differ between ranks; the team shape must not)
+        const int L = (int)h->L;
+        int W = 0;
+        for (int w = std::min(8, L); w >= 1; --w) if (L % w == 0) { W = w; break; }
+        const int G = L / W;
+        if (Sh.P * G > ELPH_SHARD_MAXREC || (G > 1 && W < 2)) { elph_set_error("sharded solve: %d ranks x %d workgroups exceed the %d records of a meeting", Sh.P, G, ELPH_SHARD_MAXREC); return ELPH_E_UNSUPPORTED; }
+        const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
+        sh.T = 1; sh.W = W; sh.G = G; sh.sq = false;
+        sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 24) * sizeof(double);
+    }
+    const size_t HS = (size_t)h->npl * WAVE;
+    const size_t n_slots = 2 * 64, n_bnd = (sh.G > 1) ? (size_t)sh.G * 2 * HS * 2 : 0;
+    const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
+    if (need > h->res_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_res) HIPCHK(hipFree(h->d_res));
+        h->d_res = nullptr;
+        HIPCHK(hipMalloc(&h->d_res, need));
+        h->res_cap = need;
+    }
+    wg::WgCtl R;
+    char *base = static_cast<char *>(h->d_res);
+    R.slots = reinterpret_cast<wg::u64 *>(base);
+    R.bnd = R.slots + n_slots;
+    R.abort = reinterpret_cast<int *>(base + (n_slots + n_bnd) * sizeof(wg::u64));
+    R.G = sh.G; R.W = sh.W;
+    const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
+    R.timeout_ticks = (long long)(eto ? atoll(eto) : 20000) * 100000LL;
+    R.fixed_iters = fixed_iters;
+    HIPCHK(hipMemsetAsync(base, 0, (n_slots + n_bnd) * sizeof(wg::u64) + 64, h->stream));
+    const dim3 grid((unsigned)(8 * sh.G));                 // one right-hand side: blocks with blockIdx % 8 == 0 work, the rest leave at once
+    hipError_t e = hipSuccess;
+    switch (h->npl) {
+        case 1: e = wg::launch_shard_npl<1>(h, sh, grid, B, m, R, Sh); break;
+        case 2: e = wg::launch_shard_npl<2>(h, sh, grid, B, m, R, Sh); break;
+        case 3: e = wg::launch_shard_npl<3>(h, sh, grid, B, m, R, Sh); break;
+        case 4: e = wg::launch_shard_npl<4>(h, sh, grid, B, m, R, Sh); break;
+        default: e = wg::launch_shard_npl<5>(h, sh, grid, B, m, R, Sh); break;
+    }
+    if (e != hipSuccess) { elph_set_error("launch k_cg_wg (shard) failed: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+    h->wg_T = sh.T; h->wg_W = sh.W; h->wg_G = sh.G;
+    h->wg_abort_off = (n_slots + n_bnd) * sizeof(wg::u64);
+    if (G_out) *G_out = sh.G;
+    return ELPH_OK;
+}

@@ -342,6 +342,7 @@ extern "C" int elph_destroy(elph_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
+    elph_shard_free(h);
     elph_hmc_free(h);
     elph_greens_free(h);
     delete h->host_pool;

@@ -210,6 +210,7 @@ struct elph_handle_s {
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
+    void *shard = nullptr;                 // ShardState (shard.hip), owned
     void *hmc = nullptr;                   // HmcState (hmc.hip), owned
     void *greens = nullptr;                // GreensState (greens.hip), owned
     void *d_res = nullptr;                 // control block of the workgroup-resident CG (cg_wg.hip): meeting records, abort word, boundary slices
@@ -300,6 +301,7 @@ int elph_i_ensure_capacity(elph_handle_s *h, int nrhs);
 int elph_i_reserve_chains(elph_handle_s *h, int nchains);   // d_E for nchains configurations, h->nchains = nchains
 void elph_i_drop_graphs(elph_handle_s *h);
 void elph_hmc_free(elph_handle_s *h);
+void elph_shard_free(elph_handle_s *h);
 void elph_greens_free(elph_handle_s *h);
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec, int ncols = 0);
 int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec, int ncols = 0);
@@ -336,6 +338,18 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+// ---- one solve over several GPUs (cg_wg.hip, shard.hip): by-value description of this rank's shard for the resident kernel
+#define ELPH_SHARD_MAXREC 128
+#define ELPH_SHARD_MAXRANKS 8
+struct ElphShardCtl {
+    int rank = 0, P = 1;
+    int own_lo = 0, own_hi = 0;       // own sites [own_lo, own_hi) of the slab lattice; [0, own_lo) and [own_hi, N) are ghosts
+    int n_to_prev = 0, n_to_next = 0; // own sites (from the bottom / from the top) that the previous / next rank holds as ghosts
+    int cap_ghost = 0;                // capacity (sites) of a ghost region of the mailbox, the same on all ranks
+    unsigned long long *mail[ELPH_SHARD_MAXRANKS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out);
+
 // ---- workgroup-resident CG (cg_wg.hip): the whole un-preconditioned solve in one launch
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G);
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);

@@ -483,3 +483,101 @@ class SpatialShardedCG:
 
     def close(self):
         self.be.close()
+
+
+# =====================================================================================================================
+# The in-library sharded solve (csrc/shard.hip + the SHARD form of the resident CG kernel, csrc/cg_wg.hip)
+# =====================================================================================================================
+
+class ShardedSolver:
+    """ONE un-preconditioned solve of MᵀM x = b (x0 = 0) over comm.world GPUs, slabs of rows of cells (`SpatialSlabs`), Holstein
+    or bond-phonon (SSH) models.  Everything inside an iteration happens on the devices: the rank's resident CG kernel stores
+    its partial sums and the checkerboard boundary rows of the residual into the neighbours' mailboxes (hipIpc-mapped device
+    memory; xGMI peer stores between GPUs) and polls its own — the host only all-gathers the 64-byte mailbox handles once
+    and provides the barrier between `elph_shard_prepare` and `elph_shard_solve`.  Also runs with several ranks on ONE GPU
+    (the test box), which RCCL refuses.
+
+    kind 0 (Holstein): cosht/sinht per bond, `update_model(expV_global)`;
+    kind 1 (SSH): `update_model_ssh(cosht_global[Nbonds, Ltau], sinht_global, expDtauMu_global)` — the per-(τ, bond) tables are
+    sharded by bond owner: a rank holds the columns of the bonds inside its slab (SSHModels.jl:581-701)."""
+
+    def __init__(self, comm, norbits, L1, L2, ltau, table, kind=0, cosht=None, sinht=None, device=None):
+        from . import _lib
+        self._lib_mod, self.lib = _lib, _lib.load()
+        self.comm, self.P, self.rank = comm, comm.world, comm.rank
+        self.kind, self.Ltau = int(kind), int(ltau)
+        self.slabs = SpatialSlabs(norbits, L1, L2, table, self.P)
+        self.N, self.row = self.slabs.N, self.slabs.row
+        sl = self.sl = self.slabs.slabs[self.rank]
+        self.Nloc = sl["rows"].size * self.row
+        self.own_lo, self.own_n = sl["lo"] * self.row, sl["R"] * self.row
+        self.gsites = self.slabs.global_sites(self.rank)
+        ltab = np.ascontiguousarray(self.slabs.local_table(self.rank, table), dtype=np.int64)
+        self.bonds = sl["bonds"]
+        prev, nxt = (self.rank - 1) % self.P, (self.rank + 1) % self.P
+        sp, sn = self.slabs.slabs[prev], self.slabs.slabs[nxt]
+        if self.P > 1 and (sl["lo"] > sp["R"] or sl["hi"] > sn["R"]):
+            raise ValueError("ghost rows reach beyond the neighbouring rank: use fewer ranks")
+        n_to_next = sn["lo"] * self.row if self.P > 1 else 0         # next rank's ghosts below its own rows = my top rows
+        n_to_prev = sp["hi"] * self.row if self.P > 1 else 0         # previous rank's ghosts above its own rows = my bottom rows
+        cap = max(max(s["lo"], s["hi"]) for s in self.slabs.slabs) * self.row
+        dev = comm.device_index() if device is None else device
+        self.h = _lib.Handle()
+        nb = ltab.shape[0]
+        c = np.ascontiguousarray(np.asarray(cosht)[self.bonds]) if (kind == 0 and nb) else None
+        s = np.ascontiguousarray(np.asarray(sinht)[self.bonds]) if (kind == 0 and nb) else None
+        _lib.check(self.lib.elph_create(C.byref(self.h), self.kind, self.Nloc, self.Ltau, nb, _lib.iptr(ltab) if nb else None,
+                                        _lib.dptr(c) if c is not None else None, _lib.dptr(s) if s is not None else None, dev))
+        hbuf = (C.c_ubyte * 64)()
+        _lib.check(self.lib.elph_shard_create(self.h, self.rank, self.P, self.own_lo, self.own_n, n_to_prev, n_to_next, cap,
+                                              C.cast(hbuf, C.c_void_p)))
+        if self.P > 1:
+            allh = b"".join(comm.allgather_object(bytes(hbuf)))
+            self._allh = C.create_string_buffer(allh, len(allh))
+            _lib.check(self.lib.elph_shard_connect(self.h, C.cast(self._allh, C.c_void_p)))
+        comm.barrier()
+
+    def _local(self, v_global):
+        return np.ascontiguousarray(np.asarray(v_global).reshape(self.N, self.Ltau)[self.gsites, :]).reshape(-1)
+
+    def update_model(self, expV_global):
+        """Holstein: exp(-Δτ V) of the whole lattice, reference layout (update_model!, HolsteinModels.jl:526-549)."""
+        self._lib_mod.check(self.lib.elph_set_expV(self.h, self._lib_mod.dptr(self._local(expV_global))))
+
+    def update_model_ssh(self, cosht_global, sinht_global, expDtauMu_global):
+        """SSH: cosht/sinht[Nbonds, Ltau] in checkerboard order (model.cosht as the reference stores it, transposed to
+        bond-major rows) and exp(Δτ μ)[N]; this rank takes the bonds of its slab."""
+        c = np.ascontiguousarray(np.asarray(cosht_global).reshape(-1, self.Ltau)[self.bonds]).reshape(-1)
+        s = np.ascontiguousarray(np.asarray(sinht_global).reshape(-1, self.Ltau)[self.bonds]).reshape(-1)
+        e = np.ascontiguousarray(np.asarray(expDtauMu_global)[self.gsites])
+        d = self._lib_mod.dptr
+        self._lib_mod.check(self.lib.elph_update_model_ssh(self.h, d(c), d(s), d(e)))
+
+    def solve(self, b_global, tol=1e-5, maxiter=10000, kmax=1e12):
+        """Returns (x_global (N·Ltau,), iterations, done) — identical on every rank."""
+        b = self._local(b_global)
+        x = np.zeros(self.Nloc * self.Ltau)
+        it, done, eps = C.c_int64(), C.c_int(), C.c_double()
+        self._lib_mod.check(self.lib.elph_shard_prepare(self.h))
+        self.comm.barrier()                                  # every mailbox is zero before any rank stores into it
+        self._lib_mod.check(self.lib.elph_shard_solve(self.h, self._lib_mod.dptr(x), self._lib_mod.dptr(b), tol, maxiter, kmax,
+                                                      C.byref(it), C.byref(done), C.byref(eps)))
+        x_own = x.reshape(self.Nloc, self.Ltau)[self.own_lo:self.own_lo + self.own_n, :]
+        parts = self.comm.allgather_object(x_own) if self.P > 1 else [x_own]
+        self.eps = float(eps.value)
+        return np.ascontiguousarray(np.concatenate(parts, axis=0)).reshape(-1), int(it.value), int(done.value)
+
+    def iterate(self, b_global, k):
+        """Exactly k iterations (no stop test); returns this rank's HIP-event time of the launch in ms (bench.py)."""
+        b = self._local(b_global)
+        ms = C.c_double()
+        self._lib_mod.check(self.lib.elph_shard_prepare(self.h))
+        self.comm.barrier()
+        self._lib_mod.check(self.lib.elph_shard_iterate(self.h, self._lib_mod.dptr(b), int(k), C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self.h:
+            self.lib.elph_shard_destroy(self.h)
+            self.lib.elph_destroy(self.h)
+            self.h = None

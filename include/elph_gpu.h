@@ -441,6 +441,38 @@ int elph_fourier_accelerate(elph_handle h, double *vout, const double *vin, cons
 int elph_tau_to_omega(elph_handle h, double *nu_complex, const double *v);
 int elph_omega_to_tau(elph_handle h, double *v, const double *nu_complex);
 
+/* ---------------------------------------------------------------- one solve over several GPUs
+ *
+ * Slabs of rows of cells along the slowest spatial index, one process per GPU, no reference equivalent (the reference is
+ * single-process): solve!(x, A, b, cg) of IterativeSolvers.jl:239-314 with x0 = 0 for ONE fermion matrix whose lattice is
+ * spread over `world` ranks.  The handle lives on the rank's SLAB lattice — [ghost rows from below | own rows | ghost rows
+ * from above], site-contiguous, created with the bonds / exp(-dtau V) / (SSH) per-(tau, bond) tables of that slab; the ghost
+ * rows are the dependency closure of the fused MtM on the own rows (elphdynamics_amd/sharded.py computes it from the bond
+ * table).  Per CG iteration the ranks exchange the two partial inner products and ONE set of checkerboard boundary rows of
+ * the residual, by device-initiated stores into each other's mailbox (hipIpc-mapped device memory: xGMI peer stores between
+ * GPUs) from inside the resident CG kernel — no collective, no host.  Sequence on every rank:
+ *   elph_shard_create   geometry (0-based local site ranges) -> a 64-byte IPC handle of this rank's mailbox
+ *   (caller: all-gather the handles — torch.distributed / MPI)
+ *   elph_shard_connect  map the other ranks' mailboxes
+ *   per solve: elph_shard_prepare (zero the own mailbox) ; caller's BARRIER ; elph_shard_solve
+ * own_lo / own_n: own sites [own_lo, own_lo + own_n) of the slab; n_to_prev / n_to_next: how many own sites (counted from
+ * the bottom / from the top) the previous / next rank of the periodic ring holds as ghosts; cap_ghost: capacity in sites of
+ * a ghost region of the mailbox, the SAME number on all ranks (>= every rank's ghost and send counts).
+ * x_slab / b_slab: host vectors on the slab lattice, reference layout (site-major), b with its ghost entries filled from
+ * the global right-hand side; x_slab's own rows are this rank's part of the solution.
+ * iters / done / eps: identical on all ranks (done: 1 eps < tol, 2 kappa bound, 3 maxiter). */
+#define ELPH_SHARD_IPC_BYTES 64
+int elph_shard_create(elph_handle h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev,
+                      int64_t n_to_next, int64_t cap_ghost, void *ipc_handle_out);
+int elph_shard_connect(elph_handle h, const void *all_ipc_handles /* world * ELPH_SHARD_IPC_BYTES, rank order */);
+int elph_shard_prepare(elph_handle h);
+int elph_shard_solve(elph_handle h, double *x_slab, const double *b_slab, double tol, int64_t maxiter, double kappa_max,
+                     int64_t *iters, int *done, double *eps);
+/* measurement: exactly `iters` iterations (no stop test); *ms = HIP-event time of this rank's launch. b_slab may be NULL
+ * (keeps the right-hand side of the previous call).  Needs elph_shard_prepare + barrier like a solve. */
+int elph_shard_iterate(elph_handle h, const double *b_slab, int64_t iters, double *ms);
+int elph_shard_destroy(elph_handle h);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */
 
 /* Measurement of one hot-path unit with inputs resident in HBM (no host traffic in the timed region).

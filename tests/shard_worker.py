@@ -1,0 +1,65 @@
+"""Worker of the in-library sharded-solve tests (one process per rank, all on device 0; gloo carries the mailbox handles, the
+barriers and the final gather — the iterations run entirely on the GPU, csrc/shard.hip).
+
+usage: shard_worker.py <case> <out prefix>      case in {sq8, hc4, e8, C, D, E}
+Every rank writes <out>.rank<r>.npz with the assembled solution and the inputs the test needs to check it."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+from elphdynamics_amd import dist, sharded, synth  # noqa: E402
+from elphdynamics_amd import lattice as lat  # noqa: E402
+
+CASES = {
+    # tag: (kind, norbits, Lspatial, bonds, Ltau, dtau)
+    "sq8": (0, 1, 8, lat.SQUARE_BONDS, 8, 0.1),
+    "hc4": (0, 2, 4, lat.HONEYCOMB_BONDS, 6, 0.1),
+    "C": (0, 1, 16, lat.SQUARE_BONDS, 160, 0.1),            # BASELINE config C
+    "D": (0, 2, 12, lat.HONEYCOMB_BONDS, 120, 0.1),         # BASELINE config D: uneven slabs for 4 ranks? 12 rows / 4 = 3
+    "e8": (1, 1, 8, lat.SQUARE_BONDS, 20, 0.05),
+    "E": (1, 1, 16, lat.SQUARE_BONDS, 160, 0.05),           # BASELINE config E (optical SSH)
+}
+
+
+def main():
+    case, out = sys.argv[1], sys.argv[2]
+    tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-9
+    comm = dist.Comm(backend="gloo")
+    kind, norb, Ls, bonds, Ltau, dtau = CASES[case]
+    la = lat.Lattice(norb, Ls, Ls, 1)
+    raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+    N, nb = la.nsites, raw.shape[0]
+    tvals = 1.0 + (0.1 * synth.randn(5, nb) if case in ("sq8", "hc4") else 0.0)      # small cases: every bond distinguishable
+    cb = lat.initialize_checkerboard(raw, tvals * np.ones(nb), dtau)
+    b = synth.randn(321, N * Ltau)
+    res = dict(N=N, Ltau=Ltau, kind=kind, table=cb["table"], b=b)
+    solver = sharded.ShardedSolver(comm, norb, Ls, Ls, Ltau, cb["table"], kind=kind, cosht=cb["cosht"], sinht=cb["sinht"], device=0)
+    if kind == 0:
+        x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
+        E = np.exp(-dtau * x)
+        solver.update_model(E)
+        res.update(E=E, c=cb["cosht"], s=cb["sinht"])
+    else:
+        # bond phonons on every bond: t' = t - alpha x, cosh / sinh(dtau t') per (bond, tau) (SSHModels.jl:510-562), mu = 0.1
+        xb = 0.25 * synth.phonon_field(nb, Ltau, Ltau * dtau, dtau, omega=0.1, lam=0.0, seed=77).reshape(nb, Ltau)
+        tp = 1.0 - 0.1 * xb
+        c, s = np.cosh(dtau * tp), np.sinh(dtau * tp)
+        emu = np.exp(dtau * (0.1 + 0.01 * synth.randn(9, N)))
+        solver.update_model_ssh(c, s, emu)
+        res.update(E=emu, c=c, s=s)
+    xs, it, done = solver.solve(b, tol=tol, maxiter=20000)
+    res.update(x=xs, it=it, done=done, eps=solver.eps, halo=np.array([solver.sl["lo"], solver.sl["hi"]]), rows=np.array([s_["R"] for s_ in solver.slabs.slabs]))
+    # a second solve on the same handle (mailbox re-zeroed, new barrier): same bits
+    xs2, it2, done2 = solver.solve(b, tol=tol, maxiter=20000)
+    res.update(x2=xs2, it2=it2)
+    solver.close()
+    np.savez(out + f".rank{comm.rank}", **res)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()
