@@ -499,46 +499,68 @@ def main():
 
 
 def main_sharded(args, comm):
-    """ONE config solve sharded over the ranks (elphdynamics_amd/sharded.py): step = one CG iteration."""
+    """ONE config solve sharded over the ranks: step = one CG iteration of that solve.
+    --mode spatial: the in-library path (csrc/shard.hip: resident CG kernel per rank, device-initiated mailbox stores, no
+    collective in the iteration); --mode sharded: tau-slabs through the step-wise API + torch.distributed (round-1 harness)."""
     import numpy as np
-    if comm.world == 1:
-        import torch                      # noqa: F401  (first, so that libelphgpu shares torch's HIP runtime)
     from elphdynamics_amd import configs, lattice as lat, sharded, synth
     kind, norb, Ls, bonds, beta, dtau = configs.CONFIGS[args.config]
-    assert kind == "holstein", "sharded mode: Holstein models"
     la = lat.Lattice(norb, Ls, Ls if Ls > 1 else 1, 1)
     raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
     cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), dtau)
     N, Ltau = la.nsites, lat.ltau_from_beta(beta, dtau)
-    x = synth.phonon_field(N, Ltau, beta, dtau)
-    E = np.exp(-dtau * x)                                     # lambda = 1, mu = 0 (configs.py)
     b = synth.rhs(N * Ltau)
     spatial = args.mode == "spatial"
-    if spatial:
-        s = sharded.SpatialShardedCG(comm, norb, la.L1, la.L2, Ltau, cb["table"], cb["cosht"], cb["sinht"])
-    else:
-        s = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"])
-    s.update_model(E)
     K, W = args.steps, args.warmup
-    s.prepare(b)
-    s.run_iterations(W)
-    s.prepare(b)
-    comm.barrier()
-    t0 = time.perf_counter()
-    s.run_iterations(K)
-    comm.barrier()
-    elapsed = comm.max(time.perf_counter() - t0)
+    if spatial:
+        s = sharded.ShardedSolver(comm, norb, la.L1, la.L2, Ltau, cb["table"], kind=0 if kind == "holstein" else 1,
+                                  cosht=cb["cosht"], sinht=cb["sinht"])
+        if kind == "holstein":
+            s.update_model(np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)))        # lambda = 1, mu = 0 (configs.py)
+        else:
+            nb = raw.shape[0]
+            xb = 0.25 * synth.phonon_field(nb, Ltau, beta, dtau, omega=0.1, lam=0.0).reshape(nb, Ltau)
+            tp = 1.0 - 0.1 * xb
+            s.update_model_ssh(np.cosh(dtau * tp), np.sinh(dtau * tp), np.ones(N))
+        if W:
+            s.iterate(b, W)
+        comm.barrier()
+        t0 = time.perf_counter()
+        ms_dev = s.iterate(b, K)                   # returns when this rank's launch has finished (includes prepare + barrier)
+        comm.barrier()
+        elapsed = comm.max(time.perf_counter() - t0)
+        ms_dev = comm.max(ms_dev)
+        descr = (f"slabs of rows of cells (+{s.sl['lo']}/{s.sl['hi']} ghost rows; {s.Nloc} of {N} sites on rank 0) over {comm.world} "
+                 f"rank(s), resident CG kernel per rank, partial sums and boundary rows by device-initiated stores into hipIpc-mapped "
+                 f"mailboxes (no collective, no host in the iteration)")
+        par = f"row_slabs{comm.world}"
+    else:
+        assert kind == "holstein", "tau-slab harness: Holstein models"
+        import torch                      # noqa: F401  (first, so that libelphgpu shares torch's HIP runtime)
+        s = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"])
+        s.update_model(np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)))
+        s.prepare(b)
+        s.run_iterations(W)
+        s.prepare(b)
+        comm.barrier()
+        t0 = time.perf_counter()
+        s.run_iterations(K)
+        comm.barrier()
+        elapsed = comm.max(time.perf_counter() - t0)
+        ms_dev = None
+        descr = (f"tau-slabs over {comm.world} GPU(s), step-wise API, 1 r-halo exchange + 2 partial-sum all-gathers per iteration "
+                 f"({'RCCL, device-resident' if s.dev is not None else 'host-staged'})")
+        par = f"tau_slabs{comm.world}"
     if comm.rank == 0:
-        print(json.dumps({
-            "metric": "cg_matvecs_per_sec", "value": 2.0 * K / elapsed, "unit": "matvec/s", "n_gpus": comm.world, "steps": K,
-            "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config {args.config}: ONE un-preconditioned CG solve (N={N}, Ltau={Ltau}), "
-                                   + (f"slabs of rows of cells (+{s.sl['lo']}/{s.sl['hi']} ghost rows) " if spatial else "tau-slabs ")
-                                   + f"over {comm.world} GPU(s), 1 r-halo exchange + 2 partial-sum all-gathers per iteration "
-                                   f"({'RCCL, device-resident' if s.dev is not None else 'host-staged'})",
-                       "parallelism": f"{'row_slabs' if spatial else 'tau_slabs'}{comm.world}"},
-            "cg_iters_per_sec": K / elapsed}))
+        out = {"metric": "cg_matvecs_per_sec", "value": 2.0 * K / elapsed, "unit": "matvec/s", "n_gpus": comm.world, "steps": K,
+               "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"BASELINE config {args.config}: ONE un-preconditioned CG solve (N={N}, Ltau={Ltau}), " + descr,
+                          "parallelism": par},
+               "cg_iters_per_sec": K / elapsed}
+        if ms_dev is not None:
+            out["us_per_iteration_device"] = 1e3 * ms_dev / K
+        print(json.dumps(out))
     s.close()
     comm.close()
 

@@ -89,9 +89,25 @@ def test_sharded_solve_baseline_configs(tmp_path, oracle, case, world):
 
 
 def test_sharded_solve_one_rank_equals_the_unsharded_handle(tmp_path):
-    """world = 1: the SHARD form of the kernel (x0 = 0 seeded in-kernel, records through the mailbox) against elph_ldiv on the same
-    lattice."""
-    from elphdynamics_amd import configs, models
-    res = _run("sq8", tmp_path, 1, tol=1e-9)
-    a = res[0]
+    """world = 1: the SHARD form of the kernel (x0 = 0 seeded in-kernel, records through the mailbox) against elph_ldiv of an ordinary
+    handle on the same lattice: same iteration count, solutions equal to the solver tolerance."""
+    import ctypes as C
+    from elphdynamics_amd import _lib
+    lib = _lib.load()
+    a = _run("sq8", tmp_path, 1, tol=1e-9)[0]
     assert int(a["done"]) == 1
+    N, L = int(a["N"]), int(a["Ltau"])
+    h = _lib.Handle()
+    tab = np.ascontiguousarray(a["table"], dtype=np.int64)
+    _lib.check(lib.elph_create(C.byref(h), 0, N, L, tab.shape[0], _lib.iptr(tab), _lib.dptr(np.ascontiguousarray(a["c"])),
+                               _lib.dptr(np.ascontiguousarray(a["s"])), 0))
+    try:
+        _lib.check(lib.elph_set_expV(h, _lib.dptr(np.ascontiguousarray(a["E"]))))
+        _lib.check(lib.elph_solver_set(h, 1e-9, 20000, 1e12))
+        x = np.zeros(N * L)
+        it, fl, res = C.c_int64(), C.c_int(), C.c_double()
+        _lib.check(lib.elph_ldiv(h, _lib.dptr(x), _lib.dptr(np.ascontiguousarray(a["b"])), 0, 0, C.byref(it), C.byref(res), C.byref(fl)))
+        assert fl.value == 0 and abs(it.value - int(a["it"])) <= 1
+        assert np.linalg.norm(x - a["x"]) / np.linalg.norm(x) < 1e-7
+    finally:
+        lib.elph_destroy(h)

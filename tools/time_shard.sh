@@ -1,0 +1,14 @@
+#!/bin/bash
+# per-iteration time of the in-library sharded solve with 1, 2 and 4 ranks SHARING the box's one GPU (rehearsal: the device code
+# is the one that runs between GPUs; the numbers say what the protocol costs, not what xGMI adds)
+set -euo pipefail
+cd "$(dirname "$0")/.."
+for cfg in C D E; do
+  for n in 1 2 4; do
+    if [ "$n" = 1 ]; then
+      ELPH_FORCE_DEVICE=0 python3 bench.py --mode spatial --config $cfg --steps 2000 --warmup 200
+    else
+      ELPH_FORCE_DEVICE=0 ELPH_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) bench.py --mode spatial --config $cfg --gpus $n --steps 2000 --warmup 200 2>/dev/null
+    fi
+  done
+done
