@@ -60,8 +60,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=400)
-    ap.add_argument("--nrhs", type=int, default=256, help="right-hand sides advanced per step (batch)")
-    ap.add_argument("--chains", type=int, default=128,
+    ap.add_argument("--nrhs", type=int, default=288, help="right-hand sides advanced per step (batch)")
+    ap.add_argument("--chains", type=int, default=144,
                     help="independent phonon configurations (Markov chains) per GPU sharing the batch: right-hand side r "
                          "uses the fermion matrix of chain r %% chains (nrhs = 2*chains = both pseudofermion solves of one "
                          "HMC force evaluation per chain); 1 = all right-hand sides on one matrix")
@@ -119,7 +119,7 @@ def main():
     # the batch = ONE launch (what = 9).  --streaming times the two-kernel iteration instead (the form used for preconditioned
     # solves and for lattices the resident kernel does not take), one pair of launches per step.
     wg_us, wg_T, wg_W, wg_G = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    check(lib.elph_bench_wg_info(m._h, C.byref(wg_us), C.byref(wg_T), C.byref(wg_W), C.byref(wg_G)))
+    check(lib.elph_bench_wg_info(m._h, nrhs, C.byref(wg_us), C.byref(wg_T), C.byref(wg_W), C.byref(wg_G)))
     resident = bool(wg_us.value) and not args.precond and not args.streaming
     what = 3 if args.precond else (9 if resident else 1)
     P = None

@@ -31,6 +31,7 @@
 namespace wg {
 
 constexpr int MC = 4;                       // colours of the lane program (square / honeycomb / chain lattices)
+#define ELPH_WG_T4_MIN_RHS 48
 typedef unsigned long long u64;
 
 template <int NPL>
@@ -148,6 +149,9 @@ __device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx &X) {
                 v[n][0] = c * v[n][0] + s * t0; v[n][3] = c * v[n][3] + s * t3;
                 v[n][1] = n1; v[n][2] = n2;
             }
+            // keep the scheduler from hoisting every slab's cross-lane moves to the front (their temporaries would all be live at
+            // once: measured as spills with five slabs in flight); two slabs interleave, which is all the DPP latency needs
+            if (NS > 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -364,6 +368,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     constexpr int NSLAB = SQ ? 0 : T + 1;              // LDS slabs per wave (lane-program form)
     constexpr int NT = SSH ? T + 1 : 1;                // hopping-table sets (SSH: one per slice t0 .. t0+T)
     constexpr int NEJ = SSH ? 1 : T + 1;               // exp(-dtau V) slices (SSH: exp(dtau mu), per site only)
+    // where the loop-invariant and the update-only vectors live.  4 slices per wave (DPP form, throughput shape): exp(-dtau V) moves
+    // to LDS (read twice per iteration; 40 registers) and x stays in registers instead (LDS is full); otherwise E in registers
+    // (0.35 us per iteration faster at 2 slices per wave), x and r in LDS
+    constexpr bool E_LDS = SQ && T >= 4, X_REG = SQ && T >= 4;
     const int W = R.W, G = R.G;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -376,8 +384,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     double *slab = lds + (size_t)wv * NSLAB * SL;
     double *rall = lds + (size_t)W * NSLAB * SL;       // [W][T][HS]: r of every wave's slices — neighbours read their halo slices here
     double *rl = rall + (size_t)wv * T * HS;
-    double *xl = rall + (size_t)W * T * HS + (size_t)wv * T * HS;      // [W][T][HS]: this wave's slices of x
-    double *partA = rall + 2 * (size_t)W * T * HS, *partB = partA + 8, *bc = partA + 16;     // bc: p.z total, r.r total, 0.0 = a poller gave up
+    double *xl = rall + (size_t)W * T * HS + (size_t)wv * T * HS;      // [W][T][HS]: this wave's slices of x (unless X_REG)
+    double *eall = rall + (size_t)(X_REG ? 1 : 2) * W * T * HS;        // [W][T+1][HS]: exp(-dtau V) of slices t0 .. t0+T (E_LDS)
+    double *el = eall + (size_t)wv * (T + 1) * HS;
+    double *partA = eall + (E_LDS ? (size_t)W * (T + 1) * HS : 0), *partB = partA + 8, *bc = partA + 16;   // bc: p.z total, r.r total, 0.0 = a poller gave up
     auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
     auto sgn = [](int t) { return (t == 0) ? -1.0 : 1.0; };
     const CgParams P = B.params;
@@ -402,13 +412,14 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // x and r live in this wave's LDS (lane-linear, conflict-free): both are only touched by the two vector updates, never by the
     // mat-vec — no register across the mat-vec, no vector-memory traffic inside the loop that a meeting's poll would wait behind,
     // and the neighbouring waves read their halo slices of r straight from here
-    double z[T][NPL], p[T + 2][NPL], E[NEJ][NPL];
+    double zw[T + 1][NPL], p[T + 2][NPL], E[E_LDS ? 1 : NEJ][NPL], xr[X_REG ? T : 1][NPL];
 #pragma unroll
     for (int j = 0; j < T; ++j)
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             rl[j * HS + lane + q * WAVE] = rg[(size_t)(t0 + j) * N + sc[q]];
-            xl[j * HS + lane + q * WAVE] = xg[(size_t)(t0 + j) * N + sc[q]];
+            if (X_REG) xr[X_REG ? j : 0][q] = xg[(size_t)(t0 + j) * N + sc[q]];
+            else xl[j * HS + lane + q * WAVE] = xg[(size_t)(t0 + j) * N + sc[q]];
         }
 #pragma unroll
     for (int j = 0; j < T + 2; ++j)
@@ -417,7 +428,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
     for (int j = 0; j < NEJ; ++j)
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) E[j][q] = Ech[(size_t)wrap(t0 + j) * m.E_tau_stride + sc[q]];
+        for (int q = 0; q < NPL; ++q) {
+            const double ev = Ech[(size_t)wrap(t0 + j) * m.E_tau_stride + sc[q]];
+            if (E_LDS) el[j * HS + lane + q * WAVE] = ev;
+            else E[E_LDS ? 0 : j][q] = ev;
+        }
     unsigned ij[NE];
     Tab<NE, UNI> tab[NT];
     SqCtx X;
@@ -435,7 +450,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             load_tab<NE, UNI>(tab[0], m.lp_c, m.lp_s, lane, m);
         }
     }
-#define EXPV(j) E[SSH ? 0 : (j)]
+#define EXPV(j, q) (E_LDS ? el[(j) * HS + lane + (q) * WAVE] : E[(SSH || E_LDS) ? 0 : (j)][q])
 
     u64 *slotsA = R.slots + (size_t)rhs * 2 * 64, *slotsB = slotsA + 64;
     u64 *bnd = R.bnd + (size_t)rhs * G * 2 * HS * 2;     // [G][first | last slice][HS][2 granules]
@@ -483,37 +498,41 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         STAMP(9);
         // ---- z = M^T M p on the own slices:  w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)]  for t = t0 .. t0+T  (T+1 forward sweeps at once),
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
-        double w[T + 1][NPL];
+        // (w and z share registers: z(t0+j) overwrites w(t0+j) once the reverse sweep of w(t0+j+1) has been taken)
+        double (&w)[T + 1][NPL] = zw;
         if constexpr (SQ) {
-            double f[T + 1][4];
 #pragma unroll
             for (int k = 0; k <= T; ++k)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f[k][q] = EXPV(k)[q] * p[k][q];
-            sq_sweepN<T + 1, false>(f, X);
+                for (int q = 0; q < 4; ++q) w[k][q] = EXPV(k, q) * p[k][q];
+            sq_sweepN<T + 1, false>(w, X);
 #pragma unroll
             for (int k = 0; k <= T; ++k) {
                 const double sg = sgn(wrap(t0 + k));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) w[k][q] = p[k + 1][q] - sg * f[k][q];
+                for (int q = 0; q < 4; ++q) w[k][q] = p[k + 1][q] - sg * w[k][q];
             }
-            double gq[T][4];
+            constexpr int RB = (T >= 4) ? 2 : T;             // reverse sweeps per batch (4 slices per wave: two batches, 16 registers less)
 #pragma unroll
-            for (int j = 0; j < T; ++j)
+            for (int j0 = 0; j0 < T; j0 += RB) {
+                double gq[RB][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gq[j][q] = w[j + 1][q];
-            sq_sweepN<T, true>(gq, X);
+                for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                const double sg = sgn(wrap(t0 + j + 1));
+                    for (int q = 0; q < 4; ++q) gq[i][q] = w[j0 + i + 1][q];
+                sq_sweepN<RB, true>(gq, X);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) z[j][q] = w[j][q] - sg * EXPV(j + 1)[q] * gq[j][q];
+                for (int i = 0; i < RB; ++i) {
+                    const double sg = sgn(wrap(t0 + j0 + i + 1));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[j0 + i][q] = w[j0 + i][q] - sg * EXPV(j0 + i + 1, q) * gq[i][q];      // z(t0+j0+i)
+                }
             }
         } else {
 #pragma unroll
             for (int k = 0; k <= T; ++k)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) slab[k * SL + lane + q * WAVE] = EXPV(k)[q] * p[k][q];
+                for (int q = 0; q < NPL; ++q) slab[k * SL + lane + q * WAVE] = EXPV(k, q) * p[k][q];
             WAVE_LDS_ORDER();
             sweepN<NPL, T + 1, false, UNI, NT, SSH ? 1 : 0, 0>(slab, ij, tab, m.ncol);
 #pragma unroll
@@ -533,10 +552,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int j = 0; j < T; ++j) {
                 const double sg = sgn(wrap(t0 + j + 1));
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) z[j][q] = w[j][q] - sg * EXPV(j + 1)[q] * slab[j * SL + lane + q * WAVE];
+                for (int q = 0; q < NPL; ++q) w[j][q] = w[j][q] - sg * EXPV(j + 1, q) * slab[j * SL + lane + q * WAVE];       // z(t0+j)
             }
             WAVE_LDS_ORDER();
         }
+        double (&z)[T + 1][NPL] = zw;                         // rows 0 .. T-1
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < T; ++j)
@@ -599,7 +619,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 rn[j][q] = rl[j * HS + lane + q * WAVE] - alpha * z[j][q];                         // :285
                 rl[j * HS + lane + q * WAVE] = rn[j][q];
                 if (own[q]) a += rn[j][q] * rn[j][q];
-                xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];                               // :282
+                if (X_REG) xr[X_REG ? j : 0][q] += alpha * p[j + 1][q];                            // :282
+                else xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];
             }
         a = wave_sum_dpp(a);
         if constexpr (SHARD) {
@@ -724,7 +745,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 for (int q = 0; q < NPL; ++q)
                     if (live[q]) {
                         rg[(size_t)(t0 + j) * N + sc[q]] = rl[j * HS + lane + q * WAVE];
-                        xg[(size_t)(t0 + j) * N + sc[q]] = xl[j * HS + lane + q * WAVE];
+                        xg[(size_t)(t0 + j) * N + sc[q]] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HS + lane + q * WAVE];
                     }
             if (g == 0 && wv == 0 && lane == 0) {
                 CgState o = S;
@@ -769,16 +790,17 @@ static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
     return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 2 && h->N == 256 && m.uniform && !(e && e[0] == '1');
 }
 
-// T slices per wave: as many as the register file takes without spilling at two waves per SIMD (DPP form 4, lane-program form 2
-// for site phonons with <= 4 sites per lane, else 1); W = the largest divisor of Ltau / T that is <= 8 waves; G = workgroups per
+// T slices per wave: what the register file takes at two waves per SIMD — lane-program form 2 for site phonons with <= 4 sites
+// per lane, else 1; DPP form 2 (6.5 us per iteration, 24 right-hand sides fill the chip), or 4 for batches of
+// ELPH_WG_T4_MIN_RHS right-hand sides and more (8.5 us per iteration, but 48 right-hand sides per round: 10.5 vs 6.5 M mat-vecs/s); W = the largest divisor of Ltau / T that is <= 8 waves; G = workgroups per
 // right-hand side (<= 32: the 2G record granules of a meeting are polled by one wave instruction)
-static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, Shape *out) {
+static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, int nrhs, Shape *out) {
     const int L = (int)h->L;
     const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m);
     const int cand[3] = {4, 2, 1};
     for (int T : cand) {
         if (forceT && T != forceT) continue;
-        if (T == 4 && (!sq || forceT != 4)) continue;       // (4 slices per wave spill at 256 registers: experiments only)
+        if (T == 4 && (!sq || (forceT != 4 && nrhs < ELPH_WG_T4_MIN_RHS))) continue;
         if (T == 2 && !sq && (ssh || h->npl > 4 || (h->npl == 4 && !m.uniform))) continue;
         if (L % T) continue;
         const int Wt = L / T;
@@ -788,7 +810,8 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, Sh
         if (G > 32) continue;
         if (G > 1 && W < 2) continue;                    // (a wave polls at most ONE neighbouring workgroup's boundary slice)
         const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
-        const size_t shm = ((size_t)W * (sq ? 0 : T + 1) * SL + 2 * (size_t)W * T * HS + 24) * sizeof(double);
+        const size_t shm = ((size_t)W * (sq ? 0 : T + 1) * SL + (size_t)((sq && T >= 4) ? 1 : 2) * W * T * HS +
+                            ((sq && T >= 4) ? (size_t)W * (T + 1) * HS : 0) + 24) * sizeof(double);
         if (shm > 160 * 1024) continue;
         out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq;
         return true;
@@ -832,13 +855,13 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
 }  // namespace wg
 
 // Whether the workgroup-resident kernel can run this handle's un-preconditioned solves (and with which shape).
-bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G) {
+bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs) {
     const char *eo = getenv("ELPH_NO_WG");                 // read per call: the tests switch between the two forms
     const bool off = eo && eo[0] == '1';
     if (off || !h->fast || h->lp_mc != 4 || h->npl > 5 || h->dot_hi != 0 || h->solo_chain >= 0) return false;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
-    if (!wg::pick_shape(h, elph_model_dev(h), et ? atoi(et) : 0, &sh)) return false;
+    if (!wg::pick_shape(h, elph_model_dev(h), et ? atoi(et) : 0, nrhs, &sh)) return false;
     if (T) *T = sh.T;
     if (W) *W = sh.W;
     if (G) *G = sh.G;
@@ -851,11 +874,11 @@ bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G) {
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran) {
     *ran = false;
     if (h->wg_broken || B.params.use_prec) return ELPH_OK;
-    if (!elph_wg_usable(h, nullptr, nullptr, nullptr)) return ELPH_OK;
+    if (!elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs)) return ELPH_OK;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
     ModelDev m = elph_model_dev(h);
-    if (!wg::pick_shape(h, m, et ? atoi(et) : 0, &sh)) return ELPH_OK;
+    if (!wg::pick_shape(h, m, et ? atoi(et) : 0, nrhs, &sh)) return ELPH_OK;
     const size_t HS = (size_t)h->npl * WAVE;
     const size_t n_slots = (size_t)nrhs * 2 * 64, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;

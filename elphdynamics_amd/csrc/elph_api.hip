@@ -1588,11 +1588,11 @@ extern "C" int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave) {
     return ELPH_OK;
 }
 
-extern "C" int elph_bench_wg_info(elph_handle h, int *usable, int *T, int *W, int *G) {
+extern "C" int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, int *W, int *G) {
     CHECK_H(h);
-    if (!usable) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (!usable || nrhs < 1) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     int t = 0, w = 0, g = 0;
-    *usable = (!h->wg_broken && elph_wg_usable(h, &t, &w, &g)) ? 1 : 0;
+    *usable = (!h->wg_broken && elph_wg_usable(h, &t, &w, &g, nrhs)) ? 1 : 0;
     if (T) *T = t;
     if (W) *W = w;
     if (G) *G = g;

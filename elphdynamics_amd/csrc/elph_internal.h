@@ -351,7 +351,7 @@ struct ElphShardCtl {
 int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out);
 
 // ---- workgroup-resident CG (cg_wg.hip): the whole un-preconditioned solve in one launch
-bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G);
+bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs = 1);
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream has drained
 CgBufs elph_make_bufs(elph_handle_s *h, int nrhs);

@@ -491,9 +491,9 @@ int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B);
 int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total);
 /* Which k_cg_ap variant a batch of nrhs uses: *slices_per_wave = 1 (k_cg_ap_fast / generic) or T (k_cg_ap_chunk<T>). */
 int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave);
-/* Whether un-preconditioned solves of this handle run as the workgroup-resident kernel (*usable = 1) and its shape:
- * T tau-slices per wavefront, W wavefronts per workgroup, G workgroups per right-hand side. */
-int elph_bench_wg_info(elph_handle h, int *usable, int *T, int *W, int *G);
+/* Whether un-preconditioned solves of a batch of nrhs right-hand sides run as the workgroup-resident kernel (*usable = 1) and
+ * its shape: T tau-slices per wavefront, W wavefronts per workgroup, G workgroups per right-hand side. */
+int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, int *W, int *G);
 
 #ifdef __cplusplus
 }

@@ -1053,7 +1053,7 @@ def test_lds_sync_build_is_bit_identical():
 def _wg_info(m):
     from elphdynamics_amd import _lib
     us, T, W, G = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    _lib.check(_lib.load().elph_bench_wg_info(m._h, C.byref(us), C.byref(T), C.byref(W), C.byref(G)))
+    _lib.check(_lib.load().elph_bench_wg_info(m._h, 1, C.byref(us), C.byref(T), C.byref(W), C.byref(G)))
     return us.value, T.value, W.value, G.value
 
 
@@ -1082,8 +1082,8 @@ def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
 
     Xs, its = solve({"ELPH_NO_WG": "1"}, 1e-5)
     variants = [{}, {"ELPH_WG_T": "1"}]
-    if tag == "C":
-        variants += [{"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
+    if tag == "C":      # 4 slices per wave is the shape of large batches (DPP form only)
+        variants += [{"ELPH_WG_T": "4"}, {"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
     for env in variants:
         Xw, itw = solve(env, 1e-5)
         assert np.max(np.abs(itw - its)) <= 1, (tag, env, itw, its)
@@ -1110,6 +1110,24 @@ def test_wg_resident_cg_with_more_teams_than_the_chip_holds():
         x = np.zeros(m.Ndim)
         it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
         assert it1 == it[i] and np.array_equal(x, X[i]), i
+    m.close()
+
+
+def test_wg_resident_cg_large_batch_shape():
+    """From 48 right-hand sides on the DPP form runs 4 slices per wave (48 right-hand sides per round instead of 24): another
+    summation tree, the same algorithm — iteration counts within 1 of the single solves, solutions equal to the tolerance."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("C", tol=1e-5)
+    nrhs = 50
+    assert _wg_info(m)[1] == 2
+    R, B = configs.rhs(m, nrhs)
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    assert not fl.any() and (res < 1e-4).all()
+    for i in (0, 23, 49):
+        x = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
+        assert abs(it1 - it[i]) <= 1 and rel(X[i], x) < 5e-5, i
     m.close()
 
 
