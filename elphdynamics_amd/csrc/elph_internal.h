@@ -320,6 +320,7 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which /*0 = k_cg_ap, 1
 int elph_launch_residual(elph_handle_s *h, int nrhs);
 int elph_launch_cg_init_only(elph_handle_s *h, int nrhs);
 int elph_launch_cg_state0_only(elph_handle_s *h, int nrhs);
+int elph_launch_cg_init_prec_only(elph_handle_s *h, int nrhs);
 int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nrhs, int cg_mode, int parts = 7);
 int elph_launch_ebar(elph_handle_s *h, int nch = 1);
 int elph_launch_fft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int64_t ncol,

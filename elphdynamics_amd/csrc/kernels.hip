@@ -1401,6 +1401,12 @@ int elph_launch_cg_init_only(elph_handle_s *h, int nrhs) {
     return check_launch("k_cg_init");
 }
 
+int elph_launch_cg_init_prec_only(elph_handle_s *h, int nrhs) {
+    CgBufs B = make_bufs(h, nrhs);
+    hipLaunchKernelGGL(k_cg_init_prec, dim3((unsigned)h->L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, B, (int)h->N, (int)h->L);
+    return check_launch("k_cg_init_prec");
+}
+
 int elph_launch_cg_state0_only(elph_handle_s *h, int nrhs) {
     CgBufs B = make_bufs(h, nrhs);
     const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;

@@ -15,6 +15,7 @@
 // (DESIGN.md §6), and it refuses two ranks on one GPU — the only multi-rank set-up the test box offers.
 
 #include <cstring>
+#include <vector>
 
 #include "elph_internal.h"
 
@@ -25,21 +26,42 @@ struct ShardState {
     void *opened[ELPH_SHARD_MAXRANKS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool connected = false, prepared = false;
     int G = 0;
+    // preconditioned solve (streaming form): global sites of the slab's sites, the spectrum area of the mailbox, scratch
+    int64_t n_global = 0, own_gstart = 0;
+    size_t nu_off = 0, ext_off = 0;           // u64 word offsets into the mailbox: spectrum [Lo2][n_global] complex; records + flags of the streaming form
+    int *d_gsites = nullptr;                  // [N_loc] global site of every slab site
+    int *d_counter = nullptr, *d_abort = nullptr;
+    unsigned epoch = 0;
 };
 
-static size_t mailbox_words(int64_t L, int cap) { return 2 * (size_t)ELPH_SHARD_MAXREC * 2 + 2 * (size_t)L * (size_t)cap * 2; }
+// mailbox layout (u64 words), identical on all ranks:
+//   [2][ELPH_SHARD_MAXREC][2]   records of the resident kernel's two meetings
+//   [2][Ltau][cap][2]           ghost rows from below / from above
+//   [8][8][2] + [8]             streaming form: records of up to 8 named all-sums (one 2-granule record per rank) + spectrum flags
+//   [Lo2][n_global][2]          spectrum nu of the whole lattice (16-byte complex), written by all ranks (KPM apply)
+static size_t mailbox_words(int64_t L, int cap, int64_t n_global, size_t *ext_off, size_t *nu_off) {
+    size_t w = 2 * (size_t)ELPH_SHARD_MAXREC * 2 + 2 * (size_t)L * (size_t)cap * 2;
+    if (ext_off) *ext_off = w;
+    w += 8 * 8 * 2 + 8;
+    if (nu_off) *nu_off = w;
+    w += (size_t)((L + 1) / 2) * (size_t)n_global * 2;
+    return w;
+}
 
 void elph_shard_free(elph_handle_s *h) {
     ShardState *S = static_cast<ShardState *>(h->shard);
     if (!S) return;
     for (int q = 0; q < ELPH_SHARD_MAXRANKS; ++q) if (S->opened[q]) (void)hipIpcCloseMemHandle(S->opened[q]);
     if (S->mail) (void)hipFree(S->mail);
+    if (S->d_gsites) (void)hipFree(S->d_gsites);
+    if (S->d_counter) (void)hipFree(S->d_counter);
     delete S;
     h->shard = nullptr;
 }
 
 extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev,
-                                 int64_t n_to_next, int64_t cap_ghost, void *ipc_handle_out) {
+                                 int64_t n_to_next, int64_t cap_ghost, int64_t n_global, int64_t own_global_start,
+                                 const int64_t *global_sites, void *ipc_handle_out) {
     if (!h) { elph_set_error("null handle"); return ELPH_E_ARG; }
     HIPCHK(hipSetDevice(h->device));
     if (world < 1 || world > ELPH_SHARD_MAXRANKS || rank < 0 || rank >= world) { elph_set_error("bad rank %d of %d (at most %d ranks)", rank, world, ELPH_SHARD_MAXRANKS); return ELPH_E_ARG; }
@@ -57,7 +79,24 @@ extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own
     S->ctl.own_lo = (int)own_lo; S->ctl.own_hi = (int)(own_lo + own_n);
     S->ctl.n_to_prev = (int)n_to_prev; S->ctl.n_to_next = (int)n_to_next;
     S->ctl.cap_ghost = (int)cap_ghost;
-    S->mail_bytes = mailbox_words(h->L, (int)cap_ghost) * sizeof(unsigned long long);
+    if (n_global < 0 || (n_global > 0 && (!global_sites || own_global_start < 0 || own_global_start + own_n > n_global))) {
+        elph_set_error("bad global geometry: %lld sites, own rows start at %lld", (long long)n_global, (long long)own_global_start);
+        return ELPH_E_ARG;
+    }
+    S->n_global = n_global; S->own_gstart = own_global_start;
+    S->mail_bytes = mailbox_words(h->L, (int)cap_ghost, n_global, &S->ext_off, &S->nu_off) * sizeof(unsigned long long);
+    if (n_global > 0) {
+        std::vector<int> gs((size_t)h->N);
+        for (int64_t i = 0; i < h->N; ++i) {
+            if (global_sites[i] < 0 || global_sites[i] >= n_global) { elph_set_error("global_sites[%lld] out of range", (long long)i); return ELPH_E_ARG; }
+            gs[(size_t)i] = (int)global_sites[i];
+        }
+        HIPCHK(hipMalloc((void **)&S->d_gsites, gs.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(S->d_gsites, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void **)&S->d_counter, 64));
+    HIPCHK(hipMemset(S->d_counter, 0, 64));
+    S->d_abort = S->d_counter + 8;
     // uncached, fine-grained: stores from another GPU become visible to this GPU's (system-scope) polls while its kernel runs
     HIPCHK(hipExtMallocWithFlags((void **)&S->mail, S->mail_bytes, hipDeviceMallocUncached));
     HIPCHK(hipMemset(S->mail, 0, S->mail_bytes));
@@ -184,4 +223,246 @@ extern "C" int elph_shard_destroy(elph_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     elph_shard_free(h);
     return ELPH_OK;
+}
+
+// =========================================================================================================================
+// KPM-preconditioned solve under sharding (IterativeSolvers.jl:153-234 with P = SymmetricKPMPreconditioner).
+// Streaming form: the two-kernel iteration of the slab handle (generic family, inner products over the own rows) with the three
+// inner products combined across ranks by a one-wave kernel through the mailbox, and the preconditioner applied as
+//     forward tau-DFT of r on the own sites  ->  every rank stores its columns of the spectrum into EVERY rank's mailbox
+//     (one all-gather by peer stores, 16 B per site and frequency)  ->  Chebyshev recursion on the WHOLE lattice (a second handle on
+//     the full lattice; every rank computes all frequency blocks — the apply is bounded by its longest recursion, which would
+//     sit on one rank under any omega-sharding as well, so the redundant work costs no time and the all-to-all back disappears)
+//     ->  inverse tau-DFT for the slab's own AND ghost sites straight from the full spectrum: P^-1 r arrives on the ghost rows
+//     without an exchange of its own.
+// No ghost-row exchange of r is needed at all in this form (r enters only through own-site quantities).
+// =========================================================================================================================
+
+typedef unsigned long long u64s;
+__device__ __forceinline__ void sst(u64s *p, u64s v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64s sld(const u64s *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// part[0 .. n) -> [sum over ALL ranks, 0, 0, ...]: one wave; the local sum is taken in index order, the ranks' sums in rank order,
+// so every rank holds the same bits.  slot: which of the 8 named all-sums (its records are single-buffered: between two uses of a
+// slot every rank passes another all-sum that needs this rank's record, which it publishes only after it has read this one).
+__global__ void __launch_bounds__(64) k_shard_allsum(double *part, int n, ElphShardCtl Sh, size_t ext_off, int slot, unsigned epoch,
+                                                     int *abort_flag, long long timeout_ticks) {
+    const int lane = threadIdx.x;
+    if (*(volatile int *)abort_flag) return;                 // a peer was given up on earlier in this solve: do not wait again
+    double a = 0.0;
+    for (int i = lane; i < n; i += 64) a += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane < 2 * Sh.P) {
+        const u64s bits = (u64s)__double_as_longlong(a);
+        const int dest = lane >> 1, half = lane & 1;
+        sst(Sh.mail[dest] + ext_off + ((size_t)slot * 8 + Sh.rank) * 2 + half, ((u64s)epoch << 32) | (half ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+    }
+    const u64s *rec = Sh.mail[Sh.rank] + ext_off + (size_t)slot * 8 * 2;
+    u64s v = 0;
+    long long t0 = 0;
+    for (int spin = 0;; ++spin) {
+        bool ok = true;
+        if (lane < 2 * Sh.P) { v = sld(rec + lane); ok = ((unsigned)(v >> 32) == epoch); }
+        if (__all(ok)) break;
+        if ((spin & 31) == 31) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > timeout_ticks) { if (lane == 0) *abort_flag = 1; return; }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const int half = (int)(unsigned)v;
+    double tot = 0.0;
+    for (int q = 0; q < Sh.P; ++q) tot += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * q + 1), __builtin_amdgcn_readlane(half, 2 * q));
+    for (int i = lane; i < n; i += 64) part[i] = (i == 0) ? tot : 0.0;
+}
+
+// nu_slab[w][s] of the own sites -> nu_full[w][global site] in the mailbox of every rank; the block that finishes last raises this
+// rank's flag (epoch) in every mailbox
+__global__ void __launch_bounds__(256) k_shard_push_nu(const double2 *__restrict__ nu_slab, ElphShardCtl Sh, int Lo2, int N_loc,
+                                                       int own_lo, int own_n, int gstart, int n_global, size_t nu_off, size_t ext_off,
+                                                       unsigned epoch, int *counter) {
+    const int w = blockIdx.x;
+    for (int i = threadIdx.x; i < own_n; i += 256) {
+        const double2 v = nu_slab[(size_t)w * N_loc + own_lo + i];
+        const u64s re = (u64s)__double_as_longlong(v.x), im = (u64s)__double_as_longlong(v.y);
+        for (int q = 0; q < Sh.P; ++q) {
+            u64s *d = Sh.mail[q] + nu_off + ((size_t)w * n_global + gstart + i) * 2;
+            sst(d, re); sst(d + 1, im);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains, then the workgroup's barrier, then ONE signal
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < Sh.P; ++q) sst(Sh.mail[q] + ext_off + 8 * 8 * 2 + Sh.rank, (u64s)epoch);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_shard_wait_nu(ElphShardCtl Sh, size_t ext_off, unsigned epoch, int *abort_flag, long long timeout_ticks) {
+    const int lane = threadIdx.x;
+    if (*(volatile int *)abort_flag) return;
+    const u64s *fl = Sh.mail[Sh.rank] + ext_off + 8 * 8 * 2;
+    long long t0 = 0;
+    for (int spin = 0;; ++spin) {
+        bool ok = true;
+        if (lane < Sh.P) ok = (sld(fl + lane) == (u64s)epoch);
+        if (__all(ok)) return;
+        if ((spin & 31) == 31) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > timeout_ticks) { if (lane == 0) *abort_flag = 1; return; }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// full spectrum out of the (uncached) mailbox into the full-lattice handle's working buffer
+__global__ void __launch_bounds__(256) k_shard_copy_nu(double2 *__restrict__ dst, const u64s *__restrict__ src, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    dst[i] = make_double2(__longlong_as_double((long long)sld(src + 2 * i)), __longlong_as_double((long long)sld(src + 2 * i + 1)));
+}
+
+// nu_slab[w][s] = nu_full[w][gsites[s]] for every slab site (own and ghost)
+__global__ void __launch_bounds__(256) k_shard_gather_nu(double2 *__restrict__ nu_slab, const double2 *__restrict__ nu_full,
+                                                         const int *__restrict__ gsites, int Lo2, int N_loc, int n_global) {
+    const int w = blockIdx.x;
+    for (int s = threadIdx.x; s < N_loc; s += 256) nu_slab[(size_t)w * N_loc + s] = nu_full[(size_t)w * n_global + gsites[s]];
+}
+
+// per-slice partial r.z over the own sites -> rz[t] (slots >= L zeroed), the layout k_cg_ap / k_cg_state0 reduce
+__global__ void __launch_bounds__(64) k_shard_rz_own(const double *__restrict__ r, const double *__restrict__ zp, double *__restrict__ rz,
+                                                     int nrz, int N, int L, int lo, int hi) {
+    const int t = blockIdx.x;
+    double a = 0.0;
+    for (int s = lo + threadIdx.x; s < hi; s += 64) a += r[(size_t)t * N + s] * zp[(size_t)t * N + s];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (threadIdx.x == 0) {
+        rz[t] = a;
+        for (int q = L + t; q < nrz; q += L) rz[q] = 0.0;
+    }
+}
+
+static int launch_ok(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { elph_set_error("launch %s failed: %s", what, hipGetErrorString(e)); return ELPH_E_HIP; }
+    return ELPH_OK;
+}
+
+static long long shard_timeout_ticks() {
+    const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
+    return (long long)(eto ? atoll(eto) : 20000) * 100000LL;
+}
+
+static int allsum(elph_handle_s *h, ShardState *S, double *part, int n, int slot) {
+    hipLaunchKernelGGL(k_shard_allsum, dim3(1), dim3(64), 0, h->stream, part, n, S->ctl, S->ext_off, slot, ++S->epoch, S->d_abort,
+                       shard_timeout_ticks());
+    return launch_ok("k_shard_allsum");
+}
+
+// z = P^-1 r on the slab (own + ghost sites) through the full-lattice handle hf; r.z partials (own sites) -> B.rz, combined over ranks
+static int shard_kpm_apply(elph_handle_s *h, elph_handle_s *hf, ShardState *S) {
+    const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+    CgBufs B = elph_make_bufs(h, 1);
+    int rc = elph_dft_fwd_twisted(h, h->d_nu, h->d_r, N, 1, nullptr);
+    if (rc) return rc;
+    const unsigned ep = ++S->epoch;
+    hipLaunchKernelGGL(k_shard_push_nu, dim3((unsigned)Lo2), dim3(256), 0, h->stream, h->d_nu, S->ctl, Lo2, N, S->ctl.own_lo,
+                       S->ctl.own_hi - S->ctl.own_lo, (int)S->own_gstart, (int)S->n_global, S->nu_off, S->ext_off, ep, S->d_counter);
+    if ((rc = launch_ok("k_shard_push_nu"))) return rc;
+    hipLaunchKernelGGL(k_shard_wait_nu, dim3(1), dim3(64), 0, h->stream, S->ctl, S->ext_off, ep, S->d_abort, shard_timeout_ticks());
+    if ((rc = launch_ok("k_shard_wait_nu"))) return rc;
+    const long long nfull = (long long)Lo2 * S->n_global;
+    hipLaunchKernelGGL(k_shard_copy_nu, dim3((unsigned)((nfull + 255) / 256)), dim3(256), 0, h->stream, hf->d_nu, S->mail + S->nu_off, nfull);
+    if ((rc = launch_ok("k_shard_copy_nu"))) return rc;
+    // Chebyshev recursion alone (parts = 2) on the full lattice, in place on hf->d_nu; hf shares this stream.  An inactive expansion
+    // (KPMPreconditioners.jl:475-478) is the identity: the spectrum goes back as it came.
+    if (hf->kpm_active && (rc = elph_launch_kpm_apply(hf, hf->d_zp, hf->d_r, 1, 0, 2))) return rc;
+    hipLaunchKernelGGL(k_shard_gather_nu, dim3((unsigned)Lo2), dim3(256), 0, h->stream, h->d_nu, hf->d_nu, S->d_gsites, Lo2, N, (int)S->n_global);
+    if ((rc = launch_ok("k_shard_gather_nu"))) return rc;
+    if ((rc = elph_dft_inv_twisted(h, h->d_zp, h->d_nu, N, 1, nullptr, nullptr, nullptr, 0))) return rc;
+    hipLaunchKernelGGL(k_shard_rz_own, dim3((unsigned)L), dim3(64), 0, h->stream, h->d_r, h->d_zp, B.rz, B.nrz, N, L, S->ctl.own_lo, S->ctl.own_hi);
+    if ((rc = launch_ok("k_shard_rz_own"))) return rc;
+    return allsum(h, S, B.rz, B.nrz, 2);
+}
+
+// hfull: a handle on the WHOLE lattice with the model set and elph_kpm_setup done (identically on every rank); it is switched to the
+// slab handle's stream for the duration of the call.  Needs elph_shard_prepare + the caller's barrier like every sharded solve.
+extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, double tol, int64_t maxiter,
+                                    double kappa_max, int64_t *iters, int *done, double *eps) {
+    if (!h || !hfull) { elph_set_error("null handle"); return ELPH_E_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    ShardState *S = static_cast<ShardState *>(h->shard);
+    if (!S || !S->prepared) { elph_set_error("elph_shard_prepare (and the caller's barrier) must precede every sharded solve"); return ELPH_E_STATE; }
+    S->prepared = false;
+    if (!x_slab || !b_slab || !(tol >= 0.0) || maxiter < 1) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (S->n_global <= 0 || hfull->N != S->n_global || hfull->L != h->L) { elph_set_error("the full-lattice handle does not match the shard's global geometry"); return ELPH_E_ARG; }
+    if (!hfull->kpm_ready) { elph_set_error("elph_kpm_setup has not been called on the full-lattice handle"); return ELPH_E_STATE; }
+    if (!h->have_E) { elph_set_error("update_model has not been called on this handle"); return ELPH_E_STATE; }
+    int rc;
+    if ((rc = elph_i_ensure_capacity(h, 1)) || (rc = elph_i_ensure_capacity(hfull, 1))) return rc;
+    // inner products over the own rows: the generic kernel family (elph_set_dot_range)
+    if ((rc = elph_set_dot_range(h, S->ctl.own_lo, S->ctl.own_hi))) return rc;
+    hipStream_t saved = hfull->stream;
+    HIPCHK(hipStreamSynchronize(hfull->stream));
+    hfull->stream = h->stream;
+    S->epoch = 0;
+    HIPCHK(hipMemsetAsync(S->d_counter, 0, 64, h->stream));
+    CgParams P;
+    P.tol = tol; P.kmax = (kappa_max > 0.0) ? kappa_max : h->kmax; P.maxiter = maxiter; P.use_prec = 1; P.record_hist = 0; P.hist_stride = 0;
+    h->cur_params = P;
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    auto body = [&]() -> int {
+        int r;
+        HIPCHK(hipMemcpyAsync(h->d_stage_in, b_slab, bytes, hipMemcpyHostToDevice, h->stream));
+        if ((r = elph_launch_r2s(h, h->d_b, h->d_stage_in, 1))) return r;
+        HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_tmp, 0, bytes, h->stream));                      // A x0 = 0
+        if ((r = elph_launch_cg_init_only(h, 1))) return r;                         // r0 = p0 = b, partial r.r and b.b over the own rows
+        CgBufs B = elph_make_bufs(h, 1);
+        const size_t Pst = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
+        if ((r = allsum(h, S, B.rr, (int)h->L, 1))) return r;
+        if ((r = allsum(h, S, h->d_part + 3 * Pst, (int)h->L, 3))) return r;         // b.b
+        if ((r = shard_kpm_apply(h, hfull, S))) return r;                           // z0 = P^-1 r0, rho0 = r0.z0 (IterativeSolvers.jl:182-189)
+        if ((r = elph_launch_cg_init_prec_only(h, 1))) return r;                    // p0 = z0
+        if ((r = elph_launch_cg_state0_only(h, 1))) return r;
+        const int check_every = 4;
+        for (int64_t launched = 0; launched <= maxiter + 1;) {
+            for (int k = 0; k < check_every; ++k, ++launched) {
+                if ((r = elph_launch_cg_kernel(h, 1, 0))) return r;                 // p = z + beta p, A p, partial p.Ap
+                if ((r = allsum(h, S, B.pap, B.npap, 0))) return r;
+                if ((r = elph_launch_cg_kernel(h, 1, 1))) return r;                 // x += alpha p, r -= alpha A p, partial r.r
+                if ((r = allsum(h, S, B.rr, (int)h->L, 1))) return r;
+                if ((r = shard_kpm_apply(h, hfull, S))) return r;                   // z = P^-1 r, partial r.z
+            }
+            HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2, hipMemcpyDeviceToHost, h->stream));
+            int ab = 0;
+            HIPCHK(hipMemcpyAsync(&ab, S->d_abort, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (ab) { elph_set_error("sharded preconditioned CG: a rank timed out waiting for its peers"); return ELPH_E_HIP; }
+            const CgState &s = h->h_state[h->ap_count & 1];
+            if (s.done) {
+                if (iters) *iters = s.iters;
+                if (done) *done = s.done;
+                if (eps) *eps = s.eps;
+                if ((r = elph_launch_s2r(h, h->d_stage_out, h->d_x, 1))) return r;
+                HIPCHK(hipMemcpyAsync(x_slab, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                return ELPH_OK;
+            }
+        }
+        elph_set_error("sharded preconditioned CG ended without a terminal state (internal error)");
+        return ELPH_E_STATE;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(h->stream);
+    hfull->stream = saved;
+    (void)elph_set_dot_range(h, 0, h->N);
+    return rc;
 }

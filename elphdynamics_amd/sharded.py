@@ -529,8 +529,11 @@ class ShardedSolver:
         _lib.check(self.lib.elph_create(C.byref(self.h), self.kind, self.Nloc, self.Ltau, nb, _lib.iptr(ltab) if nb else None,
                                         _lib.dptr(c) if c is not None else None, _lib.dptr(s) if s is not None else None, dev))
         hbuf = (C.c_ubyte * 64)()
+        gs = np.ascontiguousarray(self.gsites, dtype=np.int64)
         _lib.check(self.lib.elph_shard_create(self.h, self.rank, self.P, self.own_lo, self.own_n, n_to_prev, n_to_next, cap,
-                                              C.cast(hbuf, C.c_void_p)))
+                                              self.N, int(sl["r0"]) * self.row, _lib.iptr(gs), C.cast(hbuf, C.c_void_p)))
+        self.hf = None
+        self._full = (np.ascontiguousarray(table, dtype=np.int64), cosht, sinht, dev)
         if self.P > 1:
             allh = b"".join(comm.allgather_object(bytes(hbuf)))
             self._allh = C.create_string_buffer(allh, len(allh))
@@ -553,15 +556,40 @@ class ShardedSolver:
         d = self._lib_mod.dptr
         self._lib_mod.check(self.lib.elph_update_model_ssh(self.h, d(c), d(s), d(e)))
 
-    def solve(self, b_global, tol=1e-5, maxiter=10000, kmax=1e12):
+    def setup_kpm(self, expV_global, n=20, buf=0.05, c1=1.0, c2=1.0, seed=7, e_min=None, e_max=None):
+        """KPM preconditioner under sharding (Holstein): a second handle on the WHOLE lattice carries Ē, the Arnoldi bounds, the
+        orders and coefficients — set up identically on every rank (same inputs, same start vectors) — and runs the per-frequency
+        Chebyshev recursion; see elph_shard_solve_kpm.  Returns (active, lam_lo, lam_hi)."""
+        assert self.kind == 0, "KPM under sharding: Holstein models"
+        lm, lib = self._lib_mod, self.lib
+        tab, c, s, dev = self._full
+        if self.hf is None:
+            self.hf = lm.Handle()
+            lm.check(lib.elph_create(C.byref(self.hf), 0, self.N, self.Ltau, tab.shape[0], lm.iptr(tab),
+                                     lm.dptr(np.ascontiguousarray(c)), lm.dptr(np.ascontiguousarray(s)), dev))
+            lm.check(lib.elph_kpm_create(self.hf, n, buf, c1, c2))
+        lm.check(lib.elph_set_expV(self.hf, lm.dptr(np.ascontiguousarray(np.asarray(expV_global).reshape(-1)))))
+        rng = np.random.default_rng(seed)
+        bmax, bmin = rng.standard_normal(self.N), rng.standard_normal(self.N)
+        act, lo, hi = C.c_int(), C.c_double(), C.c_double()
+        lm.check(lib.elph_kpm_setup(self.hf, lm.dptr(bmax), lm.dptr(bmin), float("nan") if e_min is None else e_min,
+                                    float("nan") if e_max is None else e_max, C.byref(act), C.byref(lo), C.byref(hi)))
+        return act.value, lo.value, hi.value
+
+    def solve(self, b_global, tol=1e-5, maxiter=10000, kmax=1e12, precond=False):
         """Returns (x_global (N·Ltau,), iterations, done) — identical on every rank."""
         b = self._local(b_global)
         x = np.zeros(self.Nloc * self.Ltau)
         it, done, eps = C.c_int64(), C.c_int(), C.c_double()
         self._lib_mod.check(self.lib.elph_shard_prepare(self.h))
         self.comm.barrier()                                  # every mailbox is zero before any rank stores into it
-        self._lib_mod.check(self.lib.elph_shard_solve(self.h, self._lib_mod.dptr(x), self._lib_mod.dptr(b), tol, maxiter, kmax,
-                                                      C.byref(it), C.byref(done), C.byref(eps)))
+        if precond:
+            assert self.hf is not None, "setup_kpm first"
+            self._lib_mod.check(self.lib.elph_shard_solve_kpm(self.h, self.hf, self._lib_mod.dptr(x), self._lib_mod.dptr(b), tol, maxiter,
+                                                              kmax, C.byref(it), C.byref(done), C.byref(eps)))
+        else:
+            self._lib_mod.check(self.lib.elph_shard_solve(self.h, self._lib_mod.dptr(x), self._lib_mod.dptr(b), tol, maxiter, kmax,
+                                                          C.byref(it), C.byref(done), C.byref(eps)))
         x_own = x.reshape(self.Nloc, self.Ltau)[self.own_lo:self.own_lo + self.own_n, :]
         parts = self.comm.allgather_object(x_own) if self.P > 1 else [x_own]
         self.eps = float(eps.value)
@@ -581,3 +609,6 @@ class ShardedSolver:
             self.lib.elph_shard_destroy(self.h)
             self.lib.elph_destroy(self.h)
             self.h = None
+        if getattr(self, "hf", None):
+            self.lib.elph_destroy(self.hf)
+            self.hf = None

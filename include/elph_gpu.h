@@ -460,10 +460,19 @@ int elph_omega_to_tau(elph_handle h, double *v, const double *nu_complex);
  * a ghost region of the mailbox, the SAME number on all ranks (>= every rank's ghost and send counts).
  * x_slab / b_slab: host vectors on the slab lattice, reference layout (site-major), b with its ghost entries filled from
  * the global right-hand side; x_slab's own rows are this rank's part of the solution.
- * iters / done / eps: identical on all ranks (done: 1 eps < tol, 2 kappa bound, 3 maxiter). */
+ * iters / done / eps: identical on all ranks (done: 1 eps < tol, 2 kappa bound, 3 maxiter).
+ * n_global / own_global_start / global_sites (0-based global site of every slab site; n_global = 0 and NULL when only
+ * un-preconditioned solves are wanted): the geometry the preconditioned solve needs.
+ * elph_shard_solve_kpm — solve!(x, A, b, cg, P) (IterativeSolvers.jl:153-234) with the KPM preconditioner under sharding:
+ * hfull is a second handle on the WHOLE lattice (same bonds, exp(-dtau V) of all sites, elph_kpm_create + elph_kpm_setup done
+ * with the same inputs on every rank).  Per iteration the ranks trade three partial inner products and all-gather the tau-spectrum
+ * of the residual (peer stores into the mailboxes); every rank runs the per-frequency Chebyshev recursion on the whole lattice and
+ * transforms back its own and ghost rows — no omega-sharded all-to-all: the recursion's critical path is its longest frequency
+ * block either way (KPMPreconditioners.jl:426-481). */
 #define ELPH_SHARD_IPC_BYTES 64
 int elph_shard_create(elph_handle h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev,
-                      int64_t n_to_next, int64_t cap_ghost, void *ipc_handle_out);
+                      int64_t n_to_next, int64_t cap_ghost, int64_t n_global, int64_t own_global_start,
+                      const int64_t *global_sites, void *ipc_handle_out);
 int elph_shard_connect(elph_handle h, const void *all_ipc_handles /* world * ELPH_SHARD_IPC_BYTES, rank order */);
 int elph_shard_prepare(elph_handle h);
 int elph_shard_solve(elph_handle h, double *x_slab, const double *b_slab, double tol, int64_t maxiter, double kappa_max,
@@ -471,6 +480,8 @@ int elph_shard_solve(elph_handle h, double *x_slab, const double *b_slab, double
 /* measurement: exactly `iters` iterations (no stop test); *ms = HIP-event time of this rank's launch. b_slab may be NULL
  * (keeps the right-hand side of the previous call).  Needs elph_shard_prepare + barrier like a solve. */
 int elph_shard_iterate(elph_handle h, const double *b_slab, int64_t iters, double *ms);
+int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, double tol, int64_t maxiter,
+                         double kappa_max, int64_t *iters, int *done, double *eps);
 int elph_shard_destroy(elph_handle h);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py) */

@@ -56,6 +56,11 @@ def main():
     # a second solve on the same handle (mailbox re-zeroed, new barrier): same bits
     xs2, it2, done2 = solver.solve(b, tol=tol, maxiter=20000)
     res.update(x2=xs2, it2=it2)
+    if kind == 0 and os.environ.get("ELPH_TEST_KPM") == "1":
+        # KPM-preconditioned solve under sharding: same Arnoldi start vectors on every rank (and in the un-sharded check of the test)
+        act, lo, hi = solver.setup_kpm(E, n=20, buf=0.05, c1=1.0, c2=1.0, seed=7)
+        xk, itk, donek = solver.solve(b, tol=tol, maxiter=20000, precond=True)
+        res.update(xk=xk, itk=itk, donek=donek, kpm_active=act, lam_lo=lo, lam_hi=hi)
     solver.close()
     np.savez(out + f".rank{comm.rank}", **res)
     comm.close()

@@ -24,13 +24,13 @@ def _free_port():
     return p
 
 
-def _run(case, tmp_path, world, tol=1e-9):
+def _run(case, tmp_path, world, tol=1e-9, kpm=False):
     port = _free_port()
     out = str(tmp_path / f"shard_{case}_{world}")
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ELPH_FORCE_DEVICE="0", ELPH_WG_TIMEOUT_MS="60000")
+                   MASTER_PORT=str(port), ELPH_FORCE_DEVICE="0", ELPH_WG_TIMEOUT_MS="60000", ELPH_TEST_KPM="1" if kpm else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), case, out, repr(tol)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     errs = []
@@ -109,5 +109,46 @@ def test_sharded_solve_one_rank_equals_the_unsharded_handle(tmp_path):
         _lib.check(lib.elph_ldiv(h, _lib.dptr(x), _lib.dptr(np.ascontiguousarray(a["b"])), 0, 0, C.byref(it), C.byref(res), C.byref(fl)))
         assert fl.value == 0 and abs(it.value - int(a["it"])) <= 1
         assert np.linalg.norm(x - a["x"]) / np.linalg.norm(x) < 1e-7
+    finally:
+        lib.elph_destroy(h)
+
+
+@pytest.mark.parametrize("case,world", [("sq8", 2), ("C", 2), ("D", 2), ("D", 4)])
+def test_sharded_kpm_preconditioned_solve(tmp_path, case, world):
+    """SURVEY 8e 'KPM under sharding': the preconditioned solve over 2 / 4 ranks against the preconditioned solve of ONE handle on the
+    whole lattice with the same Arnoldi start vectors: same expansion (bounds), same iteration count (+-1 at the knife edge), and —
+    both solved to 1e-13 — solutions within 1e-10."""
+    import ctypes as C
+    from elphdynamics_amd import _lib
+    lib = _lib.load()
+    tol = 1e-13
+    res = _run(case, tmp_path, world, tol=tol, kpm=True)
+    a = res[0]
+    for b in res[1:]:
+        assert int(a["itk"]) == int(b["itk"]) and np.array_equal(a["xk"], b["xk"])
+    assert int(a["donek"]) == 1 and int(a["kpm_active"]) == 1
+    N, L = int(a["N"]), int(a["Ltau"])
+    h = _lib.Handle()
+    tab = np.ascontiguousarray(a["table"], dtype=np.int64)
+    _lib.check(lib.elph_create(C.byref(h), 0, N, L, tab.shape[0], _lib.iptr(tab), _lib.dptr(np.ascontiguousarray(a["c"])),
+                               _lib.dptr(np.ascontiguousarray(a["s"])), 0))
+    try:
+        _lib.check(lib.elph_set_expV(h, _lib.dptr(np.ascontiguousarray(a["E"]))))
+        _lib.check(lib.elph_kpm_create(h, 20, 0.05, 1.0, 1.0))
+        rng = np.random.default_rng(7)
+        bmax, bmin = rng.standard_normal(N), rng.standard_normal(N)
+        act, lo, hi = C.c_int(), C.c_double(), C.c_double()
+        _lib.check(lib.elph_kpm_setup(h, _lib.dptr(bmax), _lib.dptr(bmin), float("nan"), float("nan"), C.byref(act), C.byref(lo), C.byref(hi)))
+        assert act.value == 1 and lo.value == float(a["lam_lo"]) and hi.value == float(a["lam_hi"])
+        _lib.check(lib.elph_solver_set(h, tol, 20000, 1e12))
+        x = np.zeros(N * L)
+        it, fl, rs = C.c_int64(), C.c_int(), C.c_double()
+        _lib.check(lib.elph_ldiv(h, _lib.dptr(x), _lib.dptr(np.ascontiguousarray(a["b"])), 1, 0, C.byref(it), C.byref(rs), C.byref(fl)))
+        assert fl.value == 0
+        assert abs(it.value - int(a["itk"])) <= 1, (it.value, int(a["itk"]))
+        assert int(a["itk"]) < int(a["it"])                                      # the preconditioner does its job under sharding too
+        err = np.linalg.norm(a["xk"] - x) / np.linalg.norm(x)
+        assert err < 1e-10, err
+        assert np.linalg.norm(a["xk"] - a["x"]) / np.linalg.norm(a["x"]) < 1e-10  # and agrees with the sharded un-preconditioned solve
     finally:
         lib.elph_destroy(h)
