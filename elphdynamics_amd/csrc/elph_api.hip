@@ -11,8 +11,6 @@
 #include <algorithm>
 #include <numeric>
 
-#include <atomic>
-#include <thread>
 
 #include "elph_internal.h"
 
@@ -345,14 +343,12 @@ extern "C" int elph_destroy(elph_handle h) {
     elph_shard_free(h);
     elph_hmc_free(h);
     elph_greens_free(h);
-    delete h->host_pool;
-    h->host_pool = nullptr;
     elph_dft_mfma_free(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_klam, h->d_ssh_x, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_cb, h->d_ssh_slot, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
-                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res, h->d_mu_ch};
+                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res, h->d_mu_ch, h->d_kpm_start};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -1280,16 +1276,13 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     RC(kpm_reserve(h, nch));
     // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)
     if (h->kind == ELPH_MODEL_HOLSTEIN) {
-        RC(elph_launch_ebar(h, nch));
-        HIPCHK(hipMemcpyAsync(h->h_Ebar.data(), h->d_Ebar, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        RC(elph_launch_ebar(h, nch));                    // (Ē stays on the device: the Arnoldi kernel and the apply read it there)
         h->h_cbar = h->h_c;
         h->h_sbar = h->h_s;
         h->kpm_hop_per_chain = false;
     } else {
         // Ebar = exp(dtau mu), held per chain (equal unless the chemical potential is tuned per chain)
-        HIPCHK(hipMemcpy(h->h_Ebar.data(), h->d_E, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(h->d_Ebar, h->d_E, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpyAsync(h->d_Ebar, h->d_E, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToDevice, h->stream));
         h->kpm_hop_per_chain = nch > 1;
         if (nch > h->kpm_hop_cap) {          // averaged hopping tables per chain (and their lane-program / register-exchange images)
             RC(dev_alloc(&h->d_cbar, (size_t)nch * h->nb));
@@ -1353,17 +1346,53 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
                 elph_set_error("Arnoldi start vectors required when bounds are not injected");
                 return ELPH_E_ARG;
             }
-    // per chain, independent host work (no HIP calls): Arnoldi bounds, and new orders + coefficients when the bounds
-    // moved by more than buf — spread over host threads when there are several chains
+    // eigenvalue bounds (:272-273): injected, or the Arnoldi process with the caller's start vectors — on the device for all chains at
+    // once (kpm_dev.hip: one wavefront per chain and per operator, Ritz values by a wave-parallel Hessenberg QR), on the host for
+    // lattices beyond one wave
+    std::vector<double> eb((size_t)2 * nch, NAN);
+    bool need_arnoldi = false;
+    for (int c = 0; c < nch; ++c)
+        if (!(e_min_in && e_max_in && std::isfinite(e_min_in[c]) && std::isfinite(e_max_in[c]))) need_arnoldi = true;
+    bool on_device = false;
+    if (need_arnoldi) {
+        const char *eh = getenv("ELPH_KPM_HOST"), *ed = getenv("ELPH_KPM_DEVICE");     // read per call: tests pin one path
+        const bool host_only = eh && eh[0] == '1', dev_always = ed && ed[0] == '1';
+        const size_t nst = (size_t)2 * nch * N;
+        // (one or two chains: the host's scalar Arnoldi + LAPACK-style QR, 0.1 ms per chain, beats a kernel whose one wave spends
+        //  ~0.25 ms on the same sequential work; from three chains on all of them run side by side on the device)
+        if (!host_only && N <= 512 && (nch >= 3 || dev_always)) {
+            if ((int64_t)(nst + 2 * nch) > h->kpm_start_cap) {
+                RC(dev_alloc(&h->d_kpm_start, nst + 2 * (size_t)nch));
+                h->kpm_start_cap = (int64_t)(nst + 2 * nch);
+            }
+            HIPCHK(hipMemcpyAsync(h->d_kpm_start, b_max, sizeof(double) * (size_t)nch * N, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_kpm_start + (size_t)nch * N, b_min, sizeof(double) * (size_t)nch * N, hipMemcpyHostToDevice, h->stream));
+            const int rcd = elph_kpm_bounds_dev(h, nch, h->d_kpm_start, h->d_kpm_start + nst);
+            if (rcd == ELPH_OK) {
+                HIPCHK(hipMemcpyAsync(eb.data(), h->d_kpm_start + nst, sizeof(double) * 2 * (size_t)nch, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                on_device = true;
+            } else if (rcd != ELPH_E_UNSUPPORTED) {
+                return rcd;
+            }
+        }
+        if (!on_device) {
+            // host path needs Ē (and the averaged hoppings) on the host
+            HIPCHK(hipMemcpy(h->h_Ebar.data(), h->d_Ebar, sizeof(double) * (size_t)nch * N, hipMemcpyDeviceToHost));
+        }
+    }
+    // per chain: acceptance window, and new orders + coefficients when the bounds moved by more than buf (host, ~0.1 ms per chain,
+    // only when they moved)
     std::vector<char> moved((size_t)nch, 0);
     std::vector<int> was((size_t)nch, 0);
     auto one_chain = [&](int c) {
         auto &C = h->kpm_chain[(size_t)c];
         was[(size_t)c] = C.active;
-        // eigenvalue bounds (:272-273) — injected or Arnoldi with caller-supplied start vectors
         double e_min = e_min_in ? e_min_in[c] : NAN, e_max = e_max_in ? e_max_in[c] : NAN;
-        if (!(std::isfinite(e_min) && std::isfinite(e_max)))
-            (void)elph_kpm_arnoldi(h, c, b_max + (size_t)c * N, b_min + (size_t)c * N, &e_min, &e_max);
+        if (!(std::isfinite(e_min) && std::isfinite(e_max))) {
+            if (on_device) { e_min = eb[2 * (size_t)c]; e_max = eb[2 * (size_t)c + 1]; }
+            else (void)elph_kpm_arnoldi(h, c, b_max + (size_t)c * N, b_min + (size_t)c * N, &e_min, &e_max);
+        }
         if ((0.0 < e_min && e_min < 1.0) && (1.0 < e_max) && (e_max - e_min) < 2.0) {       // :280
             const double lo = std::max(0.0, (1 - 2 * h->kpm_buf) * e_min), hi = (1 + 2 * h->kpm_buf) * e_max;
             if (!jl_isapprox(lo, C.lam_lo, h->kpm_buf) || !jl_isapprox(hi, C.lam_hi, h->kpm_buf)) {   // :288
@@ -1387,19 +1416,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
             C.active = 0;                                                                    // :312-318
         }
     };
-    {
-        // ~0.15 ms of scalar work per chain; a thread costs ~30 us to start: one thread per 4 chains, at most 16
-        // (threads are parked in the handle between calls, host_pool.h; the calling thread works too)
-        int nthr = std::max(1, std::min(std::min(nch / 4, 16), (int)std::thread::hardware_concurrency()));
-        if (const char *e = getenv("ELPH_KPM_THREADS")) nthr = std::max(1, std::min(atoi(e), 64));
-        if (nthr <= 1) {
-            for (int c = 0; c < nch; ++c) one_chain(c);
-        } else {
-            if (h->host_pool && h->host_pool->workers() != nthr - 1) { delete h->host_pool; h->host_pool = nullptr; }
-            if (!h->host_pool) h->host_pool = new ElphHostPool(nthr - 1);
-            h->host_pool->run(nch, one_chain);
-        }
-    }
+    for (int c = 0; c < nch; ++c) one_chain(c);
     int any_active = 0;
     for (int c = 0; c < nch; ++c) {
         auto &C = h->kpm_chain[(size_t)c];

@@ -20,7 +20,6 @@
 #include <vector>
 
 #include "../../include/elph_gpu.h"
-#include "host_pool.h"
 
 #define ELPH_ABI_VERSION 1
 #define ELPH_WAVE 64
@@ -260,7 +259,8 @@ struct elph_handle_s {
     struct KpmChainHost { double lam_lo = 0.0, lam_hi = 2.0; int active = 1; bool fresh = true;
                           std::vector<int> order; std::vector<double> coeff; };
     std::vector<KpmChainHost> kpm_chain;   // per chain: bounds, orders, coefficients (complex interleaved)
-    ElphHostPool *host_pool = nullptr;     // parked host threads for the per-chain set-up work (created on first use)
+    double *d_kpm_start = nullptr;         // Arnoldi start vectors [2][nch][N] + the bounds [nch][2] coming back (kpm_dev.hip)
+    int64_t kpm_start_cap = 0;
     std::vector<double> h_Ebar, h_cbar, h_sbar;   // h_Ebar: [kpm_nch][N]; h_cbar, h_sbar: [nb], or [kpm_nch][nb] for SSH chains
     bool kpm_hop_per_chain = false;        // SSH with several chains: averaged hopping tables per chain
     int kpm_hop_cap = 1;                   // chains the device copies of the averaged hopping tables are allocated for
@@ -388,3 +388,4 @@ void elph_kpm_coefficients(double *c_z, int order, double lam_lo, double lam_hi,
 int elph_kpm_arnoldi(const elph_handle_s *h, int chain, const double *b_max, const double *b_min, double *e_min,
                      double *e_max);
 int elph_hess_eigvals(std::vector<double> &a, int n, std::vector<double> &wr, std::vector<double> &wi);
+int elph_kpm_bounds_dev(elph_handle_s *h, int nch, const double *d_bstart, double *d_eout);

@@ -322,10 +322,12 @@ def test_kpm_vs_oracle(oracle, tag):
     rng = np.random.default_rng(11)
     bmax, bmin = rng.standard_normal(m.Nsites), rng.standard_normal(m.Nsites)
     e_min, e_max = oracle.kpm_setup(oP, b_max=bmax, b_min=bmin)
-    pc.setup_(P, b_max=bmax, b_min=bmin)                       # own Arnoldi (host C++), same start vectors
+    pc.setup_(P, b_max=bmax, b_min=bmin)                       # own Arnoldi (device kernel, kpm_dev.hip), same start vectors
     assert P.active and oP.active == 1
-    # 20 Arnoldi steps on N=256..288: Ritz values are reproducible to ~1e-7 across summation orders
-    assert abs(P.lam_lo - oP.lam_lo) < 1e-6 and abs(P.lam_hi - oP.lam_hi) < 1e-6
+    # The largest Ritz value of a 20-step Krylov space of a 256 x 256 non-normal matrix moves by 2-3e-6 with the summation order of
+    # the Gram-Schmidt dot products alone (sequential vs tree vs BLAS: checked in numpy on this very matrix); the device sums each
+    # dot product as a DPP tree, the oracle sequentially.  The expansion takes the bounds with a 5 % margin (KPMPreconditioners.jl:282-285).
+    assert abs(P.lam_lo - oP.lam_lo) < 2e-5 and abs(P.lam_hi - oP.lam_hi) < 2e-5
     # parity of everything downstream: inject the oracle's bounds (parity runs take explicit inputs)
     P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
     pc.setup_(P, e_min=e_min, e_max=e_max)
@@ -729,7 +731,7 @@ def test_mfma_dft_inside_batched_preconditioned_solve(monkeypatch):
 
 
 @pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2)])
-def test_kpm_preconditioner_per_chain(tag, nchains, per):
+def test_kpm_preconditioner_per_chain(tag, nchains, per, monkeypatch):
     """One KPM expansion per resident phonon configuration (elph_kpm_setup_chains): every right-hand side of the batch
     is preconditioned with ITS chain's Ē, eigenvalue bounds, orders and coefficients — same bounds, same iteration
     count and the same solution as the single-configuration model given the same Arnoldi start vectors."""
@@ -746,6 +748,9 @@ def test_kpm_preconditioner_per_chain(tag, nchains, per):
     bmax, bmin = rng.standard_normal((nchains, m.Nsites)), rng.standard_normal((nchains, m.Nsites))
     models.update_model_chains_(m, X)
     P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    # (one and two chains take their Arnoldi bounds on the host, three and more on the device, kpm_dev.hip: pin the device kernel so
+    #  that a chain of the batch and the same configuration alone go through the same arithmetic)
+    monkeypatch.setenv("ELPH_KPM_DEVICE", "1")
     # the single-chain entry point refuses while several configurations are resident
     with pytest.raises(Exception):
         pc.setup_(P, b_max=bmax[0], b_min=bmin[0])
