@@ -38,6 +38,9 @@ def main(argv=None):
     sim = process_input.process_input_file(inp, device=args.device, nchains=args.chains)
     m = sim.model
     acc = measurements.new_accumulator(m) if args.chains == 1 else None
+    # the measurement sums travel in the checkpoint (the reference serialises its container, RunSimulation.jl:54-59): after a resume
+    # the averages below cover the whole run, like iters / acceptance / times do
+    ck_state = acc
 
     def measure(sim, n):
         if acc is not None:
@@ -54,7 +57,8 @@ def main(argv=None):
                     acc["n"] += 1
 
     stats = run_simulation.run_simulation_(sim, measure=measure, checkpoint=args.checkpoint, resume=args.checkpoint is not None,
-                                           checkpoint_every=60.0 * float(sim.sim_params.checkpoint_freq))
+                                           checkpoint_every=60.0 * float(sim.sim_params.checkpoint_freq), checkpoint_state=ck_state)
+
     out = dict(deck=args.deck, chains=args.chains, nsites=m.Nsites, ltau=m.Ltau, **{k: float(v) for k, v in stats.items()})
     if acc is not None and acc["n"]:
         out["density"] = acc["glob"]["density"] / acc["n"]

@@ -1651,7 +1651,12 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
     if (use_graph && h->use_graph && reps % chunk == 0) {
         // capture `chunk` units once (not cached: the bench owns it)
         hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            elph_set_error("elph_bench_run: stream capture did not start");
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return ELPH_E_HIP;
+        }
         for (int i = 0; i < chunk && rc == ELPH_OK; ++i) rc = bench_launch_unit(h, what, nrhs);
         hipError_t e = hipStreamEndCapture(h->stream, &graph);
         if (rc == ELPH_OK && e != hipSuccess) { elph_set_error("capture: %s", hipGetErrorString(e)); rc = ELPH_E_HIP; }
@@ -1662,18 +1667,21 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
         if (graph) (void)hipGraphDestroy(graph);
     }
     if (rc == ELPH_OK) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipEventRecord(e0, h->stream));
-        if (exec) {
-            for (int r = 0; r < reps / chunk; ++r) HIPCHK(hipGraphLaunch(exec, h->stream));
-        } else {
-            for (int r = 0; r < reps && rc == ELPH_OK; ++r) rc = bench_launch_unit(h, what, nrhs);
+        hipError_t er = hipStreamSynchronize(h->stream);
+        if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
+        if (er == hipSuccess) {
+            if (exec) {
+                for (int r = 0; r < reps / chunk && er == hipSuccess; ++r) er = hipGraphLaunch(exec, h->stream);
+            } else {
+                for (int r = 0; r < reps && rc == ELPH_OK; ++r) rc = bench_launch_unit(h, what, nrhs);
+            }
         }
-        HIPCHK(hipEventRecord(e1, h->stream));
-        HIPCHK(hipEventSynchronize(e1));
+        if (er == hipSuccess) er = hipEventRecord(e1, h->stream);
+        if (er == hipSuccess) er = hipEventSynchronize(e1);
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        *ms_total = (double)ms;
+        if (er == hipSuccess) er = hipEventElapsedTime(&ms, e0, e1);
+        if (er != hipSuccess) { elph_set_error("elph_bench_run: %s", hipGetErrorString(er)); rc = ELPH_E_HIP; }
+        else *ms_total = (double)ms;
     }
     if (exec) (void)hipGraphExecDestroy(exec);
     (void)hipEventDestroy(e0);

@@ -9,8 +9,11 @@
     HybridMonteCarlo, update_(model, hmc, fa, P)   HMC.jl:20-337 (struct + update!): the whole trajectory on the device
 
 The two pseudofermion solves (and the n_v measurement solves) share one fermion matrix, so they go to
-the GPU as ONE batched ldiv!; each right-hand side still follows the single-RHS recurrences and stop rule,
-so the results are bit-identical to the reference's sequential solves on the same inputs.
+the GPU as ONE batched ldiv!; each right-hand side still follows the single-RHS recurrences and stop rule — the same
+algorithm as the reference's sequential solves.  Bits: a right-hand side's result does not depend on its companions in the batch
+as long as the batch keeps one kernel shape (un-preconditioned: fewer than 48 right-hand sides on the 16 x 16 square lattice, any
+number elsewhere); larger batches sum the inner products in another tree (same values to ~1e-15 per iteration, the stop
+iteration can move by one).
 update_Lambda_/mulLambda_/mulLambdaInv_ are host utilities for building test inputs; inside calc_OinvLambda_phi and
 calc_dSfdx_ the Λ operations run on the device (k_lambda_rhs, k_force_holstein).
 """
@@ -397,6 +400,7 @@ def swap_update_(model, hmc, nbonds, P=None, rng=None):
         if model.Nph < 2:
             return 0.0
         acc, L, nch = 0.0, model.Ltau, hmc.nchains
+        nbonds = min(model.Nbonds, nbonds)                          # SwapUpdate(model::SSHModel) clamps (SpecialUpdates.jl)
         for _ in range(nbonds):
             hmc.pull_()
             ci, cj = np.zeros(nch, dtype=np.int64), np.zeros(nch, dtype=np.int64)
@@ -414,6 +418,7 @@ def swap_update_(model, hmc, nbonds, P=None, rng=None):
         if model.Nph < 2:
             return 0.0
         acc, L = 0, model.Ltau
+        nbonds = min(model.Nbonds, nbonds)                          # SwapUpdate(model::SSHModel) clamps (SpecialUpdates.jl)
         for _ in range(nbonds):
             hmc.pull_()                                             # the draw compares world lines (while xᵢ ≈ xⱼ, :325-327)
             x = model.x.reshape(model.Nph, L)

@@ -24,7 +24,23 @@ def _special(sim, dyn, n, reflect, swap, stats, P, rng):
         stats["swap_acceptance_rate"] += hmc.swap_update_(m, dyn, swap.nbonds, P, rng=rng)
 
 
-def save_checkpoint(path, sim, phase, n, stats, rng):
+def _deck_identity(sim):
+    m, dyn = sim.model, sim.simulation_dynamics
+    return dict(nsites=int(m.Nsites), ltau=int(m.Ltau), kind=int(m.kind), ndof=int(m.Ndof), nchains=int(getattr(dyn, "nchains", 1)))
+
+
+def _restore_into(dst, src):
+    """Deep in-place update: nested dicts are descended into, arrays are overwritten element-wise (the caller keeps its references)."""
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _restore_into(dst[k], v)
+        elif isinstance(v, np.ndarray) and isinstance(dst.get(k), np.ndarray) and dst[k].shape == v.shape:
+            dst[k][...] = v
+        else:
+            dst[k] = v
+
+
+def save_checkpoint(path, sim, phase, n, stats, rng, extra=None):
     """Checkpoint of a run (the reference serialises (model, μ_tuner, container, burnin_start, sim_start, sim_stats) to
     checkpoint.jls, RunSimulation.jl:54-59,120-126,175-180; dynamics, accelerator, preconditioner and estimator are rebuilt from
     the deck on resume, ProcessInputFile.jl:122-177 — the same split here): field(s), momenta, chemical potential(s), tuner(s),
@@ -32,7 +48,10 @@ def save_checkpoint(path, sim, phase, n, stats, rng):
     import pickle
     dyn = sim.simulation_dynamics
     dyn.pull_()
-    state = dict(phase=phase, n=n, stats=dict(stats), x=sim.model.x.copy(), mu=sim.model.mu.copy(),
+    # `extra`: state the CALLER accumulates over the run (the measurement sums of __main__: the reference serialises its measurement
+    # container in every checkpoint, RunSimulation.jl:54-59); `identity`: a checkpoint only resumes the deck it was written for
+    state = dict(format="elphdynamics_amd checkpoint 2", identity=_deck_identity(sim), extra=extra,
+                 phase=phase, n=n, stats=dict(stats), x=sim.model.x.copy(), mu=sim.model.mu.copy(),
                  X=None if getattr(dyn, "X", None) is None else dyn.X.copy(), V=None if getattr(dyn, "V", None) is None else dyn.V.copy(),
                  v=None if getattr(dyn, "v", None) is None else np.array(dyn.v).copy(), mu_chains=getattr(dyn, "mu_chains", None),
                  mu_tuner=getattr(sim, "mu_tuner", None), mu_tuners=getattr(sim, "mu_tuners", None),
@@ -44,12 +63,21 @@ def save_checkpoint(path, sim, phase, n, stats, rng):
     os.replace(tmp, path)
 
 
-def load_checkpoint(path, sim, rng):
-    """Put a run built from the same deck (process_input_file) back where save_checkpoint left it -> (phase, n, stats)."""
+def load_checkpoint(path, sim, rng, extra=None):
+    """Put a run built from the same deck (process_input_file) back where save_checkpoint left it -> (phase, n, stats).
+    `extra` (a dict the caller owns) is updated in place with what the caller handed to save_checkpoint.  The file is a pickle
+    written by this module: only load checkpoints of your own runs; one that belongs to another deck (lattice, time axis, model
+    family, number of chains) is refused."""
     import pickle
     from ._lib import check, dptr
     with open(path, "rb") as f:
         st = pickle.load(f)
+    if not isinstance(st, dict) or st.get("format") != "elphdynamics_amd checkpoint 2":
+        raise ValueError(f"{path}: not a checkpoint of this version of elphdynamics_amd")
+    if st["identity"] != _deck_identity(sim):
+        raise ValueError(f"{path} belongs to another deck: {st['identity']} != {_deck_identity(sim)}")
+    if extra is not None and st.get("extra") is not None:
+        _restore_into(extra, st["extra"])
     m, dyn = sim.model, sim.simulation_dynamics
     m.x[:], m.mu[:] = st["x"], st["mu"]
     if st["X"] is not None:
@@ -72,10 +100,11 @@ def load_checkpoint(path, sim, rng):
     return st["phase"], st["n"], st["stats"]
 
 
-def run_simulation_(sim, measure=None, rng=None, checkpoint=None, checkpoint_every=600.0, resume=False):
+def run_simulation_(sim, measure=None, rng=None, checkpoint=None, checkpoint_every=600.0, resume=False, checkpoint_state=None):
     """checkpoint: file written every `checkpoint_every` seconds (sim_params.checkpoint_freq is in minutes in the decks) and at
     the end of every phase; resume=True continues from it when it exists (the reference resumes when the data folder exists,
-    ElPhDynamics.jl:102-107)."""
+    ElPhDynamics.jl:102-107).  checkpoint_state: a dict of the caller's own run state (e.g. the sums its `measure` callback
+    accumulates) — written into every checkpoint and restored IN PLACE on resume, so averages cover the whole run."""
     import os
     m, fa, P, sp = sim.model, sim.fa, sim.preconditioner, sim.sim_params
     rng = rng or getattr(m, "rng", None)
@@ -85,7 +114,7 @@ def run_simulation_(sim, measure=None, rng=None, checkpoint=None, checkpoint_eve
     nch = int(getattr(sim.simulation_dynamics, "nchains", 1))
     start_phase, start_n = 0, 1
     if checkpoint and resume and os.path.exists(checkpoint):
-        start_phase, last_n, stats = load_checkpoint(checkpoint, sim, rng)
+        start_phase, last_n, stats = load_checkpoint(checkpoint, sim, rng, extra=checkpoint_state)
         start_n = last_n + 1
     t_ckpt = time.perf_counter()
     if nch > 1 and getattr(sim, "mu_tuner", None) is not None and sim.mu_tuner.active and getattr(sim, "mu_tuners", None) is None:
@@ -132,7 +161,7 @@ def run_simulation_(sim, measure=None, rng=None, checkpoint=None, checkpoint_eve
                 stats["measurement_time"] += time.perf_counter() - t0
             if checkpoint and (time.perf_counter() - t_ckpt > checkpoint_every or n == nsteps):
                 t0 = time.perf_counter()
-                save_checkpoint(checkpoint, sim, iphase, n, stats, rng)
+                save_checkpoint(checkpoint, sim, iphase, n, stats, rng, extra=checkpoint_state)
                 t_ckpt = time.perf_counter()
                 stats["write_time"] += t_ckpt - t0
     total = sp.nsteps + sp.burnin

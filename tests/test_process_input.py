@@ -225,3 +225,39 @@ def test_checkpoint_and_resume_continue_the_same_run(tmp_path):
     assert stats_c["acceptance_rate"] == stats_a["acceptance_rate"] and abs(stats_c["iters"] - stats_a["iters"]) < 1.0
     assert len(c.mu_tuner.N_traj) == len(a.mu_tuner.N_traj)
     c.model.close()
+
+
+def test_checkpoint_carries_caller_state_and_refuses_another_deck(tmp_path):
+    """The caller's accumulated state (the measurement sums of __main__) is written into every checkpoint and restored in place on
+    resume (the reference serialises its measurement container, RunSimulation.jl:54-59); a checkpoint of another deck is refused."""
+    import pytest
+    from elphdynamics_amd import run_simulation as rs
+
+    class _M:
+        Nsites, Ltau, kind, Ndof = 4, 8, 0, 32
+        x = np.zeros(32); mu = np.zeros(4)
+
+    class _D:
+        nchains = 1
+        def pull_(self): pass
+        def push_(self): pass
+
+    class _S:
+        model, simulation_dynamics, mu_tuner = _M(), _D(), None
+
+    ck = str(tmp_path / "c.pkl")
+    state = dict(n=7, glob=dict(density=1.5), corr=dict(G=np.arange(6.0)))
+    rs.save_checkpoint(ck, _S(), 1, 3, dict(iters=2.0), None, extra=state)
+    back = dict(n=0, glob=dict(density=0.0), corr=dict(G=np.zeros(6)))
+    g_ref = back["corr"]["G"]
+    S2 = _S()
+    S2.model._lib = type("L", (), {"elph_hmc_set_mu": staticmethod(lambda *a: 0)})()
+    S2.model._h = None
+    phase, n, stats = rs.load_checkpoint(ck, S2, None, extra=back)
+    assert (phase, n, stats["iters"]) == (1, 3, 2.0)
+    assert back["n"] == 7 and back["glob"]["density"] == 1.5 and back["corr"]["G"] is g_ref and np.array_equal(g_ref, np.arange(6.0))
+    S3 = _S()
+    S3.model = _M()
+    S3.model.Ltau = 16
+    with pytest.raises(ValueError):
+        rs.load_checkpoint(ck, S3, None)
