@@ -265,11 +265,11 @@ def main():
             stream["note"] = ("two-kernel streaming form: what preconditioned solves and lattices outside the resident kernel's reach run; "
                               "timed here at the same batch for comparison")
             out["roofline_streaming"] = stream
-            wkey = f"k_cg_wg<T={wg_T.value},W={wg_W.value},G={wg_G.value}>|config={args.config}|nrhs={nrhs}|chains={nchains}|iters={K}"
+            wkey = f"k_cg_wg<T={wg_T.value},W={wg_W.value},G={wg_G.value}>|config={args.config}|nrhs={nrhs}|chains={nchains}"
             wtraffic = None
-            try:
+            try:      # memory-side bytes per ITERATION of the batch (the PMC pass ran another number of iterations): x K for this launch
                 went = json.load(open(tpath)).get("kernels", {}).get(wkey)
-                wtraffic = went["hbm_bytes_per_launch"] if went else None
+                wtraffic = went["hbm_bytes_per_iteration"] * K if went else None
             except Exception:
                 wtraffic = None
             out["roofline"] = {
@@ -279,8 +279,10 @@ def main():
                 "bytes_per_launch": built_wg,
                 "bytes_model": "compulsory bytes of the kernel as built: r0, p0, x0 in, x, r out (5 vectors x 8 B x Ndim x nrhs) + "
                                "exp(-dtau V) once per chain, per LAUNCH of K iterations — the Krylov vectors stay in registers / LDS",
-                "binding_resource": "on-chip latency: two team meetings through L2 per iteration (~1.2 us each) + the checkerboard sweeps; "
-                                    "not HBM (fraction small by design)",
+                "binding_resource": "on-chip latency: two team meetings through L2 per iteration (~1.8 us each at 10 workgroups per team) + the "
+                                    "checkerboard sweeps; not HBM (fraction small by design)",
+                "traffic_note": "memory-side traffic of this kernel is its SYNCHRONISATION: write-through record / boundary granules and the "
+                                "polls of them (they bypass L2 by design), ~40 MB per iteration of 288 right-hand sides — not vector data",
                 "hbm_streaming_equivalent_GBs": equiv,
                 "x_hbm_peak_of_a_streaming_implementation": equiv / HBM_PEAK_GBS,
                 "streaming_form_same_batch": {"us_per_step": ms_stream * 1e3, "matvecs_per_sec": 2.0 * nrhs / (ms_stream * 1e-3),

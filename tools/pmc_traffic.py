@@ -91,13 +91,15 @@ def main():
         }
         if wg is not None:
             kw = find("k_cg_wg")
-            tj["kernels"][wg["traffic_key"]] = {
+            tj["kernels"][wg["traffic_key"].split("|iters=")[0]] = {
                 "rocprof_kernel": kw["kernel"], "hbm_bytes_per_launch": kw["hbm_bytes_per_launch"], "read": kw["hbm_read_bytes_corrected"],
                 "write": kw["hbm_write_bytes"], "dispatches": kw["dispatches"], "nrhs": nrhs, "ndim": ndim,
                 "iterations_per_launch": wg["iterations_per_launch"],
-                "note": "one launch = iterations_per_launch CG iterations of all right-hand sides; the Krylov vectors stay on chip",
+                "hbm_bytes_per_iteration": kw["hbm_bytes_per_launch"] / wg["iterations_per_launch"],
+                "note": "one launch = iterations_per_launch CG iterations of all right-hand sides; the Krylov vectors stay on chip: what the "
+                        "memory-side counters see are the write-through record / boundary granules of the team meetings and the polls of them",
             }
-            print(json.dumps(tj["kernels"][wg["traffic_key"]], indent=1))
+            print(json.dumps(tj["kernels"][wg["traffic_key"].split("|iters=")[0]], indent=1))
         json.dump(tj, open(dst, "w"), indent=1)
         print(json.dumps(tj["kernels"][key], indent=1))
         return
