@@ -38,6 +38,7 @@ SIGNATURES = {
     "elph_mulM": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_mulMT": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_mulMTM": (c_int, [Handle, P_dbl, P_dbl]),
+    "elph_mulMMT": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_mulM_dev": (c_int, [Handle, C.c_void_p, C.c_void_p]),
     "elph_mulMT_dev": (c_int, [Handle, C.c_void_p, C.c_void_p]),
     "elph_mulMTM_dev": (c_int, [Handle, C.c_void_p, C.c_void_p]),

@@ -593,7 +593,12 @@ static int mul_dev(elph_handle_s *h, int which, double *y_dev, const double *v_d
     RC(need_model(h));
     if (!y_dev || !v_dev) { elph_set_error("null argument"); return ELPH_E_ARG; }
     RC(elph_launch_r2s(h, h->d_b, v_dev, 1));
-    RC(elph_launch_mul(h, which, h->d_x, h->d_b, 1));
+    if (which == 3) {                                    // M Mᵀ v (Models.jl:229-238): two launches, not on the CG path
+        RC(elph_launch_mul(h, 1, h->d_tmp, h->d_b, 1));
+        RC(elph_launch_mul(h, 0, h->d_x, h->d_tmp, 1));
+    } else {
+        RC(elph_launch_mul(h, which, h->d_x, h->d_b, 1));
+    }
     RC(elph_launch_s2r(h, y_dev, h->d_x, 1));
     return ELPH_OK;
 }
@@ -611,6 +616,7 @@ static int mul_host(elph_handle_s *h, int which, double *y, const double *v) {
 extern "C" int elph_mulM(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_host(h, 0, y, v); }
 extern "C" int elph_mulMT(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_host(h, 1, y, v); }
 extern "C" int elph_mulMTM(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_host(h, 2, y, v); }
+extern "C" int elph_mulMMT(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_host(h, 3, y, v); }
 extern "C" int elph_mulM_dev(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_dev(h, 0, y, v); }
 extern "C" int elph_mulMT_dev(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_dev(h, 1, y, v); }
 extern "C" int elph_mulMTM_dev(elph_handle h, double *y, const double *v) { CHECK_H(h); return mul_dev(h, 2, y, v); }

@@ -334,10 +334,8 @@ def mulMtM_(y, model, v):
 
 
 def mulMMt_(y, model, v):
-    """Models.jl:229-238 (two launches; not on the CG path, which always uses MtM)."""
-    tmp = np.empty_like(v)
-    mulMt_(tmp, model, v)
-    mulM_(y, model, tmp)
+    """Models.jl:229-238 (two launches inside the library; not on the CG path, which always uses MtM)."""
+    check(model._lib.elph_mulMMT(model._h, dptr(_vec(y, model.Ndim)), dptr(_vec(v, model.Ndim))))
 
 
 def mul_(y, model, v):

@@ -128,6 +128,8 @@ int elph_mulM(elph_handle h, double *y, const double *v);
 int elph_mulMT(elph_handle h, double *y, const double *v);
 /* mulMᵀM!(y, model, v) — Models.jl:215-224 (one fused kernel; no v' round trip) */
 int elph_mulMTM(elph_handle h, double *y, const double *v);
+/* mulMMᵀ!(y, model, v) — Models.jl:229-238 (the `transposed` branch of mul!, :192-209; only the non-CG solvers use it) */
+int elph_mulMMT(elph_handle h, double *y, const double *v);
 /* device-pointer twins (reference layout, handle's stream, asynchronous) */
 int elph_mulM_dev(elph_handle h, double *y_dev, const double *v_dev);
 int elph_mulMT_dev(elph_handle h, double *y_dev, const double *v_dev);

@@ -232,6 +232,13 @@ def test_matvec_vs_oracle(oracle, tag):
     models.mulMt_(a, m, Mv)
     models.mulMtM_(y, m, v)
     assert rel(y, a) < 1e-14                                                                # fused MtM == Mt(M v)
+    models.mulM_(a, m, Mtu)
+    models.mulMMt_(y, m, u)
+    assert rel(y, a) < 1e-14 and rel(y, oracle.mulM(om, oracle.mulMT(om, u))) < 1e-13       # mulMMᵀ! (Models.jl:229-238)
+    models.transpose_(m)
+    models.mul_(y, m, u)                                                                    # mul! honours model.transposed (:192-209)
+    assert rel(y, a) < 1e-14
+    models.transpose_(m)
     models.mulM_(a, m, 2.0 * v - 3.0 * u)
     Mu = np.empty(m.Ndim)
     models.mulM_(Mu, m, u)
