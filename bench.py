@@ -283,6 +283,12 @@ def main():
                                     "checkerboard sweeps; not HBM (fraction small by design)",
                 "traffic_note": "memory-side traffic of this kernel is its SYNCHRONISATION: write-through record / boundary granules and the "
                                 "polls of them (they bypass L2 by design), ~40 MB per iteration of 288 right-hand sides — not vector data",
+                # the arithmetic of the same launch against the f64 vector peak (the sweeps are v_fma_f64, not MFMA — same peak figure):
+                # per right-hand side and iteration 2 mat-vecs x (2 Ndim + 6 Ltau Nbonds) + 10 Ndim of p.z, x, r, r.r, p
+                "f64_vector": (lambda fl: {"flops_per_launch": fl, "achieved_TFLOPs": fl / (us_launch * 1e-6) / 1e12,
+                                           "peak_TFLOPs": F64_MFMA_PEAK_TFLOPS,
+                                           "frac": fl / (us_launch * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS})(
+                    float(K) * nrhs * (2.0 * (2.0 * m.Ndim + 6.0 * m.Ltau * m.Nbonds) + 10.0 * m.Ndim)),
                 "hbm_streaming_equivalent_GBs": equiv,
                 "x_hbm_peak_of_a_streaming_implementation": equiv / HBM_PEAK_GBS,
                 "streaming_form_same_batch": {"us_per_step": ms_stream * 1e3, "matvecs_per_sec": 2.0 * nrhs / (ms_stream * 1e-3),

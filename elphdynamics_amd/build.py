@@ -84,3 +84,8 @@ def build_library(force=False, verbose=False, lds_sync_variant=True):
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
     return LIB
+
+
+if __name__ == "__main__":      # python -m elphdynamics_amd.build [--force]
+    import sys
+    print(build_library(force="--force" in sys.argv[1:], verbose="-v" in sys.argv[1:]))

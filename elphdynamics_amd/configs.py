@@ -28,14 +28,14 @@ CONFIGS = {
 }
 
 
-def make_model(tag, tol=1e-5, maxiter=10000, rough=True, device=0, seed=synth.SEED_FIELDS):
+def make_model(tag, tol=1e-5, maxiter=10000, rough=True, device=0, seed=synth.SEED_FIELDS, t_stddev=0.0):
     kind, norb, Ls, bonds, beta, dtau = CONFIGS[tag]
     L2 = Ls if Ls > 1 else 1
     lattice = lat.Lattice(norb, Ls, L2, 1)
     if kind == "holstein":
         m = models.HolsteinModel(lattice, beta, dtau, tol=tol, maxiter=maxiter, device=device)
         for (o1, o2, d) in bonds:
-            m.assign_t_(1.0, o1, o2, d)
+            m.assign_t_(1.0, o1, o2, d, stddev=t_stddev, rng=np.random.default_rng(seed + 991))   # (t_stddev: hopping disorder, :427-447)
         m.assign_omega_(1.0)
         m.assign_lambda_(1.0)
         m.assign_mu_(0.0)

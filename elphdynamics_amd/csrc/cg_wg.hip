@@ -119,11 +119,20 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
-struct SqCtx { double c, s; bool xodd; int up, dn; };    // partner lanes of the y-odd colour: (l + 16) & 63, (l - 16) & 63
+// Hopping of the DPP form.  UNI: one (cosh, sinh) for every bond; otherwise the pair of the bond that covers each of the lane's
+// four sites in each of the four colours (Holstein with hopping disorder) — gathered once, before the loop.
+// (SSH — one table set per time slice — was built and measured in this form too: 64 more registers per slice, one slice per
+// wave, 9.4 us per iteration against 9.2 us of the lane-program form, whose time the team of 20 workgroups sets; not kept.)
+template <bool UNI>
+struct SqCtx {
+    double c[UNI ? 1 : 4][UNI ? 1 : 4], s[UNI ? 1 : 4][UNI ? 1 : 4];
+    bool xodd; int up, dn;                                    // partner lanes of the y-odd colour: (l + 16) & 63, (l - 16) & 63
+    __device__ __forceinline__ double C(int col, int k) const { return c[UNI ? 0 : col][UNI ? 0 : k]; }
+    __device__ __forceinline__ double S(int col, int k) const { return s[UNI ? 0 : col][UNI ? 0 : k]; }
+};
 
-template <int NS, bool REVERSE>
-__device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx &X) {
-    const double c = X.c, s = X.s;
+template <int NS, bool REVERSE, bool UNI>
+__device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx<UNI> &X) {
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
         const int col = REVERSE ? 3 - cc : cc;
@@ -131,22 +140,22 @@ __device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx &X) {
         for (int n = 0; n < NS; ++n) {
             if (col == 0) {                                      // x even <-> x + 1: lane ^ 1
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const double t = dpp_f64<0xB1>(v[n][k]); v[n][k] = c * v[n][k] + s * t; }
+                for (int k = 0; k < 4; ++k) { const double t = dpp_f64<0xB1>(v[n][k]); v[n][k] = X.C(0, k) * v[n][k] + X.S(0, k) * t; }
             } else if (col == 1) {                               // x odd <-> x + 1 (mod 16): odd lanes look up, even lanes look down
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double a = dpp_f64<0x12F>(v[n][k]);    // row_ror:15 = value of lane + 1 (mod 16)
                     const double b = dpp_f64<0x121>(v[n][k]);    // row_ror:1  = value of lane - 1 (mod 16)
-                    v[n][k] = c * v[n][k] + s * (X.xodd ? a : b);
+                    v[n][k] = X.C(1, k) * v[n][k] + X.S(1, k) * (X.xodd ? a : b);
                 }
             } else if (col == 2) {                               // y even <-> y + 1: (k0,k1), (k2,k3) of the lane itself
-                const double n0 = c * v[n][0] + s * v[n][1], n1 = c * v[n][1] + s * v[n][0];
-                const double n2 = c * v[n][2] + s * v[n][3], n3 = c * v[n][3] + s * v[n][2];
+                const double n0 = X.C(2, 0) * v[n][0] + X.S(2, 0) * v[n][1], n1 = X.C(2, 1) * v[n][1] + X.S(2, 1) * v[n][0];
+                const double n2 = X.C(2, 2) * v[n][2] + X.S(2, 2) * v[n][3], n3 = X.C(2, 3) * v[n][3] + X.S(2, 3) * v[n][2];
                 v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
             } else {                                             // y odd <-> y + 1 (mod 16): (k1,k2) in the lane, k3 <-> next row group's k0
                 const double t3 = __shfl(v[n][0], X.up, WAVE), t0 = __shfl(v[n][3], X.dn, WAVE);
-                const double n1 = c * v[n][1] + s * v[n][2], n2 = c * v[n][2] + s * v[n][1];
-                v[n][0] = c * v[n][0] + s * t0; v[n][3] = c * v[n][3] + s * t3;
+                const double n1 = X.C(3, 1) * v[n][1] + X.S(3, 1) * v[n][2], n2 = X.C(3, 2) * v[n][2] + X.S(3, 2) * v[n][1];
+                v[n][0] = X.C(3, 0) * v[n][0] + X.S(3, 0) * t0; v[n][3] = X.C(3, 3) * v[n][3] + X.S(3, 3) * t3;
                 v[n][1] = n1; v[n][2] = n2;
             }
             // keep the scheduler from hoisting every slab's cross-lane moves to the front (their temporaries would all be live at
@@ -356,13 +365,15 @@ __device__ __forceinline__ bool sh_poll(const ShardCtl &Sh, bool rec, int m, int
     return true;
 }
 
-// SQ: the DPP form for the uniform 16 x 16 square lattice (NPL = 4, no LDS slabs); otherwise the lane-program form
+// SQ: the DPP form for Holstein on the 16 x 16 square lattice in the reference's colouring (NPL = 4, no LDS slabs; uniform hopping
+// in two scalars, disordered hopping in per-site registers); otherwise the lane-program form
 // SHARD: this launch is one rank's part of a solve over several GPUs (T = 1, lane-program form)
 template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
     static_assert(!SHARD || (T == 1 && !SQ), "sharded solves: one slice per wave, lane-program form");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    static_assert(!SQ || (NPL == 4 && UNI && !SSH), "DPP form: uniform 16 x 16 square lattice");
+    static_assert(!SQ || (NPL == 4 && !SSH), "DPP form: Holstein on the 16 x 16 square lattice, four sites per lane");
+    static_assert(!SQ || UNI || T <= 2, "DPP form with per-site hopping: 32 registers of (cosh, sinh) leave room for two slices");
     constexpr int NE = MC * ((NPL + 1) / 2);
     constexpr int HS = NPL * WAVE, SL = slab_len<NPL>();
     constexpr int NSLAB = SQ ? 0 : T + 1;              // LDS slabs per wave (lane-program form)
@@ -435,9 +446,21 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         }
     unsigned ij[NE];
     Tab<NE, UNI> tab[NT];
-    SqCtx X;
+    SqCtx<UNI> X;
     if constexpr (SQ) {
-        X.c = m.c_uni; X.s = m.s_uni; X.xodd = (lane & 1) != 0; X.up = (lane + 16) & 63; X.dn = (lane + 48) & 63;
+        X.xodd = (lane & 1) != 0; X.up = (lane + 16) & 63; X.dn = (lane + 48) & 63;
+        if constexpr (UNI) {
+            X.c[0][0] = m.c_uni; X.s[0][0] = m.s_uni;
+        } else {
+#pragma unroll
+            for (int col = 0; col < 4; ++col)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int bd = m.sq_bond[col * N + sc[k]];
+                    X.c[UNI ? 0 : col][UNI ? 0 : k] = m.c[bd];
+                    X.s[UNI ? 0 : col][UNI ? 0 : k] = m.s[bd];
+                }
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < NE; ++e) ij[e] = m.lp_ij[e * WAVE + lane];
@@ -505,7 +528,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int k = 0; k <= T; ++k)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[k][q] = EXPV(k, q) * p[k][q];
-            sq_sweepN<T + 1, false>(w, X);
+            sq_sweepN<T + 1, false, UNI>(w, X);
 #pragma unroll
             for (int k = 0; k <= T; ++k) {
                 const double sg = sgn(wrap(t0 + k));
@@ -520,7 +543,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) gq[i][q] = w[j0 + i + 1][q];
-                sq_sweepN<RB, true>(gq, X);
+                sq_sweepN<RB, true, UNI>(gq, X);
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const double sg = sgn(wrap(t0 + j0 + i + 1));
@@ -784,10 +807,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 
 struct Shape { int T, W, G; size_t shm; bool sq; };
 
-// DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square), one hopping for all bonds
+// DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square)
 static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
     const char *e = getenv("ELPH_WG_NO_DPP");
-    return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 2 && h->N == 256 && m.uniform && !(e && e[0] == '1');
+    return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 2 && h->N == 256 && m.sq_bond && !(e && e[0] == '1');
 }
 
 // T slices per wave: what the register file takes at two waves per SIMD — lane-program form 2 for site phonons with <= 4 sites
@@ -800,7 +823,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     const int cand[3] = {4, 2, 1};
     for (int T : cand) {
         if (forceT && T != forceT) continue;
-        if (T == 4 && (!sq || (forceT != 4 && nrhs < ELPH_WG_T4_MIN_RHS))) continue;
+        if (T == 4 && (!sq || !m.uniform || (forceT != 4 && nrhs < ELPH_WG_T4_MIN_RHS))) continue;
         if (T == 2 && !sq && (ssh || h->npl > 4 || (h->npl == 4 && !m.uniform))) continue;
         if (L % T) continue;
         const int Wt = L / T;
@@ -838,14 +861,15 @@ static hipError_t launch_shard_npl(elph_handle_s *h, const Shape &sh, dim3 grid,
 
 template <int NPL>
 static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R) {
-    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, false>(h, sh, grid, B, m, R);
     if constexpr (NPL == 4) {
         if (sh.sq) {
+            if (!m.uniform) return (sh.T == 2) ? launch_k<4, 2, false, false, true>(h, sh, grid, B, m, R) : launch_k<4, 1, false, false, true>(h, sh, grid, B, m, R);
             if (sh.T == 4) return launch_k<4, 4, false, true, true>(h, sh, grid, B, m, R);
             if (sh.T == 2) return launch_k<4, 2, false, true, true>(h, sh, grid, B, m, R);
             return launch_k<4, 1, false, true, true>(h, sh, grid, B, m, R);
         }
     }
+    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, false>(h, sh, grid, B, m, R);
     if constexpr (NPL <= 4) {
         if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false, false>(h, sh, grid, B, m, R);
     }

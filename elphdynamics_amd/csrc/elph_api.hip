@@ -126,6 +126,8 @@ static int build_lane_program(elph_handle_s *h) {
     if (h->sq_P > 0) {
         RC(dev_alloc(&h->d_sq_cbar, (size_t)4 * h->N));
         RC(dev_alloc(&h->d_sq_sbar, (size_t)4 * h->N));
+        RC(dev_alloc(&h->d_sq_bond, (size_t)4 * h->N));
+        HIPCHK(hipMemcpy(h->d_sq_bond, h->sq_bond.data(), sizeof(int) * 4 * h->N, hipMemcpyHostToDevice));
     }
     return ELPH_OK;
 }
@@ -348,7 +350,7 @@ extern "C" int elph_destroy(elph_handle h) {
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
                     h->d_coeff, h->d_klam, h->d_ssh_x, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_cb, h->d_ssh_slot, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
-                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_res, h->d_mu_ch, h->d_kpm_start};
+                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_sq_bond, h->d_res, h->d_mu_ch, h->d_kpm_start};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);

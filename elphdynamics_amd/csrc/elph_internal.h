@@ -62,6 +62,8 @@ struct ModelDev {
     // every bond carries the same (cosh, sinh) (Holstein without hopping disorder): kernels may keep them in two scalars
     int uniform;
     double c_uni, s_uni;
+    // 16 x 16 square lattice in the reference's colouring: the bond that covers site i in colour col ([4][N]; nullptr otherwise)
+    const int *sq_bond;
 };
 #ifdef __HIPCC__
 // the hopping tables of the chain right-hand side `rhs` belongs to (SSH chains; no-op otherwise)
@@ -209,6 +211,7 @@ struct elph_handle_s {
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
+    int *d_sq_bond = nullptr;                            // [4][N] device copy of sq_bond (sq_P > 0)
     void *shard = nullptr;                 // ShardState (shard.hip), owned
     void *hmc = nullptr;                   // HmcState (hmc.hip), owned
     void *greens = nullptr;                // GreensState (greens.hip), owned

@@ -973,6 +973,7 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.lp_tau_stride = (h->kind == ELPH_MODEL_SSH) ? h->lp_ne * ELPH_WAVE : 0;
     m.cs_chain_stride = m.lp_chain_stride = 0;
     m.uniform = 0; m.c_uni = 1.0; m.s_uni = 0.0;
+    m.sq_bond = (h->sq_P > 0) ? h->d_sq_bond : nullptr;
     if (h->kind == ELPH_MODEL_HOLSTEIN && h->nb > 0) {
         bool uni = true;
         for (int64_t n = 1; n < h->nb && uni; ++n) uni = (h->h_c[(size_t)n] == h->h_c[0] && h->h_s[(size_t)n] == h->h_s[0]);

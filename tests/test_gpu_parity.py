@@ -1107,6 +1107,41 @@ def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
     m.close()
 
 
+def test_wg_resident_cg_dpp_form_with_hopping_disorder(oracle, monkeypatch):
+    """Holstein on the 16 x 16 lattice with a disordered hopping table (assign_t! with stddev, HolsteinModels.jl:427-447): the DPP
+    form keeps the (cosh, sinh) of each site's four bonds in registers.  Against the streaming iteration and the oracle's M."""
+    from elphdynamics_amd import lattice as lat
+    from elphdynamics_amd import configs, models, synth
+    m = models.HolsteinModel(lat.Lattice(1, 16, 16, 1), 4.0, 0.1, tol=1e-13, maxiter=10000)
+    rng = np.random.default_rng(5)
+    m.assign_t_(1.0, 1, 1, (1, 0, 0), stddev=0.1, rng=rng)
+    m.assign_t_(1.0, 1, 1, (0, 1, 0), stddev=0.1, rng=rng)
+    m.assign_omega_(1.0); m.assign_lambda_(1.0); m.assign_mu_(0.0)
+    m.initialize_model_()
+    m.x[:] = synth.phonon_field(m.Nph, m.Ltau, 4.0, 0.1, omega=1.0, lam=1.0, seed=11)
+    models.update_model_(m)
+    usable, T, W, G = _wg_info(m)
+    assert usable == 1 and T == 2
+    R, B = configs.rhs(m, 3)
+    out = {}
+    for name, env in (("stream", {"ELPH_NO_WG": "1"}), ("dpp2", {}), ("dpp1", {"ELPH_WG_T": "1"}), ("lds", {"ELPH_WG_NO_DPP": "1"})):
+        for k in ("ELPH_NO_WG", "ELPH_WG_T", "ELPH_WG_NO_DPP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B)
+        assert not fl.any(), name
+        out[name] = X
+    for name in ("dpp2", "dpp1", "lds"):
+        assert rel(out[name], out["stream"]) < 1e-11, (name, rel(out[name], out["stream"]))
+    # M x = R for the oracle's M (x solves Mt M x = Mt R)
+    om = _oracle_model(oracle, m)
+    for i in range(3):
+        assert rel(oracle.mulM(om, out["dpp2"][i]), R[i]) < 1e-9
+    m.close()
+
+
 def test_wg_resident_cg_with_more_teams_than_the_chip_holds():
     """40 right-hand sides of config C = 400 workgroups for 256 CUs: teams at the dispatch frontier wait for their members; every
     solution equals the single solve of that right-hand side bit for bit."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Workgroup-resident CG (cg_wg.hip) vs the two-kernel streaming iteration: agreement and time per iteration.
-usage: python3 tools/time_wg.py [config tags]"""
+usage: python3 tools/time_wg.py [config tags; a trailing ~ adds hopping disorder (Holstein: stddev 0.1)]"""
 import ctypes as C
 import os
 import sys
@@ -14,7 +14,7 @@ from elphdynamics_amd._lib import check                    # noqa: E402
 
 lib = _lib.load()
 for tag in (sys.argv[1:] or ["b", "B", "C", "D", "E"]):
-    m = configs.make_model(tag, tol=1e-5)
+    m = configs.make_model(tag.rstrip("~"), tol=1e-5, t_stddev=0.1 if tag.endswith("~") else 0.0)
     us, T, W, G = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     check(lib.elph_bench_wg_info(m._h, 1, C.byref(us), C.byref(T), C.byref(W), C.byref(G)))
     print(f"== {tag}: N={m.Nsites} Ltau={m.Ltau} wg usable={us.value} T={T.value} W={W.value} G={G.value}", flush=True)
