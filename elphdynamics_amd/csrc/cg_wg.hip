@@ -31,7 +31,6 @@
 namespace wg {
 
 constexpr int MC = 4;                       // colours of the lane program (square / honeycomb / chain lattices)
-#define ELPH_WG_T4_MIN_RHS 48
 typedef unsigned long long u64;
 
 template <int NPL>
@@ -114,55 +113,105 @@ __device__ __forceinline__ void sweepN(double *buf, const unsigned (&ij)[MC * ((
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // (bound_ctrl set: every control used here reads a valid lane, and the destination then needs no initialising move)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 
-// Hopping of the DPP form.  UNI: one (cosh, sinh) for every bond; otherwise the pair of the bond that covers each of the lane's
-// four sites in each of the four colours (Holstein with hopping disorder) — gathered once, before the loop.
+// Partner value of the x-odd colour: odd lanes take lane + 1's v, even lanes lane - 1's (rows of 16, cyclic).  One DPP move
+// (row_ror:15) and one v_cndmask with the DPP modifier on its other source (row_ror:1) per word — the compiler's form is two moves
+// and a plain select (6 instead of 4 vector-ALU instructions per f64; a fifth of the mat-vec's instructions at 4 slices per wave).
+// s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states, which the compiler cannot see in here.
+__device__ __forceinline__ double dpp_pair_odd_up(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int tl, th;
+    asm volatile("s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t"
+                 "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
+                 "s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %2 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_mov_b32_dpp %1, %3 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_cndmask_b32_dpp %0, %2, %0, vcc row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_cndmask_b32_dpp %1, %3, %1, vcc row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                 : "=&v"(tl), "=&v"(th) : "v"(lo), "v"(hi) : "vcc");
+    return __hiloint2double(th, tl);
+}
+
+// Hopping of the DPP form.  Disordered hopping: the (cosh, sinh) of the bond that covers each of the lane's four sites in each of
+// the four colours, gathered once before the loop.  UNI (one hopping for every bond — the example decks): every site has exactly
+// one bond per colour, so a colour is  c (I + th P_colour)  with th = sinh/cosh, and a sweep  c^4 prod_colours (I + th P_colour):
+// the sweep applies the bracket (ONE fma per site and colour instead of mul + fma) and hands the factor k4 = c^4 to the caller,
+// who folds it into the constant of the fma that consumes the swept vector.  Same operator in real arithmetic; against the
+// reference's  c y_i + s y_j  it differs by rounding only (a few ulp per sweep; parity tolerances in tests/ unchanged).
+// f64 instructions are what the two waves of a SIMD compete for in this kernel (profiles/r02/wg_phase_stamps.log).
 // (SSH — one table set per time slice — was built and measured in this form too: 64 more registers per slice, one slice per
 // wave, 9.4 us per iteration against 9.2 us of the lane-program form, whose time the team of 20 workgroups sets; not kept.)
 template <bool UNI>
 struct SqCtx {
-    double c[UNI ? 1 : 4][UNI ? 1 : 4], s[UNI ? 1 : 4][UNI ? 1 : 4];
+    double c[UNI ? 1 : 4][UNI ? 1 : 4], s[UNI ? 1 : 4][UNI ? 1 : 4];   // UNI: s[0][0] = th, c[0][0] unused
+    double k4;                                                // factor the caller applies to a swept vector (1 unless UNI)
     bool xodd; int up, dn;                                    // partner lanes of the y-odd colour: (l + 16) & 63, (l - 16) & 63
-    __device__ __forceinline__ double C(int col, int k) const { return c[UNI ? 0 : col][UNI ? 0 : k]; }
-    __device__ __forceinline__ double S(int col, int k) const { return s[UNI ? 0 : col][UNI ? 0 : k]; }
+    // new value of a site with value v whose partner holds t
+    __device__ __forceinline__ double upd(int col, int k, double v, double t) const {
+        if constexpr (UNI) return v + s[0][0] * t;
+        else return c[UNI ? 0 : col][UNI ? 0 : k] * v + s[UNI ? 0 : col][UNI ? 0 : k] * t;
+    }
 };
+
+// One colour on CNT (1 or 2) slabs, as one scheduling region: the cross-lane moves of the slabs first, then their arithmetic.
+// Left to itself the scheduler (256 registers, none to spare) funnels every ds_bpermute through ONE temporary and waits for
+// each; with every slab's moves hoisted to the front it spills instead.
+template <int CNT, int COL, bool UNI>
+__device__ __forceinline__ void sq_colour(double (*v)[4], const SqCtx<UNI> &X) {
+    constexpr int DS = 0x080, VALU = 0x002, ARITH = UNI ? 1 : 2;          // ARITH: vector-ALU instructions per site update
+    if constexpr (COL == 0) {                                // x even <-> x + 1: lane ^ 1
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double t = dpp_f64<0xB1>(v[n][k]); v[n][k] = X.upd(0, k, v[n][k], t); }
+    } else if constexpr (COL == 1) {                         // x odd <-> x + 1 (mod 16): odd lanes look up, even lanes look down
+        // (dpp_pair_odd_up: two vector-ALU instructions per word.  ds_bpermute does it in one instruction and no vector-ALU slot — measured
+        //  SLOWER, 7.5 vs 6.8 us per iteration at 4 slices per wave: the LDS crossbar is one per CU, ~6 cycles per ds_bpermute
+        //  with 8 waves asking (tools/probes/f64_rate_probe.cpp), the vector ALUs are four)
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[n][k] = X.upd(1, k, v[n][k], dpp_pair_odd_up(v[n][k]));
+            }
+    } else if constexpr (COL == 2) {                         // y even <-> y + 1: (k0,k1), (k2,k3) of the lane itself
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            const double n0 = X.upd(2, 0, v[n][0], v[n][1]), n1 = X.upd(2, 1, v[n][1], v[n][0]);
+            const double n2 = X.upd(2, 2, v[n][2], v[n][3]), n3 = X.upd(2, 3, v[n][3], v[n][2]);
+            v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
+        }
+    } else {                                                 // y odd <-> y + 1 (mod 16): (k1,k2) in the lane, k3 <-> next row group's k0
+        double t3[CNT], t0[CNT];
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) { t3[n] = __shfl(v[n][0], X.up, WAVE); t0[n] = __shfl(v[n][3], X.dn, WAVE); }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            const double n1 = X.upd(3, 1, v[n][1], v[n][2]), n2 = X.upd(3, 2, v[n][2], v[n][1]);
+            v[n][0] = X.upd(3, 0, v[n][0], t0[n]); v[n][3] = X.upd(3, 3, v[n][3], t3[n]);
+            v[n][1] = n1; v[n][2] = n2;
+        }
+        __builtin_amdgcn_sched_group_barrier(DS, 4 * CNT, 0);
+        __builtin_amdgcn_sched_group_barrier(VALU, 4 * ARITH * CNT, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS, int N0, int COL, bool UNI>
+__device__ __forceinline__ void sq_pairs(double (&v)[NS][4], const SqCtx<UNI> &X) {
+    sq_colour<(N0 + 1 < NS) ? 2 : 1, COL, UNI>(&v[N0], X);
+    if constexpr (N0 + 2 < NS) sq_pairs<NS, N0 + 2, COL, UNI>(v, X);
+}
 
 template <int NS, bool REVERSE, bool UNI>
 __device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx<UNI> &X) {
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-        const int col = REVERSE ? 3 - cc : cc;
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-            if (col == 0) {                                      // x even <-> x + 1: lane ^ 1
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { const double t = dpp_f64<0xB1>(v[n][k]); v[n][k] = X.C(0, k) * v[n][k] + X.S(0, k) * t; }
-            } else if (col == 1) {                               // x odd <-> x + 1 (mod 16): odd lanes look up, even lanes look down
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double a = dpp_f64<0x12F>(v[n][k]);    // row_ror:15 = value of lane + 1 (mod 16)
-                    const double b = dpp_f64<0x121>(v[n][k]);    // row_ror:1  = value of lane - 1 (mod 16)
-                    v[n][k] = X.C(1, k) * v[n][k] + X.S(1, k) * (X.xodd ? a : b);
-                }
-            } else if (col == 2) {                               // y even <-> y + 1: (k0,k1), (k2,k3) of the lane itself
-                const double n0 = X.C(2, 0) * v[n][0] + X.S(2, 0) * v[n][1], n1 = X.C(2, 1) * v[n][1] + X.S(2, 1) * v[n][0];
-                const double n2 = X.C(2, 2) * v[n][2] + X.S(2, 2) * v[n][3], n3 = X.C(2, 3) * v[n][3] + X.S(2, 3) * v[n][2];
-                v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
-            } else {                                             // y odd <-> y + 1 (mod 16): (k1,k2) in the lane, k3 <-> next row group's k0
-                const double t3 = __shfl(v[n][0], X.up, WAVE), t0 = __shfl(v[n][3], X.dn, WAVE);
-                const double n1 = X.C(3, 1) * v[n][1] + X.S(3, 1) * v[n][2], n2 = X.C(3, 2) * v[n][2] + X.S(3, 2) * v[n][1];
-                v[n][0] = X.C(3, 0) * v[n][0] + X.S(3, 0) * t0; v[n][3] = X.C(3, 3) * v[n][3] + X.S(3, 3) * t3;
-                v[n][1] = n1; v[n][2] = n2;
-            }
-            // keep the scheduler from hoisting every slab's cross-lane moves to the front (their temporaries would all be live at
-            // once: measured as spills with five slabs in flight); two slabs interleave, which is all the DPP latency needs
-            if (NS > 2) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+    if constexpr (!REVERSE) { sq_pairs<NS, 0, 0, UNI>(v, X); sq_pairs<NS, 0, 1, UNI>(v, X); sq_pairs<NS, 0, 2, UNI>(v, X); sq_pairs<NS, 0, 3, UNI>(v, X); }
+    else                    { sq_pairs<NS, 0, 3, UNI>(v, X); sq_pairs<NS, 0, 2, UNI>(v, X); sq_pairs<NS, 0, 1, UNI>(v, X); sq_pairs<NS, 0, 0, UNI>(v, X); }
 }
 
 // Diagnostic build (-DELPH_WG_STAMPS, tools/time_wg_phases.py): wave 0 of workgroup 0 of right-hand side 0 adds the wall-clock
@@ -170,8 +219,11 @@ __device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx<UNI> &
 #ifdef ELPH_WG_STAMPS
 __device__ unsigned long long g_wg_stamps[16];
 #define STAMP_DECL long long _ts = wall_clock64(); unsigned long long _acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define STAMP(k) do { const long long _n = wall_clock64(); _acc[k] += (unsigned long long)(_n - _ts); _ts = _n; } while (0)
-#define STAMP_OUT(iters) do { if (rhs == 0 && g == 0 && wv == 0 && lane == 0) { for (int _k = 0; _k < 10; ++_k) g_wg_stamps[_k] = _acc[_k]; g_wg_stamps[10] = (unsigned long long)(iters); } } while (0)
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const long long _n = wall_clock64(); _acc[k] += (unsigned long long)(_n - _ts); _ts = _n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef ELPH_WG_STAMP_WAVE
+#define ELPH_WG_STAMP_WAVE 0
+#endif
+#define STAMP_OUT(iters) do { if (rhs == 0 && g == 0 && wv == ELPH_WG_STAMP_WAVE && lane == 0) { for (int _k = 0; _k < 10; ++_k) g_wg_stamps[_k] = _acc[_k]; g_wg_stamps[10] = (unsigned long long)(iters); } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(k)
@@ -450,8 +502,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     if constexpr (SQ) {
         X.xodd = (lane & 1) != 0; X.up = (lane + 16) & 63; X.dn = (lane + 48) & 63;
         if constexpr (UNI) {
-            X.c[0][0] = m.c_uni; X.s[0][0] = m.s_uni;
+            X.c[0][0] = m.c_uni; X.s[0][0] = m.s_uni / m.c_uni; X.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
         } else {
+            X.k4 = 1.0;
 #pragma unroll
             for (int col = 0; col < 4; ++col)
 #pragma unroll
@@ -515,6 +568,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         normb = sqrt(bb); eps0 = 1.0; eps = 1.0; rho = bb; kmin = 0.0;
         wg_barrier();                                   // bc[0] is rewritten by the first meeting of the loop
     }
+    // screens of the stop test (see there)
+    const double rr_far = (P.tol * normb) * (P.tol * normb) * 1.000001, y_num = 4.0 * (eps0 * normb) * (eps0 * normb);
+    const double it_kappa = 0.17 * sqrt(P.kmax);
     STAMP_DECL;
     for (long long seq = 0;; ++seq) {
         const unsigned epoch = (unsigned)seq + (SHARD ? 2u : 1u);
@@ -531,7 +587,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             sq_sweepN<T + 1, false, UNI>(w, X);
 #pragma unroll
             for (int k = 0; k <= T; ++k) {
-                const double sg = sgn(wrap(t0 + k));
+                const double sg = UNI ? sgn(wrap(t0 + k)) * X.k4 : sgn(wrap(t0 + k));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[k][q] = p[k + 1][q] - sg * w[k][q];
             }
@@ -546,9 +602,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 sq_sweepN<RB, true, UNI>(gq, X);
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    const double sg = sgn(wrap(t0 + j0 + i + 1));
+                    const double sg = UNI ? sgn(wrap(t0 + j0 + i + 1)) * X.k4 : sgn(wrap(t0 + j0 + i + 1));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) w[j0 + i][q] = w[j0 + i][q] - sg * EXPV(j0 + i + 1, q) * gq[i][q];      // z(t0+j0+i)
+                    for (int q = 0; q < 4; ++q) w[j0 + i][q] = w[j0 + i][q] - sg * (EXPV(j0 + i + 1, q) * gq[i][q]);    // z(t0+j0+i)
                 }
             }
         } else {
@@ -594,6 +650,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         // then hands the total to its workgroup through LDS
         if (lane == 0) partA[wv] = acc;
         wg_barrier();
+        STAMP(2);
         double pap;
         if constexpr (SHARD) {
             if (wv == 0) {
@@ -631,7 +688,6 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             pap = bc[0];
         }
         STAMP(1);
-        STAMP(2);
         const double alpha = rho / pap;
         // ---- x += alpha p (to memory), r -= alpha z, r.r; show the boundary slices of the new r ---------------------------
         double a = 0.0, rn[T][NPL];
@@ -745,11 +801,20 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         STAMP(5);
         STAMP(6);
         // ---- stop test of iteration it = seq + 1 (IterativeSolvers.jl:286-295) ---------------------------------------------
+        // eps = |r|/|b| < tol, kappa_min = max_j (2j / ln(2 eps0/eps_j))^2 > kappa_max, j = maxiter — a square root, two divisions and
+        // a logarithm in f64 (~150 instructions in EVERY wave: half a mat-vec of this kernel).  Two comparisons screen them out
+        // while no decision is near:  r.r well above (tol |b|)^2 rules out the first;  (2 eps0/eps)^2 = y outside [1/2, 2] means
+        // |ln(2 eps0/eps)| > 0.34, which rules out the second while 2j < 0.34 sqrt(kappa_max).  Near a decision, on the last
+        // iteration and with a residual history the exact arithmetic of the reference runs (eps, and kappa_min of THAT iteration:
+        // an iteration stops on kappa only through its own term, the earlier ones did not stop).
+        // (fixed_iters — measurement — takes the tolerance screen as passed: a solve would have stopped there; its iterations
+        // cost what the iterations of a running solve cost.)
         const long long it = seq + 1;
+        const bool fixed = R.fixed_iters > 0;
         int done = 0;
-        if (R.fixed_iters > 0) {
-            if (it >= R.fixed_iters) done = 3;
-        } else {
+        const bool screened = !P.record_hist && it < (fixed ? R.fixed_iters : P.maxiter) && (fixed || rr > rr_far) &&
+                              (rr + rr <= y_num || rr >= y_num + y_num) && (double)it < it_kappa;
+        if (!screened) {
             eps = sqrt(rr) / normb;
             const double qq = 2.0 * (double)it / log(2.0 * eps0 / eps);
             const double val = qq * qq;
@@ -757,6 +822,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             if (eps < P.tol) done = 1;
             else if (kmin > P.kmax) done = 2;
             else if (it >= P.maxiter) done = 3;
+            if (fixed) done = (it >= R.fixed_iters) ? 3 : 0;
             if (g == 0 && wv == 0 && lane == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + it] = eps;
         }
         STAMP(7);
@@ -814,21 +880,33 @@ static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
 }
 
 // T slices per wave: what the register file takes at two waves per SIMD — lane-program form 2 for site phonons with <= 4 sites
-// per lane, else 1; DPP form 2 (6.5 us per iteration, 24 right-hand sides fill the chip), or 4 for batches of
-// ELPH_WG_T4_MIN_RHS right-hand sides and more (8.5 us per iteration, but 48 right-hand sides per round: 10.5 vs 6.5 M mat-vecs/s); W = the largest divisor of Ltau / T that is <= 8 waves; G = workgroups per
-// right-hand side (<= 32: the 2G record granules of a meeting are polled by one wave instruction)
+// per lane, else 1; DPP form 2 (config C: 5.8 us per iteration, 24 right-hand sides fill the chip), or 4 for batches that the
+// 2-slice shape cannot hold in one round (6.8 us per iteration, but 48 right-hand sides per round: 14 vs 7.3 M mat-vecs/s);
+// W = the largest divisor of Ltau / T that is <= 8 waves; G = workgroups per right-hand side (<= 32: the 2G record granules of
+// a meeting are polled by one wave instruction)
+static int largest_divisor_le8(int n, int cap = 8) { for (int w = std::min(cap, n); w >= 1; --w) if (n % w == 0) return w; return 1; }
+
 static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, int nrhs, Shape *out) {
     const int L = (int)h->L;
     const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m);
     const int cand[3] = {4, 2, 1};
     for (int T : cand) {
         if (forceT && T != forceT) continue;
-        if (T == 4 && (!sq || !m.uniform || (forceT != 4 && nrhs < ELPH_WG_T4_MIN_RHS))) continue;
+        if (T == 4) {
+            if (!sq || !m.uniform) continue;
+            if (forceT != 4) {                           // only when 2 slices per wave would need a second round: 8 XCDs x (32 CUs / G2) teams
+                if (L % 2) continue;
+                const int G2 = (L / 2) / largest_divisor_le8(L / 2);
+                if (G2 > 32 || nrhs <= 8 * (32 / G2)) continue;
+            }
+        }
         if (T == 2 && !sq && (ssh || h->npl > 4 || (h->npl == 4 && !m.uniform))) continue;
         if (L % T) continue;
         const int Wt = L / T;
         int W = 0;
-        for (int w = std::min(8, Wt); w >= 1; --w) if (Wt % w == 0) { W = w; break; }
+        const char *ew = getenv("ELPH_WG_W");              // (experiments: cap on the waves per workgroup)
+        const int wmax = ew ? std::max(1, atoi(ew)) : 8;
+        for (int w = std::min(wmax, Wt); w >= 1; --w) if (Wt % w == 0) { W = w; break; }
         const int G = Wt / W;
         if (G > 32) continue;
         if (G > 1 && W < 2) continue;                    // (a wave polls at most ONE neighbouring workgroup's boundary slice)

@@ -12,11 +12,11 @@ from elphdynamics_amd import _lib, configs          # noqa: E402
 from elphdynamics_amd._lib import check            # noqa: E402
 
 lib = _lib.load()
-NAMES = ["mat-vec", "barrier1+LDS sum", "team meeting 1", "r update + halo stores", "barrier2", "x update issue", "LDS sum + team meeting 2",
-         "stop test", "halo loads + p update", "(loop top)"]
+NAMES = ["mat-vec + p.z wave sum", "meeting 1 (p.z)", "barrier", "x, r updates + boundary stores", "barrier", "meeting 2 (r.r, halo slices)", "-",
+         "stop test", "p update", "(loop top)"]
 for tag in (sys.argv[1:] or ["b", "C"]):
     m = configs.make_model(tag, tol=1e-5)
-    for nr in (1, 8):
+    for nr in (1, 24, 48):
         _, Bs = configs.rhs(m, nr)
         ms = C.c_double()
         reps = 1000
