@@ -1142,10 +1142,12 @@ def test_wg_resident_cg_dpp_form_with_hopping_disorder(oracle, monkeypatch):
     m.close()
 
 
-def test_wg_resident_cg_with_more_teams_than_the_chip_holds():
-    """40 right-hand sides of config C = 400 workgroups for 256 CUs: teams at the dispatch frontier wait for their members; every
-    solution equals the single solve of that right-hand side bit for bit."""
+def test_wg_resident_cg_with_more_teams_than_the_chip_holds(monkeypatch):
+    """40 right-hand sides of config C at 2 slices per wave (pinned: a batch this size would pick 4) = 400 workgroups for 256 CUs:
+    teams at the dispatch frontier wait for their members; every solution equals the single solve of that right-hand side bit
+    for bit."""
     from elphdynamics_amd import configs, models
+    monkeypatch.setenv("ELPH_WG_T", "2")
     m = configs.make_model("C", tol=1e-5)
     assert _wg_info(m)[0] == 1
     nrhs = 40
@@ -1161,8 +1163,8 @@ def test_wg_resident_cg_with_more_teams_than_the_chip_holds():
 
 
 def test_wg_resident_cg_large_batch_shape():
-    """From 48 right-hand sides on the DPP form runs 4 slices per wave (48 right-hand sides per round instead of 24): another
-    summation tree, the same algorithm — iteration counts within 1 of the single solves, solutions equal to the tolerance."""
+    """A batch that 2 slices per wave cannot hold in one round (config C: more than 24 right-hand sides) runs 4 slices per wave on
+    the DPP form (48 right-hand sides per round): another summation tree, the same algorithm — iteration counts within 1 of the single solves, solutions equal to the tolerance."""
     from elphdynamics_amd import configs, models
     m = configs.make_model("C", tol=1e-5)
     nrhs = 50
