@@ -32,6 +32,34 @@ __device__ __forceinline__ CgState ld_state(const CgState *p) {
     return s;
 }
 
+// ---- DPP moves of f64 values (cg_wg.hip, the 16 x 16 Chebyshev kernel) -------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // (bound_ctrl set: every control used here reads a valid lane, and the destination then needs no initialising move)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Partner value of the x-odd colour: odd lanes take lane + 1's v, even lanes lane - 1's (rows of 16, cyclic).  One DPP move
+// (row_ror:15) and one v_cndmask with the DPP modifier on its other source (row_ror:1) per word — the compiler's form is two moves
+// and a plain select (6 instead of 4 vector-ALU instructions per f64; a fifth of the mat-vec's instructions at 4 slices per wave).
+// s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states, which the compiler cannot see in here.
+__device__ __forceinline__ double dpp_pair_odd_up(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int tl, th;
+    asm volatile("s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t"
+                 "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
+                 "s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %2 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_mov_b32_dpp %1, %3 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_cndmask_b32_dpp %0, %2, %0, vcc row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_cndmask_b32_dpp %1, %3, %1, vcc row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                 : "=&v"(tl), "=&v"(th) : "v"(lo), "v"(hi) : "vcc");
+    return __hiloint2double(th, tl);
+}
+
 __device__ __forceinline__ double wave_sum2(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);

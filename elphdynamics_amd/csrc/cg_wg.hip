@@ -110,33 +110,6 @@ __device__ __forceinline__ void sweepN(double *buf, const unsigned (&ij)[MC * ((
 //           y-bonds  pair registers of one lane (k, k+1), except (k = 3, next row group's k = 0): one wave shuffle each way.
 // A sweep is ~50 VALU instructions and 4 ds_bpermute; the lane-program form is 4 LDS round trips of 16 reads + 16 writes.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // (bound_ctrl set: every control used here reads a valid lane, and the destination then needs no initialising move)
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-
-// Partner value of the x-odd colour: odd lanes take lane + 1's v, even lanes lane - 1's (rows of 16, cyclic).  One DPP move
-// (row_ror:15) and one v_cndmask with the DPP modifier on its other source (row_ror:1) per word — the compiler's form is two moves
-// and a plain select (6 instead of 4 vector-ALU instructions per f64; a fifth of the mat-vec's instructions at 4 slices per wave).
-// s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states, which the compiler cannot see in here.
-__device__ __forceinline__ double dpp_pair_odd_up(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    int tl, th;
-    asm volatile("s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t"
-                 "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
-                 "s_nop 1\n\t"
-                 "v_mov_b32_dpp %0, %2 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "v_mov_b32_dpp %1, %3 row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "v_cndmask_b32_dpp %0, %2, %0, vcc row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "v_cndmask_b32_dpp %1, %3, %1, vcc row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-                 : "=&v"(tl), "=&v"(th) : "v"(lo), "v"(hi) : "vcc");
-    return __hiloint2double(th, tl);
-}
-
 // Hopping of the DPP form.  Disordered hopping: the (cosh, sinh) of the bond that covers each of the lane's four sites in each of
 // the four colours, gathered once before the loop.  UNI (one hopping for every bond — the example decks): every site has exactly
 // one bond per colour, so a colour is  c (I + th P_colour)  with th = sinh/cosh, and a sweep  c^4 prod_colours (I + th P_colour):
