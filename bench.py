@@ -360,6 +360,8 @@ def main():
                 out[f"batch_time_to_solution_tol1e-5_nrhs{nrhs}_chains{nchains}"] = {"error": str(e)}
         if nchains > 1:
             models.update_model_(m)          # back to one configuration for the secondary single-matrix measurements
+            if args.precond:                 # (its expansion went with the chains' matrices)
+                pc.setup_(P, rng=np.random.default_rng(7 + rank))
         # ---- secondary: the same step at other batch sizes (short runs)
         if not args.no_sweep:
             sweep = {}

@@ -59,6 +59,30 @@ __device__ __forceinline__ double dpp_pair_odd_up(double v) {
                  : "=&v"(tl), "=&v"(th) : "v"(lo), "v"(hi) : "vcc");
     return __hiloint2double(th, tl);
 }
+// the same for the four values of a slab: the mask and the wait states once
+__device__ __forceinline__ void dpp_pair_odd_up4(double (&t)[4], const double (&v)[4]) {
+    int a[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[2 * k] = __double2loint(v[k]); a[2 * k + 1] = __double2hiint(v[k]); }
+#define ELPH_DPP_UP "row_ror:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define ELPH_DPP_DN "row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+    asm volatile("s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t"
+                 "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
+                 "s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %8 " ELPH_DPP_UP "v_mov_b32_dpp %1, %9 " ELPH_DPP_UP "v_mov_b32_dpp %2, %10 " ELPH_DPP_UP
+                 "v_mov_b32_dpp %3, %11 " ELPH_DPP_UP "v_mov_b32_dpp %4, %12 " ELPH_DPP_UP "v_mov_b32_dpp %5, %13 " ELPH_DPP_UP
+                 "v_mov_b32_dpp %6, %14 " ELPH_DPP_UP "v_mov_b32_dpp %7, %15 " ELPH_DPP_UP
+                 "v_cndmask_b32_dpp %0, %8, %0, vcc " ELPH_DPP_DN "v_cndmask_b32_dpp %1, %9, %1, vcc " ELPH_DPP_DN
+                 "v_cndmask_b32_dpp %2, %10, %2, vcc " ELPH_DPP_DN "v_cndmask_b32_dpp %3, %11, %3, vcc " ELPH_DPP_DN
+                 "v_cndmask_b32_dpp %4, %12, %4, vcc " ELPH_DPP_DN "v_cndmask_b32_dpp %5, %13, %5, vcc " ELPH_DPP_DN
+                 "v_cndmask_b32_dpp %6, %14, %6, vcc " ELPH_DPP_DN "v_cndmask_b32_dpp %7, %15, %7, vcc row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "vcc");
+#undef ELPH_DPP_UP
+#undef ELPH_DPP_DN
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = __hiloint2double(o[2 * k + 1], o[2 * k]);
+}
 
 __device__ __forceinline__ double wave_sum2(double v) {
 #pragma unroll

@@ -147,11 +147,12 @@ __device__ __forceinline__ void sq_colour(double (*v)[4], const SqCtx<UNI> &X) {
         //  SLOWER, 7.5 vs 6.8 us per iteration at 4 slices per wave: the LDS crossbar is one per CU, ~6 cycles per ds_bpermute
         //  with 8 waves asking (tools/probes/f64_rate_probe.cpp), the vector ALUs are four)
 #pragma unroll
-        for (int n = 0; n < CNT; ++n)
+        for (int n = 0; n < CNT; ++n) {
+            double t[4];
+            dpp_pair_odd_up4(t, v[n]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[n][k] = X.upd(1, k, v[n][k], dpp_pair_odd_up(v[n][k]));
-            }
+            for (int k = 0; k < 4; ++k) v[n][k] = X.upd(1, k, v[n][k], t[k]);
+        }
     } else if constexpr (COL == 2) {                         // y even <-> y + 1: (k0,k1), (k2,k3) of the lane itself
 #pragma unroll
         for (int n = 0; n < CNT; ++n) {
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = SQ ? ((lane & 15) + 64 * (lane >> 4) + 16 * q) : lane + q * WAVE;
-        live[q] = s < N;
+        live[q] = SQ || s < N;                            // (DPP form: N = 256 fills every register of every lane — no selects in the sums)
         own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : live[q];
         sc[q] = live[q] ? s : N - 1;
     }
