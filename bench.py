@@ -279,8 +279,8 @@ def main():
                 "bytes_per_launch": built_wg,
                 "bytes_model": "compulsory bytes of the kernel as built: r0, p0, x0 in, x, r out (5 vectors x 8 B x Ndim x nrhs) + "
                                "exp(-dtau V) once per chain, per LAUNCH of K iterations — the Krylov vectors stay in registers / LDS",
-                "binding_resource": "on-chip latency: two team meetings through L2 per iteration (~1.8 us each at 10 workgroups per team) + the "
-                                    "checkerboard sweeps; not HBM (fraction small by design)",
+                "binding_resource": "on-chip latency and f64 issue: two team meetings through L2 per iteration (1.2 + 1.4 us at 5 workgroups per "
+                                    "team) + the compute phases (~4.2 us for the two waves of a SIMD); not HBM (fraction small by design)",
                 "traffic_note": "memory-side traffic of this kernel is its SYNCHRONISATION: write-through record / boundary granules and the "
                                 "polls of them (they bypass L2 by design), ~40 MB per iteration of 288 right-hand sides — not vector data",
                 # the arithmetic of the same launch against the f64 vector peak (the sweeps are v_fma_f64, not MFMA — same peak figure):
