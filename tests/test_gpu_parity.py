@@ -363,6 +363,31 @@ def test_kpm_vs_oracle(oracle, tag):
     m.close()
 
 
+@pytest.mark.parametrize("tag", ["B", "C"])
+def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
+    """Hopping disorder (assign_t! with a standard deviation, HolsteinModels.jl:427-447): the register-exchange Chebyshev kernels
+    carry one (cosh, sinh) per site and colour instead of two scalars — the row layout on 16 x 16, one site per lane on 8 x 8."""
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    m = configs.make_model(tag, tol=1e-5, t_stddev=0.1)
+    om = _oracle_model(oracle, m)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    oP = oracle.make_kpm(om, n=20, buf=0.05, c1=1.0, c2=1.0)
+    rng = np.random.default_rng(13)
+    e_min, e_max = oracle.kpm_setup(oP, b_max=rng.standard_normal(m.Nsites), b_min=rng.standard_normal(m.Nsites))
+    pc.setup_(P, e_min=e_min, e_max=e_max)
+    assert P.active and oP.active == 1
+    R, B = configs.rhs(m, 1)
+    z = np.empty(m.Ndim)
+    pc.kpm_ldiv_(z, P, np.ascontiguousarray(R[0]))
+    assert rel(z, oracle.kpm_apply(oP, np.ascontiguousarray(R[0]))) < 1e-11
+    b = np.ascontiguousarray(B[0])
+    x = np.zeros(m.Ndim)
+    it, hist = models.solve_(x, m, b, P=P, tol=1e-5, history=True)
+    xo, ito, histo = oracle.cg_solve(om, b, tol=1e-5, maxiter=10000, P=oP, history=True)
+    assert it == ito and rel(x, xo) < 1e-8
+    m.close()
+
+
 def test_kpm_fallback_to_unpreconditioned(oracle):
     """Models.jl:129-133: a preconditioned solve that fails (maxiter) is redone without P and 10x maxiter."""
     from elphdynamics_amd import configs, models, preconditioners as pc
