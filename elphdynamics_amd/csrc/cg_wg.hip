@@ -955,6 +955,26 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     wg::Shape sh;
     ModelDev m = elph_model_dev(h);
     if (!wg::pick_shape(h, m, et ? atoi(et) : 0, nrhs, &sh)) return ELPH_OK;
+    // Which form is faster for THIS batch.  A round of the resident kernel holds 8 x (32 / G) right-hand sides (one team per G CUs
+    // of an XCD) and a batch takes ceil(nrhs / that) rounds of one iteration time each; the two-kernel streaming form is
+    // HBM-bound and linear in the batch.  Both fitted to measurements on configs B, C, D, E (tools/time_forms.py,
+    // profiles/r02/time_forms.log; us per iteration of the batch):
+    //   resident  = rounds x (1.85 + 0.2 G + 0.9 T npl [x 0.3 in the DPP form])
+    //   streaming = 8 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
+    // C: resident at every batch (13 M against 3.7 M mat-vecs/s at 256); D (teams of 15): streaming from ~64 right-hand sides on;
+    // E (teams of 20, 8 right-hand sides per round): streaming from ~16 on (3.2 M against 1.8 M at 256).  A deterministic rule
+    // (never a timing at run time): which form runs decides the last bits of a solution.
+    // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
+    {
+        const char *ea = getenv("ELPH_WG_ALWAYS");
+        if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
+            const int per_round = 8 * std::max(1, 32 / sh.G);
+            const double rounds = (double)((nrhs + per_round - 1) / per_round);
+            const double t_res = rounds * (1.85 + 0.2 * sh.G + 0.9 * sh.T * h->npl * (sh.sq ? 0.3 : 1.0));
+            const double t_str = 8.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
+            if (t_res > t_str) return ELPH_OK;
+        }
+    }
     const size_t HS = (size_t)h->npl * WAVE;
     const size_t n_slots = (size_t)nrhs * 2 * 64, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
