@@ -960,9 +960,9 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // HBM-bound and linear in the batch.  Both fitted to measurements on configs B, C, D, E (tools/time_forms.py,
     // profiles/r02/time_forms.log; us per iteration of the batch):
     //   resident  = rounds x (1.85 + 0.2 G + 0.9 T npl [x 0.3 in the DPP form])
-    //   streaming = 8 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
+    //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
     // C: resident at every batch (13 M against 3.7 M mat-vecs/s at 256); D (teams of 15): streaming from ~64 right-hand sides on;
-    // E (teams of 20, 8 right-hand sides per round): streaming from ~16 on (3.2 M against 1.8 M at 256).  A deterministic rule
+    // E (teams of 20, 8 right-hand sides per round): streaming from ~24 on (3.2 M against 1.8 M at 256).  A deterministic rule
     // (never a timing at run time): which form runs decides the last bits of a solution.
     // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
     {
@@ -971,7 +971,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
             const double t_res = rounds * (1.85 + 0.2 * sh.G + 0.9 * sh.T * h->npl * (sh.sq ? 0.3 : 1.0));
-            const double t_str = 8.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
+            const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
         }
     }
