@@ -874,7 +874,11 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
                 if (G2 > 32 || nrhs <= 8 * (32 / G2)) continue;
             }
         }
-        if (T == 2 && !sq && (ssh || h->npl > 4 || (h->npl == 4 && !m.uniform))) continue;
+        if (T == 2 && !sq && (ssh || h->npl > 5 || (h->npl >= 4 && !m.uniform))) continue;
+        if (T == 2 && !sq && h->npl == 5 && forceT != 2) {   // 5 sites per lane (honeycomb L = 12): 2 slices per wave are 8 % slower per
+            const int G1 = L / largest_divisor_le8(L);    // iteration (10.0 vs 9.3 us) but hold 24 instead of 16 right-hand sides per round
+            if (G1 <= 32 && nrhs <= 8 * (32 / G1)) continue;
+        }
         if (L % T) continue;
         const int Wt = L / T;
         int W = 0;
@@ -922,7 +926,7 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
         }
     }
     if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, false>(h, sh, grid, B, m, R);
-    if constexpr (NPL <= 4) {
+    if constexpr (NPL <= 5) {
         if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false, false>(h, sh, grid, B, m, R);
     }
     return m.uniform ? launch_k<NPL, 1, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 1, false, false, false>(h, sh, grid, B, m, R);
@@ -959,9 +963,9 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // of an XCD) and a batch takes ceil(nrhs / that) rounds of one iteration time each; the two-kernel streaming form is
     // HBM-bound and linear in the batch.  Both fitted to measurements on configs B, C, D, E (tools/time_forms.py,
     // profiles/r02/time_forms.log; us per iteration of the batch):
-    //   resident  = rounds x (1.85 + 0.2 G + 0.9 T npl [x 0.3 in the DPP form])
+    //   resident  = rounds x (2.5 + 0.25 G + 0.5 T npl)      lane-program form;   rounds x (2.2 + 0.2 G + 0.9 T)   DPP form
     //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
-    // C: resident at every batch (13 M against 3.7 M mat-vecs/s at 256); D (teams of 15): streaming from ~64 right-hand sides on;
+    // C, B, D: resident at every batch (C: 13 M against 3.7 M mat-vecs/s at 256; D: 4.6 M against 4.0 M);
     // E (teams of 20, 8 right-hand sides per round): streaming from ~24 on (3.2 M against 1.8 M at 256).  A deterministic rule
     // (never a timing at run time): which form runs decides the last bits of a solution.
     // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
@@ -970,7 +974,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
-            const double t_res = rounds * (1.85 + 0.2 * sh.G + 0.9 * sh.T * h->npl * (sh.sq ? 0.3 : 1.0));
+            const double t_res = rounds * (sh.sq ? 2.2 + 0.2 * sh.G + 0.9 * sh.T : 2.5 + 0.25 * sh.G + 0.5 * sh.T * h->npl);
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
         }
