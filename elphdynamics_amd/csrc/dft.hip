@@ -187,6 +187,7 @@ static int dft_pad(int n, int m) { return ((n + m - 1) / m) * m; }
 int elph_dft_fwd_twisted(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {
     const int L = (int)h->L, Lo2 = (L + 1) / 2, nst = (N + WAVE - 1) / WAVE;
     if (elph_dft_mfma_usable(h, 0, false, N, nrhs)) return elph_dft_mfma_fwd(h, 0, nu, vS, N, nrhs, st);
+    if (elph_dft_mfma1_usable(h, false, N, 0)) return elph_dft_mfma1_fwd(h, nu, vS, N, nrhs, st);
     hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, false>),
                            dim3((unsigned)nst, (unsigned)((Lo2 + DFT_KPT - 1) / DFT_KPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, nu,
                            vS, h->d_Tk, N, L, Lo2, dft_pad(L, 2 * DFT_TC), st, (const double *)nullptr, 0.0);
@@ -198,6 +199,7 @@ int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int 
                          const double *rvec, double *rz_part, int nrz) {
     const int L = (int)h->L, Lo2 = (L + 1) / 2, nst = (N + WAVE - 1) / WAVE;
     if (elph_dft_mfma_usable(h, 0, true, N, nrhs)) return elph_dft_mfma_inv(h, 0, outS, nu, N, nrhs, st, rvec, rz_part, nrz);
+    if (elph_dft_mfma1_usable(h, true, N, rz_part ? nrz : 0)) return elph_dft_mfma1_inv(h, outS, nu, N, nrhs, st, rvec, rz_part, nrz);
     hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>),
                            dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, outS,
                            nu, h->d_Tt, N, L, Lo2, dft_pad(Lo2, 2 * DFT_KC), st, rvec, rz_part, nrz);

@@ -134,6 +134,80 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma(double *__restrict__ out
 }
 
 
+// The same GEMM for ONE or a few right-hand sides (the reference's real call shape): one 16 x 16 output tile per wave, so a
+// transform is 160 waves at config C instead of 32, each with ALL its operands requested up front (NT data values and NT
+// pre-swizzled A tiles per lane: one memory round trip) and a dependent chain of NT MFMAs (40 x 32 cycles = 0.5 us).  The
+// scalar-twiddle kernels of dft.hip take 9.1 / 6.3 us here (forward / inverse, SGPR-bound), k_dft_mfma above with its five row
+// tiles per wave and its 6-deep tile ring more.  grid: x = column tiles / CW, y = row tile, z = right-hand side.
+template <int NT, bool INV>
+__global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_1(double *__restrict__ out, const double *__restrict__ in,
+                                                     const double *__restrict__ W, int N, int L, int K, const CgState *state,
+                                                     const double *__restrict__ rvec, double *__restrict__ rz_part, int nrz) {
+    const int rhs = blockIdx.z;
+    if (mf_done(state, rhs)) return;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, col = lane & 15, jj = lane >> 4;
+    const int ctile = blockIdx.x * CW + wv;
+    if (ctile * 16 >= N) return;
+    const int s = ctile * 16 + col;
+    const int sc = (s < N) ? s : N - 1;
+    const int mt = blockIdx.y;
+    double a[NT], b[NT];
+    const double *Wg = W + ((size_t)mt * NT) * WAVE + lane;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) a[tt] = Wg[(size_t)tt * WAVE];
+    if (!INV) {
+        const double *v = in + (size_t)rhs * N * L;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int t = 4 * tt + jj;
+            t = (t < L) ? t : L - 1;
+            b[tt] = v[(size_t)t * N + sc];
+        }
+    } else {
+        const double *nu = in + (size_t)rhs * K * N * 2;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            int k = 2 * tt + (jj >> 1);
+            k = (k < K) ? k : K - 1;
+            b[tt] = nu[((size_t)k * N + sc) * 2 + (jj & 1)];
+        }
+    }
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], b[tt], acc, 0, 0, 0);
+    const int r0 = lane >> 4;
+    if (!INV) {
+        double2 *o = reinterpret_cast<double2 *>(out) + (size_t)rhs * K * N;
+        const int k = 8 * mt + 2 * r0;
+        if (s < N) {
+            if (k < K) o[(size_t)k * N + s] = make_double2(acc.x, acc.y);
+            if (k + 1 < K) o[(size_t)(k + 1) * N + s] = make_double2(acc.z, acc.w);
+        }
+    } else {
+        double dot = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * mt + r0 + 4 * r;
+            if (s < N && t < L) {
+                const size_t i = (size_t)rhs * N * L + (size_t)t * N + s;
+                out[i] = acc[r];
+                if (rz_part) dot += rvec[i] * acc[r];
+            }
+        }
+        if (rz_part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, WAVE);
+            if (lane == 0) {
+                const int nct = (N + 15) / 16;
+                const int G = nct * (int)gridDim.y, bid = (int)blockIdx.y * nct + ctile;
+                double *slots = rz_part + (size_t)rhs * nrz;
+                slots[bid] = dot;
+                for (int q = G + bid; q < nrz; q += G) slots[q] = 0.0;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Twisted transform, one even/odd-tau split (L even; H = L/2, Q = ceil(H/2) independent frequencies):
 //   forward   nu_k = A_k + w_k B_k,  A (B) = half-length twisted DFT of the even (odd) time slices, w_k = e^{-i pi (2k+1)/L};
@@ -523,6 +597,21 @@ int launch(elph_handle_s *h, int nt, double *out, const double *in, const double
     return mf_check(INV ? "k_dft_mfma(inverse)" : "k_dft_mfma(forward)");
 }
 
+template <bool INV>
+int launch_1(elph_handle_s *h, int nt, double *out, const double *in, const double *W, int N, int K, int row_tiles, int nrhs,
+             const CgState *st, const double *rvec, double *rz_part, int nrz) {
+    const int nct = (N + 15) / 16;
+    const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)row_tiles, (unsigned)nrhs), block(CW * WAVE);
+    const int L = (int)h->L;
+#define MF1_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_1<NTV, INV>), grid, block, 0, h->stream, out, in, W, N, L, K, st, rvec, rz_part, nrz); break;
+    switch (nt) {
+        MF1_CASE(12) MF1_CASE(20) MF1_CASE(32) MF1_CASE(40) MF1_CASE(44) MF1_CASE(64)
+        default: elph_set_error("dft_mfma_1: no kernel for %d reduction tiles", nt); return ELPH_E_UNSUPPORTED;
+    }
+#undef MF1_CASE
+    return mf_check(INV ? "k_dft_mfma_1(inverse)" : "k_dft_mfma_1(forward)");
+}
+
 template <bool INV, bool XR = false>
 int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, const double *in, int N, int nrhs, const CgState *st,
               const double *rvec, double *rz_part, int nrz, XrFuse X = XrFuse{}) {
@@ -575,9 +664,29 @@ bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N
     if (!T.W && !split) return false;
     if (force == 1) return true;
     // measured crossover against the scalar-twiddle kernels (tools/time_dft_crossover.py, configs C and D): the split form wins
-    // from ~100 column-tile waves (8 right-hand sides at N = 256), the direct form from ~512 waves
-    if (split) return (long long)((N + 15) / 16) * nrhs >= 100;
+    // from ~100 column-tile waves (8 right-hand sides at N = 256), the direct form from ~512 waves; against the
+    // one-tile-per-wave form (k_dft_mfma_1; config C: preconditioned iteration 60.2 vs 69.9 us at 10 right-hand sides,
+    // 122.9 vs 96.0 at 64) from ~320
+    if (split) return (long long)((N + 15) / 16) * nrhs >= (which == 0 && elph_dft_mfma1_usable(h, inverse, N, 0) ? 320 : 100);
     return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;
+}
+
+// one output tile per wave: the twisted pair for batches below the crossover of the forms above (ELPH_DFT_MFMA1=0: scalar kernels)
+bool elph_dft_mfma1_usable(const elph_handle_s *h, bool inverse, int N, int nrz_slots) {
+    const char *e = getenv("ELPH_DFT_MFMA1");
+    if (e && atoi(e) == 0) return false;
+    const elph_handle_s::MfmaTab &T = h->mf[0][inverse ? 1 : 0];
+    if (!T.W) return false;
+    return !inverse || nrz_slots <= 0 || ((N + 15) / 16) * T.groups * MG <= nrz_slots;
+}
+int elph_dft_mfma1_fwd(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {
+    const elph_handle_s::MfmaTab &T = h->mf[0][0];
+    return launch_1<false>(h, T.nt, reinterpret_cast<double *>(nu), vS, T.W, N, (int)(h->L + 1) / 2, T.groups * MG, nrhs, st, nullptr, nullptr, 0);
+}
+int elph_dft_mfma1_inv(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st, const double *rvec,
+                       double *rz_part, int nrz) {
+    const elph_handle_s::MfmaTab &T = h->mf[0][1];
+    return launch_1<true>(h, T.nt, outS, reinterpret_cast<const double *>(nu), T.W, N, (int)(h->L + 1) / 2, T.groups * MG, nrhs, st, rvec, rz_part, nrz);
 }
 
 int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {

@@ -378,6 +378,10 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
 // ---- batched tau-axis transforms on the matrix cores (dft_mfma.hip); which: 0 twisted, 1 plain
 int elph_dft_mfma_build_tables(elph_handle_s *h);
 bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs);
+bool elph_dft_mfma1_usable(const elph_handle_s *h, bool inverse, int N, int nrz_slots);
+int elph_dft_mfma1_fwd(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st);
+int elph_dft_mfma1_inv(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st, const double *rvec,
+                       double *rz_part, int nrz);
 int elph_dft_mfma_fwd_xr(elph_handle_s *h, double2 *nu, double *rS, const double *zS, const double *pap, int npap, double *rr,
                          double *alpha, int N, int nrhs, const CgState *st);
 void elph_dft_mfma_free(elph_handle_s *h);
