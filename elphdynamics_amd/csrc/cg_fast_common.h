@@ -90,11 +90,21 @@ __device__ __forceinline__ double wave_sum2(double v) {
     return v;
 }
 
-__device__ __forceinline__ double reduce_partials2(const double *p, int n) {
+// sum of n partial sums (one wave; lane l adds entries l, l + 64, ... in that order, then the butterfly).  The loads of a group of
+// eight go out together: as a plain loop every coherent load waits for the one before it — ten memory round trips in a row for the
+// 640 r.z slots of config C, most of the time k_cg_ap_fast spent for one right-hand side.
+__device__ __forceinline__ double reduce_partials_lane(const double *p, int n, int lane) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += WAVE) a += ld_coh(p + i);
+    for (int i0 = lane; i0 < n; i0 += 8 * WAVE) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i0 + k * WAVE < n) ? ld_coh(p + i0 + k * WAVE) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (i0 + k * WAVE < n) a += v[k];
+    }
     return wave_sum2(a);
 }
+__device__ __forceinline__ double reduce_partials2(const double *p, int n) { return reduce_partials_lane(p, n, threadIdx.x); }
 
 // XCD-aware mapping of a 1-D grid of 8*C*nrhs workgroups onto (tau, rhs); C = ceil(L/8)
 __device__ __forceinline__ bool xcd_map(int L, int &t, int &rhs) {
