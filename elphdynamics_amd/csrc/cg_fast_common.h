@@ -84,10 +84,20 @@ __device__ __forceinline__ void dpp_pair_odd_up4(double (&t)[4], const double (&
     for (int k = 0; k < 4; ++k) t[k] = __hiloint2double(o[2 * k + 1], o[2 * k]);
 }
 
+// wave-wide sum, the same value in every lane: quad swaps and row mirrors (DPP) give every lane the sum of its 16-lane row, the
+// four row sums are added in a fixed order through scalar registers.  (The xor butterfly over ds_bpermute it replaces is six
+// dependent LDS round trips — ~0.3 us on the critical path of the one-wave kernels, which call it two or three times.)
 __device__ __forceinline__ double wave_sum2(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    v += dpp_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);         // row_half_mirror
+    v += dpp_f64<0x140>(v);         // row_mirror
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // sum of n partial sums (one wave; lane l adds entries l, l + 64, ... in that order, then the butterfly).  The loads of a group of
@@ -105,6 +115,27 @@ __device__ __forceinline__ double reduce_partials_lane(const double *p, int n, i
     return wave_sum2(a);
 }
 __device__ __forceinline__ double reduce_partials2(const double *p, int n) { return reduce_partials_lane(p, n, threadIdx.x); }
+
+// Stop test of an iteration (IterativeSolvers.jl:212-219 / :286-295): eps = |r|/|b| < tol, kappa_min = max_j (2j/ln(2 eps0/eps_j))^2
+// > kappa_max, j = maxiter.  Two comparisons screen out the square root, the divisions and the logarithm (~150 dependent f64
+// instructions, half a microsecond on the critical path of every wave) while no decision is near: r.r well above (tol |b|)^2
+// rules out convergence; (2 eps0/eps)^2 outside [1/2, 2] means |ln(2 eps0/eps)| > 0.34, which rules out the kappa stop while
+// 2j < 0.34 sqrt(kappa_max).  Near a decision, on the last iteration and with a residual history the reference's arithmetic runs
+// (eps, and kappa_min of that iteration: an iteration stops on kappa only through its own term).  Returns the done code.
+__device__ __forceinline__ int cg_stop_test(const CgParams &P, const CgState &S, double rr, long long seq, double &eps, double &kmin) {
+    const double tb = P.tol * S.normb, y_num = 4.0 * (S.eps0 * S.normb) * (S.eps0 * S.normb);
+    const bool screened = !P.record_hist && seq < P.maxiter && rr > tb * tb * 1.000001 &&
+                          (rr + rr <= y_num || rr >= y_num + y_num) && (double)seq < 0.17 * sqrt(P.kmax);
+    if (screened) return 0;
+    eps = sqrt(rr) / S.normb;
+    const double qq = 2.0 * (double)seq / log(2.0 * S.eps0 / eps);
+    const double val = qq * qq;
+    kmin = (val > kmin) ? val : kmin;
+    if (eps < P.tol) return 1;
+    if (kmin > P.kmax) return 2;
+    if (seq >= P.maxiter) return 3;
+    return 0;
+}
 
 // XCD-aware mapping of a 1-D grid of 8*C*nrhs workgroups onto (tau, rhs); C = ceil(L/8)
 __device__ __forceinline__ bool xcd_map(int L, int &t, int &rhs) {
