@@ -1,3 +1,5 @@
+"""Whole batched solves with the form chosen by the library (auto), with the resident kernel forced (ELPH_WG_ALWAYS=1) and with the
+streaming kernels forced (ELPH_NO_WG=1).  usage: python3 tools/time_form_choice.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())

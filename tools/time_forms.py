@@ -1,3 +1,5 @@
+"""Un-preconditioned CG iteration, streaming (two kernels) against workgroup-resident form, per config and batch size:
+the data the form-selection rule of elph_wg_cg (cg_wg.hip) is fitted to.  usage: python3 tools/time_forms.py B D E C"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
