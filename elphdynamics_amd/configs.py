@@ -25,6 +25,8 @@ CONFIGS = {
     "g": ("holstein", 1, 24, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 576  (2 wavefronts per slice)
     "G": ("holstein", 1, 32, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 1024
     "h": ("holstein", 2, 18, lat.HONEYCOMB_BONDS, 0.6, 0.1),        # N = 648 honeycomb
+    # a long time axis: 1280 slices (beyond the direct-DFT tables: dft_big.hip)
+    "l": ("holstein", 1, 4, lat.SQUARE_BONDS, 128.0, 0.1),
 }
 
 

@@ -186,6 +186,7 @@ static int dft_pad(int n, int m) { return ((n + m - 1) / m) * m; }
 // nu[rhs][k][s] (half spectrum, k < ceil(L/2)) = FFT_t(Theta .* v)[k]
 int elph_dft_fwd_twisted(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st) {
     const int L = (int)h->L, Lo2 = (L + 1) / 2, nst = (N + WAVE - 1) / WAVE;
+    if (elph_dft_big(h)) return elph_dft_big_fwd(h, true, nu, vS, N, nrhs);       // (finished right-hand sides are transformed too)
     if (elph_dft_mfma_usable(h, 0, false, N, nrhs)) return elph_dft_mfma_fwd(h, 0, nu, vS, N, nrhs, st);
     if (elph_dft_mfma1_usable(h, false, N, 0)) return elph_dft_mfma1_fwd(h, nu, vS, N, nrhs, st);
     hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, false>),
@@ -198,6 +199,7 @@ int elph_dft_fwd_twisted(elph_handle_s *h, double2 *nu, const double *vS, int N,
 int elph_dft_inv_twisted(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st,
                          const double *rvec, double *rz_part, int nrz) {
     const int L = (int)h->L, Lo2 = (L + 1) / 2, nst = (N + WAVE - 1) / WAVE;
+    if (elph_dft_big(h)) return elph_dft_big_inv(h, true, outS, nu, N, nrhs, rvec, rz_part, nrz);
     if (elph_dft_mfma_usable(h, 0, true, N, nrhs)) return elph_dft_mfma_inv(h, 0, outS, nu, N, nrhs, st, rvec, rz_part, nrz);
     if (elph_dft_mfma1_usable(h, true, N, rz_part ? nrz : 0)) return elph_dft_mfma1_inv(h, outS, nu, N, nrhs, st, rvec, rz_part, nrz);
     hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>),
@@ -223,6 +225,15 @@ __global__ void __launch_bounds__(256) k_dft_diag(double2 *__restrict__ u, const
 // out = Re iFFT( diag^power .* FFT(in) ), N columns, nvec vectors sharing one diagonal
 int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const double *diagS, double power, int N, double2 *u, int nvec) {
     const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
+    if (elph_dft_big(h)) {
+        int rc = elph_dft_big_fwd(h, false, u, inS, N, nvec);
+        if (rc) return rc;
+        const long long total = (long long)nvec * Lh * N;
+        hipLaunchKernelGGL(k_dft_diag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, u, diagS, power, N, L, Lh, total);
+        rc = dft_check("k_dft_diag");
+        if (rc) return rc;
+        return elph_dft_big_inv(h, false, outS, u, N, nvec, nullptr, nullptr, 0);
+    }
     if (elph_dft_mfma_usable(h, 1, false, N, nvec) && elph_dft_mfma_usable(h, 1, true, N, nvec)) {
         int rc = elph_dft_mfma_fwd(h, 1, u, inS, N, nvec, nullptr);
         if (rc) return rc;
@@ -243,6 +254,7 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
 // nu[rhs][k][s] (half spectrum, k <= L/2) = FFT_t(v)[k]  — plain (untwisted) transform, no diagonal
 int elph_dft_fwd_plain(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs) {
     const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
+    if (elph_dft_big(h)) return elph_dft_big_fwd(h, false, nu, vS, N, nrhs);
     if (elph_dft_mfma_usable(h, 1, false, N, nrhs)) return elph_dft_mfma_fwd(h, 1, nu, vS, N, nrhs, nullptr);
     hipLaunchKernelGGL((k_dft_fwd_tab<DFT_KPT, DFT_TC, true>),
                            dim3((unsigned)nst, (unsigned)((Lh + DFT_KPT - 1) / DFT_KPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, nu, vS,
@@ -253,6 +265,7 @@ int elph_dft_fwd_plain(elph_handle_s *h, double2 *nu, const double *vS, int N, i
 // out = Re iFFT(nu) from the half spectrum k <= L/2 (Hermitian weights and 1/L in the table)
 int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs) {
     const int L = (int)h->L, Lh = L / 2 + 1, nst = (N + WAVE - 1) / WAVE;
+    if (elph_dft_big(h)) return elph_dft_big_inv(h, false, outS, nu, N, nrhs, nullptr, nullptr, 0);
     if (elph_dft_mfma_usable(h, 1, true, N, nrhs)) return elph_dft_mfma_inv(h, 1, outS, nu, N, nrhs, nullptr, nullptr, nullptr, 0);
     hipLaunchKernelGGL((k_dft_inv_tab<DFT_TPT, DFT_KC>),
                            dim3((unsigned)nst, (unsigned)((L + DFT_TPT - 1) / DFT_TPT), (unsigned)nrhs), dim3(WAVE), 0, h->stream, outS,
@@ -263,6 +276,7 @@ int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N,
 
 // host: build the four twiddle tables with exact index reduction
 int elph_dft_build_tables(elph_handle_s *h) {
+    if (h->L > 1024) return elph_dft_big_build_tables(h);      // long axes: one Cooley-Tukey split instead of O(L^2) tables (dft_big.hip)
     const int L = (int)h->L, Lo2 = (L + 1) / 2, Lh = L / 2 + 1;
     const int Lp = dft_pad(L, 2 * DFT_TC), Kp2 = dft_pad(Lo2, 2 * DFT_KC), Kph = dft_pad(Lh, 2 * DFT_KC);
     const double2 zero = make_double2(0.0, 0.0);

@@ -223,7 +223,7 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
         return ELPH_E_UNSUPPORTED;
     }
     if (nsites * ltau > (int64_t)1 << 30) { elph_set_error("ndim too large"); return ELPH_E_UNSUPPORTED; }
-    if (ltau > 1024) { elph_set_error("ltau=%lld > 1024: the direct-DFT twiddle tables are O(L^2); a mixed-radix FFT is not built yet", (long long)ltau); return ELPH_E_UNSUPPORTED; }
+    if (ltau > 1024 * 1024) { elph_set_error("ltau=%lld: the time axis is limited to 1024 * 1024 slices", (long long)ltau); return ELPH_E_UNSUPPORTED; }
     if (nbonds > 0 && !neighbor_table) { elph_set_error("neighbor_table is null"); return ELPH_E_ARG; }
     if (kind == ELPH_MODEL_HOLSTEIN && nbonds > 0 && (!cosht || !sinht)) { elph_set_error("cosht/sinht null"); return ELPH_E_ARG; }
     for (int64_t n = 0; n < nbonds; ++n) {
@@ -346,6 +346,7 @@ extern "C" int elph_destroy(elph_handle h) {
     elph_hmc_free(h);
     elph_greens_free(h);
     elph_dft_mfma_free(h);
+    elph_dft_big_free(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,

@@ -291,7 +291,10 @@ struct elph_handle_s {
     double *d_r2_tw = nullptr;             // [L/2] (cos, -sin) of pi (2k+1) / L
     double *d_diag = nullptr;              // fourier-acceleration diagonal staging
     int64_t diag_cap = 0;
-    std::vector<int> fft_radices;
+    // long time axes (L > 1024, dft_big.hip): one Cooley-Tukey split L = big_L1 * big_L2, tables and two complex work vectors
+    int big_L1 = 0, big_L2 = 0;
+    double2 *d_big_W1 = nullptr, *d_big_W2 = nullptr, *d_big_TW = nullptr, *d_big_TH = nullptr, *d_big_a = nullptr, *d_big_b = nullptr;
+    size_t big_cap = 0;
 };
 
 // ---- launchers implemented in kernels.hip -------------------------------------------------
@@ -378,6 +381,12 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
 // ---- batched tau-axis transforms on the matrix cores (dft_mfma.hip); which: 0 twisted, 1 plain
 int elph_dft_mfma_build_tables(elph_handle_s *h);
 bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs);
+bool elph_dft_big(const elph_handle_s *h);
+int elph_dft_big_build_tables(elph_handle_s *h);
+void elph_dft_big_free(elph_handle_s *h);
+int elph_dft_big_fwd(elph_handle_s *h, bool twisted, double2 *nu, const double *vS, int N, int nvec);
+int elph_dft_big_inv(elph_handle_s *h, bool twisted, double *outS, const double2 *nu, int N, int nvec, const double *rvec,
+                     double *rz_part, int nrz);
 bool elph_dft_mfma1_usable(const elph_handle_s *h, bool inverse, int N, int nrz_slots);
 int elph_dft_mfma1_fwd(elph_handle_s *h, double2 *nu, const double *vS, int N, int nrhs, const CgState *st);
 int elph_dft_mfma1_inv(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st, const double *rvec,

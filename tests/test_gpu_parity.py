@@ -160,6 +160,70 @@ def test_fft_golden(lib, L):
         m.close()
 
 
+@pytest.mark.parametrize("L", [1280, 2048, 1155, 4096])
+def test_long_time_axis_transforms(lib, L):
+    """Time axes beyond 1024 slices (dft_big.hip: one Cooley-Tukey split, both factors <= 1024; the reference's FFTW plans take
+    any length, TimeFreqFFTs.jl:32-45) against numpy's FFT: the twisted pair, the round trip and fourier_accelerate!."""
+    from elphdynamics_amd import _lib
+    N = 3
+    rng = np.random.default_rng(L)
+    m = RawModel(lib, 0, N, L, np.zeros((0, 2), dtype=np.int64))
+    try:
+        v = rng.standard_normal(N * L)
+        theta = np.exp(-1j * np.pi * np.arange(L) / L)
+        ref = np.fft.fft(theta[None, :] * v.reshape(N, L), axis=1).reshape(-1)
+        nu = np.zeros(2 * N * L)
+        _lib.check(lib.elph_tau_to_omega(m.h, _lib.dptr(nu), _lib.dptr(v)))
+        assert rel(nu[0::2], ref.real) < 1e-12 and rel(nu[1::2], ref.imag) < 1e-12
+        back = np.zeros(N * L)
+        _lib.check(lib.elph_omega_to_tau(m.h, _lib.dptr(back), _lib.dptr(nu)))
+        assert rel(back, v) < 1e-12
+        d2 = rng.uniform(0.5, 2.0, N * L)
+        for power in (-1.0, 0.5):
+            out = np.zeros(N * L)
+            _lib.check(lib.elph_fourier_accelerate(m.h, _lib.dptr(out), _lib.dptr(v), _lib.dptr(d2), power, N))
+            refa = np.real(np.fft.ifft(d2.reshape(N, L) ** power * np.fft.fft(v.reshape(N, L), axis=1), axis=1)).reshape(-1)
+            assert rel(out, refa) < 1e-12
+    finally:
+        m.close()
+
+
+def test_long_time_axis_kpm_and_cg_vs_oracle(oracle):
+    """Config l: the 4 x 4 Holstein lattice with 1280 time slices — mat-vec, KPM apply (two-step transforms around the Chebyshev
+    kernel) and the preconditioned solve against the oracle."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    m = configs.make_model("l", tol=1e-5)
+    assert m.Ltau == 1280
+    om = _oracle_model(oracle, m)
+    v = synth.randn(77, m.Ndim)
+    y = np.empty(m.Ndim)
+    models.mulMtM_(y, m, v)
+    assert rel(y, oracle.mulMTM(om, v)) < 1e-13
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    oP = oracle.make_kpm(om, n=20, buf=0.05, c1=1.0, c2=1.0)
+    rng = np.random.default_rng(17)
+    e_min, e_max = oracle.kpm_setup(oP, b_max=rng.standard_normal(m.Nsites), b_min=rng.standard_normal(m.Nsites))
+    pc.setup_(P, e_min=e_min, e_max=e_max)
+    assert P.active and oP.active == 1
+    R, B = configs.rhs(m, 1)
+    z = np.empty(m.Ndim)
+    pc.kpm_ldiv_(z, P, np.ascontiguousarray(R[0]))
+    assert rel(z, oracle.kpm_apply(oP, np.ascontiguousarray(R[0]))) < 1e-10
+    b = np.ascontiguousarray(B[0])
+    x = np.zeros(m.Ndim)
+    it, hist = models.solve_(x, m, b, P=P, tol=1e-5, history=True)
+    xo, ito, histo = oracle.cg_solve(om, b, tol=1e-5, maxiter=10000, P=oP, history=True)
+    assert abs(it - ito) <= 1 and rel(x, xo) < 1e-6
+    m.close()
+
+
+def test_long_time_axis_prime_length_is_refused(lib):
+    """A prime number of slices beyond 1024 has no split into two factors <= 1024: elph_create says so."""
+    from elphdynamics_amd import _lib
+    with pytest.raises(_lib.ElphError):
+        RawModel(lib, 0, 3, 1031, np.zeros((0, 2), dtype=np.int64))
+
+
 @pytest.mark.parametrize("tag", ["sq4_L8", "sq4_L40"])
 def test_kpm_golden(lib, tag):
     from elphdynamics_amd import _lib
