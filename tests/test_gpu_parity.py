@@ -559,6 +559,31 @@ def test_calc_OinvLambda_phi_vs_oracle(oracle):
     m.close()
 
 
+@pytest.mark.parametrize("tag", ["B", "e"])
+def test_calc_OinvLambda_phi_when_the_first_solve_fails(oracle, tag):
+    """HMC.jl:880: a flagged phi+ solve suppresses the phi- solve — its output stays zero, the iteration count is that of the first
+    solve alone and is not halved (:907-909).  The device runs both solves as one batch; the bookkeeping follows the reference."""
+    from elphdynamics_amd import configs, hmc, synth
+    from oracle.oracle import dp
+    m = configs.make_model(tag, tol=1e-9, maxiter=4)
+    om = _oracle_model(oracle, m)
+    n = m.Ndim
+    phi_p, phi_m = synth.randn(311, n), synth.randn(312, n)
+    if m.kind == 0:
+        Lam = np.zeros(n)
+        oracle.lib.elpho_update_Lambda(dp(Lam), m.Nsites, m.Ltau, m.dtau, dp(m.x), dp(m.lam), dp(m.lam2))
+        b = np.zeros(n)
+        oracle.lib.elpho_mulLambda(dp(b), dp(phi_p), dp(Lam), m.Nsites, m.Ltau)
+    else:
+        b = phi_p                                                  # SSH: mulLambda! is a no-op (HMC.jl:943-946,970-973)
+    xo, ito, reso, flo = oracle.ldiv(om, b, solver_tol=1e-9, solver_maxiter=4)
+    assert flo != 0 and ito == 4
+    Xp, Xm, iters, flag = hmc.calc_OinvLambda_phi(m, phi_p, phi_m, None, power=1.0)
+    assert flag == flo and iters == ito
+    assert not Xm.any() and not Xp.any()                           # ldiv! zero-fills a flagged solution (Models.jl:160-166)
+    m.close()
+
+
 def test_greens_estimator_vs_oracle(oracle):
     """GreensFunctions.update!/estimate (:201-234,:334-346): M^-1 R for n_v vectors, G = (M^-1 r)[n] r[m]."""
     from elphdynamics_amd import configs, hmc, synth
