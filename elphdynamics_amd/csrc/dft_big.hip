@@ -5,7 +5,8 @@
 // FourierAcceleration.jl:91-143.  Same conventions as dft.hip: forward unnormalised exp(-2 pi i k t / L), inverse scaled 1/L,
 // twisted transform = FFT of Theta .* v with Theta_t = exp(-i pi t / L).
 //
-// One Cooley-Tukey split L = L1 * L2 (both factors <= 1024, chosen near sqrt(L) on the host; a prime L > 1024 is refused):
+// One Cooley-Tukey split L = L1 * L2 (both factors <= 1024, chosen near sqrt(L) on the host; a length without such a split —
+// a prime — runs the direct transform with one table of L roots of unity, k_big_direct: any length works, those slowly):
 //   t = L2 a + b,  k = c + L1 d:
 //   X[c + L1 d] = sum_b  W2[d][b] * ( TW[(c b) mod L] * sum_a W1[c][a] u[L2 a + b] )
 // i.e. L2 transforms of length L1 (stride L2), a twiddle, L1 transforms of length L2 — each a direct DFT with a small table
@@ -89,6 +90,29 @@ __global__ void __launch_bounds__(WAVE) k_big_step2(double2 *__restrict__ X, con
     if (s < N) X[base + (size_t)k * N + s] = make_double2(scale * ax, scale * ay);
 }
 
+// lengths without such a split (a prime L > 1024): the direct transform with the one table of L roots of unity,
+// X[k] = scale * sum_t TW[(k t) mod L]^(+-1) u[t] — O(L^2) per column, O(L) table; correct for any length, slow
+template <bool INV>
+__global__ void __launch_bounds__(WAVE) k_big_direct(double2 *__restrict__ X, const double2 *__restrict__ u, const double2 *__restrict__ TW,
+                                                     int N, int L, double scale) {
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int k = blockIdx.y;
+    const size_t base = (size_t)blockIdx.z * L * N;
+    const int sc = (s < N) ? s : N - 1;
+    double ax = 0.0, ay = 0.0;
+    int idx = 0;
+    for (int t = 0; t < L; ++t) {
+        const double2 x = u[base + (size_t)t * N + sc];
+        const double2 ww = TW[idx];
+        const double wy = INV ? -ww.y : ww.y;
+        ax += ww.x * x.x - wy * x.y;
+        ay += ww.x * x.y + wy * x.x;
+        idx += k;
+        if (idx >= L) idx -= L;
+    }
+    if (s < N) X[base + (size_t)k * N + s] = make_double2(scale * ax, scale * ay);
+}
+
 // half spectrum out of the full one: nu[vec][k][s] = X[vec][k][s], k < K
 __global__ void __launch_bounds__(256) k_big_take(double2 *__restrict__ nu, const double2 *__restrict__ X, int N, int L, int K, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -159,6 +183,12 @@ template <bool INV>
 int big_fft(elph_handle_s *h, int N, int nvec) {
     const int L = (int)h->L, L1 = h->big_L1, L2 = h->big_L2, nst = (N + WAVE - 1) / WAVE;
     const dim3 grid((unsigned)nst, (unsigned)L, (unsigned)nvec);
+    if (L2 == 1) {                                        // no split: direct transform, result back into d_big_a
+        hipLaunchKernelGGL((k_big_direct<INV>), grid, dim3(WAVE), 0, h->stream, h->d_big_b, h->d_big_a, h->d_big_TW, N, L, INV ? 1.0 / (double)L : 1.0);
+        hipError_t e = hipMemcpyAsync(h->d_big_a, h->d_big_b, (size_t)nvec * L * N * sizeof(double2), hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) { elph_set_error("dft_big: copy: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+        return big_check(INV ? "k_big_direct(inverse)" : "k_big_direct(forward)");
+    }
     hipLaunchKernelGGL((k_big_step1<INV>), grid, dim3(WAVE), 0, h->stream, h->d_big_b, h->d_big_a, h->d_big_W1, h->d_big_TW, N, L, L1, L2);
     hipLaunchKernelGGL((k_big_step2<INV>), grid, dim3(WAVE), 0, h->stream, h->d_big_a, h->d_big_b, h->d_big_W2, N, L, L1, L2,
                        INV ? 1.0 / (double)L : 1.0);
@@ -176,10 +206,11 @@ int elph_dft_big_build_tables(elph_handle_s *h) {
     int best = 0;
     for (int f = 2; (long long)f * f <= L; ++f)
         if (L % f == 0 && L / f <= 1024) best = f;            // the largest divisor <= sqrt(L) whose cofactor fits
-    if (best == 0 || best > 1024) { elph_set_error("ltau=%d > 1024 has no factorisation L1*L2 with both factors <= 1024 (a prime-length transform is not built)", L); return ELPH_E_UNSUPPORTED; }
-    const int L1 = best, L2 = L / best;
-    std::vector<double2> W1((size_t)L1 * L1), W2((size_t)L2 * L2), TW((size_t)L), TH((size_t)L);
-    for (int c = 0; c < L1; ++c)
+    // no such split (a prime, or a prime factor beyond 1024): L1 = L, L2 = 1 selects the direct transform (k_big_direct)
+    const bool split = best >= 2;
+    const int L1 = split ? best : L, L2 = split ? L / best : 1;
+    std::vector<double2> W1(split ? (size_t)L1 * L1 : 1), W2((size_t)L2 * L2), TW((size_t)L), TH((size_t)L);
+    for (int c = 0; split && c < L1; ++c)
         for (int a = 0; a < L1; ++a) { const double x = 2.0 * M_PI * (double)(((long long)c * a) % L1) / (double)L1; W1[(size_t)c * L1 + a] = make_double2(cos(x), -sin(x)); }
     for (int d = 0; d < L2; ++d)
         for (int b = 0; b < L2; ++b) { const double x = 2.0 * M_PI * (double)(((long long)d * b) % L2) / (double)L2; W2[(size_t)d * L2 + b] = make_double2(cos(x), -sin(x)); }

@@ -160,10 +160,11 @@ def test_fft_golden(lib, L):
         m.close()
 
 
-@pytest.mark.parametrize("L", [1280, 2048, 1155, 4096])
+@pytest.mark.parametrize("L", [1280, 2048, 1155, 4096, 1031])
 def test_long_time_axis_transforms(lib, L):
-    """Time axes beyond 1024 slices (dft_big.hip: one Cooley-Tukey split, both factors <= 1024; the reference's FFTW plans take
-    any length, TimeFreqFFTs.jl:32-45) against numpy's FFT: the twisted pair, the round trip and fourier_accelerate!."""
+    """Time axes beyond 1024 slices (dft_big.hip: one Cooley-Tukey split, both factors <= 1024; a prime length — 1031 — runs a
+    direct transform; the reference's FFTW plans take any length, TimeFreqFFTs.jl:32-45) against numpy's FFT: the twisted pair,
+    the round trip and fourier_accelerate!."""
     from elphdynamics_amd import _lib
     N = 3
     rng = np.random.default_rng(L)
@@ -215,13 +216,6 @@ def test_long_time_axis_kpm_and_cg_vs_oracle(oracle):
     xo, ito, histo = oracle.cg_solve(om, b, tol=1e-5, maxiter=10000, P=oP, history=True)
     assert abs(it - ito) <= 1 and rel(x, xo) < 1e-6
     m.close()
-
-
-def test_long_time_axis_prime_length_is_refused(lib):
-    """A prime number of slices beyond 1024 has no split into two factors <= 1024: elph_create says so."""
-    from elphdynamics_amd import _lib
-    with pytest.raises(_lib.ElphError):
-        RawModel(lib, 0, 3, 1031, np.zeros((0, 2), dtype=np.int64))
 
 
 @pytest.mark.parametrize("tag", ["sq4_L8", "sq4_L40"])
