@@ -37,9 +37,12 @@ template <int NPL>
 __host__ __device__ constexpr int slab_len() { return NPL * WAVE + 2 * WAVE; }
 
 struct WgCtl {
-    u64 *slots;          // [nrhs][p.z | r.r][Gmax = 32][2 granules]; zeroed by the host before every launch
-    u64 *bnd;            // [nrhs][G][2][NPL*64][2 granules]: first / last slice of r of every workgroup (G > 1 only); zeroed like slots
+    u64 *slots;          // [nrhs][p.z | r.r][Gmax = 32][2 granules]
+    u64 *bnd;            // [nrhs][G][2][NPL*64][2 granules]: first / last slice of r of every workgroup (G > 1 only)
     int *abort;
+    unsigned epoch0;     // tags of this launch are epoch0 + iteration: every launch of a handle gets a range of its own, so the
+                         // granules need no zeroing between launches (the host zeroes them when it allocates them and when the
+                         // 32-bit range wraps) — a 12 MB fill and its launch boundary less per solve at 288 right-hand sides
     int G, W;
     long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
     long long fixed_iters;     // > 0: measurement mode, exactly this many iterations, no stop test
@@ -443,7 +446,6 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         sc[q] = live[q] ? s : N - 1;
     }
     double *xg = B.x + (size_t)rhs * ndim, *rg = B.r + (size_t)rhs * ndim;
-    const double *pg = B.p + (size_t)rhs * ndim;       // parity 0: p0 of k_cg_init
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
 
     // x and r live in this wave's LDS (lane-linear, conflict-free): both are only touched by the two vector updates, never by the
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
     for (int j = 0; j < T + 2; ++j)
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) p[j][q] = pg[(size_t)wrap(t0 + j - 1) * N + sc[q]];
+        for (int q = 0; q < NPL; ++q) p[j][q] = rg[(size_t)wrap(t0 + j - 1) * N + sc[q]];      // p0 = r0 (:272): one vector less to read
 #pragma unroll
     for (int j = 0; j < NEJ; ++j)
 #pragma unroll
@@ -547,7 +549,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     const double it_kappa = 0.17 * sqrt(P.kmax);
     STAMP_DECL;
     for (long long seq = 0;; ++seq) {
-        const unsigned epoch = (unsigned)seq + (SHARD ? 2u : 1u);
+        const unsigned epoch = R.epoch0 + (unsigned)seq + (SHARD ? 2u : 1u);
         STAMP(9);
         // ---- z = M^T M p on the own slices:  w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)]  for t = t0 .. t0+T  (T+1 forward sweeps at once),
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
@@ -807,7 +809,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
                 for (int q = 0; q < NPL; ++q)
                     if (live[q]) {
-                        rg[(size_t)(t0 + j) * N + sc[q]] = rl[j * HS + lane + q * WAVE];
+                        // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
+                        //  caller may want it)
+                        if (SHARD) rg[(size_t)(t0 + j) * N + sc[q]] = rl[j * HS + lane + q * WAVE];
                         xg[(size_t)(t0 + j) * N + sc[q]] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HS + lane + q * WAVE];
                     }
             if (g == 0 && wv == 0 && lane == 0) {
@@ -982,23 +986,31 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     const size_t HS = (size_t)h->npl * WAVE;
     const size_t n_slots = (size_t)nrhs * 2 * 64, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
+    // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
+    // 32-bit range wraps.  The abort word sits at the END of the allocation (its place must not move with the batch size).
+    const unsigned long long span = (unsigned long long)std::min<long long>(fixed_iters > 0 ? fixed_iters : B.params.maxiter, 1LL << 30) + 2;
+    bool zero = false;
     if (need > h->res_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->d_res) HIPCHK(hipFree(h->d_res));
         h->d_res = nullptr;
         HIPCHK(hipMalloc(&h->d_res, need));
         h->res_cap = need;
+        zero = true;
     }
+    if ((unsigned long long)h->wg_epoch + span >= 0xFFFFFFFFull) zero = true;
+    if (zero) { HIPCHK(hipMemsetAsync(h->d_res, 0, h->res_cap, h->stream)); h->wg_epoch = 0; }
     wg::WgCtl R;
     char *base = static_cast<char *>(h->d_res);
     R.slots = reinterpret_cast<wg::u64 *>(base);
     R.bnd = R.slots + n_slots;
-    R.abort = reinterpret_cast<int *>(base + (n_slots + n_bnd) * sizeof(wg::u64));
+    R.abort = reinterpret_cast<int *>(base + h->res_cap - 64);
+    R.epoch0 = h->wg_epoch;
+    h->wg_epoch += (unsigned)span;
     R.G = sh.G; R.W = sh.W;
     const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
     R.timeout_ticks = (long long)(eto ? atoll(eto) : 20000) * 100000LL;     // wall_clock64 runs at 100 MHz
     R.fixed_iters = fixed_iters;
-    HIPCHK(hipMemsetAsync(base, 0, (n_slots + n_bnd) * sizeof(wg::u64) + 64, h->stream));   // every polled word, every launch
     const dim3 grid((unsigned)(8 * ((nrhs + 7) / 8) * sh.G));
     hipError_t e = hipSuccess;
     switch (h->npl) {
@@ -1010,7 +1022,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     }
     if (e != hipSuccess) { elph_set_error("launch k_cg_wg failed: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
     h->wg_T = sh.T; h->wg_W = sh.W; h->wg_G = sh.G;
-    h->wg_abort_off = (n_slots + n_bnd) * sizeof(wg::u64);
+    h->wg_abort_off = h->res_cap - 64;
     *ran = true;
     return ELPH_OK;
 }
@@ -1057,23 +1069,33 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     const size_t HS = (size_t)h->npl * WAVE;
     const size_t n_slots = 2 * 64, n_bnd = (sh.G > 1) ? (size_t)sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
+    // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
+    // 32-bit range wraps.  The abort word sits at the END of the allocation (its place must not move with the batch size).
+    const unsigned long long span = (unsigned long long)std::min<long long>(fixed_iters > 0 ? fixed_iters : B.params.maxiter, 1LL << 30) + 2;
+    bool zero = false;
     if (need > h->res_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->d_res) HIPCHK(hipFree(h->d_res));
         h->d_res = nullptr;
         HIPCHK(hipMalloc(&h->d_res, need));
         h->res_cap = need;
+        zero = true;
     }
+    if ((unsigned long long)h->wg_epoch + span >= 0xFFFFFFFFull) zero = true;
+    if (zero) { HIPCHK(hipMemsetAsync(h->d_res, 0, h->res_cap, h->stream)); h->wg_epoch = 0; }
     wg::WgCtl R;
     char *base = static_cast<char *>(h->d_res);
     R.slots = reinterpret_cast<wg::u64 *>(base);
     R.bnd = R.slots + n_slots;
-    R.abort = reinterpret_cast<int *>(base + (n_slots + n_bnd) * sizeof(wg::u64));
+    R.abort = reinterpret_cast<int *>(base + h->res_cap - 64);
+    R.epoch0 = 0;                                          // (the records of a sharded solve live in the ranks' mailboxes: one numbering for all)
+    (void)span;
     R.G = sh.G; R.W = sh.W;
     const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
     R.timeout_ticks = (long long)(eto ? atoll(eto) : 20000) * 100000LL;
     R.fixed_iters = fixed_iters;
-    HIPCHK(hipMemsetAsync(base, 0, (n_slots + n_bnd) * sizeof(wg::u64) + 64, h->stream));
+    HIPCHK(hipMemsetAsync(base, 0, h->res_cap, h->stream));   // boundary granules of this rank's workgroups: tags restart at 2
+    h->wg_epoch = 0;
     const dim3 grid((unsigned)(8 * sh.G));                 // one right-hand side: blocks with blockIdx % 8 == 0 work, the rest leave at once
     hipError_t e = hipSuccess;
     switch (h->npl) {
@@ -1085,7 +1107,7 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     }
     if (e != hipSuccess) { elph_set_error("launch k_cg_wg (shard) failed: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
     h->wg_T = sh.T; h->wg_W = sh.W; h->wg_G = sh.G;
-    h->wg_abort_off = (n_slots + n_bnd) * sizeof(wg::u64);
+    h->wg_abort_off = h->res_cap - 64;
     if (G_out) *G_out = sh.G;
     return ELPH_OK;
 }

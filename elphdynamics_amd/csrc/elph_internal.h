@@ -218,6 +218,7 @@ struct elph_handle_s {
     void *d_res = nullptr;                 // control block of the workgroup-resident CG (cg_wg.hip): meeting records, abort word, boundary slices
     size_t res_cap = 0;
     bool wg_broken = false;                // a workgroup-resident launch timed out once: do not try again on this handle
+    unsigned wg_epoch = 0;                 // next free tag of the meeting records (cg_wg.hip: WgCtl::epoch0)
     size_t wg_abort_off = 0;               // byte offset of the abort word in d_res
     int wg_T = 0, wg_W = 0, wg_G = 0;      // shape of the last workgroup-resident solve (0: none yet)
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
