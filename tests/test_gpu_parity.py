@@ -1288,6 +1288,26 @@ def test_wg_resident_cg_large_batch_shape():
     m.close()
 
 
+def test_wg_resident_cg_record_numbering_across_batches(monkeypatch):
+    """The meeting records are numbered per launch and not zeroed in between (WgCtl::epoch0); their memory is reinterpreted with every
+    batch size.  One handle, batches of changing size back to back: every solution equals the streaming form's."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("C", tol=1e-5)
+    R, B = configs.rhs(m, 50)
+    monkeypatch.setenv("ELPH_NO_WG", "1")
+    Xref = np.zeros_like(B)
+    itref, _, fl = models.ldiv_batched_(Xref, m, B)
+    assert not fl.any()
+    monkeypatch.setenv("ELPH_NO_WG", "0")
+    for rnd in range(2):
+        for nr in (1, 48, 3, 24, 50, 2, 40, 25):
+            X = np.zeros((nr, m.Ndim))
+            it, res, fl = models.ldiv_batched_(X, m, np.ascontiguousarray(B[:nr]))
+            assert not fl.any(), (rnd, nr)
+            assert max(rel(X[i], Xref[i]) for i in range(nr)) < 1e-4 and np.max(np.abs(it - itref[:nr])) <= 3, (rnd, nr)
+    m.close()
+
+
 def test_wg_resident_cg_honeycomb_two_slices_per_wave():
     """Config D (honeycomb, 5 sites per lane): a batch beyond the 16 right-hand sides one round holds at 1 slice per wave runs
     2 slices per wave (24 per round) — against single solves (1 slice per wave) of the same right-hand sides."""
