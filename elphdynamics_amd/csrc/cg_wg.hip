@@ -878,9 +878,12 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
                 if (G2 > 32 || nrhs <= 8 * (32 / G2)) continue;
             }
         }
-        if (T == 2 && !sq && (ssh || h->npl > 5 || (h->npl >= 4 && !m.uniform))) continue;
-        if (T == 2 && !sq && h->npl == 5 && forceT != 2) {   // 5 sites per lane (honeycomb L = 12): 2 slices per wave are 8 % slower per
-            const int G1 = L / largest_divisor_le8(L);    // iteration (10.0 vs 9.3 us) but hold 24 instead of 16 right-hand sides per round
+        if (T == 2 && !sq && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
+        if (T == 2 && !sq && (h->npl == 5 || ssh) && forceT != 2) {
+            // 5 sites per lane (honeycomb L = 12) and bond phonons (three table sets per wave: 41 registers spill): 2 slices per wave are
+            // slower per iteration (D: 10.0 vs 9.3 us; E: 12.9 vs 9.5 us) but hold more right-hand sides per round (D: 24 instead
+            // of 16; E: 24 instead of 8) — taken once a batch exceeds the round of 1 slice per wave
+            const int G1 = L / largest_divisor_le8(L);
             if (G1 <= 32 && nrhs <= 8 * (32 / G1)) continue;
         }
         if (L % T) continue;
@@ -929,7 +932,10 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
             return launch_k<4, 1, false, true, true>(h, sh, grid, B, m, R);
         }
     }
-    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, false>(h, sh, grid, B, m, R);
+    if (h->kind == ELPH_MODEL_SSH) {
+        if constexpr (NPL <= 4) { if (sh.T == 2) return launch_k<NPL, 2, true, false, false>(h, sh, grid, B, m, R); }
+        return launch_k<NPL, 1, true, false, false>(h, sh, grid, B, m, R);
+    }
     if constexpr (NPL <= 5) {
         if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false, false>(h, sh, grid, B, m, R);
     }
@@ -967,10 +973,11 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // of an XCD) and a batch takes ceil(nrhs / that) rounds of one iteration time each; the two-kernel streaming form is
     // HBM-bound and linear in the batch.  Both fitted to measurements on configs B, C, D, E (tools/time_forms.py,
     // profiles/r02/time_forms.log; us per iteration of the batch):
-    //   resident  = rounds x (2.5 + 0.25 G + 0.5 T npl)      lane-program form;   rounds x (2.2 + 0.2 G + 0.9 T)   DPP form
+    //   resident  = rounds x (2.5 + 0.25 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
+    //               rounds x (2.2 + 0.2 G + 0.9 T)   DPP form
     //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
-    // C, B, D: resident at every batch (C: 13 M against 3.7 M mat-vecs/s at 256; D: 4.6 M against 4.0 M);
-    // E (teams of 20, 8 right-hand sides per round): streaming from ~24 on (3.2 M against 1.8 M at 256).  A deterministic rule
+    // C, B, D, E: resident at every batch (C: 14 M against 3.7 M mat-vecs/s at 256; D: 4.6 M against 4.0 M; E: 3.7 M against 3.2 M);
+    // the rule still decides for other lattices and time axes.  A deterministic rule
     // (never a timing at run time): which form runs decides the last bits of a solution.
     // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
     {
@@ -978,7 +985,8 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
-            const double t_res = rounds * (sh.sq ? 2.2 + 0.2 * sh.G + 0.9 * sh.T : 2.5 + 0.25 * sh.G + 0.5 * sh.T * h->npl);
+            const double t_res = rounds * (sh.sq ? 2.2 + 0.2 * sh.G + 0.9 * sh.T
+                                                 : 2.5 + 0.25 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
         }

@@ -1329,6 +1329,26 @@ def test_wg_resident_cg_honeycomb_two_slices_per_wave():
     m.close()
 
 
+def test_wg_resident_cg_ssh_two_slices_per_wave():
+    """Config E (bond phonons): a batch beyond the 8 right-hand sides one round holds at 1 slice per wave runs 2 slices per wave
+    (24 per round; three hopping-table sets per wave) — against single solves (1 slice per wave) of the same right-hand sides."""
+    from elphdynamics_amd import configs, models, _lib
+    m = configs.make_model("E", tol=1e-5)
+    nrhs = 12
+    us, T, W, G = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _lib.check(_lib.load().elph_bench_wg_info(m._h, nrhs, C.byref(us), C.byref(T), C.byref(W), C.byref(G)))
+    assert us.value == 1 and T.value == 2, (us.value, T.value)
+    R, B = configs.rhs(m, nrhs)
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    assert not fl.any() and (res < 1e-4).all()
+    for i in (0, 5, 11):
+        x = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
+        assert abs(it1 - it[i]) <= 1 and rel(X[i], x) < 5e-5, i
+    m.close()
+
+
 def test_wg_resident_cg_maxiter_history_and_initial_guess(oracle):
     """Stop rule details through the resident kernel: maxiter exhaustion (flag 1), eps history, non-zero initial guess."""
     from elphdynamics_amd import configs, models
