@@ -172,9 +172,15 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_1(double *__restrict__ o
             b[tt] = nu[((size_t)k * N + sc) * 2 + (jj & 1)];
         }
     }
-    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // two accumulators (even / odd reduction tiles): the 40 MFMAs are a dependent chain of 32 cycles each otherwise
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0}, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], b[tt], acc, 0, 0, 0);
+    for (int tt = 0; tt + 1 < NT; tt += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt], b[tt], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt + 1], b[tt + 1], acc1, 0, 0, 0);
+    }
+    if (NT & 1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[NT - 1], b[NT - 1], acc, 0, 0, 0);
+    acc += acc1;
     const int r0 = lane >> 4;
     if (!INV) {
         double2 *o = reinterpret_cast<double2 *>(out) + (size_t)rhs * K * N;
