@@ -139,14 +139,15 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma(double *__restrict__ out
 // pre-swizzled A tiles per lane: one memory round trip) and a dependent chain of NT MFMAs (40 x 32 cycles = 0.5 us).  The
 // scalar-twiddle kernels of dft.hip take 9.1 / 6.3 us here (forward / inverse, SGPR-bound), k_dft_mfma above with its five row
 // tiles per wave and its 6-deep tile ring more.  grid: x = column tiles / CW, y = row tile, z = right-hand side.
+constexpr int CW1 = 1;                // waves per workgroup of k_dft_mfma_1 (one: 160 workgroups spread over the chip)
 template <int NT, bool INV>
-__global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_1(double *__restrict__ out, const double *__restrict__ in,
+__global__ void __launch_bounds__(CW1 * WAVE) k_dft_mfma_1(double *__restrict__ out, const double *__restrict__ in,
                                                      const double *__restrict__ W, int N, int L, int K, const CgState *state,
                                                      const double *__restrict__ rvec, double *__restrict__ rz_part, int nrz) {
     const int rhs = blockIdx.z;
     if (mf_done(state, rhs)) return;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, col = lane & 15, jj = lane >> 4;
-    const int ctile = blockIdx.x * CW + wv;
+    const int ctile = blockIdx.x * CW1 + wv;
     if (ctile * 16 >= N) return;
     const int s = ctile * 16 + col;
     const int sc = (s < N) ? s : N - 1;
@@ -607,7 +608,7 @@ template <bool INV>
 int launch_1(elph_handle_s *h, int nt, double *out, const double *in, const double *W, int N, int K, int row_tiles, int nrhs,
              const CgState *st, const double *rvec, double *rz_part, int nrz) {
     const int nct = (N + 15) / 16;
-    const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)row_tiles, (unsigned)nrhs), block(CW * WAVE);
+    const dim3 grid((unsigned)((nct + CW1 - 1) / CW1), (unsigned)row_tiles, (unsigned)nrhs), block(CW1 * WAVE);
     const int L = (int)h->L;
 #define MF1_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_1<NTV, INV>), grid, block, 0, h->stream, out, in, W, N, L, K, st, rvec, rz_part, nrz); break;
     switch (nt) {
