@@ -672,9 +672,9 @@ bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N
     if (force == 1) return true;
     // measured crossover against the scalar-twiddle kernels (tools/time_dft_crossover.py, configs C and D): the split form wins
     // from ~100 column-tile waves (8 right-hand sides at N = 256), the direct form from ~512 waves; against the
-    // one-tile-per-wave form (k_dft_mfma_1; config C: preconditioned iteration 60.2 vs 69.9 us at 10 right-hand sides,
-    // 122.9 vs 96.0 at 64) from ~320
-    if (split) return (long long)((N + 15) / 16) * nrhs >= (which == 0 && elph_dft_mfma1_usable(h, inverse, N, 0) ? 320 : 100);
+    // one-tile-per-wave form (k_dft_mfma_1; config C, preconditioned iteration: 54.8 vs 69.9 us at 10 right-hand sides, 71.8 vs
+    // 74.2 at 24, 80.7 vs 76.9 at 32, 100.7 vs 83.5 at 48) from ~450
+    if (split) return (long long)((N + 15) / 16) * nrhs >= (which == 0 && elph_dft_mfma1_usable(h, inverse, N, 0) ? 448 : 100);
     return (long long)((N + 15) / 16) * T.groups * nrhs >= 512;
 }
 

@@ -10,7 +10,7 @@ P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
 pc.setup_(P, rng=np.random.default_rng(7))
 print("orders sum", int(P.orders.sum()), "max", int(P.orders.max()), "Lo2", len(P.orders))
 ms = C.c_double()
-for nrhs in (1, 2, 10, 64, 128):
+for nrhs in ([int(a) for a in sys.argv[2:]] or (1, 2, 10, 64, 128)):
     R, B = configs.rhs(m, nrhs)
     out = {}
     for what, name in ((1, "cg_iter"), (2, "kpm_apply"), (3, "pcg_iter")):
