@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(CW1 * WAVE) k_dft_mfma_1(double *__restrict__ 
                                                      const double *__restrict__ W, int N, int L, int K, const CgState *state,
                                                      const double *__restrict__ rvec, double *__restrict__ rz_part, int nrz) {
     const int rhs = blockIdx.z;
-    if (mf_done(state, rhs)) return;
+    // (the "finished" flag is asked for first and looked at after the operand loads have gone out: its round trip overlaps theirs)
+    const int done_flag = state ? __hip_atomic_load(&state[2 * rhs].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, col = lane & 15, jj = lane >> 4;
     const int ctile = blockIdx.x * CW1 + wv;
     if (ctile * 16 >= N) return;
@@ -173,6 +174,7 @@ __global__ void __launch_bounds__(CW1 * WAVE) k_dft_mfma_1(double *__restrict__ 
             b[tt] = nu[((size_t)k * N + sc) * 2 + (jj & 1)];
         }
     }
+    if (done_flag) return;
     // two accumulators (even / odd reduction tiles): the 40 MFMAs are a dependent chain of 32 cycles each otherwise
     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0}, acc1 = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
