@@ -365,7 +365,7 @@ def main():
         # ---- secondary: the same step at other batch sizes (short runs)
         if not args.no_sweep:
             sweep = {}
-            for nr in (1, 2, 10, 24, 64, 128, 256):
+            for nr in (1, 2, 10, 24, 48, 64, 128, 256):
                 _, Bs = configs.rhs(m, nr)
                 row = {}
                 for form, wh in ((("resident", 9),) if resident else ()) + (("streaming", 3 if args.precond else 1),):
