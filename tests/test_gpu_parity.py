@@ -1308,6 +1308,33 @@ def test_wg_resident_cg_record_numbering_across_batches(monkeypatch):
     m.close()
 
 
+def test_wg_resident_cg_timeout_falls_back_to_the_streaming_iteration(monkeypatch):
+    """A team that cannot meet within the wall-clock bound gives up, every other wave leaves, and the host solves the batch again with
+    the two-kernel iteration from the caller's initial guess (run_cg).  Forced here: 400 workgroups for 256 CUs (teams at the
+    dispatch frontier wait for a whole solve of the resident ones, ~3 ms) with a bound of 1 ms.  Same bits as the streaming form."""
+    from elphdynamics_amd import configs, models
+    R, B = None, None
+    out = {}
+    for name, env in (("stream", {"ELPH_NO_WG": "1"}), ("timeout", {"ELPH_WG_T": "2", "ELPH_WG_TIMEOUT_MS": "1"})):
+        for k in ("ELPH_NO_WG", "ELPH_WG_T", "ELPH_WG_TIMEOUT_MS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = configs.make_model("C", tol=1e-5)
+        if B is None:
+            R, B = configs.rhs(m, 40)
+        X = np.full_like(B, 0.25)                                  # a non-zero initial guess must survive the aborted attempt
+        it, res, fl = models.ldiv_batched_(X, m, B)
+        assert not fl.any() and (res < 1e-4).all(), name
+        out[name] = (X, it)
+        if name == "timeout":                                      # the handle does not try the resident kernel again
+            x = np.zeros(m.Ndim)
+            it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[0]))
+            assert fl1 == 0
+        m.close()
+    assert np.array_equal(out["timeout"][1], out["stream"][1]) and np.array_equal(out["timeout"][0], out["stream"][0])
+
+
 def test_wg_resident_cg_honeycomb_two_slices_per_wave():
     """Config D (honeycomb, 5 sites per lane): a batch beyond the 16 right-hand sides one round holds at 1 slice per wave runs
     2 slices per wave (24 per round) — against single solves (1 slice per wave) of the same right-hand sides."""
