@@ -70,6 +70,9 @@ def parse():
                          "sharded: ONE solve, tau-slabs over the GPUs; spatial: ONE solve, slabs of rows of cells + ghost "
                          "rows (the north_star's decomposition) — RCCL halo exchange + all-gathers per iteration "
                          "(strong scaling; latency-bound at these sizes, reported for completeness)")
+    ap.add_argument("--ranks-per-proc", type=int, default=1,
+                    help="--mode spatial only: rank threads per process (rehearsal of more ranks than the one-GPU box admits "
+                         "processes: 8 ranks = 4 processes x 2; --gpus = total ranks)")
     ap.add_argument("--config", default="C", help="BASELINE config tag (C = Holstein square L=16 Ltau=160)")
     ap.add_argument("--precond", action="store_true", help="KPM (tau-FFT) preconditioned CG iteration")
     ap.add_argument("--streaming", action="store_true", help="time the two-kernel (HBM-streaming) iteration instead of the workgroup-resident kernel")
@@ -84,6 +87,12 @@ def main():
     from elphdynamics_amd import dist as edist
     comm = edist.Comm()            # imports torch (and initialises RCCL) only when WORLD_SIZE > 1
     rank, local_rank, world = comm.rank, comm.local_rank, comm.world
+    if args.mode == "spatial" and args.ranks_per_proc > 1:
+        if args.gpus != world * args.ranks_per_proc:
+            raise SystemExit(f"--gpus {args.gpus} but {world} process(es) x {args.ranks_per_proc} rank threads")
+        edist.HybridComm.spawn(comm, args.ranks_per_proc, lambda hc: main_sharded(args, hc))
+        comm.close()
+        return
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 

@@ -328,7 +328,7 @@ __device__ __forceinline__ void wg_barrier() {
 //     the neighbour's mailbox (granules: the data is its own flag) and takes its own ghost rows of r from its mailbox
 //     together with the second meeting — ONE exchange of the checkerboard boundary rows per iteration;
 //   * the solve starts from x = 0 inside the kernel (r0 = p0 = b, |b|^2 by a first meeting): no host-side combination.
-// Mailbox (identical layout on every rank): [2 meetings][128 records][2 granules] then ghost rows from below / from above
+// Mailbox (identical layout on every rank): [2 meetings][ELPH_SHARD_MAXREC = 256 records][2 granules] then ghost rows from below / from above
 // [Ltau][cap_ghost][2 granules] each.  It is zeroed by elph_shard_prepare; the caller's barrier between prepare and solve
 // keeps a fast rank's first stores from being wiped.
 // ------------------------------------------------------------------------------------------------------------------------
@@ -353,25 +353,29 @@ __device__ __forceinline__ void sh_publish(const ShardCtl &Sh, int m, int g, int
 }
 
 // poll the P G records of meeting m in the own mailbox (wave 0: rec = true) and this lane's ghost granules (gaddr[q] != nullptr);
-// on success `total` = sum of the records in (rank, workgroup) order and gv[q] = the ghost values
+// on success `total` = sum of the records in (rank, workgroup) order and gv[q] = the ghost values.
+// Up to SH_MAXREC = 256 records = 512 granules: eight per lane (8 ranks x 20 workgroups at Ltau = 160 are 320 of them).
 template <int NPL>
 __device__ __forceinline__ bool sh_poll(const ShardCtl &Sh, bool rec, int m, int G, const u64 *const (&gaddr)[NPL], unsigned epoch,
                                         int lane, const WgCtl &R, double &total, double (&gv)[NPL]) {
+    constexpr int NV = 2 * SH_MAXREC / WAVE;
     const int nrec2 = 2 * Sh.P * G;
     const u64 *rbase = Sh.mail[Sh.rank] + (size_t)m * SH_MAXREC * 2;
-    u64 v[4] = {0, 0, 0, 0}, g0[NPL], g1[NPL];
+    u64 v[NV], g0[NPL], g1[NPL];
+#pragma unroll
+    for (int s = 0; s < NV; ++s) v[s] = 0;
     long long t_start = 0;
     for (int spin = 0;; ++spin) {
         bool ok = true;
         if (rec) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) if (lane + 64 * s < nrec2) v[s] = ld_sys(rbase + lane + 64 * s);
+            for (int s = 0; s < NV; ++s) if (lane + WAVE * s < nrec2) v[s] = ld_sys(rbase + lane + WAVE * s);
         }
 #pragma unroll
         for (int q = 0; q < NPL; ++q) if (gaddr[q]) { g0[q] = ld_sys(gaddr[q]); g1[q] = ld_sys(gaddr[q] + 1); }
         if (rec) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) if (lane + 64 * s < nrec2) ok = ok && (unsigned)(v[s] >> 32) == epoch;
+            for (int s = 0; s < NV; ++s) if (lane + WAVE * s < nrec2) ok = ok && (unsigned)(v[s] >> 32) == epoch;
         }
 #pragma unroll
         for (int q = 0; q < NPL; ++q) if (gaddr[q]) ok = ok && (unsigned)(g0[q] >> 32) == epoch && (unsigned)(g1[q] >> 32) == epoch;
@@ -383,10 +387,11 @@ __device__ __forceinline__ bool sh_poll(const ShardCtl &Sh, bool rec, int m, int
     if (rec) {
         const int nr = Sh.P * G;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NV; ++s) {
+            if (s * (WAVE / 2) >= nr) break;
             const int half = (int)(unsigned)v[s];
-            for (int k = 0; k < 32; ++k)
-                if (s * 32 + k < nr) total += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * k + 1), __builtin_amdgcn_readlane(half, 2 * k));
+            for (int k = 0; k < WAVE / 2; ++k)
+                if (s * (WAVE / 2) + k < nr) total += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * k + 1), __builtin_amdgcn_readlane(half, 2 * k));
         }
     }
 #pragma unroll
@@ -1064,12 +1069,10 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     }
     ModelDev m = elph_model_dev(h);
     wg::Shape sh;
-    {   // one slice per wave on every rank (slab sizes differ between ranks; the team shape must not)
-        const int L = (int)h->L;
-        int W = 0;
-        for (int w = std::min(8, L); w >= 1; --w) if (L % w == 0) { W = w; break; }
-        const int G = L / W;
-        if (Sh.P * G > ELPH_SHARD_MAXREC || (G > 1 && W < 2)) { elph_set_error("sharded solve: %d ranks x %d workgroups exceed the %d records of a meeting", Sh.P, G, ELPH_SHARD_MAXREC); return ELPH_E_UNSUPPORTED; }
+    {   // one slice per wave on every rank (slab sizes differ between ranks; the team shape must not): elph_shard_shape
+        int W = 0, G = 0;
+        const int rc = elph_shard_shape(h->L, Sh.P, &W, &G, nullptr, nullptr);
+        if (rc) return rc;
         const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
         sh.T = 1; sh.W = W; sh.G = G; sh.sq = false;
         sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 24) * sizeof(double);

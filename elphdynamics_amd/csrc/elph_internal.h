@@ -347,7 +347,7 @@ int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 // ---- one solve over several GPUs (cg_wg.hip, shard.hip): by-value description of this rank's shard for the resident kernel
-#define ELPH_SHARD_MAXREC 128
+#define ELPH_SHARD_MAXREC 256      // records of a meeting: ranks x workgroups per rank (8 x 20 at Ltau = 160; polled as 8 x 64 granules)
 #define ELPH_SHARD_MAXRANKS 8
 struct ElphShardCtl {
     int rank = 0, P = 1;
@@ -356,6 +356,7 @@ struct ElphShardCtl {
     int cap_ghost = 0;                // capacity (sites) of a ghost region of the mailbox, the same on all ranks
     unsigned long long *mail[ELPH_SHARD_MAXRANKS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
+extern "C" int elph_shard_shape(int64_t ltau, int world, int *waves, int *groups, int *records, int *max_records);   // shard.hip
 int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out);
 
 // ---- workgroup-resident CG (cg_wg.hip): the whole un-preconditioned solve in one launch

@@ -14,7 +14,9 @@
 // RCCL is not used on this path on purpose: its smallest collective costs more than a whole iteration at these sizes
 // (DESIGN.md §6), and it refuses two ranks on one GPU — the only multi-rank set-up the test box offers.
 
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "elph_internal.h"
@@ -48,15 +50,63 @@ static size_t mailbox_words(int64_t L, int cap, int64_t n_global, size_t *ext_of
     return w;
 }
 
+// Mailboxes created by THIS process, keyed by their IPC handle: a host that drives several ranks from one process (one thread
+// per GPU — or the test box's 8 ranks in fewer processes than the box admits on its card) hands elph_shard_connect the same
+// all-gathered handle list as everybody else; a handle found here is mapped by its device pointer (hipIpcOpenMemHandle refuses
+// memory of the calling process), with peer access enabled when the mailbox lives on another device.
+struct LocalMailbox { unsigned char key[ELPH_SHARD_IPC_BYTES]; unsigned long long *ptr; int device; };
+static std::mutex g_local_mu;
+static std::vector<LocalMailbox> g_local_mail;
+
+static void local_mail_register(const void *key, unsigned long long *ptr, int device) {
+    LocalMailbox m;
+    memcpy(m.key, key, ELPH_SHARD_IPC_BYTES);
+    m.ptr = ptr; m.device = device;
+    std::lock_guard<std::mutex> lk(g_local_mu);
+    g_local_mail.push_back(m);
+}
+
+static void local_mail_forget(const unsigned long long *ptr) {
+    std::lock_guard<std::mutex> lk(g_local_mu);
+    for (size_t i = 0; i < g_local_mail.size(); ++i)
+        if (g_local_mail[i].ptr == ptr) { g_local_mail.erase(g_local_mail.begin() + (long)i); return; }
+}
+
+static bool local_mail_find(const void *key, unsigned long long **ptr, int *device) {
+    std::lock_guard<std::mutex> lk(g_local_mu);
+    for (const LocalMailbox &m : g_local_mail)
+        if (memcmp(m.key, key, ELPH_SHARD_IPC_BYTES) == 0) { *ptr = m.ptr; *device = m.device; return true; }
+    return false;
+}
+
 void elph_shard_free(elph_handle_s *h) {
     ShardState *S = static_cast<ShardState *>(h->shard);
     if (!S) return;
+    if (S->mail) local_mail_forget(S->mail);
     for (int q = 0; q < ELPH_SHARD_MAXRANKS; ++q) if (S->opened[q]) (void)hipIpcCloseMemHandle(S->opened[q]);
     if (S->mail) (void)hipFree(S->mail);
     if (S->d_gsites) (void)hipFree(S->d_gsites);
     if (S->d_counter) (void)hipFree(S->d_counter);
     delete S;
     h->shard = nullptr;
+}
+
+// Team shape of the sharded resident kernel and whether its meetings hold the records of `world` ranks — host arithmetic only (no
+// device needed): one slice per wave, W = the largest divisor of Ltau that is <= 8 waves, G = Ltau / W workgroups per rank.
+extern "C" int elph_shard_shape(int64_t ltau, int world, int *waves, int *groups, int *records, int *max_records) {
+    if (ltau < 1 || world < 1 || world > ELPH_SHARD_MAXRANKS) { elph_set_error("bad argument: ltau %lld, world %d (at most %d ranks)", (long long)ltau, world, ELPH_SHARD_MAXRANKS); return ELPH_E_ARG; }
+    int W = 0;
+    for (int w = (int)std::min<int64_t>(8, ltau); w >= 1; --w) if (ltau % w == 0) { W = w; break; }
+    const int64_t G = ltau / W;
+    if (waves) *waves = W;
+    if (groups) *groups = (int)G;
+    if (records) *records = (int)(world * G);
+    if (max_records) *max_records = ELPH_SHARD_MAXREC;
+    if (world * G > ELPH_SHARD_MAXREC || (G > 1 && W < 2)) {
+        elph_set_error("sharded solve: %d ranks x %lld workgroups exceed the %d records of a meeting", world, (long long)G, ELPH_SHARD_MAXREC);
+        return ELPH_E_UNSUPPORTED;
+    }
+    return ELPH_OK;
 }
 
 extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev,
@@ -105,6 +155,7 @@ extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own
     HIPCHK(hipIpcGetMemHandle(&mh, S->mail));
     static_assert(sizeof(hipIpcMemHandle_t) == ELPH_SHARD_IPC_BYTES, "IPC handle size");
     memcpy(ipc_handle_out, &mh, sizeof(mh));
+    local_mail_register(&mh, S->mail, h->device);
     S->ctl.mail[rank] = S->mail;
     return ELPH_OK;
 }
@@ -119,6 +170,17 @@ extern "C" int elph_shard_connect(elph_handle h, const void *all_ipc_handles) {
         if (q == S->ctl.rank) continue;
         hipIpcMemHandle_t mh;
         memcpy(&mh, p + (size_t)q * ELPH_SHARD_IPC_BYTES, sizeof(mh));
+        unsigned long long *lp = nullptr;
+        int ldev = -1;
+        if (local_mail_find(&mh, &lp, &ldev)) {               // rank q lives in this process
+            if (ldev != h->device) {
+                hipError_t pe = hipDeviceEnablePeerAccess(ldev, 0);
+                if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else if (pe != hipSuccess) { elph_set_error("hipDeviceEnablePeerAccess(device %d -> %d): %s", h->device, ldev, hipGetErrorString(pe)); return ELPH_E_HIP; }
+            }
+            S->ctl.mail[q] = lp;
+            continue;
+        }
         void *ptr = nullptr;
         hipError_t e = hipIpcOpenMemHandle(&ptr, mh, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) { elph_set_error("hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e)); return ELPH_E_HIP; }

@@ -118,6 +118,91 @@ class Comm:
             self.dist.destroy_process_group()
 
 
+class _HybridShared:
+    """State the rank threads of one process share (HybridComm)."""
+
+    def __init__(self, proc_comm, nthreads):
+        import threading
+        self.proc_comm, self.nthreads = proc_comm, int(nthreads)
+        self.tb = threading.Barrier(self.nthreads)
+        self.slots = [None] * self.nthreads
+        self.result = None
+
+
+class HybridComm:
+    """Several ranks per process: rank = process rank * threads + thread index.  One thread per rank (every rank its own library
+    handle, HIP stream and — on a multi-GPU host — device); between processes the process's `Comm` (gloo / RCCL), inside a
+    process a thread barrier.  Only thread 0 ever touches torch.distributed.  What the in-library sharded solve needs from a
+    host: all-gather of small objects (the 64-byte mailbox handles, the pieces of the result) and a barrier.
+    Why it exists: a host language with one process and several GPUs (threads or tasks per device) drives `elph_shard_*` like
+    this, and the one-GPU test box admits fewer processes on its card than the 8 ranks BASELINE.json names."""
+
+    def __init__(self, shared, thread_index):
+        self.sh, self.t = shared, int(thread_index)
+        pc = shared.proc_comm
+        self.world = pc.world * shared.nthreads
+        self.rank = pc.rank * shared.nthreads + self.t
+        self.local_rank = pc.local_rank * shared.nthreads + self.t
+        self.backend = pc.backend
+
+    @staticmethod
+    def spawn(proc_comm, nthreads, target):
+        """Run target(comm) on `nthreads` rank threads of this process; returns the list of results (exceptions re-raised)."""
+        import threading
+        shared = _HybridShared(proc_comm, nthreads)
+        out, err = [None] * nthreads, [None] * nthreads
+
+        def run(t):
+            try:
+                out[t] = target(HybridComm(shared, t))
+            except BaseException as e:      # noqa: BLE001 — re-raised below; the other threads must not wait for this one forever
+                err[t] = e
+                shared.tb.abort()
+
+        th = [threading.Thread(target=run, args=(t,)) for t in range(nthreads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        for e in err:
+            if e is not None and not isinstance(e, threading.BrokenBarrierError):
+                raise e
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def device_index(self):
+        forced = os.environ.get("ELPH_FORCE_DEVICE")
+        return int(forced) if forced is not None else self.local_rank
+
+    def barrier(self):
+        self.sh.tb.wait()
+        if self.t == 0:
+            self.sh.proc_comm.barrier()
+        self.sh.tb.wait()
+
+    def allgather_object(self, obj):
+        self.sh.slots[self.t] = obj
+        self.sh.tb.wait()
+        if self.t == 0:
+            per_proc = self.sh.proc_comm.allgather_object(list(self.sh.slots))
+            self.sh.result = [o for lst in per_proc for o in lst]
+        self.sh.tb.wait()
+        res = self.sh.result
+        self.sh.tb.wait()                   # nobody overwrites slots / result before everybody has read them
+        return res
+
+    def max(self, value):
+        return max(float(v) for v in self.allgather_object(float(value)))
+
+    def sum(self, value):
+        return float(sum(float(v) for v in self.allgather_object(float(value))))
+
+    def close(self):
+        self.barrier()
+
+
 def timed_steps(comm, run_steps, steps):
     """The bench contract: barrier + synchronise, run exactly `steps` steps, synchronise + barrier, MAX over ranks.
     `run_steps(k)` must return only after the device has finished the k steps.  Returns (elapsed_max, total_work)

@@ -557,18 +557,29 @@ class ShardedSolver:
         self._lib_mod.check(self.lib.elph_update_model_ssh(self.h, d(c), d(s), d(e)))
 
     def setup_kpm(self, expV_global, n=20, buf=0.05, c1=1.0, c2=1.0, seed=7, e_min=None, e_max=None):
-        """KPM preconditioner under sharding (Holstein): a second handle on the WHOLE lattice carries Ē, the Arnoldi bounds, the
+        """KPM preconditioner under sharding (Holstein; SSH with expV_global = (cosht, sinht, exp(Δτμ)) of the whole lattice):
+        a second handle on the WHOLE lattice carries Ē, the Arnoldi bounds, the
         orders and coefficients — set up identically on every rank (same inputs, same start vectors) — and runs the per-frequency
         Chebyshev recursion; see elph_shard_solve_kpm.  Returns (active, lam_lo, lam_hi)."""
-        assert self.kind == 0, "KPM under sharding: Holstein models"
         lm, lib = self._lib_mod, self.lib
         tab, c, s, dev = self._full
         if self.hf is None:
             self.hf = lm.Handle()
-            lm.check(lib.elph_create(C.byref(self.hf), 0, self.N, self.Ltau, tab.shape[0], lm.iptr(tab),
-                                     lm.dptr(np.ascontiguousarray(c)), lm.dptr(np.ascontiguousarray(s)), dev))
+            if self.kind == 0:
+                lm.check(lib.elph_create(C.byref(self.hf), 0, self.N, self.Ltau, tab.shape[0], lm.iptr(tab),
+                                         lm.dptr(np.ascontiguousarray(c)), lm.dptr(np.ascontiguousarray(s)), dev))
+            else:
+                lm.check(lib.elph_create(C.byref(self.hf), 1, self.N, self.Ltau, tab.shape[0], lm.iptr(tab), None, None, dev))
             lm.check(lib.elph_kpm_create(self.hf, n, buf, c1, c2))
-        lm.check(lib.elph_set_expV(self.hf, lm.dptr(np.ascontiguousarray(np.asarray(expV_global).reshape(-1)))))
+        if self.kind == 0:
+            lm.check(lib.elph_set_expV(self.hf, lm.dptr(np.ascontiguousarray(np.asarray(expV_global).reshape(-1)))))
+        else:
+            # bond phonons: expV_global = (cosht[Nbonds, Ltau], sinht[Nbonds, Ltau], exp(dtau mu)[N]) of the WHOLE lattice — the expansion
+            # takes the tau-means of the hopping tables (update_A!, KPMPreconditioners.jl:355-381)
+            cg, sg, eg = expV_global
+            d = lm.dptr
+            lm.check(lib.elph_update_model_ssh(self.hf, d(np.ascontiguousarray(np.asarray(cg).reshape(-1))),
+                                               d(np.ascontiguousarray(np.asarray(sg).reshape(-1))), d(np.ascontiguousarray(eg))))
         rng = np.random.default_rng(seed)
         bmax, bmin = rng.standard_normal(self.N), rng.standard_normal(self.N)
         act, lo, hi = C.c_int(), C.c_double(), C.c_double()

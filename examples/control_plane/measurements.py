@@ -14,8 +14,8 @@ reference's `position` arrays.  Orbitals are 1-based, displacements 0-based, as 
 """
 import numpy as np
 
-from . import greens, models
-from .mu_tuner import measure_N2, measure_density
+from elphdynamics_amd import greens, models
+from mu_tuner import measure_N2, measure_density
 
 KINDS = ("Greens", "DenDen", "SpinSpin", "PairGreens")
 

@@ -14,8 +14,8 @@ import math
 
 import numpy as np
 
-from . import greens, models
-from ._lib import check, dptr
+from elphdynamics_amd import greens, models
+from elphdynamics_amd._lib import check, dptr
 
 
 def forgetful_mean(x, xbar_prev, c):

@@ -1,4 +1,4 @@
-"""python -m elphdynamics_amd deck.toml [--chains N] [--device D] [--out phonon_config.out]
+"""python examples/control_plane/run_deck.py deck.toml [--chains N] [--device D] [--out phonon_config.out]
 
 Runs one of the reference's TOML decks on the GPU the way `julia -e "using ElPhDynamics; simulate(ARGS)" -- deck.toml` runs it
 (ElPhDynamics.jl:80-130): burn-in and simulation updates with the deck's dynamics, special updates, μ-tuning and, at every
@@ -6,6 +6,11 @@ measurement, the correlation functions of measurements.py averaged over the run.
 optionally writes the final phonon configuration in the reference's text format.  The reference's measurement files, bins,
 checkpoints and logs are not produced (control plane)."""
 import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import json
 import sys
 
@@ -13,14 +18,16 @@ import numpy as np
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(prog="python -m elphdynamics_amd")
+    ap = argparse.ArgumentParser(prog="python examples/control_plane/run_deck.py")
     ap.add_argument("deck")
     ap.add_argument("--chains", type=int, default=1, help="independent runs of the deck advanced in lockstep on this GPU")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default=None, help="write the final phonon configuration (chain 0) here")
     ap.add_argument("--checkpoint", default=None, help="checkpoint file: written periodically, resumed from when it exists")
     args = ap.parse_args(argv)
-    from . import dist, io, measurements, process_input, run_simulation
+    from elphdynamics_amd import dist, io, process_input
+    import measurements
+    import run_simulation
     # several GPUs (python -m torch.distributed.run --nproc-per-node N -m elphdynamics_amd deck.toml …): every rank runs its own
     # chains of the deck on its own GPU with its own seed — the reference's independent run-IDs (ElPhDynamics.jl:90-95); no
     # data-path communication, rank 0 prints the gathered statistics
@@ -45,7 +52,7 @@ def main(argv=None):
     def measure(sim, n):
         if acc is not None:
             # the Green's estimate of this measurement is fresh (run_simulation_ called update!); add every pair's contribution
-            from . import greens
+            from elphdynamics_amd import greens
             for i in range(1, sim.Gr.nv):
                 for j in range(i + 1, sim.Gr.nv + 1):
                     greens.setup_(sim.Gr, i, j)
@@ -65,7 +72,7 @@ def main(argv=None):
         out["mu"] = acc["glob"]["mu"] / acc["n"]
         out["G_r0_tau0"] = float(np.real(acc["corr"]["Greens"][0, 0, 0, 0, 0]) / acc["n"])
     if sim.mu_tuner.active and args.chains == 1:
-        from .mu_tuner import estimate_mu
+        from mu_tuner import estimate_mu
         estimate_mu(sim.mu_tuner)
         out["mu_avg"], out["mu_err"] = sim.mu_tuner.mu_avg, sim.mu_tuner.mu_err
     if args.out:

@@ -12,8 +12,8 @@ import time
 
 import numpy as np
 
-from . import greens, hmc, langevin
-from .mu_tuner import make_chain_tuners, update_mu_, update_mu_chains_
+from elphdynamics_amd import greens, hmc, langevin
+from mu_tuner import MuTuner, make_chain_tuners, update_mu_, update_mu_chains_
 
 
 def _special(sim, dyn, n, reflect, swap, stats, P, rng):
@@ -69,7 +69,7 @@ def load_checkpoint(path, sim, rng, extra=None):
     written by this module: only load checkpoints of your own runs; one that belongs to another deck (lattice, time axis, model
     family, number of chains) is refused."""
     import pickle
-    from ._lib import check, dptr
+    from elphdynamics_amd._lib import check, dptr
     with open(path, "rb") as f:
         st = pickle.load(f)
     if not isinstance(st, dict) or st.get("format") != "elphdynamics_amd checkpoint 2":
@@ -108,6 +108,9 @@ def run_simulation_(sim, measure=None, rng=None, checkpoint=None, checkpoint_eve
     import os
     m, fa, P, sp = sim.model, sim.fa, sim.preconditioner, sim.sim_params
     rng = rng or getattr(m, "rng", None)
+    tp = getattr(sim, "mu_tuner", None)
+    if tp is not None and not isinstance(tp, MuTuner):                   # the deck reader hands over the [tune_density] parameters only
+        sim.mu_tuner = MuTuner(tp.active, tp.mu0, tp.N_target, tp.nsites, tp.beta, tp.dtau, tp.memory, tp.kappa_min)
     stats = dict(simulation_time=0.0, measurement_time=0.0, write_time=0.0, iters=0.0, acceptance_rate=0.0,
                  reflect_acceptance_rate=0.0, swap_acceptance_rate=0.0)
     is_hmc = isinstance(sim.simulation_dynamics, hmc.HybridMonteCarlo)

@@ -11,7 +11,8 @@ DECKS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decks")
 
 @pytest.mark.parametrize("kind", ["Greens", "DenDen", "SpinSpin", "PairGreens"])
 def test_whole_table_forms_equal_the_literal_ones(kind):
-    from elphdynamics_amd import lattice as lat, measurements as M
+    from elphdynamics_amd import lattice as lat
+    import measurements as M
     rng = np.random.default_rng(3)
     L, ns, L1, L2, L3 = 5, 2, 3, 4, 2
     model = SimpleNamespace(Ltau=L, lattice=lat.Lattice(ns, L1, L2, L3))
@@ -27,7 +28,7 @@ def test_whole_table_forms_equal_the_literal_ones(kind):
 
 
 def test_translational_average_is_the_periodic_cross_correlation():
-    from elphdynamics_amd import measurements as M
+    import measurements as M
     rng = np.random.default_rng(1)
     f, g = rng.standard_normal((4, 3, 2)), rng.standard_normal((4, 3, 2))
     ta = M.translational_average(f.astype(complex), g)
@@ -39,7 +40,9 @@ def test_translational_average_is_the_periodic_cross_correlation():
 
 @pytest.mark.gpu
 def test_measurements_of_a_deck_run():
-    from elphdynamics_amd import measurements as M, process_input as pi, run_simulation as rs
+    from elphdynamics_amd import process_input as pi
+    import measurements as M
+    import run_simulation as rs
     sim = pi.process_input_file(os.path.join(DECKS, "holstein_hmc_honeycomb_L3.toml"))
     m = sim.model
     acc = M.new_accumulator(m)
@@ -81,7 +84,8 @@ def test_measurements_of_a_deck_run():
 
 @pytest.mark.gpu
 def test_measurements_of_a_bond_phonon_deck():
-    from elphdynamics_amd import measurements as M, process_input as pi
+    from elphdynamics_amd import process_input as pi
+    import measurements as M
     sim = pi.process_input_file(os.path.join(DECKS, "ssh_langevin_square_L4.toml"))
     m = sim.model
     acc = M.new_accumulator(m)

@@ -12,7 +12,7 @@ DECKS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decks")
 def test_forgetful_statistics_equal_the_windowed_ones(c):
     """forgetful_mean / forgetful_welfords (MuFinder.jl:210-261) are incremental forms of the mean / standard deviation over
     the most recent fraction c of the history, x[i:] with i = 1 + floor((1 - c) N) (1-based)."""
-    from elphdynamics_amd.mu_tuner import forgetful_mean, forgetful_welfords
+    from mu_tuner import forgetful_mean, forgetful_welfords
     rng = np.random.default_rng(4)
     x, xb, wb, ws = [], 0.0, 0.0, 0.0
     for n in range(1, 60):
@@ -29,7 +29,7 @@ def test_forgetful_statistics_equal_the_windowed_ones(c):
 
 def test_tuner_moves_mu_against_the_density_error():
     """update_μ!(tuner, N, N²) (:112-166): μ = μ̄ + (target − N̄)/κ̄ with κ̄ clamped to [κ_min/√n, √var N/σ_μ]."""
-    from elphdynamics_amd.mu_tuner import MuTuner, estimate_mu
+    from mu_tuner import MuTuner, estimate_mu
     t = MuTuner(True, 0.0, 16.0, 16, 2.0, 0.1, 0.75, 1.6)
     mu = t.update(20.0, 20.0 ** 2 + 3.0)             # too many electrons -> μ goes down
     assert mu < 0.0 and t.kappa_bar == pytest.approx(1.6) and t.L == 20

@@ -470,8 +470,14 @@ int elph_omega_to_tau(elph_handle h, double *v, const double *nu_complex);
  * with the same inputs on every rank).  Per iteration the ranks trade three partial inner products and all-gather the tau-spectrum
  * of the residual (peer stores into the mailboxes); every rank runs the per-frequency Chebyshev recursion on the whole lattice and
  * transforms back its own and ghost rows — no omega-sharded all-to-all: the recursion's critical path is its longest frequency
- * block either way (KPMPreconditioners.jl:426-481). */
+ * block either way (KPMPreconditioners.jl:426-481).
+ * Ranks that live in ONE process (a host thread or task per GPU) use the same calls: a handle in the all-gathered list that this
+ * process created itself is mapped by its device pointer (peer access enabled between devices) instead of through hipIpc.
+ * elph_shard_shape — host arithmetic, no device: the team shape (waves per workgroup, workgroups per rank) the sharded kernel
+ * takes for a time axis and the number of records world ranks put into a meeting against the capacity; ELPH_E_UNSUPPORTED
+ * when they do not fit (every BASELINE config fits at 1, 2, 4 and 8 ranks: 8 x 20 = 160 of 256 at Ltau = 160). */
 #define ELPH_SHARD_IPC_BYTES 64
+int elph_shard_shape(int64_t ltau, int world, int *waves, int *groups, int *records, int *max_records);
 int elph_shard_create(elph_handle h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev,
                       int64_t n_to_next, int64_t cap_ghost, int64_t n_global, int64_t own_global_start,
                       const int64_t *global_sites, void *ipc_handle_out);

@@ -1,5 +1,6 @@
-"""Worker of the in-library sharded-solve tests (one process per rank, all on device 0; gloo carries the mailbox handles, the
-barriers and the final gather — the iterations run entirely on the GPU, csrc/shard.hip).
+"""Worker of the in-library sharded-solve tests (one process per rank — or, ELPH_RANKS_PER_PROC = k, k rank threads per process:
+the test box admits six processes on its card, BASELINE.json names eight ranks — all on device 0; gloo carries the mailbox
+handles, the barriers and the final gather — the iterations run entirely on the GPU, csrc/shard.hip).
 
 usage: shard_worker.py <case> <out prefix>      case in {sq8, hc4, e8, C, D, E}
 Every rank writes <out>.rank<r>.npz with the assembled solution and the inputs the test needs to check it."""
@@ -25,10 +26,7 @@ CASES = {
 }
 
 
-def main():
-    case, out = sys.argv[1], sys.argv[2]
-    tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-9
-    comm = dist.Comm(backend="gloo")
+def run_rank(comm, case, out, tol):
     kind, norb, Ls, bonds, Ltau, dtau = CASES[case]
     la = lat.Lattice(norb, Ls, Ls, 1)
     raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
@@ -56,14 +54,26 @@ def main():
     # a second solve on the same handle (mailbox re-zeroed, new barrier): same bits
     xs2, it2, done2 = solver.solve(b, tol=tol, maxiter=20000)
     res.update(x2=xs2, it2=it2)
-    if kind == 0 and os.environ.get("ELPH_TEST_KPM") == "1":
+    if os.environ.get("ELPH_TEST_KPM") == "1":
         # KPM-preconditioned solve under sharding: same Arnoldi start vectors on every rank (and in the un-sharded check of the test)
-        act, lo, hi = solver.setup_kpm(E, n=20, buf=0.05, c1=1.0, c2=1.0, seed=7)
+        act, lo, hi = solver.setup_kpm(E if kind == 0 else (c, s, emu), n=20, buf=0.05, c1=1.0, c2=1.0, seed=7)
         xk, itk, donek = solver.solve(b, tol=tol, maxiter=20000, precond=True)
         res.update(xk=xk, itk=itk, donek=donek, kpm_active=act, lam_lo=lo, lam_hi=hi)
     solver.close()
     np.savez(out + f".rank{comm.rank}", **res)
     comm.close()
+
+
+def main():
+    case, out = sys.argv[1], sys.argv[2]
+    tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-9
+    per_proc = int(os.environ.get("ELPH_RANKS_PER_PROC", "1"))
+    comm = dist.Comm(backend="gloo")
+    if per_proc == 1:
+        run_rank(comm, case, out, tol)
+    else:
+        dist.HybridComm.spawn(comm, per_proc, lambda c: run_rank(c, case, out, tol))
+        comm.close()
 
 
 if __name__ == "__main__":

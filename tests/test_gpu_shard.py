@@ -24,13 +24,18 @@ def _free_port():
     return p
 
 
-def _run(case, tmp_path, world, tol=1e-9, kpm=False):
+def _run(case, tmp_path, world, tol=1e-9, kpm=False, per_proc=1):
+    """world ranks as world / per_proc processes of per_proc rank threads each (the box admits six processes on its card: eight
+    ranks run as four processes of two)."""
     port = _free_port()
     out = str(tmp_path / f"shard_{case}_{world}")
     procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ELPH_FORCE_DEVICE="0", ELPH_WG_TIMEOUT_MS="60000", ELPH_TEST_KPM="1" if kpm else "0")
+    assert world % per_proc == 0
+    nproc = world // per_proc
+    for r in range(nproc):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ELPH_FORCE_DEVICE="0", ELPH_WG_TIMEOUT_MS="60000", ELPH_TEST_KPM="1" if kpm else "0",
+                   ELPH_RANKS_PER_PROC=str(per_proc))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), case, out, repr(tol)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     errs = []
@@ -78,11 +83,15 @@ def test_sharded_solve_small_lattices(tmp_path, oracle, case, world, halo):
     assert err < 1e-7 and rres < 1e-8
 
 
-@pytest.mark.parametrize("case,world", [("C", 2), ("D", 2), ("D", 4), ("E", 2), ("E", 4)])
+@pytest.mark.parametrize("case,world", [("C", 2), ("D", 2), ("D", 4), ("E", 2), ("E", 4), ("C", 8), ("D", 8), ("E", 8)])
 def test_sharded_solve_baseline_configs(tmp_path, oracle, case, world):
-    """Configs D and E (and C) at full size, sharded over 2 and 4 ranks, solved to 1e-13 on both sides: the sharded solution is
-    within the north_star's 1e-10 of the oracle's un-sharded one."""
-    res = _run(case, tmp_path, world, tol=1e-13)
+    """Configs D and E (and C) at full size, sharded over 2, 4 and 8 ranks (BASELINE.json: "1, 2, 4 and 8 GPUs"), solved to 1e-13 on
+    both sides: the sharded solution is within the north_star's 1e-10 of the oracle's un-sharded one.  Eight ranks run as four
+    processes of two rank threads (the box admits six processes on its card): 8 x 20 = 160 records per meeting at Ltau = 160,
+    config D in slabs of 1,2,1,2,... rows."""
+    res = _run(case, tmp_path, world, tol=1e-13, per_proc=2 if world == 8 else 1)
+    if world == 8:
+        assert int(res[0]["rows"].sum()) == (12 if case == "D" else 16) and len(res[0]["rows"]) == 8
     err, rres = _check(res, oracle, 1e-13)
     assert err < 1e-10, err
     assert rres < 1e-11
@@ -113,7 +122,7 @@ def test_sharded_solve_one_rank_equals_the_unsharded_handle(tmp_path):
         lib.elph_destroy(h)
 
 
-@pytest.mark.parametrize("case,world", [("sq8", 2), ("C", 2), ("D", 2), ("D", 4)])
+@pytest.mark.parametrize("case,world", [("sq8", 2), ("C", 2), ("D", 2), ("D", 4), ("e8", 2), ("E", 2), ("C", 8)])
 def test_sharded_kpm_preconditioned_solve(tmp_path, case, world):
     """SURVEY 8e 'KPM under sharding': the preconditioned solve over 2 / 4 ranks against the preconditioned solve of ONE handle on the
     whole lattice with the same Arnoldi start vectors: same expansion (bounds), same iteration count (+-1 at the knife edge), and —
@@ -122,18 +131,25 @@ def test_sharded_kpm_preconditioned_solve(tmp_path, case, world):
     from elphdynamics_amd import _lib
     lib = _lib.load()
     tol = 1e-13
-    res = _run(case, tmp_path, world, tol=tol, kpm=True)
+    res = _run(case, tmp_path, world, tol=tol, kpm=True, per_proc=2 if world == 8 else 1)
     a = res[0]
     for b in res[1:]:
         assert int(a["itk"]) == int(b["itk"]) and np.array_equal(a["xk"], b["xk"])
     assert int(a["donek"]) == 1 and int(a["kpm_active"]) == 1
-    N, L = int(a["N"]), int(a["Ltau"])
+    N, L, kind = int(a["N"]), int(a["Ltau"]), int(a["kind"])
     h = _lib.Handle()
     tab = np.ascontiguousarray(a["table"], dtype=np.int64)
-    _lib.check(lib.elph_create(C.byref(h), 0, N, L, tab.shape[0], _lib.iptr(tab), _lib.dptr(np.ascontiguousarray(a["c"])),
-                               _lib.dptr(np.ascontiguousarray(a["s"])), 0))
+    if kind == 0:
+        _lib.check(lib.elph_create(C.byref(h), 0, N, L, tab.shape[0], _lib.iptr(tab), _lib.dptr(np.ascontiguousarray(a["c"])),
+                                   _lib.dptr(np.ascontiguousarray(a["s"])), 0))
+    else:
+        _lib.check(lib.elph_create(C.byref(h), 1, N, L, tab.shape[0], _lib.iptr(tab), None, None, 0))
     try:
-        _lib.check(lib.elph_set_expV(h, _lib.dptr(np.ascontiguousarray(a["E"]))))
+        if kind == 0:
+            _lib.check(lib.elph_set_expV(h, _lib.dptr(np.ascontiguousarray(a["E"]))))
+        else:       # bond phonons: per-(bond, tau) tables of the whole lattice, tau-means inside the expansion (KPMPreconditioners.jl:355-381)
+            _lib.check(lib.elph_update_model_ssh(h, _lib.dptr(np.ascontiguousarray(a["c"]).reshape(-1)),
+                                                 _lib.dptr(np.ascontiguousarray(a["s"]).reshape(-1)), _lib.dptr(np.ascontiguousarray(a["E"]))))
         _lib.check(lib.elph_kpm_create(h, 20, 0.05, 1.0, 1.0))
         rng = np.random.default_rng(7)
         bmax, bmin = rng.standard_normal(N), rng.standard_normal(N)

@@ -131,3 +131,77 @@ def test_spatial_slab_tables():
         slabs(1, 8, lat.SQUARE_BONDS, 16)           # more ranks than rows of cells
     S1, tab1 = slabs(1, 8, lat.SQUARE_BONDS, 1)
     assert S1.slabs[0]["lo"] == 0 and len(S1.slabs[0]["bonds"]) == tab1.shape[0]
+
+
+# ---- eight ranks (BASELINE.json: "1, 2, 4 and 8 GPUs"): the host-side arithmetic of the in-library sharded solve -----------------
+
+@pytest.mark.parametrize("tag,norb,Ls,Ltau,rows8,halo", [("C", 1, 16, 160, [2] * 8, (2, 2)), ("D", 2, 12, 120, [1, 2] * 4, (1, 1)),
+                                                         ("E", 1, 16, 160, [2] * 8, (2, 2))])
+def test_slabs_and_team_shape_accept_eight_ranks(tag, norb, Ls, Ltau, rows8, halo):
+    """SpatialSlabs (own rows + dependency-closure ghost rows) and the library's team-shape arithmetic (elph_shard_shape: host
+    code, no device) take every BASELINE config at 1, 2, 4 and 8 ranks: no ELPH_E_UNSUPPORTED, ghost rows inside the neighbour."""
+    import ctypes as C
+    from elphdynamics_amd import _lib, sharded
+    from elphdynamics_amd import lattice as lat
+    lib = _lib.load()
+    la = lat.Lattice(norb, Ls, Ls, 1)
+    bonds = lat.SQUARE_BONDS if norb == 1 else lat.HONEYCOMB_BONDS
+    raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+    cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), 0.1)
+    for world in (1, 2, 4, 8):
+        sl = sharded.SpatialSlabs(norb, Ls, Ls, cb["table"], world)
+        rows = [s["R"] for s in sl.slabs]
+        assert sum(rows) == Ls
+        if world == 8:
+            assert rows == rows8
+        covered = np.zeros(la.nsites, dtype=int)
+        for q in range(world):
+            s, sp, sn = sl.slabs[q], sl.slabs[(q - 1) % world], sl.slabs[(q + 1) % world]
+            if world > 1:
+                assert (s["lo"], s["hi"]) == halo
+                assert s["lo"] <= sp["R"] and s["hi"] <= sn["R"]          # the mailbox protocol: ghosts come from the ring neighbours only
+            gs = sl.global_sites(q)
+            covered[gs[s["lo"] * sl.row:(s["lo"] + s["R"]) * sl.row]] += 1
+            assert (s["lo"] + s["R"] + s["hi"]) * sl.row <= 320           # the resident kernel's slab limit (5 sites per lane)
+        assert np.all(covered == 1)                                        # every site owned exactly once
+        W, G, rec, cap = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rc = lib.elph_shard_shape(Ltau, world, C.byref(W), C.byref(G), C.byref(rec), C.byref(cap))
+        assert rc == 0, lib.elph_last_error()
+        assert W.value * G.value == Ltau and rec.value == world * G.value <= cap.value == 256
+    # what does not fit is refused cleanly: a prime time axis has one wave per workgroup
+    assert lib.elph_shard_shape(1021, 2, None, None, None, None) == -5 and b"records" in lib.elph_last_error()
+    assert lib.elph_shard_shape(160, 9, None, None, None, None) == -1
+
+
+def _hybrid_worker_main():
+    """(run as a subprocess by the test below) two processes x three rank threads = six ranks over gloo + thread barriers"""
+    from elphdynamics_amd import dist
+    comm = dist.Comm(backend="gloo")
+
+    def body(c):
+        got = c.allgather_object(("rank", c.rank))
+        assert got == [("rank", r) for r in range(c.world)], got
+        for k in range(3):
+            c.barrier()
+            got = c.allgather_object(c.rank * 10 + k)
+            assert got == [r * 10 + k for r in range(c.world)]
+        c.close()
+        return c.rank
+
+    ranks = dist.HybridComm.spawn(comm, 3, body)
+    assert ranks == [comm.rank * 3 + t for t in range(3)]
+    comm.close()
+
+
+def test_hybrid_comm_threads_times_processes(tmp_path):
+    """dist.HybridComm: several ranks per process (threads) times several processes (gloo) — what drives eight ranks of the sharded
+    solve from four processes on the one-GPU box, and a single-process multi-GPU host in production."""
+    port = _free_port()
+    procs = []
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_sharded_gloo as t; t._hybrid_worker_main()" % (ROOT, os.path.join(ROOT, "tests"))
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
