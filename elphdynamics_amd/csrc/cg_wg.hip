@@ -37,7 +37,7 @@ template <int NPL>
 __host__ __device__ constexpr int slab_len() { return NPL * WAVE + 2 * WAVE; }
 
 struct WgCtl {
-    u64 *slots;          // [nrhs][p.z | r.r][Gmax = 32][2 granules]
+    u64 *slots;          // [nrhs][SLOTS_PER_RHS]: four-sum records [32][8 granules] | single-sum records [32][2] (a shard: [p.z | r.r][32][2])
     u64 *bnd;            // [nrhs][G][2][NPL*64][2 granules]: first / last slice of r of every workgroup (G > 1 only)
     int *abort;
     unsigned epoch0;     // tags of this launch are epoch0 + iteration: every launch of a handle gets a range of its own, so the
@@ -274,6 +274,83 @@ __device__ __forceinline__ bool poll_granules(const u64 *rec, int G, const u64 *
     }
 }
 
+// ---- the ONE meeting of an iteration (single-meeting form): a workgroup's record is FOUR sums — p.z, r.z, z.z and r.r — as eight
+// self-tagged granules; a team's records fill 8 G granules (G <= 32: up to four loads per lane of the polling wave).
+constexpr int REC4 = 8;                      // granules per record
+constexpr int SLOTS_A = REC4 * 32;           // granules of a right-hand side's four-sum records (G <= 32)
+constexpr int SLOTS_PER_RHS = SLOTS_A + 64;  // + the single-sum records of the fallback meeting (direct r.r)
+
+// the workgroup's record: `mine` = sum_part4 (lanes 8 j .. 8 j + 7 hold value j); lanes 8 j and 8 j + 1 store its two halves
+__device__ __forceinline__ void publish_rec4(u64 *slots, int g, double mine, unsigned epoch, int lane) {
+    if (lane < 32 && (lane & 7) < 2) {
+        const u64 bits = (u64)__double_as_longlong(mine);
+        st_gran(slots + REC4 * g + 2 * (lane >> 3) + (lane & 1), ((u64)epoch << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+    }
+}
+
+// The four totals of the team from the polled granules, lane-parallel (no scalar round trips): lane l of load k holds granule
+// l of records 8k .. 8k+7 = {record 8k + (l >> 3), value (l & 7) >> 1, half l & 1}.  Halves -> f64 in the even lanes, records of
+// the four loads added in load order, then a butterfly over the eight records of a load (lanes 8 apart): every lane with
+// (l & 7) == 2 j ends with the total of value j.  One fixed tree, the same in every wave that runs it on the same records.
+template <int NL>
+__device__ __forceinline__ double sum_rec4(const u64 (&v)[NL], int G, int lane) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int lo = (int)(unsigned)v[k];
+        const int hi = __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xF, 0xF, true);      // quad_perm [1,1,3,3]: the odd neighbour's half
+        const double val = __hiloint2double(hi, lo);
+        acc += (8 * k + (lane >> 3) < G) ? val : 0.0;
+    }
+    acc += dpp_f64<0x128>(acc);                         // row_ror:8 — records 1 apart (8 lanes)
+    acc += __shfl_xor(acc, 16, WAVE);
+    acc += __shfl_xor(acc, 32, WAVE);
+    return acc;
+}
+
+// sum over the W wave partials of value j for j = 0..3 at once: lane 8 j + w reads part[j][w]; a butterfly inside each group of eight
+// lanes leaves the total of value j in all eight of them (same tree in every wave)
+__device__ __forceinline__ double sum_part4(const double *part, int W, int lane) {
+    double v = (lane < 32 && (lane & 7) < W) ? part[lane] : 0.0;
+    v += dpp_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);         // row_half_mirror: lanes 4 apart inside a group of eight
+    return v;
+}
+
+// poll the team's four-sum records (rec != nullptr: NL loads per lane cover 8 G granules) and up to two boundary SEGMENTS (64 values of
+// a neighbouring workgroup's boundary slice of z, one per lane: b0 / b1 point at this lane's granule pair, nullptr = none).  The
+// boundary slices are 2 NPL segments; the waves of a workgroup share them out (see the meeting), so a wave holds 4-8 registers of
+// granules while z and p are live instead of 4 NPL + 4.  One poll at a time.
+template <int NL>
+__device__ __forceinline__ bool poll_rec4(const u64 *rec, int G, const u64 *b0, const u64 *b1, unsigned epoch, int lane, const WgCtl &R,
+                                          u64 (&v)[NL], double &z0, double &z1) {
+    const int ngran = REC4 * G;
+    u64 a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+    long long t_start = 0;
+    for (int spin = 0;; ++spin) {
+        bool ok = true;
+        if (rec) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) if (lane + WAVE * k < ngran) v[k] = ld_gran(rec + lane + WAVE * k);
+        }
+        if (b0) { a0 = ld_gran(b0); a1 = ld_gran(b0 + 1); }
+        if (b1) { c0 = ld_gran(b1); c1 = ld_gran(b1 + 1); }
+        if (rec) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) if (lane + WAVE * k < ngran) ok = ok && (unsigned)(v[k] >> 32) == epoch;
+        }
+        if (b0) ok = ok && (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch;
+        if (b1) ok = ok && (unsigned)(c0 >> 32) == epoch && (unsigned)(c1 >> 32) == epoch;
+        if (__all(ok)) break;
+        if (poll_bail<1>(spin, t_start, lane, R)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    z0 = __hiloint2double((int)(unsigned)a1, (int)(unsigned)a0);
+    z1 = __hiloint2double((int)(unsigned)c1, (int)(unsigned)c0);
+    return true;
+}
+
 __device__ __forceinline__ void st_f64_gran(u64 *g2, double v, unsigned epoch) {
     const u64 bits = (u64)__double_as_longlong(v), tag = (u64)epoch << 32;
     st_gran(g2, tag | (bits & 0xFFFFFFFFull));
@@ -292,6 +369,26 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     const double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
     const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
     return (r0 + r1) + (r2 + r3);
+}
+
+// FOUR wave-wide sums at once, transposed on the way: after two exchange steps inside each quad a lane carries ONE of the four
+// values (index lane & 3), then rotations by 4 and 8 inside the 16-lane row and two wave shuffles add the lanes of that index.
+// ~35 vector-ALU instructions and 4 ds_bpermute against 4 x 23 for four separate sums.  The result is taken from lanes 0..3
+// (value lane & 3): one fixed tree, the same in every wave and every run.
+__device__ __forceinline__ double wave_sum4(double a0, double a1, double a2, double a3, int lane) {
+    const bool odd = (lane & 1) != 0, hi2 = (lane & 2) != 0;
+    double k0 = odd ? a1 : a0, k1 = odd ? a3 : a2;            // kept; the other two go to lane ^ 1
+    const double s0 = odd ? a0 : a1, s1 = odd ? a2 : a3;
+    k0 += dpp_f64<0xB1>(s0);                                  // quad_perm [1,0,3,2]
+    k1 += dpp_f64<0xB1>(s1);
+    double k = hi2 ? k1 : k0;
+    const double s = hi2 ? k0 : k1;
+    k += dpp_f64<0x4E>(s);                                    // quad_perm [2,3,0,1]: lane & 3 = value index from here on
+    k += dpp_f64<0x124>(k);                                   // row_ror:4
+    k += dpp_f64<0x128>(k);                                   // row_ror:8
+    k += __shfl_xor(k, 16, WAVE);
+    k += __shfl_xor(k, 32, WAVE);
+    return k;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -417,9 +514,13 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // to LDS (read twice per iteration; 40 registers) and x stays in registers instead (LDS is full); otherwise E in registers
     // (0.35 us per iteration faster at 2 slices per wave), x and r in LDS
     constexpr bool E_LDS = SQ && T >= 4, X_REG = SQ && T >= 4;
+    // ONE: the single-meeting iteration (see the loop); a shard keeps the two-meeting form (its second meeting carries the ghost rows)
+    constexpr bool ONE = !SHARD;
     const int W = R.W, G = R.G;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    // (a shard: ONE right-hand side, its G workgroups are the whole grid, spread over the XCDs — several ranks on one GPU, the test
+    //  box, would otherwise pile their teams onto the XCD where every dispatch starts: 2 x 20 workgroups do not fit its 32 CUs)
+    const int xcd = SHARD ? 0 : (blockIdx.x & 7), idx = SHARD ? blockIdx.x : (blockIdx.x >> 3);
     const int tq = idx / G, g = idx - tq * G;
     const int rhs = tq * 8 + xcd;
     if (rhs >= B.nrhs) return;
@@ -433,6 +534,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     double *eall = rall + (size_t)(X_REG ? 1 : 2) * W * T * HS;        // [W][T+1][HS]: exp(-dtau V) of slices t0 .. t0+T (E_LDS)
     double *el = eall + (size_t)wv * (T + 1) * HS;
     double *partA = eall + (E_LDS ? (size_t)W * (T + 1) * HS : 0), *partB = partA + 8, *bc = partA + 16;   // bc: p.z total, r.r total, 0.0 = a poller gave up
+    // single-meeting form: part[4][8] wave partials of p.z, r.z, z.z, r.r | tot[8]: the four totals, [4] the direct r.r of the fallback
+    // meeting, [5] 0.0 = a poller gave up | partF[8] | rhalo[2][HS]: the boundary slices of r of the two neighbouring workgroups (kept in
+    // LDS rather than in registers: the 4-slice shape has none to spare)
+    double *part = partA, *tot = partA + 32, *partF = partA + 40, *rhalo = partA + 48, *zhalo = rhalo + 2 * HS;   // zhalo[2][HS]: their boundary slices of z
     auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
     auto sgn = [](int t) { return (t == 0) ? -1.0 : 1.0; };
     const CgParams P = B.params;
@@ -509,13 +614,27 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     }
 #define EXPV(j, q) (E_LDS ? el[(j) * HS + lane + (q) * WAVE] : E[(SSH || E_LDS) ? 0 : (j)][q])
 
-    u64 *slotsA = R.slots + (size_t)rhs * 2 * 64, *slotsB = slotsA + 64;
+    u64 *slotsA = R.slots + (size_t)rhs * (ONE ? SLOTS_PER_RHS : 2 * 64), *slotsB = slotsA + (ONE ? SLOTS_A : 64);
     u64 *bnd = R.bnd + (size_t)rhs * G * 2 * HS * 2;     // [G][first | last slice][HS][2 granules]
     const int gm = (g == 0) ? G - 1 : g - 1, gp = (g == G - 1) ? 0 : g + 1;
     double rho = S.rho, kmin = S.kmin, eps = S.eps;
     double eps0 = S.eps0, normb = S.normb;
 
-    if (threadIdx.x == 0) bc[2] = 1.0;                 // (ordered before its first reader by the barriers of iteration 0)
+    if (threadIdx.x == 0) { if (ONE) tot[5] = 1.0; else bc[2] = 1.0; }     // (ordered before its first reader by the barriers of iteration 0)
+    // single-meeting form: the boundary waves of a workgroup keep the neighbouring workgroup's boundary slice of r (p0 = r0: it sits in
+    // the halo of p)
+    if constexpr (ONE) {
+        if (G > 1) {
+            if (wv == 0) {
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) rhalo[lane + q * WAVE] = p[0][q];
+            }
+            if (wv == W - 1) {
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) rhalo[HS + lane + q * WAVE] = p[T + 1][q];
+            }
+        }
+    }
     // ghost sites of this lane: where their values arrive in the own mailbox (nullptr: not a ghost site), slice t0
     const u64 *gaddr[NPL];
     if constexpr (SHARD) {
@@ -617,6 +736,143 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             WAVE_LDS_ORDER();
         }
         double (&z)[T + 1][NPL] = zw;                         // rows 0 .. T-1
+        double rr, hx[NPL];                                   // rr: r.r of the NEW residual; hx: the halo slice that comes from another workgroup (waves 0 and W-1)
+        if constexpr (ONE) {
+        // ================= single-meeting iteration ==========================================================================
+        // The two meetings of the textbook iteration (p.z -> alpha; then r.r of the new residual and its boundary slices -> beta, halo
+        // of p) fold into ONE: every workgroup publishes FOUR sums — p.z, r.z, z.z and the r.r of the current residual — and the
+        // boundary slices of z.  With them every wave has  alpha = r.r / p.z  and, by the algebraic identity of r' = r - alpha z,
+        //     r'.r' = r.r - 2 alpha r.z + alpha^2 z.z
+        // so beta and the stop test need no second reduction, and the neighbour's boundary slice of r' is its r (kept here) minus
+        // alpha times its z (just received).  The direct r.r enters every iteration afresh (summed from the actual vector when it is
+        // made, published one meeting later): the identity is applied for ONE step only, its rounding error (a few ulp of r.r) never
+        // accumulates.  When the step shrinks the residual so much that the identity cancels (r'.r' < r.r / 1000: never in the
+        // hundreds of iterations of these matrices, but possible on a nearly diagonal one) the direct sum is taken in a second,
+        // single-sum meeting — the same branch in every wave of the team, since all hold the same bits.
+        double s_pz = 0.0, s_rz = 0.0, s_zz = 0.0, s_rr = 0.0;
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q)
+                if (own[q]) {
+                    const double rv = rl[j * HS + lane + q * WAVE];
+                    s_pz += p[j + 1][q] * z[j][q];
+                    s_rz += rv * z[j][q];
+                    s_zz += z[j][q] * z[j][q];
+                    s_rr += rv * rv;
+                }
+        {
+            const double k4 = wave_sum4(s_pz, s_rz, s_zz, s_rr, lane);
+            if (lane < 4) part[lane * 8 + wv] = k4;
+        }
+        if (G > 1) {                                          // boundary slices of z for the neighbouring workgroups (self-tagged granules)
+            if (wv == 0) {
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 0) * HS + lane + q * WAVE) * 2, z[0][q], epoch);
+            }
+            if (wv == W - 1) {
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 1) * HS + lane + q * WAVE) * 2, z[T - 1][q], epoch);
+            }
+        }
+        STAMP(0);
+        wg_barrier();
+        STAMP(2);
+        double pap, rz, zz, rr0;
+        if (G == 1) {
+            const double t4 = sum_part4(part, W, lane);
+            pap = readlane_f64(t4, 0); rz = readlane_f64(t4, 8); zz = readlane_f64(t4, 16); rr0 = readlane_f64(t4, 24);
+        } else {
+            // Every wave fetches its share of the two boundary slices of z (2 NPL segments of 64 values, segment s -> wave s % W, two
+            // at a time) into LDS; one of them also trades the team's records.
+            constexpr int NSEG = 2 * NPL;
+            const int rw = (W > NSEG) ? NSEG : ((W >= 3) ? 1 : 0);        // (a wave without a segment if there is one)
+            if (wv == rw) publish_rec4(slotsA, g, sum_part4(part, W, lane), epoch, lane);
+            bool ok = true;
+            double t4 = 0.0;
+            for (int s0 = wv; s0 < NSEG || (s0 == wv && wv == rw); s0 += 2 * W) {
+                const int s1 = s0 + W;
+                const u64 *b0 = nullptr, *b1 = nullptr;
+                if (s0 < NSEG) b0 = bnd + ((((s0 < NPL) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane + (size_t)(s0 % NPL) * WAVE) * 2;
+                if (s1 < NSEG) b1 = bnd + ((((s1 < NPL) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane + (size_t)(s1 % NPL) * WAVE) * 2;
+                const bool recs = (wv == rw && s0 == wv);
+                double z0 = 0.0, z1 = 0.0;
+                if (G <= 8) {
+                    u64 v[1] = {0};
+                    ok = poll_rec4<1>(recs ? slotsA : nullptr, G, b0, b1, epoch, lane, R, v, z0, z1) && ok;
+                    if (recs) t4 = sum_rec4<1>(v, G, lane);
+                } else {
+                    u64 v[4] = {0, 0, 0, 0};
+                    ok = poll_rec4<4>(recs ? slotsA : nullptr, G, b0, b1, epoch, lane, R, v, z0, z1) && ok;
+                    if (recs) t4 = sum_rec4<4>(v, G, lane);
+                }
+                if (b0) zhalo[(size_t)s0 * WAVE + lane] = z0;             // (segment s = side * NPL + q lives at [side][q * 64 + lane])
+                if (b1) zhalo[(size_t)s1 * WAVE + lane] = z1;
+                if (!ok) break;
+            }
+            if (wv == rw && lane < 8 && !(lane & 1)) tot[lane >> 1] = t4;
+            if (!ok && lane == 0) tot[5] = 0.0;
+            wg_barrier();
+            if (tot[5] == 0.0) return;
+            pap = tot[0]; rz = tot[1]; zz = tot[2]; rr0 = tot[3];
+        }
+        STAMP(1);
+        rho = rr0;                                            // r.r of the residual this iteration started from, summed from the vector
+        const double alpha = rr0 / pap;                                                            // :278-279 (rho = r.r)
+        rr = rr0 + alpha * (alpha * zz - 2.0 * rz);
+        // ---- x += alpha p, r -= alpha z (own slices) ----------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const double rn = rl[j * HS + lane + q * WAVE] - alpha * z[j][q];                   // :285
+                rl[j * HS + lane + q * WAVE] = rn;
+                if (X_REG) xr[X_REG ? j : 0][q] += alpha * p[j + 1][q];                            // :282
+                else xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];
+            }
+        if (G > 1 && (wv == 0 || wv == W - 1)) {              // the neighbouring workgroup's boundary slice of the new residual
+            double *rh = rhalo + ((wv == 0) ? 0 : HS);
+            const double *zh = zhalo + ((wv == 0) ? 0 : HS);
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) rh[lane + q * WAVE] = rh[lane + q * WAVE] - alpha * zh[lane + q * WAVE];
+        }
+        STAMP(3);
+        if (!(rr > 1e-3 * rr0)) {
+            // the identity cancels: take r'.r' from the vector itself (second meeting of this iteration; every wave of the team is here)
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) if (own[q]) { const double rn = rl[j * HS + lane + q * WAVE]; a += rn * rn; }
+            a = wave_sum_dpp(a);
+            if (lane == 0) partF[wv] = a;
+            wg_barrier();
+            if (G == 1) {
+                rr = wg_sum(partF, W, lane);
+            } else {
+                if (wv == 0) {
+                    const double mine = wg_sum(partF, W, lane);
+                    if (lane < 2) {
+                        const u64 bits = (u64)__double_as_longlong(mine);
+                        st_gran(slotsB + 2 * g + lane, ((u64)epoch << 32) | (lane ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+                    }
+                    u64 v = 0;
+                    const bool ok = poll_records(slotsB, G, epoch, lane, R, v);
+                    const int half = (int)(unsigned)v;
+                    double t = 0.0;
+                    for (int k = 0; k < G; ++k)
+                        t += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * k + 1), __builtin_amdgcn_readlane(half, 2 * k));
+                    if (lane == 0) { tot[4] = t; if (!ok) tot[5] = 0.0; }
+                }
+                wg_barrier();
+                if (tot[5] == 0.0) return;
+                rr = tot[4];
+            }
+        }
+        wg_barrier();                                         // the new residual of every wave is in LDS: the neighbours' halo slices
+        STAMP(4);
+        } else {
+        // ================= two-meeting iteration (sharded solves) ===============================================================
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < T; ++j)
@@ -717,7 +973,6 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         wg_barrier();
         STAMP(4);
         // ---- meeting 2: r.r and the halo slices of the new r ------------------------------------------------------------------
-        double rr, hx[NPL];                                   // hx: the halo slice that comes from another workgroup (waves 0 and W-1)
         if constexpr (SHARD) {
             // every wave takes the ghost rows of its slice from the mailbox; wave 0 also trades the r.r records of all ranks
             double tot = 0.0, gv[NPL];
@@ -779,6 +1034,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             if (bc[2] == 0.0) return;
             rr = bc[1];
         }
+        }   // two-meeting iteration
         STAMP(5);
         STAMP(6);
         // ---- stop test of iteration it = seq + 1 (IterativeSolvers.jl:286-295) ---------------------------------------------
@@ -836,7 +1092,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             const double *sr = rall + ((size_t)((wv < W - 1) ? wv + 1 : 0) * T + 0) * HS;          // first slice of the wave above
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const double hl = lx ? hx[q] : sl[lane + q * WAVE], hr = rx ? hx[q] : sr[lane + q * WAVE];
+                const double hl = lx ? (ONE ? rhalo[lane + q * WAVE] : hx[q]) : sl[lane + q * WAVE];
+                const double hr = rx ? (ONE ? rhalo[HS + lane + q * WAVE] : hx[q]) : sr[lane + q * WAVE];
                 p[0][q] = hl + beta * p[0][q];
                 p[T + 1][q] = hr + beta * p[T + 1][q];
             }
@@ -902,7 +1159,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         if (G > 1 && W < 2) continue;                    // (a wave polls at most ONE neighbouring workgroup's boundary slice)
         const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
         const size_t shm = ((size_t)W * (sq ? 0 : T + 1) * SL + (size_t)((sq && T >= 4) ? 1 : 2) * W * T * HS +
-                            ((sq && T >= 4) ? (size_t)W * (T + 1) * HS : 0) + 24) * sizeof(double);
+                            ((sq && T >= 4) ? (size_t)W * (T + 1) * HS : 0) + 48 + 4 * HS) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS]
         if (shm > 160 * 1024) continue;
         out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq;
         return true;
@@ -997,7 +1254,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         }
     }
     const size_t HS = (size_t)h->npl * WAVE;
-    const size_t n_slots = (size_t)nrhs * 2 * 64, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
+    const size_t n_slots = (size_t)nrhs * wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
     // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
     // 32-bit range wraps.  The abort word sits at the END of the allocation (its place must not move with the batch size).
@@ -1107,7 +1364,7 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     R.fixed_iters = fixed_iters;
     HIPCHK(hipMemsetAsync(base, 0, h->res_cap, h->stream));   // boundary granules of this rank's workgroups: tags restart at 2
     h->wg_epoch = 0;
-    const dim3 grid((unsigned)(8 * sh.G));                 // one right-hand side: blocks with blockIdx % 8 == 0 work, the rest leave at once
+    const dim3 grid((unsigned)sh.G);                       // one right-hand side: its G workgroups, round-robin over the XCDs
     hipError_t e = hipSuccess;
     switch (h->npl) {
         case 1: e = wg::launch_shard_npl<1>(h, sh, grid, B, m, R, Sh); break;

@@ -15,6 +15,7 @@
 // (DESIGN.md §6), and it refuses two ranks on one GPU — the only multi-rank set-up the test box offers.
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -179,6 +180,7 @@ extern "C" int elph_shard_connect(elph_handle h, const void *all_ipc_handles) {
                 else if (pe != hipSuccess) { elph_set_error("hipDeviceEnablePeerAccess(device %d -> %d): %s", h->device, ldev, hipGetErrorString(pe)); return ELPH_E_HIP; }
             }
             S->ctl.mail[q] = lp;
+            if (getenv("ELPH_SHARD_DEBUG")) fprintf(stderr, "[shard] rank %d: rank %d is local (device %d, mailbox %p; own %p)\n", S->ctl.rank, q, ldev, (void *)lp, (void *)S->mail);
             continue;
         }
         void *ptr = nullptr;

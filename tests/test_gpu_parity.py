@@ -376,9 +376,10 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g"])
+@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E"])
 def test_kpm_vs_oracle(oracle, tag):
-    """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle."""
+    """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle.  e / E: bond phonons — the
+    expansion is built on the tau-means of the per-(tau, bond) hopping tables (update_A!, KPMPreconditioners.jl:355-381)."""
     from elphdynamics_amd import configs, models, preconditioners as pc
     m = configs.make_model(tag, tol=1e-5)
     om = _oracle_model(oracle, m)
@@ -1170,10 +1171,10 @@ def test_lds_sync_build_is_bit_identical():
 
 # ------------------------------------------------------------------------------------------ workgroup-resident CG (cg_wg.hip)
 
-def _wg_info(m):
+def _wg_info(m, nrhs=1):
     from elphdynamics_amd import _lib
     us, T, W, G = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    _lib.check(_lib.load().elph_bench_wg_info(m._h, 1, C.byref(us), C.byref(T), C.byref(W), C.byref(G)))
+    _lib.check(_lib.load().elph_bench_wg_info(m._h, nrhs, C.byref(us), C.byref(T), C.byref(W), C.byref(G)))
     return us.value, T.value, W.value, G.value
 
 
@@ -1285,6 +1286,58 @@ def test_wg_resident_cg_large_batch_shape():
         x = np.zeros(m.Ndim)
         it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
         assert abs(it1 - it[i]) <= 1 and rel(X[i], x) < 5e-5, i
+    m.close()
+
+
+def test_wg_resident_cg_bench_shape_vs_oracle(oracle):
+    """The shape bench.py times — config C, independent chains side by side (right-hand side r on the matrix of chain r % nchains), a
+    batch large enough for 4 slices per wave (T = 4, G = 5) — against the ORACLE directly: every checked right-hand side, solved to
+    1e-13 on both sides, is within the north_star's 1e-10 of the oracle's solve on that chain's matrix."""
+    from elphdynamics_amd import configs, models, synth
+    m = configs.make_model("C", tol=1e-13, maxiter=20000)
+    nch, nrhs = 26, 52
+    Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=synth.SEED_FIELDS + 17 * c) for c in range(nch)])
+    models.update_model_chains_(m, Xc)
+    usable, T, W, G = _wg_info(m, nrhs)
+    assert usable == 1 and (T, W, G) == (4, 8, 5)
+    R = np.stack([synth.rhs(m.Ndim, seed=synth.SEED_RHS + 7919 * i) for i in range(nrhs)])
+    X = np.zeros_like(R)
+    it, res, fl = models.ldiv_batched_(X, m, R)                  # (the right-hand sides need not be Mt R for this comparison)
+    assert not fl.any() and (res < 1e-12).all()
+    for i in (0, 1, 25, 26, 27, 51):
+        c = i % nch
+        E = oracle.update_model_holstein(m.Nsites, m.Ltau, m.dtau, Xc[c], m.lam, m.lam2, m.mu)
+        om = oracle.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+        xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(R[i]), solver_tol=1e-13, solver_maxiter=20000)
+        assert flo == 0 and abs(int(it[i]) - ito) <= max(3, ito // 100), (i, int(it[i]), ito)
+        assert rel(X[i], xo) < 1e-10, (i, rel(X[i], xo))
+    m.close()
+
+
+def test_wg_resident_cg_shape_pin_makes_bits_independent_of_the_batch(monkeypatch):
+    """Which team shape runs decides the last bits of a solution (another summation tree), and the shape follows the batch size
+    (config C: 2 slices per wave up to 24 right-hand sides, 4 above).  ELPH_WG_T pins it: with the pin a right-hand side's solution
+    and iteration count are bit-identical whether it is solved alone, in a batch of 3 or in a batch of 50 — what a deployment that
+    must reproduce a chain's trajectory on another batch size sets."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("C", tol=1e-9)
+    R, B = configs.rhs(m, 50)
+    for pin in ("4", "2"):
+        monkeypatch.setenv("ELPH_WG_T", pin)
+        assert _wg_info(m, 1)[1] == int(pin) and _wg_info(m, 50)[1] == int(pin)
+        Xb = np.zeros_like(B)
+        itb, _, fl = models.ldiv_batched_(Xb, m, B)
+        assert not fl.any()
+        X3 = np.zeros((3, m.Ndim))
+        it3, _, _ = models.ldiv_batched_(X3, m, np.ascontiguousarray(B[:3]))
+        assert np.array_equal(X3, Xb[:3]) and np.array_equal(it3, itb[:3])
+        for i in (0, 31, 49):
+            x = np.zeros(m.Ndim)
+            it1, _, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
+            assert fl1 == 0 and it1 == itb[i] and np.array_equal(x, Xb[i]), (pin, i)
+    # without the pin the two batch sizes take different shapes (documented behaviour, not a defect): same solution to the tolerance
+    monkeypatch.delenv("ELPH_WG_T")
+    assert _wg_info(m, 1)[1] == 2 and _wg_info(m, 50)[1] == 4
     m.close()
 
 

@@ -12,7 +12,7 @@ from elphdynamics_amd import _lib, configs          # noqa: E402
 from elphdynamics_amd._lib import check            # noqa: E402
 
 lib = _lib.load()
-NAMES = ["mat-vec + p.z wave sum", "meeting 1 (p.z)", "barrier", "x, r updates + boundary stores", "barrier", "meeting 2 (r.r, halo slices)", "-",
+NAMES = ["mat-vec + four sums + boundary stores of z", "the meeting (records, boundary slices of z)", "barrier", "x, r updates, halo of r", "barrier (r in LDS)", "-", "-",
          "stop test", "p update", "(loop top)"]
 for tag in (sys.argv[1:] or ["b", "C"]):
     m = configs.make_model(tag, tol=1e-5)
