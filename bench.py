@@ -3,24 +3,27 @@
 
     python bench.py --gpus N --steps K --warmup W [--nrhs R] [--precond]
 
-A *step* is one conjugate-gradient iteration (1 MtM apply = 2 mat-vecs, + the vector updates and both
-reductions; + 1 KPM apply with --precond) advanced for a batch of `nrhs` right-hand sides resident in HBM.
-Default batch: 64 independent Markov chains per GPU (64 phonon configurations = 64 different fermion matrices,
-the reference runs them as separate processes, ElPhDynamics.jl:90-95) x the 2 pseudofermion solves of one HMC
-force evaluation each (HMC.jl:851-886) = 128 right-hand sides (315 MB of solver vectors: the batch is what fills the GPU).  W untimed warm-up steps, then exactly K steps
-bracketed by barrier + device synchronise on both sides; the time is the MAX over ranks and
-value = (2 * nrhs * K * n_gpus) / time.  One JSON line on rank 0.
+A *step* is one conjugate-gradient iteration (1 MtM apply = 2 mat-vecs, + the vector updates and the reductions; + 1 KPM apply with
+--precond) advanced for a batch of `nrhs` right-hand sides resident in HBM.  Default batch: 144 independent Markov chains per GPU
+(144 phonon configurations = 144 different fermion matrices; the reference runs them as separate processes, ElPhDynamics.jl:90-95)
+x the 2 pseudofermion solves of one HMC force evaluation each (HMC.jl:851-886) = 288 right-hand sides.  Un-preconditioned solves
+run as the workgroup-resident kernel (csrc/cg_wg.hip: the whole solve in one launch), so the K timed steps are ONE launch of it.
+W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronise on both sides; the time is the MAX over
+ranks and value = (2 * nrhs * K * n_gpus) / time.  One JSON line on rank 0.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every GPU carries its own chains — no data-path
-collective, "weak" scaling (SURVEY.md §8e replica mode).  ONE solve sharded over the GPUs (spatial slabs with ghost
-rows, or tau-slabs; RCCL halo exchange + partial-sum all-gathers per iteration) is --mode spatial / --mode sharded:
-strong scaling, latency-bound at these sizes.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every GPU carries its own chains — no data-path collective, "weak"
+scaling (SURVEY.md §8e replica mode).  ONE solve sharded over the GPUs (row slabs + ghost rows, device-initiated mailbox stores) is
+--mode spatial: strong scaling, latency-bound at these sizes.
 
-Also in the JSON line:
-  roofline      the dominant kernel k_cg_ap timed ALONE with HIP events on the launch stream:
-                achieved = algorithmic bytes per launch / average launch duration  
-  cpu_baseline  the CPU oracle (oracle/elph_oracle.c, -O3 -march=native -ffast-math, 1 thread = the
-                reference's configuration, ElPhDynamics.jl:74-75) on a bounded sample of the same workload.
+The JSON line (the driver's record keeps SCALARS of `roofline` and `cpu_baseline` only, so everything that matters is a flat key):
+  roofline      the dominant kernel of the timed region.  Resident kernel: bound = "f64_vector+sync" — achieved = flops of the launch
+                (2 mat-vecs x (2 Ndim + 6 Ltau Nbonds) + 10 Ndim per right-hand side and iteration) / launch duration
+                against the 78.6 TFLOP/s f64 vector peak; its HBM fraction (small by design: the Krylov vectors stay on chip) is
+                hbm_frac.  streaming_*: the two-kernel iteration at the same batch (k_cg_ap on its compulsory bytes against 8 TB/s).
+                precond_*: the KPM-preconditioned iteration (BASELINE config "with tau-FFT precond"): every kernel timed alone with
+                HIP events, priced on the compulsory bytes of ALL its kernels.
+  cpu_baseline  the CPU oracle (oracle/elph_oracle.c, -O3 -march=native -ffast-math, 1 thread = the reference's configuration,
+                ElPhDynamics.jl:74-75) on a bounded sample of the same workload.
 """
 import argparse
 import ctypes as C
@@ -78,7 +81,7 @@ def parse():
     ap.add_argument("--streaming", action="store_true", help="time the two-kernel (HBM-streaming) iteration instead of the workgroup-resident kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary nrhs sweep")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=4.0)
     return ap.parse_args()
 
 
@@ -197,7 +200,9 @@ def main():
             "ms_per_step_events": ms_events / K,
         }
 
-        # ---- roofline of the dominant kernel of the STREAMING form (k_cg_ap), timed alone with HIP events on its stream
+        # ---- roofline ------------------------------------------------------------------------------------------------------------
+        # (1) the two-kernel STREAMING iteration at the same batch: k_cg_ap and k_cg_xr timed alone with HIP events on their stream,
+        #     priced on the compulsory bytes of each kernel as built against the HBM peak
         reps = 2000 if not resident else 400
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
         run(4, nrhs, 320, graph=0)
@@ -217,124 +222,112 @@ def main():
         ach = built_ap / (ms_ap * 1e-3) / 1e9
         kname = f"k_cg_ap_chunk<T={Tsl.value}>" if Tsl.value > 1 else "k_cg_ap_fast"
         tkey = f"{kname}|config={args.config}|nrhs={nrhs}|chains={nchains}"
-        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        try:                  # PMC bytes are only valid for the exact kernel / batch / slices-per-wave they were collected on
-            ent = json.load(open(tpath)).get("kernels", {}).get(tkey)
-            if ent is not None:
-                traffic = ent["hbm_bytes_per_launch"]
-            else:
-                traffic_note = f"profiles/traffic.json holds no PMC pass for '{tkey}' (tools/profile_bench.sh re-collects it)"
-        except Exception as e:
-            traffic_note = f"profiles/traffic.json unreadable: {e}"
-        out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": ms_ap * 1e3,
-                           "bytes_per_launch": built_ap,
-                           "bytes_model": "compulsory bytes of the kernel as built: 6 vectors (reads r|P^-1 r, p_old, x; writes p, z, x) "
-                                          "x 8 B x Ndim x nrhs + exp(-dtau V) (SSH: the per-slice hopping tables) once per chain",
-                           "traffic_key": tkey,
-                           "algorithmic_GBs": alg_ap / (ms_ap * 1e-3) / 1e9,
-                           "algorithmic_note": "SURVEY.md 8(d) counts the unfused passes (96 B x Ndim x nrhs for this kernel); the fused "
-                                               "kernel does not move them, so this figure may exceed the HBM peak and is NOT the roofline fraction"}
-        if traffic_note:
-            out["roofline"]["traffic_note"] = traffic_note
-        if traffic:      # what the memory-side counters saw per launch, and the rate that is
-            out["roofline"]["traffic_GBs"] = traffic / (ms_ap * 1e-3) / 1e9
-            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_GBs"] / HBM_PEAK_GBS
-            out["roofline"]["traffic_over_bytes"] = traffic / built_ap
+
+        def pmc(key, field):      # PMC bytes are only valid for the exact kernel / batch / shape they were collected on
+            try:
+                ent = json.load(open(tpath)).get("kernels", {}).get(key)
+                return ent[field] if ent is not None else None
+            except Exception:
+                return None
+
+        traffic = pmc(tkey, "hbm_bytes_per_launch")
         check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
         run(5, nrhs, 320, graph=0)
         ms_xr = run(5, nrhs, reps, graph=0) / reps
-        out["roofline"]["k_cg_xr"] = {"avg_launch_us": ms_xr * 1e3, "bytes_per_launch": built_xr,
-                                      "achieved": built_xr / (ms_xr * 1e-3) / 1e9, "frac": built_xr / (ms_xr * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        it_bytes = built_ap + built_xr
         if resident:
             check(lib.elph_bench_prepare(m._h, 1, nrhs, None))
             run(1, nrhs, 40)
             ms_stream = run(1, nrhs, 400) / 400
         else:
             ms_stream = ms_events / K
-        it_GBs = it_bytes / (ms_stream * 1e-3) / 1e9
-        out["roofline"]["whole_iteration"] = {
-            "us_per_step": ms_stream * 1e3, "bytes_per_step": it_bytes, "achieved_GBs": it_GBs, "frac": it_GBs / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_step": alg_it, "algorithmic_GBs": alg_it / (ms_stream * 1e-3) / 1e9,
-            "matvecs_per_sec": 2.0 * nrhs / (ms_stream * 1e-3),
+        stream = {
+            "bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_key": tkey, "avg_launch_us": ms_ap * 1e3, "bytes_per_launch": built_ap,
+            "bytes_model": "compulsory bytes of k_cg_ap as built: 6 vectors (reads r|P^-1 r, p_old, x; writes p, z, x) x 8 B x Ndim x nrhs "
+                           "+ exp(-dtau V) (SSH: per-slice hopping tables) once per chain",
+            "algorithmic_GBs": alg_ap / (ms_ap * 1e-3) / 1e9,          # SURVEY 8(d)'s UNFUSED 96 B/elt: not a roofline fraction
+            "xr_kernel_us": ms_xr * 1e3, "xr_bytes_per_launch": built_xr, "xr_frac": built_xr / (ms_xr * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "iteration_us": ms_stream * 1e3, "iteration_bytes": built_ap + built_xr,
+            "iteration_frac": (built_ap + built_xr) / (ms_stream * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "iteration_matvecs_per_sec": 2.0 * nrhs / (ms_stream * 1e-3),
         }
-        if resident:
-            # The timed region above is ONE launch of k_cg_wg (K iterations of all right-hand sides).  Its Krylov vectors never leave the
-            # chip: per launch it reads r0, p0, x0 and exp(-dtau V) once and writes x and r once.  HBM is not what bounds it — the two
-            # team meetings per iteration are (profiles/r02/wg_phase_stamps.log) — so the HBM fraction is small BY DESIGN;
-            # the number to hold against the roofline of the streaming form is hbm_streaming_equivalent: what an implementation that
-            # streams the algorithm's vectors per iteration (120 B x Ndim) would have to sustain to match this rate.
+        if traffic:      # what the memory-side counters saw per launch
+            stream["traffic_frac"] = traffic / (ms_ap * 1e-3) / 1e9 / HBM_PEAK_GBS
+            stream["traffic_over_bytes"] = traffic / built_ap
+        if not resident:
+            out["roofline"] = stream
+        else:
+            # (2) the RESIDENT kernel — the timed region above is ONE launch of k_cg_wg (K iterations of all right-hand sides).  Its
+            # Krylov vectors never leave the chip: per launch it reads r0 (= p0), x0, exp(-dtau V) once and writes x once, so HBM does not
+            # bind it (hbm_frac is small BY DESIGN).  What binds it is f64 vector issue (v_fma_f64 + DPP moves of the checkerboard) and
+            # the ONE team meeting per iteration through L2 — so the roofline it is held against is the f64 vector peak:
+            #   flops per right-hand side and iteration = 2 mat-vecs x (2 Ndim + 6 Ltau Nbonds) + 10 Ndim (p.z, x, r, r.r, p)  [SURVEY 8(d)]
             us_launch = ms_events * 1e3
-            built_wg = 5.0 * vec + tab                        # reads r0, p0, x0 + tables; writes x, r
-            ach_wg = built_wg / (us_launch * 1e-6) / 1e9
-            equiv = alg_it * K / (us_launch * 1e-6) / 1e9
-            stream = out["roofline"]
-            stream["note"] = ("two-kernel streaming form: what preconditioned solves and lattices outside the resident kernel's reach run; "
-                              "timed here at the same batch for comparison")
-            out["roofline_streaming"] = stream
+            flops = float(K) * nrhs * (2.0 * (2.0 * m.Ndim + 6.0 * m.Ltau * m.Nbonds) + 10.0 * m.Ndim)
+            tfl = flops / (us_launch * 1e-6) / 1e12
+            built_wg = 4.0 * vec + tab                        # reads r0 (also p0), x0 + tables; writes x (and r at the end of a sharded solve)
+            hbm_GBs = built_wg / (us_launch * 1e-6) / 1e9
             wkey = f"k_cg_wg<T={wg_T.value},W={wg_W.value},G={wg_G.value}>|config={args.config}|nrhs={nrhs}|chains={nchains}"
-            wtraffic = None
-            try:      # memory-side bytes per ITERATION of the batch (the PMC pass ran another number of iterations): x K for this launch
-                went = json.load(open(tpath)).get("kernels", {}).get(wkey)
-                wtraffic = went["hbm_bytes_per_iteration"] * K if went else None
+            per_it = pmc(wkey, "hbm_bytes_per_iteration")
+            sync_share = None
+            try:      # share of an iteration a wave spends in the meeting, from the stamped diagnostic build (profiles/, not measured live)
+                sync_share = json.load(open(tpath)).get("wg_sync_share", {}).get(f"T={wg_T.value}")
             except Exception:
-                wtraffic = None
+                pass
             out["roofline"] = {
-                "bound": "hbm", "kernel": f"k_cg_wg<T={wg_T.value},W={wg_W.value},G={wg_G.value}>", "traffic_key": wkey,
-                "achieved": ach_wg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_wg / HBM_PEAK_GBS, "traffic": wtraffic,
-                "avg_launch_us": us_launch, "iterations_per_launch": K, "us_per_iteration_of_the_batch": us_launch / K,
-                "bytes_per_launch": built_wg,
-                "bytes_model": "compulsory bytes of the kernel as built: r0, p0, x0 in, x, r out (5 vectors x 8 B x Ndim x nrhs) + "
-                               "exp(-dtau V) once per chain, per LAUNCH of K iterations — the Krylov vectors stay in registers / LDS",
-                "binding_resource": "on-chip latency and f64 issue: two team meetings through L2 per iteration (1.2 + 1.4 us at 5 workgroups per "
-                                    "team) + the compute phases (~4.2 us for the two waves of a SIMD); not HBM (fraction small by design)",
-                "traffic_note": "memory-side traffic of this kernel is its SYNCHRONISATION: write-through record / boundary granules and the "
-                                "polls of them (they bypass L2 by design), ~40 MB per iteration of 288 right-hand sides — not vector data",
-                # the arithmetic of the same launch against the f64 vector peak (the sweeps are v_fma_f64, not MFMA — same peak figure):
-                # per right-hand side and iteration 2 mat-vecs x (2 Ndim + 6 Ltau Nbonds) + 10 Ndim of p.z, x, r, r.r, p
-                "f64_vector": (lambda fl: {"flops_per_launch": fl, "achieved_TFLOPs": fl / (us_launch * 1e-6) / 1e12,
-                                           "peak_TFLOPs": F64_MFMA_PEAK_TFLOPS,
-                                           "frac": fl / (us_launch * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS})(
-                    float(K) * nrhs * (2.0 * (2.0 * m.Ndim + 6.0 * m.Ltau * m.Nbonds) + 10.0 * m.Ndim)),
-                "hbm_streaming_equivalent_GBs": equiv,
-                "x_hbm_peak_of_a_streaming_implementation": equiv / HBM_PEAK_GBS,
-                "streaming_form_same_batch": {"us_per_step": ms_stream * 1e3, "matvecs_per_sec": 2.0 * nrhs / (ms_stream * 1e-3),
-                                              "speedup_of_resident": (ms_stream * 1e3) / (us_launch / K)},
-                "teams": {"slices_per_wave": wg_T.value, "waves_per_workgroup": wg_W.value, "workgroups_per_rhs": wg_G.value,
-                          "workgroups_in_grid": 8 * ((nrhs + 7) // 8) * wg_G.value},
+                "bound": "f64_vector+sync", "kernel": f"k_cg_wg<T={wg_T.value},W={wg_W.value},G={wg_G.value}>",
+                "achieved": tfl, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F64_MFMA_PEAK_TFLOPS,
+                "traffic": (per_it * K) if per_it else None, "traffic_key": wkey,
+                "flops_per_launch": flops, "avg_launch_us": us_launch, "iterations_per_launch": K, "us_per_iteration": us_launch / K,
+                "f64_TFLOPs": tfl, "f64_frac": tfl / F64_MFMA_PEAK_TFLOPS,
+                "sync_share_profiled": sync_share,
+                "meetings_per_iteration": 1,
+                "hbm_bytes_per_launch": built_wg, "hbm_GBs": hbm_GBs, "hbm_frac": hbm_GBs / HBM_PEAK_GBS,
+                "hbm_streaming_equivalent_GBs": alg_it * K / (us_launch * 1e-6) / 1e9,   # what a streaming implementation of 8(d)'s 120 B x Ndim would need
+                "slices_per_wave": wg_T.value, "waves_per_workgroup": wg_W.value, "workgroups_per_rhs": wg_G.value,
+                "workgroups_in_grid": 8 * ((nrhs + 7) // 8) * wg_G.value,
+                "streaming_ap_kernel": kname, "streaming_ap_us": stream["avg_launch_us"], "streaming_ap_frac": stream["frac"],
+                "streaming_ap_traffic": traffic, "streaming_xr_us": stream["xr_kernel_us"], "streaming_xr_frac": stream["xr_frac"],
+                "streaming_iter_us": stream["iteration_us"], "streaming_iter_frac": stream["iteration_frac"],
+                "streaming_matvecs_per_sec": stream["iteration_matvecs_per_sec"],
+                "speedup_over_streaming": stream["iteration_us"] / (us_launch / K),
+                "note": "flops per SURVEY 8(d); peak = f64 vector (= f64 MFMA) 78.6 TFLOP/s; hbm_frac is small by design (vectors stay on chip)",
             }
+            out["roofline_streaming"] = stream
 
         # ---- the preconditioned iteration (BASELINE config C "with tau-FFT FourierAcceleration precond"): every kernel of it
-        # timed alone with HIP events, its compulsory bytes, and the matrix-core rate of the two tau-transforms
+        # timed alone with HIP events, priced on the compulsory bytes of ALL its kernels, and the matrix-core rate of the two tau-transforms
         if not args.no_sweep and m.kind == 0:
             try:
                 Pr = P or pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
                 (pc.setup_chains_ if nchains > 1 else pc.setup_)(Pr, rng=np.random.default_rng(7))
                 rp = {}
-                names = {4: "k_cg_ap", 6: "kpm_forward_transform(+residual update)", 7: "kpm_chebyshev", 8: "kpm_inverse_transform", 3: "whole_iteration"}
+                names = {4: "ap", 6: "fwd", 7: "cheb", 8: "inv", 3: "iter"}
                 Hh, Qq = m.Ltau // 2, (m.Ltau // 2 + 1) // 2
                 gemm_flops = 2.0 * (2.0 * (2 * Qq) * Hh) * m.Nsites * nrhs if m.Ltau % 2 == 0 else None   # two half-length f64 GEMMs (even / odd slices)
-                byts = {4: built_ap, 6: 4.0 * vec, 7: 2.0 * vec, 8: 2.0 * vec, 3: built_ap + 8.0 * vec}
+                # k_cg_ap 6 vectors + tables; forward transform with the residual update folded in: reads r, z, writes r, nu (4; the half
+                # spectrum nu is one vector of bytes); Chebyshev reads and writes nu (2); inverse reads nu, writes P^-1 r (2)
+                byts = {4: built_ap, 6: 4.0 * vec, 7: 2.0 * vec, 8: 2.0 * vec}
+                byts[3] = byts[4] + byts[6] + byts[7] + byts[8]
                 for wh in (4, 6, 7, 8, 3):
                     check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
                     run(3, nrhs, 2)                           # sane p.z partials / states for the kernels timed alone
-                    run(wh, nrhs, 64)
-                    us = 1e3 * run(wh, nrhs, 640) / 640
-                    e = {"avg_launch_us": us, "bytes_per_launch": byts[wh], "achieved_GBs": byts[wh] / (us * 1e-6) / 1e9,
-                         "hbm_frac": byts[wh] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                    run(wh, nrhs, 32)
+                    us = 1e3 * run(wh, nrhs, 320) / 320
+                    rp[f"precond_{names[wh]}_us"] = us
+                    rp[f"precond_{names[wh]}_hbm_frac"] = byts[wh] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
                     if wh in (6, 8) and gemm_flops:
-                        e["mfma_f64_TFLOPs"] = gemm_flops / (us * 1e-6) / 1e12
-                        e["mfma_frac"] = e["mfma_f64_TFLOPs"] / F64_MFMA_PEAK_TFLOPS
-                        e["flops_per_launch"] = gemm_flops
-                    rp[names[wh]] = e
-                rp["note"] = ("bytes: k_cg_ap as above (src = P^-1 r); forward transform reads r, z and writes r, nu (4 vectors; the half "
-                              "spectrum nu is one vector of bytes); Chebyshev reads and writes nu; inverse reads nu, writes P^-1 r.  "
-                              "SURVEY 8(d)'s 16 B x Ndim per KPM apply assumes the three kernels fused into one.  The Chebyshev kernel is "
-                              "latency-bound by its longest recursion, not by bytes.  mfma: two (L/2 x L/2) real f64 GEMMs per transform "
-                              f"on v_mfma_f64_16x16x4_f64, peak {F64_MFMA_PEAK_TFLOPS} TFLOP/s")
-                out["roofline_preconditioned"] = rp
+                        rp[f"precond_{names[wh]}_mfma_frac"] = gemm_flops / (us * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS
+                rp["precond_bytes"] = byts[3]
+                rp["precond_hbm_frac"] = rp["precond_iter_hbm_frac"]
+                rp["precond_matvecs_per_sec"] = 2.0 * nrhs / (rp["precond_iter_us"] * 1e-6)
+                out["roofline"].update(rp)
+                out["roofline_preconditioned"] = dict(rp, note=(
+                    "bytes: k_cg_ap 6 vectors + tables (src = P^-1 r); forward transform reads r, z and writes r, nu (4 vectors); Chebyshev reads "
+                    "and writes nu; inverse reads nu, writes P^-1 r — 14 vectors per iteration.  SURVEY 8(d)'s 16 B x Ndim per KPM apply "
+                    "assumes the three kernels fused into one.  The Chebyshev kernel is latency-bound by its longest recursion.  mfma: two "
+                    f"(L/2 x L/2) real f64 GEMMs per transform on v_mfma_f64_16x16x4_f64, peak {F64_MFMA_PEAK_TFLOPS} TFLOP/s"))
             except Exception as e:
                 out["roofline_preconditioned"] = {"error": repr(e)}
 
@@ -415,6 +408,8 @@ def main():
                 tts["preconditioned_cg_iter_us_nrhs1"] = 1e3 * ms.value / 160
                 tts["kpm_orders_sum"] = int(P2.orders.sum())
                 out["time_to_solution_tol1e-5"] = tts
+                out["roofline"]["precond_iter_us_nrhs1"] = tts["preconditioned_cg_iter_us_nrhs1"]
+                out["roofline"]["kpm_apply_us_nrhs1"] = tts["kpm_apply_us_nrhs1"]
             except Exception as e:
                 out["time_to_solution_tol1e-5"] = {"error": str(e)}
 
@@ -466,6 +461,8 @@ def main():
                     hm["gpu_over_cpu_chain_evaluations"] = hm[f"gpu_chains{HMC_CHAINS}"]["chain_evaluations_per_sec"] / hm["cpu_oracle_1core"]["chain_evaluations_per_sec"]
                     mo.close()
                 out["hmc_update_kpm"] = hm
+                out["roofline"]["hmc_update_ms_1chain"] = hm["gpu_chains1"]["ms_per_update"]
+                out["roofline"][f"hmc_chain_update_ms_{HMC_CHAINS}chains"] = hm[f"gpu_chains{HMC_CHAINS}"]["ms_per_chain_update"]
             except Exception as e:
                 out["hmc_update_kpm"] = {"error": repr(e)}
 
@@ -499,7 +496,7 @@ def main():
                         best = None
                         for nt in sorted({min(8, os.cpu_count()), min(32, os.cpu_count()), min(64, os.cpu_count())}):
                             secs, _ = _om.cg_iterations_omp(om, b0, 100, nt)          # warm-up + cost estimate
-                            n_omp = int(max(100, min(20000, 3.0 / max(secs / 100, 1e-7))))  # ~3 s per thread count
+                            n_omp = int(max(100, min(20000, 1.0 / max(secs / 100, 1e-7))))  # ~1 s per thread count
                             secs, _ = _om.cg_iterations_omp(om, b0, n_omp, nt)
                             rate = 2.0 * n_omp / secs
                             if best is None or rate > best[0]:

@@ -42,6 +42,17 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// The 2 x 2 patch layout of the 16 x 16 square lattice (cg_wg.hip: the DPP checkerboard; cg_fast_impl.inc: the Chebyshev recursion):
+// lane l holds the patch X = (l >> 1) & 7, Y = 2 (l >> 4) + (l & 1); register q is the site x = 2 X + (q & 1), y = 2 Y + (q >> 1),
+// with the two rows of the patch stored in reverse order in the lanes of odd Y.  Returns x + 16 y.
+__host__ __device__ __forceinline__ int sq_patch_site(int lane, int q) {
+    const int X = (lane >> 1) & 7, par = lane & 1, Y = 2 * (lane >> 4) + par;
+    const int yb = par ? 1 - (q >> 1) : (q >> 1);
+    return (2 * X + (q & 1)) + 16 * (2 * Y + yb);
+}
+// partner lane of the crossing half of the y-odd colour in that layout (registers 0, 1): the lane of patch Y + 1 for odd Y, Y - 1 for even Y
+__host__ __device__ __forceinline__ int sq_patch_ycross(int lane) { return (lane & 1) ? ((lane + 15) & 63) : ((lane + 49) & 63); }
+
 // Partner value of the x-odd colour: odd lanes take lane + 1's v, even lanes lane - 1's (rows of 16, cyclic).  One DPP move
 // (row_ror:15) and one v_cndmask with the DPP modifier on its other source (row_ror:1) per word — the compiler's form is two moves
 // and a plain select (6 instead of 4 vector-ALU instructions per f64; a fifth of the mat-vec's instructions at 4 slices per wave).

@@ -107,11 +107,16 @@ __device__ __forceinline__ void sweepN(double *buf, const unsigned (&ij)[MC * ((
 
 // ------------------------------------------------------------------------------------------------------------------------
 // The 16 x 16 square lattice with the reference's colouring [x-even | x-odd | y-even | y-odd] (verified on the host:
-// detect_square) and one hopping for all bonds: the checkerboard WITHOUT LDS.  Lane l holds the four sites
-//     x = l & 15,  y = 4 (l >> 4) + k,  k = 0..3        (a column segment; a 16-lane DPP row is a row of the lattice)
-// so that   x-bonds  pair neighbouring lanes of one DPP row:  colour 0 = quad_perm [1,0,3,2], colour 1 = row rotate by +-1,
-//           y-bonds  pair registers of one lane (k, k+1), except (k = 3, next row group's k = 0): one wave shuffle each way.
-// A sweep is ~50 VALU instructions and 4 ds_bpermute; the lane-program form is 4 LDS round trips of 16 reads + 16 writes.
+// detect_square): the checkerboard WITHOUT LDS slabs.  Lane l holds a 2 x 2 PATCH of sites:
+//     X = (l >> 1) & 7,  Y = 2 (l >> 4) + (l & 1):  x = 2 X + (q & 1),  y = 2 Y + (q >> 1)   (registers q = 0..3)
+// with the two rows of the patch stored in REVERSE order in the lanes of odd Y (q >> 1 = 0 is the row y = 2 Y + 1 there).  Then
+//   x-even, y-even  pair two registers of one lane                                   — no data movement at all;
+//   x-odd           pairs (q odd) with the lane 2 up in the 16-lane DPP row and (q even) with the lane 2 down (patches X +- 1 of
+//                   the same Y sit 2 lanes apart, cyclically — exactly the period of row_ror): 4 DPP moves of an f64;
+//   y-odd           registers 2, 3 (the upper row of an even Y, the lower row of an odd Y — the same registers thanks to the
+//                   reversed storage) swap with the neighbouring lane of the quad pair: 2 DPP moves of an f64;  registers 0, 1
+//                   cross to the next / previous group of 16 lanes: one ds_bpermute pair each.
+// A sweep is 12 DPP moves + 4 ds_bpermute + 16 fma per slab (the column-segment layout it replaces: 24 + 4 + 16).
 // ------------------------------------------------------------------------------------------------------------------------
 // Hopping of the DPP form.  Disordered hopping: the (cosh, sinh) of the bond that covers each of the lane's four sites in each of
 // the four colours, gathered once before the loop.  UNI (one hopping for every bond — the example decks): every site has exactly
@@ -126,7 +131,7 @@ template <bool UNI>
 struct SqCtx {
     double c[UNI ? 1 : 4][UNI ? 1 : 4], s[UNI ? 1 : 4][UNI ? 1 : 4];   // UNI: s[0][0] = th, c[0][0] unused
     double k4;                                                // factor the caller applies to a swept vector (1 unless UNI)
-    bool xodd; int up, dn;                                    // partner lanes of the y-odd colour: (l + 16) & 63, (l - 16) & 63
+    int yx;                                                   // partner lane of the crossing half of the y-odd colour: (l + 15) & 63 for odd Y, (l + 49) & 63 for even Y
     // new value of a site with value v whose partner holds t
     __device__ __forceinline__ double upd(int col, int k, double v, double t) const {
         if constexpr (UNI) return v + s[0][0] * t;
@@ -140,41 +145,41 @@ struct SqCtx {
 template <int CNT, int COL, bool UNI>
 __device__ __forceinline__ void sq_colour(double (*v)[4], const SqCtx<UNI> &X) {
     constexpr int DS = 0x080, VALU = 0x002, ARITH = UNI ? 1 : 2;          // ARITH: vector-ALU instructions per site update
-    if constexpr (COL == 0) {                                // x even <-> x + 1: lane ^ 1
-#pragma unroll
-        for (int n = 0; n < CNT; ++n)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const double t = dpp_f64<0xB1>(v[n][k]); v[n][k] = X.upd(0, k, v[n][k], t); }
-    } else if constexpr (COL == 1) {                         // x odd <-> x + 1 (mod 16): odd lanes look up, even lanes look down
-        // (dpp_pair_odd_up: two vector-ALU instructions per word.  ds_bpermute does it in one instruction and no vector-ALU slot — measured
-        //  SLOWER, 7.5 vs 6.8 us per iteration at 4 slices per wave: the LDS crossbar is one per CU, ~6 cycles per ds_bpermute
-        //  with 8 waves asking (tools/probes/f64_rate_probe.cpp), the vector ALUs are four)
+    if constexpr (COL == 0) {                                // x even: (0,1), (2,3) of the lane itself
 #pragma unroll
         for (int n = 0; n < CNT; ++n) {
-            double t[4];
-            dpp_pair_odd_up4(t, v[n]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[n][k] = X.upd(1, k, v[n][k], t[k]);
-        }
-    } else if constexpr (COL == 2) {                         // y even <-> y + 1: (k0,k1), (k2,k3) of the lane itself
-#pragma unroll
-        for (int n = 0; n < CNT; ++n) {
-            const double n0 = X.upd(2, 0, v[n][0], v[n][1]), n1 = X.upd(2, 1, v[n][1], v[n][0]);
-            const double n2 = X.upd(2, 2, v[n][2], v[n][3]), n3 = X.upd(2, 3, v[n][3], v[n][2]);
+            const double n0 = X.upd(0, 0, v[n][0], v[n][1]), n1 = X.upd(0, 1, v[n][1], v[n][0]);
+            const double n2 = X.upd(0, 2, v[n][2], v[n][3]), n3 = X.upd(0, 3, v[n][3], v[n][2]);
             v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
         }
-    } else {                                                 // y odd <-> y + 1 (mod 16): (k1,k2) in the lane, k3 <-> next row group's k0
-        double t3[CNT], t0[CNT];
-#pragma unroll
-        for (int n = 0; n < CNT; ++n) { t3[n] = __shfl(v[n][0], X.up, WAVE); t0[n] = __shfl(v[n][3], X.dn, WAVE); }
+    } else if constexpr (COL == 1) {                         // x odd: q odd <-> q - 1 of the lane 2 up, q even <-> q + 1 of the lane 2 down
 #pragma unroll
         for (int n = 0; n < CNT; ++n) {
-            const double n1 = X.upd(3, 1, v[n][1], v[n][2]), n2 = X.upd(3, 2, v[n][2], v[n][1]);
-            v[n][0] = X.upd(3, 0, v[n][0], t0[n]); v[n][3] = X.upd(3, 3, v[n][3], t3[n]);
-            v[n][1] = n1; v[n][2] = n2;
+            const double t1 = dpp_f64<0x12E>(v[n][0]), t3 = dpp_f64<0x12E>(v[n][2]);     // row_ror:14 = lane + 2
+            const double t0 = dpp_f64<0x122>(v[n][1]), t2 = dpp_f64<0x122>(v[n][3]);     // row_ror:2  = lane - 2
+            v[n][0] = X.upd(1, 0, v[n][0], t0); v[n][1] = X.upd(1, 1, v[n][1], t1);
+            v[n][2] = X.upd(1, 2, v[n][2], t2); v[n][3] = X.upd(1, 3, v[n][3], t3);
         }
+    } else if constexpr (COL == 2) {                         // y even: (0,2), (1,3) of the lane itself
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            const double n0 = X.upd(2, 0, v[n][0], v[n][2]), n2 = X.upd(2, 2, v[n][2], v[n][0]);
+            const double n1 = X.upd(2, 1, v[n][1], v[n][3]), n3 = X.upd(2, 3, v[n][3], v[n][1]);
+            v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
+        }
+    } else {                                                 // y odd: 2, 3 swap inside the lane pair; 0, 1 cross to the neighbouring row group
+        double c0[CNT], c1[CNT];
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) { c0[n] = __shfl(v[n][0], X.yx, WAVE); c1[n] = __shfl(v[n][1], X.yx, WAVE); }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            const double t2 = dpp_f64<0xB1>(v[n][2]), t3 = dpp_f64<0xB1>(v[n][3]);       // quad_perm [1,0,3,2]
+            v[n][2] = X.upd(3, 2, v[n][2], t2); v[n][3] = X.upd(3, 3, v[n][3], t3);
+        }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) { v[n][0] = X.upd(3, 0, v[n][0], c0[n]); v[n][1] = X.upd(3, 1, v[n][1], c1[n]); }
         __builtin_amdgcn_sched_group_barrier(DS, 4 * CNT, 0);
-        __builtin_amdgcn_sched_group_barrier(VALU, 4 * ARITH * CNT, 0);
+        __builtin_amdgcn_sched_group_barrier(VALU, (4 + 4 * ARITH) * CNT, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -550,7 +555,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     bool live[NPL], own[NPL];                          // own: the site enters the inner products (a shard counts its own rows only)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = SQ ? ((lane & 15) + 64 * (lane >> 4) + 16 * q) : lane + q * WAVE;
+        const int s = SQ ? sq_patch_site(lane, q) : lane + q * WAVE;
         live[q] = SQ || s < N;                            // (DPP form: N = 256 fills every register of every lane — no selects in the sums)
         own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : live[q];
         sc[q] = live[q] ? s : N - 1;
@@ -586,7 +591,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     Tab<NE, UNI> tab[NT];
     SqCtx<UNI> X;
     if constexpr (SQ) {
-        X.xodd = (lane & 1) != 0; X.up = (lane + 16) & 63; X.dn = (lane + 48) & 63;
+        X.yx = sq_patch_ycross(lane);
         if constexpr (UNI) {
             X.c[0][0] = m.c_uni; X.s[0][0] = m.s_uni / m.c_uni; X.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
         } else {
