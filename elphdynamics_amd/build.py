@@ -6,9 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("ELPH_LIB") or os.path.join(HERE, "libelphgpu.so")
-SOURCES = ["kernels.hip", "cg_fast.hip", "cg_fast6.hip", "cg_wg.hip", "shard.hip", "kpm_dev.hip", "dft.hip", "dft_mfma.hip", "dft_big.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
+SOURCES = ["kernels.hip", "cg_fast.hip", "cg_fast6.hip", "cg_wg.hip", "pcg_wg.hip", "shard.hip", "kpm_dev.hip", "dft.hip", "dft_mfma.hip", "dft_big.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
 OBJDIR = os.path.join(HERE, "build")
-HEADERS = [os.path.join(CSRC, "elph_internal.h"), os.path.join(CSRC, "cg_fast_impl.inc"), os.path.join(CSRC, "cg_fast_common.h"), os.path.join(HERE, "..", "include", "elph_gpu.h")]
+HEADERS = [os.path.join(CSRC, "elph_internal.h"), os.path.join(CSRC, "cg_fast_impl.inc"), os.path.join(CSRC, "cg_fast_common.h"), os.path.join(CSRC, "cg_wg_dev.h"), os.path.join(CSRC, "kpm_sq_dev.h"), os.path.join(HERE, "..", "include", "elph_gpu.h")]
 
 
 def _hipcc():

@@ -18,6 +18,7 @@
 // Reference semantics: see kernels.hip / SURVEY.md Appendix A.
 
 #include "cg_fast_common.h"
+#include "kpm_sq_dev.h"
 
 #define ELPH_LP_MC 4
 #define LPNS lp4

@@ -713,6 +713,35 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
         }
     }
 
+    // the whole PRECONDITIONED solve in one launch (pcg_wg.hip: k_pcg_wg) for one to eight right-hand sides on the 16 x 16 square lattice
+    if (use_prec && maxiter >= 1 && elph_pcg_wg_usable(h, nrhs)) {
+        bool ran = false;
+        CgBufs B = elph_make_bufs(h, nrhs);
+        B.params = P;
+        const size_t xbytes = (size_t)nrhs * (size_t)h->ndim * sizeof(double);
+        HIPCHK(hipMemcpyAsync(h->d_tmp, h->d_x, xbytes, hipMemcpyDeviceToDevice, h->stream));     // the initial guess, for the fallback (A x0 in d_tmp has been consumed)
+        RC(elph_pcg_wg(h, B, nrhs, 0, &ran));
+        if (ran) {
+            HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            bool aborted = false;
+            RC(elph_wg_aborted(h, &aborted));
+            if (!aborted) {
+                for (int r = 0; r < nrhs; ++r) {
+                    if (!h->h_state[2 * r].done) { elph_set_error("resident preconditioned CG ended without a terminal state (internal error)"); return ELPH_E_STATE; }
+                    iters[r] = h->h_state[2 * r].iters;
+                }
+                if (eps_hist) {
+                    HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, sizeof(double) * (size_t)nrhs * (size_t)(maxiter + 1), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(hipStreamSynchronize(h->stream));
+                }
+                return ELPH_OK;
+            }
+            HIPCHK(hipMemcpyAsync(h->d_x, h->d_tmp, xbytes, hipMemcpyDeviceToDevice, h->stream));
+            RC(elph_launch_cg_init(h, nrhs, use_prec));
+        }
+    }
+
     const int64_t max_chunks = (maxiter + 1 + h->chunk - 1) / h->chunk + 1;
     bool all_done = false;
     for (int64_t c = 0; c < max_chunks && !all_done; ++c) {
@@ -1589,8 +1618,8 @@ static int bench_launch_unit(elph_handle_s *h, int what, int nrhs) {
 extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B) {
     CHECK_H(h);
     RC(need_model(h));
-    if (nrhs < 1 || what < 0 || what > 9) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    if ((what == 2 || what == 3 || (what >= 6 && what <= 8)) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
+    if (nrhs < 1 || what < 0 || what > 10) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if ((what == 2 || what == 3 || what == 10 || (what >= 6 && what <= 8)) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
     RC(ensure_capacity(h, nrhs));
     if (B) {
         const size_t bytes = (size_t)nrhs * (size_t)h->ndim * sizeof(double);
@@ -1599,7 +1628,7 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
     }
     // fixed-count CG: tol = 0 never converges, kmax = inf, x0 = 0
     CgParams P;
-    P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3 || (what >= 6 && what <= 8)); P.record_hist = 0; P.hist_stride = 0;
+    P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3 || what == 10 || (what >= 6 && what <= 8)); P.record_hist = 0; P.hist_stride = 0;
     h->cur_params = P;
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
     RC(elph_launch_cg_init(h, nrhs, P.use_prec));
@@ -1627,19 +1656,19 @@ extern "C" int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, 
 
 extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total) {
     CHECK_H(h);
-    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 9) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 10) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     int rc = ELPH_OK;
-    if (what == 9) {        // `reps` iterations of the whole batch in one launch of the workgroup-resident kernel
+    if (what == 9 || what == 10) {        // `reps` iterations of the whole batch in one launch of the workgroup-resident kernel (10: the preconditioned one)
         bool ran = false, aborted = false;
         CgBufs B = elph_make_bufs(h, nrhs);
         B.params = h->cur_params;
         hipError_t er = hipStreamSynchronize(h->stream);
         if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
         if (er == hipSuccess) {
-            rc = elph_wg_cg(h, B, nrhs, reps, &ran);
+            rc = (what == 9) ? elph_wg_cg(h, B, nrhs, reps, &ran) : elph_pcg_wg(h, B, nrhs, reps, &ran);
             if (rc == ELPH_OK && !ran) { elph_set_error("the workgroup-resident kernel does not apply to this handle"); rc = ELPH_E_UNSUPPORTED; }
         }
         if (er == hipSuccess && rc == ELPH_OK) er = hipEventRecord(e1, h->stream);

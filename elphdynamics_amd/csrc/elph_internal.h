@@ -363,6 +363,9 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs = 1);
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream has drained
+// ---- workgroup-resident KPM-preconditioned CG (pcg_wg.hip): the whole preconditioned solve of 1..8 right-hand sides in one launch
+bool elph_pcg_wg_usable(const elph_handle_s *h, int nrhs);
+int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 CgBufs elph_make_bufs(elph_handle_s *h, int nrhs);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part = nullptr, int nrz = 0, bool *did_rz = nullptr,
                        const double *rr_part = nullptr);

@@ -500,7 +500,9 @@ int elph_shard_destroy(elph_handle h);
  *       6 / 7 / 8 = the forward transform / Chebyshev recursion / inverse transform of the KPM apply alone (as the
  *       preconditioned iteration launches them), 9 = `reps` un-preconditioned CG iterations of every right-hand side in ONE
  *       launch of the workgroup-resident kernel (cg_wg.hip: the form elph_ldiv/elph_cg_solve use when elph_bench_wg_info
- *       says it applies; needs a fresh elph_bench_prepare before every run).
+ *       says it applies; needs a fresh elph_bench_prepare before every run), 10 = `reps` KPM-PRECONDITIONED iterations in one
+ *       launch of the resident preconditioned kernel (pcg_wg.hip: what elph_ldiv with a preconditioner runs for 1..8 right-hand
+ *       sides on the 16 x 16 square lattice; ELPH_E_UNSUPPORTED elsewhere; fresh elph_bench_prepare(…, 10, …) before every run).
  * elph_bench_prepare: loads nrhs right-hand sides (B: host, reference layout, nrhs*ndim; NULL keeps what the
  *   last solve left on the device), zeroes x, seeds the CG state with tol = 0 (never converges).
  * elph_bench_run: launches `reps` units back-to-back on the handle's stream (captured graph chunks when

@@ -447,6 +447,47 @@ def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
     m.close()
 
 
+def test_resident_preconditioned_cg_vs_streaming_and_oracle(oracle, monkeypatch):
+    """pcg_wg.hip (ELPH_PCG_WG=1: the whole KPM-preconditioned solve of 1..8 right-hand sides in one launch — CG workgroups, helper
+    workgroups for the two tau-transforms and the Chebyshev recursions, flags through L2 instead of kernel boundaries) against the
+    five-kernel streaming form and the oracle on config C: same iteration counts, same residual history, solutions to 1e-10."""
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    m = configs.make_model("C", tol=1e-5)
+    om = _oracle_model(oracle, m)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    oP = oracle.make_kpm(om, n=20, buf=0.05, c1=1.0, c2=1.0)
+    rng = np.random.default_rng(11)
+    e_min, e_max = oracle.kpm_setup(oP, b_max=rng.standard_normal(m.Nsites), b_min=rng.standard_normal(m.Nsites))
+    pc.setup_(P, e_min=e_min, e_max=e_max)
+    R, B = configs.rhs(m, 3)
+    out = {}
+    for name, flag in (("stream", "0"), ("resident", "1")):
+        monkeypatch.setenv("ELPH_PCG_WG", flag)
+        m.solver.tol = 1e-5
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B, P=P)
+        assert not fl.any(), name
+        x1 = np.zeros(m.Ndim)
+        it1, hist = models.solve_(x1, m, np.ascontiguousarray(B[0]), P=P, tol=1e-5, history=True)
+        m.solver.tol = 1e-13
+        X13 = np.zeros_like(B)
+        it13, _, fl13 = models.ldiv_batched_(X13, m, B, P=P)
+        assert not fl13.any(), name
+        out[name] = (X, it, hist, it1, X13, it13)
+    a, b = out["resident"], out["stream"]
+    assert np.array_equal(a[1], b[1]) and a[3] == b[3] and np.max(np.abs(a[5] - b[5])) <= 1
+    assert rel(a[0], b[0]) < 1e-9 and rel(a[4], b[4]) < 1e-11
+    n = min(len(a[2]), len(b[2]))
+    assert np.max(np.abs(a[2][:n] - b[2][:n]) / b[2][:n]) < 1e-9
+    xo, ito, histo = oracle.cg_solve(om, np.ascontiguousarray(B[0]), tol=1e-5, maxiter=10000, P=oP, history=True)
+    assert a[3] == ito
+    k = min(21, ito // 4 + 1)
+    assert np.max(np.abs(a[2][:k] - histo[:k]) / histo[:k]) < 1e-10
+    xo13, _, _, _ = oracle.ldiv(om, np.ascontiguousarray(B[0]), P=oP, solver_tol=1e-13, solver_maxiter=20000)
+    assert rel(a[4][0], xo13) < 1e-10
+    m.close()
+
+
 def test_kpm_fallback_to_unpreconditioned(oracle):
     """Models.jl:129-133: a preconditioned solve that fails (maxiter) is redone without P and 10x maxiter."""
     from elphdynamics_amd import configs, models, preconditioners as pc
