@@ -222,7 +222,7 @@ struct elph_handle_s {
     size_t wg_abort_off = 0;               // byte offset of the abort word in d_res
     int wg_T = 0, wg_W = 0, wg_G = 0;      // shape of the last workgroup-resident solve (0: none yet)
     long long ap_count = 0;                // k_cg_ap launches since the last cg_init (ping-pong parity)
-    int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, 2/4/5/8/10/16/20 force
+    int force_T = 0;                       // ELPH_CHUNK_T: 0 auto, 1 never chunk, n > 1 force n slices per wave (template sizes 2/4/5/8/10/16/20 dividing Ltau: the unrolled kernel; any other: k_cg_ap_chunk_rt, ragged last chunk)
 
     // solver defaults (model.solver)
     double tol = 1e-4, kmax = 1e12;

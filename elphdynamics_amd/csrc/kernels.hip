@@ -1099,7 +1099,7 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     B.dot_lo = h->dot_hi > 0 ? h->dot_lo : 0;
     B.dot_hi = h->dot_hi > 0 ? h->dot_hi : (int)h->N;
     B.nrz = (int)(h->L * h->npl);
-    B.npap = (int)(h->L / elph_choose_T(h, nrhs));
+    { const int Tc = elph_choose_T(h, nrhs); B.npap = (int)((h->L + Tc - 1) / Tc); }      // (a ragged cut: ceil)
     B.nrhs = nrhs;
     return B;
 }

@@ -527,14 +527,17 @@ extern "C" int elph_debug_pcg_stamps(unsigned long long *out32) {
 
 // Whether the resident preconditioned kernel takes this solve, and its team shape.
 static bool pcg_shape(const elph_handle_s *h, int nrhs, int *Wo, int *Go, int *nto) {
-    // OFF unless ELPH_PCG_WG=1: measured on MI355X (profiles/r03/pcg_wg_phase_stamps.log) this form takes 38.9 us per iteration for one
+    // Measured on MI355X (profiles/r03/pcg_wg_phase_stamps.log) this form takes 38.9 us per iteration for one
     // right-hand side of config C against 35.2 us of the five-kernel streaming form — the two tau-transforms cost 6 us each on the
     // 20 CUs of a team (two tiles per SIMD share the matrix core, and every stage ends in drain + barrier + flag + poll) where the
     // stand-alone kernels spread one tile per CU over 160 CUs and take ~4 us including their launch; the longest Chebyshev recursion
     // (16 us) is common to both forms.  Kept, tested (tests/test_gpu_parity.py) and timed (tools/time_pcg.py) as the measured answer
     // to "fold the preconditioned iteration into one launch".
+    // Where it wins is 6..8 right-hand sides (eight teams on eight XCDs side by side: 39.9 us per iteration at 8 against 47.1 us
+    // streaming, profiles/r03/time_kpm_streaming_small_batches.log) — the default; ELPH_PCG_WG=1 takes every batch of 1..8, =0 none.
     const char *eo = getenv("ELPH_PCG_WG");
-    if (!(eo && eo[0] == '1')) return false;
+    if (eo && eo[0] == '0') return false;
+    if (!(eo && eo[0] == '1') && nrhs < 6) return false;
     if (!h->fast || h->wg_broken || h->kind != ELPH_MODEL_HOLSTEIN || h->sq_P != 2 || h->N != 256 || !h->sq_uniform || h->lp_mc != 4) return false;
     if (!h->kpm_ready || !h->kpm_active || h->dot_hi != 0 || h->solo_chain >= 0) return false;
     if (nrhs < 1 || nrhs > 8) return false;

@@ -644,6 +644,40 @@ def test_greens_estimator_vs_oracle(oracle):
     m.close()
 
 
+@pytest.mark.parametrize("tag", ["C", "D", "E", "T"])
+def test_streaming_cg_with_ragged_chunks(tag, oracle, monkeypatch):
+    """k_cg_ap_chunk_rt: the batched streaming kernel with a run-time chunk length and a ragged last chunk (what a batch runs when the
+    template sizes would need more waves than the chip has slots: 288 right-hand sides of config C take 7 chunks of 23, ..., 22
+    slices).  Forced here through ELPH_CHUNK_T on small batches: against the unrolled template kernel (same operations per element:
+    solutions within the rounding of the regrouped p.z sums) and against the oracle; Holstein square / honeycomb / triangular
+    (six colours) and SSH; un-preconditioned and (C) KPM-preconditioned."""
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    monkeypatch.setenv("ELPH_NO_WG", "1")
+    out = {}
+    for T in ("0", "23", "7", "3"):
+        monkeypatch.setenv("ELPH_CHUNK_T", T)
+        m = configs.make_model(tag, tol=1e-13, maxiter=20000)
+        R, B = configs.rhs(m, 5)
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B)
+        assert not fl.any(), (tag, T)
+        out[T] = (X, it)
+        if T == "23":
+            om = _oracle_model(oracle, m)
+            xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(B[0]), solver_tol=1e-13, solver_maxiter=20000)
+            assert flo == 0 and rel(X[0], xo) < 1e-10 and abs(int(it[0]) - ito) <= max(3, ito // 100)
+            if tag == "C":
+                P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+                pc.setup_(P, rng=np.random.default_rng(3))
+                Xp = np.zeros_like(B)
+                itp, resp, flp = models.ldiv_batched_(Xp, m, B, P=P)
+                assert not flp.any() and itp.max() < it.min() and rel(Xp, X) < 1e-10
+        m.close()
+    for T in ("23", "7", "3"):
+        assert np.max(np.abs(out[T][1] - out["0"][1])) <= max(3, int(out["0"][1].max()) // 100), (tag, T, out[T][1], out["0"][1])   # (1e-13: the residual history is flat at the end)
+        assert rel(out[T][0], out["0"][0]) < 1e-11, (tag, T, rel(out[T][0], out["0"][0]))
+
+
 def test_repeated_solves_are_bit_identical():
     """Regression for a same-kernel reader/writer race on the double-buffered CG state: every solve of the same
     system must return the same bits and the same iteration count (single and batched, tiny and full size)."""
