@@ -101,6 +101,7 @@ SIGNATURES = {
     "elph_fourier_accelerate": (c_int, [Handle, P_dbl, P_dbl, P_dbl, c_dbl, c_i64]),
     "elph_tau_to_omega": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_omega_to_tau": (c_int, [Handle, P_dbl, P_dbl]),
+    "elph_wg_status": (c_int, [Handle, P_int, P_i64]),
     "elph_shard_shape": (c_int, [c_i64, c_int, P_int, P_int, P_int, P_int]),
     "elph_shard_create": (c_int, [Handle, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, P_i64, C.c_void_p]),
     "elph_shard_connect": (c_int, [Handle, C.c_void_p]),

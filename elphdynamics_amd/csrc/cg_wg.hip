@@ -98,6 +98,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // mat-vec — no register across the mat-vec, no vector-memory traffic inside the loop that a meeting's poll would wait behind,
     // and the neighbouring waves read their halo slices of r straight from here
     double zw[T + 1][NPL], p[T + 2][NPL], E[E_LDS ? 1 : NEJ][NPL], xr[X_REG ? T : 1][NPL];
+    // (Measured and NOT done here: skipping the read of x0 when the library knows it is zero, and reading the own slices of r0 once for r
+    //  and p0 = r0.  Either changes the register assignment of the LOOP — 256 registers, none to spare at 4 slices per wave — and
+    //  costs it 8-20 %: 5.6-6.4 against 5.2 us per iteration at 48 right-hand sides (profiles/r03/wg_load_variants.log).)
 #pragma unroll
     for (int j = 0; j < T; ++j)
 #pragma unroll
@@ -601,16 +604,22 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         STAMP(7);
         if (done) {
             STAMP_OUT(it);
+            // (the store addresses are made here, from a laundered lane number: computed before the loop they sit in 2 registers per
+            //  value for the whole solve — in a kernel that has none to spare: 10 -> 2 spilled registers at 4 slices per wave)
+            int lane2 = lane;
+            asm volatile("" : "+v"(lane2));
 #pragma unroll
             for (int j = 0; j < T; ++j)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q)
-                    if (live[q]) {
+                for (int q = 0; q < NPL; ++q) {
+                    const int s2 = SQ ? sq_patch_site(lane2, q) : lane2 + q * WAVE;
+                    if (SQ || s2 < N) {
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
-                        if (SHARD) rg[(size_t)(t0 + j) * N + sc[q]] = rl[j * HS + lane + q * WAVE];
-                        xg[(size_t)(t0 + j) * N + sc[q]] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HS + lane + q * WAVE];
+                        if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HS + lane + q * WAVE];
+                        xg[(size_t)(t0 + j) * N + s2] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HS + lane + q * WAVE];
                     }
+                }
             if (g == 0 && wv == 0 && lane == 0) {
                 CgState o = S;
                 o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = it + 1; o.iters = it; o.done = done;
@@ -761,7 +770,14 @@ bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs) {
 // ELPH_E_HIP with "workgroup-resident" in the message: a team timed out; the caller re-initialises and runs the two-kernel path.
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran) {
     *ran = false;
-    if (h->wg_broken || B.params.use_prec) return ELPH_OK;
+    if (B.params.use_prec) return ELPH_OK;
+    if (h->wg_broken) {
+        // a team timed out on an earlier solve (the GPU was shared with something that held its CUs): the handle runs the streaming
+        // iteration for the next ELPH_WG_COOLDOWN solves (default 16), then tries the resident kernel again with a cleared abort word
+        if (--h->wg_cooldown > 0) return ELPH_OK;
+        h->wg_broken = false;
+        if (h->d_res && h->wg_abort_off) HIPCHK(hipMemsetAsync(static_cast<char *>(h->d_res) + h->wg_abort_off, 0, sizeof(int), h->stream));
+    }
     if (!elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs)) return ELPH_OK;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
@@ -815,8 +831,14 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     h->wg_epoch += (unsigned)span;
     R.G = sh.G; R.W = sh.W;
     const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
-    R.timeout_ticks = (long long)(eto ? atoll(eto) : 20000) * 100000LL;     // wall_clock64 runs at 100 MHz
+    // (2 s: a team at the dispatch frontier of an oversubscribed grid waits for whole solves of the resident ones — tens of ms for a
+    //  batch of hundreds of right-hand sides; a measurement launch of thousands of fixed iterations gets its own duration on top)
+    R.timeout_ticks = ((long long)(eto ? atoll(eto) : 2000) + (fixed_iters > 0 ? fixed_iters / 10 : 0)) * 100000LL;     // wall_clock64 runs at 100 MHz
     R.fixed_iters = fixed_iters;
+    R.x0_zero = 0;
+    h->wg_x0_zero = false;
+    if (fixed_iters <= 0)       // the caller's initial guess survives in d_zp (unused by an un-preconditioned solve) for the fallback
+        HIPCHK(hipMemcpyAsync(h->d_zp, h->d_x, (size_t)nrhs * (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     const dim3 grid((unsigned)(8 * ((nrhs + 7) / 8) * sh.G));
     hipError_t e = hipSuccess;
     switch (h->npl) {
@@ -841,6 +863,9 @@ int elph_wg_aborted(elph_handle_s *h, bool *aborted) {
     HIPCHK(hipMemcpy(&ab, static_cast<char *>(h->d_res) + h->wg_abort_off, sizeof(int), hipMemcpyDeviceToHost));
     if (ab) {
         h->wg_broken = true;
+        const char *ec = getenv("ELPH_WG_COOLDOWN");
+        h->wg_cooldown = ec ? std::max(1, atoi(ec)) : 16;
+        ++h->wg_fallbacks;
         *aborted = true;
         elph_set_error("workgroup-resident CG timed out waiting for its team (T=%d W=%d G=%d); falling back to the two-kernel iteration",
                        h->wg_T, h->wg_W, h->wg_G);
@@ -896,8 +921,9 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     (void)span;
     R.G = sh.G; R.W = sh.W;
     const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
-    R.timeout_ticks = (long long)(eto ? atoll(eto) : 20000) * 100000LL;
+    R.timeout_ticks = (long long)(eto ? atoll(eto) : 2000) * 100000LL;
     R.fixed_iters = fixed_iters;
+    R.x0_zero = 0;
     HIPCHK(hipMemsetAsync(base, 0, h->res_cap, h->stream));   // boundary granules of this rank's workgroups: tags restart at 2
     h->wg_epoch = 0;
     const dim3 grid((unsigned)sh.G);                       // one right-hand side: its G workgroups, round-robin over the XCDs

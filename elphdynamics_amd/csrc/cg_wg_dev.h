@@ -22,6 +22,7 @@ struct WgCtl {
     int G, W;
     long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
     long long fixed_iters;     // > 0: measurement mode, exactly this many iterations, no stop test
+    int x0_zero;               // the initial guess is zero (the library zeroed it): x0 is not read
 };
 
 template <int NPL>

@@ -223,7 +223,8 @@ extern "C" int elph_create(elph_handle *out, int kind, int64_t nsites, int64_t l
         return ELPH_E_UNSUPPORTED;
     }
     if (nsites * ltau > (int64_t)1 << 30) { elph_set_error("ndim too large"); return ELPH_E_UNSUPPORTED; }
-    if (ltau > 1024 * 1024) { elph_set_error("ltau=%lld: the time axis is limited to 1024 * 1024 slices", (long long)ltau); return ELPH_E_UNSUPPORTED; }
+    // (beyond 1024 slices the tau-transforms run as dft_big.hip's two-step form, whose launches carry the slice index in gridDim.y)
+    if (ltau > 65535) { elph_set_error("ltau=%lld: the time axis is limited to 65535 slices (launch geometry of the long-axis transform)", (long long)ltau); return ELPH_E_UNSUPPORTED; }
     if (nbonds > 0 && !neighbor_table) { elph_set_error("neighbor_table is null"); return ELPH_E_ARG; }
     if (kind == ELPH_MODEL_HOLSTEIN && nbonds > 0 && (!cosht || !sinht)) { elph_set_error("cosht/sinht null"); return ELPH_E_ARG; }
     for (int64_t n = 0; n < nbonds; ++n) {
@@ -680,15 +681,15 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
     }
     if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);   // parameters are baked into captured launches
     h->cur_params = P;
-    RC(elph_launch_cg_init(h, nrhs, use_prec));
+    RC(elph_launch_cg_init(h, nrhs, use_prec));      // (consumes h->x_zero: A x0 = 0 without the mat-vec)
+    h->wg_x0_zero = h->x_zero_seen;
 
     // whole solve in one launch with the Krylov vectors in registers (cg_wg.hip: k_cg_wg) when it applies
-    if (h->fast && !use_prec && maxiter >= 1 && !h->wg_broken && elph_wg_usable(h, nullptr, nullptr, nullptr)) {
+    if (h->fast && !use_prec && maxiter >= 1 && elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs)) {
         bool ran = false;
         CgBufs B = elph_make_bufs(h, nrhs);
         B.params = P;
-        // the caller's initial guess survives in d_zp (unused by an un-preconditioned solve) for the fallback below
-        HIPCHK(hipMemcpyAsync(h->d_zp, h->d_x, (size_t)nrhs * (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // (elph_wg_cg saves the caller's initial guess in d_zp — unused by an un-preconditioned solve — once it has decided to launch)
         RC(elph_wg_cg(h, B, nrhs, 0, &ran));
         if (ran) {
             HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyDeviceToHost, h->stream));
@@ -882,6 +883,7 @@ static int stage_in_dev(elph_handle_s *h, int nrhs, const double *X_dev, const d
     RC(ensure_capacity(h, nrhs));
     RC(elph_launch_r2s(h, h->d_b, B_dev, nrhs));
     RC(elph_launch_r2s(h, h->d_x, X_dev, nrhs));
+    h->x_zero = false;                              // (a caller's initial guess)
     return ELPH_OK;
 }
 
@@ -911,6 +913,7 @@ extern "C" int elph_ldiv_batched(elph_handle h, int nrhs, double *X, const doubl
     RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, nrhs));
     HIPCHK(hipMemcpyAsync(h->d_stage_in, X, bytes, hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, nrhs));
+    h->x_zero = false;                              // (a caller's initial guess)
     RC(ldiv_core(h, nrhs, use_prec, maxiter, iters, residual_error, flag));
     RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, nrhs));
     HIPCHK(hipMemcpyAsync(X, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -936,6 +939,7 @@ extern "C" int elph_cg_solve(elph_handle h, double *x, const double *b, double t
     RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 1));
     HIPCHK(hipMemcpyAsync(h->d_stage_in, x, bytes, hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, 1));
+    h->x_zero = false;                              // (a caller's initial guess)
     RC(run_cg(h, 1, use_precond ? 1 : 0, tol, maxiter, kappa_max, iters, eps_hist));
     RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, 1));
     HIPCHK(hipMemcpyAsync(x, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1092,6 +1096,7 @@ extern "C" int elph_fermion_force_holstein(elph_handle h, const double *x, const
     RC(elph_launch_r2s(h, h->d_phi, h->d_stage_in, 2));
     RC(elph_launch_lambda_rhs(h, h->d_b, h->d_phi, h->d_xfield, dtau));
     HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * bytes, h->stream));                      // fill!(O⁻¹Λϕ, 0)  (HMC.jl:854,883)
+    h->x_zero = true;
     // the two solves as one batch at tol^power (HMC.jl:827-828, restored below as at :912)
     const double tol0 = h->tol;
     h->tol = pow(tol0, tol_power);
@@ -1132,6 +1137,7 @@ static int ssh_force_core(elph_handle_s *h, const double *rhs_plus, const double
     HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, rhs_minus, bytes, hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 2));
     HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * bytes, h->stream));
+    h->x_zero = true;
     const double tol0 = h->tol;
     h->tol = pow(tol0, tol_power);
     int64_t it2[2] = {0, 0};
@@ -1631,6 +1637,7 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
     P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3 || what == 10 || (what >= 6 && what <= 8)); P.record_hist = 0; P.hist_stride = 0;
     h->cur_params = P;
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
+    h->x_zero = true;
     RC(elph_launch_cg_init(h, nrhs, P.use_prec));
     HIPCHK(hipStreamSynchronize(h->stream));
     return ELPH_OK;
@@ -1640,6 +1647,15 @@ extern "C" int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave) {
     CHECK_H(h);
     if (nrhs < 1 || !slices_per_wave) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     *slices_per_wave = elph_choose_T(h, nrhs);
+    return ELPH_OK;
+}
+
+// Health of the workgroup-resident kernels on this handle: *cooling_down = solves left on the streaming iteration after a team timed
+// out (0: the resident kernel is in use), *fallbacks = how many launches were given up and re-solved by the streaming iteration.
+extern "C" int elph_wg_status(elph_handle h, int *cooling_down, int64_t *fallbacks) {
+    CHECK_H(h);
+    if (cooling_down) *cooling_down = h->wg_broken ? h->wg_cooldown : 0;
+    if (fallbacks) *fallbacks = h->wg_fallbacks;
     return ELPH_OK;
 }
 
@@ -1668,6 +1684,7 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
         hipError_t er = hipStreamSynchronize(h->stream);
         if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
         if (er == hipSuccess) {
+            h->wg_x0_zero = h->x_zero_seen;                 // (elph_bench_prepare zeroed x)
             rc = (what == 9) ? elph_wg_cg(h, B, nrhs, reps, &ran) : elph_pcg_wg(h, B, nrhs, reps, &ran);
             if (rc == ELPH_OK && !ran) { elph_set_error("the workgroup-resident kernel does not apply to this handle"); rc = ELPH_E_UNSUPPORTED; }
         }

@@ -217,7 +217,12 @@ struct elph_handle_s {
     void *greens = nullptr;                // GreensState (greens.hip), owned
     void *d_res = nullptr;                 // control block of the workgroup-resident CG (cg_wg.hip): meeting records, abort word, boundary slices
     size_t res_cap = 0;
-    bool wg_broken = false;                // a workgroup-resident launch timed out once: do not try again on this handle
+    // x = 0 hint: set by the library right after it zeroes d_x for a solve it is about to start (fill!(x, 0) of the callers, HMC.jl:854);
+    // elph_launch_cg_init consumes it (A x0 = 0 needs no mat-vec; x_zero_seen tells the resident kernel not to read x0 either)
+    bool x_zero = false, x_zero_seen = false, wg_x0_zero = false;
+    bool wg_broken = false;                // a workgroup-resident launch timed out: streaming iteration for the next wg_cooldown solves, then retry
+    int wg_cooldown = 0;
+    long long wg_fallbacks = 0;            // how many times that happened (elph_wg_status)
     unsigned wg_epoch = 0;                 // next free tag of the meeting records (cg_wg.hip: WgCtl::epoch0)
     size_t wg_abort_off = 0;               // byte offset of the abort word in d_res
     int wg_T = 0, wg_W = 0, wg_G = 0;      // shape of the last workgroup-resident solve (0: none yet)

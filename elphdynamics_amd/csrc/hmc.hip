@@ -302,6 +302,7 @@ int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power,
     else
         RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
     HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * (size_t)nch * nd * sizeof(double), h->stream));
+    h->x_zero = true;
     const double tol0 = h->tol;
     h->tol = pow(tol0, power);
     std::vector<int64_t> it2((size_t)2 * nch, 0);
@@ -850,6 +851,7 @@ int langevin_force(elph_handle_s *h, HmcState *st, double *dS, const double *g_h
     if (use_precond) RC(elph_kpm_setup_chains(h, bmax, bmin, nullptr, nullptr, nullptr, nullptr, nullptr));   // setup!(P), :366
     RC(elph_launch_mul(h, 1, h->d_b, st->R2, nch));                             // Mᵀg (model.v″, :378)
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nch * nd * sizeof(double), h->stream));   // fill!(M⁻¹g, 0), :367
+    h->x_zero = true;
     std::vector<double> res((size_t)nch);
     RC(elph_i_ldiv_core(h, nch, use_precond ? 1 : 0, 0, iters, res.data(), flag));
     const long long n = (long long)st->nf * h->L * nch;

@@ -1217,8 +1217,15 @@ int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec) {
     CgBufs B = make_bufs(h, nrhs);
     h->ap_count = 0;
     const int N = (int)h->N, L = (int)h->L;
-    int rc = elph_launch_mul(h, 2, h->d_tmp, h->d_x, nrhs);
-    if (rc) return rc;
+    int rc = ELPH_OK;
+    h->x_zero_seen = h->x_zero;
+    h->x_zero = false;
+    if (h->x_zero_seen) {       // x0 = 0 (the library zeroed it for this solve): A x0 = 0 without the mat-vec
+        if (hipMemsetAsync(h->d_tmp, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream) != hipSuccess) { elph_set_error("memset failed"); return ELPH_E_HIP; }
+    } else {
+        rc = elph_launch_mul(h, 2, h->d_tmp, h->d_x, nrhs);
+        if (rc) return rc;
+    }
     const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
     double *bb = h->d_part + 3 * P;
     hipLaunchKernelGGL(k_cg_init, dim3((unsigned)L, (unsigned)nrhs), dim3(WAVE), 0, h->stream, B, h->d_b, h->d_tmp, bb, N, L);

@@ -589,8 +589,9 @@ int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_ite
     h->wg_epoch += (unsigned)span;
     R.G = G; R.W = W;
     const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
-    R.timeout_ticks = (long long)(eto ? atoll(eto) : 20000) * 100000LL;
+    R.timeout_ticks = (long long)(eto ? atoll(eto) : 2000) * 100000LL;
     R.fixed_iters = fixed_iters;
+    R.x0_zero = 0;
     wg::PcgCtl Pc;
     Pc.flags = R.slots + n_slots;
     Pc.Wf = h->mf[0][0].W; Pc.Wi = h->mf[0][1].W;

@@ -421,7 +421,7 @@ static int launch_ok(const char *what) {
 
 static long long shard_timeout_ticks() {
     const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
-    return (long long)(eto ? atoll(eto) : 20000) * 100000LL;
+    return (long long)(eto ? atoll(eto) : 2000) * 100000LL;
 }
 
 static int allsum(elph_handle_s *h, ShardState *S, double *part, int n, int slot) {

@@ -72,8 +72,14 @@ def load_checkpoint(path, sim, rng, extra=None):
     from elphdynamics_amd._lib import check, dptr
     with open(path, "rb") as f:
         st = pickle.load(f)
-    if not isinstance(st, dict) or st.get("format") != "elphdynamics_amd checkpoint 2":
-        raise ValueError(f"{path}: not a checkpoint of this version of elphdynamics_amd")
+    if not isinstance(st, dict) or not {"phase", "n", "stats", "x", "mu"} <= set(st):
+        raise ValueError(f"{path}: not a checkpoint of elphdynamics_amd")
+    if "format" not in st:          # version 1 (before the identity / caller-state fields): resumed without the deck check
+        import warnings
+        warnings.warn(f"{path}: checkpoint without a format tag (version 1): resuming without the deck-identity check")
+        st = dict(st, identity=_deck_identity(sim), extra=None)
+    elif st["format"] != "elphdynamics_amd checkpoint 2":
+        raise ValueError(f"{path}: checkpoint format {st['format']!r} is not known to this version")
     if st["identity"] != _deck_identity(sim):
         raise ValueError(f"{path} belongs to another deck: {st['identity']} != {_deck_identity(sim)}")
     if extra is not None and st.get("extra") is not None:

@@ -509,6 +509,11 @@ int elph_shard_destroy(elph_handle h);
  *   use_graph != 0 and reps is a multiple of the chunk), brackets them with HIP events recorded on that
  *   stream, synchronises, and returns the event time in ms (total, not per rep). */
 int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B);
+/* The whole-solve-in-one-launch kernels (cg_wg.hip) wait for their team members with a wall-clock bound (ELPH_WG_TIMEOUT_MS, 2 s); a
+ * launch that gives up — the GPU's CUs were held by other work — is solved again by the streaming iteration (same result to the
+ * solver tolerance; ldiv!'s flags unchanged) and the handle stays on the streaming iteration for ELPH_WG_COOLDOWN solves (16) before
+ * it tries again.  *cooling_down: solves left in that state (0 = the resident kernel is in use); *fallbacks: launches given up so far. */
+int elph_wg_status(elph_handle h, int *cooling_down, int64_t *fallbacks);
 int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total);
 /* Which k_cg_ap variant a batch of nrhs uses: *slices_per_wave = 1 (k_cg_ap_fast / generic) or T (k_cg_ap_chunk<T>). */
 int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave);

@@ -1455,10 +1455,20 @@ def test_wg_resident_cg_timeout_falls_back_to_the_streaming_iteration(monkeypatc
         it, res, fl = models.ldiv_batched_(X, m, B)
         assert not fl.any() and (res < 1e-4).all(), name
         out[name] = (X, it)
-        if name == "timeout":                                      # the handle does not try the resident kernel again
-            x = np.zeros(m.Ndim)
-            it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[0]))
-            assert fl1 == 0
+        if name == "timeout":
+            # the fallback is visible (elph_wg_status), the handle stays on the streaming iteration for ELPH_WG_COOLDOWN solves and
+            # then takes the resident kernel again (a single right-hand side meets the 1 ms bound)
+            from elphdynamics_amd import _lib
+            cd, fb = C.c_int(), C.c_int64()
+            _lib.check(_lib.load().elph_wg_status(m._h, C.byref(cd), C.byref(fb)))
+            assert fb.value == 1 and cd.value == 16 and _wg_info(m)[0] == 0
+            monkeypatch.setenv("ELPH_WG_TIMEOUT_MS", "2000")
+            for k in range(17):
+                x = np.zeros(m.Ndim)
+                it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[0]))
+                assert fl1 == 0
+            _lib.check(_lib.load().elph_wg_status(m._h, C.byref(cd), C.byref(fb)))
+            assert fb.value == 1 and cd.value == 0 and _wg_info(m)[0] == 1
         m.close()
     assert np.array_equal(out["timeout"][1], out["stream"][1]) and np.array_equal(out["timeout"][0], out["stream"][0])
 
