@@ -787,10 +787,10 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // of an XCD) and a batch takes ceil(nrhs / that) rounds of one iteration time each; the two-kernel streaming form is
     // HBM-bound and linear in the batch.  Both fitted to measurements on configs B, C, D, E (tools/time_forms.py,
     // profiles/r02/time_forms.log; us per iteration of the batch):
-    //   resident  = rounds x (2.5 + 0.25 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
-    //               rounds x (2.2 + 0.2 G + 0.9 T)   DPP form
+    //   resident  = rounds x (2.0 + 0.12 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
+    //               rounds x (1.6 + 0.12 G + 0.75 T)   DPP form          (single-meeting iteration, round 3)
     //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
-    // C, B, D, E: resident at every batch (C: 14 M against 3.7 M mat-vecs/s at 256; D: 4.6 M against 4.0 M; E: 3.7 M against 3.2 M);
+    // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 5.5 M against 4.0 M; E: 4.4 M against 3.2 M);
     // the rule still decides for other lattices and time axes.  A deterministic rule
     // (never a timing at run time): which form runs decides the last bits of a solution.
     // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
@@ -799,8 +799,8 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
-            const double t_res = rounds * (sh.sq ? 2.2 + 0.2 * sh.G + 0.9 * sh.T
-                                                 : 2.5 + 0.25 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
+            const double t_res = rounds * (sh.sq ? 1.6 + 0.12 * sh.G + 0.75 * sh.T
+                                                 : 2.0 + 0.12 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
         }
