@@ -50,8 +50,13 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // to LDS (read twice per iteration; 40 registers) and x stays in registers instead (LDS is full); otherwise E in registers
     // (0.35 us per iteration faster at 2 slices per wave), x and r in LDS
     constexpr bool E_LDS = SQ && T >= 4, X_REG = SQ && T >= 4;
-    // ONE: the single-meeting iteration (see the loop); a shard keeps the two-meeting form (its second meeting carries the ghost rows)
-    constexpr bool ONE = !SHARD;
+    // ONE: the single-meeting iteration (see the loop) — for a shard too: its meeting is two-level (workgroups of the rank, then ranks)
+    // and carries the ghost rows of z
+#ifdef ELPH_SHARD_TWO_MEETINGS
+    constexpr bool ONE = !SHARD;                       // (A/B build: a shard keeps round 2's two-meeting iteration)
+#else
+    constexpr bool ONE = true;
+#endif
     const int W = R.W, G = R.G;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     // (a shard: ONE right-hand side, its G workgroups are the whole grid, spread over the XCDs — several ranks on one GPU, the test
@@ -159,7 +164,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     double rho = S.rho, kmin = S.kmin, eps = S.eps;
     double eps0 = S.eps0, normb = S.normb;
 
-    if (threadIdx.x == 0) { if (ONE) tot[5] = 1.0; else bc[2] = 1.0; }     // (ordered before its first reader by the barriers of iteration 0)
+    if (threadIdx.x == 0) { tot[5] = 1.0; bc[2] = 1.0; }     // (ordered before their first readers by the barriers that follow; bc: a shard's seed meeting)
     // single-meeting form: the boundary waves of a workgroup keep the neighbouring workgroup's boundary slice of r (p0 = r0: it sits in
     // the halo of p)
     if constexpr (ONE) {
@@ -304,6 +309,24 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             const double k4 = wave_sum4(s_pz, s_rz, s_zz, s_rr, lane);
             if (lane < 4) part[lane * 8 + wv] = k4;
         }
+        if constexpr (SHARD) {
+            // the rows of z my rank neighbours hold as ghosts: straight into their mailboxes (device-initiated stores over xGMI),
+            // self-tagged — with alpha from the meeting the neighbour makes its ghost rows of the new residual itself
+            const int prev = (Sh.rank + Sh.P - 1) % Sh.P, next = (Sh.rank + 1) % Sh.P;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int s = lane + q * WAVE;
+                const u64 bits = (u64)__double_as_longlong(z[0][q]), tag = (u64)epoch << 32;
+                if (s >= Sh.own_lo && s < Sh.own_lo + Sh.n_to_prev) {              // bottom rows -> previous rank's ghosts above its own rows
+                    u64 *d = sh_ghost(Sh.mail[prev], 1, L, Sh.cap_ghost, t0, s - Sh.own_lo);
+                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                }
+                if (s >= Sh.own_hi - Sh.n_to_next && s < Sh.own_hi) {              // top rows -> next rank's ghosts below its own rows
+                    u64 *d = sh_ghost(Sh.mail[next], 0, L, Sh.cap_ghost, t0, s - (Sh.own_hi - Sh.n_to_next));
+                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                }
+            }
+        }
         if (G > 1) {                                          // boundary slices of z for the neighbouring workgroups (self-tagged granules)
             if (wv == 0) {
 #pragma unroll
@@ -318,7 +341,88 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         wg_barrier();
         STAMP(2);
         double pap, rz, zz, rr0;
-        if (G == 1) {
+        double gz[NPL];                                       // a shard: z of this wave's slice on the ghost rows (from the rank neighbours)
+        if constexpr (SHARD) {
+            // Two-level meeting.  Every workgroup publishes its four sums to the workgroups of its rank (device memory); workgroup 0
+            // of the rank adds them and stores the RANK's record into every rank's mailbox; every workgroup then adds the P rank
+            // records in rank order — one local hop and one hop between GPUs per iteration (round 2: two meetings of P G records
+            // each).  Meanwhile every wave takes the ghost rows of z of its slice from the own mailbox, the two boundary waves also
+            // the neighbouring workgroup's boundary slice of z (own rows from that workgroup, ghost rows from the mailbox).
+            const int rw = (W >= 3) ? 1 : 0;
+            u64 *rankrec = Sh.mail[Sh.rank] + (size_t)SH_MAXREC * 2;          // [P][8 granules] (the area of round 2's second meeting)
+            bool ok = true;
+            if (wv == rw) publish_rec4(slotsA, g, sum_part4(part, W, lane), epoch, lane);
+            {   // ghost rows of the own slice (+ the halo slice of a boundary wave)
+                const bool bw = G > 1 && (wv == 0 || wv == W - 1);
+                const int th = (wv == 0) ? wrap(t0 - 1) : wrap(t0 + T);
+                const u64 *bh = bw ? ((wv == 0) ? bnd + (((size_t)gm * 2 + 1) * HS) * 2 : bnd + (((size_t)gp * 2 + 0) * HS) * 2) : nullptr;
+                const u64 *ga2[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int s = lane + q * WAVE;
+                    ga2[q] = !bw ? nullptr
+                           : (s < Sh.own_lo) ? sh_ghost(Sh.mail[Sh.rank], 0, L, Sh.cap_ghost, th, s)
+                           : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, th, s - Sh.own_hi) : nullptr;
+                }
+                u64 a0[NPL], a1[NPL], h0[NPL], h1[NPL], c0[NPL], c1[NPL];
+                long long t_start = 0;
+                for (int spin = 0;; ++spin) {
+                    bool good = true;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        if (gaddr[q]) { a0[q] = ld_sys(gaddr[q]); a1[q] = ld_sys(gaddr[q] + 1); }
+                        if (bh) { h0[q] = ld_gran(bh + 2 * (lane + q * WAVE)); h1[q] = ld_gran(bh + 2 * (lane + q * WAVE) + 1); }
+                        if (ga2[q]) { c0[q] = ld_sys(ga2[q]); c1[q] = ld_sys(ga2[q] + 1); }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) {
+                        if (gaddr[q]) good = good && (unsigned)(a0[q] >> 32) == epoch && (unsigned)(a1[q] >> 32) == epoch;
+                        if (bh) good = good && (unsigned)(h0[q] >> 32) == epoch && (unsigned)(h1[q] >> 32) == epoch;
+                        if (ga2[q]) good = good && (unsigned)(c0[q] >> 32) == epoch && (unsigned)(c1[q] >> 32) == epoch;
+                    }
+                    if (__all(good)) break;
+                    if (poll_bail<NPL>(spin, t_start, lane, R)) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    gz[q] = gaddr[q] ? __hiloint2double((int)(unsigned)a1[q], (int)(unsigned)a0[q]) : 0.0;
+                    if (bw) {
+                        const double hv = ga2[q] ? __hiloint2double((int)(unsigned)c1[q], (int)(unsigned)c0[q])
+                                                 : __hiloint2double((int)(unsigned)h1[q], (int)(unsigned)h0[q]);
+                        zhalo[((wv == 0) ? 0 : HS) + lane + q * WAVE] = hv;
+                    }
+                }
+            }
+            if (wv == rw) {
+                if (g == 0) {       // the rank's record: the local records in workgroup order, then to every rank's mailbox
+                    double d0, d1, t4 = 0.0;
+                    if (G <= 8) { u64 v[1] = {0}; ok = poll_rec4<1>(slotsA, G, nullptr, nullptr, epoch, lane, R, v, d0, d1) && ok; t4 = sum_rec4<1>(v, G, lane); }
+                    else        { u64 v[4] = {0, 0, 0, 0}; ok = poll_rec4<4>(slotsA, G, nullptr, nullptr, epoch, lane, R, v, d0, d1) && ok; t4 = sum_rec4<4>(v, G, lane); }
+                    const double mine = __shfl(t4, lane & 6, WAVE);            // lane l: the total of value (l & 7) >> 1
+                    if (lane < 8 * Sh.P) {
+                        const u64 bits = (u64)__double_as_longlong(mine);
+                        st_sys(Sh.mail[lane >> 3] + (size_t)SH_MAXREC * 2 + (size_t)Sh.rank * REC4 + (lane & 7),
+                               ((u64)epoch << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+                    }
+                }
+                u64 v[1] = {0};
+                long long t_start = 0;
+                for (int spin = 0;; ++spin) {
+                    bool good = true;
+                    if (lane < REC4 * Sh.P) { v[0] = ld_sys(rankrec + lane); good = (unsigned)(v[0] >> 32) == epoch; }
+                    if (__all(good)) break;
+                    if (poll_bail<1>(spin, t_start, lane, R)) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const double t4 = sum_rec4<1>(v, Sh.P, lane);                  // ranks in rank order: the same bits on every rank
+                if (lane < 8 && !(lane & 1)) tot[lane >> 1] = t4;
+            }
+            if (!ok && lane == 0) tot[5] = 0.0;
+            wg_barrier();
+            if (tot[5] == 0.0) return;
+            pap = tot[0]; rz = tot[1]; zz = tot[2]; rr0 = tot[3];
+        } else if (G == 1) {
             const double t4 = sum_part4(part, W, lane);
             pap = readlane_f64(t4, 0); rz = readlane_f64(t4, 8); zz = readlane_f64(t4, 16); rr0 = readlane_f64(t4, 24);
         } else {
@@ -364,7 +468,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         for (int j = 0; j < T; ++j)
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const double rn = rl[j * HS + lane + q * WAVE] - alpha * z[j][q];                   // :285
+                const double zq = (SHARD && gaddr[q]) ? gz[q] : z[j][q];                           // (a shard's ghost rows: the owner's z)
+                const double rn = rl[j * HS + lane + q * WAVE] - alpha * zq;                        // :285
                 rl[j * HS + lane + q * WAVE] = rn;
                 if (X_REG) xr[X_REG ? j : 0][q] += alpha * p[j + 1][q];                            // :282
                 else xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];
@@ -386,7 +491,20 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             a = wave_sum_dpp(a);
             if (lane == 0) partF[wv] = a;
             wg_barrier();
-            if (G == 1) {
+            if constexpr (SHARD) {
+                if (wv == 0) {
+                    sh_publish(Sh, 0, g, G, wg_sum(partF, W, lane), epoch, lane);
+                    const u64 *none[NPL];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) none[q] = nullptr;
+                    double t = 0.0, dummy[NPL];
+                    const bool ok = sh_poll<NPL>(Sh, true, 0, G, none, epoch, lane, R, t, dummy);
+                    if (lane == 0) { tot[4] = t; if (!ok) tot[5] = 0.0; }
+                }
+                wg_barrier();
+                if (tot[5] == 0.0) return;
+                rr = tot[4];
+            } else if (G == 1) {
                 rr = wg_sum(partF, W, lane);
             } else {
                 if (wv == 0) {
@@ -893,10 +1011,10 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
         if (rc) return rc;
         const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
         sh.T = 1; sh.W = W; sh.G = G; sh.sq = false;
-        sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 24) * sizeof(double);
+        sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 48 + 4 * HS) * sizeof(double);     // + partials, totals, rhalo[2][HS], zhalo[2][HS]
     }
     const size_t HS = (size_t)h->npl * WAVE;
-    const size_t n_slots = 2 * 64, n_bnd = (sh.G > 1) ? (size_t)sh.G * 2 * HS * 2 : 0;
+    const size_t n_slots = wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? (size_t)sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
     // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
     // 32-bit range wraps.  The abort word sits at the END of the allocation (its place must not move with the batch size).
