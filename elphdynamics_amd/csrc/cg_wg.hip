@@ -803,6 +803,13 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
                 if (G2 > 32 || nrhs <= 8 * (32 / G2)) continue;
             }
         }
+        if (T == 2 && sq && forceT != 2) {
+            // DPP form: a batch that one round of 1 slice per wave holds (config C: up to 8 right-hand sides, one team of 20 workgroups per
+            // XCD) runs that shape — with ONE meeting per iteration the shorter mat-vec wins over the larger team: 3.47 against 4.00 us
+            // per iteration for one right-hand side (round 2, two meetings: the other way round)
+            const int G1 = L / largest_divisor_le8(L);
+            if (G1 <= 32 && L / G1 >= 2 && nrhs <= 8 * (32 / G1)) continue;
+        }
         if (T == 2 && !sq && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
         if (T == 2 && !sq && (h->npl == 5 || ssh) && forceT != 2) {
             // 5 sites per lane (honeycomb L = 12) and bond phonons (three table sets per wave: 41 registers spill): 2 slices per wave are
@@ -906,7 +913,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // HBM-bound and linear in the batch.  Both fitted to measurements on configs B, C, D, E (tools/time_forms.py,
     // profiles/r02/time_forms.log; us per iteration of the batch):
     //   resident  = rounds x (2.0 + 0.12 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
-    //               rounds x (1.6 + 0.12 G + 0.75 T)   DPP form          (single-meeting iteration, round 3)
+    //               rounds x (2.66 + 0.01 G + 0.62 T)   DPP form         (single-meeting iteration, round 3: 3.5 / 4.0 / 5.2 us at 1 / 2 / 4 slices)
     //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
     // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 5.5 M against 4.0 M; E: 4.4 M against 3.2 M);
     // the rule still decides for other lattices and time axes.  A deterministic rule
@@ -917,7 +924,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
-            const double t_res = rounds * (sh.sq ? 1.6 + 0.12 * sh.G + 0.75 * sh.T
+            const double t_res = rounds * (sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
                                                  : 2.0 + 0.12 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;

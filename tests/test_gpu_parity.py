@@ -1277,7 +1277,7 @@ def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
         return X, it
 
     Xs, its = solve({"ELPH_NO_WG": "1"}, 1e-5)
-    variants = [{}, {"ELPH_WG_T": "1"}]
+    variants = [{}, {"ELPH_WG_T": "1"}, {"ELPH_WG_T": "2"}]
     if tag == "C":      # 4 slices per wave is the shape of large batches (DPP form only)
         variants += [{"ELPH_WG_T": "4"}, {"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
     for env in variants:
@@ -1305,10 +1305,10 @@ def test_wg_resident_cg_dpp_form_with_hopping_disorder(oracle, monkeypatch):
     m.x[:] = synth.phonon_field(m.Nph, m.Ltau, 4.0, 0.1, omega=1.0, lam=1.0, seed=11)
     models.update_model_(m)
     usable, T, W, G = _wg_info(m)
-    assert usable == 1 and T == 2
+    assert usable == 1 and T == 1 and _wg_info(m, 60)[1] == 2          # Ltau = 40: 1 slice per wave up to 48 right-hand sides, then 2 (per-site hopping: never 4)
     R, B = configs.rhs(m, 3)
     out = {}
-    for name, env in (("stream", {"ELPH_NO_WG": "1"}), ("dpp2", {}), ("dpp1", {"ELPH_WG_T": "1"}), ("lds", {"ELPH_WG_NO_DPP": "1"})):
+    for name, env in (("stream", {"ELPH_NO_WG": "1"}), ("dpp2", {"ELPH_WG_T": "2"}), ("dpp1", {}), ("lds", {"ELPH_WG_NO_DPP": "1"})):
         for k in ("ELPH_NO_WG", "ELPH_WG_T", "ELPH_WG_NO_DPP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -1352,7 +1352,7 @@ def test_wg_resident_cg_large_batch_shape():
     from elphdynamics_amd import configs, models
     m = configs.make_model("C", tol=1e-5)
     nrhs = 50
-    assert _wg_info(m)[1] == 2
+    assert _wg_info(m)[1] == 1 and _wg_info(m, 20)[1] == 2 and _wg_info(m, nrhs)[1] == 4
     R, B = configs.rhs(m, nrhs)
     X = np.zeros_like(B)
     it, res, fl = models.ldiv_batched_(X, m, B)
@@ -1391,7 +1391,7 @@ def test_wg_resident_cg_bench_shape_vs_oracle(oracle):
 
 def test_wg_resident_cg_shape_pin_makes_bits_independent_of_the_batch(monkeypatch):
     """Which team shape runs decides the last bits of a solution (another summation tree), and the shape follows the batch size
-    (config C: 2 slices per wave up to 24 right-hand sides, 4 above).  ELPH_WG_T pins it: with the pin a right-hand side's solution
+    (config C: 1 slice per wave up to 8 right-hand sides, 2 up to 24, 4 above).  ELPH_WG_T pins it: with the pin a right-hand side's solution
     and iteration count are bit-identical whether it is solved alone, in a batch of 3 or in a batch of 50 — what a deployment that
     must reproduce a chain's trajectory on another batch size sets."""
     from elphdynamics_amd import configs, models
@@ -1412,7 +1412,7 @@ def test_wg_resident_cg_shape_pin_makes_bits_independent_of_the_batch(monkeypatc
             assert fl1 == 0 and it1 == itb[i] and np.array_equal(x, Xb[i]), (pin, i)
     # without the pin the two batch sizes take different shapes (documented behaviour, not a defect): same solution to the tolerance
     monkeypatch.delenv("ELPH_WG_T")
-    assert _wg_info(m, 1)[1] == 2 and _wg_info(m, 50)[1] == 4
+    assert _wg_info(m, 1)[1] == 1 and _wg_info(m, 20)[1] == 2 and _wg_info(m, 50)[1] == 4
     m.close()
 
 
