@@ -31,7 +31,7 @@ namespace lp6 {
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
-int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, bool *did_rz, const double *rr_part);
+int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, bool *did_rz, const double *rr_part, int fold_nct);
 }  // namespace lp6
 // ---- dispatch on the handle's lane-program width ------------------------------------------------------------
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec) {
@@ -44,8 +44,8 @@ int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
     return h->lp_mc == 4 ? lp4::elph_fast_cg_xr(h, B, nrhs, parity) : lp6::elph_fast_cg_xr(h, B, nrhs, parity);
 }
-int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, bool *did_rz, const double *rr_part) {
-    return h->lp_mc == 4 ? lp4::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part)
-                         : lp6::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part);
+int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, bool *did_rz, const double *rr_part, int fold_nct) {
+    return h->lp_mc == 4 ? lp4::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part, fold_nct)
+                         : lp6::elph_fast_kpm_cheb(h, nrhs, st, rz_part, nrz, did_rz, rr_part, fold_nct);
 }
 

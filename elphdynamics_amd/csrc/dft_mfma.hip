@@ -239,6 +239,13 @@ struct XrFuse {
     double *rr;               // r.r partial slots [nrhs][rr_slots]
     double *alpha;            // [nrhs]
     int npap, rr_slots;
+    // FOLD (forward, streaming form): a frequency whose Chebyshev series has order 1 is its leading coefficient — z_w = |c0|^2 r_w — so
+    // the transform writes the spectrum of those frequencies already scaled and adds their share of r.(P^-1 r) (Parseval), and the
+    // Chebyshev kernel does not touch them (config C: 47 of 80 frequencies, 111 MB of its 189 MB per iteration of 288 right-hand sides).
+    // fold[chain][w][2] = {scale, weight of |nu_w|^2 in r.z}; {1, 0} for the frequencies the Chebyshev kernel keeps.
+    const double *fold;
+    double *frz;              // r.z partial slots [nrhs][fnrz]; this kernel fills slots fslot0 + column tile
+    int fnch, fnrz, fslot0;
 };
 
 template <int NT, bool INV, bool XR>
@@ -524,6 +531,8 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
                 if (ctile == 0) X.alpha[rhs] = alpha;
             }
         }
+        double facc = 0.0;
+        const double *fch = X.fold ? X.fold + 2 * (size_t)(rhs % X.fnch) * H : nullptr;
         double2 *o = reinterpret_cast<double2 *>(out) + (size_t)rhs * H * N;
 #pragma unroll
         for (int g = 0; g < MG; ++g) {
@@ -535,10 +544,24 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
                     const double bx = e ? acc1[g].z : acc1[g].x, by = e ? acc1[g].w : acc1[g].y;
                     const double2 wk = tw[k];
                     const double tx = wk.x * bx - wk.y * by, ty = wk.x * by + wk.y * bx;          // t = w_k B
-                    o[(size_t)k * N + s] = make_double2(ax + tx, ay + ty);                        // nu_k = A + t
-                    o[(size_t)(H - 1 - k) * N + s] = make_double2(ax - tx, -(ay - ty));           // nu_kc = conj(A - t)
+                    double2 n0 = make_double2(ax + tx, ay + ty);                                   // nu_k = A + t
+                    double2 n1 = make_double2(ax - tx, -(ay - ty));                                // nu_kc = conj(A - t)
+                    if (X.fold) {
+                        const double *fk = fch + 2 * (size_t)k, *fc = fch + 2 * (size_t)(H - 1 - k);
+                        const double s0 = fk[0], w0 = fk[1], s1 = fc[0], w1 = fc[1];
+                        facc += w0 * (n0.x * n0.x + n0.y * n0.y);
+                        if (H - 1 - k != k) facc += w1 * (n1.x * n1.x + n1.y * n1.y);
+                        n0.x *= s0; n0.y *= s0; n1.x *= s1; n1.y *= s1;
+                    }
+                    o[(size_t)k * N + s] = n0;
+                    o[(size_t)(H - 1 - k) * N + s] = n1;
                 }
             }
+        }
+        if (X.fold && blockIdx.y == 0) {      // (one row group: every frequency of these 16 columns is in this wave)
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) facc += __shfl_xor(facc, o2, WAVE);
+            if (lane == 0) X.frz[(size_t)rhs * X.fnrz + X.fslot0 + ctile] = facc;
         }
     } else {
         double dot = 0.0;
@@ -706,6 +729,17 @@ int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS
     return launch<false>(h, T.nt, reinterpret_cast<double *>(nu), vS, T.W, N, K, T.groups, nrhs, st, nullptr, nullptr, 0);
 }
 
+// whether launch_r2<false> takes the streaming form (the one that knows the order-1 fold)
+bool elph_dft_mfma_fold_usable(const elph_handle_s *h) {
+    const char *ef = getenv("ELPH_KPM_FOLD");
+    if (ef && atoi(ef) == 0) return false;
+    const elph_handle_s::MfmaTab &T = h->mf_r2[0];
+    if (!T.W || !r2_enabled() || T.groups != 1 || (h->L & 1)) return false;
+    const size_t panel = (size_t)MG * T.nt * WAVE * sizeof(double);
+    const char *es = getenv("ELPH_DFT_STREAM");
+    return panel <= 144 * 1024 && !(es && atoi(es) == 0);
+}
+
 // forward twisted transform of r - alpha z with the residual update of k_cg_xr folded in (see XrFuse); usable: see below
 bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs) {
     const char *e = getenv("ELPH_FUSE_XR");
@@ -715,8 +749,9 @@ bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs) {
 }
 
 int elph_dft_mfma_fwd_xr(elph_handle_s *h, double2 *nu, double *rS, const double *zS, const double *pap, int npap, double *rr,
-                         double *alpha, int N, int nrhs, const CgState *st) {
-    XrFuse X{zS, rS, pap, rr, alpha, npap, (int)h->L};
+                         double *alpha, int N, int nrhs, const CgState *st, const double *fold, int fold_nch, double *frz, int fnrz,
+                         int fslot0) {
+    XrFuse X{zS, rS, pap, rr, alpha, npap, (int)h->L, fold, frz, fold_nch, fnrz, fslot0};
     return launch_r2<false, true>(h, h->mf_r2[0], reinterpret_cast<double *>(nu), rS, N, nrhs, st, nullptr, nullptr, 0, X);
 }
 

@@ -350,7 +350,7 @@ extern "C" int elph_destroy(elph_handle h) {
     elph_dft_big_free(h);
     void *ptrs[] = {h->d_bi, h->d_bj, h->d_coloff, h->d_c, h->d_s, h->d_E, h->d_lam, h->d_stage_in, h->d_stage_out,
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
-                    h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched,
+                    h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched, h->d_kdesc, h->d_kfold,
                     h->d_coeff, h->d_klam, h->d_ssh_x, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_cb, h->d_ssh_slot, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
                     h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_sq_bond, h->d_res, h->d_mu_ch, h->d_kpm_start};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1249,6 +1249,8 @@ static int kpm_reserve(elph_handle_s *h, int nch) {
         RC(dev_alloc(&h->d_order, (size_t)nch * Lo2));
         RC(dev_alloc(&h->d_coff, (size_t)nch * (Lo2 + 1)));
         RC(dev_alloc(&h->d_wsched, (size_t)nch * Lo2));
+        RC(dev_alloc(&h->d_kdesc, (size_t)nch * Lo2));
+        RC(dev_alloc(&h->d_kfold, (size_t)nch * Lo2 * 2));
         RC(dev_alloc(&h->d_klam, (size_t)nch * 2));
         h->kpm_tab_cap = nch;
     }
@@ -1264,6 +1266,8 @@ static int kpm_upload(elph_handle_s *h) {
     h->h_wsched.assign((size_t)nch * Lo2, 0);
     h->h_lam.assign((size_t)nch * 2, 1.0);
     h->h_coeff.clear();
+    h->h_kdesc.assign((size_t)nch * Lo2, KpmDesc());
+    h->h_kfold.assign((size_t)nch * Lo2 * 2, 0.0);
     int off = 0;
     for (int c = 0; c < nch; ++c) {
         const auto &C = h->kpm_chain[(size_t)c];
@@ -1287,6 +1291,19 @@ static int kpm_upload(elph_handle_s *h) {
         // schedule: frequency blocks by decreasing order (the low frequencies carry the long recursions)
         std::iota(ws, ws + Lo2, 0);
         std::stable_sort(ws, ws + Lo2, [&](int a, int b) { return ord[a] > ord[b]; });
+        for (int y = 0; y < Lo2; ++y) {
+            const int w = ws[y];
+            KpmDesc d;
+            d.w = w; d.order = ord[w]; d.coff = cof[w]; d.pad = 0;
+            d.c0x = h->h_coeff[2 * (size_t)cof[w]]; d.c0y = h->h_coeff[2 * (size_t)cof[w] + 1];
+            h->h_kdesc[(size_t)c * Lo2 + y] = d;
+            // order-1 fold (active chains only: an identity expansion hands over the r.r partial sums instead, bit for bit)
+            const bool fold = C.active && d.order == 1;
+            const double s1 = fold ? d.c0x * d.c0x + d.c0y * d.c0y : 1.0;
+            const double wgt = ((h->L & 1) && w == Lo2 - 1) ? 1.0 : 2.0;
+            h->h_kfold[2 * ((size_t)c * Lo2 + w)] = s1;
+            h->h_kfold[2 * ((size_t)c * Lo2 + w) + 1] = fold ? wgt * s1 / (double)h->L : 0.0;
+        }
         h->h_lam[2 * c] = (C.lam_hi + C.lam_lo) / 2;
         h->h_lam[2 * c + 1] = C.active ? (C.lam_hi - C.lam_lo) / 2 : -1.0;      // < 0 marks the identity (KpmChainView::active)
     }
@@ -1299,6 +1316,8 @@ static int kpm_upload(elph_handle_s *h) {
     HIPCHK(hipMemcpy(h->d_order, h->h_order.data(), sizeof(int) * h->h_order.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_coff, h->h_coff.data(), sizeof(int) * h->h_coff.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_wsched, h->h_wsched.data(), sizeof(int) * h->h_wsched.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_kdesc, h->h_kdesc.data(), sizeof(KpmDesc) * h->h_kdesc.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_kfold, h->h_kfold.data(), sizeof(double) * h->h_kfold.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_klam, h->h_lam.data(), sizeof(double) * h->h_lam.size(), hipMemcpyHostToDevice));
     h->lam_lo = h->kpm_chain[0].lam_lo; h->lam_hi = h->kpm_chain[0].lam_hi;
     h->lam_avg = h->h_lam[0]; h->lam_mag = h->h_lam[1];

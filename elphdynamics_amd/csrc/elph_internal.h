@@ -115,6 +115,10 @@ struct CgState {
 };
 
 
+// one frequency block of a chain's schedule, packed so that a Chebyshev block learns what it has to do from ONE 32-byte load
+// (frequency, order, offset of its coefficients, leading coefficient) instead of a chain of four dependent ones
+struct KpmDesc { int w, order, coff, pad; double c0x, c0y; };
+
 struct KpmDev {
     int active;
     int Lo2;
@@ -128,6 +132,7 @@ struct KpmDev {
     const int *coff;          // [nchains][Lo2+1] offsets into coeff (absolute: a chain's base is included)
     const double2 *coeff;     // [sum over chains of sum order]
     const int *wsched;        // [nchains][Lo2] omega indices sorted by decreasing order (longest first)
+    const KpmDesc *desc;      // [nchains][Lo2] the same schedule, packed (entry y: frequency wsched[y])
     const double *lp_cbar;    // lane-program copies of cbar/sbar [NE][64]
     const double *lp_sbar;
     // SSH chains: every chain has its own tau-averaged hopping (cbar, sbar) — strides between chains, 0 when shared (Holstein)
@@ -137,6 +142,7 @@ struct KpmDev {
 // One chain's view of the expansion (device side).
 struct KpmChainView {
     const int *order, *coff, *wsched;
+    const KpmDesc *desc;
     const double *Ebar;
     double a, b;              // 1/lam_mag, lam_avg/lam_mag
     const double *cbar, *sbar, *lp_cbar, *lp_sbar;    // this chain's averaged hopping tables
@@ -150,6 +156,7 @@ __device__ __forceinline__ KpmChainView kpm_chain_view(const KpmDev &K, int rhs,
         V.order = K.order + (size_t)c * K.Lo2;
         V.coff = K.coff + (size_t)c * (K.Lo2 + 1);
         V.wsched = K.wsched + (size_t)c * K.Lo2;
+        V.desc = K.desc + (size_t)c * K.Lo2;
         V.Ebar = K.Ebar + (size_t)c * N;
         const double avg = K.lam[2 * c], mag = K.lam[2 * c + 1];
         V.a = 1.0 / mag;
@@ -159,7 +166,7 @@ __device__ __forceinline__ KpmChainView kpm_chain_view(const KpmDev &K, int rhs,
         V.lp_cbar = K.lp_cbar + c * K.lp_hop_stride; V.lp_sbar = K.lp_sbar + c * K.lp_hop_stride;
     } else {
         V.cbar = K.cbar; V.sbar = K.sbar; V.lp_cbar = K.lp_cbar; V.lp_sbar = K.lp_sbar;
-        V.order = K.order; V.coff = K.coff; V.wsched = K.wsched; V.Ebar = K.Ebar;
+        V.order = K.order; V.coff = K.coff; V.wsched = K.wsched; V.desc = K.desc; V.Ebar = K.Ebar;
         V.a = 1.0 / K.lam_mag;
         V.b = K.lam_avg / K.lam_mag;
         V.active = K.active != 0;
@@ -280,6 +287,10 @@ struct elph_handle_s {
     int64_t kpm_tab_cap = 0;               // chains the device tables are allocated for
     double *d_Ebar = nullptr, *d_cbar = nullptr, *d_sbar = nullptr;
     int *d_order = nullptr, *d_coff = nullptr, *d_wsched = nullptr;
+    KpmDesc *d_kdesc = nullptr;
+    std::vector<KpmDesc> h_kdesc;
+    double *d_kfold = nullptr;             // [kpm_nch][Lo2][2] order-1 fold of the forward transform: {scale, r.z weight} (dft_mfma.hip: XrFuse)
+    std::vector<double> h_kfold;
     double2 *d_coeff = nullptr;
     int64_t coeff_cap = 0;
     double2 *d_nu = nullptr;               // cap_rhs * Lo2 * N complex (half spectrum, omega-major)
@@ -373,7 +384,7 @@ bool elph_pcg_wg_usable(const elph_handle_s *h, int nrhs);
 int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 CgBufs elph_make_bufs(elph_handle_s *h, int nrhs);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part = nullptr, int nrz = 0, bool *did_rz = nullptr,
-                       const double *rr_part = nullptr);
+                       const double *rr_part = nullptr, int fold_nct = 0);
 int elph_choose_T(const elph_handle_s *h, int nrhs);
 // packs per-bond values (order of h_bi/h_bj) into the lane-program layout [NE][64] (idle slots = fill)
 void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill);
@@ -391,6 +402,7 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
 // ---- batched tau-axis transforms on the matrix cores (dft_mfma.hip); which: 0 twisted, 1 plain
 int elph_dft_mfma_build_tables(elph_handle_s *h);
 bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs);
+bool elph_dft_mfma_fold_usable(const elph_handle_s *h);
 bool elph_dft_big(const elph_handle_s *h);
 int elph_dft_big_build_tables(elph_handle_s *h);
 void elph_dft_big_free(elph_handle_s *h);
@@ -402,7 +414,8 @@ int elph_dft_mfma1_fwd(elph_handle_s *h, double2 *nu, const double *vS, int N, i
 int elph_dft_mfma1_inv(elph_handle_s *h, double *outS, const double2 *nu, int N, int nrhs, const CgState *st, const double *rvec,
                        double *rz_part, int nrz);
 int elph_dft_mfma_fwd_xr(elph_handle_s *h, double2 *nu, double *rS, const double *zS, const double *pap, int npap, double *rr,
-                         double *alpha, int N, int nrhs, const CgState *st);
+                         double *alpha, int N, int nrhs, const CgState *st, const double *fold = nullptr, int fold_nch = 1,
+                         double *frz = nullptr, int fnrz = 0, int fslot0 = 0);
 void elph_dft_mfma_free(elph_handle_s *h);
 bool elph_dft_mfma_usable(const elph_handle_s *h, int which, bool inverse, int N, int nrhs);
 int elph_dft_mfma_fwd(elph_handle_s *h, int which, double2 *nu, const double *vS, int N, int nrhs, const CgState *st);

@@ -999,7 +999,7 @@ KpmDev elph_kpm_dev(const elph_handle_s *h) {
     K.lam_avg = h->lam_avg; K.lam_mag = h->lam_mag;
     K.nchains = h->kpm_nch; K.lam = h->d_klam;
     K.Ebar = h->d_Ebar; K.cbar = h->d_cbar; K.sbar = h->d_sbar;
-    K.order = h->d_order; K.coff = h->d_coff; K.coeff = h->d_coeff; K.wsched = h->d_wsched;
+    K.order = h->d_order; K.coff = h->d_coff; K.coeff = h->d_coeff; K.wsched = h->d_wsched; K.desc = h->d_kdesc;
     K.lp_cbar = h->d_lp_cbar; K.lp_sbar = h->d_lp_sbar;
     const bool hop_per_chain = (h->kind == ELPH_MODEL_SSH && h->kpm_nch > 1);
     K.hop_stride = hop_per_chain ? (long long)h->nb : 0;
@@ -1012,7 +1012,7 @@ KpmDev elph_kpm_dev(const elph_handle_s *h) {
         K.nchains = 1;
         K.lam_avg = h->h_lam[2 * c]; K.lam_mag = h->h_lam[2 * c + 1];
         K.Ebar += (size_t)c * h->N;
-        K.order += (size_t)c * K.Lo2; K.coff += (size_t)c * (K.Lo2 + 1); K.wsched += (size_t)c * K.Lo2;
+        K.order += (size_t)c * K.Lo2; K.coff += (size_t)c * (K.Lo2 + 1); K.wsched += (size_t)c * K.Lo2; K.desc += (size_t)c * K.Lo2;
     }
     return K;
 }
@@ -1170,9 +1170,18 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     KpmDev K = elph_kpm_dev(h);
     ModelDev m = elph_model_dev(h);
 
+    // FOLD (dft_mfma.hip: XrFuse): in the batched CG iteration (forward transform with the residual update folded in, register-exchange
+    // Chebyshev kernel with the r.z partials in frequency space) the frequencies of order 1 — z_w = |c0|^2 r_w — are finished by the
+    // forward transform; the Chebyshev kernel keeps their slot bookkeeping only
+    static const bool freq_rz_on = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
+    const int nct = (N + 15) / 16;
+    const bool fold = cg_mode == 2 && h->fast && h->sq_P > 0 && h->lp_mc == 4 && freq_rz_on && h->d_kfold &&
+                      2 * Lo2 + nct <= B.nrz && B.dot_lo == 0 && B.dot_hi == N && elph_dft_mfma_fold_usable(h);
     if (!(parts & 1)) {
     } else if (cg_mode == 2) {
-        int rcd = elph_dft_mfma_fwd_xr(h, h->d_nu, const_cast<double *>(rS), B.z, B.pap, B.npap, B.rr, B.alpha, N, nrhs, st);
+        int rcd = elph_dft_mfma_fwd_xr(h, h->d_nu, const_cast<double *>(rS), B.z, B.pap, B.npap, B.rr, B.alpha, N, nrhs, st,
+                                       fold ? h->d_kfold + (h->solo_chain >= 0 && h->kpm_nch > 1 ? 2 * (size_t)h->solo_chain * Lo2 : 0) : nullptr,
+                                       (h->solo_chain >= 0) ? 1 : std::max(1, h->kpm_nch), B.rz, B.nrz, 2 * Lo2);
         if (rcd) return rcd;
     } else {
         int rcd = elph_dft_fwd_twisted(h, h->d_nu, rS, N, nrhs, st);
@@ -1185,7 +1194,7 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     } else if (h->fast) {
         static const bool freq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
         const bool want = cg_mode && freq_rz && 2 * Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N;
-        int rcf = elph_fast_kpm_cheb(h, nrhs, st, want ? B.rz : nullptr, B.nrz, &rz_done, B.rr);
+        int rcf = elph_fast_kpm_cheb(h, nrhs, st, want ? B.rz : nullptr, B.nrz, &rz_done, B.rr, (fold && want) ? nct : 0);
         if (rcf) return rcf;
     } else {
         // one thread per bond of the largest colour (up to 1024): a colour is then one LDS round trip per thread; the bond
