@@ -35,7 +35,8 @@ namespace wg {
 // SQ: the DPP form for Holstein on the 16 x 16 square lattice in the reference's colouring (NPL = 4, no LDS slabs; uniform hopping
 // in two scalars, disordered hopping in per-site registers); otherwise the lane-program form
 // SHARD: this launch is one rank's part of a solve over several GPUs (T = 1, lane-program form)
-template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD>
+// X0Z: the initial guess is known to be zero (the library zeroed it for this solve): x0 is not read
+template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
     static_assert(!SHARD || (T == 1 && !SQ), "sharded solves: one slice per wave, lane-program form");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -103,16 +104,17 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // mat-vec — no register across the mat-vec, no vector-memory traffic inside the loop that a meeting's poll would wait behind,
     // and the neighbouring waves read their halo slices of r straight from here
     double zw[T + 1][NPL], p[T + 2][NPL], E[E_LDS ? 1 : NEJ][NPL], xr[X_REG ? T : 1][NPL];
-    // (Measured and NOT done here: skipping the read of x0 when the library knows it is zero, and reading the own slices of r0 once for r
-    //  and p0 = r0.  Either changes the register assignment of the LOOP — 256 registers, none to spare at 4 slices per wave — and
-    //  costs it 8-20 %: 5.6-6.4 against 5.2 us per iteration at 48 right-hand sides (profiles/r03/wg_load_variants.log).)
+    // (x0 = 0 known to the library: a compile-time variant, X0Z, does not read it — 12 us less per launch of 288 right-hand sides.  As a
+    //  RUN-TIME choice, and likewise reading the own slices of r0 once for r and p0 = r0, it changes the register assignment of the
+    //  LOOP — 256 registers, none to spare at 4 slices per wave — and costs it 8-20 %: 5.6-6.4 against 5.2 us per iteration at 48
+    //  right-hand sides (profiles/r03/wg_load_variants.log).)
 #pragma unroll
     for (int j = 0; j < T; ++j)
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             rl[j * HS + lane + q * WAVE] = rg[(size_t)(t0 + j) * N + sc[q]];
-            if (X_REG) xr[X_REG ? j : 0][q] = xg[(size_t)(t0 + j) * N + sc[q]];
-            else xl[j * HS + lane + q * WAVE] = xg[(size_t)(t0 + j) * N + sc[q]];
+            if (X_REG) xr[X_REG ? j : 0][q] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
+            else xl[j * HS + lane + q * WAVE] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
         }
 #pragma unroll
     for (int j = 0; j < T + 2; ++j)
@@ -837,12 +839,12 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     return false;
 }
 
-template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD = false>
+template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD = false, bool X0Z = false>
 static hipError_t launch_k(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R,
                            const ShardCtl &Sh = ShardCtl()) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
+    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD, X0Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R, Sh);
+    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD, X0Z>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R, Sh);
     return hipGetLastError();
 }
 
@@ -859,7 +861,7 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
     if constexpr (NPL == 4) {
         if (sh.sq) {
             if (!m.uniform) return (sh.T == 2) ? launch_k<4, 2, false, false, true>(h, sh, grid, B, m, R) : launch_k<4, 1, false, false, true>(h, sh, grid, B, m, R);
-            if (sh.T == 4) return launch_k<4, 4, false, true, true>(h, sh, grid, B, m, R);
+            if (sh.T == 4) return R.x0_zero ? launch_k<4, 4, false, true, true, false, true>(h, sh, grid, B, m, R) : launch_k<4, 4, false, true, true>(h, sh, grid, B, m, R);
             if (sh.T == 2) return launch_k<4, 2, false, true, true>(h, sh, grid, B, m, R);
             return launch_k<4, 1, false, true, true>(h, sh, grid, B, m, R);
         }
@@ -960,7 +962,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     //  batch of hundreds of right-hand sides; a measurement launch of thousands of fixed iterations gets its own duration on top)
     R.timeout_ticks = ((long long)(eto ? atoll(eto) : 2000) + (fixed_iters > 0 ? fixed_iters / 10 : 0)) * 100000LL;     // wall_clock64 runs at 100 MHz
     R.fixed_iters = fixed_iters;
-    R.x0_zero = 0;
+    { const char *ez = getenv("ELPH_WG_X0Z"); R.x0_zero = (h->wg_x0_zero && !(ez && ez[0] == '0')) ? 1 : 0; }     // (x0 = 0 known: the 4-slice DPP shape has an instantiation that does not read it)
     h->wg_x0_zero = false;
     if (fixed_iters <= 0)       // the caller's initial guess survives in d_zp (unused by an un-preconditioned solve) for the fallback
         HIPCHK(hipMemcpyAsync(h->d_zp, h->d_x, (size_t)nrhs * (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));

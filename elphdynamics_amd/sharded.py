@@ -594,6 +594,8 @@ class ShardedSolver:
         it, done, eps = C.c_int64(), C.c_int(), C.c_double()
         self._lib_mod.check(self.lib.elph_shard_prepare(self.h))
         self.comm.barrier()                                  # every mailbox is zero before any rank stores into it
+        import time
+        t_lib = time.perf_counter()
         if precond:
             assert self.hf is not None, "setup_kpm first"
             self._lib_mod.check(self.lib.elph_shard_solve_kpm(self.h, self.hf, self._lib_mod.dptr(x), self._lib_mod.dptr(b), tol, maxiter,
@@ -601,6 +603,7 @@ class ShardedSolver:
         else:
             self._lib_mod.check(self.lib.elph_shard_solve(self.h, self._lib_mod.dptr(x), self._lib_mod.dptr(b), tol, maxiter, kmax,
                                                           C.byref(it), C.byref(done), C.byref(eps)))
+        self.last_solve_s = time.perf_counter() - t_lib      # inside the library (host pointers in and out), without the gather below
         x_own = x.reshape(self.Nloc, self.Ltau)[self.own_lo:self.own_lo + self.own_n, :]
         parts = self.comm.allgather_object(x_own) if self.P > 1 else [x_own]
         self.eps = float(eps.value)

@@ -59,6 +59,16 @@ def run_rank(comm, case, out, tol):
         act, lo, hi = solver.setup_kpm(E if kind == 0 else (c, s, emu), n=20, buf=0.05, c1=1.0, c2=1.0, seed=7)
         xk, itk, donek = solver.solve(b, tol=tol, maxiter=20000, precond=True)
         res.update(xk=xk, itk=itk, donek=donek, kpm_active=act, lam_lo=lo, lam_hi=hi)
+        if os.environ.get("ELPH_TEST_TIMING") == "1":      # (tools/time_shard_kpm.sh: wall time of a second, warm solve)
+            import time
+            comm.barrier()
+            xk2, itk2, _ = solver.solve(b, tol=tol, maxiter=20000, precond=True)
+            dt = comm.max(solver.last_solve_s)
+            xs3, it3, _ = solver.solve(b, tol=tol, maxiter=20000)
+            dt3 = comm.max(solver.last_solve_s)
+            if comm.rank == 0:
+                print(f"TIMING {case} world={comm.world}: KPM solve {1e3*dt:.2f} ms / {itk2} it = {1e6*dt/max(itk2,1):.1f} us per iteration (library call, host pointers in and out); "
+                      f"plain {1e3*dt3:.2f} ms / {it3} it = {1e6*dt3/max(it3,1):.1f} us per iteration", flush=True)
     solver.close()
     np.savez(out + f".rank{comm.rank}", **res)
     comm.close()
