@@ -59,12 +59,30 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     constexpr bool ONE = true;
 #endif
     const int W = R.W, G = R.G;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     // (a shard: ONE right-hand side, its G workgroups are the whole grid, spread over the XCDs — several ranks on one GPU, the test
     //  box, would otherwise pile their teams onto the XCD where every dispatch starts: 2 x 20 workgroups do not fit its 32 CUs)
     const int xcd = SHARD ? 0 : (blockIdx.x & 7), idx = SHARD ? blockIdx.x : (blockIdx.x >> 3);
     const int tq = idx / G, g = idx - tq * G;
-    const int rhs = tq * 8 + xcd;
+    // PERSISTENT TEAMS (-DELPH_WG_PERSISTENT; not the default): the grid holds at most as many teams as the chip keeps resident
+    // (R.teams_per_xcd per XCD, one workgroup per CU) and a team takes the right-hand sides tq, tq + teams, ... of its XCD's residue class
+    // one after the other, so that no workgroup ever waits for one that has not been dispatched yet.  The default keeps ONE solve per
+    // workgroup and an oversubscribed grid (teams at the dispatch frontier wait for members that start when another team ends —
+    // blocks are dispatched in index order; the wall-clock bound, the fallback and the cool-down of elph_wg_cg are the guard):
+    // measured, the loop around the solve costs 4 % (30.7 against 29.5 us per iteration of 288 right-hand sides, 5.51 against 5.22 at
+    // 48 — what stays live across the loop spills 126 scalar registers), profiles/r03/wg_persistent_teams.log.
+#ifdef ELPH_WG_PERSISTENT
+    for (int tqi = tq;; tqi += R.teams_per_xcd) {
+    // (the thread number is laundered per right-hand side: everything derived from it — sites, LDS offsets, DPP partners, addresses —
+    //  is made afresh for each solve; hoisted out of this loop it would sit in registers for all of them)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & (WAVE - 1);
+#else
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int tqi = tq;
+    {
+#endif
+    const int rhs = tqi * 8 + xcd;
     if (rhs >= B.nrhs) return;
     const int N = m.N, L = m.L;
     const int t0 = (g * W + wv) * T;
@@ -85,7 +103,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     const CgParams P = B.params;
     CgState *st2 = B.state + 2 * rhs;
     const CgState S = ld_state(st2);
+#ifdef ELPH_WG_PERSISTENT
+    if (!SHARD && (S.done || S.seq != 0)) continue;    // fresh solves only (the host guarantees it); a shard seeds its state below
+#else
     if (!SHARD && (S.done || S.seq != 0)) return;      // fresh solves only (the host guarantees it); a shard seeds its state below
+#endif
 
     // site of register q of this lane: lane + 64 q (layout S order), or the column segments of the DPP form
     int sc[NPL];
@@ -746,7 +768,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 st2[0] = o;
                 st2[1] = o;
             }
+#ifdef ELPH_WG_PERSISTENT
+            break;
+#else
             return;
+#endif
         }
         const double beta = rr / rho;
         rho = rr;
@@ -768,6 +794,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
             for (int q = 0; q < NPL; ++q) p[j + 1][q] = rl[j * HS + lane + q * WAVE] + beta * p[j + 1][q];
         STAMP(8);
+    }
+#ifdef ELPH_WG_PERSISTENT
+    if (SHARD) return;
+    wg_barrier();                                      // (the LDS of this right-hand side is rewritten by the next one)
+#endif
     }
 #undef EXPV
 }
@@ -966,7 +997,13 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     h->wg_x0_zero = false;
     if (fixed_iters <= 0)       // the caller's initial guess survives in d_zp (unused by an un-preconditioned solve) for the fallback
         HIPCHK(hipMemcpyAsync(h->d_zp, h->d_x, (size_t)nrhs * (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    const dim3 grid((unsigned)(8 * ((nrhs + 7) / 8) * sh.G));
+#ifdef ELPH_WG_PERSISTENT
+    // persistent teams: per XCD (32 CUs, one workgroup each) floor(32 / G) teams at most
+    R.teams_per_xcd = std::max(1, std::min((nrhs + 7) / 8, 32 / sh.G));
+#else
+    R.teams_per_xcd = (nrhs + 7) / 8;                      // one solve per workgroup: every right-hand side has its team in the grid
+#endif
+    const dim3 grid((unsigned)(8 * R.teams_per_xcd * sh.G));
     hipError_t e = hipSuccess;
     switch (h->npl) {
         case 1: e = wg::launch_npl<1>(h, sh, grid, B, m, R); break;
@@ -1053,6 +1090,7 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     R.x0_zero = 0;
     HIPCHK(hipMemsetAsync(base, 0, h->res_cap, h->stream));   // boundary granules of this rank's workgroups: tags restart at 2
     h->wg_epoch = 0;
+    R.teams_per_xcd = 1;
     const dim3 grid((unsigned)sh.G);                       // one right-hand side: its G workgroups, round-robin over the XCDs
     hipError_t e = hipSuccess;
     switch (h->npl) {

@@ -592,6 +592,7 @@ int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_ite
     R.timeout_ticks = (long long)(eto ? atoll(eto) : 2000) * 100000LL;
     R.fixed_iters = fixed_iters;
     R.x0_zero = 0;
+    R.teams_per_xcd = 1;
     wg::PcgCtl Pc;
     Pc.flags = R.slots + n_slots;
     Pc.Wf = h->mf[0][0].W; Pc.Wi = h->mf[0][1].W;
