@@ -453,6 +453,12 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
         const double2 *src = reinterpret_cast<const double2 *>(W + (size_t)mt0 * NT * WAVE);
         double2 *dst = reinterpret_cast<double2 *>(Wl);
         for (int i = threadIdx.x; i < MG * NT * WAVE / 2; i += CW * WAVE) dst[i] = src[i];
+        // (the fold table of this right-hand side's chain rides behind the panel: the epilogue reads it from LDS, not through L2)
+        if (!INV && X.fold) {
+            const double2 *fs = reinterpret_cast<const double2 *>(X.fold) + (size_t)(rhs % X.fnch) * H;
+            double2 *fd = reinterpret_cast<double2 *>(Wl + (size_t)MG * NT * WAVE);
+            for (int i = threadIdx.x; i < H; i += CW * WAVE) fd[i] = fs[i];
+        }
     }
     double alpha = 0.0, acc = 0.0;
     if (!INV && XR) {
@@ -532,7 +538,7 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
             }
         }
         double facc = 0.0;
-        const double *fch = X.fold ? X.fold + 2 * (size_t)(rhs % X.fnch) * H : nullptr;
+        const double *fch = Wl + (size_t)MG * NT * WAVE;          // (LDS copy of this chain's fold table, staged with the panel)
         double2 *o = reinterpret_cast<double2 *>(out) + (size_t)rhs * H * N;
 #pragma unroll
         for (int g = 0; g < MG; ++g) {
@@ -547,8 +553,8 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
                     double2 n0 = make_double2(ax + tx, ay + ty);                                   // nu_k = A + t
                     double2 n1 = make_double2(ax - tx, -(ay - ty));                                // nu_kc = conj(A - t)
                     if (X.fold) {
-                        const double *fk = fch + 2 * (size_t)k, *fc = fch + 2 * (size_t)(H - 1 - k);
-                        const double s0 = fk[0], w0 = fk[1], s1 = fc[0], w1 = fc[1];
+                        const double2 f0 = reinterpret_cast<const double2 *>(fch)[k], f1 = reinterpret_cast<const double2 *>(fch)[H - 1 - k];
+                        const double s0 = f0.x, w0 = f0.y, s1 = f1.x, w1 = f1.y;
                         facc += w0 * (n0.x * n0.x + n0.y * n0.y);
                         if (H - 1 - k != k) facc += w1 * (n1.x * n1.x + n1.y * n1.y);
                         n0.x *= s0; n0.y *= s0; n1.x *= s1; n1.y *= s1;
@@ -654,16 +660,17 @@ int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, co
     // streaming form: W panel of a row group in LDS.  Up to 64 KB is the default dynamic-LDS limit; the long time axes
     // (L = 256 ... 400: 80 ... 128 KB of the CU's 160 KB) ask for it explicitly, once per kernel instantiation
     const size_t panel = (size_t)MG * T.nt * WAVE * sizeof(double);
+    const size_t shm_s = panel + (X.fold ? (size_t)(L / 2) * 2 * sizeof(double) : 0);      // + the fold table of the chain (forward, XrFuse)
     const char *es = getenv("ELPH_DFT_STREAM");
     if (panel <= 144 * 1024 && !(es && atoi(es) == 0)) {
         hipError_t attr_rc = hipSuccess;
 #define R2S_LAUNCH(NTV, RZV) do {                                                                                              \
             auto kfn = k_dft_mfma_r2s<NTV, INV, XR, RZV>;                                                                       \
-            if (panel > 64 * 1024) {                                                                                            \
+            if (shm_s > 64 * 1024) {                                                                                            \
                 static bool raised = false;                                                                                     \
-                if (!raised) { attr_rc = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel); raised = (attr_rc == hipSuccess); } \
+                if (!raised) { attr_rc = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(panel + 8192)); raised = (attr_rc == hipSuccess); } \
             }                                                                                                                   \
-            if (attr_rc == hipSuccess) hipLaunchKernelGGL(kfn, grid, block, panel, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
+            if (attr_rc == hipSuccess) hipLaunchKernelGGL(kfn, grid, block, shm_s, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
         } while (0)
 #define R2S_CASE(NTV) case NTV: if (INV && rz_part) R2S_LAUNCH(NTV, INV); else R2S_LAUNCH(NTV, false); break;
         switch (T.nt) {

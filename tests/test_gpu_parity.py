@@ -447,12 +447,25 @@ def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
     m.close()
 
 
-def test_resident_preconditioned_cg_vs_streaming_and_oracle(oracle, monkeypatch):
+@pytest.mark.parametrize("ltau", [160, 80])
+def test_resident_preconditioned_cg_vs_streaming_and_oracle(oracle, monkeypatch, ltau):
     """pcg_wg.hip (ELPH_PCG_WG=1: the whole KPM-preconditioned solve of 1..8 right-hand sides in one launch — CG workgroups, helper
     workgroups for the two tau-transforms and the Chebyshev recursions, flags through L2 instead of kernel boundaries) against the
-    five-kernel streaming form and the oracle on config C: same iteration counts, same residual history, solutions to 1e-10."""
-    from elphdynamics_amd import configs, models, preconditioners as pc
-    m = configs.make_model("C", tol=1e-5)
+    five-kernel streaming form and the oracle on config C (160 time slices: 40 reduction tiles per transform tile) and on the same
+    lattice with 80 slices (the 20-tile instantiation; 5 CG workgroups, helpers with two frequencies per wave pair idle in part):
+    same iteration counts, same residual history, solutions to 1e-10."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    from elphdynamics_amd import lattice as lat
+    if ltau == 160:
+        m = configs.make_model("C", tol=1e-5)
+    else:
+        m = models.HolsteinModel(lat.Lattice(1, 16, 16, 1), 8.0, 0.1, tol=1e-5, maxiter=10000)
+        m.assign_t_(1.0, 1, 1, (1, 0, 0)); m.assign_t_(1.0, 1, 1, (0, 1, 0))
+        m.assign_omega_(1.0); m.assign_lambda_(1.0); m.assign_mu_(0.0)
+        m.initialize_model_()
+        m.x[:] = synth.phonon_field(m.Nph, m.Ltau, 8.0, 0.1, omega=1.0, lam=1.0, seed=21)
+        models.update_model_(m)
+        assert m.Ltau == 80
     om = _oracle_model(oracle, m)
     P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
     oP = oracle.make_kpm(om, n=20, buf=0.05, c1=1.0, c2=1.0)
