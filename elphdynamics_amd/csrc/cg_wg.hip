@@ -32,25 +32,34 @@
 
 namespace wg {
 
-// SQ: the DPP form for Holstein on the 16 x 16 square lattice in the reference's colouring (NPL = 4, no LDS slabs; uniform hopping
-// in two scalars, disordered hopping in per-site registers); otherwise the lane-program form
+// SQ: the DPP form for the 16 x 16 square lattice in the reference's colouring (NPL = 4, no LDS slabs; Holstein: uniform hopping in
+// two scalars, disordered hopping in per-site registers; SSH: a table set per time slice, SqSsh); otherwise the lane-program form
+//     FORM 0: lane program, 1: the square-lattice DPP form (SQ), 2: the honeycomb DPP form (HC: 12 x 12 cells, six sites per lane of
+//     which a quarter are mirror lanes, uniform hopping; cg_wg_dev.h)
 // SHARD: this launch is one rank's part of a solve over several GPUs (T = 1, lane-program form)
 // X0Z: the initial guess is known to be zero (the library zeroed it for this solve): x0 is not read
-template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD, bool X0Z = false>
+template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
-    static_assert(!SHARD || (T == 1 && !SQ), "sharded solves: one slice per wave, lane-program form");
+    constexpr bool SQ = FORM == 1, HC = FORM == 2, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    static_assert(!SHARD || (T == 1 && !REGX), "sharded solves: one slice per wave, lane-program form");
+    static_assert(!HC || (NPL == HC_NPL && UNI && !SSH && T <= 2), "honeycomb DPP form: six sites per lane, uniform hopping");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    static_assert(!SQ || (NPL == 4 && !SSH), "DPP form: Holstein on the 16 x 16 square lattice, four sites per lane");
+    static_assert(!SQ || NPL == 4, "DPP form: the 16 x 16 square lattice, four sites per lane");
+    static_assert(!(SQ && SSH) || (!UNI && T <= 2), "DPP form with bond phonons: a table set per slice, at most two slices per wave");
     static_assert(!SQ || UNI || T <= 2, "DPP form with per-site hopping: 32 registers of (cosh, sinh) leave room for two slices");
     constexpr int NE = MC * ((NPL + 1) / 2);
     constexpr int HS = NPL * WAVE, SL = slab_len<NPL>();
-    constexpr int NSLAB = SQ ? 0 : T + 1;              // LDS slabs per wave (lane-program form)
+    constexpr int NSLAB = REGX ? 0 : T + 1;            // LDS slabs per wave (lane-program form)
     constexpr int NT = SSH ? T + 1 : 1;                // hopping-table sets (SSH: one per slice t0 .. t0+T)
     constexpr int NEJ = SSH ? 1 : T + 1;               // exp(-dtau V) slices (SSH: exp(dtau mu), per site only)
     // where the loop-invariant and the update-only vectors live.  4 slices per wave (DPP form, throughput shape): exp(-dtau V) moves
     // to LDS (read twice per iteration; 40 registers) and x stays in registers instead (LDS is full); otherwise E in registers
     // (0.35 us per iteration faster at 2 slices per wave), x and r in LDS
-    constexpr bool E_LDS = SQ && T >= 4, X_REG = SQ && T >= 4;
+    // bond phonons, DPP form, 2 slices per wave: the table set of slice t0 in LDS (24 doubles per lane), x in registers
+    constexpr bool S_LDS = SQ && SSH && T == 2;
+    // honeycomb DPP form, 2 slices per wave: exp(-dtau V) in LDS too (six sites per lane: 36 registers)
+    constexpr bool E_LDS = (SQ && T >= 4) || (HC && T >= 2), X_REG = (SQ && T >= 4) || S_LDS;
+    constexpr int NSREG = (SQ && SSH) ? (S_LDS ? T : T + 1) : 1;
     // ONE: the single-meeting iteration (see the loop) — for a shard too: its meeting is two-level (workgroups of the rank, then ranks)
     // and carries the ghost rows of z
 #ifdef ELPH_SHARD_TWO_MEETINGS
@@ -93,7 +102,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     double *xl = rall + (size_t)W * T * HS + (size_t)wv * T * HS;      // [W][T][HS]: this wave's slices of x (unless X_REG)
     double *eall = rall + (size_t)(X_REG ? 1 : 2) * W * T * HS;        // [W][T+1][HS]: exp(-dtau V) of slices t0 .. t0+T (E_LDS)
     double *el = eall + (size_t)wv * (T + 1) * HS;
-    double *partA = eall + (E_LDS ? (size_t)W * (T + 1) * HS : 0), *partB = partA + 8, *bc = partA + 16;   // bc: p.z total, r.r total, 0.0 = a poller gave up
+    double *partA = eall + (E_LDS ? (size_t)W * (T + 1) * HS : (S_LDS ? (size_t)W * SQ_TABS * WAVE : 0)), *partB = partA + 8, *bc = partA + 16;   // bc: p.z total, r.r total, 0.0 = a poller gave up
     // single-meeting form: part[4][8] wave partials of p.z, r.z, z.z, r.r | tot[8]: the four totals, [4] the direct r.r of the fallback
     // meeting, [5] 0.0 = a poller gave up | partF[8] | rhalo[2][HS]: the boundary slices of r of the two neighbouring workgroups (kept in
     // LDS rather than in registers: the 4-slice shape has none to spare)
@@ -114,9 +123,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     bool live[NPL], own[NPL];                          // own: the site enters the inner products (a shard counts its own rows only)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = SQ ? sq_patch_site(lane, q) : lane + q * WAVE;
-        live[q] = SQ || s < N;                            // (DPP form: N = 256 fills every register of every lane — no selects in the sums)
-        own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : live[q];
+        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : lane + q * WAVE);
+        live[q] = REGX || s < N;                          // (DPP forms: every register of every lane holds a site — no selects in the sums)
+        own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : (HC ? hc_real(lane) : live[q]);     // (honeycomb: mirror lanes carry copies)
         sc[q] = live[q] ? s : N - 1;
     }
     double *xg = B.x + (size_t)rhs * ndim, *rg = B.r + (size_t)rhs * ndim;
@@ -153,7 +162,51 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     unsigned ij[NE];
     Tab<NE, UNI> tab[NT];
     SqCtx<UNI> X;
-    if constexpr (SQ) {
+    SqSsh<NSREG, S_LDS> XS;
+    HcCtx XH;
+    // LDS slot of the value a lane READS when it makes p from the residual (honeycomb: a mirror lane reads the real lane's)
+    const int ll = HC ? hc_src_lane(lane) : lane;
+    if constexpr (HC) {
+        XH.th = m.s_uni / m.c_uni; XH.k3 = m.c_uni * m.c_uni * m.c_uni;
+        XH.up = (lane + 16) & (WAVE - 1); XH.dn = (lane + 48) & (WAVE - 1);
+    } else if constexpr (SQ && SSH) {
+        // table set j = the hopping of slice t0 + j, gathered from the per-(tau, bond) tables through the site -> bond map of each colour
+        ssh_chain_select(m, rhs);
+        XS.yx = sq_patch_ycross(lane);
+        XS.l0 = eall + (size_t)wv * SQ_TABS * WAVE + lane;
+#pragma unroll
+        for (int j = 0; j <= T; ++j) {
+            const double *cj = m.c + (size_t)wrap(t0 + j) * m.cs_tau_stride, *sj = m.s + (size_t)wrap(t0 + j) * m.cs_tau_stride;
+            SqTabS tb;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int b0 = m.sq_bond[0 * N + sc[2 * pr]], b2 = m.sq_bond[2 * N + sc[pr]];
+                tb.ci[0][pr] = cj[b0]; tb.si[0][pr] = sj[b0];
+                tb.ci[1][pr] = cj[b2]; tb.si[1][pr] = sj[b2];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b1 = m.sq_bond[1 * N + sc[k]], b3 = m.sq_bond[3 * N + sc[k]];
+                tb.cx[0][k] = cj[b1]; tb.sx[0][k] = sj[b1];
+                tb.cx[1][k] = cj[b3]; tb.sx[1][k] = sj[b3];
+            }
+            if (S_LDS && j == 0) {
+                double *d = eall + (size_t)wv * SQ_TABS * WAVE + lane;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    d[(0 + pr) * WAVE] = tb.ci[0][pr]; d[(2 + pr) * WAVE] = tb.si[0][pr];
+                    d[(4 + pr) * WAVE] = tb.ci[1][pr]; d[(6 + pr) * WAVE] = tb.si[1][pr];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d[(8 + k) * WAVE] = tb.cx[0][k]; d[(12 + k) * WAVE] = tb.sx[0][k];
+                    d[(16 + k) * WAVE] = tb.cx[1][k]; d[(20 + k) * WAVE] = tb.sx[1][k];
+                }
+            } else {
+                XS.t[S_LDS ? (j > 0 ? j - 1 : 0) : (j < NSREG ? j : 0)] = tb;
+            }
+        }
+    } else if constexpr (SQ) {
         X.yx = sq_patch_ycross(lane);
         if constexpr (UNI) {
             X.c[0][0] = m.c_uni; X.s[0][0] = m.s_uni / m.c_uni; X.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
@@ -247,12 +300,37 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
         // (w and z share registers: z(t0+j) overwrites w(t0+j) once the reverse sweep of w(t0+j+1) has been taken)
         double (&w)[T + 1][NPL] = zw;
-        if constexpr (SQ) {
+        if constexpr (HC) {
+#pragma unroll
+            for (int k = 0; k <= T; ++k)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) w[k][q] = EXPV(k, q) * p[k][q];
+            hc_sweepN<T + 1, false>(w, XH);
+#pragma unroll
+            for (int k = 0; k <= T; ++k) {
+                const double sg = sgn(wrap(t0 + k)) * XH.k3;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) w[k][q] = p[k + 1][q] - sg * w[k][q];
+            }
+            double gq[T][NPL];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) gq[i][q] = w[i + 1][q];
+            hc_sweepN<T, true>(gq, XH);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const double sg = sgn(wrap(t0 + i + 1)) * XH.k3;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) w[i][q] = w[i][q] - sg * (EXPV(i + 1, q) * gq[i][q]);            // z(t0+i)
+            }
+        } else if constexpr (SQ) {
 #pragma unroll
             for (int k = 0; k <= T; ++k)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[k][q] = EXPV(k, q) * p[k][q];
-            sq_sweepN<T + 1, false, UNI>(w, X);
+            if constexpr (SSH) sq_sweepS<T + 1, false, 0>(w, XS);
+            else sq_sweepN<T + 1, false, UNI>(w, X);
 #pragma unroll
             for (int k = 0; k <= T; ++k) {
                 const double sg = UNI ? sgn(wrap(t0 + k)) * X.k4 : sgn(wrap(t0 + k));
@@ -267,7 +345,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) gq[i][q] = w[j0 + i + 1][q];
-                sq_sweepN<RB, true, UNI>(gq, X);
+                if constexpr (SSH) sq_sweepS<RB, true, 1>(gq, XS);          // (RB = T: one batch, the sets of t0+1 ..)
+                else sq_sweepN<RB, true, UNI>(gq, X);
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const double sg = UNI ? sgn(wrap(t0 + j0 + i + 1)) * X.k4 : sgn(wrap(t0 + j0 + i + 1));
@@ -754,8 +833,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int j = 0; j < T; ++j)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
-                    const int s2 = SQ ? sq_patch_site(lane2, q) : lane2 + q * WAVE;
-                    if (SQ || s2 < N) {
+                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : lane2 + q * WAVE);
+                    if (HC ? hc_real(lane2) : (SQ || s2 < N)) {
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
                         if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HS + lane + q * WAVE];
@@ -783,8 +862,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             const double *sr = rall + ((size_t)((wv < W - 1) ? wv + 1 : 0) * T + 0) * HS;          // first slice of the wave above
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const double hl = lx ? (ONE ? rhalo[lane + q * WAVE] : hx[q]) : sl[lane + q * WAVE];
-                const double hr = rx ? (ONE ? rhalo[HS + lane + q * WAVE] : hx[q]) : sr[lane + q * WAVE];
+                const double hl = lx ? (ONE ? rhalo[ll + q * WAVE] : hx[q]) : sl[ll + q * WAVE];
+                const double hr = rx ? (ONE ? rhalo[HS + ll + q * WAVE] : hx[q]) : sr[ll + q * WAVE];
                 p[0][q] = hl + beta * p[0][q];
                 p[T + 1][q] = hr + beta * p[T + 1][q];
             }
@@ -792,7 +871,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
         for (int j = 0; j < T; ++j)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) p[j + 1][q] = rl[j * HS + lane + q * WAVE] + beta * p[j + 1][q];
+            for (int q = 0; q < NPL; ++q) p[j + 1][q] = rl[j * HS + ll + q * WAVE] + beta * p[j + 1][q];
         STAMP(8);
     }
 #ifdef ELPH_WG_PERSISTENT
@@ -807,12 +886,12 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 // host side
 // ------------------------------------------------------------------------------------------
 
-struct Shape { int T, W, G; size_t shm; bool sq; };
+struct Shape { int T, W, G; size_t shm; bool sq, hc; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6)
 
 // DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square)
 static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
     const char *e = getenv("ELPH_WG_NO_DPP");
-    return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 2 && h->N == 256 && m.sq_bond && !(e && e[0] == '1');
+    return h->sq_P == 2 && h->N == 256 && m.sq_bond && !(e && e[0] == '1');
 }
 
 // T slices per wave: what the register file takes at two waves per SIMD — lane-program form 2 for site phonons with <= 4 sites
@@ -820,31 +899,38 @@ static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
 // 2-slice shape cannot hold in one round (6.8 us per iteration, but 48 right-hand sides per round: 14 vs 7.3 M mat-vecs/s);
 // W = the largest divisor of Ltau / T that is <= 8 waves; G = workgroups per right-hand side (<= 32: the 2G record granules of
 // a meeting are polled by one wave instruction)
+// honeycomb DPP form: Holstein with uniform hopping on 12 x 12 cells in the reference's colouring (detect_honeycomb12)
+static bool hc_form(const elph_handle_s *h, const ModelDev &m) {
+    const char *e = getenv("ELPH_WG_NO_DPP");
+    return h->kind == ELPH_MODEL_HOLSTEIN && h->hc12 && m.uniform && !(e && e[0] == '1');
+}
+
 static int largest_divisor_le8(int n, int cap = 8) { for (int w = std::min(cap, n); w >= 1; --w) if (n % w == 0) return w; return 1; }
 
 static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, int nrhs, Shape *out) {
     const int L = (int)h->L;
-    const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m);
+    const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m);
+    const int npl = hc ? HC_NPL : h->npl;
     const int cand[3] = {4, 2, 1};
     for (int T : cand) {
         if (forceT && T != forceT) continue;
         if (T == 4) {
-            if (!sq || !m.uniform) continue;
+            if (!sq || !m.uniform || ssh) continue;
             if (forceT != 4) {                           // only when 2 slices per wave would need a second round: 8 XCDs x (32 CUs / G2) teams
                 if (L % 2) continue;
                 const int G2 = (L / 2) / largest_divisor_le8(L / 2);
                 if (G2 > 32 || nrhs <= 8 * (32 / G2)) continue;
             }
         }
-        if (T == 2 && sq && forceT != 2) {
+        if (T == 2 && (sq || hc) && forceT != 2) {
             // DPP form: a batch that one round of 1 slice per wave holds (config C: up to 8 right-hand sides, one team of 20 workgroups per
             // XCD) runs that shape — with ONE meeting per iteration the shorter mat-vec wins over the larger team: 3.47 against 4.00 us
             // per iteration for one right-hand side (round 2, two meetings: the other way round)
             const int G1 = L / largest_divisor_le8(L);
             if (G1 <= 32 && L / G1 >= 2 && nrhs <= 8 * (32 / G1)) continue;
         }
-        if (T == 2 && !sq && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
-        if (T == 2 && !sq && (h->npl == 5 || ssh) && forceT != 2) {
+        if (T == 2 && !sq && !hc && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
+        if (T == 2 && !sq && !hc && (h->npl == 5 || ssh) && forceT != 2) {
             // 5 sites per lane (honeycomb L = 12) and bond phonons (three table sets per wave: 41 registers spill): 2 slices per wave are
             // slower per iteration (D: 10.0 vs 9.3 us; E: 12.9 vs 9.5 us) but hold more right-hand sides per round (D: 24 instead
             // of 16; E: 24 instead of 8) — taken once a batch exceeds the round of 1 slice per wave
@@ -860,51 +946,55 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         const int G = Wt / W;
         if (G > 32) continue;
         if (G > 1 && W < 2) continue;                    // (a wave polls at most ONE neighbouring workgroup's boundary slice)
-        const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
-        const size_t shm = ((size_t)W * (sq ? 0 : T + 1) * SL + (size_t)((sq && T >= 4) ? 1 : 2) * W * T * HS +
-                            ((sq && T >= 4) ? (size_t)W * (T + 1) * HS : 0) + 48 + 4 * HS) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS]
+        const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * WAVE;
+        const bool s_lds = sq && ssh && T == 2;            // (the kernel's S_LDS: table set of slice t0 in LDS, x in registers)
+        const bool e_lds = (sq && T >= 4) || (hc && T >= 2);
+        const size_t shm = ((size_t)W * ((sq || hc) ? 0 : T + 1) * SL + (size_t)(((sq && T >= 4) || s_lds) ? 1 : 2) * W * T * HS +
+                            (e_lds ? (size_t)W * (T + 1) * HS : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
+                            48 + 4 * HS) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS]
         if (shm > 160 * 1024) continue;
-        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq;
+        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->npl = npl;
         return true;
     }
     return false;
 }
 
-template <int NPL, int T, bool SSH, bool UNI, bool SQ, bool SHARD = false, bool X0Z = false>
+template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD = false, bool X0Z = false>
 static hipError_t launch_k(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R,
                            const ShardCtl &Sh = ShardCtl()) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD, X0Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
+    hipError_t e = hipFuncSetAttribute((const void *)k_cg_wg<NPL, T, SSH, UNI, FORM, SHARD, X0Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI, SQ, SHARD, X0Z>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R, Sh);
+    hipLaunchKernelGGL((k_cg_wg<NPL, T, SSH, UNI, FORM, SHARD, X0Z>), grid, dim3(sh.W * WAVE), sh.shm, h->stream, B, m, R, Sh);
     return hipGetLastError();
 }
 
 template <int NPL>
 static hipError_t launch_shard_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R,
                                    const ShardCtl &Sh) {
-    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, false, true>(h, sh, grid, B, m, R, Sh);
-    return m.uniform ? launch_k<NPL, 1, false, true, false, true>(h, sh, grid, B, m, R, Sh)
-                     : launch_k<NPL, 1, false, false, false, true>(h, sh, grid, B, m, R, Sh);
+    if (h->kind == ELPH_MODEL_SSH) return launch_k<NPL, 1, true, false, 0, true>(h, sh, grid, B, m, R, Sh);
+    return m.uniform ? launch_k<NPL, 1, false, true, 0, true>(h, sh, grid, B, m, R, Sh)
+                     : launch_k<NPL, 1, false, false, 0, true>(h, sh, grid, B, m, R, Sh);
 }
 
 template <int NPL>
 static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R) {
     if constexpr (NPL == 4) {
         if (sh.sq) {
-            if (!m.uniform) return (sh.T == 2) ? launch_k<4, 2, false, false, true>(h, sh, grid, B, m, R) : launch_k<4, 1, false, false, true>(h, sh, grid, B, m, R);
-            if (sh.T == 4) return R.x0_zero ? launch_k<4, 4, false, true, true, false, true>(h, sh, grid, B, m, R) : launch_k<4, 4, false, true, true>(h, sh, grid, B, m, R);
-            if (sh.T == 2) return launch_k<4, 2, false, true, true>(h, sh, grid, B, m, R);
-            return launch_k<4, 1, false, true, true>(h, sh, grid, B, m, R);
+            if (h->kind == ELPH_MODEL_SSH) return (sh.T == 2) ? launch_k<4, 2, true, false, 1>(h, sh, grid, B, m, R) : launch_k<4, 1, true, false, 1>(h, sh, grid, B, m, R);
+            if (!m.uniform) return (sh.T == 2) ? launch_k<4, 2, false, false, 1>(h, sh, grid, B, m, R) : launch_k<4, 1, false, false, 1>(h, sh, grid, B, m, R);
+            if (sh.T == 4) return R.x0_zero ? launch_k<4, 4, false, true, 1, false, true>(h, sh, grid, B, m, R) : launch_k<4, 4, false, true, 1>(h, sh, grid, B, m, R);
+            if (sh.T == 2) return launch_k<4, 2, false, true, 1>(h, sh, grid, B, m, R);
+            return launch_k<4, 1, false, true, 1>(h, sh, grid, B, m, R);
         }
     }
     if (h->kind == ELPH_MODEL_SSH) {
-        if constexpr (NPL <= 4) { if (sh.T == 2) return launch_k<NPL, 2, true, false, false>(h, sh, grid, B, m, R); }
-        return launch_k<NPL, 1, true, false, false>(h, sh, grid, B, m, R);
+        if constexpr (NPL <= 4) { if (sh.T == 2) return launch_k<NPL, 2, true, false, 0>(h, sh, grid, B, m, R); }
+        return launch_k<NPL, 1, true, false, 0>(h, sh, grid, B, m, R);
     }
     if constexpr (NPL <= 5) {
-        if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false, false>(h, sh, grid, B, m, R);
+        if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true, 0>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false, 0>(h, sh, grid, B, m, R);
     }
-    return m.uniform ? launch_k<NPL, 1, false, true, false>(h, sh, grid, B, m, R) : launch_k<NPL, 1, false, false, false>(h, sh, grid, B, m, R);
+    return m.uniform ? launch_k<NPL, 1, false, true, 0>(h, sh, grid, B, m, R) : launch_k<NPL, 1, false, false, 0>(h, sh, grid, B, m, R);
 }
 
 }  // namespace wg
@@ -947,8 +1037,9 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // profiles/r02/time_forms.log; us per iteration of the batch):
     //   resident  = rounds x (2.0 + 0.12 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
     //               rounds x (2.66 + 0.01 G + 0.62 T)   DPP form         (single-meeting iteration, round 3: 3.5 / 4.0 / 5.2 us at 1 / 2 / 4 slices)
+    //               rounds x (0.9 + 3.04 T)   DPP form with bond phonons (E: 3.9 / 7.0 us);   rounds x (2.1 + 1.7 T)   honeycomb DPP form (D: 3.8 / 5.5 us)
     //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
-    // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 5.5 M against 4.0 M; E: 4.4 M against 3.2 M);
+    // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 8.5 M against 4.2 M; E: 6.8 M against 3.2 M);
     // the rule still decides for other lattices and time axes.  A deterministic rule
     // (never a timing at run time): which form runs decides the last bits of a solution.
     // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
@@ -957,13 +1048,14 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
-            const double t_res = rounds * (sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
+            const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.9 / 7.0 us at 1 / 2 slices per wave)
+            const double t_res = rounds * (ssh_sq ? 0.9 + 3.04 * sh.T : sh.hc ? 2.1 + 1.7 * sh.T : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
                                                  : 2.0 + 0.12 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
         }
     }
-    const size_t HS = (size_t)h->npl * WAVE;
+    const size_t HS = (size_t)sh.npl * WAVE;
     const size_t n_slots = (size_t)nrhs * wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
     // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
@@ -1005,7 +1097,9 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
 #endif
     const dim3 grid((unsigned)(8 * R.teams_per_xcd * sh.G));
     hipError_t e = hipSuccess;
-    switch (h->npl) {
+    if (sh.hc) {
+        e = (sh.T == 2) ? wg::launch_k<wg::HC_NPL, 2, false, true, 2>(h, sh, grid, B, m, R) : wg::launch_k<wg::HC_NPL, 1, false, true, 2>(h, sh, grid, B, m, R);
+    } else switch (h->npl) {
         case 1: e = wg::launch_npl<1>(h, sh, grid, B, m, R); break;
         case 2: e = wg::launch_npl<2>(h, sh, grid, B, m, R); break;
         case 3: e = wg::launch_npl<3>(h, sh, grid, B, m, R); break;
@@ -1056,7 +1150,7 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
         const int rc = elph_shard_shape(h->L, Sh.P, &W, &G, nullptr, nullptr);
         if (rc) return rc;
         const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
-        sh.T = 1; sh.W = W; sh.G = G; sh.sq = false;
+        sh.T = 1; sh.W = W; sh.G = G; sh.sq = false; sh.hc = false; sh.npl = h->npl;
         sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 48 + 4 * HS) * sizeof(double);     // + partials, totals, rhalo[2][HS], zhalo[2][HS]
     }
     const size_t HS = (size_t)h->npl * WAVE;

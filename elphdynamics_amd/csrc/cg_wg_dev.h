@@ -103,10 +103,12 @@ __device__ __forceinline__ void sweepN(double *buf, const unsigned (&ij)[MC * ((
 // who folds it into the constant of the fma that consumes the swept vector.  Same operator in real arithmetic; against the
 // reference's  c y_i + s y_j  it differs by rounding only (a few ulp per sweep; parity tolerances in tests/ unchanged).
 // f64 instructions are what the two waves of a SIMD compete for in this kernel (profiles/r02/wg_phase_stamps.log).
-// (SSH — one table set per time slice — was built and measured in this form too: 64 more registers per slice, one slice per
-// wave, 9.4 us per iteration against 9.2 us of the lane-program form, whose time the team of 20 workgroups sets; not kept.)
+// (SSH — one table set per time slice: SqSsh below.  Round 2 built it with a (cosh, sinh) per site and colour, one slice per wave,
+// under the two-meeting iteration whose team of 20 workgroups set the time — no gain then.)
 template <bool UNI>
 struct SqCtx {
+    static constexpr int ARITH = UNI ? 1 : 2;                 // vector-ALU instructions per site update
+    static constexpr bool GROUPS = true;                      // the y-odd colour is laid out with scheduling groups (see sq_colour)
     double c[UNI ? 1 : 4][UNI ? 1 : 4], s[UNI ? 1 : 4][UNI ? 1 : 4];   // UNI: s[0][0] = th, c[0][0] unused
     double k4;                                                // factor the caller applies to a swept vector (1 unless UNI)
     int yx;                                                   // partner lane of the crossing half of the y-odd colour: (l + 15) & 63 for odd Y, (l + 49) & 63 for even Y
@@ -115,19 +117,61 @@ struct SqCtx {
         if constexpr (UNI) return v + s[0][0] * t;
         else return c[UNI ? 0 : col][UNI ? 0 : k] * v + s[UNI ? 0 : col][UNI ? 0 : k] * t;
     }
+    // (slab n of the sweep: every slab has the same hopping)
+    __device__ __forceinline__ double up(int n, int col, int k, double v, double t) const { return upd(col, k, v, t); }
 };
 
-// One colour on CNT (1 or 2) slabs, as one scheduling region: the cross-lane moves of the slabs first, then their arithmetic.
-// Left to itself the scheduler (256 registers, none to spare) funnels every ds_bpermute through ONE temporary and waits for
-// each; with every slab's moves hoisted to the front it spills instead.
-template <int CNT, int COL, bool UNI>
-__device__ __forceinline__ void sq_colour(double (*v)[4], const SqCtx<UNI> &X) {
-    constexpr int DS = 0x080, VALU = 0x002, ARITH = UNI ? 1 : 2;          // ARITH: vector-ALU instructions per site update
+// Bond phonons (SSH) on the same lattice: EVERY time slice has its own hopping, a wave that owns T slices sweeps with T + 1 table
+// sets.  A set, as a lane keeps it: ONE (cosh, sinh) per register pair for the two colours that pair registers of the lane, one per
+// register for the two crossing colours — 24 doubles (a (cosh, sinh) per site and colour would be 32).  Two sets fit the register
+// file next to the Krylov vectors; at 2 slices per wave the set of slice t0 (used by the forward sweep only; the sets of t0+1, t0+2
+// serve the forward and the reverse sweep) lives in LDS, [24][64] lane-linear per wave.
+struct SqTabS {
+    double ci[2][2], si[2][2];     // [x-even | y-even][pair]: x-even pairs registers (0,1), (2,3); y-even pairs (0,2), (1,3)
+    double cx[2][4], sx[2][4];     // [x-odd | y-odd][register]
+};
+constexpr int SQ_TABS = 24;        // doubles per lane and set; LDS order: ci[0], si[0], ci[1], si[1], cx[0], sx[0], cx[1], sx[1]
+
+template <int NREG, bool LDS0>
+struct SqSsh {
+    SqTabS t[NREG];                // LDS0: t[k] = set k + 1 (set 0 in LDS); otherwise t[k] = set k
+    const double *l0;              // LDS0: this lane's column of set 0 (entry e at l0[e * 64])
+    int yx;
+    __device__ __forceinline__ double up_set(int set, int col, int k, double v, double tv) const {
+        double c, s;
+        if (LDS0 && set == 0) {
+            const int e = (col == 0) ? (k >> 1) : (col == 2) ? 4 + (k & 1) : (col == 1) ? 8 + k : 16 + k;
+            c = l0[e * WAVE]; s = l0[(e + ((col & 1) ? 4 : 2)) * WAVE];
+        } else {
+            const SqTabS &T = t[LDS0 ? set - 1 : set];
+            if (col == 0)      { c = T.ci[0][k >> 1]; s = T.si[0][k >> 1]; }
+            else if (col == 2) { c = T.ci[1][k & 1];  s = T.si[1][k & 1]; }
+            else               { c = T.cx[col >> 1][k]; s = T.sx[col >> 1][k]; }
+        }
+        return c * v + s * tv;
+    }
+};
+// slab n of a sweep uses table set SOFF + n (forward sweep of w(t0 .. t0+T): 0; reverse sweep of w(t0+1 ..): 1)
+template <int NREG, bool LDS0, int SOFF>
+struct SqSshView {
+    static constexpr int ARITH = 2;
+    static constexpr bool GROUPS = false;
+    const SqSsh<NREG, LDS0> &X;
+    int yx;
+    __device__ __forceinline__ double up(int n, int col, int k, double v, double t) const { return X.up_set(SOFF + n, col, k, v, t); }
+};
+
+// One colour on CNT (1 or 2) slabs (slabs N0, N0 + 1 of the sweep), as one scheduling region: the cross-lane moves of the slabs
+// first, then their arithmetic.  Left to itself the scheduler (256 registers, none to spare) funnels every ds_bpermute through ONE
+// temporary and waits for each; with every slab's moves hoisted to the front it spills instead.
+template <int CNT, int COL, int N0, class CTX>
+__device__ __forceinline__ void sq_colour(double (*v)[4], const CTX &X) {
+    constexpr int DS = 0x080, VALU = 0x002, ARITH = CTX::ARITH;
     if constexpr (COL == 0) {                                // x even: (0,1), (2,3) of the lane itself
 #pragma unroll
         for (int n = 0; n < CNT; ++n) {
-            const double n0 = X.upd(0, 0, v[n][0], v[n][1]), n1 = X.upd(0, 1, v[n][1], v[n][0]);
-            const double n2 = X.upd(0, 2, v[n][2], v[n][3]), n3 = X.upd(0, 3, v[n][3], v[n][2]);
+            const double n0 = X.up(N0 + n, 0, 0, v[n][0], v[n][1]), n1 = X.up(N0 + n, 0, 1, v[n][1], v[n][0]);
+            const double n2 = X.up(N0 + n, 0, 2, v[n][2], v[n][3]), n3 = X.up(N0 + n, 0, 3, v[n][3], v[n][2]);
             v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
         }
     } else if constexpr (COL == 1) {                         // x odd: q odd <-> q - 1 of the lane 2 up, q even <-> q + 1 of the lane 2 down
@@ -135,14 +179,14 @@ __device__ __forceinline__ void sq_colour(double (*v)[4], const SqCtx<UNI> &X) {
         for (int n = 0; n < CNT; ++n) {
             const double t1 = dpp_f64<0x12E>(v[n][0]), t3 = dpp_f64<0x12E>(v[n][2]);     // row_ror:14 = lane + 2
             const double t0 = dpp_f64<0x122>(v[n][1]), t2 = dpp_f64<0x122>(v[n][3]);     // row_ror:2  = lane - 2
-            v[n][0] = X.upd(1, 0, v[n][0], t0); v[n][1] = X.upd(1, 1, v[n][1], t1);
-            v[n][2] = X.upd(1, 2, v[n][2], t2); v[n][3] = X.upd(1, 3, v[n][3], t3);
+            v[n][0] = X.up(N0 + n, 1, 0, v[n][0], t0); v[n][1] = X.up(N0 + n, 1, 1, v[n][1], t1);
+            v[n][2] = X.up(N0 + n, 1, 2, v[n][2], t2); v[n][3] = X.up(N0 + n, 1, 3, v[n][3], t3);
         }
     } else if constexpr (COL == 2) {                         // y even: (0,2), (1,3) of the lane itself
 #pragma unroll
         for (int n = 0; n < CNT; ++n) {
-            const double n0 = X.upd(2, 0, v[n][0], v[n][2]), n2 = X.upd(2, 2, v[n][2], v[n][0]);
-            const double n1 = X.upd(2, 1, v[n][1], v[n][3]), n3 = X.upd(2, 3, v[n][3], v[n][1]);
+            const double n0 = X.up(N0 + n, 2, 0, v[n][0], v[n][2]), n2 = X.up(N0 + n, 2, 2, v[n][2], v[n][0]);
+            const double n1 = X.up(N0 + n, 2, 1, v[n][1], v[n][3]), n3 = X.up(N0 + n, 2, 3, v[n][3], v[n][1]);
             v[n][0] = n0; v[n][1] = n1; v[n][2] = n2; v[n][3] = n3;
         }
     } else {                                                 // y odd: 2, 3 swap inside the lane pair; 0, 1 cross to the neighbouring row group
@@ -152,26 +196,119 @@ __device__ __forceinline__ void sq_colour(double (*v)[4], const SqCtx<UNI> &X) {
 #pragma unroll
         for (int n = 0; n < CNT; ++n) {
             const double t2 = dpp_f64<0xB1>(v[n][2]), t3 = dpp_f64<0xB1>(v[n][3]);       // quad_perm [1,0,3,2]
-            v[n][2] = X.upd(3, 2, v[n][2], t2); v[n][3] = X.upd(3, 3, v[n][3], t3);
+            v[n][2] = X.up(N0 + n, 3, 2, v[n][2], t2); v[n][3] = X.up(N0 + n, 3, 3, v[n][3], t3);
         }
 #pragma unroll
-        for (int n = 0; n < CNT; ++n) { v[n][0] = X.upd(3, 0, v[n][0], c0[n]); v[n][1] = X.upd(3, 1, v[n][1], c1[n]); }
-        __builtin_amdgcn_sched_group_barrier(DS, 4 * CNT, 0);
-        __builtin_amdgcn_sched_group_barrier(VALU, (4 + 4 * ARITH) * CNT, 0);
+        for (int n = 0; n < CNT; ++n) { v[n][0] = X.up(N0 + n, 3, 0, v[n][0], c0[n]); v[n][1] = X.up(N0 + n, 3, 1, v[n][1], c1[n]); }
+        if constexpr (CTX::GROUPS) {
+            __builtin_amdgcn_sched_group_barrier(DS, 4 * CNT, 0);
+            __builtin_amdgcn_sched_group_barrier(VALU, (4 + 4 * ARITH) * CNT, 0);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NS, int N0, int COL, bool UNI>
-__device__ __forceinline__ void sq_pairs(double (&v)[NS][4], const SqCtx<UNI> &X) {
-    sq_colour<(N0 + 1 < NS) ? 2 : 1, COL, UNI>(&v[N0], X);
-    if constexpr (N0 + 2 < NS) sq_pairs<NS, N0 + 2, COL, UNI>(v, X);
+template <int NS, int N0, int COL, class CTX>
+__device__ __forceinline__ void sq_pairs(double (&v)[NS][4], const CTX &X) {
+    sq_colour<(N0 + 1 < NS) ? 2 : 1, COL, N0, CTX>(&v[N0], X);
+    if constexpr (N0 + 2 < NS) sq_pairs<NS, N0 + 2, COL, CTX>(v, X);
+}
+
+template <int NS, bool REVERSE, class CTX>
+__device__ __forceinline__ void sq_sweepC(double (&v)[NS][4], const CTX &X) {
+    if constexpr (!REVERSE) { sq_pairs<NS, 0, 0, CTX>(v, X); sq_pairs<NS, 0, 1, CTX>(v, X); sq_pairs<NS, 0, 2, CTX>(v, X); sq_pairs<NS, 0, 3, CTX>(v, X); }
+    else                    { sq_pairs<NS, 0, 3, CTX>(v, X); sq_pairs<NS, 0, 2, CTX>(v, X); sq_pairs<NS, 0, 1, CTX>(v, X); sq_pairs<NS, 0, 0, CTX>(v, X); }
 }
 
 template <int NS, bool REVERSE, bool UNI>
-__device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx<UNI> &X) {
-    if constexpr (!REVERSE) { sq_pairs<NS, 0, 0, UNI>(v, X); sq_pairs<NS, 0, 1, UNI>(v, X); sq_pairs<NS, 0, 2, UNI>(v, X); sq_pairs<NS, 0, 3, UNI>(v, X); }
-    else                    { sq_pairs<NS, 0, 3, UNI>(v, X); sq_pairs<NS, 0, 2, UNI>(v, X); sq_pairs<NS, 0, 1, UNI>(v, X); sq_pairs<NS, 0, 0, UNI>(v, X); }
+__device__ __forceinline__ void sq_sweepN(double (&v)[NS][4], const SqCtx<UNI> &X) { sq_sweepC<NS, REVERSE, SqCtx<UNI>>(v, X); }
+
+// SSH: slab n with table set SOFF + n
+template <int NS, bool REVERSE, int SOFF, int NREG, bool LDS0>
+__device__ __forceinline__ void sq_sweepS(double (&v)[NS][4], const SqSsh<NREG, LDS0> &X) {
+    const SqSshView<NREG, LDS0, SOFF> V{X, X.yx};
+    sq_sweepC<NS, REVERSE, SqSshView<NREG, LDS0, SOFF>>(v, V);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The honeycomb lattice of 12 x 12 cells (config D: 288 sites) in the reference's colouring [A-B of a cell | B(x,y)-A(x+1,y) |
+// B(x,y)-A(x,y+1)] (verified on the host: detect_honeycomb12): the checkerboard WITHOUT LDS slabs.  A 16-lane DPP row holds the
+// twelve cells x = 0..11 of three lattice rows in its lanes 2..13, one lane per x, plus TWO MIRROR LANES on either side — lanes 0, 1
+// carry copies of x = 10, 11 and lanes 14, 15 copies of x = 0, 1 — so that the x-neighbour is always the next lane of the row
+// (row_ror:1 / row_ror:15) although 12 is no period of any DPP pattern.  Row g of the wave (lanes 16 g ..) holds the lattice rows
+// y = 3 g + j, a lane the six sites q = 2 j + orbital of its three cells:
+//   A-B of a cell        pairs registers (0,1), (2,3), (4,5) of the lane                    — no data movement;
+//   B(x,y)-A(x+1,y)      the A registers take B of the lane below, the B registers A of the lane above: 6 DPP moves of an f64;
+//   B(x,y)-A(x,y+1)      pairs (1,2), (3,4) of the lane; register 5 crosses to register 0 of the next row of the wave: one
+//                        ds_bpermute pair each way.
+// The mirror lanes do everything the real lanes do, on copies.  A colour-2 step spoils the outermost correct lane on either side
+// (lane 0 has no x = 9 below it); a mat-vec holds two such steps (forward sweep, reverse sweep), so lanes 2..13 — the real ones —
+// end it exact, the mirrors not.  The mirrors are never repaired: every vector update is pointwise, p of a mirror lane is made
+// from the REAL lane's residual (read from LDS at the real lane's slot), so p, the only input of the next mat-vec, is an exact
+// copy again.  Mirror lanes stay out of the inner products and of the stores to memory.  25 % of the lanes work twice — the vector
+// ALU is not what bounds this kernel — against 0.4 us of LDS traffic per sweep in the lane-program form.
+// Uniform hopping only (one (cosh, sinh) for all bonds: the example decks): a colour is c (I + th P), a sweep c^3 prod (I + th P).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int HC_NPL = 6;
+__device__ __forceinline__ int hc_site(int lane, int q) {
+    const int c = lane & 15, x = (c >= 2) ? ((c >= 14) ? c - 14 : c - 2) : c + 10;
+    return 2 * (x + 12 * (3 * (lane >> 4) + (q >> 1))) + (q & 1);
+}
+__device__ __forceinline__ bool hc_real(int lane) { const int c = lane & 15; return c >= 2 && c <= 13; }
+// the real lane whose copy a mirror lane carries (a real lane: itself)
+__device__ __forceinline__ int hc_src_lane(int lane) { const int c = lane & 15; return (c < 2) ? lane + 12 : ((c > 13) ? lane - 12 : lane); }
+
+struct HcCtx {
+    double th, k3;             // tanh of the bond angle; the factor c^3 the caller applies to a swept vector
+    int up, dn;                // lane + 16, lane - 16 (cyclic in the wave): the next / previous row
+};
+
+template <int CNT, int COL>
+__device__ __forceinline__ void hc_colour(double (*v)[HC_NPL], const HcCtx &X) {
+    if constexpr (COL == 0) {
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double a = v[n][2 * j] + X.th * v[n][2 * j + 1], b = v[n][2 * j + 1] + X.th * v[n][2 * j];
+                v[n][2 * j] = a; v[n][2 * j + 1] = b;
+            }
+    } else if constexpr (COL == 1) {
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            double ta[3], tb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { ta[j] = dpp_f64<0x121>(v[n][2 * j + 1]); tb[j] = dpp_f64<0x12F>(v[n][2 * j]); }   // row_ror:1 = lane - 1, row_ror:15 = lane + 1
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { v[n][2 * j] += X.th * ta[j]; v[n][2 * j + 1] += X.th * tb[j]; }
+        }
+    } else {
+        double c0[CNT], c5[CNT];
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) { c0[n] = __shfl(v[n][5], X.dn, WAVE); c5[n] = __shfl(v[n][0], X.up, WAVE); }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double b = v[n][2 * j + 1] + X.th * v[n][2 * j + 2], a = v[n][2 * j + 2] + X.th * v[n][2 * j + 1];
+                v[n][2 * j + 1] = b; v[n][2 * j + 2] = a;
+            }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) { v[n][0] += X.th * c0[n]; v[n][5] += X.th * c5[n]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS, int N0, int COL>
+__device__ __forceinline__ void hc_pairs(double (&v)[NS][HC_NPL], const HcCtx &X) {
+    hc_colour<(N0 + 1 < NS) ? 2 : 1, COL>(&v[N0], X);
+    if constexpr (N0 + 2 < NS) hc_pairs<NS, N0 + 2, COL>(v, X);
+}
+
+template <int NS, bool REVERSE>
+__device__ __forceinline__ void hc_sweepN(double (&v)[NS][HC_NPL], const HcCtx &X) {
+    if constexpr (!REVERSE) { hc_pairs<NS, 0, 0>(v, X); hc_pairs<NS, 0, 1>(v, X); hc_pairs<NS, 0, 2>(v, X); }
+    else                    { hc_pairs<NS, 0, 2>(v, X); hc_pairs<NS, 0, 1>(v, X); hc_pairs<NS, 0, 0>(v, X); }
 }
 
 // Diagnostic build (-DELPH_WG_STAMPS, tools/time_wg_phases.py): wave 0 of workgroup 0 of right-hand side 0 adds the wall-clock

@@ -81,6 +81,7 @@ void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, d
 }
 
 static void detect_square(elph_handle_s *h);
+static void detect_honeycomb12(elph_handle_s *h);
 
 static int build_lane_program(elph_handle_s *h) {
     h->lp_mc = (h->ncol <= 4) ? 4 : 6;      // kernels exist for 4-colour (square, honeycomb, chain) and 6-colour (triangular) programs
@@ -122,6 +123,7 @@ static int build_lane_program(elph_handle_s *h) {
     RC(dev_alloc(&h->d_lp_s, ntau * NE * ELPH_WAVE));
     RC(dev_alloc(&h->d_lp_cbar, (size_t)NE * ELPH_WAVE));
     RC(dev_alloc(&h->d_lp_sbar, (size_t)NE * ELPH_WAVE));
+    detect_honeycomb12(h);
     detect_square(h);
     if (h->sq_P > 0) {
         RC(dev_alloc(&h->d_sq_cbar, (size_t)4 * h->N));
@@ -159,6 +161,33 @@ static void detect_square(elph_handle_s *h) {
     }
     for (int v : h->sq_bond) if (v < 0) return;
     h->sq_P = L / 8;
+}
+
+// Recognise the honeycomb lattice of 12 x 12 two-site cells (site = 2 (x + 12 y) + orbital) with the reference's colouring
+// [A-B of a cell | B(x,y)-A(x+1,y) | B(x,y)-A(x,y+1)] (the bond definitions of examples/holstein_hmc_honeycomb.toml through
+// Checkerboard.jl:471-515).  Only then may the register-exchange form of the resident CG run (cg_wg_dev.h, HcCtx).
+static void detect_honeycomb12(elph_handle_s *h) {
+    h->hc12 = false;
+    const int L = 12;
+    if (h->N != 2 * L * L || h->ncol != 3 || h->nb != 3 * L * L) return;
+    std::vector<char> seen((size_t)3 * h->N, 0);
+    for (int col = 0; col < 3; ++col) {
+        const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
+        if (b1 - b0 != L * L) return;
+        for (int n = b0; n < b1; ++n) {
+            int i = h->h_bi[n], j = h->h_bj[n];
+            if (i & 1) std::swap(i, j);                      // i: the A site (orbital 0), j: the B site
+            if ((i & 1) != 0 || (j & 1) != 1) return;
+            const int ca = i >> 1, cb = j >> 1, xa = ca % L, ya = ca / L, xb = cb % L, yb = cb / L;
+            bool ok = false;
+            if (col == 0) ok = (ca == cb);
+            else if (col == 1) ok = (ya == yb) && (xa == (xb + 1) % L);
+            else ok = (xa == xb) && (ya == (yb + 1) % L);
+            if (!ok || seen[(size_t)col * h->N + i] || seen[(size_t)col * h->N + j]) return;
+            seen[(size_t)col * h->N + i] = seen[(size_t)col * h->N + j] = 1;
+        }
+    }
+    h->hc12 = true;
 }
 
 // uploads the lane-program copy of the per-bond cosh/sinh tables (h_c/h_s)

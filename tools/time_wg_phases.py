@@ -16,7 +16,7 @@ NAMES = ["mat-vec + four sums + boundary stores of z", "the meeting (records, bo
          "stop test", "p update", "(loop top)"]
 for tag in (sys.argv[1:] or ["b", "C"]):
     m = configs.make_model(tag, tol=1e-5)
-    for nr in (1, 24, 48):
+    for nr in [int(v) for v in os.environ.get("ELPH_NRS", "1,24,48").split(",")]:
         _, Bs = configs.rhs(m, nr)
         ms = C.c_double()
         reps = 1000
