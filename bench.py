@@ -364,6 +364,24 @@ def main():
             models.update_model_(m)          # back to one configuration for the secondary single-matrix measurements
             if args.precond:                 # (its expansion went with the chains' matrices)
                 pc.setup_(P, rng=np.random.default_rng(7 + rank))
+        # ---- secondary: the resident kernel on the other BASELINE lattices (configs D: honeycomb L = 12, Ntau = 120; E: optical SSH
+        # L = 16, Ntau = 160 — parity-test cases, SURVEY §8 sizes table), 256 right-hand sides, un-preconditioned iteration
+        if not args.no_sweep and rank == 0 and args.config == "C" and resident:
+            other = {}
+            for tag in ("D", "E"):
+                try:
+                    mo_ = configs.make_model(tag, tol=1e-5, device=comm.device_index())
+                    _, Bo = configs.rhs(mo_, 256)
+                    msd = C.c_double()
+                    for reps in (160, 1600):
+                        check(lib.elph_bench_prepare(mo_._h, 1, 256, _lib.dptr(np.ascontiguousarray(Bo))))
+                        check(lib.elph_bench_run(mo_._h, 9, 256, reps, 0, C.byref(msd)))
+                    other[tag] = {"us_per_step": 1e3 * msd.value / 1600, "matvecs_per_sec": 2.0 * 256 * 1600 / (msd.value * 1e-3), "nrhs": 256}
+                    out["roofline"][f"config_{tag}_matvecs_per_sec_nrhs256"] = other[tag]["matvecs_per_sec"]
+                    mo_.close()
+                except Exception as e:
+                    other[tag] = {"error": str(e)}
+            out["other_baseline_lattices_resident"] = other
         # ---- secondary: the same step at other batch sizes (short runs)
         if not args.no_sweep:
             sweep = {}
