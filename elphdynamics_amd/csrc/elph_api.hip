@@ -1429,6 +1429,12 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sq_sbar, qs.data(), sizeof(double) * qs.size(), hipMemcpyHostToDevice));
     }
+    if (hop_fresh && h->hc12) {
+        bool uni = h->nb > 0 && !h->kpm_hop_per_chain;
+        for (size_t k = 1; k < (size_t)h->nb && uni; ++k) uni = h->h_cbar[k] == h->h_cbar[0] && h->h_sbar[k] == h->h_sbar[0];
+        if (uni != h->hc_uniform) drop_graphs(h);
+        h->hc_uniform = uni;
+    }
     h->kpm_hop_uploaded = true;
     const int was_active = h->kpm_active;
     bool changed = !h->kpm_ready || resized;

@@ -217,6 +217,7 @@ struct elph_handle_s {
     int sq_P = 0;
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
+    bool hc_uniform = false;               // ... and its tau-averaged hopping tables are one (cosh, sinh) for every bond (the register-exchange Chebyshev recursion)
     bool hc12 = false;                     // honeycomb lattice of 12 x 12 cells in the reference's colouring (detect_honeycomb12): the DPP form of k_cg_wg
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     int *d_sq_bond = nullptr;                            // [4][N] device copy of sq_bond (sq_P > 0)

@@ -1,4 +1,4 @@
-// kpm_sq_dev.h — the register-exchange Chebyshev recursion of the even-L square lattices (KPMPreconditioners.jl:606-693) as device
+// kpm_sq_dev.h — the register-exchange Chebyshev recursions (even-L square lattices; honeycomb of 12 x 12 cells) (KPMPreconditioners.jl:606-693) as device
 // functions: used by k_kpm_cheb_sq (cg_fast_impl.inc, the streaming KPM apply) and by the resident preconditioned solver (pcg_wg.hip).
 #pragma once
 #include "cg_fast_common.h"
@@ -92,16 +92,62 @@ __device__ __forceinline__ void sq16_cb_apply(double (&v)[4], const SqLane<2> &T
 #undef SQC
 #undef SQS
 
-template <int P, bool TRANSPOSED, bool UNI, bool ROWS = false>
-__device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qacc)[P * P], const double (&vin)[P * P],
-                                              const double (&eb)[P * P], const double2 *c, int order, double a, double b,
-                                              const SqLane<P> &T) {
-    constexpr int NS = P * P;
-    // u_1 = v, u_2 = A'u_1, u_{n+1} = 2 A'u_n - u_{n-1} with A' = a A - b (mulA'!, KPMPreconditioners.jl:685-693; A = CB diag(eb),
-    // transposed: diag(eb) CB^T).  The scale a (and the 2 of the recurrence) ride on the diagonal the step multiplies by anyway:
-    // e1 = a eb, e2 = 2 a eb, so a step is the checkerboard apply plus 4 instructions per site (one fewer than scaling, A', 2 A'u - u
-    // separately), and the two history vectors swap roles instead of being copied — the recursion is a dependent chain of up to
-    // 2 (order - 1) of these steps, and one wave issues one vector instruction every 4-5 cycles.
+// The honeycomb lattice of 12 x 12 cells (config D) in the reference's colouring [A-B of a cell | B(x,y)-A(x+1,y) | B(x,y)-A(x,y+1)]
+// (detect_honeycomb12), QUAD layout of the Chebyshev recursion: lane 4 y + i (48 of the 64 lanes) holds the three cells x = 3 i + b of
+// lattice row y — six sites, register 2 b + orbital.  12 = 3 cells in a lane x 4 lanes of a DPP quad, so the x-direction wraps where
+// quad_perm wraps: A-B pairs registers (0,1), (2,3), (4,5); B(x,y)-A(x+1,y) pairs (1,2), (3,4) of the lane and sends register 5 to
+// register 0 of the next lane of the quad (two DPP moves of an f64); B(x,y)-A(x,y+1) crosses to the lane 4 up / 4 down, cyclically
+// in 48 (six ds_bpermute pairs, issued together: one LDS round trip, with `mid` inside it).  18 fma + 4 DPP moves + 12 ds_bpermute
+// per apply — no LDS slab, no mirror lanes to repair (the resident CG, cg_wg_dev.h, uses mirror lanes instead: there p is re-made
+// pointwise every iteration; a recursion has nothing that repairs them).  Uniform hopping: a colour is c (I + th P), T.th = s/c;
+// the caller folds c^3 into the scale of A'.
+struct HcLane { double th; int up, dn; };       // up / dn: lane + 4 / lane - 4 modulo 48 (idle lanes 48..63: themselves)
+
+__device__ __forceinline__ int hc12q_site(int lane, int q) {
+    const int l = (lane < 48) ? lane : lane - 48;          // (idle lanes shadow lanes 0..15: valid addresses, never stored)
+    return 2 * ((3 * (l & 3) + (q >> 1)) + 12 * (l >> 2)) + (q & 1);
+}
+
+template <bool REVERSE, class F>
+__device__ __forceinline__ void hc12q_cb_apply(double (&v)[6], const HcLane &T, F &&mid) {
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        const int col = REVERSE ? 2 - cc : cc;
+        if (col == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double a = v[2 * j] + T.th * v[2 * j + 1], b = v[2 * j + 1] + T.th * v[2 * j];
+                v[2 * j] = a; v[2 * j + 1] = b;
+            }
+        } else if (col == 1) {
+            const double t0 = dpp_f64<0x93>(v[5]);           // quad_perm [3,0,1,2]: the lane below in the quad
+            const double t5 = dpp_f64<0x39>(v[0]);           // quad_perm [1,2,3,0]: the lane above
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double b = v[2 * j + 1] + T.th * v[2 * j + 2], a = v[2 * j + 2] + T.th * v[2 * j + 1];
+                v[2 * j + 1] = b; v[2 * j + 2] = a;
+            }
+            v[0] += T.th * t0; v[5] += T.th * t5;
+        } else {
+            double fa[3], fb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { fa[j] = __shfl(v[2 * j + 1], T.dn, WAVE); fb[j] = __shfl(v[2 * j], T.up, WAVE); }
+            mid();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { v[2 * j] += T.th * fa[j]; v[2 * j + 1] += T.th * fb[j]; }
+        }
+    }
+}
+
+// u_1 = v, u_2 = A'u_1, u_{n+1} = 2 A'u_n - u_{n-1} with A' = a A - b (mulA'!, KPMPreconditioners.jl:685-693; A = CB diag(eb),
+// transposed: diag(eb) CB^T) on NS values per lane; apply(w, mid) is the checkerboard of the lattice's lane layout (in place; it runs
+// mid() where a cross-lane round trip leaves room).  The scale a (and the 2 of the recurrence) ride on the diagonal the step
+// multiplies by anyway: e1 = a eb, e2 = 2 a eb, so a step is the checkerboard apply plus 4 instructions per site (one fewer than
+// scaling, A', 2 A'u - u separately), and the two history vectors swap roles instead of being copied — the recursion is a dependent
+// chain of up to 2 (order - 1) of these steps, and one wave issues one vector instruction every 4-5 cycles.
+template <int NS, bool TRANSPOSED, class APPLY>
+__device__ __forceinline__ void kpm_series(double (&Pacc)[NS], double (&Qacc)[NS], const double (&vin)[NS], const double (&eb)[NS],
+                                           const double2 *c, int order, double a, double b, APPLY &&apply) {
     double ua[NS], ub[NS], e1[NS], e2[NS];
     const double b2 = 2.0 * b;
     {
@@ -111,7 +157,7 @@ __device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qa
     }
     // one step: un = the latest vector, um = the one before (overwritten by the new one)
     // The coefficient sums of a step's result (P += Re c_n u_n, Q += Im c_n u_n) and the history term of the next step do not
-    // depend on the next checkerboard apply: they run inside it, while its ds_bpermute pair is in flight (sq16_cb_apply's `mid`) —
+    // depend on the next checkerboard apply: they run inside it, while its ds_bpermute pair is in flight (the apply's `mid`) —
     // ~12 of the 60 instructions of a step off the dependent chain.
     double2 cpend = make_double2(0.0, 0.0);               // coefficient of the vector in `un` whose sums are still pending
     bool pend = false;
@@ -126,8 +172,7 @@ __device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qa
                 if (pend) { Pacc[q] += cpend.x * un[q]; Qacc[q] += cpend.y * un[q]; }
             }
         };
-        if constexpr (ROWS) sq16_cb_apply<TRANSPOSED, UNI>(w, T, mid);
-        else { mid(); sq_cb_apply<P, TRANSPOSED, UNI>(w, T); }
+        apply(w, mid);
 #pragma unroll
         for (int q = 0; q < NS; ++q) um[q] = TRANSPOSED ? e[q] * w[q] - t[q] : w[q] - t[q];
         cpend = cn; pend = true;
@@ -147,5 +192,20 @@ __device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qa
     else if (order >= 2) flush(ub);
 }
 
+template <int P, bool TRANSPOSED, bool UNI, bool ROWS = false>
+__device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qacc)[P * P], const double (&vin)[P * P],
+                                              const double (&eb)[P * P], const double2 *c, int order, double a, double b,
+                                              const SqLane<P> &T) {
+    kpm_series<P * P, TRANSPOSED>(Pacc, Qacc, vin, eb, c, order, a, b, [&T](double (&w)[P * P], auto &&mid) {
+        if constexpr (ROWS) sq16_cb_apply<TRANSPOSED, UNI>(w, T, mid);
+        else { mid(); sq_cb_apply<P, TRANSPOSED, UNI>(w, T); }
+    });
+}
+
+template <bool TRANSPOSED>
+__device__ __forceinline__ void kpm_series_hc(double (&Pacc)[6], double (&Qacc)[6], const double (&vin)[6], const double (&eb)[6],
+                                              const double2 *c, int order, double a, double b, const HcLane &T) {
+    kpm_series<6, TRANSPOSED>(Pacc, Qacc, vin, eb, c, order, a, b, [&T](double (&w)[6], auto &&mid) { hc12q_cb_apply<TRANSPOSED>(w, T, mid); });
+}
 
 }  // namespace kpmsq

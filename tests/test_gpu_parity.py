@@ -935,7 +935,34 @@ def test_mfma_dft_inside_batched_preconditioned_solve(monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2)])
+@pytest.mark.parametrize("tag", ["C", "D"])
+def test_kpm_register_exchange_recursion_equals_the_lds_recursion(tag, monkeypatch):
+    """The Chebyshev recursion of the KPM apply in registers (square lattice: 2 x 2 patches; honeycomb of 12 x 12 cells: three cells
+    per lane, four lanes of a DPP quad per lattice row) against the lane-program recursion in LDS (ELPH_NO_SQ=1): the same series
+    (KPMPreconditioners.jl:606-693), factored colours and another summation order — P^-1 r to 1e-12, and the same iteration counts."""
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    m = configs.make_model(tag, tol=1e-10)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_(P, rng=np.random.default_rng(7))
+    R, B = configs.rhs(m, 3)
+    out = {}
+    for name, env in (("reg", None), ("lds", "1")):
+        if env is None:
+            monkeypatch.delenv("ELPH_NO_SQ", raising=False)
+        else:
+            monkeypatch.setenv("ELPH_NO_SQ", env)
+        z = np.zeros(m.Ndim)
+        pc.kpm_ldiv_(z, P, np.ascontiguousarray(B[0]))
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B, P=P)
+        assert not fl.any()
+        out[name] = (z, X, it)
+    assert rel(out["reg"][0], out["lds"][0]) < 1e-12
+    assert np.max(np.abs(out["reg"][2] - out["lds"][2])) <= 1 and rel(out["reg"][1], out["lds"][1]) < 1e-9
+    m.close()
+
+
+@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2), ("D", 4, 2)])
 def test_kpm_preconditioner_per_chain(tag, nchains, per, monkeypatch):
     """One KPM expansion per resident phonon configuration (elph_kpm_setup_chains): every right-hand side of the batch
     is preconditioned with ITS chain's Ē, eigenvalue bounds, orders and coefficients — same bounds, same iteration
