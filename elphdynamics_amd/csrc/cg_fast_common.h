@@ -95,6 +95,14 @@ __device__ __forceinline__ void dpp_pair_odd_up4(double (&t)[4], const double (&
     for (int k = 0; k < 4; ++k) t[k] = __hiloint2double(o[2 * k + 1], o[2 * k]);
 }
 
+// Honeycomb lattice of 12 x 12 two-site cells, QUAD layout (kpm_sq_dev.h, cg_wg_dev.h): lane 4 y + i (48 of the 64 lanes) holds the
+// cells x = 3 i .. 3 i + 2 of lattice row y, register q = 2 b + orbital the site of cell x = 3 i + b; site = 2 (x + 12 y) + orbital.
+// Lanes 48..63 shadow lanes 0..15 (valid addresses; they never store and never enter a sum).
+__device__ __forceinline__ int hc12q_site(int lane, int q) {
+    const int l = (lane < 48) ? lane : lane - 48;
+    return 2 * ((3 * (l & 3) + (q >> 1)) + 12 * (l >> 2)) + (q & 1);
+}
+
 // wave-wide sum, the same value in every lane: quad swaps and row mirrors (DPP) give every lane the sum of its 16-lane row, the
 // four row sums are added in a fixed order through scalar registers.  (The xor butterfly over ds_bpermute it replaces is six
 // dependent LDS round trips — ~0.3 us on the critical path of the one-wave kernels, which call it two or three times.)

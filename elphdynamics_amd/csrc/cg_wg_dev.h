@@ -248,6 +248,10 @@ __device__ __forceinline__ void sq_sweepS(double (&v)[NS][4], const SqSsh<NREG, 
 // copy again.  Mirror lanes stay out of the inner products and of the stores to memory.  25 % of the lanes work twice — the vector
 // ALU is not what bounds this kernel — against 0.4 us of LDS traffic per sweep in the lane-program form.
 // Uniform hopping only (one (cosh, sinh) for all bonds: the example decks): a colour is c (I + th P), a sweep c^3 prod (I + th P).
+// (The QUAD layout of the Chebyshev recursion — kpm_sq_dev.h: three cells of a row per lane, four lanes of a DPP quad per row, no
+// mirrors, 4 DPP moves + 12 ds_bpermute per slab on 48 lanes — was built into this kernel too and is SLOWER here: 65.1 against 60.2 us
+// per iteration of 256 right-hand sides, 4.27 against 3.82 at 8 (profiles/r03/time_forms_D_quad_layout_rejected.log): eight waves of a
+// CU share ONE LDS crossbar, a recursion's single wave per SIMD does not.)
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int HC_NPL = 6;
 __device__ __forceinline__ int hc_site(int lane, int q) {

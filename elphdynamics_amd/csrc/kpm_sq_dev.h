@@ -103,10 +103,7 @@ __device__ __forceinline__ void sq16_cb_apply(double (&v)[4], const SqLane<2> &T
 // the caller folds c^3 into the scale of A'.
 struct HcLane { double th; int up, dn; };       // up / dn: lane + 4 / lane - 4 modulo 48 (idle lanes 48..63: themselves)
 
-__device__ __forceinline__ int hc12q_site(int lane, int q) {
-    const int l = (lane < 48) ? lane : lane - 48;          // (idle lanes shadow lanes 0..15: valid addresses, never stored)
-    return 2 * ((3 * (l & 3) + (q >> 1)) + 12 * (l >> 2)) + (q & 1);
-}
+using ::hc12q_site;        // (cg_fast_common.h: shared with the resident CG)
 
 template <bool REVERSE, class F>
 __device__ __forceinline__ void hc12q_cb_apply(double (&v)[6], const HcLane &T, F &&mid) {
