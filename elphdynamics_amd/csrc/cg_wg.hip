@@ -241,7 +241,12 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     double rho = S.rho, kmin = S.kmin, eps = S.eps;
     double eps0 = S.eps0, normb = S.normb;
 
-    if (threadIdx.x == 0) { tot[5] = 1.0; bc[2] = 1.0; }     // (ordered before their first readers by the barriers that follow; bc: a shard's seed meeting)
+    // (ordered before their first readers by the barriers that follow.  bc — the seed meeting of a shard, the two-meeting form — shares
+    //  its three words with part[16..18], the z.z partials of waves 0..2: in the single-meeting form of an un-sharded solve it must NOT
+    //  be touched here — nothing orders this store of wave 0 before the first iteration's part[] stores of a wave that finished its
+    //  set-up sooner, and a late 1.0 in place of wave 2's z.z partial costs that solve its first beta: one iteration more, about one
+    //  first solve in three of a fresh handle with the slow set-up of the bond-phonon DPP form)
+    if (threadIdx.x == 0) { tot[5] = 1.0; if (SHARD || !ONE) bc[2] = 1.0; }
     // single-meeting form: the boundary waves of a workgroup keep the neighbouring workgroup's boundary slice of r (p0 = r0: it sits in
     // the halo of p)
     if constexpr (ONE) {

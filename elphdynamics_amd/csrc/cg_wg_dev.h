@@ -115,7 +115,7 @@ struct SqCtx {
     // new value of a site with value v whose partner holds t
     __device__ __forceinline__ double upd(int col, int k, double v, double t) const {
         if constexpr (UNI) return v + s[0][0] * t;
-        else return c[UNI ? 0 : col][UNI ? 0 : k] * v + s[UNI ? 0 : col][UNI ? 0 : k] * t;
+        else return __builtin_fma(s[UNI ? 0 : col][UNI ? 0 : k], t, c[UNI ? 0 : col][UNI ? 0 : k] * v);      // (spelled out: see SqSsh::up_set)
     }
     // (slab n of the sweep: every slab has the same hopping)
     __device__ __forceinline__ double up(int n, int col, int k, double v, double t) const { return upd(col, k, v, t); }
@@ -148,7 +148,9 @@ struct SqSsh {
             else if (col == 2) { c = T.ci[1][k & 1];  s = T.si[1][k & 1]; }
             else               { c = T.cx[col >> 1][k]; s = T.sx[col >> 1][k]; }
         }
-        return c * v + s * tv;
+        // (the contraction is spelled out — round(c v), then one fma: left to -ffp-contract the compiler picks which product it fuses, and
+        //  two builds of this file, e.g. the ELPH_LDS_SYNC A/B library, need not pick the same)
+        return __builtin_fma(s, tv, c * v);
     }
 };
 // slab n of a sweep uses table set SOFF + n (forward sweep of w(t0 .. t0+T): 0; reverse sweep of w(t0+1 ..): 1)
