@@ -1572,10 +1572,13 @@ def test_wg_resident_cg_ssh_two_slices_per_wave():
     m.close()
 
 
-def test_wg_resident_cg_maxiter_history_and_initial_guess(oracle):
-    """Stop rule details through the resident kernel: maxiter exhaustion (flag 1), eps history, non-zero initial guess."""
+@pytest.mark.parametrize("tag", ["B", "C", "D", "E"])
+def test_wg_resident_cg_maxiter_history_and_initial_guess(oracle, tag):
+    """Stop rule details through the resident kernel, every checkerboard form of it (lane program: B; DPP on the square lattice: C;
+    honeycomb with mirror lanes: D; bond phonons with a table set per slice: E): maxiter exhaustion (flag 1), eps history against
+    the oracle at 1e-10, non-zero initial guess."""
     from elphdynamics_amd import configs, models
-    m = configs.make_model("B", tol=1e-8)
+    m = configs.make_model(tag, tol=1e-8)
     assert _wg_info(m)[0] == 1
     om = _oracle_model(oracle, m)
     R, B = configs.rhs(m, 1)
