@@ -1447,6 +1447,38 @@ def test_wg_resident_cg_bench_shape_vs_oracle(oracle):
     m.close()
 
 
+def test_wg_resident_cg_honeycomb_and_ssh_batches_vs_oracle(oracle):
+    """Configs D and E in the shape a batch of chains runs — 2 slices per wave, the register-exchange checkerboards (honeycomb: mirror
+    lanes; bond phonons: one hopping-table set per time slice, one of three in LDS) — against the ORACLE directly: solved to 1e-13 on
+    both sides, every checked right-hand side is within the north_star's 1e-10 of the oracle's solve on that chain's matrix."""
+    from elphdynamics_amd import configs, models, synth
+    for tag, nch in (("D", 13), ("E", 13)):
+        m = configs.make_model(tag, tol=1e-13, maxiter=20000)
+        nrhs = 2 * nch
+        if m.kind == models.SSH:
+            Xc = np.stack([m.x * (0.6 + 0.8 * c / nch) * (1.0 + 0.2 * synth.randn(synth.SEED_FIELDS + 17 * c, m.Ndof)) for c in range(nch)])
+        else:
+            Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=synth.SEED_FIELDS + 17 * c) for c in range(nch)])
+        models.update_model_chains_(m, Xc)
+        usable, T, W, G = _wg_info(m, nrhs)
+        assert usable == 1 and T == 2, (tag, T, W, G)
+        R = np.stack([synth.rhs(m.Ndim, seed=synth.SEED_RHS + 7919 * i) for i in range(nrhs)])
+        X = np.zeros_like(R)
+        it, res, fl = models.ldiv_batched_(X, m, R)
+        assert not fl.any() and (res < 1e-12).all(), tag
+        for i in (0, nch - 1, nch, nrhs - 1):
+            c = i % nch
+            m1 = configs.make_model(tag, tol=1e-13, maxiter=20000)      # (a host-side model of chain c: its tables for the oracle)
+            m1.x[:] = Xc[c]
+            models.update_model_(m1)
+            om = _oracle_model(oracle, m1)
+            xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(R[i]), solver_tol=1e-13, solver_maxiter=20000)
+            assert flo == 0 and abs(int(it[i]) - ito) <= max(3, ito // 100), (tag, i, int(it[i]), ito)
+            assert rel(X[i], xo) < 1e-10, (tag, i, rel(X[i], xo))
+            m1.close()
+        m.close()
+
+
 def test_wg_resident_cg_shape_pin_makes_bits_independent_of_the_batch(monkeypatch):
     """Which team shape runs decides the last bits of a solution (another summation tree), and the shape follows the batch size
     (config C: 1 slice per wave up to 8 right-hand sides, 2 up to 24, 4 above).  ELPH_WG_T pins it: with the pin a right-hand side's solution
