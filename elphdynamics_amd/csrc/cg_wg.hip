@@ -2,20 +2,21 @@
 // (IterativeSolvers.jl:239-314) in ONE launch, Krylov vectors in registers, for lattices with a 4-colour lane program.
 //
 // Why: the two-kernel iteration (cg_fast_impl.inc) streams r, p, x, z through HBM/L2 every iteration — HBM-bound in a large
-// batch (0.72 of the 8 TB/s peak), launch-bound for the reference's real call shape (1-2 right-hand sides: 10 us per
+// batch (0.6-0.7 of the 8 TB/s peak), launch-bound for the reference's real call shape (1-2 right-hand sides: 8 us per
 // iteration for 0.6 us of work).  Here a right-hand side belongs to a TEAM of G workgroups of W wavefronts; a wavefront owns
-// T consecutive tau-slices for the whole solve and keeps x, r, p (own slices + one halo slice each side) and exp(-dtau V)
-// in registers.  Nothing of the Krylov vectors goes back to memory between iterations: an iteration costs two
-// checkerboard-sweep passes in the wave's private LDS slabs plus two MEETINGS of the team:
-//   (1) p.z  ->  alpha            (2) r.r + the boundary slices of the new r  ->  eps, stop test, beta, halo of the new p
+// T consecutive tau-slices for the whole solve and keeps p (own slices + one halo slice each side) and exp(-dtau V) in registers,
+// x and r in its LDS (or registers, by shape).  Nothing of the Krylov vectors goes back to memory between iterations: an
+// iteration costs two checkerboard-sweep passes (in registers — the DPP forms of cg_wg_dev.h — or in the wave's private LDS
+// slabs) plus ONE MEETING of the team: every workgroup publishes FOUR sums — p.z, r.z, z.z and the r.r of the current residual —
+// and the boundary slices of z; alpha = r.r / p.z, r'.r' = r.r - 2 alpha r.z + alpha^2 z.z gives beta and the stop test without a
+// second reduction, and the neighbouring workgroup's boundary slice of r' is its r minus alpha times its z (see the loop).
 // A meeting is hierarchical: wave partials -> LDS -> s_barrier (inside the workgroup), then — only if the team has more
-// than one workgroup — one 16-byte record per workgroup through L2: two 8-byte {tag = iteration, half of the f64} granules
-// written by ONE sc1 store each and polled by every wave with sc1 loads until all tags carry the iteration number
-// (cdna_hip_programming.md, Guideline 16, form R2: the data is the flag; no fence).  Boundary slices of r (2 KB) that cross
-// a workgroup boundary are sc1-stored before the workgroup's barrier and the r.r record that follows it is their flag
-// (form R1: every storing wave drains vmcnt before the barrier; consumers read them with sc1 loads after their own poll).
-// Every wave of a team reduces the same records in the same order, so alpha, beta and the stop decision are bit-identical
-// across the team and from run to run.
+// than one workgroup — one 64-byte record per workgroup through L2: eight 8-byte {tag = iteration, half of an f64} granules
+// written by ONE sc1 store each and polled with sc1 loads until all tags carry the iteration number
+// (cdna_hip_programming.md, Guideline 16, form R2: the data is the flag; no fence).  The boundary slices of z travel as granules
+// of the same kind.  Every wave of a team reduces the same records in the same order, so alpha, beta and the stop decision are
+// bit-identical across the team and from run to run.  (A sharded solve, SHARD, meets on two levels: the workgroups of a rank, then
+// the ranks through their mailboxes.  -DELPH_SHARD_TWO_MEETINGS keeps round 2's two-meeting iteration for A/B.)
 //
 // Placement: team members are blocks with equal blockIdx % 8 (they share an XCD and its L2 under the observed round-robin
 // placement — speed only, never correctness).  The grid may hold more teams than the chip can keep resident: blocks are
