@@ -26,6 +26,7 @@
 // two-kernel iteration.
 
 #include <algorithm>
+#include <type_traits>
 
 #include "cg_fast_common.h"
 
@@ -43,13 +44,17 @@ template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = f
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
     constexpr bool SQ = FORM == 1, HC = FORM == 2, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
     static_assert(!SHARD || (T == 1 && !REGX), "sharded solves: one slice per wave, lane-program form");
-    static_assert(!HC || (NPL == HC_NPL && UNI && !SSH && T <= 2), "honeycomb DPP form: six sites per lane, uniform hopping");
+    static_assert(!HC || (NPL == HC_NPL && UNI && !SSH && T <= 3), "honeycomb DPP form: six sites per lane, uniform hopping");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(!SQ || NPL == 4, "DPP form: the 16 x 16 square lattice, four sites per lane");
     static_assert(!(SQ && SSH) || (!UNI && T <= 2), "DPP form with bond phonons: a table set per slice, at most two slices per wave");
     static_assert(!SQ || UNI || T <= 2, "DPP form with per-site hopping: 32 registers of (cosh, sinh) leave room for two slices");
     constexpr int NE = MC * ((NPL + 1) / 2);
     constexpr int HS = NPL * WAVE, SL = slab_len<NPL>();
+    // slices in LDS: LSL lanes per register, HSL doubles per slice.  Honeycomb form: the 48 REAL lanes only — a mirror lane READS the
+    // slot of the lane it mirrors (lr) and writes nothing (lwok): its r, exp(-dtau V) and halo values are the real lane's by
+    // construction, and a quarter of the LDS is not spent on copies (what lets 3 slices per wave fit)
+    constexpr int LSL = HC ? 48 : WAVE, HSL = NPL * LSL;
     constexpr int NSLAB = REGX ? 0 : T + 1;            // LDS slabs per wave (lane-program form)
     constexpr int NT = SSH ? T + 1 : 1;                // hopping-table sets (SSH: one per slice t0 .. t0+T)
     constexpr int NEJ = SSH ? 1 : T + 1;               // exp(-dtau V) slices (SSH: exp(dtau mu), per site only)
@@ -59,7 +64,13 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // bond phonons, DPP form, 2 slices per wave: the table set of slice t0 in LDS (24 doubles per lane), x in registers
     constexpr bool S_LDS = SQ && SSH && T == 2;
     // honeycomb DPP form, 2 slices per wave: exp(-dtau V) in LDS too (six sites per lane: 36 registers)
-    constexpr bool E_LDS = (SQ && T >= 4) || (HC && T >= 2), X_REG = (SQ && T >= 4) || S_LDS;
+    constexpr bool E_LDS = (SQ && T >= 4) || (HC && T >= 2), X_REG = (SQ && T >= 4) || S_LDS || (HC && T >= 3);
+    // (honeycomb: neighbouring waves SHARE the slice of exp(-dtau V) between them — [W T + 1] slices per workgroup instead of W (T + 1);
+    //  both write the same values to it)
+    constexpr bool E_SHARED = HC;
+    // honeycomb, 3 slices per wave: the two HALO slices of p wait in LDS between the p-update that makes them and the mat-vec that
+    // consumes them (24 registers that would otherwise sit through both sweeps)
+    constexpr bool PH_LDS = HC && T >= 3;
     constexpr int NSREG = (SQ && SSH) ? (S_LDS ? T : T + 1) : 1;
     // ONE: the single-meeting iteration (see the loop) — for a shard too: its meeting is two-level (workgroups of the rank, then ranks)
     // and carries the ghost rows of z
@@ -96,18 +107,22 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     if (rhs >= B.nrhs) return;
     const int N = m.N, L = m.L;
     const int t0 = (g * W + wv) * T;
+    const int lr = HC ? 12 * (hc_src_lane(lane) >> 4) + (hc_src_lane(lane) & 15) - 2 : lane;      // LDS slot this lane reads (and, if lwok, writes)
+    const bool lwok = !HC || hc_real(lane);
     const size_t ndim = (size_t)N * L;
     double *slab = lds + (size_t)wv * NSLAB * SL;
     double *rall = lds + (size_t)W * NSLAB * SL;       // [W][T][HS]: r of every wave's slices — neighbours read their halo slices here
-    double *rl = rall + (size_t)wv * T * HS;
-    double *xl = rall + (size_t)W * T * HS + (size_t)wv * T * HS;      // [W][T][HS]: this wave's slices of x (unless X_REG)
-    double *eall = rall + (size_t)(X_REG ? 1 : 2) * W * T * HS;        // [W][T+1][HS]: exp(-dtau V) of slices t0 .. t0+T (E_LDS)
-    double *el = eall + (size_t)wv * (T + 1) * HS;
-    double *partA = eall + (E_LDS ? (size_t)W * (T + 1) * HS : (S_LDS ? (size_t)W * SQ_TABS * WAVE : 0)), *partB = partA + 8, *bc = partA + 16;   // bc: p.z total, r.r total, 0.0 = a poller gave up
+    double *rl = rall + (size_t)wv * T * HSL;
+    double *xl = rall + (size_t)W * T * HSL + (size_t)wv * T * HSL;    // [W][T][HSL]: this wave's slices of x (unless X_REG)
+    double *eall = rall + (size_t)(X_REG ? 1 : 2) * W * T * HSL;       // [W][T+1][HSL]: exp(-dtau V) of slices t0 .. t0+T (E_LDS)
+    double *el = eall + (size_t)wv * (E_SHARED ? T : T + 1) * HSL;
+    double *partA = eall + (E_LDS ? (E_SHARED ? ((size_t)W * T + 1) * HSL : (size_t)W * (T + 1) * HSL) : (S_LDS ? (size_t)W * SQ_TABS * WAVE : 0)), *partB = partA + 8, *bc = partA + 16;   // bc: p.z total, r.r total, 0.0 = a poller gave up
     // single-meeting form: part[4][8] wave partials of p.z, r.z, z.z, r.r | tot[8]: the four totals, [4] the direct r.r of the fallback
     // meeting, [5] 0.0 = a poller gave up | partF[8] | rhalo[2][HS]: the boundary slices of r of the two neighbouring workgroups (kept in
     // LDS rather than in registers: the 4-slice shape has none to spare)
-    double *part = partA, *tot = partA + 32, *partF = partA + 40, *rhalo = partA + 48, *zhalo = rhalo + 2 * HS;   // zhalo[2][HS]: their boundary slices of z
+    double *part = partA, *tot = partA + 32, *partF = partA + 40, *rhalo = partA + 48, *zhalo = rhalo + 2 * HSL;
+    double *phl = zhalo + 2 * HSL + (size_t)wv * 2 * HSL;             // [W][2][HSL]: the halo slices of p (PH_LDS)
+#define PHALO(k, q) phl[((k) ? 1 : 0) * HSL + lr + (q) * LSL]   // zhalo[2][HS]: their boundary slices of z
     auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
     auto sgn = [](int t) { return (t == 0) ? -1.0 : 1.0; };
     const CgParams P = B.params;
@@ -144,20 +159,23 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     for (int j = 0; j < T; ++j)
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            rl[j * HS + lane + q * WAVE] = rg[(size_t)(t0 + j) * N + sc[q]];
+            if (lwok) rl[j * HSL + lr + q * LSL] = rg[(size_t)(t0 + j) * N + sc[q]];
             if (X_REG) xr[X_REG ? j : 0][q] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
-            else xl[j * HS + lane + q * WAVE] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
+            else if (lwok) xl[j * HSL + lr + q * LSL] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
         }
 #pragma unroll
     for (int j = 0; j < T + 2; ++j)
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) p[j][q] = rg[(size_t)wrap(t0 + j - 1) * N + sc[q]];      // p0 = r0 (:272): one vector less to read
+        for (int q = 0; q < NPL; ++q) {
+            p[j][q] = rg[(size_t)wrap(t0 + j - 1) * N + sc[q]];      // p0 = r0 (:272): one vector less to read
+            if (PH_LDS && (j == 0 || j == T + 1) && lwok) PHALO(j, q) = p[j][q];
+        }
 #pragma unroll
     for (int j = 0; j < NEJ; ++j)
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             const double ev = Ech[(size_t)wrap(t0 + j) * m.E_tau_stride + sc[q]];
-            if (E_LDS) el[j * HS + lane + q * WAVE] = ev;
+            if (E_LDS) { if (lwok) el[j * HSL + lr + q * LSL] = ev; }
             else E[E_LDS ? 0 : j][q] = ev;
         }
     unsigned ij[NE];
@@ -165,8 +183,6 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     SqCtx<UNI> X;
     SqSsh<NSREG, S_LDS> XS;
     HcCtx XH;
-    // LDS slot of the value a lane READS when it makes p from the residual (honeycomb: a mirror lane reads the real lane's)
-    const int ll = HC ? hc_src_lane(lane) : lane;
     if constexpr (HC) {
         XH.th = m.s_uni / m.c_uni; XH.k3 = m.c_uni * m.c_uni * m.c_uni;
         XH.up = (lane + 16) & (WAVE - 1); XH.dn = (lane + 48) & (WAVE - 1);
@@ -234,7 +250,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             load_tab<NE, UNI>(tab[0], m.lp_c, m.lp_s, lane, m);
         }
     }
-#define EXPV(j, q) (E_LDS ? el[(j) * HS + lane + (q) * WAVE] : E[(SSH || E_LDS) ? 0 : (j)][q])
+#define EXPV(j, q) (E_LDS ? el[(j) * HSL + lr + (q) * LSL] : E[(SSH || E_LDS) ? 0 : (j)][q])
 
     u64 *slotsA = R.slots + (size_t)rhs * (ONE ? SLOTS_PER_RHS : 2 * 64), *slotsB = slotsA + (ONE ? SLOTS_A : 64);
     u64 *bnd = R.bnd + (size_t)rhs * G * 2 * HS * 2;     // [G][first | last slice][HS][2 granules]
@@ -254,11 +270,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         if (G > 1) {
             if (wv == 0) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) rhalo[lane + q * WAVE] = p[0][q];
+                for (int q = 0; q < NPL; ++q) if (lwok) rhalo[lr + q * LSL] = p[0][q];
             }
             if (wv == W - 1) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) rhalo[HS + lane + q * WAVE] = p[T + 1][q];
+                for (int q = 0; q < NPL; ++q) if (lwok) rhalo[HSL + lr + q * LSL] = p[T + 1][q];
             }
         }
     }
@@ -310,26 +326,31 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
             for (int k = 0; k <= T; ++k)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) w[k][q] = EXPV(k, q) * p[k][q];
+                for (int q = 0; q < NPL; ++q) w[k][q] = EXPV(k, q) * ((PH_LDS && k == 0) ? PHALO(0, q) : p[k][q]);
             hc_sweepN<T + 1, false>(w, XH);
 #pragma unroll
             for (int k = 0; k <= T; ++k) {
                 const double sg = sgn(wrap(t0 + k)) * XH.k3;
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) w[k][q] = p[k + 1][q] - sg * w[k][q];
+                for (int q = 0; q < NPL; ++q) w[k][q] = ((PH_LDS && k == T) ? PHALO(1, q) : p[k + 1][q]) - sg * w[k][q];
             }
-            double gq[T][NPL];
+            auto rev = [&](auto nb, int j0) {            // reverse sweeps of the slabs j0 .. j0 + nb - 1 at once (3 slices per wave: 2 + 1)
+                constexpr int NB = decltype(nb)::value;
+                double gq[NB][NPL];
 #pragma unroll
-            for (int i = 0; i < T; ++i)
+                for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) gq[i][q] = w[i + 1][q];
-            hc_sweepN<T, true>(gq, XH);
+                    for (int q = 0; q < NPL; ++q) gq[i][q] = w[j0 + i + 1][q];
+                hc_sweepN<NB, true>(gq, XH);
 #pragma unroll
-            for (int i = 0; i < T; ++i) {
-                const double sg = sgn(wrap(t0 + i + 1)) * XH.k3;
+                for (int i = 0; i < NB; ++i) {
+                    const double sg = sgn(wrap(t0 + j0 + i + 1)) * XH.k3;
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) w[i][q] = w[i][q] - sg * (EXPV(i + 1, q) * gq[i][q]);            // z(t0+i)
-            }
+                    for (int q = 0; q < NPL; ++q) w[j0 + i][q] = w[j0 + i][q] - sg * (EXPV(j0 + i + 1, q) * gq[i][q]);     // z(t0+j0+i)
+                }
+            };
+            if constexpr (T == 3) { rev(std::integral_constant<int, 1>(), 0); rev(std::integral_constant<int, 1>(), 1); rev(std::integral_constant<int, 1>(), 2); }
+            else rev(std::integral_constant<int, T>(), 0);
         } else if constexpr (SQ) {
 #pragma unroll
             for (int k = 0; k <= T; ++k)
@@ -389,6 +410,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             WAVE_LDS_ORDER();
         }
         double (&z)[T + 1][NPL] = zw;                         // rows 0 .. T-1
+        // (honeycomb, 3 slices per wave: the addresses of the boundary granules are made afresh every iteration from a laundered lane
+        //  number — kept across the loop they are 2 registers each, 24 of them, in a kernel that has none to spare)
+        int lane_b = lane;
+        if constexpr (HC && T >= 3) asm volatile("" : "+v"(lane_b));
         double rr, hx[NPL];                                   // rr: r.r of the NEW residual; hx: the halo slice that comes from another workgroup (waves 0 and W-1)
         if constexpr (ONE) {
         // ================= single-meeting iteration ==========================================================================
@@ -408,7 +433,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
             for (int q = 0; q < NPL; ++q)
                 if (own[q]) {
-                    const double rv = rl[j * HS + lane + q * WAVE];
+                    const double rv = rl[j * HSL + lr + q * LSL];
                     s_pz += p[j + 1][q] * z[j][q];
                     s_rz += rv * z[j][q];
                     s_zz += z[j][q] * z[j][q];
@@ -439,11 +464,17 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         if (G > 1) {                                          // boundary slices of z for the neighbouring workgroups (self-tagged granules)
             if (wv == 0) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 0) * HS + lane + q * WAVE) * 2, z[0][q], epoch);
+                for (int q = 0; q < NPL; ++q) {
+                    st_f64_gran(bnd + (((size_t)g * 2 + 0) * HS + lane_b + q * WAVE) * 2, z[0][q], epoch);
+                    if constexpr (HC && T >= 3) __builtin_amdgcn_sched_barrier(0);      // (one value's granules and address at a time)
+                }
             }
             if (wv == W - 1) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 1) * HS + lane + q * WAVE) * 2, z[T - 1][q], epoch);
+                for (int q = 0; q < NPL; ++q) {
+                    st_f64_gran(bnd + (((size_t)g * 2 + 1) * HS + lane_b + q * WAVE) * 2, z[T - 1][q], epoch);
+                    if constexpr (HC && T >= 3) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         STAMP(0);
@@ -499,7 +530,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     if (bw) {
                         const double hv = ga2[q] ? __hiloint2double((int)(unsigned)c1[q], (int)(unsigned)c0[q])
                                                  : __hiloint2double((int)(unsigned)h1[q], (int)(unsigned)h0[q]);
-                        zhalo[((wv == 0) ? 0 : HS) + lane + q * WAVE] = hv;
+                        zhalo[((wv == 0) ? 0 : HSL) + lr + q * LSL] = hv;
                     }
                 }
             }
@@ -545,8 +576,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int s0 = wv; s0 < NSEG || (s0 == wv && wv == rw); s0 += 2 * W) {
                 const int s1 = s0 + W;
                 const u64 *b0 = nullptr, *b1 = nullptr;
-                if (s0 < NSEG) b0 = bnd + ((((s0 < NPL) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane + (size_t)(s0 % NPL) * WAVE) * 2;
-                if (s1 < NSEG) b1 = bnd + ((((s1 < NPL) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane + (size_t)(s1 % NPL) * WAVE) * 2;
+                if (s0 < NSEG) b0 = bnd + ((((s0 < NPL) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane_b + (size_t)(s0 % NPL) * WAVE) * 2;
+                if (s1 < NSEG) b1 = bnd + ((((s1 < NPL) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane_b + (size_t)(s1 % NPL) * WAVE) * 2;
                 const bool recs = (wv == rw && s0 == wv);
                 double z0 = 0.0, z1 = 0.0;
                 if (G <= 8) {
@@ -558,8 +589,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     ok = poll_rec4<4>(recs ? slotsA : nullptr, G, b0, b1, epoch, lane, R, v, z0, z1) && ok;
                     if (recs) t4 = sum_rec4<4>(v, G, lane);
                 }
-                if (b0) zhalo[(size_t)s0 * WAVE + lane] = z0;             // (segment s = side * NPL + q lives at [side][q * 64 + lane])
-                if (b1) zhalo[(size_t)s1 * WAVE + lane] = z1;
+                if (b0 && lwok) zhalo[(size_t)s0 * LSL + lr] = z0;        // (segment s = side * NPL + q lives at [side][q * LSL + slot])
+                if (b1 && lwok) zhalo[(size_t)s1 * LSL + lr] = z1;
                 if (!ok) break;
             }
             if (wv == rw && lane < 8 && !(lane & 1)) tot[lane >> 1] = t4;
@@ -578,16 +609,16 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 const double zq = (SHARD && gaddr[q]) ? gz[q] : z[j][q];                           // (a shard's ghost rows: the owner's z)
-                const double rn = rl[j * HS + lane + q * WAVE] - alpha * zq;                        // :285
-                rl[j * HS + lane + q * WAVE] = rn;
+                const double rn = rl[j * HSL + lr + q * LSL] - alpha * zq;                          // :285
+                if (lwok) rl[j * HSL + lr + q * LSL] = rn;
                 if (X_REG) xr[X_REG ? j : 0][q] += alpha * p[j + 1][q];                            // :282
-                else xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];
+                else if (lwok) xl[j * HSL + lr + q * LSL] += alpha * p[j + 1][q];
             }
         if (G > 1 && (wv == 0 || wv == W - 1)) {              // the neighbouring workgroup's boundary slice of the new residual
-            double *rh = rhalo + ((wv == 0) ? 0 : HS);
-            const double *zh = zhalo + ((wv == 0) ? 0 : HS);
+            double *rh = rhalo + ((wv == 0) ? 0 : HSL);
+            const double *zh = zhalo + ((wv == 0) ? 0 : HSL);
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) rh[lane + q * WAVE] = rh[lane + q * WAVE] - alpha * zh[lane + q * WAVE];
+            for (int q = 0; q < NPL; ++q) if (lwok) rh[lr + q * LSL] = rh[lr + q * LSL] - alpha * zh[lr + q * LSL];
         }
         STAMP(3);
         if (!(rr > 1e-3 * rr0)) {
@@ -596,7 +627,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
             for (int j = 0; j < T; ++j)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) if (own[q]) { const double rn = rl[j * HS + lane + q * WAVE]; a += rn * rn; }
+                for (int q = 0; q < NPL; ++q) if (own[q]) { const double rn = rl[j * HSL + lr + q * LSL]; a += rn * rn; }
             a = wave_sum_dpp(a);
             if (lane == 0) partF[wv] = a;
             wg_barrier();
@@ -698,11 +729,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         for (int j = 0; j < T; ++j)
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                rn[j][q] = rl[j * HS + lane + q * WAVE] - alpha * z[j][q];                         // :285
-                rl[j * HS + lane + q * WAVE] = rn[j][q];
+                rn[j][q] = rl[j * HSL + lr + q * LSL] - alpha * z[j][q];                           // :285
+                rl[j * HSL + lr + q * LSL] = rn[j][q];
                 if (own[q]) a += rn[j][q] * rn[j][q];
                 if (X_REG) xr[X_REG ? j : 0][q] += alpha * p[j + 1][q];                            // :282
-                else xl[j * HS + lane + q * WAVE] += alpha * p[j + 1][q];
+                else xl[j * HSL + lr + q * LSL] += alpha * p[j + 1][q];
             }
         a = wave_sum_dpp(a);
         if constexpr (SHARD) {
@@ -843,8 +874,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     if (HC ? hc_real(lane2) : (SQ || s2 < N)) {
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
-                        if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HS + lane + q * WAVE];
-                        xg[(size_t)(t0 + j) * N + s2] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HS + lane + q * WAVE];
+                        if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HSL + lr + q * LSL];
+                        xg[(size_t)(t0 + j) * N + s2] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HSL + lr + q * LSL];
                     }
                 }
             if (g == 0 && wv == 0 && lane == 0) {
@@ -864,20 +895,25 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         // ---- next direction on the own slices and on the two halo slices (p = r + beta p is pointwise) --------------------
         {
             const bool lx = (G > 1 && wv == 0), rx = (G > 1 && wv == W - 1);
-            const double *sl = rall + ((size_t)((wv > 0) ? wv - 1 : W - 1) * T + (T - 1)) * HS;     // last slice of the wave below
-            const double *sr = rall + ((size_t)((wv < W - 1) ? wv + 1 : 0) * T + 0) * HS;          // first slice of the wave above
+            const double *sl = rall + ((size_t)((wv > 0) ? wv - 1 : W - 1) * T + (T - 1)) * HSL;    // last slice of the wave below
+            const double *sr = rall + ((size_t)((wv < W - 1) ? wv + 1 : 0) * T + 0) * HSL;         // first slice of the wave above
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const double hl = lx ? (ONE ? rhalo[ll + q * WAVE] : hx[q]) : sl[ll + q * WAVE];
-                const double hr = rx ? (ONE ? rhalo[HS + ll + q * WAVE] : hx[q]) : sr[ll + q * WAVE];
-                p[0][q] = hl + beta * p[0][q];
-                p[T + 1][q] = hr + beta * p[T + 1][q];
+                const double hl = lx ? (ONE ? rhalo[lr + q * LSL] : hx[q]) : sl[lr + q * LSL];
+                const double hr = rx ? (ONE ? rhalo[HSL + lr + q * LSL] : hx[q]) : sr[lr + q * LSL];
+                if constexpr (PH_LDS) {
+                    const double n0 = hl + beta * PHALO(0, q), n1 = hr + beta * PHALO(1, q);
+                    if (lwok) { PHALO(0, q) = n0; PHALO(1, q) = n1; }
+                } else {
+                    p[0][q] = hl + beta * p[0][q];
+                    p[T + 1][q] = hr + beta * p[T + 1][q];
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < T; ++j)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) p[j + 1][q] = rl[j * HS + ll + q * WAVE] + beta * p[j + 1][q];
+            for (int q = 0; q < NPL; ++q) p[j + 1][q] = rl[j * HSL + lr + q * LSL] + beta * p[j + 1][q];
         STAMP(8);
     }
 #ifdef ELPH_WG_PERSISTENT
@@ -886,6 +922,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #endif
     }
 #undef EXPV
+#undef PHALO
 }
 
 // ------------------------------------------------------------------------------------------
@@ -917,9 +954,21 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     const int L = (int)h->L;
     const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m);
     const int npl = hc ? HC_NPL : h->npl;
-    const int cand[3] = {4, 2, 1};
+    const int cand[4] = {4, 3, 2, 1};
     for (int T : cand) {
         if (forceT && T != forceT) continue;
+        if (T == 3) {
+            // honeycomb form only: 48 right-hand sides per round instead of 24 at 2 slices per wave, but 9.7 us per iteration against 5.5
+            // (the kernel spills 69 registers: six sites per lane x three slices is more than the register file and the LDS hold next to
+            // each other) — taken when the rounds it saves outweigh that: 25-48, 73-96, 121-144, ... and everything from 217 on
+            if (!hc || L % 3 || L % 2) continue;
+            if (forceT != 3) {
+                const int G2 = (L / 2) / largest_divisor_le8(L / 2), G3 = (L / 3) / largest_divisor_le8(L / 3);
+                if (G2 > 32 || G3 > 32) continue;
+                const int r2 = 8 * (32 / G2), r3 = 8 * (32 / G3);
+                if (nrhs <= r2 || 9.7 * ((nrhs + r3 - 1) / r3) >= 5.5 * ((nrhs + r2 - 1) / r2)) continue;
+            }
+        }
         if (T == 4) {
             if (!sq || !m.uniform || ssh) continue;
             if (forceT != 4) {                           // only when 2 slices per wave would need a second round: 8 XCDs x (32 CUs / G2) teams
@@ -952,12 +1001,12 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         const int G = Wt / W;
         if (G > 32) continue;
         if (G > 1 && W < 2) continue;                    // (a wave polls at most ONE neighbouring workgroup's boundary slice)
-        const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * WAVE;
+        const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * (hc ? 48 : WAVE);     // (the kernel's HSL: a slice in LDS)
         const bool s_lds = sq && ssh && T == 2;            // (the kernel's S_LDS: table set of slice t0 in LDS, x in registers)
-        const bool e_lds = (sq && T >= 4) || (hc && T >= 2);
-        const size_t shm = ((size_t)W * ((sq || hc) ? 0 : T + 1) * SL + (size_t)(((sq && T >= 4) || s_lds) ? 1 : 2) * W * T * HS +
-                            (e_lds ? (size_t)W * (T + 1) * HS : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
-                            48 + 4 * HS) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS]
+        const bool e_lds = (sq && T >= 4) || (hc && T >= 2), x_reg = (sq && T >= 4) || s_lds || (hc && T >= 3);
+        const size_t shm = ((size_t)W * ((sq || hc) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
+                            (e_lds ? (hc ? ((size_t)W * T + 1) * HS : (size_t)W * (T + 1) * HS) : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
+                            48 + 4 * HS + ((hc && T >= 3) ? (size_t)W * 2 * HS : 0)) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS] (+ the halo slices of p)
         if (shm > 160 * 1024) continue;
         out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->npl = npl;
         return true;
@@ -1055,7 +1104,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
             const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.9 / 7.0 us at 1 / 2 slices per wave)
-            const double t_res = rounds * (ssh_sq ? 0.9 + 3.04 * sh.T : sh.hc ? 2.1 + 1.7 * sh.T : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
+            const double t_res = rounds * (ssh_sq ? 0.9 + 3.04 * sh.T : sh.hc ? (sh.T == 3 ? 9.7 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
                                                  : 2.0 + 0.12 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
@@ -1104,7 +1153,8 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     const dim3 grid((unsigned)(8 * R.teams_per_xcd * sh.G));
     hipError_t e = hipSuccess;
     if (sh.hc) {
-        e = (sh.T == 2) ? wg::launch_k<wg::HC_NPL, 2, false, true, 2>(h, sh, grid, B, m, R) : wg::launch_k<wg::HC_NPL, 1, false, true, 2>(h, sh, grid, B, m, R);
+        e = (sh.T == 3) ? wg::launch_k<wg::HC_NPL, 3, false, true, 2>(h, sh, grid, B, m, R)
+          : (sh.T == 2) ? wg::launch_k<wg::HC_NPL, 2, false, true, 2>(h, sh, grid, B, m, R) : wg::launch_k<wg::HC_NPL, 1, false, true, 2>(h, sh, grid, B, m, R);
     } else switch (h->npl) {
         case 1: e = wg::launch_npl<1>(h, sh, grid, B, m, R); break;
         case 2: e = wg::launch_npl<2>(h, sh, grid, B, m, R); break;
