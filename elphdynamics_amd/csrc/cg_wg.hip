@@ -334,8 +334,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) w[k][q] = ((PH_LDS && k == T) ? PHALO(1, q) : p[k + 1][q]) - sg * w[k][q];
             }
-            auto rev = [&](auto nb, int j0) {            // reverse sweeps of the slabs j0 .. j0 + nb - 1 at once (3 slices per wave: 2 + 1)
-                constexpr int NB = decltype(nb)::value;
+            // reverse sweeps of the slabs J0 .. J0 + NB - 1 at once (both compile-time: a run-time index into w would put it on the stack)
+            auto rev = [&](auto nb, auto j0c) __attribute__((always_inline)) {
+                constexpr int NB = decltype(nb)::value, j0 = decltype(j0c)::value;
                 double gq[NB][NPL];
 #pragma unroll
                 for (int i = 0; i < NB; ++i)
@@ -349,8 +350,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     for (int q = 0; q < NPL; ++q) w[j0 + i][q] = w[j0 + i][q] - sg * (EXPV(j0 + i + 1, q) * gq[i][q]);     // z(t0+j0+i)
                 }
             };
-            if constexpr (T == 3) { rev(std::integral_constant<int, 1>(), 0); rev(std::integral_constant<int, 1>(), 1); rev(std::integral_constant<int, 1>(), 2); }
-            else rev(std::integral_constant<int, T>(), 0);
+            using std::integral_constant;
+            if constexpr (T == 3) { rev(integral_constant<int, 2>(), integral_constant<int, 0>()); rev(integral_constant<int, 1>(), integral_constant<int, 2>()); }
+            else rev(integral_constant<int, T>(), integral_constant<int, 0>());
         } else if constexpr (SQ) {
 #pragma unroll
             for (int k = 0; k <= T; ++k)
