@@ -1175,7 +1175,9 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     // forward transform; the Chebyshev kernel keeps their slot bookkeeping only
     static const bool freq_rz_on = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
     const int nct = (N + 15) / 16;
-    const bool fold = cg_mode == 2 && h->fast && h->sq_P > 0 && h->lp_mc == 4 && freq_rz_on && h->d_kfold &&
+    const bool no_sq = []() { const char *e = getenv("ELPH_NO_SQ"); return e && e[0] == '1'; }();                    // (A/B: the LDS recursion, which knows no fold)
+    const bool reg_cheb = !no_sq && (h->sq_P > 0 || (h->hc12 && h->hc_uniform && h->kind == ELPH_MODEL_HOLSTEIN));     // (a register-exchange Chebyshev kernel: the one that knows the fold)
+    const bool fold = cg_mode == 2 && h->fast && reg_cheb && h->lp_mc == 4 && freq_rz_on && h->d_kfold &&
                       2 * Lo2 + nct <= B.nrz && B.dot_lo == 0 && B.dot_hi == N && elph_dft_mfma_fold_usable(h);
     if (!(parts & 1)) {
     } else if (cg_mode == 2) {
@@ -1190,7 +1192,7 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     const size_t shm = (size_t)N * sizeof(double2);
     bool rz_done = false;     // r.z partials already produced in frequency space by the Chebyshev kernel
     if (!(parts & 2)) {
-        rz_done = h->fast && h->sq_P > 0 && cg_mode;      // (timing the inverse transform alone: the form that follows the register-exchange kernel)
+        rz_done = h->fast && reg_cheb && cg_mode;      // (timing the inverse transform alone: the form that follows the register-exchange kernel)
     } else if (h->fast) {
         static const bool freq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
         const bool want = cg_mode && freq_rz && 2 * Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N;
