@@ -34,6 +34,10 @@
 
 namespace wg {
 
+#ifdef ELPH_WG_ARRIVE
+__device__ unsigned long long g_wg_arrive[4096 * 4];
+#endif
+
 // SQ: the DPP form for the 16 x 16 square lattice in the reference's colouring (NPL = 4, no LDS slabs; Holstein: uniform hopping in
 // two scalars, disordered hopping in per-site registers; SSH: a table set per time slice, SqSsh); otherwise the lane-program form
 //     FORM 0: lane program, 1: the square-lattice DPP form (SQ), 2: the honeycomb DPP form (HC: 12 x 12 cells, six sites per lane of
@@ -104,6 +108,15 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     {
 #endif
     const int rhs = tqi * 8 + xcd;
+#ifdef ELPH_WG_ARRIVE
+    // diagnostic build (tools/diag_wg_arrive.py): where and when every workgroup of the grid started — XCC_ID and the hardware id of its
+    // CU, the wall clock — to see which members a team that timed out was waiting for
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_wg_arrive[blockIdx.x * 4 + 0] = 1ull + (unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);      // XCC_ID[3:0]
+        g_wg_arrive[blockIdx.x * 4 + 1] = (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);            // HW_ID
+        g_wg_arrive[blockIdx.x * 4 + 2] = (unsigned long long)wall_clock64();
+    }
+#endif
     if (rhs >= B.nrhs) return;
     const int N = m.N, L = m.L;
     const int t0 = (g * W + wv) * T;
@@ -317,6 +330,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     STAMP_DECL;
     for (long long seq = 0;; ++seq) {
         const unsigned epoch = R.epoch0 + (unsigned)seq + (SHARD ? 2u : 1u);
+#ifdef ELPH_WG_ARRIVE
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg_arrive[blockIdx.x * 4 + 3] = (unsigned long long)seq + 1;      // iterations this workgroup has begun
+#endif
         STAMP(9);
         // ---- z = M^T M p on the own slices:  w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)]  for t = t0 .. t0+T  (T+1 forward sweeps at once),
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
@@ -1189,6 +1205,12 @@ int elph_wg_aborted(elph_handle_s *h, bool *aborted) {
     return ELPH_OK;
 }
 
+#ifdef ELPH_WG_ARRIVE
+extern "C" int elph_debug_wg_arrive(unsigned long long *out, int n_blocks, int clear) {
+    if (clear) { static unsigned long long z[4096 * 4]; return hipMemcpyToSymbol(HIP_SYMBOL(wg::g_wg_arrive), z, sizeof(z)) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(wg::g_wg_arrive), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef ELPH_WG_STAMPS
 extern "C" int elph_debug_wg_stamps(unsigned long long *out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(wg::g_wg_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
