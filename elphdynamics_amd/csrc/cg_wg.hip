@@ -111,11 +111,13 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #ifdef ELPH_WG_ARRIVE
     // diagnostic build (tools/diag_wg_arrive.py): where and when every workgroup of the grid started — XCC_ID and the hardware id of its
     // CU, the wall clock — to see which members a team that timed out was waiting for
+#ifndef ELPH_WG_ARRIVE_NOSTART
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         g_wg_arrive[blockIdx.x * 4 + 0] = 1ull + (unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);      // XCC_ID[3:0]
         g_wg_arrive[blockIdx.x * 4 + 1] = (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);            // HW_ID
         g_wg_arrive[blockIdx.x * 4 + 2] = (unsigned long long)wall_clock64();
     }
+#endif
 #endif
     if (rhs >= B.nrhs) return;
     const int N = m.N, L = m.L;
@@ -265,8 +267,14 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     }
 #define EXPV(j, q) (E_LDS ? el[(j) * HSL + lr + (q) * LSL] : E[(SSH || E_LDS) ? 0 : (j)][q])
 
-    u64 *slotsA = R.slots + (size_t)rhs * (ONE ? SLOTS_PER_RHS : 2 * 64), *slotsB = slotsA + (ONE ? SLOTS_A : 64);
-    u64 *bnd = R.bnd + (size_t)rhs * G * 2 * HS * 2;     // [G][first | last slice][HS][2 granules]
+    // records and boundary granules exist TWICE, by the parity of the iteration: a workgroup that has met for iteration k goes on and
+    // publishes its record of k + 1 one mat-vec later — into the OTHER set, so that a member that is late reading the records of k
+    // (its polling wave held up: two workgroups sharing a CU, a time-sliced GPU) still finds them; nobody can reach k + 2 before that
+    // member has published k + 1, i.e. finished reading k.  (With ONE set such a member waited for tags that had already moved on —
+    // the time-out of the experimental 4-wave shape, tools/diag_wg_arrive.py.)
+    constexpr size_t SLOTS_RHS = ONE ? SLOTS_PER_RHS : 2 * 64;
+    u64 *const slots0 = R.slots + (size_t)rhs * 2 * SLOTS_RHS;
+    u64 *const bnd0 = R.bnd + (size_t)rhs * 2 * G * 2 * HS * 2;     // [parity][G][first | last slice][HS][2 granules]
     const int gm = (g == 0) ? G - 1 : g - 1, gp = (g == G - 1) ? 0 : g + 1;
     double rho = S.rho, kmin = S.kmin, eps = S.eps;
     double eps0 = S.eps0, normb = S.normb;
@@ -330,9 +338,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     STAMP_DECL;
     for (long long seq = 0;; ++seq) {
         const unsigned epoch = R.epoch0 + (unsigned)seq + (SHARD ? 2u : 1u);
-#ifdef ELPH_WG_ARRIVE
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg_arrive[blockIdx.x * 4 + 3] = (unsigned long long)seq + 1;      // iterations this workgroup has begun
-#endif
+        const unsigned par = epoch & 1u;
+        u64 *const slotsA = slots0 + (size_t)par * SLOTS_RHS, *const slotsB = slotsA + (ONE ? SLOTS_A : 64);
+        u64 *const bnd = bnd0 + (size_t)par * G * 2 * HS * 2;
+        const size_t ghp = SHARD ? (size_t)par * 2 * L * Sh.cap_ghost * 2 : 0;      // (a shard: the ghost rows of z in the mailboxes, by parity too)
         STAMP(9);
         // ---- z = M^T M p on the own slices:  w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)]  for t = t0 .. t0+T  (T+1 forward sweeps at once),
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
@@ -470,11 +479,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 const int s = lane + q * WAVE;
                 const u64 bits = (u64)__double_as_longlong(z[0][q]), tag = (u64)epoch << 32;
                 if (s >= Sh.own_lo && s < Sh.own_lo + Sh.n_to_prev) {              // bottom rows -> previous rank's ghosts above its own rows
-                    u64 *d = sh_ghost(Sh.mail[prev], 1, L, Sh.cap_ghost, t0, s - Sh.own_lo);
+                    u64 *d = sh_ghost(Sh.mail[prev], 1, L, Sh.cap_ghost, t0, s - Sh.own_lo) + ghp;
                     st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
                 }
                 if (s >= Sh.own_hi - Sh.n_to_next && s < Sh.own_hi) {              // top rows -> next rank's ghosts below its own rows
-                    u64 *d = sh_ghost(Sh.mail[next], 0, L, Sh.cap_ghost, t0, s - (Sh.own_hi - Sh.n_to_next));
+                    u64 *d = sh_ghost(Sh.mail[next], 0, L, Sh.cap_ghost, t0, s - (Sh.own_hi - Sh.n_to_next)) + ghp;
                     st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
                 }
             }
@@ -507,7 +516,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             // each).  Meanwhile every wave takes the ghost rows of z of its slice from the own mailbox, the two boundary waves also
             // the neighbouring workgroup's boundary slice of z (own rows from that workgroup, ghost rows from the mailbox).
             const int rw = (W >= 3) ? 1 : 0;
-            u64 *rankrec = Sh.mail[Sh.rank] + (size_t)SH_MAXREC * 2;          // [P][8 granules] (the area of round 2's second meeting)
+            u64 *rankrec = Sh.mail[Sh.rank] + (size_t)SH_MAXREC * 2 + (size_t)par * 8 * REC4;      // [parity][P <= 8][8 granules] (the area of round 2's second meeting)
             bool ok = true;
             if (wv == rw) publish_rec4(slotsA, g, sum_part4(part, W, lane), epoch, lane);
             {   // ghost rows of the own slice (+ the halo slice of a boundary wave)
@@ -519,8 +528,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 for (int q = 0; q < NPL; ++q) {
                     const int s = lane + q * WAVE;
                     ga2[q] = !bw ? nullptr
-                           : (s < Sh.own_lo) ? sh_ghost(Sh.mail[Sh.rank], 0, L, Sh.cap_ghost, th, s)
-                           : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, th, s - Sh.own_hi) : nullptr;
+                           : (s < Sh.own_lo) ? sh_ghost(Sh.mail[Sh.rank], 0, L, Sh.cap_ghost, th, s) + ghp
+                           : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, th, s - Sh.own_hi) + ghp : nullptr;
                 }
                 u64 a0[NPL], a1[NPL], h0[NPL], h1[NPL], c0[NPL], c1[NPL];
                 long long t_start = 0;
@@ -528,7 +537,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     bool good = true;
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
-                        if (gaddr[q]) { a0[q] = ld_sys(gaddr[q]); a1[q] = ld_sys(gaddr[q] + 1); }
+                        if (gaddr[q]) { a0[q] = ld_sys(gaddr[q] + ghp); a1[q] = ld_sys(gaddr[q] + ghp + 1); }
                         if (bh) { h0[q] = ld_gran(bh + 2 * (lane + q * WAVE)); h1[q] = ld_gran(bh + 2 * (lane + q * WAVE) + 1); }
                         if (ga2[q]) { c0[q] = ld_sys(ga2[q]); c1[q] = ld_sys(ga2[q] + 1); }
                     }
@@ -560,7 +569,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     const double mine = __shfl(t4, lane & 6, WAVE);            // lane l: the total of value (l & 7) >> 1
                     if (lane < 8 * Sh.P) {
                         const u64 bits = (u64)__double_as_longlong(mine);
-                        st_sys(Sh.mail[lane >> 3] + (size_t)SH_MAXREC * 2 + (size_t)Sh.rank * REC4 + (lane & 7),
+                        st_sys(Sh.mail[lane >> 3] + (size_t)SH_MAXREC * 2 + (size_t)par * 8 * REC4 + (size_t)Sh.rank * REC4 + (lane & 7),
                                ((u64)epoch << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
                     }
                 }
@@ -613,6 +622,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             }
             if (wv == rw && lane < 8 && !(lane & 1)) tot[lane >> 1] = t4;
             if (!ok && lane == 0) tot[5] = 0.0;
+#ifdef ELPH_WG_ARRIVE
+            if (!ok && lane == 0 && blockIdx.x < 4096) g_wg_arrive[blockIdx.x * 4 + 3] = ((unsigned long long)(seq + 1) << 8) | (1ull << wv);   // iteration and wave of a poll that gave up
+#endif
             wg_barrier();
             if (tot[5] == 0.0) return;
             pap = tot[0]; rz = tot[1]; zz = tot[2]; rr0 = tot[3];
@@ -1129,7 +1141,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         }
     }
     const size_t HS = (size_t)sh.npl * WAVE;
-    const size_t n_slots = (size_t)nrhs * wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? (size_t)nrhs * sh.G * 2 * HS * 2 : 0;
+    const size_t n_slots = 2 * (size_t)nrhs * wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? 2 * (size_t)nrhs * sh.G * 2 * HS * 2 : 0;      // (x 2: by the parity of the iteration)
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
     // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
     // 32-bit range wraps.  The abort word sits at the END of the allocation (its place must not move with the batch size).
@@ -1234,7 +1246,7 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
         sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 48 + 4 * HS) * sizeof(double);     // + partials, totals, rhalo[2][HS], zhalo[2][HS]
     }
     const size_t HS = (size_t)h->npl * WAVE;
-    const size_t n_slots = wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? (size_t)sh.G * 2 * HS * 2 : 0;
+    const size_t n_slots = 2 * wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? 2 * (size_t)sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
     // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
     // 32-bit range wraps.  The abort word sits at the END of the allocation (its place must not move with the batch size).

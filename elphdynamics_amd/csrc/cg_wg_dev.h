@@ -552,7 +552,7 @@ __device__ __forceinline__ void wg_barrier() {
 //     together with the second meeting — ONE exchange of the checkerboard boundary rows per iteration;
 //   * the solve starts from x = 0 inside the kernel (r0 = p0 = b, |b|^2 by a first meeting): no host-side combination.
 // Mailbox (identical layout on every rank): [2 meetings][ELPH_SHARD_MAXREC = 256 records][2 granules] then ghost rows from below / from above
-// [Ltau][cap_ghost][2 granules] each.  It is zeroed by elph_shard_prepare; the caller's barrier between prepare and solve
+// [Ltau][cap_ghost][2 granules] each, the pair once per parity of the iteration (k_cg_wg adds the parity's offset itself).  It is zeroed by elph_shard_prepare; the caller's barrier between prepare and solve
 // keeps a fast rank's first stores from being wiped.
 // ------------------------------------------------------------------------------------------------------------------------
 using ShardCtl = ElphShardCtl;                   // elph_internal.h

@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(512) k_pcg_wg(CgBufs B, ModelDev m, WgCtl R, P
     SqCtx<true> X;
     X.yx = sq_patch_ycross(lane);
     X.c[0][0] = m.c_uni; X.s[0][0] = m.s_uni / m.c_uni; X.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
-    u64 *slotsA = R.slots + (size_t)rhs * SLOTS_PER_RHS, *slotsB = slotsA + SLOTS_A;
+    u64 *const slots0 = R.slots + (size_t)rhs * 2 * SLOTS_PER_RHS;      // (records by the parity of the iteration: cg_wg.hip)
     double rho = S.rho, kmin = S.kmin, eps = S.eps;
     const double eps0 = S.eps0, normb = S.normb;
     if (S.done || S.seq != 0) {                          // (the host guarantees a fresh solve; tell the helpers if not)
@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(512) k_pcg_wg(CgBufs B, ModelDev m, WgCtl R, P
     PST_DECL;
     for (long long seq = 0;; ++seq) {
         const unsigned epoch = R.epoch0 + (unsigned)seq + 1u;
+        u64 *const slotsA = slots0 + (size_t)(epoch & 1u) * SLOTS_PER_RHS, *const slotsB = slotsA + SLOTS_A;
         PST(11);
         // ---- z = M^T M p on the own slices (cg_wg.hip, DPP form) -----------------------------------------------------------------------
         double (&w)[T + 1][NPL] = zw;
@@ -566,7 +567,7 @@ int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_ite
     if (!B.params.use_prec || !pcg_shape(h, nrhs, &W, &G, &nt)) return ELPH_OK;
     ModelDev m = elph_model_dev(h);
     if (!m.uniform || !m.sq_bond) return ELPH_OK;
-    const size_t n_slots = (size_t)nrhs * wg::SLOTS_PER_RHS, n_flags = (size_t)nrhs * wg::PCG_FLAGS;
+    const size_t n_slots = 2 * (size_t)nrhs * wg::SLOTS_PER_RHS, n_flags = (size_t)nrhs * wg::PCG_FLAGS;
     const size_t need = (n_slots + n_flags) * sizeof(wg::u64) + 64;
     const unsigned long long span = (unsigned long long)std::min<long long>(fixed_iters > 0 ? fixed_iters : B.params.maxiter, 1LL << 30) + 2;
     bool zero = false;

@@ -39,11 +39,11 @@ struct ShardState {
 
 // mailbox layout (u64 words), identical on all ranks:
 //   [2][ELPH_SHARD_MAXREC][2]   records of the resident kernel's two meetings
-//   [2][Ltau][cap][2]           ghost rows from below / from above
+//   [2][2][Ltau][cap][2]        ghost rows from below / from above, once per parity of the iteration
 //   [8][8][2] + [8]             streaming form: records of up to 8 named all-sums (one 2-granule record per rank) + spectrum flags
 //   [Lo2][n_global][2]          spectrum nu of the whole lattice (16-byte complex), written by all ranks (KPM apply)
 static size_t mailbox_words(int64_t L, int cap, int64_t n_global, size_t *ext_off, size_t *nu_off) {
-    size_t w = 2 * (size_t)ELPH_SHARD_MAXREC * 2 + 2 * (size_t)L * (size_t)cap * 2;
+    size_t w = 2 * (size_t)ELPH_SHARD_MAXREC * 2 + 2 * 2 * (size_t)L * (size_t)cap * 2;      // (ghost regions twice: by the parity of the iteration)
     if (ext_off) *ext_off = w;
     w += 8 * 8 * 2 + 8;
     if (nu_off) *nu_off = w;

@@ -16,13 +16,17 @@ grid = 8 * ((nr + 7) // 8) * G.value
 print(f"{tag} nrhs={nr}: T={T.value} W={W.value} G={G.value} grid={grid}")
 lib.elph_debug_wg_arrive(None, 0, 1)
 ms = C.c_double()
-check(lib.elph_bench_prepare(m._h, 1, nr, _lib.dptr(np.ascontiguousarray(Bs))))
-rc = lib.elph_bench_run(m._h, 9, nr, 200, 0, C.byref(ms))
-print("run rc", rc, lib.elph_last_error().decode() if rc else f"{1e3*ms.value/200:.2f} us/iter")
+rc = 0
+for reps in [int(v) for v in os.environ.get("REPS", "200,1000").split(",")]:
+    check(lib.elph_bench_prepare(m._h, 1, nr, _lib.dptr(np.ascontiguousarray(Bs))))
+    rc = lib.elph_bench_run(m._h, 9, nr, reps, 0, C.byref(ms))
+    print("run of", reps, "iterations: rc", rc, lib.elph_last_error().decode() if rc else f"{1e3*ms.value/reps:.2f} us/iter", flush=True)
+    if rc:
+        break
 out = (C.c_ulonglong * (4 * grid))()
 assert lib.elph_debug_wg_arrive(out, grid, 0) == 0
 a = np.array(out[:]).reshape(grid, 4)
-arrived = a[:, 0] > 0
+arrived = (a[:, 0] > 0) if (a[:, 0] > 0).any() else np.ones(grid, dtype=bool)      # (a build without the start records, ARRIVE_EXTRA=-DELPH_WG_ARRIVE_NOSTART: everything counts as arrived)
 t0 = a[arrived, 2].min() if arrived.any() else 0
 print("arrived", int(arrived.sum()), "of", grid)
 xcc = (a[:, 0] - 1) & 0xF
@@ -42,7 +46,8 @@ for x in range(8):
     prog = {}
     for b in arr:
         prog.setdefault((b >> 3) // G.value, []).append(int(a[b, 3]))
-    print(f"   iterations begun per team (min..max over its workgroups): " + ", ".join(f"team {t}: {min(v)}..{max(v)}" for t, v in sorted(prog.items())))
+    print("   polls that gave up, per team [(workgroup in team, iteration, wave mask)]: " +
+          "; ".join(f"team {t}: " + str([(i, v >> 8, v & 255) for i, v in enumerate(vs) if v][:8]) for t, vs in sorted(prog.items())))
     late = sorted(((int(a[b, 2]) - int(t0)) / 100.0, b >> 3) for b in arr)[-3:]
     print(f"XCD {x}: arrived {len(arr)} of {len(idx)}; never started (index in XCD): {miss[:24]}; workgroups per CU max {max(cu.values()) if cu else 0} on {len(cu)} CUs; latest starts (us, index) {late}")
 m.close()
