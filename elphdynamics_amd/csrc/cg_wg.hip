@@ -1122,9 +1122,9 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // profiles/r02/time_forms.log; us per iteration of the batch):
     //   resident  = rounds x (2.0 + 0.12 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
     //               rounds x (2.66 + 0.01 G + 0.62 T)   DPP form         (single-meeting iteration, round 3: 3.5 / 4.0 / 5.2 us at 1 / 2 / 4 slices)
-    //               rounds x (0.9 + 3.04 T)   DPP form with bond phonons (E: 3.9 / 7.0 us);   rounds x (2.1 + 1.7 T)   honeycomb DPP form (D: 3.8 / 5.5 us)
+    //               rounds x (2.5 + 1.3 T)   DPP form with bond phonons (E: 3.8 / 5.1 us);   rounds x (2.1 + 1.7 T)   honeycomb DPP form (D: 3.8 / 5.5 us; 9.7 at 3 slices)
     //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
-    // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 8.5 M against 4.2 M; E: 6.8 M against 3.2 M);
+    // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 8.9 M against 4.2 M; E: 9.7 M against 3.2 M);
     // the rule still decides for other lattices and time axes.  A deterministic rule
     // (never a timing at run time): which form runs decides the last bits of a solution.
     // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
@@ -1133,8 +1133,8 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
         if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
-            const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.9 / 7.0 us at 1 / 2 slices per wave)
-            const double t_res = rounds * (ssh_sq ? 0.9 + 3.04 * sh.T : sh.hc ? (sh.T == 3 ? 9.7 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
+            const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.8 / 5.1 us at 1 / 2 slices per wave)
+            const double t_res = rounds * (ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 9.7 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
                                                  : 2.0 + 0.12 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
