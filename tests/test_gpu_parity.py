@@ -1479,6 +1479,31 @@ def test_wg_resident_cg_honeycomb_and_ssh_batches_vs_oracle(oracle):
         m.close()
 
 
+def test_wg_resident_cg_two_workgroups_per_cu_do_not_lose_records(monkeypatch):
+    """The experimental 4-wave shape (ELPH_WG_W=4: two workgroups per CU, teams of 20, three teams per XCD) — the shape in which a member
+    of a team was late enough READING the records of iteration k to find those of k + 1 in their place while the slots were re-used
+    every iteration (time-out within a few hundred iterations; profiles/r03/wg_record_reuse_stall.log).  With records, boundary granules
+    and ghost rows double-buffered by the parity of the iteration the solves complete in the resident kernel — no fallback — and
+    agree with the default shape."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("C", tol=1e-9)
+    R, B = configs.rhs(m, 24)
+    X0 = np.zeros_like(B)
+    it0, res0, fl0 = models.ldiv_batched_(X0, m, B)
+    assert not fl0.any()
+    monkeypatch.setenv("ELPH_WG_T", "2")
+    monkeypatch.setenv("ELPH_WG_W", "4")
+    monkeypatch.setenv("ELPH_WG_TIMEOUT_MS", "500")
+    usable, T, W, G = _wg_info(m, 24)
+    assert usable == 1 and (T, W, G) == (2, 4, 20)
+    for _ in range(3):                      # ~1400 iterations each
+        X1 = np.zeros_like(B)
+        it1, res1, fl1 = models.ldiv_batched_(X1, m, B)
+        assert not fl1.any() and _wg_status(m) == (0, 0), _wg_status(m)
+        assert np.max(np.abs(it1 - it0)) <= 3 and rel(X1, X0) < 1e-7      # (another team shape: other summation trees)
+    m.close()
+
+
 def test_wg_resident_cg_shape_pin_makes_bits_independent_of_the_batch(monkeypatch):
     """Which team shape runs decides the last bits of a solution (another summation tree), and the shape follows the batch size
     (config C: 1 slice per wave up to 8 right-hand sides, 2 up to 24, 4 above).  ELPH_WG_T pins it: with the pin a right-hand side's solution
