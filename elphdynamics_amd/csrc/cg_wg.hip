@@ -72,6 +72,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // (honeycomb: neighbouring waves SHARE the slice of exp(-dtau V) between them — [W T + 1] slices per workgroup instead of W (T + 1);
     //  both write the same values to it)
     constexpr bool E_SHARED = HC;
+    // honeycomb, 3 slices per wave: x lives in MEMORY (it is touched once per iteration, x += alpha p): its slices are loaded behind the
+    // sums — the meeting that follows hides the round trip — and stored back by the update; between two updates no register holds it
+    constexpr bool X_GLB = HC && T >= 3;
     // honeycomb, 3 slices per wave: the two HALO slices of p wait in LDS between the p-update that makes them and the mat-vec that
     // consumes them (24 registers that would otherwise sit through both sweeps)
     constexpr bool PH_LDS = HC && T >= 3;
@@ -175,7 +178,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             if (lwok) rl[j * HSL + lr + q * LSL] = rg[(size_t)(t0 + j) * N + sc[q]];
-            if (X_REG) xr[X_REG ? j : 0][q] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
+            if (X_GLB) {}      // (x0 is where it is: the caller's initial guess in memory)
+            else if (X_REG) xr[X_REG ? j : 0][q] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
             else if (lwok) xl[j * HSL + lr + q * LSL] = X0Z ? 0.0 : xg[(size_t)(t0 + j) * N + sc[q]];
         }
 #pragma unroll
@@ -470,6 +474,12 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             const double k4 = wave_sum4(s_pz, s_rz, s_zz, s_rr, lane);
             if (lane < 4) part[lane * 8 + wv] = k4;
         }
+        if constexpr (X_GLB) {
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) xr[X_REG ? j : 0][q] = xg[(size_t)(t0 + j) * N + sc[q]];
+        }
         if constexpr (SHARD) {
             // the rows of z my rank neighbours hold as ghosts: straight into their mailboxes (device-initiated stores over xGMI),
             // self-tagged — with alpha from the meeting the neighbour makes its ghost rows of the new residual itself
@@ -641,7 +651,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 const double zq = (SHARD && gaddr[q]) ? gz[q] : z[j][q];                           // (a shard's ghost rows: the owner's z)
                 const double rn = rl[j * HSL + lr + q * LSL] - alpha * zq;                          // :285
                 if (lwok) rl[j * HSL + lr + q * LSL] = rn;
-                if (X_REG) xr[X_REG ? j : 0][q] += alpha * p[j + 1][q];                            // :282
+                if (X_GLB) { if (lwok) xg[(size_t)(t0 + j) * N + sc[q]] = xr[X_REG ? j : 0][q] + alpha * p[j + 1][q]; }
+                else if (X_REG) xr[X_REG ? j : 0][q] += alpha * p[j + 1][q];                       // :282
                 else if (lwok) xl[j * HSL + lr + q * LSL] += alpha * p[j + 1][q];
             }
         if (G > 1 && (wv == 0 || wv == W - 1)) {              // the neighbouring workgroup's boundary slice of the new residual
@@ -905,7 +916,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
                         if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HSL + lr + q * LSL];
-                        xg[(size_t)(t0 + j) * N + s2] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HSL + lr + q * LSL];
+                        if (!X_GLB) xg[(size_t)(t0 + j) * N + s2] = X_REG ? xr[X_REG ? j : 0][q] : xl[j * HSL + lr + q * LSL];
                     }
                 }
             if (g == 0 && wv == 0 && lane == 0) {
@@ -988,15 +999,16 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     for (int T : cand) {
         if (forceT && T != forceT) continue;
         if (T == 3) {
-            // honeycomb form only: 48 right-hand sides per round instead of 24 at 2 slices per wave, but 9.7 us per iteration against 5.5
-            // (the kernel spills 69 registers: six sites per lane x three slices is more than the register file and the LDS hold next to
-            // each other) — taken when the rounds it saves outweigh that: 25-48, 73-96, 121-144, ... and everything from 217 on
+            // honeycomb form only: 48 right-hand sides per round instead of 24 at 2 slices per wave, but 8.6 us per iteration against 5.7
+            // (the kernel still spills 42 registers: six sites per lane x three slices is more than the register file and the LDS hold
+            // next to each other, even with x in memory) — taken when the rounds it saves outweigh that: 25-48 and everything from 73
+            // right-hand sides on
             if (!hc || L % 3 || L % 2) continue;
             if (forceT != 3) {
                 const int G2 = (L / 2) / largest_divisor_le8(L / 2), G3 = (L / 3) / largest_divisor_le8(L / 3);
                 if (G2 > 32 || G3 > 32) continue;
                 const int r2 = 8 * (32 / G2), r3 = 8 * (32 / G3);
-                if (nrhs <= r2 || 9.7 * ((nrhs + r3 - 1) / r3) >= 5.5 * ((nrhs + r2 - 1) / r2)) continue;
+                if (nrhs <= r2 || 8.6 * ((nrhs + r3 - 1) / r3) >= 5.7 * ((nrhs + r2 - 1) / r2)) continue;
             }
         }
         if (T == 4) {
@@ -1134,7 +1146,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
             const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.8 / 5.1 us at 1 / 2 slices per wave)
-            const double t_res = rounds * (ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 9.7 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
+            const double t_res = rounds * (ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
                                                  : 2.0 + 0.12 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
