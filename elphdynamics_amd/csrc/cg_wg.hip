@@ -995,6 +995,27 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     const int L = (int)h->L;
     const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m);
     const int npl = hc ? HC_NPL : h->npl;
+    // one site per lane (the 8 x 8 lattice: config B): the whole time axis fits ONE workgroup — up to 8 waves of 4, 5 or 8 slices — and
+    // a team of one needs no records, no boundary granules, no polls: its meeting is an LDS reduction and a barrier, and a round holds
+    // 256 right-hand sides.  Its iteration is longer (config B: 6.3 us at 5 slices per wave against 3.5 at 2 with teams of four), so it
+    // is the shape of batches beyond one round of 2 slices per wave (B: 64): 256 right-hand sides 14.0 -> 6.4 us = 36 -> 80 M mat-vecs/s
+    bool big_batch = true;
+    if (!forceT && L % 2 == 0) {
+        const int G2 = (L / 2) / largest_divisor_le8(L / 2);
+        big_batch = G2 <= 32 && nrhs > 8 * (32 / G2);
+    }
+    if (!ssh && !sq && !hc && h->npl == 1 && big_batch) {
+        const int one[3] = {4, 5, 8};
+        for (int T : one) {
+            if ((forceT && T != forceT) || L % T || L / T > 8 || L / T < 2) continue;
+            const int W = L / T;
+            const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * WAVE;
+            const size_t shm = ((size_t)W * (T + 1) * SL + 2 * (size_t)W * T * HS + 48 + 4 * HS) * sizeof(double);
+            if (shm > 160 * 1024) continue;
+            out->T = T; out->W = W; out->G = 1; out->shm = shm; out->sq = false; out->hc = false; out->npl = npl;
+            return true;
+        }
+    }
     const int cand[4] = {4, 3, 2, 1};
     for (int T : cand) {
         if (forceT && T != forceT) continue;
@@ -1088,6 +1109,11 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
         if constexpr (NPL <= 4) { if (sh.T == 2) return launch_k<NPL, 2, true, false, 0>(h, sh, grid, B, m, R); }
         return launch_k<NPL, 1, true, false, 0>(h, sh, grid, B, m, R);
     }
+    if constexpr (NPL == 1) {       // (one workgroup per right-hand side: pick_shape)
+        if (sh.T == 4) return m.uniform ? launch_k<1, 4, false, true, 0>(h, sh, grid, B, m, R) : launch_k<1, 4, false, false, 0>(h, sh, grid, B, m, R);
+        if (sh.T == 5) return m.uniform ? launch_k<1, 5, false, true, 0>(h, sh, grid, B, m, R) : launch_k<1, 5, false, false, 0>(h, sh, grid, B, m, R);
+        if (sh.T == 8) return m.uniform ? launch_k<1, 8, false, true, 0>(h, sh, grid, B, m, R) : launch_k<1, 8, false, false, 0>(h, sh, grid, B, m, R);
+    }
     if constexpr (NPL <= 5) {
         if (sh.T == 2) return m.uniform ? launch_k<NPL, 2, false, true, 0>(h, sh, grid, B, m, R) : launch_k<NPL, 2, false, false, 0>(h, sh, grid, B, m, R);
     }
@@ -1147,7 +1173,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
             const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.8 / 5.1 us at 1 / 2 slices per wave)
             const double t_res = rounds * (ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
-                                                 : 2.0 + 0.12 * sh.G + 0.5 * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
+                                                 : 2.0 + 0.12 * sh.G + (sh.T >= 4 ? 0.85 : 0.5) * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
         }

@@ -1422,6 +1422,28 @@ def test_wg_resident_cg_large_batch_shape():
     m.close()
 
 
+def test_wg_resident_cg_one_workgroup_per_rhs_shape(oracle):
+    """Config B (8 x 8, one site per lane): a batch beyond one round of 2 slices per wave (64 right-hand sides) runs the whole time
+    axis of a right-hand side in ONE workgroup (8 waves x 5 slices, a team of one: no records, no polls; 256 per round) — against
+    single solves (teams of four) and, solved to 1e-13, against the oracle at 1e-10."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("B", tol=1e-13, maxiter=20000)
+    nrhs = 70
+    assert _wg_info(m)[1:] == (2, 5, 4) and _wg_info(m, nrhs)[1:] == (5, 8, 1)
+    om = _oracle_model(oracle, m)
+    R, B = configs.rhs(m, nrhs)
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    assert not fl.any() and (res < 1e-12).all()
+    for i in (0, 33, 69):
+        x = np.zeros(m.Ndim)
+        it1, res1, fl1 = models.ldiv_(x, m, np.ascontiguousarray(B[i]))
+        assert abs(it1 - it[i]) <= 3 and rel(X[i], x) < 1e-10, i
+        xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(B[i]), solver_tol=1e-13, solver_maxiter=20000)
+        assert flo == 0 and rel(X[i], xo) < 1e-10, (i, rel(X[i], xo))
+    m.close()
+
+
 def test_wg_resident_cg_bench_shape_vs_oracle(oracle):
     """The shape bench.py times — config C, independent chains side by side (right-hand side r on the matrix of chain r % nchains), a
     batch large enough for 4 slices per wave (T = 4, G = 5) — against the ORACLE directly: every checked right-hand side, solved to
