@@ -46,7 +46,8 @@ __device__ unsigned long long g_wg_arrive[4096 * 4];
 // X0Z: the initial guess is known to be zero (the library zeroed it for this solve): x0 is not read
 template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
-    constexpr bool SQ = FORM == 1, HC = FORM == 2, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    static_assert(!S8 || (NPL == 1 && UNI && !SSH && !SHARD), "8 x 8 DPP form: one site per lane, uniform hopping");
     static_assert(!SHARD || (T == 1 && !REGX), "sharded solves: one slice per wave, lane-program form");
     static_assert(!HC || (NPL == HC_NPL && UNI && !SSH && T <= 3), "honeycomb DPP form: six sites per lane, uniform hopping");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     bool live[NPL], own[NPL];                          // own: the site enters the inner products (a shard counts its own rows only)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : lane + q * WAVE);
+        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : (S8 ? s8_site(lane) : lane + q * WAVE));
         live[q] = REGX || s < N;                          // (DPP forms: every register of every lane holds a site — no selects in the sums)
         own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : (HC ? hc_real(lane) : live[q]);     // (honeycomb: mirror lanes carry copies)
         sc[q] = live[q] ? s : N - 1;
@@ -202,7 +203,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     SqCtx<UNI> X;
     SqSsh<NSREG, S_LDS> XS;
     HcCtx XH;
-    if constexpr (HC) {
+    S8Ctx X8;
+    if constexpr (S8) {
+        X8.th = m.s_uni / m.c_uni; X8.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
+        X8.yx = sq_patch_ycross(lane); X8.xodd = (lane >> 1) & 1;
+    } else if constexpr (HC) {
         XH.th = m.s_uni / m.c_uni; XH.k3 = m.c_uni * m.c_uni * m.c_uni;
         XH.up = (lane + 16) & (WAVE - 1); XH.dn = (lane + 48) & (WAVE - 1);
     } else if constexpr (SQ && SSH) {
@@ -351,7 +356,19 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
         // (w and z share registers: z(t0+j) overwrites w(t0+j) once the reverse sweep of w(t0+j+1) has been taken)
         double (&w)[T + 1][NPL] = zw;
-        if constexpr (HC) {
+        if constexpr (S8) {
+#pragma unroll
+            for (int k = 0; k <= T; ++k) w[k][0] = EXPV(k, 0) * p[k][0];
+            s8_sweepN<T + 1, false>(w, X8);
+#pragma unroll
+            for (int k = 0; k <= T; ++k) w[k][0] = p[k + 1][0] - sgn(wrap(t0 + k)) * X8.k4 * w[k][0];
+            double gq[T][1];
+#pragma unroll
+            for (int i = 0; i < T; ++i) gq[i][0] = w[i + 1][0];
+            s8_sweepN<T, true>(gq, X8);
+#pragma unroll
+            for (int i = 0; i < T; ++i) w[i][0] = w[i][0] - sgn(wrap(t0 + i + 1)) * X8.k4 * (EXPV(i + 1, 0) * gq[i][0]);      // z(t0+i)
+        } else if constexpr (HC) {
 #pragma unroll
             for (int k = 0; k <= T; ++k)
 #pragma unroll
@@ -911,7 +928,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int j = 0; j < T; ++j)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
-                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : lane2 + q * WAVE);
+                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : (S8 ? s8_site(lane2) : lane2 + q * WAVE));
                     if (HC ? hc_real(lane2) : (SQ || s2 < N)) {
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
@@ -970,7 +987,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 // host side
 // ------------------------------------------------------------------------------------------
 
-struct Shape { int T, W, G; size_t shm; bool sq, hc; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6)
+struct Shape { int T, W, G; size_t shm; bool sq, hc, s8; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6)
 
 // DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square)
 static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
@@ -989,11 +1006,17 @@ static bool hc_form(const elph_handle_s *h, const ModelDev &m) {
     return h->kind == ELPH_MODEL_HOLSTEIN && h->hc12 && m.uniform && !(e && e[0] == '1');
 }
 
+// 8 x 8 DPP form: Holstein with uniform hopping on the 8 x 8 square lattice in the reference's colouring (detect_square: sq_P = 1)
+static bool s8_form(const elph_handle_s *h, const ModelDev &m) {
+    const char *e = getenv("ELPH_WG_NO_DPP");
+    return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 1 && h->N == 64 && m.uniform && !(e && e[0] == '1');
+}
+
 static int largest_divisor_le8(int n, int cap = 8) { for (int w = std::min(cap, n); w >= 1; --w) if (n % w == 0) return w; return 1; }
 
 static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, int nrhs, Shape *out) {
     const int L = (int)h->L;
-    const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m);
+    const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m), s8 = !sq && !hc && s8_form(h, m);
     const int npl = hc ? HC_NPL : h->npl;
     // one site per lane (the 8 x 8 lattice: config B): the whole time axis fits ONE workgroup — up to 8 waves of 4, 5 or 8 slices — and
     // a team of one needs no records, no boundary granules, no polls: its meeting is an LDS reduction and a barrier, and a round holds
@@ -1004,15 +1027,17 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         const int G2 = (L / 2) / largest_divisor_le8(L / 2);
         big_batch = G2 <= 32 && nrhs > 8 * (32 / G2);
     }
-    if (!ssh && !sq && !hc && h->npl == 1 && big_batch) {
+    // (the 8 x 8 DPP form: the team of one is the fastest shape at every batch size — 2.04 us per iteration for one right-hand side, 2.3 us
+    //  for 256 = 222 M mat-vecs/s — its sweeps are a few dozen register moves)
+    if (!ssh && !sq && !hc && h->npl == 1 && (big_batch || s8)) {
         const int one[3] = {4, 5, 8};
         for (int T : one) {
             if ((forceT && T != forceT) || L % T || L / T > 8 || L / T < 2) continue;
             const int W = L / T;
             const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * WAVE;
-            const size_t shm = ((size_t)W * (T + 1) * SL + 2 * (size_t)W * T * HS + 48 + 4 * HS) * sizeof(double);
+            const size_t shm = ((size_t)W * (s8 ? 0 : T + 1) * SL + 2 * (size_t)W * T * HS + 48 + 4 * HS) * sizeof(double);
             if (shm > 160 * 1024) continue;
-            out->T = T; out->W = W; out->G = 1; out->shm = shm; out->sq = false; out->hc = false; out->npl = npl;
+            out->T = T; out->W = W; out->G = 1; out->shm = shm; out->sq = false; out->hc = false; out->s8 = s8; out->npl = npl;
             return true;
         }
     }
@@ -1067,11 +1092,11 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * (hc ? 48 : WAVE);     // (the kernel's HSL: a slice in LDS)
         const bool s_lds = sq && ssh && T == 2;            // (the kernel's S_LDS: table set of slice t0 in LDS, x in registers)
         const bool e_lds = (sq && T >= 4) || (hc && T >= 2), x_reg = (sq && T >= 4) || s_lds || (hc && T >= 3);
-        const size_t shm = ((size_t)W * ((sq || hc) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
+        const size_t shm = ((size_t)W * ((sq || hc || s8) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
                             (e_lds ? (hc ? ((size_t)W * T + 1) * HS : (size_t)W * (T + 1) * HS) : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
                             48 + 4 * HS + ((hc && T >= 3) ? (size_t)W * 2 * HS : 0)) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS] (+ the halo slices of p)
         if (shm > 160 * 1024) continue;
-        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->npl = npl;
+        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->s8 = s8; out->npl = npl;
         return true;
     }
     return false;
@@ -1108,6 +1133,17 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
     if (h->kind == ELPH_MODEL_SSH) {
         if constexpr (NPL <= 4) { if (sh.T == 2) return launch_k<NPL, 2, true, false, 0>(h, sh, grid, B, m, R); }
         return launch_k<NPL, 1, true, false, 0>(h, sh, grid, B, m, R);
+    }
+    if constexpr (NPL == 1) {
+        if (sh.s8) {                // (the 8 x 8 DPP form)
+            switch (sh.T) {
+                case 8: return launch_k<1, 8, false, true, 4>(h, sh, grid, B, m, R);
+                case 5: return launch_k<1, 5, false, true, 4>(h, sh, grid, B, m, R);
+                case 4: return launch_k<1, 4, false, true, 4>(h, sh, grid, B, m, R);
+                case 2: return launch_k<1, 2, false, true, 4>(h, sh, grid, B, m, R);
+                default: return launch_k<1, 1, false, true, 4>(h, sh, grid, B, m, R);
+            }
+        }
     }
     if constexpr (NPL == 1) {       // (one workgroup per right-hand side: pick_shape)
         if (sh.T == 4) return m.uniform ? launch_k<1, 4, false, true, 0>(h, sh, grid, B, m, R) : launch_k<1, 4, false, false, 0>(h, sh, grid, B, m, R);
@@ -1160,6 +1196,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     // profiles/r02/time_forms.log; us per iteration of the batch):
     //   resident  = rounds x (2.0 + 0.12 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
     //               rounds x (2.66 + 0.01 G + 0.62 T)   DPP form         (single-meeting iteration, round 3: 3.5 / 4.0 / 5.2 us at 1 / 2 / 4 slices)
+    //               rounds x 2.3   8 x 8 DPP form (one workgroup per right-hand side, 256 per round);
     //               rounds x (2.5 + 1.3 T)   DPP form with bond phonons (E: 3.8 / 5.1 us);   rounds x (2.1 + 1.7 T)   honeycomb DPP form (D: 3.8 / 5.5 us; 9.7 at 3 slices)
     //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
     // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 8.9 M against 4.2 M; E: 9.7 M against 3.2 M);
@@ -1172,7 +1209,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
             const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.8 / 5.1 us at 1 / 2 slices per wave)
-            const double t_res = rounds * (ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
+            const double t_res = rounds * (sh.s8 ? 2.3 : ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
                                                  : 2.0 + 0.12 * sh.G + (sh.T >= 4 ? 0.85 : 0.5) * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
@@ -1280,7 +1317,7 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
         const int rc = elph_shard_shape(h->L, Sh.P, &W, &G, nullptr, nullptr);
         if (rc) return rc;
         const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
-        sh.T = 1; sh.W = W; sh.G = G; sh.sq = false; sh.hc = false; sh.npl = h->npl;
+        sh.T = 1; sh.W = W; sh.G = G; sh.sq = false; sh.hc = false; sh.s8 = false; sh.npl = h->npl;
         sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 48 + 4 * HS) * sizeof(double);     // + partials, totals, rhalo[2][HS], zhalo[2][HS]
     }
     const size_t HS = (size_t)h->npl * WAVE;

@@ -317,6 +317,47 @@ __device__ __forceinline__ void hc_sweepN(double (&v)[NS][HC_NPL], const HcCtx &
     else                    { hc_pairs<NS, 0, 2>(v, X); hc_pairs<NS, 0, 1>(v, X); hc_pairs<NS, 0, 0>(v, X); }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The 8 x 8 square lattice (config B: 64 sites, ONE per lane) in the reference's colouring [x-even | x-odd | y-even | y-odd] (verified
+// on the host: detect_square, sq_P = 1): the checkerboard without LDS slabs.  Lane l holds the site x = (l >> 1) & 7,
+// y = 2 (l >> 4) + (l & 1): two lattice rows are interleaved in a 16-lane DPP row, so that x +- 1 is the lane 2 up / 2 down of the
+// row, cyclically (the period of row_ror, as on the 16 x 16 lattice):
+//   x-even  partner = lane ^ 2: quad_perm [2,3,0,1];            x-odd   the lane 2 up (x odd) or 2 down (x even): two row
+//   y-even  partner = lane ^ 1: quad_perm [1,0,3,2];                    rotations and a select;
+//   y-odd   the next / previous 16-lane row, other parity (sq_patch_ycross): one ds_bpermute pair.
+// 10 moves + 1 ds_bpermute pair + 4 fma per slab.  Uniform hopping: a colour is c (I + th P), the caller applies c^4.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int s8_site(int lane) { return ((lane >> 1) & 7) + 8 * (2 * (lane >> 4) + (lane & 1)); }
+struct S8Ctx { double th, k4; int yx; bool xodd; };
+
+template <int NS, bool REVERSE>
+__device__ __forceinline__ void s8_sweepN(double (&v)[NS][1], const S8Ctx &X) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int col = REVERSE ? 3 - cc : cc;
+        if (col == 0) {
+#pragma unroll
+            for (int n = 0; n < NS; ++n) v[n][0] += X.th * dpp_f64<0x4E>(v[n][0]);
+        } else if (col == 1) {
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const double up = dpp_f64<0x12E>(v[n][0]), dn = dpp_f64<0x122>(v[n][0]);      // row_ror:14 = lane + 2, row_ror:2 = lane - 2
+                v[n][0] += X.th * (X.xodd ? up : dn);
+            }
+        } else if (col == 2) {
+#pragma unroll
+            for (int n = 0; n < NS; ++n) v[n][0] += X.th * dpp_f64<0xB1>(v[n][0]);
+        } else {
+            double t[NS];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) t[n] = __shfl(v[n][0], X.yx, WAVE);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) v[n][0] += X.th * t[n];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Diagnostic build (-DELPH_WG_STAMPS, tools/time_wg_phases.py): wave 0 of workgroup 0 of right-hand side 0 adds the wall-clock
 // ticks (100 MHz) it spends in each phase of an iteration to a buffer no kernel reads.  Never compiled into the product.
 #ifdef ELPH_WG_STAMPS

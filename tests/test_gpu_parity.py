@@ -1338,6 +1338,8 @@ def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
         variants += [{"ELPH_WG_T": "4"}, {"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
     if tag in ("D", "E"):   # honeycomb (mirror lanes) / bond phonons (a table set per time slice): the DPP form is the default, the lane-program form the A/B
         variants += [{"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "2"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
+    if tag == "B":          # the 8 x 8 DPP form (one site per lane; default: one workgroup per right-hand side, 5 slices per wave) and its lane-program A/B
+        variants += [{"ELPH_WG_T": "5"}, {"ELPH_WG_T": "8"}, {"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "5"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "8"}]
     for env in variants:
         Xw, itw = solve(env, 1e-5)
         assert np.max(np.abs(itw - its)) <= 1, (tag, env, itw, its)
@@ -1422,14 +1424,17 @@ def test_wg_resident_cg_large_batch_shape():
     m.close()
 
 
-def test_wg_resident_cg_one_workgroup_per_rhs_shape(oracle):
-    """Config B (8 x 8, one site per lane): a batch beyond one round of 2 slices per wave (64 right-hand sides) runs the whole time
-    axis of a right-hand side in ONE workgroup (8 waves x 5 slices, a team of one: no records, no polls; 256 per round) — against
-    single solves (teams of four) and, solved to 1e-13, against the oracle at 1e-10."""
+@pytest.mark.parametrize("dpp", [True, False])
+def test_wg_resident_cg_one_workgroup_per_rhs_shape(oracle, monkeypatch, dpp):
+    """Config B (8 x 8, one site per lane): the whole time axis of a right-hand side in ONE workgroup (8 waves x 5 slices, a team of
+    one: no records, no polls; 256 per round) — in the 8 x 8 DPP form at every batch size, in the lane-program form (ELPH_WG_NO_DPP=1)
+    for batches beyond one round of 2 slices per wave (64) — against single solves and, solved to 1e-13, against the oracle at 1e-10."""
     from elphdynamics_amd import configs, models
+    if not dpp:
+        monkeypatch.setenv("ELPH_WG_NO_DPP", "1")
     m = configs.make_model("B", tol=1e-13, maxiter=20000)
     nrhs = 70
-    assert _wg_info(m)[1:] == (2, 5, 4) and _wg_info(m, nrhs)[1:] == (5, 8, 1)
+    assert _wg_info(m)[1:] == ((5, 8, 1) if dpp else (2, 5, 4)) and _wg_info(m, nrhs)[1:] == (5, 8, 1)
     om = _oracle_model(oracle, m)
     R, B = configs.rhs(m, nrhs)
     X = np.zeros_like(B)
