@@ -364,11 +364,12 @@ def main():
             models.update_model_(m)          # back to one configuration for the secondary single-matrix measurements
             if args.precond:                 # (its expansion went with the chains' matrices)
                 pc.setup_(P, rng=np.random.default_rng(7 + rank))
-        # ---- secondary: the resident kernel on the other BASELINE lattices (configs D: honeycomb L = 12, Ntau = 120; E: optical SSH
-        # L = 16, Ntau = 160 — parity-test cases, SURVEY §8 sizes table), 256 right-hand sides, un-preconditioned iteration
+        # ---- secondary: the resident kernel on the other BASELINE lattices (configs B: square L = 8, Ntau = 40; D: honeycomb L = 12,
+        # Ntau = 120; E: optical SSH L = 16, Ntau = 160 — parity-test cases, SURVEY §8 sizes table), 256 right-hand sides,
+        # un-preconditioned iteration
         if not args.no_sweep and rank == 0 and args.config == "C" and resident:
             other = {}
-            for tag in ("D", "E"):
+            for tag in ("B", "D", "E"):
                 try:
                     mo_ = configs.make_model(tag, tol=1e-5, device=comm.device_index())
                     _, Bo = configs.rhs(mo_, 256)
