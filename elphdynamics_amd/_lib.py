@@ -23,6 +23,7 @@ ERRORS = {-1: "ELPH_E_ARG", -2: "ELPH_E_HIP", -3: "ELPH_E_STATE", -4: "ELPH_E_NO
 SIGNATURES = {
     "elph_last_error": (C.c_char_p, []),
     "elph_abi_version": (c_int, []),
+    "elph_build_info": (C.c_char_p, []),
     "elph_device_count": (c_int, []),
     "elph_create": (c_int, [C.POINTER(Handle), c_int, c_i64, c_i64, c_i64, P_i64, P_dbl, P_dbl, c_int]),
     "elph_destroy": (c_int, [Handle]),
@@ -48,18 +49,6 @@ SIGNATURES = {
     "elph_ldiv_batched": (c_int, [Handle, c_int, P_dbl, P_dbl, c_int, c_i64, P_i64, P_dbl, P_int]),
     "elph_ldiv_dev": (c_int, [Handle, C.c_void_p, C.c_void_p, c_int, c_i64, P_i64, P_dbl, P_int]),
     "elph_ldiv_batched_dev": (c_int, [Handle, c_int, C.c_void_p, C.c_void_p, c_int, c_i64, P_i64, P_dbl, P_int]),
-    "elph_cgstep_begin": (c_int, [Handle, P_dbl, c_dbl, c_i64, c_dbl]),
-    "elph_cgstep_state0": (c_int, [Handle]),
-    "elph_cgstep_ap": (c_int, [Handle]),
-    "elph_cgstep_xr": (c_int, [Handle]),
-    "elph_cgstep_status": (c_int, [Handle, P_i64, P_int, P_dbl]),
-    "elph_cgstep_result": (c_int, [Handle, P_dbl]),
-    "elph_dev_buffer": (c_int, [Handle, c_int, C.POINTER(C.c_void_p), P_i64]),
-    "elph_buffer_read": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
-    "elph_buffer_write": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
-    "elph_set_dot_range": (c_int, [Handle, c_i64, c_i64]),
-    "elph_buffer_read_rows": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
-    "elph_buffer_write_rows": (c_int, [Handle, c_int, c_i64, c_i64, P_dbl]),
     "elph_fermion_force_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl,
                                             P_i64, P_int]),
     "elph_fermion_force_ssh": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
@@ -107,9 +96,13 @@ SIGNATURES = {
     "elph_shard_connect": (c_int, [Handle, C.c_void_p]),
     "elph_shard_prepare": (c_int, [Handle]),
     "elph_shard_solve": (c_int, [Handle, P_dbl, P_dbl, c_dbl, c_i64, c_dbl, P_i64, P_int, P_dbl]),
-    "elph_shard_iterate": (c_int, [Handle, P_dbl, c_i64, P_dbl]),
     "elph_shard_solve_kpm": (c_int, [Handle, Handle, P_dbl, P_dbl, c_dbl, c_i64, c_dbl, P_i64, P_int, P_dbl]),
     "elph_shard_destroy": (c_int, [Handle]),
+}
+
+# private measurement hooks (csrc/elph_bench.h: exported by the library, not part of the drop-in ABI; bench.py and tools/ use them)
+BENCH_SIGNATURES = {
+    "elph_shard_iterate": (c_int, [Handle, P_dbl, c_i64, P_dbl]),
     "elph_bench_prepare": (c_int, [Handle, c_int, c_int, P_dbl]),
     "elph_bench_run": (c_int, [Handle, c_int, c_int, c_int, c_int, P_dbl]),
     "elph_bench_info": (c_int, [Handle, c_int, P_int]),
@@ -140,7 +133,7 @@ def load():
         raise ImportError(f"{path} is missing: build it with hipcc first (python -c 'import __graft_entry__ as g; g.build()'); "
                           "elphdynamics_amd has no CPU fallback")
     lib = C.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(BENCH_SIGNATURES.items()):
         fn = getattr(lib, name)   # AttributeError here == ABI mismatch
         fn.restype = res
         fn.argtypes = args

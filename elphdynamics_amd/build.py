@@ -1,14 +1,34 @@
-"""Build libelphgpu.so in-tree with hipcc for gfx950 (the only target)."""
+"""Build libelphgpu.so in-tree with hipcc for gfx950 (the only target).
+
+What is rebuilt is decided by CONTENT, not by time stamps: every object has a key = sha256(its source + every header of csrc/ and
+include/ + the compiler flags + `hipcc --version`), kept in build/manifest.json; an object whose key is unchanged is reused, and the
+library is relinked whenever the set of keys differs from the one baked into it.  The overall key of the sources (`source_hash()`),
+the compiler and the time of the link are compiled into the library and come back from `elph_build_info()` — so a prebuilt .so that
+travelled with a snapshot is recognised as current (reported "reused") or stale (rebuilt), and the GPU box's logs show which sources
+the code that ran was made from.
+"""
+import hashlib
+import json
 import os
 import shutil
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("ELPH_LIB") or os.path.join(HERE, "libelphgpu.so")
 SOURCES = ["kernels.hip", "cg_fast.hip", "cg_fast6.hip", "cg_wg.hip", "pcg_wg.hip", "shard.hip", "kpm_dev.hip", "dft.hip", "dft_mfma.hip", "dft_big.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
 OBJDIR = os.path.join(HERE, "build")
-HEADERS = [os.path.join(CSRC, "elph_internal.h"), os.path.join(CSRC, "cg_fast_impl.inc"), os.path.join(CSRC, "cg_fast_common.h"), os.path.join(CSRC, "cg_wg_dev.h"), os.path.join(CSRC, "kpm_sq_dev.h"), os.path.join(HERE, "..", "include", "elph_gpu.h")]
+MANIFEST = os.path.join(OBJDIR, "manifest.json")
+ARCH = "gfx950"
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+# A/B build for tests/test_gpu_parity.py::test_lds_sync_build_is_bit_identical: the lane-program kernels order their
+# private-LDS traffic with a compiler barrier only (cg_fast_common.h, WAVE_LDS_ORDER); this variant compiles the same
+# translation units with a real s_waitcnt + s_barrier per colour (-DELPH_LDS_SYNC) — a compiler reordering regression
+# would show as a difference between the two libraries.  Every other object is shared with the product build.
+LIB_LDSSYNC = os.path.join(HERE, "libelphgpu_ldssync.so")
+LDSSYNC_SOURCES = ("cg_fast.hip", "cg_fast6.hip", "cg_wg.hip")
 
 
 def _hipcc():
@@ -18,74 +38,140 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libelphgpu.so cannot be built (ROCm toolchain required)")
 
 
+def _headers():
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
+    return hs + [os.path.join(HERE, "..", "include", "elph_gpu.h")]
+
+
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def source_hash():
+    """sha256 over every source and header the library is made from (names + contents), first 16 hex digits."""
+    return _sha([os.path.join(CSRC, s) for s in SOURCES] + _headers())[:16]
+
+
+_compiler_id = None
+
+
+def compiler_id():
+    global _compiler_id
+    if _compiler_id is None:
+        out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
+        _compiler_id = " | ".join(l.strip() for l in out.splitlines() if l.strip())[:300]
+    return _compiler_id
+
+
+def _load_manifest():
+    try:
+        with open(MANIFEST) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def library_build_info(path=None):
+    """The build record baked into a built library, read from the file's bytes (no dlopen: the answer must not depend on which copy
+    of the library this process may already have mapped).  None: missing, or from before elph_build_info existed."""
+    path = path or LIB
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(b"libelphgpu abi=1 src=")
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i:j].decode(errors="replace")
+
+
+def library_source_hash(path=None):
+    info = library_build_info(path)
+    if not info:
+        return None
+    for tok in info.split():
+        if tok.startswith("src="):
+            return tok[4:]
+    return None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_source_hash(LIB) != source_hash()
 
 
-# A/B build for tests/test_gpu_parity.py::test_lds_sync_build_is_bit_identical: the lane-program kernels order their
-# private-LDS traffic with a compiler barrier only (cg_fast_common.h, WAVE_LDS_ORDER); this variant compiles the same two
-# translation units with a real s_waitcnt + s_barrier per colour (-DELPH_LDS_SYNC) — a compiler reordering regression
-# would show as a difference between the two libraries.  Every other object is shared with the product build.
-LIB_LDSSYNC = os.path.join(HERE, "libelphgpu_ldssync.so")
-LDSSYNC_SOURCES = ("cg_fast.hip", "cg_fast6.hip", "cg_wg.hip")
-
-
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+last_build = {"compiled": [], "linked": [], "reused": True}
 
 
 def build_library(force=False, verbose=False, lds_sync_variant=True):
     """Compile the HIP kernels + C-ABI into elphdynamics_amd/libelphgpu.so (and the ELPH_LDS_SYNC A/B variant next to it).
-    Returns the path of the product library.  One object per source (rebuilt only when it or a header is newer), compiled
-    side by side, then one link per library."""
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    want_main = force or _stale(LIB, deps)
-    want_var = lds_sync_variant and (force or _stale(LIB_LDSSYNC, deps))
-    if not want_main and not want_var:
-        return LIB
+    Returns the path of the product library; `last_build` says what was compiled / linked / reused.  One object per source
+    (recompiled only when its content key changed), compiled side by side, then one link per library."""
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    hdr_t = max(os.path.getmtime(h) for h in HEADERS)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-    jobs, objs, objs_var = [], [], []
+    man = {} if force else _load_manifest()
+    hdr = _headers()
+    src_hash = source_hash()
+    cid = compiler_id()
+    jobs, objs, objs_var, compiled = [], [], [], []
+    new_man = {}
 
-    def compile_if_stale(src, obj, extra=()):
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            cmd = [hipcc, *flags, *extra, "-x", "hip", "-c", src, "-o", obj]
+    def want(src, obj, extra=()):
+        key = _sha([src] + hdr, extra=" ".join(FLAGS + list(extra)) + cid)
+        name = os.path.basename(obj)
+        new_man[name] = key
+        if force or not os.path.exists(obj) or man.get(name) != key:
+            cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", src, "-o", obj]
             if verbose:
-                print(" ".join(cmd))
+                print(" ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd)))
+            compiled.append(name)
 
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s + ".o")
         objs.append(obj)
-        compile_if_stale(src, obj)
+        want(src, obj)
         if lds_sync_variant and s in LDSSYNC_SOURCES:
             obj_v = os.path.join(OBJDIR, s + ".ldssync.o")
             objs_var.append(obj_v)
-            compile_if_stale(src, obj_v, ("-DELPH_LDS_SYNC",))
+            want(src, obj_v, ("-DELPH_LDS_SYNC",))
         else:
             objs_var.append(obj)
     for cmd, p in jobs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    for lib, ob, want in ((LIB, objs, True), (LIB_LDSSYNC, objs_var, lds_sync_variant)):
-        if not want:
+    linked = []
+    targets = [(LIB, objs, "product")] + ([(LIB_LDSSYNC, objs_var, "lds_sync")] if lds_sync_variant else [])
+    for lib, ob, variant in targets:
+        if not (force or compiled or library_source_hash(lib) != src_hash):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *ob, "-o", lib]
+        # the build record travels inside the library (elph_build_info, elph_api.hip): a translation unit of its own, remade at every link
+        info_c = os.path.join(OBJDIR, f"build_info_{variant}.cpp")
+        info_o = info_c[:-4] + ".o"
+        stamp = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())
+        text = (f"libelphgpu abi=1 src={src_hash} arch={ARCH} variant={variant} built={stamp} flags={'_'.join(FLAGS[1:])} "
+                f"compiler=[{cid}]")
+        with open(info_c, "w") as f:
+            f.write('extern "C" const char elph_build_info_text[] = ' + json.dumps(text) + ";\n")
+        subprocess.run([hipcc, "-O1", "-fPIC", "-x", "c++", "-c", info_c, "-o", info_o], check=True)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *ob, info_o, "-o", lib]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        linked.append(os.path.basename(lib))
+    with open(MANIFEST, "w") as f:
+        json.dump(new_man, f, indent=0, sort_keys=True)
+    last_build.update(compiled=compiled, linked=linked, reused=not (compiled or linked))
     return LIB
 
 
-if __name__ == "__main__":      # python -m elphdynamics_amd.build [--force]
+if __name__ == "__main__":      # python -m elphdynamics_amd.build [--force] [-v]
     import sys
     print(build_library(force="--force" in sys.argv[1:], verbose="-v" in sys.argv[1:]))
+    print("compiled:", last_build["compiled"] or "nothing", "| linked:", last_build["linked"] or "nothing", "| source hash", source_hash())

@@ -1172,19 +1172,26 @@ bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs) {
     return true;
 }
 
+// A team timed out on an earlier solve (the GPU was shared with something that held its CUs): the handle runs the streaming iteration
+// for the next ELPH_WG_COOLDOWN solves (default 16), then tries the resident kernels again with a cleared abort word.  One step per
+// solve that WOULD have taken a resident kernel — called by both of them (elph_wg_cg, elph_pcg_wg), so a handle that only ever runs
+// preconditioned solves recovers too.
+int elph_wg_cooldown_step(elph_handle_s *h) {
+    if (!h->wg_broken) return ELPH_OK;
+    if (--h->wg_cooldown > 0) return ELPH_OK;
+    h->wg_broken = false;
+    if (h->d_res && h->wg_abort_off) HIPCHK(hipMemsetAsync(static_cast<char *>(h->d_res) + h->wg_abort_off, 0, sizeof(int), h->stream));
+    return ELPH_OK;
+}
+
 // Runs the whole un-preconditioned CG for rhs [0, nrhs) after elph_launch_cg_init (fixed_iters > 0: exactly that many
 // iterations without stop test — measurement).  *ran = false: not applicable, nothing was launched.
 // ELPH_E_HIP with "workgroup-resident" in the message: a team timed out; the caller re-initialises and runs the two-kernel path.
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran) {
     *ran = false;
     if (B.params.use_prec) return ELPH_OK;
-    if (h->wg_broken) {
-        // a team timed out on an earlier solve (the GPU was shared with something that held its CUs): the handle runs the streaming
-        // iteration for the next ELPH_WG_COOLDOWN solves (default 16), then tries the resident kernel again with a cleared abort word
-        if (--h->wg_cooldown > 0) return ELPH_OK;
-        h->wg_broken = false;
-        if (h->d_res && h->wg_abort_off) HIPCHK(hipMemsetAsync(static_cast<char *>(h->d_res) + h->wg_abort_off, 0, sizeof(int), h->stream));
-    }
+    { const int rcs = elph_wg_cooldown_step(h); if (rcs) return rcs; }
+    if (h->wg_broken) return ELPH_OK;
     if (!elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs)) return ELPH_OK;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
@@ -1345,8 +1352,9 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     R.epoch0 = 0;                                          // (the records of a sharded solve live in the ranks' mailboxes: one numbering for all)
     (void)span;
     R.G = sh.G; R.W = sh.W;
-    const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
-    R.timeout_ticks = (long long)(eto ? atoll(eto) : 2000) * 100000LL;
+    // (a sharded solve has NO streaming fallback behind it — a time-out is a failed solve — and its ranks start with whatever skew the
+    //  host's barrier, first-launch code loading and time-slicing leave: the long bound, elph_shard_timeout_ms)
+    R.timeout_ticks = elph_shard_timeout_ms() * 100000LL;
     R.fixed_iters = fixed_iters;
     R.x0_zero = 0;
     HIPCHK(hipMemsetAsync(base, 0, h->res_cap, h->stream));   // boundary granules of this rank's workgroups: tags restart at 2

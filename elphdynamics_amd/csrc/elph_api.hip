@@ -29,6 +29,9 @@ void elph_set_error(const char *fmt, ...) {
 
 extern "C" const char *elph_last_error(void) { return g_err; }
 extern "C" int elph_abi_version(void) { return ELPH_ABI_VERSION; }
+// the build record: written by elphdynamics_amd/build.py into a translation unit of its own at every link
+extern "C" const char elph_build_info_text[];
+extern "C" const char *elph_build_info(void) { return elph_build_info_text; }
 
 extern "C" int elph_device_count(void) {
     int n = 0;
@@ -694,6 +697,8 @@ static int get_chunk_graph(elph_handle_s *h, int nrhs, int use_prec, hipGraphExe
 // Runs CG on d_b / d_x (layout S) for nrhs right-hand sides.  Returns per-rhs iteration counts.
 static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t maxiter, double kmax, int64_t *iters,
                   double *eps_hist /* host, optional, nrhs*(maxiter+1) */) {
+    const bool x0_zero = h->x_zero;        // the hint belongs to THIS solve: consumed before anything can return
+    h->x_zero = false;
     if (use_prec && !h->kpm_ready) { elph_set_error("preconditioned solve requested before elph_kpm_setup"); return ELPH_E_STATE; }
     CgParams P;
     P.tol = tol; P.kmax = kmax; P.maxiter = maxiter; P.use_prec = use_prec;
@@ -710,7 +715,7 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
     }
     if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);   // parameters are baked into captured launches
     h->cur_params = P;
-    RC(elph_launch_cg_init(h, nrhs, use_prec));      // (consumes h->x_zero: A x0 = 0 without the mat-vec)
+    RC(elph_launch_cg_init(h, nrhs, use_prec, x0_zero));      // (x0 = 0: A x0 = 0 without the mat-vec)
     h->wg_x0_zero = h->x_zero_seen;
 
     // whole solve in one launch with the Krylov vectors in registers (cg_wg.hip: k_cg_wg) when it applies
@@ -976,58 +981,10 @@ extern "C" int elph_cg_solve(elph_handle h, double *x, const double *b, double t
     return ELPH_OK;
 }
 
-// ------------------------------------------------------------------------------------------
-// step-wise CG for multi-GPU drivers (elphdynamics_amd/sharded.py): the same kernels as elph_cg_solve, one phase per
-// call, so the caller can exchange halo slices and combine partial sums across ranks between the phases
-// ------------------------------------------------------------------------------------------
-
-extern "C" int elph_cgstep_begin(elph_handle h, const double *b, double tol, int64_t maxiter, double kappa_max) {
-    CHECK_H(h);
-    RC(need_model(h));
-    if (!b || !(tol >= 0.0) || maxiter < 1) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    RC(ensure_capacity(h, 1));
-    CgParams P;
-    P.tol = tol; P.kmax = (kappa_max > 0.0) ? kappa_max : h->kmax; P.maxiter = maxiter; P.use_prec = 0; P.record_hist = 0; P.hist_stride = 0;
-    if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);
-    h->cur_params = P;
-    const size_t bytes = (size_t)h->ndim * sizeof(double);
-    HIPCHK(hipMemcpyAsync(h->d_stage_in, b, bytes, hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 1));
-    HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_tmp, 0, bytes, h->stream));          // A x0 = 0
-    RC(elph_launch_cg_init_only(h, 1));                              // r0 = b, p0 = b, partial r.r and b.b
-    return ELPH_OK;
-}
-
-extern "C" int elph_cgstep_state0(elph_handle h) { CHECK_H(h); return elph_launch_cg_state0_only(h, 1); }
-extern "C" int elph_cgstep_ap(elph_handle h) { CHECK_H(h); return elph_launch_cg_kernel(h, 1, 0); }
-extern "C" int elph_cgstep_xr(elph_handle h) { CHECK_H(h); return elph_launch_cg_kernel(h, 1, 1); }
-
-extern "C" int elph_cgstep_status(elph_handle h, int64_t *iters, int *done, double *eps) {
-    CHECK_H(h);
-    HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    const CgState &s = h->h_state[h->ap_count & 1];                  // the copy written by the latest k_cg_ap launch
-    if (iters) *iters = s.iters;
-    if (done) *done = s.done;
-    if (eps) *eps = s.eps;
-    return ELPH_OK;
-}
-
-extern "C" int elph_cgstep_result(elph_handle h, double *x) {
-    CHECK_H(h);
-    if (!x) { elph_set_error("null argument"); return ELPH_E_ARG; }
-    RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, 1));
-    HIPCHK(hipMemcpyAsync(x, h->d_stage_out, (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return ELPH_OK;
-}
-
-// Sites [site_lo, site_hi) (0-based) enter the inner products of the step-wise / full CG (p.z, r.r, b.b); the other sites
-// of the handle's lattice are ghost sites of a spatial shard: they take part in the mat-vec, their values come from the
+// (internal: shard.hip) Sites [site_lo, site_hi) (0-based) enter the inner products of the streaming CG (p.z, r.r, b.b); the other
+// sites of the handle's lattice are ghost sites of a spatial shard: they take part in the mat-vec, their values come from the
 // neighbouring ranks.  A restricted range runs the generic kernel family.  (0, nsites) restores the default.
-extern "C" int elph_set_dot_range(elph_handle h, int64_t site_lo, int64_t site_hi) {
-    CHECK_H(h);
+int elph_i_set_dot_range(elph_handle_s *h, int64_t site_lo, int64_t site_hi) {
     if (site_lo < 0 || site_hi > h->N || site_lo >= site_hi) { elph_set_error("bad site range [%lld, %lld)", (long long)site_lo, (long long)site_hi); return ELPH_E_ARG; }
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);
@@ -1035,65 +992,6 @@ extern "C" int elph_set_dot_range(elph_handle h, int64_t site_lo, int64_t site_h
     h->dot_lo = all ? 0 : (int)site_lo;
     h->dot_hi = all ? 0 : (int)site_hi;
     h->fast = all ? h->fast_capable : false;
-    return ELPH_OK;
-}
-
-// rows of a layout-S vector: for every tau the sites [site_lo, site_lo + nsites) -> host[tau * nsites + k]
-static int buffer_rows(elph_handle_s *h, int which, int64_t site_lo, int64_t nsites, double *host, bool write) {
-    if (which != 3 && which != 4) { elph_set_error("rows access is for the vectors r (3) and x (4)"); return ELPH_E_ARG; }
-    void *p = nullptr; int64_t n = 0;
-    RC(elph_dev_buffer(h, which, &p, &n));
-    if (!host || site_lo < 0 || nsites < 1 || site_lo + nsites > h->N) { elph_set_error("bad site range"); return ELPH_E_ARG; }
-    double *d = (double *)p + site_lo;
-    const size_t dpitch = (size_t)h->N * sizeof(double), hpitch = (size_t)nsites * sizeof(double);
-    if (write) HIPCHK(hipMemcpy2DAsync(d, dpitch, host, hpitch, hpitch, (size_t)h->L, hipMemcpyHostToDevice, h->stream));
-    else HIPCHK(hipMemcpy2DAsync(host, hpitch, d, dpitch, hpitch, (size_t)h->L, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return ELPH_OK;
-}
-
-extern "C" int elph_buffer_read_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, double *host) {
-    CHECK_H(h);
-    return buffer_rows(h, which, site_lo, nsites, host, false);
-}
-
-extern "C" int elph_buffer_write_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, const double *host) {
-    CHECK_H(h);
-    return buffer_rows(h, which, site_lo, nsites, const_cast<double *>(host), true);
-}
-
-// device buffers of the step-wise solve (layout S: slice tau of a vector = N contiguous doubles at tau*N)
-extern "C" int elph_dev_buffer(elph_handle h, int which, void **ptr, int64_t *count) {
-    CHECK_H(h);
-    if (!ptr || !count) { elph_set_error("null argument"); return ELPH_E_ARG; }
-    RC(ensure_capacity(h, 1));
-    const size_t P = (size_t)h->cap_rhs * (size_t)h->L * (size_t)h->npl;
-    switch (which) {
-        case 0: *ptr = h->d_part; *count = h->L / elph_choose_T(h, 1); break;          // p.z partials of k_cg_ap
-        case 1: *ptr = h->d_part + P; *count = h->L; break;                            // r.r partials of k_cg_xr / init
-        case 2: *ptr = h->d_part + 3 * P; *count = h->L; break;                        // b.b partials of init
-        case 3: *ptr = h->d_r; *count = h->ndim; break;
-        case 4: *ptr = h->d_x; *count = h->ndim; break;
-        default: elph_set_error("unknown buffer %d", which); return ELPH_E_ARG;
-    }
-    return ELPH_OK;
-}
-
-extern "C" int elph_buffer_read(elph_handle h, int which, int64_t offset, int64_t count, double *host) {
-    void *p = nullptr; int64_t n = 0;
-    RC(elph_dev_buffer(h, which, &p, &n));
-    if (!host || offset < 0 || count < 0 || offset + count > n) { elph_set_error("bad range"); return ELPH_E_ARG; }
-    HIPCHK(hipMemcpyAsync(host, (double *)p + offset, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return ELPH_OK;
-}
-
-extern "C" int elph_buffer_write(elph_handle h, int which, int64_t offset, int64_t count, const double *host) {
-    void *p = nullptr; int64_t n = 0;
-    RC(elph_dev_buffer(h, which, &p, &n));
-    if (!host || offset < 0 || count < 0 || offset + count > n) { elph_set_error("bad range"); return ELPH_E_ARG; }
-    HIPCHK(hipMemcpyAsync((double *)p + offset, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));   // host buffer may be a temporary
     return ELPH_OK;
 }
 
@@ -1691,9 +1589,10 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
     P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3 || what == 10 || (what >= 6 && what <= 8)); P.record_hist = 0; P.hist_stride = 0;
     h->cur_params = P;
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
-    h->x_zero = true;
-    RC(elph_launch_cg_init(h, nrhs, P.use_prec));
+    h->x_zero = false;
+    RC(elph_launch_cg_init(h, nrhs, P.use_prec, true));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->bench_fresh = true;
     return ELPH_OK;
 }
 
@@ -1738,7 +1637,8 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
         hipError_t er = hipStreamSynchronize(h->stream);
         if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
         if (er == hipSuccess) {
-            h->wg_x0_zero = h->x_zero_seen;                 // (elph_bench_prepare zeroed x)
+            h->wg_x0_zero = h->bench_fresh && h->x_zero_seen;      // (x is known to be zero only right after elph_bench_prepare)
+            h->bench_fresh = false;
             rc = (what == 9) ? elph_wg_cg(h, B, nrhs, reps, &ran) : elph_pcg_wg(h, B, nrhs, reps, &ran);
             if (rc == ELPH_OK && !ran) { elph_set_error("the workgroup-resident kernel does not apply to this handle"); rc = ELPH_E_UNSUPPORTED; }
         }

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/elph_gpu.h"
+#include "elph_bench.h"
 
 #define ELPH_ABI_VERSION 1
 #define ELPH_WAVE 64
@@ -227,8 +228,10 @@ struct elph_handle_s {
     void *d_res = nullptr;                 // control block of the workgroup-resident CG (cg_wg.hip): meeting records, abort word, boundary slices
     size_t res_cap = 0;
     // x = 0 hint: set by the library right after it zeroes d_x for a solve it is about to start (fill!(x, 0) of the callers, HMC.jl:854);
-    // elph_launch_cg_init consumes it (A x0 = 0 needs no mat-vec; x_zero_seen tells the resident kernel not to read x0 either)
+    // run_cg reads AND clears it first thing (an early error return cannot leave it behind for the next solve) and hands it to
+    // elph_launch_cg_init (A x0 = 0 needs no mat-vec; x_zero_seen tells the resident kernel not to read x0 either)
     bool x_zero = false, x_zero_seen = false, wg_x0_zero = false;
+    bool bench_fresh = false;              // elph_bench_prepare ran and no elph_bench_run(9 | 10) has consumed its zeroed x yet
     bool wg_broken = false;                // a workgroup-resident launch timed out: streaming iteration for the next wg_cooldown solves, then retry
     int wg_cooldown = 0;
     long long wg_fallbacks = 0;            // how many times that happened (elph_wg_status)
@@ -323,6 +326,7 @@ KpmDev elph_kpm_dev(const elph_handle_s *h);
 // elph_api.hip internals used by hmc.hip
 int elph_i_ldiv_core(elph_handle_s *h, int nrhs, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag);
 int elph_i_ensure_capacity(elph_handle_s *h, int nrhs);
+int elph_i_set_dot_range(elph_handle_s *h, int64_t site_lo, int64_t site_hi);   // inner products over [lo, hi) only (a shard's own sites)
 int elph_i_reserve_chains(elph_handle_s *h, int nchains);   // d_E for nchains configurations, h->nchains = nchains
 void elph_i_drop_graphs(elph_handle_s *h);
 void elph_hmc_free(elph_handle_s *h);
@@ -339,7 +343,7 @@ int elph_launch_ssh_scatter(elph_handle_s *h, double *F_dev, const double *q_dev
 int elph_i_ssh_upload_params(elph_handle_s *h, int64_t nph, const int64_t *cb_index, const double *t_ph, const double *alpha,
                              const double *alpha2, const double *t_bare_cb, const double *mu);
 int elph_launch_mul(elph_handle_s *h, int which /*0 M, 1 MT, 2 MTM*/, double *yS, const double *vS, int nvec);
-int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec);
+int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec, bool x_zero = false);   // x_zero: d_x was zeroed by the library for THIS solve
 int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec);
 int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which /*0 = k_cg_ap, 1 = k_cg_xr*/);
 int elph_launch_residual(elph_handle_s *h, int nrhs);
@@ -381,6 +385,8 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs = 1);
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream has drained
+int elph_wg_cooldown_step(elph_handle_s *h);                // one solve of the cool-down after a time-out (both resident kernels call it)
+long long elph_shard_timeout_ms();                          // wait bound of the sharded solves (shard.hip)
 // ---- workgroup-resident KPM-preconditioned CG (pcg_wg.hip): the whole preconditioned solve of 1..8 right-hand sides in one launch
 bool elph_pcg_wg_usable(const elph_handle_s *h, int nrhs);
 int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);

@@ -1223,14 +1223,13 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
 
 int elph_launch_rz_partials(elph_handle_s *h, int nrhs);
 
-int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec) {
+int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec, bool x_zero) {
     // expects d_b (layout S), d_x = initial guess; computes r0, p0 and seeds the state
     CgBufs B = make_bufs(h, nrhs);
     h->ap_count = 0;
     const int N = (int)h->N, L = (int)h->L;
     int rc = ELPH_OK;
-    h->x_zero_seen = h->x_zero;
-    h->x_zero = false;
+    h->x_zero_seen = x_zero;
     if (h->x_zero_seen) {       // x0 = 0 (the library zeroed it for this solve): A x0 = 0 without the mat-vec
         if (hipMemsetAsync(h->d_tmp, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream) != hipSuccess) { elph_set_error("memset failed"); return ELPH_E_HIP; }
     } else {

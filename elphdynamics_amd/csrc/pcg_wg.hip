@@ -541,6 +541,11 @@ static bool pcg_shape(const elph_handle_s *h, int nrhs, int *Wo, int *Go, int *n
     if (!(eo && eo[0] == '1') && nrhs < 6) return false;
     if (!h->fast || h->wg_broken || h->kind != ELPH_MODEL_HOLSTEIN || h->sq_P != 2 || h->N != 256 || !h->sq_uniform || h->lp_mc != 4) return false;
     if (!h->kpm_ready || !h->kpm_active || h->dot_hi != 0 || h->solo_chain >= 0) return false;
+    // (h->kpm_active says that SOME chain's expansion is active; the kernel runs the series of every right-hand side's chain without
+    //  looking at KpmChainView::active, so a chain whose expansion is the identity — lam_mag uploaded as -1, tables unset — keeps the
+    //  whole batch on the streaming form, which hands such a chain z = r)
+    for (int c = 0; c < h->kpm_nch; ++c)
+        if ((size_t)c < h->kpm_chain.size() ? !h->kpm_chain[(size_t)c].active : (h->h_lam.size() > 2 * (size_t)c + 1 && h->h_lam[2 * (size_t)c + 1] <= 0.0)) return false;
     if (nrhs < 1 || nrhs > 8) return false;
     const int L = (int)h->L;
     if (L % 2) return false;
@@ -564,7 +569,9 @@ bool elph_pcg_wg_usable(const elph_handle_s *h, int nrhs) { return pcg_shape(h, 
 int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran) {
     *ran = false;
     int W = 0, G = 0, nt = 0;
-    if (!B.params.use_prec || !pcg_shape(h, nrhs, &W, &G, &nt)) return ELPH_OK;
+    if (!B.params.use_prec) return ELPH_OK;
+    { const int rcs = elph_wg_cooldown_step(h); if (rcs) return rcs; }       // (a handle that only runs preconditioned solves recovers here)
+    if (!pcg_shape(h, nrhs, &W, &G, &nt)) return ELPH_OK;
     ModelDev m = elph_model_dev(h);
     if (!m.uniform || !m.sq_bond) return ELPH_OK;
     const size_t n_slots = 2 * (size_t)nrhs * wg::SLOTS_PER_RHS, n_flags = (size_t)nrhs * wg::PCG_FLAGS;

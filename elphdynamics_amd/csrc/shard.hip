@@ -419,10 +419,15 @@ static int launch_ok(const char *what) {
     return ELPH_OK;
 }
 
-static long long shard_timeout_ticks() {
-    const char *eto = getenv("ELPH_WG_TIMEOUT_MS");
-    return (long long)(eto ? atoll(eto) : 2000) * 100000LL;
+// Wait bound of the sharded solves (ms): ELPH_SHARD_TIMEOUT_MS, else ELPH_WG_TIMEOUT_MS, else 20 s.  A sharded solve has no fallback
+// behind it (a time-out is ELPH_E_HIP), so it keeps the long bound; the 2 s default of ELPH_WG_TIMEOUT_MS belongs to the un-sharded
+// resident kernels, which fall back to the streaming iteration.
+long long elph_shard_timeout_ms() {
+    const char *es = getenv("ELPH_SHARD_TIMEOUT_MS"), *ew = getenv("ELPH_WG_TIMEOUT_MS");
+    const long long ms = es ? atoll(es) : (ew ? atoll(ew) : 20000);
+    return ms > 0 ? ms : 20000;
 }
+static long long shard_timeout_ticks() { return elph_shard_timeout_ms() * 100000LL; }      // wall_clock64 runs at 100 MHz
 
 static int allsum(elph_handle_s *h, ShardState *S, double *part, int n, int slot) {
     hipLaunchKernelGGL(k_shard_allsum, dim3(1), dim3(64), 0, h->stream, part, n, S->ctl, S->ext_off, slot, ++S->epoch, S->d_abort,
@@ -472,7 +477,7 @@ extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_
     int rc;
     if ((rc = elph_i_ensure_capacity(h, 1)) || (rc = elph_i_ensure_capacity(hfull, 1))) return rc;
     // inner products over the own rows: the generic kernel family (elph_set_dot_range)
-    if ((rc = elph_set_dot_range(h, S->ctl.own_lo, S->ctl.own_hi))) return rc;
+    if ((rc = elph_i_set_dot_range(h, S->ctl.own_lo, S->ctl.own_hi))) return rc;
     hipStream_t saved = hfull->stream;
     HIPCHK(hipStreamSynchronize(hfull->stream));
     hfull->stream = h->stream;
@@ -527,6 +532,6 @@ extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_
     rc = body();
     (void)hipStreamSynchronize(h->stream);
     hfull->stream = saved;
-    (void)elph_set_dot_range(h, 0, h->N);
+    (void)elph_i_set_dot_range(h, 0, h->N);
     return rc;
 }

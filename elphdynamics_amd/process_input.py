@@ -9,7 +9,7 @@ drives the GPU path unchanged.
 What is read: [lattice], [holstein] / [ssh] (all tables, disorder widths included), [solver] (+ [solver.preconditioner]),
 [[fourier_acceleration]], [hmc] (+ [hmc.burnin], [hmc.reflection_update], [hmc.swap_update]) / [langevin],
 [measurements].num_random_vectors, [simulation] (seed, counts, names — kept in sim.sim_params, nothing is created on disk).
-[tune_density] (its parameters; the tuner is control plane, examples/control_plane/).  What is not: the measurement container and its folders, logging, checkpoints — the reference's
+[tune_density] (its parameters only; the tuner is control plane and stays with the caller).  What is not: the measurement container and its folders, logging, checkpoints — the reference's
 control plane (SURVEY §8 "out of scope"); sim.input keeps the whole parsed deck for a driver that wants them.
 
 Only solver.type = "CG" exists on the GPU (the path of BASELINE.json); GMRES / BiCGStab decks raise.
@@ -152,8 +152,7 @@ def initialize_simulation_params(inp):
 
 def initialize_mutuner(inp, model):
     """ProcessInputFile.jl:611-624 — the PARAMETERS of the [tune_density] table only (active, μ₀, target ⟨N⟩, memory, κ_min·N): the
-    tuner itself (MuFinder.jl) is control plane and not part of this package (examples/control_plane/mu_tuner.py builds one from
-    these); the device side of a μ update is elph_hmc_set_mu / models.set_mu_."""
+    tuner itself (MuFinder.jl) is control plane and not part of this package; the device side of a μ update is elph_hmc_set_mu / models.set_mu_."""
     mu0 = float(np.mean(model.mu))
     td = inp.get("tune_density")
     if td is None:

@@ -46,6 +46,10 @@ const char *elph_last_error(void);
 
 /* ABI version of the loaded library (for the Julia wrapper's sanity check). */
 int elph_abi_version(void);
+/* How this library was built: "libelphgpu abi=1 src=<sha256 of csrc/ + include/, 16 hex digits> arch=gfx950 variant=... built=<UTC>
+ * flags=... compiler=[hipcc --version]" — static storage.  elphdynamics_amd/build.py compares `src` with the sources at hand: a stale
+ * shipped library is rebuilt, a current one reused; smoke() and bench.py print it so that a run's log names the code that ran. */
+const char *elph_build_info(void);
 
 /* Number of visible HIP devices (0 if none); does not create a context. */
 int elph_device_count(void);
@@ -167,40 +171,6 @@ int elph_ldiv_dev(elph_handle h, double *x_dev, const double *b_dev, int use_pre
 int elph_ldiv_batched_dev(elph_handle h, int nrhs, double *X_dev, const double *B_dev,
                           int use_precond, int64_t maxiter, int64_t *iters,
                           double *residual_error, int *flag);
-
-/* ---------------------------------------------------------------- step-wise CG (multi-GPU drivers) */
-
-/* The kernels of elph_cg_solve (un-preconditioned, one right-hand side), one phase per call, for drivers that shard
- * ONE solve over several GPUs (elphdynamics_amd/sharded.py): between the phases the caller exchanges
- * halo slices of r and replaces the per-slice partial sums by cross-rank totals, through the device buffers below.
- *   begin   : x0 = 0, r0 = p0 = b (host, reference layout), partial sums r.r and b.b   IterativeSolvers.jl:259-268
- *   state0  : |b|, eps0, rho0 from the partial-sum buffers                                :262,271-274
- *   ap      : stop test of the previous iteration, beta, p = r + beta p, z = MtM p, partial p.z   :277-279,286-310
- *   xr      : alpha, x += alpha p, r -= alpha z, partial r.r                              :279-285
- *   status  : (iterations completed, done flag 0/1/2/3, last eps)
- * elph_dev_buffer: which = 0 p.z partials, 1 r.r partials, 2 b.b partials, 3 r, 4 x (vectors in the device layout:
- * slice tau = nsites contiguous doubles at offset tau*nsites). */
-int elph_cgstep_begin(elph_handle h, const double *b, double tol, int64_t maxiter, double kappa_max);
-int elph_cgstep_state0(elph_handle h);
-int elph_cgstep_ap(elph_handle h);
-int elph_cgstep_xr(elph_handle h);
-int elph_cgstep_status(elph_handle h, int64_t *iters, int *done, double *eps);
-int elph_cgstep_result(elph_handle h, double *x);
-int elph_dev_buffer(elph_handle h, int which, void **ptr, int64_t *count);
-/* host <-> device copies of a range of one of those buffers (synchronous on the handle's stream) */
-int elph_buffer_read(elph_handle h, int which, int64_t offset, int64_t count, double *host);
-int elph_buffer_write(elph_handle h, int which, int64_t offset, int64_t count, const double *host);
-
-/* Spatial shards (north_star "shards along the spatial axis with halo exchange of the checkerboard boundary"):
- * a rank's handle is built on its slab of the lattice = its own rows of cells plus the ghost rows the fused MᵀM apply
- * reads (elphdynamics_amd/sharded.py computes them from the bond table).  elph_set_dot_range: only sites
- * [site_lo, site_hi) (0-based, the rank's own sites) enter the inner products p·z, r·r, b·b of the solver; the ghost
- * sites take part in the mat-vec and are refreshed from the neighbouring ranks once per iteration
- * (elph_buffer_read_rows / _write_rows: for every tau the sites [site_lo, site_lo + nsites) of r (which = 3) or
- * x (which = 4), host[tau * nsites + k]).  A restricted range runs the generic kernel family. */
-int elph_set_dot_range(elph_handle h, int64_t site_lo, int64_t site_hi);
-int elph_buffer_read_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, double *host);
-int elph_buffer_write_rows(elph_handle h, int which, int64_t site_lo, int64_t nsites, const double *host);
 
 /* ---------------------------------------------------------------- fermion force */
 
@@ -485,41 +455,17 @@ int elph_shard_connect(elph_handle h, const void *all_ipc_handles /* world * ELP
 int elph_shard_prepare(elph_handle h);
 int elph_shard_solve(elph_handle h, double *x_slab, const double *b_slab, double tol, int64_t maxiter, double kappa_max,
                      int64_t *iters, int *done, double *eps);
-/* measurement: exactly `iters` iterations (no stop test); *ms = HIP-event time of this rank's launch. b_slab may be NULL
- * (keeps the right-hand side of the previous call).  Needs elph_shard_prepare + barrier like a solve. */
-int elph_shard_iterate(elph_handle h, const double *b_slab, int64_t iters, double *ms);
 int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, double tol, int64_t maxiter,
                          double kappa_max, int64_t *iters, int *done, double *eps);
 int elph_shard_destroy(elph_handle h);
 
-/* ---------------------------------------------------------------- measurement hooks (bench.py) */
+/* ---------------------------------------------------------------- health of the resident kernels */
 
-/* Measurement of one hot-path unit with inputs resident in HBM (no host traffic in the timed region).
- * what: 0 = MᵀM apply, 1 = one un-preconditioned CG iteration of the two-kernel (streaming) form (k_cg_ap + k_cg_xr, stop
- *       test disabled), 2 = KPM apply, 3 = one preconditioned CG iteration, 4 = k_cg_ap alone, 5 = k_cg_xr alone,
- *       6 / 7 / 8 = the forward transform / Chebyshev recursion / inverse transform of the KPM apply alone (as the
- *       preconditioned iteration launches them), 9 = `reps` un-preconditioned CG iterations of every right-hand side in ONE
- *       launch of the workgroup-resident kernel (cg_wg.hip: the form elph_ldiv/elph_cg_solve use when elph_bench_wg_info
- *       says it applies; needs a fresh elph_bench_prepare before every run), 10 = `reps` KPM-PRECONDITIONED iterations in one
- *       launch of the resident preconditioned kernel (pcg_wg.hip: what elph_ldiv with a preconditioner runs for 1..8 right-hand
- *       sides on the 16 x 16 square lattice; ELPH_E_UNSUPPORTED elsewhere; fresh elph_bench_prepare(…, 10, …) before every run).
- * elph_bench_prepare: loads nrhs right-hand sides (B: host, reference layout, nrhs*ndim; NULL keeps what the
- *   last solve left on the device), zeroes x, seeds the CG state with tol = 0 (never converges).
- * elph_bench_run: launches `reps` units back-to-back on the handle's stream (captured graph chunks when
- *   use_graph != 0 and reps is a multiple of the chunk), brackets them with HIP events recorded on that
- *   stream, synchronises, and returns the event time in ms (total, not per rep). */
-int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B);
 /* The whole-solve-in-one-launch kernels (cg_wg.hip) wait for their team members with a wall-clock bound (ELPH_WG_TIMEOUT_MS, 2 s); a
  * launch that gives up — the GPU's CUs were held by other work — is solved again by the streaming iteration (same result to the
  * solver tolerance; ldiv!'s flags unchanged) and the handle stays on the streaming iteration for ELPH_WG_COOLDOWN solves (16) before
  * it tries again.  *cooling_down: solves left in that state (0 = the resident kernel is in use); *fallbacks: launches given up so far. */
 int elph_wg_status(elph_handle h, int *cooling_down, int64_t *fallbacks);
-int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total);
-/* Which k_cg_ap variant a batch of nrhs uses: *slices_per_wave = 1 (k_cg_ap_fast / generic) or T (k_cg_ap_chunk<T>). */
-int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave);
-/* Whether un-preconditioned solves of a batch of nrhs right-hand sides run as the workgroup-resident kernel (*usable = 1) and
- * its shape: T tau-slices per wavefront, W wavefronts per workgroup, G workgroups per right-hand side. */
-int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, int *W, int *G);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,7 @@
 """Worker of the 2-rank sharded-CG tests (launched once per rank by tests/test_sharded_*.py).
 
-usage: sharded_worker.py {numpy|gpu}[-spatial] <out.npz>
-  numpy : local compute by a numpy/oracle stand-in backend (CPU, gloo) — TEST-ONLY code path
-  gpu   : local compute by libelphgpu (both ranks on device 0, collectives staged through gloo)
+usage: sharded_worker.py numpy[-spatial] <out.npz>
+  numpy    : local compute by a numpy/oracle stand-in backend (CPU, gloo) — TEST-ONLY code path (tests/protocol_reference.py)
   -spatial : slabs of rows of cells (SpatialShardedCG) instead of tau-slabs (ShardedCG)
 """
 import os
@@ -14,12 +13,13 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from elphdynamics_amd import dist, sharded, synth  # noqa: E402
+from elphdynamics_amd import dist, synth  # noqa: E402
+import protocol_reference as sharded  # noqa: E402
 from elphdynamics_amd import lattice as lat  # noqa: E402
 
 
 class NumpyBackend:
-    """Stand-in for GpuBackend with the SAME phase semantics as k_cg_init / k_cg_state0 / k_cg_ap / k_cg_xr, local
+    """Local back end with the phase semantics of k_cg_init / k_cg_state0 / k_cg_ap / k_cg_xr, local
     operator applied by the CPU oracle.  Test infrastructure only."""
 
     def __init__(self, N, L2, table, c, s):
@@ -133,9 +133,8 @@ def main_spatial(mode, out, comm):
         x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
         E = np.exp(-dtau * (1.0 * x - 0.0))
         b = synth.randn(321, N * Ltau)
-        factory = (lambda n, l, t, c, s_: NumpyBackend(n, l, t, c, s_)) if mode == "numpy" else None
-        solver = sharded.SpatialShardedCG(comm, norb, Ls, Ls, Ltau, cb["table"], cb["cosht"], cb["sinht"], backend_factory=factory,
-                                          device=0)
+        solver = sharded.SpatialShardedCG(comm, norb, Ls, Ls, Ltau, cb["table"], cb["cosht"], cb["sinht"],
+                                          backend_factory=lambda n, l, t, c, s_: NumpyBackend(n, l, t, c, s_))
         solver.update_model(E)
         xs, it, done = solver.solve(b, tol=1e-9, maxiter=2000, check_every=4)
         res.update({f"{tag}_x": xs, f"{tag}_it": it, f"{tag}_done": done, f"{tag}_E": E, f"{tag}_b": b, f"{tag}_table": cb["table"],
@@ -160,11 +159,9 @@ def main():
     x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
     E = np.exp(-dtau * (1.0 * x - 0.0))
     b = synth.randn(321, N * Ltau)
-    if mode == "numpy":
-        factory = lambda: NumpyBackend(N, Ltau // comm.world + 2, cb["table"], cb["cosht"], cb["sinht"])  # noqa: E731
-    else:
-        factory = None
-    solver = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"], backend_factory=factory, device=0)
+    assert mode == "numpy", mode
+    factory = lambda: NumpyBackend(N, Ltau // comm.world + 2, cb["table"], cb["cosht"], cb["sinht"])  # noqa: E731
+    solver = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"], backend_factory=factory)
     solver.update_model(E)
     xs, it, done = solver.solve(b, tol=1e-9, maxiter=2000, check_every=4)
     np.savez(out + f".rank{comm.rank}", x=xs, it=it, done=done, E=E, b=b, table=cb["table"], c=cb["cosht"], s=cb["sinht"],

@@ -1,9 +1,7 @@
-"""Sharded single solve (elphdynamics_amd/sharded.py), world_size 2:
-  * CPU (gloo): the protocol — tau-slab decomposition, zeroed-wrap / sign-flipped local expV, r-halo exchange, cross-rank
-    combination of the per-slice partial sums — with a numpy/oracle stand-in for the local kernels;
-  * GPU (marked gpu): the same driver on libelphgpu's step-wise entry points, two ranks sharing device 0,
-    collectives staged through gloo (the box has one GPU; on a multi-GPU node the backend is nccl = RCCL).
-Both are checked against an un-sharded oracle solve of the same system."""
+"""Sharded single solve, world_size 2, CPU (gloo): the host-spelled protocol of tests/protocol_reference.py — slab decomposition
+(the product's `sharded.SpatialSlabs`), ghost exchange of r, cross-rank combination of the partial sums — with a numpy/oracle stand-in
+for the local kernels, checked against an un-sharded oracle solve of the same system; the slab and team-shape arithmetic of the
+in-library sharded solve at 1, 2, 4 and 8 ranks; `dist.HybridComm`.  (The in-library solve itself on the GPU: tests/test_gpu_shard.py.)"""
 import os
 import socket
 import subprocess
@@ -60,22 +58,6 @@ def test_sharded_protocol_two_ranks_cpu(tmp_path, oracle):
     _check(_run("numpy", tmp_path), oracle)
 
 
-@pytest.mark.gpu
-def test_sharded_solve_two_ranks_one_gpu(tmp_path, oracle):
-    _check(_run("gpu", tmp_path), oracle)
-
-
-@pytest.mark.gpu
-def test_sharded_solver_device_resident_nccl_path(tmp_path):
-    """The nccl (RCCL) flavour of the driver: collectives act on zero-copy torch views of the solver's device buffers,
-    kernels and collectives ordered on one stream.  One rank here (single-GPU box)."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    env.pop("WORLD_SIZE", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sharded_nccl_worker.py")], env=env, capture_output=True,
-                       text=True, timeout=600)
-    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
-
-
 # ---------------------------------------------------------------------------------------------- spatial slabs
 
 def _check_spatial(res, oracle):
@@ -98,11 +80,6 @@ def test_spatial_sharded_protocol_two_ranks_cpu(tmp_path, oracle):
     """Slabs of rows of cells + ghost rows (SpatialShardedCG): square 8x8 and honeycomb 4x4, 2 gloo ranks, numpy/oracle
     stand-in for the local kernels — the slab tables, the masked inner products, the ghost-row exchange of r."""
     _check_spatial(_run("numpy-spatial", tmp_path), oracle)
-
-
-@pytest.mark.gpu
-def test_spatial_sharded_solve_two_ranks_one_gpu(tmp_path, oracle):
-    _check_spatial(_run("gpu-spatial", tmp_path), oracle)
 
 
 def test_spatial_slab_tables():
