@@ -12,8 +12,11 @@ W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync
 ranks and value = (2 * nrhs * K * n_gpus) / time.  One JSON line on rank 0.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every GPU carries its own chains — no data-path collective, "weak"
-scaling (SURVEY.md §8e replica mode).  ONE solve sharded over the GPUs (row slabs + ghost rows, device-initiated mailbox stores) is
---mode spatial: strong scaling, latency-bound at these sizes.
+scaling (SURVEY.md §8e replica mode) — that is `value`.  The same run then records the north_star's OTHER curve as the sub-record
+`spatial`: ONE solve of configs C, D and E sharded over the N ranks (row slabs + ghost rows, device-initiated mailbox stores, the
+in-library path of csrc/shard.hip) with its device time per iteration, mat-vecs/s, fraction of the f64 roof of the N GPUs, the rank
+count RCCL sees and the peer-access matrix.  `--mode spatial` makes that solve (of --config) the headline line instead: strong
+scaling, latency-bound at these sizes; its line carries `roofline` and, on one rank, `cpu_baseline` too.
 
 The JSON line (the driver's record keeps SCALARS of `roofline` and `cpu_baseline` only, so everything that matters is a flat key):
   roofline      the dominant kernel of the timed region.  Resident kernel: bound = "f64_vector+sync" — achieved = flops of the launch
@@ -68,11 +71,12 @@ def parse():
                     help="independent phonon configurations (Markov chains) per GPU sharing the batch: right-hand side r "
                          "uses the fermion matrix of chain r %% chains (nrhs = 2*chains = both pseudofermion solves of one "
                          "HMC force evaluation per chain); 1 = all right-hand sides on one matrix")
-    ap.add_argument("--mode", default="chains", choices=["chains", "sharded", "spatial"],
-                    help="chains (default): independent chains per GPU, no data-path collective (weak scaling). "
-                         "sharded: ONE solve, tau-slabs over the GPUs; spatial: ONE solve, slabs of rows of cells + ghost "
-                         "rows (the north_star's decomposition) — RCCL halo exchange + all-gathers per iteration "
-                         "(strong scaling; latency-bound at these sizes, reported for completeness)")
+    ap.add_argument("--mode", default="chains", choices=["chains", "spatial"],
+                    help="chains (default): independent chains per GPU, no data-path collective (weak scaling; with N > 1 the line "
+                         "also carries the `spatial` sub-record).  spatial: ONE solve of --config over the N ranks, slabs of rows of "
+                         "cells + ghost rows (the north_star's decomposition), device-initiated mailbox stores, as the headline "
+                         "(strong scaling; latency-bound at these sizes)")
+    ap.add_argument("--spatial-steps", type=int, default=2000, help="iterations of each sharded solve of the `spatial` sub-record")
     ap.add_argument("--ranks-per-proc", type=int, default=1,
                     help="--mode spatial only: rank threads per process (rehearsal of more ranks than the one-GPU box admits "
                          "processes: 8 ranks = 4 processes x 2; --gpus = total ranks)")
@@ -81,6 +85,7 @@ def parse():
     ap.add_argument("--streaming", action="store_true", help="time the two-kernel (HBM-streaming) iteration instead of the workgroup-resident kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary nrhs sweep")
+    ap.add_argument("--no-spatial", action="store_true", help="skip the `spatial` sub-record (sharded solves of C, D, E over the ranks)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     return ap.parse_args()
 
@@ -103,7 +108,7 @@ def main():
         args.no_cpu = True
         args.no_sweep = True
     import numpy as np
-    if args.mode in ("sharded", "spatial"):
+    if args.mode == "spatial":
         return main_sharded(args, comm)
     from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth
     from elphdynamics_amd._lib import check
@@ -198,6 +203,7 @@ def main():
             "cg_iters_per_sec": nrhs * K * world / elapsed,
             "cg_batch_steps_per_sec": K / elapsed,
             "ms_per_step_events": ms_events / K,
+            "build_info": lib.elph_build_info().decode(),
         }
 
         # ---- roofline ------------------------------------------------------------------------------------------------------------
@@ -322,6 +328,13 @@ def main():
                 rp["precond_bytes"] = byts[3]
                 rp["precond_hbm_frac"] = rp["precond_iter_hbm_frac"]
                 rp["precond_matvecs_per_sec"] = 2.0 * nrhs / (rp["precond_iter_us"] * 1e-6)
+                # co-headline: the PRODUCTION path (every deck has [solver.preconditioner]; BASELINE config 3 "with tau-FFT precond") — the
+                # same batch, one KPM-preconditioned CG iteration per step (k_cg_ap + forward transform with the residual update +
+                # Chebyshev + inverse transform), timed in flight with HIP events
+                out["precond_value"] = rp["precond_matvecs_per_sec"]
+                out["precond_unit"] = "matvec/s"
+                out["precond_ms_per_step"] = rp["precond_iter_us"] * 1e-3
+                out["precond_cg_iters_per_sec"] = nrhs / (rp["precond_iter_us"] * 1e-6)
                 out["roofline"].update(rp)
                 out["roofline_preconditioned"] = dict(rp, note=(
                     "bytes: k_cg_ap 6 vectors + tables (src = P^-1 r); forward transform reads r, z and writes r, nu (4 vectors); Chebyshev reads "
@@ -528,76 +541,169 @@ def main():
                         out["cpu_baseline_all_cores"] = {"value": None, "note": f"failed: {e}"}
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out))
     m.close()
+    # ---- the north_star's other curve: ONE solve of configs C, D, E sharded over the N ranks (all ranks take part; N = 1 included as
+    # the first point of the 1 / 2 / 4 / 8 series unless the secondary measurements are off)
+    spatial = None
+    if not args.no_spatial and (world > 1 or not args.no_sweep):
+        spatial = spatial_records(comm, args.spatial_steps, cpu=False)
+    if rank == 0:
+        if spatial is not None:
+            out["spatial"] = spatial
+        print(json.dumps(out))
     comm.close()
 
 
-def main_sharded(args, comm):
-    """ONE config solve sharded over the ranks: step = one CG iteration of that solve.
-    --mode spatial: the in-library path (csrc/shard.hip: resident CG kernel per rank, device-initiated mailbox stores, no
-    collective in the iteration); --mode sharded: tau-slabs through the step-wise API + torch.distributed (round-1 harness)."""
+F64_FLOPS_PER_ITER = lambda ndim, ltau, nbonds: 2.0 * (2.0 * ndim + 6.0 * ltau * nbonds) + 10.0 * ndim     # noqa: E731  SURVEY §8(d)
+
+
+def spatial_record(tag, world, ranks_rccl, K, ms_dev_max, elapsed_max, N, Ltau, nbonds, slab, peer, selftest_us, backend):
+    """The JSON sub-record of one sharded solve (pure arithmetic: the CPU test of the schema calls it at world 2 over gloo).
+    ms_dev_max: MAX over ranks of the HIP-event time of the K-iteration launch; elapsed_max: MAX of the host time around it."""
+    us_dev = 1e3 * ms_dev_max / K
+    flops = F64_FLOPS_PER_ITER(N * Ltau, Ltau, nbonds)
+    tfl = flops / (us_dev * 1e-6) / 1e12
+    return {
+        "config": tag, "workload": f"ONE un-preconditioned CG solve of BASELINE config {tag} (N={N}, Ltau={Ltau}) over {world} rank(s): {slab}",
+        "ranks": world, "rccl_ranks": ranks_rccl, "dist_backend": backend, "iterations": K,
+        "us_per_iteration_device": us_dev, "us_per_iteration_host": 1e6 * elapsed_max / K,
+        "matvecs_per_sec": 2.0 / (us_dev * 1e-6), "cg_iters_per_sec": 1.0 / (us_dev * 1e-6),
+        "bound": "f64_vector+sync", "achieved": tfl, "peak": F64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+        "frac": tfl / (F64_MFMA_PEAK_TFLOPS * world),
+        "hbm_streaming_equivalent_frac": ALG_BYTES_PER_ELT["cg_iter"] * N * Ltau / (us_dev * 1e-6) / 1e9 / (HBM_PEAK_GBS * world),
+        "peer_access": peer, "selftest_us_per_round": selftest_us,
+        "scaling": "strong", "transport": "device-initiated stores into hipIpc / peer-mapped mailboxes, one inter-rank hop per iteration; no collective",
+    }
+
+
+def peer_matrix(lib, ndev):
+    """hipDeviceCanAccessPeer for every pair of the first ndev devices (None where the library cannot tell: no GPU)."""
+    can = C.c_int()
+    rows = []
+    for a in range(ndev):
+        row = []
+        for b in range(ndev):
+            row.append(int(can.value) if lib.elph_peer_access(a, b, C.byref(can)) == 0 else None)
+        rows.append(row)
+    return rows
+
+
+def make_sharded(tag, comm):
+    """ShardedSolver of a BASELINE config with its synthetic model set: (solver, b, N, Ltau, nbonds, slab description)."""
     import numpy as np
     from elphdynamics_amd import configs, lattice as lat, sharded, synth
-    kind, norb, Ls, bonds, beta, dtau = configs.CONFIGS[args.config]
+    kind, norb, Ls, bonds, beta, dtau = configs.CONFIGS[tag]
     la = lat.Lattice(norb, Ls, Ls if Ls > 1 else 1, 1)
     raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
     cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), dtau)
     N, Ltau = la.nsites, lat.ltau_from_beta(beta, dtau)
     b = synth.rhs(N * Ltau)
-    spatial = args.mode == "spatial"
+    s = sharded.ShardedSolver(comm, norb, la.L1, la.L2, Ltau, cb["table"], kind=0 if kind == "holstein" else 1,
+                              cosht=cb["cosht"], sinht=cb["sinht"])
+    if kind == "holstein":
+        s.update_model(np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)))        # lambda = 1, mu = 0 (configs.py)
+    else:
+        nb = raw.shape[0]
+        xb = 0.25 * synth.phonon_field(nb, Ltau, beta, dtau, omega=0.1, lam=0.0).reshape(nb, Ltau)
+        tp = 1.0 - 0.1 * xb
+        s.update_model_ssh(np.cosh(dtau * tp), np.sinh(dtau * tp), np.ones(N))
+    slab = (f"slabs of rows of cells (+{s.sl['lo']}/{s.sl['hi']} ghost rows; {s.Nloc} of {N} sites on rank 0), resident CG kernel per rank, "
+            f"partial sums and boundary rows by device-initiated stores into mapped mailboxes")
+    return s, b, N, Ltau, raw.shape[0], slab
+
+
+def measure_sharded(tag, comm, K, W, factory=None):
+    """One sharded solve of K iterations after W warm-up iterations: the sub-record (identical on every rank).  factory: stand-in for
+    make_sharded (the CPU test of the record's schema; the product path has none)."""
+    from elphdynamics_amd import _lib
+    lib = _lib.load()
+    s, b, N, Ltau, nb, slab = (factory or make_sharded)(tag, comm)
+    if W:
+        s.iterate(b, W)
+    comm.barrier()
+    t0 = time.perf_counter()
+    ms_dev = s.iterate(b, K)                   # returns when this rank's launch has finished (includes prepare + barrier)
+    comm.barrier()
+    elapsed = comm.max(time.perf_counter() - t0)
+    ms_dev = comm.max(ms_dev)
+    rccl = None
+    dist = getattr(comm, "dist", None) or getattr(getattr(getattr(comm, "sh", None), "proc_comm", None), "dist", None)
+    if dist is not None and dist.is_initialized():
+        rccl = int(dist.get_world_size())
+    devs = sorted(set(comm.allgather_object(comm.device_index())))
+    peer = peer_matrix(lib, max(devs) + 1) if lib.elph_device_count() > 0 else None
+    st = [float(x) for x in s.selftest_us] if s.selftest_us is not None else None
+    rec = spatial_record(tag, comm.world, rccl, K, ms_dev, elapsed, N, Ltau, nb, slab, peer, st, getattr(comm, "backend", None))
+    rec["devices"] = devs
+    s.close()
+    return rec
+
+
+def spatial_records(comm, K, cpu=False, factory=None):
+    """Configs C, D and E over the ranks of `comm`; a config whose slabs do not fit this rank count is recorded with its reason."""
+    out = {"note": "unmeasured across physical GPUs until a multi-GPU node runs this: on a one-GPU box every rank shares device 0 "
+                   "(ELPH_FORCE_DEVICE) and the numbers are the protocol's cost, not xGMI's"} if len(set(comm.allgather_object(comm.device_index()))) < comm.world and comm.world > 1 else {}
+    for tag in ("C", "D", "E"):
+        try:
+            out[tag] = measure_sharded(tag, comm, K, max(1, K // 10), factory)
+        except Exception as e:     # the same exception on every rank (geometry) — or a failed rank: recorded, never fatal for the headline
+            out[tag] = {"config": tag, "ranks": comm.world, "error": repr(e)}
+    return out
+
+
+def main_sharded(args, comm):
+    """--mode spatial: ONE solve of --config sharded over the ranks is the headline; step = one CG iteration of that solve (the
+    in-library path, csrc/shard.hip: resident CG kernel per rank, device-initiated mailbox stores, no collective in the iteration)."""
     K, W = args.steps, args.warmup
-    if spatial:
-        s = sharded.ShardedSolver(comm, norb, la.L1, la.L2, Ltau, cb["table"], kind=0 if kind == "holstein" else 1,
-                                  cosht=cb["cosht"], sinht=cb["sinht"])
+    rec = measure_sharded(args.config, comm, K, W)
+    if comm.rank == 0:
+        out = {"metric": "cg_matvecs_per_sec", "value": rec["matvecs_per_sec"], "unit": "matvec/s", "n_gpus": comm.world, "steps": K,
+               "warmup": W, "ms_per_step": rec["us_per_iteration_device"] * 1e-3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": rec["workload"], "parallelism": f"row_slabs{comm.world}"},
+               "cg_iters_per_sec": rec["cg_iters_per_sec"], "us_per_iteration_device": rec["us_per_iteration_device"],
+               "roofline": {k: rec[k] for k in ("bound", "achieved", "peak", "unit", "frac", "hbm_streaming_equivalent_frac")} |
+                           {"kernel": "k_cg_wg<SHARD>", "traffic": None, "ranks": rec["ranks"], "rccl_ranks": rec["rccl_ranks"]},
+               "spatial": {args.config: rec}}
+        if not args.no_cpu and comm.world >= 1:
+            out["cpu_baseline"] = cpu_baseline_leg(args.config, args.cpu_seconds)
+        print(json.dumps(out))
+    comm.close()
+
+
+def cpu_baseline_leg(tag, seconds):
+    """The CPU oracle (1 thread = the reference's configuration) on a bounded sample of config `tag` with the synthetic model of
+    make_sharded: un-preconditioned CG iterations of one right-hand side."""
+    try:
+        import numpy as np
+        from elphdynamics_amd import configs, lattice as lat, synth
+        from oracle.oracle import Oracle
+        orc = Oracle(fast=True)
+        kind, norb, Ls, bonds, beta, dtau = configs.CONFIGS[tag]
+        la = lat.Lattice(norb, Ls, Ls if Ls > 1 else 1, 1)
+        raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+        cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), dtau)
+        N, Ltau = la.nsites, lat.ltau_from_beta(beta, dtau)
         if kind == "holstein":
-            s.update_model(np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)))        # lambda = 1, mu = 0 (configs.py)
+            om = orc.make_model(0, N, Ltau, cb["table"], cb["cosht"], cb["sinht"], np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)))
         else:
             nb = raw.shape[0]
-            xb = 0.25 * synth.phonon_field(nb, Ltau, beta, dtau, omega=0.1, lam=0.0).reshape(nb, Ltau)
-            tp = 1.0 - 0.1 * xb
-            s.update_model_ssh(np.cosh(dtau * tp), np.sinh(dtau * tp), np.ones(N))
-        if W:
-            s.iterate(b, W)
-        comm.barrier()
-        t0 = time.perf_counter()
-        ms_dev = s.iterate(b, K)                   # returns when this rank's launch has finished (includes prepare + barrier)
-        comm.barrier()
-        elapsed = comm.max(time.perf_counter() - t0)
-        ms_dev = comm.max(ms_dev)
-        descr = (f"slabs of rows of cells (+{s.sl['lo']}/{s.sl['hi']} ghost rows; {s.Nloc} of {N} sites on rank 0) over {comm.world} "
-                 f"rank(s), resident CG kernel per rank, partial sums and boundary rows by device-initiated stores into hipIpc-mapped "
-                 f"mailboxes (no collective, no host in the iteration)")
-        par = f"row_slabs{comm.world}"
-    else:
-        assert kind == "holstein", "tau-slab harness: Holstein models"
-        import torch                      # noqa: F401  (first, so that libelphgpu shares torch's HIP runtime)
-        s = sharded.ShardedCG(comm, N, Ltau, cb["table"], cb["cosht"], cb["sinht"])
-        s.update_model(np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)))
-        s.prepare(b)
-        s.run_iterations(W)
-        s.prepare(b)
-        comm.barrier()
-        t0 = time.perf_counter()
-        s.run_iterations(K)
-        comm.barrier()
-        elapsed = comm.max(time.perf_counter() - t0)
-        ms_dev = None
-        descr = (f"tau-slabs over {comm.world} GPU(s), step-wise API, 1 r-halo exchange + 2 partial-sum all-gathers per iteration "
-                 f"({'RCCL, device-resident' if s.dev is not None else 'host-staged'})")
-        par = f"tau_slabs{comm.world}"
-    if comm.rank == 0:
-        out = {"metric": "cg_matvecs_per_sec", "value": 2.0 * K / elapsed, "unit": "matvec/s", "n_gpus": comm.world, "steps": K,
-               "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"BASELINE config {args.config}: ONE un-preconditioned CG solve (N={N}, Ltau={Ltau}), " + descr,
-                          "parallelism": par},
-               "cg_iters_per_sec": K / elapsed}
-        if ms_dev is not None:
-            out["us_per_iteration_device"] = 1e3 * ms_dev / K
-        print(json.dumps(out))
-    s.close()
-    comm.close()
+            tp = 1.0 - 0.1 * 0.25 * synth.phonon_field(nb, Ltau, beta, dtau, omega=0.1, lam=0.0).reshape(nb, Ltau)
+            om = orc.make_model(1, N, Ltau, cb["table"], np.cosh(dtau * tp).reshape(-1), np.sinh(dtau * tp).reshape(-1), np.ones(N))
+        b0 = synth.rhs(N * Ltau)
+        tt = time.perf_counter()
+        orc.cg_solve(om, b0, tol=0.0, maxiter=100)
+        per_it = (time.perf_counter() - tt) / 100
+        n_it = int(max(100, min(200000, seconds / per_it)))
+        tt = time.perf_counter()
+        orc.cg_solve(om, b0, tol=0.0, maxiter=n_it)
+        dt = time.perf_counter() - tt
+        return {"value": 2.0 * n_it / dt, "unit": "matvec/s", "cores": 1, "kind": "port",
+                "sample": f"{n_it} un-preconditioned CG iterations (tol=0) of one right-hand side of config {tag}, oracle/elph_oracle.c built "
+                          f"-O3 -march=native -ffast-math, single thread ({os.cpu_count()} host cores present)",
+                "cg_iters_per_sec": n_it / dt, "seconds": dt}
+    except Exception as e:
+        return {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
 
 
 if __name__ == "__main__":

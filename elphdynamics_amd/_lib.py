@@ -95,6 +95,8 @@ SIGNATURES = {
     "elph_shard_create": (c_int, [Handle, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, P_i64, C.c_void_p]),
     "elph_shard_connect": (c_int, [Handle, C.c_void_p]),
     "elph_shard_prepare": (c_int, [Handle]),
+    "elph_shard_selftest": (c_int, [Handle, c_int, P_dbl, P_dbl]),
+    "elph_peer_access": (c_int, [c_int, c_int, P_int]),
     "elph_shard_solve": (c_int, [Handle, P_dbl, P_dbl, c_dbl, c_i64, c_dbl, P_i64, P_int, P_dbl]),
     "elph_shard_solve_kpm": (c_int, [Handle, Handle, P_dbl, P_dbl, c_dbl, c_i64, c_dbl, P_i64, P_int, P_dbl]),
     "elph_shard_destroy": (c_int, [Handle]),

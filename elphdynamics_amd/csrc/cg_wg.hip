@@ -1190,8 +1190,7 @@ int elph_wg_cooldown_step(elph_handle_s *h) {
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran) {
     *ran = false;
     if (B.params.use_prec) return ELPH_OK;
-    { const int rcs = elph_wg_cooldown_step(h); if (rcs) return rcs; }
-    if (h->wg_broken) return ELPH_OK;
+    if (h->wg_broken) return ELPH_OK;                   // (cooling down after a time-out: elph_wg_cooldown_step, run_cg)
     if (!elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs)) return ELPH_OK;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;

@@ -715,6 +715,7 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
     }
     if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);   // parameters are baked into captured launches
     h->cur_params = P;
+    RC(elph_wg_cooldown_step(h));          // one solve of the cool-down after a resident kernel timed out (either kernel, either kind of solve)
     RC(elph_launch_cg_init(h, nrhs, use_prec, x0_zero));      // (x0 = 0: A x0 = 0 without the mat-vec)
     h->wg_x0_zero = h->x_zero_seen;
 
@@ -1637,9 +1638,10 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
         hipError_t er = hipStreamSynchronize(h->stream);
         if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
         if (er == hipSuccess) {
+            rc = elph_wg_cooldown_step(h);
             h->wg_x0_zero = h->bench_fresh && h->x_zero_seen;      // (x is known to be zero only right after elph_bench_prepare)
             h->bench_fresh = false;
-            rc = (what == 9) ? elph_wg_cg(h, B, nrhs, reps, &ran) : elph_pcg_wg(h, B, nrhs, reps, &ran);
+            if (rc == ELPH_OK) rc = (what == 9) ? elph_wg_cg(h, B, nrhs, reps, &ran) : elph_pcg_wg(h, B, nrhs, reps, &ran);
             if (rc == ELPH_OK && !ran) { elph_set_error("the workgroup-resident kernel does not apply to this handle"); rc = ELPH_E_UNSUPPORTED; }
         }
         if (er == hipSuccess && rc == ELPH_OK) er = hipEventRecord(e1, h->stream);

@@ -569,9 +569,7 @@ bool elph_pcg_wg_usable(const elph_handle_s *h, int nrhs) { return pcg_shape(h, 
 int elph_pcg_wg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran) {
     *ran = false;
     int W = 0, G = 0, nt = 0;
-    if (!B.params.use_prec) return ELPH_OK;
-    { const int rcs = elph_wg_cooldown_step(h); if (rcs) return rcs; }       // (a handle that only runs preconditioned solves recovers here)
-    if (!pcg_shape(h, nrhs, &W, &G, &nt)) return ELPH_OK;
+    if (!B.params.use_prec || !pcg_shape(h, nrhs, &W, &G, &nt)) return ELPH_OK;
     ModelDev m = elph_model_dev(h);
     if (!m.uniform || !m.sq_bond) return ELPH_OK;
     const size_t n_slots = 2 * (size_t)nrhs * wg::SLOTS_PER_RHS, n_flags = (size_t)nrhs * wg::PCG_FLAGS;

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "elph_internal.h"
@@ -35,6 +36,7 @@ struct ShardState {
     int *d_gsites = nullptr;                  // [N_loc] global site of every slab site
     int *d_counter = nullptr, *d_abort = nullptr;
     unsigned epoch = 0;
+    unsigned selftest_calls = 0;
 };
 
 // mailbox layout (u64 words), identical on all ranks:
@@ -428,6 +430,101 @@ long long elph_shard_timeout_ms() {
     return ms > 0 ? ms : 20000;
 }
 static long long shard_timeout_ticks() { return elph_shard_timeout_ms() * 100000LL; }      // wall_clock64 runs at 100 MHz
+
+// ---- preflight of the mailbox protocol (elph_shard_selftest) ---------------------------------------------------------------------------
+// `rounds` lock-step rounds between ALL ranks, one wave per rank: in round k every rank stores the granule {seq, k} into slot [rank] of
+// all-sum record 7 in every peer's mailbox (the same sc1 / system-scope stores the solve uses: hipIpc- or pointer-mapped memory, xGMI
+// between GPUs) and polls its own mailbox until every peer's granule shows round >= k.  lat[q] = mean ticks between this rank's store
+// of round k and seeing rank q's; status[q] = 1 when rank q never answered within the bound.  Nothing else in the library uses record 7.
+__global__ void __launch_bounds__(64) k_shard_selftest(ElphShardCtl Sh, size_t ext_off, unsigned seq, int rounds, long long timeout_ticks,
+                                                       long long *lat, int *status) {
+    const int lane = threadIdx.x, P = Sh.P;
+    const size_t base = ext_off + (size_t)7 * 8 * 2;
+    long long acc = 0;
+    bool dead = false;
+    for (int k = 1; k <= rounds; ++k) {
+        const u64s g = ((u64s)seq << 32) | (u64s)(unsigned)k;
+        if (lane < P) sst(Sh.mail[lane] + base + (size_t)Sh.rank * 2, g);
+        const long long t_store = wall_clock64();
+        bool seen = (lane >= P);
+        long long t_seen = t_store;
+        for (int spin = 0;; ++spin) {
+            if (!seen) {
+                const u64s v = sld(Sh.mail[Sh.rank] + base + (size_t)lane * 2);
+                if ((unsigned)(v >> 32) == seq && (unsigned)v >= (unsigned)k) { seen = true; t_seen = wall_clock64(); }
+            }
+            if (__all(seen)) break;
+            if ((spin & 31) == 31 && wall_clock64() - t_store > timeout_ticks) { dead = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (dead) { if (lane < P) status[lane] = seen ? 0 : 1; break; }
+        acc += t_seen - t_store;
+    }
+    if (lane < P) { lat[lane] = dead ? -1 : acc; if (!dead) status[lane] = 0; }
+}
+
+// Collective over the ranks of a connected shard, under the protocol of a solve: elph_shard_prepare on every rank, the caller's barrier,
+// then this call on every rank.  us_per_round[P] (may be NULL): mean time between this rank's store and the sight of rank q's granule
+// (own entry: the local round trip); *slowest_us: the largest of them.  A peer that does not answer within ELPH_SHARD_SELFTEST_MS
+// (default 10 s: first contact includes code loading and whatever skew the host barrier leaves) gives ELPH_E_HIP with the silent
+// ranks named — at set-up, instead of a time-out inside the first solve.
+extern "C" int elph_shard_selftest(elph_handle h, int rounds, double *us_per_round, double *slowest_us) {
+    if (!h || !h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
+    HIPCHK(hipSetDevice(h->device));
+    ShardState *S = static_cast<ShardState *>(h->shard);
+    if (!S->prepared) { elph_set_error("elph_shard_prepare (and the caller's barrier) must precede elph_shard_selftest"); return ELPH_E_STATE; }
+    S->prepared = false;
+    if (rounds < 1 || rounds > (1 << 20)) { elph_set_error("bad number of rounds"); return ELPH_E_ARG; }
+    const int P = S->ctl.P;
+    long long *d_lat = nullptr;
+    HIPCHK(hipMalloc((void **)&d_lat, 64 * sizeof(long long) + 64 * sizeof(int)));
+    int *d_status = reinterpret_cast<int *>(d_lat + 64);
+    HIPCHK(hipMemsetAsync(d_lat, 0xFF, 64 * sizeof(long long) + 64 * sizeof(int), h->stream));
+    const char *eb = getenv("ELPH_SHARD_SELFTEST_MS");
+    const long long bound_ms = (eb && atoll(eb) > 0) ? atoll(eb) : 10000;
+    const unsigned seq = 0x5E1F0000u + (++S->selftest_calls & 0xFFFFu);       // (a collective: every rank's n-th call carries the same number)
+    hipLaunchKernelGGL(k_shard_selftest, dim3(1), dim3(64), 0, h->stream, S->ctl, S->ext_off, seq, rounds, bound_ms * 100000LL, d_lat, d_status);
+    int rc = launch_ok("k_shard_selftest");
+    long long lat[ELPH_SHARD_MAXRANKS];
+    int status[ELPH_SHARD_MAXRANKS];
+    if (rc == ELPH_OK) {
+        hipError_t e = hipMemcpyAsync(lat, d_lat, sizeof(long long) * (size_t)P, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(status, d_status, sizeof(int) * (size_t)P, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { elph_set_error("elph_shard_selftest: %s", hipGetErrorString(e)); rc = ELPH_E_HIP; }
+    }
+    (void)hipFree(d_lat);
+    if (rc) return rc;
+    std::string silent;
+    double worst = 0.0;
+    for (int q = 0; q < P; ++q) {
+        if (status[q] != 0) { silent += (silent.empty() ? "" : ", ") + std::to_string(q); continue; }
+        const double us = (double)lat[q] / (double)rounds / 100.0;       // wall_clock64: 100 MHz
+        if (us_per_round) us_per_round[q] = us;
+        worst = std::max(worst, us);
+    }
+    if (!silent.empty()) {
+        elph_set_error("elph_shard_selftest: rank %d saw no mailbox granule from rank(s) %s within %lld ms (peer mapping, peer access or the "
+                       "prepare/barrier order is broken)", S->ctl.rank, silent.c_str(), bound_ms);
+        return ELPH_E_HIP;
+    }
+    if (slowest_us) *slowest_us = worst;
+    return ELPH_OK;
+}
+
+// Whether device `dev_a` can map memory of device `dev_b` (hipDeviceCanAccessPeer; 1 for dev_a == dev_b): what the mailbox stores of a
+// solve sharded over the GPUs of a node need.  No handle, no context switch.
+extern "C" int elph_peer_access(int dev_a, int dev_b, int *can) {
+    if (!can) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { elph_set_error("no HIP device visible"); return ELPH_E_NOGPU; }
+    if (dev_a < 0 || dev_b < 0 || dev_a >= n || dev_b >= n) { elph_set_error("device index out of range (%d devices)", n); return ELPH_E_ARG; }
+    if (dev_a == dev_b) { *can = 1; return ELPH_OK; }
+    int c = 0;
+    HIPCHK(hipDeviceCanAccessPeer(&c, dev_a, dev_b));
+    *can = c;
+    return ELPH_OK;
+}
 
 static int allsum(elph_handle_s *h, ShardState *S, double *part, int n, int slot) {
     hipLaunchKernelGGL(k_shard_allsum, dim3(1), dim3(64), 0, h->stream, part, n, S->ctl, S->ext_off, slot, ++S->epoch, S->d_abort,

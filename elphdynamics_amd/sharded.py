@@ -13,6 +13,7 @@ device-initiated stores into the neighbours' mailboxes.  This module is the host
 tests/protocol_reference.py.)
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -110,7 +111,7 @@ class ShardedSolver:
     kind 1 (SSH): `update_model_ssh(cosht_global[Nbonds, Ltau], sinht_global, expDtauMu_global)` — the per-(τ, bond) tables are
     sharded by bond owner: a rank holds the columns of the bonds inside its slab (SSHModels.jl:581-701)."""
 
-    def __init__(self, comm, norbits, L1, L2, ltau, table, kind=0, cosht=None, sinht=None, device=None):
+    def __init__(self, comm, norbits, L1, L2, ltau, table, kind=0, cosht=None, sinht=None, device=None, selftest=True):
         from . import _lib
         self._lib_mod, self.lib = _lib, _lib.load()
         self.comm, self.P, self.rank = comm, comm.world, comm.rank
@@ -148,6 +149,27 @@ class ShardedSolver:
             self._allh = C.create_string_buffer(allh, len(allh))
             _lib.check(self.lib.elph_shard_connect(self.h, C.cast(self._allh, C.c_void_p)))
         comm.barrier()
+        # preflight of the mailbox protocol between every pair of ranks: a broken peer mapping shows HERE, with the silent ranks named,
+        # instead of as a time-out inside the first solve.  selftest_us[q]: mean time from this rank's store to the sight of rank q's.
+        self.selftest_us = None
+        if selftest and os.environ.get("ELPH_SHARD_NO_SELFTEST") != "1":
+            self.selftest_us = self.selftest()
+
+    def selftest(self, rounds=64):
+        """elph_shard_selftest: `rounds` lock-step granule exchanges between all pairs of ranks; returns us per round per peer."""
+        us = np.zeros(self.P)
+        worst = C.c_double()
+        self._lib_mod.check(self.lib.elph_shard_prepare(self.h))
+        self.comm.barrier()
+        rc = self.lib.elph_shard_selftest(self.h, int(rounds), self._lib_mod.dptr(us), C.byref(worst))
+        err = self.lib.elph_last_error().decode() if rc else ""
+        bad = self.comm.allgather_object((self.rank, rc, err)) if self.P > 1 else [(self.rank, rc, err)]
+        self.comm.barrier()
+        failed = [(r, e) for r, c, e in bad if c]
+        if failed:
+            raise self._lib_mod.ElphError(-2, "; ".join(f"rank {r}: {e}" for r, e in failed))
+        self.selftest_slowest_us = float(worst.value)
+        return us
 
     def _local(self, v_global):
         return np.ascontiguousarray(np.asarray(v_global).reshape(self.N, self.Ltau)[self.gsites, :]).reshape(-1)

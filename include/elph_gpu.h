@@ -453,6 +453,15 @@ int elph_shard_create(elph_handle h, int rank, int world, int64_t own_lo, int64_
                       const int64_t *global_sites, void *ipc_handle_out);
 int elph_shard_connect(elph_handle h, const void *all_ipc_handles /* world * ELPH_SHARD_IPC_BYTES, rank order */);
 int elph_shard_prepare(elph_handle h);
+/* Preflight of the mailbox protocol, a collective like a solve (elph_shard_prepare on every rank, the caller's barrier, then this on
+ * every rank): `rounds` lock-step exchanges of one tagged granule between ALL pairs of ranks through the mapped mailboxes — the stores
+ * and polls a solve uses (xGMI peer stores between GPUs).  us_per_round[world] (may be NULL): mean time from this rank's store to the
+ * sight of rank q's granule; *slowest_us: their maximum.  A rank that does not answer within ELPH_SHARD_SELFTEST_MS (10 s) gives
+ * ELPH_E_HIP with the silent ranks named — at set-up instead of a time-out inside the first solve. */
+int elph_shard_selftest(elph_handle h, int rounds, double *us_per_round, double *slowest_us);
+/* *can = 1 when device dev_a can map memory of dev_b (hipDeviceCanAccessPeer; 1 on the diagonal): what a solve sharded over the
+ * GPUs of a node needs between ring neighbours (boundary rows) and all pairs (rank records). */
+int elph_peer_access(int dev_a, int dev_b, int *can);
 int elph_shard_solve(elph_handle h, double *x_slab, const double *b_slab, double tol, int64_t maxiter, double kappa_max,
                      int64_t *iters, int *done, double *eps);
 int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, double tol, int64_t maxiter,

@@ -36,6 +36,8 @@ def run_rank(comm, case, out, tol):
     b = synth.randn(321, N * Ltau)
     res = dict(N=N, Ltau=Ltau, kind=kind, table=cb["table"], b=b)
     solver = sharded.ShardedSolver(comm, norb, Ls, Ls, Ltau, cb["table"], kind=kind, cosht=cb["cosht"], sinht=cb["sinht"], device=0)
+    # the preflight of the mailbox protocol ran in the constructor (elph_shard_selftest): us per lock-step round, per peer
+    res.update(selftest_us=np.asarray(solver.selftest_us), selftest_slowest_us=solver.selftest_slowest_us)
     if kind == 0:
         x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
         E = np.exp(-dtau * x)

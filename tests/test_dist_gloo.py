@@ -61,3 +61,64 @@ def test_two_rank_gloo_replica_path(tmp_path):
     assert a["seed"] != b["seed"] and a["x0"] != b["x0"]          # independent chains
     assert a["elapsed"] == b["elapsed"] and a["work"] == b["work"] == 120.0
     assert a["elapsed"] >= 0.1 - 1e-3                               # MAX over ranks (rank 1 slept 0.1 s)
+
+
+SPATIAL_WORKER = textwrap.dedent("""
+    import json, sys, time
+    sys.path.insert(0, %r)
+    import bench
+    from elphdynamics_amd import dist
+    comm = dist.Comm(backend="gloo")
+
+    class FakeSolver:                       # stands in for sharded.ShardedSolver (no GPU here): what the record reads from it
+        sl = {"lo": 2, "hi": 2}
+        Nloc = 96
+        selftest_us = [0.4, 1.3]
+        def iterate(self, b, k):
+            time.sleep(0.001 * (1 + comm.rank))
+            return 0.006 * k * (1 + comm.rank)      # ms of the launch: rank 1 is slower, MAX must pick it up
+        def close(self):
+            pass
+
+    def factory(tag, comm_):
+        if tag == "D":
+            raise ValueError("ghost rows reach beyond the neighbouring rank: use fewer ranks")
+        return FakeSolver(), None, 256, 160, 512, "stand-in slabs"
+
+    rec = bench.spatial_records(comm, 200, factory=factory)
+    print(json.dumps({"rank": comm.rank, "rec": rec}), flush=True)
+    comm.close()
+""") % ROOT
+
+
+def test_spatial_sub_record_schema_two_ranks_gloo(tmp_path):
+    """bench.py's `spatial` sub-record (ONE solve of C, D, E sharded over the ranks) at world 2 over gloo with a stand-in solver: the
+    keys the north_star's curve needs, MAX over ranks of the device time, the rank count the process group sees, identical records
+    on every rank, and a config that does not fit recorded with its reason instead of killing the line."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(SPATIAL_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    a, b = sorted(outs, key=lambda d: d["rank"])
+    assert a["rec"] == b["rec"]
+    rec = a["rec"]
+    assert set(rec) >= {"C", "D", "E"}
+    c = rec["C"]
+    for key in ("config", "ranks", "rccl_ranks", "dist_backend", "iterations", "us_per_iteration_device", "us_per_iteration_host",
+                "matvecs_per_sec", "cg_iters_per_sec", "bound", "achieved", "peak", "unit", "frac", "peer_access",
+                "selftest_us_per_round", "scaling", "devices"):
+        assert key in c, key
+    assert c["ranks"] == 2 and c["rccl_ranks"] == 2 and c["dist_backend"] == "gloo" and c["scaling"] == "strong"
+    assert abs(c["us_per_iteration_device"] - 12.0) < 1e-9                 # MAX over ranks: 0.006 ms x 2 per iteration
+    assert abs(c["matvecs_per_sec"] - 2.0 / 12e-6) < 1e-3
+    assert c["peak"] == 2 * 78.6 and 0.0 < c["frac"] < 1.0 and c["unit"] == "TFLOP/s"
+    assert "error" in rec["D"] and "ghost rows" in rec["D"]["error"] and rec["D"]["ranks"] == 2

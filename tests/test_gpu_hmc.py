@@ -82,7 +82,8 @@ def _oracle_update(oracle, om, m, fa, x, v, dt, nt, nb, alpha, rnd, P=None):
                                       P=P, tol=m.solver.tol, maxiter=m.solver.maxiter)
 
 
-@pytest.mark.parametrize("tag,nb,nt", [("b", 1, 5), ("b", 3, 4), ("d", 1, 4), ("t", 1, 3), ("B", 1, 3), ("C", 1, 2), ("g", 1, 2)])
+@pytest.mark.parametrize("tag,nb,nt", [("b", 1, 5), ("b", 3, 4), ("d", 1, 4), ("t", 1, 3), ("B", 1, 3), ("C", 1, 2), ("g", 1, 2),
+                                       ("D", 1, 2)])       # BASELINE config 4: "Holstein HMC honeycomb L=12 Ntau=120"
 def test_hmc_update_vs_oracle(oracle, tag, nb, nt):
     from elphdynamics_amd import hmc
     m, fa, om = _pair(oracle, tag, tol=1e-6, lam2=0.02)

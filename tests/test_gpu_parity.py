@@ -501,6 +501,95 @@ def test_resident_preconditioned_cg_vs_streaming_and_oracle(oracle, monkeypatch,
     m.close()
 
 
+@pytest.mark.parametrize("inactive", [None, 2])
+def test_resident_preconditioned_cg_default_batch_of_chains(monkeypatch, inactive):
+    """What the defaults select for 3-4 HMC chains: 4 chains x 2 = 8 right-hand sides, KPM-preconditioned, ELPH_PCG_WG unset — the
+    resident kernel (k_pcg_wg) when every chain's expansion is active, against the streaming form (ELPH_PCG_WG=0): same iteration
+    counts, solutions to 1e-9 at tol 1e-5 and 1e-11 at 1e-13.  With ONE chain's expansion inactive (its injected bounds fail the test
+    of KPMPreconditioners.jl:280: identity, z = r) the resident kernel — which runs every chain's series without looking at the
+    active flag — must not be taken: both settings then run the streaming form and agree bit for bit, and the inactive chain's
+    right-hand sides need the un-preconditioned iteration count."""
+    import ctypes as C
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    m = configs.make_model("C", tol=1e-5)
+    nch = 4
+    Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=300 + 17 * c) for c in range(nch)])
+    models.update_model_chains_(m, Xc)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    rng = np.random.default_rng(5)
+    act, lo, hi = pc.setup_chains_(P, b_max=rng.standard_normal((nch, m.Nsites)), b_min=rng.standard_normal((nch, m.Nsites)))
+    assert act.all()
+    if inactive is not None:      # the same bounds again, chain `inactive` with e_min > 1: not accepted -> identity expansion for that chain
+        e_min, e_max = lo / 0.9, hi / 1.1
+        e_min[inactive] = 1.5
+        act, _, _ = pc.setup_chains_(P, e_min=e_min, e_max=e_max)
+        assert act.tolist() == [1 if c != inactive else 0 for c in range(nch)]
+    R, B = configs.rhs(m, 2 * nch)
+    out = {}
+    for name, flag in (("default", None), ("stream", "0")):
+        if flag is None:
+            monkeypatch.delenv("ELPH_PCG_WG", raising=False)
+        else:
+            monkeypatch.setenv("ELPH_PCG_WG", flag)
+        m.solver.tol = 1e-5
+        X = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(X, m, B, P=P)
+        assert not fl.any(), (name, fl)
+        m.solver.tol = 1e-13
+        X13 = np.zeros_like(B)
+        it13, _, fl13 = models.ldiv_batched_(X13, m, B, P=P)
+        assert not fl13.any(), name
+        out[name] = (X, it, X13, it13)
+    a, b = out["default"], out["stream"]
+    assert np.array_equal(a[1], b[1]) and np.max(np.abs(a[3] - b[3])) <= 1
+    if inactive is None:
+        assert rel(a[0], b[0]) < 1e-9 and rel(a[2], b[2]) < 1e-11
+        assert not np.array_equal(a[0], b[0])                   # (two different kernels did run: summation orders differ)
+    else:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+        own = [r for r in range(2 * nch) if r % nch == inactive]
+        others = [r for r in range(2 * nch) if r % nch != inactive]
+        assert min(a[1][own]) > 5 * max(a[1][others])           # identity preconditioner: hundreds of iterations against ~25
+    m.close()
+
+
+def test_resident_preconditioned_cg_recovers_after_a_timeout(monkeypatch):
+    """A handle that only runs PRECONDITIONED solves: k_pcg_wg gives up (1 ms bound with eight teams side by side is not reliably
+    enough — so the time-out is forced by ELPH_WG_TIMEOUT_MS=0-like bound of 1 tick through the environment), the solve is redone by
+    the streaming form, elph_wg_status counts the fallback and the cool-down runs DOWN over the following preconditioned solves
+    (round 3: only un-preconditioned solves counted it down) until the resident kernel is taken again."""
+    import ctypes as C
+    from elphdynamics_amd import configs, models, preconditioners as pc
+    m = configs.make_model("C", tol=1e-5)
+    lib = m._lib
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_(P, rng=np.random.default_rng(3))
+    R, B = configs.rhs(m, 8)
+    monkeypatch.setenv("ELPH_PCG_WG", "1")
+    monkeypatch.setenv("ELPH_WG_COOLDOWN", "3")
+    X0 = np.zeros_like(B)
+    it0, _, fl0 = models.ldiv_batched_(X0, m, B, P=P)            # healthy resident solve
+    cool, falls = C.c_int(), C.c_int64()
+    lib.elph_wg_status(m._h, C.byref(cool), C.byref(falls))
+    assert not fl0.any() and cool.value == 0 and falls.value == 0
+    monkeypatch.setenv("ELPH_WG_TIMEOUT_MS", "-1")               # every wait gives up at its first look at the clock
+    X1 = np.zeros_like(B)
+    it1, _, fl1 = models.ldiv_batched_(X1, m, B, P=P)
+    lib.elph_wg_status(m._h, C.byref(cool), C.byref(falls))
+    assert not fl1.any() and np.array_equal(it1, it0) and rel(X1, X0) < 1e-9      # redone by the streaming form
+    assert falls.value == 1 and cool.value == 3
+    monkeypatch.setenv("ELPH_WG_TIMEOUT_MS", "60000")
+    seen = []
+    for k in range(4):
+        X = np.zeros_like(B)
+        it, _, fl = models.ldiv_batched_(X, m, B, P=P)
+        assert not fl.any() and np.array_equal(it, it0)
+        lib.elph_wg_status(m._h, C.byref(cool), C.byref(falls))
+        seen.append(cool.value)
+    assert seen == [2, 1, 0, 0] and falls.value == 1, seen      # two solves on the streaming form, then the resident kernel again
+    m.close()
+
+
 def test_kpm_fallback_to_unpreconditioned(oracle):
     """Models.jl:129-133: a preconditioned solve that fails (maxiter) is redone without P and 10x maxiter."""
     from elphdynamics_amd import configs, models, preconditioners as pc
@@ -731,7 +820,7 @@ def _oracle_force(oracle, om, m, phi_p, phi_m, tol):
     return F, X, Sf
 
 
-@pytest.mark.parametrize("tag", ["b", "B", "d", "g"])
+@pytest.mark.parametrize("tag", ["b", "B", "d", "g", "C", "D"])
 def test_fermion_force_vs_oracle(oracle, tag):
     """update_model! + calc_O⁻¹Λϕ! + calc_dSfdx! on the device vs the oracle's composition."""
     from elphdynamics_amd import configs, hmc, synth

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _run(case, tmp_path, world, tol=1e-9, kpm=False, per_proc=1):
+def _run(case, tmp_path, world, tol=1e-9, kpm=False, per_proc=1, pin_timeout=True):
     """world ranks as world / per_proc processes of per_proc rank threads each (the box admits six processes on its card: eight
     ranks run as four processes of two)."""
     port = _free_port()
@@ -34,8 +34,12 @@ def _run(case, tmp_path, world, tol=1e-9, kpm=False, per_proc=1):
     nproc = world // per_proc
     for r in range(nproc):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ELPH_FORCE_DEVICE="0", ELPH_WG_TIMEOUT_MS="60000", ELPH_TEST_KPM="1" if kpm else "0",
-                   ELPH_RANKS_PER_PROC=str(per_proc))
+                   MASTER_PORT=str(port), ELPH_FORCE_DEVICE="0", ELPH_TEST_KPM="1" if kpm else "0", ELPH_RANKS_PER_PROC=str(per_proc))
+        if pin_timeout:
+            env["ELPH_WG_TIMEOUT_MS"] = "60000"
+        else:          # the library's own wait bound of a sharded solve (ELPH_SHARD_TIMEOUT_MS / 20 s; there is no fallback behind it)
+            env.pop("ELPH_WG_TIMEOUT_MS", None)
+            env.pop("ELPH_SHARD_TIMEOUT_MS", None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), case, out, repr(tol)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     errs = []
@@ -83,13 +87,17 @@ def test_sharded_solve_small_lattices(tmp_path, oracle, case, world, halo):
     assert err < 1e-7 and rres < 1e-8
 
 
-@pytest.mark.parametrize("case,world", [("C", 2), ("D", 2), ("D", 4), ("E", 2), ("E", 4), ("C", 8), ("D", 8), ("E", 8)])
+@pytest.mark.parametrize("case,world", [("C", 2), ("C", 4), ("D", 2), ("D", 4), ("E", 2), ("E", 4), ("C", 8), ("D", 8), ("E", 8)])
 def test_sharded_solve_baseline_configs(tmp_path, oracle, case, world):
     """Configs D and E (and C) at full size, sharded over 2, 4 and 8 ranks (BASELINE.json: "1, 2, 4 and 8 GPUs"), solved to 1e-13 on
     both sides: the sharded solution is within the north_star's 1e-10 of the oracle's un-sharded one.  Eight ranks run as four
     processes of two rank threads (the box admits six processes on its card): 8 x 20 = 160 records per meeting at Ltau = 160,
     config D in slabs of 1,2,1,2,... rows."""
-    res = _run(case, tmp_path, world, tol=1e-13, per_proc=2 if world == 8 else 1)
+    # (config C runs at the library's DEFAULT wait bound — the others pin a long one: a sharded time-out has no fallback)
+    res = _run(case, tmp_path, world, tol=1e-13, per_proc=2 if world == 8 else 1, pin_timeout=(case != "C"))
+    for a in res:      # the preflight (elph_shard_selftest, in the solver's constructor) saw every peer: finite times, own entry included
+        assert a["selftest_us"].shape == (world,) and np.all(np.isfinite(a["selftest_us"])) and np.all(a["selftest_us"] >= 0.0)
+        assert 0.0 < float(a["selftest_slowest_us"]) < 5e6
     if world == 8:
         assert int(res[0]["rows"].sum()) == (12 if case == "D" else 16) and len(res[0]["rows"]) == 8
     err, rres = _check(res, oracle, 1e-13)
@@ -122,7 +130,7 @@ def test_sharded_solve_one_rank_equals_the_unsharded_handle(tmp_path):
         lib.elph_destroy(h)
 
 
-@pytest.mark.parametrize("case,world", [("sq8", 2), ("C", 2), ("D", 2), ("D", 4), ("e8", 2), ("E", 2), ("C", 8)])
+@pytest.mark.parametrize("case,world", [("sq8", 2), ("C", 2), ("D", 2), ("D", 4), ("e8", 2), ("E", 2), ("C", 8), ("E", 8)])
 def test_sharded_kpm_preconditioned_solve(tmp_path, case, world):
     """SURVEY 8e 'KPM under sharding': the preconditioned solve over 2 / 4 ranks against the preconditioned solve of ONE handle on the
     whole lattice with the same Arnoldi start vectors: same expansion (bounds), same iteration count (+-1 at the knife edge), and —
@@ -168,3 +176,35 @@ def test_sharded_kpm_preconditioned_solve(tmp_path, case, world):
         assert np.linalg.norm(a["xk"] - a["x"]) / np.linalg.norm(a["x"]) < 1e-10  # and agrees with the sharded un-preconditioned solve
     finally:
         lib.elph_destroy(h)
+
+
+def test_shard_selftest_names_a_silent_rank(tmp_path):
+    """elph_shard_selftest with a peer that never answers (rank 1 of 2 skips the call): rank 0 gets ELPH_E_HIP naming rank 1 within the
+    bound (ELPH_SHARD_SELFTEST_MS), not a hang and not a time-out inside a solve."""
+    code = (
+        "import os, sys, ctypes as C\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import numpy as np\n"
+        "from elphdynamics_amd import dist, sharded, _lib, lattice as lat\n"
+        "comm = dist.Comm(backend='gloo')\n"
+        "la = lat.Lattice(1, 8, 8, 1)\n"
+        "raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in lat.SQUARE_BONDS], axis=0)\n"
+        "cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), 0.1)\n"
+        "s = sharded.ShardedSolver(comm, 1, 8, 8, 8, cb['table'], kind=0, cosht=cb['cosht'], sinht=cb['sinht'], device=0, selftest=False)\n"
+        "lib = _lib.load()\n"
+        "_lib.check(lib.elph_shard_prepare(s.h)); comm.barrier()\n"
+        "if comm.rank == 0:\n"
+        "    us = np.zeros(2); w = C.c_double()\n"
+        "    rc = lib.elph_shard_selftest(s.h, 8, _lib.dptr(us), C.byref(w))\n"
+        "    print('RC', rc, lib.elph_last_error().decode(), flush=True)\n"
+        "comm.barrier(); s.close(); comm.close()\n")
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ELPH_FORCE_DEVICE="0", ELPH_SHARD_SELFTEST_MS="300")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e[-2000:] for _, e in outs]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RC")][0]
+    assert line.startswith("RC -2") and "rank(s) 1" in line and "300 ms" in line, line
