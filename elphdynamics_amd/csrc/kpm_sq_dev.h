@@ -136,36 +136,15 @@ __device__ __forceinline__ void hc12q_cb_apply(double (&v)[6], const HcLane &T, 
     }
 }
 
-// Coefficients of one series staged in LDS (k_kpm_cheb_sq: once per frequency by the block's threads).  Why: from global memory a
-// coefficient is a scalar load, and scalar loads share the lgkm counter with the step's ds_bpermute but return OUT OF ORDER — every
-// wait for a bpermute result is then a wait for lgkmcnt(0), i.e. for the coefficient load as well, and with one expansion per chain
-// (144 tables in the bench batch) those loads miss the scalar cache every fourth step (a 64-byte line holds four coefficients) and go
-// to L2: several hundred cycles on the dependent chain of the longest recursion, of every right-hand side.  An LDS read of one address
-// by all lanes is a broadcast, returns in order with the bpermutes, and costs a fixed ~100 cycles issued a step ahead.  The value
-// goes back to scalar registers (readfirstlane): the fma takes it as its scalar operand, as before — no vector registers held.
-struct CoefLds {
-    const double2 *lds;       // __shared__
-    __device__ __forceinline__ double2 operator[](int n) const {
-        const double2 v = lds[n];
-        auto rfl = [](double x) {
-            const long long b = __double_as_longlong(x);
-            const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-            return __hiloint2double(hi, lo);
-        };
-        return make_double2(rfl(v.x), rfl(v.y));
-    }
-};
-
 // u_1 = v, u_2 = A'u_1, u_{n+1} = 2 A'u_n - u_{n-1} with A' = a A - b (mulA'!, KPMPreconditioners.jl:685-693; A = CB diag(eb),
 // transposed: diag(eb) CB^T) on NS values per lane; apply(w, mid) is the checkerboard of the lattice's lane layout (in place; it runs
 // mid() where a cross-lane round trip leaves room).  The scale a (and the 2 of the recurrence) ride on the diagonal the step
 // multiplies by anyway: e1 = a eb, e2 = 2 a eb, so a step is the checkerboard apply plus 4 instructions per site (one fewer than
 // scaling, A', 2 A'u - u separately), and the two history vectors swap roles instead of being copied — the recursion is a dependent
 // chain of up to 2 (order - 1) of these steps, and one wave issues one vector instruction every 4-5 cycles.
-// c: the series' coefficients — a pointer (global memory: wave-uniform scalar loads) or any callable n -> double2 (CoefLds below).
-template <int NS, bool TRANSPOSED, class COEF, class APPLY>
+template <int NS, bool TRANSPOSED, class APPLY>
 __device__ __forceinline__ void kpm_series(double (&Pacc)[NS], double (&Qacc)[NS], const double (&vin)[NS], const double (&eb)[NS],
-                                           const COEF &c, int order, double a, double b, APPLY &&apply) {
+                                           const double2 *c, int order, double a, double b, APPLY &&apply) {
     double ua[NS], ub[NS], e1[NS], e2[NS];
     const double b2 = 2.0 * b;
     {
@@ -210,9 +189,9 @@ __device__ __forceinline__ void kpm_series(double (&Pacc)[NS], double (&Qacc)[NS
     else if (order >= 2) flush(ub);
 }
 
-template <int P, bool TRANSPOSED, bool UNI, bool ROWS = false, class COEF = const double2 *>
+template <int P, bool TRANSPOSED, bool UNI, bool ROWS = false>
 __device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qacc)[P * P], const double (&vin)[P * P],
-                                              const double (&eb)[P * P], const COEF &c, int order, double a, double b,
+                                              const double (&eb)[P * P], const double2 *c, int order, double a, double b,
                                               const SqLane<P> &T) {
     kpm_series<P * P, TRANSPOSED>(Pacc, Qacc, vin, eb, c, order, a, b, [&T](double (&w)[P * P], auto &&mid) {
         if constexpr (ROWS) sq16_cb_apply<TRANSPOSED, UNI>(w, T, mid);
@@ -220,9 +199,9 @@ __device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qa
     });
 }
 
-template <bool TRANSPOSED, class COEF = const double2 *>
+template <bool TRANSPOSED>
 __device__ __forceinline__ void kpm_series_hc(double (&Pacc)[6], double (&Qacc)[6], const double (&vin)[6], const double (&eb)[6],
-                                              const COEF &c, int order, double a, double b, const HcLane &T) {
+                                              const double2 *c, int order, double a, double b, const HcLane &T) {
     kpm_series<6, TRANSPOSED>(Pacc, Qacc, vin, eb, c, order, a, b, [&T](double (&w)[6], auto &&mid) { hc12q_cb_apply<TRANSPOSED>(w, T, mid); });
 }
 
