@@ -122,16 +122,33 @@ def build_library(force=False, verbose=False, lds_sync_variant=True):
     jobs, objs, objs_var, compiled = [], [], [], []
     new_man = {}
 
+    root = os.path.realpath(os.path.join(HERE, ".."))
+
+    def deps_of(obj):
+        """Headers of THIS repository the object was compiled from, as the compiler recorded them (obj.d, -MD); None: unknown."""
+        try:
+            toks = open(obj + ".d").read().replace("\\\n", " ").split()
+        except OSError:
+            return None
+        out = sorted({os.path.realpath(t) for t in toks[1:] if os.path.realpath(t).startswith(root) and t.endswith((".h", ".inc"))})
+        return out if all(os.path.exists(d) for d in out) else None
+
+    pending = []
+
     def want(src, obj, extra=()):
-        key = _sha([src] + hdr, extra=" ".join(FLAGS + list(extra)) + cid)
+        # key over the source and the headers it really includes (from the last compile's dependency file; every header when unknown)
         name = os.path.basename(obj)
-        new_man[name] = key
-        if force or not os.path.exists(obj) or man.get(name) != key:
-            cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", src, "-o", obj]
+        d = deps_of(obj)
+        key = _sha([src] + (d if d is not None else hdr), extra=" ".join(FLAGS + list(extra)) + cid + ("" if d is not None else "|all-headers"))
+        if force or not os.path.exists(obj) or d is None or man.get(name) != key:
+            cmd = [hipcc, *FLAGS, *extra, "-MD", "-MF", obj + ".d", "-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd)))
             compiled.append(name)
+            pending.append((name, src, obj, extra))
+        else:
+            new_man[name] = key
 
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s + ".o")
@@ -146,6 +163,9 @@ def build_library(force=False, verbose=False, lds_sync_variant=True):
     for cmd, p in jobs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+    for name, src, obj, extra in pending:          # keys of what was just compiled: over the dependencies the compiler has now recorded
+        d = deps_of(obj)
+        new_man[name] = _sha([src] + (d if d is not None else hdr), extra=" ".join(FLAGS + list(extra)) + cid + ("" if d is not None else "|all-headers"))
     linked = []
     targets = [(LIB, objs, "product")] + ([(LIB_LDSSYNC, objs_var, "lds_sync")] if lds_sync_variant else [])
     for lib, ob, variant in targets:
