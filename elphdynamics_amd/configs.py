@@ -21,6 +21,11 @@ CONFIGS = {
     "t": ("holstein", 1, 3, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # odd L: 9 ragged colours (generic kernels)
     "u": ("holstein", 1, 4, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # even-L triangular: 6 colours (lane program lp6)
     "T": ("holstein", 1, 16, lat.TRIANGULAR_BONDS, 16.0, 0.1),      # holstein_hmc_triangular.toml geometry at config-C size
+    # even-L square lattices other than 8 and 16: the GRID register-exchange forms (2 x 2 patches on an L/2 x L/2 grid of lanes)
+    "s": ("holstein", 1, 6, lat.SQUARE_BONDS, 2.0, 0.1),            # N = 36, Ltau = 20
+    "q": ("holstein", 1, 10, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 100, Ltau = 40
+    "Q": ("holstein", 1, 14, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 196, Ltau = 40
+    "S": ("holstein", 1, 12, lat.SQUARE_BONDS, 16.0, 0.1),          # N = 144, Ltau = 160: config C's time axis on a 12 x 12 lattice
     # lattices beyond 512 sites: multi-wavefront workgroups of the generic kernels
     "g": ("holstein", 1, 24, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 576  (2 wavefronts per slice)
     "G": ("holstein", 1, 32, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 1024

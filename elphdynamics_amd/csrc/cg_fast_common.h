@@ -95,6 +95,74 @@ __device__ __forceinline__ void dpp_pair_odd_up4(double (&t)[4], const double (&
     for (int k = 0; k < 4; ++k) t[k] = __hiloint2double(o[2 * k + 1], o[2 * k]);
 }
 
+// ---- GRID layout: ANY even-L square lattice, 4 <= L <= 16, in the reference's colouring [x-even | x-odd | y-even | y-odd] ----------------
+// (detect_square; cg_wg.hip FORM 5, cg_fast_impl.inc: the Chebyshev recursion).  The 2 x 2 patches of the lattice sit on a G x G grid
+// of lanes, G = L / 2 <= 8: lane l < G*G holds the patch X = l % G, Y = l / G; register q is the site x = 2 X + (q & 1),
+// y = 2 Y + (q >> 1); site = x + L y.  x-even and y-even bonds pair two registers of a lane; x-odd and y-odd bonds cross to the
+// patches X +- 1 / Y +- 1 (cyclically) — by ds_bpermute, whatever G is: the 16 x 16 and 8 x 8 lattices have DPP forms of their own
+// (sq_patch_site, s8_site), this is the form of every OTHER size (L = 4, 6, 10, 12, 14): no LDS slab, no per-colour LDS round trip, 8
+// crossing values per slab and sweep.  Lanes >= G*G idle: their partners are themselves, they never store and never enter a sum.
+// Uniform hopping only: a colour is c (I + th P), the caller applies c^4 (as in the DPP forms).
+struct GridCtx {
+    double th, k4;           // tanh of the bond angle; c^4
+    int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1
+};
+__host__ __device__ __forceinline__ int grid_site(int lane, int q, int G) {
+    const int l = (lane < G * G) ? lane : 0, X = l % G, Y = l / G;
+    return (2 * X + (q & 1)) + 2 * G * (2 * Y + (q >> 1));
+}
+__device__ __forceinline__ GridCtx grid_ctx(int lane, int G, double c, double s) {
+    GridCtx X;
+    X.th = s / c; X.k4 = (c * c) * (c * c);
+    if (lane < G * G) {
+        const int x = lane % G, y = lane / G;
+        X.xu = (x + 1) % G + G * y; X.xd = (x + G - 1) % G + G * y;
+        X.yu = x + G * ((y + 1) % G); X.yd = x + G * ((y + G - 1) % G);
+    } else {
+        X.xu = X.xd = X.yu = X.yd = lane;
+    }
+    return X;
+}
+// one colour on CNT slabs at once: the crossing values of all slabs first (their ds_bpermute round trips overlap), then the arithmetic
+template <int CNT, int COL>
+__device__ __forceinline__ void grid_colour(double (*v)[4], const GridCtx &X) {
+    if constexpr (COL == 0 || COL == 2) {                   // in the lane: x-even (0,1), (2,3); y-even (0,2), (1,3)
+        constexpr int a1 = (COL == 0) ? 1 : 2, b0 = (COL == 0) ? 2 : 1;
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            const double n0 = v[n][0] + X.th * v[n][a1], n1 = v[n][a1] + X.th * v[n][0];
+            const double n2 = v[n][b0] + X.th * v[n][3], n3 = v[n][3] + X.th * v[n][b0];
+            v[n][0] = n0; v[n][a1] = n1; v[n][b0] = n2; v[n][3] = n3;
+        }
+    } else {
+        // x-odd: the sites x = 2 X + 1 (q = 1, 3) pair with x = 2 X + 2 = q - 1 of the patch X + 1; q = 0, 2 with q + 1 of the patch X - 1
+        // y-odd: the sites y = 2 Y + 1 (q = 2, 3) pair with q - 2 of the patch Y + 1; q = 0, 1 with q + 2 of the patch Y - 1
+        constexpr int hi0 = (COL == 1) ? 1 : 2, hi1 = 3, lo0 = 0, lo1 = (COL == 1) ? 2 : 1;
+        const int up = (COL == 1) ? X.xu : X.yu, dn = (COL == 1) ? X.xd : X.yd;
+        double fu0[CNT], fu1[CNT], fd0[CNT], fd1[CNT];
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            fu0[n] = __shfl(v[n][lo0], up, WAVE); fu1[n] = __shfl(v[n][lo1], up, WAVE);      // the upper neighbour's low-side sites
+            fd0[n] = __shfl(v[n][hi0], dn, WAVE); fd1[n] = __shfl(v[n][hi1], dn, WAVE);      // the lower neighbour's high-side sites
+        }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            v[n][hi0] += X.th * fu0[n]; v[n][hi1] += X.th * fu1[n];
+            v[n][lo0] += X.th * fd0[n]; v[n][lo1] += X.th * fd1[n];
+        }
+    }
+}
+template <int NS, int N0, int COL>
+__device__ __forceinline__ void grid_pairs(double (&v)[NS][4], const GridCtx &X) {
+    grid_colour<(N0 + 1 < NS) ? 2 : 1, COL>(&v[N0], X);
+    if constexpr (N0 + 2 < NS) grid_pairs<NS, N0 + 2, COL>(v, X);
+}
+template <int NS, bool REVERSE>
+__device__ __forceinline__ void grid_sweepN(double (&v)[NS][4], const GridCtx &X) {
+    if constexpr (!REVERSE) { grid_pairs<NS, 0, 0>(v, X); grid_pairs<NS, 0, 1>(v, X); grid_pairs<NS, 0, 2>(v, X); grid_pairs<NS, 0, 3>(v, X); }
+    else                    { grid_pairs<NS, 0, 3>(v, X); grid_pairs<NS, 0, 2>(v, X); grid_pairs<NS, 0, 1>(v, X); grid_pairs<NS, 0, 0>(v, X); }
+}
+
 // Honeycomb lattice of 12 x 12 two-site cells, QUAD layout (kpm_sq_dev.h, cg_wg_dev.h): lane 4 y + i (48 of the 64 lanes) holds the
 // cells x = 3 i .. 3 i + 2 of lattice row y, register q = 2 b + orbital the site of cell x = 3 i + b; site = 2 (x + 12 y) + orbital.
 // Lanes 48..63 shadow lanes 0..15 (valid addresses; they never store and never enter a sum).

@@ -41,12 +41,14 @@ __device__ unsigned long long g_wg_arrive[4096 * 4];
 // SQ: the DPP form for the 16 x 16 square lattice in the reference's colouring (NPL = 4, no LDS slabs; Holstein: uniform hopping in
 // two scalars, disordered hopping in per-site registers; SSH: a table set per time slice, SqSsh); otherwise the lane-program form
 //     FORM 0: lane program, 1: the square-lattice DPP form (SQ), 2: the honeycomb DPP form (HC: 12 x 12 cells, six sites per lane of
-//     which a quarter are mirror lanes, uniform hopping; cg_wg_dev.h)
+//     which a quarter are mirror lanes, uniform hopping; cg_wg_dev.h), 4: the 8 x 8 DPP form, 5: the GRID form — any other even-L
+//     square lattice up to 16 x 16 (cg_fast_common.h: 2 x 2 patches on a G x G grid of lanes, crossings by ds_bpermute)
 // SHARD: this launch is one rank's part of a solve over several GPUs (T = 1, lane-program form)
 // X0Z: the initial guess is known to be zero (the library zeroed it for this solve): x0 is not read
 template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
-    constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, GR = FORM == 5, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    static_assert(!GR || (NPL == 4 && UNI && !SSH && !SHARD && T <= 2), "grid form (even-L square lattices, 2 x 2 patches on a G x G lane grid): uniform hopping, at most two slices per wave");
     static_assert(!S8 || (NPL == 1 && UNI && !SSH && !SHARD), "8 x 8 DPP form: one site per lane, uniform hopping");
     static_assert(!SHARD || (T == 1 && !REGX), "sharded solves: one slice per wave, lane-program form");
     static_assert(!HC || (NPL == HC_NPL && UNI && !SSH && T <= 3), "honeycomb DPP form: six sites per lane, uniform hopping");
@@ -127,7 +129,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     const int N = m.N, L = m.L;
     const int t0 = (g * W + wv) * T;
     const int lr = HC ? 12 * (hc_src_lane(lane) >> 4) + (hc_src_lane(lane) & 15) - 2 : lane;      // LDS slot this lane reads (and, if lwok, writes)
-    const bool lwok = !HC || hc_real(lane);
+    const int GG = GR ? m.grid_G : 0;                     // grid form: G x G lanes hold the lattice, the rest idle
+    const bool lwok = HC ? hc_real(lane) : (GR ? lane < GG * GG : true);
     const size_t ndim = (size_t)N * L;
     double *slab = lds + (size_t)wv * NSLAB * SL;
     double *rall = lds + (size_t)W * NSLAB * SL;       // [W][T][HS]: r of every wave's slices — neighbours read their halo slices here
@@ -158,8 +161,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     bool live[NPL], own[NPL];                          // own: the site enters the inner products (a shard counts its own rows only)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : (S8 ? s8_site(lane) : lane + q * WAVE));
-        live[q] = REGX || s < N;                          // (DPP forms: every register of every lane holds a site — no selects in the sums)
+        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : (S8 ? s8_site(lane) : (GR ? grid_site(lane, q, GG) : lane + q * WAVE)));
+        live[q] = GR ? lwok : (REGX || s < N);            // (DPP forms: every register of every lane holds a site — no selects in the sums)
         own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : (HC ? hc_real(lane) : live[q]);     // (honeycomb: mirror lanes carry copies)
         sc[q] = live[q] ? s : N - 1;
     }
@@ -204,7 +207,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     SqSsh<NSREG, S_LDS> XS;
     HcCtx XH;
     S8Ctx X8;
-    if constexpr (S8) {
+    GridCtx XG;
+    if constexpr (GR) {
+        XG = grid_ctx(lane, GG, m.c_uni, m.s_uni);
+    } else if constexpr (S8) {
         X8.th = m.s_uni / m.c_uni; X8.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
         X8.yx = sq_patch_ycross(lane); X8.xodd = (lane >> 1) & 1;
     } else if constexpr (HC) {
@@ -399,6 +405,30 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             using std::integral_constant;
             if constexpr (T == 3) { rev(integral_constant<int, 2>(), integral_constant<int, 0>()); rev(integral_constant<int, 1>(), integral_constant<int, 2>()); }
             else rev(integral_constant<int, T>(), integral_constant<int, 0>());
+        } else if constexpr (GR) {
+#pragma unroll
+            for (int k = 0; k <= T; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[k][q] = EXPV(k, q) * p[k][q];
+            grid_sweepN<T + 1, false>(w, XG);
+#pragma unroll
+            for (int k = 0; k <= T; ++k) {
+                const double sg = sgn(wrap(t0 + k)) * XG.k4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[k][q] = p[k + 1][q] - sg * w[k][q];
+            }
+            double gq[T][4];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gq[i][q] = w[i + 1][q];
+            grid_sweepN<T, true>(gq, XG);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const double sg = sgn(wrap(t0 + i + 1)) * XG.k4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[i][q] = w[i][q] - sg * (EXPV(i + 1, q) * gq[i][q]);      // z(t0+i)
+            }
         } else if constexpr (SQ) {
 #pragma unroll
             for (int k = 0; k <= T; ++k)
@@ -928,8 +958,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int j = 0; j < T; ++j)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
-                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : (S8 ? s8_site(lane2) : lane2 + q * WAVE));
-                    if (HC ? hc_real(lane2) : (SQ || s2 < N)) {
+                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : (S8 ? s8_site(lane2) : (GR ? grid_site(lane2, q, GG) : lane2 + q * WAVE)));
+                    if (HC ? hc_real(lane2) : (GR ? lane2 < GG * GG : (SQ || s2 < N))) {
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
                         if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HSL + lr + q * LSL];
@@ -987,7 +1017,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 // host side
 // ------------------------------------------------------------------------------------------
 
-struct Shape { int T, W, G; size_t shm; bool sq, hc, s8; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6)
+struct Shape { int T, W, G; size_t shm; bool sq, hc, s8, gr; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6; grid form: 4)
 
 // DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square)
 static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
@@ -1012,12 +1042,20 @@ static bool s8_form(const elph_handle_s *h, const ModelDev &m) {
     return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 1 && h->N == 64 && m.uniform && !(e && e[0] == '1');
 }
 
+// grid form: Holstein with uniform hopping on any OTHER even-L square lattice up to 16 x 16 in the reference's colouring (detect_square:
+// sq_L; L = 16 and 8 have DPP forms of their own)
+static bool gr_form(const elph_handle_s *h, const ModelDev &m) {
+    const char *e = getenv("ELPH_WG_NO_DPP");
+    return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_L >= 4 && h->sq_L != 16 && h->sq_L != 8 && m.uniform && m.grid_G > 0 && !(e && e[0] == '1');
+}
+
 static int largest_divisor_le8(int n, int cap = 8) { for (int w = std::min(cap, n); w >= 1; --w) if (n % w == 0) return w; return 1; }
 
 static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, int nrhs, Shape *out) {
     const int L = (int)h->L;
     const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m), s8 = !sq && !hc && s8_form(h, m);
-    const int npl = hc ? HC_NPL : h->npl;
+    const bool gr = !sq && !hc && !s8 && gr_form(h, m);
+    const int npl = hc ? HC_NPL : (gr ? 4 : h->npl);
     // one site per lane (the 8 x 8 lattice: config B): the whole time axis fits ONE workgroup — up to 8 waves of 4, 5 or 8 slices — and
     // a team of one needs no records, no boundary granules, no polls: its meeting is an LDS reduction and a barrier, and a round holds
     // 256 right-hand sides.  Its iteration is longer (config B: 6.3 us at 5 slices per wave against 3.5 at 2 with teams of four), so it
@@ -1029,7 +1067,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     }
     // (the 8 x 8 DPP form: the team of one is the fastest shape at every batch size — 2.04 us per iteration for one right-hand side, 2.3 us
     //  for 256 = 222 M mat-vecs/s — its sweeps are a few dozen register moves)
-    if (!ssh && !sq && !hc && h->npl == 1 && (big_batch || s8)) {
+    if (!ssh && !sq && !hc && !gr && h->npl == 1 && (big_batch || s8)) {
         const int one[3] = {4, 5, 8};
         for (int T : one) {
             if ((forceT && T != forceT) || L % T || L / T > 8 || L / T < 2) continue;
@@ -1037,7 +1075,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
             const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * WAVE;
             const size_t shm = ((size_t)W * (s8 ? 0 : T + 1) * SL + 2 * (size_t)W * T * HS + 48 + 4 * HS) * sizeof(double);
             if (shm > 160 * 1024) continue;
-            out->T = T; out->W = W; out->G = 1; out->shm = shm; out->sq = false; out->hc = false; out->s8 = s8; out->npl = npl;
+            out->T = T; out->W = W; out->G = 1; out->shm = shm; out->sq = false; out->hc = false; out->s8 = s8; out->gr = false; out->npl = npl;
             return true;
         }
     }
@@ -1065,15 +1103,16 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
                 if (G2 > 32 || nrhs <= 8 * (32 / G2)) continue;
             }
         }
-        if (T == 2 && (sq || hc) && forceT != 2) {
+        if (gr && T > 2) continue;
+        if (T == 2 && (sq || hc || gr) && forceT != 2) {
             // DPP form: a batch that one round of 1 slice per wave holds (config C: up to 8 right-hand sides, one team of 20 workgroups per
             // XCD) runs that shape — with ONE meeting per iteration the shorter mat-vec wins over the larger team: 3.47 against 4.00 us
             // per iteration for one right-hand side (round 2, two meetings: the other way round)
             const int G1 = L / largest_divisor_le8(L);
             if (G1 <= 32 && L / G1 >= 2 && nrhs <= 8 * (32 / G1)) continue;
         }
-        if (T == 2 && !sq && !hc && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
-        if (T == 2 && !sq && !hc && (h->npl == 5 || ssh) && forceT != 2) {
+        if (T == 2 && !sq && !hc && !gr && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
+        if (T == 2 && !sq && !hc && !gr && (h->npl == 5 || ssh) && forceT != 2) {
             // 5 sites per lane (honeycomb L = 12) and bond phonons (three table sets per wave: 41 registers spill): 2 slices per wave are
             // slower per iteration (D: 10.0 vs 9.3 us; E: 12.9 vs 9.5 us) but hold more right-hand sides per round (D: 24 instead
             // of 16; E: 24 instead of 8) — taken once a batch exceeds the round of 1 slice per wave
@@ -1092,11 +1131,11 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * (hc ? 48 : WAVE);     // (the kernel's HSL: a slice in LDS)
         const bool s_lds = sq && ssh && T == 2;            // (the kernel's S_LDS: table set of slice t0 in LDS, x in registers)
         const bool e_lds = (sq && T >= 4) || (hc && T >= 2), x_reg = (sq && T >= 4) || s_lds || (hc && T >= 3);
-        const size_t shm = ((size_t)W * ((sq || hc || s8) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
+        const size_t shm = ((size_t)W * ((sq || hc || s8 || gr) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
                             (e_lds ? (hc ? ((size_t)W * T + 1) * HS : (size_t)W * (T + 1) * HS) : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
                             48 + 4 * HS + ((hc && T >= 3) ? (size_t)W * 2 * HS : 0)) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS] (+ the halo slices of p)
         if (shm > 160 * 1024) continue;
-        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->s8 = s8; out->npl = npl;
+        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->s8 = s8; out->gr = gr; out->npl = npl;
         return true;
     }
     return false;
@@ -1215,7 +1254,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
             const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.8 / 5.1 us at 1 / 2 slices per wave)
-            const double t_res = rounds * (sh.s8 ? 2.3 : ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : sh.sq ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
+            const double t_res = rounds * (sh.s8 ? 2.3 : ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : (sh.sq || sh.gr) ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
                                                  : 2.0 + 0.12 * sh.G + (sh.T >= 4 ? 0.85 : 0.5) * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
@@ -1263,7 +1302,9 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
 #endif
     const dim3 grid((unsigned)(8 * R.teams_per_xcd * sh.G));
     hipError_t e = hipSuccess;
-    if (sh.hc) {
+    if (sh.gr) {
+        e = (sh.T == 2) ? wg::launch_k<4, 2, false, true, 5>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 5>(h, sh, grid, B, m, R);
+    } else if (sh.hc) {
         e = (sh.T == 3) ? wg::launch_k<wg::HC_NPL, 3, false, true, 2>(h, sh, grid, B, m, R)
           : (sh.T == 2) ? wg::launch_k<wg::HC_NPL, 2, false, true, 2>(h, sh, grid, B, m, R) : wg::launch_k<wg::HC_NPL, 1, false, true, 2>(h, sh, grid, B, m, R);
     } else switch (h->npl) {

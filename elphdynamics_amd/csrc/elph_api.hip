@@ -128,7 +128,7 @@ static int build_lane_program(elph_handle_s *h) {
     RC(dev_alloc(&h->d_lp_sbar, (size_t)NE * ELPH_WAVE));
     detect_honeycomb12(h);
     detect_square(h);
-    if (h->sq_P > 0) {
+    if (h->sq_L > 0) {
         RC(dev_alloc(&h->d_sq_cbar, (size_t)4 * h->N));
         RC(dev_alloc(&h->d_sq_sbar, (size_t)4 * h->N));
         RC(dev_alloc(&h->d_sq_bond, (size_t)4 * h->N));
@@ -138,12 +138,15 @@ static int build_lane_program(elph_handle_s *h) {
 }
 
 // Recognise the even-L square lattice with the reference's colouring [x-even | x-odd | y-even | y-odd]
-// (L = 8 or 16, site = x + L*y).  Only then may the register-exchange Chebyshev kernel run; any deviation
-// (other lattice, other bond order, disordered table) leaves sq_P = 0 and the LDS kernels are used.
+// (even L from 4 to 16, site = x + L*y).  Only then may the register-exchange forms run (sq_L; sq_P = L / 8 for L = 8, 16, the sizes with
+// DPP layouts of their own; the GRID layout of cg_fast_common.h serves the others); any deviation (other lattice, other bond order,
+// disordered table) leaves sq_L = sq_P = 0 and the LDS kernels are used.
 static void detect_square(elph_handle_s *h) {
     h->sq_P = 0;
+    h->sq_L = 0;
     int L = 0;
-    if (h->N == 64) L = 8; else if (h->N == 256) L = 16; else return;
+    for (int l = 4; l <= 16; l += 2) if ((int64_t)l * l == h->N) L = l;
+    if (L == 0) return;
     if (h->ncol != 4 || h->nb != 2 * h->N) return;
     h->sq_bond.assign((size_t)4 * h->N, -1);
     for (int col = 0; col < 4; ++col) {
@@ -163,7 +166,8 @@ static void detect_square(elph_handle_s *h) {
         }
     }
     for (int v : h->sq_bond) if (v < 0) return;
-    h->sq_P = L / 8;
+    h->sq_L = L;
+    h->sq_P = (L == 8 || L == 16) ? L / 8 : 0;
 }
 
 // Recognise the honeycomb lattice of 12 x 12 two-site cells (site = 2 (x + 12 y) + orbital) with the reference's colouring
@@ -1282,7 +1286,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
                 RC(dev_alloc(&h->d_lp_cbar, (size_t)nch * h->lp_ne * ELPH_WAVE));
                 RC(dev_alloc(&h->d_lp_sbar, (size_t)nch * h->lp_ne * ELPH_WAVE));
             }
-            if (h->sq_P > 0) {
+            if (h->sq_L > 0) {
                 RC(dev_alloc(&h->d_sq_cbar, (size_t)nch * 4 * h->N));
                 RC(dev_alloc(&h->d_sq_sbar, (size_t)nch * 4 * h->N));
             }
@@ -1314,7 +1318,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         HIPCHK(hipMemcpy(h->d_lp_cbar, lc.data(), sizeof(double) * lc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_lp_sbar, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
     }
-    if (hop_fresh && h->sq_P > 0) {
+    if (hop_fresh && h->sq_L > 0) {
         const size_t per = (size_t)4 * h->N;
         std::vector<double> qc((size_t)hch * per), qs((size_t)hch * per);
         bool uni = true;

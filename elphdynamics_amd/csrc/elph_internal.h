@@ -65,6 +65,8 @@ struct ModelDev {
     double c_uni, s_uni;
     // 16 x 16 square lattice in the reference's colouring: the bond that covers site i in colour col ([4][N]; nullptr otherwise)
     const int *sq_bond;
+    // any even-L square lattice (4 <= L <= 16) in that colouring: G = L / 2, the lane grid of the GRID layout (cg_fast_common.h); 0 otherwise
+    int grid_G;
 };
 #ifdef __HIPCC__
 // the hopping tables of the chain right-hand side `rhs` belongs to (SSH chains; no-op otherwise)
@@ -216,6 +218,7 @@ struct elph_handle_s {
     double *d_lp_c = nullptr, *d_lp_s = nullptr, *d_lp_cbar = nullptr, *d_lp_sbar = nullptr;
     // even-L square lattice (L = 8 or 16) recognised in the bond table: P = L/8, per-site per-colour coefficients
     int sq_P = 0;
+    int sq_L = 0;                          // even-L square lattice (4 <= L <= 16) recognised in the bond table: L (sq_P = L / 8 for L = 8, 16, the sizes with DPP forms)
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     bool hc_uniform = false;               // ... and its tau-averaged hopping tables are one (cosh, sinh) for every bond (the register-exchange Chebyshev recursion)

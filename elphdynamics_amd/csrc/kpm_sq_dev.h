@@ -199,6 +199,17 @@ __device__ __forceinline__ void kpm_series_sq(double (&Pacc)[P * P], double (&Qa
     });
 }
 
+// the GRID layout (cg_fast_common.h: any even-L square lattice up to 16 x 16, uniform hopping): the step's independent work (mid) first,
+// then the sweep — four crossing values per crossing colour in one ds_bpermute round trip each
+template <bool TRANSPOSED>
+__device__ __forceinline__ void kpm_series_grid(double (&Pacc)[4], double (&Qacc)[4], const double (&vin)[4], const double (&eb)[4],
+                                                const double2 *c, int order, double a, double b, const GridCtx &T) {
+    kpm_series<4, TRANSPOSED>(Pacc, Qacc, vin, eb, c, order, a, b, [&T](double (&w)[4], auto &&mid) {
+        mid();
+        grid_sweepN<1, TRANSPOSED>(reinterpret_cast<double (&)[1][4]>(w), T);
+    });
+}
+
 template <bool TRANSPOSED>
 __device__ __forceinline__ void kpm_series_hc(double (&Pacc)[6], double (&Qacc)[6], const double (&vin)[6], const double (&eb)[6],
                                               const double2 *c, int order, double a, double b, const HcLane &T) {

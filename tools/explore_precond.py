@@ -22,9 +22,12 @@ def make(nrhs, nch, seed0=100):
     return m, P
 
 
+GRAPH = 1 if os.environ.get("ELPH_USE_GRAPH") == "1" else 0
+
+
 def run(m, what, nrhs, reps):
     ms = C.c_double()
-    check(lib.elph_bench_run(m._h, what, nrhs, reps, 0, C.byref(ms)))
+    check(lib.elph_bench_run(m._h, what, nrhs, reps, GRAPH, C.byref(ms)))
     return 1e3 * ms.value / reps
 
 
