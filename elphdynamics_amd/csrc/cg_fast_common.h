@@ -151,16 +151,18 @@ __device__ __forceinline__ void grid_colour(double (*v)[4], const GridCtx &X) {
             v[n][lo0] += X.th * fd0[n]; v[n][lo1] += X.th * fd1[n];
         }
     }
+    __builtin_amdgcn_sched_barrier(0);          // (a colour of a group of slabs is one scheduling region: hoisted to the front, every slab's crossings spill)
 }
-template <int NS, int N0, int COL>
+// (GRP slabs per scheduling group: 2 — their ds_bpermute round trips overlap; 1 where registers are short: 8 temporaries fewer)
+template <int NS, int N0, int COL, int GRP>
 __device__ __forceinline__ void grid_pairs(double (&v)[NS][4], const GridCtx &X) {
-    grid_colour<(N0 + 1 < NS) ? 2 : 1, COL>(&v[N0], X);
-    if constexpr (N0 + 2 < NS) grid_pairs<NS, N0 + 2, COL>(v, X);
+    grid_colour<(N0 + GRP <= NS) ? GRP : NS - N0, COL>(&v[N0], X);
+    if constexpr (N0 + GRP < NS) grid_pairs<NS, N0 + GRP, COL, GRP>(v, X);
 }
-template <int NS, bool REVERSE>
+template <int NS, bool REVERSE, int GRP = 2>
 __device__ __forceinline__ void grid_sweepN(double (&v)[NS][4], const GridCtx &X) {
-    if constexpr (!REVERSE) { grid_pairs<NS, 0, 0>(v, X); grid_pairs<NS, 0, 1>(v, X); grid_pairs<NS, 0, 2>(v, X); grid_pairs<NS, 0, 3>(v, X); }
-    else                    { grid_pairs<NS, 0, 3>(v, X); grid_pairs<NS, 0, 2>(v, X); grid_pairs<NS, 0, 1>(v, X); grid_pairs<NS, 0, 0>(v, X); }
+    if constexpr (!REVERSE) { grid_pairs<NS, 0, 0, GRP>(v, X); grid_pairs<NS, 0, 1, GRP>(v, X); grid_pairs<NS, 0, 2, GRP>(v, X); grid_pairs<NS, 0, 3, GRP>(v, X); }
+    else                    { grid_pairs<NS, 0, 3, GRP>(v, X); grid_pairs<NS, 0, 2, GRP>(v, X); grid_pairs<NS, 0, 1, GRP>(v, X); grid_pairs<NS, 0, 0, GRP>(v, X); }
 }
 
 // Honeycomb lattice of 12 x 12 two-site cells, QUAD layout (kpm_sq_dev.h, cg_wg_dev.h): lane 4 y + i (48 of the 64 lanes) holds the

@@ -48,7 +48,7 @@ __device__ unsigned long long g_wg_arrive[4096 * 4];
 template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
     constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, GR = FORM == 5, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
-    static_assert(!GR || (NPL == 4 && UNI && !SSH && !SHARD && T <= 2), "grid form (even-L square lattices, 2 x 2 patches on a G x G lane grid): uniform hopping, at most two slices per wave");
+    static_assert(!GR || (NPL == 4 && UNI && !SSH && !SHARD && T <= 4), "grid form (even-L square lattices, 2 x 2 patches on a G x G lane grid): uniform hopping, at most four slices per wave");
     static_assert(!S8 || (NPL == 1 && UNI && !SSH && !SHARD), "8 x 8 DPP form: one site per lane, uniform hopping");
     static_assert(!SHARD || (T == 1 && !REGX), "sharded solves: one slice per wave, lane-program form");
     static_assert(!HC || (NPL == HC_NPL && UNI && !SSH && T <= 3), "honeycomb DPP form: six sites per lane, uniform hopping");
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     // bond phonons, DPP form, 2 slices per wave: the table set of slice t0 in LDS (24 doubles per lane), x in registers
     constexpr bool S_LDS = SQ && SSH && T == 2;
     // honeycomb DPP form, 2 slices per wave: exp(-dtau V) in LDS too (six sites per lane: 36 registers)
-    constexpr bool E_LDS = (SQ && T >= 4) || (HC && T >= 2), X_REG = (SQ && T >= 4) || S_LDS || (HC && T >= 3);
+    constexpr bool E_LDS = ((SQ || GR) && T >= 4) || (HC && T >= 2), X_REG = ((SQ || GR) && T >= 4) || S_LDS || (HC && T >= 3);
     // (honeycomb: neighbouring waves SHARE the slice of exp(-dtau V) between them — [W T + 1] slices per workgroup instead of W (T + 1);
     //  both write the same values to it)
     constexpr bool E_SHARED = HC;
@@ -410,24 +410,28 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int k = 0; k <= T; ++k)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[k][q] = EXPV(k, q) * p[k][q];
-            grid_sweepN<T + 1, false>(w, XG);
+            grid_sweepN<T + 1, false, (T >= 4) ? 1 : 2>(w, XG);
 #pragma unroll
             for (int k = 0; k <= T; ++k) {
                 const double sg = sgn(wrap(t0 + k)) * XG.k4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[k][q] = p[k + 1][q] - sg * w[k][q];
             }
-            double gq[T][4];
+            constexpr int RBG = (T >= 4) ? 2 : T;            // reverse sweeps per batch (4 slices per wave: two batches, as in the DPP form)
 #pragma unroll
-            for (int i = 0; i < T; ++i)
+            for (int j0 = 0; j0 < T; j0 += RBG) {
+                double gq[RBG][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gq[i][q] = w[i + 1][q];
-            grid_sweepN<T, true>(gq, XG);
+                for (int i = 0; i < RBG; ++i)
 #pragma unroll
-            for (int i = 0; i < T; ++i) {
-                const double sg = sgn(wrap(t0 + i + 1)) * XG.k4;
+                    for (int q = 0; q < 4; ++q) gq[i][q] = w[j0 + i + 1][q];
+                grid_sweepN<RBG, true, (T >= 4) ? 1 : 2>(gq, XG);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) w[i][q] = w[i][q] - sg * (EXPV(i + 1, q) * gq[i][q]);      // z(t0+i)
+                for (int i = 0; i < RBG; ++i) {
+                    const double sg = sgn(wrap(t0 + j0 + i + 1)) * XG.k4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[j0 + i][q] = w[j0 + i][q] - sg * (EXPV(j0 + i + 1, q) * gq[i][q]);      // z(t0+j0+i)
+                }
             }
         } else if constexpr (SQ) {
 #pragma unroll
@@ -1096,14 +1100,14 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
             }
         }
         if (T == 4) {
-            if (!sq || !m.uniform || ssh) continue;
+            if (!(sq || gr) || !m.uniform || ssh) continue;
             if (forceT != 4) {                           // only when 2 slices per wave would need a second round: 8 XCDs x (32 CUs / G2) teams
                 if (L % 2) continue;
                 const int G2 = (L / 2) / largest_divisor_le8(L / 2);
                 if (G2 > 32 || nrhs <= 8 * (32 / G2)) continue;
             }
         }
-        if (gr && T > 2) continue;
+        if (gr && T == 3) continue;
         if (T == 2 && (sq || hc || gr) && forceT != 2) {
             // DPP form: a batch that one round of 1 slice per wave holds (config C: up to 8 right-hand sides, one team of 20 workgroups per
             // XCD) runs that shape — with ONE meeting per iteration the shorter mat-vec wins over the larger team: 3.47 against 4.00 us
@@ -1130,7 +1134,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         if (G > 1 && W < 2) continue;                    // (a wave polls at most ONE neighbouring workgroup's boundary slice)
         const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * (hc ? 48 : WAVE);     // (the kernel's HSL: a slice in LDS)
         const bool s_lds = sq && ssh && T == 2;            // (the kernel's S_LDS: table set of slice t0 in LDS, x in registers)
-        const bool e_lds = (sq && T >= 4) || (hc && T >= 2), x_reg = (sq && T >= 4) || s_lds || (hc && T >= 3);
+        const bool e_lds = ((sq || gr) && T >= 4) || (hc && T >= 2), x_reg = ((sq || gr) && T >= 4) || s_lds || (hc && T >= 3);
         const size_t shm = ((size_t)W * ((sq || hc || s8 || gr) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
                             (e_lds ? (hc ? ((size_t)W * T + 1) * HS : (size_t)W * (T + 1) * HS) : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
                             48 + 4 * HS + ((hc && T >= 3) ? (size_t)W * 2 * HS : 0)) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS] (+ the halo slices of p)
@@ -1303,7 +1307,8 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     const dim3 grid((unsigned)(8 * R.teams_per_xcd * sh.G));
     hipError_t e = hipSuccess;
     if (sh.gr) {
-        e = (sh.T == 2) ? wg::launch_k<4, 2, false, true, 5>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 5>(h, sh, grid, B, m, R);
+        e = (sh.T == 4) ? wg::launch_k<4, 4, false, true, 5>(h, sh, grid, B, m, R)
+          : (sh.T == 2) ? wg::launch_k<4, 2, false, true, 5>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 5>(h, sh, grid, B, m, R);
     } else if (sh.hc) {
         e = (sh.T == 3) ? wg::launch_k<wg::HC_NPL, 3, false, true, 2>(h, sh, grid, B, m, R)
           : (sh.T == 2) ? wg::launch_k<wg::HC_NPL, 2, false, true, 2>(h, sh, grid, B, m, R) : wg::launch_k<wg::HC_NPL, 1, false, true, 2>(h, sh, grid, B, m, R);

@@ -1429,6 +1429,8 @@ def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
         variants += [{"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "2"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
     if tag in ("b", "s", "q", "Q", "S"):   # the GRID form (any other even-L square lattice: 2 x 2 patches on an L/2 x L/2 lane grid) and its lane-program A/B
         variants += [{"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
+        if tag in ("S", "Q"):          # 4 slices per wave: the shape of batches beyond one round of 2 (time axes that are multiples of 4)
+            variants += [{"ELPH_WG_T": "4"}]
     if tag == "B":          # the 8 x 8 DPP form (one site per lane; default: one workgroup per right-hand side, 5 slices per wave) and its lane-program A/B
         variants += [{"ELPH_WG_T": "5"}, {"ELPH_WG_T": "8"}, {"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "5"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "8"}]
     for env in variants:
