@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary nrhs sweep")
     ap.add_argument("--no-spatial", action="store_true", help="skip the `spatial` sub-record (sharded solves of C, D, E over the ranks)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--hmc-seconds", type=float, default=6.0, help="wall time of the back-to-back HMC updates of the 64-chain leg")
     return ap.parse_args()
 
 
@@ -464,12 +465,20 @@ def main():
                     Hh.device_rng_(3)      # random inputs drawn inside the library (on the GPU), as a production run would
                     upd = (lambda: ehmc.update_chains_(mh, Hh, fah, Ph)) if nch_h > 1 else (lambda: ehmc.update_(mh, Hh, fah, Ph, pull=False))
                     upd()
+                    # steady state of the production caller: updates back to back for ~hmc_seconds (the chains of a production run do
+                    # nothing else; also the one stretch of this run long enough for a 5 s GPU-activity sampler to see)
+                    n_upd, dth, acc_all, its_all = 0, 0.0, [], []
+                    budget = args.hmc_seconds if nch_h > 1 else min(1.0, args.hmc_seconds)
                     tq = time.perf_counter()
-                    acc_h, its_h = upd()
-                    dth = time.perf_counter() - tq
+                    while n_upd < 1 or dth < budget:
+                        acc_h, its_h = upd()
+                        n_upd += 1
+                        acc_all.append(np.mean(acc_h)); its_all.append(np.mean(its_h))
+                        dth = time.perf_counter() - tq
+                    dth /= n_upd
                     hm[f"gpu_chains{nch_h}"] = {"nt": nt_g, "ms_per_update": 1e3 * dth, "ms_per_chain_update": 1e3 * dth / nch_h,
-                                               "chain_evaluations_per_sec": nch_h * (nt_g + 2) / dth,
-                                               "iters_per_solve": float(np.mean(its_h)), "accepted": float(np.mean(acc_h)),
+                                               "chain_evaluations_per_sec": nch_h * (nt_g + 2) / dth, "updates_timed": n_upd,
+                                               "iters_per_solve": float(np.mean(its_all)), "accepted": float(np.mean(acc_all)),
                                                "random_numbers": "library generator (elph_hmc_set_rng)"}
                     mh.close()
                 if not args.no_cpu:
