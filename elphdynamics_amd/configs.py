@@ -26,6 +26,10 @@ CONFIGS = {
     "q": ("holstein", 1, 10, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 100, Ltau = 40
     "Q": ("holstein", 1, 14, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 196, Ltau = 40
     "S": ("holstein", 1, 12, lat.SQUARE_BONDS, 16.0, 0.1),          # N = 144, Ltau = 160: config C's time axis on a 12 x 12 lattice
+    # honeycomb lattices other than 12 x 12 cells: the HGRID register-exchange forms (1, 2 or 4 cells per lane on a grid of lanes)
+    "y": ("holstein", 2, 6, lat.HONEYCOMB_BONDS, 2.0, 0.1),         # N = 72,  Ltau = 20   (one cell per lane)
+    "z": ("holstein", 2, 10, lat.HONEYCOMB_BONDS, 4.0, 0.1),        # N = 200, Ltau = 40   (two cells per lane)
+    "Y": ("holstein", 2, 16, lat.HONEYCOMB_BONDS, 4.0, 0.1),        # N = 512, Ltau = 40   (four cells per lane: 512 sites in one wave)
     # lattices beyond 512 sites: multi-wavefront workgroups of the generic kernels
     "g": ("holstein", 1, 24, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 576  (2 wavefronts per slice)
     "G": ("holstein", 1, 32, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 1024

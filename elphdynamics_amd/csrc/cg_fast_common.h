@@ -165,6 +165,113 @@ __device__ __forceinline__ void grid_sweepN(double (&v)[NS][4], const GridCtx &X
     else                    { grid_pairs<NS, 0, 3, GRP>(v, X); grid_pairs<NS, 0, 2, GRP>(v, X); grid_pairs<NS, 0, 1, GRP>(v, X); grid_pairs<NS, 0, 0, GRP>(v, X); }
 }
 
+// ---- HGRID layout: ANY honeycomb lattice of L x L two-site cells (site = 2 (x + L y) + orbital) in the reference's colouring
+// [A-B of a cell | B(x,y)-A(x+1,y) | B(x,y)-A(x,y+1)] (detect_honeycomb) whose cells fit a grid of lanes: PX x PY cells per lane
+// (NPL = 2 PX PY registers: 1 x 1 -> 2, 2 x 1 -> 4, 2 x 2 -> 8), lanes on a GX x GY grid, GX = L / PX, GY = L / PY, GX GY <= 64 —
+// L <= 8 with one cell per lane, L = 10 with two, L = 14 and 16 with four (512 sites in ONE wave).  Register 2 (cx + PX cy) + orbital
+// is the site of cell (PX X + cx, PY Y + cy) of lane (X, Y) = (l % GX, l / GX).  A-B pairs registers of the lane; the other two colours
+// pair registers of the lane inside the patch and cross to the lane X + 1 / Y + 1 at its edge — by ds_bpermute (the 12 x 12 lattice has a
+// DPP form of its own, hc_site).  Uniform hopping: a colour is c (I + th P), the caller applies c^3.
+template <int NPL> struct HgDim { static constexpr int PX = (NPL >= 4) ? 2 : 1, PY = (NPL >= 8) ? 2 : 1; };
+struct HgCtx {
+    double th, k3;
+    int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1 (cyclic); idle lanes: themselves
+};
+template <int NPL>
+__host__ __device__ __forceinline__ int hgrid_site(int lane, int q, int L) {
+    constexpr int PX = HgDim<NPL>::PX, PY = HgDim<NPL>::PY;
+    const int GX = L / PX, GY = L / PY;
+    const int l = (lane < GX * GY) ? lane : 0, X = l % GX, Y = l / GX;
+    const int c = q >> 1, cx = c % PX, cy = c / PX;
+    return 2 * ((PX * X + cx) + L * (PY * Y + cy)) + (q & 1);
+}
+template <int NPL>
+__device__ __forceinline__ HgCtx hgrid_ctx(int lane, int L, double c, double s) {
+    constexpr int PX = HgDim<NPL>::PX, PY = HgDim<NPL>::PY;
+    const int GX = L / PX, GY = L / PY;
+    HgCtx X;
+    X.th = s / c; X.k3 = c * c * c;
+    if (lane < GX * GY) {
+        const int x = lane % GX, y = lane / GX;
+        X.xu = (x + 1) % GX + GX * y; X.xd = (x + GX - 1) % GX + GX * y;
+        X.yu = x + GX * ((y + 1) % GY); X.yd = x + GX * ((y + GY - 1) % GY);
+    } else {
+        X.xu = X.xd = X.yu = X.yd = lane;
+    }
+    return X;
+}
+template <int NPL, int CNT, int COL>
+__device__ __forceinline__ void hgrid_colour(double (*v)[NPL], const HgCtx &X) {
+    constexpr int PX = HgDim<NPL>::PX, PY = HgDim<NPL>::PY;
+    auto A = [](int cx, int cy) { return 2 * (cx + PX * cy); };
+    auto B = [](int cx, int cy) { return 2 * (cx + PX * cy) + 1; };
+    if constexpr (COL == 0) {                              // A-B of a cell
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int c = 0; c < PX * PY; ++c) {
+                const double a = v[n][2 * c] + X.th * v[n][2 * c + 1], b = v[n][2 * c + 1] + X.th * v[n][2 * c];
+                v[n][2 * c] = a; v[n][2 * c + 1] = b;
+            }
+    } else if constexpr (COL == 1) {                       // B(x,y) - A(x+1,y)
+        double fu[CNT][PY], fd[CNT][PY];
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int cy = 0; cy < PY; ++cy) {
+                fu[n][cy] = __shfl(v[n][A(0, cy)], X.xu, WAVE);             // A(x+1) of my edge B: the next lane's first column
+                fd[n][cy] = __shfl(v[n][B(PX - 1, cy)], X.xd, WAVE);        // B(x-1) of my first A: the previous lane's last column
+            }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int cy = 0; cy < PY; ++cy) {
+                double olda[PX], oldb[PX];
+#pragma unroll
+                for (int cx = 0; cx < PX; ++cx) { olda[cx] = v[n][A(cx, cy)]; oldb[cx] = v[n][B(cx, cy)]; }
+#pragma unroll
+                for (int cx = 0; cx < PX; ++cx) {
+                    v[n][B(cx, cy)] = oldb[cx] + X.th * ((cx < PX - 1) ? olda[(cx + 1 < PX) ? cx + 1 : 0] : fu[n][cy]);
+                    v[n][A(cx, cy)] = olda[cx] + X.th * ((cx > 0) ? oldb[(cx > 0) ? cx - 1 : 0] : fd[n][cy]);
+                }
+            }
+    } else {                                               // B(x,y) - A(x,y+1)
+        double fu[CNT][PX], fd[CNT][PX];
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int cx = 0; cx < PX; ++cx) {
+                fu[n][cx] = __shfl(v[n][A(cx, 0)], X.yu, WAVE);
+                fd[n][cx] = __shfl(v[n][B(cx, PY - 1)], X.yd, WAVE);
+            }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n)
+#pragma unroll
+            for (int cx = 0; cx < PX; ++cx) {
+                double olda[PY], oldb[PY];
+#pragma unroll
+                for (int cy = 0; cy < PY; ++cy) { olda[cy] = v[n][A(cx, cy)]; oldb[cy] = v[n][B(cx, cy)]; }
+#pragma unroll
+                for (int cy = 0; cy < PY; ++cy) {
+                    v[n][B(cx, cy)] = oldb[cy] + X.th * ((cy < PY - 1) ? olda[(cy + 1 < PY) ? cy + 1 : 0] : fu[n][cx]);
+                    v[n][A(cx, cy)] = olda[cy] + X.th * ((cy > 0) ? oldb[(cy > 0) ? cy - 1 : 0] : fd[n][cx]);
+                }
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int NPL, int NS, int N0, int COL>
+__device__ __forceinline__ void hgrid_pairs(double (&v)[NS][NPL], const HgCtx &X) {
+    constexpr int GRP = (NPL >= 8) ? 1 : 2;
+    hgrid_colour<NPL, (N0 + GRP <= NS) ? GRP : NS - N0, COL>(&v[N0], X);
+    if constexpr (N0 + GRP < NS) hgrid_pairs<NPL, NS, N0 + GRP, COL>(v, X);
+}
+template <int NPL, int NS, bool REVERSE>
+__device__ __forceinline__ void hgrid_sweepN(double (&v)[NS][NPL], const HgCtx &X) {
+    if constexpr (!REVERSE) { hgrid_pairs<NPL, NS, 0, 0>(v, X); hgrid_pairs<NPL, NS, 0, 1>(v, X); hgrid_pairs<NPL, NS, 0, 2>(v, X); }
+    else                    { hgrid_pairs<NPL, NS, 0, 2>(v, X); hgrid_pairs<NPL, NS, 0, 1>(v, X); hgrid_pairs<NPL, NS, 0, 0>(v, X); }
+}
+
 // Honeycomb lattice of 12 x 12 two-site cells, QUAD layout (kpm_sq_dev.h, cg_wg_dev.h): lane 4 y + i (48 of the 64 lanes) holds the
 // cells x = 3 i .. 3 i + 2 of lattice row y, register q = 2 b + orbital the site of cell x = 3 i + b; site = 2 (x + 12 y) + orbital.
 // Lanes 48..63 shadow lanes 0..15 (valid addresses; they never store and never enter a sum).

@@ -42,12 +42,14 @@ __device__ unsigned long long g_wg_arrive[4096 * 4];
 // two scalars, disordered hopping in per-site registers; SSH: a table set per time slice, SqSsh); otherwise the lane-program form
 //     FORM 0: lane program, 1: the square-lattice DPP form (SQ), 2: the honeycomb DPP form (HC: 12 x 12 cells, six sites per lane of
 //     which a quarter are mirror lanes, uniform hopping; cg_wg_dev.h), 4: the 8 x 8 DPP form, 5: the GRID form — any other even-L
-//     square lattice up to 16 x 16 (cg_fast_common.h: 2 x 2 patches on a G x G grid of lanes, crossings by ds_bpermute)
+//     square lattice up to 16 x 16 (cg_fast_common.h: 2 x 2 patches on a G x G grid of lanes, crossings by ds_bpermute), 6: the HGRID
+//     form — any other honeycomb lattice up to 16 x 16 cells (1, 2 or 4 cells per lane on a grid of lanes; m.hc_L cells per side)
 // SHARD: this launch is one rank's part of a solve over several GPUs (T = 1, lane-program form)
 // X0Z: the initial guess is known to be zero (the library zeroed it for this solve): x0 is not read
 template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
-    constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, GR = FORM == 5, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, GR = FORM == 5, HG = FORM == 6, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    static_assert(!HG || ((NPL == 2 || NPL == 4 || NPL == 8) && UNI && !SSH && !SHARD && T <= 2), "honeycomb grid form: 1, 2 or 4 cells per lane, uniform hopping, at most two slices per wave");
     static_assert(!GR || (NPL == 4 && UNI && !SSH && !SHARD && T <= 4), "grid form (even-L square lattices, 2 x 2 patches on a G x G lane grid): uniform hopping, at most four slices per wave");
     static_assert(!S8 || (NPL == 1 && UNI && !SSH && !SHARD), "8 x 8 DPP form: one site per lane, uniform hopping");
     static_assert(!SHARD || (T == 1 && !REGX), "sharded solves: one slice per wave, lane-program form");
@@ -130,7 +132,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     const int t0 = (g * W + wv) * T;
     const int lr = HC ? 12 * (hc_src_lane(lane) >> 4) + (hc_src_lane(lane) & 15) - 2 : lane;      // LDS slot this lane reads (and, if lwok, writes)
     const int GG = GR ? m.grid_G : 0;                     // grid form: G x G lanes hold the lattice, the rest idle
-    const bool lwok = HC ? hc_real(lane) : (GR ? lane < GG * GG : true);
+    const int HL = HG ? m.hc_L : 0;                       // honeycomb grid form: (HL / PX) x (HL / PY) lanes
+    const bool lwok = HC ? hc_real(lane) : (GR ? lane < GG * GG : (HG ? lane < (HL / HgDim<NPL>::PX) * (HL / HgDim<NPL>::PY) : true));
     const size_t ndim = (size_t)N * L;
     double *slab = lds + (size_t)wv * NSLAB * SL;
     double *rall = lds + (size_t)W * NSLAB * SL;       // [W][T][HS]: r of every wave's slices — neighbours read their halo slices here
@@ -161,8 +164,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     bool live[NPL], own[NPL];                          // own: the site enters the inner products (a shard counts its own rows only)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : (S8 ? s8_site(lane) : (GR ? grid_site(lane, q, GG) : lane + q * WAVE)));
-        live[q] = GR ? lwok : (REGX || s < N);            // (DPP forms: every register of every lane holds a site — no selects in the sums)
+        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : (S8 ? s8_site(lane) : (GR ? grid_site(lane, q, GG) : (HG ? hgrid_site<NPL>(lane, q, HL) : lane + q * WAVE))));
+        live[q] = (GR || HG) ? lwok : (REGX || s < N);            // (DPP forms: every register of every lane holds a site — no selects in the sums)
         own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : (HC ? hc_real(lane) : live[q]);     // (honeycomb: mirror lanes carry copies)
         sc[q] = live[q] ? s : N - 1;
     }
@@ -208,8 +211,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     HcCtx XH;
     S8Ctx X8;
     GridCtx XG;
+    HgCtx XHG;
     if constexpr (GR) {
         XG = grid_ctx(lane, GG, m.c_uni, m.s_uni);
+    } else if constexpr (HG) {
+        XHG = hgrid_ctx<NPL>(lane, HL, m.c_uni, m.s_uni);
     } else if constexpr (S8) {
         X8.th = m.s_uni / m.c_uni; X8.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
         X8.yx = sq_patch_ycross(lane); X8.xodd = (lane >> 1) & 1;
@@ -405,6 +411,30 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             using std::integral_constant;
             if constexpr (T == 3) { rev(integral_constant<int, 2>(), integral_constant<int, 0>()); rev(integral_constant<int, 1>(), integral_constant<int, 2>()); }
             else rev(integral_constant<int, T>(), integral_constant<int, 0>());
+        } else if constexpr (HG) {
+#pragma unroll
+            for (int k = 0; k <= T; ++k)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) w[k][q] = EXPV(k, q) * p[k][q];
+            hgrid_sweepN<NPL, T + 1, false>(w, XHG);
+#pragma unroll
+            for (int k = 0; k <= T; ++k) {
+                const double sg = sgn(wrap(t0 + k)) * XHG.k3;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) w[k][q] = p[k + 1][q] - sg * w[k][q];
+            }
+            double gq[T][NPL];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) gq[i][q] = w[i + 1][q];
+            hgrid_sweepN<NPL, T, true>(gq, XHG);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const double sg = sgn(wrap(t0 + i + 1)) * XHG.k3;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) w[i][q] = w[i][q] - sg * (EXPV(i + 1, q) * gq[i][q]);      // z(t0+i)
+            }
         } else if constexpr (GR) {
 #pragma unroll
             for (int k = 0; k <= T; ++k)
@@ -962,8 +992,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int j = 0; j < T; ++j)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
-                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : (S8 ? s8_site(lane2) : (GR ? grid_site(lane2, q, GG) : lane2 + q * WAVE)));
-                    if (HC ? hc_real(lane2) : (GR ? lane2 < GG * GG : (SQ || s2 < N))) {
+                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : (S8 ? s8_site(lane2) : (GR ? grid_site(lane2, q, GG) : (HG ? hgrid_site<NPL>(lane2, q, HL) : lane2 + q * WAVE))));
+                    if (HC ? hc_real(lane2) : (GR ? lane2 < GG * GG : (HG ? lane2 < (HL / HgDim<NPL>::PX) * (HL / HgDim<NPL>::PY) : (SQ || s2 < N)))) {
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
                         if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HSL + lr + q * LSL];
@@ -1021,7 +1051,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 // host side
 // ------------------------------------------------------------------------------------------
 
-struct Shape { int T, W, G; size_t shm; bool sq, hc, s8, gr; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6; grid form: 4)
+struct Shape { int T, W, G; size_t shm; bool sq, hc, s8, gr, hg; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6; grid form: 4)
 
 // DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square)
 static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
@@ -1053,13 +1083,28 @@ static bool gr_form(const elph_handle_s *h, const ModelDev &m) {
     return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_L >= 4 && h->sq_L != 16 && h->sq_L != 8 && m.uniform && m.grid_G > 0 && !(e && e[0] == '1');
 }
 
+// honeycomb grid form: Holstein with uniform hopping on any OTHER honeycomb lattice of L x L cells in the reference's colouring whose cells
+// fit a grid of lanes (detect_honeycomb: hc_L; L = 12 has a DPP form of its own).  Returns the registers per lane (2, 4 or 8), 0: no.
+static int hg_form(const elph_handle_s *h, const ModelDev &m) {
+    const char *e = getenv("ELPH_WG_NO_DPP");
+    if (h->kind != ELPH_MODEL_HOLSTEIN || h->hc_L < 2 || h->hc12 || !m.uniform || m.hc_L != h->hc_L || (e && e[0] == '1')) return 0;
+    const int L = h->hc_L;
+    if (L * L <= 64) return 2;
+    if (L % 2 == 0 && (L / 2) * L <= 64) return 4;
+    if (L % 2 == 0 && (L / 2) * (L / 2) <= 64) return 8;
+    return 0;
+}
+
 static int largest_divisor_le8(int n, int cap = 8) { for (int w = std::min(cap, n); w >= 1; --w) if (n % w == 0) return w; return 1; }
 
 static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, int nrhs, Shape *out) {
     const int L = (int)h->L;
     const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m), s8 = !sq && !hc && s8_form(h, m);
     const bool gr = !sq && !hc && !s8 && gr_form(h, m);
-    const int npl = hc ? HC_NPL : (gr ? 4 : h->npl);
+    const int hgn = (!sq && !hc && !s8 && !gr) ? hg_form(h, m) : 0;
+    const bool hg = hgn > 0;
+    const int npl = hc ? HC_NPL : (gr ? 4 : (hg ? hgn : h->npl));
+    if (!hc && !gr && !hg && h->npl > 5) return false;     // (the lane-program form carries at most 320 sites; elph_wg_usable lets larger honeycomb lattices through for the grid form only)
     // one site per lane (the 8 x 8 lattice: config B): the whole time axis fits ONE workgroup — up to 8 waves of 4, 5 or 8 slices — and
     // a team of one needs no records, no boundary granules, no polls: its meeting is an LDS reduction and a barrier, and a round holds
     // 256 right-hand sides.  Its iteration is longer (config B: 6.3 us at 5 slices per wave against 3.5 at 2 with teams of four), so it
@@ -1071,7 +1116,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     }
     // (the 8 x 8 DPP form: the team of one is the fastest shape at every batch size — 2.04 us per iteration for one right-hand side, 2.3 us
     //  for 256 = 222 M mat-vecs/s — its sweeps are a few dozen register moves)
-    if (!ssh && !sq && !hc && !gr && h->npl == 1 && (big_batch || s8)) {
+    if (!ssh && !sq && !hc && !gr && !hg && h->npl == 1 && (big_batch || s8)) {
         const int one[3] = {4, 5, 8};
         for (int T : one) {
             if ((forceT && T != forceT) || L % T || L / T > 8 || L / T < 2) continue;
@@ -1079,7 +1124,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
             const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * WAVE;
             const size_t shm = ((size_t)W * (s8 ? 0 : T + 1) * SL + 2 * (size_t)W * T * HS + 48 + 4 * HS) * sizeof(double);
             if (shm > 160 * 1024) continue;
-            out->T = T; out->W = W; out->G = 1; out->shm = shm; out->sq = false; out->hc = false; out->s8 = s8; out->gr = false; out->npl = npl;
+            out->T = T; out->W = W; out->G = 1; out->shm = shm; out->sq = false; out->hc = false; out->s8 = s8; out->gr = false; out->hg = false; out->npl = npl;
             return true;
         }
     }
@@ -1108,15 +1153,16 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
             }
         }
         if (gr && T == 3) continue;
-        if (T == 2 && (sq || hc || gr) && forceT != 2) {
+        if (hg && T > 2) continue;
+        if (T == 2 && (sq || hc || gr || hg) && forceT != 2) {
             // DPP form: a batch that one round of 1 slice per wave holds (config C: up to 8 right-hand sides, one team of 20 workgroups per
             // XCD) runs that shape — with ONE meeting per iteration the shorter mat-vec wins over the larger team: 3.47 against 4.00 us
             // per iteration for one right-hand side (round 2, two meetings: the other way round)
             const int G1 = L / largest_divisor_le8(L);
             if (G1 <= 32 && L / G1 >= 2 && nrhs <= 8 * (32 / G1)) continue;
         }
-        if (T == 2 && !sq && !hc && !gr && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
-        if (T == 2 && !sq && !hc && !gr && (h->npl == 5 || ssh) && forceT != 2) {
+        if (T == 2 && !sq && !hc && !gr && !hg && ((ssh && h->npl > 4) || h->npl > 5 || (!ssh && h->npl >= 4 && !m.uniform))) continue;
+        if (T == 2 && !sq && !hc && !gr && !hg && (h->npl == 5 || ssh) && forceT != 2) {
             // 5 sites per lane (honeycomb L = 12) and bond phonons (three table sets per wave: 41 registers spill): 2 slices per wave are
             // slower per iteration (D: 10.0 vs 9.3 us; E: 12.9 vs 9.5 us) but hold more right-hand sides per round (D: 24 instead
             // of 16; E: 24 instead of 8) — taken once a batch exceeds the round of 1 slice per wave
@@ -1135,11 +1181,11 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
         const size_t SL = (size_t)npl * WAVE + 2 * WAVE, HS = (size_t)npl * (hc ? 48 : WAVE);     // (the kernel's HSL: a slice in LDS)
         const bool s_lds = sq && ssh && T == 2;            // (the kernel's S_LDS: table set of slice t0 in LDS, x in registers)
         const bool e_lds = ((sq || gr) && T >= 4) || (hc && T >= 2), x_reg = ((sq || gr) && T >= 4) || s_lds || (hc && T >= 3);
-        const size_t shm = ((size_t)W * ((sq || hc || s8 || gr) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
+        const size_t shm = ((size_t)W * ((sq || hc || s8 || gr || hg) ? 0 : T + 1) * SL + (size_t)(x_reg ? 1 : 2) * W * T * HS +
                             (e_lds ? (hc ? ((size_t)W * T + 1) * HS : (size_t)W * (T + 1) * HS) : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
                             48 + 4 * HS + ((hc && T >= 3) ? (size_t)W * 2 * HS : 0)) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS] (+ the halo slices of p)
         if (shm > 160 * 1024) continue;
-        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->s8 = s8; out->gr = gr; out->npl = npl;
+        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->s8 = s8; out->gr = gr; out->hg = hg; out->npl = npl;
         return true;
     }
     return false;
@@ -1205,7 +1251,8 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs) {
     const char *eo = getenv("ELPH_NO_WG");                 // read per call: the tests switch between the two forms
     const bool off = eo && eo[0] == '1';
-    if (off || !h->fast || h->lp_mc != 4 || h->npl > 5 || h->dot_hi != 0 || h->solo_chain >= 0) return false;
+    // (h->npl > 5: the lane-program form's limit — 320 sites; the honeycomb grid form carries up to 512 in one wave)
+    if (off || !h->fast || h->lp_mc != 4 || (h->npl > 5 && !(h->hc_L > 0 && !h->hc12 && h->kind == ELPH_MODEL_HOLSTEIN)) || h->dot_hi != 0 || h->solo_chain >= 0) return false;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
     if (!wg::pick_shape(h, elph_model_dev(h), et ? atoi(et) : 0, nrhs, &sh)) return false;
@@ -1258,7 +1305,7 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
             const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.8 / 5.1 us at 1 / 2 slices per wave)
-            const double t_res = rounds * (sh.s8 ? 2.3 : ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : (sh.sq || sh.gr) ? 2.66 + 0.01 * sh.G + 0.62 * sh.T
+            const double t_res = rounds * (sh.s8 ? 2.3 : ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : (sh.sq || sh.gr || sh.hg) ? 2.66 + 0.01 * sh.G + 0.62 * sh.T * (sh.hg ? sh.npl / 4.0 : 1.0)
                                                  : 2.0 + 0.12 * sh.G + (sh.T >= 4 ? 0.85 : 0.5) * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
             const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
             if (t_res > t_str) return ELPH_OK;
@@ -1306,7 +1353,13 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
 #endif
     const dim3 grid((unsigned)(8 * R.teams_per_xcd * sh.G));
     hipError_t e = hipSuccess;
-    if (sh.gr) {
+    if (sh.hg) {
+        switch (sh.npl) {
+            case 2: e = (sh.T == 2) ? wg::launch_k<2, 2, false, true, 6>(h, sh, grid, B, m, R) : wg::launch_k<2, 1, false, true, 6>(h, sh, grid, B, m, R); break;
+            case 4: e = (sh.T == 2) ? wg::launch_k<4, 2, false, true, 6>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 6>(h, sh, grid, B, m, R); break;
+            default: e = (sh.T == 2) ? wg::launch_k<8, 2, false, true, 6>(h, sh, grid, B, m, R) : wg::launch_k<8, 1, false, true, 6>(h, sh, grid, B, m, R); break;
+        }
+    } else if (sh.gr) {
         e = (sh.T == 4) ? wg::launch_k<4, 4, false, true, 5>(h, sh, grid, B, m, R)
           : (sh.T == 2) ? wg::launch_k<4, 2, false, true, 5>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 5>(h, sh, grid, B, m, R);
     } else if (sh.hc) {

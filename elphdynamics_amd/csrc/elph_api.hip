@@ -170,13 +170,15 @@ static void detect_square(elph_handle_s *h) {
     h->sq_P = (L == 8 || L == 16) ? L / 8 : 0;
 }
 
-// Recognise the honeycomb lattice of 12 x 12 two-site cells (site = 2 (x + 12 y) + orbital) with the reference's colouring
+// Recognise a honeycomb lattice of L x L two-site cells (site = 2 (x + L y) + orbital; hc_L, and hc12 for L = 12) with the reference's colouring
 // [A-B of a cell | B(x,y)-A(x+1,y) | B(x,y)-A(x,y+1)] (the bond definitions of examples/holstein_hmc_honeycomb.toml through
 // Checkerboard.jl:471-515).  Only then may the register-exchange form of the resident CG run (cg_wg_dev.h, HcCtx).
 static void detect_honeycomb12(elph_handle_s *h) {
     h->hc12 = false;
-    const int L = 12;
-    if (h->N != 2 * L * L || h->ncol != 3 || h->nb != 3 * L * L) return;
+    h->hc_L = 0;
+    int L = 0;
+    for (int l = 2; l <= 64; ++l) if ((int64_t)2 * l * l == h->N) L = l;
+    if (L == 0 || h->ncol != 3 || h->nb != 3 * L * L) return;
     std::vector<char> seen((size_t)3 * h->N, 0);
     for (int col = 0; col < 3; ++col) {
         const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
@@ -194,7 +196,8 @@ static void detect_honeycomb12(elph_handle_s *h) {
             seen[(size_t)col * h->N + i] = seen[(size_t)col * h->N + j] = 1;
         }
     }
-    h->hc12 = true;
+    h->hc_L = L;
+    h->hc12 = (L == 12);
 }
 
 // uploads the lane-program copy of the per-bond cosh/sinh tables (h_c/h_s)
@@ -1332,7 +1335,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sq_sbar, qs.data(), sizeof(double) * qs.size(), hipMemcpyHostToDevice));
     }
-    if (hop_fresh && h->hc12) {
+    if (hop_fresh && h->hc_L > 0) {
         bool uni = h->nb > 0 && !h->kpm_hop_per_chain;
         for (size_t k = 1; k < (size_t)h->nb && uni; ++k) uni = h->h_cbar[k] == h->h_cbar[0] && h->h_sbar[k] == h->h_sbar[0];
         if (uni != h->hc_uniform) drop_graphs(h);

@@ -67,6 +67,8 @@ struct ModelDev {
     const int *sq_bond;
     // any even-L square lattice (4 <= L <= 16) in that colouring: G = L / 2, the lane grid of the GRID layout (cg_fast_common.h); 0 otherwise
     int grid_G;
+    // any honeycomb lattice of hc_L x hc_L two-site cells in the reference's colouring (detect_honeycomb); 0 otherwise
+    int hc_L;
 };
 #ifdef __HIPCC__
 // the hopping tables of the chain right-hand side `rhs` belongs to (SSH chains; no-op otherwise)
@@ -222,6 +224,7 @@ struct elph_handle_s {
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     bool hc_uniform = false;               // ... and its tau-averaged hopping tables are one (cosh, sinh) for every bond (the register-exchange Chebyshev recursion)
+    int hc_L = 0;                          // honeycomb lattice of hc_L x hc_L cells in the reference's colouring (detect_honeycomb); hc12: hc_L == 12
     bool hc12 = false;                     // honeycomb lattice of 12 x 12 cells in the reference's colouring (detect_honeycomb12): the DPP form of k_cg_wg
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     int *d_sq_bond = nullptr;                            // [4][N] device copy of sq_bond (sq_P > 0)

@@ -975,6 +975,7 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.uniform = 0; m.c_uni = 1.0; m.s_uni = 0.0;
     m.sq_bond = (h->sq_L > 0) ? h->d_sq_bond : nullptr;
     m.grid_G = (h->sq_L >= 4 && h->sq_L <= 16) ? h->sq_L / 2 : 0;
+    m.hc_L = h->hc_L;
     if (h->kind == ELPH_MODEL_HOLSTEIN && h->nb > 0) {
         bool uni = true;
         for (int64_t n = 1; n < h->nb && uni; ++n) uni = (h->h_c[(size_t)n] == h->h_c[0] && h->h_s[(size_t)n] == h->h_s[0]);
@@ -1177,7 +1178,7 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     static const bool freq_rz_on = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
     const int nct = (N + 15) / 16;
     const bool no_sq = []() { const char *e = getenv("ELPH_NO_SQ"); return e && e[0] == '1'; }();                    // (A/B: the LDS recursion, which knows no fold)
-    const bool reg_cheb = !no_sq && (h->sq_P > 0 || (h->sq_L > 0 && h->sq_uniform && h->kind == ELPH_MODEL_HOLSTEIN) || (h->hc12 && h->hc_uniform && h->kind == ELPH_MODEL_HOLSTEIN));     // (a register-exchange Chebyshev kernel: the one that knows the fold)
+    const bool reg_cheb = !no_sq && (h->sq_P > 0 || (h->sq_L > 0 && h->sq_uniform && h->kind == ELPH_MODEL_HOLSTEIN) || (h->hc_L > 0 && h->hc_uniform && h->kind == ELPH_MODEL_HOLSTEIN && (h->hc12 || h->hc_L * h->hc_L <= 64 || (h->hc_L % 2 == 0 && h->hc_L <= 16))));     // (a register-exchange Chebyshev kernel: the one that knows the fold)
     const bool fold = cg_mode == 2 && h->fast && reg_cheb && h->lp_mc == 4 && freq_rz_on && h->d_kfold &&
                       2 * Lo2 + nct <= B.nrz && B.dot_lo == 0 && B.dot_hi == N && elph_dft_mfma_fold_usable(h);
     if (!(parts & 1)) {

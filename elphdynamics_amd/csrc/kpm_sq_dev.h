@@ -210,6 +210,16 @@ __device__ __forceinline__ void kpm_series_grid(double (&Pacc)[4], double (&Qacc
     });
 }
 
+// the HGRID layout (cg_fast_common.h: honeycomb lattices on a grid of lanes, NS = 2, 4 or 8 registers per lane, uniform hopping)
+template <int NS, bool TRANSPOSED>
+__device__ __forceinline__ void kpm_series_hgrid(double (&Pacc)[NS], double (&Qacc)[NS], const double (&vin)[NS], const double (&eb)[NS],
+                                                 const double2 *c, int order, double a, double b, const HgCtx &T) {
+    kpm_series<NS, TRANSPOSED>(Pacc, Qacc, vin, eb, c, order, a, b, [&T](double (&w)[NS], auto &&mid) {
+        mid();
+        hgrid_sweepN<NS, 1, TRANSPOSED>(reinterpret_cast<double (&)[1][NS]>(w), T);
+    });
+}
+
 template <bool TRANSPOSED>
 __device__ __forceinline__ void kpm_series_hc(double (&Pacc)[6], double (&Qacc)[6], const double (&vin)[6], const double (&eb)[6],
                                               const double2 *c, int order, double a, double b, const HcLane &T) {
