@@ -1191,6 +1191,38 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
     return false;
 }
 
+// ---- the cost model behind the choice of form: ONE table, every entry with the measurement it was fitted to -----------------------
+// us per iteration of ONE round of the resident kernel (a round holds 8 x floor(32 / G) right-hand sides: one team per G CUs of an XCD)
+//     t = a + g * G + s * T * (sites per lane / 4 where the form scales with them)
+// and of the two-kernel streaming iteration (HBM-bound, linear in the batch).  Fitted on MI355X; a form that is not in the table is
+// priced as the lane program.  The rule only has to order the two forms: a 20 % error in an entry moves a crossover by a few
+// right-hand sides.
+struct WgCost { const char *form; double a, g, s; const char *measured; };
+static const WgCost wg_cost_table[] = {
+    {"lane program (FORM 0)",            2.00, 0.12, 0.50, "profiles/r02/time_forms.log: configs B, C, D, E at 1-2 slices per wave; x sites per lane; + 3.9 for SSH at 2 slices, 0.85 T per slice from 4"},
+    {"16x16 DPP (FORM 1, Holstein)",     2.66, 0.01, 0.62, "profiles/r03/time_forms.log: 3.5 / 4.0 / 5.2 us at 1 / 2 / 4 slices per wave"},
+    {"16x16 DPP, bond phonons",          2.50, 0.00, 1.30, "profiles/r03/time_forms_E_ssh_dpp.log: 3.8 / 5.1 us at 1 / 2 slices"},
+    {"honeycomb 12x12 DPP (FORM 2)",     2.10, 0.00, 1.70, "profiles/r03/time_forms_D_honeycomb_dpp.log: 3.8 / 5.5 us at 1 / 2 slices; 8.6 us at 3 (time_forms_D_three_slices_per_wave.log)"},
+    {"8x8 DPP (FORM 4), team of one",    2.30, 0.00, 0.00, "profiles/r03/time_wg_B_8x8_dpp_form.log: 2.04-2.3 us whatever the batch"},
+    {"GRID (FORM 5)",                    2.90, 0.01, 1.35, "profiles/r04/grid_form_even_L_square_lattices.log: L = 12: 4.3 / 5.6 / 10.0 us at 1 / 2 / 4 slices; L = 14, 10: 3.6-4.0 at 1"},
+    {"HGRID (FORM 6)",                   2.30, 0.01, 1.10, "profiles/r04/hgrid_form_honeycomb_lattices.log: L = 6: 2.5 us (2 registers per lane), L = 10: 3.3-3.8 (4), L = 16: 4.5-5.8 (8); x sites per lane / 4"},
+};
+static const double wg_streaming_cost[3] = {10.0, 0.56, 0.02};   // us: launch floor + nrhs x (0.56 x Ndim / 40960 [x 1.1 for SSH] + 0.02) — profiles/r03/time_forms.log (C: 37 us at 64, 128 at 256)
+
+static double resident_iteration_us(const elph_handle_s *h, const Shape &sh) {
+    const bool ssh = h->kind == ELPH_MODEL_SSH;
+    if (sh.s8) return wg_cost_table[4].a;
+    if (sh.sq && ssh) return wg_cost_table[2].a + wg_cost_table[2].s * sh.T;
+    if (sh.hc) return (sh.T == 3) ? 8.6 : wg_cost_table[3].a + wg_cost_table[3].s * sh.T;
+    if (sh.sq) return wg_cost_table[1].a + wg_cost_table[1].g * sh.G + wg_cost_table[1].s * sh.T;
+    if (sh.gr) return wg_cost_table[5].a + wg_cost_table[5].g * sh.G + wg_cost_table[5].s * sh.T;
+    if (sh.hg) return wg_cost_table[6].a + wg_cost_table[6].g * sh.G + wg_cost_table[6].s * sh.T * (sh.npl / 4.0);
+    return wg_cost_table[0].a + wg_cost_table[0].g * sh.G + (sh.T >= 4 ? 0.85 : wg_cost_table[0].s) * sh.T * h->npl + ((ssh && sh.T == 2) ? 3.9 : 0.0);
+}
+static double streaming_iteration_us(const elph_handle_s *h, int nrhs) {
+    return wg_streaming_cost[0] + nrhs * (wg_streaming_cost[1] * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + wg_streaming_cost[2]);
+}
+
 template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD = false, bool X0Z = false>
 static hipError_t launch_k(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R,
                            const ShardCtl &Sh = ShardCtl()) {
@@ -1286,29 +1318,15 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
     wg::Shape sh;
     ModelDev m = elph_model_dev(h);
     if (!wg::pick_shape(h, m, et ? atoi(et) : 0, nrhs, &sh)) return ELPH_OK;
-    // Which form is faster for THIS batch.  A round of the resident kernel holds 8 x (32 / G) right-hand sides (one team per G CUs
-    // of an XCD) and a batch takes ceil(nrhs / that) rounds of one iteration time each; the two-kernel streaming form is
-    // HBM-bound and linear in the batch.  Both fitted to measurements on configs B, C, D, E (tools/time_forms.py,
-    // profiles/r02/time_forms.log; us per iteration of the batch):
-    //   resident  = rounds x (2.0 + 0.12 G + 0.5 T npl [+ 3.9 for SSH at 2 slices per wave])   lane-program form;
-    //               rounds x (2.66 + 0.01 G + 0.62 T)   DPP form         (single-meeting iteration, round 3: 3.5 / 4.0 / 5.2 us at 1 / 2 / 4 slices)
-    //               rounds x 2.3   8 x 8 DPP form (one workgroup per right-hand side, 256 per round);
-    //               rounds x (2.5 + 1.3 T)   DPP form with bond phonons (E: 3.8 / 5.1 us);   rounds x (2.1 + 1.7 T)   honeycomb DPP form (D: 3.8 / 5.5 us; 9.7 at 3 slices)
-    //   streaming = 10 + nrhs x (0.56 Ndim / 40960 [x 1.1 for SSH] + 0.02)
-    // C, B, D, E: resident at every batch (C: 17.5 M against 3.7 M mat-vecs/s at 256; D: 8.9 M against 4.2 M; E: 9.7 M against 3.2 M);
-    // the rule still decides for other lattices and time axes.  A deterministic rule
-    // (never a timing at run time): which form runs decides the last bits of a solution.
-    // fixed_iters > 0 (measurement of this kernel) and ELPH_WG_ALWAYS=1 skip it.
+    // Which form is faster for THIS batch: a deterministic rule (never a timing at run time — which form runs decides the last bits of a
+    // solution) from ONE table of measured constants, wg_cost_table above.  fixed_iters > 0 (measurement of this kernel) and
+    // ELPH_WG_ALWAYS=1 skip it.
     {
         const char *ea = getenv("ELPH_WG_ALWAYS");
         if (fixed_iters <= 0 && !(ea && ea[0] == '1')) {
             const int per_round = 8 * std::max(1, 32 / sh.G);
             const double rounds = (double)((nrhs + per_round - 1) / per_round);
-            const bool ssh_sq = sh.sq && h->kind == ELPH_MODEL_SSH;    // (bond phonons in the DPP form: 3.8 / 5.1 us at 1 / 2 slices per wave)
-            const double t_res = rounds * (sh.s8 ? 2.3 : ssh_sq ? 2.5 + 1.3 * sh.T : sh.hc ? (sh.T == 3 ? 8.6 : 2.1 + 1.7 * sh.T) : (sh.sq || sh.gr || sh.hg) ? 2.66 + 0.01 * sh.G + 0.62 * sh.T * (sh.hg ? sh.npl / 4.0 : 1.0)
-                                                 : 2.0 + 0.12 * sh.G + (sh.T >= 4 ? 0.85 : 0.5) * sh.T * h->npl + ((h->kind == ELPH_MODEL_SSH && sh.T == 2) ? 3.9 : 0.0));
-            const double t_str = 10.0 + nrhs * (0.56 * (double)h->ndim / 40960.0 * (h->kind == ELPH_MODEL_SSH ? 1.1 : 1.0) + 0.02);
-            if (t_res > t_str) return ELPH_OK;
+            if (rounds * wg::resident_iteration_us(h, sh) > wg::streaming_iteration_us(h, nrhs)) return ELPH_OK;
         }
     }
     const size_t HS = (size_t)sh.npl * WAVE;
