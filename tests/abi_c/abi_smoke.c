@@ -95,6 +95,7 @@ int main(int argc, char **argv) {
     const int64_t iters_plain = iters;
     /* flag logic: a solve cut short is reported and zero-filled, never thrown — Models.jl:157-180 */
     CHECK_RC(elph_solver_set(h, 1e-14, 3, 1e12));
+    memset(y, 0, sizeof(double) * (size_t)ndim);           /* ldiv! starts from the caller's x (callers pass zeros: HMC.jl:854) */
     CHECK_RC(elph_ldiv(h, y, b, 0, 0, &iters, &resid, &flag));
     {
         double nz = 0.0;
