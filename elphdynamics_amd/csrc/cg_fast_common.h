@@ -107,22 +107,26 @@ struct GridCtx {
     double th, k4;           // tanh of the bond angle; c^4
     int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1
 };
-__host__ __device__ __forceinline__ int grid_site(int lane, int q, int G) {
-    const int l = (lane < G * G) ? lane : 0, X = l % G, Y = l / G;
-    return (2 * X + (q & 1)) + 2 * G * (2 * Y + (q >> 1));
+// (GX x GY lanes: a rectangular lattice of 2 GX x 2 GY sites, periodic in both directions — the slab of a sharded solve is one: its
+//  own rows and ghost rows closed into a ring, shard.hip)
+__host__ __device__ __forceinline__ int grid_site(int lane, int q, int GX, int GY) {
+    const int l = (lane < GX * GY) ? lane : 0, X = l % GX, Y = l / GX;
+    return (2 * X + (q & 1)) + 2 * GX * (2 * Y + (q >> 1));
 }
-__device__ __forceinline__ GridCtx grid_ctx(int lane, int G, double c, double s) {
+__host__ __device__ __forceinline__ int grid_site(int lane, int q, int G) { return grid_site(lane, q, G, G); }
+__device__ __forceinline__ GridCtx grid_ctx(int lane, int GX, int GY, double c, double s) {
     GridCtx X;
     X.th = s / c; X.k4 = (c * c) * (c * c);
-    if (lane < G * G) {
-        const int x = lane % G, y = lane / G;
-        X.xu = (x + 1) % G + G * y; X.xd = (x + G - 1) % G + G * y;
-        X.yu = x + G * ((y + 1) % G); X.yd = x + G * ((y + G - 1) % G);
+    if (lane < GX * GY) {
+        const int x = lane % GX, y = lane / GX;
+        X.xu = (x + 1) % GX + GX * y; X.xd = (x + GX - 1) % GX + GX * y;
+        X.yu = x + GX * ((y + 1) % GY); X.yd = x + GX * ((y + GY - 1) % GY);
     } else {
         X.xu = X.xd = X.yu = X.yd = lane;
     }
     return X;
 }
+__device__ __forceinline__ GridCtx grid_ctx(int lane, int G, double c, double s) { return grid_ctx(lane, G, G, c, s); }
 // one colour on CNT slabs at once: the crossing values of all slabs first (their ds_bpermute round trips overlap), then the arithmetic
 template <int CNT, int COL>
 __device__ __forceinline__ void grid_colour(double (*v)[4], const GridCtx &X) {
@@ -177,18 +181,21 @@ struct HgCtx {
     double th, k3;
     int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1 (cyclic); idle lanes: themselves
 };
+// (LX x LY cells, periodic in both directions; LX = LY for a whole lattice, a sharded solve's slab is LX x rows)
 template <int NPL>
-__host__ __device__ __forceinline__ int hgrid_site(int lane, int q, int L) {
+__host__ __device__ __forceinline__ int hgrid_site(int lane, int q, int LX, int LY) {
     constexpr int PX = HgDim<NPL>::PX, PY = HgDim<NPL>::PY;
-    const int GX = L / PX, GY = L / PY;
+    const int GX = LX / PX, GY = LY / PY;
     const int l = (lane < GX * GY) ? lane : 0, X = l % GX, Y = l / GX;
     const int c = q >> 1, cx = c % PX, cy = c / PX;
-    return 2 * ((PX * X + cx) + L * (PY * Y + cy)) + (q & 1);
+    return 2 * ((PX * X + cx) + LX * (PY * Y + cy)) + (q & 1);
 }
 template <int NPL>
-__device__ __forceinline__ HgCtx hgrid_ctx(int lane, int L, double c, double s) {
+__host__ __device__ __forceinline__ int hgrid_site(int lane, int q, int L) { return hgrid_site<NPL>(lane, q, L, L); }
+template <int NPL>
+__device__ __forceinline__ HgCtx hgrid_ctx(int lane, int LX, int LY, double c, double s) {
     constexpr int PX = HgDim<NPL>::PX, PY = HgDim<NPL>::PY;
-    const int GX = L / PX, GY = L / PY;
+    const int GX = LX / PX, GY = LY / PY;
     HgCtx X;
     X.th = s / c; X.k3 = c * c * c;
     if (lane < GX * GY) {
@@ -200,6 +207,8 @@ __device__ __forceinline__ HgCtx hgrid_ctx(int lane, int L, double c, double s) 
     }
     return X;
 }
+template <int NPL>
+__device__ __forceinline__ HgCtx hgrid_ctx(int lane, int L, double c, double s) { return hgrid_ctx<NPL>(lane, L, L, c, s); }
 template <int NPL, int CNT, int COL>
 __device__ __forceinline__ void hgrid_colour(double (*v)[NPL], const HgCtx &X) {
     constexpr int PX = HgDim<NPL>::PX, PY = HgDim<NPL>::PY;

@@ -49,10 +49,10 @@ __device__ unsigned long long g_wg_arrive[4096 * 4];
 template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
     constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, GR = FORM == 5, HG = FORM == 6, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
-    static_assert(!HG || ((NPL == 2 || NPL == 4 || NPL == 8) && UNI && !SSH && !SHARD && T <= 2), "honeycomb grid form: 1, 2 or 4 cells per lane, uniform hopping, at most two slices per wave");
-    static_assert(!GR || (NPL == 4 && UNI && !SSH && !SHARD && T <= 4), "grid form (even-L square lattices, 2 x 2 patches on a G x G lane grid): uniform hopping, at most four slices per wave");
+    static_assert(!HG || ((NPL == 2 || NPL == 4 || NPL == 8) && UNI && !SSH && T <= 2), "honeycomb grid form: 1, 2 or 4 cells per lane, uniform hopping, at most two slices per wave");
+    static_assert(!GR || (NPL == 4 && UNI && !SSH && T <= 4), "grid form (even-L square lattices, 2 x 2 patches on a G x G lane grid): uniform hopping, at most four slices per wave");
     static_assert(!S8 || (NPL == 1 && UNI && !SSH && !SHARD), "8 x 8 DPP form: one site per lane, uniform hopping");
-    static_assert(!SHARD || (T == 1 && !REGX), "sharded solves: one slice per wave, lane-program form");
+    static_assert(!SHARD || (T == 1 && (FORM == 0 || FORM == 5 || FORM == 6)), "sharded solves: one slice per wave; lane-program, GRID or HGRID form (the slab closed into a ring)");
     static_assert(!HC || (NPL == HC_NPL && UNI && !SSH && T <= 3), "honeycomb DPP form: six sites per lane, uniform hopping");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(!SQ || NPL == 4, "DPP form: the 16 x 16 square lattice, four sites per lane");
@@ -131,9 +131,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     const int N = m.N, L = m.L;
     const int t0 = (g * W + wv) * T;
     const int lr = HC ? 12 * (hc_src_lane(lane) >> 4) + (hc_src_lane(lane) & 15) - 2 : lane;      // LDS slot this lane reads (and, if lwok, writes)
-    const int GG = GR ? m.grid_G : 0;                     // grid form: G x G lanes hold the lattice, the rest idle
-    const int HL = HG ? m.hc_L : 0;                       // honeycomb grid form: (HL / PX) x (HL / PY) lanes
-    const bool lwok = HC ? hc_real(lane) : (GR ? lane < GG * GG : (HG ? lane < (HL / HgDim<NPL>::PX) * (HL / HgDim<NPL>::PY) : true));
+    const int GGX = GR ? m.grid_GX : 0, GGY = GR ? m.grid_GY : 0;      // grid form: GX x GY lanes hold the lattice, the rest idle
+    const int HLX = HG ? m.hc_LX : 0, HLY = HG ? m.hc_LY : 0;         // honeycomb grid form: (LX / PX) x (LY / PY) lanes
+    const bool lwok = HC ? hc_real(lane) : (GR ? lane < GGX * GGY : (HG ? lane < (HLX / HgDim<NPL>::PX) * (HLY / HgDim<NPL>::PY) : true));
     const size_t ndim = (size_t)N * L;
     double *slab = lds + (size_t)wv * NSLAB * SL;
     double *rall = lds + (size_t)W * NSLAB * SL;       // [W][T][HS]: r of every wave's slices — neighbours read their halo slices here
@@ -160,14 +160,15 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #endif
 
     // site of register q of this lane: lane + 64 q (layout S order), or the column segments of the DPP form
-    int sc[NPL];
+    int sc[NPL], ss[NPL];
     bool live[NPL], own[NPL];                          // own: the site enters the inner products (a shard counts its own rows only)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : (S8 ? s8_site(lane) : (GR ? grid_site(lane, q, GG) : (HG ? hgrid_site<NPL>(lane, q, HL) : lane + q * WAVE))));
+        const int s = SQ ? sq_patch_site(lane, q) : (HC ? hc_site(lane, q) : (S8 ? s8_site(lane) : (GR ? grid_site(lane, q, GGX, GGY) : (HG ? hgrid_site<NPL>(lane, q, HLX, HLY) : lane + q * WAVE))));
         live[q] = (GR || HG) ? lwok : (REGX || s < N);            // (DPP forms: every register of every lane holds a site — no selects in the sums)
-        own[q] = SHARD ? (s >= Sh.own_lo && s < Sh.own_hi) : (HC ? hc_real(lane) : live[q]);     // (honeycomb: mirror lanes carry copies)
+        own[q] = SHARD ? (live[q] && s >= Sh.own_lo && s < Sh.own_hi) : (HC ? hc_real(lane) : live[q]);     // (honeycomb: mirror lanes carry copies)
         sc[q] = live[q] ? s : N - 1;
+        ss[q] = live[q] ? s : N;                          // (a shard asks where a site sits among own and ghost rows: an idle register sits nowhere)
     }
     double *xg = B.x + (size_t)rhs * ndim, *rg = B.r + (size_t)rhs * ndim;
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
@@ -213,9 +214,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     GridCtx XG;
     HgCtx XHG;
     if constexpr (GR) {
-        XG = grid_ctx(lane, GG, m.c_uni, m.s_uni);
+        XG = grid_ctx(lane, GGX, GGY, m.c_uni, m.s_uni);
     } else if constexpr (HG) {
-        XHG = hgrid_ctx<NPL>(lane, HL, m.c_uni, m.s_uni);
+        XHG = hgrid_ctx<NPL>(lane, HLX, HLY, m.c_uni, m.s_uni);
     } else if constexpr (S8) {
         X8.th = m.s_uni / m.c_uni; X8.k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
         X8.yx = sq_patch_ycross(lane); X8.xodd = (lane >> 1) & 1;
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     if constexpr (SHARD) {
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-            const int s = lane + q * WAVE;
+            const int s = ss[q];
             gaddr[q] = (s < Sh.own_lo) ? sh_ghost(Sh.mail[Sh.rank], 0, L, Sh.cap_ghost, t0, s)
                      : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, t0, s - Sh.own_hi) : nullptr;
         }
@@ -567,7 +568,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             const int prev = (Sh.rank + Sh.P - 1) % Sh.P, next = (Sh.rank + 1) % Sh.P;
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const int s = lane + q * WAVE;
+                const int s = ss[q];
                 const u64 bits = (u64)__double_as_longlong(z[0][q]), tag = (u64)epoch << 32;
                 if (s >= Sh.own_lo && s < Sh.own_lo + Sh.n_to_prev) {              // bottom rows -> previous rank's ghosts above its own rows
                     u64 *d = sh_ghost(Sh.mail[prev], 1, L, Sh.cap_ghost, t0, s - Sh.own_lo) + ghp;
@@ -617,7 +618,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 const u64 *ga2[NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
-                    const int s = lane + q * WAVE;
+                    const int s = ss[q];
                     ga2[q] = !bw ? nullptr
                            : (s < Sh.own_lo) ? sh_ghost(Sh.mail[Sh.rank], 0, L, Sh.cap_ghost, th, s) + ghp
                            : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, th, s - Sh.own_hi) + ghp : nullptr;
@@ -992,8 +993,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int j = 0; j < T; ++j)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
-                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : (S8 ? s8_site(lane2) : (GR ? grid_site(lane2, q, GG) : (HG ? hgrid_site<NPL>(lane2, q, HL) : lane2 + q * WAVE))));
-                    if (HC ? hc_real(lane2) : (GR ? lane2 < GG * GG : (HG ? lane2 < (HL / HgDim<NPL>::PX) * (HL / HgDim<NPL>::PY) : (SQ || s2 < N)))) {
+                    const int s2 = SQ ? sq_patch_site(lane2, q) : (HC ? hc_site(lane2, q) : (S8 ? s8_site(lane2) : (GR ? grid_site(lane2, q, GGX, GGY) : (HG ? hgrid_site<NPL>(lane2, q, HLX, HLY) : lane2 + q * WAVE))));
+                    if (HC ? hc_real(lane2) : (GR ? lane2 < GGX * GGY : (HG ? lane2 < (HLX / HgDim<NPL>::PX) * (HLY / HgDim<NPL>::PY) : (SQ || s2 < N)))) {
                         // (the residual stays on the chip: ldiv! judges a solution by its TRUE residual, Models.jl:150-160; a shard's
                         //  caller may want it)
                         if (SHARD) rg[(size_t)(t0 + j) * N + s2] = rl[j * HSL + lr + q * LSL];
@@ -1076,22 +1077,25 @@ static bool s8_form(const elph_handle_s *h, const ModelDev &m) {
     return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_P == 1 && h->N == 64 && m.uniform && !(e && e[0] == '1');
 }
 
-// grid form: Holstein with uniform hopping on any OTHER even-L square lattice up to 16 x 16 in the reference's colouring (detect_square:
-// sq_L; L = 16 and 8 have DPP forms of their own)
-static bool gr_form(const elph_handle_s *h, const ModelDev &m) {
+// grid form: Holstein with uniform hopping on a periodic LX x LY square lattice in the reference's colouring whose 2 x 2 patches fit the
+// lanes of a wave (detect_square: sq_LX, sq_LY).  An ordinary solve takes it for the sizes WITHOUT a DPP form of their own (not 16 x 16,
+// not 8 x 8); a sharded solve (for_shard) for every size — the slab closed into a ring is such a lattice, and the DPP forms know no shards.
+static bool gr_form(const elph_handle_s *h, const ModelDev &m, bool for_shard = false) {
     const char *e = getenv("ELPH_WG_NO_DPP");
-    return h->kind == ELPH_MODEL_HOLSTEIN && h->sq_L >= 4 && h->sq_L != 16 && h->sq_L != 8 && m.uniform && m.grid_G > 0 && !(e && e[0] == '1');
+    if (h->kind != ELPH_MODEL_HOLSTEIN || h->sq_LX < 4 || h->sq_LY < 4 || !m.uniform || m.grid_GX * m.grid_GY < 1 || m.grid_GX * m.grid_GY > 64 || (e && e[0] == '1')) return false;
+    return for_shard || h->sq_P == 0;
 }
 
-// honeycomb grid form: Holstein with uniform hopping on any OTHER honeycomb lattice of L x L cells in the reference's colouring whose cells
-// fit a grid of lanes (detect_honeycomb: hc_L; L = 12 has a DPP form of its own).  Returns the registers per lane (2, 4 or 8), 0: no.
-static int hg_form(const elph_handle_s *h, const ModelDev &m) {
+// honeycomb grid form: Holstein with uniform hopping on a periodic honeycomb lattice of LX x LY cells in the reference's colouring whose cells
+// fit a grid of lanes (detect_honeycomb: hc_LX, hc_LY; 12 x 12 has a DPP form of its own — which knows no shards).  Returns the registers per
+// lane (2, 4 or 8: 1, 2 x 1 or 2 x 2 cells), 0: no.
+static int hg_form(const elph_handle_s *h, const ModelDev &m, bool for_shard = false) {
     const char *e = getenv("ELPH_WG_NO_DPP");
-    if (h->kind != ELPH_MODEL_HOLSTEIN || h->hc_L < 2 || h->hc12 || !m.uniform || m.hc_L != h->hc_L || (e && e[0] == '1')) return 0;
-    const int L = h->hc_L;
-    if (L * L <= 64) return 2;
-    if (L % 2 == 0 && (L / 2) * L <= 64) return 4;
-    if (L % 2 == 0 && (L / 2) * (L / 2) <= 64) return 8;
+    if (h->kind != ELPH_MODEL_HOLSTEIN || h->hc_LX < 2 || h->hc_LY < 2 || (h->hc12 && !for_shard) || !m.uniform || m.hc_LX != h->hc_LX || (e && e[0] == '1')) return 0;
+    const int LX = h->hc_LX, LY = h->hc_LY;
+    if (LX * LY <= 64) return 2;
+    if (LX % 2 == 0 && (LX / 2) * LY <= 64) return 4;
+    if (LX % 2 == 0 && LY % 2 == 0 && (LX / 2) * (LY / 2) <= 64) return 8;
     return 0;
 }
 
@@ -1239,6 +1243,16 @@ static hipError_t launch_shard_npl(elph_handle_s *h, const Shape &sh, dim3 grid,
     return m.uniform ? launch_k<NPL, 1, false, true, 0, true>(h, sh, grid, B, m, R, Sh)
                      : launch_k<NPL, 1, false, false, 0, true>(h, sh, grid, B, m, R, Sh);
 }
+// a shard in a register-exchange form: the slab is a periodic rectangle (its rows closed into a ring by the caller's bond table)
+static hipError_t launch_shard_grid(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R,
+                                    const ShardCtl &Sh) {
+    if (sh.gr) return launch_k<4, 1, false, true, 5, true>(h, sh, grid, B, m, R, Sh);
+    switch (sh.npl) {
+        case 2: return launch_k<2, 1, false, true, 6, true>(h, sh, grid, B, m, R, Sh);
+        case 4: return launch_k<4, 1, false, true, 6, true>(h, sh, grid, B, m, R, Sh);
+        default: return launch_k<8, 1, false, true, 6, true>(h, sh, grid, B, m, R, Sh);
+    }
+}
 
 template <int NPL>
 static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R) {
@@ -1284,7 +1298,7 @@ bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs) {
     const char *eo = getenv("ELPH_NO_WG");                 // read per call: the tests switch between the two forms
     const bool off = eo && eo[0] == '1';
     // (h->npl > 5: the lane-program form's limit — 320 sites; the honeycomb grid form carries up to 512 in one wave)
-    if (off || !h->fast || h->lp_mc != 4 || (h->npl > 5 && !(h->hc_L > 0 && !h->hc12 && h->kind == ELPH_MODEL_HOLSTEIN)) || h->dot_hi != 0 || h->solo_chain >= 0) return false;
+    if (off || !h->fast || h->lp_mc != 4 || (h->npl > 5 && !(h->hc_LX > 0 && !h->hc12 && h->kind == ELPH_MODEL_HOLSTEIN)) || h->dot_hi != 0 || h->solo_chain >= 0) return false;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
     if (!wg::pick_shape(h, elph_model_dev(h), et ? atoi(et) : 0, nrhs, &sh)) return false;
@@ -1429,21 +1443,31 @@ extern "C" int elph_debug_wg_stamps(unsigned long long *out16) {
 
 // One rank's launch of a solve over several GPUs (shard.hip holds the mailbox and calls this).  x0 = 0, b in B.r and B.p.
 int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out) {
-    if (!h->fast_capable || h->lp_mc != 4 || h->npl > 5) {
+    ModelDev m = elph_model_dev(h);
+    // a slab whose rows the caller closed into a ring (a periodic rectangle in the reference's colouring: sharded.py, ring=True) runs a
+    // register-exchange form — the own rows of z = M^T M p do not see the ring bond (it lies beyond the ghost rows' dependency closure)
+    // (measured, profiles/r04/shard_ring_grid_forms_ab.log: the GRID form pays from three sites per lane of the lane program — a
+    //  slab of up to 128 sites is two LDS values per lane and colour, cheaper than four registers on half the lanes: config C over 4 / 8
+    //  ranks 5.3 / 6.0 us in the lane program against 6.5 / 7.2; the HGRID form with 8 registers per lane spills in the shard's
+    //  kernel: config D on one rank 16.6 against 9.6 us)
+    const bool gr = wg::gr_form(h, m, true) && h->npl >= 3;
+    int hgn = gr ? 0 : wg::hg_form(h, m, true);
+    if (hgn == 8) hgn = 0;
+    if (!gr && !hgn && (!h->fast_capable || h->lp_mc != 4 || h->npl > 5)) {
         elph_set_error("sharded solve: the slab needs a 4-colour lane program and <= 320 sites (N = %lld)", (long long)h->N);
         return ELPH_E_UNSUPPORTED;
     }
-    ModelDev m = elph_model_dev(h);
     wg::Shape sh;
     {   // one slice per wave on every rank (slab sizes differ between ranks; the team shape must not): elph_shard_shape
         int W = 0, G = 0;
         const int rc = elph_shard_shape(h->L, Sh.P, &W, &G, nullptr, nullptr);
         if (rc) return rc;
-        const size_t SL = (size_t)h->npl * WAVE + 2 * WAVE, HS = (size_t)h->npl * WAVE;
-        sh.T = 1; sh.W = W; sh.G = G; sh.sq = false; sh.hc = false; sh.s8 = false; sh.npl = h->npl;
-        sh.shm = ((size_t)W * 2 * SL + 2 * (size_t)W * HS + 48 + 4 * HS) * sizeof(double);     // + partials, totals, rhalo[2][HS], zhalo[2][HS]
+        sh.npl = gr ? 4 : (hgn ? hgn : h->npl);
+        const size_t SL = (size_t)sh.npl * WAVE + 2 * WAVE, HS = (size_t)sh.npl * WAVE;
+        sh.T = 1; sh.W = W; sh.G = G; sh.sq = false; sh.hc = false; sh.s8 = false; sh.gr = gr; sh.hg = hgn > 0;
+        sh.shm = ((size_t)W * ((gr || hgn) ? 0 : 2) * SL + 2 * (size_t)W * HS + 48 + 4 * HS) * sizeof(double);     // + partials, totals, rhalo[2][HS], zhalo[2][HS]
     }
-    const size_t HS = (size_t)h->npl * WAVE;
+    const size_t HS = (size_t)sh.npl * WAVE;
     const size_t n_slots = 2 * wg::SLOTS_PER_RHS, n_bnd = (sh.G > 1) ? 2 * (size_t)sh.G * 2 * HS * 2 : 0;
     const size_t need = (n_slots + n_bnd) * sizeof(wg::u64) + 64;
     // tags: a range of (iterations + 2) values per launch; the control block is zeroed only when it is (re)allocated or the
@@ -1478,7 +1502,8 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     R.teams_per_xcd = 1;
     const dim3 grid((unsigned)sh.G);                       // one right-hand side: its G workgroups, round-robin over the XCDs
     hipError_t e = hipSuccess;
-    switch (h->npl) {
+    if (sh.gr || sh.hg) e = wg::launch_shard_grid(h, sh, grid, B, m, R, Sh);
+    else switch (h->npl) {
         case 1: e = wg::launch_shard_npl<1>(h, sh, grid, B, m, R, Sh); break;
         case 2: e = wg::launch_shard_npl<2>(h, sh, grid, B, m, R, Sh); break;
         case 3: e = wg::launch_shard_npl<3>(h, sh, grid, B, m, R, Sh); break;

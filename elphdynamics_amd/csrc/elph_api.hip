@@ -141,63 +141,88 @@ static int build_lane_program(elph_handle_s *h) {
 // (even L from 4 to 16, site = x + L*y).  Only then may the register-exchange forms run (sq_L; sq_P = L / 8 for L = 8, 16, the sizes with
 // DPP layouts of their own; the GRID layout of cg_fast_common.h serves the others); any deviation (other lattice, other bond order,
 // disordered table) leaves sq_L = sq_P = 0 and the LDS kernels are used.
-static void detect_square(elph_handle_s *h) {
-    h->sq_P = 0;
-    h->sq_L = 0;
-    int L = 0;
-    for (int l = 4; l <= 16; l += 2) if ((int64_t)l * l == h->N) L = l;
-    if (L == 0) return;
-    if (h->ncol != 4 || h->nb != 2 * h->N) return;
+static bool match_square(elph_handle_s *h, int LX, int LY) {
     h->sq_bond.assign((size_t)4 * h->N, -1);
     for (int col = 0; col < 4; ++col) {
         const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
-        if (b1 - b0 != h->N / 2) return;
+        if (b1 - b0 != h->N / 2) return false;
         for (int n = b0; n < b1; ++n) {
             const int i = h->h_bi[n], j = h->h_bj[n];
-            const int xi = i % L, yi = i / L, xj = j % L, yj = j / L;
+            const int xi = i % LX, yi = i / LX, xj = j % LX, yj = j / LX;
             bool ok = false;
             // expected partner of site (x,y): col 0: x^1 ; col 1: x odd -> x+1, even -> x-1 ; cols 2,3 the same along y
-            auto partner = [L](int x, int colpar) { return colpar == 0 ? (x ^ 1) : ((x & 1) ? (x + 1) % L : (x + L - 1) % L); };
-            if (col < 2) ok = (yi == yj) && (partner(xi, col) == xj) && (partner(xj, col) == xi);
-            else ok = (xi == xj) && (partner(yi, col - 2) == yj) && (partner(yj, col - 2) == yi);
-            if (!ok) return;
+            auto partner = [](int x, int colpar, int L) { return colpar == 0 ? (x ^ 1) : ((x & 1) ? (x + 1) % L : (x + L - 1) % L); };
+            if (col < 2) ok = (yi == yj) && (partner(xi, col, LX) == xj) && (partner(xj, col, LX) == xi);
+            else ok = (xi == xj) && (partner(yi, col - 2, LY) == yj) && (partner(yj, col - 2, LY) == yi);
+            if (!ok) return false;
             h->sq_bond[(size_t)col * h->N + i] = n;
             h->sq_bond[(size_t)col * h->N + j] = n;
         }
     }
-    for (int v : h->sq_bond) if (v < 0) return;
-    h->sq_L = L;
-    h->sq_P = (L == 8 || L == 16) ? L / 8 : 0;
+    for (int v : h->sq_bond) if (v < 0) return false;
+    return true;
+}
+
+static void detect_square(elph_handle_s *h) {
+    h->sq_P = 0;
+    h->sq_L = 0;
+    h->sq_LX = h->sq_LY = 0;
+    if (h->ncol != 4 || h->nb != 2 * h->N || h->N < 16) return;
+    // candidates: the square first, then every even LX x LY with LX LY = N whose 2 x 2 patches fit the 64 lanes of a wave (the slab of a
+    // sharded solve: its rows closed into a ring)
+    std::vector<std::pair<int, int>> cand;
+    for (int l = 4; l <= 16; l += 2) if ((int64_t)l * l == h->N) cand.push_back({l, l});
+    for (int lx = 4; lx <= 32; lx += 2)
+        if (h->N % lx == 0) { const int ly = (int)(h->N / lx); if (ly >= 4 && ly % 2 == 0 && lx != ly && (lx / 2) * (ly / 2) <= 64) cand.push_back({lx, ly}); }
+    for (auto &c : cand) {
+        if (!match_square(h, c.first, c.second)) continue;
+        h->sq_LX = c.first; h->sq_LY = c.second;
+        if (c.first == c.second) { h->sq_L = c.first; h->sq_P = (c.first == 8 || c.first == 16) ? c.first / 8 : 0; }
+        return;
+    }
+    h->sq_bond.clear();
 }
 
 // Recognise a honeycomb lattice of L x L two-site cells (site = 2 (x + L y) + orbital; hc_L, and hc12 for L = 12) with the reference's colouring
 // [A-B of a cell | B(x,y)-A(x+1,y) | B(x,y)-A(x,y+1)] (the bond definitions of examples/holstein_hmc_honeycomb.toml through
 // Checkerboard.jl:471-515).  Only then may the register-exchange form of the resident CG run (cg_wg_dev.h, HcCtx).
-static void detect_honeycomb12(elph_handle_s *h) {
-    h->hc12 = false;
-    h->hc_L = 0;
-    int L = 0;
-    for (int l = 2; l <= 64; ++l) if ((int64_t)2 * l * l == h->N) L = l;
-    if (L == 0 || h->ncol != 3 || h->nb != 3 * L * L) return;
+static bool match_honeycomb(elph_handle_s *h, int LX, int LY) {
     std::vector<char> seen((size_t)3 * h->N, 0);
     for (int col = 0; col < 3; ++col) {
         const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
-        if (b1 - b0 != L * L) return;
+        if (b1 - b0 != LX * LY) return false;
         for (int n = b0; n < b1; ++n) {
             int i = h->h_bi[n], j = h->h_bj[n];
             if (i & 1) std::swap(i, j);                      // i: the A site (orbital 0), j: the B site
-            if ((i & 1) != 0 || (j & 1) != 1) return;
-            const int ca = i >> 1, cb = j >> 1, xa = ca % L, ya = ca / L, xb = cb % L, yb = cb / L;
+            if ((i & 1) != 0 || (j & 1) != 1) return false;
+            const int ca = i >> 1, cb = j >> 1, xa = ca % LX, ya = ca / LX, xb = cb % LX, yb = cb / LX;
             bool ok = false;
             if (col == 0) ok = (ca == cb);
-            else if (col == 1) ok = (ya == yb) && (xa == (xb + 1) % L);
-            else ok = (xa == xb) && (ya == (yb + 1) % L);
-            if (!ok || seen[(size_t)col * h->N + i] || seen[(size_t)col * h->N + j]) return;
+            else if (col == 1) ok = (ya == yb) && (xa == (xb + 1) % LX);
+            else ok = (xa == xb) && (ya == (yb + 1) % LY);
+            if (!ok || seen[(size_t)col * h->N + i] || seen[(size_t)col * h->N + j]) return false;
             seen[(size_t)col * h->N + i] = seen[(size_t)col * h->N + j] = 1;
         }
     }
-    h->hc_L = L;
-    h->hc12 = (L == 12);
+    return true;
+}
+
+static void detect_honeycomb12(elph_handle_s *h) {
+    h->hc12 = false;
+    h->hc_L = 0;
+    h->hc_LX = h->hc_LY = 0;
+    if (h->ncol != 3 || (h->N & 1) || h->nb != 3 * (h->N / 2) || h->N < 8) return;
+    const int cells = (int)(h->N / 2);
+    std::vector<std::pair<int, int>> cand;
+    for (int l = 2; l <= 64; ++l) if (l * l == cells) cand.push_back({l, l});
+    for (int lx = 2; lx <= 32; ++lx)
+        if (cells % lx == 0) { const int ly = cells / lx; if (ly >= 2 && lx != ly) cand.push_back({lx, ly}); }
+    for (auto &c : cand) {
+        if (!match_honeycomb(h, c.first, c.second)) continue;
+        h->hc_LX = c.first; h->hc_LY = c.second;
+        if (c.first == c.second) { h->hc_L = c.first; h->hc12 = (c.first == 12); }
+        return;
+    }
 }
 
 // uploads the lane-program copy of the per-bond cosh/sinh tables (h_c/h_s)
@@ -1335,7 +1360,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         HIPCHK(hipMemcpy(h->d_sq_cbar, qc.data(), sizeof(double) * qc.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_sq_sbar, qs.data(), sizeof(double) * qs.size(), hipMemcpyHostToDevice));
     }
-    if (hop_fresh && h->hc_L > 0) {
+    if (hop_fresh && h->hc_LX > 0) {
         bool uni = h->nb > 0 && !h->kpm_hop_per_chain;
         for (size_t k = 1; k < (size_t)h->nb && uni; ++k) uni = h->h_cbar[k] == h->h_cbar[0] && h->h_sbar[k] == h->h_sbar[0];
         if (uni != h->hc_uniform) drop_graphs(h);

@@ -65,10 +65,11 @@ struct ModelDev {
     double c_uni, s_uni;
     // 16 x 16 square lattice in the reference's colouring: the bond that covers site i in colour col ([4][N]; nullptr otherwise)
     const int *sq_bond;
-    // any even-L square lattice (4 <= L <= 16) in that colouring: G = L / 2, the lane grid of the GRID layout (cg_fast_common.h); 0 otherwise
-    int grid_G;
-    // any honeycomb lattice of hc_L x hc_L two-site cells in the reference's colouring (detect_honeycomb); 0 otherwise
-    int hc_L;
+    // a periodic square lattice of (2 grid_GX) x (2 grid_GY) sites in that colouring (square: GX = GY = L / 2; the slab of a sharded solve:
+    // 16 x rows): the lane grid of the GRID layout (cg_fast_common.h); 0 otherwise
+    int grid_GX, grid_GY;
+    // a periodic honeycomb lattice of hc_LX x hc_LY two-site cells in the reference's colouring (detect_honeycomb); 0 otherwise
+    int hc_LX, hc_LY;
 };
 #ifdef __HIPCC__
 // the hopping tables of the chain right-hand side `rhs` belongs to (SSH chains; no-op otherwise)
@@ -221,10 +222,12 @@ struct elph_handle_s {
     // even-L square lattice (L = 8 or 16) recognised in the bond table: P = L/8, per-site per-colour coefficients
     int sq_P = 0;
     int sq_L = 0;                          // even-L square lattice (4 <= L <= 16) recognised in the bond table: L (sq_P = L / 8 for L = 8, 16, the sizes with DPP forms)
+    int sq_LX = 0, sq_LY = 0;              // periodic LX x LY square lattice (both even, LX LY / 4 <= 64 lanes) recognised: sq_L = LX when LX == LY
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     bool hc_uniform = false;               // ... and its tau-averaged hopping tables are one (cosh, sinh) for every bond (the register-exchange Chebyshev recursion)
     int hc_L = 0;                          // honeycomb lattice of hc_L x hc_L cells in the reference's colouring (detect_honeycomb); hc12: hc_L == 12
+    int hc_LX = 0, hc_LY = 0;              // periodic honeycomb lattice of LX x LY cells recognised: hc_L = LX when LX == LY
     bool hc12 = false;                     // honeycomb lattice of 12 x 12 cells in the reference's colouring (detect_honeycomb12): the DPP form of k_cg_wg
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     int *d_sq_bond = nullptr;                            // [4][N] device copy of sq_bond (sq_P > 0)

@@ -974,8 +974,8 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.cs_chain_stride = m.lp_chain_stride = 0;
     m.uniform = 0; m.c_uni = 1.0; m.s_uni = 0.0;
     m.sq_bond = (h->sq_L > 0) ? h->d_sq_bond : nullptr;
-    m.grid_G = (h->sq_L >= 4 && h->sq_L <= 16) ? h->sq_L / 2 : 0;
-    m.hc_L = h->hc_L;
+    m.grid_GX = h->sq_LX / 2; m.grid_GY = h->sq_LY / 2;
+    m.hc_LX = h->hc_LX; m.hc_LY = h->hc_LY;
     if (h->kind == ELPH_MODEL_HOLSTEIN && h->nb > 0) {
         bool uni = true;
         for (int64_t n = 1; n < h->nb && uni; ++n) uni = (h->h_c[(size_t)n] == h->h_c[0] && h->h_s[(size_t)n] == h->h_s[0]);

@@ -40,7 +40,12 @@ class SpatialSlabs:
     """Row decomposition of a lattice (site = norbits*(l1 + L1*l2) + orbit, L3 = 1) over P ranks along l2, with the ghost
     rows each rank's fused MᵀM needs.  Pure integer set-up, identical on every rank."""
 
-    def __init__(self, norbits, L1, L2, table, P):
+    def __init__(self, norbits, L1, L2, table, P, ring=False):
+        """ring: close every slab into a RING — the bonds that leave through its last row re-enter at its first row.  The own rows do
+        not see the difference (the ring bond lies beyond the dependency closure that fixed the ghost rows: it only stirs the outermost
+        ghost rows, whose values are discarded anyway), but the slab becomes a periodic rectangle in the reference's colouring, which the
+        library's register-exchange forms recognise (GRID / HGRID, csrc/cg_fast_common.h)."""
+        self.ring = bool(ring)
         self.ns, self.L1, self.L2, self.P = int(norbits), int(L1), int(L2), int(P)
         self.row = self.ns * self.L1                              # sites per row of cells
         self.N = self.row * self.L2
@@ -78,16 +83,24 @@ class SpatialSlabs:
         inc = (li >= 0) & (lj >= 0) & (np.abs(li - lj) <= 1)      # both ends in the slab, no wrap through its open ends
         if (need & ~inc).any():
             raise ValueError(f"rank {q}: a bond the own rows depend on leaves the slab")
-        return dict(R=R, lo=lo, hi=hi, rows=rows, bonds=np.nonzero(inc)[0], r0=r0)
+        ringb = np.zeros_like(inc)
+        if self.ring:
+            # bonds between the slab's last row and the global row above it: their outer end is re-attached to the slab's first row
+            nxt = (rows[-1] + 1) % self.L2
+            ringb = ~inc & (((li == rows.size - 1) & (gj == nxt)) | ((lj == rows.size - 1) & (gi == nxt)))
+        return dict(R=R, lo=lo, hi=hi, rows=rows, bonds=np.nonzero(inc | ringb)[0], r0=r0, ring_next=int((rows[-1] + 1) % self.L2) if self.ring else -1)
 
     def local_table(self, q, table):
         """1-based local neighbour table of rank q's slab, bonds in the global checkerboard order."""
         sl = self.slabs[q]
         t0 = np.asarray(table, dtype=np.int64) - 1
         loc_of = -np.ones(self.L2, dtype=np.int64)
-        loc_of[sl["rows"]] = np.arange(sl["rows"].size)
+        if sl.get("ring_next", -1) >= 0:
+            loc_of[sl["ring_next"]] = 0                          # the ring: the row above the slab's last row IS its first row
+        loc_of[sl["rows"]] = np.arange(sl["rows"].size)           # (a slab that covers the whole lattice: the true row wins — the same one)
         b = t0[sl["bonds"]]
         loc = loc_of[b // self.row] * self.row + (b % self.row)
+        assert (loc >= 0).all()
         return loc + 1
 
     def global_sites(self, q):
@@ -116,7 +129,9 @@ class ShardedSolver:
         self._lib_mod, self.lib = _lib, _lib.load()
         self.comm, self.P, self.rank = comm, comm.world, comm.rank
         self.kind, self.Ltau = int(kind), int(ltau)
-        self.slabs = SpatialSlabs(norbits, L1, L2, table, self.P)
+        # Holstein slabs are closed into rings (exact on the own rows; lets the library run its register-exchange forms on the slab)
+        ring = (int(kind) == 0 and self.P > 1 and os.environ.get("ELPH_SHARD_RING", "1") != "0")
+        self.slabs = SpatialSlabs(norbits, L1, L2, table, self.P, ring=ring)
         self.N, self.row = self.slabs.N, self.slabs.row
         sl = self.sl = self.slabs.slabs[self.rank]
         self.Nloc = sl["rows"].size * self.row

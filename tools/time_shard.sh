@@ -7,10 +7,10 @@ cd "$(dirname "$0")/.."
 for cfg in C D E; do
   for n in 1 2 4; do
     if [ "$n" = 1 ]; then
-      ELPH_FORCE_DEVICE=0 python3 bench.py --mode spatial --config $cfg --steps 2000 --warmup 200
+      ELPH_FORCE_DEVICE=0 python3 bench.py --mode spatial --config $cfg --steps 2000 --warmup 200 --no-cpu
     else
-      ELPH_FORCE_DEVICE=0 ELPH_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) bench.py --mode spatial --config $cfg --gpus $n --steps 2000 --warmup 200 2>/dev/null
+      ELPH_FORCE_DEVICE=0 ELPH_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) bench.py --mode spatial --config $cfg --gpus $n --steps 2000 --warmup 200 --no-cpu 2>/dev/null
     fi
   done
-  ELPH_FORCE_DEVICE=0 ELPH_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29608 bench.py --mode spatial --config $cfg --gpus 8 --ranks-per-proc 2 --steps 2000 --warmup 200 2>/dev/null
+  ELPH_FORCE_DEVICE=0 ELPH_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29608 bench.py --mode spatial --config $cfg --gpus 8 --ranks-per-proc 2 --steps 2000 --warmup 200 --no-cpu 2>/dev/null
 done
