@@ -30,6 +30,12 @@ CONFIGS = {
     "y": ("holstein", 2, 6, lat.HONEYCOMB_BONDS, 2.0, 0.1),         # N = 72,  Ltau = 20   (one cell per lane)
     "z": ("holstein", 2, 10, lat.HONEYCOMB_BONDS, 4.0, 0.1),        # N = 200, Ltau = 40   (two cells per lane)
     "Y": ("holstein", 2, 16, lat.HONEYCOMB_BONDS, 4.0, 0.1),        # N = 512, Ltau = 40   (four cells per lane: 512 sites in one wave)
+    # rectangular periodic lattices (Lspatial = (L1, L2)): the same forms on a rectangular grid of lanes — the shapes a sharded solve's
+    # ring-closed slabs take, here as whole lattices
+    "r": ("holstein", 1, (12, 6), lat.SQUARE_BONDS, 4.0, 0.1),      # N = 72,  Ltau = 40   (6 x 3 lanes)
+    "R": ("holstein", 1, (8, 16), lat.SQUARE_BONDS, 4.0, 0.1),      # N = 128, Ltau = 40   (4 x 8 lanes)
+    "w": ("holstein", 2, (6, 4), lat.HONEYCOMB_BONDS, 2.4, 0.1),    # N = 48,  Ltau = 24   (one cell per lane)
+    "W": ("holstein", 2, (12, 8), lat.HONEYCOMB_BONDS, 2.4, 0.1),   # N = 192, Ltau = 24   (two cells per lane)
     # lattices beyond 512 sites: multi-wavefront workgroups of the generic kernels
     "g": ("holstein", 1, 24, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 576  (2 wavefronts per slice)
     "G": ("holstein", 1, 32, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 1024
@@ -41,8 +47,8 @@ CONFIGS = {
 
 def make_model(tag, tol=1e-5, maxiter=10000, rough=True, device=0, seed=synth.SEED_FIELDS, t_stddev=0.0):
     kind, norb, Ls, bonds, beta, dtau = CONFIGS[tag]
-    L2 = Ls if Ls > 1 else 1
-    lattice = lat.Lattice(norb, Ls, L2, 1)
+    L1, L2 = Ls if isinstance(Ls, tuple) else (Ls, Ls if Ls > 1 else 1)
+    lattice = lat.Lattice(norb, L1, L2, 1)
     if kind == "holstein":
         m = models.HolsteinModel(lattice, beta, dtau, tol=tol, maxiter=maxiter, device=device)
         for (o1, o2, d) in bonds:

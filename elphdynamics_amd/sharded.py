@@ -88,6 +88,24 @@ class SpatialSlabs:
             # bonds between the slab's last row and the global row above it: their outer end is re-attached to the slab's first row
             nxt = (rows[-1] + 1) % self.L2
             ringb = ~inc & (((li == rows.size - 1) & (gj == nxt)) | ((lj == rows.size - 1) & (gi == nxt)))
+            # the ring must not change the colouring (the library recomputes colours as maximal runs of site-disjoint bonds): a ring bond
+            # that meets another bond of its own colour at the first row — a slab whose first and last rows do not sit at a colour
+            # boundary — would be applied as a colour of its own, in the middle of the sweep: then the slab stays open
+            def ncolours(sel):
+                loc_of2 = loc_of.copy()
+                loc_of2[nxt] = 0 if loc_of2[nxt] < 0 else loc_of2[nxt]
+                b = t0[np.nonzero(sel)[0]]
+                loc = loc_of2[b // self.row] * self.row + (b % self.row)
+                seen, n = set(), 1
+                for i, j in loc:
+                    if i in seen or j in seen:
+                        seen, n = set(), n + 1
+                    seen.add(int(i)); seen.add(int(j))
+                return n
+            if ringb.any() and ncolours(inc | ringb) != ncolours(inc):
+                ringb[:] = False
+        if not ringb.any():
+            return dict(R=R, lo=lo, hi=hi, rows=rows, bonds=np.nonzero(inc)[0], r0=r0, ring_next=-1)
         return dict(R=R, lo=lo, hi=hi, rows=rows, bonds=np.nonzero(inc | ringb)[0], r0=r0, ring_next=int((rows[-1] + 1) % self.L2) if self.ring else -1)
 
     def local_table(self, q, table):

@@ -271,7 +271,7 @@ def _oracle_model(orc, m):
                           np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
 
 
-@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y"])
+@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W"])
 def test_matvec_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models, synth
     m = configs.make_model(tag)
@@ -304,7 +304,7 @@ def test_matvec_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y"])
+@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W"])
 def test_cg_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models
     m = configs.make_model(tag, tol=1e-5)
@@ -376,7 +376,7 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y"])
+@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W"])
 def test_kpm_vs_oracle(oracle, tag):
     """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle.  e / E: bond phonons — the
     expansion is built on the tau-means of the per-(tau, bond) hopping tables (update_A!, KPMPreconditioners.jl:355-381)."""
@@ -1398,7 +1398,7 @@ def _wg_info(m, nrhs=1):
     return us.value, T.value, W.value, G.value
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "e", "B", "C", "D", "E", "s", "q", "Q", "S", "y", "z", "Y"])
+@pytest.mark.parametrize("tag", ["b", "d", "e", "B", "C", "D", "E", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W"])
 def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
     """The whole solve in one launch (Krylov vectors in registers / LDS, teams of workgroups meeting through L2) against the
     streaming two-kernel iteration: same algorithm, different summation trees for p.z and r.r — same iteration count up to
@@ -1427,7 +1427,7 @@ def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
         variants += [{"ELPH_WG_T": "4"}, {"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
     if tag in ("D", "E"):   # honeycomb (mirror lanes) / bond phonons (a table set per time slice): the DPP form is the default, the lane-program form the A/B
         variants += [{"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "2"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
-    if tag in ("b", "s", "q", "Q", "S", "d", "y", "z"):   # the GRID / HGRID forms (other even-L square lattices, other honeycomb lattices on a grid of lanes) and their lane-program A/B
+    if tag in ("b", "s", "q", "Q", "S", "d", "y", "z", "r", "R", "w", "W"):   # the GRID / HGRID forms (other even-L square lattices, other honeycomb lattices on a grid of lanes) and their lane-program A/B
         variants += [{"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
         if tag in ("S", "Q"):          # 4 slices per wave: the shape of batches beyond one round of 2 (time axes that are multiples of 4)
             variants += [{"ELPH_WG_T": "4"}]

@@ -182,3 +182,43 @@ def test_hybrid_comm_threads_times_processes(tmp_path):
     for p in procs:
         o, e = p.communicate(timeout=300)
         assert p.returncode == 0, e[-3000:]
+
+
+# ---- ring-closed slabs: the periodic rectangle the register-exchange forms run on is exact on the own rows ---------------------------
+
+@pytest.mark.parametrize("norb,Ls,bonds,worlds", [(1, 16, "sq", (1, 2, 3, 4, 5, 8)), (2, 12, "hc", (1, 2, 4, 5, 8)), (1, 12, "sq", (1, 2, 3))])
+def test_ring_closed_slab_matvec_is_exact_on_the_own_rows(oracle, norb, Ls, bonds, worlds):
+    """SpatialSlabs(ring=True): the bonds that leave a slab's last ghost row re-enter at its first row.  z = Mᵀ(M p) of the ring slab,
+    computed by the oracle's checkerboard mat-vec on the slab's own table (disordered hoppings, so a bond attached to the wrong values
+    shows), equals the whole lattice's z on the slab's OWN rows — the statement the sharded solve on the GRID / HGRID forms rests on —
+    and the ring did close (every site of the slab has its full coordination: a periodic rectangle)."""
+    from elphdynamics_amd import lattice as lat
+    from elphdynamics_amd import sharded
+    bl = lat.SQUARE_BONDS if bonds == "sq" else lat.HONEYCOMB_BONDS
+    la = lat.Lattice(norb, Ls, Ls, 1)
+    raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bl], axis=0)
+    rng = np.random.default_rng(5)
+    cb = lat.initialize_checkerboard(raw, 1.0 + 0.3 * rng.standard_normal(raw.shape[0]), 0.1)
+    N, L = la.nsites, 3
+    E = np.exp(-0.1 * rng.standard_normal((N, L)))                 # (the reference's layout: index = site * Ltau + tau)
+    p = rng.standard_normal((N, L))
+    glob = oracle.make_model(0, N, L, cb["table"], cb["cosht"], cb["sinht"], E.reshape(-1))
+    z = oracle.mulMTM(glob, p.reshape(-1)).reshape(N, L)
+    coord = 4 if bonds == "sq" else 3
+    for world in worlds:
+        S = sharded.SpatialSlabs(norb, Ls, Ls, cb["table"], world, ring=True)
+        for q in range(world):
+            s = S.slabs[q]
+            lt = S.local_table(q, cb["table"])
+            gs = S.global_sites(q)
+            n = gs.size
+            if True:
+                assert s.get("ring_next", -1) >= 0 or s["rows"].size == Ls, (world, q)
+                deg = np.bincount(lt.reshape(-1) - 1, minlength=n)
+                if s["rows"].size > 2:                                                  # (two-row rings double their y-bonds)
+                    assert np.all(deg == coord), (world, q, deg.min(), deg.max())
+            loc = oracle.make_model(0, n, L, lt, cb["cosht"][s["bonds"]], cb["sinht"][s["bonds"]], np.ascontiguousarray(E[gs]).reshape(-1))
+            zl = oracle.mulMTM(loc, np.ascontiguousarray(p[gs]).reshape(-1)).reshape(n, L)
+            own = slice(s["lo"] * S.row, (s["lo"] + s["R"]) * S.row)
+            err = np.max(np.abs(zl[own] - z[gs[own]])) / np.max(np.abs(z))
+            assert err < 1e-14, (world, q, err)
