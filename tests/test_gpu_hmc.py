@@ -83,7 +83,8 @@ def _oracle_update(oracle, om, m, fa, x, v, dt, nt, nb, alpha, rnd, P=None):
 
 
 @pytest.mark.parametrize("tag,nb,nt", [("b", 1, 5), ("b", 3, 4), ("d", 1, 4), ("t", 1, 3), ("B", 1, 3), ("C", 1, 2), ("g", 1, 2),
-                                       ("D", 1, 2)])       # BASELINE config 4: "Holstein HMC honeycomb L=12 Ntau=120"
+                                       ("D", 1, 2),        # BASELINE config 4: "Holstein HMC honeycomb L=12 Ntau=120"
+                                       ("q", 1, 2), ("z", 1, 2), ("r", 1, 2)])     # the GRID / HGRID forms (L = 10 square, 10 x 10 honeycomb cells, 12 x 6 rectangle)
 def test_hmc_update_vs_oracle(oracle, tag, nb, nt):
     from elphdynamics_amd import hmc
     m, fa, om = _pair(oracle, tag, tol=1e-6, lam2=0.02)
@@ -216,7 +217,7 @@ def test_hmc_error_paths():
     e.close()
 
 
-@pytest.mark.parametrize("tag,nch,nb,with_kpm", [("b", 3, 1, False), ("B", 4, 3, True), ("d", 2, 1, True)])
+@pytest.mark.parametrize("tag,nch,nb,with_kpm", [("b", 3, 1, False), ("B", 4, 3, True), ("d", 2, 1, True), ("q", 3, 1, True), ("y", 2, 1, True)])
 def test_hmc_chains_in_lockstep_equal_single_chain_updates(tag, nch, nb, with_kpm):
     """elph_hmc_update_chains: nch Markov chains advanced in lockstep by one handle (all 2*nch pseudofermion solves of an
     evaluation as one batch, one KPM expansion per chain) — every chain ends where the single-chain update ends when it

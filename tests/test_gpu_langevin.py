@@ -40,7 +40,7 @@ def test_langevin_step_matches_dense_golden(cls, key):
     m.close()
 
 
-@pytest.mark.parametrize("tag,scheme,with_kpm", [("b", 0, False), ("d", 1, True), ("B", 2, True), ("C", 2, True), ("D", 2, True)])
+@pytest.mark.parametrize("tag,scheme,with_kpm", [("b", 0, False), ("d", 1, True), ("B", 2, True), ("C", 2, True), ("D", 2, True), ("q", 2, True), ("z", 1, True)])
 def test_langevin_step_vs_oracle(oracle, tag, scheme, with_kpm):
     """Two consecutive steps (the field stays on the device between them) vs the oracle, with the KPM preconditioner set up
     from the same Arnoldi start vectors; also the reference's iteration-count conventions."""
