@@ -40,6 +40,11 @@ CONFIGS = {
     "g": ("holstein", 1, 24, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 576  (2 wavefronts per slice)
     "G": ("holstein", 1, 32, lat.SQUARE_BONDS, 0.8, 0.1),           # N = 1024
     "h": ("holstein", 2, 18, lat.HONEYCOMB_BONDS, 0.6, 0.1),        # N = 648 honeycomb
+    # even-L square lattices beyond 16 x 16 with a PGRID patch (pgrid_dev.h: the KPM recursion in registers); g (24) and G (32) above are two more
+    "k": ("holstein", 1, 20, lat.SQUARE_BONDS, 1.0, 0.1),           # N = 400: 2 x 4 patches on 10 x 5 lanes
+    "j": ("holstein", 1, 28, lat.SQUARE_BONDS, 0.6, 0.1),           # N = 784: 4 x 4 patches on 7 x 7 lanes
+    "i": ("holstein", 1, 18, lat.SQUARE_BONDS, 0.6, 0.1),           # N = 324: 2 x 6 patches on 9 x 3 lanes
+    "K": ("holstein", 1, 24, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 576, Ltau = 40: long recursions (order ~ 50 at the lowest frequency)
     # a long time axis: 1280 slices (beyond the direct-DFT tables: dft_big.hip)
     "l": ("holstein", 1, 4, lat.SQUARE_BONDS, 128.0, 0.1),
 }

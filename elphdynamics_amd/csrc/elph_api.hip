@@ -13,6 +13,7 @@
 
 
 #include "elph_internal.h"
+#include "pgrid_dev.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -179,6 +180,13 @@ static void detect_square(elph_handle_s *h) {
         h->sq_LX = c.first; h->sq_LY = c.second;
         if (c.first == c.second) { h->sq_L = c.first; h->sq_P = (c.first == 8 || c.first == 16) ? c.first / 8 : 0; }
         return;
+    }
+    // a larger square lattice: PX x PY patches per lane (pgrid_dev.h) — the Chebyshev recursion of the preconditioner in registers
+    h->pg_L = h->pg_PX = h->pg_PY = 0;
+    for (int l = 18; l <= 32; l += 2) {
+        int px = 0, py = 0;
+        if ((int64_t)l * l != h->N || !pgrid::pick_patch(l, &px, &py)) continue;
+        if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; }
     }
     h->sq_bond.clear();
 }
@@ -1365,6 +1373,11 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         for (size_t k = 1; k < (size_t)h->nb && uni; ++k) uni = h->h_cbar[k] == h->h_cbar[0] && h->h_sbar[k] == h->h_sbar[0];
         if (uni != h->hc_uniform) drop_graphs(h);
         h->hc_uniform = uni;
+    }
+    if (hop_fresh && h->pg_L > 0) {
+        bool uni = h->nb > 0 && !h->kpm_hop_per_chain;
+        for (size_t k = 1; k < (size_t)h->nb && uni; ++k) uni = h->h_cbar[k] == h->h_cbar[0] && h->h_sbar[k] == h->h_sbar[0];
+        h->pg_uniform = uni;
     }
     h->kpm_hop_uploaded = true;
     const int was_active = h->kpm_active;

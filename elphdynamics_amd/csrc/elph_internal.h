@@ -226,6 +226,8 @@ struct elph_handle_s {
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     bool hc_uniform = false;               // ... and its tau-averaged hopping tables are one (cosh, sinh) for every bond (the register-exchange Chebyshev recursion)
+    int pg_L = 0, pg_PX = 0, pg_PY = 0;    // even-L square lattice beyond 16 x 16 in the reference's colouring (detect_square): PX x PY sites per lane (pgrid_dev.h)
+    bool pg_uniform = false;               // ... and one (cbar, sbar) for every bond
     int hc_L = 0;                          // honeycomb lattice of hc_L x hc_L cells in the reference's colouring (detect_honeycomb); hc12: hc_L == 12
     int hc_LX = 0, hc_LY = 0;              // periodic honeycomb lattice of LX x LY cells recognised: hc_L = LX when LX == LY
     bool hc12 = false;                     // honeycomb lattice of 12 x 12 cells in the reference's colouring (detect_honeycomb12): the DPP form of k_cg_wg
@@ -394,6 +396,10 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs = 1);
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream has drained
+bool elph_pg_cheb_usable(const elph_handle_s *h);                       // pgrid.hip
+int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
+bool elph_pg_ap_usable(const elph_handle_s *h);
+int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity);
 int elph_wg_cooldown_step(elph_handle_s *h);                // one solve of the cool-down after a time-out (both resident kernels call it)
 long long elph_shard_timeout_ms();                          // wait bound of the sharded solves (shard.hip)
 // ---- workgroup-resident KPM-preconditioned CG (pcg_wg.hip): the whole preconditioned solve of 1..8 right-hand sides in one launch

@@ -1195,6 +1195,11 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     bool rz_done = false;     // r.z partials already produced in frequency space by the Chebyshev kernel
     if (!(parts & 2)) {
         rz_done = h->fast && reg_cheb && cg_mode;      // (timing the inverse transform alone: the form that follows the register-exchange kernel)
+    } else if (elph_pg_cheb_usable(h)) {
+        // an even-L square lattice beyond 16 x 16 (L = 18 ... 32), uniform hopping: the recursion in registers, a patch of sites per lane
+        // (whether the lattice still fits the lane-program family — 18 x 18, 20 x 20 — or only the generic kernels)
+        int rcp = elph_pg_kpm_cheb(h, nrhs, st);
+        if (rcp) return rcp;
     } else if (h->fast) {
         static const bool freq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
         const bool want = cg_mode && freq_rz && 2 * Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N;
@@ -1297,8 +1302,10 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
         const int N = (int)h->N, L = (int)h->L;
         dim3 grid((unsigned)L, (unsigned)nrhs, 1);
         const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
+        const bool pg = elph_pg_ap_usable(h) && m.uniform && B.npap == L;      // a large even-L square lattice: the patch-layout kernel (pgrid.hip)
+        if (pg) { rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1)); if (rc) return rc; }
         DISPATCH_NPL(gen_npl(h), {
-            hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
+            if (!pg) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
             hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3((unsigned)gen_bs(h)), 0, h->stream, B, N, L, (int)((h->ap_count + 1) & 1));
         });
         h->ap_count++;
@@ -1324,6 +1331,11 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     const int N = (int)h->N, L = (int)h->L;
     dim3 grid((unsigned)L, (unsigned)nrhs, 1);
     const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
+    if (which == 0 && elph_pg_ap_usable(h) && m.uniform && B.npap == L) {
+        int rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1));
+        h->ap_count++;
+        return rc;
+    }
     DISPATCH_NPL(gen_npl(h), {
         if (which == 0) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
         else hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3((unsigned)gen_bs(h)), 0, h->stream, B, N, L, (int)(h->ap_count & 1));

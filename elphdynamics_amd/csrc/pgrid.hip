@@ -1,0 +1,317 @@
+// pgrid.hip — register-exchange kernels for even-L square lattices beyond 16 x 16 (L = 18, 20, 24, 28, 32; pgrid_dev.h: a PX x PY
+// patch of sites per lane, the whole time slice in ONE wavefront), uniform hopping, site phonons (Holstein).
+//
+// k_kpm_cheb_pg: the per-frequency Chebyshev recursion of the KPM preconditioner (KPMPreconditioners.jl:426-481 ldiv!, :606-693 the
+// series) — what the generic kernel (kernels.hip: k_kpm_cheb, a workgroup of up to 1024 threads per (right-hand side, frequency), one
+// LDS round trip and two barriers per checkerboard colour) spends 180-216 us on for ONE right-hand side at L = 24 / 32.  Here a block
+// is two wavefronts — the real and the imaginary parts of nu_w — and a step of the recursion is the patch sweep (4 colours, no
+// barrier) plus four instructions per site; the two waves meet through LDS only where the complex coefficients mix them (twice per
+// frequency).
+#include <algorithm>
+#include <cstdlib>
+
+#include "elph_internal.h"
+#include "pgrid_dev.h"
+
+#define WAVE ELPH_WAVE
+
+namespace {
+
+// sum_n c_n T_n(A') v  for one real vector in the patch layout: Pacc = sum Re(c_n) u_n, Qacc = sum Im(c_n) u_n with
+//   u_1 = v, u_2 = A' u_1 (shifted and scaled: A' = a A + b), u_{n+1} = 2 A' u_n - u_{n-1}
+//   A = CB diag(Ebar)  (TRANSPOSED: diag(Ebar) CB^T),  e1 = a c^4 Ebar (the scale of A' and the c^4 of the factored colours ride on it)
+// The arithmetic of kpm_series (kpm_sq_dev.h) with the registers cut to five vectors + one temporary: the doubled diagonal 2 e1 is made
+// on the fly (an exact doubling: the same roundings), and the history term is built IN PLACE in the vector the new one overwrites.
+template <int NS, bool TRANSPOSED, class APPLY>
+__device__ __forceinline__ void series_lean(double (&Pacc)[NS], double (&Qacc)[NS], const double (&vin)[NS], const double (&e1)[NS],
+                                            const double2 *c, int order, double b, APPLY &&apply) {
+    double ua[NS], ub[NS];
+    {
+        const double2 c0 = c[0];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { Pacc[q] = c0.x * vin[q]; Qacc[q] = c0.y * vin[q]; ua[q] = vin[q]; ub[q] = 0.0; }
+    }
+    // one step: un = the latest vector, um = the one before (overwritten by the new one); tw = 1 for the first step (u_2 = A' u_1), 2 after
+    auto step = [&](double (&un)[NS], double (&um)[NS], double tw, double bb, bool first, const double2 cprev, bool have_prev) {
+        double w[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            w[q] = TRANSPOSED ? un[q] : (tw * e1[q]) * un[q];
+            um[q] = first ? bb * un[q] : bb * un[q] + um[q];              // the history term b' u_n + u_{n-1}  (b' = b or 2 b)
+            if (have_prev) { Pacc[q] += cprev.x * un[q]; Qacc[q] += cprev.y * un[q]; }      // the sums of the vector made one step ago
+        }
+        apply(w);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) um[q] = TRANSPOSED ? (tw * e1[q]) * w[q] - um[q] : w[q] - um[q];
+    };
+    const double b2 = 2.0 * b;
+    if (order >= 2) step(ua, ub, 1.0, b, true, make_double2(0.0, 0.0), false);          // u_2 in ub (its coefficient: c[1])
+    int n = 3;
+    for (; n + 1 <= order; n += 2) {
+        step(ub, ua, 2.0, b2, false, c[n - 2], true);          // u_n in ua; the sums of u_{n-1} (coefficient c[n-2]) ride along
+        step(ua, ub, 2.0, b2, false, c[n - 1], true);          // u_{n+1} in ub
+    }
+    if (n <= order) {
+        step(ub, ua, 2.0, b2, false, c[n - 2], true);          // u_order in ua
+        const double2 cl = c[order - 1];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { Pacc[q] += cl.x * ua[q]; Qacc[q] += cl.y * ua[q]; }
+    } else if (order >= 2) {
+        const double2 cl = c[order - 1];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { Pacc[q] += cl.x * ub[q]; Qacc[q] += cl.y * ub[q]; }
+    }
+}
+
+template <int PX, int PY>
+__global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ nu, KpmDev K, int N, int Ls, int Lo2, const CgState *state) {
+    constexpr int NS = PX * PY;
+    __shared__ double xch[2][NS * WAVE];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int rhs = blockIdx.x;               // x = right-hand side, y = frequency in longest-first order
+    if (state && state[2 * rhs].done) return;
+    const KpmChainView V = kpm_chain_view(K, rhs, N);
+    const int w = V.wsched[blockIdx.y];
+    const int order = V.order[w];
+    const double2 *c = K.coeff + V.coff[w];
+    if (order == 1) {
+        // A series of order 1 is its leading coefficient: z_w = c0 (conj(c0) r_w) — no checkerboard, no patch layout.  That is most
+        // frequencies (order_w ~ 1 / phi_w: 45 of 80 at L_tau = 160), and a block of its own for each would hold a wave slot for a few
+        // microseconds of launch and dependent loads to do a microsecond of arithmetic: the FIRST ORD1_BLOCKS order-1 positions of the
+        // (longest-first) schedule share all of them, the rest leave at once.  (products first, then the sums: the roundings of the
+        // general path)
+        constexpr int ORD1_BLOCKS = 4;
+        const int y = (int)blockIdx.y;
+        if (y >= ORD1_BLOCKS && V.order[V.wsched[y - ORD1_BLOCKS]] == 1) return;
+        for (int yy = y; yy < Lo2; yy += ORD1_BLOCKS) {
+            const int ww = V.wsched[yy];
+            const double2 c0 = K.coeff[V.coff[ww]];
+            double2 *uc = nu + ((size_t)rhs * Lo2 + ww) * N;
+            for (int i = threadIdx.x; i < N; i += 2 * WAVE) {
+                const double2 v = uc[i];
+                const double mr = __dadd_rn(__dmul_rn(c0.x, v.x), __dmul_rn(c0.y, v.y)), mi = __dsub_rn(__dmul_rn(c0.x, v.y), __dmul_rn(c0.y, v.x));
+                uc[i] = make_double2(__dsub_rn(__dmul_rn(c0.x, mr), __dmul_rn(c0.y, mi)), __dadd_rn(__dmul_rn(c0.x, mi), __dmul_rn(c0.y, mr)));
+            }
+        }
+        return;
+    }
+    double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
+    const bool act = lane < (Ls / PX) * (Ls / PY);
+    const pgrid::Ctx X = pgrid::ctx<PX, PY>(lane, Ls, V.cbar[0], V.sbar[0]);
+    const double a = V.a * X.k4, b = V.b;
+    int site[NS];
+    double e1[NS], vin[NS], Pa[NS], Qa[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        site[q] = pgrid::site<PX, PY>(lane, q, Ls);
+        e1[q] = a * V.Ebar[site[q]];
+        vin[q] = u[2 * site[q] + wv];
+    }
+    // M^-T[w,w]: conjugated coefficients, transposed A   (KPMPreconditioners.jl:621-648)
+    series_lean<NS, true>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { pgrid::sweep<PX, PY, true>(v, X); });
+#pragma unroll
+    for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const double Qo = xch[wv ^ 1][q * WAVE + lane];
+        vin[q] = (wv == 0) ? Pa[q] + Qo : Pa[q] - Qo;          // (vin now holds the middle vector: the input of the second series)
+    }
+    __syncthreads();
+    // M^-1[w,w]   (:650-677)
+    series_lean<NS, false>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { pgrid::sweep<PX, PY, false>(v, X); });
+#pragma unroll
+    for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const double Qo = xch[wv ^ 1][q * WAVE + lane];
+        const double res = (wv == 0) ? Pa[q] - Qo : Pa[q] + Qo;
+        if (act) u[2 * site[q] + wv] = res;
+    }
+}
+
+__device__ __forceinline__ double pg_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+// every wave reduces ALL partials itself: same loads, same tree => the same bits in every wave (kernels.hip: reduce_partials)
+__device__ __forceinline__ double pg_reduce_partials(const double *p, int n, int lane) {
+    double a = 0.0;
+    for (int i = lane; i < n; i += WAVE) a += p[i];
+    return pg_wave_sum(a);
+}
+
+// The first kernel of a CG iteration (IterativeSolvers.jl:153-234 / :236-315; the contract of kernels.hip: k_cg_ap — stop test of the
+// previous iteration, beta, p = (z | r) + beta p, z = M^T (M p), the partial sums of p.z, the other copy of the state) for a large
+// square lattice: ONE wavefront takes Tmax consecutive time slices of one right-hand side and walks through them with p(t-1), w(t-1)
+// in registers — every slice of z|r, p_old and exp(-dtau V) is read once (+ two halo slices per chunk), p_new and z are written once;
+// the two checkerboard sweeps per slice (M: forward on E(t) p(t-1); M^T: reverse on w(t), then E(t)) are patch sweeps in registers.
+// The generic kernel it replaces takes one slice per workgroup: three slices of z|r and p_old read per slice written, and
+// every colour of its sweeps is an LDS round trip between two barriers (283 us per iteration of 72 right-hand sides at L = 32, where
+// the bytes that must move take ~100).
+//   w(t)   = p(t) - sg(t) c^4 S(E(t) p(t-1))            sg(t) = -1 at t = 0 (antiperiodic), S / S^T: the sweep without its c^4
+//   z(t-1) = w(t-1) - sg(t) c^4 E(t) S^T(w(t))
+template <int PX, int PY>
+__global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int parity, int Ls, int Tmax) {
+    constexpr int NS = PX * PY;
+    const int N = m.N, L = m.L, lane = threadIdx.x;
+    const int nch = (L + Tmax - 1) / Tmax;
+    const int rhs = blockIdx.x / nch, ch = blockIdx.x - rhs * nch;
+    const int t0 = ch * Tmax, T = (L - t0 < Tmax) ? L - t0 : Tmax;
+    const size_t ndim = (size_t)N * L;
+    CgState *st2 = B.state + 2 * rhs;
+    const CgState S = st2[parity];
+    CgState *Sout = st2 + (parity ^ 1);
+    if (S.done) {
+        if (ch == 0 && lane == 0) *Sout = S;
+        return;
+    }
+    const CgParams P = B.params;
+    const long long seq = S.seq;
+    const bool first = (seq == 0);
+    double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
+    if (!first) {
+        // stop test of iteration `seq` (IterativeSolvers.jl:286-295 / :211-219)
+        const double rr = pg_reduce_partials(B.rr + (size_t)rhs * L, L, lane);
+        eps = sqrt(rr) / S.normb;
+        const double qq = 2.0 * (double)seq / log(2.0 * S.eps0 / eps);
+        const double val = qq * qq;
+        kmin = (val > kmin) ? val : kmin;
+        int done = 0;
+        if (eps < P.tol) done = 1;
+        else if (kmin > P.kmax) done = 2;
+        else if (seq >= P.maxiter) done = 3;
+        if (ch == 0 && lane == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + seq] = eps;
+        if (done) {
+            if (ch == 0 && lane == 0) {
+                CgState o = S;
+                o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = done;
+                *Sout = o;
+            }
+            return;
+        }
+        const double rho_new = P.use_prec ? pg_reduce_partials(B.rz + (size_t)rhs * B.nrz, B.nrz, lane) : rr;
+        beta = rho_new / S.rho;            // :222-223 / :303-304
+        rho = rho_new;
+    }
+    const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
+    const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
+    double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
+    double *z = B.z + (size_t)rhs * ndim;
+    const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
+    const bool act = lane < (Ls / PX) * (Ls / PY);
+    const pgrid::Ctx X = pgrid::ctx<PX, PY>(lane, Ls, m.c_uni, m.s_uni);
+    int site[NS];
+    bool dot[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { site[q] = pgrid::site<PX, PY>(lane, q, Ls); dot[q] = act && site[q] >= B.dot_lo && site[q] < B.dot_hi; }
+    auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
+    auto load_p = [&](int t, double (&pv)[NS]) {          // p(t) = (z | r)(t) + beta p_old(t)   (:229-230 / :309-310); the first iteration: p0 as the init kernel stored it
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const size_t i = (size_t)t * N + site[q];
+            pv[q] = first ? pold[i] : src[i] + beta * pold[i];
+        }
+    };
+    double pprev[NS], wprev[NS], pcur[NS], wcur[NS], Ecur[NS];
+    load_p(wrap(t0 - 1), pprev);
+    double acc = 0.0;
+#pragma unroll 1
+    for (int j = 0; j <= T; ++j) {
+        const int t = wrap(t0 + j);
+        const double sg = (t == 0) ? -X.k4 : X.k4;         // the sign of the antiperiodic boundary with the c^4 of the factored colours
+        load_p(t, pcur);
+        const double *Et = Ech + (size_t)t * m.E_tau_stride;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { Ecur[q] = Et[site[q]]; wcur[q] = Ecur[q] * pprev[q]; }
+        if (j < T && act) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) pnew[(size_t)t * N + site[q]] = pcur[q];
+        }
+        pgrid::sweep<PX, PY, false>(wcur, X);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) wcur[q] = pcur[q] - sg * wcur[q];
+        if (j > 0) {
+            double g[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) g[q] = wcur[q];
+            pgrid::sweep<PX, PY, true>(g, X);
+            const int tz = wrap(t0 + j - 1);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const double zz = wprev[q] - sg * Ecur[q] * g[q];
+                if (act) z[(size_t)tz * N + site[q]] = zz;
+                if (dot[q]) acc += pprev[q] * zz;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { pprev[q] = pcur[q]; wprev[q] = wcur[q]; }
+    }
+    acc = pg_wave_sum(acc);
+    if (lane == 0) {
+        // one partial sum per chunk, in the slot of its first slice; the slots of its other slices are zero (npap = L: the generic family's layout)
+        double *pap = B.pap + (size_t)rhs * B.npap;
+        pap[t0] = acc;
+        for (int j = 1; j < T; ++j) pap[t0 + j] = 0.0;
+        if (ch == 0) {
+            CgState o = S;
+            o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = seq + 1; o.iters = seq; o.done = 0;
+            *Sout = o;
+        }
+    }
+}
+
+int pg_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { elph_set_error("launch %s failed: %s", what, hipGetErrorString(e)); return ELPH_E_HIP; }
+    return ELPH_OK;
+}
+
+}   // namespace
+
+// Can the per-frequency recursion of this handle run in the patch layout?  (ELPH_NO_PG=1: the generic kernel, the A/B — read per call)
+bool elph_pg_cheb_usable(const elph_handle_s *h) {
+    const char *e = getenv("ELPH_NO_PG");
+    return h->pg_L > 0 && h->pg_uniform && h->kind == ELPH_MODEL_HOLSTEIN && !(e && e[0] == '1');
+}
+
+// nu (d_nu: [nrhs][Lo2][N] complex) <- P^-1 in frequency space, every (right-hand side, frequency) a block of two wavefronts
+int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
+    KpmDev K = elph_kpm_dev(h);
+    const int Lo2 = (int)((h->L + 1) / 2), N = (int)h->N, Ls = h->pg_L;
+    const dim3 grid((unsigned)nrhs, (unsigned)Lo2), block(2 * WAVE);
+    if (h->pg_PX == 4 && h->pg_PY == 4) hipLaunchKernelGGL((k_kpm_cheb_pg<4, 4>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st);
+    else if (h->pg_PX == 2 && h->pg_PY == 6) hipLaunchKernelGGL((k_kpm_cheb_pg<2, 6>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st);
+    else if (h->pg_PX == 2 && h->pg_PY == 4) hipLaunchKernelGGL((k_kpm_cheb_pg<2, 4>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st);
+    else { elph_set_error("k_kpm_cheb_pg: no instantiation for %d x %d patches", h->pg_PX, h->pg_PY); return ELPH_E_UNSUPPORTED; }
+    return pg_check("k_kpm_cheb_pg");
+}
+
+// the mat-vec kernel of the CG iteration in the patch layout (generic family only: the lane-program family has its own chunked kernel)
+bool elph_pg_ap_usable(const elph_handle_s *h) {
+    const char *e = getenv("ELPH_NO_PG");
+    return h->pg_L > 0 && !h->fast && h->kind == ELPH_MODEL_HOLSTEIN && !(e && e[0] == '1');
+}
+
+int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity) {
+    if (!m.uniform) return ELPH_E_UNSUPPORTED;
+    if (B.npap != (int)h->L) { elph_set_error("k_cg_ap_pg: one p.z slot per time slice expected"); return ELPH_E_UNSUPPORTED; }
+    // slices per wave: the longest chunk that still leaves a wave per SIMD (1024); never beyond 20 (what a chunk gains in halo reads is
+    // 2 / T); a small batch: one slice per wave, the shape of the generic kernel
+    const int L = (int)h->L;
+    static const int forceT = []() { const char *e = getenv("ELPH_PG_T"); return e ? atoi(e) : 0; }();
+    int T = 1;
+    for (int c : {20, 16, 10, 8, 5, 4, 2}) { if ((long long)nrhs * ((L + c - 1) / c) >= 1024) { T = c; break; } }
+    if (forceT > 0) T = forceT;
+    T = std::max(1, std::min(T, L));
+    const int nch = (L + T - 1) / T;
+    const dim3 grid((unsigned)(nrhs * nch)), block(WAVE);
+    const int Ls = h->pg_L;
+    if (h->pg_PX == 4 && h->pg_PY == 4) hipLaunchKernelGGL((k_cg_ap_pg<4, 4>), grid, block, 0, h->stream, B, m, parity, Ls, T);
+    else if (h->pg_PX == 2 && h->pg_PY == 6) hipLaunchKernelGGL((k_cg_ap_pg<2, 6>), grid, block, 0, h->stream, B, m, parity, Ls, T);
+    else if (h->pg_PX == 2 && h->pg_PY == 4) hipLaunchKernelGGL((k_cg_ap_pg<2, 4>), grid, block, 0, h->stream, B, m, parity, Ls, T);
+    else { elph_set_error("k_cg_ap_pg: no instantiation for %d x %d patches", h->pg_PX, h->pg_PY); return ELPH_E_UNSUPPORTED; }
+    return pg_check("k_cg_ap_pg");
+}

@@ -1,0 +1,112 @@
+// pgrid_dev.h — the PGRID layout: an even-L square lattice LARGER than 16 x 16 in the registers of ONE wavefront.
+//
+// The GRID layout (cg_fast_common.h) gives a lane a 2 x 2 patch: 64 lanes carry at most 16 x 16 sites.  The lattices people actually
+// simulate are larger (L = 20, 24, 32: 400 ... 1024 sites per time slice), and for them the library had only the generic kernels — a
+// workgroup of up to 1024 threads per slice, every checkerboard colour an LDS round trip and a barrier.  Here a lane holds a PX x PY
+// patch (PX, PY even): lane (X, Y) = (l % GX, l / GX), GX = L / PX, GY = L / PY, register q = cx + PX cy is the site
+// (PX X + cx) + L (PY Y + cy).  The reference's colouring of the square lattice (Checkerboard.jl:57-141 through lattice.py; recognised
+// by detect_square, elph_api.hip) is [x-even | x-odd | y-even | y-odd] bonds: the even colours and the inner pairs of the odd colours
+// pair registers of one lane; only the patch EDGES cross — PY values per direction for x-odd, PX for y-odd, by ds_bpermute, all issued
+// before the first is used.  A 4 x 4 patch does 16 fma per colour and moves 4 + 4 values in two of the four colours: a quarter of the
+// exchange per fma of the 2 x 2 patch, and no barrier anywhere.
+//   L = 32, 28: 4 x 4 patches (64 / 49 lanes, 16 registers per vector)      L = 24, 18: 2 x 6 (48 / 27 lanes, 12 registers)
+//   L = 20:     2 x 4 (50 lanes, 8 registers)
+// Uniform hopping only (one (cosh, sinh) for every bond — the decks): a colour is c (I + th P) with th = sinh / cosh, the caller
+// scales by c^4 once.
+#pragma once
+#include "elph_internal.h"
+
+namespace pgrid {
+
+constexpr int WAVE_ = ELPH_WAVE;
+
+struct Ctx {
+    double th, k4;           // tanh of the bond angle; c^4
+    int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1 (cyclic); idle lanes: themselves
+};
+
+template <int PX, int PY>
+__host__ __device__ __forceinline__ int site(int lane, int q, int L) {
+    const int GX = L / PX, GY = L / PY;
+    const int l = (lane < GX * GY) ? lane : 0, X = l % GX, Y = l / GX;
+    const int cx = q % PX, cy = q / PX;
+    return (PX * X + cx) + L * (PY * Y + cy);
+}
+
+template <int PX, int PY>
+__device__ __forceinline__ Ctx ctx(int lane, int L, double c, double s) {
+    const int GX = L / PX, GY = L / PY;
+    Ctx X;
+    X.th = s / c; X.k4 = (c * c) * (c * c);
+    if (lane < GX * GY) {
+        const int x = lane % GX, y = lane / GX;
+        X.xu = (x + 1) % GX + GX * y; X.xd = (x + GX - 1) % GX + GX * y;
+        X.yu = x + GX * ((y + 1) % GY); X.yd = x + GX * ((y + GY - 1) % GY);
+    } else {
+        X.xu = X.xd = X.yu = X.yd = lane;
+    }
+    return X;
+}
+
+// one colour of the checkerboard on the PX x PY values of a lane: v <- (I + th P_colour) v
+template <int PX, int PY, int COL>
+__device__ __forceinline__ void colour(double (&v)[PX * PY], const Ctx &X) {
+    constexpr bool ALONG_X = (COL < 2), ODD = (COL & 1);
+    constexpr int PA = ALONG_X ? PX : PY;        // patch extent along the colour's direction
+    constexpr int PB = ALONG_X ? PY : PX;        // ... and across it
+    constexpr int SA = ALONG_X ? 1 : PX;         // register strides along / across
+    constexpr int SB = ALONG_X ? PX : 1;
+    if constexpr (ODD) {
+        // the edge pairs cross to the neighbouring patches: my last column pairs with the first column of the patch above, my first
+        // column with the last column of the patch below
+        const int up = ALONG_X ? X.xu : X.yu, dn = ALONG_X ? X.xd : X.yd;
+        double fu[PB], fd[PB];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            fu[b] = __shfl(v[0 * SA + b * SB], up, WAVE_);
+            fd[b] = __shfl(v[(PA - 1) * SA + b * SB], dn, WAVE_);
+        }
+        // the inner pairs (1,2), (3,4), ... while the crossings fly
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int a = 1; a + 1 < PA; a += 2) {
+                const int i = a * SA + b * SB, j = i + SA;
+                const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
+                v[i] = ni; v[j] = nj;
+            }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            v[(PA - 1) * SA + b * SB] += X.th * fu[b];
+            v[0 * SA + b * SB] += X.th * fd[b];
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int a = 0; a + 1 < PA; a += 2) {
+                const int i = a * SA + b * SB, j = i + SA;
+                const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
+                v[i] = ni; v[j] = nj;
+            }
+    }
+}
+
+// the whole checkerboard (REVERSE: its transpose — the colours in reverse order; every colour is symmetric), WITHOUT the factor c^4
+template <int PX, int PY, bool REVERSE>
+__device__ __forceinline__ void sweep(double (&v)[PX * PY], const Ctx &X) {
+    if constexpr (!REVERSE) { colour<PX, PY, 0>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 3>(v, X); }
+    else                    { colour<PX, PY, 3>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 0>(v, X); }
+}
+
+// The patch shape for an L x L lattice (0: none — the lattice keeps the generic kernels).
+inline bool pick_patch(int L, int *PX, int *PY) {
+    switch (L) {
+        case 32: case 28: *PX = 4; *PY = 4; return true;
+        case 24: case 18: *PX = 2; *PY = 6; return true;
+        case 20: *PX = 2; *PY = 4; return true;
+        default: return false;
+    }
+}
+
+}   // namespace pgrid
