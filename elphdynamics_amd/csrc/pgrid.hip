@@ -208,27 +208,52 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
 #pragma unroll
     for (int q = 0; q < NS; ++q) { site[q] = pgrid::site<PX, PY>(lane, q, Ls); dot[q] = act && site[q] >= B.dot_lo && site[q] < B.dot_hi; }
     auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
-    auto load_p = [&](int t, double (&pv)[NS]) {          // p(t) = (z | r)(t) + beta p_old(t)   (:229-230 / :309-310); the first iteration: p0 as the init kernel stored it
+    // p(t) = (z | r)(t) + beta p_old(t)   (:229-230 / :309-310); the first iteration: p0 as the init kernel stored it
+    auto load_raw = [&](int t, double (&sv)[NS], double (&qv)[NS]) {
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const size_t i = (size_t)t * N + site[q];
-            pv[q] = first ? pold[i] : src[i] + beta * pold[i];
+            qv[q] = pold[i];
+            sv[q] = first ? 0.0 : src[i];
         }
     };
-    double pprev[NS], wprev[NS], pcur[NS], wcur[NS], Ecur[NS];
-    load_p(wrap(t0 - 1), pprev);
+    auto load_e = [&](int t, double (&ev)[NS]) {
+        const double *Et = Ech + (size_t)t * m.E_tau_stride;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) ev[q] = Et[site[q]];
+    };
+    double pprev[NS], wprev[NS];
+    {
+        double s0[NS], q0[NS];
+        load_raw(wrap(t0 - 1), s0, q0);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) pprev[q] = first ? q0[q] : s0[q] + beta * q0[q];
+    }
+    // the loads of slice t + 1 are issued before the sweeps of slice t: a wave is alone or nearly alone on its SIMD (a slice is 2 x NS
+    // registers per vector), nothing else would hide the round trip
+    double Sn[NS], Qn[NS], En[NS];
+    load_raw(t0, Sn, Qn);
+    load_e(t0, En);
     double acc = 0.0;
 #pragma unroll 1
     for (int j = 0; j <= T; ++j) {
         const int t = wrap(t0 + j);
         const double sg = (t == 0) ? -X.k4 : X.k4;         // the sign of the antiperiodic boundary with the c^4 of the factored colours
-        load_p(t, pcur);
-        const double *Et = Ech + (size_t)t * m.E_tau_stride;
+        double pcur[NS], wcur[NS], Ecur[NS];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) { Ecur[q] = Et[site[q]]; wcur[q] = Ecur[q] * pprev[q]; }
-        if (j < T && act) {
+        for (int q = 0; q < NS; ++q) {
+            pcur[q] = first ? Qn[q] : Sn[q] + beta * Qn[q];
+            Ecur[q] = En[q];
+            wcur[q] = Ecur[q] * pprev[q];
+        }
+        if (j < T) {
+            const int tn = wrap(t0 + j + 1);
+            load_raw(tn, Sn, Qn);
+            load_e(tn, En);
+            if (act) {
 #pragma unroll
-            for (int q = 0; q < NS; ++q) pnew[(size_t)t * N + site[q]] = pcur[q];
+                for (int q = 0; q < NS; ++q) pnew[(size_t)t * N + site[q]] = pcur[q];
+            }
         }
         pgrid::sweep<PX, PY, false>(wcur, X);
 #pragma unroll
@@ -298,12 +323,15 @@ bool elph_pg_ap_usable(const elph_handle_s *h) {
 int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity) {
     if (!m.uniform) return ELPH_E_UNSUPPORTED;
     if (B.npap != (int)h->L) { elph_set_error("k_cg_ap_pg: one p.z slot per time slice expected"); return ELPH_E_UNSUPPORTED; }
-    // slices per wave: the longest chunk that still leaves a wave per SIMD (1024); never beyond 20 (what a chunk gains in halo reads is
-    // 2 / T); a small batch: one slice per wave, the shape of the generic kernel
+    // slices per wave: the SHORTEST chunk whose waves still fit the chip in one round — 1024 SIMDs x the waves a SIMD holds of this
+    // instantiation (one for 12 or 16 sites per lane: 256 + ~100 registers with the prefetched slice; two for 8) — a second, partly
+    // filled round costs more than the two halo slices per chunk (measured at L = 32, 72 right-hand sides: 16 slices per wave = 720
+    // waves 98 us, 10 = 1152 waves 140 us; profiles/r04/pgrid_large_square_lattices.log); beyond one round of 40-slice chunks: 20
     const int L = (int)h->L;
     static const int forceT = []() { const char *e = getenv("ELPH_PG_T"); return e ? atoi(e) : 0; }();
-    int T = 1;
-    for (int c : {20, 16, 10, 8, 5, 4, 2}) { if ((long long)nrhs * ((L + c - 1) / c) >= 1024) { T = c; break; } }
+    const long long slots = 1024LL * ((h->pg_PX * h->pg_PY <= 8) ? 2 : 1);
+    int T = 20;
+    for (int c : {1, 2, 4, 5, 8, 10, 16, 20, 32, 40}) { if ((long long)nrhs * ((L + c - 1) / c) <= slots) { T = c; break; } }
     if (forceT > 0) T = forceT;
     T = std::max(1, std::min(T, L));
     const int nch = (L + T - 1) / T;
