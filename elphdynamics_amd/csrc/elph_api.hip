@@ -182,11 +182,11 @@ static void detect_square(elph_handle_s *h) {
         return;
     }
     // a larger square lattice: PX x PY patches per lane (pgrid_dev.h) — the Chebyshev recursion of the preconditioner in registers
-    h->pg_L = h->pg_PX = h->pg_PY = 0;
+    h->pg_L = h->pg_PX = h->pg_PY = h->pg_kind = 0;
     for (int l = 18; l <= 32; l += 2) {
         int px = 0, py = 0;
         if ((int64_t)l * l != h->N || !pgrid::pick_patch(l, &px, &py)) continue;
-        if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; }
+        if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 1; }
     }
     h->sq_bond.clear();
 }
@@ -228,7 +228,11 @@ static void detect_honeycomb12(elph_handle_s *h) {
     for (auto &c : cand) {
         if (!match_honeycomb(h, c.first, c.second)) continue;
         h->hc_LX = c.first; h->hc_LY = c.second;
-        if (c.first == c.second) { h->hc_L = c.first; h->hc12 = (c.first == 12); }
+        if (c.first == c.second) {
+            h->hc_L = c.first; h->hc12 = (c.first == 12);
+            int px = 0, py = 0;
+            if (c.first > 16 && pgrid::pick_hpatch(c.first, &px, &py)) { h->pg_L = c.first; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 2; }     // (pgrid.hip: PX x PY cells per lane)
+        }
         return;
     }
 }

@@ -17,6 +17,9 @@
 
 namespace {
 
+using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>;
+using HC32 = pgrid::Hc<3, 2>; using HC42 = pgrid::Hc<4, 2>; using HC33 = pgrid::Hc<3, 3>;
+
 // sum_n c_n T_n(A') v  for one real vector in the patch layout: Pacc = sum Re(c_n) u_n, Qacc = sum Im(c_n) u_n with
 //   u_1 = v, u_2 = A' u_1 (shifted and scaled: A' = a A + b), u_{n+1} = 2 A' u_n - u_{n-1}
 //   A = CB diag(Ebar)  (TRANSPOSED: diag(Ebar) CB^T),  e1 = a c^4 Ebar (the scale of A' and the c^4 of the factored colours ride on it)
@@ -63,9 +66,9 @@ __device__ __forceinline__ void series_lean(double (&Pacc)[NS], double (&Qacc)[N
     }
 }
 
-template <int PX, int PY>
+template <class LAT>
 __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ nu, KpmDev K, int N, int Ls, int Lo2, const CgState *state) {
-    constexpr int NS = PX * PY;
+    constexpr int NS = LAT::NS;
     __shared__ double xch[2][NS * WAVE];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     const int rhs = blockIdx.x;               // x = right-hand side, y = frequency in longest-first order
@@ -96,19 +99,19 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
         return;
     }
     double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
-    const bool act = lane < (Ls / PX) * (Ls / PY);
-    const pgrid::Ctx X = pgrid::ctx<PX, PY>(lane, Ls, V.cbar[0], V.sbar[0]);
-    const double a = V.a * X.k4, b = V.b;
+    const bool act = lane < LAT::lanes(Ls);
+    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, V.cbar[0], V.sbar[0]);
+    const double a = V.a * X.ks, b = V.b;
     int site[NS];
     double e1[NS], vin[NS], Pa[NS], Qa[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-        site[q] = pgrid::site<PX, PY>(lane, q, Ls);
+        site[q] = LAT::site_of(lane, q, Ls);
         e1[q] = a * V.Ebar[site[q]];
         vin[q] = u[2 * site[q] + wv];
     }
     // M^-T[w,w]: conjugated coefficients, transposed A   (KPMPreconditioners.jl:621-648)
-    series_lean<NS, true>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { pgrid::sweep<PX, PY, true>(v, X); });
+    series_lean<NS, true>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { LAT::template apply<true>(v, X); });
 #pragma unroll
     for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
     __syncthreads();
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
     }
     __syncthreads();
     // M^-1[w,w]   (:650-677)
-    series_lean<NS, false>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { pgrid::sweep<PX, PY, false>(v, X); });
+    series_lean<NS, false>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { LAT::template apply<false>(v, X); });
 #pragma unroll
     for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
     __syncthreads();
@@ -153,9 +156,9 @@ __device__ __forceinline__ double pg_reduce_partials(const double *p, int n, int
 // the bytes that must move take ~100).
 //   w(t)   = p(t) - sg(t) c^4 S(E(t) p(t-1))            sg(t) = -1 at t = 0 (antiperiodic), S / S^T: the sweep without its c^4
 //   z(t-1) = w(t-1) - sg(t) c^4 E(t) S^T(w(t))
-template <int PX, int PY>
+template <class LAT>
 __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int parity, int Ls, int Tmax) {
-    constexpr int NS = PX * PY;
+    constexpr int NS = LAT::NS;
     const int N = m.N, L = m.L, lane = threadIdx.x;
     const int nch = (L + Tmax - 1) / Tmax;
     const int rhs = blockIdx.x / nch, ch = blockIdx.x - rhs * nch;
@@ -201,12 +204,12 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
     double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
     double *z = B.z + (size_t)rhs * ndim;
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
-    const bool act = lane < (Ls / PX) * (Ls / PY);
-    const pgrid::Ctx X = pgrid::ctx<PX, PY>(lane, Ls, m.c_uni, m.s_uni);
+    const bool act = lane < LAT::lanes(Ls);
+    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni);
     int site[NS];
     bool dot[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { site[q] = pgrid::site<PX, PY>(lane, q, Ls); dot[q] = act && site[q] >= B.dot_lo && site[q] < B.dot_hi; }
+    for (int q = 0; q < NS; ++q) { site[q] = LAT::site_of(lane, q, Ls); dot[q] = act && site[q] >= B.dot_lo && site[q] < B.dot_hi; }
     auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
     // p(t) = (z | r)(t) + beta p_old(t)   (:229-230 / :309-310); the first iteration: p0 as the init kernel stored it
     auto load_raw = [&](int t, double (&sv)[NS], double (&qv)[NS]) {
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
 #pragma unroll 1
     for (int j = 0; j <= T; ++j) {
         const int t = wrap(t0 + j);
-        const double sg = (t == 0) ? -X.k4 : X.k4;         // the sign of the antiperiodic boundary with the c^4 of the factored colours
+        const double sg = (t == 0) ? -X.ks : X.ks;         // the sign of the antiperiodic boundary with the c^4 (c^3) of the factored colours
         double pcur[NS], wcur[NS], Ecur[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
@@ -255,14 +258,14 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
                 for (int q = 0; q < NS; ++q) pnew[(size_t)t * N + site[q]] = pcur[q];
             }
         }
-        pgrid::sweep<PX, PY, false>(wcur, X);
+        LAT::template apply<false>(wcur, X);
 #pragma unroll
         for (int q = 0; q < NS; ++q) wcur[q] = pcur[q] - sg * wcur[q];
         if (j > 0) {
             double g[NS];
 #pragma unroll
             for (int q = 0; q < NS; ++q) g[q] = wcur[q];
-            pgrid::sweep<PX, PY, true>(g, X);
+            LAT::template apply<true>(g, X);
             const int tz = wrap(t0 + j - 1);
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -307,10 +310,16 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     KpmDev K = elph_kpm_dev(h);
     const int Lo2 = (int)((h->L + 1) / 2), N = (int)h->N, Ls = h->pg_L;
     const dim3 grid((unsigned)nrhs, (unsigned)Lo2), block(2 * WAVE);
-    if (h->pg_PX == 4 && h->pg_PY == 4) hipLaunchKernelGGL((k_kpm_cheb_pg<4, 4>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st);
-    else if (h->pg_PX == 2 && h->pg_PY == 6) hipLaunchKernelGGL((k_kpm_cheb_pg<2, 6>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st);
-    else if (h->pg_PX == 2 && h->pg_PY == 4) hipLaunchKernelGGL((k_kpm_cheb_pg<2, 4>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st);
-    else { elph_set_error("k_kpm_cheb_pg: no instantiation for %d x %d patches", h->pg_PX, h->pg_PY); return ELPH_E_UNSUPPORTED; }
+#define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st)
+    const int px = h->pg_PX, py = h->pg_PY;
+    if (h->pg_kind == 1 && px == 4 && py == 4) PG_CHEB(SQ44);
+    else if (h->pg_kind == 1 && px == 2 && py == 6) PG_CHEB(SQ26);
+    else if (h->pg_kind == 1 && px == 2 && py == 4) PG_CHEB(SQ24);
+    else if (h->pg_kind == 2 && px == 3 && py == 2) PG_CHEB(HC32);
+    else if (h->pg_kind == 2 && px == 4 && py == 2) PG_CHEB(HC42);
+    else if (h->pg_kind == 2 && px == 3 && py == 3) PG_CHEB(HC33);
+    else { elph_set_error("k_kpm_cheb_pg: no instantiation for kind %d, %d x %d patches", h->pg_kind, px, py); return ELPH_E_UNSUPPORTED; }
+#undef PG_CHEB
     return pg_check("k_kpm_cheb_pg");
 }
 
@@ -326,10 +335,10 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     // slices per wave: the SHORTEST chunk whose waves still fit the chip in one round — 1024 SIMDs x the waves a SIMD holds of this
     // instantiation (one for 12 or 16 sites per lane: 256 + ~100 registers with the prefetched slice; two for 8) — a second, partly
     // filled round costs more than the two halo slices per chunk (measured at L = 32, 72 right-hand sides: 16 slices per wave = 720
-    // waves 98 us, 10 = 1152 waves 140 us; profiles/r04/pgrid_large_square_lattices.log); beyond one round of 40-slice chunks: 20
+    // waves 98 us, 10 = 1152 waves 140 us; profiles/r04/pgrid_large_lattices.log); beyond one round of 40-slice chunks: 20
     const int L = (int)h->L;
     static const int forceT = []() { const char *e = getenv("ELPH_PG_T"); return e ? atoi(e) : 0; }();
-    const long long slots = 1024LL * ((h->pg_PX * h->pg_PY <= 8) ? 2 : 1);
+    const long long slots = 1024LL * ((h->pg_kind == 1 && h->pg_PX * h->pg_PY <= 8) ? 2 : 1);
     int T = 20;
     for (int c : {1, 2, 4, 5, 8, 10, 16, 20, 32, 40}) { if ((long long)nrhs * ((L + c - 1) / c) <= slots) { T = c; break; } }
     if (forceT > 0) T = forceT;
@@ -337,9 +346,15 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     const int nch = (L + T - 1) / T;
     const dim3 grid((unsigned)(nrhs * nch)), block(WAVE);
     const int Ls = h->pg_L;
-    if (h->pg_PX == 4 && h->pg_PY == 4) hipLaunchKernelGGL((k_cg_ap_pg<4, 4>), grid, block, 0, h->stream, B, m, parity, Ls, T);
-    else if (h->pg_PX == 2 && h->pg_PY == 6) hipLaunchKernelGGL((k_cg_ap_pg<2, 6>), grid, block, 0, h->stream, B, m, parity, Ls, T);
-    else if (h->pg_PX == 2 && h->pg_PY == 4) hipLaunchKernelGGL((k_cg_ap_pg<2, 4>), grid, block, 0, h->stream, B, m, parity, Ls, T);
-    else { elph_set_error("k_cg_ap_pg: no instantiation for %d x %d patches", h->pg_PX, h->pg_PY); return ELPH_E_UNSUPPORTED; }
+#define PG_AP(LAT) hipLaunchKernelGGL((k_cg_ap_pg<LAT>), grid, block, 0, h->stream, B, m, parity, Ls, T)
+    const int px = h->pg_PX, py = h->pg_PY;
+    if (h->pg_kind == 1 && px == 4 && py == 4) PG_AP(SQ44);
+    else if (h->pg_kind == 1 && px == 2 && py == 6) PG_AP(SQ26);
+    else if (h->pg_kind == 1 && px == 2 && py == 4) PG_AP(SQ24);
+    else if (h->pg_kind == 2 && px == 3 && py == 2) PG_AP(HC32);
+    else if (h->pg_kind == 2 && px == 4 && py == 2) PG_AP(HC42);
+    else if (h->pg_kind == 2 && px == 3 && py == 3) PG_AP(HC33);
+    else { elph_set_error("k_cg_ap_pg: no instantiation for kind %d, %d x %d patches", h->pg_kind, px, py); return ELPH_E_UNSUPPORTED; }
+#undef PG_AP
     return pg_check("k_cg_ap_pg");
 }

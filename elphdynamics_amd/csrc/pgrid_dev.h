@@ -21,7 +21,7 @@ namespace pgrid {
 constexpr int WAVE_ = ELPH_WAVE;
 
 struct Ctx {
-    double th, k4;           // tanh of the bond angle; c^4
+    double th, ks;           // tanh of the bond angle; the factor taken out of the colours: c^4 (square), c^3 (honeycomb)
     int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1 (cyclic); idle lanes: themselves
 };
 
@@ -37,7 +37,7 @@ template <int PX, int PY>
 __device__ __forceinline__ Ctx ctx(int lane, int L, double c, double s) {
     const int GX = L / PX, GY = L / PY;
     Ctx X;
-    X.th = s / c; X.k4 = (c * c) * (c * c);
+    X.th = s / c; X.ks = (c * c) * (c * c);
     if (lane < GX * GY) {
         const int x = lane % GX, y = lane / GX;
         X.xu = (x + 1) % GX + GX * y; X.xd = (x + GX - 1) % GX + GX * y;
@@ -97,6 +97,85 @@ template <int PX, int PY, bool REVERSE>
 __device__ __forceinline__ void sweep(double (&v)[PX * PY], const Ctx &X) {
     if constexpr (!REVERSE) { colour<PX, PY, 0>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 3>(v, X); }
     else                    { colour<PX, PY, 3>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 0>(v, X); }
+}
+
+// ---- honeycomb: L x L two-site cells (site = 2 (x + L y) + orbital) in the reference's colouring [A-B of a cell | B(x,y)-A(x+1,y) |
+// B(x,y)-A(x,y+1)] (detect_honeycomb, elph_api.hip), PX x PY CELLS per lane: register q = 2 (cx + PX cy) + orbital.  A-B pairs registers
+// of the lane; the other two colours pair registers of the lane inside the patch and cross at its edge — PY resp. PX values each way.
+// No even/odd structure: any patch shape that divides L.  (Lattices of up to 16 x 16 cells have the HGRID form, cg_fast_common.h.)
+template <int PX, int PY>
+__host__ __device__ __forceinline__ int hsite(int lane, int q, int L) {
+    const int GX = L / PX, GY = L / PY;
+    const int l = (lane < GX * GY) ? lane : 0, X = l % GX, Y = l / GX;
+    const int c = q >> 1, cx = c % PX, cy = c / PX;
+    return 2 * ((PX * X + cx) + L * (PY * Y + cy)) + (q & 1);
+}
+template <int PX, int PY, int COL>
+__device__ __forceinline__ void hcolour(double (&v)[2 * PX * PY], const Ctx &X) {
+    if constexpr (COL == 0) {
+#pragma unroll
+        for (int c = 0; c < PX * PY; ++c) {
+            const double na = v[2 * c] + X.th * v[2 * c + 1], nb = v[2 * c + 1] + X.th * v[2 * c];
+            v[2 * c] = na; v[2 * c + 1] = nb;
+        }
+    } else {
+        constexpr bool ALONG_X = (COL == 1);
+        constexpr int PA = ALONG_X ? PX : PY, PB = ALONG_X ? PY : PX;
+        constexpr int SA = ALONG_X ? 1 : PX, SB = ALONG_X ? PX : 1;          // cell strides along / across
+        const int up = ALONG_X ? X.xu : X.yu, dn = ALONG_X ? X.xd : X.yd;
+        double fu[PB], fd[PB];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            fu[b] = __shfl(v[2 * (0 * SA + b * SB)], up, WAVE_);                    // the A site of the first cell of the patch above
+            fd[b] = __shfl(v[2 * ((PA - 1) * SA + b * SB) + 1], dn, WAVE_);         // the B site of the last cell of the patch below
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int a = 0; a + 1 < PA; ++a) {                                      // B(a) - A(a + 1) inside the patch
+                const int i = 2 * (a * SA + b * SB) + 1, j = 2 * ((a + 1) * SA + b * SB);
+                const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
+                v[i] = ni; v[j] = nj;
+            }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            v[2 * ((PA - 1) * SA + b * SB) + 1] += X.th * fu[b];
+            v[2 * (0 * SA + b * SB)] += X.th * fd[b];
+        }
+    }
+}
+
+// ---- the two lattices behind one interface: NS registers per vector, site(), ctx(), sweep<REVERSE>() -----------------------------------
+template <int PX_, int PY_> struct Sq {
+    static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_;
+    __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
+    __host__ __device__ static int site_of(int lane, int q, int L) { return site<PX, PY>(lane, q, L); }
+    __device__ static Ctx make_ctx(int lane, int L, double c, double s) { return ctx<PX, PY>(lane, L, c, s); }
+    template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) { sweep<PX, PY, REVERSE>(v, X); }
+};
+template <int PX_, int PY_> struct Hc {
+    static constexpr int PX = PX_, PY = PY_, NS = 2 * PX_ * PY_;
+    __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
+    __host__ __device__ static int site_of(int lane, int q, int L) { return hsite<PX, PY>(lane, q, L); }
+    __device__ static Ctx make_ctx(int lane, int L, double c, double s) {
+        Ctx X = ctx<PX, PY>(lane, L, c, s);
+        X.ks = c * c * c;                      // three colours
+        return X;
+    }
+    template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) {
+        if constexpr (!REVERSE) { hcolour<PX, PY, 0>(v, X); hcolour<PX, PY, 1>(v, X); hcolour<PX, PY, 2>(v, X); }
+        else                    { hcolour<PX, PY, 2>(v, X); hcolour<PX, PY, 1>(v, X); hcolour<PX, PY, 0>(v, X); }
+    }
+};
+
+// The cell patch for an L x L honeycomb lattice beyond 16 x 16 cells (false: none).
+inline bool pick_hpatch(int L, int *PX, int *PY) {
+    switch (L) {
+        case 18: *PX = 3; *PY = 2; return true;      // 6 x 9 lanes, 12 registers per vector
+        case 20: *PX = 4; *PY = 2; return true;      // 5 x 10 lanes, 16
+        case 21: case 24: *PX = 3; *PY = 3; return true;      // 7 x 7 / 8 x 8 lanes, 18
+        default: return false;
+    }
 }
 
 // The patch shape for an L x L lattice (0: none — the lattice keeps the generic kernels).
