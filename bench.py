@@ -397,6 +397,30 @@ def main():
                 except Exception as e:
                     other[tag] = {"error": str(e)}
             out["other_baseline_lattices_resident"] = other
+            # ---- secondary: lattices of production size beyond the BASELINE ones (square 32 x 32, honeycomb 24 x 24 cells: the PGRID
+            # kernels, a patch of sites per lane) — the streaming iterations, un-preconditioned and KPM-preconditioned, 72 right-hand sides
+            large = {}
+            for tag in ("X32", "X24"):
+                try:
+                    ml_ = configs.make_model(tag, tol=1e-5, device=comm.device_index())
+                    Pl_ = pc.SymmetricKPMPreconditioner(ml_, 20, 0.05, 1.0, 1.0)
+                    pc.setup_(Pl_, rng=np.random.default_rng(7))
+                    Bl = np.ascontiguousarray(np.stack([synth.randn(300 + r, ml_.Ndim) for r in range(72)]))
+                    rec = {"nsites": int(ml_.Nsites), "ltau": int(ml_.Ltau), "nrhs": 72}
+                    msl = C.c_double()
+                    for wh, nm in ((1, "cg_iter_us"), (3, "preconditioned_cg_iter_us")):
+                        check(lib.elph_bench_prepare(ml_._h, wh, 72, _lib.dptr(Bl)))
+                        check(lib.elph_bench_run(ml_._h, wh, 72, 32, 0, C.byref(msl)))
+                        check(lib.elph_bench_prepare(ml_._h, wh, 72, None))
+                        check(lib.elph_bench_run(ml_._h, wh, 72, 160, 0, C.byref(msl)))
+                        rec[nm] = 1e3 * msl.value / 160
+                    rec["preconditioned_ps_per_element"] = 1e6 * rec["preconditioned_cg_iter_us"] / (72.0 * ml_.Ndim)
+                    rec["preconditioned_matvecs_per_sec"] = 2.0 * 72 / (rec["preconditioned_cg_iter_us"] * 1e-6)
+                    large[tag] = rec
+                    ml_.close()
+                except Exception as e:
+                    large[tag] = {"error": str(e)}
+            out["large_lattices"] = large
         # ---- secondary: the same step at other batch sizes (short runs)
         if not args.no_sweep:
             sweep = {}

@@ -50,6 +50,9 @@ CONFIGS = {
     "h21": ("holstein", 2, 21, lat.HONEYCOMB_BONDS, 0.6, 0.1),      # N = 882:  3 x 3 cells on 7 x 7 lanes (odd L)
     "h24": ("holstein", 2, 24, lat.HONEYCOMB_BONDS, 0.6, 0.1),      # N = 1152: 3 x 3 cells on 8 x 8 lanes
     "H18": ("holstein", 2, 18, lat.HONEYCOMB_BONDS, 3.0, 0.1),      # N = 648, Ltau = 30: long recursions
+    # production-size lattices beyond the BASELINE ones, for bench.py's `large_lattices` record (PGRID kernels, csrc/pgrid.hip)
+    "X32": ("holstein", 1, 32, lat.SQUARE_BONDS, 16.0, 0.1),        # square 32 x 32, Ltau = 160: 163 840 unknowns
+    "X24": ("holstein", 2, 24, lat.HONEYCOMB_BONDS, 12.0, 0.1),     # honeycomb 24 x 24 cells, Ltau = 120: 138 240 unknowns
     # a long time axis: 1280 slices (beyond the direct-DFT tables: dft_big.hip)
     "l": ("holstein", 1, 4, lat.SQUARE_BONDS, 128.0, 0.1),
 }
