@@ -1085,7 +1085,8 @@ def test_kpm_patch_recursion_equals_the_generic_recursion(tag, monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2), ("D", 4, 2)])
+@pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2), ("D", 4, 2),
+                                             ("G", 3, 2), ("h", 2, 2)])      # (G, h: the PGRID kernels, one expansion per chain)
 def test_kpm_preconditioner_per_chain(tag, nchains, per, monkeypatch):
     """One KPM expansion per resident phonon configuration (elph_kpm_setup_chains): every right-hand side of the batch
     is preconditioned with ITS chain's Ē, eigenvalue bounds, orders and coefficients — same bounds, same iteration
