@@ -400,6 +400,8 @@ int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream 
 bool elph_pg_cheb_usable(const elph_handle_s *h);                       // pgrid.hip
 int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
 bool elph_pg_ap_usable(const elph_handle_s *h);
+bool elph_pg_mul_usable(const elph_handle_s *h);
+int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, const double *vS, int nvec);
 int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity);
 int elph_wg_cooldown_step(elph_handle_s *h);                // one solve of the cool-down after a time-out (both resident kernels call it)
 long long elph_shard_timeout_ms();                          // wait bound of the sharded solves (shard.hip)

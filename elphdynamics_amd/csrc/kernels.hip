@@ -1081,6 +1081,7 @@ int elph_launch_zero(elph_handle_s *h, double *p, int64_t n) {
 int elph_launch_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec) {
     if (h->fast) return elph_fast_mul(h, which, yS, vS, nvec);
     ModelDev m = elph_model_dev(h);
+    if (which >= 0 && which <= 2 && elph_pg_mul_usable(h) && m.uniform) return elph_pg_mul(h, m, which, yS, vS, nvec);     // large square / honeycomb lattices: pgrid.hip
     dim3 grid((unsigned)h->L, (unsigned)nvec, 1);
     const size_t shm = (2 * (size_t)h->N + 16) * sizeof(double);
     DISPATCH_NPL(gen_npl(h), {

@@ -291,6 +291,94 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
     }
 }
 
+// y = M v (WHICH 0), M^T v (1), M^T M v (2) — mulM!, mulMT!, mulMTM! (HolsteinModels.jl:569-684) in the patch layout, one wavefront per
+// chunk of Tmax slices of a vector; the arithmetic of the generic k_mul (kernels.hip) with register sweeps:
+//   (M v)(t)   = v(t) - sg(t) c^k S(E(t) v(t-1))          (M^T v)(t) = v(t) - sg(t+1) c^k E(t+1) S^T(v(t+1))
+template <class LAT, int WHICH>
+__global__ void __launch_bounds__(WAVE) k_mul_pg(double *__restrict__ y, const double *__restrict__ v, ModelDev m, int Ls, int Tmax) {
+    constexpr int NS = LAT::NS;
+    const int N = m.N, L = m.L, lane = threadIdx.x;
+    const int nch = (L + Tmax - 1) / Tmax;
+    const int vecno = blockIdx.x / nch, ch = blockIdx.x - vecno * nch;
+    const int t0 = ch * Tmax, T = (L - t0 < Tmax) ? L - t0 : Tmax;
+    const size_t vec = (size_t)vecno * (size_t)N * (size_t)L;
+    const double *vv = v + vec;
+    double *yy = y + vec;
+    const double *Ech = m.E + (size_t)(vecno % m.nchains) * m.E_chain_stride;
+    const bool act = lane < LAT::lanes(Ls);
+    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni);
+    int site[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) site[q] = LAT::site_of(lane, q, Ls);
+    auto wrap = [L](int t) { return (t < 0) ? t + L : ((t >= L) ? t - L : t); };
+    auto load = [&](const double *base, int t, double (&a)[NS]) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) a[q] = base[(size_t)t * N + site[q]];
+    };
+    auto sgn = [&X](int t) { return (t == 0) ? -X.ks : X.ks; };
+    if constexpr (WHICH == 0) {
+        double vprev[NS];
+        load(vv, wrap(t0 - 1), vprev);
+#pragma unroll 1
+        for (int j = 0; j < T; ++j) {
+            const int t = t0 + j;
+            double vc[NS], f[NS];
+            load(vv, t, vc);
+            const double *Et = Ech + (size_t)t * m.E_tau_stride;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) f[q] = Et[site[q]] * vprev[q];
+            LAT::template apply<false>(f, X);
+            const double sg = sgn(t);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { if (act) yy[(size_t)t * N + site[q]] = vc[q] - sg * f[q]; vprev[q] = vc[q]; }
+        }
+    } else if constexpr (WHICH == 1) {
+        double vc[NS];
+        load(vv, t0, vc);
+#pragma unroll 1
+        for (int j = 0; j < T; ++j) {
+            const int t = t0 + j, tp = wrap(t + 1);
+            double vn[NS], g[NS];
+            load(vv, tp, vn);
+            const double *Ep = Ech + (size_t)tp * m.E_tau_stride;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) g[q] = vn[q];
+            LAT::template apply<true>(g, X);
+            const double sg = sgn(tp);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { if (act) yy[(size_t)t * N + site[q]] = vc[q] - sg * Ep[site[q]] * g[q]; vc[q] = vn[q]; }
+        }
+    } else {
+        // w(t) = v(t) - sg(t) c^k S(E(t) v(t-1)) for t0 .. t0+T; y(t-1) = w(t-1) - sg(t) c^k E(t) S^T(w(t))
+        double vprev[NS], wprev[NS];
+        load(vv, wrap(t0 - 1), vprev);
+#pragma unroll 1
+        for (int j = 0; j <= T; ++j) {
+            const int t = wrap(t0 + j);
+            double vc[NS], wc[NS], Ec[NS];
+            load(vv, t, vc);
+            const double *Et = Ech + (size_t)t * m.E_tau_stride;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { Ec[q] = Et[site[q]]; wc[q] = Ec[q] * vprev[q]; }
+            LAT::template apply<false>(wc, X);
+            const double sg = sgn(t);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) wc[q] = vc[q] - sg * wc[q];
+            if (j > 0) {
+                double g[NS];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) g[q] = wc[q];
+                LAT::template apply<true>(g, X);
+                const int tz = wrap(t0 + j - 1);
+#pragma unroll
+                for (int q = 0; q < NS; ++q) if (act) yy[(size_t)tz * N + site[q]] = wprev[q] - sg * Ec[q] * g[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { vprev[q] = vc[q]; wprev[q] = wc[q]; }
+        }
+    }
+}
+
 int pg_check(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { elph_set_error("launch %s failed: %s", what, hipGetErrorString(e)); return ELPH_E_HIP; }
@@ -357,4 +445,32 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     else { elph_set_error("k_cg_ap_pg: no instantiation for kind %d, %d x %d patches", h->pg_kind, px, py); return ELPH_E_UNSUPPORTED; }
 #undef PG_AP
     return pg_check("k_cg_ap_pg");
+}
+
+// mulM!, mulMT!, mulMTM! in the patch layout (generic family only)
+bool elph_pg_mul_usable(const elph_handle_s *h) { return elph_pg_ap_usable(h); }
+
+int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, const double *vS, int nvec) {
+    if (!m.uniform) return ELPH_E_UNSUPPORTED;
+    const int L = (int)h->L, Ls = h->pg_L;
+    int T = 20;
+    for (int c : {1, 2, 4, 5, 8, 10, 16, 20}) { if ((long long)nvec * ((L + c - 1) / c) <= 2048) { T = c; break; } }
+    T = std::max(1, std::min(T, L));
+    const dim3 grid((unsigned)(nvec * ((L + T - 1) / T))), block(WAVE);
+#define PG_MUL(LAT)                                                                                                       \
+    do {                                                                                                                  \
+        if (which == 0) hipLaunchKernelGGL((k_mul_pg<LAT, 0>), grid, block, 0, h->stream, yS, vS, m, Ls, T);              \
+        else if (which == 1) hipLaunchKernelGGL((k_mul_pg<LAT, 1>), grid, block, 0, h->stream, yS, vS, m, Ls, T);         \
+        else hipLaunchKernelGGL((k_mul_pg<LAT, 2>), grid, block, 0, h->stream, yS, vS, m, Ls, T);                         \
+    } while (0)
+    const int px = h->pg_PX, py = h->pg_PY;
+    if (h->pg_kind == 1 && px == 4 && py == 4) PG_MUL(SQ44);
+    else if (h->pg_kind == 1 && px == 2 && py == 6) PG_MUL(SQ26);
+    else if (h->pg_kind == 1 && px == 2 && py == 4) PG_MUL(SQ24);
+    else if (h->pg_kind == 2 && px == 3 && py == 2) PG_MUL(HC32);
+    else if (h->pg_kind == 2 && px == 4 && py == 2) PG_MUL(HC42);
+    else if (h->pg_kind == 2 && px == 3 && py == 3) PG_MUL(HC33);
+    else { elph_set_error("k_mul_pg: no instantiation for kind %d, %d x %d patches", h->pg_kind, px, py); return ELPH_E_UNSUPPORTED; }
+#undef PG_MUL
+    return pg_check("k_mul_pg");
 }
