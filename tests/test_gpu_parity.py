@@ -422,10 +422,12 @@ def test_kpm_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["B", "C"])
+@pytest.mark.parametrize("tag", ["B", "C", "g", "h"])
 def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
     """Hopping disorder (assign_t! with a standard deviation, HolsteinModels.jl:427-447): the register-exchange Chebyshev kernels
-    carry one (cosh, sinh) per site and colour instead of two scalars — the row layout on 16 x 16, one site per lane on 8 x 8."""
+    carry one (cosh, sinh) per site and colour instead of two scalars — the row layout on 16 x 16, one site per lane on 8 x 8.
+    g, h (24 x 24 square, 18 x 18 honeycomb cells): the PGRID kernels know uniform hopping only — these lattices must fall back to the
+    generic kernels, and do."""
     from elphdynamics_amd import configs, models, preconditioners as pc
     m = configs.make_model(tag, tol=1e-5, t_stddev=0.1)
     om = _oracle_model(oracle, m)
