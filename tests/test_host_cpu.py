@@ -102,3 +102,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "elph_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_every_environment_switch_is_in_the_design_table():
+    """DESIGN.md §9 promises ONE table with every ELPH_* switch the library or the Python host reads: a switch added to the sources without a
+    row there fails here."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "elphdynamics_amd", "csrc", "*")):
+        if os.path.isfile(f):
+            names |= set(re.findall(r'getenv\("(ELPH_[A-Z0-9_]+)"\)', open(f, errors="replace").read()))
+    for f in glob.glob(os.path.join(ROOT, "elphdynamics_amd", "*.py")) + [os.path.join(ROOT, "bench.py")]:
+        names |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(ELPH_[A-Z0-9_]+)"', open(f).read()))
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    table = design[design.index("## 9. Environment switches"):]
+    missing = sorted(n for n in names if n not in table)
+    assert len(names) > 30 and not missing, missing
