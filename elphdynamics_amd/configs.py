@@ -50,6 +50,12 @@ CONFIGS = {
     "h21": ("holstein", 2, 21, lat.HONEYCOMB_BONDS, 0.6, 0.1),      # N = 882:  3 x 3 cells on 7 x 7 lanes (odd L)
     "h24": ("holstein", 2, 24, lat.HONEYCOMB_BONDS, 0.6, 0.1),      # N = 1152: 3 x 3 cells on 8 x 8 lanes
     "H18": ("holstein", 2, 18, lat.HONEYCOMB_BONDS, 3.0, 0.1),      # N = 648, Ltau = 30: long recursions
+    # triangular lattices in the patch layout (pgrid::Tri; t, u, T above are three more: t — odd L — keeps the generic kernels)
+    "t6": ("holstein", 1, 6, lat.TRIANGULAR_BONDS, 1.0, 0.1),       # 2 x 2 patches on 3 x 3 lanes
+    "t12": ("holstein", 1, 12, lat.TRIANGULAR_BONDS, 2.0, 0.1),     # N = 144, Ltau = 20
+    "t20": ("holstein", 1, 20, lat.TRIANGULAR_BONDS, 1.0, 0.1),     # 2 x 4 patches (still the lane-program family for the mat-vec)
+    "t24": ("holstein", 1, 24, lat.TRIANGULAR_BONDS, 0.8, 0.1),     # N = 576: 2 x 6 patches, generic family: mat-vec kernels in patches too
+    "t32": ("holstein", 1, 32, lat.TRIANGULAR_BONDS, 0.6, 0.1),     # N = 1024: 4 x 4 patches
     # production-size lattices beyond the BASELINE ones, for bench.py's `large_lattices` record (PGRID kernels, csrc/pgrid.hip)
     "X32": ("holstein", 1, 32, lat.SQUARE_BONDS, 16.0, 0.1),        # square 32 x 32, Ltau = 160: 163 840 unknowns
     "X24": ("holstein", 2, 24, lat.HONEYCOMB_BONDS, 12.0, 0.1),     # honeycomb 24 x 24 cells, Ltau = 120: 138 240 unknowns

@@ -86,6 +86,7 @@ void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, d
 
 static void detect_square(elph_handle_s *h);
 static void detect_honeycomb12(elph_handle_s *h);
+static void detect_triangular(elph_handle_s *h);
 
 static int build_lane_program(elph_handle_s *h) {
     h->lp_mc = (h->ncol <= 4) ? 4 : 6;      // kernels exist for 4-colour (square, honeycomb, chain) and 6-colour (triangular) programs
@@ -129,6 +130,7 @@ static int build_lane_program(elph_handle_s *h) {
     RC(dev_alloc(&h->d_lp_sbar, (size_t)NE * ELPH_WAVE));
     detect_honeycomb12(h);
     detect_square(h);
+    detect_triangular(h);
     if (h->sq_L > 0) {
         RC(dev_alloc(&h->d_sq_cbar, (size_t)4 * h->N));
         RC(dev_alloc(&h->d_sq_sbar, (size_t)4 * h->N));
@@ -162,6 +164,44 @@ static bool match_square(elph_handle_s *h, int LX, int LY) {
     }
     for (int v : h->sq_bond) if (v < 0) return false;
     return true;
+}
+
+// Recognise an even-L triangular lattice (site = x + L y; bonds (1,0), (0,1), (1,-1): examples/holstein_hmc_triangular.toml) in the colouring
+// the checkerboard gives them: [x-even | x-odd | y-even | diagonal from even y | y-odd | diagonal from odd y], the diagonal of (x, y)
+// ending at (x - 1, y + 1).  Only then may the patch-layout kernels run on it (pgrid.hip, pgrid::Tri).
+static void detect_triangular(elph_handle_s *h) {
+    if (h->ncol != 6 || h->nb != 3 * h->N || h->N < 16) return;
+    int L = 0;
+    for (int l = 4; l <= 64; l += 2) if ((int64_t)l * l == h->N) L = l;
+    int px = 0, py = 0;
+    if (!L || !pgrid::pick_tpatch(L, &px, &py)) return;
+    auto partner = [L](int col, int x, int y, int *px_, int *py_) {
+        const int xp = (x + 1) % L, xm = (x + L - 1) % L, yp = (y + 1) % L, ym = (y + L - 1) % L;
+        switch (col) {
+            case 0: *px_ = x ^ 1; *py_ = y; break;
+            case 1: *px_ = (x & 1) ? xp : xm; *py_ = y; break;
+            case 2: *px_ = x; *py_ = y ^ 1; break;
+            case 3: if (!(y & 1)) { *px_ = xm; *py_ = yp; } else { *px_ = xp; *py_ = ym; } break;
+            case 4: *px_ = x; *py_ = (y & 1) ? yp : ym; break;
+            default: if (y & 1) { *px_ = xm; *py_ = yp; } else { *px_ = xp; *py_ = ym; } break;
+        }
+    };
+    std::vector<char> seen((size_t)6 * h->N, 0);
+    for (int col = 0; col < 6; ++col) {
+        const int b0 = h->h_coloff[col], b1 = h->h_coloff[col + 1];
+        if (b1 - b0 != h->N / 2) return;
+        for (int n = b0; n < b1; ++n) {
+            const int i = h->h_bi[n], j = h->h_bj[n];
+            int qx, qy;
+            partner(col, i % L, i / L, &qx, &qy);
+            if (qx + L * qy != j) return;
+            partner(col, j % L, j / L, &qx, &qy);
+            if (qx + L * qy != i) return;
+            if (seen[(size_t)col * h->N + i] || seen[(size_t)col * h->N + j]) return;
+            seen[(size_t)col * h->N + i] = seen[(size_t)col * h->N + j] = 1;
+        }
+    }
+    h->pg_L = L; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 3;
 }
 
 static void detect_square(elph_handle_s *h) {

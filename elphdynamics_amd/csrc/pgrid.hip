@@ -18,6 +18,7 @@
 namespace {
 
 using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>;
+using TR22 = pgrid::Tri<2, 2>; using TR24 = pgrid::Tri<2, 4>; using TR26 = pgrid::Tri<2, 6>; using TR44 = pgrid::Tri<4, 4>;
 using HC32 = pgrid::Hc<3, 2>; using HC42 = pgrid::Hc<4, 2>; using HC33 = pgrid::Hc<3, 3>;
 
 // sum_n c_n T_n(A') v  for one real vector in the patch layout: Pacc = sum Re(c_n) u_n, Qacc = sum Im(c_n) u_n with
@@ -406,6 +407,10 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_CHEB(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_CHEB(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_CHEB(HC33);
+    else if (h->pg_kind == 3 && px == 2 && py == 2) PG_CHEB(TR22);
+    else if (h->pg_kind == 3 && px == 2 && py == 4) PG_CHEB(TR24);
+    else if (h->pg_kind == 3 && px == 2 && py == 6) PG_CHEB(TR26);
+    else if (h->pg_kind == 3 && px == 4 && py == 4) PG_CHEB(TR44);
     else { elph_set_error("k_kpm_cheb_pg: no instantiation for kind %d, %d x %d patches", h->pg_kind, px, py); return ELPH_E_UNSUPPORTED; }
 #undef PG_CHEB
     return pg_check("k_kpm_cheb_pg");
@@ -426,7 +431,7 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     // waves 98 us, 10 = 1152 waves 140 us; profiles/r04/pgrid_large_lattices.log); beyond one round of 40-slice chunks: 20
     const int L = (int)h->L;
     static const int forceT = []() { const char *e = getenv("ELPH_PG_T"); return e ? atoi(e) : 0; }();
-    const long long slots = 1024LL * ((h->pg_kind == 1 && h->pg_PX * h->pg_PY <= 8) ? 2 : 1);
+    const long long slots = 1024LL * ((h->pg_kind != 2 && h->pg_PX * h->pg_PY <= 8) ? 2 : 1);
     int T = 20;
     for (int c : {1, 2, 4, 5, 8, 10, 16, 20, 32, 40}) { if ((long long)nrhs * ((L + c - 1) / c) <= slots) { T = c; break; } }
     if (forceT > 0) T = forceT;
@@ -442,6 +447,10 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_AP(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_AP(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_AP(HC33);
+    else if (h->pg_kind == 3 && px == 2 && py == 2) PG_AP(TR22);
+    else if (h->pg_kind == 3 && px == 2 && py == 4) PG_AP(TR24);
+    else if (h->pg_kind == 3 && px == 2 && py == 6) PG_AP(TR26);
+    else if (h->pg_kind == 3 && px == 4 && py == 4) PG_AP(TR44);
     else { elph_set_error("k_cg_ap_pg: no instantiation for kind %d, %d x %d patches", h->pg_kind, px, py); return ELPH_E_UNSUPPORTED; }
 #undef PG_AP
     return pg_check("k_cg_ap_pg");
@@ -470,6 +479,10 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_MUL(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_MUL(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_MUL(HC33);
+    else if (h->pg_kind == 3 && px == 2 && py == 2) PG_MUL(TR22);
+    else if (h->pg_kind == 3 && px == 2 && py == 4) PG_MUL(TR24);
+    else if (h->pg_kind == 3 && px == 2 && py == 6) PG_MUL(TR26);
+    else if (h->pg_kind == 3 && px == 4 && py == 4) PG_MUL(TR44);
     else { elph_set_error("k_mul_pg: no instantiation for kind %d, %d x %d patches", h->pg_kind, px, py); return ELPH_E_UNSUPPORTED; }
 #undef PG_MUL
     return pg_check("k_mul_pg");

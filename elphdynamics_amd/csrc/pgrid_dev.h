@@ -23,6 +23,7 @@ constexpr int WAVE_ = ELPH_WAVE;
 struct Ctx {
     double th, ks;           // tanh of the bond angle; the factor taken out of the colours: c^4 (square), c^3 (honeycomb)
     int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1 (cyclic); idle lanes: themselves
+    int du, dd;              // lanes of the patches (X - 1, Y + 1) and (X + 1, Y - 1): the diagonal bonds of the triangular lattice
 };
 
 template <int PX, int PY>
@@ -42,8 +43,9 @@ __device__ __forceinline__ Ctx ctx(int lane, int L, double c, double s) {
         const int x = lane % GX, y = lane / GX;
         X.xu = (x + 1) % GX + GX * y; X.xd = (x + GX - 1) % GX + GX * y;
         X.yu = x + GX * ((y + 1) % GY); X.yd = x + GX * ((y + GY - 1) % GY);
+        X.du = (x + GX - 1) % GX + GX * ((y + 1) % GY); X.dd = (x + 1) % GX + GX * ((y + GY - 1) % GY);
     } else {
-        X.xu = X.xd = X.yu = X.yd = lane;
+        X.xu = X.xd = X.yu = X.yd = X.du = X.dd = lane;
     }
     return X;
 }
@@ -145,6 +147,60 @@ __device__ __forceinline__ void hcolour(double (&v)[2 * PX * PY], const Ctx &X) 
     }
 }
 
+// ---- triangular: the square lattice's sites with a third bond direction (1, -1) — (x, y) - (x - 1, y + 1) — in the reference's colouring
+// [x-even | x-odd | y-even | diagonal from even y | y-odd | diagonal from odd y] (the order Checkerboard.jl's colouring gives the bond
+// definitions of examples/holstein_hmc_triangular.toml; recognised by detect_triangular, elph_api.hip).  PX x PY patches as for the
+// square lattice; a diagonal from an even row stays inside the patch rows (cy, cy + 1) and crosses only in x (the column cx = 0 to the
+// patch X - 1); a diagonal from the patch's LAST row goes to the patch row above: PX - 1 values from (X, Y + 1), one — the corner — from
+// (X - 1, Y + 1).
+template <int PX, int PY, int PAR>      // PAR = 0: diagonals from even rows, 1: from odd rows
+__device__ __forceinline__ void tdiag(double (&v)[PX * PY], const Ctx &X) {
+    // rows (cy, cy + 1) with cy = PAR, PAR + 2, ... inside the patch: (cx, cy) - (cx - 1, cy + 1)
+    // crossings in x for the inner row pairs: my (0, cy) with (PX - 1, cy + 1) of the patch X - 1; my (PX - 1, cy + 1) with (0, cy) of X + 1
+    constexpr int NR = (PAR == 0) ? PY / 2 : PY / 2 - 1;                                     // inner row pairs: cy = PAR + 2 k, cy + 1 < PY
+    double fxd[NR > 0 ? NR : 1], fxu[NR > 0 ? NR : 1];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int cy = PAR + 2 * k;
+        fxd[k] = __shfl(v[(PX - 1) + PX * (cy + 1)], X.xd, WAVE_);       // the patch X - 1: its (PX - 1, cy + 1)
+        fxu[k] = __shfl(v[0 + PX * cy], X.xu, WAVE_);                    // the patch X + 1: its (0, cy)
+    }
+    // the last row (PAR = 1 only: cy = PY - 1 is odd) pairs with row 0 of the patch row above
+    double fyu[PX], fyd[PX];
+    if constexpr (PAR == 1) {
+#pragma unroll
+        for (int cx = 1; cx < PX; ++cx) fyu[cx] = __shfl(v[(cx - 1) + PX * 0], X.yu, WAVE_);          // (cx, PY-1) - (cx-1, 0) of (X, Y+1)
+        fyu[0] = __shfl(v[(PX - 1) + PX * 0], X.du, WAVE_);                                           // (0, PY-1) - (PX-1, 0) of (X-1, Y+1)
+#pragma unroll
+        for (int cx = 0; cx + 1 < PX; ++cx) fyd[cx] = __shfl(v[(cx + 1) + PX * (PY - 1)], X.yd, WAVE_);   // (cx, 0) - (cx+1, PY-1) of (X, Y-1)
+        fyd[PX - 1] = __shfl(v[0 + PX * (PY - 1)], X.dd, WAVE_);                                      // (PX-1, 0) - (0, PY-1) of (X+1, Y-1)
+    }
+    // inside the lane
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int cy = PAR + 2 * k;
+#pragma unroll
+        for (int cx = 1; cx < PX; ++cx) {
+            const int i = cx + PX * cy, j = (cx - 1) + PX * (cy + 1);
+            const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
+            v[i] = ni; v[j] = nj;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int cy = PAR + 2 * k;
+        v[0 + PX * cy] += X.th * fxd[k];
+        v[(PX - 1) + PX * (cy + 1)] += X.th * fxu[k];
+    }
+    if constexpr (PAR == 1) {
+#pragma unroll
+        for (int cx = 0; cx < PX; ++cx) {
+            v[cx + PX * (PY - 1)] += X.th * fyu[cx];
+            v[cx + PX * 0] += X.th * fyd[cx];
+        }
+    }
+}
+
 // ---- the two lattices behind one interface: NS registers per vector, site(), ctx(), sweep<REVERSE>() -----------------------------------
 template <int PX_, int PY_> struct Sq {
     static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_;
@@ -167,6 +223,31 @@ template <int PX_, int PY_> struct Hc {
         else                    { hcolour<PX, PY, 2>(v, X); hcolour<PX, PY, 1>(v, X); hcolour<PX, PY, 0>(v, X); }
     }
 };
+
+inline bool pick_patch(int L, int *PX, int *PY);
+template <int PX_, int PY_> struct Tri {
+    static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_;
+    __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
+    __host__ __device__ static int site_of(int lane, int q, int L) { return site<PX, PY>(lane, q, L); }
+    __device__ static Ctx make_ctx(int lane, int L, double c, double s) {
+        Ctx X = ctx<PX, PY>(lane, L, c, s);
+        X.ks = (c * c * c) * (c * c * c);      // six colours
+        return X;
+    }
+    template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) {
+        if constexpr (!REVERSE) {
+            colour<PX, PY, 0>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 2>(v, X); tdiag<PX, PY, 0>(v, X); colour<PX, PY, 3>(v, X); tdiag<PX, PY, 1>(v, X);
+        } else {
+            tdiag<PX, PY, 1>(v, X); colour<PX, PY, 3>(v, X); tdiag<PX, PY, 0>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 0>(v, X);
+        }
+    }
+};
+// The patch for an even-L triangular lattice (any even L from 4: no other register form exists for it).
+inline bool pick_tpatch(int L, int *PX, int *PY) {
+    if (L < 4 || (L & 1)) return false;
+    if (L <= 16) { *PX = 2; *PY = 2; return true; }
+    return pick_patch(L, PX, PY);
+}
 
 // The cell patch for an L x L honeycomb lattice beyond 16 x 16 cells (false: none).
 inline bool pick_hpatch(int L, int *PX, int *PY) {

@@ -1,5 +1,5 @@
 """cg_iter / kpm_apply / pcg_iter times for a Holstein square lattice of any size:  time_lattice.py Lspace Ltau [nrhs ...]
-(ELPH_TIME_HONEYCOMB=1: a honeycomb lattice of Lspace x Lspace two-site cells)"""
+(ELPH_TIME_HONEYCOMB=1: a honeycomb lattice of Lspace x Lspace two-site cells; ELPH_TIME_TRIANGULAR=1: a triangular lattice)"""
 import sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -7,9 +7,10 @@ from elphdynamics_amd import lattice as lat, models, preconditioners as pc, synt
 from elphdynamics_amd._lib import check, dptr
 Ls, Lt = int(sys.argv[1]), int(sys.argv[2])
 HC = os.environ.get("ELPH_TIME_HONEYCOMB") == "1"
+TRI = os.environ.get("ELPH_TIME_TRIANGULAR") == "1"
 la = lat.Lattice(2 if HC else 1, Ls, Ls, 1)
 m = models.HolsteinModel(la, Lt * 0.1, 0.1, tol=1e-5, maxiter=20000)
-for (o1, o2, d) in (lat.HONEYCOMB_BONDS if HC else lat.SQUARE_BONDS):
+for (o1, o2, d) in (lat.HONEYCOMB_BONDS if HC else (lat.TRIANGULAR_BONDS if TRI else lat.SQUARE_BONDS)):
     m.assign_t_(1.0, o1, o2, d)
 m.assign_omega_(1.0); m.assign_lambda_(1.0); m.assign_mu_(0.0)
 m.initialize_model_()
