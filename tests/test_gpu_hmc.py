@@ -84,7 +84,8 @@ def _oracle_update(oracle, om, m, fa, x, v, dt, nt, nb, alpha, rnd, P=None):
 
 @pytest.mark.parametrize("tag,nb,nt", [("b", 1, 5), ("b", 3, 4), ("d", 1, 4), ("t", 1, 3), ("B", 1, 3), ("C", 1, 2), ("g", 1, 2),
                                        ("D", 1, 2),        # BASELINE config 4: "Holstein HMC honeycomb L=12 Ntau=120"
-                                       ("q", 1, 2), ("z", 1, 2), ("r", 1, 2)])     # the GRID / HGRID forms (L = 10 square, 10 x 10 honeycomb cells, 12 x 6 rectangle)
+                                       ("q", 1, 2), ("z", 1, 2), ("r", 1, 2),      # the GRID / HGRID forms (L = 10 square, 10 x 10 honeycomb cells, 12 x 6 rectangle)
+                                       ("t12", 1, 2), ("h", 1, 2), ("k", 1, 2)])   # the PGRID kernels (12 x 12 triangular, 18 x 18 honeycomb cells, 20 x 20 square)
 def test_hmc_update_vs_oracle(oracle, tag, nb, nt):
     from elphdynamics_amd import hmc
     m, fa, om = _pair(oracle, tag, tol=1e-6, lam2=0.02)
