@@ -397,10 +397,10 @@ def main():
                 except Exception as e:
                     other[tag] = {"error": str(e)}
             out["other_baseline_lattices_resident"] = other
-            # ---- secondary: lattices of production size beyond the BASELINE ones (square 32 x 32, honeycomb 24 x 24 cells: the PGRID
+            # ---- secondary: lattices of production size beyond the BASELINE ones (square 32 x 32, honeycomb 24 x 24 cells, triangular 24 x 24: the PGRID
             # kernels, a patch of sites per lane) — the streaming iterations, un-preconditioned and KPM-preconditioned, 72 right-hand sides
             large = {}
-            for tag in ("X32", "X24"):
+            for tag in ("X32", "X24", "XT24"):
                 try:
                     ml_ = configs.make_model(tag, tol=1e-5, device=comm.device_index())
                     Pl_ = pc.SymmetricKPMPreconditioner(ml_, 20, 0.05, 1.0, 1.0)

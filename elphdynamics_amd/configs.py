@@ -59,6 +59,7 @@ CONFIGS = {
     # production-size lattices beyond the BASELINE ones, for bench.py's `large_lattices` record (PGRID kernels, csrc/pgrid.hip)
     "X32": ("holstein", 1, 32, lat.SQUARE_BONDS, 16.0, 0.1),        # square 32 x 32, Ltau = 160: 163 840 unknowns
     "X24": ("holstein", 2, 24, lat.HONEYCOMB_BONDS, 12.0, 0.1),     # honeycomb 24 x 24 cells, Ltau = 120: 138 240 unknowns
+    "XT24": ("holstein", 1, 24, lat.TRIANGULAR_BONDS, 16.0, 0.1),   # triangular 24 x 24, Ltau = 160: 92 160 unknowns
     # a long time axis: 1280 slices (beyond the direct-DFT tables: dft_big.hip)
     "l": ("holstein", 1, 4, lat.SQUARE_BONDS, 128.0, 0.1),
 }
