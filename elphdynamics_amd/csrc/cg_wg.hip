@@ -31,6 +31,7 @@
 #include "cg_fast_common.h"
 
 #include "cg_wg_dev.h"
+#include "pgrid_dev.h"
 
 namespace wg {
 
@@ -48,7 +49,10 @@ __device__ unsigned long long g_wg_arrive[4096 * 4];
 // X0Z: the initial guess is known to be zero (the library zeroed it for this solve): x0 is not read
 template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
-    constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, GR = FORM == 5, HG = FORM == 6, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, TG = FORM == 7, GR = FORM == 5 || TG, HG = FORM == 6, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
+    // (FORM 7, TG: an even-L TRIANGULAR lattice up to 16 x 16 in the GRID layout — the same 2 x 2 patches, the two diagonal colours of
+    //  pgrid::Tri<2, 2> added to the sweep, c^6 where the square lattice takes c^4)
+    static_assert(!TG || !SHARD, "triangular grid form: no shards");
     static_assert(!HG || ((NPL == 2 || NPL == 4 || NPL == 8) && UNI && !SSH && T <= 2), "honeycomb grid form: 1, 2 or 4 cells per lane, uniform hopping, at most two slices per wave");
     static_assert(!GR || (NPL == 4 && UNI && !SSH && T <= 4), "grid form (even-L square lattices, 2 x 2 patches on a G x G lane grid): uniform hopping, at most four slices per wave");
     static_assert(!S8 || (NPL == 1 && UNI && !SSH && !SHARD), "8 x 8 DPP form: one site per lane, uniform hopping");
@@ -213,8 +217,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     S8Ctx X8;
     GridCtx XG;
     HgCtx XHG;
+    pgrid::Ctx XT;
     if constexpr (GR) {
         XG = grid_ctx(lane, GGX, GGY, m.c_uni, m.s_uni);
+        if constexpr (TG) { XT = pgrid::Tri<2, 2>::make_ctx(lane, 2 * GGX, m.c_uni, m.s_uni); XG.k4 = XT.ks; }      // (k4 carries c^6 here)
     } else if constexpr (HG) {
         XHG = hgrid_ctx<NPL>(lane, HLX, HLY, m.c_uni, m.s_uni);
     } else if constexpr (S8) {
@@ -441,7 +447,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             for (int k = 0; k <= T; ++k)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[k][q] = EXPV(k, q) * p[k][q];
-            grid_sweepN<T + 1, false, (T >= 4) ? 1 : 2>(w, XG);
+            if constexpr (TG) {
+#pragma unroll
+                for (int k = 0; k <= T; ++k) pgrid::Tri<2, 2>::apply<false>(w[k], XT);
+            } else grid_sweepN<T + 1, false, (T >= 4) ? 1 : 2>(w, XG);
 #pragma unroll
             for (int k = 0; k <= T; ++k) {
                 const double sg = sgn(wrap(t0 + k)) * XG.k4;
@@ -456,7 +465,10 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 for (int i = 0; i < RBG; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) gq[i][q] = w[j0 + i + 1][q];
-                grid_sweepN<RBG, true, (T >= 4) ? 1 : 2>(gq, XG);
+                if constexpr (TG) {
+#pragma unroll
+                    for (int i = 0; i < RBG; ++i) pgrid::Tri<2, 2>::apply<true>(gq[i], XT);
+                } else grid_sweepN<RBG, true, (T >= 4) ? 1 : 2>(gq, XG);
 #pragma unroll
                 for (int i = 0; i < RBG; ++i) {
                     const double sg = sgn(wrap(t0 + j0 + i + 1)) * XG.k4;
@@ -1052,7 +1064,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 // host side
 // ------------------------------------------------------------------------------------------
 
-struct Shape { int T, W, G; size_t shm; bool sq, hc, s8, gr, hg; int npl; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6; grid form: 4)
+struct Shape { int T, W, G; size_t shm; bool sq, hc, s8, gr, hg; int npl; bool tg = false; };   // npl: sites per lane of the kernel (honeycomb DPP form: 6; grid form: 4)
 
 // DPP form: Holstein on the 16 x 16 square lattice in the reference's colouring (detect_square)
 static bool sq_form(const elph_handle_s *h, const ModelDev &m) {
@@ -1086,6 +1098,13 @@ static bool gr_form(const elph_handle_s *h, const ModelDev &m, bool for_shard = 
     return for_shard || h->sq_P == 0;
 }
 
+// triangular grid form: Holstein with uniform hopping on an even-L triangular lattice of at most 16 x 16 sites in the reference's colouring
+// (detect_triangular: pg_kind 3): the GRID layout with the two diagonal colours (pgrid::Tri<2, 2>)
+static bool tg_form(const elph_handle_s *h, const ModelDev &m) {
+    const char *e = getenv("ELPH_WG_NO_DPP");
+    return h->kind == ELPH_MODEL_HOLSTEIN && h->pg_kind == 3 && h->pg_L >= 4 && h->pg_L <= 16 && m.uniform && m.grid_GX == h->pg_L / 2 && m.grid_GY == h->pg_L / 2 && !(e && e[0] == '1');
+}
+
 // honeycomb grid form: Holstein with uniform hopping on a periodic honeycomb lattice of LX x LY cells in the reference's colouring whose cells
 // fit a grid of lanes (detect_honeycomb: hc_LX, hc_LY; 12 x 12 has a DPP form of its own — which knows no shards).  Returns the registers per
 // lane (2, 4 or 8: 1, 2 x 1 or 2 x 2 cells), 0: no.
@@ -1104,10 +1123,12 @@ static int largest_divisor_le8(int n, int cap = 8) { for (int w = std::min(cap, 
 static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, int nrhs, Shape *out) {
     const int L = (int)h->L;
     const bool ssh = (h->kind == ELPH_MODEL_SSH), sq = sq_form(h, m), hc = !sq && hc_form(h, m), s8 = !sq && !hc && s8_form(h, m);
-    const bool gr = !sq && !hc && !s8 && gr_form(h, m);
+    const bool tg = !sq && !hc && !s8 && tg_form(h, m);
+    const bool gr = !sq && !hc && !s8 && (tg || gr_form(h, m));
     const int hgn = (!sq && !hc && !s8 && !gr) ? hg_form(h, m) : 0;
     const bool hg = hgn > 0;
     const int npl = hc ? HC_NPL : (gr ? 4 : (hg ? hgn : h->npl));
+    if (h->lp_mc != 4 && !tg) return false;               // (a six-colour lattice has no lane-program form here: only the triangular grid form)
     if (!hc && !gr && !hg && h->npl > 5) return false;     // (the lane-program form carries at most 320 sites; elph_wg_usable lets larger honeycomb lattices through for the grid form only)
     // one site per lane (the 8 x 8 lattice: config B): the whole time axis fits ONE workgroup — up to 8 waves of 4, 5 or 8 slices — and
     // a team of one needs no records, no boundary granules, no polls: its meeting is an LDS reduction and a barrier, and a round holds
@@ -1189,7 +1210,7 @@ static bool pick_shape(const elph_handle_s *h, const ModelDev &m, int forceT, in
                             (e_lds ? (hc ? ((size_t)W * T + 1) * HS : (size_t)W * (T + 1) * HS) : 0) + (s_lds ? (size_t)W * wg::SQ_TABS * WAVE : 0) +
                             48 + 4 * HS + ((hc && T >= 3) ? (size_t)W * 2 * HS : 0)) * sizeof(double);   // + partials, totals, rhalo[2][HS], zhalo[2][HS] (+ the halo slices of p)
         if (shm > 160 * 1024) continue;
-        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->s8 = s8; out->gr = gr; out->hg = hg; out->npl = npl;
+        out->T = T; out->W = W; out->G = G; out->shm = shm; out->sq = sq; out->hc = hc; out->s8 = s8; out->gr = gr; out->hg = hg; out->npl = npl; out->tg = tg;
         return true;
     }
     return false;
@@ -1209,6 +1230,7 @@ static const WgCost wg_cost_table[] = {
     {"honeycomb 12x12 DPP (FORM 2)",     2.10, 0.00, 1.70, "profiles/r03/time_forms_D_honeycomb_dpp.log: 3.8 / 5.5 us at 1 / 2 slices; 8.6 us at 3 (time_forms_D_three_slices_per_wave.log)"},
     {"8x8 DPP (FORM 4), team of one",    2.30, 0.00, 0.00, "profiles/r03/time_wg_B_8x8_dpp_form.log: 2.04-2.3 us whatever the batch"},
     {"GRID (FORM 5)",                    2.90, 0.01, 1.35, "profiles/r04/grid_form_even_L_square_lattices.log: L = 12: 4.3 / 5.6 / 10.0 us at 1 / 2 / 4 slices; L = 14, 10: 3.6-4.0 at 1"},
+    {"TGRID (FORM 7, triangular)",       3.20, 0.00, 2.20, "profiles/r04/tgrid_triangular_resident.log: L = 16: 4.9 / 6.7 / 12.4 us at 1 / 2 / 4 slices per wave (4: 69 doubles spilled)"},
     {"HGRID (FORM 6)",                   2.30, 0.01, 1.10, "profiles/r04/hgrid_form_honeycomb_lattices.log: L = 6: 2.5 us (2 registers per lane), L = 10: 3.3-3.8 (4), L = 16: 4.5-5.8 (8); x sites per lane / 4"},
 };
 static const double wg_streaming_cost[3] = {10.0, 0.56, 0.02};   // us: launch floor + nrhs x (0.56 x Ndim / 40960 [x 1.1 for SSH] + 0.02) — profiles/r03/time_forms.log (C: 37 us at 64, 128 at 256)
@@ -1219,8 +1241,9 @@ static double resident_iteration_us(const elph_handle_s *h, const Shape &sh) {
     if (sh.sq && ssh) return wg_cost_table[2].a + wg_cost_table[2].s * sh.T;
     if (sh.hc) return (sh.T == 3) ? 8.6 : wg_cost_table[3].a + wg_cost_table[3].s * sh.T;
     if (sh.sq) return wg_cost_table[1].a + wg_cost_table[1].g * sh.G + wg_cost_table[1].s * sh.T;
+    if (sh.gr && sh.tg) return wg_cost_table[6].a + wg_cost_table[6].g * sh.G + wg_cost_table[6].s * sh.T;
     if (sh.gr) return wg_cost_table[5].a + wg_cost_table[5].g * sh.G + wg_cost_table[5].s * sh.T;
-    if (sh.hg) return wg_cost_table[6].a + wg_cost_table[6].g * sh.G + wg_cost_table[6].s * sh.T * (sh.npl / 4.0);
+    if (sh.hg) return wg_cost_table[7].a + wg_cost_table[7].g * sh.G + wg_cost_table[7].s * sh.T * (sh.npl / 4.0);
     return wg_cost_table[0].a + wg_cost_table[0].g * sh.G + (sh.T >= 4 ? 0.85 : wg_cost_table[0].s) * sh.T * h->npl + ((ssh && sh.T == 2) ? 3.9 : 0.0);
 }
 static double streaming_iteration_us(const elph_handle_s *h, int nrhs) {
@@ -1298,7 +1321,8 @@ bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs) {
     const char *eo = getenv("ELPH_NO_WG");                 // read per call: the tests switch between the two forms
     const bool off = eo && eo[0] == '1';
     // (h->npl > 5: the lane-program form's limit — 320 sites; the honeycomb grid form carries up to 512 in one wave)
-    if (off || !h->fast || h->lp_mc != 4 || (h->npl > 5 && !(h->hc_LX > 0 && !h->hc12 && h->kind == ELPH_MODEL_HOLSTEIN)) || h->dot_hi != 0 || h->solo_chain >= 0) return false;
+    const bool tri_grid = h->kind == ELPH_MODEL_HOLSTEIN && h->pg_kind == 3 && h->pg_L <= 16;      // (a six-colour lattice, but its resident form needs no lane program)
+    if (off || !h->fast || (h->lp_mc != 4 && !tri_grid) || (h->npl > 5 && !(h->hc_LX > 0 && !h->hc12 && h->kind == ELPH_MODEL_HOLSTEIN)) || h->dot_hi != 0 || h->solo_chain >= 0) return false;
     const char *et = getenv("ELPH_WG_T");
     wg::Shape sh;
     if (!wg::pick_shape(h, elph_model_dev(h), et ? atoi(et) : 0, nrhs, &sh)) return false;
@@ -1391,6 +1415,9 @@ int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iter
             case 4: e = (sh.T == 2) ? wg::launch_k<4, 2, false, true, 6>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 6>(h, sh, grid, B, m, R); break;
             default: e = (sh.T == 2) ? wg::launch_k<8, 2, false, true, 6>(h, sh, grid, B, m, R) : wg::launch_k<8, 1, false, true, 6>(h, sh, grid, B, m, R); break;
         }
+    } else if (sh.gr && sh.tg) {
+        e = (sh.T == 4) ? wg::launch_k<4, 4, false, true, 7>(h, sh, grid, B, m, R)
+          : (sh.T == 2) ? wg::launch_k<4, 2, false, true, 7>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 7>(h, sh, grid, B, m, R);
     } else if (sh.gr) {
         e = (sh.T == 4) ? wg::launch_k<4, 4, false, true, 5>(h, sh, grid, B, m, R)
           : (sh.T == 2) ? wg::launch_k<4, 2, false, true, 5>(h, sh, grid, B, m, R) : wg::launch_k<4, 1, false, true, 5>(h, sh, grid, B, m, R);

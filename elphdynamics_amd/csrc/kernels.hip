@@ -975,6 +975,7 @@ ModelDev elph_model_dev(const elph_handle_s *h) {
     m.uniform = 0; m.c_uni = 1.0; m.s_uni = 0.0;
     m.sq_bond = (h->sq_L > 0) ? h->d_sq_bond : nullptr;
     m.grid_GX = h->sq_LX / 2; m.grid_GY = h->sq_LY / 2;
+    if (h->pg_kind == 3 && h->pg_L <= 16) m.grid_GX = m.grid_GY = h->pg_L / 2;      // an even-L triangular lattice: the same grid of 2 x 2 patches (cg_wg.hip: FORM 7)
     m.hc_LX = h->hc_LX; m.hc_LY = h->hc_LY;
     if (h->kind == ELPH_MODEL_HOLSTEIN && h->nb > 0) {
         bool uni = true;

@@ -1428,7 +1428,7 @@ def _wg_info(m, nrhs=1):
     return us.value, T.value, W.value, G.value
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "e", "B", "C", "D", "E", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W"])
+@pytest.mark.parametrize("tag", ["b", "d", "e", "B", "C", "D", "E", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "u", "T", "t6", "t12"])
 def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
     """The whole solve in one launch (Krylov vectors in registers / LDS, teams of workgroups meeting through L2) against the
     streaming two-kernel iteration: same algorithm, different summation trees for p.z and r.r — same iteration count up to
@@ -1457,6 +1457,9 @@ def test_wg_resident_cg_equals_the_two_kernel_iteration(tag, monkeypatch):
         variants += [{"ELPH_WG_T": "4"}, {"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
     if tag in ("D", "E"):   # honeycomb (mirror lanes) / bond phonons (a table set per time slice): the DPP form is the default, the lane-program form the A/B
         variants += [{"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "2"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
+    if tag in ("u", "T", "t6", "t12"):   # triangular lattices: the GRID layout with two diagonal colours (FORM 7); no lane-program form to compare with
+        if tag in ("T", "t12"):
+            variants += [{"ELPH_WG_T": "4"}]
     if tag in ("b", "s", "q", "Q", "S", "d", "y", "z", "r", "R", "w", "W"):   # the GRID / HGRID forms (other even-L square lattices, other honeycomb lattices on a grid of lanes) and their lane-program A/B
         variants += [{"ELPH_WG_NO_DPP": "1"}, {"ELPH_WG_NO_DPP": "1", "ELPH_WG_T": "1"}]
         if tag in ("S", "Q"):          # 4 slices per wave: the shape of batches beyond one round of 2 (time axes that are multiples of 4)
