@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(WAVE) k_kpm_bounds(double *__restrict__ e_out 
                                                     const double *__restrict__ bstart /*[2][nch][N]: b_max, b_min*/, const int *__restrict__ bi,
                                                     const int *__restrict__ bj, const int *__restrict__ coloff, int ncol,
                                                     const double *__restrict__ cbar, const double *__restrict__ sbar, long long hop_stride,
-                                                    int N, int n, int nch) {
+                                                    int N, int n, int nch, int nb_lds) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NS = NPL * WAVE;
     const int lane = threadIdx.x, chain = blockIdx.x;
@@ -221,6 +221,15 @@ __global__ void __launch_bounds__(WAVE) k_kpm_bounds(double *__restrict__ e_out 
     double *Awork = H + (size_t)(n + 1) * n;          // [n][n]
     const double *eb_g = Ebar + (size_t)chain * N;
     const double *cb = cbar + (size_t)chain * hop_stride, *sb = sbar + (size_t)chain * hop_stride;
+    // the bond program of the checkerboard -> LDS (nb_lds = number of bonds when the host found room for it): an Arnoldi step walks it once,
+    // colour by colour, a dependent chain of loads — from L2 that was most of a step
+    if (nb_lds > 0) {
+        double *lcb = Awork + (size_t)n * n, *lsb = lcb + nb_lds;
+        int *lbi = reinterpret_cast<int *>(lsb + nb_lds), *lbj = lbi + nb_lds;
+        for (int b = lane; b < nb_lds; b += WAVE) { lcb[b] = cb[b]; lsb[b] = sb[b]; lbi[b] = bi[b]; lbj[b] = bj[b]; }
+        LDS_ORDER();
+        cb = lcb; sb = lsb; bi = lbi; bj = lbj;
+    }
     const double *b0 = bstart + ((size_t)(inverse ? 1 : 0) * nch + chain) * N;
     double eb[NPL], b[NPL], v[NPL];
     bool live[NPL];
@@ -300,8 +309,13 @@ int elph_kpm_bounds_dev(elph_handle_s *h, int nch, const double *d_bstart, doubl
     if (n > 64) return ELPH_E_UNSUPPORTED;
     const int npl = (N + WAVE - 1) / WAVE;
     const size_t NS = (size_t)npl * WAVE;
-    const size_t shm = ((size_t)(n + 1) * NS + NS + (size_t)(n + 1) * n + (size_t)n * n + 8) * sizeof(double);
+    size_t shm = ((size_t)(n + 1) * NS + NS + (size_t)(n + 1) * n + (size_t)n * n + 8) * sizeof(double);
     if (shm > 160 * 1024) return ELPH_E_UNSUPPORTED;
+    int nb_lds = 0;                                   // the bond program in LDS too, where it fits (64 KB of the 160 are plenty for 8 waves per CU)
+    {
+        const size_t extra = (size_t)h->nb * (2 * sizeof(double) + 2 * sizeof(int)) + 16;
+        if (h->nb > 0 && shm + extra <= 64 * 1024) { shm += extra; nb_lds = (int)h->nb; }
+    }
     const long long hop_stride = h->kpm_hop_per_chain ? (long long)h->nb : 0;
     const dim3 grid((unsigned)nch, 2), block(WAVE);
 #define KB_LAUNCH(NPLV)                                                                                                              \
@@ -309,7 +323,7 @@ int elph_kpm_bounds_dev(elph_handle_s *h, int nch, const double *d_bstart, doubl
         hipError_t e = hipFuncSetAttribute((const void *)kd::k_kpm_bounds<NPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
         if (e != hipSuccess) { elph_set_error("k_kpm_bounds: %s", hipGetErrorString(e)); return ELPH_E_HIP; }                         \
         hipLaunchKernelGGL((kd::k_kpm_bounds<NPLV>), grid, block, shm, h->stream, d_eout, h->d_Ebar, d_bstart, h->d_bi, h->d_bj,       \
-                           h->d_coloff, h->ncol, h->d_cbar, h->d_sbar, hop_stride, N, n, nch);                                        \
+                           h->d_coloff, h->ncol, h->d_cbar, h->d_sbar, hop_stride, N, n, nch, nb_lds);                                \
     }
     switch (npl) {
         case 1: KB_LAUNCH(1); break;
