@@ -383,7 +383,7 @@ def main():
         # un-preconditioned iteration
         if not args.no_sweep and rank == 0 and args.config == "C" and resident:
             other = {}
-            for tag in ("B", "D", "E"):
+            for tag in ("B", "D", "E", "T"):      # (T: the triangular deck's geometry at config C's size — the resident form of round 4)
                 try:
                     mo_ = configs.make_model(tag, tol=1e-5, device=comm.device_index())
                     _, Bo = configs.rhs(mo_, 256)
