@@ -1087,6 +1087,36 @@ def test_kpm_patch_recursion_equals_the_generic_recursion(tag, monkeypatch):
     m.close()
 
 
+@pytest.mark.parametrize("tag", ["k", "i", "t12", "t20", "u"])
+def test_patch_matvec_kernels_on_lattices_of_the_lane_program_family(oracle, tag, monkeypatch):
+    """L = 18 / 20 square and triangular lattices up to L = 22 still fit the lane-program family, which brings its own mat-vec kernels — the
+    patch-layout ones (k_mul_pg, k_cg_ap_pg with 2 x 4 / 2 x 2 patches and the triangular 2 x 4) would never run on them.  With the family
+    switched off (ELPH_NO_FAST=1, read when the handle is created) they do: mat-vecs, a batched solve and a preconditioned solve against
+    the oracle."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    monkeypatch.setenv("ELPH_NO_FAST", "1")
+    m = configs.make_model(tag, tol=1e-9)
+    om = _oracle_model(oracle, m)
+    v = synth.randn(5, m.Ndim)
+    y = np.empty(m.Ndim)
+    for fn, ofn in ((models.mulM_, oracle.mulM), (models.mulMt_, oracle.mulMT), (models.mulMtM_, oracle.mulMTM)):
+        fn(y, m, v)
+        assert rel(y, ofn(om, v)) < 1e-13
+    R, B = configs.rhs(m, 3)
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    assert not fl.any()
+    for r in range(3):
+        xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(B[r]), solver_tol=1e-9, solver_maxiter=10000)
+        assert flo == 0 and abs(int(it[r]) - ito) <= 2 and rel(X[r], xo) < 1e-6
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_(P, rng=np.random.default_rng(3))
+    xk = np.zeros(m.Ndim)
+    itk, resk, flk = models.ldiv_(xk, m, np.ascontiguousarray(B[0]), P=P)
+    assert flk == 0 and rel(xk, X[0]) < 1e-6
+    m.close()
+
+
 @pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2), ("D", 4, 2),
                                              ("G", 3, 2), ("h", 2, 2)])      # (G, h: the PGRID kernels, one expansion per chain)
 def test_kpm_preconditioner_per_chain(tag, nchains, per, monkeypatch):
