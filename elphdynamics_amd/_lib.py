@@ -16,6 +16,7 @@ P_i64, P_dbl, P_int = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c
 Handle = C.c_void_p
 
 ELPH_OK = 0
+ABI_VERSION = 2          # include/elph_gpu.h: ELPH_ABI_VERSION this binding was written against (checked exactly at load)
 ELPH_E_ARG, ELPH_E_HIP, ELPH_E_STATE, ELPH_E_NOGPU, ELPH_E_UNSUPPORTED = -1, -2, -3, -4, -5
 ERRORS = {-1: "ELPH_E_ARG", -2: "ELPH_E_HIP", -3: "ELPH_E_STATE", -4: "ELPH_E_NOGPU", -5: "ELPH_E_UNSUPPORTED"}
 
@@ -53,6 +54,11 @@ SIGNATURES = {
                                             P_i64, P_int]),
     "elph_fermion_force_ssh": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
     "elph_fermion_force_ssh_fields": (c_int, [Handle, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl, P_dbl, P_i64, P_int]),
+    "elph_muldMdx_holstein": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl]),
+    "elph_muldMdx_holstein_dev": (c_int, [Handle, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P_dbl, P_dbl, c_dbl]),
+    "elph_muldMdx_ssh": (c_int, [Handle, P_dbl, P_dbl, P_dbl]),
+    "elph_muldMdx_ssh_fields": (c_int, [Handle, P_dbl, P_dbl, P_dbl]),
+    "elph_muldMdx_ssh_fields_dev": (c_int, [Handle, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elph_hmc_create": (c_int, [Handle, P_dbl, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl]),
     "elph_hmc_set_state": (c_int, [Handle, P_dbl, P_dbl]),
     "elph_hmc_get_state": (c_int, [Handle, P_dbl, P_dbl]),
@@ -139,6 +145,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError here == ABI mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.elph_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path} speaks ABI {lib.elph_abi_version()}, this binding was written for {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 

@@ -10,6 +10,7 @@ the code that ran was made from.
 import hashlib
 import json
 import os
+import re
 import shutil
 import subprocess
 import time
@@ -52,6 +53,12 @@ def _sha(paths, extra=""):
     return h.hexdigest()
 
 
+def abi_version():
+    """ELPH_ABI_VERSION as include/elph_gpu.h defines it: the one place the number lives."""
+    with open(os.path.join(HERE, "..", "include", "elph_gpu.h")) as f:
+        return int(re.search(r"^#define ELPH_ABI_VERSION (\d+)", f.read(), re.M).group(1))
+
+
 def source_hash():
     """sha256 over every source and header the library is made from (names + contents), first 16 hex digits."""
     return _sha([os.path.join(CSRC, s) for s in SOURCES] + _headers())[:16]
@@ -85,9 +92,10 @@ def library_build_info(path=None):
             blob = f.read()
     except OSError:
         return None
-    i = blob.find(b"libelphgpu abi=1 src=")
-    if i < 0:
+    m = re.search(rb"libelphgpu abi=\d+ src=", blob)
+    if not m:
         return None
+    i = m.start()
     j = blob.find(b"\0", i)
     return blob[i:j].decode(errors="replace")
 
@@ -175,7 +183,7 @@ def build_library(force=False, verbose=False, lds_sync_variant=True):
         info_c = os.path.join(OBJDIR, f"build_info_{variant}.cpp")
         info_o = info_c[:-4] + ".o"
         stamp = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())
-        text = (f"libelphgpu abi=1 src={src_hash} arch={ARCH} variant={variant} built={stamp} flags={'_'.join(FLAGS[1:])} "
+        text = (f"libelphgpu abi={abi_version()} src={src_hash} arch={ARCH} variant={variant} built={stamp} flags={'_'.join(FLAGS[1:])} "
                 f"compiler=[{cid}]")
         with open(info_c, "w") as f:
             f.write('extern "C" const char elph_build_info_text[] = ' + json.dumps(text) + ";\n")

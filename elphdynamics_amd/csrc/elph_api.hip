@@ -1223,6 +1223,112 @@ extern "C" int elph_fermion_force_ssh_fields(elph_handle h, const double *rhs_pl
 }
 
 // ------------------------------------------------------------------------------------------
+// muldMdx!(dMdx, u, model, v): ⟨∂M/∂x⟩ = uᵀ(∂M/∂x)v per field, for caller-given u and v — the operator calc_dSfdx! (HMC.jl:799,804)
+// and LangevinDynamics.calc_dSfdx! (:378) call; HolsteinModels.jl:691-755, SSHModels.jl:707-829
+// ------------------------------------------------------------------------------------------
+
+// u, v, x, dMdx: device pointers, reference layout; lambda, lambda2: host double[nsites]
+extern "C" int elph_muldMdx_holstein_dev(elph_handle h, double *dMdx_dev, const double *u_dev, const double *v_dev, const double *x_dev,
+                                         const double *lambda, const double *lambda2, double dtau) {
+    CHECK_H(h);
+    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
+    RC(need_model(h));
+    if (!dMdx_dev || !u_dev || !v_dev || !x_dev || !lambda || !lambda2) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    if (h->nchains != 1) { elph_set_error("muldMdx! acts on one phonon configuration; the handle holds %d chains", h->nchains); return ELPH_E_STATE; }
+    RC(ensure_capacity(h, 2));
+    const size_t nd = (size_t)h->ndim, N = (size_t)h->N;
+    HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RC(elph_launch_r2s(h, h->d_xfield, x_dev, 1));
+    RC(elph_launch_r2s(h, h->d_b, u_dev, 1));
+    RC(elph_launch_r2s(h, h->d_b + nd, v_dev, 1));
+    RC(elph_launch_dmdx_holstein(h, h->d_tmp, h->d_b, h->d_b + nd, h->d_xfield, dtau, 1.0));
+    RC(elph_launch_s2r(h, dMdx_dev, h->d_tmp, 1));
+    HIPCHK(hipStreamSynchronize(h->stream));           // lambda / lambda2 are the caller's host arrays
+    return ELPH_OK;
+}
+
+extern "C" int elph_muldMdx_holstein(elph_handle h, double *dMdx, const double *u, const double *v, const double *x,
+                                     const double *lambda, const double *lambda2, double dtau) {
+    CHECK_H(h);
+    if (!dMdx || !u || !v || !x) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ensure_capacity(h, 3));                         // stage_in: u, v, x
+    const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, u, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, v, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in + 2 * nd, x, bytes, hipMemcpyHostToDevice, h->stream));
+    RC(elph_muldMdx_holstein_dev(h, h->d_stage_out, h->d_stage_in, h->d_stage_in + nd, h->d_stage_in + 2 * nd, lambda, lambda2, dtau));
+    HIPCHK(hipMemcpyAsync(dMdx, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// the bond brackets q[tau][n] of muldMdx!(·, u, ssh, v) left in h->d_p (u, v: device, reference layout)
+static int ssh_dmdx_core(elph_handle_s *h, const double *u_dev, const double *v_dev) {
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    RC(need_model(h));
+    if (!u_dev || !v_dev) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    if (h->nchains != 1) { elph_set_error("muldMdx! acts on one phonon configuration; the handle holds %d chains", h->nchains); return ELPH_E_STATE; }
+    RC(ensure_capacity(h, 2));
+    const size_t nd = (size_t)h->ndim, nq = (size_t)h->L * (size_t)h->nb;
+    if (nq > 2 * nd) { elph_set_error("more bonds than 2*nsites: scratch too small"); return ELPH_E_UNSUPPORTED; }
+    RC(elph_launch_r2s(h, h->d_b, u_dev, 1));
+    RC(elph_launch_r2s(h, h->d_b + nd, v_dev, 1));
+    return elph_launch_force_ssh(h, h->d_p, h->d_b + nd, h->d_b, 1);      // b0 = e^{Δτμ} v(τ−1), c0 = CBᵀ u
+}
+
+static int ssh_dmdx_stage(elph_handle_s *h, const double *u, const double *v) {
+    if (!u || !v) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ensure_capacity(h, 2));
+    const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, u, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, v, bytes, hipMemcpyHostToDevice, h->stream));
+    return ssh_dmdx_core(h, h->d_stage_in, h->d_stage_in + nd);
+}
+
+extern "C" int elph_muldMdx_ssh(elph_handle h, double *q_out, const double *u, const double *v) {
+    CHECK_H(h);
+    if (!q_out) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ssh_dmdx_stage(h, u, v));
+    const size_t L = (size_t)h->L, nb = (size_t)h->nb, nq = L * nb;
+    std::vector<double> qt(nq);
+    if (nq) HIPCHK(hipMemcpyAsync(qt.data(), h->d_p, nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t t = 0; t < L; ++t)
+        for (size_t n = 0; n < nb; ++n) q_out[n * L + t] = qt[t * nb + n];
+    return ELPH_OK;
+}
+
+static int ssh_dmdx_fields(elph_handle_s *h, double **dF, size_t *nf) {
+    if (!h->cs_host_stale || h->ssh_nph < 0) { elph_set_error("elph_update_model_ssh_fields has not been called for the current field"); return ELPH_E_STATE; }
+    *nf = (size_t)h->ssh_nph * (size_t)h->L;
+    *dF = h->d_tmp;
+    if (*nf > (size_t)h->cap_rhs * (size_t)h->ndim) { elph_set_error("more phonon fields than scratch"); return ELPH_E_UNSUPPORTED; }
+    return elph_launch_ssh_scatter(h, *dF, h->d_p, h->d_ssh_x, h->d_ssh_par, h->d_ssh_cb, h->ssh_nph, h->ssh_dtau);
+}
+
+extern "C" int elph_muldMdx_ssh_fields(elph_handle h, double *dMdx, const double *u, const double *v) {
+    CHECK_H(h);
+    if (!dMdx) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ssh_dmdx_stage(h, u, v));
+    double *dF = nullptr; size_t nf = 0;
+    RC(ssh_dmdx_fields(h, &dF, &nf));
+    if (nf) HIPCHK(hipMemcpyAsync(dMdx, dF, nf * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+extern "C" int elph_muldMdx_ssh_fields_dev(elph_handle h, double *dMdx_dev, const double *u_dev, const double *v_dev) {
+    CHECK_H(h);
+    if (!dMdx_dev) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    RC(ssh_dmdx_core(h, u_dev, v_dev));
+    double *dF = nullptr; size_t nf = 0;
+    RC(ssh_dmdx_fields(h, &dF, &nf));
+    if (nf) HIPCHK(hipMemcpyAsync(dMdx_dev, dF, nf * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return ELPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // KPM preconditioner
 // ------------------------------------------------------------------------------------------
 

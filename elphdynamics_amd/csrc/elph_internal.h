@@ -22,7 +22,6 @@
 #include "../../include/elph_gpu.h"
 #include "elph_bench.h"
 
-#define ELPH_ABI_VERSION 1
 #define ELPH_WAVE 64
 #define ELPH_MAX_NPL 8          // sites per thread
 #define ELPH_MAX_SITES 8192      // generic kernels: workgroups of up to 1024 threads x 8 sites

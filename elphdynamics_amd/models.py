@@ -351,6 +351,28 @@ def transpose_(model):
     model.transposed = not model.transposed
 
 
+def muldMdx_(dMdx, u, model, v):
+    """muldMdx!(dMdx, u, model, v): dMdx[field] = uᵀ(∂M/∂x_field)v — HolsteinModels.jl:691-755 (dMdx: Ndim) / SSHModels.jl:707-829
+    (dMdx: Ndof = Nph·Lτ, equivalent fields summed and copied as at :820-826).  The matrix is that of the last update_model_."""
+    _vec(u, model.Ndim), _vec(v, model.Ndim)
+    if model.kind == HOLSTEIN:
+        check(model._lib.elph_muldMdx_holstein(model._h, dptr(_vec(dMdx, model.Ndim)), dptr(u), dptr(v), dptr(np.ascontiguousarray(model.x)),
+                                               dptr(model.lam), dptr(model.lam2), model.dtau))
+        return
+    _vec(dMdx, model.Ndof)
+    if model.Nph == 0:
+        return
+    raw = np.empty(model.Ndof)
+    check(model._lib.elph_muldMdx_ssh_fields(model._h, dptr(raw), dptr(u), dptr(v)))
+    pf = getattr(model, "primary_field", None)
+    if pf is None:
+        dMdx[:] = raw
+    else:                                            # primary field of every field (SSHModels.jl:480-502), 0-based here
+        acc = np.zeros(model.Ndof)
+        np.add.at(acc, pf, raw)                      # dMdx[primary_field[field]] += dmdx  (:817)
+        dMdx[:] = acc[pf]                            # @. dMdx = dMdx[primary_field]      (:826)
+
+
 # ----------------------------------------------------------------------------------------------
 # solvers
 # ----------------------------------------------------------------------------------------------

@@ -44,9 +44,13 @@ typedef struct elph_handle_s *elph_handle;
 /* Text of the last error on this thread (never NULL). */
 const char *elph_last_error(void);
 
-/* ABI version of the loaded library (for the Julia wrapper's sanity check). */
+/* ABI version this header describes.  Bumped whenever an entry point is removed or changes meaning (2: round 4 removed the
+ * elph_cgstep_*, elph_dev_buffer, elph_buffer_* exports and round 5 added elph_muldMdx_*); loaders check for EXACTLY the version they
+ * were written against (julia/ElPhGPU.jl, elphdynamics_amd/_lib.py). */
+#define ELPH_ABI_VERSION 2
+/* ABI version of the loaded library. */
 int elph_abi_version(void);
-/* How this library was built: "libelphgpu abi=1 src=<sha256 of csrc/ + include/, 16 hex digits> arch=gfx950 variant=... built=<UTC>
+/* How this library was built: "libelphgpu abi=<ELPH_ABI_VERSION> src=<sha256 of csrc/ + include/, 16 hex digits> arch=gfx950 variant=... built=<UTC>
  * flags=... compiler=[hipcc --version]" — static storage.  elphdynamics_amd/build.py compares `src` with the sources at hand: a stale
  * shipped library is rebuilt, a current one reused; smoke() and bench.py print it so that a run's log names the code that ran. */
 const char *elph_build_info(void);
@@ -206,6 +210,26 @@ int elph_fermion_force_ssh(elph_handle h, const double *rhs_plus, const double *
  * accumulated into. */
 int elph_fermion_force_ssh_fields(elph_handle h, const double *rhs_plus, const double *rhs_minus, int use_precond,
                                   double tol_power, double *dSdx, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
+
+/* muldMdx!(dMdx, u, model, v): dMdx[field] = uᵀ·(∂M/∂x_field)·v for caller-given u and v — the L3 operator that calc_dSfdx! applies
+ * to (u, v) = (M·O⁻¹Λϕ±, O⁻¹Λϕ±) (HMC.jl:799,804) and LangevinDynamics.calc_dSfdx! to (g, M⁻¹g) (:378).  The matrix is the handle's
+ * current one (the last update_model).
+ *   Holstein (HolsteinModels.jl:691-755): dMdx[i,τ] = [CBᵀu](i,τ) · sg(τ) Δτ (λ_i + 2 λ₂_i x(i,τ)) e^{-ΔτV}(i,τ) · v(i,τ−1), sg(1) = −1 with
+ *   v(i,0) = v(i,Lτ); x, u, v, dMdx: double[Ndim], reference layout; lambda, lambda2: double[nsites] (host arrays in both forms). */
+int elph_muldMdx_holstein(elph_handle h, double *dMdx, const double *u, const double *v, const double *x,
+                          const double *lambda, const double *lambda2, double dtau);
+int elph_muldMdx_holstein_dev(elph_handle h, double *dMdx_dev, const double *u_dev, const double *v_dev, const double *x_dev,
+                              const double *lambda, const double *lambda2, double dtau);
+/*   SSH (SSHModels.jl:707-829), bond-local part: q_out[n·Lτ + τ] = c_j b_i + c_i b_j for checkerboard bond n (τ fastest) with
+ *   b = the partial forward product of e^{Δτμ}v(τ−1), c = the partial inverse product of CBᵀu, both after bond n (:775-806), so that
+ *   dMdx[primary_field[field(phonon(n), τ)]] += sg(τ) Δτ (α + 2 α₂ x) q_out[...]  (:797-823) is the caller's scatter — as for
+ *   elph_fermion_force_ssh.  Works after either elph_update_model_ssh or elph_update_model_ssh_fields. */
+int elph_muldMdx_ssh(elph_handle h, double *q_out, const double *u, const double *v);
+/*   SSH with the scatter on the device, for the fields, couplings and bond positions of the last elph_update_model_ssh_fields:
+ *   dMdx[(p−1)·Lτ + τ] = sg(τ) Δτ (α_p + 2 α₂_p x) q[τ][bond(p)], double[nph·Lτ]; the primary_field sum over equivalent fields
+ *   (:820-826) stays with the caller. */
+int elph_muldMdx_ssh_fields(elph_handle h, double *dMdx, const double *u, const double *v);
+int elph_muldMdx_ssh_fields_dev(elph_handle h, double *dMdx_dev, const double *u_dev, const double *v_dev);
 
 /* ---------------------------------------------------------------- HMC trajectory */
 

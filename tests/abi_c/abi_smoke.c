@@ -10,6 +10,7 @@
  *   elph_kpm_create / _setup       SymmetricKPMPreconditioner, setup!(P)           KPMPreconditioners.jl:219-235,259-321
  *   elph_kpm_orders / _apply       P.order, ldiv!(z, P, r)                         KPMPreconditioners.jl:296-308,426-481
  *   elph_ldiv(use_precond = 1)     ldiv!(x, model, b, P)                           Models.jl:74-137
+ *   elph_muldMdx_holstein          muldMdx!(dMdx, u, model, v)                     HolsteinModels.jl:691-755
  *   elph_destroy                   finalizer
  * against the golden vectors of tests/golden/ (independent dense numpy/scipy restatement), exported to a flat binary by
  * tests/abi_c/export_fixture.py.  Exit code 0 and a last line "ABI SMOKE OK" on success; any mismatch prints what and exits 1.
@@ -70,7 +71,7 @@ int main(int argc, char **argv) {
     (void)E;
 
     printf("abi version %d; devices %d\n%s\n", elph_abi_version(), elph_device_count(), elph_build_info());
-    if (elph_abi_version() != 1) { fprintf(stderr, "unexpected ABI version\n"); return 1; }
+    if (elph_abi_version() != ELPH_ABI_VERSION) { fprintf(stderr, "unexpected ABI version\n"); return 1; }
     if (elph_device_count() < 1) { fprintf(stderr, "no HIP device: the library has no CPU path\n"); return 3; }
 
     elph_handle h = NULL;
@@ -131,6 +132,33 @@ int main(int argc, char **argv) {
     printf("  ldiv!(…, P): %lld iterations (plain: %lld), residual %.2e, flag %d\n", (long long)iters, (long long)iters_plain, resid, flag);
     if (flag != 0) ++failures;
     expect("ldiv!(…, P) vs dense solve", rel_err(y, xsol, ndim), 1e-10);
+
+    /* muldMdx!(dMdx, u, model, v) — HolsteinModels.jl:691-755, the operator calc_dSfdx! applies (HMC.jl:799,804) — against its own
+     * definition: dMdx[f] = d/dx_f (u . M(x) v), central difference through update_model! + mulM! of this same ABI (u = b, v = v) */
+    {
+        double *d = (double *)calloc((size_t)ndim, sizeof(double)), *xp = (double *)malloc(sizeof(double) * (size_t)ndim);
+        CHECK_RC(elph_update_model_holstein(h, x, lam, lam2, mu, dtau));
+        CHECK_RC(elph_muldMdx_holstein(h, d, b, v, x, lam, lam2, dtau));
+        const int64_t probe[4] = {0, L - 1, ndim / 2 + 1, ndim - 1};
+        const double eps = 1e-6;
+        double worst = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            double s[2];
+            for (int sg = 0; sg < 2; ++sg) {
+                memcpy(xp, x, sizeof(double) * (size_t)ndim);
+                xp[probe[k]] += sg ? -eps : eps;
+                CHECK_RC(elph_update_model_holstein(h, xp, lam, lam2, mu, dtau));
+                CHECK_RC(elph_mulM(h, y, v));
+                s[sg] = 0.0;
+                for (int64_t i = 0; i < ndim; ++i) s[sg] += b[i] * y[i];
+            }
+            const double fd = (s[0] - s[1]) / (2 * eps), err = fabs(fd - d[probe[k]]) / fmax(1.0, fabs(fd));
+            if (err > worst) worst = err;
+        }
+        expect("muldMdx! vs d(u.Mv)/dx (4 fields)", worst, 1e-7);
+        CHECK_RC(elph_update_model_holstein(h, x, lam, lam2, mu, dtau));
+        free(d); free(xp);
+    }
 
     /* usage errors come back as codes with a message, never as a crash */
     {

@@ -769,6 +769,74 @@ def gen_greens(h, tag, norb, Lsp, seed, nv=3):
     save(f"greens_{tag}.npz", **out)
 
 
+# ----------------------------------------------------------------------------- muldMdx! (HolsteinModels.jl:691-755, SSHModels.jl:707-829)
+def _dense_M_c(N, L, cb_of_tau, E):
+    """dense_M for complex hoppings / potentials (complex-step differentiation)."""
+    M = np.eye(N * L, dtype=complex)
+    for t in range(L):
+        B = cb_of_tau(t) @ np.diag(E[:, t])
+        tm1 = (t - 1) % L
+        sign = +1.0 if t == 0 else -1.0
+        rows = np.arange(N) * L + t
+        cols = np.arange(N) * L + tm1
+        M[np.ix_(rows, cols)] += sign * B
+    return M
+
+
+def _dense_cb_c(N, table, c, s):
+    CB = np.eye(N, dtype=complex)
+    for n in range(table.shape[0]):
+        i, j = table[n, 0] - 1, table[n, 1] - 1
+        B = np.eye(N, dtype=complex)
+        B[i, i] = B[j, j] = c[n]
+        B[i, j] = B[j, i] = s[n]
+        CB = B @ CB
+    return CB
+
+
+def gen_dmdx(step=1e-30):
+    """dMdx[f] = uᵀ (∂M/∂x_f) v from the DEFINITION of the derivative: M is analytic in every field x_f (Holstein: through
+    exp(-Δτ(λx + λ₂x² − μ)); SSH with α₂ = 0: through cosh/sinh(Δτ(t − αx))), so Im[uᵀ M(x + i·step·e_f) v] / step is ∂/∂x_f of uᵀMv to
+    machine precision — no loop of the reference's muldMdx! (nor of the oracle's) is restated here.  Inputs are those of
+    holstein_sq4_L8.npz / ssh_sq4_L8_a.npz."""
+    g = np.load(os.path.join(HERE, "holstein_sq4_L8.npz"))
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    u, v = synth.randn(901, N * L), synth.randn(902, N * L)
+    CB = dense_cb(N, g["table"], g["cosht"], g["sinht"]).astype(complex)
+    lam, lam2, mu = g["lam"], g["lam2"], g["mu"]
+    d = np.zeros(N * L)
+    for f in range(N * L):
+        x = g["x"].astype(complex)
+        x[f] += 1j * step
+        X = x.reshape(N, L)
+        E = np.exp(-dtau * (lam[:, None] * X + lam2[:, None] * X ** 2 - mu[:, None]))
+        d[f] = (u @ (_dense_M_c(N, L, lambda tau: CB, E) @ v)).imag / step
+    save("muldmdx_sq4_L8.npz", u=u, v=v, dMdx=d)
+
+    g = np.load(os.path.join(HERE, "ssh_sq4_L8_a.npz"))
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    nb = g["table"].shape[0]
+    assert not np.any(g["alpha2"])
+    u, v = synth.randn(903, N * L), synth.randn(904, N * L)
+    cbp, p2b = g["cbperm"], g["phonon_to_bond"]
+    E = np.repeat(np.asarray(g["expDtauMu"], dtype=complex)[:, None], L, axis=1)
+    nph = p2b.shape[0]
+    d = np.zeros(nph * L)
+    for f in range(nph * L):
+        x = g["x"].astype(complex)
+        x[f] += 1j * step
+        X = x.reshape(nph, L)
+        tp = np.asarray(g["t"], dtype=complex)[:, None] * np.ones((1, L))          # raw bond order
+        tp[p2b - 1] -= g["alpha"][p2b - 1][:, None] * X
+        c = np.zeros((nb, L), dtype=complex)
+        s = np.zeros((nb, L), dtype=complex)
+        c[cbp - 1] = np.cosh(dtau * tp)
+        s[cbp - 1] = np.sinh(dtau * tp)
+        M = _dense_M_c(N, L, lambda tau: _dense_cb_c(N, g["table"], c[:, tau], s[:, tau]), E)
+        d[f] = (u @ (M @ v)).imag / step
+    save("muldmdx_ssh_sq4_L8_a.npz", u=u, v=v, dMdx=d)
+
+
 if __name__ == "__main__":
     gen_tables()
     h1 = gen_holstein("sq4_L8", 1, 4, SQUARE, 8, 0.1, seed=11)
@@ -792,3 +860,4 @@ if __name__ == "__main__":
     gen_special(h1, "sq4_L8", seed=81)
     h2 = gen_holstein("sq4_L40", 1, 4, SQUARE, 40, 0.1, seed=55)
     gen_kpm(h2, "sq4_L40")
+    gen_dmdx()

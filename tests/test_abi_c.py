@@ -47,7 +47,7 @@ def test_c_program_links_and_refuses_without_a_gpu(tmp_path):
         pytest.skip("a GPU is visible here: the GPU test runs the program in full")
     exe = _build(tmp_path)
     p = subprocess.run([exe, FIX], capture_output=True, text=True, timeout=120)
-    assert p.returncode == 3 and "no CPU path" in p.stderr and "libelphgpu abi=1 src=" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-500:])
+    assert p.returncode == 3 and "no CPU path" in p.stderr and "libelphgpu abi=2 src=" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-500:])
 
 
 @pytest.mark.gpu

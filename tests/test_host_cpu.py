@@ -76,7 +76,7 @@ def test_abi_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared | hooks:
         assert hasattr(lib, name)
-    assert lib.elph_abi_version() == 1
+    assert lib.elph_abi_version() == _lib.ABI_VERSION == 2
     assert isinstance(lib.elph_last_error(), bytes)
 
 

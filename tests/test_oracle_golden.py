@@ -154,6 +154,34 @@ def test_ssh_matvec_and_solve(oracle):
     assert rel(x, g["xsol"]) < 1e-9
 
 
+def test_muldMdx_holstein_is_the_derivative_of_uMv(oracle):
+    """elpho_muldMdx_holstein (HolsteinModels.jl:691-755) against ∂(uᵀMv)/∂x_f from complex-step differentiation of the dense M
+    (tests/golden/make_golden.py::gen_dmdx — the definition, not a loop restatement)."""
+    g, d = golden("holstein_sq4_L8.npz"), golden("muldmdx_sq4_L8.npz")
+    m, N, L = _holstein_model(oracle, g)
+    out = np.zeros(N * L)
+    oracle.lib.elpho_muldMdx_holstein(dp(out), dp(np.ascontiguousarray(d["u"])), C.byref(m), dp(np.ascontiguousarray(d["v"])),
+                                      float(g["dtau"]), dp(g["lam"]), dp(g["lam2"]), dp(np.ascontiguousarray(g["x"])))
+    assert rel(out, d["dMdx"]) < 1e-13
+
+
+def test_muldMdx_ssh_is_the_derivative_of_uMv(oracle):
+    """elpho_muldMdx_ssh (SSHModels.jl:707-829; α₂ = 0 so that the reference's ∂K/∂x is the true derivative) against the same
+    definition-level fixture."""
+    g, d = golden("ssh_sq4_L8_a.npz"), golden("muldmdx_ssh_sq4_L8_a.npz")
+    N, L, dtau = int(g["N"]), int(g["Ltau"]), float(g["dtau"])
+    tab = np.ascontiguousarray(g["table"])
+    nb = tab.shape[0]
+    m = oracle.make_model(1, N, L, tab, np.ascontiguousarray(g["cosht"]), np.ascontiguousarray(g["sinht"]), np.ascontiguousarray(g["expDtauMu"]))
+    nph = g["phonon_to_bond"].shape[0]
+    b2p = np.zeros(nb, dtype=np.int64)                                  # phonon (1-based) on checkerboard bond n, 0 = none
+    b2p[g["cbperm"][g["phonon_to_bond"] - 1] - 1] = np.arange(1, nph + 1)
+    out = np.zeros(nph * L)
+    oracle.lib.elpho_muldMdx_ssh(dp(out), dp(np.ascontiguousarray(d["u"])), C.byref(m), dp(np.ascontiguousarray(d["v"])), dtau, ip(b2p),
+                                 dp(np.ascontiguousarray(g["alpha"])), dp(np.ascontiguousarray(g["alpha2"])), dp(np.ascontiguousarray(g["x"])), nph)
+    assert rel(out, d["dMdx"]) < 1e-12
+
+
 @pytest.mark.parametrize("L", [8, 20, 40, 120, 160, 7])
 def test_fft_and_fourier_acceleration(oracle, L):
     g = golden("fft.npz")
