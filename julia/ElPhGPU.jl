@@ -1,21 +1,47 @@
-# ElPhGPU.jl — the Julia side of the drop-in: GPU-backed `<: AbstractModel` wrappers for ElPhDynamics.jl whose operator API
-# (`mul!`, `mulM!`, `mulMᵀ!`, `mulMᵀM!`, `mulMMᵀ!`, `ldiv!` in both arities, `update_model!`, `transpose!`), KPM preconditioner
-# (`setup!`, `ldiv!(z, P, r)`) and `fourier_accelerate!` are thin `ccall`s into libelphgpu.so (include/elph_gpu.h).
+# ElPhGPU.jl — the Julia side of the drop-in: the reference's OWN model values (`HolsteinModel`, `SSHModel`) keep every method they
+# have, and the fermion-matrix path of a model that has been `attach!`ed to an MI355X runs in libelphgpu.so (include/elph_gpu.h).
 #
-# STATUS: NOT EXECUTED.  Julia is installed neither in the build image nor on the GPU box of this project, so this file has never
-# been parsed by a Julia compiler.  It is written against the reference's sources as they lie in src/ (file:line cited at every
-# method) and against the C ABI that IS tested: tests/abi_c/abi_smoke.c makes exactly these calls, in this order, from plain C
-# (gcc, no Python in the process), and tests/test_gpu_parity.py drives the same entry points through ctypes against the oracle.
+# Design (round 5; the round-4 wrapper type `GPUHolsteinModel <: AbstractModel` is gone — it lost every caller that dispatches on the
+# concrete model type: update_Λ!, mulΛ!, calc_Sb, special_update!, … 33 signatures, tests/test_julia_dispatch.py lists them):
 #
-# How a maintainer wires it in (three lines in the reference, nothing else changes):
-#   src/ElPhDynamics.jl, after `include("Models.jl")` … `include("FourierAcceleration.jl")`:   include("ElPhGPU.jl")
-#   src/ProcessInputFile.jl:216-326 (`initialize_model`), last line:   model = ElPhGPU.gpu(model)      # when the deck asks for it
-#   src/ProcessInputFile.jl:473-513 (`initialize_preconditioner`):     P = ElPhGPU.GPUKPMPreconditioner(model, n, buf, c1, c2)
-# `HMC.calc_O⁻¹Λϕ!` (HMC.jl:820-915), `GreensFunctions.update!` (:201-234), `LangevinDynamics.calc_dSfdx!` (:350-384) and
-# `SpecialUpdates` keep calling `update_model!`, `ldiv!`, `mulMᵀ!`, `setup!` — by dispatch they now land here.
+#   * No new model type.  `ElPhGPU.attach!(model)` creates the device handle and records it in a registry keyed by the model's
+#     identity (`IdDict`).  The model stays a `HolsteinModel{Float64,Float64,…}` / `SSHModel{Float64,Float64,…}`: HMC.jl, PhononAction.jl,
+#     SpecialUpdates.jl, Measurements.jl, SimulationSummary.jl, InitializePhonons.jl, read_/write_phonons!, Serialization of checkpoints —
+#     all untouched and all still applicable.
+#   * No method is overwritten.  This file ADDS methods whose signatures are strictly more specific than the reference's
+#     (`Vector{Float64}` where the reference says `AbstractVector{T}`, `HolsteinModel{Float64,Float64}` where it says
+#     `HolsteinModel{T1,T2}`), so Julia's dispatch prefers them for the real-valued production case, nothing is redefined (no
+#     "method overwritten" warning, legal during precompilation on Julia ≥ 1.10), and complex or `SubArray` arguments still reach the
+#     reference's methods.  Every added method starts with a registry lookup and, when the model is not attached (or the call is one
+#     the library does not serve: M⋅x = b through GMRES/BiCGStab, a Left/Right preconditioner), hands over to the reference's method
+#     with `invoke` — the CPU path is always one `detach!` away and is what an unattached model runs.
+#   * The host fields stay current.  `update_model!` first runs the reference's method (host `expnΔτV` / `cosht`, `sinht`, `t′`,
+#     `expΔτμ` and the equal-fields check) and then uploads exactly those numbers (`elph_set_expV` / `elph_update_model_ssh`), so the
+#     device matrix is bit-identical to the host one and every reader of the host fields (KPM diagnostics, measurements, a fallback
+#     through `invoke`) sees the current configuration.  `attach!(model, host_sync = false)` computes exp / cosh / sinh on the device
+#     instead and leaves the host copies stale until `pull!(model)` — for drivers that never read them.
 #
-# Layouts are the reference's own (Utilities.jl:12-15: `Vector{Float64}` of length Ndim, τ fastest; `Matrix{Int}` 2 × Nbonds
-# column-major, 1-based; SSH `cosht/sinht` (Lτ × Nbonds) column-major): Julia arrays are passed as they are.
+# Served on the device (file:line = the reference method the added method stands in front of):
+#   update_model!(model)                      HolsteinModels.jl:526-549, SSHModels.jl:510-562
+#   mulM!, mulMᵀ!                             HolsteinModels.jl:569-626,631-684, SSHModels.jl:581-640,646-701
+#   mulMᵀM!, mulMMᵀ!  (hence mul!)            Models.jl:215-238 (mul! :192-209 dispatches onto these four)
+#   muldMdx!(dMdx, u, model, v)               HolsteinModels.jl:691-755, SSHModels.jl:707-829
+#   ldiv!(x, model, b[, P]; maxiter)          Models.jl:74-137,139-186   -> (iters, residual_error, flag), @info lines, zero-fill, retry
+#   solve!(x, model, b, cg[, P]; …)           IterativeSolvers.jl:153-234,239-314
+#   setup!(P), ldiv!(z, P, r)                 KPMPreconditioners.jl:259-321,426-481  for P::SymmetricKPMPreconditioner of an attached model
+#   calc_O⁻¹Λϕ!(hmc, model, P, power)         HMC.jl:820-915: the two pseudofermion solves as ONE batch of two right-hand sides
+#   fourier_accelerate!(v′, fa, v, power)     FourierAcceleration.jl:131-137 for an accelerator registered with `attach!(fa, model)`
+#
+# Wiring in the reference (two lines; nothing else changes):
+#   src/ElPhDynamics.jl, after include("ProcessInputFile.jl"):                                    include("ElPhGPU.jl")
+#   src/ElPhDynamics.jl `simulate`, after process_input_file / process_checkpoint returned (:103-118):   ElPhGPU.attach!(model)
+#
+# STATUS: NOT EXECUTED.  Julia is installed neither in the build image nor on the GPU box of this project: this file has never been
+# parsed by a Julia compiler.  What IS checked, on every test run: tests/test_julia_dispatch.py (every `ccall` below against the
+# prototypes of include/elph_gpu.h — symbol, argument count, argument types; block structure of this file; every reference function
+# whose signature names a concrete model type is either left alone or specialised here; every added signature is more specific than
+# the reference method it names), and the calls themselves, in this order, from plain C (tests/abi_c/abi_smoke.c) and through ctypes
+# (tests/test_gpu_parity.py, tests/test_gpu_muldmdx.py) against the oracle on the GPU.
 
 module ElPhGPU
 
@@ -23,21 +49,30 @@ using LinearAlgebra
 using Random
 using Logging
 
-import LinearAlgebra: mul!, ldiv!, transpose!
+import LinearAlgebra: ldiv!
 
+using ..Utilities: get_index
+using ..IterativeSolvers: ConjugateGradient
+import ..IterativeSolvers: solve!
 using ..Models: AbstractModel, HolsteinModel, SSHModel
-import ..Models: mulM!, mulMᵀ!, mulMᵀM!, mulMMᵀ!, update_model!
-using ..KPMPreconditioners: KPMPreconditioner
+import ..Models: mulM!, mulMᵀ!, mulMᵀM!, mulMMᵀ!, muldMdx!, update_model!
+using ..KPMPreconditioners: KPMPreconditioner, SymmetricKPMPreconditioner, KPMExpansion
 import ..KPMPreconditioners: setup!
 using ..FourierAcceleration: FourierAccelerator
 import ..FourierAcceleration: fourier_accelerate!
+using ..HMC: HybridMonteCarlo, update_Λ!, mulΛ!
+import ..HMC: calc_O⁻¹Λϕ!
 
-export GPUHolsteinModel, GPUSSHModel, GPUKPMPreconditioner, gpu, ldiv_batched!, ElphError
+export attach!, detach!, attached, pull!, ldiv_batched!, ElphError
 
 "Path of the shared library; `ENV[\"ELPHGPU_LIB\"]` overrides (the in-tree build is elphdynamics_amd/libelphgpu.so)."
 const lib = get(ENV, "ELPHGPU_LIB", "libelphgpu.so")
 
-const ELPH_ABI = 1                      # include/elph_gpu.h: elph_abi_version()
+"include/elph_gpu.h: ELPH_ABI_VERSION this file was written against; checked for equality when the first model is attached."
+const ELPH_ABI = 2
+
+"The models whose fermion matrix the library holds: real parameters, real matrix elements (`is_complex = false`)."
+const GPUModel = Union{HolsteinModel{Float64,Float64},SSHModel{Float64,Float64}}
 
 struct ElphError <: Exception
     code::Cint                          # ELPH_E_ARG -1, _HIP -2, _STATE -3, _NOGPU -4, _UNSUPPORTED -5
@@ -51,39 +86,49 @@ function chk(rc::Cint)
     throw(ElphError(rc, unsafe_string(ccall((:elph_last_error, lib), Cstring, ()))))
 end
 
-"What the loaded library was built from (source hash, compiler, time): `elph_build_info`."
+"What the loaded library was built from (source hash, compiler, time)."
 build_info() = unsafe_string(ccall((:elph_build_info, lib), Cstring, ()))
 
 # ------------------------------------------------------------------------------------------------------------------------------
-# Model wrappers.  A wrapper OWNS nothing but the device handle; every host-visible field the callers reach into (SURVEY §8b:
-# x, rng, solver.tol/.maxiter, mul_by_M, transposed, Ndof, Ndim, Nph, Nsites, Lτ, Δτ, λ, λ₂, μ, v″, lattice, neighbor_table, …)
-# stays in the reference's own struct `host` and is forwarded by getproperty / setproperty!.
+# The registry: model identity -> device state.  The model itself is not changed, wrapped or subtyped.
 # ------------------------------------------------------------------------------------------------------------------------------
 
-abstract type GPUModel{T1,T2,T3,T4} <: AbstractModel{T1,T2,T3,T4} end
-
-"Holstein model whose fermion matrix lives on an MI355X (HolsteinModels.jl:22-314 keeps parameters, x, rng, scratch)."
-mutable struct GPUHolsteinModel{T1,T2,T3,T4} <: GPUModel{T1,T2,T3,T4}
-    host::HolsteinModel{T1,T2,T3,T4}
+mutable struct Entry
     handle::Ptr{Cvoid}
+    host_sync::Bool                     # update_model! keeps the host fields current (default) or computes on the device only
+    batch_pseudofermions::Bool          # calc_O⁻¹Λϕ!: ϕ₊ and ϕ₋ as one batch of two right-hand sides
+    kpm::Any                            # the KPMExpansion whose parameters elph_kpm_create received (nothing: none yet)
+    kpm_ready::Bool                     # setup!(P) has run on the device (the expansion of e.kpm exists there)
+    X2::Matrix{Float64}                 # Ndim × 2 staging for batched solves (no allocation in the hot loop)
+    B2::Matrix{Float64}
+    q::Matrix{Float64}                  # Lτ × Nbonds bond brackets of muldMdx! (SSH)
+    bmax::Vector{Float64}               # Arnoldi start vectors of setup!(P)
+    bmin::Vector{Float64}
+    cb_index::Vector{Int64}             # SSH, host_sync = false: checkerboard position of every phonon's bond, 1-based
+    t_ph::Vector{Float64}               #   bare hopping of every phonon's bond
+    t_bare_cb::Vector{Float64}          #   bare hopping of every bond, checkerboard order
+    gpu_calls::Int                      # served on the device / handed to the reference's method — `status(model)`
+    fallbacks::Int
 end
 
-"SSH (bond-phonon) model on the device (SSHModels.jl:79-314)."
-mutable struct GPUSSHModel{T1,T2,T3,T4} <: GPUModel{T1,T2,T3,T4}
-    host::SSHModel{T1,T2,T3,T4}
-    handle::Ptr{Cvoid}
-    cb_index::Vector{Int64}             # checkerboard_perm[phonon_to_bond[p]]  (1-based position of each phonon's bond)
-    t_ph::Vector{Float64}               # t[phonon_to_bond[p]]
-    t_bare_cb::Vector{Float64}          # bare hopping of every bond, checkerboard order
-end
+const REGISTRY = IdDict{Any,Entry}()
+const FA_REGISTRY = IdDict{Any,Any}()   # FourierAccelerator -> its model
 
-Base.getproperty(g::GPUModel, s::Symbol) = hasfield(typeof(g), s) ? getfield(g, s) : getproperty(getfield(g, :host), s)
-Base.setproperty!(g::GPUModel, s::Symbol, v) = hasfield(typeof(g), s) ? setfield!(g, s, v) : setproperty!(getfield(g, :host), s, v)
-Base.propertynames(g::GPUModel) = (fieldnames(typeof(g))..., propertynames(getfield(g, :host))...)
+"The device state of `model`, or `nothing` when it is not attached (then every method below defers to the reference's)."
+entry(model) = get(REGISTRY, model, nothing)::Union{Nothing,Entry}
+
+"`true` when the fermion matrix of `model` lives on a GPU."
+attached(model) = haskey(REGISTRY, model)
+
+"(calls served on the device, calls handed to the reference's CPU method) since `attach!`."
+function status(model)
+    e = entry(model)
+    return e === nothing ? (0, 0) : (e.gpu_calls, e.fallbacks)
+end
 
 function create_handle(kind::Integer, N::Integer, Lτ::Integer, Nbonds::Integer, neighbor_table, cosht, sinht, device::Integer)
     v = ccall((:elph_abi_version, lib), Cint, ())
-    v == ELPH_ABI || error("libelphgpu ABI version $v, this wrapper was written for $ELPH_ABI")
+    v == ELPH_ABI || error("libelphgpu speaks ABI $v, ElPhGPU.jl was written for $ELPH_ABI ($(build_info()))")
     h = Ref{Ptr{Cvoid}}(C_NULL)
     chk(ccall((:elph_create, lib), Cint,
               (Ref{Ptr{Cvoid}}, Cint, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Cint),
@@ -91,115 +136,271 @@ function create_handle(kind::Integer, N::Integer, Lτ::Integer, Nbonds::Integer,
     return h[]
 end
 
-destroy!(g::GPUModel) = (getfield(g, :handle) == C_NULL || ccall((:elph_destroy, lib), Cint, (Ptr{Cvoid},), getfield(g, :handle)); setfield!(g, :handle, C_NULL); nothing)
-
 """
-    GPUHolsteinModel(m::HolsteinModel; device=0)
+    attach!(model; device = 0, host_sync = true, batch_pseudofermions = true) -> model
 
-`m` must be initialised (`initialize_model!`, HolsteinModels.jl:484-517: `neighbor_table`, `cosht`, `sinht` in checkerboard
-order).  Errors with ELPH_E_NOGPU when no gfx950 device is visible: there is no CPU fallback.
+Put the fermion matrix of an initialised model (`initialize_model!`, HolsteinModels.jl:484-517 / SSHModels.jl:348-505:
+`neighbor_table`, `cosht`, `sinht` in checkerboard order) on GPU `device` and route the operator API of this model there.  Throws
+`ElphError(ELPH_E_NOGPU)` when no gfx950 device is visible — the library has no CPU path; the reference's own methods are the CPU
+path and stay in force for every model that is not attached.  Attaching twice is a no-op.
 """
-function GPUHolsteinModel(m::HolsteinModel{T1,T2,T3,T4}; device::Integer=0) where {T1,T2,T3,T4}
-    nt = m.Nbonds > 0 ? m.neighbor_table : zeros(Int64, 2, 0)
-    h = create_handle(0, m.Nsites, m.Lτ, m.Nbonds, nt, m.cosht, m.sinht, device)
-    g = GPUHolsteinModel{T1,T2,T3,T4}(m, h)
-    finalizer(destroy!, g)
-    push_solver!(g)
-    update_model!(g)
-    return g
-end
-
-"""
-    GPUSSHModel(m::SSHModel; device=0)
-
-`cosht/sinht` are computed on the device from `m.x` at every `update_model!` (no host cosh/sinh, no tables over PCIe).
-"""
-function GPUSSHModel(m::SSHModel{T1,T2,T3,T4}; device::Integer=0) where {T1,T2,T3,T4}
-    h = create_handle(1, m.Nsites, m.Lτ, m.Nbonds, m.neighbor_table, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), device)
-    cb_index  = Int64[m.checkerboard_perm[m.phonon_to_bond[p]] for p in 1:m.Nph]
-    t_ph      = Float64[m.t[m.phonon_to_bond[p]] for p in 1:m.Nph]
-    t_bare_cb = zeros(Float64, m.Nbonds)
-    for bond in 1:m.Nbonds
-        t_bare_cb[m.checkerboard_perm[bond]] = m.t[bond]
-    end
-    g = GPUSSHModel{T1,T2,T3,T4}(m, h, cb_index, t_ph, t_bare_cb)
-    finalizer(destroy!, g)
-    push_solver!(g)
-    update_model!(g)
-    return g
-end
-
-"Wrap whatever `initialize_model` built."
-gpu(m::HolsteinModel; device::Integer=0) = GPUHolsteinModel(m, device=device)
-gpu(m::SSHModel; device::Integer=0) = GPUSSHModel(m, device=device)
-
-# ---- update_model! ------------------------------------------------------------------------------------------------------------
-
-"update_model!(holstein): expnΔτV = exp(-Δτ(λx + λ₂x² - μ)) on the device — HolsteinModels.jl:526-549"
-function update_model!(g::GPUHolsteinModel)
-    m = g.host
-    chk(ccall((:elph_update_model_holstein, lib), Cint,
-              (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64),
-              g.handle, m.x, m.λ, m.λ₂, m.μ, m.Δτ))
-    return nothing
-end
-
-"update_model!(ssh): expΔτμ, t′ = t − (αx + sign(x)α₂x²), cosh/sinh(Δτ t′) per (τ, bond) on the device — SSHModels.jl:510-562.
-The equality test of symmetry-equivalent fields (:548-559) stays on the host, as in the reference."
-function update_model!(g::GPUSSHModel)
-    m = g.host
-    for field in 1:m.Ndof
-        field′ = m.primary_field[field]
-        if field != field′ && !(m.x[field] ≈ m.x[field′])
-            error("(x[$field]=$(m.x[field])) != (x[$field′]=$(m.x[field′]))\n")
+function attach!(model::GPUModel; device::Integer=0, host_sync::Bool=true, batch_pseudofermions::Bool=true)
+    attached(model) && return model
+    N, Lτ, Nb = model.Nsites, model.Lτ, model.Nbonds
+    if model isa HolsteinModel
+        nt = Nb > 0 ? model.neighbor_table : zeros(Int64, 2, 0)
+        h = create_handle(0, N, Lτ, Nb, nt, model.cosht, model.sinht, device)
+        cb_index = Int64[]; t_ph = Float64[]; t_bare_cb = Float64[]
+    else
+        h = create_handle(1, N, Lτ, Nb, model.neighbor_table, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), device)
+        cb_index = Int64[model.checkerboard_perm[model.phonon_to_bond[p]] for p in 1:model.Nph]
+        t_ph = Float64[model.t[model.phonon_to_bond[p]] for p in 1:model.Nph]
+        t_bare_cb = zeros(Float64, Nb)
+        for bond in 1:Nb
+            t_bare_cb[model.checkerboard_perm[bond]] = model.t[bond]
         end
     end
-    chk(ccall((:elph_update_model_ssh_fields, lib), Cint,
-              (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64),
-              g.handle, m.x, m.Nph, g.cb_index, g.t_ph, m.α, m.α₂, g.t_bare_cb, m.μ, m.Δτ))
-    return nothing
+    e = Entry(h, host_sync, batch_pseudofermions, nothing, false, zeros(model.Ndim, 2), zeros(model.Ndim, 2),
+              zeros(Lτ, model isa SSHModel ? Nb : 0), zeros(N), zeros(N), cb_index, t_ph, t_bare_cb, 0, 0)
+    REGISTRY[model] = e
+    update_model!(model)
+    return model
 end
 
-"Bring `model.cosht` / `model.sinht` of the host struct up to date after a device-side update (readers: KPM diagnostics, dumps)."
-function pull_cosh_sinh!(g::GPUModel)
-    chk(ccall((:elph_get_cosh_sinh, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), g.handle, g.host.cosht, g.host.sinht))
-    return nothing
+"Register a FourierAccelerator built from `model` (FourierAcceleration.jl:47-82) so that `fourier_accelerate!` runs on its device."
+function attach!(fa::FourierAccelerator{Float64}, model::GPUModel)
+    attached(model) || error("attach!(fa, model): attach the model first")
+    FA_REGISTRY[fa] = model
+    return fa
 end
 
-# ---- mul! family — Models.jl:192-248, HolsteinModels.jl:569-684, SSHModels.jl:581-701 ------------------------------------------
+"""
+    detach!(model)
 
-for (jl, c) in ((:mulM!, :elph_mulM), (:mulMᵀ!, :elph_mulMT), (:mulMᵀM!, :elph_mulMTM), (:mulMMᵀ!, :elph_mulMMT))
-    @eval function $jl(y::AbstractVector{Float64}, g::GPUModel, v::AbstractVector{Float64})
-        @assert length(y) == g.Ndim && length(v) == g.Ndim
-        chk(ccall(($(QuoteNode(c)), lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), g.handle, y, v))
-        return nothing
+Free the device handle; from here on every call runs the reference's own methods again.  A preconditioner that was set up on the
+device forgets its bounds (λ_lo, λ_hi back to the constructor's 0 and 2, KPMPreconditioners.jl:68-69), so that the next `setup!` on
+the CPU recomputes its coefficients instead of trusting numbers it never computed.
+"""
+function detach!(model)
+    e = entry(model)
+    e === nothing && return nothing
+    if e.kpm !== nothing
+        op = e.kpm
+        op.λ_lo = 0.0; op.λ_hi = 2.0; op.λ_avg = 1.0; op.λ_mag = 1.0
     end
+    for (fa, m) in collect(FA_REGISTRY)
+        m === model && delete!(FA_REGISTRY, fa)
+    end
+    e.handle == C_NULL || ccall((:elph_destroy, lib), Cint, (Ptr{Cvoid},), e.handle)
+    e.handle = C_NULL
+    delete!(REGISTRY, model)
+    return nothing
 end
 
-"mul!(y, model, v): honours model.mul_by_M and model.transposed — Models.jl:192-209"
-function mul!(y::AbstractVector{Float64}, g::GPUModel, v::AbstractVector{Float64})
-    if g.mul_by_M
-        g.transposed ? mulMᵀ!(y, g, v) : mulM!(y, g, v)
+function detach_all!()
+    for m in collect(keys(REGISTRY))
+        detach!(m)
+    end
+    return nothing
+end
+
+function __init__()
+    atexit(detach_all!)
+    return nothing
+end
+
+served!(e::Entry) = (e.gpu_calls += 1; nothing)
+deferred!(e::Union{Nothing,Entry}) = (e === nothing || (e.fallbacks += 1); nothing)
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# update_model!
+# ------------------------------------------------------------------------------------------------------------------------------
+
+"update_model!(holstein): expnΔτV = exp(-Δτ(λx + λ₂x² - μ)) — HolsteinModels.jl:526-549 — on the host AND on the device (same bits)"
+function update_model!(m::HolsteinModel{Float64,Float64})
+    e = entry(m)
+    if e === nothing || e.host_sync
+        invoke(update_model!, Tuple{HolsteinModel}, m)
+        e === nothing && return nothing
+        chk(ccall((:elph_set_expV, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), e.handle, m.expnΔτV))
     else
-        g.transposed ? mulMMᵀ!(y, g, v) : mulMᵀM!(y, g, v)
+        chk(ccall((:elph_update_model_holstein, lib), Cint,
+                  (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64),
+                  e.handle, m.x, m.λ, m.λ₂, m.μ, m.Δτ))
+    end
+    served!(e)                          # (an expansion set up for an earlier configuration stays usable until the next setup!, as in
+                                        #  the reference, where ldiv!(x, model, b, P) applies whatever setup!(P) last left in P)
+    return nothing
+end
+
+"update_model!(ssh): expΔτμ, t′ = t − (αx + sign(x)α₂x²), cosh/sinh(Δτ t′) per (τ, bond), equal-fields check — SSHModels.jl:510-562"
+function update_model!(m::SSHModel{Float64,Float64})
+    e = entry(m)
+    if e === nothing || e.host_sync
+        invoke(update_model!, Tuple{SSHModel}, m)
+        e === nothing && return nothing
+        # model.cosht / .sinht are (Lτ × Nbonds) column-major = [bond][τ], the layout elph_update_model_ssh takes
+        chk(ccall((:elph_update_model_ssh, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                  e.handle, m.cosht, m.sinht, m.expΔτμ))
+    else
+        for field in 1:m.Ndof           # the equal-fields check stays on the host, as in the reference (:548-559)
+            field′ = m.primary_field[field]
+            if field != field′ && !(m.x[field] ≈ m.x[field′])
+                error("(x[$field]=$(m.x[field])) != (x[$field′]=$(m.x[field′]))\n")
+            end
+        end
+        chk(ccall((:elph_update_model_ssh_fields, lib), Cint,
+                  (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64),
+                  e.handle, m.x, m.Nph, e.cb_index, e.t_ph, m.α, m.α₂, e.t_bare_cb, m.μ, m.Δτ))
+    end
+    served!(e)
+    return nothing
+end
+
+"""
+    pull!(model)
+
+`host_sync = false` only: bring the host copies of the device-computed matrix elements up to date (SSH: `model.cosht`, `model.sinht`
+through `elph_get_cosh_sinh`; Holstein: `model.expnΔτV` by the reference's own update_model!, the host exp being what it would have
+computed anyway).
+"""
+function pull!(m::GPUModel)
+    e = entry(m)
+    e === nothing && return nothing
+    if m isa HolsteinModel
+        invoke(update_model!, Tuple{HolsteinModel}, m)
+    else
+        chk(ccall((:elph_get_cosh_sinh, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, m.cosht, m.sinht))
+        @. m.expΔτμ = exp(m.Δτ * m.μ)
     end
     return nothing
 end
 
-"transpose!(model): M ⇆ Mᵀ for mul! — Models.jl:244-248"
-transpose!(g::GPUModel) = (g.host.transposed = !g.host.transposed; nothing)
+# ------------------------------------------------------------------------------------------------------------------------------
+# mul! family — HolsteinModels.jl:569-684, SSHModels.jl:581-701, Models.jl:215-238.  `mul!` (Models.jl:192-209) needs no method of
+# its own: it dispatches on model.mul_by_M / model.transposed onto these four.
+# ------------------------------------------------------------------------------------------------------------------------------
 
-# ---- ldiv! — Models.jl:74-137 (with P), :139-186 (without) ----------------------------------------------------------------------
+"y = M⋅v"
+function mulM!(y::Vector{Float64}, m::HolsteinModel{Float64,Float64}, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(mulM!, Tuple{AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, y, m, v)
+    @assert length(y) == m.Ndim && length(v) == m.Ndim
+    chk(ccall((:elph_mulM, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
+    served!(e)
+    return nothing
+end
+
+function mulM!(y::Vector{Float64}, m::SSHModel{Float64,Float64}, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(mulM!, Tuple{AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, y, m, v)
+    @assert length(y) == m.Ndim && length(v) == m.Ndim
+    chk(ccall((:elph_mulM, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
+    served!(e)
+    return nothing
+end
+
+"y = Mᵀ⋅v"
+function mulMᵀ!(y::Vector{Float64}, m::HolsteinModel{Float64,Float64}, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(mulMᵀ!, Tuple{AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, y, m, v)
+    @assert length(y) == m.Ndim && length(v) == m.Ndim
+    chk(ccall((:elph_mulMT, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
+    served!(e)
+    return nothing
+end
+
+function mulMᵀ!(y::Vector{Float64}, m::SSHModel{Float64,Float64}, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(mulMᵀ!, Tuple{AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, y, m, v)
+    @assert length(y) == m.Ndim && length(v) == m.Ndim
+    chk(ccall((:elph_mulMT, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
+    served!(e)
+    return nothing
+end
+
+"y = MᵀM⋅v in one fused pass (the reference goes through model.v′, Models.jl:215-224)"
+function mulMᵀM!(y::Vector{Float64}, m::GPUModel, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(mulMᵀM!, Tuple{AbstractVector{Float64},AbstractModel,AbstractVector{Float64}}, y, m, v)
+    @assert length(y) == m.Ndim && length(v) == m.Ndim
+    chk(ccall((:elph_mulMTM, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
+    served!(e)
+    return nothing
+end
+
+"y = MMᵀ⋅v (Models.jl:229-238)"
+function mulMMᵀ!(y::Vector{Float64}, m::GPUModel, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(mulMMᵀ!, Tuple{AbstractVector{Float64},AbstractModel,AbstractVector{Float64}}, y, m, v)
+    @assert length(y) == m.Ndim && length(v) == m.Ndim
+    chk(ccall((:elph_mulMMT, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
+    served!(e)
+    return nothing
+end
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# muldMdx! — dMdx[field] = uᵀ⋅(∂M/∂x_field)⋅v; calc_dSfdx! calls it with (u, v) = (M⋅O⁻¹Λϕ±, O⁻¹Λϕ±) (HMC.jl:799,804),
+# LangevinDynamics.calc_dSfdx! with (g, M⁻¹g) (:378)
+# ------------------------------------------------------------------------------------------------------------------------------
+
+"muldMdx!(dMdx, u, holstein, v) — HolsteinModels.jl:691-755"
+function muldMdx!(dMdx::Vector{Float64}, u::Vector{Float64}, m::HolsteinModel{Float64,Float64}, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, dMdx, u, m, v)
+    @assert length(dMdx) == m.Ndim && length(u) == m.Ndim && length(v) == m.Ndim
+    chk(ccall((:elph_muldMdx_holstein, lib), Cint,
+              (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64),
+              e.handle, dMdx, u, v, m.x, m.λ, m.λ₂, m.Δτ))
+    served!(e)
+    return nothing
+end
+
+"muldMdx!(dMdx, u, ssh, v) — SSHModels.jl:707-829: the bond brackets ⟨c_n|…|b_n⟩ come from the device (the two checkerboard
+recursions per time slice), ∂K/∂x, the τ = 1 sign and the sum over equivalent fields are applied here exactly as at :797-826"
+function muldMdx!(dMdx::Vector{Float64}, u::Vector{Float64}, m::SSHModel{Float64,Float64}, v::Vector{Float64})
+    e = entry(m)
+    e === nothing && return invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, dMdx, u, m, v)
+    @assert length(dMdx) == m.Ndof && length(u) == m.Ndim && length(v) == m.Ndim
+    q = e.q                             # q[τ, n] = c_j b_i + c_i b_j for checkerboard bond n: (Lτ × Nbonds) column-major = elph_muldMdx_ssh's q_out
+    chk(ccall((:elph_muldMdx_ssh, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), e.handle, q, u, v))
+    Lτ, Δτ = m.Lτ, m.Δτ
+    fill!(dMdx, 0.0)
+    @inbounds for n in 1:m.Nbonds
+        bond = m.inv_checkerboard_perm[n]
+        phonon = m.bond_to_phonon[bond]
+        phonon == 0 && continue
+        for τ in 1:Lτ
+            field = get_index(τ, phonon, Lτ)
+            dKdx = m.α[phonon] + 2 * m.α₂[phonon] * m.x[field]
+            dmdx = Δτ * dKdx * q[τ, n]
+            if τ == 1
+                dmdx = -dmdx
+            end
+            dMdx[m.primary_field[field]] += dmdx
+        end
+    end
+    @views @. dMdx = dMdx[m.primary_field]
+    served!(e)
+    return nothing
+end
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# ldiv! — Models.jl:74-137 (with P), :139-186 (without); solve! — IterativeSolvers.jl:153-234, 239-314
+# ------------------------------------------------------------------------------------------------------------------------------
 
 "callers mutate model.solver.tol between solves (HMC.jl:827-828, restored :912): the current values travel with every solve"
-push_solver!(g::GPUModel) = chk(ccall((:elph_solver_set, lib), Cint, (Ptr{Cvoid}, Float64, Int64, Float64),
-                                      g.handle, g.solver.tol, g.solver.maxiter, g.solver.κmax))
+function push_solver!(e::Entry, m::GPUModel)
+    chk(ccall((:elph_solver_set, lib), Cint, (Ptr{Cvoid}, Float64, Int64, Float64),
+              e.handle, m.solver.tol, m.solver.maxiter, m.solver.κmax))
+    return nothing
+end
 
 function log_flag(flag::Integer, err, iters, with_P::Bool)
     # the reference's @info lines — Models.jl:108,117 (with preconditioner), :163,172 (without)
-    suffix = with_P ? ", W/ Preconditioner" : ""
-    flag == 1 && @info("Hit Max Iters, Residual Error = $err, Iterations = $iters$suffix")
-    flag == 2 && @info("Large Residual Error = $err, Iterations = $iters$suffix")
+    suffix = with_P ? "W/ Preconditioner" : "W/O Preconditioner"
+    flag == 1 && @info("Hit Max Iters, Residual Error = $err, Iterations = $iters, $suffix")
+    flag == 2 && @info("Large Residual Error = $err, Iterations = $iters, $suffix")
     if flag > 0
         logger = global_logger()
         hasproperty(logger, :stream) && flush(logger.stream)
@@ -207,151 +408,259 @@ function log_flag(flag::Integer, err, iters, with_P::Bool)
     return nothing
 end
 
-"""
-    ldiv!(x, model, b; maxiter=0) -> (iters, residual_error, flag)                       Models.jl:139-186
-    ldiv!(x, model, b, P; maxiter=0) -> (iters, residual_error, flag)                    Models.jl:74-137
+"Is this a solve the library serves?  MᵀM⋅x = b by conjugate gradients (every caller on the path: HMC.jl:851-886, GreensFunctions.jl:225,
+LangevinDynamics.jl:374); M⋅x = b / Mᵀ⋅x = b through GMRES / BiCGStab stay with the reference's solvers (which then call the mat-vecs above)."
+servable(m::GPUModel) = !m.mul_by_M && !m.transposed && m.solver isa ConjugateGradient
 
-Solve MᵀM⋅x = b from the caller's `x` (callers pass zeros: HMC.jl:854) with the reference's stop rule, true-residual check, flags
-0 / 1 (hit maxiter) / 2 (false convergence), zero-fill of `x` when flag > 0 and — with a preconditioner — the un-preconditioned
-retry with 10·maxiter.  `P == I` takes the first form, as Models.jl:83-86.  `model.mul_by_M`/`transposed` select what is solved
-in the reference (M, Mᵀ, MᵀM, MMᵀ: `mul!`); every caller on the path solves MᵀM (HMC.jl:851-886, GreensFunctions.jl:225,
-LangevinDynamics.jl:374) and that is what the library solves — anything else is refused here rather than answered wrongly.
-"""
-function ldiv!(x::AbstractVector{Float64}, g::GPUModel, b::AbstractVector{Float64}; maxiter::Int=0)::Tuple{Int,Float64,Int}
-    return _ldiv!(x, g, b, false, maxiter)
+"0: P is the identity; 1: P is the symmetric KPM preconditioner of this model, set up on the device; -1: anything else"
+function precond_mode(e::Entry, m::GPUModel, P)
+    P === I && return 0
+    P isa UniformScaling && return (P == I ? 0 : -1)
+    if P isa SymmetricKPMPreconditioner && P.expansion.model === m && e.kpm === P.expansion && e.kpm_ready && !P.transposed
+        return 1
+    end
+    return -1
 end
 
-function ldiv!(x::AbstractVector{Float64}, g::GPUModel, b::AbstractVector{Float64}, P; maxiter::Int=0)::Tuple{Int,Float64,Int}
-    P == I && return _ldiv!(x, g, b, false, maxiter)
-    P isa GPUKPMPreconditioner || error("ldiv!(x, ::GPUModel, b, P): P must be I or a GPUKPMPreconditioner of this model")
-    P.model === g || error("the preconditioner belongs to another model")
-    return _ldiv!(x, g, b, true, maxiter)
-end
-
-function _ldiv!(x, g::GPUModel, b, use_P::Bool, maxiter::Int)
-    (g.mul_by_M || g.transposed) && error("libelphgpu solves MᵀM⋅x = b (mul_by_M = false, transposed = false)")
-    push_solver!(g)
+function gpu_ldiv!(x::Vector{Float64}, e::Entry, m::GPUModel, b::Vector{Float64}, use_P::Bool, maxiter::Int)
+    @assert length(x) == m.Ndim && length(b) == m.Ndim
+    push_solver!(e, m)
     iters = Ref{Int64}(0); err = Ref{Float64}(0.0); flag = Ref{Cint}(0)
     chk(ccall((:elph_ldiv, lib), Cint,
               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Int64, Ref{Int64}, Ref{Float64}, Ref{Cint}),
-              g.handle, x, b, use_P ? 1 : 0, maxiter, iters, err, flag))
+              e.handle, x, b, use_P ? 1 : 0, maxiter, iters, err, flag))
+    # elph_ldiv has already done what Models.jl:96-134 does (true residual, flag, zero-fill, the un-preconditioned retry with
+    # 10·maxiter): only the log lines are left
     log_flag(flag[], err[], iters[], use_P)
+    served!(e)
     return Int(iters[]), err[], Int(flag[])
 end
 
 """
-    ldiv_batched!(X, model, B[, P]; maxiter=0) -> (iters[], residual_error[], flag[])
+    ldiv!(x, model, b; maxiter = 0)    -> (iters, residual_error, flag)                    Models.jl:139-186
+    ldiv!(x, model, b, P; maxiter = 0) -> (iters, residual_error, flag)                    Models.jl:74-137
 
-`size(B, 2)` right-hand sides in one call (columns): the two pseudofermion solves of `calc_O⁻¹Λϕ!` (HMC.jl:851-886), the nᵥ solves
-of `GreensFunctions.update!` (:201-234).  Every column follows exactly the single-solve recurrences and stop rule.
+MᵀM⋅x = b from the caller's `x` (callers pass zeros: HMC.jl:854) with the reference's stop rule, true-residual check, flags 0 / 1
+(hit maxiter) / 2 (false convergence), zero-fill of `x` when flag > 0 and — with a preconditioner — the un-preconditioned retry with
+10⋅maxiter.
 """
-function ldiv_batched!(X::AbstractMatrix{Float64}, g::GPUModel, B::AbstractMatrix{Float64}, P=I; maxiter::Int=0)
-    push_solver!(g)
+function ldiv!(x::Vector{Float64}, m::GPUModel, b::Vector{Float64}; maxiter::Int=0)::Tuple{Int,Float64,Int}
+    e = entry(m)
+    if e === nothing || !servable(m)
+        deferred!(e)
+        return invoke(ldiv!, Tuple{AbstractVector,AbstractModel,AbstractVector}, x, m, b; maxiter=maxiter)
+    end
+    return gpu_ldiv!(x, e, m, b, false, maxiter)
+end
+
+function ldiv!(x::Vector{Float64}, m::GPUModel, b::Vector{Float64}, P; maxiter::Int=0)::Tuple{Int,Float64,Int}
+    e = entry(m)
+    mode = (e === nothing || !servable(m)) ? -1 : precond_mode(e, m, P)
+    if mode < 0
+        deferred!(e)
+        return invoke(ldiv!, Tuple{AbstractVector,AbstractModel,AbstractVector,Any}, x, m, b, P; maxiter=maxiter)
+    end
+    return gpu_ldiv!(x, e, m, b, mode == 1, maxiter)
+end
+
+"""
+    ldiv_batched!(X, model, B[, P]; maxiter = 0) -> (iters[], residual_error[], flag[])
+
+`size(B, 2)` right-hand sides in one call (columns): the two pseudofermion solves of `calc_O⁻¹Λϕ!` (HMC.jl:851-886), the nᵥ solves of
+`GreensFunctions.update!` (:201-234).  Every column follows exactly the single-solve recurrences, stop rule and flag logic.  No
+reference method exists for this (the reference solves one at a time); an unattached model loops over `ldiv!`.
+"""
+function ldiv_batched!(X::Matrix{Float64}, m::GPUModel, B::Matrix{Float64}, P=I; maxiter::Int=0)
     n = size(B, 2)
+    @assert size(X) == size(B) && size(B, 1) == m.Ndim
     iters = zeros(Int64, n); err = zeros(Float64, n); flag = zeros(Cint, n)
+    e = entry(m)
+    mode = (e === nothing || !servable(m)) ? -1 : precond_mode(e, m, P)
+    if mode < 0
+        deferred!(e)
+        for k in 1:n
+            xk = X[:, k]
+            it, er, fl = ldiv!(xk, m, B[:, k], P, maxiter=maxiter)
+            X[:, k] = xk
+            iters[k] = it; err[k] = er; flag[k] = fl
+        end
+        return iters, err, Int.(flag)
+    end
+    push_solver!(e, m)
     chk(ccall((:elph_ldiv_batched, lib), Cint,
               (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Cint, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Cint}),
-              g.handle, n, X, B, P == I ? 0 : 1, maxiter, iters, err, flag))
+              e.handle, n, X, B, mode, maxiter, iters, err, flag))
     for k in 1:n
-        log_flag(flag[k], err[k], iters[k], !(P == I))
+        log_flag(flag[k], err[k], iters[k], mode == 1)
     end
+    served!(e)
     return iters, err, Int.(flag)
 end
 
-"solve!(x, A, b, cg[, P]) without ldiv!'s wrapper — IterativeSolvers.jl:153-234, 239-314 — returns the iteration count"
-function solve!(x::AbstractVector{Float64}, g::GPUModel, b::AbstractVector{Float64}, solver, P=I;
-                maxiter::Int=0, tol::Float64=0.0, κmax::Float64=0.0)::Int
+function gpu_solve!(x::Vector{Float64}, e::Entry, m::GPUModel, b::Vector{Float64}, cg::ConjugateGradient{Float64,Float64}, use_P::Bool,
+                    maxiter::Int, tol::Float64, κmax::Float64)
+    @assert length(x) == m.Ndim && length(b) == m.Ndim
     iters = Ref{Int64}(0)
     chk(ccall((:elph_cg_solve, lib), Cint,
               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Int64, Float64, Cint, Ref{Int64}, Ptr{Float64}),
-              g.handle, x, b, iszero(tol) ? solver.tol : tol, iszero(maxiter) ? solver.maxiter : maxiter,
-              iszero(κmax) ? solver.κmax : κmax, P == I ? 0 : 1, iters, C_NULL))
+              e.handle, x, b, iszero(tol) ? cg.tol : tol, iszero(maxiter) ? cg.maxiter : maxiter,
+              iszero(κmax) ? cg.κmax : κmax, use_P ? 1 : 0, iters, C_NULL))
+    served!(e)
     return Int(iters[])
 end
 
-# ---- KPM preconditioner — KPMPreconditioners.jl:219-235 (type), :259-321 (setup!), :426-481 (apply) ------------------------------
-
-"Tag type: the expansion (Ē, Arnoldi bounds, orders, Chebyshev coefficients) lives inside the model's device handle."
-mutable struct GPUKPMPreconditioner{T<:GPUModel}
-    model::T
-    active::Bool
-    λ_lo::Float64
-    λ_hi::Float64
-    transposed::Bool
+"solve!(x, A, b, cg; maxiter, tol, κmax) -> iters — IterativeSolvers.jl:239-314 (no true-residual check, no flags: that is ldiv!'s)"
+function solve!(x::Vector{Float64}, m::GPUModel, b::Vector{Float64}, cg::ConjugateGradient{Float64,Float64};
+                maxiter::Int=0, tol::Float64=0.0, κmax::Float64=0.0)::Int
+    e = entry(m)
+    if e === nothing || !servable(m)
+        deferred!(e)
+        return invoke(solve!, Tuple{AbstractVector{Float64},Any,AbstractVector{Float64},ConjugateGradient{Float64,Float64}}, x, m, b, cg;
+                      maxiter=maxiter, tol=tol, κmax=κmax)
+    end
+    return gpu_solve!(x, e, m, b, cg, false, maxiter, tol, κmax)
 end
 
-"GPUKPMPreconditioner(model, n, buf, c1, c2): arguments of SymmetricKPMPreconditioner (KPMPreconditioners.jl:224)"
-function GPUKPMPreconditioner(g::GPUModel, n::Int, buf::Float64, c1::Float64, c2::Float64)
-    chk(ccall((:elph_kpm_create, lib), Cint, (Ptr{Cvoid}, Cint, Float64, Float64, Float64), g.handle, n, buf, c1, c2))
-    return GPUKPMPreconditioner(g, false, 0.0, 2.0, false)
+"solve!(x, A, b, cg, P; maxiter, tol, κmax) -> iters — IterativeSolvers.jl:153-234"
+function solve!(x::Vector{Float64}, m::GPUModel, b::Vector{Float64}, cg::ConjugateGradient{Float64,Float64}, P;
+                maxiter::Int=0, tol::Float64=0.0, κmax::Float64=0.0)::Int
+    e = entry(m)
+    mode = (e === nothing || !servable(m)) ? -1 : precond_mode(e, m, P)
+    if mode < 0
+        deferred!(e)
+        return invoke(solve!, Tuple{AbstractVector{Float64},Any,AbstractVector{Float64},ConjugateGradient{Float64,Float64},Any}, x, m, b, cg, P;
+                      maxiter=maxiter, tol=tol, κmax=κmax)
+    end
+    return gpu_solve!(x, e, m, b, cg, mode == 1, maxiter, tol, κmax)
 end
 
-"setup!(P): τ-average Ē, Arnoldi eigenvalue bounds from two start vectors drawn from model.rng (KPMPreconditioners.jl:859-861,
-902-904), acceptance test, orders and coefficients — :259-321.  Call after update_model!, as HMC.jl:834 does."
-function setup!(P::GPUKPMPreconditioner)
-    g = P.model
-    N = g.Nsites
-    b_max = randn(g.rng, N)
-    b_min = randn(g.rng, N)
+# ------------------------------------------------------------------------------------------------------------------------------
+# KPM preconditioner — the reference's own SymmetricKPMPreconditioner (KPMPreconditioners.jl:219-235) of an attached model
+# ------------------------------------------------------------------------------------------------------------------------------
+
+const GPUSymmetricKPM = SymmetricKPMPreconditioner{Float64,Float64,<:GPUModel}
+
+"""
+    setup!(P)                                                                             KPMPreconditioners.jl:259-321
+
+τ-average Ē (update_A!, :332-381), the two Arnoldi runs for e_max and 1/e_min (:845-942) from start vectors drawn from `model.rng` — the
+same 2·Nsites `randn(rng, Float64)` calls in the same order as :859-861 and :902-904, so the stream of `model.rng` advances exactly as
+in a CPU run — the acceptance test, λ_lo/λ_hi with the `buf` hysteresis, orders and Chebyshev coefficients (:259-321), all on the
+device.  `P.expansion.active`, `.λ_lo`, `.λ_hi`, `.λ_avg`, `.λ_mag` and `.order` mirror the device's values for the readers of those
+fields; the coefficients themselves stay on the device.
+"""
+function setup!(P::GPUSymmetricKPM)
+    op = P.expansion
+    m = op.model
+    e = entry(m)
+    if e === nothing
+        return invoke(setup!, Tuple{KPMPreconditioner}, P)
+    end
+    if e.kpm !== op                     # first use of this expansion on this handle: its n, buf, c1, c2 (KPMPreconditioners.jl:63-93)
+        chk(ccall((:elph_kpm_create, lib), Cint, (Ptr{Cvoid}, Cint, Float64, Float64, Float64), e.handle, op.n, op.buf, op.c1, op.c2))
+        e.kpm = op
+    end
+    N = m.Nsites
+    for i in 1:N
+        e.bmax[i] = randn(m.rng, Float64)
+    end
+    for i in 1:N
+        e.bmin[i] = randn(m.rng, Float64)
+    end
     act = Ref{Cint}(0); lo = Ref{Float64}(0.0); hi = Ref{Float64}(0.0)
     chk(ccall((:elph_kpm_setup, lib), Cint,
               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Ref{Cint}, Ref{Float64}, Ref{Float64}),
-              g.handle, b_max, b_min, NaN, NaN, act, lo, hi))
-    P.active = act[] != 0
-    P.λ_lo = lo[]; P.λ_hi = hi[]
+              e.handle, e.bmax, e.bmin, NaN, NaN, act, lo, hi))
+    op.active = act[] != 0
+    if op.active
+        op.λ_lo = lo[]; op.λ_hi = hi[]
+        op.λ_avg = (op.λ_hi + op.λ_lo) / 2
+        op.λ_mag = (op.λ_hi - op.λ_lo) / 2
+        total = Ref{Int64}(0)
+        chk(ccall((:elph_kpm_orders, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ref{Int64}), e.handle, op.order, total))
+    end
+    e.kpm_ready = true
+    served!(e)
     return nothing
 end
 
-"ldiv!(z, P, r): z = P⁻¹ r (twisted τ-FFT, per-ω Chebyshev series, inverse) — KPMPreconditioners.jl:426-481; a copy when inactive"
-function ldiv!(z::AbstractVector{Float64}, P::GPUKPMPreconditioner, r::AbstractVector{Float64})
-    chk(ccall((:elph_kpm_apply, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), P.model.handle, z, r))
+"ldiv!(z, P, r): z = P⁻¹⋅r (twisted τ-FFT, per-ω Chebyshev series, inverse) — KPMPreconditioners.jl:426-481; a copy when inactive"
+function ldiv!(z::Vector{Float64}, P::GPUSymmetricKPM, r::Vector{Float64})
+    op = P.expansion
+    e = entry(op.model)
+    if e === nothing || e.kpm !== op || !e.kpm_ready || P.transposed
+        deferred!(e)
+        return invoke(ldiv!, Tuple{AbstractVector{Float64},KPMPreconditioner,AbstractVector{Float64}}, z, P, r)
+    end
+    @assert length(z) == op.model.Ndim && length(r) == op.model.Ndim
+    chk(ccall((:elph_kpm_apply, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, z, r))
+    served!(e)
     return nothing
 end
 
-Base.:(==)(P::GPUKPMPreconditioner, ::UniformScaling) = false
-Base.:(==)(::UniformScaling, P::GPUKPMPreconditioner) = false
+# ------------------------------------------------------------------------------------------------------------------------------
+# calc_O⁻¹Λϕ! — HMC.jl:820-915 with the two pseudofermion systems as one batch of two right-hand sides (same matrix, same
+# tolerance): every other line is the reference's, in the reference's order
+# ------------------------------------------------------------------------------------------------------------------------------
 
-# ---- Fourier acceleration — FourierAcceleration.jl:91-143 ------------------------------------------------------------------------
+function calc_O⁻¹Λϕ!(hmc::HybridMonteCarlo{Float64}, model::GPUModel, preconditioner, power::Float64)::Tuple{Int,Int}
+    e = entry(model)
+    mode = (e === nothing || !e.batch_pseudofermions || !servable(model)) ? -1 : 0
+    if mode < 0
+        return invoke(calc_O⁻¹Λϕ!, Tuple{HybridMonteCarlo{Float64},AbstractModel{Float64,Float64},Any,Float64}, hmc, model, preconditioner, power)
+    end
+    Λϕ₊, Λϕ₋, O⁻¹Λϕ₊, O⁻¹Λϕ₋ = hmc.Λϕ₊, hmc.Λϕ₋, hmc.O⁻¹Λϕ₊, hmc.O⁻¹Λϕ₋
+    tol = model.solver.tol
+    model.solver.tol = tol^power                                          # :827-828
+    hmc.iters = 0
+    setup!(preconditioner)                                                # :834 (a no-op method exists for I, KPMPreconditioners.jl:323)
+    mode = precond_mode(e, model, preconditioner)
+    if mode < 0                                                           # a preconditioner the library does not hold: one at a time
+        model.solver.tol = tol
+        return invoke(calc_O⁻¹Λϕ!, Tuple{HybridMonteCarlo{Float64},AbstractModel{Float64,Float64},Any,Float64}, hmc, model, preconditioner, power)
+    end
+    update_Λ!(hmc, model)                                                 # :840-842
+    mulΛ!(Λϕ₊, hmc.ϕ₊, hmc, model)
+    mulΛ!(Λϕ₋, hmc.ϕ₋, hmc, model)
+    X, B = e.X2, e.B2
+    fill!(X, 0.0)                                                         # fill!(O⁻¹Λϕ±, 0.0), :854,883
+    copyto!(view(B, :, 1), Λϕ₊)
+    copyto!(view(B, :, 2), Λϕ₋)
+    model.transposed = false
+    iters, err, flags = ldiv_batched!(X, model, B, preconditioner)
+    copyto!(O⁻¹Λϕ₊, view(X, :, 1))
+    hmc.iters += iters[1]
+    flag = flags[1]
+    if iszero(flag)                                                       # the second system counts only if the first converged, :880
+        copyto!(O⁻¹Λϕ₋, view(X, :, 2))
+        hmc.iters += iters[2]
+        flag = flags[2]
+    end
+    if iszero(flag)
+        hmc.iters = cld(hmc.iters, 2)                                     # :907-909
+    end
+    model.solver.tol = tol                                                # :912
+    return hmc.iters, flag
+end
 
-"""
-    fourier_accelerate!(v′, fa, model, v, power; use_mass=false)
+# ------------------------------------------------------------------------------------------------------------------------------
+# Fourier acceleration — FourierAcceleration.jl:131-137 (real in, real out: the form HMC.jl:386,656,715 and LangevinDynamics.jl use)
+# ------------------------------------------------------------------------------------------------------------------------------
 
-v′ = iFFT_τ( D^power ∘ FFT_τ(v) ), D = fa.M (use_mass) or fa.Q, real in, real out (FourierAcceleration.jl:128-135) on the device
-of `model`.  The reference's method has no model argument (`fourier_accelerate!(v′, fa, v, power)`); HMC.jl:386,656,715 and
-LangevinDynamics.jl pass `fa` built from the same model, so the call sites gain the one argument — or keep FFTW: both give the
-same numbers to 1e-13.
-"""
-function fourier_accelerate!(v′::AbstractVector{Float64}, fa::FourierAccelerator{Float64}, g::GPUModel, v::AbstractVector{Float64},
-                             power::Float64; use_mass::Bool=false)
+"v′ = iFFT_τ( D^power ∘ FFT_τ(v) ), D = fa.M (use_mass) or fa.Q, on the device of the model `fa` was registered with"
+function fourier_accelerate!(v′::Vector{Float64}, fa::FourierAccelerator{Float64}, v::Vector{Float64}, power::Float64; use_mass::Bool=false)
+    m = get(FA_REGISTRY, fa, nothing)
+    e = m === nothing ? nothing : entry(m)
+    if e === nothing
+        return invoke(fourier_accelerate!, Tuple{AbstractVector{Float64},FourierAccelerator{Float64},AbstractVector{Float64},Float64}, v′, fa, v, power;
+                      use_mass=use_mass)
+    end
+    @assert length(v′) == fa.N * fa.L && length(v) == fa.N * fa.L
     chk(ccall((:elph_fourier_accelerate, lib), Cint,
               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Int64),
-              g.handle, v′, v, use_mass ? fa.M : fa.Q, power, fa.N))
+              e.handle, v′, v, use_mass ? fa.M : fa.Q, power, fa.N))
+    served!(e)
     return nothing
 end
-
-"in-place form — FourierAcceleration.jl:137-141"
-fourier_accelerate!(v::AbstractVector{Float64}, fa::FourierAccelerator{Float64}, g::GPUModel, power::Float64; use_mass::Bool=false) =
-    fourier_accelerate!(v, fa, g, v, power, use_mass=use_mass)
-
-# ---- twisted transforms — TimeFreqFFTs.jl:55-73, 112-130 -------------------------------------------------------------------------
-
-"τ_to_ω!(ν, model, v): ν = FFT_τ(Θ ∘ v), Θ_τ = exp(-iπ(τ-1)/Lτ); ν complex, length Ndim"
-function τ_to_ω!(ν::AbstractVector{ComplexF64}, g::GPUModel, v::AbstractVector{Float64})
-    chk(ccall((:elph_tau_to_omega, lib), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}), g.handle, ν, v))
-    return nothing
-end
-
-"ω_to_τ!(v, model, ν): v = real(conj(Θ) ∘ iFFT_τ(ν))"
-function ω_to_τ!(v::AbstractVector{Float64}, g::GPUModel, ν::AbstractVector{ComplexF64})
-    chk(ccall((:elph_omega_to_tau, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}), g.handle, v, ν))
-    return nothing
-end
-
-# ---- sizes, as Models.jl:254-284 ---------------------------------------------------------------------------------------------------
-
-Base.eltype(g::GPUModel) = eltype(g.host)
-Base.size(g::GPUModel) = size(g.host)
-Base.size(g::GPUModel, d::Int) = size(g.host, d)
-Base.length(g::GPUModel) = length(g.host)
 
 end # module
