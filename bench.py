@@ -91,8 +91,52 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N rank processes ourselves — fresh children of
+    `python -m torch.distributed.run` on 127.0.0.1, before this process has touched a GPU or imported torch (a child, never an exec) —
+    and leave with their exit code.  A request for N GPUs therefore either prints a line with n_gpus = N or fails; it never prints a
+    one-GPU line.  (The reference's way of filling a node is N independent run-IDs, ElPhDynamics.jl:90-95.)"""
+    import socket
+    import subprocess
+    if os.environ.get("ELPH_BENCH_NO_SELF_LAUNCH") == "1":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} ranks (WORLD_SIZE is not set and self-launch is disabled): "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+    rpp = max(1, args.ranks_per_proc if args.mode == "spatial" else 1)
+    if args.gpus % rpp:
+        raise SystemExit(f"--gpus {args.gpus} is not a multiple of --ranks-per-proc {rpp}")
+    nproc = args.gpus // rpp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {args.gpus} without a launcher: starting {nproc} rank process(es): {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ, ELPH_BENCH_SELF_LAUNCHED="1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_line(args, comm):
+    """ELPH_BENCH_DRY=1: the launch / rendezvous / reduction path of an N-rank run WITHOUT device work (the CPU test of self_launch at
+    world 2 over gloo) — value is null and the line says so; never a measurement."""
+    from elphdynamics_amd import dist as edist
+    elapsed, work = edist.timed_steps(comm, lambda k: (time.sleep(0.01 * (1 + comm.rank)), 2.0 * args.nrhs * k)[1], max(1, args.steps))
+    if comm.rank == 0:
+        print(json.dumps({"metric": "cg_matvecs_per_sec", "value": None, "unit": "matvec/s", "n_gpus": comm.world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f64", "data": "DRY RUN: no device work (ELPH_BENCH_DRY=1), launch path only", "dry_run": True,
+                          "work_all_ranks": work, "elapsed_max": elapsed, "self_launched": os.environ.get("ELPH_BENCH_SELF_LAUNCHED") == "1",
+                          "dist_backend": comm.backend}))
+    comm.close()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        self_launch(args)              # does not return
+    rpp = max(1, args.ranks_per_proc) if args.mode == "spatial" else 1
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")) * rpp:      # before the rendezvous: a wrong rank count must not hang in it
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} x {rpp} rank thread(s) per process")
     from elphdynamics_amd import dist as edist
     comm = edist.Comm()            # imports torch (and initialises RCCL) only when WORLD_SIZE > 1
     rank, local_rank, world = comm.rank, comm.local_rank, comm.world
@@ -102,8 +146,10 @@ def main():
         edist.HybridComm.spawn(comm, args.ranks_per_proc, lambda hc: main_sharded(args, hc))
         comm.close()
         return
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("ELPH_BENCH_DRY") == "1":
+        return dry_line(args, comm)
 
     if world > 1:        # the CPU baseline and the secondary measurements belong to the N = 1 run (rank 0 only, contract ④)
         args.no_cpu = True
@@ -598,8 +644,35 @@ def main():
     if rank == 0:
         if spatial is not None:
             out["spatial"] = spatial
+            flat = {}
+            for tag in ("C", "D", "E"):
+                rec = spatial.get(tag) or {}
+                if "us_per_iteration_device" in rec:
+                    flat[f"spatial_{tag}_us_per_iteration"] = rec["us_per_iteration_device"]
+                    flat[f"spatial_{tag}_matvecs_per_sec"] = rec["matvecs_per_sec"]
+                    flat.setdefault("spatial_ranks", rec["ranks"])
+                    flat.setdefault("rccl_ranks", rec["rccl_ranks"])
+                    flat.setdefault("spatial_devices", len(rec.get("devices") or []))
+            out.update(flat)
+            out["roofline"].update(flat)
+        out["roofline"] = order_roofline(out["roofline"])
         print(json.dumps(out))
     comm.close()
+
+
+# The driver's record keeps the FIRST two dozen scalars of `roofline` (and drops every non-standard top-level key): what must survive
+# goes first — the dominant kernel's line, then the production (KPM-preconditioned) iteration, the streaming form, the HMC update and
+# the sharded solve.
+ROOFLINE_FIRST = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "us_per_iteration",
+                  "precond_iter_us", "precond_hbm_frac", "precond_matvecs_per_sec", "precond_ap_us", "precond_fwd_us", "precond_cheb_us",
+                  "precond_inv_us", "streaming_iter_us", "streaming_iter_frac", "hmc_update_ms_1chain",
+                  "spatial_C_us_per_iteration", "spatial_C_matvecs_per_sec", "spatial_ranks", "rccl_ranks", "spatial_devices")
+
+
+def order_roofline(roof):
+    first = {k: roof[k] for k in ROOFLINE_FIRST if k in roof}
+    first.update((k, v) for k, v in roof.items() if k not in first)
+    return first
 
 
 F64_FLOPS_PER_ITER = lambda ndim, ltau, nbonds: 2.0 * (2.0 * ndim + 6.0 * ltau * nbonds) + 10.0 * ndim     # noqa: E731  SURVEY §8(d)
@@ -692,11 +765,38 @@ def spatial_records(comm, K, cpu=False, factory=None):
     out = {"note": "unmeasured across physical GPUs until a multi-GPU node runs this: on a one-GPU box every rank shares device 0 "
                    "(ELPH_FORCE_DEVICE) and the numbers are the protocol's cost, not xGMI's"} if len(set(comm.allgather_object(comm.device_index()))) < comm.world and comm.world > 1 else {}
     for tag in ("C", "D", "E"):
-        try:
-            out[tag] = measure_sharded(tag, comm, K, max(1, K // 10), factory)
-        except Exception as e:     # the same exception on every rank (geometry) — or a failed rank: recorded, never fatal for the headline
-            out[tag] = {"config": tag, "ranks": comm.world, "error": repr(e)}
+        out[tag] = measure_sharded_agreed(tag, comm, K, max(1, K // 10), factory)
     return out
+
+
+def measure_sharded_agreed(tag, comm, K, W, factory=None):
+    """measure_sharded with the ranks agreeing on failure BEFORE any of them enters a collective or a mailbox wait of the config: the
+    set-up (slab geometry, handle, model, self-test) runs first and its outcome is all-gathered; if any rank failed, every rank skips
+    the config and records the first error — a rank that failed alone (out of memory, a self-test error) cannot leave the others
+    blocked in a barrier.  A failure inside the timed solve itself is bounded by the sharded solve's own wait bound
+    (ELPH_SHARD_TIMEOUT_MS) and reported the same way."""
+    made, err = None, None
+    try:
+        made = (factory or make_sharded)(tag, comm)
+    except Exception as e:
+        err = repr(e)
+    errs = comm.allgather_object(err)
+    if any(errs):
+        if made is not None:
+            try:
+                made[0].close()
+            except Exception:
+                pass
+        return {"config": tag, "ranks": comm.world, "error": next(e for e in errs if e), "failed_ranks": [r for r, e in enumerate(errs) if e]}
+    rec, err = None, None
+    try:
+        rec = measure_sharded(tag, comm, K, W, factory=lambda *_: made)
+    except Exception as e:
+        err = repr(e)
+    errs = comm.allgather_object(err)
+    if any(errs):
+        return {"config": tag, "ranks": comm.world, "error": next(e for e in errs if e), "failed_ranks": [r for r, e in enumerate(errs) if e]}
+    return rec
 
 
 def main_sharded(args, comm):

@@ -122,3 +122,30 @@ def test_spatial_sub_record_schema_two_ranks_gloo(tmp_path):
     assert abs(c["matvecs_per_sec"] - 2.0 / 12e-6) < 1e-3
     assert c["peak"] == 2 * 78.6 and 0.0 < c["frac"] < 1.0 and c["unit"] == "TFLOP/s"
     assert "error" in rec["D"] and "ghost rows" in rec["D"]["error"] and rec["D"]["ranks"] == 2
+
+
+def test_bench_self_launches_its_ranks_or_refuses():
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.py starts the two rank processes itself (torch.distributed.run on 127.0.0.1,
+    before touching a GPU) and the line says n_gpus = 2 — never a one-GPU line for a two-GPU request.  Here on the CPU over gloo with
+    ELPH_BENCH_DRY=1 (launch / rendezvous / reduction path only: value is null and the line is marked a dry run)."""
+    import json
+    env = dict(os.environ, ELPH_BENCH_DRY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["self_launched"] is True
+    assert d["work_all_ranks"] == 2 * 2.0 * 288 * 3 and d["elapsed_max"] >= 0.02 - 1e-3      # SUM of the work, MAX of the time (rank 1 sleeps 0.02 s, rank 0 0.01 s)
+    assert "starting 2 rank process(es)" in p.stderr
+    # refusal instead of a silent one-GPU measurement when self-launch is switched off
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, ELPH_BENCH_NO_SELF_LAUNCH="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")] and "needs 2 ranks" in p.stderr
+    # a launcher that started the wrong number of ranks is refused too (was: accepted when WORLD_SIZE == 1)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0",
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), ELPH_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=30)
+    assert p.returncode != 0
