@@ -361,7 +361,14 @@ def main():
                 gemm_flops = 2.0 * (2.0 * (2 * Qq) * Hh) * m.Nsites * nrhs if m.Ltau % 2 == 0 else None   # two half-length f64 GEMMs (even / odd slices)
                 # k_cg_ap 6 vectors + tables; forward transform with the residual update folded in: reads r, z, writes r, nu (4; the half
                 # spectrum nu is one vector of bytes); Chebyshev reads and writes nu (2); inverse reads nu, writes P^-1 r (2)
-                byts = {4: built_ap, 6: 4.0 * vec, 7: 2.0 * vec, 8: 2.0 * vec}
+                check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
+                fused = C.c_int()
+                check(lib.elph_bench_px_info(m._h, C.byref(fused)))
+                if fused.value:      # p/x-fused (round 5): k_cg_ap reads the ready p (+ tables), writes z; the inverse transform reads nu, p, x and
+                    byts = {4: 2.0 * vec + tab, 6: 4.0 * vec, 7: 2.0 * vec, 8: 5.0 * vec}      # writes p, x: 13 vectors per iteration instead of 14
+                else:
+                    byts = {4: built_ap, 6: 4.0 * vec, 7: 2.0 * vec, 8: 2.0 * vec}
+                rp["precond_px_fused"] = int(fused.value)
                 byts[3] = byts[4] + byts[6] + byts[7] + byts[8]
                 for wh in (4, 6, 7, 8, 3):
                     check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
@@ -372,6 +379,18 @@ def main():
                     rp[f"precond_{names[wh]}_hbm_frac"] = byts[wh] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
                     if wh in (6, 8) and gemm_flops:
                         rp[f"precond_{names[wh]}_mfma_frac"] = gemm_flops / (us * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS
+                # the form elph_ldiv_batched runs from 128 right-hand sides: the same iteration as two half-batches on two streams
+                try:
+                    check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
+                    run(11, nrhs, 32)
+                    rp["precond_iter_us_one_stream"] = rp["precond_iter_us"]
+                    us2 = 1e3 * run(11, nrhs, 320) / 320
+                    rp["precond_iter_us_two_streams"] = us2
+                    if nrhs >= 128 and os.environ.get("ELPH_SPLIT_STREAMS") != "0":       # what a solve of this batch runs
+                        rp["precond_iter_us"] = us2
+                        rp["precond_iter_hbm_frac"] = byts[3] / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS
+                except Exception as e:
+                    rp["precond_two_streams_error"] = repr(e)
                 rp["precond_bytes"] = byts[3]
                 rp["precond_hbm_frac"] = rp["precond_iter_hbm_frac"]
                 rp["precond_matvecs_per_sec"] = 2.0 * nrhs / (rp["precond_iter_us"] * 1e-6)
@@ -384,8 +403,9 @@ def main():
                 out["precond_cg_iters_per_sec"] = nrhs / (rp["precond_iter_us"] * 1e-6)
                 out["roofline"].update(rp)
                 out["roofline_preconditioned"] = dict(rp, note=(
-                    "bytes: k_cg_ap 6 vectors + tables (src = P^-1 r); forward transform reads r, z and writes r, nu (4 vectors); Chebyshev reads "
-                    "and writes nu; inverse reads nu, writes P^-1 r — 14 vectors per iteration.  SURVEY 8(d)'s 16 B x Ndim per KPM apply "
+                    "bytes (unfused): k_cg_ap 6 vectors + tables (src = P^-1 r); forward transform reads r, z and writes r, nu (4 vectors); Chebyshev reads "
+                    "and writes nu; inverse reads nu, writes P^-1 r — 14 vectors per iteration.  p/x-fused (precond_px_fused = 1): k_cg_ap reads p, writes z "
+                    "(2 + tables); the inverse reads nu, p, x and writes p, x (5) — 13.  SURVEY 8(d)'s 16 B x Ndim per KPM apply "
                     "assumes the three kernels fused into one.  The Chebyshev kernel is latency-bound by its longest recursion.  mfma: two "
                     f"(L/2 x L/2) real f64 GEMMs per transform on v_mfma_f64_16x16x4_f64, peak {F64_MFMA_PEAK_TFLOPS} TFLOP/s"))
             except Exception as e:

@@ -29,7 +29,7 @@
 // the 6-colour instantiation lives in cg_fast6.hip
 namespace lp6 {
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
-int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool px);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, bool *did_rz, const double *rr_part, int fold_nct);
 }  // namespace lp6
@@ -38,8 +38,8 @@ int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int
     return h->lp_mc == 4 ? lp4::elph_fast_mul(h, which, yS, vS, nvec) : lp6::elph_fast_mul(h, which, yS, vS, nvec);
 }
 int elph_choose_T(const elph_handle_s *h, int nrhs) { return lp4::elph_choose_T(h, nrhs); }
-int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
-    return h->lp_mc == 4 ? lp4::elph_fast_cg_ap(h, B, nrhs, parity) : lp6::elph_fast_cg_ap(h, B, nrhs, parity);
+int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool px) {
+    return h->lp_mc == 4 ? lp4::elph_fast_cg_ap(h, B, nrhs, parity, px) : lp6::elph_fast_cg_ap(h, B, nrhs, parity, px);
 }
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {
     return h->lp_mc == 4 ? lp4::elph_fast_cg_xr(h, B, nrhs, parity) : lp6::elph_fast_cg_xr(h, B, nrhs, parity);

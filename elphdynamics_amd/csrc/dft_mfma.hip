@@ -16,9 +16,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "elph_internal.h"
-
-#define WAVE ELPH_WAVE
+#include "cg_fast_common.h"      // reduce_partials_lane: the SAME summation order as k_cg_ap takes for r.z (PxFuse)
 
 namespace {
 
@@ -248,6 +246,19 @@ struct XrFuse {
     int fnch, fnrz, fslot0;
 };
 
+// PX (inverse only, streaming form, one row group): the tail of the preconditioned CG iteration is done on the way out — with
+// z = P^-1 r in the accumulators,  x <- x + alpha p  (the pending update of this iteration) and  p <- z + beta p,  beta = (r.z) / rho
+// from the r.z partials the Chebyshev kernel left in frequency space and the rho of the current state copy.  z itself is never
+// written; the next k_cg_ap_chunk<PX> reads p only.  Same arithmetic per element as k_cg_ap_chunk's own p- and x-update
+// (sv + beta qv, xv + alpha qv) and the same summation order for r.z (reduce_partials_lane): the two forms give the same bits.
+struct PxFuse {
+    double *p;                // [nrhs][ndim], slot 0 of the ping-pong pair: updated in place
+    double *x;                // [nrhs][ndim]
+    const double *alpha;      // [nrhs] step length of this iteration (written by the forward transform's XrFuse)
+    const double *rz;         // r.z partial slots [nrhs][nrz]
+    int nrz;
+};
+
 template <int NT, bool INV, bool XR>
 __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ out, const double *__restrict__ in,
                                                       const double *__restrict__ W, const double2 *__restrict__ tw, int N, int L,
@@ -404,11 +415,12 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2(double *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------
 // RZ (inverse only): fuse the time-domain r.z partial sums (needs this lane's slice of r); without it the inverse is a pure
 // transform (the Chebyshev kernel delivered r.z in frequency space) and fits a third wave per SIMD
-template <int NT, bool INV, bool XR, bool RZ>
+template <int NT, bool INV, bool XR, bool RZ, bool PX = false>
 __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__ out, const double *__restrict__ in,
                                                        const double *__restrict__ W, const double2 *__restrict__ tw, int N, int L,
                                                        const CgState *state, const double *__restrict__ rvec,
-                                                       double *__restrict__ rz_part, int nrz, XrFuse X) {
+                                                       double *__restrict__ rz_part, int nrz, XrFuse X, PxFuse PXF = PxFuse{}) {
+    static_assert(!PX || (INV && !RZ && !XR), "PxFuse rides on the pure inverse transform");
     extern __shared__ double Wl[];                                       // [MG][NT][64]
     const int rhs = blockIdx.z;
     if (mf_done(state, rhs)) return;                                     // uniform over the workgroup
@@ -487,6 +499,27 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
                 rv1[g * 4 + r] = rvec[i + N];
             }
         }
+    }
+    // PxFuse: beta and alpha of this right-hand side; p and x of the first row tile fetched now, under the MFMAs (the other
+    // tiles one ahead in the epilogue)
+    double px_beta = 0.0, px_alpha = 0.0;
+    double pq[PX ? 2 : 1][PX ? 8 : 1], xq[PX ? 2 : 1][PX ? 8 : 1];
+    double *pb = PX ? PXF.p + (size_t)rhs * N * L : nullptr, *xb = PX ? PXF.x + (size_t)rhs * N * L : nullptr;
+    auto px_fetch = [&](int g, double (&pv)[PX ? 8 : 1], double (&xv)[PX ? 8 : 1]) {
+#pragma unroll
+        for (int r = 0; r < (PX ? 4 : 0); ++r) {
+            int jr = 16 * (mt0 + g) + (lane >> 4) + 4 * r;
+            jr = (jr < H) ? jr : H - 1;
+            const size_t i = (size_t)(2 * jr) * N + sc;
+            pv[2 * r] = pb[i]; pv[2 * r + 1] = pb[i + N];
+            xv[2 * r] = xb[i]; xv[2 * r + 1] = xb[i + N];
+        }
+    };
+    if constexpr (PX) {
+        const double rzs = reduce_partials_lane(PXF.rz + (size_t)rhs * PXF.nrz, PXF.nrz, lane);
+        px_beta = rzs / __hip_atomic_load(&state[2 * rhs].rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        px_alpha = __hip_atomic_load(PXF.alpha + rhs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        px_fetch(0, pq[0], xq[0]);
     }
     double4_t acc0[MG], acc1[MG];
 #pragma unroll
@@ -568,6 +601,24 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
 #pragma unroll
             for (int o2 = 32; o2 > 0; o2 >>= 1) facc += __shfl_xor(facc, o2, WAVE);
             if (lane == 0) X.frz[(size_t)rhs * X.fnrz + X.fslot0 + ctile] = facc;
+        }
+    } else if constexpr (PX) {
+#pragma unroll
+        for (int g = 0; g < MG; ++g) {
+            if (g + 1 < MG) px_fetch(g + 1, pq[(g + 1) & 1], xq[(g + 1) & 1]);
+            const double (&pv)[8] = pq[g & 1];
+            const double (&xv)[8] = xq[g & 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * (mt0 + g) + r0 + 4 * r;
+                if (s < N && j < H) {
+                    const size_t i = (size_t)(2 * j) * N + s;
+                    xb[i] = xv[2 * r] + px_alpha * pv[2 * r];
+                    xb[i + N] = xv[2 * r + 1] + px_alpha * pv[2 * r + 1];
+                    pb[i] = acc0[g][r] + px_beta * pv[2 * r];
+                    pb[i + N] = acc1[g][r] + px_beta * pv[2 * r + 1];
+                }
+            }
         }
     } else {
         double dot = 0.0;
@@ -652,7 +703,7 @@ int launch_1(elph_handle_s *h, int nt, double *out, const double *in, const doub
 
 template <bool INV, bool XR = false>
 int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, const double *in, int N, int nrhs, const CgState *st,
-              const double *rvec, double *rz_part, int nrz, XrFuse X = XrFuse{}) {
+              const double *rvec, double *rz_part, int nrz, XrFuse X = XrFuse{}, PxFuse PXF = PxFuse{}) {
     const int nct = (N + 15) / 16;
     const dim3 grid((unsigned)((nct + CW - 1) / CW), (unsigned)T.groups, (unsigned)nrhs), block(CW * WAVE);
     const int L = (int)h->L;
@@ -664,15 +715,15 @@ int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, co
     const char *es = getenv("ELPH_DFT_STREAM");
     if (panel <= 144 * 1024 && !(es && atoi(es) == 0)) {
         hipError_t attr_rc = hipSuccess;
-#define R2S_LAUNCH(NTV, RZV) do {                                                                                              \
-            auto kfn = k_dft_mfma_r2s<NTV, INV, XR, RZV>;                                                                       \
+#define R2S_LAUNCH(NTV, RZV, PXV) do {                                                                                         \
+            auto kfn = k_dft_mfma_r2s<NTV, INV, XR, RZV, PXV>;                                                                  \
             if (shm_s > 64 * 1024) {                                                                                            \
                 static bool raised = false;                                                                                     \
                 if (!raised) { attr_rc = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(panel + 8192)); raised = (attr_rc == hipSuccess); } \
             }                                                                                                                   \
-            if (attr_rc == hipSuccess) hipLaunchKernelGGL(kfn, grid, block, shm_s, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); \
+            if (attr_rc == hipSuccess) hipLaunchKernelGGL(kfn, grid, block, shm_s, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X, PXF); \
         } while (0)
-#define R2S_CASE(NTV) case NTV: if (INV && rz_part) R2S_LAUNCH(NTV, INV); else R2S_LAUNCH(NTV, false); break;
+#define R2S_CASE(NTV) case NTV: if (INV && !XR && PXF.p) R2S_LAUNCH(NTV, false, (INV && !XR)); else if (INV && rz_part) R2S_LAUNCH(NTV, INV, false); else R2S_LAUNCH(NTV, false, false); break;
         switch (T.nt) {
             R2S_CASE(5) R2S_CASE(10) R2S_CASE(15) R2S_CASE(20) R2S_CASE(25) R2S_CASE(32) R2S_CASE(40) R2S_CASE(50)
             default: elph_set_error("dft_mfma_r2s: no kernel for %d reduction tiles", T.nt); return ELPH_E_UNSUPPORTED;
@@ -682,6 +733,7 @@ int launch_r2(elph_handle_s *h, const elph_handle_s::MfmaTab &T, double *out, co
         if (attr_rc != hipSuccess) { elph_set_error("hipFuncSetAttribute(dynamic LDS %zu B) failed: %s", panel, hipGetErrorString(attr_rc)); return ELPH_E_HIP; }
         return mf_check(INV ? "k_dft_mfma_r2s(inverse)" : "k_dft_mfma_r2s(forward)");
     }
+    if (PXF.p) { elph_set_error("dft_mfma: the p/x-fused inverse exists in the streaming form only"); return ELPH_E_STATE; }
 #define R2_CASE(NTV) case NTV: hipLaunchKernelGGL((k_dft_mfma_r2<NTV, INV, XR>), grid, block, 0, h->stream, out, in, T.W, tw, N, L, st, rvec, rz_part, nrz, X); break;
     switch (T.nt) {
         R2_CASE(5) R2_CASE(10) R2_CASE(15) R2_CASE(20) R2_CASE(25) R2_CASE(32)
@@ -773,6 +825,24 @@ int elph_dft_mfma_inv(elph_handle_s *h, int which, double *outS, const double2 *
     const int K = which == 0 ? (int)(h->L + 1) / 2 : (int)h->L / 2 + 1;
     if (rz_part && (int)((N + 15) / 16) * T.groups > nrz) { elph_set_error("dft_mfma: %d partial slots needed, %d available", ((N + 15) / 16) * T.groups, nrz); return ELPH_E_STATE; }
     return launch<true>(h, T.nt, outS, reinterpret_cast<const double *>(nu), T.W, N, K, T.groups, nrhs, st, rvec, rz_part, nrz);
+}
+
+// inverse twisted transform with the p- and x-update of the preconditioned CG iteration in its epilogue (PxFuse)
+bool elph_dft_mfma_px_usable(const elph_handle_s *h, int N, int nrhs) {
+    const char *e = getenv("ELPH_FUSE_PX");
+    if (e && atoi(e) == 0) return false;
+    const elph_handle_s::MfmaTab &T = h->mf_r2[1];
+    if (!T.W || !r2_enabled() || T.groups != 1 || (h->L & 1)) return false;       // one row group: every element of p, x belongs to one lane
+    const size_t panel = (size_t)MG * T.nt * WAVE * sizeof(double);
+    const char *es = getenv("ELPH_DFT_STREAM");
+    return panel <= 144 * 1024 && !(es && atoi(es) == 0) && elph_dft_mfma_usable(h, 0, true, N, nrhs);
+}
+
+int elph_dft_mfma_inv_px(elph_handle_s *h, const double2 *nu, int N, int nrhs, const CgState *st, double *pS, double *xS,
+                         const double *alpha, const double *rz, int nrz) {
+    if (!st) { elph_set_error("dft_mfma: the p/x-fused inverse needs the CG state"); return ELPH_E_STATE; }
+    PxFuse PXF{pS, xS, alpha, rz, nrz};
+    return launch_r2<true>(h, h->mf_r2[1], nullptr, reinterpret_cast<const double *>(nu), N, nrhs, st, nullptr, nullptr, 0, XrFuse{}, PXF);
 }
 
 // host: the four W matrices in A-tile order (zero-padded to groups*MG row tiles x nt reduction tiles)

@@ -473,6 +473,8 @@ extern "C" int elph_destroy(elph_handle h) {
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->split_ev) (void)hipEventDestroy(h->split_ev);
     delete h;
     return ELPH_OK;
 }
@@ -778,6 +780,66 @@ static int get_chunk_graph(elph_handle_s *h, int nrhs, int use_prec, hipGraphExe
     return ELPH_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// A large KPM-preconditioned batch as TWO half-batches on two streams.  One iteration is four dependent kernels (k_cg_ap, forward
+// transform + residual update, Chebyshev recursion, inverse transform + p/x-update), each ending in a drain of the whole chip before the
+// next may start, the Chebyshev one latency-bound and the transforms quantised in rounds of waves (288 right-hand sides: 2.25 rounds).
+// Two independent halves, each with its own chain of kernels, fill one another's tails and run the latency-bound kernel of one under
+// the HBM-bound kernels of the other.  The second half is a VIEW of the handle: a copy whose per-right-hand-side device arrays start at
+// right-hand side n/2 and whose stream is the second stream — every launcher reads buffers and stream from the handle it is given, so
+// nothing else changes, and each right-hand side sees exactly the arithmetic of the single-stream form (same kernels, same partial-sum
+// layout per right-hand side).  Needs the p/x-fused iteration (the unfused one ping-pongs p between two slots whose distance depends on
+// the batch size) and halves that hold whole groups of chains.  ELPH_SPLIT_STREAMS=0 off, =1 wherever legal; default from 128 right-hand sides.
+// ------------------------------------------------------------------------------------------
+struct SplitRun {
+    bool on = false;
+    int n1 = 0, n2 = 0;
+    elph_handle_s *view = nullptr;
+    ~SplitRun() { delete view; }
+};
+
+static bool split_legal(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
+    if (!use_prec || hist || h->use_graph || nrhs < 4 || (nrhs & 1) || h->solo_chain >= 0 || h->dot_hi > 0) return false;
+    const int n1 = nrhs / 2;
+    if (n1 % std::max(1, h->nchains) || n1 % std::max(1, h->kpm_nch)) return false;
+    return elph_px_plan(h, n1);
+}
+
+static bool split_wanted(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
+    const char *e = getenv("ELPH_SPLIT_STREAMS");
+    if (e && e[0] == '0') return false;
+    if (!split_legal(h, nrhs, use_prec, hist)) return false;
+    return (e && e[0] == '1') || nrhs >= 128;
+}
+
+// after elph_launch_cg_init(h, nrhs, 1, …) on the main stream
+static int split_begin(elph_handle_s *h, int nrhs, SplitRun &S) {
+    if (!h->stream2) HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    if (!h->split_ev) HIPCHK(hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming));
+    S.n1 = nrhs / 2; S.n2 = nrhs - S.n1;
+    h->px_solve = true;                                   // (split_legal: the halves run p/x-fused whatever the whole batch would have run)
+    S.view = new elph_handle_s(*h);
+    elph_handle_s *v = S.view;
+    const size_t r0 = (size_t)S.n1, nd = (size_t)h->ndim, Lo2 = (size_t)(h->L + 1) / 2, nrz = (size_t)h->L * (size_t)h->npl;
+    v->d_x += r0 * nd; v->d_r += r0 * nd; v->d_z += r0 * nd; v->d_zp += r0 * nd; v->d_b += r0 * nd; v->d_tmp += r0 * nd; v->d_p += r0 * nd;
+    v->d_nu += r0 * Lo2 * (size_t)h->N;
+    v->d_state += 2 * r0; v->h_state += 2 * r0; v->d_alpha += r0;
+    v->d_part += r0 * nrz;        // the three partial-sum arrays lie cap_rhs * nrz apart and are indexed [rhs][<= nrz]: one offset serves all
+    v->stream = h->stream2;
+    v->graphs.clear();
+    HIPCHK(hipEventRecord(h->split_ev, h->stream));       // the start state (x0, r0, p0, rho0 of every right-hand side) is on the main stream
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->split_ev, 0));
+    S.on = true;
+    return ELPH_OK;
+}
+
+// the main stream continues only after the second half has finished
+static int split_join(elph_handle_s *h) {
+    HIPCHK(hipEventRecord(h->split_ev, h->stream2));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->split_ev, 0));
+    return ELPH_OK;
+}
+
 // Runs CG on d_b / d_x (layout S) for nrhs right-hand sides.  Returns per-rhs iteration counts.
 static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t maxiter, double kmax, int64_t *iters,
                   double *eps_hist /* host, optional, nrhs*(maxiter+1) */) {
@@ -864,6 +926,29 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
 
     const int64_t max_chunks = (maxiter + 1 + h->chunk - 1) / h->chunk + 1;
     bool all_done = false;
+    if (split_wanted(h, nrhs, use_prec, eps_hist != nullptr)) {
+        SplitRun S;
+        RC(split_begin(h, nrhs, S));
+        for (int64_t c = 0; c < max_chunks && !all_done; ++c) {
+            for (int it = 0; it < h->chunk; ++it) {
+                RC(elph_launch_cg_iteration(h, S.n1, use_prec));
+                RC(elph_launch_cg_iteration(S.view, S.n2, use_prec));
+            }
+            HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)S.n1, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(S.view->h_state, S.view->d_state, sizeof(CgState) * 2 * (size_t)S.n2, hipMemcpyDeviceToHost, S.view->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipStreamSynchronize(S.view->stream));
+            all_done = true;
+            for (int r = 0; r < nrhs; ++r) {
+                const CgState &a = h->h_state[2 * r], &b = h->h_state[2 * r + 1];
+                const CgState &s = (b.seq > a.seq) ? b : a;
+                if (!s.done) all_done = false;
+                else iters[r] = s.iters;
+            }
+        }
+        if (!all_done) { elph_set_error("CG chunk loop (two streams) ended without a terminal state (internal error)"); return ELPH_E_STATE; }
+        return ELPH_OK;
+    }
     for (int64_t c = 0; c < max_chunks && !all_done; ++c) {
         if (h->use_graph) {
             hipGraphExec_t exec;
@@ -1759,6 +1844,7 @@ static int bench_launch_unit(elph_handle_s *h, int what, int nrhs) {
         case 1: return elph_launch_cg_iteration(h, nrhs, 0);
         case 2: return elph_launch_kpm_apply(h, h->d_zp, h->d_b, nrhs, 0);
         case 3: return elph_launch_cg_iteration(h, nrhs, 1);
+        case 11: return ELPH_E_ARG;      // (two half-batches on two streams: elph_bench_run drives both handles itself)
         case 4: return elph_launch_cg_kernel(h, nrhs, 0);
         case 5: return elph_launch_cg_kernel(h, nrhs, 1);
         default: {
@@ -1772,8 +1858,8 @@ static int bench_launch_unit(elph_handle_s *h, int what, int nrhs) {
 extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B) {
     CHECK_H(h);
     RC(need_model(h));
-    if (nrhs < 1 || what < 0 || what > 10) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    if ((what == 2 || what == 3 || what == 10 || (what >= 6 && what <= 8)) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
+    if (nrhs < 1 || what < 0 || what > 11) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if ((what == 2 || what == 3 || what == 10 || what == 11 || (what >= 6 && what <= 8)) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
     RC(ensure_capacity(h, nrhs));
     if (B) {
         const size_t bytes = (size_t)nrhs * (size_t)h->ndim * sizeof(double);
@@ -1782,7 +1868,7 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
     }
     // fixed-count CG: tol = 0 never converges, kmax = inf, x0 = 0
     CgParams P;
-    P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3 || what == 10 || (what >= 6 && what <= 8)); P.record_hist = 0; P.hist_stride = 0;
+    P.tol = 0.0; P.kmax = INFINITY; P.maxiter = (long long)1 << 40; P.use_prec = (what == 3 || what == 10 || what == 11 || (what >= 6 && what <= 8)); P.record_hist = 0; P.hist_stride = 0;
     h->cur_params = P;
     HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
     h->x_zero = false;
@@ -1819,9 +1905,16 @@ extern "C" int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, 
     return ELPH_OK;
 }
 
+extern "C" int elph_bench_px_info(elph_handle h, int *fused) {
+    CHECK_H(h);
+    if (!fused) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    *fused = h->px_solve ? 1 : 0;
+    return ELPH_OK;
+}
+
 extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total) {
     CHECK_H(h);
-    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 10) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 11) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -1849,6 +1942,29 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
         if (rc) return rc;
         RC(elph_wg_aborted(h, &aborted));
         if (aborted) return ELPH_E_HIP;
+        *ms_total = (double)ms;
+        return ELPH_OK;
+    }
+    if (what == 11) {        // `reps` preconditioned iterations of the batch as two half-batches on two streams (run_cg's form from 128 right-hand sides)
+        if (!split_legal(h, nrhs, 1, false)) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); elph_set_error("the two-stream form does not apply to this batch"); return ELPH_E_UNSUPPORTED; }
+        SplitRun S;
+        hipError_t er = hipStreamSynchronize(h->stream);
+        if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
+        if (er == hipSuccess) rc = split_begin(h, nrhs, S);
+        for (int r = 0; r < reps && rc == ELPH_OK && er == hipSuccess; ++r) {
+            rc = elph_launch_cg_iteration(h, S.n1, 1);
+            if (rc == ELPH_OK) rc = elph_launch_cg_iteration(S.view, S.n2, 1);
+        }
+        if (rc == ELPH_OK && er == hipSuccess) rc = split_join(h);
+        if (S.on) h->ap_count = S.view->ap_count;
+        if (er == hipSuccess && rc == ELPH_OK) er = hipEventRecord(e1, h->stream);
+        if (er == hipSuccess && rc == ELPH_OK) er = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (er == hipSuccess && rc == ELPH_OK) er = hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (er != hipSuccess) { elph_set_error("bench (two streams): %s", hipGetErrorString(er)); return ELPH_E_HIP; }
+        if (rc) return rc;
         *ms_total = (double)ms;
         return ELPH_OK;
     }

@@ -15,7 +15,9 @@ extern "C" {
  *       launch of the workgroup-resident kernel (cg_wg.hip: the form elph_ldiv/elph_cg_solve use when elph_bench_wg_info
  *       says it applies; needs a fresh elph_bench_prepare before every run), 10 = `reps` KPM-PRECONDITIONED iterations in one
  *       launch of the resident preconditioned kernel (pcg_wg.hip: what elph_ldiv with a preconditioner runs for 1..8 right-hand
- *       sides on the 16 x 16 square lattice; ELPH_E_UNSUPPORTED elsewhere; fresh elph_bench_prepare(…, 10, …) before every run).
+ *       sides on the 16 x 16 square lattice; ELPH_E_UNSUPPORTED elsewhere; fresh elph_bench_prepare(…, 10, …) before every run), 11 = `reps` preconditioned iterations
+ *       of the batch as TWO half-batches on two streams (the form elph_ldiv_batched runs from 128 right-hand sides; prepare with what = 3;
+ *       ELPH_E_UNSUPPORTED where the halves are not whole groups of chains or the p/x-fused iteration does not apply).
  * elph_bench_prepare: loads nrhs right-hand sides (B: host, reference layout, nrhs*ndim; NULL keeps what the
  *   last solve left on the device), zeroes x, seeds the CG state with tol = 0 (never converges).
  * elph_bench_run: launches `reps` units back-to-back on the handle's stream (captured graph chunks when
@@ -28,6 +30,10 @@ int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave);
 /* Whether un-preconditioned solves of a batch of nrhs right-hand sides run as the workgroup-resident kernel (*usable = 1) and
  * its shape: T tau-slices per wavefront, W wavefronts per workgroup, G workgroups per right-hand side. */
 int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, int *W, int *G);
+
+/* Whether the LAST preconditioned solve / elph_bench_prepare ran its iteration p/x-fused (*fused = 1: x += alpha p and p = P^-1 r + beta p
+ * in the epilogue of the inverse tau-transform, k_cg_ap_chunk<PX> reading the ready p; kernels.hip: px_plan). */
+int elph_bench_px_info(elph_handle h, int *fused);
 
 /* the sharded solve (shard.hip): exactly `iters` iterations (no stop test); *ms = HIP-event time of this rank's launch.  b_slab may
  * be NULL (keeps the right-hand side of the previous call).  Needs elph_shard_prepare + barrier like a solve. */

@@ -200,6 +200,9 @@ struct elph_handle_s {
     bool fast_capable = false;             // lane-program kernels possible for this bond table (fast may be switched off)
     int solo_chain = -1;                   // >= 0: kernels see only this chain (single re-solve of one RHS of a chains batch)
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
+    hipStream_t stream2 = nullptr;         // second stream + event of the two-half-batches form of a preconditioned batch (elph_api.hip: SplitRun)
+    hipEvent_t split_ev = nullptr;
+    bool px_solve = false;                 // the current solve's preconditioned iteration is p/x-fused (kernels.hip: px_plan)
     // SSH update_model! on the device (elph_update_model_ssh_fields): staging of x, per-phonon tables, slot map
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
     int *d_ssh_cb = nullptr, *d_ssh_slot = nullptr;
@@ -378,7 +381,7 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
 
 // ---- fast path (cg_fast.hip) ----------------------------------------------------------------
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
-int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool px = false);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 // ---- one solve over several GPUs (cg_wg.hip, shard.hip): by-value description of this rank's shard for the resident kernel
 #define ELPH_SHARD_MAXREC 256      // records of a meeting: ranks x workgroups per rank (8 x 20 at Ltau = 160; polled as 8 x 64 granules)
@@ -428,6 +431,10 @@ int elph_dft_accel(elph_handle_s *h, double *outS, const double *inS, const doub
 // ---- batched tau-axis transforms on the matrix cores (dft_mfma.hip); which: 0 twisted, 1 plain
 int elph_dft_mfma_build_tables(elph_handle_s *h);
 bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs);
+bool elph_dft_mfma_px_usable(const elph_handle_s *h, int N, int nrhs);
+bool elph_px_plan(elph_handle_s *h, int nrhs);      // kernels.hip: would a preconditioned batch of nrhs run p/x-fused?
+int elph_dft_mfma_inv_px(elph_handle_s *h, const double2 *nu, int N, int nrhs, const CgState *st, double *pS, double *xS,
+                         const double *alpha, const double *rz, int nrz);
 bool elph_dft_mfma_fold_usable(const elph_handle_s *h);
 bool elph_dft_big(const elph_handle_s *h);
 int elph_dft_big_build_tables(elph_handle_s *h);

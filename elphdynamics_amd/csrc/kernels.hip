@@ -1153,6 +1153,33 @@ int elph_launch_ebar(elph_handle_s *h, int nch) {
     return check_launch("k_ebar");
 }
 
+// Does the preconditioned iteration of THIS solve run p/x-fused (PxFuse, dft_mfma.hip)?  Decided once per solve (elph_launch_cg_init) so
+// that k_cg_ap_chunk<PX> and the inverse transform agree: the batched Holstein iteration on a four-colour lane program whose
+// Chebyshev kernel leaves r.z in frequency space (so that beta is known BEFORE the inverse transform), residual update folded into the
+// forward transform, streaming MFMA inverse with one row group, the templated chunk lengths.  ELPH_FUSE_PX=0: off (A/B, parity tests).
+static bool reg_cheb_form(const elph_handle_s *h) {      // a register-exchange Chebyshev kernel (the forms that deliver r.z in frequency space)
+    const char *e = getenv("ELPH_NO_SQ");
+    if (e && e[0] == '1') return false;
+    return h->sq_P > 0 || (h->sq_L > 0 && h->sq_uniform && h->kind == ELPH_MODEL_HOLSTEIN) ||
+           (h->hc_L > 0 && h->hc_uniform && h->kind == ELPH_MODEL_HOLSTEIN && (h->hc12 || h->hc_L * h->hc_L <= 64 || (h->hc_L % 2 == 0 && h->hc_L <= 16)));
+}
+
+static bool px_plan(elph_handle_s *h, int nrhs) {
+    if (!h->fast || !h->kpm_active || h->kind != ELPH_MODEL_HOLSTEIN || h->lp_mc != 4) return false;
+    const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+    CgBufs B = make_bufs(h, nrhs);
+    if (!(B.dot_lo == 0 && B.dot_hi == N) || !elph_dft_mfma_xr_usable(h, N, nrhs)) return false;      // the iteration takes cg_mode 2
+    const char *ef = getenv("ELPH_FREQ_RZ");
+    if ((ef && ef[0] == '0') || 2 * Lo2 > B.nrz) return false;
+    if (!reg_cheb_form(h) || elph_pg_cheb_usable(h)) return false;
+    { const char *ec = getenv("ELPH_CHEB_COMPLEX"); if (ec && ec[0] == '1') return false; }
+    const int T = (B.npap == L) ? 1 : (L + B.npap - 1) / B.npap;
+    if (!(T > 1 && L % T == 0 && (T == 20 || T == 16 || T == 10 || T == 8 || T == 5 || T == 4 || T == 2))) return false;
+    return elph_dft_mfma_px_usable(h, N, nrhs);
+}
+
+bool elph_px_plan(elph_handle_s *h, int nrhs) { return px_plan(h, nrhs); }
+
 // z = P^-1 r on layout-S vectors.  cg_mode: 0 standalone; 1 inside CG (skip when done, fuse r.z partials); 2 as 1 with the
 // residual update r -= alpha A p (k_cg_xr) folded into the forward transform (rS is then written)
 // parts (measurement only, bench.py's per-kernel times): bit 0 forward transform, bit 1 Chebyshev recursion, bit 2 inverse transform
@@ -1222,7 +1249,12 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         });
     }
     // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz; the kernel clears the rest
-    if (parts & 4) {
+    if ((parts & 4) && cg_mode == 2 && h->px_solve) {
+        // p/x-fused tail: x += alpha p, p = P^-1 r + beta p in the epilogue of the inverse transform; P^-1 r itself is not written
+        if (!rz_done) { elph_set_error("p/x-fused iteration planned, but the Chebyshev kernel did not deliver r.z (internal error)"); return ELPH_E_STATE; }
+        int rcd = elph_dft_mfma_inv_px(h, h->d_nu, N, nrhs, st, h->d_p, h->d_x, B.alpha, B.rz, B.nrz);
+        if (rcd) return rcd;
+    } else if (parts & 4) {
         const bool fuse = cg_mode && !rz_done;
         int rcd = elph_dft_inv_twisted(h, zS, h->d_nu, N, nrhs, st, fuse ? rS : nullptr, fuse ? B.rz : nullptr, B.nrz);
         if (rcd) return rcd;
@@ -1238,6 +1270,11 @@ int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec, bool x_zero) {
     h->ap_count = 0;
     const int N = (int)h->N, L = (int)h->L;
     int rc = ELPH_OK;
+    {   // the form of this solve's preconditioned iteration; a captured graph of the other form is dropped
+        const bool px = use_prec && h->kpm_ready && px_plan(h, nrhs);
+        if (px != h->px_solve) elph_i_drop_graphs(h);
+        h->px_solve = px;
+    }
     h->x_zero_seen = x_zero;
     if (h->x_zero_seen) {       // x0 = 0 (the library zeroed it for this solve): A x0 = 0 without the mat-vec
         if (hipMemsetAsync(h->d_tmp, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream) != hipSuccess) { elph_set_error("memset failed"); return ELPH_E_HIP; }
@@ -1292,11 +1329,13 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
     CgBufs B = make_bufs(h, nrhs);
     int rc;
     if (h->fast) {
-        rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1));
+        const bool px = use_prec && h->px_solve;
+        rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1), px);
         h->ap_count++;
         if (rc) return rc;
         if (use_prec && h->kpm_active && B.dot_lo == 0 && B.dot_hi == (int)h->N && elph_dft_mfma_xr_usable(h, (int)h->N, nrhs))
             return elph_launch_kpm_apply(h, h->d_zp, h->d_r, nrhs, 2);      // k_cg_xr rides on the forward transform
+        if (px) { elph_set_error("p/x-fused iteration planned, but the residual update is not folded into the forward transform (internal error)"); return ELPH_E_STATE; }
         rc = elph_fast_cg_xr(h, B, nrhs, (int)(h->ap_count & 1));
         if (rc) return rc;
     } else {
@@ -1323,7 +1362,7 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     CgBufs B = make_bufs(h, nrhs);
     if (h->fast) {
         if (which == 0) {
-            int rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1));
+            int rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1), B.params.use_prec && h->px_solve);
             h->ap_count++;
             return rc;
         }

@@ -1335,6 +1335,81 @@ def test_mfma_dft_long_time_axes(lib, L, monkeypatch):
         m.close()
 
 
+def _px_fused(m):
+    from elphdynamics_amd import _lib
+    f = C.c_int()
+    _lib.check(_lib.load().elph_bench_px_info(m._h, C.byref(f)))
+    return bool(f.value)
+
+
+@pytest.mark.parametrize("tag,nchains,per,chunk_T", [("C", 16, 2, None), ("C", 1, 48, None), ("C", 64, 2, None), ("C", 144, 2, None), ("C", 20, 2, "5"),
+                                                      ("D", 16, 2, None), ("D", 64, 2, None), ("B", 64, 2, None), ("S", 32, 2, None)])
+def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, per, chunk_T, monkeypatch):
+    """The batched KPM-preconditioned iteration with x += alpha p and p = P^-1 r + beta p moved into the epilogue of the inverse
+    tau-transform (dft_mfma.hip: PxFuse; k_cg_ap_chunk<PX> reads the ready p): same arithmetic per element and the same summation
+    order for r.z as the unfused form, so iteration counts are EQUAL and the solutions agree to round-off of the last bit
+    (IterativeSolvers.jl:153-234 — the recurrences are untouched, only where they are evaluated moves)."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    if chunk_T:
+        monkeypatch.setenv("ELPH_CHUNK_T", chunk_T)
+    m = configs.make_model(tag, tol=1e-8)
+    nrhs = nchains * per
+    if nchains > 1:
+        X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=8000 + c) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    (pc.setup_chains_ if nchains > 1 else pc.setup_)(P, rng=np.random.default_rng(11))
+    B = np.stack([synth.randn(8100 + r, m.Ndim) for r in range(nrhs)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_FUSE_PX", mode)
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any()
+        out[mode] = (Xs, it, _px_fused(m))
+    assert out["0"][2] is False and out["1"][2] is True, "the fused form was not taken: the A/B compares a kernel with itself"
+    assert np.array_equal(out["0"][1], out["1"][1])
+    assert rel(out["1"][0], out["0"][0]) < 1e-13
+    m.close()
+
+
+@pytest.mark.parametrize("tag,nchains,per,chunk_T", [("C", 32, 2, "4"), ("C", 64, 2, None), ("C", 144, 2, None), ("C", 1, 64, "4"), ("D", 64, 2, "4")])
+def test_preconditioned_batch_as_two_half_batches_on_two_streams(tag, nchains, per, chunk_T, monkeypatch):
+    """elph_ldiv_batched of a large KPM-preconditioned batch runs as two half-batches on two streams (elph_api.hip: SplitRun; default
+    from 128 right-hand sides, forced here): every right-hand side goes through the same kernels with the same partial-sum layout as in
+    one stream.  With the chunk length pinned (ELPH_CHUNK_T) the two forms give the SAME BITS; with the library's own choice the
+    halves may take another chunk length than the whole batch (another grouping of the p.z partial sums): iteration counts within
+    one, solutions to 1e-9 of two tol = 1e-8 solves."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    if chunk_T:
+        monkeypatch.setenv("ELPH_CHUNK_T", chunk_T)
+    m = configs.make_model(tag, tol=1e-8)
+    nrhs = nchains * per
+    if nchains > 1:
+        X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=8300 + c) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    (pc.setup_chains_ if nchains > 1 else pc.setup_)(P, rng=np.random.default_rng(12))
+    B = np.stack([synth.randn(8400 + r, m.Ndim) for r in range(nrhs)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_SPLIT_STREAMS", mode)
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any() and _px_fused(m)
+        out[mode] = (Xs, it)
+    if chunk_T:
+        assert np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][0], out["1"][0])
+    else:
+        assert np.abs(out["0"][1] - out["1"][1]).max() <= 1 and rel(out["1"][0], out["0"][0]) < 1e-9
+    # the solve after a split one is an ordinary one again (the view and its stream are gone with the solve)
+    monkeypatch.setenv("ELPH_SPLIT_STREAMS", "0")
+    x1 = np.zeros(m.Ndim)
+    it1, _, fl1 = models.ldiv_(x1, m, np.ascontiguousarray(B[0]), P=P)
+    assert fl1 == 0 and abs(it1 - int(out["0"][1][0])) <= 1 and rel(x1, out["0"][0][0]) < 1e-9
+    m.close()
+
+
 @pytest.mark.parametrize("Lt", [30, 50, 400])
 def test_batched_preconditioned_solve_with_odd_half_length(Lt, monkeypatch):
     """Ltau = 2 (mod 4): the split transforms (odd half length), the folded residual update and the frequency-space r.z inside a
