@@ -186,6 +186,8 @@ def main():
     check(lib.elph_bench_wg_info(m._h, nrhs, C.byref(wg_us), C.byref(wg_T), C.byref(wg_W), C.byref(wg_G)))
     resident = bool(wg_us.value) and not args.precond and not args.streaming
     what = 3 if args.precond else (9 if resident else 1)
+    # a KPM-preconditioned batch from 192 right-hand sides runs as two half-batches on two streams (elph_api.hip: SplitRun): time that form
+    two_streams = bool(args.precond and nrhs >= 192 and os.environ.get("ELPH_SPLIT_STREAMS") != "0")
     P = None
     if args.precond:      # one KPM expansion per chain (its own Ē, spectrum bounds, orders and coefficients)
         P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
@@ -205,6 +207,13 @@ def main():
 
     prep = 1 if what == 9 else what
     check(lib.elph_bench_prepare(m._h, prep, nrhs, _lib.dptr(Bc)))
+    if two_streams:
+        try:
+            run(11, nrhs, 2)
+            what = 11
+        except _lib.ElphError:      # halves that are not whole groups of chains, or no p/x-fused iteration for this shape: one stream
+            two_streams = False
+            check(lib.elph_bench_prepare(m._h, prep, nrhs, None))
     if W:
         run(what, nrhs, W)                   # warm-up
     check(lib.elph_bench_prepare(m._h, prep, nrhs, None))
@@ -244,7 +253,8 @@ def main():
                             f"{world} GPU(s) with their own chains",
                 "nrhs": nrhs, "chains_per_gpu": nchains, "ndim": ndim, "preconditioned": bool(args.precond),
                 "form": ("workgroup-resident: K iterations of the whole batch in one launch (k_cg_wg)" if resident else
-                         "two-kernel iteration, one pair of launches per step (k_cg_ap + k_cg_xr%s)" % (" + KPM apply" if args.precond else "")),
+                         "two-kernel iteration, one pair of launches per step (k_cg_ap + k_cg_xr%s)" % (" + KPM apply" if args.precond else "") +
+                         (", as two half-batches on two streams" if two_streams else "")),
                 "parallelism": f"gpus{world}xchains{nchains}",
             },
             "cg_iters_per_sec": nrhs * K * world / elapsed,
@@ -379,14 +389,14 @@ def main():
                     rp[f"precond_{names[wh]}_hbm_frac"] = byts[wh] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
                     if wh in (6, 8) and gemm_flops:
                         rp[f"precond_{names[wh]}_mfma_frac"] = gemm_flops / (us * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS
-                # the form elph_ldiv_batched runs from 128 right-hand sides: the same iteration as two half-batches on two streams
+                # the form elph_ldiv_batched runs from 192 right-hand sides: the same iteration as two half-batches on two streams
                 try:
                     check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
                     run(11, nrhs, 32)
                     rp["precond_iter_us_one_stream"] = rp["precond_iter_us"]
                     us2 = 1e3 * run(11, nrhs, 320) / 320
                     rp["precond_iter_us_two_streams"] = us2
-                    if nrhs >= 128 and os.environ.get("ELPH_SPLIT_STREAMS") != "0":       # what a solve of this batch runs
+                    if nrhs >= 192 and os.environ.get("ELPH_SPLIT_STREAMS") != "0":       # what a solve of this batch runs
                         rp["precond_iter_us"] = us2
                         rp["precond_iter_hbm_frac"] = byts[3] / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS
                 except Exception as e:

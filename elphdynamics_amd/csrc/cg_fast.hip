@@ -38,6 +38,7 @@ int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int
     return h->lp_mc == 4 ? lp4::elph_fast_mul(h, which, yS, vS, nvec) : lp6::elph_fast_mul(h, which, yS, vS, nvec);
 }
 int elph_choose_T(const elph_handle_s *h, int nrhs) { return lp4::elph_choose_T(h, nrhs); }
+int elph_choose_T_px(const elph_handle_s *h, int nrhs) { return lp4::elph_choose_T_px(h, nrhs); }
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool px) {
     return h->lp_mc == 4 ? lp4::elph_fast_cg_ap(h, B, nrhs, parity, px) : lp6::elph_fast_cg_ap(h, B, nrhs, parity, px);
 }

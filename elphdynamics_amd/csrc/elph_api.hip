@@ -789,27 +789,31 @@ static int get_chunk_graph(elph_handle_s *h, int nrhs, int use_prec, hipGraphExe
 // right-hand side n/2 and whose stream is the second stream — every launcher reads buffers and stream from the handle it is given, so
 // nothing else changes, and each right-hand side sees exactly the arithmetic of the single-stream form (same kernels, same partial-sum
 // layout per right-hand side).  Needs the p/x-fused iteration (the unfused one ping-pongs p between two slots whose distance depends on
-// the batch size) and halves that hold whole groups of chains.  ELPH_SPLIT_STREAMS=0 off, =1 wherever legal; default from 128 right-hand sides.
+// the batch size) and halves that hold whole groups of chains.  ELPH_SPLIT_STREAMS=0 off, =1 wherever legal; default from 192 right-hand sides.
 // ------------------------------------------------------------------------------------------
 struct SplitRun {
     bool on = false;
     int n1 = 0, n2 = 0;
-    elph_handle_s *view = nullptr;
-    ~SplitRun() { delete view; }
+    elph_handle_s *main = nullptr, *view = nullptr;
+    ~SplitRun() { if (main) main->T_rhs_hint = 0; delete view; }
 };
 
 static bool split_legal(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
     if (!use_prec || hist || h->use_graph || nrhs < 4 || (nrhs & 1) || h->solo_chain >= 0 || h->dot_hi > 0) return false;
     const int n1 = nrhs / 2;
     if (n1 % std::max(1, h->nchains) || n1 % std::max(1, h->kpm_nch)) return false;
-    return elph_px_plan(h, n1);
+    const int keep = h->T_rhs_hint;
+    h->T_rhs_hint = nrhs;                 // the halves choose their slices per wave for the whole batch in flight
+    const bool ok = elph_px_plan(h, n1);
+    h->T_rhs_hint = keep;
+    return ok;
 }
 
 static bool split_wanted(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
     const char *e = getenv("ELPH_SPLIT_STREAMS");
     if (e && e[0] == '0') return false;
     if (!split_legal(h, nrhs, use_prec, hist)) return false;
-    return (e && e[0] == '1') || nrhs >= 128;
+    return (e && e[0] == '1') || nrhs >= 192;      // (128 right-hand sides: 130 us either way, profiles/r05/px_chunk_T.log)
 }
 
 // after elph_launch_cg_init(h, nrhs, 1, …) on the main stream
@@ -817,7 +821,9 @@ static int split_begin(elph_handle_s *h, int nrhs, SplitRun &S) {
     if (!h->stream2) HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     if (!h->split_ev) HIPCHK(hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming));
     S.n1 = nrhs / 2; S.n2 = nrhs - S.n1;
+    S.main = h;
     h->px_solve = true;                                   // (split_legal: the halves run p/x-fused whatever the whole batch would have run)
+    h->T_rhs_hint = nrhs;                                 // slices per wave for the right-hand sides in flight = both halves
     S.view = new elph_handle_s(*h);
     elph_handle_s *v = S.view;
     const size_t r0 = (size_t)S.n1, nd = (size_t)h->ndim, Lo2 = (size_t)(h->L + 1) / 2, nrz = (size_t)h->L * (size_t)h->npl;
@@ -1612,6 +1618,7 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     if (hop_fresh && h->pg_L > 0) {
         bool uni = h->nb > 0 && !h->kpm_hop_per_chain;
         for (size_t k = 1; k < (size_t)h->nb && uni; ++k) uni = h->h_cbar[k] == h->h_cbar[0] && h->h_sbar[k] == h->h_sbar[0];
+        if (uni != h->pg_uniform) drop_graphs(h);       // (a captured chunk holds the Chebyshev kernel chosen under the old flag)
         h->pg_uniform = uni;
     }
     h->kpm_hop_uploaded = true;
@@ -1881,7 +1888,7 @@ extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const doubl
 extern "C" int elph_bench_info(elph_handle h, int nrhs, int *slices_per_wave) {
     CHECK_H(h);
     if (nrhs < 1 || !slices_per_wave) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    *slices_per_wave = elph_choose_T(h, nrhs);
+    *slices_per_wave = (h->px_solve && h->cur_params.use_prec) ? elph_choose_T_px(h, nrhs) : elph_choose_T(h, nrhs);
     return ELPH_OK;
 }
 
@@ -1945,7 +1952,7 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
         *ms_total = (double)ms;
         return ELPH_OK;
     }
-    if (what == 11) {        // `reps` preconditioned iterations of the batch as two half-batches on two streams (run_cg's form from 128 right-hand sides)
+    if (what == 11) {        // `reps` preconditioned iterations of the batch as two half-batches on two streams (run_cg's form from 192 right-hand sides)
         if (!split_legal(h, nrhs, 1, false)) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); elph_set_error("the two-stream form does not apply to this batch"); return ELPH_E_UNSUPPORTED; }
         SplitRun S;
         hipError_t er = hipStreamSynchronize(h->stream);

@@ -16,7 +16,7 @@ extern "C" {
  *       says it applies; needs a fresh elph_bench_prepare before every run), 10 = `reps` KPM-PRECONDITIONED iterations in one
  *       launch of the resident preconditioned kernel (pcg_wg.hip: what elph_ldiv with a preconditioner runs for 1..8 right-hand
  *       sides on the 16 x 16 square lattice; ELPH_E_UNSUPPORTED elsewhere; fresh elph_bench_prepare(…, 10, …) before every run), 11 = `reps` preconditioned iterations
- *       of the batch as TWO half-batches on two streams (the form elph_ldiv_batched runs from 128 right-hand sides; prepare with what = 3;
+ *       of the batch as TWO half-batches on two streams (the form elph_ldiv_batched runs from 192 right-hand sides; prepare with what = 3;
  *       ELPH_E_UNSUPPORTED where the halves are not whole groups of chains or the p/x-fused iteration does not apply).
  * elph_bench_prepare: loads nrhs right-hand sides (B: host, reference layout, nrhs*ndim; NULL keeps what the
  *   last solve left on the device), zeroes x, seeds the CG state with tol = 0 (never converges).

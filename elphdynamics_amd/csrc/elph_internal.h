@@ -202,6 +202,7 @@ struct elph_handle_s {
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
     hipStream_t stream2 = nullptr;         // second stream + event of the two-half-batches form of a preconditioned batch (elph_api.hip: SplitRun)
     hipEvent_t split_ev = nullptr;
+    int T_rhs_hint = 0;                    // > 0: right-hand sides in flight when the slices per wave are chosen (two-stream batches: both halves)
     bool px_solve = false;                 // the current solve's preconditioned iteration is p/x-fused (kernels.hip: px_plan)
     // SSH update_model! on the device (elph_update_model_ssh_fields): staging of x, per-phonon tables, slot map
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
@@ -346,6 +347,13 @@ int elph_i_reserve_chains(elph_handle_s *h, int nchains);   // d_E for nchains c
 void elph_i_drop_graphs(elph_handle_s *h);
 void elph_hmc_free(elph_handle_s *h);
 void elph_shard_free(elph_handle_s *h);
+// sharded callers (shard.hip): hooks for hmc.hip
+bool elph_i_shard_active(const elph_handle_s *h);                           // a shard with its collectives set (or a single rank)
+void elph_i_shard_own_range(const elph_handle_s *h, int *lo, int *hi);      // own sites [lo, hi) of the slab
+int elph_i_shard_allreduce(elph_handle_s *h, double *buf, int n);
+int elph_i_shard_ghost_sync(elph_handle_s *h, double *vecS, int nvec);
+int elph_i_shard_ldiv_dev(elph_handle_s *h, elph_handle_s *hfull, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag);
+int elph_i_shard_solve_pair(elph_handle_s *h, elph_handle_s *hfull, int use_prec, double tol_power, int64_t *iters, int *flag);
 void elph_greens_free(elph_handle_s *h);
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec, int ncols = 0);
 int elph_launch_s2r(elph_handle_s *h, double *dstR, const double *srcS, int nvec, int ncols = 0);
@@ -415,6 +423,7 @@ CgBufs elph_make_bufs(elph_handle_s *h, int nrhs);
 int elph_fast_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part = nullptr, int nrz = 0, bool *did_rz = nullptr,
                        const double *rr_part = nullptr, int fold_nct = 0);
 int elph_choose_T(const elph_handle_s *h, int nrhs);
+int elph_choose_T_px(const elph_handle_s *h, int nrhs);      // the p/x-fused kernel's own rule (three waves per SIMD)
 // packs per-bond values (order of h_bi/h_bj) into the lane-program layout [NE][64] (idle slots = fill)
 void elph_lp_pack(const elph_handle_s *h, const double *per_bond, double *out, double fill);
 

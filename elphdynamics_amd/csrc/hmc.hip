@@ -166,13 +166,14 @@ __device__ __forceinline__ double blk_sum(double v, double *sc) {
 // per-slice partial of Sb/Δτ   (calc_Sb, PhononAction.jl:11-66)
 __global__ void __launch_bounds__(TPB) k_hmc_sb_part(double *__restrict__ part, const double *__restrict__ x,
                                                      const double *__restrict__ par, int N, int L, double dtau,
-                                                     const double *__restrict__ wcol) {
+                                                     const double *__restrict__ wcol, int col_lo = 0, int col_hi = 1 << 30) {
     __shared__ double sc[8];
     const int t = blockIdx.x, tm1 = (t == 0) ? L - 1 : t - 1;
     x += (size_t)blockIdx.y * (size_t)N * L;                   // blockIdx.y = chain
     part += (size_t)blockIdx.y * L;
     double acc = 0.0;
     for (int s = threadIdx.x; s < N; s += TPB) {
+        if (s < col_lo || s >= col_hi) continue;               // a sharded lattice: this rank's own columns only
         if (wcol && wcol[s] == 0.0) continue;                  // only primary phonons count (PhononAction.jl:83)
         const double xt = x[(size_t)t * N + s], xm = x[(size_t)tm1 * N + s], w = par[s], w4 = par[N + s];
         acc += w * w * (xt * xt) / 2 + w4 * (xt * xt * xt * xt);
@@ -184,13 +185,17 @@ __global__ void __launch_bounds__(TPB) k_hmc_sb_part(double *__restrict__ part, 
 
 // partial dot products of vector blockIdx.y (n elements each): part[y][b] = sum over block b's range of a·b
 __global__ void __launch_bounds__(TPB) k_hmc_dot_part(double *__restrict__ part, const double *__restrict__ a,
-                                                      const double *__restrict__ b, long long n, long long per_block) {
+                                                      const double *__restrict__ b, long long n, long long per_block,
+                                                      int ncols = 0, int col_lo = 0, int col_hi = 0) {
     __shared__ double sc[8];
     a += (size_t)blockIdx.y * (size_t)n; b += (size_t)blockIdx.y * (size_t)n;
     part += (size_t)blockIdx.y * gridDim.x;
     const long long lo = (long long)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
     double acc = 0.0;
-    for (long long i = lo + threadIdx.x; i < hi; i += TPB) acc += a[i] * b[i];
+    for (long long i = lo + threadIdx.x; i < hi; i += TPB) {
+        if (ncols > 0) { const int c = (int)(i % ncols); if (c < col_lo || c >= col_hi) continue; }      // (sharded: own columns of [tau][col])
+        acc += a[i] * b[i];
+    }
     acc = blk_sum(acc, sc);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
@@ -229,10 +234,15 @@ __global__ void __launch_bounds__(TPB) k_mask_cols(double *__restrict__ F, const
     if (i < n) F[i] *= wcol[i % nf];
 }
 
+// a sharded lattice (shard.hip: elph_shard_set_collectives): sums count this rank's own columns and are added over the ranks
+bool sharded(const elph_handle_s *h) { return h->shard != nullptr && elph_i_shard_active(h); }
+
 int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, long long n, int count, double *out) {
     const int nb = (int)h->L;
     const long long per = (n + nb - 1) / nb;
-    hipLaunchKernelGGL(k_hmc_dot_part, dim3((unsigned)nb, (unsigned)count), dim3(TPB), 0, h->stream, st->part, a, b, n, per);
+    int ncols = 0, clo = 0, chi = 0;
+    if (sharded(h)) { ncols = (int)(n / h->L); elph_i_shard_own_range(h, &clo, &chi); }
+    hipLaunchKernelGGL(k_hmc_dot_part, dim3((unsigned)nb, (unsigned)count), dim3(TPB), 0, h->stream, st->part, a, b, n, per, ncols, clo, chi);
     RC(chk("k_hmc_dot_part"));
     std::vector<double> p((size_t)nb * count);
     HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
@@ -242,6 +252,7 @@ int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, 
         for (int q = 0; q < nb; ++q) s += p[(size_t)k * nb + q];
         out[k] = s;
     }
+    if (sharded(h)) RC(elph_i_shard_allreduce(h, out, count));
     return ELPH_OK;
 }
 
@@ -254,8 +265,10 @@ int alias_sum(elph_handle_s *h, HmcState *st, double *F) {
 
 int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
     const int L = (int)h->L, nch = st->nch;
+    int clo = 0, chi = 1 << 30;
+    if (sharded(h)) elph_i_shard_own_range(h, &clo, &chi);
     hipLaunchKernelGGL(k_hmc_sb_part, dim3((unsigned)L, (unsigned)nch), dim3(TPB), 0, h->stream, st->part, st->x, st->par, st->nf, L,
-                       st->dtau, (const double *)(st->shared ? st->wcol : nullptr));
+                       st->dtau, (const double *)(st->shared ? st->wcol : nullptr), clo, chi);
     RC(chk("k_hmc_sb_part"));
     std::vector<double> p((size_t)L * nch);
     HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
@@ -265,6 +278,7 @@ int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
         for (int q = 0; q < L; ++q) s += p[(size_t)c * L + q];
         out[c] = st->dtau * s;
     }
+    if (sharded(h)) RC(elph_i_shard_allreduce(h, out, nch));
     return ELPH_OK;
 }
 
@@ -303,6 +317,10 @@ int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power,
         RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
     HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * (size_t)nch * nd * sizeof(double), h->stream));
     h->x_zero = true;
+    if (sharded(h)) {      // one lattice over several ranks: the two solves one after the other through the sharded kernel (shard.hip)
+        h->x_zero = false;
+        return elph_i_shard_solve_pair(h, nullptr, 0, power, iters, flag);
+    }
     const double tol0 = h->tol;
     h->tol = pow(tol0, power);
     std::vector<int64_t> it2((size_t)2 * nch, 0);
@@ -357,6 +375,10 @@ int force(elph_handle_s *h, HmcState *st, bool with_Sb) {
     } else {
         RC(elph_launch_force_holstein(h, st->dS, h->d_x, st->phi, st->x, st->dtau, st->nch));
     }
+    // a sharded lattice: the fermion force is exact on the own rows (the MᵀM closure); the ghost rows — which the leapfrog moves along with
+    // the own ones, so that the next update_model! sees the whole slab — take it from their owners.  The boson force and the Fourier
+    // acceleration below are pointwise in the site index.
+    if (sharded(h)) RC(elph_i_shard_ghost_sync(h, st->dS, 1));
     if (with_Sb) {
         hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1,
                            st->nch);
@@ -692,6 +714,14 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     }
     if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     const int nch = st->nch;
+    if (sharded(h)) {
+        // one lattice over several ranks: the trajectory runs on the slab (own + ghost rows); the random vectors must be the slab's part
+        // of the GLOBAL vectors (ghost entries included) and the uniform of the Metropolis test the same number on every rank
+        if (st->ssh || nch != 1 || use_precond || st->rng_on || !R || !Rp || !Rm || !u_accept) {
+            elph_set_error("HMC on a sharded lattice: Holstein, one chain, un-preconditioned, with R, Rp, Rm and u_accept given (the slab's part of the global vectors)");
+            return ELPH_E_UNSUPPORTED;
+        }
+    }
     RC(elph_i_ensure_capacity(h, 2 * nch));
     RC(elph_i_reserve_chains(h, nch));
     // nd: site vectors (ϕ±, R±, solutions); nfd: field vectors (x, v, dS/dx) of one chain
@@ -740,6 +770,8 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
                            (int)h->N, (int)h->L, st->dtau, nch);
         RC(chk("k_hmc_phi"));
     }
+    // a sharded lattice: MᵀR± is exact on the own rows only (its ghost rows would need R beyond the slab); ϕ± of the ghost rows from their owners
+    if (sharded(h)) RC(elph_i_shard_ghost_sync(h, st->phi, 2));
 
     RC(calc_OinvLphi(h, st, use_precond, 2.0, kpm_randn, &kpm_calls, itrs.data(), flag.data()));
     // standard_update! :373 counts these iterations;  multitimestep_update! :507 has "iters += iters": not counted

@@ -1103,7 +1103,10 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     B.dot_lo = h->dot_hi > 0 ? h->dot_lo : 0;
     B.dot_hi = h->dot_hi > 0 ? h->dot_hi : (int)h->N;
     B.nrz = (int)(h->L * h->npl);
-    { const int Tc = elph_choose_T(h, nrhs); B.npap = (int)((h->L + Tc - 1) / Tc); }      // (a ragged cut: ceil)
+    {   // slices per wave of k_cg_ap: the p/x-fused kernel of a preconditioned batch has its own rule
+        const int Tc = (h->px_solve && h->cur_params.use_prec) ? elph_choose_T_px(h, h->T_rhs_hint > 0 ? h->T_rhs_hint : nrhs) : elph_choose_T(h, nrhs);
+        B.npap = (int)((h->L + Tc - 1) / Tc);      // (a ragged cut: ceil)
+    }
     B.nrhs = nrhs;
     return B;
 }
@@ -1173,7 +1176,7 @@ static bool px_plan(elph_handle_s *h, int nrhs) {
     if ((ef && ef[0] == '0') || 2 * Lo2 > B.nrz) return false;
     if (!reg_cheb_form(h) || elph_pg_cheb_usable(h)) return false;
     { const char *ec = getenv("ELPH_CHEB_COMPLEX"); if (ec && ec[0] == '1') return false; }
-    const int T = (B.npap == L) ? 1 : (L + B.npap - 1) / B.npap;
+    const int T = elph_choose_T_px(h, h->T_rhs_hint > 0 ? h->T_rhs_hint : nrhs);
     if (!(T > 1 && L % T == 0 && (T == 20 || T == 16 || T == 10 || T == 8 || T == 5 || T == 4 || T == 2))) return false;
     return elph_dft_mfma_px_usable(h, N, nrhs);
 }

@@ -37,6 +37,11 @@ struct ShardState {
     int *d_counter = nullptr, *d_abort = nullptr;
     unsigned epoch = 0;
     unsigned selftest_calls = 0;
+    // the sharded CALLERS (elph_shard_ldiv, elph_shard_fermion_force_*, elph_hmc_update on a sharded handle): what they need from the host
+    elph_shard_barrier_fn barrier = nullptr;
+    elph_shard_allreduce_fn allreduce = nullptr;
+    void *coll_ctx = nullptr;
+    std::vector<int> gsites_host;             // [N_loc] global site of every slab site (host copy of d_gsites)
 };
 
 // mailbox layout (u64 words), identical on all ranks:
@@ -144,6 +149,7 @@ extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own
             if (global_sites[i] < 0 || global_sites[i] >= n_global) { elph_set_error("global_sites[%lld] out of range", (long long)i); return ELPH_E_ARG; }
             gs[(size_t)i] = (int)global_sites[i];
         }
+        S->gsites_host = gs;
         HIPCHK(hipMalloc((void **)&S->d_gsites, gs.size() * sizeof(int)));
         HIPCHK(hipMemcpy(S->d_gsites, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
     }
@@ -558,16 +564,12 @@ static int shard_kpm_apply(elph_handle_s *h, elph_handle_s *hf, ShardState *S) {
     return allsum(h, S, B.rz, B.nrz, 2);
 }
 
-// hfull: a handle on the WHOLE lattice with the model set and elph_kpm_setup done (identically on every rank); it is switched to the
-// slab handle's stream for the duration of the call.  Needs elph_shard_prepare + the caller's barrier like every sharded solve.
-extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, double tol, int64_t maxiter,
-                                    double kappa_max, int64_t *iters, int *done, double *eps) {
-    if (!h || !hfull) { elph_set_error("null handle"); return ELPH_E_ARG; }
-    HIPCHK(hipSetDevice(h->device));
-    ShardState *S = static_cast<ShardState *>(h->shard);
-    if (!S || !S->prepared) { elph_set_error("elph_shard_prepare (and the caller's barrier) must precede every sharded solve"); return ELPH_E_STATE; }
+// the preconditioned sharded solve on DEVICE-resident vectors: right-hand side in h->d_b (layout S, slab with its ghost entries), solution
+// left in h->d_x; needs S->prepared (elph_shard_prepare + the ranks' barrier)
+static int shard_kpm_core(elph_handle_s *h, elph_handle_s *hfull, ShardState *S, double tol, int64_t maxiter, double kappa_max,
+                          int64_t *iters, int *done, double *eps) {
+    if (!S->prepared) { elph_set_error("elph_shard_prepare (and the caller's barrier) must precede every sharded solve"); return ELPH_E_STATE; }
     S->prepared = false;
-    if (!x_slab || !b_slab || !(tol >= 0.0) || maxiter < 1) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     if (S->n_global <= 0 || hfull->N != S->n_global || hfull->L != h->L) { elph_set_error("the full-lattice handle does not match the shard's global geometry"); return ELPH_E_ARG; }
     if (!hfull->kpm_ready) { elph_set_error("elph_kpm_setup has not been called on the full-lattice handle"); return ELPH_E_STATE; }
     if (!h->have_E) { elph_set_error("update_model has not been called on this handle"); return ELPH_E_STATE; }
@@ -586,8 +588,6 @@ extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_
     const size_t bytes = (size_t)h->ndim * sizeof(double);
     auto body = [&]() -> int {
         int r;
-        HIPCHK(hipMemcpyAsync(h->d_stage_in, b_slab, bytes, hipMemcpyHostToDevice, h->stream));
-        if ((r = elph_launch_r2s(h, h->d_b, h->d_stage_in, 1))) return r;
         HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));
         HIPCHK(hipMemsetAsync(h->d_tmp, 0, bytes, h->stream));                      // A x0 = 0
         if ((r = elph_launch_cg_init_only(h, 1))) return r;                         // r0 = p0 = b, partial r.r and b.b over the own rows
@@ -617,9 +617,6 @@ extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_
                 if (iters) *iters = s.iters;
                 if (done) *done = s.done;
                 if (eps) *eps = s.eps;
-                if ((r = elph_launch_s2r(h, h->d_stage_out, h->d_x, 1))) return r;
-                HIPCHK(hipMemcpyAsync(x_slab, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
                 return ELPH_OK;
             }
         }
@@ -631,4 +628,314 @@ extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_
     hfull->stream = saved;
     (void)elph_i_set_dot_range(h, 0, h->N);
     return rc;
+}
+
+// hfull: a handle on the WHOLE lattice with the model set and elph_kpm_setup done (identically on every rank); it is switched to the
+// slab handle's stream for the duration of the call.  Needs elph_shard_prepare + the caller's barrier like every sharded solve.
+extern "C" int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, double tol, int64_t maxiter,
+                                    double kappa_max, int64_t *iters, int *done, double *eps) {
+    if (!h || !hfull) { elph_set_error("null handle"); return ELPH_E_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    ShardState *S = static_cast<ShardState *>(h->shard);
+    if (!S) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
+    if (!x_slab || !b_slab || !(tol >= 0.0) || maxiter < 1) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    int rc;
+    if ((rc = elph_i_ensure_capacity(h, 1))) return rc;
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, b_slab, bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = elph_launch_r2s(h, h->d_b, h->d_stage_in, 1))) return rc;
+    if ((rc = shard_kpm_core(h, hfull, S, tol, maxiter, kappa_max, iters, done, eps))) return rc;
+    if ((rc = elph_launch_s2r(h, h->d_stage_out, h->d_x, 1))) return rc;
+    HIPCHK(hipMemcpyAsync(x_slab, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+
+// =========================================================================================================================
+// The CALLERS of the solve on a sharded lattice (BASELINE configs "HMC ... spatial-sharded"): ldiv!'s wrapper (Models.jl:74-186), the
+// fermion force (HMC.jl:790-915) and — hmc.hip, through the elph_i_shard_* hooks below — one HMC update, on DEVICE-resident slab vectors.
+// Everything but the solve is pointwise in the site index or reaches no further than the MᵀM closure the slab already holds, so it runs
+// on the slab handle unchanged; what crosses ranks besides the solve are a few scalars (the true residual, the energies) and, once per
+// force evaluation, the ghost rows of a vector — through two host collectives the caller provides once (elph_shard_set_collectives: a
+// barrier, and an in-place sum over the ranks; MPI.Barrier / MPI.Allreduce!, torch.distributed, or a thread barrier for ranks that
+// share a process).  The conjugate-gradient iteration itself stays as it was: device-initiated mailbox stores, no host.
+// =========================================================================================================================
+
+extern "C" int elph_shard_set_collectives(elph_handle h, elph_shard_barrier_fn barrier, elph_shard_allreduce_fn allreduce_sum, void *ctx) {
+    if (!h || !h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
+    ShardState *S = static_cast<ShardState *>(h->shard);
+    if ((!barrier || !allreduce_sum) && S->ctl.P > 1) { elph_set_error("a barrier and an all-reduce are needed for more than one rank"); return ELPH_E_ARG; }
+    S->barrier = barrier; S->allreduce = allreduce_sum; S->coll_ctx = ctx;
+    return ELPH_OK;
+}
+
+static ShardState *shard_callers(elph_handle_s *h) {
+    ShardState *S = h ? static_cast<ShardState *>(h->shard) : nullptr;
+    if (!S) { elph_set_error("elph_shard_create has not been called"); return nullptr; }
+    if (S->ctl.P > 1 && (!S->barrier || !S->allreduce)) { elph_set_error("elph_shard_set_collectives has not been called"); return nullptr; }
+    return S;
+}
+
+bool elph_i_shard_active(const elph_handle_s *h) {
+    const ShardState *S = h ? static_cast<const ShardState *>(h->shard) : nullptr;
+    return S && (S->ctl.P == 1 || (S->barrier && S->allreduce));
+}
+
+void elph_i_shard_own_range(const elph_handle_s *h, int *lo, int *hi) {
+    const ShardState *S = static_cast<const ShardState *>(h->shard);
+    *lo = S->ctl.own_lo; *hi = S->ctl.own_hi;
+}
+
+// in-place sum over the ranks of n doubles (identical result on every rank: the caller's all-reduce)
+int elph_i_shard_allreduce(elph_handle_s *h, double *buf, int n) {
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (S->ctl.P == 1 || n == 0) return ELPH_OK;
+    if (S->allreduce(S->coll_ctx, buf, n) != 0) { elph_set_error("the caller's all-reduce failed"); return ELPH_E_HIP; }
+    return ELPH_OK;
+}
+
+static int shard_arm(elph_handle_s *h, ShardState *S) {      // mailbox zeroed on every rank before any of them stores into one
+    int rc = elph_shard_prepare(h);
+    if (rc) return rc;
+    if (S->ctl.P > 1 && S->barrier(S->coll_ctx) != 0) { elph_set_error("the caller's barrier failed"); return ELPH_E_HIP; }
+    return ELPH_OK;
+}
+
+// Ghost rows of a site vector (layout S on the slab, nvec vectors) from their owners: every rank contributes its own rows to a vector on
+// the WHOLE lattice, the ranks sum it, and each takes its ghost rows from the sum.  Host-staged (once per force evaluation / refresh,
+// not per CG iteration); the own rows are not touched.
+int elph_i_shard_ghost_sync(elph_handle_s *h, double *vecS, int nvec) {
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (S->ctl.P == 1) return ELPH_OK;
+    if (S->n_global <= 0 || S->gsites_host.empty()) { elph_set_error("the shard was created without its global geometry"); return ELPH_E_STATE; }
+    const size_t N = (size_t)h->N, L = (size_t)h->L, NG = (size_t)S->n_global;
+    std::vector<double> loc(N * L * (size_t)nvec), glob(NG * L * (size_t)nvec, 0.0);
+    HIPCHK(hipMemcpyAsync(loc.data(), vecS, loc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t lo = (size_t)S->ctl.own_lo, hi = (size_t)S->ctl.own_hi;
+    for (size_t v = 0; v < (size_t)nvec; ++v)
+        for (size_t t = 0; t < L; ++t)
+            for (size_t s2 = lo; s2 < hi; ++s2) glob[(v * L + t) * NG + (size_t)S->gsites_host[s2]] = loc[(v * L + t) * N + s2];
+    int rc = elph_i_shard_allreduce(h, glob.data(), (int)glob.size());
+    if (rc) return rc;
+    for (size_t v = 0; v < (size_t)nvec; ++v)
+        for (size_t t = 0; t < L; ++t)
+            for (size_t s2 = 0; s2 < N; ++s2)
+                if (s2 < lo || s2 >= hi) loc[(v * L + t) * N + s2] = glob[(v * L + t) * NG + (size_t)S->gsites_host[s2]];
+    HIPCHK(hipMemcpyAsync(vecS, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// partial sums over the OWN sites of one slice each: part[0][t] = sum (a - b)^2, part[1][t] = sum b^2
+__global__ void __launch_bounds__(64) k_shard_resid_own(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ part,
+                                                        int N, int L, int lo, int hi) {
+    const int t = blockIdx.x;
+    double num = 0.0, den = 0.0;
+    for (int s2 = lo + (int)threadIdx.x; s2 < hi; s2 += 64) {
+        const size_t i = (size_t)t * N + s2;
+        const double d = a[i] - b[i];
+        num += d * d; den += b[i] * b[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) { num += __shfl_xor(num, o, 64); den += __shfl_xor(den, o, 64); }
+    if (threadIdx.x == 0) { part[t] = num; part[L + t] = den; }
+}
+
+// ldiv!(x, model, b[, P]) on the slab, device-resident: right-hand side in h->d_b (slot 0, layout S, ghost entries filled), solution in
+// h->d_x (slot 0; exact on own AND ghost rows: the solve keeps r, p, x of the ghost rows current through the boundary exchange).
+// Models.jl:74-137,139-186 line for line: solve, true residual |MᵀM x − b| / |b| (own rows of every rank, summed), flag 1 (hit maxiter) / 2
+// (false convergence), zero-fill, and with a preconditioner the un-preconditioned retry with 10 maxiter.  iters / resid / flag come out
+// identical on every rank (the sums are).
+int elph_i_shard_ldiv_dev(elph_handle_s *h, elph_handle_s *hfull, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag) {
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (use_prec && !hfull) { elph_set_error("a preconditioned sharded solve needs the full-lattice handle"); return ELPH_E_ARG; }
+    if (maxiter == 0) maxiter = h->maxiter;                                  // Models.jl:78-80,143-145
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    auto solve = [&](int prec, int64_t mi, int64_t *it) -> int {
+        int rc = shard_arm(h, S);
+        if (rc) return rc;
+        if (prec) {
+            int done = 0; double eps = 0.0;
+            return shard_kpm_core(h, hfull, S, h->tol, mi, h->kmax, it, &done, &eps);
+        }
+        rc = shard_run(h, nullptr, h->tol, mi, h->kmax, 0, nullptr);
+        if (rc) return rc;
+        const CgState &st = h->h_state[0];
+        if (!st.done) { elph_set_error("sharded CG ended without a terminal state (internal error)"); return ELPH_E_STATE; }
+        *it = st.iters;
+        return ELPH_OK;
+    };
+    auto residual_flag = [&](int64_t it, int64_t cmp_maxiter, double *res, int *fl) -> int {
+        int rc = elph_launch_mul(h, 2, h->d_tmp, h->d_x, 1);                 // mul!(v, model, x) on the slab: exact on the own rows
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_shard_resid_own, dim3((unsigned)h->L), dim3(64), 0, h->stream, h->d_tmp, h->d_b, h->d_part, (int)h->N, (int)h->L,
+                           S->ctl.own_lo, S->ctl.own_hi);
+        if ((rc = launch_ok("k_shard_resid_own"))) return rc;
+        std::vector<double> p(2 * (size_t)h->L);
+        HIPCHK(hipMemcpyAsync(p.data(), h->d_part, p.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        double nd[2] = {0.0, 0.0};
+        for (int64_t t = 0; t < h->L; ++t) { nd[0] += p[(size_t)t]; nd[1] += p[(size_t)(h->L + t)]; }
+        if ((rc = elph_i_shard_allreduce(h, nd, 2))) return rc;
+        *res = sqrt(nd[0]) / sqrt(nd[1]);
+        if (*res > sqrt(h->tol)) {                                           // Models.jl:100,157 (NaN compares false, as in the reference)
+            *fl = (it == cmp_maxiter) ? 1 : 2;
+            HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));             // fill!(x, 0)
+        } else {
+            *fl = 0;
+        }
+        return ELPH_OK;
+    };
+    int rc;
+    if ((rc = solve(use_prec, maxiter, iters))) return rc;
+    if ((rc = residual_flag(*iters, use_prec ? maxiter : h->maxiter, resid, flag))) return rc;      // :103 compares maxiter, :160 solver.maxiter
+    if (use_prec && *flag > 0) {                                             // :129-133
+        if ((rc = solve(0, 10 * maxiter, iters))) return rc;
+        if ((rc = residual_flag(*iters, h->maxiter, resid, flag))) return rc;
+    }
+    return ELPH_OK;
+}
+
+extern "C" int elph_shard_ldiv(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, int use_precond, int64_t maxiter,
+                               int64_t *iters, double *residual_error, int *flag) {
+    if (!h) { elph_set_error("null handle"); return ELPH_E_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    if (!x_slab || !b_slab || !iters || !residual_error || !flag || maxiter < 0) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (!h->have_E) { elph_set_error("update_model has not been called on this handle"); return ELPH_E_STATE; }
+    int rc;
+    if ((rc = elph_i_ensure_capacity(h, 1))) return rc;
+    const size_t bytes = (size_t)h->ndim * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, b_slab, bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = elph_launch_r2s(h, h->d_b, h->d_stage_in, 1))) return rc;
+    if ((rc = elph_i_shard_ldiv_dev(h, hfull, use_precond, maxiter, iters, residual_error, flag))) return rc;
+    if ((rc = elph_launch_s2r(h, h->d_stage_out, h->d_x, 1))) return rc;
+    HIPCHK(hipMemcpyAsync(x_slab, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
+// The two pseudofermion solves of calc_O⁻¹Λϕ! (HMC.jl:851-886) on the slab: right-hand sides in h->d_b[0], h->d_b[1], solutions into
+// h->d_x[0], h->d_x[1] (capacity >= 2), at tol^power; iters = cld(total, 2) and the flag as the reference returns them (:907-909); a
+// failed first solve suppresses the second (:880).  One sharded solve at a time (the SHARD kernel carries one right-hand side).
+int elph_i_shard_solve_pair(elph_handle_s *h, elph_handle_s *hfull, int use_prec, double tol_power, int64_t *iters, int *flag) {
+    const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double);
+    const double tol0 = h->tol;
+    h->tol = pow(tol0, tol_power);
+    int64_t it1 = 0, it2 = 0;
+    double res = 0.0;
+    int fl = 0;
+    // (+): slot 0 as it lies; keep b(−) aside, it moves into slot 0 for its own solve
+    int rc = elph_i_shard_ldiv_dev(h, hfull, use_prec, 0, &it1, &res, &fl);
+    int64_t tot = it1;
+    if (rc == ELPH_OK && fl == 0) {
+        hipError_t e = hipMemcpyAsync(h->d_zp, h->d_x, bytes, hipMemcpyDeviceToDevice, h->stream);           // X₊ aside (d_zp: free outside a preconditioned streaming solve... kept until below)
+        if (e == hipSuccess) e = hipMemcpyAsync(h->d_stage_out, h->d_b, bytes, hipMemcpyDeviceToDevice, h->stream);   // b₊ aside
+        if (e == hipSuccess) e = hipMemcpyAsync(h->d_b, h->d_b + nd, bytes, hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) { h->tol = tol0; elph_set_error("sharded pair: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+        std::vector<double> xp(nd);
+        // (a preconditioned sharded solve uses d_zp itself: X₊ waits on the host for the length of the second solve)
+        e = hipMemcpyAsync(xp.data(), h->d_x, bytes, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { h->tol = tol0; elph_set_error("sharded pair: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+        rc = elph_i_shard_ldiv_dev(h, hfull, use_prec, 0, &it2, &res, &fl);
+        if (rc == ELPH_OK) {
+            tot += it2;
+            e = hipMemcpyAsync(h->d_x + nd, h->d_x, bytes, hipMemcpyDeviceToDevice, h->stream);                  // X₋ -> slot 1
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_x, xp.data(), bytes, hipMemcpyHostToDevice, h->stream);   // X₊ -> slot 0
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_b + nd, h->d_b, bytes, hipMemcpyDeviceToDevice, h->stream);   // b₋ back to slot 1
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_b, h->d_stage_out, bytes, hipMemcpyDeviceToDevice, h->stream); // b₊ back to slot 0
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { h->tol = tol0; elph_set_error("sharded pair: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+        }
+    } else if (rc == ELPH_OK) {
+        rc = elph_launch_zero(h, h->d_x + nd, (int64_t)nd);
+    }
+    h->tol = tol0;
+    if (rc) return rc;
+    if (fl == 0) tot = (tot + 1) / 2;                                         // cld(iters, 2)
+    *iters = tot;
+    *flag = fl;
+    return ELPH_OK;
+}
+
+// One fermion-force evaluation of the Holstein model on a sharded lattice: elph_fermion_force_holstein's steps (update_model!,
+// calc_O⁻¹Λϕ!, calc_dSfdx!) on the slab.  All vectors are slab vectors (own + ghost rows, ghost entries filled from the global arrays);
+// the force is exact on the OWN rows (the same closure argument as for z = Mᵀ(M p): CB, then CBᵀ) and only those are accumulated into.
+extern "C" int elph_shard_fermion_force_holstein(elph_handle h, elph_handle hfull, const double *x, const double *lambda, const double *lambda2,
+                                                 const double *mu, double dtau, const double *phi_plus, const double *phi_minus, int use_precond,
+                                                 double tol_power, double *dSfdx, double *Xp_out, double *Xm_out, int64_t *iters, int *flag) {
+    if (!h) { elph_set_error("null handle"); return ELPH_E_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (h->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("not a Holstein handle"); return ELPH_E_ARG; }
+    if (!x || !lambda || !lambda2 || !mu || !phi_plus || !phi_minus || !dSfdx || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    int rc;
+    if ((rc = elph_i_ensure_capacity(h, 2))) return rc;
+    const size_t nd = (size_t)h->ndim, N = (size_t)h->N, bytes = nd * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->d_lam, lambda, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + N, lambda2, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_lam + 2 * N, mu, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, x, bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = elph_launch_expV(h, h->d_stage_in, dtau))) return rc;
+    if ((rc = elph_launch_r2s(h, h->d_xfield, h->d_stage_in, 1))) return rc;
+    h->have_E = true;
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, phi_plus, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, phi_minus, bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = elph_launch_r2s(h, h->d_phi, h->d_stage_in, 2))) return rc;
+    if ((rc = elph_launch_lambda_rhs(h, h->d_b, h->d_phi, h->d_xfield, dtau))) return rc;
+    if ((rc = elph_i_shard_solve_pair(h, hfull, use_precond, tol_power, iters, flag))) return rc;
+    if ((rc = elph_launch_force_holstein(h, h->d_tmp, h->d_x, h->d_phi, h->d_xfield, dtau))) return rc;
+    if ((rc = elph_launch_s2r(h, h->d_stage_out, h->d_tmp, 1))) return rc;
+    std::vector<double> F(nd);
+    HIPCHK(hipMemcpyAsync(F.data(), h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (Xp_out || Xm_out) {
+        if ((rc = elph_launch_s2r(h, h->d_stage_in, h->d_x, 2))) return rc;
+        if (Xp_out) HIPCHK(hipMemcpyAsync(Xp_out, h->d_stage_in, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (Xm_out) HIPCHK(hipMemcpyAsync(Xm_out, h->d_stage_in + nd, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t L = (size_t)h->L;
+    for (size_t s2 = (size_t)S->ctl.own_lo; s2 < (size_t)S->ctl.own_hi; ++s2)
+        for (size_t t = 0; t < L; ++t) dSfdx[s2 * L + t] += F[s2 * L + t];      // own rows only ("@. dSfdx += ...", HMC.jl:803-811)
+    return ELPH_OK;
+}
+
+// The same for the bond-phonon model (elph_fermion_force_ssh): the two solves on the given right-hand sides and the bond brackets
+// q_out[n Ltau + tau] of the slab's bonds (local checkerboard order).  A bracket is exact on the rank that owns its bond (both ends in
+// the own rows, or one end in the first ghost row across the slab's edge: the crossing colour is the last factor of the sweep); the
+// caller keeps the brackets of its own bonds and scatters them onto the phonon fields (sharded.py: ShardedSolver.force_ssh).
+extern "C" int elph_shard_fermion_force_ssh(elph_handle h, elph_handle hfull, const double *rhs_plus, const double *rhs_minus, int use_precond,
+                                            double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters, int *flag) {
+    if (!h) { elph_set_error("null handle"); return ELPH_E_ARG; }
+    HIPCHK(hipSetDevice(h->device));
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (h->kind != ELPH_MODEL_SSH) { elph_set_error("not an SSH handle"); return ELPH_E_ARG; }
+    if (!h->have_E) { elph_set_error("update_model has not been called on this handle"); return ELPH_E_STATE; }
+    if (!rhs_plus || !rhs_minus || !q_out || !iters || !flag) { elph_set_error("null argument"); return ELPH_E_ARG; }
+    int rc;
+    if ((rc = elph_i_ensure_capacity(h, 2))) return rc;
+    const size_t nd = (size_t)h->ndim, bytes = nd * sizeof(double), L = (size_t)h->L, nb = (size_t)h->nb, nq = L * nb;
+    if (nq > 2 * nd) { elph_set_error("more bonds than 2*nsites: scratch too small"); return ELPH_E_UNSUPPORTED; }
+    HIPCHK(hipMemcpyAsync(h->d_stage_in, rhs_plus, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_stage_in + nd, rhs_minus, bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = elph_launch_r2s(h, h->d_b, h->d_stage_in, 2))) return rc;
+    if ((rc = elph_i_shard_solve_pair(h, hfull, use_precond, tol_power, iters, flag))) return rc;
+    if ((rc = elph_launch_force_ssh(h, h->d_p, h->d_x))) return rc;
+    std::vector<double> qt(nq);
+    if (nq) HIPCHK(hipMemcpyAsync(qt.data(), h->d_p, nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (Xp_out || Xm_out) {
+        if ((rc = elph_launch_s2r(h, h->d_stage_in, h->d_x, 2))) return rc;
+        if (Xp_out) HIPCHK(hipMemcpyAsync(Xp_out, h->d_stage_in, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (Xm_out) HIPCHK(hipMemcpyAsync(Xm_out, h->d_stage_in + nd, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t t = 0; t < L; ++t)
+        for (size_t n = 0; n < nb; ++n) q_out[n * L + t] = qt[t * nb + n];
+    return ELPH_OK;
 }

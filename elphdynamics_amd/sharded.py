@@ -273,6 +273,100 @@ class ShardedSolver:
         self.eps = float(eps.value)
         return np.ascontiguousarray(np.concatenate(parts, axis=0)).reshape(-1), int(it.value), int(done.value)
 
+    # ---- the callers of the solve on a sharded lattice (include/elph_gpu.h: elph_shard_set_collectives, elph_shard_ldiv,
+    # ---- elph_shard_fermion_force_*, elph_hmc_update on the slab handle) ---------------------------------------------------
+    BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+    def install_collectives(self):
+        """Register the two host collectives the sharded callers need (a barrier; an in-place sum over the ranks, added in rank order
+        so that every rank gets the same bits) — here through the communicator that already carries the mailbox handles."""
+        if getattr(self, "_coll", None):
+            return
+
+        def bar(ctx):
+            try:
+                self.comm.barrier()
+                return 0
+            except Exception:                                # never let an exception cross the C boundary
+                return 1
+
+        def ars(ctx, buf, n):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                parts = self.comm.allgather_object(a.copy()) if self.P > 1 else [a.copy()]
+                tot = np.array(parts[0], dtype=np.float64, copy=True)
+                for q in parts[1:]:
+                    tot += q
+                a[:] = tot
+                return 0
+            except Exception:
+                return 1
+
+        self._coll = (self.BARRIER_FN(bar), self.ALLREDUCE_FN(ars))
+        self._lib_mod.check(self.lib.elph_shard_set_collectives(self.h, C.cast(self._coll[0], C.c_void_p), C.cast(self._coll[1], C.c_void_p), None))
+
+    def set_solver(self, tol, maxiter, kmax=1e12):
+        self._lib_mod.check(self.lib.elph_solver_set(self.h, float(tol), int(maxiter), float(kmax)))
+
+    def _gather_own(self, v_slab):
+        """Own rows of a slab vector from every rank -> the vector on the whole lattice (identical on every rank)."""
+        own = np.asarray(v_slab).reshape(self.Nloc, self.Ltau)[self.own_lo:self.own_lo + self.own_n, :]
+        parts = self.comm.allgather_object(own) if self.P > 1 else [own]
+        return np.ascontiguousarray(np.concatenate(parts, axis=0)).reshape(-1)
+
+    def ldiv(self, b_global, precond=False, maxiter=0):
+        """ldiv!(x, model, b[, P]) over the ranks — Models.jl:74-137,139-186: (x_global, iters, residual_error, flag), identical everywhere."""
+        self.install_collectives()
+        lm = self._lib_mod
+        b = self._local(b_global)
+        x = np.zeros(self.Nloc * self.Ltau)
+        it, res, fl = C.c_int64(), C.c_double(), C.c_int()
+        lm.check(self.lib.elph_shard_ldiv(self.h, self.hf if precond else None, lm.dptr(x), lm.dptr(b), 1 if precond else 0, int(maxiter),
+                                          C.byref(it), C.byref(res), C.byref(fl)))
+        return self._gather_own(x), int(it.value), float(res.value), int(fl.value)
+
+    def fermion_force_holstein(self, x_global, lam, lam2, mu, dtau, phi_p, phi_m, precond=False, power=1.0):
+        """update_model! + calc_O⁻¹Λϕ! + calc_dSfdx! of the Holstein model over the ranks (HMC.jl:790-915): returns
+        (dSf/dx on the whole lattice, O⁻¹Λϕ₊, O⁻¹Λϕ₋, iters, flag)."""
+        self.install_collectives()
+        lm, d = self._lib_mod, self._lib_mod.dptr
+        site = lambda a: np.ascontiguousarray(np.asarray(a)[self.gsites])      # noqa: E731
+        F = np.zeros(self.Nloc * self.Ltau)
+        Xp, Xm = np.zeros_like(F), np.zeros_like(F)
+        it, fl = C.c_int64(), C.c_int()
+        lm.check(self.lib.elph_shard_fermion_force_holstein(
+            self.h, self.hf if precond else None, d(self._local(x_global)), d(site(lam)), d(site(lam2)), d(site(mu)), float(dtau),
+            d(self._local(phi_p)), d(self._local(phi_m)), 1 if precond else 0, float(power), d(F), d(Xp), d(Xm), C.byref(it), C.byref(fl)))
+        return self._gather_own(F), self._gather_own(Xp), self._gather_own(Xm), int(it.value), int(fl.value)
+
+    def owned_bonds(self):
+        """Local bonds (positions in this slab's table) whose force bracket this rank owns: the bond's first site (i < j in the
+        reference's tables, Lattices.jl:323-340) lies in the own rows.  Every bond of the lattice has exactly one owner."""
+        ltab = self.slabs.local_table(self.rank, self._full[0]) - 1
+        return np.nonzero((ltab[:, 0] >= self.own_lo) & (ltab[:, 0] < self.own_lo + self.own_n))[0]
+
+    def fermion_force_ssh(self, rhs_p, rhs_m, nbonds_global, precond=False, power=1.0):
+        """The two solves of calc_O⁻¹Λϕ! and the bond brackets of muldMdx! (SSHModels.jl:707-829) over the ranks: returns
+        (q[nbonds_global, Ltau] in the global checkerboard order, iters, flag) — what elph_fermion_force_ssh returns for one handle."""
+        self.install_collectives()
+        lm, d = self._lib_mod, self._lib_mod.dptr
+        nbl = len(self.bonds)
+        q = np.zeros(nbl * self.Ltau)
+        it, fl = C.c_int64(), C.c_int()
+        lm.check(self.lib.elph_shard_fermion_force_ssh(self.h, self.hf if precond else None, d(self._local(rhs_p)), d(self._local(rhs_m)),
+                                                       1 if precond else 0, float(power), d(q), None, None, C.byref(it), C.byref(fl)))
+        q = q.reshape(nbl, self.Ltau)
+        own = self.owned_bonds()
+        mine = (np.asarray(self.bonds)[own], q[own])
+        parts = self.comm.allgather_object(mine) if self.P > 1 else [mine]
+        out = np.full((int(nbonds_global), self.Ltau), np.nan)
+        for gb, qq in parts:
+            assert np.all(np.isnan(out[gb])), "a bond with two owners"
+            out[gb] = qq
+        assert not np.isnan(out).any(), "a bond without an owner"
+        return out, int(it.value), int(fl.value)
+
     def iterate(self, b_global, k):
         """Exactly k iterations (no stop test); returns this rank's HIP-event time of the launch in ms (bench.py)."""
         b = self._local(b_global)

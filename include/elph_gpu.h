@@ -492,6 +492,35 @@ int elph_shard_solve_kpm(elph_handle h, elph_handle hfull, double *x_slab, const
                          double kappa_max, int64_t *iters, int *done, double *eps);
 int elph_shard_destroy(elph_handle h);
 
+/* The CALLERS of the solve on a sharded lattice (BASELINE configs "HMC ... spatial-sharded across 8 GPUs"): ldiv!'s wrapper, the fermion
+ * force and — elph_hmc_update on a sharded handle — one HMC update.  Everything but the solve is pointwise in the site index or stays
+ * inside the MᵀM closure the slab already holds; what crosses ranks besides the solve are a few scalars (true residual, energies) and,
+ * once per force evaluation, the ghost rows of one vector.  Those go through two host collectives the caller registers once per handle
+ * (MPI.Barrier / MPI.Allreduce!(SUM), torch.distributed, a thread barrier for ranks that share a process); the CG iteration itself
+ * keeps its device-initiated mailbox stores.  The library arms the mailbox itself (elph_shard_prepare + the barrier) before every solve
+ * of these calls.  All vectors are SLAB vectors (own + ghost rows, reference layout, ghost entries filled from the global arrays);
+ * results are valid on the OWN rows; scalars (iters, residual_error, flag, energies, accepted) come out identical on every rank.
+ *   barrier(ctx) -> 0 on success;  allreduce_sum(ctx, buf, n): in-place sum over the ranks of n doubles, the SAME result on every rank. */
+typedef int (*elph_shard_barrier_fn)(void *ctx);
+typedef int (*elph_shard_allreduce_fn)(void *ctx, double *buf, int n);
+int elph_shard_set_collectives(elph_handle h, elph_shard_barrier_fn barrier, elph_shard_allreduce_fn allreduce_sum, void *ctx);
+/* ldiv!(x, model, b[, P]; maxiter) -> (iters, residual_error, flag) — Models.jl:74-137,139-186 — on a sharded lattice: the solve, the true
+ * residual |MᵀM x − b| / |b| over all ranks' own rows, flag 1 / 2 with zero-fill, and with use_precond (hfull: the full-lattice handle
+ * with elph_kpm_setup done, as for elph_shard_solve_kpm) the un-preconditioned retry with 10·maxiter.  Solver settings: elph_solver_set
+ * on h. */
+int elph_shard_ldiv(elph_handle h, elph_handle hfull, double *x_slab, const double *b_slab, int use_precond, int64_t maxiter,
+                    int64_t *iters, double *residual_error, int *flag);
+/* elph_fermion_force_holstein on a sharded lattice: update_model!, Λϕ±, the two solves (one after the other: the sharded kernel carries
+ * one right-hand side; a failed first solve suppresses the second, iters = cld(total, 2): HMC.jl:851-909) and calc_dSfdx! on the slab;
+ * dSfdx is accumulated into on the OWN rows only. */
+int elph_shard_fermion_force_holstein(elph_handle h, elph_handle hfull, const double *x, const double *lambda, const double *lambda2,
+                                      const double *mu, double dtau, const double *phi_plus, const double *phi_minus, int use_precond,
+                                      double tol_power, double *dSfdx, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
+/* elph_fermion_force_ssh on a sharded lattice: q_out[n·Ltau + tau] for the slab's bonds in their local checkerboard order; a bracket is
+ * exact on the rank that owns the bond — the caller keeps those and scatters them onto the phonon fields. */
+int elph_shard_fermion_force_ssh(elph_handle h, elph_handle hfull, const double *rhs_plus, const double *rhs_minus, int use_precond,
+                                 double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
+
 /* ---------------------------------------------------------------- health of the resident kernels */
 
 /* The whole-solve-in-one-launch kernels (cg_wg.hip) wait for their team members with a wall-clock bound (ELPH_WG_TIMEOUT_MS, 2 s); a

@@ -1376,7 +1376,7 @@ def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, 
 @pytest.mark.parametrize("tag,nchains,per,chunk_T", [("C", 32, 2, "4"), ("C", 64, 2, None), ("C", 144, 2, None), ("C", 1, 64, "4"), ("D", 64, 2, "4")])
 def test_preconditioned_batch_as_two_half_batches_on_two_streams(tag, nchains, per, chunk_T, monkeypatch):
     """elph_ldiv_batched of a large KPM-preconditioned batch runs as two half-batches on two streams (elph_api.hip: SplitRun; default
-    from 128 right-hand sides, forced here): every right-hand side goes through the same kernels with the same partial-sum layout as in
+    from 192 right-hand sides, forced here): every right-hand side goes through the same kernels with the same partial-sum layout as in
     one stream.  With the chunk length pinned (ELPH_CHUNK_T) the two forms give the SAME BITS; with the library's own choice the
     halves may take another chunk length than the whole batch (another grouping of the p.z partial sums): iteration counts within
     one, solutions to 1e-9 of two tol = 1e-8 solves."""

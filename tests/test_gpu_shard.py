@@ -208,3 +208,87 @@ def test_shard_selftest_names_a_silent_rank(tmp_path):
     assert all(p.returncode == 0 for p in procs), [e[-2000:] for _, e in outs]
     line = [l for l in outs[0][0].splitlines() if l.startswith("RC")][0]
     assert line.startswith("RC -2") and "rank(s) 1" in line and "300 ms" in line, line
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The CALLERS of the solve on a sharded lattice (BASELINE configs 4 and 5: "HMC ... spatial-sharded"): ldiv!'s wrapper, the fermion force,
+# one HMC update — several ranks on the box's one GPU against ONE handle on the whole lattice.
+# ---------------------------------------------------------------------------------------------------------------------------------
+
+def _run_callers(what, tag, tmp_path, world, per_proc=1, extra_env=None):
+    port = _free_port()
+    out = str(tmp_path / f"callers_{what}_{tag}_{world}")
+    nproc = world // per_proc
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ELPH_FORCE_DEVICE="0", ELPH_RANKS_PER_PROC=str(per_proc), ELPH_WG_TIMEOUT_MS="60000")
+        if per_proc > 1:      # rank threads of one process: every rank's stream on a hardware queue of its own (kernels that wait for each other)
+            env["GPU_MAX_HW_QUEUES"] = "8"
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_callers_worker.py"), what, tag, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        errs.append((p.returncode, e[-3000:]))
+    assert all(rc == 0 for rc, _ in errs), errs
+    return [np.load(out + f".rank{r}.npz") for r in range(world)]
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("tag,world", [("D", 2), ("D", 4), ("E", 2)])
+def test_sharded_ldiv_has_the_reference_semantics(tmp_path, tag, world):
+    """elph_shard_ldiv = ldiv!(x, model, b) over the ranks (Models.jl:139-186): iteration count, true residual and flag identical on every
+    rank and equal to ONE handle's; flag 1 (hit maxiter) / 2 (false convergence) with x zero-filled everywhere."""
+    res = _run_callers("ldiv", tag, tmp_path, world)
+    a = res[0]
+    for b in res[1:]:
+        assert int(b["it"]) == int(a["it"]) and float(b["resid"]) == float(a["resid"]) and int(b["flag"]) == int(a["flag"]) and np.array_equal(a["x"], b["x"])
+        assert int(b["flag5"]) == int(a["flag5"]) and int(b["it5"]) == int(a["it5"])
+    assert int(a["flag"]) == 0 and int(a["flag_ref"]) == 0 and abs(int(a["it"]) - int(a["it_ref"])) <= 2
+    assert _rel(a["x"], a["x_ref"]) < 1e-10
+    assert float(a["resid"]) < 1e-10 and abs(float(a["resid"]) - float(a["resid_ref"])) < 1e-11
+    assert int(a["it5"]) == 5 and int(a["flag5"]) == 1 and not a["x5"].any() and float(a["resid5"]) > 1e-3
+    assert int(a["it6"]) == 5 and int(a["flag6"]) == 2 and float(a["nz6"]) == 0.0
+
+
+@pytest.mark.parametrize("tag,world,per_proc", [("D", 2, 1), ("D", 4, 1), ("D", 8, 2), ("E", 2, 1), ("E", 4, 1), ("E", 8, 2)])
+def test_sharded_fermion_force_vs_one_handle(tmp_path, tag, world, per_proc):
+    """BASELINE configs 4 and 5: the fermion force of the Holstein honeycomb lattice (D) and the bond brackets of the optical SSH model (E)
+    sharded over 2 / 4 / 8 ranks reproduce elph_fermion_force_* of ONE handle to 1e-10 (solves to 1e-12 on both sides); iters and flag
+    identical on every rank."""
+    res = _run_callers("force", tag, tmp_path, world, per_proc=per_proc)
+    a = res[0]
+    key = "F" if tag == "D" else "q"
+    for b in res[1:]:
+        assert int(b["it"]) == int(a["it"]) and int(b["flag"]) == 0 and np.array_equal(a[key], b[key])
+    assert int(a["flag"]) == 0 and int(a["flag_ref"]) == 0 and abs(int(a["it"]) - int(a["it_ref"])) <= 2
+    assert _rel(a[key], a[key + "_ref"]) < 1e-10, _rel(a[key], a[key + "_ref"])
+    if tag == "D":
+        assert _rel(a["Xp"], a["Xp_ref"]) < 1e-10 and _rel(a["Xm"], a["Xm_ref"]) < 1e-10
+
+
+@pytest.mark.parametrize("world,nb", [(2, 1), (4, 1), (2, 3)])
+def test_sharded_hmc_update_vs_one_handle(tmp_path, world, nb):
+    """One HMC update of BASELINE config 4 (Holstein honeycomb L = 12, Ntau = 120) on a lattice sharded over 2 / 4 ranks —
+    elph_hmc_update on the slab handle: sharded solves, own-row energies summed over the ranks, ghost rows of ϕ± and of the fermion force
+    from their owners — against the update of ONE handle with the same random numbers: same decision, H, S, K and the field to 1e-9."""
+    res = _run_callers("hmc", "D", tmp_path, world, extra_env={"ELPH_TEST_NB": str(nb)})
+    a = res[0]
+    for b in res[1:]:
+        assert int(b["accepted"]) == int(a["accepted"]) and np.array_equal(a["energies"], b["energies"]) and np.array_equal(a["x"], b["x"])
+    assert int(a["accepted"]) == int(a["accepted_ref"]) == 1 and int(a["flag"]) == int(a["flag_ref"]) == 0
+    e, er = a["energies"], a["energies_ref"]
+    assert abs(e[0] - er[0]) < 1e-9 * abs(er[0]) and abs(e[1] - er[1]) < 1e-8 * abs(er[1])
+    assert abs(e[2] - er[2]) < 1e-8 * abs(er[2]) and abs(e[3] - er[3]) < 1e-8 * abs(er[3])
+    assert _rel(a["x"], a["x_ref"]) < 1e-9 and _rel(a["v"], a["v_ref"]) < 1e-8
+    assert abs(float(a["iters"]) - float(a["iters_ref"])) <= 1
