@@ -1168,7 +1168,7 @@ static bool reg_cheb_form(const elph_handle_s *h) {      // a register-exchange 
 }
 
 static bool px_plan(elph_handle_s *h, int nrhs) {
-    if (!h->fast || !h->kpm_active || h->kind != ELPH_MODEL_HOLSTEIN || h->lp_mc != 4) return false;
+    if (!h->fast || !h->kpm_active || h->lp_mc != 4) return false;      // (Holstein and bond-phonon models alike)
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     CgBufs B = make_bufs(h, nrhs);
     if (!(B.dot_lo == 0 && B.dot_hi == N) || !elph_dft_mfma_xr_usable(h, N, nrhs)) return false;      // the iteration takes cg_mode 2

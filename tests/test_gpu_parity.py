@@ -1343,7 +1343,8 @@ def _px_fused(m):
 
 
 @pytest.mark.parametrize("tag,nchains,per,chunk_T", [("C", 16, 2, None), ("C", 1, 48, None), ("C", 64, 2, None), ("C", 144, 2, None), ("C", 20, 2, "5"),
-                                                      ("D", 16, 2, None), ("D", 64, 2, None), ("B", 64, 2, None), ("S", 32, 2, None)])
+                                                      ("D", 16, 2, None), ("D", 64, 2, None), ("B", 64, 2, None), ("S", 32, 2, None),
+                                                      ("E", 16, 2, None), ("E", 64, 2, None), ("E", 1, 48, None)])      # bond phonons (BASELINE config 5)
 def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, per, chunk_T, monkeypatch):
     """The batched KPM-preconditioned iteration with x += alpha p and p = P^-1 r + beta p moved into the epilogue of the inverse
     tau-transform (dft_mfma.hip: PxFuse; k_cg_ap_chunk<PX> reads the ready p): same arithmetic per element and the same summation
@@ -1354,7 +1355,10 @@ def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, 
         monkeypatch.setenv("ELPH_CHUNK_T", chunk_T)
     m = configs.make_model(tag, tol=1e-8)
     nrhs = nchains * per
-    if nchains > 1:
+    if nchains > 1 and m.kind == models.SSH:      # bond phonons: the deck's field rescaled and roughened per chain (|alpha x| stays below t)
+        X = np.stack([m.x * (0.55 + 0.9 * c / nchains) * (1.0 + 0.2 * synth.randn(8000 + c, m.Ndof)) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+    elif nchains > 1:
         X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=8000 + c) for c in range(nchains)])
         models.update_model_chains_(m, X)
     P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
