@@ -646,23 +646,39 @@ def main():
                                                  f"config-{args.config} workload, oracle/elph_oracle.c built -O3 -march=native "
                                                  f"-ffast-math, single thread ({os.cpu_count()} host cores present)",
                                        "cg_iters_per_sec": n_it / dt, "seconds": dt}
-                if m.kind == 0:
-                    try:     # all-host-cores variant: NOT the reference's configuration (it is single-threaded)
-                        from oracle import oracle as _om
-                        best = None
-                        for nt in sorted({min(8, os.cpu_count()), min(32, os.cpu_count()), min(64, os.cpu_count())}):
-                            secs, _ = _om.cg_iterations_omp(om, b0, 100, nt)          # warm-up + cost estimate
-                            n_omp = int(max(100, min(20000, 1.0 / max(secs / 100, 1e-7))))  # ~1 s per thread count
-                            secs, _ = _om.cg_iterations_omp(om, b0, n_omp, nt)
-                            rate = 2.0 * n_omp / secs
-                            if best is None or rate > best[0]:
-                                best = (rate, nt)
-                        out["cpu_baseline_all_cores"] = {"value": best[0], "unit": "matvec/s", "cores": best[1],
-                                                         "kind": "port", "note": "OpenMP over sites / bonds-within-colour / "
-                                                         "BLAS-1 reductions; best of 8/32/64 threads; NOT the reference's "
-                                                         "configuration (single-threaded, ElPhDynamics.jl:74-75)"}
-                    except Exception as e:
-                        out["cpu_baseline_all_cores"] = {"value": None, "note": f"failed: {e}"}
+                # all host cores THE REFERENCE'S WAY: it has no threads (ElPhDynamics.jl:74-75 pins BLAS and FFTW to one) and fills a node
+                # with independent run-IDs, one single-threaded process per core (ElPhDynamics.jl:90-95) — so: one single-threaded oracle
+                # solve per usable core, all at once, each on its own copy of the model; value = the sum of their rates.  (Round 4's
+                # OpenMP variant of ONE solve did not scale — 1.15x on 8 threads — and was no baseline of anything: dropped.)
+                try:
+                    import subprocess
+                    import tempfile
+                    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                    n_each = int(max(200, min(200000, 0.5 * args.cpu_seconds / per_it)))
+                    with tempfile.TemporaryDirectory() as td:
+                        f_in = os.path.join(td, "chain.npz")
+                        if m.kind == 0:
+                            np.savez(f_in, kind=0, N=m.Nsites, L=m.Ltau, table=m.neighbor_table, c=m.cosht, s=m.sinht, E=E, b=b0, n=n_each)
+                        else:
+                            np.savez(f_in, kind=1, N=m.Nsites, L=m.Ltau, table=m.neighbor_table, c=np.ascontiguousarray(m.cosht).reshape(-1),
+                                     s=np.ascontiguousarray(m.sinht).reshape(-1), E=m.expDtauMu, b=b0, n=n_each)
+                        # fresh CHILD processes (never an exec of this GPU-initialised one), CPU only: they import numpy and the oracle
+                        child = ("import sys, time, numpy as np; sys.path.insert(0, %r); from oracle.oracle import Oracle; a = np.load(%r); "
+                                 "o = Oracle(fast=True); om = o.make_model(int(a['kind']), int(a['N']), int(a['L']), a['table'], "
+                                 "np.ascontiguousarray(a['c']), np.ascontiguousarray(a['s']), np.ascontiguousarray(a['E'])); b = np.ascontiguousarray(a['b']); "
+                                 "o.cg_solve(om, b, tol=0.0, maxiter=50); t = time.perf_counter(); o.cg_solve(om, b, tol=0.0, maxiter=int(a['n'])); "
+                                 "print(time.perf_counter() - t)") % (ROOT, f_in)
+                        env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+                        procs = [subprocess.Popen([sys.executable, "-c", child], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+                                 for _ in range(cores)]
+                        secs = [float(pr.communicate(timeout=120 + 4 * args.cpu_seconds)[0].strip().splitlines()[-1]) for pr in procs]
+                    out["cpu_baseline_all_cores"] = {
+                        "value": sum(2.0 * n_each / t_ for t_ in secs), "unit": "matvec/s", "cores": cores, "kind": "port",
+                        "per_core_min": 2.0 * n_each / max(secs), "per_core_max": 2.0 * n_each / min(secs),
+                        "sample": f"{cores} independent single-threaded processes at once ({n_each} iterations each), one per usable core — the "
+                                  "reference's own way of using a node (independent run-IDs, ElPhDynamics.jl:90-95); value = sum of their rates"}
+                except Exception as e:
+                    out["cpu_baseline_all_cores"] = {"value": None, "note": f"failed: {e}"}
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     m.close()

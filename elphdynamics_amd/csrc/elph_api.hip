@@ -867,7 +867,15 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
     }
     if (memcmp(&P, &h->cur_params, sizeof(P)) != 0) drop_graphs(h);   // parameters are baked into captured launches
     h->cur_params = P;
-    RC(elph_wg_cooldown_step(h));          // one solve of the cool-down after a resident kernel timed out (either kernel, either kind of solve)
+    // one solve of the cool-down after a resident kernel timed out — counted only for solves that WOULD have taken a resident kernel (either
+    // kernel, either kind of solve): a stream of large streaming batches in between does not bring the retry forward, and a solve that
+    // never launches a resident kernel does not clear the abort word
+    if (h->wg_broken) {
+        bool eligible = false;
+        if (!use_prec) eligible = h->fast && maxiter >= 1 && elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs);
+        else { h->wg_broken = false; eligible = maxiter >= 1 && elph_pcg_wg_usable(h, nrhs); h->wg_broken = true; }      // (its shape test reads the flag itself)
+        if (eligible) RC(elph_wg_cooldown_step(h));
+    }
     RC(elph_launch_cg_init(h, nrhs, use_prec, x0_zero));      // (x0 = 0: A x0 = 0 without the mat-vec)
     h->wg_x0_zero = h->x_zero_seen;
 

@@ -478,14 +478,19 @@ extern "C" int elph_shard_selftest(elph_handle h, int rounds, double *us_per_rou
     if (!h || !h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
     HIPCHK(hipSetDevice(h->device));
     ShardState *S = static_cast<ShardState *>(h->shard);
+    // arguments first: a bad call must not consume the prepare + barrier the ranks have just paid for
+    if (rounds < 1 || rounds > (1 << 20)) { elph_set_error("bad number of rounds"); return ELPH_E_ARG; }
     if (!S->prepared) { elph_set_error("elph_shard_prepare (and the caller's barrier) must precede elph_shard_selftest"); return ELPH_E_STATE; }
     S->prepared = false;
-    if (rounds < 1 || rounds > (1 << 20)) { elph_set_error("bad number of rounds"); return ELPH_E_ARG; }
     const int P = S->ctl.P;
+    static_assert(ELPH_SHARD_MAXRANKS <= 64, "the self-test's device buffers hold 64 ranks");
     long long *d_lat = nullptr;
     HIPCHK(hipMalloc((void **)&d_lat, 64 * sizeof(long long) + 64 * sizeof(int)));
     int *d_status = reinterpret_cast<int *>(d_lat + 64);
-    HIPCHK(hipMemsetAsync(d_lat, 0xFF, 64 * sizeof(long long) + 64 * sizeof(int), h->stream));
+    {
+        hipError_t em = hipMemsetAsync(d_lat, 0xFF, 64 * sizeof(long long) + 64 * sizeof(int), h->stream);
+        if (em != hipSuccess) { (void)hipFree(d_lat); elph_set_error("elph_shard_selftest: %s", hipGetErrorString(em)); return ELPH_E_HIP; }
+    }
     const char *eb = getenv("ELPH_SHARD_SELFTEST_MS");
     const long long bound_ms = (eb && atoll(eb) > 0) ? atoll(eb) : 10000;
     const unsigned seq = 0x5E1F0000u + (++S->selftest_calls & 0xFFFFu);       // (a collective: every rank's n-th call carries the same number)
