@@ -653,7 +653,8 @@ def main():
                 try:
                     import subprocess
                     import tempfile
-                    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                    cores = min(visible, int(os.environ.get("ELPH_BENCH_CPU_WORKERS", "16")))      # a one-GPU box's CPU share is 16 cores, whatever it shows
                     n_each = int(max(200, min(200000, 0.5 * args.cpu_seconds / per_it)))
                     with tempfile.TemporaryDirectory() as td:
                         f_in = os.path.join(td, "chain.npz")
@@ -675,7 +676,8 @@ def main():
                     out["cpu_baseline_all_cores"] = {
                         "value": sum(2.0 * n_each / t_ for t_ in secs), "unit": "matvec/s", "cores": cores, "kind": "port",
                         "per_core_min": 2.0 * n_each / max(secs), "per_core_max": 2.0 * n_each / min(secs),
-                        "sample": f"{cores} independent single-threaded processes at once ({n_each} iterations each), one per usable core — the "
+                        "host_cores_visible": visible,
+                        "sample": f"{cores} independent single-threaded processes at once ({n_each} iterations each), one per core of the box's CPU share — the "
                                   "reference's own way of using a node (independent run-IDs, ElPhDynamics.jl:90-95); value = sum of their rates"}
                 except Exception as e:
                     out["cpu_baseline_all_cores"] = {"value": None, "note": f"failed: {e}"}
