@@ -352,6 +352,7 @@ bool elph_i_shard_active(const elph_handle_s *h);                           // a
 void elph_i_shard_own_range(const elph_handle_s *h, int *lo, int *hi);      // own sites [lo, hi) of the slab
 int elph_i_shard_allreduce(elph_handle_s *h, double *buf, int n);
 int elph_i_shard_ghost_sync(elph_handle_s *h, double *vecS, int nvec);
+int elph_i_shard_ghost_sync_cols(elph_handle_s *h, double *vecS, int nvec, int ncols, const int *gcol, int ngcol, const double *own);
 int elph_i_shard_ldiv_dev(elph_handle_s *h, elph_handle_s *hfull, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag);
 int elph_i_shard_solve_pair(elph_handle_s *h, elph_handle_s *hfull, int use_prec, double tol_power, int64_t *iters, int *flag);
 void elph_greens_free(elph_handle_s *h);

@@ -44,6 +44,12 @@ struct HmcState {
     int *prim = nullptr, *next = nullptr;
     double *wcol = nullptr;
     std::vector<int> prim_host;
+    // a sharded lattice with bond phonons (elph_shard_hmc_set_columns): the slab's phonon columns in the numbering of the whole lattice, which of
+    // them this rank owns (weight 1 / 0, device copy in wown) — sums over fields count owned columns, the force of the others comes from their owners
+    double *wown = nullptr;
+    std::vector<int> gcol;
+    std::vector<double> wown_host;
+    int ngcol = 0;
     // optional generator for the random inputs the caller leaves NULL (elph_hmc_set_rng)
     bool rng_on = false;
     uint64_t rng_seed = 0, rng_batches = 0;
@@ -237,11 +243,12 @@ __global__ void __launch_bounds__(TPB) k_mask_cols(double *__restrict__ F, const
 // a sharded lattice (shard.hip: elph_shard_set_collectives): sums count this rank's own columns and are added over the ranks
 bool sharded(const elph_handle_s *h) { return h->shard != nullptr && elph_i_shard_active(h); }
 
-int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, long long n, int count, double *out) {
+int dots_host(elph_handle_s *h, HmcState *st, const double *a, const double *b, long long n, int count, double *out, bool site_vectors = true) {
     const int nb = (int)h->L;
     const long long per = (n + nb - 1) / nb;
     int ncols = 0, clo = 0, chi = 0;
-    if (sharded(h)) { ncols = (int)(n / h->L); elph_i_shard_own_range(h, &clo, &chi); }
+    // a shard: site vectors count the own rows; field vectors of the Holstein model are site vectors; bond-phonon fields were masked by the caller
+    if (sharded(h) && (site_vectors || !st->wown)) { ncols = (int)(n / h->L); elph_i_shard_own_range(h, &clo, &chi); }
     hipLaunchKernelGGL(k_hmc_dot_part, dim3((unsigned)nb, (unsigned)count), dim3(TPB), 0, h->stream, st->part, a, b, n, per, ncols, clo, chi);
     RC(chk("k_hmc_dot_part"));
     std::vector<double> p((size_t)nb * count);
@@ -266,9 +273,10 @@ int alias_sum(elph_handle_s *h, HmcState *st, double *F) {
 int calc_Sb(elph_handle_s *h, HmcState *st, double *out) {
     const int L = (int)h->L, nch = st->nch;
     int clo = 0, chi = 1 << 30;
-    if (sharded(h)) elph_i_shard_own_range(h, &clo, &chi);
+    if (sharded(h) && !st->wown) elph_i_shard_own_range(h, &clo, &chi);
+    const double *w = st->wown ? st->wown : (st->shared ? st->wcol : nullptr);      // (bond phonons on a shard: the owned columns)
     hipLaunchKernelGGL(k_hmc_sb_part, dim3((unsigned)L, (unsigned)nch), dim3(TPB), 0, h->stream, st->part, st->x, st->par, st->nf, L,
-                       st->dtau, (const double *)(st->shared ? st->wcol : nullptr), clo, chi);
+                       st->dtau, w, clo, chi);
     RC(chk("k_hmc_sb_part"));
     std::vector<double> p((size_t)L * nch);
     HIPCHK(hipMemcpyAsync(p.data(), st->part, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
@@ -351,12 +359,12 @@ int calc_H(elph_handle_s *h, HmcState *st, double *H, double *S, double *K) {
     RC(dots_host(h, st, h->d_b, h->d_x, (long long)h->ndim, 2 * nch, sf.data()));
     RC(calc_Sb(h, st, sb.data()));
     RC(fa(h, st, st->y, st->v, 1.0));
-    if (st->shared) {       // calc_K of the SSH model counts primary fields only (HMC.jl:720-738)
+    if (st->shared || st->wown) {       // calc_K of the SSH model counts primary fields only (HMC.jl:720-738); on a shard: the owned columns
         const long long nn = (long long)st->nf * h->L * nch;
-        hipLaunchKernelGGL(k_mask_cols, dim3(nblk(nn)), dim3(TPB), 0, h->stream, st->y, (const double *)st->wcol, st->nf, nn);
+        hipLaunchKernelGGL(k_mask_cols, dim3(nblk(nn)), dim3(TPB), 0, h->stream, st->y, (const double *)(st->wown ? st->wown : st->wcol), st->nf, nn);
         RC(chk("k_mask_cols"));
     }
-    RC(dots_host(h, st, st->v, st->y, (long long)st->nf * h->L, nch, k.data()));
+    RC(dots_host(h, st, st->v, st->y, (long long)st->nf * h->L, nch, k.data(), false));
     for (int c = 0; c < nch; ++c) {
         S[c] = (sf[(size_t)c] + sf[(size_t)nch + c]) / 2 + sb[(size_t)c];
         K[c] = k[(size_t)c] / 2;
@@ -378,7 +386,8 @@ int force(elph_handle_s *h, HmcState *st, bool with_Sb) {
     // a sharded lattice: the fermion force is exact on the own rows (the MᵀM closure); the ghost rows — which the leapfrog moves along with
     // the own ones, so that the next update_model! sees the whole slab — take it from their owners.  The boson force and the Fourier
     // acceleration below are pointwise in the site index.
-    if (sharded(h)) RC(elph_i_shard_ghost_sync(h, st->dS, 1));
+    if (sharded(h) && st->ssh) RC(elph_i_shard_ghost_sync_cols(h, st->dS, 1, st->nf, st->gcol.data(), st->ngcol, st->wown_host.data()));
+    else if (sharded(h)) RC(elph_i_shard_ghost_sync(h, st->dS, 1));
     if (with_Sb) {
         hipLaunchKernelGGL(k_hmc_dsb, dim3(nblk(n)), dim3(TPB), 0, h->stream, st->dS, st->x, st->par, st->nf, (int)h->L, st->dtau, 1,
                            st->nch);
@@ -468,6 +477,7 @@ void elph_hmc_free(elph_handle_s *h) {
     if (st->prim) (void)hipFree(st->prim);
     if (st->next) (void)hipFree(st->next);
     if (st->wcol) (void)hipFree(st->wcol);
+    if (st->wown) (void)hipFree(st->wown);
     delete st;
     h->hmc = nullptr;
 }
@@ -679,6 +689,32 @@ extern "C" int elph_hmc_set_shared_fields(elph_handle h, const int64_t *primary_
     return ELPH_OK;
 }
 
+// Bond phonons on a sharded lattice: the slab's phonon columns (the phonons of its bonds, ghost bonds included) in the numbering of the whole
+// lattice, and which of them this rank owns (the bond's first site lies in the own rows: every phonon has exactly one owner).  Call after
+// elph_hmc_create_ssh on the slab handle.  Sums over fields (S_b, K) then count owned columns and are added over the ranks; the fermion
+// force — exact on the owner, where the bond bracket is — reaches the other holders of a column through the host all-reduce.
+extern "C" int elph_shard_hmc_set_columns(elph_handle h, const int64_t *global_column, int64_t n_global_columns, const double *own_weight) {
+    CHECK_H(h);
+    HmcState *st = state_of(h);
+    if (!st || !st->ssh) { elph_set_error("elph_hmc_create_ssh has not been called"); return ELPH_E_STATE; }
+    if (!h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
+    if (!global_column || !own_weight || n_global_columns < st->nf) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    st->gcol.assign((size_t)st->nf, 0);
+    st->wown_host.assign((size_t)st->nf, 0.0);
+    for (int c = 0; c < st->nf; ++c) {
+        if (global_column[c] < 0 || global_column[c] >= n_global_columns || !(own_weight[c] == 0.0 || own_weight[c] == 1.0)) {
+            elph_set_error("column %d: global column %lld of %lld, weight %g", c, (long long)global_column[c], (long long)n_global_columns, own_weight[c]);
+            return ELPH_E_ARG;
+        }
+        st->gcol[(size_t)c] = (int)global_column[c];
+        st->wown_host[(size_t)c] = own_weight[c];
+    }
+    st->ngcol = (int)n_global_columns;
+    if (!st->wown) HIPCHK(hipMalloc((void **)&st->wown, (size_t)st->nf * sizeof(double)));
+    HIPCHK(hipMemcpy(st->wown, st->wown_host.data(), (size_t)st->nf * sizeof(double), hipMemcpyHostToDevice));
+    return ELPH_OK;
+}
+
 extern "C" int elph_hmc_set_rng(elph_handle h, uint64_t seed) {
     CHECK_H(h);
     HmcState *st = state_of(h);
@@ -717,8 +753,9 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     if (sharded(h)) {
         // one lattice over several ranks: the trajectory runs on the slab (own + ghost rows); the random vectors must be the slab's part
         // of the GLOBAL vectors (ghost entries included) and the uniform of the Metropolis test the same number on every rank
-        if (st->ssh || nch != 1 || use_precond || st->rng_on || !R || !Rp || !Rm || !u_accept) {
-            elph_set_error("HMC on a sharded lattice: Holstein, one chain, un-preconditioned, with R, Rp, Rm and u_accept given (the slab's part of the global vectors)");
+        if ((st->ssh && (!st->wown || st->shared)) || nch != 1 || use_precond || st->rng_on || !R || !Rp || !Rm || !u_accept) {
+            elph_set_error("HMC on a sharded lattice: one chain, un-preconditioned, with R, Rp, Rm and u_accept given (the slab's part of the global "
+                           "vectors); bond phonons after elph_shard_hmc_set_columns, without shared fields");
             return ELPH_E_UNSUPPORTED;
         }
     }

@@ -735,6 +735,31 @@ int elph_i_shard_ghost_sync(elph_handle_s *h, double *vecS, int nvec) {
     return ELPH_OK;
 }
 
+// The same for vectors whose columns are not sites (bond-phonon fields): gcol[c] = the column's number on the whole lattice, own[c] = 1 when
+// this rank owns it; owned columns are contributed, the others taken from the sum.
+int elph_i_shard_ghost_sync_cols(elph_handle_s *h, double *vecS, int nvec, int ncols, const int *gcol, int ngcol, const double *own) {
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (S->ctl.P == 1) return ELPH_OK;
+    const size_t N = (size_t)ncols, L = (size_t)h->L, NG = (size_t)ngcol;
+    std::vector<double> loc(N * L * (size_t)nvec), glob(NG * L * (size_t)nvec, 0.0);
+    HIPCHK(hipMemcpyAsync(loc.data(), vecS, loc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t v = 0; v < (size_t)nvec; ++v)
+        for (size_t t = 0; t < L; ++t)
+            for (size_t c = 0; c < N; ++c)
+                if (own[c] != 0.0) glob[(v * L + t) * NG + (size_t)gcol[c]] = loc[(v * L + t) * N + c];
+    int rc = elph_i_shard_allreduce(h, glob.data(), (int)glob.size());
+    if (rc) return rc;
+    for (size_t v = 0; v < (size_t)nvec; ++v)
+        for (size_t t = 0; t < L; ++t)
+            for (size_t c = 0; c < N; ++c)
+                if (own[c] == 0.0) loc[(v * L + t) * N + c] = glob[(v * L + t) * NG + (size_t)gcol[c]];
+    HIPCHK(hipMemcpyAsync(vecS, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ELPH_OK;
+}
+
 // partial sums over the OWN sites of one slice each: part[0][t] = sum (a - b)^2, part[1][t] = sum b^2
 __global__ void __launch_bounds__(64) k_shard_resid_own(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ part,
                                                         int N, int L, int lo, int hi) {

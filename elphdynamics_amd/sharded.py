@@ -367,6 +367,24 @@ class ShardedSolver:
         assert not np.isnan(out).any(), "a bond without an owner"
         return out, int(it.value), int(fl.value)
 
+    def ssh_phonon_columns(self, checkerboard_perm, phonon_to_bond):
+        """The slab's phonon columns for a bond-phonon model: (global phonon index of every local column, its local checkerboard position
+        1-based, owned 1.0 / 0.0).  A slab holds the phonons of its bonds, ghost bonds included; the owner of a phonon is the owner of its
+        bond (`owned_bonds`)."""
+        cbp = np.asarray(checkerboard_perm, dtype=np.int64)              # raw bond (1-based index - 1) -> checkerboard position (1-based)
+        p2b = np.asarray(phonon_to_bond, dtype=np.int64)
+        pos_of_phonon = cbp[p2b - 1] - 1                                  # global checkerboard position (0-based) of every phonon's bond
+        phonon_at = -np.ones(len(self._full[0]), dtype=np.int64)
+        phonon_at[pos_of_phonon] = np.arange(len(p2b))
+        own = np.zeros(len(self.bonds), dtype=bool)
+        own[self.owned_bonds()] = True
+        gcol, cbl, w = [], [], []
+        for k, gb in enumerate(np.asarray(self.bonds)):
+            ph = phonon_at[gb]
+            if ph >= 0:
+                gcol.append(int(ph)); cbl.append(k + 1); w.append(1.0 if own[k] else 0.0)
+        return np.asarray(gcol, dtype=np.int64), np.asarray(cbl, dtype=np.int64), np.asarray(w, dtype=np.float64)
+
     def iterate(self, b_global, k):
         """Exactly k iterations (no stop test); returns this rank's HIP-event time of the launch in ms (bench.py)."""
         b = self._local(b_global)

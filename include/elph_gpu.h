@@ -521,6 +521,14 @@ int elph_shard_fermion_force_holstein(elph_handle h, elph_handle hfull, const do
 int elph_shard_fermion_force_ssh(elph_handle h, elph_handle hfull, const double *rhs_plus, const double *rhs_minus, int use_precond,
                                  double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
 
+/* elph_hmc_update on a SHARDED handle (elph_hmc_create / elph_hmc_create_ssh + elph_hmc_set_state on the slab handle, collectives set): one HMC
+ * update of the whole lattice over the ranks — one chain, un-preconditioned; R, Rp, Rm and every per-site / per-phonon array are the slab's
+ * part of the global ones (ghost entries included), u_accept the same number on every rank.  Bond phonons additionally need the slab's phonon
+ * columns in the numbering of the whole lattice and their owners (the phonons of the slab's bonds; owner = the rank whose own rows hold the
+ * bond's first site): global_column[nph_slab], own_weight[nph_slab] in {0, 1}; the state vectors of elph_hmc_set_state / _get_state are then
+ * double[nph_slab * Ltau] in that column order. */
+int elph_shard_hmc_set_columns(elph_handle h, const int64_t *global_column, int64_t n_global_columns, const double *own_weight);
+
 /* ---------------------------------------------------------------- health of the resident kernels */
 
 /* The whole-solve-in-one-launch kernels (cg_wg.hip) wait for their team members with a wall-clock bound (ELPH_WG_TIMEOUT_MS, 2 s); a

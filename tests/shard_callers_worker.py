@@ -50,10 +50,16 @@ def run_rank(comm, what, tag, out):
     rnd = dict(R=synth.randn(500, Ndof), Rp=synth.randn(501, Ndim), Rm=synth.randn(502, Ndim), u=0.0)
     if what == "hmc":
         m.solver.tol = 1e-10
+        if kind != "holstein" and getattr(m, "omega4", None) is None:
+            m.omega4 = np.zeros(m.Nph)
         m.omega4[:] = 0.02
         fa = pc.FourierAccelerator(m)
         pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
         omega, omega4, faM = m.omega.copy(), m.omega4.copy(), np.array(fa.M)
+        if kind != "holstein":
+            x0 = m.x.copy()
+            ssh = dict(cbperm=np.array(m.checkerboard_perm), p2b=np.array(m.phonon_to_bond), t=np.array(m.t), alpha=np.array(m.alpha),
+                       alpha2=np.array(m.alpha2), t_bare_cb=np.array(m.t_bare_cb), mu=np.array(m.mu), Nph=m.Nph)
     if ref0 and what == "ldiv":
         xr = np.zeros(Ndim)
         itr, rsr, flr = models.ldiv_(xr, m, np.ascontiguousarray(b))
@@ -99,7 +105,7 @@ def run_rank(comm, what, tag, out):
     elif what == "force":
         q, it, fl = S.fermion_force_ssh(bp, bm, Nb)
         res.update(q=q, it=it, flag=fl)
-    elif what == "hmc":
+    elif what == "hmc" and kind == "holstein":
         S.set_solver(1e-10, 20000)
         d = _lib.dptr
         site = lambda a: np.ascontiguousarray(np.asarray(a)[S.gsites])       # noqa: E731
@@ -113,6 +119,35 @@ def run_rank(comm, what, tag, out):
         xs, vs = np.zeros(S.Nloc * Ltau), np.zeros(S.Nloc * Ltau)
         _lib.check(lib.elph_hmc_get_state(S.h, d(xs), d(vs)))
         res.update(accepted=acc.value, flag=fl.value, iters=its.value, energies=en, x=S._gather_own(xs), v=S._gather_own(vs))
+    elif what == "hmc":
+        # bond phonons (BASELINE config 5): the slab's phonon columns = the phonons of its bonds; per-phonon arrays in that order
+        S.set_solver(1e-10, 20000)
+        d, ip = _lib.dptr, _lib.iptr
+        S.install_collectives()
+        gcol, cbl, wown = S.ssh_phonon_columns(ssh["cbperm"], ssh["p2b"])
+        nphl = len(gcol)
+        col = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64)[gcol])                                   # noqa: E731
+        fld = lambda a: np.ascontiguousarray(np.asarray(a).reshape(ssh["Nph"], Ltau)[gcol]).reshape(-1)               # noqa: E731
+        t_ph = np.ascontiguousarray(ssh["t"][ssh["p2b"] - 1][gcol])
+        t_bare_loc = np.ascontiguousarray(ssh["t_bare_cb"][np.asarray(S.bonds)])
+        _lib.check(lib.elph_hmc_create_ssh(S.h, nphl, d(col(omega)), d(col(omega4)), ip(np.ascontiguousarray(cbl)), d(t_ph), d(col(ssh["alpha"])),
+                                           d(col(ssh["alpha2"])), d(t_bare_loc), d(np.ascontiguousarray(ssh["mu"][S.gsites])), dtau, d(fld(faM))))
+        _lib.check(lib.elph_shard_hmc_set_columns(S.h, ip(np.ascontiguousarray(gcol)), ssh["Nph"], d(wown)))
+        _lib.check(lib.elph_hmc_set_state(S.h, d(fld(x0)), d(np.zeros(nphl * Ltau))))
+        acc, fl, its, en = C.c_int(), C.c_int(), C.c_double(), np.zeros(5)
+        _lib.check(lib.elph_hmc_update(S.h, dt, nt, nb, 0.0, 0, d(fld(rnd["R"])), d(S._local(rnd["Rp"])), d(S._local(rnd["Rm"])), None, rnd["u"],
+                                       C.byref(acc), C.byref(its), d(en), C.byref(fl)))
+        xs, vs = np.zeros(nphl * Ltau), np.zeros(nphl * Ltau)
+        _lib.check(lib.elph_hmc_get_state(S.h, d(xs), d(vs)))
+        # the owned columns of every rank -> the field on the whole lattice
+        mine = (gcol[wown == 1.0], xs.reshape(nphl, Ltau)[wown == 1.0], vs.reshape(nphl, Ltau)[wown == 1.0])
+        parts = comm.allgather_object(mine) if comm.world > 1 else [mine]
+        xg, vg = np.full((ssh["Nph"], Ltau), np.nan), np.full((ssh["Nph"], Ltau), np.nan)
+        for g_, x_, v_ in parts:
+            assert np.isnan(xg[g_]).all(), "a phonon with two owners"
+            xg[g_], vg[g_] = x_, v_
+        assert not np.isnan(xg).any(), "a phonon without an owner"
+        res.update(accepted=acc.value, flag=fl.value, iters=its.value, energies=en, x=xg.reshape(-1), v=vg.reshape(-1))
     S.close()
     np.savez(out + f".rank{comm.rank}", **res)
     comm.close()

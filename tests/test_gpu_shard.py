@@ -277,12 +277,29 @@ def test_sharded_fermion_force_vs_one_handle(tmp_path, tag, world, per_proc):
         assert _rel(a["Xp"], a["Xp_ref"]) < 1e-10 and _rel(a["Xm"], a["Xm_ref"]) < 1e-10
 
 
-@pytest.mark.parametrize("world,nb", [(2, 1), (4, 1), (2, 3)])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_hmc_update_bond_phonons_vs_one_handle(tmp_path, world):
+    """BASELINE config 5 (optical SSH, L = 16, Ntau = 160): one HMC update on a lattice sharded over 2 / 4 ranks — the slab's phonon columns are
+    the phonons of its bonds (ghost bonds included), update_model! of the hoppings on the device per slab, the bond-bracket force exact on
+    the owner of a bond and handed to the other holders, S_b and K over owned columns — against the update of ONE handle."""
+    res = _run_callers("hmc", "E", tmp_path, world, per_proc=2 if world == 8 else 1)      # (eight ranks: four processes of two rank threads)
+    a = res[0]
+    for b in res[1:]:
+        assert int(b["accepted"]) == int(a["accepted"]) and np.array_equal(a["energies"], b["energies"]) and np.array_equal(a["x"], b["x"])
+    assert int(a["accepted"]) == int(a["accepted_ref"]) == 1 and int(a["flag"]) == int(a["flag_ref"]) == 0
+    e, er = a["energies"], a["energies_ref"]
+    assert abs(e[0] - er[0]) < 1e-9 * abs(er[0]) and abs(e[1] - er[1]) < 1e-8 * abs(er[1])
+    assert abs(e[2] - er[2]) < 1e-8 * abs(er[2]) and abs(e[3] - er[3]) < 1e-8 * abs(er[3])
+    assert _rel(a["x"], a["x_ref"]) < 1e-9 and _rel(a["v"], a["v_ref"]) < 1e-8
+    assert abs(float(a["iters"]) - float(a["iters_ref"])) <= 1
+
+
+@pytest.mark.parametrize("world,nb", [(2, 1), (4, 1), (2, 3), (8, 1)])
 def test_sharded_hmc_update_vs_one_handle(tmp_path, world, nb):
     """One HMC update of BASELINE config 4 (Holstein honeycomb L = 12, Ntau = 120) on a lattice sharded over 2 / 4 ranks —
     elph_hmc_update on the slab handle: sharded solves, own-row energies summed over the ranks, ghost rows of ϕ± and of the fermion force
     from their owners — against the update of ONE handle with the same random numbers: same decision, H, S, K and the field to 1e-9."""
-    res = _run_callers("hmc", "D", tmp_path, world, extra_env={"ELPH_TEST_NB": str(nb)})
+    res = _run_callers("hmc", "D", tmp_path, world, per_proc=2 if world == 8 else 1, extra_env={"ELPH_TEST_NB": str(nb)})
     a = res[0]
     for b in res[1:]:
         assert int(b["accepted"]) == int(a["accepted"]) and np.array_equal(a["energies"], b["energies"]) and np.array_equal(a["x"], b["x"])
