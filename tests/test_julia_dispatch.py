@@ -303,3 +303,66 @@ def test_block_keywords_balance(code):
 def test_integration_doc_names_the_binding_as_it_is():
     txt = open(os.path.join(ROOT, "INTEGRATION.md"), encoding="utf-8").read()
     assert "ElPhGPU.attach!(model)" in txt and "GPUHolsteinModel" not in txt
+
+
+# ---- field accesses: every `x.field` the binding writes on a reference object names a field that object's struct declares ---------------
+
+IDENT = r"[\w′″‴⁻₊₋!]+"
+
+
+def _struct_fields(path, name):
+    """Field names of `[mutable] struct name … end` in a reference source file (lines `    field::Type`, inner constructors skipped)."""
+    src = open(path, encoding="utf-8").read()
+    m = re.search(r"^(?:mutable\s+)?struct\s+" + re.escape(name) + r"\b[^\n]*\n", src, re.M)
+    assert m, (path, name)
+    fields, depth = [], 0
+    for line in src[m.end():].split("\n"):
+        st = line.strip()
+        if st.startswith('"') or st.startswith("#") or not st:
+            continue
+        if re.match(r"^function\b", st):
+            depth += 1
+        if depth == 0:
+            f = re.match(r"^(" + IDENT + r")::", st)
+            if f:
+                fields.append(f.group(1))
+            elif st == "end":
+                break
+        elif re.match(r"^end\b", st) and line.startswith("    end"):
+            depth -= 1
+    return set(fields)
+
+
+def test_every_field_the_binding_touches_exists_in_the_reference(code):
+    """The binding has never been executed: a mistyped field name would only show in Julia.  Here every `var.field` on a variable that holds
+    a reference object (by the naming convention of the file: m / model, hmc, op, P, fa, cg, and `.solver`) is looked up in the struct
+    definitions of the reference's sources."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference sources not on this machine")
+    j = lambda f: os.path.join(REF, f)      # noqa: E731
+    model = _struct_fields(j("HolsteinModels.jl"), "HolsteinModel") | _struct_fields(j("SSHModels.jl"), "SSHModel")
+    fields = {
+        "m": model, "model": model,
+        "hmc": _struct_fields(j("HMC.jl"), "HybridMonteCarlo"),
+        "op": _struct_fields(j("KPMPreconditioners.jl"), "KPMExpansion"),
+        "P": _struct_fields(j("KPMPreconditioners.jl"), "SymmetricKPMPreconditioner"),
+        "fa": _struct_fields(j("FourierAcceleration.jl"), "FourierAccelerator"),
+        "cg": _struct_fields(j("IterativeSolvers.jl"), "ConjugateGradient"),
+    }
+    assert {"x", "expnΔτV", "cosht", "neighbor_table", "solver", "rng", "v′", "primary_field", "inv_checkerboard_perm", "bond_to_phonon"} <= model
+    assert {"Λϕ₊", "O⁻¹Λϕ₋", "ϕ₊", "iters"} <= fields["hmc"] and {"λ_lo", "order", "model", "n", "buf", "c1", "c2", "active"} <= fields["op"]
+    seen = 0
+    for mm in re.finditer(r"(?<![\w.′″‴])(m|model|hmc|op|P|fa|cg)\.(" + IDENT + r")", code):
+        var, f = mm.group(1), mm.group(2)
+        if code[mm.end():mm.end() + 1] == "(":      # a qualified function call (none expected), not a field
+            continue
+        assert f in fields[var], f"{var}.{f} (line {code.count(chr(10), 0, mm.start()) + 1}): no such field in the reference's struct"
+        seen += 1
+    for mm in re.finditer(r"\.solver\.(" + IDENT + r")", code):
+        assert mm.group(1) in fields["cg"], mm.group(0)
+        seen += 1
+    assert seen > 80
+    # the binding's own registry entry: every e.field is a field of `mutable struct Entry`
+    ent = set(re.findall(r"^\s+(" + IDENT + r")::", code[code.index("mutable struct Entry"):code.index("const REGISTRY")], re.M))
+    for mm in re.finditer(r"(?<![\w.])e\.(" + IDENT + r")", code):
+        assert mm.group(1) in ent | {"code", "msg"}, mm.group(0)      # (e::ElphError in showerror)
