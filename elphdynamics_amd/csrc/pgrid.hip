@@ -17,7 +17,7 @@
 
 namespace {
 
-using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>;
+using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>; using SQ2A = pgrid::Sq<2, 10>;
 using TR22 = pgrid::Tri<2, 2>; using TR24 = pgrid::Tri<2, 4>; using TR26 = pgrid::Tri<2, 6>; using TR44 = pgrid::Tri<4, 4>;
 using HC32 = pgrid::Hc<3, 2>; using HC42 = pgrid::Hc<4, 2>; using HC33 = pgrid::Hc<3, 3>;
 
@@ -404,6 +404,7 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
     if (h->pg_kind == 1 && px == 4 && py == 4) PG_CHEB(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_CHEB(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_CHEB(SQ24);
+    else if (h->pg_kind == 1 && px == 2 && py == 10) PG_CHEB(SQ2A);
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_CHEB(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_CHEB(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_CHEB(HC33);
@@ -444,6 +445,7 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     if (h->pg_kind == 1 && px == 4 && py == 4) PG_AP(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_AP(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_AP(SQ24);
+    else if (h->pg_kind == 1 && px == 2 && py == 10) PG_AP(SQ2A);
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_AP(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_AP(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_AP(HC33);
@@ -476,6 +478,7 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
     if (h->pg_kind == 1 && px == 4 && py == 4) PG_MUL(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_MUL(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_MUL(SQ24);
+    else if (h->pg_kind == 1 && px == 2 && py == 10) PG_MUL(SQ2A);
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_MUL(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_MUL(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_MUL(HC33);

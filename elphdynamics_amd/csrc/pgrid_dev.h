@@ -265,6 +265,7 @@ inline bool pick_patch(int L, int *PX, int *PY) {
         case 32: case 28: *PX = 4; *PY = 4; return true;
         case 24: case 18: *PX = 2; *PY = 6; return true;
         case 20: *PX = 2; *PY = 4; return true;
+        case 30: *PX = 2; *PY = 10; return true;     // 15 x 3 lanes, 20 registers per vector (round 5)
         default: return false;
     }
 }

@@ -271,7 +271,7 @@ def _oracle_model(orc, m):
                           np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
 
 
-@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32"])
+@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "l30", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32"])
 def test_matvec_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models, synth
     m = configs.make_model(tag)
@@ -304,7 +304,7 @@ def test_matvec_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32"])
+@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "l30", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32"])
 def test_cg_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models
     m = configs.make_model(tag, tol=1e-5)
@@ -376,7 +376,7 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32"])
+@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32"])
 def test_kpm_vs_oracle(oracle, tag):
     """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle.  e / E: bond phonons — the
     expansion is built on the tau-means of the per-(tau, bond) hopping tables (update_A!, KPMPreconditioners.jl:355-381)."""
@@ -1060,7 +1060,7 @@ def test_kpm_register_exchange_recursion_equals_the_lds_recursion(tag, monkeypat
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["g", "G", "k", "j", "i", "K", "h", "h20", "h21", "h24", "H18", "u", "T", "t6", "t12", "t20", "t24", "t32"])
+@pytest.mark.parametrize("tag", ["g", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "u", "T", "t6", "t12", "t20", "t24", "t32"])
 def test_kpm_patch_recursion_equals_the_generic_recursion(tag, monkeypatch):
     """Even-L square lattices beyond 16 x 16 (L = 18, 20, 24, 28, 32) and honeycomb lattices beyond 16 x 16 cells (L = 18, 20, 21, 24): the
     Chebyshev recursion with a PX x PY patch of sites (cells) per lane (csrc/pgrid.hip) against the generic kernel's recursion through LDS (ELPH_NO_PG=1) — the same series, factored colours: P^-1 r to
