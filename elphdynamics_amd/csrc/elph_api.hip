@@ -1556,7 +1556,8 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     RC(kpm_reserve(h, nch));
     // update_A!  (KPMPreconditioners.jl:332-349 Holstein; :355-381 SSH)
     if (h->kind == ELPH_MODEL_HOLSTEIN) {
-        RC(elph_launch_ebar(h, nch));                    // (Ē stays on the device: the Arnoldi kernel and the apply read it there)
+        if (!h->ebar_external) RC(elph_launch_ebar(h, nch));      // (Ē stays on the device: the Arnoldi kernel and the apply read it there;
+                                                                  //  ebar_external: d_Ebar was filled by the caller — elph_i_kpm_setup_ebar)
         h->h_cbar = h->h_c;
         h->h_sbar = h->h_s;
         h->kpm_hop_per_chain = false;
@@ -1726,6 +1727,22 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
     }
     h->kpm_ready = true;
     return ELPH_OK;
+}
+
+// setup!(P) of a Holstein handle whose τ-averaged exp(−ΔτV) comes from OUTSIDE: the full-lattice handle of a sharded HMC update holds no
+// field of its own — every rank contributes the Ē of its own rows and the sum is injected here (hmc.hip).  One chain.
+int elph_i_kpm_setup_ebar(elph_handle_s *h, const double *Ebar_host, const double *b_max, const double *b_min) {
+    if (h->kind != ELPH_MODEL_HOLSTEIN || !h->kpm_created) { elph_set_error("Ē injection: a Holstein handle with elph_kpm_create done"); return ELPH_E_STATE; }
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }
+    RC(kpm_reserve(h, 1));
+    HIPCHK(hipMemcpy(h->d_Ebar, Ebar_host, sizeof(double) * (size_t)h->N, hipMemcpyHostToDevice));
+    const bool had_E = h->have_E;
+    h->have_E = true;                  // (the expansion needs Ē and the hopping only; this handle never multiplies by M)
+    h->ebar_external = true;
+    const int rc = kpm_setup_core(h, b_max, b_min, nullptr, nullptr, nullptr, nullptr, nullptr);
+    h->ebar_external = false;
+    h->have_E = had_E;
+    return rc;
 }
 
 extern "C" int elph_kpm_setup(elph_handle h, const double *b_max, const double *b_min, double e_min, double e_max,

@@ -203,6 +203,7 @@ struct elph_handle_s {
     hipStream_t stream2 = nullptr;         // second stream + event of the two-half-batches form of a preconditioned batch (elph_api.hip: SplitRun)
     hipEvent_t split_ev = nullptr;
     int T_rhs_hint = 0;                    // > 0: right-hand sides in flight when the slices per wave are chosen (two-stream batches: both halves)
+    bool ebar_external = false;            // kpm_setup_core: d_Ebar was filled by the caller (elph_i_kpm_setup_ebar)
     bool px_solve = false;                 // the current solve's preconditioned iteration is p/x-fused (kernels.hip: px_plan)
     // SSH update_model! on the device (elph_update_model_ssh_fields): staging of x, per-phonon tables, slot map
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
@@ -354,6 +355,9 @@ int elph_i_shard_allreduce(elph_handle_s *h, double *buf, int n);
 int elph_i_shard_ghost_sync(elph_handle_s *h, double *vecS, int nvec);
 int elph_i_shard_ghost_sync_cols(elph_handle_s *h, double *vecS, int nvec, int ncols, const int *gcol, int ngcol, const double *own);
 int elph_i_shard_ldiv_dev(elph_handle_s *h, elph_handle_s *hfull, int use_prec, int64_t maxiter, int64_t *iters, double *resid, int *flag);
+int elph_i_kpm_setup_ebar(elph_handle_s *h, const double *Ebar_host, const double *b_max, const double *b_min);      // elph_api.hip
+elph_handle_s *elph_i_shard_full(const elph_handle_s *h);                  // the full-lattice handle registered with elph_shard_set_full_lattice (or nullptr)
+int elph_i_shard_global_ebar(elph_handle_s *h, std::vector<double> &Ebar_global);      // Ē of the whole lattice from every rank's own rows
 int elph_i_shard_solve_pair(elph_handle_s *h, elph_handle_s *hfull, int use_prec, double tol_power, int64_t *iters, int *flag);
 void elph_greens_free(elph_handle_s *h);
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec, int ncols = 0);

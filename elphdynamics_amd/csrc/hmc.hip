@@ -312,6 +312,21 @@ int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power,
     const size_t nd = (size_t)h->ndim;
     const int nch = st->nch;
     int use = 0;
+    if (use_precond && sharded(h)) {
+        // a sharded lattice: the expansion lives on the full-lattice handle (elph_shard_set_full_lattice), set up identically on every rank from
+        // the SAME start vectors (kpm_randn holds vectors of the whole lattice) and the Ē summed over the ranks' own rows
+        elph_handle_s *hf = elph_i_shard_full(h);
+        const size_t NG = (size_t)hf->N;
+        const double *bmax = kpm_randn + (size_t)(2 * *kpm_calls) * NG, *bmin = bmax + NG;
+        ++*kpm_calls;
+        std::vector<double> Eg;
+        RC(elph_i_shard_global_ebar(h, Eg));
+        RC(elph_i_kpm_setup_ebar(hf, Eg.data(), bmax, bmin));
+        RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
+        HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * (size_t)nch * nd * sizeof(double), h->stream));
+        h->x_zero = false;
+        return elph_i_shard_solve_pair(h, hf, 1, power, iters, flag);
+    }
     if (use_precond) {
         // start vectors of this set-up call: [b_max | b_min][chain][N]
         const double *bmax = kpm_randn + (size_t)(2 * *kpm_calls) * (size_t)nch * (size_t)h->N, *bmin = bmax + (size_t)nch * h->N;
@@ -748,14 +763,16 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
         elph_set_error("R, Rp, Rm, u_accept (and kpm_randn with a preconditioner) are required unless elph_hmc_set_rng was called");
         return ELPH_E_ARG;
     }
-    if (use_precond && !h->kpm_created) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
+    if (use_precond && !h->kpm_created && !sharded(h)) { elph_set_error("elph_kpm_create has not been called"); return ELPH_E_STATE; }
     const int nch = st->nch;
     if (sharded(h)) {
         // one lattice over several ranks: the trajectory runs on the slab (own + ghost rows); the random vectors must be the slab's part
         // of the GLOBAL vectors (ghost entries included) and the uniform of the Metropolis test the same number on every rank
-        if ((st->ssh && (!st->wown || st->shared)) || nch != 1 || use_precond || st->rng_on || !R || !Rp || !Rm || !u_accept) {
-            elph_set_error("HMC on a sharded lattice: one chain, un-preconditioned, with R, Rp, Rm and u_accept given (the slab's part of the global "
-                           "vectors); bond phonons after elph_shard_hmc_set_columns, without shared fields");
+        const bool prec_ok = !use_precond || (!st->ssh && elph_i_shard_full(h) && elph_i_shard_full(h)->kpm_created && kpm_randn);
+        if ((st->ssh && (!st->wown || st->shared)) || nch != 1 || !prec_ok || st->rng_on || !R || !Rp || !Rm || !u_accept) {
+            elph_set_error("HMC on a sharded lattice: one chain, with R, Rp, Rm and u_accept given (the slab's part of the global vectors); bond "
+                           "phonons after elph_shard_hmc_set_columns, without shared fields, un-preconditioned; a preconditioner (Holstein) needs "
+                           "elph_shard_set_full_lattice with elph_kpm_create done and kpm_randn = start vectors of the WHOLE lattice");
             return ELPH_E_UNSUPPORTED;
         }
     }

@@ -42,6 +42,7 @@ struct ShardState {
     elph_shard_allreduce_fn allreduce = nullptr;
     void *coll_ctx = nullptr;
     std::vector<int> gsites_host;             // [N_loc] global site of every slab site (host copy of d_gsites)
+    elph_handle_s *full = nullptr;            // the full-lattice handle of the preconditioned callers (elph_shard_set_full_lattice; not owned)
 };
 
 // mailbox layout (u64 words), identical on all ranks:
@@ -675,6 +676,22 @@ extern "C" int elph_shard_set_collectives(elph_handle h, elph_shard_barrier_fn b
     return ELPH_OK;
 }
 
+// The full-lattice handle that carries the KPM expansion for preconditioned solves inside elph_hmc_update on a sharded handle (the other
+// sharded callers take it as an argument).  elph_kpm_create must have been called on it; it needs no field of its own: every force evaluation
+// injects the τ-averaged exp(−ΔτV) of the whole lattice, summed over the ranks' own rows.
+extern "C" int elph_shard_set_full_lattice(elph_handle h, elph_handle hfull) {
+    if (!h || !h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
+    ShardState *S = static_cast<ShardState *>(h->shard);
+    if (hfull && (hfull->N != S->n_global || hfull->L != h->L || hfull->kind != h->kind)) { elph_set_error("the full-lattice handle does not match the shard's global geometry"); return ELPH_E_ARG; }
+    S->full = hfull;
+    return ELPH_OK;
+}
+
+elph_handle_s *elph_i_shard_full(const elph_handle_s *h) {
+    const ShardState *S = h ? static_cast<const ShardState *>(h->shard) : nullptr;
+    return S ? S->full : nullptr;
+}
+
 static ShardState *shard_callers(elph_handle_s *h) {
     ShardState *S = h ? static_cast<ShardState *>(h->shard) : nullptr;
     if (!S) { elph_set_error("elph_shard_create has not been called"); return nullptr; }
@@ -733,6 +750,32 @@ int elph_i_shard_ghost_sync(elph_handle_s *h, double *vecS, int nvec) {
     HIPCHK(hipMemcpyAsync(vecS, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return ELPH_OK;
+}
+
+// Ē = τ-mean of exp(−ΔτV) on the WHOLE lattice (update_A!, KPMPreconditioners.jl:332-349): every rank averages its own rows (the slab
+// handle's d_E), the ranks sum the disjoint pieces.
+__global__ void __launch_bounds__(64) k_shard_ebar_own(double *__restrict__ out, const double *__restrict__ E, int N, int L, int lo, int hi) {
+    const int s2 = lo + (int)(blockIdx.x * 64 + threadIdx.x);
+    if (s2 >= hi) return;
+    double a = 0.0;
+    for (int t = 0; t < L; ++t) a += E[(size_t)t * N + s2];
+    out[s2 - lo] = a / L;
+}
+
+int elph_i_shard_global_ebar(elph_handle_s *h, std::vector<double> &Eg) {
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (S->n_global <= 0) { elph_set_error("the shard was created without its global geometry"); return ELPH_E_STATE; }
+    const int lo = S->ctl.own_lo, hi = S->ctl.own_hi, n = hi - lo;
+    hipLaunchKernelGGL(k_shard_ebar_own, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_tmp, h->d_E, (int)h->N, (int)h->L, lo, hi);
+    int rc = launch_ok("k_shard_ebar_own");
+    if (rc) return rc;
+    std::vector<double> own((size_t)n);
+    HIPCHK(hipMemcpyAsync(own.data(), h->d_tmp, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    Eg.assign((size_t)S->n_global, 0.0);
+    for (int i = 0; i < n; ++i) Eg[(size_t)S->gsites_host[(size_t)(lo + i)]] = own[(size_t)i];
+    return elph_i_shard_allreduce(h, Eg.data(), (int)Eg.size());
 }
 
 // The same for vectors whose columns are not sites (bond-phonon fields): gcol[c] = the column's number on the whole lattice, own[c] = 1 when

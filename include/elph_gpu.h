@@ -528,6 +528,10 @@ int elph_shard_fermion_force_ssh(elph_handle h, elph_handle hfull, const double 
  * bond's first site): global_column[nph_slab], own_weight[nph_slab] in {0, 1}; the state vectors of elph_hmc_set_state / _get_state are then
  * double[nph_slab * Ltau] in that column order. */
 int elph_shard_hmc_set_columns(elph_handle h, const int64_t *global_column, int64_t n_global_columns, const double *own_weight);
+/* A KPM-preconditioned update on a sharded Holstein handle (use_precond = 1): hfull = a handle on the WHOLE lattice with elph_kpm_create done
+ * (it needs no field: every setup!(P) inside the update injects the τ-averaged exp(−ΔτV) of the whole lattice, summed over the ranks' own
+ * rows); kpm_randn of elph_hmc_update then holds the (nt + 2) pairs of Arnoldi start vectors of the WHOLE lattice, the same on every rank. */
+int elph_shard_set_full_lattice(elph_handle h, elph_handle hfull);
 
 /* ---------------------------------------------------------------- health of the resident kernels */
 

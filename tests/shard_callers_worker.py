@@ -48,6 +48,9 @@ def run_rank(comm, what, tag, out):
     bp, bm = synth.randn(61, Ndim), synth.randn(62, Ndim)
     dt, nt, nb = 0.05, 2, int(os.environ.get("ELPH_TEST_NB", "1"))
     rnd = dict(R=synth.randn(500, Ndof), Rp=synth.randn(501, Ndim), Rm=synth.randn(502, Ndim), u=0.0)
+    with_kpm = os.environ.get("ELPH_TEST_KPM") == "1"
+    if with_kpm:
+        rnd["kpm_randn"] = synth.randn(503, (nt + 2) * 2 * m.Nsites)
     if what == "hmc":
         m.solver.tol = 1e-10
         if kind != "holstein" and getattr(m, "omega4", None) is None:
@@ -76,7 +79,8 @@ def run_rank(comm, what, tag, out):
         res.update(q_ref=qr.reshape(Nb, Ltau), it_ref=itr.value, flag_ref=flr.value)
     elif ref0 and what == "hmc":
         H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt, alpha=0.0, Nb=nb)
-        a, i = hmc.update_(m, H, fa, None, randoms=rnd)
+        Pk = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0) if with_kpm else None
+        a, i = hmc.update_(m, H, fa, Pk, randoms=rnd)
         res.update(accepted_ref=int(a), iters_ref=i, flag_ref=H.flag, energies_ref=np.array([H.H0, H.H1, H.S, H.K, H.P_accept]), x_ref=m.x.copy(), v_ref=H.v.copy())
     m.close()
     comm.barrier()
@@ -113,9 +117,12 @@ def run_rank(comm, what, tag, out):
         # the sharded update: the slab's part of every global array
         _lib.check(lib.elph_hmc_create(S.h, d(site(omega)), d(site(omega4)), d(site(lam)), d(site(lam2)), d(site(mu)), dtau, d(S._local(faM))))
         _lib.check(lib.elph_hmc_set_state(S.h, d(S._local(x0)), d(np.zeros(S.Nloc * Ltau))))
+        if with_kpm:      # the expansion lives on a handle of the whole lattice (created by setup_kpm; its Ē is injected at every setup!(P))
+            S.setup_kpm(E, n=20, buf=0.05, c1=1.0, c2=1.0, seed=1)
+            _lib.check(lib.elph_shard_set_full_lattice(S.h, S.hf))
         acc, fl, its, en = C.c_int(), C.c_int(), C.c_double(), np.zeros(5)
-        _lib.check(lib.elph_hmc_update(S.h, dt, nt, nb, 0.0, 0, d(S._local(rnd["R"])), d(S._local(rnd["Rp"])), d(S._local(rnd["Rm"])), None, rnd["u"],
-                                       C.byref(acc), C.byref(its), d(en), C.byref(fl)))
+        _lib.check(lib.elph_hmc_update(S.h, dt, nt, nb, 0.0, 1 if with_kpm else 0, d(S._local(rnd["R"])), d(S._local(rnd["Rp"])), d(S._local(rnd["Rm"])),
+                                       d(rnd["kpm_randn"]) if with_kpm else None, rnd["u"], C.byref(acc), C.byref(its), d(en), C.byref(fl)))
         xs, vs = np.zeros(S.Nloc * Ltau), np.zeros(S.Nloc * Ltau)
         _lib.check(lib.elph_hmc_get_state(S.h, d(xs), d(vs)))
         res.update(accepted=acc.value, flag=fl.value, iters=its.value, energies=en, x=S._gather_own(xs), v=S._gather_own(vs))

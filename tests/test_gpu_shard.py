@@ -294,6 +294,22 @@ def test_sharded_hmc_update_bond_phonons_vs_one_handle(tmp_path, world):
     assert abs(float(a["iters"]) - float(a["iters_ref"])) <= 1
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hmc_update_with_the_kpm_preconditioner(tmp_path, world):
+    """The production shape of BASELINE config 4: every force / action evaluation of the sharded update solves with the KPM preconditioner —
+    the expansion on a handle of the whole lattice, set up at every setup!(P) from the SAME Arnoldi start vectors on every rank and the
+    τ-averaged exp(−ΔτV) summed over the ranks' own rows (elph_shard_set_full_lattice) — against the preconditioned update of ONE handle."""
+    res = _run_callers("hmc", "D", tmp_path, world, extra_env={"ELPH_TEST_KPM": "1"})
+    a = res[0]
+    for b in res[1:]:
+        assert int(b["accepted"]) == int(a["accepted"]) and np.array_equal(a["energies"], b["energies"]) and np.array_equal(a["x"], b["x"])
+    assert int(a["accepted"]) == int(a["accepted_ref"]) == 1 and int(a["flag"]) == int(a["flag_ref"]) == 0
+    e, er = a["energies"], a["energies_ref"]
+    assert abs(e[0] - er[0]) < 1e-9 * abs(er[0]) and abs(e[1] - er[1]) < 1e-8 * abs(er[1])
+    assert _rel(a["x"], a["x_ref"]) < 1e-9 and _rel(a["v"], a["v_ref"]) < 1e-8
+    assert abs(float(a["iters"]) - float(a["iters_ref"])) <= 1 and float(a["iters"]) < 100     # (preconditioned at tol 1e-10: 61 iterations per solve; plain: several hundred)
+
+
 @pytest.mark.parametrize("world,nb", [(2, 1), (4, 1), (2, 3), (8, 1)])
 def test_sharded_hmc_update_vs_one_handle(tmp_path, world, nb):
     """One HMC update of BASELINE config 4 (Holstein honeycomb L = 12, Ntau = 120) on a lattice sharded over 2 / 4 ranks —
