@@ -31,6 +31,7 @@
 #   setup!(P), ldiv!(z, P, r)                 KPMPreconditioners.jl:259-321,426-481  for P::SymmetricKPMPreconditioner of an attached model
 #   calc_O⁻¹Λϕ!(hmc, model, P, power)         HMC.jl:820-915: the two pseudofermion solves as ONE batch of two right-hand sides
 #   fourier_accelerate!(v′, fa, v, power)     FourierAcceleration.jl:131-137 for an accelerator registered with `attach!(fa, model)`
+#   update!(model, hmc, fa, P)                HMC.jl:307-337 — opt-in (`attach!(model, resident_hmc = true)`): the whole trajectory in one call
 #
 # Wiring in the reference (two lines; nothing else changes):
 #   src/ElPhDynamics.jl, after include("ProcessInputFile.jl"):                                    include("ElPhGPU.jl")
@@ -61,7 +62,7 @@ import ..KPMPreconditioners: setup!
 using ..FourierAcceleration: FourierAccelerator
 import ..FourierAcceleration: fourier_accelerate!
 using ..HMC: HybridMonteCarlo, update_Λ!, mulΛ!
-import ..HMC: calc_O⁻¹Λϕ!
+import ..HMC: calc_O⁻¹Λϕ!, update!
 
 export attach!, detach!, attached, pull!, ldiv_batched!, ElphError
 
@@ -109,6 +110,12 @@ mutable struct Entry
     t_bare_cb::Vector{Float64}          #   bare hopping of every bond, checkerboard order
     gpu_calls::Int                      # served on the device / handed to the reference's method — `status(model)`
     fallbacks::Int
+    resident_hmc::Bool                  # update!(model, hmc, fa, P): the whole trajectory on the device (elph_hmc_update)
+    hmc_fa::Any                         # the FourierAccelerator the device-side HMC state was created with (nothing: none yet)
+    hmc_Msum::Float64                   # checksums of fa.M and model.μ at that time: a change re-creates the state / pushes μ
+    hmc_μsum::Float64
+    kpm_randn::Vector{Float64}          # (Nt + 2) pairs of Arnoldi start vectors of one update
+    energies::Vector{Float64}           # H₀, H₁, S, K, P_accept of the last resident update
 end
 
 const REGISTRY = IdDict{Any,Entry}()
@@ -137,14 +144,15 @@ function create_handle(kind::Integer, N::Integer, Lτ::Integer, Nbonds::Integer,
 end
 
 """
-    attach!(model; device = 0, host_sync = true, batch_pseudofermions = true) -> model
+    attach!(model; device = 0, host_sync = true, batch_pseudofermions = true, resident_hmc = false) -> model
 
 Put the fermion matrix of an initialised model (`initialize_model!`, HolsteinModels.jl:484-517 / SSHModels.jl:348-505:
 `neighbor_table`, `cosht`, `sinht` in checkerboard order) on GPU `device` and route the operator API of this model there.  Throws
 `ElphError(ELPH_E_NOGPU)` when no gfx950 device is visible — the library has no CPU path; the reference's own methods are the CPU
-path and stay in force for every model that is not attached.  Attaching twice is a no-op.
+path and stay in force for every model that is not attached.  Attaching twice is a no-op.  `resident_hmc = true`: `update!(model, hmc, fa, P)`
+runs the whole trajectory on the device (see `update!` below for what that changes).
 """
-function attach!(model::GPUModel; device::Integer=0, host_sync::Bool=true, batch_pseudofermions::Bool=true)
+function attach!(model::GPUModel; device::Integer=0, host_sync::Bool=true, batch_pseudofermions::Bool=true, resident_hmc::Bool=false)
     attached(model) && return model
     N, Lτ, Nb = model.Nsites, model.Lτ, model.Nbonds
     if model isa HolsteinModel
@@ -161,7 +169,8 @@ function attach!(model::GPUModel; device::Integer=0, host_sync::Bool=true, batch
         end
     end
     e = Entry(h, host_sync, batch_pseudofermions, nothing, false, zeros(model.Ndim, 2), zeros(model.Ndim, 2),
-              zeros(Lτ, model isa SSHModel ? Nb : 0), zeros(N), zeros(N), cb_index, t_ph, t_bare_cb, 0, 0)
+              zeros(Lτ, model isa SSHModel ? Nb : 0), zeros(N), zeros(N), cb_index, t_ph, t_bare_cb, 0, 0,
+              resident_hmc, nothing, 0.0, 0.0, Float64[], zeros(5))
     REGISTRY[model] = e
     update_model!(model)
     return model
@@ -641,6 +650,102 @@ function calc_O⁻¹Λϕ!(hmc::HybridMonteCarlo{Float64}, model::GPUModel, preco
     end
     model.solver.tol = tol                                                # :912
     return hmc.iters, flag
+end
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# update!(model, hmc, fa, P) — HMC.jl:307-337 (standard_update! :343-463, multitimestep_update! :469-638) with the WHOLE trajectory in one
+# library call: x, v, ϕ±, O⁻¹Λϕ±, dS/dx stay on the device for its length.  Opt-in (`attach!(model, resident_hmc = true)`), because it is
+# the one method here that replaces caller code rather than an operator:
+#   * the random numbers are drawn from model.rng HERE, in the reference's order — R (refresh_v!, :655), R₊, R₋ (refresh_ϕ!, :675-676), one
+#     pair of Arnoldi start vectors per setup!(P) (KPMPreconditioners.jl:859-861, 902-904; Nt + 2 of them), the uniform of the Metropolis test
+#     (:441) — so a trajectory that is not killed consumes the stream exactly as a CPU run; a killed one (flag > 0) has drawn all Nt + 2 pairs
+#     where the reference stops early;
+#   * hmc.log / hmc.verbose (update_log) are not served: such an `hmc` takes the reference's method;
+#   * after the call model.x, hmc.v, hmc.accepted, hmc.H / .S / .K, hmc.iters, hmc.updates and the host copy of exp(−ΔτV) are current; the
+#     work vectors hmc.ϕ±, hmc.O⁻¹Λϕ±, hmc.dSdx are NOT (they live on the device).
+# ------------------------------------------------------------------------------------------------------------------------------
+
+"(re)create the device-side HMC state for this accelerator (elph_hmc_create / elph_hmc_create_ssh: ω, ω₄, couplings, μ, Δτ, fa.M)"
+function hmc_state!(e::Entry, m::GPUModel, fa::FourierAccelerator{Float64})
+    Msum = sum(fa.M)
+    if e.hmc_fa !== fa || e.hmc_Msum != Msum
+        if m isa HolsteinModel
+            chk(ccall((:elph_hmc_create, lib), Cint,
+                      (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+                      e.handle, m.ω, m.ω₄, m.λ, m.λ₂, m.μ, m.Δτ, fa.M))
+        else
+            chk(ccall((:elph_hmc_create_ssh, lib), Cint,
+                      (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+                      e.handle, m.Nph, m.ω, m.ω₄, e.cb_index, e.t_ph, m.α, m.α₂, e.t_bare_cb, m.μ, m.Δτ, fa.M))
+            if any(f -> m.primary_field[f] != f, 1:m.Ndof)      # phonon types of one name share their fields (SSHModels.jl:480-502)
+                prim = Int64[div(m.primary_field[(p - 1) * m.Lτ + 1] - 1, m.Lτ) for p in 1:m.Nph]      # 0-based primary column of every phonon
+                chk(ccall((:elph_hmc_set_shared_fields, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), e.handle, prim))
+            end
+        end
+        e.hmc_fa = fa; e.hmc_Msum = Msum; e.hmc_μsum = sum(m.μ)
+    elseif e.hmc_μsum != sum(m.μ)      # the chemical-potential tuner moved μ (MuFinder.jl:68-107)
+        chk(ccall((:elph_hmc_set_mu, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), e.handle, m.μ))
+        e.hmc_μsum = sum(m.μ)
+    end
+    return nothing
+end
+
+function update!(model::GPUModel, hmc::HybridMonteCarlo{Float64}, fa::FourierAccelerator{Float64}, preconditioner)::Tuple{Bool,Float64}
+    e = entry(model)
+    use_P = -1
+    if e !== nothing && e.resident_hmc && servable(model) && !hmc.log && hmc.Ndof > 0 &&
+       !(model isa HolsteinModel && !isempty(model.ωᵢⱼ))      # (dispersive modes: not on the device)
+        if preconditioner === I
+            use_P = 0
+        elseif preconditioner isa GPUSymmetricKPM && preconditioner.expansion.model === model && !preconditioner.transposed
+            op = preconditioner.expansion
+            if e.kpm !== op
+                chk(ccall((:elph_kpm_create, lib), Cint, (Ptr{Cvoid}, Cint, Float64, Float64, Float64), e.handle, op.n, op.buf, op.c1, op.c2))
+                e.kpm = op
+            end
+            use_P = 1
+        end
+    end
+    if use_P < 0
+        deferred!(e)
+        return invoke(update!, Tuple{AbstractModel{Float64,Float64},HybridMonteCarlo{Float64},FourierAccelerator{Float64},Any}, model, hmc, fa, preconditioner)
+    end
+    hmc_state!(e, model, fa)
+    push_solver!(e, model)
+    chk(ccall((:elph_hmc_set_state, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, model.x, hmc.v))
+    # the random numbers of one update, from model.rng in the reference's order
+    R = hmc.y
+    randn!(R, model)                                                      # refresh_v!, HMC.jl:655 (bond phonons: v[primary_field])
+    randn!(model.rng, hmc.R₊)                                             # refresh_ϕ!, :675-676
+    randn!(model.rng, hmc.R₋)
+    N, Nt = model.Nsites, hmc.Nt
+    if use_P == 1
+        length(e.kpm_randn) == 2 * N * (Nt + 2) || resize!(e.kpm_randn, 2 * N * (Nt + 2))
+        for k in 1:(2 * N * (Nt + 2))                                     # per setup!(P): N scalars for e_max, N for e_min
+            e.kpm_randn[k] = randn(model.rng, Float64)
+        end
+    end
+    u = rand(model.rng)                                                   # :441
+    acc = Ref{Cint}(0); its = Ref{Float64}(0.0); flag = Ref{Cint}(0)
+    chk(ccall((:elph_hmc_update, lib), Cint,
+              (Ptr{Cvoid}, Float64, Int64, Cint, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64,
+               Ref{Cint}, Ref{Float64}, Ptr{Float64}, Ref{Cint}),
+              e.handle, hmc.Δt, Nt, hmc.Nb, hmc.α, use_P, R, hmc.R₊, hmc.R₋, use_P == 1 ? pointer(e.kpm_randn) : Ptr{Float64}(C_NULL), u,
+              acc, its, e.energies, flag))
+    chk(ccall((:elph_hmc_get_state, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, model.x, hmc.v))
+    # the host copy of the matrix elements follows the field (the device rebuilt its own inside the update)
+    if model isa HolsteinModel
+        invoke(update_model!, Tuple{HolsteinModel}, model)
+    else
+        invoke(update_model!, Tuple{SSHModel}, model)
+    end
+    hmc.accepted = acc[] != 0
+    hmc.H = e.energies[2]; hmc.S = e.energies[3]; hmc.K = e.energies[4]
+    hmc.iters = round(Int, its[])
+    hmc.t = Nt                                                            # where `for hmc.t in 1:Nt` (:394, :535) leaves it
+    hmc.updates += 1                                                      # :329
+    served!(e)
+    return hmc.accepted, its[]
 end
 
 # ------------------------------------------------------------------------------------------------------------------------------

@@ -94,7 +94,7 @@ ABSTRACT_SPECIALISED = {
     "mulMᵀM!": ("Models.jl", 215), "mulMMᵀ!": ("Models.jl", 229),
     "ldiv!": ("Models.jl", 74), "solve!": ("IterativeSolvers.jl", 153),
     "setup!": ("KPMPreconditioners.jl", 259), "calc_O⁻¹Λϕ!": ("HMC.jl", 820),
-    "fourier_accelerate!": ("FourierAcceleration.jl", 131),
+    "fourier_accelerate!": ("FourierAcceleration.jl", 131), "update!": ("HMC.jl", 310),
 }
 
 
