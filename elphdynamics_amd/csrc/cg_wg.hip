@@ -701,10 +701,18 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             // at a time) into LDS; one of them also trades the team's records.
             constexpr int NSEG = 2 * NPL;
             const int rw = (W > NSEG) ? NSEG : ((W >= 3) ? 1 : 0);        // (a wave without a segment if there is one)
-            if (wv == rw) publish_rec4(slotsA, g, sum_part4(part, W, lane), epoch, lane);
             bool ok = true;
             double t4 = 0.0;
+#ifdef ELPH_WG_NOMEET
+            // diagnostic bound (tools/time_wg_nomeet.py, never the product): an iteration WITHOUT its meeting — no record, no poll, the
+            // workgroup's own sums taken for the team's, the boundary slices of z left as they are.  What any rearrangement of the
+            // meeting (a pipelined recurrence, XCD-local records) could reach at most; the numbers it computes mean nothing.
+            if (wv == rw) t4 = __shfl(sum_part4(part, W, lane), 8 * ((lane & 7) >> 1), WAVE);
+            for (int s0 = wv; false;) {
+#else
+            if (wv == rw) publish_rec4(slotsA, g, sum_part4(part, W, lane), epoch, lane);
             for (int s0 = wv; s0 < NSEG || (s0 == wv && wv == rw); s0 += 2 * W) {
+#endif
                 const int s1 = s0 + W;
                 const u64 *b0 = nullptr, *b1 = nullptr;
                 if (s0 < NSEG) b0 = bnd + ((((s0 < NPL) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane_b + (size_t)(s0 % NPL) * WAVE) * 2;
@@ -735,8 +743,13 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         }
         STAMP(1);
         rho = rr0;                                            // r.r of the residual this iteration started from, summed from the vector
+#ifdef ELPH_WG_NOMEET
+        const double alpha = 1e-6 * (rr0 / pap);              // (the workgroup's own sums are no CG: keep the vectors bounded — r almost constant, beta = 1/2 —
+        rr = 0.5 * rr0 + 1e-30 * fabs(rr0 + alpha * (alpha * zz - 2.0 * rz));      //  so that no NaN sends a workgroup into the direct-sum meeting)
+#else
         const double alpha = rr0 / pap;                                                            // :278-279 (rho = r.r)
         rr = rr0 + alpha * (alpha * zz - 2.0 * rz);
+#endif
         // ---- x += alpha p, r -= alpha z (own slices) ----------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < T; ++j)
@@ -981,8 +994,12 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         const long long it = seq + 1;
         const bool fixed = R.fixed_iters > 0;
         int done = 0;
+#ifdef ELPH_WG_NOMEET
+        const bool screened = it < R.fixed_iters;             // (the sums mean nothing: no stop arithmetic before the last iteration)
+#else
         const bool screened = !P.record_hist && it < (fixed ? R.fixed_iters : P.maxiter) && (fixed || rr > rr_far) &&
                               (rr + rr <= y_num || rr >= y_num + y_num) && (double)it < it_kappa;
+#endif
         if (!screened) {
             eps = sqrt(rr) / normb;
             const double qq = 2.0 * (double)it / log(2.0 * eps0 / eps);
