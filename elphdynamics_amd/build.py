@@ -18,7 +18,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("ELPH_LIB") or os.path.join(HERE, "libelphgpu.so")
-SOURCES = ["kernels.hip", "cg_fast.hip", "cg_fast6.hip", "cg_wg.hip", "pcg_wg.hip", "shard.hip", "pgrid.hip", "kpm_dev.hip", "dft.hip", "dft_mfma.hip", "dft_big.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
+SOURCES = ["kernels.hip", "cg_fast.hip", "cg_fast6.hip", "cg_wg.hip", "pcg_wg.hip", "shard.hip", "slabs.hip", "pgrid.hip", "kpm_dev.hip", "dft.hip", "dft_mfma.hip", "dft_big.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
 OBJDIR = os.path.join(HERE, "build")
 MANIFEST = os.path.join(OBJDIR, "manifest.json")
 ARCH = "gfx950"

@@ -47,8 +47,21 @@ __device__ unsigned long long g_wg_arrive[4096 * 4];
 //     form — any other honeycomb lattice up to 16 x 16 cells (1, 2 or 4 cells per lane on a grid of lanes; m.hc_L cells per side)
 // SHARD: this launch is one rank's part of a solve over several GPUs (T = 1, lane-program form)
 // X0Z: the initial guess is known to be zero (the library zeroed it for this solve): x0 is not read
-template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false>
+// RANKS (with SHARD): SEVERAL RANKS OF ONE SHARDED SOLVE IN ONE LAUNCH (the slabs of a lattice beyond one wave's slice on ONE GPU,
+// slabs.hip): rank q's G workgroups are the blocks q G .. q G + G - 1 and every rank's launch arguments — its slab's buffers, tables,
+// control block, mailboxes — come from memory (R.ranks).  The ranks wait for each other, so they must all be resident: one grid
+// guarantees what P streams do not (streams share the process's few hardware queues, and a queue runs its launches one after the other).
+struct WgRankArgs { CgBufs B; ModelDev m; WgCtl R; ShardCtl Sh; };
+template <int NPL, int T, bool SSH, bool UNI, int FORM, bool SHARD, bool X0Z = false, bool RANKS = false>
 __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, ShardCtl Sh) {
+    static_assert(!RANKS || SHARD, "several ranks per launch: sharded solves only");
+    unsigned bid = 0;
+    if constexpr (RANKS) {
+        const WgRankArgs *__restrict__ A = static_cast<const WgRankArgs *>(R.ranks);
+        const unsigned rk = blockIdx.x / (unsigned)R.G;
+        bid = blockIdx.x - rk * (unsigned)R.G;
+        B = A[rk].B; m = A[rk].m; Sh = A[rk].Sh; R = A[rk].R;
+    }
     constexpr bool SQ = FORM == 1, HC = FORM == 2, S8 = FORM == 4, TG = FORM == 7, GR = FORM == 5 || TG, HG = FORM == 6, REGX = FORM != 0;      // REGX: the checkerboard exchanges registers, no LDS slabs
     // (FORM 7, TG: an even-L TRIANGULAR lattice up to 16 x 16 in the GRID layout — the same 2 x 2 patches, the two diagonal colours of
     //  pgrid::Tri<2, 2> added to the sweep, c^6 where the square lattice takes c^4)
@@ -98,7 +111,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
     const int W = R.W, G = R.G;
     // (a shard: ONE right-hand side, its G workgroups are the whole grid, spread over the XCDs — several ranks on one GPU, the test
     //  box, would otherwise pile their teams onto the XCD where every dispatch starts: 2 x 20 workgroups do not fit its 32 CUs)
-    const int xcd = SHARD ? 0 : (blockIdx.x & 7), idx = SHARD ? blockIdx.x : (blockIdx.x >> 3);
+    const int xcd = SHARD ? 0 : (blockIdx.x & 7), idx = SHARD ? (RANKS ? bid : blockIdx.x) : (blockIdx.x >> 3);
     const int tq = idx / G, g = idx - tq * G;
     // PERSISTENT TEAMS (-DELPH_WG_PERSISTENT; not the default): the grid holds at most as many teams as the chip keeps resident
     // (R.teams_per_xcd per XCD, one workgroup per CU) and a team takes the right-hand sides tq, tq + teams, ... of its XCD's residue class
@@ -1486,8 +1499,10 @@ extern "C" int elph_debug_wg_stamps(unsigned long long *out16) {
 #endif
 
 // One rank's launch of a solve over several GPUs (shard.hip holds the mailbox and calls this).  x0 = 0, b in B.r and B.p.
-int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out) {
-    ModelDev m = elph_model_dev(h);
+// one rank's launch arguments of a sharded solve: form and team shape of its slab, control block (zeroed), tags
+static int shard_rank_setup(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, ModelDev &m, wg::Shape &sh,
+                            wg::WgCtl &R) {
+    m = elph_model_dev(h);
     // a slab whose rows the caller closed into a ring (a periodic rectangle in the reference's colouring: sharded.py, ring=True) runs a
     // register-exchange form — the own rows of z = M^T M p do not see the ring bond (it lies beyond the ghost rows' dependency closure)
     // (measured, profiles/r04/shard_ring_grid_forms_ab.log: the GRID form pays from three sites per lane of the lane program — a
@@ -1501,7 +1516,6 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
         elph_set_error("sharded solve: the slab needs a 4-colour lane program and <= 320 sites (N = %lld)", (long long)h->N);
         return ELPH_E_UNSUPPORTED;
     }
-    wg::Shape sh;
     {   // one slice per wave on every rank (slab sizes differ between ranks; the team shape must not): elph_shard_shape
         int W = 0, G = 0;
         const int rc = elph_shard_shape(h->L, Sh.P, &W, &G, nullptr, nullptr);
@@ -1528,7 +1542,6 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     }
     if ((unsigned long long)h->wg_epoch + span >= 0xFFFFFFFFull) zero = true;
     if (zero) { HIPCHK(hipMemsetAsync(h->d_res, 0, h->res_cap, h->stream)); h->wg_epoch = 0; }
-    wg::WgCtl R;
     char *base = static_cast<char *>(h->d_res);
     R.slots = reinterpret_cast<wg::u64 *>(base);
     R.bnd = R.slots + n_slots;
@@ -1544,6 +1557,15 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     HIPCHK(hipMemsetAsync(base, 0, h->res_cap, h->stream));   // boundary granules of this rank's workgroups: tags restart at 2
     h->wg_epoch = 0;
     R.teams_per_xcd = 1;
+    return ELPH_OK;
+}
+
+int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out) {
+    ModelDev m;
+    wg::Shape sh;
+    wg::WgCtl R;
+    const int rcs = shard_rank_setup(h, B, fixed_iters, Sh, m, sh, R);
+    if (rcs) return rcs;
     const dim3 grid((unsigned)sh.G);                       // one right-hand side: its G workgroups, round-robin over the XCDs
     hipError_t e = hipSuccess;
     if (sh.gr || sh.hg) e = wg::launch_shard_grid(h, sh, grid, B, m, R, Sh);
@@ -1558,5 +1580,53 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
     h->wg_T = sh.T; h->wg_W = sh.W; h->wg_G = sh.G;
     h->wg_abort_off = h->res_cap - 64;
     if (G_out) *G_out = sh.G;
+    return ELPH_OK;
+}
+
+// ALL RANKS OF A SHARDED SOLVE WHOSE SLABS LIVE ON ONE DEVICE, IN ONE LAUNCH (slabs.hip): the same kernel, rank q's workgroups = blocks
+// q G .. q G + G - 1, launch arguments from d_args (device memory, P x elph_wg_rank_args_bytes()).  Every slab must take the lane-program
+// form with the same sites per lane and the same team shape; all P G workgroups must be resident at once (they wait for each other).
+size_t elph_wg_rank_args_bytes() { return sizeof(wg::WgRankArgs); }
+
+int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long long fixed_iters, const ElphShardCtl *ctls, void *h_args,
+                     void *d_args, hipStream_t stream, long long timeout_ms, int *G_out) {
+    if (P < 1 || P > ELPH_SHARD_MAXRANKS) { elph_set_error("bad rank count %d", P); return ELPH_E_ARG; }
+    wg::WgRankArgs *A = static_cast<wg::WgRankArgs *>(h_args);          // (pinned, owned by the caller: the copy below is asynchronous)
+    wg::Shape sh0;
+    bool uni = true;
+    for (int q = 0; q < P; ++q) {
+        if (hs[q]->stream != stream) { elph_set_error("slab %d runs on another stream", q); return ELPH_E_STATE; }
+        wg::Shape sh;
+        const int rc = shard_rank_setup(hs[q], Bs[q], fixed_iters, ctls[q], A[(size_t)q].m, sh, A[(size_t)q].R);
+        if (rc) return rc;
+        if (sh.gr || sh.hg || hs[q]->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("slabs on one device: lane-program form, site phonons"); return ELPH_E_UNSUPPORTED; }
+        if (q == 0) sh0 = sh;
+        else if (sh.npl != sh0.npl || sh.W != sh0.W || sh.G != sh0.G || sh.shm != sh0.shm) { elph_set_error("slabs on one device: slab %d has another shape", q); return ELPH_E_UNSUPPORTED; }
+        uni = uni && A[(size_t)q].m.uniform;
+        if (timeout_ms > 0) A[(size_t)q].R.timeout_ticks = timeout_ms * 100000LL;      // (slabs of one device: a streaming fallback exists, the short bound)
+        A[(size_t)q].B = Bs[q];
+        A[(size_t)q].Sh = ctls[q];
+    }
+    if ((long long)P * sh0.G > 240) { elph_set_error("slabs on one device: %d x %d workgroups cannot all be resident", P, sh0.G); return ELPH_E_UNSUPPORTED; }
+    HIPCHK(hipMemcpyAsync(d_args, A, (size_t)P * sizeof(wg::WgRankArgs), hipMemcpyHostToDevice, stream));
+    wg::WgCtl R0 = A[0].R;
+    R0.ranks = d_args;
+    const dim3 grid((unsigned)(P * sh0.G)), block((unsigned)(sh0.W * WAVE));
+    hipError_t e = hipSuccess;
+#define RANKS_LAUNCH(NPLV, UNIV) do {                                                                                                  \
+        auto kfn = wg::k_cg_wg<NPLV, 1, false, UNIV, 0, true, false, true>;                                                            \
+        e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh0.shm);                          \
+        if (e == hipSuccess) { hipLaunchKernelGGL(kfn, grid, block, sh0.shm, stream, Bs[0], A[0].m, R0, ctls[0]); e = hipGetLastError(); } \
+    } while (0)
+#define RANKS_CASE(NPLV) case NPLV: if (uni) RANKS_LAUNCH(NPLV, true); else RANKS_LAUNCH(NPLV, false); break;
+    switch (sh0.npl) {
+        RANKS_CASE(1) RANKS_CASE(2) RANKS_CASE(3) RANKS_CASE(4)
+        default: if (uni) RANKS_LAUNCH(5, true); else RANKS_LAUNCH(5, false); break;
+    }
+#undef RANKS_CASE
+#undef RANKS_LAUNCH
+    if (e != hipSuccess) { elph_set_error("launch k_cg_wg (ranks) failed: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
+    for (int q = 0; q < P; ++q) { hs[q]->wg_T = 1; hs[q]->wg_W = sh0.W; hs[q]->wg_G = sh0.G; hs[q]->wg_abort_off = hs[q]->res_cap - 64; }
+    if (G_out) *G_out = sh0.G;
     return ELPH_OK;
 }

@@ -24,6 +24,7 @@ struct WgCtl {
     long long fixed_iters;     // > 0: measurement mode, exactly this many iterations, no stop test
     int x0_zero;               // the initial guess is zero (the library zeroed it): x0 is not read
     int teams_per_xcd;         // persistent teams: team tq of an XCD takes right-hand sides tq, tq + teams_per_xcd, ... (times 8, plus the XCD)
+    const void *ranks = nullptr;   // k_cg_wg<..., RANKS>: WgRankArgs[P] in device memory — the launch arguments of every rank of the grid (nullptr otherwise)
 };
 
 template <int NPL>

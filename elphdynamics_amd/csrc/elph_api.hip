@@ -874,6 +874,9 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
         bool eligible = false;
         if (!use_prec) eligible = h->fast && maxiter >= 1 && elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs);
         else { h->wg_broken = false; eligible = maxiter >= 1 && elph_pcg_wg_usable(h, nrhs); h->wg_broken = true; }      // (its shape test reads the flag itself)
+        if (!use_prec && !eligible && h->slabs && x0_zero && maxiter >= 1 && !eps_hist) {      // (the slab form of a large lattice, slabs.hip)
+            h->wg_broken = false; eligible = elph_i_slabs_usable(h, nrhs); h->wg_broken = true;
+        }
         if (eligible) RC(elph_wg_cooldown_step(h));
     }
     RC(elph_launch_cg_init(h, nrhs, use_prec, x0_zero));      // (x0 = 0: A x0 = 0 without the mat-vec)
@@ -907,6 +910,15 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
             HIPCHK(hipMemcpyAsync(h->d_x, h->d_zp, (size_t)nrhs * (size_t)h->ndim * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             RC(elph_launch_cg_init(h, nrhs, use_prec));
         }
+    }
+
+    // a lattice beyond one wave's slice: the resident kernel on slabs of rows of the lattice, all on this device, one launch per right-hand
+    // side (slabs.hip).  x0 = 0 only (the slab kernel starts from it): ldiv!'s zero-fill.
+    if (!use_prec && maxiter >= 1 && x0_zero && !eps_hist && elph_i_slabs_usable(h, nrhs)) {
+        bool ran = false;
+        RC(elph_i_slabs_solve(h, nrhs, P, 0, iters, &ran, nullptr));
+        if (ran) return ELPH_OK;
+        RC(elph_launch_cg_init(h, nrhs, use_prec, true));      // (x is zero again: elph_i_slabs_solve)
     }
 
     // the whole PRECONDITIONED solve in one launch (pcg_wg.hip: k_pcg_wg) for one to eight right-hand sides on the 16 x 16 square lattice
@@ -1105,6 +1117,21 @@ static int stage_in_dev(elph_handle_s *h, int nrhs, const double *X_dev, const d
     return ELPH_OK;
 }
 
+// Is the caller's initial guess all zeros?  Looked at only where it decides something: a lattice beyond one wave's slice whose
+// un-preconditioned solve of one or two right-hand sides the slab form (slabs.hip; it starts from x = 0) could take.  Stops at the first
+// non-zero; a zero guess costs one pass over the vector on the host (1.3 MB at 32 x 32 sites, 160 slices) — against a solve of milliseconds.
+static bool x0_is_zero(elph_handle_s *h, int nrhs, int use_prec, const double *X) {
+    if (use_prec || h->have_E == false) return false;
+    const bool prev = h->wg_broken;
+    h->wg_broken = false;                            // (cooling down: the hint still lets run_cg count the solve)
+    const bool cand = elph_i_slabs_usable(h, nrhs);
+    h->wg_broken = prev;
+    if (!cand) return false;
+    const size_t n = (size_t)nrhs * (size_t)h->ndim;
+    for (size_t i = 0; i < n; ++i) if (X[i] != 0.0) return false;
+    return true;
+}
+
 extern "C" int elph_ldiv_batched_dev(elph_handle h, int nrhs, double *X_dev, const double *B_dev, int use_prec,
                                      int64_t maxiter, int64_t *iters, double *residual_error, int *flag) {
     CHECK_H(h);
@@ -1129,9 +1156,14 @@ extern "C" int elph_ldiv_batched(elph_handle h, int nrhs, double *X, const doubl
     const size_t bytes = (size_t)nrhs * (size_t)h->ndim * sizeof(double);
     HIPCHK(hipMemcpyAsync(h->d_stage_in, B, bytes, hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, nrhs));
-    HIPCHK(hipMemcpyAsync(h->d_stage_in, X, bytes, hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, nrhs));
-    h->x_zero = false;                              // (a caller's initial guess)
+    if (x0_is_zero(h, nrhs, use_prec, X)) {          // fill!(x, 0) of the callers (HMC.jl:854, GreensFunctions.jl:334): seen on the host, the slab form may take the solve
+        HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));
+        h->x_zero = true;
+    } else {
+        HIPCHK(hipMemcpyAsync(h->d_stage_in, X, bytes, hipMemcpyHostToDevice, h->stream));
+        RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, nrhs));
+        h->x_zero = false;                          // (a caller's initial guess)
+    }
     RC(ldiv_core(h, nrhs, use_prec, maxiter, iters, residual_error, flag));
     RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, nrhs));
     HIPCHK(hipMemcpyAsync(X, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1155,9 +1187,14 @@ extern "C" int elph_cg_solve(elph_handle h, double *x, const double *b, double t
     const size_t bytes = (size_t)h->ndim * sizeof(double);
     HIPCHK(hipMemcpyAsync(h->d_stage_in, b, bytes, hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 1));
-    HIPCHK(hipMemcpyAsync(h->d_stage_in, x, bytes, hipMemcpyHostToDevice, h->stream));
-    RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, 1));
-    h->x_zero = false;                              // (a caller's initial guess)
+    if (!eps_hist && x0_is_zero(h, 1, use_precond, x)) {
+        HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));
+        h->x_zero = true;
+    } else {
+        HIPCHK(hipMemcpyAsync(h->d_stage_in, x, bytes, hipMemcpyHostToDevice, h->stream));
+        RC(elph_launch_r2s(h, h->d_x, h->d_stage_in, 1));
+        h->x_zero = false;                          // (a caller's initial guess)
+    }
     RC(run_cg(h, 1, use_precond ? 1 : 0, tol, maxiter, kappa_max, iters, eps_hist));
     RC(elph_launch_s2r(h, h->d_stage_out, h->d_x, 1));
     HIPCHK(hipMemcpyAsync(x, h->d_stage_out, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1890,7 +1927,7 @@ static int bench_launch_unit(elph_handle_s *h, int what, int nrhs) {
 extern "C" int elph_bench_prepare(elph_handle h, int what, int nrhs, const double *B) {
     CHECK_H(h);
     RC(need_model(h));
-    if (nrhs < 1 || what < 0 || what > 11) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (nrhs < 1 || what < 0 || what > 12) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     if ((what == 2 || what == 3 || what == 10 || what == 11 || (what >= 6 && what <= 8)) && !h->kpm_ready) { elph_set_error("KPM not set up"); return ELPH_E_STATE; }
     RC(ensure_capacity(h, nrhs));
     if (B) {
@@ -1946,7 +1983,19 @@ extern "C" int elph_bench_px_info(elph_handle h, int *fused) {
 
 extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int use_graph, double *ms_total) {
     CHECK_H(h);
-    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 11) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (nrhs < 1 || nrhs > h->cap_rhs || reps < 1 || !ms_total || what < 0 || what > 12) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    if (what == 12) {        // `reps` un-preconditioned iterations of every right-hand side in the slab form of a large lattice (slabs.hip): sum of the launches' event times
+        const int prev_broken = h->wg_broken;
+        h->wg_broken = false;
+        const bool ok = elph_i_slabs_usable(h, nrhs);
+        h->wg_broken = prev_broken;
+        if (!ok) { elph_set_error("the slab form does not apply to this handle / batch"); return ELPH_E_UNSUPPORTED; }
+        bool ran = false;
+        std::vector<int64_t> its((size_t)nrhs);
+        RC(elph_i_slabs_solve(h, nrhs, h->cur_params, reps, its.data(), &ran, ms_total));
+        if (!ran) { elph_set_error("the slab form gave up (time-out)"); return ELPH_E_HIP; }
+        return ELPH_OK;
+    }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

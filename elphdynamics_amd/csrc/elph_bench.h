@@ -17,7 +17,9 @@ extern "C" {
  *       launch of the resident preconditioned kernel (pcg_wg.hip: what elph_ldiv with a preconditioner runs for 1..8 right-hand
  *       sides on the 16 x 16 square lattice; ELPH_E_UNSUPPORTED elsewhere; fresh elph_bench_prepare(…, 10, …) before every run), 11 = `reps` preconditioned iterations
  *       of the batch as TWO half-batches on two streams (the form elph_ldiv_batched runs from 192 right-hand sides; prepare with what = 3;
- *       ELPH_E_UNSUPPORTED where the halves are not whole groups of chains or the p/x-fused iteration does not apply).
+ *       ELPH_E_UNSUPPORTED where the halves are not whole groups of chains or the p/x-fused iteration does not apply),
+ *       12 = `reps` un-preconditioned iterations of every right-hand side in the SLAB form of a lattice beyond 320 sites (slabs.hip: the resident
+ *       kernel on slabs of rows, all on this device, one launch per right-hand side; prepare with what = 1; *ms_total = sum of the launches).
  * elph_bench_prepare: loads nrhs right-hand sides (B: host, reference layout, nrhs*ndim; NULL keeps what the
  *   last solve left on the device), zeroes x, seeds the CG state with tol = 0 (never converges).
  * elph_bench_run: launches `reps` units back-to-back on the handle's stream (captured graph chunks when
@@ -34,6 +36,10 @@ int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, int *W, int
 /* Whether the LAST preconditioned solve / elph_bench_prepare ran its iteration p/x-fused (*fused = 1: x += alpha p and p = P^-1 r + beta p
  * in the epilogue of the inverse tau-transform, k_cg_ap_chunk<PX> reading the ready p; kernels.hip: px_plan). */
 int elph_bench_px_info(elph_handle h, int *fused);
+
+/* Whether an un-preconditioned solve of nrhs right-hand sides FROM x = 0 on this handle runs in the slab form (slabs.hip: lattices beyond
+ * 320 sites as slabs of rows on the same device, the resident kernel per slab, one launch) and its shape. */
+int elph_bench_slabs_info(elph_handle h, int nrhs, int *usable, int *slabs, int *sites_per_slab, int *own_sites);
 
 /* the sharded solve (shard.hip): exactly `iters` iterations (no stop test); *ms = HIP-event time of this rank's launch.  b_slab may
  * be NULL (keeps the right-hand side of the previous call).  Needs elph_shard_prepare + barrier like a solve. */

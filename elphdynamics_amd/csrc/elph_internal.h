@@ -240,6 +240,9 @@ struct elph_handle_s {
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
     int *d_sq_bond = nullptr;                            // [4][N] device copy of sq_bond (sq_P > 0)
     void *shard = nullptr;                 // ShardState (shard.hip), owned
+    void *slabs = nullptr;                 // SlabSet (slabs.hip), owned: slab handles of this lattice on the same device
+    bool slabs_tried = false;              // the slab decomposition was attempted (slabs == nullptr: it does not apply)
+    bool is_slab = false;                  // this handle IS a slab of another handle (never decomposed again)
     void *hmc = nullptr;                   // HmcState (hmc.hip), owned
     void *greens = nullptr;                // GreensState (greens.hip), owned
     void *d_res = nullptr;                 // control block of the workgroup-resident CG (cg_wg.hip): meeting records, abort word, boundary slices
@@ -408,6 +411,16 @@ struct ElphShardCtl {
 };
 extern "C" int elph_shard_shape(int64_t ltau, int world, int *waves, int *groups, int *records, int *max_records);   // shard.hip
 int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, const ElphShardCtl &Sh, int *G_out);
+// all ranks of a sharded solve whose slabs live on ONE device in one launch (cg_wg.hip; h_args pinned, d_args device: P x elph_wg_rank_args_bytes())
+size_t elph_wg_rank_args_bytes();
+int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long long fixed_iters, const ElphShardCtl *ctls, void *h_args,
+                     void *d_args, hipStream_t stream, long long timeout_ms, int *G_out);
+int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
+                           long long fixed_iters, long long timeout_ms, CgState *state_out, double *ms_out);      // shard.hip
+// ---- slabs.hip: the resident un-preconditioned solve of a lattice BEYOND one wave's slice (N > 320) as slabs of rows on the same device
+bool elph_i_slabs_usable(elph_handle_s *h, int nrhs);      // builds the slabs on first use
+int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long fixed_iters, int64_t *iters, bool *ran, double *ms_out);
+void elph_i_slabs_free(elph_handle_s *h);
 
 // ---- workgroup-resident CG (cg_wg.hip): the whole un-preconditioned solve in one launch
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs = 1);

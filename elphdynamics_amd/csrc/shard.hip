@@ -262,6 +262,63 @@ static int shard_run(elph_handle_s *h, const double *b_slab, double tol, int64_t
     return ELPH_OK;
 }
 
+// ALL RANKS OF A SOLVE WHOSE SLABS LIVE ON ONE DEVICE (slabs.hip), one launch: every slab's right-hand side is in its d_b already (layout S);
+// the solutions stay in the slabs' d_x.  Everything is queued on the ONE stream the slab handles share — the mailboxes are zeroed, the
+// Krylov vectors seeded and the kernel launched in stream order, so no barrier is needed between "prepare" and "solve".
+int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
+                           long long fixed_iters, long long timeout_ms, CgState *state_out, double *ms_out) {
+    if (P < 2 || P > ELPH_SHARD_MAXRANKS) { elph_set_error("bad rank count %d", P); return ELPH_E_ARG; }
+    hipStream_t st = hs[0]->stream;
+    std::vector<CgBufs> Bs((size_t)P);
+    std::vector<ElphShardCtl> ctls((size_t)P);
+    CgParams Pm;
+    Pm.tol = tol; Pm.kmax = kmax; Pm.maxiter = maxiter; Pm.use_prec = 0; Pm.record_hist = 0; Pm.hist_stride = 0;
+    for (int q = 0; q < P; ++q) {
+        elph_handle_s *h = hs[q];
+        ShardState *S = static_cast<ShardState *>(h->shard);
+        if (!S || !S->connected || h->stream != st) { elph_set_error("slab %d is not connected / runs on another stream", q); return ELPH_E_STATE; }
+        if (!h->have_E) { elph_set_error("slab %d has no exp(-dtau V)", q); return ELPH_E_STATE; }
+        int rc = elph_i_ensure_capacity(h, 1);
+        if (rc) return rc;
+        h->cur_params = Pm;
+        const size_t bytes = (size_t)h->ndim * sizeof(double);
+        HIPCHK(hipMemsetAsync(S->mail, 0, S->mail_bytes, st));
+        HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, st));
+        HIPCHK(hipMemcpyAsync(h->d_r, h->d_b, bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->d_p, h->d_b, bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemsetAsync(h->d_state, 0, 2 * sizeof(CgState), st));
+        Bs[(size_t)q] = elph_make_bufs(h, 1);
+        Bs[(size_t)q].params = Pm;
+        ctls[(size_t)q] = S->ctl;
+        S->prepared = false;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms_out) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    int G = 0;
+    int rc = elph_wg_cg_ranks(hs, P, Bs.data(), fixed_iters, ctls.data(), h_args, d_args, st, timeout_ms, &G);
+    if (rc == ELPH_OK && ms_out) {
+        hipError_t er = hipEventRecord(e1, st);
+        if (er == hipSuccess) er = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (er == hipSuccess) er = hipEventElapsedTime(&ms, e0, e1);
+        if (er != hipSuccess) { elph_set_error("slab solve: %s", hipGetErrorString(er)); rc = ELPH_E_HIP; }
+        *ms_out = (double)ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(hs[0]->h_state, hs[0]->d_state, sizeof(CgState) * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int q = 0; q < P; ++q) {
+        bool aborted = false;
+        rc = elph_wg_aborted(hs[q], &aborted);
+        if (rc) return rc;
+        if (aborted) { hs[q]->wg_broken = false; hs[q]->wg_cooldown = 0; return ELPH_E_HIP; }      // (the caller owns the fallback and its cool-down)
+    }
+    if (state_out) *state_out = hs[0]->h_state[0];
+    return ELPH_OK;
+}
+
 extern "C" int elph_shard_solve(elph_handle h, double *x_slab, const double *b_slab, double tol, int64_t maxiter, double kappa_max,
                                 int64_t *iters, int *done, double *eps) {
     if (!h) { elph_set_error("null handle"); return ELPH_E_ARG; }

@@ -1,0 +1,108 @@
+"""The slab form of the resident un-preconditioned solve (csrc/slabs.hip): a lattice beyond one wave's slice (N > 320 sites) cut into slabs
+of rows on ONE device, the sharded resident kernel per slab, all slabs in one launch.  Against the streaming iteration (ELPH_SLABS=0) and
+the oracle (IterativeSolvers.jl:239-314, Models.jl:74-186)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _oracle_model, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _info(m, nrhs=1):
+    use, P, nloc, own = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    from elphdynamics_amd._lib import check
+    check(m._lib.elph_bench_slabs_info(m._h, nrhs, C.byref(use), C.byref(P), C.byref(nloc), C.byref(own)))
+    return use.value, P.value, nloc.value, own.value
+
+
+@pytest.fixture
+def slabs_env():
+    old = {k: os.environ.get(k) for k in ("ELPH_SLABS", "ELPH_SLABS_P")}
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+# square 18, 20, 24, 28, 30, 32; honeycomb 18 x 18 and 20 x 20 cells (two sites per cell); triangular 24 x 24 has six colours: no slabs
+@pytest.mark.parametrize("tag", ["i", "k", "g", "j", "l30", "G", "H18", "h20"])
+def test_slab_solve_vs_streaming_and_oracle(oracle, slabs_env, tag):
+    from elphdynamics_amd import configs, models
+    os.environ["ELPH_SLABS"] = "1"                       # wherever the decomposition exists (the default rule takes a subset: next test)
+    m = configs.make_model(tag, tol=1e-5)
+    use, P, nloc, own = _info(m)
+    assert use == 1 and 2 <= P <= 8 and own * P == m.Nsites and own < nloc <= 320, (use, P, nloc, own)
+    om = _oracle_model(oracle, m)
+    R, B = configs.rhs(m, 2)
+    b = np.ascontiguousarray(B[0])
+    x = np.zeros(m.Ndim)
+    it, res, flag = models.ldiv_(x, m, b)                # x = 0 on entry: the slab form
+    os.environ["ELPH_SLABS"] = "0"
+    xs = np.zeros(m.Ndim)
+    its, ress, flags = models.ldiv_(xs, m, b)
+    xo, ito, reso, flago = oracle.ldiv(om, b, solver_tol=1e-5, solver_maxiter=10000)
+    assert flag == flags == flago == 0 and abs(it - its) <= 1 and abs(it - ito) <= 1
+    assert 0.5 * reso < res < 2.0 * reso and res <= np.sqrt(1e-5)
+    assert rel(x, xs) < 1e-4 and not np.array_equal(x, xs)      # (another summation tree: the same solve to the tolerance, not the same bits; the tight solve below is the parity check)
+    # deterministic: the same bits again
+    os.environ["ELPH_SLABS"] = "1"
+    x2 = np.zeros(m.Ndim)
+    assert models.ldiv_(x2, m, b)[0] == it and np.array_equal(x, x2)
+    # a caller's initial guess (x != 0) is the streaming iteration's: the bits of ELPH_SLABS=0
+    g0 = 0.5 * xs
+    xa, xb = g0.copy(), g0.copy()
+    ita = models.ldiv_(xa, m, b)[0]
+    os.environ["ELPH_SLABS"] = "0"
+    itb = models.ldiv_(xb, m, b)[0]
+    assert ita == itb and np.array_equal(xa, xb)
+    # two right-hand sides (forced mode: one launch after the other) = the single solves
+    os.environ["ELPH_SLABS"] = "1"
+    X = np.zeros((2, m.Ndim))
+    itB, resB, flB = models.ldiv_batched_(X, m, np.ascontiguousarray(B))
+    assert itB[0] == it and np.array_equal(X[0], x) and flB[1] == 0
+    # tight solve against the oracle: the north_star's bound on M^-1 R
+    m.solver.tol = 1e-13
+    x3 = np.zeros(m.Ndim)
+    it3, res3, flag3 = models.ldiv_(x3, m, b)
+    xo3, ito3, *_ = oracle.ldiv(om, b, solver_tol=1e-13, solver_maxiter=10000)
+    assert flag3 == 0 and abs(it3 - ito3) <= max(3, ito3 // 100)
+    assert rel(x3, xo3) < 1e-10
+    m.close()
+
+
+def test_slab_rule_and_hopping_disorder(oracle, slabs_env):
+    """The default rule (no ELPH_SLABS): from 576 sites, an even slab count, slabs of at most 256 sites, one right-hand side; below that and
+    for two right-hand sides the streaming iteration.  Hopping disorder takes the per-bond tables of the slabs."""
+    from elphdynamics_amd import configs, models
+    os.environ.pop("ELPH_SLABS", None)
+    os.environ.pop("ELPH_SLABS_P", None)
+    for tag, want in (("g", (1, 6, 192, 96)), ("G", (1, 8, 256, 128)), ("k", (0, 0, 0, 0)), ("j", (0, 0, 0, 0))):
+        m = configs.make_model(tag, tol=1e-5)
+        assert _info(m, 1) == want, (tag, _info(m, 1))
+        assert _info(m, 2)[0] == 0
+        m.close()
+    m = configs.make_model("g", tol=1e-5, t_stddev=0.1)
+    assert _info(m, 1)[0] == 1
+    om = _oracle_model(oracle, m)
+    _, B = configs.rhs(m, 1)
+    b = np.ascontiguousarray(B[0])
+    m.solver.tol = 1e-13
+    x = np.zeros(m.Ndim)
+    it, res, flag = models.ldiv_(x, m, b)
+    xo, ito, *_ = oracle.ldiv(om, b, solver_tol=1e-13, solver_maxiter=10000)
+    assert flag == 0 and abs(it - ito) <= max(3, ito // 100) and rel(x, xo) < 1e-10
+    # the model moves (update_model!): the slabs follow
+    m.x[:] = 0.7 * m.x[::-1]
+    models.update_model_(m)
+    om2 = _oracle_model(oracle, m)
+    x2 = np.zeros(m.Ndim)
+    it2, res2, flag2 = models.ldiv_(x2, m, b)
+    xo2, ito2, *_ = oracle.ldiv(om2, b, solver_tol=1e-13, solver_maxiter=10000)
+    assert flag2 == 0 and abs(it2 - ito2) <= max(3, ito2 // 100) and rel(x2, xo2) < 1e-10
+    m.close()
