@@ -490,6 +490,16 @@ def main():
                         check(lib.elph_bench_prepare(ml_._h, wh, 72, None))
                         check(lib.elph_bench_run(ml_._h, wh, 72, 160, 0, C.byref(msl)))
                         rec[nm] = 1e3 * msl.value / 160
+                    # one right-hand side (the reference's call shape): the streaming pair and — where the rule of slabs.hip takes it —
+                    # the slab form (the resident kernel on slabs of rows of the lattice, all slabs one launch)
+                    for wh, nm in ((1, "cg_iter_us_1rhs_streaming"), (12, "cg_iter_us_1rhs_slabs")):
+                        try:
+                            for reps in (64, 400):
+                                check(lib.elph_bench_prepare(ml_._h, 1, 1, _lib.dptr(np.ascontiguousarray(Bl[:1]))))
+                                check(lib.elph_bench_run(ml_._h, wh, 1, reps, 0, C.byref(msl)))
+                            rec[nm] = 1e3 * msl.value / 400
+                        except _lib.ElphError:
+                            rec[nm] = None               # (the slab form does not apply to this lattice)
                     rec["preconditioned_ps_per_element"] = 1e6 * rec["preconditioned_cg_iter_us"] / (72.0 * ml_.Ndim)
                     rec["preconditioned_matvecs_per_sec"] = 2.0 * 72 / (rec["preconditioned_cg_iter_us"] * 1e-6)
                     large[tag] = rec

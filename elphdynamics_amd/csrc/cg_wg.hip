@@ -1590,7 +1590,7 @@ size_t elph_wg_rank_args_bytes() { return sizeof(wg::WgRankArgs); }
 
 int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long long fixed_iters, const ElphShardCtl *ctls, void *h_args,
                      void *d_args, hipStream_t stream, long long timeout_ms, int *G_out) {
-    if (P < 1 || P > ELPH_SHARD_MAXRANKS) { elph_set_error("bad rank count %d", P); return ELPH_E_ARG; }
+    if (P < 1 || P > 2 * ELPH_SHARD_MAXRANKS) { elph_set_error("bad rank count %d", P); return ELPH_E_ARG; }      // (up to two sets of slabs)
     wg::WgRankArgs *A = static_cast<wg::WgRankArgs *>(h_args);          // (pinned, owned by the caller: the copy below is asynchronous)
     wg::Shape sh0;
     bool uni = true;

@@ -415,7 +415,7 @@ int elph_wg_cg_shard(elph_handle_s *h, const CgBufs &B, long long fixed_iters, c
 size_t elph_wg_rank_args_bytes();
 int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long long fixed_iters, const ElphShardCtl *ctls, void *h_args,
                      void *d_args, hipStream_t stream, long long timeout_ms, int *G_out);
-int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
+int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, int nsets, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
                            long long fixed_iters, long long timeout_ms, CgState *state_out, double *ms_out);      // shard.hip
 // ---- slabs.hip: the resident un-preconditioned solve of a lattice BEYOND one wave's slice (N > 320) as slabs of rows on the same device
 bool elph_i_slabs_usable(elph_handle_s *h, int nrhs);      // builds the slabs on first use

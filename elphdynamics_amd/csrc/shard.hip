@@ -265,15 +265,17 @@ static int shard_run(elph_handle_s *h, const double *b_slab, double tol, int64_t
 // ALL RANKS OF A SOLVE WHOSE SLABS LIVE ON ONE DEVICE (slabs.hip), one launch: every slab's right-hand side is in its d_b already (layout S);
 // the solutions stay in the slabs' d_x.  Everything is queued on the ONE stream the slab handles share — the mailboxes are zeroed, the
 // Krylov vectors seeded and the kernel launched in stream order, so no barrier is needed between "prepare" and "solve".
-int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
+int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, int nsets, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
                            long long fixed_iters, long long timeout_ms, CgState *state_out, double *ms_out) {
-    if (P < 2 || P > ELPH_SHARD_MAXRANKS) { elph_set_error("bad rank count %d", P); return ELPH_E_ARG; }
+    // hs[set * P + q]: `nsets` independent solves (each over its own P slabs and their mailboxes) in the one launch
+    if (P < 2 || P > ELPH_SHARD_MAXRANKS || nsets < 1 || nsets > 2) { elph_set_error("bad rank count %d x %d", nsets, P); return ELPH_E_ARG; }
+    const int PT = P * nsets;
     hipStream_t st = hs[0]->stream;
-    std::vector<CgBufs> Bs((size_t)P);
-    std::vector<ElphShardCtl> ctls((size_t)P);
+    std::vector<CgBufs> Bs((size_t)PT);
+    std::vector<ElphShardCtl> ctls((size_t)PT);
     CgParams Pm;
     Pm.tol = tol; Pm.kmax = kmax; Pm.maxiter = maxiter; Pm.use_prec = 0; Pm.record_hist = 0; Pm.hist_stride = 0;
-    for (int q = 0; q < P; ++q) {
+    for (int q = 0; q < PT; ++q) {
         elph_handle_s *h = hs[q];
         ShardState *S = static_cast<ShardState *>(h->shard);
         if (!S || !S->connected || h->stream != st) { elph_set_error("slab %d is not connected / runs on another stream", q); return ELPH_E_STATE; }
@@ -295,7 +297,7 @@ int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, void *h_args, void *
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ms_out) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     int G = 0;
-    int rc = elph_wg_cg_ranks(hs, P, Bs.data(), fixed_iters, ctls.data(), h_args, d_args, st, timeout_ms, &G);
+    int rc = elph_wg_cg_ranks(hs, PT, Bs.data(), fixed_iters, ctls.data(), h_args, d_args, st, timeout_ms, &G);
     if (rc == ELPH_OK && ms_out) {
         hipError_t er = hipEventRecord(e1, st);
         if (er == hipSuccess) er = hipEventSynchronize(e1);
@@ -307,15 +309,15 @@ int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, void *h_args, void *
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(hs[0]->h_state, hs[0]->d_state, sizeof(CgState) * 2, hipMemcpyDeviceToHost, st));
+    for (int k = 0; k < nsets; ++k) HIPCHK(hipMemcpyAsync(hs[k * P]->h_state, hs[k * P]->d_state, sizeof(CgState) * 2, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int q = 0; q < P; ++q) {
+    for (int q = 0; q < PT; ++q) {
         bool aborted = false;
         rc = elph_wg_aborted(hs[q], &aborted);
         if (rc) return rc;
         if (aborted) { hs[q]->wg_broken = false; hs[q]->wg_cooldown = 0; return ELPH_E_HIP; }      // (the caller owns the fallback and its cool-down)
     }
-    if (state_out) *state_out = hs[0]->h_state[0];
+    if (state_out) for (int k = 0; k < nsets; ++k) state_out[k] = hs[k * P]->h_state[0];
     return ELPH_OK;
 }
 

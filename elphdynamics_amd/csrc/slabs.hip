@@ -29,9 +29,11 @@ namespace {
 struct SlabPtrs { double *p[ELPH_SHARD_MAXRANKS]; const int *g[ELPH_SHARD_MAXRANKS]; };
 
 struct SlabSet {
-    int P = 0, Nloc = 0, own_lo = 0, own_n = 0;
-    std::vector<elph_handle_s *> hs;
-    std::vector<int *> d_g;                 // [Nloc] site of the parent lattice of every slab site
+    int P = 0, Nloc = 0, own_lo = 0, own_n = 0, hi = 0;
+    int nsets = 0;                          // sets of P slab handles: set k solves right-hand side k of a pair in the same launch (own mailboxes)
+    int G = 0;                              // workgroups per slab
+    std::vector<elph_handle_s *> hs;        // [nsets][P]
+    std::vector<int *> d_g;                 // [P][Nloc] site of the parent lattice of every slab site
     void *h_args = nullptr, *d_args = nullptr;
     hipStream_t stream = nullptr;           // the stream the slab handles were last bound to
 };
@@ -93,12 +95,12 @@ bool plan(const elph_handle_s *h, int P, int &lo, int &hi, const char *&why) {
     return true;
 }
 
-int build(elph_handle_s *h, int P, int lo, int hi, SlabSet **out) {
-    const int N = (int)h->N, nb = (int)h->nb, n = N / P, Nloc = lo + n + hi;
-    SlabSet *S = new SlabSet();
-    S->P = P; S->Nloc = Nloc; S->own_lo = lo; S->own_n = n;
-    S->hs.assign((size_t)P, nullptr);
-    S->d_g.assign((size_t)P, nullptr);
+// one more set of P slab handles (its own mailboxes); d_g is made with the first
+int add_set(elph_handle_s *h, SlabSet *S) {
+    const int N = (int)h->N, nb = (int)h->nb, P = S->P, n = S->own_n, lo = S->own_lo, hi = S->hi, Nloc = S->Nloc;
+    const size_t base = S->hs.size();
+    S->hs.resize(base + (size_t)P, nullptr);
+    if (S->d_g.empty()) S->d_g.assign((size_t)P, nullptr);
     std::vector<unsigned char> ipc((size_t)P * ELPH_SHARD_IPC_BYTES);
     std::vector<char> Cs, need;
     int rc = ELPH_OK;
@@ -121,7 +123,7 @@ int build(elph_handle_s *h, int P, int lo, int hi, SlabSet **out) {
         elph_handle sh = nullptr;
         rc = elph_create(&sh, ELPH_MODEL_HOLSTEIN, Nloc, h->L, (int64_t)(tab.size() / 2), tab.data(), c.data(), s.data(), h->device);
         if (rc) break;
-        S->hs[(size_t)q] = sh;
+        S->hs[base + (size_t)q] = sh;
         sh->is_slab = true;
         rc = elph_set_stream(sh, h->stream);
         if (rc) break;
@@ -129,14 +131,27 @@ int build(elph_handle_s *h, int P, int lo, int hi, SlabSet **out) {
         rc = elph_shard_create(sh, q, P, lo, n, /* to prev = its ghosts above */ hi, /* to next = its ghosts below */ lo, std::max(lo, hi), 0, 0, &zero,
                                ipc.data() + (size_t)q * ELPH_SHARD_IPC_BYTES);
         if (rc) break;
-        if (hipMalloc((void **)&S->d_g[(size_t)q], (size_t)Nloc * sizeof(int)) != hipSuccess ||
-            hipMemcpy(S->d_g[(size_t)q], g.data(), (size_t)Nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        if (!S->d_g[(size_t)q] && (hipMalloc((void **)&S->d_g[(size_t)q], (size_t)Nloc * sizeof(int)) != hipSuccess ||
+                                   hipMemcpy(S->d_g[(size_t)q], g.data(), (size_t)Nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)) {
             elph_set_error("slabs: allocation failed"); rc = ELPH_E_HIP; break;
         }
     }
-    for (int q = 0; q < P && rc == ELPH_OK; ++q) rc = elph_shard_connect(S->hs[(size_t)q], ipc.data());
+    for (int q = 0; q < P && rc == ELPH_OK; ++q) rc = elph_shard_connect(S->hs[base + (size_t)q], ipc.data());
+    if (rc) {
+        for (size_t k = base; k < S->hs.size(); ++k) if (S->hs[k]) (void)elph_destroy(S->hs[k]);
+        S->hs.resize(base);
+        return rc;
+    }
+    ++S->nsets;
+    return ELPH_OK;
+}
+
+int build(elph_handle_s *h, int P, int lo, int hi, int G, SlabSet **out) {
+    SlabSet *S = new SlabSet();
+    S->P = P; S->Nloc = lo + (int)h->N / P + hi; S->own_lo = lo; S->own_n = (int)h->N / P; S->hi = hi; S->G = G;
+    int rc = add_set(h, S);
     if (rc == ELPH_OK) {
-        const size_t bytes = (size_t)P * elph_wg_rank_args_bytes();
+        const size_t bytes = 2 * (size_t)P * elph_wg_rank_args_bytes();
         if (hipHostMalloc(&S->h_args, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&S->d_args, bytes) != hipSuccess) {
             elph_set_error("slabs: allocation failed"); rc = ELPH_E_HIP;
         }
@@ -147,12 +162,12 @@ int build(elph_handle_s *h, int P, int lo, int hi, SlabSet **out) {
     return ELPH_OK;
 }
 
-SlabPtrs ptrs_of(const SlabSet *S, int which /* 0 d_b, 1 d_E, 2 d_x */) {
+SlabPtrs ptrs_of(const SlabSet *S, int set, int which /* 0 d_b, 1 d_E, 2 d_x */) {
     SlabPtrs T;
     for (int q = 0; q < ELPH_SHARD_MAXRANKS; ++q) {
         T.p[q] = nullptr; T.g[q] = nullptr;
         if (q < S->P) {
-            elph_handle_s *s = S->hs[(size_t)q];
+            elph_handle_s *s = S->hs[(size_t)set * (size_t)S->P + (size_t)q];
             T.p[q] = which == 0 ? s->d_b : (which == 1 ? s->d_E : s->d_x);
             T.g[q] = S->d_g[(size_t)q];
         }
@@ -172,16 +187,22 @@ void elph_i_slabs_free(elph_handle_s *h) {
 //     slab of 144..192 sites 10.6-11.0, 240..256 sites 12.5-12.7, 270..300 sites (five sites per lane) 16.9-18.5, odd slab counts 14.2-14.4;
 //     streaming: 9.3 (18 x 18), 9.9 (20 x 20), 13.5 (24 x 24), 14.0 (28 x 28), 16.2 (30 x 30), 14.2 (32 x 32)
 // so: lattices from 576 sites, an EVEN number of slabs of at most 256 sites each (own + ghost), the count with the smallest slab; one
-// right-hand side (the slab kernel takes them one launch after the other: two cost 22-25 us against 15-18 streaming).
+// right-hand side, or two where two SETS of slabs fit the chip together (2 P G <= 240 workgroups: both solves in one launch — one launch
+// after the other two right-hand sides cost 22-25 us against 15-18 streaming).
 // ELPH_SLABS=0: never; =1: wherever the decomposition exists (any count, slabs up to 320 sites, up to 8 right-hand sides: the tests);
 // ELPH_SLABS_P forces the slab count.
 bool elph_i_slabs_usable(elph_handle_s *h, int nrhs) {
     const char *e = getenv("ELPH_SLABS");
     const int force = e ? atoi(e) : -1;
-    if (force == 0 || nrhs < 1 || nrhs > (force == 1 ? 8 : 1)) return false;
+    if (force == 0 || nrhs < 1 || nrhs > (force == 1 ? 8 : 2)) return false;
     if (h->kind != ELPH_MODEL_HOLSTEIN || h->is_slab || h->shard || h->nchains != 1 || h->solo_chain >= 0 || h->dot_hi != 0 || h->wg_broken) return false;
     if (h->N <= 5 * ELPH_WAVE || !h->have_E) return false;
-    if (h->slabs) return true;
+    if (h->slabs) {
+        // two right-hand sides (the pseudofermion pair): only as ONE launch of two sets of slabs — all 2 P G workgroups resident at once;
+        // one after the other they lose to the streaming pair
+        const SlabSet *S = static_cast<const SlabSet *>(h->slabs);
+        return nrhs == 1 || force == 1 || 2LL * S->P * S->G <= 240;
+    }
     if (h->slabs_tried) return false;
     h->slabs_tried = true;
     const char *ep = getenv("ELPH_SLABS_P");
@@ -205,11 +226,13 @@ bool elph_i_slabs_usable(elph_handle_s *h, int nrhs) {
         std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.nloc < b.nloc; });
         for (const Cand &c : cands) {
             SlabSet *S = nullptr;
-            if (build(h, c.P, c.lo, c.hi, &S) != ELPH_OK) { why = "a slab handle could not be made"; continue; }
+            int W = 0, G = 0;
+            (void)elph_shard_shape(h->L, c.P, &W, &G, nullptr, nullptr);
+            if (build(h, c.P, c.lo, c.hi, G, &S) != ELPH_OK) { why = "a slab handle could not be made"; continue; }
             // (that every slab takes the lane-program form of the sharded kernel is checked by the launch set-up of the first solve)
             h->slabs = S;
-            if (getenv("ELPH_SLABS_DEBUG")) fprintf(stderr, "[slabs] N = %lld: %d slabs of %d own + %d / %d ghost sites\n", (long long)h->N, c.P, S->own_n, c.lo, c.hi);
-            return true;
+            if (getenv("ELPH_SLABS_DEBUG")) fprintf(stderr, "[slabs] N = %lld: %d slabs of %d own + %d / %d ghost sites, %d workgroups each\n", (long long)h->N, c.P, S->own_n, c.lo, c.hi, G);
+            return nrhs == 1 || force == 1 || 2LL * S->P * S->G <= 240;
         }
     }
     if (getenv("ELPH_SLABS_DEBUG")) fprintf(stderr, "[slabs] N = %lld: not decomposed (%s)\n", (long long)h->N, why);
@@ -228,20 +251,30 @@ int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long 
         for (elph_handle_s *s : S->hs) { const int rc = elph_set_stream(s, h->stream); if (rc) return rc; }
         S->stream = h->stream;
     }
-    const int N = (int)h->N, L = (int)h->L, Nloc = S->Nloc;
+    const int N = (int)h->N, L = (int)h->L, Nloc = S->Nloc, Pq = S->P;
+    // a pair of right-hand sides runs as two sets of slabs in ONE launch where all their workgroups are resident together
+    const bool pairs = nrhs >= 2 && 2LL * Pq * S->G <= 240;
+    if (pairs && S->nsets < 2) {
+        const int rc = add_set(h, S);
+        if (rc) return rc;
+    }
     for (elph_handle_s *s : S->hs) { const int rc = elph_i_ensure_capacity(s, 1); if (rc) return rc; }
-    const dim3 gg((unsigned)((Nloc + 255) / 256), (unsigned)L, (unsigned)S->P), gs((unsigned)((S->own_n + 255) / 256), (unsigned)L, (unsigned)S->P);
-    hipLaunchKernelGGL(k_slab_gather, gg, dim3(256), 0, h->stream, ptrs_of(S, 1), (const double *)h->d_E, N, Nloc);
-    for (elph_handle_s *s : S->hs) s->have_E = true;
+    const dim3 gg((unsigned)((Nloc + 255) / 256), (unsigned)L, (unsigned)Pq), gs((unsigned)((S->own_n + 255) / 256), (unsigned)L, (unsigned)Pq);
+    for (int k = 0; k < (pairs ? 2 : 1); ++k) {
+        hipLaunchKernelGGL(k_slab_gather, gg, dim3(256), 0, h->stream, ptrs_of(S, k, 1), (const double *)h->d_E, N, Nloc);
+        for (int q = 0; q < Pq; ++q) S->hs[(size_t)k * Pq + q]->have_E = true;
+    }
     const char *et = getenv("ELPH_WG_TIMEOUT_MS");
     const long long timeout_ms = et ? std::max(1, atoi(et)) : 2000;
     double ms_sum = 0.0;
-    for (int r = 0; r < nrhs; ++r) {
-        hipLaunchKernelGGL(k_slab_gather, gg, dim3(256), 0, h->stream, ptrs_of(S, 0), (const double *)(h->d_b + (size_t)r * h->ndim), N, Nloc);
+    for (int r = 0; r < nrhs;) {
+        const int ns = (pairs && r + 1 < nrhs) ? 2 : 1;        // right-hand sides of this launch
+        for (int k = 0; k < ns; ++k)
+            hipLaunchKernelGGL(k_slab_gather, gg, dim3(256), 0, h->stream, ptrs_of(S, k, 0), (const double *)(h->d_b + (size_t)(r + k) * h->ndim), N, Nloc);
         HIPCHK(hipGetLastError());
-        CgState st;
+        CgState st[2];
         double ms = 0.0;
-        const int rc = elph_i_shard_run_ranks(S->hs.data(), S->P, S->h_args, S->d_args, P.tol, P.maxiter, P.kmax, fixed_iters, timeout_ms, &st,
+        const int rc = elph_i_shard_run_ranks(S->hs.data(), Pq, ns, S->h_args, S->d_args, P.tol, P.maxiter, P.kmax, fixed_iters, timeout_ms, st,
                                               ms_out ? &ms : nullptr);
         if (rc == ELPH_E_UNSUPPORTED) {                  // the slabs do not take the sharded kernel's lane-program form: never again
             elph_i_slabs_free(h);
@@ -261,13 +294,16 @@ int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long 
         }
         if (rc) return rc;
         ms_sum += ms;
-        if (!st.done && fixed_iters <= 0) { elph_set_error("slab CG ended without a terminal state (internal error)"); return ELPH_E_STATE; }
-        hipLaunchKernelGGL(k_slab_scatter, gs, dim3(256), 0, h->stream, ptrs_of(S, 2), h->d_x + (size_t)r * h->ndim, N, Nloc, S->own_lo, S->own_n);
+        for (int k = 0; k < ns; ++k) {
+            if (!st[k].done && fixed_iters <= 0) { elph_set_error("slab CG ended without a terminal state (internal error)"); return ELPH_E_STATE; }
+            hipLaunchKernelGGL(k_slab_scatter, gs, dim3(256), 0, h->stream, ptrs_of(S, k, 2), h->d_x + (size_t)(r + k) * h->ndim, N, Nloc, S->own_lo, S->own_n);
+            st[k].seq = st[k].iters + 1;
+            h->h_state[2 * (r + k)] = st[k];
+            h->h_state[2 * (r + k) + 1] = st[k];
+            if (iters) iters[r + k] = st[k].iters;
+        }
         HIPCHK(hipGetLastError());
-        st.seq = st.iters + 1;
-        h->h_state[2 * r] = st;
-        h->h_state[2 * r + 1] = st;
-        if (iters) iters[r] = st.iters;
+        r += ns;
     }
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state, sizeof(CgState) * 2 * (size_t)nrhs, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

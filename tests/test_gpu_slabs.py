@@ -61,11 +61,18 @@ def test_slab_solve_vs_streaming_and_oracle(oracle, slabs_env, tag):
     os.environ["ELPH_SLABS"] = "0"
     itb = models.ldiv_(xb, m, b)[0]
     assert ita == itb and np.array_equal(xa, xb)
-    # two right-hand sides (forced mode: one launch after the other) = the single solves
+    # two right-hand sides — two SETS of slabs in one launch where they fit the chip together, else one launch after the other — are the
+    # single solves, bit for bit; three: a pair and a single
     os.environ["ELPH_SLABS"] = "1"
+    x1 = np.zeros(m.Ndim)
+    it1 = models.ldiv_(x1, m, np.ascontiguousarray(B[1]))[0]
     X = np.zeros((2, m.Ndim))
     itB, resB, flB = models.ldiv_batched_(X, m, np.ascontiguousarray(B))
-    assert itB[0] == it and np.array_equal(X[0], x) and flB[1] == 0
+    assert itB[0] == it and itB[1] == it1 and np.array_equal(X[0], x) and np.array_equal(X[1], x1) and flB[1] == 0
+    B3 = np.ascontiguousarray(np.stack([B[1], B[0], B[1]]))
+    X3 = np.zeros((3, m.Ndim))
+    it3b = models.ldiv_batched_(X3, m, B3)[0]
+    assert list(it3b) == [it1, it, it1] and np.array_equal(X3[0], x1) and np.array_equal(X3[1], x) and np.array_equal(X3[2], x1)
     # tight solve against the oracle: the north_star's bound on M^-1 R
     m.solver.tol = 1e-13
     x3 = np.zeros(m.Ndim)
@@ -85,8 +92,16 @@ def test_slab_rule_and_hopping_disorder(oracle, slabs_env):
     for tag, want in (("g", (1, 6, 192, 96)), ("G", (1, 8, 256, 128)), ("k", (0, 0, 0, 0)), ("j", (0, 0, 0, 0))):
         m = configs.make_model(tag, tol=1e-5)
         assert _info(m, 1) == want, (tag, _info(m, 1))
-        assert _info(m, 2)[0] == 0
+        assert _info(m, 2)[0] == want[0] and _info(m, 3)[0] == 0      # (8 time slices: one workgroup per slab, two sets fit the chip)
         m.close()
+    # 160 time slices = 20 workgroups per slab: two sets of 6 slabs are 240 workgroups (fit), two sets of 8 are 320 (do not)
+    from elphdynamics_amd import lattice as lat
+    for Ls, pair in ((24, 1), (32, 0)):
+        configs.CONFIGS["_slab_rule"] = ("holstein", 1, Ls, lat.SQUARE_BONDS, 16.0, 0.1)
+        m = configs.make_model("_slab_rule", tol=1e-5)
+        assert _info(m, 1)[0] == 1 and _info(m, 2)[0] == pair
+        m.close()
+    configs.CONFIGS.pop("_slab_rule")
     m = configs.make_model("g", tol=1e-5, t_stddev=0.1)
     assert _info(m, 1)[0] == 1
     om = _oracle_model(oracle, m)

@@ -1,3 +1,4 @@
+"""(round 5) The slab form (slabs.hip) for every admissible slab count of L x L square lattices, Ltau = 160, one right-hand side: us per iteration of the streaming pair (1) and of the slab form (12).  The data of the rule in elph_i_slabs_usable.  usage: python3 tools/sweep_slabs.py"""
 import ctypes as C, os, sys, subprocess, json
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 def child(Ls, P):

@@ -44,6 +44,7 @@ for Ls in [int(a) for a in sys.argv[1:]] or [18, 20, 24, 28, 30, 32]:
         os.environ["ELPH_SLABS"] = mode
         x = np.zeros(m.Ndim)
         models.ldiv_(x, m, b)                      # warm
+        x[:] = 0.0
         t0 = time.perf_counter()
         it, resid, flag = models.ldiv_(x, m, b)
         res[mode] = (1e3 * (time.perf_counter() - t0), it, resid, flag, x.copy())
