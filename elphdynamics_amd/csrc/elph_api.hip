@@ -874,7 +874,7 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
         bool eligible = false;
         if (!use_prec) eligible = h->fast && maxiter >= 1 && elph_wg_usable(h, nullptr, nullptr, nullptr, nrhs);
         else { h->wg_broken = false; eligible = maxiter >= 1 && elph_pcg_wg_usable(h, nrhs); h->wg_broken = true; }      // (its shape test reads the flag itself)
-        if (!use_prec && !eligible && h->slabs && x0_zero && maxiter >= 1 && !eps_hist) {      // (the slab form of a large lattice, slabs.hip)
+        if (!use_prec && !eligible && h->slabs && x0_zero && maxiter >= 1) {      // (the slab form of a large lattice, slabs.hip)
             h->wg_broken = false; eligible = elph_i_slabs_usable(h, nrhs); h->wg_broken = true;
         }
         if (eligible) RC(elph_wg_cooldown_step(h));
@@ -914,10 +914,16 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
 
     // a lattice beyond one wave's slice: the resident kernel on slabs of rows of the lattice, all on this device, one launch per right-hand
     // side (slabs.hip).  x0 = 0 only (the slab kernel starts from it): ldiv!'s zero-fill.
-    if (!use_prec && maxiter >= 1 && x0_zero && !eps_hist && elph_i_slabs_usable(h, nrhs)) {
+    if (!use_prec && maxiter >= 1 && x0_zero && elph_i_slabs_usable(h, nrhs)) {
         bool ran = false;
         RC(elph_i_slabs_solve(h, nrhs, P, 0, iters, &ran, nullptr));
-        if (ran) return ELPH_OK;
+        if (ran) {
+            if (eps_hist) {
+                HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, sizeof(double) * (size_t)nrhs * (size_t)(maxiter + 1), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+            }
+            return ELPH_OK;
+        }
         RC(elph_launch_cg_init(h, nrhs, use_prec, true));      // (x is zero again: elph_i_slabs_solve)
     }
 
@@ -1187,7 +1193,7 @@ extern "C" int elph_cg_solve(elph_handle h, double *x, const double *b, double t
     const size_t bytes = (size_t)h->ndim * sizeof(double);
     HIPCHK(hipMemcpyAsync(h->d_stage_in, b, bytes, hipMemcpyHostToDevice, h->stream));
     RC(elph_launch_r2s(h, h->d_b, h->d_stage_in, 1));
-    if (!eps_hist && x0_is_zero(h, 1, use_precond, x)) {
+    if (x0_is_zero(h, 1, use_precond, x)) {
         HIPCHK(hipMemsetAsync(h->d_x, 0, bytes, h->stream));
         h->x_zero = true;
     } else {

@@ -266,7 +266,9 @@ static int shard_run(elph_handle_s *h, const double *b_slab, double tol, int64_t
 // the solutions stay in the slabs' d_x.  Everything is queued on the ONE stream the slab handles share — the mailboxes are zeroed, the
 // Krylov vectors seeded and the kernel launched in stream order, so no barrier is needed between "prepare" and "solve".
 int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, int nsets, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
-                           long long fixed_iters, long long timeout_ms, CgState *state_out, double *ms_out) {
+                           long long fixed_iters, long long timeout_ms, CgState *state_out, double *ms_out, double *const *hist_dev,
+                           long long hist_stride) {
+    // hist_dev[set] (optional): device array of hist_stride values that takes the eps history of that set's solve (entry 0, eps0, is the caller's)
     // hs[set * P + q]: `nsets` independent solves (each over its own P slabs and their mailboxes) in the one launch
     if (P < 2 || P > ELPH_SHARD_MAXRANKS || nsets < 1 || nsets > 2) { elph_set_error("bad rank count %d x %d", nsets, P); return ELPH_E_ARG; }
     const int PT = P * nsets;
@@ -274,7 +276,7 @@ int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, int nsets, void *h_a
     std::vector<CgBufs> Bs((size_t)PT);
     std::vector<ElphShardCtl> ctls((size_t)PT);
     CgParams Pm;
-    Pm.tol = tol; Pm.kmax = kmax; Pm.maxiter = maxiter; Pm.use_prec = 0; Pm.record_hist = 0; Pm.hist_stride = 0;
+    Pm.tol = tol; Pm.kmax = kmax; Pm.maxiter = maxiter; Pm.use_prec = 0; Pm.record_hist = hist_dev ? 1 : 0; Pm.hist_stride = hist_dev ? hist_stride : 0;
     for (int q = 0; q < PT; ++q) {
         elph_handle_s *h = hs[q];
         ShardState *S = static_cast<ShardState *>(h->shard);
@@ -291,6 +293,7 @@ int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, int nsets, void *h_a
         HIPCHK(hipMemsetAsync(h->d_state, 0, 2 * sizeof(CgState), st));
         Bs[(size_t)q] = elph_make_bufs(h, 1);
         Bs[(size_t)q].params = Pm;
+        if (hist_dev) Bs[(size_t)q].hist = hist_dev[q / P];      // (workgroup 0 of rank 0 writes; every rank runs the exact stop arithmetic)
         ctls[(size_t)q] = S->ctl;
         S->prepared = false;
     }

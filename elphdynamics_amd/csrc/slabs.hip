@@ -274,8 +274,10 @@ int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long 
         HIPCHK(hipGetLastError());
         CgState st[2];
         double ms = 0.0;
+        double *hist[2] = {nullptr, nullptr};
+        if (P.record_hist) for (int k = 0; k < ns; ++k) hist[k] = h->d_hist + (size_t)(r + k) * (size_t)P.hist_stride;
         const int rc = elph_i_shard_run_ranks(S->hs.data(), Pq, ns, S->h_args, S->d_args, P.tol, P.maxiter, P.kmax, fixed_iters, timeout_ms, st,
-                                              ms_out ? &ms : nullptr);
+                                              ms_out ? &ms : nullptr, P.record_hist ? hist : nullptr, P.hist_stride);
         if (rc == ELPH_E_UNSUPPORTED) {                  // the slabs do not take the sharded kernel's lane-program form: never again
             elph_i_slabs_free(h);
             HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
