@@ -1599,9 +1599,9 @@ int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long lon
         wg::Shape sh;
         const int rc = shard_rank_setup(hs[q], Bs[q], fixed_iters, ctls[q], A[(size_t)q].m, sh, A[(size_t)q].R);
         if (rc) return rc;
-        if (sh.gr || sh.hg || hs[q]->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("slabs on one device: lane-program form, site phonons"); return ELPH_E_UNSUPPORTED; }
+        if (sh.hg || hs[q]->kind != ELPH_MODEL_HOLSTEIN) { elph_set_error("slabs on one device: lane-program or GRID form, site phonons"); return ELPH_E_UNSUPPORTED; }
         if (q == 0) sh0 = sh;
-        else if (sh.npl != sh0.npl || sh.W != sh0.W || sh.G != sh0.G || sh.shm != sh0.shm) { elph_set_error("slabs on one device: slab %d has another shape", q); return ELPH_E_UNSUPPORTED; }
+        else if (sh.npl != sh0.npl || sh.W != sh0.W || sh.G != sh0.G || sh.shm != sh0.shm || sh.gr != sh0.gr) { elph_set_error("slabs on one device: slab %d has another shape", q); return ELPH_E_UNSUPPORTED; }
         uni = uni && A[(size_t)q].m.uniform;
         if (timeout_ms > 0) A[(size_t)q].R.timeout_ticks = timeout_ms * 100000LL;      // (slabs of one device: a streaming fallback exists, the short bound)
         A[(size_t)q].B = Bs[q];
@@ -1619,6 +1619,11 @@ int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long lon
         if (e == hipSuccess) { hipLaunchKernelGGL(kfn, grid, block, sh0.shm, stream, Bs[0], A[0].m, R0, ctls[0]); e = hipGetLastError(); } \
     } while (0)
 #define RANKS_CASE(NPLV) case NPLV: if (uni) RANKS_LAUNCH(NPLV, true); else RANKS_LAUNCH(NPLV, false); break;
+    if (sh0.gr) {      // slabs closed into rings: periodic rectangles in the reference's colouring, the GRID form (2 x 2 patches per lane)
+        auto kfn = wg::k_cg_wg<4, 1, false, true, 5, true, false, true>;
+        e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh0.shm);
+        if (e == hipSuccess) { hipLaunchKernelGGL(kfn, grid, block, sh0.shm, stream, Bs[0], A[0].m, R0, ctls[0]); e = hipGetLastError(); }
+    } else
     switch (sh0.npl) {
         RANKS_CASE(1) RANKS_CASE(2) RANKS_CASE(3) RANKS_CASE(4)
         default: if (uni) RANKS_LAUNCH(5, true); else RANKS_LAUNCH(5, false); break;

@@ -32,6 +32,7 @@ struct SlabSet {
     int P = 0, Nloc = 0, own_lo = 0, own_n = 0, hi = 0;
     int nsets = 0;                          // sets of P slab handles: set k solves right-hand side k of a pair in the same launch (own mailboxes)
     int G = 0;                              // workgroups per slab
+    int ring_row = 0;                       // > 0: sites per row of the recognised square lattice — the slabs are closed into rings (add_set)
     std::vector<elph_handle_s *> hs;        // [nsets][P]
     std::vector<int *> d_g;                 // [P][Nloc] site of the parent lattice of every slab site
     void *h_args = nullptr, *d_args = nullptr;
@@ -61,6 +62,11 @@ void closure(const elph_handle_s *h, int start, int n, std::vector<char> &S, std
     };
     for (int b = 0; b < nb; ++b) visit(b);             // M^T backwards (bond 0 was applied last) ...
     for (int b = nb - 1; b >= 0; --b) visit(b);        // ... then M backwards
+}
+
+bool uniform_hop(const elph_handle_s *h) {
+    for (int64_t n = 1; n < h->nb; ++n) if (h->h_c[(size_t)n] != h->h_c[0] || h->h_s[(size_t)n] != h->h_s[0]) return false;
+    return h->nb > 0;
 }
 
 void free_set(SlabSet *S) {
@@ -110,14 +116,47 @@ int add_set(elph_handle_s *h, SlabSet *S) {
         closure(h, q * n, n, Cs, need);
         std::vector<int64_t> tab;
         std::vector<double> c, s;
-        for (int b = 0; b < nb; ++b) {
-            const int i = loc[(size_t)h->h_bi[(size_t)b]], j = loc[(size_t)h->h_bj[(size_t)b]];
-            if (i < 0 || j < 0) {
-                if (need[(size_t)b]) { elph_set_error("slabs: a bond the own sites depend on leaves the slab"); rc = ELPH_E_UNSUPPORTED; break; }
-                continue;
+        // THE RING (as sharded.py: SpatialSlabs(ring=True)): on a square lattice the library recognised (row = L sites) the bonds that leave
+        // the slab through its last row re-enter at its first row — the own sites do not see the difference (the ring bond lies beyond the
+        // closure that fixed the ghost rows; it only stirs the outermost ghost rows, whose values nothing reads), but the slab becomes a
+        // periodic rectangle in the reference's colouring, which the GRID form of the resident kernel takes (2 x 2 patches in registers
+        // instead of the lane program's LDS slabs).  Kept only if it leaves the colouring alone.
+        for (int pass = (S->ring_row > 0 ? 0 : 1); pass < 2; ++pass) {
+            const bool ring = pass == 0;
+            tab.clear(); c.clear(); s.clear();
+            const int row = S->ring_row, top = g[(size_t)Nloc - 1];          // (the slab's last site)
+            for (int b = 0; b < nb; ++b) {
+                int i = loc[(size_t)h->h_bi[(size_t)b]], j = loc[(size_t)h->h_bj[(size_t)b]];
+                if (ring && (i < 0) != (j < 0)) {
+                    const int in = (i < 0) ? j : i, out = (i < 0) ? h->h_bi[(size_t)b] : h->h_bj[(size_t)b];
+                    const int k = ((out - top - 1) % N + N) % N;              // the outer end is site k of the row above the slab
+                    if (in >= Nloc - row && k < row) { if (i < 0) i = k; else j = k; }
+                }
+                if (i < 0 || j < 0) {
+                    if (need[(size_t)b]) { elph_set_error("slabs: a bond the own sites depend on leaves the slab"); rc = ELPH_E_UNSUPPORTED; break; }
+                    continue;
+                }
+                tab.push_back(i + 1); tab.push_back(j + 1);
+                c.push_back(h->h_c[(size_t)b]); s.push_back(h->h_s[(size_t)b]);
             }
-            tab.push_back(i + 1); tab.push_back(j + 1);
-            c.push_back(h->h_c[(size_t)b]); s.push_back(h->h_s[(size_t)b]);
+            if (rc || !ring) break;
+            // colours = maximal runs of site-disjoint bonds (elph_create): the ring must not add one
+            auto ncolours = [&](const std::vector<int64_t> &t) {
+                std::vector<char> used((size_t)Nloc, 0);
+                int nc = t.empty() ? 0 : 1;
+                for (size_t b2 = 0; b2 + 1 < t.size(); b2 += 2) {
+                    const size_t a = (size_t)t[b2] - 1, d = (size_t)t[b2 + 1] - 1;
+                    if (used[a] || used[d]) { ++nc; std::fill(used.begin(), used.end(), 0); }
+                    used[a] = used[d] = 1;
+                }
+                return nc;
+            };
+            std::vector<int64_t> open_tab;
+            for (int b = 0; b < nb; ++b) {
+                const int i = loc[(size_t)h->h_bi[(size_t)b]], j = loc[(size_t)h->h_bj[(size_t)b]];
+                if (i >= 0 && j >= 0) { open_tab.push_back(i + 1); open_tab.push_back(j + 1); }
+            }
+            if (ncolours(tab) == ncolours(open_tab)) break;      // the ring stands
         }
         if (rc) break;
         elph_handle sh = nullptr;
@@ -149,6 +188,16 @@ int add_set(elph_handle_s *h, SlabSet *S) {
 int build(elph_handle_s *h, int P, int lo, int hi, int G, SlabSet **out) {
     SlabSet *S = new SlabSet();
     S->P = P; S->Nloc = lo + (int)h->N / P + hi; S->own_lo = lo; S->own_n = (int)h->N / P; S->hi = hi; S->G = G;
+    {   // rings on a recognised square lattice whose slabs are whole rows: an even number of them, at least four, at most 64 lanes of 2 x 2 patches.
+        // OPT-IN (ELPH_SLABS_RING=1): measured slower — the GRID form of the sharded kernel sits at 256 registers with scratch: 15.5 us per
+        // iteration against 11.0 (24 x 24) / 12.5 (32 x 32) in the lane program (profiles/r05/slabs_resident_large_lattices.log)
+        const char *er = getenv("ELPH_SLABS_RING");
+        const int row = (h->pg_kind == 1) ? h->pg_L : 0;
+        if ((er && er[0] == '1') && row > 0 && (int64_t)row * row == h->N && S->Nloc % row == 0 && lo % row == 0 && S->own_n % row == 0 && (row & 1) == 0) {
+            const int rows = S->Nloc / row;
+            if (rows >= 4 && (rows & 1) == 0 && (row / 2) * (rows / 2) <= 64 && uniform_hop(h)) S->ring_row = row;
+        }
+    }
     int rc = add_set(h, S);
     if (rc == ELPH_OK) {
         const size_t bytes = 2 * (size_t)P * elph_wg_rank_args_bytes();

@@ -21,7 +21,7 @@ def _info(m, nrhs=1):
 
 @pytest.fixture
 def slabs_env():
-    old = {k: os.environ.get(k) for k in ("ELPH_SLABS", "ELPH_SLABS_P")}
+    old = {k: os.environ.get(k) for k in ("ELPH_SLABS", "ELPH_SLABS_P", "ELPH_SLABS_RING")}
     yield
     for k, v in old.items():
         if v is None:
@@ -121,3 +121,25 @@ def test_slab_rule_and_hopping_disorder(oracle, slabs_env):
     xo2, ito2, *_ = oracle.ldiv(om2, b, solver_tol=1e-13, solver_maxiter=10000)
     assert flag2 == 0 and abs(it2 - ito2) <= max(3, ito2 // 100) and rel(x2, xo2) < 1e-10
     m.close()
+
+
+def test_slabs_closed_into_rings_take_the_grid_form(oracle, slabs_env):
+    """ELPH_SLABS_RING=1 (opt-in: measured slower): on a recognised square lattice the slabs are closed into rings — periodic rectangles in the
+    reference's colouring, the GRID form of the sharded kernel; the own sites do not see the ring bond.  Same solve."""
+    from elphdynamics_amd import configs, models
+    os.environ["ELPH_SLABS"] = "1"
+    res = {}
+    for ring in ("0", "1"):
+        os.environ["ELPH_SLABS_RING"] = ring
+        m = configs.make_model("G", tol=1e-13)
+        _, B = configs.rhs(m, 1)
+        b = np.ascontiguousarray(B[0])
+        x = np.zeros(m.Ndim)
+        it, r, flag = models.ldiv_(x, m, b)
+        assert flag == 0
+        res[ring] = (it, x)
+        if ring == "1":
+            xo, ito, *_ = oracle.ldiv(_oracle_model(oracle, m), b, solver_tol=1e-13, solver_maxiter=10000)
+            assert abs(it - ito) <= max(3, ito // 100) and rel(x, xo) < 1e-10
+        m.close()
+    assert abs(res["0"][0] - res["1"][0]) <= 2 and rel(res["0"][1], res["1"][1]) < 1e-10 and not np.array_equal(res["0"][1], res["1"][1])
