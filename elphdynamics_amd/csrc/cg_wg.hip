@@ -1611,7 +1611,10 @@ int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long lon
     HIPCHK(hipMemcpyAsync(d_args, A, (size_t)P * sizeof(wg::WgRankArgs), hipMemcpyHostToDevice, stream));
     wg::WgCtl R0 = A[0].R;
     R0.ranks = d_args;
-    const dim3 grid((unsigned)(P * sh0.G)), block((unsigned)(sh0.W * WAVE));
+    // (tests, ELPH_SLABS_TEST_TIMEOUT=2: the last rank's workgroups are NOT launched — the others wait for them until their bound and give up)
+    const char *edrop = getenv("ELPH_SLABS_TEST_TIMEOUT");
+    const int drop = (edrop && edrop[0] == '2') ? 1 : 0;
+    const dim3 grid((unsigned)((P - drop) * sh0.G)), block((unsigned)(sh0.W * WAVE));
     hipError_t e = hipSuccess;
 #define RANKS_LAUNCH(NPLV, UNIV) do {                                                                                                  \
         auto kfn = wg::k_cg_wg<NPLV, 1, false, UNIV, 0, true, false, true>;                                                            \

@@ -315,6 +315,8 @@ int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long 
     }
     const char *et = getenv("ELPH_WG_TIMEOUT_MS");
     const long long timeout_ms = et ? std::max(1, atoi(et)) : 2000;
+    const char *etest = getenv("ELPH_SLABS_TEST_TIMEOUT");
+    const bool test_give_up = etest && etest[0] == '1';      // (tests: 1 = the launch is taken to have given up — the host side of a time-out; 2 = a real one, cg_wg.hip)
     double ms_sum = 0.0;
     for (int r = 0; r < nrhs;) {
         const int ns = (pairs && r + 1 < nrhs) ? 2 : 1;        // right-hand sides of this launch
@@ -325,8 +327,9 @@ int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long 
         double ms = 0.0;
         double *hist[2] = {nullptr, nullptr};
         if (P.record_hist) for (int k = 0; k < ns; ++k) hist[k] = h->d_hist + (size_t)(r + k) * (size_t)P.hist_stride;
-        const int rc = elph_i_shard_run_ranks(S->hs.data(), Pq, ns, S->h_args, S->d_args, P.tol, P.maxiter, P.kmax, fixed_iters, timeout_ms, st,
-                                              ms_out ? &ms : nullptr, P.record_hist ? hist : nullptr, P.hist_stride);
+        int rc = elph_i_shard_run_ranks(S->hs.data(), Pq, ns, S->h_args, S->d_args, P.tol, P.maxiter, P.kmax, fixed_iters, timeout_ms, st,
+                                        ms_out ? &ms : nullptr, P.record_hist ? hist : nullptr, P.hist_stride);
+        if (test_give_up && rc == ELPH_OK) rc = ELPH_E_HIP;
         if (rc == ELPH_E_UNSUPPORTED) {                  // the slabs do not take the sharded kernel's lane-program form: never again
             elph_i_slabs_free(h);
             HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));

@@ -143,3 +143,54 @@ def test_slabs_closed_into_rings_take_the_grid_form(oracle, slabs_env):
             assert abs(it - ito) <= max(3, ito // 100) and rel(x, xo) < 1e-10
         m.close()
     assert abs(res["0"][0] - res["1"][0]) <= 2 and rel(res["0"][1], res["1"][1]) < 1e-10 and not np.array_equal(res["0"][1], res["1"][1])
+
+
+@pytest.mark.parametrize("how", ["1", "2"])
+def test_slab_time_out_falls_back_and_comes_back(slabs_env, how):
+    """A slab launch that gives up (ELPH_SLABS_TEST_TIMEOUT: 1 = forced on the host side, 2 = a real one — the last slab's workgroups are
+    not launched and the others wait for them until their bound, 200 ms here) is re-solved by the streaming iteration — the solution is the
+    streaming form's, the handle counts the event, cools down for 16 eligible solves and then takes the slab form again."""
+    from elphdynamics_amd import configs, models
+    from elphdynamics_amd._lib import check
+    os.environ.pop("ELPH_SLABS", None)
+    m = configs.make_model("G", tol=1e-9)
+    _, B = configs.rhs(m, 1)
+    b = np.ascontiguousarray(B[0])
+
+    def solve():
+        x = np.zeros(m.Ndim)
+        it, res, flag = models.ldiv_(x, m, b)
+        assert flag == 0
+        cd, fb = C.c_int(), C.c_int64()
+        check(m._lib.elph_wg_status(m._h, C.byref(cd), C.byref(fb)))
+        return x, it, cd.value, fb.value
+
+    x_slab, it_slab, cd, fb = solve()
+    assert cd == 0 and fb == 0
+    os.environ["ELPH_SLABS"] = "0"
+    x_str, it_str, _, _ = solve()
+    os.environ.pop("ELPH_SLABS")
+    assert not np.array_equal(x_slab, x_str) and rel(x_slab, x_str) < 1e-7
+    os.environ["ELPH_SLABS_TEST_TIMEOUT"] = how
+    old_to = os.environ.get("ELPH_WG_TIMEOUT_MS")
+    os.environ["ELPH_WG_TIMEOUT_MS"] = "200"
+    try:
+        x1, it1, cd1, fb1 = solve()
+    finally:
+        os.environ.pop("ELPH_SLABS_TEST_TIMEOUT")
+        if old_to is None:
+            os.environ.pop("ELPH_WG_TIMEOUT_MS")
+        else:
+            os.environ["ELPH_WG_TIMEOUT_MS"] = old_to
+    assert fb1 == 1 and cd1 > 0 and np.array_equal(x1, x_str) and it1 == it_str        # given up, re-solved by the streaming iteration
+    seen_slab_again = False
+    for k in range(20):
+        x, it, cd, fb = solve()
+        assert fb == 1
+        if np.array_equal(x, x_slab):
+            seen_slab_again = True
+            assert cd == 0 and k >= 15
+            break
+        assert np.array_equal(x, x_str) and cd > 0
+    assert seen_slab_again
+    m.close()
