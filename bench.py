@@ -186,8 +186,10 @@ def main():
     check(lib.elph_bench_wg_info(m._h, nrhs, C.byref(wg_us), C.byref(wg_T), C.byref(wg_W), C.byref(wg_G)))
     resident = bool(wg_us.value) and not args.precond and not args.streaming
     what = 3 if args.precond else (9 if resident else 1)
-    # a KPM-preconditioned batch from 192 right-hand sides runs as two half-batches on two streams (elph_api.hip: SplitRun): time that form
-    two_streams = bool(args.precond and nrhs >= 192 and os.environ.get("ELPH_SPLIT_STREAMS") != "0")
+    # a KPM-preconditioned batch from 192 right-hand sides (128 on lattices of five sites per lane: config D) runs as two half-batches on two
+    # streams (elph_api.hip: SplitRun, split_wanted): time that form
+    split_from = 128 if (m.Nsites + 63) // 64 >= 5 else 192
+    two_streams = bool(args.precond and nrhs >= split_from and os.environ.get("ELPH_SPLIT_STREAMS") != "0")
     P = None
     if args.precond:      # one KPM expansion per chain (its own Ē, spectrum bounds, orders and coefficients)
         P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
@@ -396,7 +398,7 @@ def main():
                     rp["precond_iter_us_one_stream"] = rp["precond_iter_us"]
                     us2 = 1e3 * run(11, nrhs, 320) / 320
                     rp["precond_iter_us_two_streams"] = us2
-                    if nrhs >= 192 and os.environ.get("ELPH_SPLIT_STREAMS") != "0":       # what a solve of this batch runs
+                    if nrhs >= split_from and os.environ.get("ELPH_SPLIT_STREAMS") != "0":       # what a solve of this batch runs
                         rp["precond_iter_us"] = us2
                         rp["precond_iter_hbm_frac"] = byts[3] / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS
                 except Exception as e:

@@ -20,7 +20,7 @@ def child(Ls, P):
         except Exception as e:
             out[what] = str(e)[:80]
     print("RESULT", Ls, P, out, flush=True)
-if len(sys.argv) > 2:
+if len(sys.argv) > 2:      # (child: lattice size and the slab count it was started for — 0: whatever the environment says)
     child(int(sys.argv[1]), int(sys.argv[2]))
 else:
     for Ls in (18, 20, 24, 28, 30, 32):

@@ -96,7 +96,7 @@ def main():
         for n in (sizes[::2] if quick else sizes):
             auto1 = child(tag, n, "prec", {"ELPH_SPLIT_STREAMS": "0"})
             auto2 = child(tag, n, "prec2", {})
-            lib_pick = auto2 if (n >= 192 and auto2.get("us")) else auto1
+            lib_pick = auto2 if (n >= (128 if tag == "D" else 192) and auto2.get("us")) else auto1      # (elph_api.hip: split_wanted)
             alts = {}
             for T in (8, 16, 20):
                 for w in ("prec", "prec2"):
@@ -111,6 +111,33 @@ def main():
             print(f"{tag} nrhs {n:4d}: library T={lib_pick.get('T')} px={lib_pick.get('px')} {'two streams' if lib_pick is auto2 else 'one stream'} "
                   f"{lib_pick.get('us') or float('nan'):8.2f} (one stream {auto1.get('us') or float('nan'):.2f}, two {auto2.get('us') or float('nan'):.2f}) | " +
                   ", ".join(f"{k} {v['us']:.2f}" for k, v in sorted(alts.items())) + mark, flush=True)
+    print("== lattices beyond 320 sites, one right-hand side from x = 0: the slab form (slabs.hip) vs the streaming pair, us per CG iteration (Ltau = 160)")
+    sweep = os.path.join(ROOT, "tools", "sweep_slabs.py")
+    for Ls in ((24, 32) if quick else (18, 20, 24, 28, 30, 32)):
+        res = {}
+        for mode, env in (("library", {}), ("streaming", {"ELPH_SLABS": "0"}), ("slabs forced", {"ELPH_SLABS": "1"})):
+            e = dict(os.environ, ELPH_WG_TIMEOUT_MS="500")
+            for k in ("ELPH_SLABS", "ELPH_SLABS_P"):
+                e.pop(k, None)
+            e.update(env)
+            p = subprocess.run([sys.executable, sweep, str(Ls), "0"], env=e, capture_output=True, text=True, timeout=300)
+            for line in p.stdout.splitlines():
+                if line.startswith("RESULT"):
+                    d = eval(line.split(None, 3)[3])
+                    # what = 12 is the slab form where the mode admits it; the library's own pick: the slab form if its rule takes the lattice
+                    res[mode] = d
+        lib_us = res.get("library", {}).get(12)
+        lib_form = "slabs" if isinstance(lib_us, float) else "streaming"
+        if lib_form == "streaming":
+            lib_us = res.get("library", {}).get(1)
+        alts = {"streaming": res.get("streaming", {}).get(1), "slabs": res.get("slabs forced", {}).get(12)}
+        alts = {k: v for k, v in alts.items() if isinstance(v, float)}
+        best = min(alts.items(), key=lambda kv: kv[1])
+        mark = ""
+        if isinstance(lib_us, float) and best[1] < 0.92 * lib_us:
+            mark = f"   <-- {best[0]} is {100 * (1 - best[1] / lib_us):.0f} % faster"
+            flagged.append((f"square {Ls}x{Ls}", 1, lib_form, best))
+        print(f"square {Ls} x {Ls}: library picks {lib_form:9s} {lib_us if isinstance(lib_us, float) else float('nan'):7.2f} | " + ", ".join(f"{k} {v:.2f}" for k, v in alts.items()) + mark, flush=True)
     print(f"== {len(flagged)} decision(s) flagged (> 8 % slower than an alternative on this box)")
     for f in flagged:
         print("   ", f)
