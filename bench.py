@@ -186,9 +186,9 @@ def main():
     check(lib.elph_bench_wg_info(m._h, nrhs, C.byref(wg_us), C.byref(wg_T), C.byref(wg_W), C.byref(wg_G)))
     resident = bool(wg_us.value) and not args.precond and not args.streaming
     what = 3 if args.precond else (9 if resident else 1)
-    # a KPM-preconditioned batch from 192 right-hand sides (128 on lattices of five sites per lane: config D) runs as two half-batches on two
+    # a KPM-preconditioned batch from 192 right-hand sides (64 on lattices of five and more sites per lane: config D) runs as two half-batches on two
     # streams (elph_api.hip: SplitRun, split_wanted): time that form
-    split_from = 128 if (m.Nsites + 63) // 64 >= 5 else 192
+    split_from = 64 if (m.Nsites + 63) // 64 >= 5 else 192
     two_streams = bool(args.precond and nrhs >= split_from and os.environ.get("ELPH_SPLIT_STREAMS") != "0")
     P = None
     if args.precond:      # one KPM expansion per chain (its own Ē, spectrum bounds, orders and coefficients)

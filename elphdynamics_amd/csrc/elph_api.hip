@@ -814,8 +814,9 @@ static bool split_wanted(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
     if (e && e[0] == '0') return false;
     if (!split_legal(h, nrhs, use_prec, hist)) return false;
     // (config C, 128 right-hand sides: 130 us either way, profiles/r05/px_chunk_T.log; five sites per lane — the honeycomb lattice of config D,
-    //  whose fused kernel stays at two waves per SIMD — gains from 128: 131 -> 116 us, 256: 262 -> 230, profiles/r05/px_fused_five_sites_per_lane.log)
-    return (e && e[0] == '1') || nrhs >= (h->npl >= 5 ? 128 : 192);
+    //  whose fused kernel stays at two waves per SIMD — gains from 64 on: D 128: 131 -> 116 us, 256: 262 -> 230, profiles/r05/px_fused_five_sites_per_lane.log;
+    //  honeycomb 16 x 16 cells, eight sites per lane: 64 right-hand sides 64 -> 55 us, 256: 159 -> 145; D at 64: 89 -> 87)
+    return (e && e[0] == '1') || nrhs >= (h->npl >= 5 ? 64 : 192);
 }
 
 // after elph_launch_cg_init(h, nrhs, 1, …) on the main stream

@@ -2,8 +2,9 @@
 import os, sys, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
 import validate_form_choice as v
-for tag in ("D",):
-    for n in (64, 128, 256):
+import sys as _s
+for tag in (_s.argv[1:] or ["D"]):
+    for n in (64, 128, 256, 512):
         row = {}
         for name, env, w in (("px 1 stream", {"ELPH_SPLIT_STREAMS": "0"}, "prec"), ("px 2 streams", {}, "prec2"),
                              ("unfused 1 stream", {"ELPH_FUSE_PX": "0", "ELPH_SPLIT_STREAMS": "0"}, "prec"),

@@ -96,7 +96,7 @@ def main():
         for n in (sizes[::2] if quick else sizes):
             auto1 = child(tag, n, "prec", {"ELPH_SPLIT_STREAMS": "0"})
             auto2 = child(tag, n, "prec2", {})
-            lib_pick = auto2 if (n >= (128 if tag == "D" else 192) and auto2.get("us")) else auto1      # (elph_api.hip: split_wanted)
+            lib_pick = auto2 if (n >= (64 if tag == "D" else 192) and auto2.get("us")) else auto1      # (elph_api.hip: split_wanted)
             alts = {}
             for T in (8, 16, 20):
                 for w in ("prec", "prec2"):
