@@ -194,3 +194,56 @@ def test_slab_time_out_falls_back_and_comes_back(slabs_env, how):
         assert np.array_equal(x, x_str) and cd > 0
     assert seen_slab_again
     m.close()
+
+
+def test_slab_form_edge_cases_match_the_streaming_iteration(slabs_env):
+    """ldiv!'s outcomes other than convergence, through the slab form and through the streaming pair: an iteration limit that is reached
+    (flag and zero-fill, Models.jl:150-186), the κ stop, a zero right-hand side, and solve!'s residual history (IterativeSolvers.jl:286-295)."""
+    from elphdynamics_amd import configs, models
+    m = configs.make_model("G", tol=1e-9, maxiter=10000)
+    _, B = configs.rhs(m, 1)
+    b = np.ascontiguousarray(B[0])
+
+    def both(fn):
+        out = {}
+        for mode in ("1", "0"):
+            os.environ["ELPH_SLABS"] = mode
+            out[mode] = fn()
+        return out["1"], out["0"]
+
+    # the iteration limit: same count, same flag, same zero-fill
+    def limited():
+        x = np.full(m.Ndim, 0.0)
+        it, res, flag = models.ldiv_(x, m, b, maxiter=7)
+        return it, flag, float(np.abs(x).max()), res
+    a, s = both(limited)
+    assert a[0] == s[0] == 7 and a[1] == s[1] and a[1] != 0 and (a[2] == 0.0) == (s[2] == 0.0) and abs(a[3] - s[3]) <= 1e-9 * abs(s[3])
+
+    # a zero right-hand side is 0/0 in the reference's CG as well (eps = |r| / |b|, alpha = r.r / p.Ap: IterativeSolvers.jl:259-285 — it runs
+    # to the iteration limit on NaNs): both forms do exactly that, with the same count and flag
+    def zero_rhs():
+        x = np.zeros(m.Ndim)
+        it, res, flag = models.ldiv_(x, m, np.zeros(m.Ndim), maxiter=50)
+        return it, flag, bool(np.isnan(x).all())
+    a, s = both(zero_rhs)
+    assert a == s
+
+    # solve! with its history: the same eps sequence to rounding, the same count
+    def hist():
+        x = np.zeros(m.Ndim)
+        it, h = models.solve_(x, m, b, tol=1e-9, history=True)
+        return it, h, x
+    a, s = both(hist)
+    assert abs(a[0] - s[0]) <= 1
+    n = min(a[0], s[0], 41)
+    assert np.max(np.abs(a[1][:n] - s[1][:n]) / s[1][:n]) < 1e-10 and a[1][0] == s[1][0] == 1.0
+    assert a[1][a[0]] < 1e-9 <= a[1][a[0] - 1]
+    assert rel(a[2], s[2]) < 1e-7
+
+    # the kappa stop (IterativeSolvers.jl:289-295): a tiny kappa_max ends both forms at the same early iteration
+    def kappa():
+        x = np.zeros(m.Ndim)
+        return models.solve_(x, m, b, tol=1e-9, kmax=4.0)
+    a, s = both(kappa)
+    assert a == s and 1 <= a < 41
+    m.close()

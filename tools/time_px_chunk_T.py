@@ -11,7 +11,7 @@ from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth
 
 nrhs = int(sys.argv[1]) if len(sys.argv) > 1 else 288
 lib = _lib.load()
-m = configs.make_model("C", tol=1e-5)
+m = configs.make_model(os.environ.get("ELPH_TIME_TAG", "C"), tol=1e-5)
 nch = nrhs // 2
 X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=100 + c) for c in range(nch)])
 models.update_model_chains_(m, X)
