@@ -247,3 +247,30 @@ def test_slab_form_edge_cases_match_the_streaming_iteration(slabs_env):
     a, s = both(kappa)
     assert a == s and 1 <= a < 41
     m.close()
+
+
+def test_hmc_update_on_a_large_lattice_through_the_slab_form(slabs_env):
+    """One un-preconditioned HMC update (HMC.jl:343-463) on the 24 x 24 lattice: the two pseudofermion systems of every force / action
+    evaluation run as two sets of slabs in one launch (x0 = 0 is the library's own: fill!(O⁻¹Λϕ, 0), HMC.jl:854) — the same trajectory as
+    with the streaming pair, to the solver tolerance."""
+    from elphdynamics_amd import configs, hmc, preconditioners as pc
+    from test_gpu_hmc import _randoms
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["ELPH_SLABS"] = mode
+        m = configs.make_model("g", tol=1e-8, maxiter=40000)
+        fa = pc.FourierAccelerator(m)
+        pc.update_M_(fa, m, 0.0, np.inf, 1.0, 0.3)
+        dt, nt = 0.02, 2
+        H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt)
+        acc, its = hmc.update_(m, H, fa, None, randoms=_randoms(m, nt, 1500, False, 0.0))
+        assert H.flag == 0
+        if mode == "1":
+            use, P, nloc, own = _info(m, 2)
+            assert use == 1 and P == 6
+        out[mode] = (acc, its, H.H0, H.H1, m.x.copy(), H.v.copy())
+        m.close()
+    a, s = out["1"], out["0"]
+    assert a[0] == s[0] and abs(a[1] - s[1]) <= 1
+    assert abs(a[2] - s[2]) < 1e-9 * abs(s[2]) and abs(a[3] - s[3]) < 1e-8 * abs(s[3])
+    assert rel(a[4], s[4]) < 1e-7 and rel(a[5], s[5]) < 1e-7 and not np.array_equal(a[4], s[4])
