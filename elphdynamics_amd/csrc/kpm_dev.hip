@@ -288,7 +288,11 @@ __global__ void __launch_bounds__(WAVE) k_kpm_bounds(double *__restrict__ e_out 
     }
     LDS_ORDER();
     double best = INFINITY;
+#ifdef ELPH_KB_NOQR      // (timing experiment, wrong bounds: the Arnoldi process alone)
+    if (__all(finite)) best = Awork[0] + 1.0;
+#else
     if (__all(finite)) best = hess_max_real(Awork, l, lane);
+#endif
     if (lane == 0) {
         if (!inverse) e_out[2 * chain + 1] = best;                                   // e_max (:890-895)
         else e_out[2 * chain + 0] = isfinite(best) ? 1.0 / best : -INFINITY;         // e_min (:934-939)
