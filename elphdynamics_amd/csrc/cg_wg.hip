@@ -359,12 +359,12 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         wg_barrier();
         if (wv == 0) {
             const double mine = wg_sum(partA, W, lane);
-            sh_publish(Sh, 0, g, G, mine, 1u, lane);
+            sh_publish<RANKS>(Sh, 0, g, G, mine, 1u, lane);
             const u64 *none[NPL];
 #pragma unroll
             for (int q = 0; q < NPL; ++q) none[q] = nullptr;
             double tot = 0.0, dummy[NPL];
-            const bool ok = sh_poll<NPL>(Sh, true, 0, G, none, 1u, lane, R, tot, dummy);
+            const bool ok = sh_poll<NPL, RANKS>(Sh, true, 0, G, none, 1u, lane, R, tot, dummy);
             if (lane == 0) { bc[0] = tot; if (!ok) bc[2] = 0.0; }
         }
         wg_barrier();
@@ -597,11 +597,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 const u64 bits = (u64)__double_as_longlong(z[0][q]), tag = (u64)epoch << 32;
                 if (s >= Sh.own_lo && s < Sh.own_lo + Sh.n_to_prev) {              // bottom rows -> previous rank's ghosts above its own rows
                     u64 *d = sh_ghost(Sh.mail[prev], 1, L, Sh.cap_ghost, t0, s - Sh.own_lo) + ghp;
-                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                    st_mail<RANKS>(d, tag | (bits & 0xFFFFFFFFull)); st_mail<RANKS>(d + 1, tag | (bits >> 32));
                 }
                 if (s >= Sh.own_hi - Sh.n_to_next && s < Sh.own_hi) {              // top rows -> next rank's ghosts below its own rows
                     u64 *d = sh_ghost(Sh.mail[next], 0, L, Sh.cap_ghost, t0, s - (Sh.own_hi - Sh.n_to_next)) + ghp;
-                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                    st_mail<RANKS>(d, tag | (bits & 0xFFFFFFFFull)); st_mail<RANKS>(d + 1, tag | (bits >> 32));
                 }
             }
         }
@@ -654,9 +654,9 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     bool good = true;
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
-                        if (gaddr[q]) { a0[q] = ld_sys(gaddr[q] + ghp); a1[q] = ld_sys(gaddr[q] + ghp + 1); }
+                        if (gaddr[q]) { a0[q] = ld_mail<RANKS>(gaddr[q] + ghp); a1[q] = ld_mail<RANKS>(gaddr[q] + ghp + 1); }
                         if (bh) { h0[q] = ld_gran(bh + 2 * (lane + q * WAVE)); h1[q] = ld_gran(bh + 2 * (lane + q * WAVE) + 1); }
-                        if (ga2[q]) { c0[q] = ld_sys(ga2[q]); c1[q] = ld_sys(ga2[q] + 1); }
+                        if (ga2[q]) { c0[q] = ld_mail<RANKS>(ga2[q]); c1[q] = ld_mail<RANKS>(ga2[q] + 1); }
                     }
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                     const double mine = __shfl(t4, lane & 6, WAVE);            // lane l: the total of value (l & 7) >> 1
                     if (lane < 8 * Sh.P) {
                         const u64 bits = (u64)__double_as_longlong(mine);
-                        st_sys(Sh.mail[lane >> 3] + (size_t)SH_MAXREC * 2 + (size_t)par * 8 * REC4 + (size_t)Sh.rank * REC4 + (lane & 7),
+                        st_mail<RANKS>(Sh.mail[lane >> 3] + (size_t)SH_MAXREC * 2 + (size_t)par * 8 * REC4 + (size_t)Sh.rank * REC4 + (lane & 7),
                                ((u64)epoch << 32) | ((lane & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
                     }
                 }
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 long long t_start = 0;
                 for (int spin = 0;; ++spin) {
                     bool good = true;
-                    if (lane < REC4 * Sh.P) { v[0] = ld_sys(rankrec + lane); good = (unsigned)(v[0] >> 32) == epoch; }
+                    if (lane < REC4 * Sh.P) { v[0] = ld_mail<RANKS>(rankrec + lane); good = (unsigned)(v[0] >> 32) == epoch; }
                     if (__all(good)) break;
                     if (poll_bail<1>(spin, t_start, lane, R)) { ok = false; break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -794,12 +794,12 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
             wg_barrier();
             if constexpr (SHARD) {
                 if (wv == 0) {
-                    sh_publish(Sh, 0, g, G, wg_sum(partF, W, lane), epoch, lane);
+                    sh_publish<RANKS>(Sh, 0, g, G, wg_sum(partF, W, lane), epoch, lane);
                     const u64 *none[NPL];
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) none[q] = nullptr;
                     double t = 0.0, dummy[NPL];
-                    const bool ok = sh_poll<NPL>(Sh, true, 0, G, none, epoch, lane, R, t, dummy);
+                    const bool ok = sh_poll<NPL, RANKS>(Sh, true, 0, G, none, epoch, lane, R, t, dummy);
                     if (lane == 0) { tot[4] = t; if (!ok) tot[5] = 0.0; }
                 }
                 wg_barrier();
@@ -850,12 +850,12 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         if constexpr (SHARD) {
             if (wv == 0) {
                 const double mine = wg_sum(partA, W, lane);
-                sh_publish(Sh, 0, g, G, mine, epoch, lane);
+                sh_publish<RANKS>(Sh, 0, g, G, mine, epoch, lane);
                 const u64 *none[NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) none[q] = nullptr;
                 double tot = 0.0, dummy[NPL];
-                const bool ok = sh_poll<NPL>(Sh, true, 0, G, none, epoch, lane, R, tot, dummy);
+                const bool ok = sh_poll<NPL, RANKS>(Sh, true, 0, G, none, epoch, lane, R, tot, dummy);
                 if (lane == 0) { bc[0] = tot; if (!ok) bc[2] = 0.0; }
             }
             wg_barrier();
@@ -906,11 +906,11 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 const u64 bits = (u64)__double_as_longlong(rn[0][q]), tag = (u64)epoch << 32;
                 if (s >= Sh.own_lo && s < Sh.own_lo + Sh.n_to_prev) {              // bottom rows -> previous rank's ghosts above its own rows
                     u64 *d = sh_ghost(Sh.mail[prev], 1, L, Sh.cap_ghost, t0, s - Sh.own_lo);
-                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                    st_mail<RANKS>(d, tag | (bits & 0xFFFFFFFFull)); st_mail<RANKS>(d + 1, tag | (bits >> 32));
                 }
                 if (s >= Sh.own_hi - Sh.n_to_next && s < Sh.own_hi) {              // top rows -> next rank's ghosts below its own rows
                     u64 *d = sh_ghost(Sh.mail[next], 0, L, Sh.cap_ghost, t0, s - (Sh.own_hi - Sh.n_to_next));
-                    st_sys(d, tag | (bits & 0xFFFFFFFFull)); st_sys(d + 1, tag | (bits >> 32));
+                    st_mail<RANKS>(d, tag | (bits & 0xFFFFFFFFull)); st_mail<RANKS>(d + 1, tag | (bits >> 32));
                 }
             }
         }
@@ -934,8 +934,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         if constexpr (SHARD) {
             // every wave takes the ghost rows of its slice from the mailbox; wave 0 also trades the r.r records of all ranks
             double tot = 0.0, gv[NPL];
-            if (wv == 0) sh_publish(Sh, 1, g, G, wg_sum(partB, W, lane), epoch, lane);
-            bool ok = sh_poll<NPL>(Sh, wv == 0, 1, G, gaddr, epoch, lane, R, tot, gv);
+            if (wv == 0) sh_publish<RANKS>(Sh, 1, g, G, wg_sum(partB, W, lane), epoch, lane);
+            bool ok = sh_poll<NPL, RANKS>(Sh, wv == 0, 1, G, gaddr, epoch, lane, R, tot, gv);
 #pragma unroll
             for (int q = 0; q < NPL; ++q) if (gaddr[q]) rl[lane + q * WAVE] = gv[q];
             if (G > 1 && (wv == 0 || wv == W - 1)) {          // the tau-neighbour workgroup of this rank: its boundary slice (own rows; ghosts follow below)
@@ -954,7 +954,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                            : (s >= Sh.own_hi && s < N) ? sh_ghost(Sh.mail[Sh.rank], 1, L, Sh.cap_ghost, th, s - Sh.own_hi) : nullptr;
                 }
                 double t2 = 0.0, gv2[NPL];
-                ok = sh_poll<NPL>(Sh, false, 1, G, ga2, epoch, lane, R, t2, gv2) && ok;
+                ok = sh_poll<NPL, RANKS>(Sh, false, 1, G, ga2, epoch, lane, R, t2, gv2) && ok;
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) if (ga2[q]) hx[q] = gv2[q];
             }

@@ -603,16 +603,22 @@ constexpr size_t SH_REC_WORDS = 2 * (size_t)SH_MAXREC * 2;
 
 __device__ __forceinline__ void st_sys(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ u64 ld_sys(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// mailbox accesses of a sharded solve.  LOCAL: all ranks are slabs on THIS device (slabs.hip, k_cg_wg<..., RANKS>) and their mailboxes ordinary
+// device memory — agent scope, as the records of an un-sharded team (st_gran / ld_gran); otherwise another GPU may be the writer or the
+// reader: system scope on the uncached fine-grained mailbox
+template <bool LOCAL> __device__ __forceinline__ void st_mail(u64 *p, u64 v) { if constexpr (LOCAL) st_gran(p, v); else st_sys(p, v); }
+template <bool LOCAL> __device__ __forceinline__ u64 ld_mail(const u64 *p) { if constexpr (LOCAL) return ld_gran(p); else return ld_sys(p); }
 __device__ __forceinline__ u64 *sh_ghost(u64 *mail, int region, int L, int cap, int t, int k) {
     return mail + SH_REC_WORDS + (((size_t)region * L + t) * cap + k) * 2;
 }
 
 // wave 0 of a workgroup: store this workgroup's record of meeting m into every rank's mailbox
+template <bool LOCAL = false>
 __device__ __forceinline__ void sh_publish(const ShardCtl &Sh, int m, int g, int G, double mine, unsigned epoch, int lane) {
     if (lane < 2 * Sh.P) {
         const u64 bits = (u64)__double_as_longlong(mine);
         const int dest = lane >> 1, half = lane & 1;
-        st_sys(Sh.mail[dest] + ((size_t)m * SH_MAXREC + (size_t)Sh.rank * G + g) * 2 + half,
+        st_mail<LOCAL>(Sh.mail[dest] + ((size_t)m * SH_MAXREC + (size_t)Sh.rank * G + g) * 2 + half,
                ((u64)epoch << 32) | (half ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
     }
 }
@@ -620,7 +626,7 @@ __device__ __forceinline__ void sh_publish(const ShardCtl &Sh, int m, int g, int
 // poll the P G records of meeting m in the own mailbox (wave 0: rec = true) and this lane's ghost granules (gaddr[q] != nullptr);
 // on success `total` = sum of the records in (rank, workgroup) order and gv[q] = the ghost values.
 // Up to SH_MAXREC = 256 records = 512 granules: eight per lane (8 ranks x 20 workgroups at Ltau = 160 are 320 of them).
-template <int NPL>
+template <int NPL, bool LOCAL = false>
 __device__ __forceinline__ bool sh_poll(const ShardCtl &Sh, bool rec, int m, int G, const u64 *const (&gaddr)[NPL], unsigned epoch,
                                         int lane, const WgCtl &R, double &total, double (&gv)[NPL]) {
     constexpr int NV = 2 * SH_MAXREC / WAVE;
@@ -634,10 +640,10 @@ __device__ __forceinline__ bool sh_poll(const ShardCtl &Sh, bool rec, int m, int
         bool ok = true;
         if (rec) {
 #pragma unroll
-            for (int s = 0; s < NV; ++s) if (lane + WAVE * s < nrec2) v[s] = ld_sys(rbase + lane + WAVE * s);
+            for (int s = 0; s < NV; ++s) if (lane + WAVE * s < nrec2) v[s] = ld_mail<LOCAL>(rbase + lane + WAVE * s);
         }
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) if (gaddr[q]) { g0[q] = ld_sys(gaddr[q]); g1[q] = ld_sys(gaddr[q] + 1); }
+        for (int q = 0; q < NPL; ++q) if (gaddr[q]) { g0[q] = ld_mail<LOCAL>(gaddr[q]); g1[q] = ld_mail<LOCAL>(gaddr[q] + 1); }
         if (rec) {
 #pragma unroll
             for (int s = 0; s < NV; ++s) if (lane + WAVE * s < nrec2) ok = ok && (unsigned)(v[s] >> 32) == epoch;

@@ -170,6 +170,25 @@ extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own
     return ELPH_OK;
 }
 
+// slabs.hip: ALL ranks of this solve are slabs on this handle's device and run as one launch (k_cg_wg<..., RANKS>, agent-scope mailbox
+// accesses) — the mailbox becomes ordinary device memory (the fine-grained uncached allocation is what makes it visible to another GPU;
+// here it only makes every poll a trip to memory).  Between elph_shard_create and elph_shard_connect.
+int elph_i_shard_make_local(elph_handle_s *h) {
+    ShardState *S = static_cast<ShardState *>(h->shard);
+    if (!S || S->connected) { elph_set_error("elph_i_shard_make_local: between create and connect"); return ELPH_E_STATE; }
+    unsigned long long *fresh = nullptr;
+    HIPCHK(hipMalloc((void **)&fresh, S->mail_bytes));
+    HIPCHK(hipMemset(fresh, 0, S->mail_bytes));
+    {
+        std::lock_guard<std::mutex> lk(g_local_mu);
+        for (LocalMailbox &m : g_local_mail) if (m.ptr == S->mail) m.ptr = fresh;
+    }
+    (void)hipFree(S->mail);
+    S->mail = fresh;
+    S->ctl.mail[S->ctl.rank] = fresh;
+    return ELPH_OK;
+}
+
 extern "C" int elph_shard_connect(elph_handle h, const void *all_ipc_handles) {
     if (!h || !h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
     HIPCHK(hipSetDevice(h->device));

@@ -170,6 +170,8 @@ int add_set(elph_handle_s *h, SlabSet *S) {
         rc = elph_shard_create(sh, q, P, lo, n, /* to prev = its ghosts above */ hi, /* to next = its ghosts below */ lo, std::max(lo, hi), 0, 0, &zero,
                                ipc.data() + (size_t)q * ELPH_SHARD_IPC_BYTES);
         if (rc) break;
+        rc = elph_i_shard_make_local(sh);
+        if (rc) break;
         if (!S->d_g[(size_t)q] && (hipMalloc((void **)&S->d_g[(size_t)q], (size_t)Nloc * sizeof(int)) != hipSuccess ||
                                    hipMemcpy(S->d_g[(size_t)q], g.data(), (size_t)Nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)) {
             elph_set_error("slabs: allocation failed"); rc = ELPH_E_HIP; break;
