@@ -119,3 +119,22 @@ def test_every_environment_switch_is_in_the_design_table():
     table = design[design.index("## 9. Environment switches"):]
     missing = sorted(n for n in names if n not in table)
     assert len(names) > 30 and not missing, missing
+
+
+def test_tools_compile_and_are_indexed():
+    """Every helper under tools/ is valid Python (byte-compiles: they only run on the GPU box, where a syntax error costs a gpurun call) and has a
+    row in tools/README.md."""
+    import glob
+    import py_compile
+    import tempfile
+    readme = open(os.path.join(ROOT, "tools", "README.md")).read()
+    missing = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))):
+            py_compile.compile(f, cfile=os.path.join(tmp, os.path.basename(f) + "c"), doraise=True)
+            if "`" + os.path.basename(f) + "`" not in readme:
+                missing.append(os.path.basename(f))
+    for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh"))):
+        if "`" + os.path.basename(f) + "`" not in readme:
+            missing.append(os.path.basename(f))
+    assert not missing, missing
