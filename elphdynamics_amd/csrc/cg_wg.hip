@@ -1090,6 +1090,309 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
 #undef PHALO
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// THE ROW FORM (round 5): Holstein with uniform hopping on the 16 x 16 square lattice (config C), batches that take the 4-slices-per-wave
+// shape.  Same team protocol as k_cg_wg's single-meeting iteration (one 64-byte record per workgroup, boundary slices of z as granules,
+// r'.r' by the one-step identity, the same stop test) around ANOTHER layout of the vectors: a 16-lane DPP ROW holds ONE time slice —
+// lane (X, Y) = (l & 3, (l >> 2) & 3) a 4 x 4 patch of its sites, register q = cx + 4 cy — and the four rows of a wave four consecutive
+// slices, 32 slices per workgroup.  Per colour the even bonds and the inner odd bonds pair registers of a lane; only the patch edges
+// cross: x-odd by quad permutations, y-odd by row rotations — 16 DPP moves of an f64 per sweep of a slice, all inside the row (the 2 x 2
+// patches of k_cg_wg: 12 moves + 4 ds_bpermute per SLAB sweep, nine slab sweeps per mat-vec pair of four slices).  The tau shift, which
+// there is a renaming of registers (at the price of one halo sweep per wave), goes through LDS here: p of the slice below, then
+// t = sg k4 E o CB^T(M p) of the slice above, 16 ds_write_b64 + 16 ds_read_b64 each and a barrier.  Only the workgroup's TOP boundary needs
+// a redundant slice (m and t of the slice above its last one): one extra sweep pair, by the last wave.
+// Measured before it was built (tools/probes/matvec_row_layout_probe.cpp): 2.4 us per mat-vec pair + sums + updates of a round of the
+// chip against ~3.9 us of the 2 x 2 layout.
+namespace rowf {
+constexpr int SV = 256;                       // values of a slice
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) { return dpp_f64<CTRL>(v); }
+// one colour of the checkerboard on the 4 x 4 patch v[cx + 4 cy]: v <- (I + th P_colour) v.  COL 0: x-even, 1: x-odd, 2: y-even, 3: y-odd
+template <int COL>
+__device__ __forceinline__ void colour(double (&v)[16], double th) {
+    if constexpr (COL == 0) {
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 4; cx += 2) { const int i = cx + 4 * cy, j = i + 1; const double a = v[i] + th * v[j], b = v[j] + th * v[i]; v[i] = a; v[j] = b; }
+    } else if constexpr (COL == 2) {
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx)
+#pragma unroll
+            for (int cy = 0; cy < 4; cy += 2) { const int i = cx + 4 * cy, j = i + 4; const double a = v[i] + th * v[j], b = v[j] + th * v[i]; v[i] = a; v[j] = b; }
+    } else if constexpr (COL == 1) {
+        double fu[4], fd[4];
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy) { fu[cy] = dpp<0x39>(v[0 + 4 * cy]); fd[cy] = dpp<0x93>(v[3 + 4 * cy]); }      // quad_perm [1,2,3,0]: from the patch X + 1; [3,0,1,2]: from X - 1
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy) { const int i = 1 + 4 * cy, j = i + 1; const double a = v[i] + th * v[j], b = v[j] + th * v[i]; v[i] = a; v[j] = b; }
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy) { v[3 + 4 * cy] += th * fu[cy]; v[0 + 4 * cy] += th * fd[cy]; }
+    } else {
+        double fu[4], fd[4];
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) { fu[cx] = dpp<0x12C>(v[cx + 0]); fd[cx] = dpp<0x124>(v[cx + 12]); }            // row_ror:12: from lane + 4 (the patch Y + 1); row_ror:4: from lane - 4
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) { const int i = cx + 4, j = i + 4; const double a = v[i] + th * v[j], b = v[j] + th * v[i]; v[i] = a; v[j] = b; }
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) { v[cx + 12] += th * fu[cx]; v[cx + 0] += th * fd[cx]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <bool REVERSE>
+__device__ __forceinline__ void sweep(double (&v)[16], double th) {
+    if constexpr (!REVERSE) { colour<0>(v, th); colour<1>(v, th); colour<2>(v, th); colour<3>(v, th); }
+    else { colour<3>(v, th); colour<2>(v, th); colour<1>(v, th); colour<0>(v, th); }
+}
+}  // namespace rowf
+
+template <bool X0Z>
+__global__ void __launch_bounds__(512) k_cg_row(CgBufs B, ModelDev m, WgCtl R) {
+    using rowf::SV;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int W = 8, NPLM = 4, HS = 256, LSL = WAVE;      // (the meeting sees a slice as four segments of 64 values, as k_cg_wg's 2 x 2 layout does)
+    const int G = R.G;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tq = idx / G, g = idx - tq * G;
+    const int rhs = tq * 8 + xcd;
+    if (rhs >= B.nrhs) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1), row = lane >> 4, l16 = lane & 15;
+    const int N = m.N, L = m.L;
+    const int vr = 4 * wv + row;                       // this lane's row of the workgroup: 0 .. 31
+    const int t = g * 32 + vr;                         // ... and its time slice
+    const size_t ndim = (size_t)N * L;
+    // LDS: XB[34][256] exchange rows (row 0: p of the slice below the workgroup, kept; 1..32: the rows' p, then t; 33: t of the slice above) |
+    //      RL[34][256] r (0 and 33: the neighbouring workgroups' boundary slices) | PH1[256] p of the slice above | EH[256] its exp(-dtau V) |
+    //      zhalo[2][256] | part[32] tot[8] partF[8]
+    double *XB = lds, *RL = XB + 34 * SV, *PH1 = RL + 34 * SV, *EH = PH1 + SV, *zhalo = EH + SV, *part = zhalo + 2 * SV, *tot = part + 32, *partF = tot + 8;
+    auto wrap = [L](int tt) { return (tt < 0) ? tt + L : ((tt >= L) ? tt - L : tt); };
+    auto sgn = [](int tt) { return (tt == 0) ? -1.0 : 1.0; };
+    const CgParams P = B.params;
+    CgState *st2 = B.state + 2 * rhs;
+    const CgState S = ld_state(st2);
+    if (S.done || S.seq != 0) return;                  // fresh solves only (the host guarantees it)
+    // site of register q of a lane: (4 X + cx) + 16 (4 Y + cy) — made where it is used (set-up, final store), not kept across the loop
+    auto site_of = [](int l16v, int q) { return (4 * (l16v & 3) + (q & 3)) + 16 * (4 * (l16v >> 2) + (q >> 2)); };
+    double *xg = B.x + (size_t)rhs * ndim;
+    const double *rg = B.r + (size_t)rhs * ndim;
+    const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
+    const double th = m.s_uni / m.c_uni, k4 = (m.c_uni * m.c_uni) * (m.c_uni * m.c_uni);
+    double p[16], x[16], e[16], z[16];      // (x in memory instead — loaded behind the sums, stored by the update — was measured slower: 9.3 against 8.0 us)
+    const int own = (1 + vr) * SV + l16;               // this lane's words of its row: own + 16 q
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const double rv = rg[(size_t)t * N + site_of(l16, q)];
+        RL[own + 16 * q] = rv;
+        p[q] = rv;                                     // p0 = r0 (IterativeSolvers.jl:272)
+        x[q] = X0Z ? 0.0 : xg[(size_t)t * N + site_of(l16, q)];
+        e[q] = Ech[(size_t)t * m.E_tau_stride + site_of(l16, q)];
+    }
+    if (vr == 0) {                                     // the slice below the workgroup: p0 = r0 of it
+        const int tb = wrap(g * 32 - 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const double rv = rg[(size_t)tb * N + site_of(l16, q)]; XB[l16 + 16 * q] = rv; RL[l16 + 16 * q] = rv; }
+    }
+    if (vr == 31) {                                    // the slice above
+        const int ta = wrap(g * 32 + 32);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double rv = rg[(size_t)ta * N + site_of(l16, q)];
+            PH1[l16 + 16 * q] = rv; RL[33 * SV + l16 + 16 * q] = rv;
+            EH[l16 + 16 * q] = Ech[(size_t)ta * m.E_tau_stride + site_of(l16, q)];
+        }
+    }
+    if (threadIdx.x == 0) tot[5] = 1.0;
+    u64 *const slots0 = R.slots + (size_t)rhs * 2 * SLOTS_PER_RHS;
+    u64 *const bnd0 = R.bnd + (size_t)rhs * 2 * G * 2 * HS * 2;     // [parity][G][first | last slice][HS][2 granules]
+    const int gm = (g == 0) ? G - 1 : g - 1, gp = (g == G - 1) ? 0 : g + 1;
+    double rho = S.rho, kmin = S.kmin, eps = S.eps;
+    const double eps0 = S.eps0, normb = S.normb;
+    const double rr_far = (P.tol * normb) * (P.tol * normb) * 1.000001, y_num = 4.0 * (eps0 * normb) * (eps0 * normb);
+    const double it_kappa = 0.17 * sqrt(P.kmax);
+    const double sg_own = sgn(t) * k4, sg_top = sgn(wrap(g * 32 + 32)) * k4;
+    wg_barrier();
+    STAMP_DECL;
+    for (long long seq = 0;; ++seq) {
+        const unsigned epoch = R.epoch0 + (unsigned)seq + 1u;
+        const unsigned par = epoch & 1u;
+        u64 *const slotsA = slots0 + (size_t)par * SLOTS_PER_RHS, *const slotsB = slotsA + SLOTS_A;
+        u64 *const bnd = bnd0 + (size_t)par * G * 2 * HS * 2;
+        STAMP(9);
+        // ---- z = M^T M p:  m(t) = p(t) - sg(t) k4 CB [E(t) o p(t-1)];  tv(t) = sg(t) k4 E(t) o CB^T m(t);  z(t) = m(t) - tv(t+1)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) XB[own + 16 * q] = p[q];
+        wg_barrier();
+        double u[16];
+#ifndef ELPH_ROW_NOHALO      // (timing experiment, wrong results: without the redundant slice of the last wave)
+        if (wv == W - 1) {
+            // the slice ABOVE the workgroup first (every row of this wave computes it, identically; in the registers the own slice uses next): its
+            // m from the kept p of that slice and the p of the workgroup's last slice (in its exchange row), then its tv into exchange row 33
+#pragma unroll
+            for (int q = 0; q < 16; ++q) u[q] = EH[l16 + 16 * q] * XB[32 * SV + l16 + 16 * q];
+            rowf::sweep<false>(u, th);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) u[q] = PH1[l16 + 16 * q] - sg_top * u[q];       // m of the slice above
+            rowf::sweep<true>(u, th);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) XB[33 * SV + l16 + 16 * q] = sg_top * (EH[l16 + 16 * q] * u[q]);
+        }
+#endif
+#pragma unroll
+        for (int q = 0; q < 16; ++q) u[q] = e[q] * XB[own - SV + 16 * q];            // p of the slice below (row 0: the kept halo)
+        rowf::sweep<false>(u, th);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { z[q] = p[q] - sg_own * u[q]; u[q] = z[q]; }   // z holds m for now
+        rowf::sweep<true>(u, th);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) u[q] = sg_own * (e[q] * u[q]);                  // tv of the own slice
+        wg_barrier();                                  // everybody has read the p of the row below: the rows take the tv's now
+#pragma unroll
+        for (int q = 0; q < 16; ++q) XB[own + 16 * q] = u[q];
+        wg_barrier();
+        double s_pz = 0.0, s_rz = 0.0, s_zz = 0.0, s_rr = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            z[q] = z[q] - XB[own + SV + 16 * q];       // z(t) = m(t) - tv(t+1)
+            const double rv = RL[own + 16 * q];
+            s_pz += p[q] * z[q]; s_rz += rv * z[q]; s_zz += z[q] * z[q]; s_rr += rv * rv;
+        }
+        {
+            const double k4s = wave_sum4(s_pz, s_rz, s_zz, s_rr, lane);
+            if (lane < 4) part[lane * 8 + wv] = k4s;
+        }
+        STAMP(0);
+        // boundary slices of z for the neighbouring workgroups (self-tagged granules; word i of a slice = 16 q + l16, as both sides see it)
+        if (vr == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 0) * HS + l16 + 16 * q) * 2, z[q], epoch);
+        }
+        if (vr == 31) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) st_f64_gran(bnd + (((size_t)g * 2 + 1) * HS + l16 + 16 * q) * 2, z[q], epoch);
+        }
+        wg_barrier();
+        STAMP(2);
+        double pap, rz, zz, rr0;
+        {
+            // the meeting, as k_cg_wg's: wave s takes segment s of the two boundary slices (8 segments of 64 values), wave 1 the records too
+            constexpr int NSEG = 2 * NPLM, rw = 1;
+            if (wv == rw) publish_rec4(slotsA, g, sum_part4(part, W, lane), epoch, lane);
+            bool ok = true;
+            double t4 = 0.0;
+            {
+                const int s0 = wv;
+                const u64 *b0 = bnd + ((((s0 < NPLM) ? (size_t)gm * 2 + 1 : (size_t)gp * 2 + 0) * HS) + lane + (size_t)(s0 % NPLM) * WAVE) * 2;
+                const bool recs = (wv == rw);
+                double z0 = 0.0, z1 = 0.0;
+                if (G <= 8) {
+                    u64 v[1] = {0};
+                    ok = poll_rec4<1>(recs ? slotsA : nullptr, G, b0, nullptr, epoch, lane, R, v, z0, z1) && ok;
+                    if (recs) t4 = sum_rec4<1>(v, G, lane);
+                } else {
+                    u64 v[4] = {0, 0, 0, 0};
+                    ok = poll_rec4<4>(recs ? slotsA : nullptr, G, b0, nullptr, epoch, lane, R, v, z0, z1) && ok;
+                    if (recs) t4 = sum_rec4<4>(v, G, lane);
+                }
+                zhalo[(size_t)s0 * LSL + lane] = z0;   // (segment s = side * 4 + k lives at [side][64 k + lane])
+                static_assert(NSEG == W, "one segment per wave");
+            }
+            if (wv == rw && lane < 8 && !(lane & 1)) tot[lane >> 1] = t4;
+            if (!ok && lane == 0) tot[5] = 0.0;
+            wg_barrier();
+            if (tot[5] == 0.0) return;
+            pap = tot[0]; rz = tot[1]; zz = tot[2]; rr0 = tot[3];
+        }
+        STAMP(1);
+        rho = rr0;
+        const double alpha = rr0 / pap;
+        double rr = rr0 + alpha * (alpha * zz - 2.0 * rz);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            RL[own + 16 * q] = RL[own + 16 * q] - alpha * z[q];
+            x[q] += alpha * p[q];
+        }
+        if (wv == 0 || wv == W - 1) {                  // the neighbouring workgroups' boundary slices of the new residual
+            double *rh = RL + ((wv == 0) ? 0 : 33 * SV);
+            const double *zh = zhalo + ((wv == 0) ? 0 : SV);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rh[lane + 64 * k] = rh[lane + 64 * k] - alpha * zh[lane + 64 * k];
+        }
+        if (!(rr > 1e-3 * rr0)) {
+            // the identity cancels: r'.r' from the vector itself (second meeting of this iteration; every wave of the team is here)
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const double rn = RL[own + 16 * q]; a += rn * rn; }
+            a = wave_sum_dpp(a);
+            if (lane == 0) partF[wv] = a;
+            wg_barrier();
+            if (wv == 0) {
+                const double mine = wg_sum(partF, W, lane);
+                if (lane < 2) {
+                    const u64 bits = (u64)__double_as_longlong(mine);
+                    st_gran(slotsB + 2 * g + lane, ((u64)epoch << 32) | (lane ? (bits >> 32) : (bits & 0xFFFFFFFFull)));
+                }
+                u64 v = 0;
+                const bool ok = poll_records(slotsB, G, epoch, lane, R, v);
+                const int half = (int)(unsigned)v;
+                double tt = 0.0;
+                for (int k = 0; k < G; ++k)
+                    tt += __hiloint2double(__builtin_amdgcn_readlane(half, 2 * k + 1), __builtin_amdgcn_readlane(half, 2 * k));
+                if (lane == 0) { tot[4] = tt; if (!ok) tot[5] = 0.0; }
+            }
+            wg_barrier();
+            if (tot[5] == 0.0) return;
+            rr = tot[4];
+        }
+        STAMP(3);
+        // ---- stop test of iteration it = seq + 1 (IterativeSolvers.jl:286-295), screened as in k_cg_wg
+        const long long it = seq + 1;
+        const bool fixed = R.fixed_iters > 0;
+        int done = 0;
+        const bool screened = !P.record_hist && it < (fixed ? R.fixed_iters : P.maxiter) && (fixed || rr > rr_far) &&
+                              (rr + rr <= y_num || rr >= y_num + y_num) && (double)it < it_kappa;
+        if (!screened) {
+            eps = sqrt(rr) / normb;
+            const double qq = 2.0 * (double)it / log(2.0 * eps0 / eps);
+            const double val = qq * qq;
+            kmin = (val > kmin) ? val : kmin;
+            if (eps < P.tol) done = 1;
+            else if (kmin > P.kmax) done = 2;
+            else if (it >= P.maxiter) done = 3;
+            if (fixed) done = (it >= R.fixed_iters) ? 3 : 0;
+            if (g == 0 && wv == 0 && lane == 0 && P.record_hist) B.hist[(size_t)rhs * P.hist_stride + it] = eps;
+        }
+        STAMP(7);
+        if (done) {
+            STAMP_OUT(it);
+            int l16b = l16;
+            asm volatile("" : "+v"(l16b));             // (addresses made here, from a laundered lane number: not 32 registers across the loop)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xg[(size_t)t * N + site_of(l16b, q)] = x[q];
+            if (g == 0 && wv == 0 && lane == 0) {
+                CgState o = S;
+                o.rho = rho; o.kmin = kmin; o.eps = eps; o.seq = it + 1; o.iters = it; o.done = done;
+                st2[0] = o;
+                st2[1] = o;
+            }
+            return;
+        }
+        const double beta = rr / rho;
+        rho = rr;
+        // ---- next direction: own slice, and the two kept slices of the neighbouring workgroups (p = r + beta p is pointwise)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) p[q] = RL[own + 16 * q] + beta * p[q];
+        if (wv == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) XB[lane + 64 * k] = RL[lane + 64 * k] + beta * XB[lane + 64 * k];
+        }
+        if (wv == W - 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) PH1[lane + 64 * k] = RL[33 * SV + lane + 64 * k] + beta * PH1[lane + 64 * k];
+        }
+        STAMP(8);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1307,12 +1610,32 @@ static hipError_t launch_shard_grid(elph_handle_s *h, const Shape &sh, dim3 grid
     }
 }
 
+// the row form (k_cg_row) of the 4-slices-per-wave shape of the 16 x 16 DPP form: 32 slices per workgroup
+static bool row_form(const elph_handle_s *h, const Shape &sh) {
+    const char *e = getenv("ELPH_WG_ROW");
+    if (!(e && e[0] == '1')) return false;
+    return sh.sq && sh.T == 4 && sh.W == 8 && h->N == 256 && h->L % 32 == 0 && sh.G == (int)(h->L / 32) && sh.G >= 2 && sh.G <= 32;
+}
+
 template <int NPL>
 static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const CgBufs &B, const ModelDev &m, const WgCtl &R) {
     if constexpr (NPL == 4) {
         if (sh.sq) {
             if (h->kind == ELPH_MODEL_SSH) return (sh.T == 2) ? launch_k<4, 2, true, false, 1>(h, sh, grid, B, m, R) : launch_k<4, 1, true, false, 1>(h, sh, grid, B, m, R);
             if (!m.uniform) return (sh.T == 2) ? launch_k<4, 2, false, false, 1>(h, sh, grid, B, m, R) : launch_k<4, 1, false, false, 1>(h, sh, grid, B, m, R);
+            if (sh.T == 4 && row_form(h, sh)) {      // the row form of the same shape (k_cg_row: a time slice per 16-lane row, 4 x 4 patches)
+                const size_t shm = ((size_t)(34 + 34) * rowf::SV + 2 * rowf::SV + 2 * rowf::SV + 48) * sizeof(double);
+                if (R.x0_zero) {
+                    hipError_t e = hipFuncSetAttribute((const void *)k_cg_row<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL((k_cg_row<true>), grid, dim3(8 * WAVE), shm, h->stream, B, m, R);
+                } else {
+                    hipError_t e = hipFuncSetAttribute((const void *)k_cg_row<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL((k_cg_row<false>), grid, dim3(8 * WAVE), shm, h->stream, B, m, R);
+                }
+                return hipGetLastError();
+            }
             if (sh.T == 4) return R.x0_zero ? launch_k<4, 4, false, true, 1, false, true>(h, sh, grid, B, m, R) : launch_k<4, 4, false, true, 1>(h, sh, grid, B, m, R);
             if (sh.T == 2) return launch_k<4, 2, false, true, 1>(h, sh, grid, B, m, R);
             return launch_k<4, 1, false, true, 1>(h, sh, grid, B, m, R);

@@ -1914,3 +1914,42 @@ def test_wg_resident_cg_maxiter_history_and_initial_guess(oracle, tag):
     it2 = models.solve_(x, m, b, tol=1e-30, maxiter=17)
     assert it2 == 17
     m.close()
+
+
+def test_row_form_of_the_resident_kernel_is_the_same_solve():
+    """k_cg_row (opt-in, ELPH_WG_ROW=1; measured slower — profiles/r05/wg_row_form_4x4_patches_rejected.log): the 4-slices-per-wave shape of config C with a time
+    slice per 16-lane row and 4 x 4 patches per lane.  Same team protocol, another layout and summation tree: iteration counts within the
+    knife edge, solutions to the solver tolerance, against the 2 x 2 form and the streaming iteration."""
+    import os
+    from elphdynamics_amd import configs, models
+    old = os.environ.get("ELPH_WG_ROW")
+    try:
+        m = configs.make_model("C", tol=1e-10)
+        _, B = configs.rhs(m, 30)
+        B = np.ascontiguousarray(B)
+        out = {}
+        for mode in ("0", "1"):
+            os.environ["ELPH_WG_ROW"] = mode
+            X = np.zeros_like(B)
+            it, res, fl = models.ldiv_batched_(X, m, B)
+            assert not fl.any()
+            out[mode] = (it.copy(), X.copy())
+        assert np.abs(out["0"][0] - out["1"][0]).max() <= 3
+        assert rel(out["0"][1], out["1"][1]) < 1e-8 and not np.array_equal(out["0"][1], out["1"][1])
+        # a caller's initial guess (the instantiation that reads x0) and a tight solve against M^-1 R
+        os.environ["ELPH_WG_ROW"] = "1"
+        R, B2 = configs.rhs(m, 26)
+        m.solver.tol = 1e-13
+        X0 = 0.5 * out["0"][1][:26]
+        X = X0.copy()
+        it, res, fl = models.ldiv_batched_(X, m, np.ascontiguousarray(B2))
+        assert not fl.any()
+        Mx = np.empty(m.Ndim)
+        models.mulM_(Mx, m, X[3])
+        assert rel(Mx, R[3]) < 1e-8
+        m.close()
+    finally:
+        if old is None:
+            os.environ.pop("ELPH_WG_ROW", None)
+        else:
+            os.environ["ELPH_WG_ROW"] = old
