@@ -239,6 +239,21 @@ class HybridMonteCarlo:
 _NO_RANDOMS = {}          # every input NULL: drawn by the handle's own generator (HybridMonteCarlo.device_rng_)
 
 
+def set_mu_(model, hmc, mu):
+    """The chemical-potential tuner moved μ (MuFinder.jl:68-107: model.μ .= μ′ between two updates): the device-side copy of an existing HMC state
+    follows — elph_hmc_set_mu (one μ[N] for every chain) or elph_hmc_set_mu_chains (mu of shape (nchains, N): a tuner per chain) — and
+    exp(−ΔτV) is rebuilt from the resident field."""
+    from ._lib import check, dptr
+    mu = np.ascontiguousarray(mu, dtype=np.float64)
+    if mu.ndim == 2:
+        assert mu.shape == (hmc.nchains, model.Nsites)
+        check(model._lib.elph_hmc_set_mu_chains(model._h, dptr(mu.reshape(-1))))
+    else:
+        assert mu.shape == (model.Nsites,)
+        model.mu[:] = mu
+        check(model._lib.elph_hmc_set_mu(model._h, dptr(mu)))
+
+
 def draw_randoms(hmc, rng, with_kpm):
     """The random numbers one update! consumes, in the order the reference draws them from model.rng
     (refresh_v! :652, refresh_ϕ! :674-675, one pair of Arnoldi start vectors per setup!(P), rand :441)."""

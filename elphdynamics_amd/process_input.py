@@ -152,7 +152,7 @@ def initialize_simulation_params(inp):
 
 def initialize_mutuner(inp, model):
     """ProcessInputFile.jl:611-624 — the PARAMETERS of the [tune_density] table only (active, μ₀, target ⟨N⟩, memory, κ_min·N): the
-    tuner itself (MuFinder.jl) is control plane and not part of this package; the device side of a μ update is elph_hmc_set_mu / models.set_mu_."""
+    tuner itself (MuFinder.jl) is control plane and not part of this package; the device side of a μ update is elph_hmc_set_mu / hmc.set_mu_."""
     mu0 = float(np.mean(model.mu))
     td = inp.get("tune_density")
     if td is None:

@@ -847,3 +847,46 @@ def test_ssh_swap_update_of_chains():
     frac = hmc.swap_update_(m, H, 2, None, rng=rng)
     assert 0.0 <= frac <= 1.0
     m.close()
+
+
+def test_chemical_potential_moved_by_the_tuner(oracle):
+    """model.μ changes between two updates (MuFinder.jl:68-107; what julia/ElPhGPU.jl's resident update! does with elph_hmc_set_mu): the update that follows
+    is the update of a state created with the new μ — same bits — and the oracle's with that μ; with chains in lockstep every chain can carry
+    its own μ (elph_hmc_set_mu_chains) and is the single chain with that μ."""
+    from elphdynamics_amd import hmc
+    dt, nt = 0.05, 2
+    # (a) one chain: create with mu = 0, move to mu1, update  ==  create with mu1, update
+    m, fa, _ = _pair(oracle, "b", tol=1e-7)
+    rnd = _randoms(m, nt, 2100, False, 0.0)
+    mu1 = 0.3 + 0.05 * np.arange(m.Nsites) / m.Nsites
+    H = hmc.HybridMonteCarlo(m, fa, dt, nt * dt)
+    hmc.set_mu_(m, H, mu1)
+    acc, its = hmc.update_(m, H, fa, None, randoms=rnd)
+    m2, fa2, _ = _pair(oracle, "b", tol=1e-7)
+    m2.mu[:] = mu1
+    from elphdynamics_amd import models
+    models.update_model_(m2)
+    E = oracle.update_model_holstein(m2.Nsites, m2.Ltau, m2.dtau, m2.x, m2.lam, m2.lam2, m2.mu)
+    om2 = oracle.make_model(0, m2.Nsites, m2.Ltau, m2.neighbor_table, m2.cosht, m2.sinht, E)
+    x0 = m2.x.copy()
+    H2 = hmc.HybridMonteCarlo(m2, fa2, dt, nt * dt)
+    acc2, its2 = hmc.update_(m2, H2, fa2, None, randoms=rnd)
+    assert acc == acc2 and its == its2 and H.H0 == H2.H0 and H.H1 == H2.H1 and np.array_equal(m.x, m2.x) and np.array_equal(H.v, H2.v)
+    acc_o, x_o, v_o, info = _oracle_update(oracle, om2, m2, fa2, x0, np.zeros(m2.Ndof), dt, nt, 1, 0.0, rnd)
+    assert acc2 == acc_o and abs(H2.H0 - info["H0"]) < 1e-9 * abs(info["H0"]) and rel(m2.x, x_o) < 3e-7
+    m.close(); m2.close()
+    # (b) two chains in lockstep, each with its own mu: chain c == the single chain with mu_c
+    m3, fa3, _ = _pair(oracle, "b", tol=1e-7)
+    Hc = hmc.HybridMonteCarlo(m3, fa3, dt, nt * dt, nchains=2)
+    Hc.X[:] = m3.x
+    Hc.push_()
+    mus = np.stack([np.zeros(m3.Nsites), mu1])
+    hmc.set_mu_(m3, Hc, mus)
+    rc = dict(R=np.stack([rnd["R"], rnd["R"]]), Rp=np.stack([rnd["Rp"], rnd["Rp"]]), Rm=np.stack([rnd["Rm"], rnd["Rm"]]), kpm_randn=None, u=np.zeros(2))
+    accs, itss = hmc.update_chains_(m3, Hc, fa3, None, randoms=rc, pull=True)
+    assert accs[1] == acc2 and abs(Hc.energies[1, 0] - H2.H0) < 1e-12 * abs(H2.H0) and rel(Hc.X[1], m2.x) < 1e-9
+    m4, fa4, _ = _pair(oracle, "b", tol=1e-7)
+    H4 = hmc.HybridMonteCarlo(m4, fa4, dt, nt * dt)
+    hmc.update_(m4, H4, fa4, None, randoms=rnd)
+    assert abs(Hc.energies[0, 0] - H4.H0) < 1e-12 * abs(H4.H0) and rel(Hc.X[0], m4.x) < 1e-9 and not np.allclose(Hc.X[0], Hc.X[1])
+    m3.close(); m4.close()
