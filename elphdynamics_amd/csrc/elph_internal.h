@@ -418,7 +418,8 @@ int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long lon
 int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, int nsets, void *h_args, void *d_args, double tol, int64_t maxiter, double kmax,
                            long long fixed_iters, long long timeout_ms, CgState *state_out, double *ms_out, double *const *hist_dev = nullptr,
                            long long hist_stride = 0);      // shard.hip
-int elph_i_shard_make_local(elph_handle_s *h);      // shard.hip: the mailbox of a slab on the solve's one device as ordinary device memory
+int elph_i_shard_create_local(elph_handle_s *h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev, int64_t n_to_next,
+                              int64_t cap_ghost, void *key_out);      // shard.hip: elph_shard_create for slabs that all live on one device (mailbox = ordinary device memory, not exported)
 // ---- slabs.hip: the resident un-preconditioned solve of a lattice BEYOND one wave's slice (N > 320) as slabs of rows on the same device
 bool elph_i_slabs_usable(elph_handle_s *h, int nrhs);      // builds the slabs on first use
 int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long fixed_iters, int64_t *iters, bool *ran, double *ms_out);      // (P.record_hist: the eps histories go to h->d_hist)

@@ -15,6 +15,7 @@
 // (DESIGN.md §6), and it refuses two ranks on one GPU — the only multi-rank set-up the test box offers.
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -118,9 +119,29 @@ extern "C" int elph_shard_shape(int64_t ltau, int world, int *waves, int *groups
     return ELPH_OK;
 }
 
+// local_only (slabs.hip): ALL ranks of this solve are slabs on this handle's device and run as one launch (k_cg_wg<..., RANKS>, agent-scope mailbox
+// accesses) — the mailbox is ordinary device memory, never exported (the fine-grained uncached allocation and its IPC handle are what make a
+// mailbox visible to another GPU / process; an exported allocation freed early was also seen to stay reserved: 2 MB per slab and model),
+// and the "handle" handed back is a process-local key for elph_shard_connect's registry.
+static int shard_create(elph_handle_s *h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev, int64_t n_to_next,
+                        int64_t cap_ghost, int64_t n_global, int64_t own_global_start, const int64_t *global_sites, void *ipc_handle_out,
+                        bool local_only);
+
 extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev,
                                  int64_t n_to_next, int64_t cap_ghost, int64_t n_global, int64_t own_global_start,
                                  const int64_t *global_sites, void *ipc_handle_out) {
+    return shard_create(h, rank, world, own_lo, own_n, n_to_prev, n_to_next, cap_ghost, n_global, own_global_start, global_sites, ipc_handle_out, false);
+}
+
+int elph_i_shard_create_local(elph_handle_s *h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev, int64_t n_to_next,
+                              int64_t cap_ghost, void *key_out) {
+    const int64_t zero = 0;
+    return shard_create(h, rank, world, own_lo, own_n, n_to_prev, n_to_next, cap_ghost, 0, 0, &zero, key_out, true);
+}
+
+static int shard_create(elph_handle_s *h, int rank, int world, int64_t own_lo, int64_t own_n, int64_t n_to_prev, int64_t n_to_next,
+                        int64_t cap_ghost, int64_t n_global, int64_t own_global_start, const int64_t *global_sites, void *ipc_handle_out,
+                        bool local_only) {
     if (!h) { elph_set_error("null handle"); return ELPH_E_ARG; }
     HIPCHK(hipSetDevice(h->device));
     if (world < 1 || world > ELPH_SHARD_MAXRANKS || rank < 0 || rank >= world) { elph_set_error("bad rank %d of %d (at most %d ranks)", rank, world, ELPH_SHARD_MAXRANKS); return ELPH_E_ARG; }
@@ -157,35 +178,28 @@ extern "C" int elph_shard_create(elph_handle h, int rank, int world, int64_t own
     HIPCHK(hipMalloc((void **)&S->d_counter, 64));
     HIPCHK(hipMemset(S->d_counter, 0, 64));
     S->d_abort = S->d_counter + 8;
-    // uncached, fine-grained: stores from another GPU become visible to this GPU's (system-scope) polls while its kernel runs
-    HIPCHK(hipExtMallocWithFlags((void **)&S->mail, S->mail_bytes, hipDeviceMallocUncached));
-    HIPCHK(hipMemset(S->mail, 0, S->mail_bytes));
-    HIPCHK(hipDeviceSynchronize());
-    hipIpcMemHandle_t mh;
-    HIPCHK(hipIpcGetMemHandle(&mh, S->mail));
     static_assert(sizeof(hipIpcMemHandle_t) == ELPH_SHARD_IPC_BYTES, "IPC handle size");
-    memcpy(ipc_handle_out, &mh, sizeof(mh));
-    local_mail_register(&mh, S->mail, h->device);
-    S->ctl.mail[rank] = S->mail;
-    return ELPH_OK;
-}
-
-// slabs.hip: ALL ranks of this solve are slabs on this handle's device and run as one launch (k_cg_wg<..., RANKS>, agent-scope mailbox
-// accesses) — the mailbox becomes ordinary device memory (the fine-grained uncached allocation is what makes it visible to another GPU;
-// here it only makes every poll a trip to memory).  Between elph_shard_create and elph_shard_connect.
-int elph_i_shard_make_local(elph_handle_s *h) {
-    ShardState *S = static_cast<ShardState *>(h->shard);
-    if (!S || S->connected) { elph_set_error("elph_i_shard_make_local: between create and connect"); return ELPH_E_STATE; }
-    unsigned long long *fresh = nullptr;
-    HIPCHK(hipMalloc((void **)&fresh, S->mail_bytes));
-    HIPCHK(hipMemset(fresh, 0, S->mail_bytes));
-    {
-        std::lock_guard<std::mutex> lk(g_local_mu);
-        for (LocalMailbox &m : g_local_mail) if (m.ptr == S->mail) m.ptr = fresh;
+    if (local_only) {
+        HIPCHK(hipMalloc((void **)&S->mail, S->mail_bytes));
+        HIPCHK(hipMemset(S->mail, 0, S->mail_bytes));
+        unsigned char key[ELPH_SHARD_IPC_BYTES];
+        memset(key, 0, sizeof(key));
+        memcpy(key, "ELPHLOCL", 8);
+        const unsigned long long pv = (unsigned long long)(uintptr_t)S->mail;
+        memcpy(key + 8, &pv, sizeof(pv));
+        memcpy(ipc_handle_out, key, sizeof(key));
+        local_mail_register(key, S->mail, h->device);
+    } else {
+        // uncached, fine-grained: stores from another GPU become visible to this GPU's (system-scope) polls while its kernel runs
+        HIPCHK(hipExtMallocWithFlags((void **)&S->mail, S->mail_bytes, hipDeviceMallocUncached));
+        HIPCHK(hipMemset(S->mail, 0, S->mail_bytes));
+        HIPCHK(hipDeviceSynchronize());
+        hipIpcMemHandle_t mh;
+        HIPCHK(hipIpcGetMemHandle(&mh, S->mail));
+        memcpy(ipc_handle_out, &mh, sizeof(mh));
+        local_mail_register(&mh, S->mail, h->device);
     }
-    (void)hipFree(S->mail);
-    S->mail = fresh;
-    S->ctl.mail[S->ctl.rank] = fresh;
+    S->ctl.mail[rank] = S->mail;
     return ELPH_OK;
 }
 

@@ -166,11 +166,8 @@ int add_set(elph_handle_s *h, SlabSet *S) {
         sh->is_slab = true;
         rc = elph_set_stream(sh, h->stream);
         if (rc) break;
-        const int64_t zero = 0;
-        rc = elph_shard_create(sh, q, P, lo, n, /* to prev = its ghosts above */ hi, /* to next = its ghosts below */ lo, std::max(lo, hi), 0, 0, &zero,
-                               ipc.data() + (size_t)q * ELPH_SHARD_IPC_BYTES);
-        if (rc) break;
-        rc = elph_i_shard_make_local(sh);
+        rc = elph_i_shard_create_local(sh, q, P, lo, n, /* to prev = its ghosts above */ hi, /* to next = its ghosts below */ lo, std::max(lo, hi),
+                                       ipc.data() + (size_t)q * ELPH_SHARD_IPC_BYTES);
         if (rc) break;
         if (!S->d_g[(size_t)q] && (hipMalloc((void **)&S->d_g[(size_t)q], (size_t)Nloc * sizeof(int)) != hipSuccess ||
                                    hipMemcpy(S->d_g[(size_t)q], g.data(), (size_t)Nloc * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)) {

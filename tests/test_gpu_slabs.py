@@ -274,3 +274,50 @@ def test_hmc_update_on_a_large_lattice_through_the_slab_form(slabs_env):
     assert a[0] == s[0] and abs(a[1] - s[1]) <= 1
     assert abs(a[2] - s[2]) < 1e-9 * abs(s[2]) and abs(a[3] - s[3]) < 1e-8 * abs(s[3])
     assert rel(a[4], s[4]) < 1e-7 and rel(a[5], s[5]) < 1e-7 and not np.array_equal(a[4], s[4])
+
+
+def test_slabs_follow_the_callers_stream_and_are_freed_with_the_handle(slabs_env):
+    """elph_set_stream on the lattice's handle after its slabs exist: the slab handles are re-bound (one launch needs ONE stream) and the solve is the
+    same bits; creating and destroying models that grew slabs (two sets: a pair of right-hand sides) leaves the device's free memory where it was."""
+    from elphdynamics_amd import _lib, configs, models
+    from elphdynamics_amd._lib import check
+    from test_gpu_muldmdx import _DevBuf
+    lib = _lib.load()
+    os.environ.pop("ELPH_SLABS", None)
+    m = configs.make_model("g", tol=1e-9)
+    _, B = configs.rhs(m, 2)
+    B = np.ascontiguousarray(B)
+    X = np.zeros_like(B)
+    it, res, fl = models.ldiv_batched_(X, m, B)
+    assert _info(m, 2)[0] == 1 and not fl.any()
+    if _DevBuf.hip is None:
+        _DevBuf.hip = C.CDLL("libamdhip64.so")
+    hip = _DevBuf.hip
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    check(lib.elph_set_stream(m._h, st))
+    X2 = np.zeros_like(B)
+    it2, _, fl2 = models.ldiv_batched_(X2, m, B)
+    assert np.array_equal(it, it2) and np.array_equal(X, X2) and not fl2.any()
+    check(lib.elph_set_stream(m._h, None))
+    X3 = np.zeros_like(B)
+    assert np.array_equal(models.ldiv_batched_(X3, m, B)[0], it) and np.array_equal(X, X3)
+    assert hip.hipStreamDestroy(st) == 0
+    m.close()
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    def cycle():
+        mm = configs.make_model("g", tol=1e-6)
+        Xc = np.zeros_like(B)
+        models.ldiv_batched_(Xc, mm, B)
+        mm.close()
+
+    cycle()
+    f0 = free_bytes()
+    for _ in range(6):
+        cycle()
+    assert abs(free_bytes() - f0) < (8 << 20), (f0, free_bytes())      # (the allocator may keep a few MB of pools; a leaked slab set is ~40 MB per cycle)
