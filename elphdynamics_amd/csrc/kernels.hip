@@ -613,7 +613,9 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
     // bond program -> LDS (after the slab: [N] double2 | [nb] cosh | [nb] sinh | [nb] i | j << 16)
     const unsigned *lij = nullptr;
     const double *lc = nullptr, *ls = nullptr;
-    if (lds_tables) {
+    const KpmChainView V = kpm_chain_view(K, rhs, m.N);
+    K.cbar = V.cbar; K.sbar = V.sbar;                               // this chain's averaged hopping (SSH chains) — BEFORE the tables are staged:
+    if (lds_tables) {                                               // (round 5: the LDS copy took chain 0's tables for every chain of an SSH batch)
         double *tc = lds + 2 * (size_t)m.N, *ts = tc + m.nb;
         unsigned *tij = reinterpret_cast<unsigned *>(ts + m.nb);
         for (int n = threadIdx.x; n < m.nb; n += blockDim.x) {
@@ -622,8 +624,6 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
         }
         lij = tij; lc = tc; ls = ts;                               // the first barrier inside kpm_mulAprime publishes them
     }
-    const KpmChainView V = kpm_chain_view(K, rhs, m.N);
-    K.cbar = V.cbar; K.sbar = V.sbar;                               // this chain's averaged hopping (SSH chains)
     const int w = V.wsched[blockIdx.y];
     const int N = m.N;
     const int order = V.order[w];

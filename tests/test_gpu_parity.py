@@ -1117,6 +1117,15 @@ def test_patch_matvec_kernels_on_lattices_of_the_lane_program_family(oracle, tag
     m.close()
 
 
+def test_kpm_preconditioner_per_chain_generic_family(monkeypatch):
+    """The same with the generic kernel family (ELPH_NO_FAST=1: lattices without a lane program) on bond phonons: every chain's Chebyshev
+    recursion takes ITS τ-averaged hopping tables — the LDS copy of the bond program used chain 0's for all (found in round 5 by running the
+    suite under ELPH_NO_FAST=1: 20 iterations where the chain alone needs 15)."""
+    monkeypatch.setenv("ELPH_NO_FAST", "1")
+    test_kpm_preconditioner_per_chain("e", 3, 2, monkeypatch)
+    test_kpm_preconditioner_per_chain("E", 8, 2, monkeypatch)
+
+
 @pytest.mark.parametrize("tag,nchains,per", [("b", 3, 2), ("B", 4, 2), ("C", 8, 2), ("e", 3, 2), ("E", 8, 2), ("D", 4, 2),
                                              ("G", 3, 2), ("h", 2, 2)])      # (G, h: the PGRID kernels, one expansion per chain)
 def test_kpm_preconditioner_per_chain(tag, nchains, per, monkeypatch):
