@@ -90,3 +90,42 @@ def test_greens_function_results_stay_on_the_device():
         host = np.asarray(getattr(est, nm)).reshape(-1, order="F").view(np.float64)
         assert np.array_equal(out, host), nm
     m.close()
+
+
+def test_two_host_threads_each_with_its_own_handle():
+    """Handles are independent: two host threads (one handle each, as a Julia process with two tasks or the rank threads of the sharded path hold them) solve
+    at the same time — plain, preconditioned, batched — and every result is the bits of the same call made alone."""
+    import threading
+    from elphdynamics_amd import configs, models, preconditioners as pc
+
+    def work(tag, seed, out, n):
+        m = configs.make_model(tag, tol=1e-8)
+        _, B = configs.rhs(m, 3, seed=seed)
+        B = np.ascontiguousarray(B)
+        P = pc.SymmetricKPMPreconditioner(m, min(20, m.Nsites), 0.05, 1.0, 1.0)
+        pc.setup_(P, rng=np.random.default_rng(seed))
+        res = []
+        for _ in range(n):
+            x = np.zeros(m.Ndim)
+            it = models.ldiv_(x, m, B[0])[0]
+            xp = np.zeros(m.Ndim)
+            itp = models.ldiv_(xp, m, B[1], P)[0]
+            X = np.zeros_like(B)
+            itb = models.ldiv_batched_(X, m, B)[0]
+            res.append((it, itp, tuple(itb), x.copy(), xp.copy(), X.copy()))
+        m.close()
+        out.append(res)
+
+    alone_a, alone_b = [], []
+    work("B", 41, alone_a, 1)
+    work("d", 43, alone_b, 1)
+    ta, tb = [], []
+    th = [threading.Thread(target=work, args=("B", 41, ta, 12)), threading.Thread(target=work, args=("d", 43, tb, 12))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(ta) == 1 and len(tb) == 1
+    for got, ref in ((ta[0], alone_a[0][0]), (tb[0], alone_b[0][0])):
+        for r in got:
+            assert r[:3] == ref[:3] and all(np.array_equal(a, b) for a, b in zip(r[3:], ref[3:]))
