@@ -135,7 +135,9 @@ __device__ double hess_max_real(double *a, int n, int lane) {
                     for (int k = m; k <= nn - 1; ++k) {
                         if (k != m) {
                             p = AH(k, k - 1); q = AH(k + 1, k - 1); r = (k != nn - 1) ? AH(k + 2, k - 1) : 0.0;
-                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+                            // (one reciprocal and three products where hqr divides three times — and likewise below: an f64 division is a dozen dependent
+                            //  instructions, eight of them were half of a step of this latency-bound chain; the eigenvalues move by rounding only)
+                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { const double ix = 1.0 / x; p *= ix; q *= ix; r *= ix; }
                         }
                         if ((s = sgn(sqrt(p * p + q * q + r * r), p)) != 0.0) {
                             if (lane == 0) {
@@ -145,7 +147,8 @@ __device__ double hess_max_real(double *a, int n, int lane) {
                                     AH(k, k - 1) = -s * x;
                                 }
                             }
-                            p += s; x = p / s; y = q / s; z = r / s; q /= p; r /= p;
+                            p += s;
+                            { const double is = 1.0 / s, ip = 1.0 / p; x = p * is; y = q * is; z = r * is; q *= ip; r *= ip; }
                             const bool three = (k != nn - 1);
                             for (int j = k + lane; j <= nn; j += WAVE) {            // rows k, k+1, k+2: one column per lane
                                 const double a0 = AH(k, j), a1 = AH(k + 1, j), a2 = three ? AH(k + 2, j) : 0.0;
