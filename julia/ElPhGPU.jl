@@ -41,8 +41,20 @@
 # parsed by a Julia compiler.  What IS checked, on every test run: tests/test_julia_dispatch.py (every `ccall` below against the
 # prototypes of include/elph_gpu.h — symbol, argument count, argument types; block structure of this file; every reference function
 # whose signature names a concrete model type is either left alone or specialised here; every added signature is more specific than
-# the reference method it names), and the calls themselves, in this order, from plain C (tests/abi_c/abi_smoke.c) and through ctypes
-# (tests/test_gpu_parity.py, tests/test_gpu_muldmdx.py) against the oracle on the GPU.
+# the reference method it names; EVERY `invoke(f, Tuple{…}, …)` tuple is a subtype of the reference method it must reach — same arity,
+# each element equal to or narrower than the reference's, every type variable the reference shares between arguments bound to one
+# value — and of no method of this file (tests/julia_types.py restates the needed part of Julia's subtype relation; round 5's eight
+# bare `HolsteinModel` / `SSHModel` / `AbstractModel` tuples are kept there as cases the check must reject)), and the calls themselves,
+# in this order, from plain C (tests/abi_c/abi_smoke.c) and through ctypes (tests/test_gpu_parity.py, tests/test_gpu_muldmdx.py)
+# against the oracle on the GPU.  FIRST RUN with Julia and a GPU: `ElPhGPU.selftest(model)` on a 4 × 4 model (end of this file) — the
+# attached and the detached pass of the whole operator API, compared.
+#
+# The fall-back idiom: `invoke(f, Tuple{AbstractVector{Float64}, typeof(m), AbstractVector{Float64}}, y, m, v)`.  The model's CONCRETE
+# type is a subtype of whatever the reference's signature says about the model (`HolsteinModel{T1,T3}`, `SSHModel{T1,T2}`,
+# `AbstractModel{T1,T2}` with T2 tied to the vectors), and `AbstractVector` keeps the tuple out of the methods added here (which
+# take `Vector{Float64}`), so the reference's method is the most specific one that covers it.  Where the model is the ONLY argument
+# (`update_model!`) `typeof(m)` would select the method added here; those fall-backs name the reference's own signature type instead
+# (`Tuple{HolsteinModel}`, `Tuple{SSHModel}` == `Tuple{SSHModel{T1,T2}} where {T1,T2}`: each variable occurs once).
 
 module ElPhGPU
 
@@ -64,7 +76,7 @@ import ..FourierAcceleration: fourier_accelerate!
 using ..HMC: HybridMonteCarlo, update_Λ!, mulΛ!
 import ..HMC: calc_O⁻¹Λϕ!, update!
 
-export attach!, detach!, attached, pull!, ldiv_batched!, ElphError
+export attach!, detach!, attached, pull!, ldiv_batched!, selftest, ElphError
 
 "Path of the shared library; `ENV[\"ELPHGPU_LIB\"]` overrides (the in-tree build is elphdynamics_amd/libelphgpu.so)."
 const lib = get(ENV, "ELPHGPU_LIB", "libelphgpu.so")
@@ -116,6 +128,7 @@ mutable struct Entry
     hmc_μsum::Float64
     kpm_randn::Vector{Float64}          # (Nt + 2) pairs of Arnoldi start vectors of one update
     energies::Vector{Float64}           # H₀, H₁, S, K, P_accept of the last resident update
+    device::Int                         # the GPU the handle lives on (selftest re-attaches with the caller's options)
 end
 
 const REGISTRY = IdDict{Any,Entry}()
@@ -170,7 +183,7 @@ function attach!(model::GPUModel; device::Integer=0, host_sync::Bool=true, batch
     end
     e = Entry(h, host_sync, batch_pseudofermions, nothing, false, zeros(model.Ndim, 2), zeros(model.Ndim, 2),
               zeros(Lτ, model isa SSHModel ? Nb : 0), zeros(N), zeros(N), cb_index, t_ph, t_bare_cb, 0, 0,
-              resident_hmc, nothing, 0.0, 0.0, Float64[], zeros(5))
+              resident_hmc, nothing, 0.0, 0.0, Float64[], zeros(5), Int(device))
     REGISTRY[model] = e
     update_model!(model)
     return model
@@ -293,7 +306,7 @@ end
 "y = M⋅v"
 function mulM!(y::Vector{Float64}, m::HolsteinModel{Float64,Float64}, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(mulM!, Tuple{AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, y, m, v)
+    e === nothing && return invoke(mulM!, Tuple{AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, y, m, v)
     @assert length(y) == m.Ndim && length(v) == m.Ndim
     chk(ccall((:elph_mulM, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
     served!(e)
@@ -302,7 +315,7 @@ end
 
 function mulM!(y::Vector{Float64}, m::SSHModel{Float64,Float64}, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(mulM!, Tuple{AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, y, m, v)
+    e === nothing && return invoke(mulM!, Tuple{AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, y, m, v)
     @assert length(y) == m.Ndim && length(v) == m.Ndim
     chk(ccall((:elph_mulM, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
     served!(e)
@@ -312,7 +325,7 @@ end
 "y = Mᵀ⋅v"
 function mulMᵀ!(y::Vector{Float64}, m::HolsteinModel{Float64,Float64}, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(mulMᵀ!, Tuple{AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, y, m, v)
+    e === nothing && return invoke(mulMᵀ!, Tuple{AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, y, m, v)
     @assert length(y) == m.Ndim && length(v) == m.Ndim
     chk(ccall((:elph_mulMT, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
     served!(e)
@@ -321,7 +334,7 @@ end
 
 function mulMᵀ!(y::Vector{Float64}, m::SSHModel{Float64,Float64}, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(mulMᵀ!, Tuple{AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, y, m, v)
+    e === nothing && return invoke(mulMᵀ!, Tuple{AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, y, m, v)
     @assert length(y) == m.Ndim && length(v) == m.Ndim
     chk(ccall((:elph_mulMT, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
     served!(e)
@@ -331,7 +344,7 @@ end
 "y = MᵀM⋅v in one fused pass (the reference goes through model.v′, Models.jl:215-224)"
 function mulMᵀM!(y::Vector{Float64}, m::GPUModel, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(mulMᵀM!, Tuple{AbstractVector{Float64},AbstractModel,AbstractVector{Float64}}, y, m, v)
+    e === nothing && return invoke(mulMᵀM!, Tuple{AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, y, m, v)
     @assert length(y) == m.Ndim && length(v) == m.Ndim
     chk(ccall((:elph_mulMTM, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
     served!(e)
@@ -341,7 +354,7 @@ end
 "y = MMᵀ⋅v (Models.jl:229-238)"
 function mulMMᵀ!(y::Vector{Float64}, m::GPUModel, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(mulMMᵀ!, Tuple{AbstractVector{Float64},AbstractModel,AbstractVector{Float64}}, y, m, v)
+    e === nothing && return invoke(mulMMᵀ!, Tuple{AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, y, m, v)
     @assert length(y) == m.Ndim && length(v) == m.Ndim
     chk(ccall((:elph_mulMMT, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, y, v))
     served!(e)
@@ -356,7 +369,7 @@ end
 "muldMdx!(dMdx, u, holstein, v) — HolsteinModels.jl:691-755"
 function muldMdx!(dMdx::Vector{Float64}, u::Vector{Float64}, m::HolsteinModel{Float64,Float64}, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, dMdx, u, m, v)
+    e === nothing && return invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, dMdx, u, m, v)
     @assert length(dMdx) == m.Ndim && length(u) == m.Ndim && length(v) == m.Ndim
     chk(ccall((:elph_muldMdx_holstein, lib), Cint,
               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64),
@@ -369,7 +382,7 @@ end
 recursions per time slice), ∂K/∂x, the τ = 1 sign and the sum over equivalent fields are applied here exactly as at :797-826"
 function muldMdx!(dMdx::Vector{Float64}, u::Vector{Float64}, m::SSHModel{Float64,Float64}, v::Vector{Float64})
     e = entry(m)
-    e === nothing && return invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, dMdx, u, m, v)
+    e === nothing && return invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, dMdx, u, m, v)
     @assert length(dMdx) == m.Ndof && length(u) == m.Ndim && length(v) == m.Ndim
     q = e.q                             # q[τ, n] = c_j b_i + c_i b_j for checkerboard bond n: (Lτ × Nbonds) column-major = elph_muldMdx_ssh's q_out
     chk(ccall((:elph_muldMdx_ssh, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), e.handle, q, u, v))
@@ -457,7 +470,7 @@ function ldiv!(x::Vector{Float64}, m::GPUModel, b::Vector{Float64}; maxiter::Int
     e = entry(m)
     if e === nothing || !servable(m)
         deferred!(e)
-        return invoke(ldiv!, Tuple{AbstractVector,AbstractModel,AbstractVector}, x, m, b; maxiter=maxiter)
+        return invoke(ldiv!, Tuple{AbstractVector,typeof(m),AbstractVector}, x, m, b; maxiter=maxiter)
     end
     return gpu_ldiv!(x, e, m, b, false, maxiter)
 end
@@ -467,7 +480,7 @@ function ldiv!(x::Vector{Float64}, m::GPUModel, b::Vector{Float64}, P; maxiter::
     mode = (e === nothing || !servable(m)) ? -1 : precond_mode(e, m, P)
     if mode < 0
         deferred!(e)
-        return invoke(ldiv!, Tuple{AbstractVector,AbstractModel,AbstractVector,Any}, x, m, b, P; maxiter=maxiter)
+        return invoke(ldiv!, Tuple{AbstractVector,typeof(m),AbstractVector,Any}, x, m, b, P; maxiter=maxiter)
     end
     return gpu_ldiv!(x, e, m, b, mode == 1, maxiter)
 end
@@ -766,6 +779,81 @@ function fourier_accelerate!(v′::Vector{Float64}, fa::FourierAccelerator{Float
               e.handle, v′, v, use_mass ? fa.M : fa.Q, power, fa.N))
     served!(e)
     return nothing
+end
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# selftest — the first thing to run where Julia and a GPU meet (this file was written where neither existed)
+# ------------------------------------------------------------------------------------------------------------------------------
+
+relerr(a, b) = norm(a .- b) / max(norm(b), floatmin(Float64))
+
+"""
+    selftest(model; P = I, rtol_mul = 1e-12, rtol_solve = 1e-10, solver_tol = 1e-13, verbose = true) -> NamedTuple
+
+Run the operator API of `model` twice on the same seeded vectors — attached (the library) and detached (the reference's own methods,
+reached through the `invoke` fall-backs of this file) — and compare: `update_model!`, `mulM!`, `mulMᵀ!`, `mulMᵀM!`, `mulMMᵀ!`,
+`muldMdx!` to `rtol_mul`; `ldiv!(x, model, b)` (and `ldiv!(x, model, b, P)` when a `SymmetricKPMPreconditioner` of this model is
+given) to `rtol_solve`, the solver's tolerance tightened to `solver_tol` for the duration so that both solutions sit at the fixed point.
+Use a small model (4 × 4 sites, Lτ ≈ 20): the detached pass is the CPU code.  The model's phonon field, solver settings and attachment
+(same device, same options) are as before on return; `model.rng` advances only if `P` is given (two `setup!`s).  Throws an
+`ErrorException` naming the first quantity out of tolerance; returns the measured errors and iteration counts otherwise.
+
+What a failure means: a MethodError in the detached pass — an `invoke` tuple of this file does not select the reference's method (the
+static check tests/test_julia_dispatch.py restates Julia's rule and may be wrong where this run is right); a numerical mismatch in
+the attached pass — the layout handed to `elph_create` (checkerboard order of `neighbor_table`, `cosht`/`sinht`) is not what this
+version of the reference's `initialize_model!` produces.
+"""
+function selftest(model::GPUModel; P=I, rtol_mul::Float64=1e-12, rtol_solve::Float64=1e-10, solver_tol::Float64=1e-13, verbose::Bool=true)
+    n = model.Ndim
+    rng = MersenneTwister(20260131)
+    v = randn(rng, n); u = randn(rng, n); b = randn(rng, n)
+    e0 = entry(model)
+    opts = e0 === nothing ? (device=0, host_sync=true, batch_pseudofermions=true, resident_hmc=false) :
+           (device=e0.device, host_sync=e0.host_sync, batch_pseudofermions=e0.batch_pseudofermions, resident_hmc=e0.resident_hmc)
+    saved = (model.mul_by_M, model.transposed, model.solver.tol)
+    model.mul_by_M = false; model.transposed = false; model.solver.tol = solver_tol
+    with_P = P isa SymmetricKPMPreconditioner
+    function pass()
+        update_model!(model)
+        yM = zeros(n); mulM!(yM, model, v)
+        yMᵀ = zeros(n); mulMᵀ!(yMᵀ, model, v)
+        yMᵀM = zeros(n); mulMᵀM!(yMᵀM, model, v)
+        yMMᵀ = zeros(n); mulMMᵀ!(yMMᵀ, model, v)
+        d = zeros(model isa HolsteinModel ? n : model.Ndof); muldMdx!(d, u, model, v)
+        x = zeros(n); it, _, fl = ldiv!(x, model, b)
+        xP = zeros(n); itP = 0; flP = 0
+        if with_P
+            setup!(P)
+            itP, _, flP = ldiv!(xP, model, b, P)
+        end
+        return (yM=yM, yMᵀ=yMᵀ, yMᵀM=yMᵀM, yMMᵀ=yMMᵀ, dMdx=d, x=x, iters=it, flag=fl, xP=xP, itersP=itP, flagP=flP)
+    end
+    local g, c, served
+    try
+        e0 === nothing && attach!(model)
+        g = pass()
+        served = status(model)
+        detach!(model)
+        c = pass()                          # every call: added method -> registry miss -> invoke -> the reference's method
+    finally
+        model.mul_by_M, model.transposed, model.solver.tol = saved
+        attached(model) && e0 === nothing && detach!(model)
+        if e0 !== nothing && !attached(model)
+            attach!(model; opts...)
+        end
+    end
+    errs = (mulM=relerr(g.yM, c.yM), mulMᵀ=relerr(g.yMᵀ, c.yMᵀ), mulMᵀM=relerr(g.yMᵀM, c.yMᵀM), mulMMᵀ=relerr(g.yMMᵀ, c.yMMᵀ),
+            muldMdx=relerr(g.dMdx, c.dMdx), ldiv=relerr(g.x, c.x), ldiv_P=with_P ? relerr(g.xP, c.xP) : 0.0,
+            iters=(g.iters, c.iters), iters_P=(g.itersP, c.itersP), flags=(g.flag, c.flag, g.flagP, c.flagP), device_calls=served[1])
+    verbose && @info "ElPhGPU.selftest" errs build=build_info()
+    served[1] >= 7 || error("selftest: the attached pass was not served by the library (device calls: $(served[1]))")
+    for k in (:mulM, :mulMᵀ, :mulMᵀM, :mulMMᵀ, :muldMdx)
+        errs[k] <= rtol_mul || error("selftest: $k differs between the library and the reference's method: $(errs[k]) > $rtol_mul")
+    end
+    all(iszero, errs.flags) || error("selftest: a solve did not converge (flags $(errs.flags)); use a smaller model or a looser solver_tol")
+    errs.ldiv <= rtol_solve || error("selftest: ldiv! solutions differ: $(errs.ldiv) > $rtol_solve (iterations $(errs.iters))")
+    errs.ldiv_P <= rtol_solve || error("selftest: preconditioned ldiv! solutions differ: $(errs.ldiv_P) > $rtol_solve (iterations $(errs.iters_P))")
+    return errs
 end
 
 end # module

@@ -111,7 +111,7 @@ def _strip(src):
             j = i + 1
             while src[j] != '"':
                 j += 2 if src[j] == "\\" else 1
-            out.append('""')
+            out.append('""' + "\n" * src[i:j].count("\n"))
             i = j + 1
         elif c == "#":
             j = src.find("\n", i)
@@ -366,3 +366,274 @@ def test_every_field_the_binding_touches_exists_in_the_reference(code):
     ent = set(re.findall(r"^\s+(" + IDENT + r")::", code[code.index("mutable struct Entry"):code.index("const REGISTRY")], re.M))
     for mm in re.finditer(r"(?<![\w.])e\.(" + IDENT + r")", code):
         assert mm.group(1) in ent | {"code", "msg"}, mm.group(0)      # (e::ElphError in showerror)
+
+
+# ---- the fall-backs: every `invoke(f, Tuple{…}, …)` of the binding reaches the reference's method ------------------------------------------
+#
+# `invoke` throws a MethodError unless its tuple type is a SUBTYPE of some method's signature; round 5 shipped eight tuples with a bare
+# `HolsteinModel` / `SSHModel` / `AbstractModel` where the reference's signature ties the model's T2 to the vectors' element type — for
+# every un-attached model that was a MethodError on the first mat-vec.  tests/julia_types.py restates the needed part of Julia's subtype
+# relation; here every tuple is parsed and checked against the header of the reference method it must reach.
+
+import julia_types as JT  # noqa: E402
+
+# the reference's methods of every function the binding invokes: (name, file, line, header).  Interface declarations only (no bodies);
+# re-derived from /root/reference/src when it is present (test_reference_method_table_is_current).
+INVOKED = ["update_model!", "mulM!", "mulMᵀ!", "mulMᵀM!", "mulMMᵀ!", "muldMdx!", "ldiv!", "solve!", "setup!", "calc_O⁻¹Λϕ!", "update!",
+           "fourier_accelerate!"]
+# a name can belong to different generic functions in different modules: the files whose methods extend the function the binding imports
+OWNER_FILES = {"update!": {"HMC.jl"}, "setup!": {"KPMPreconditioners.jl"}, "solve!": {"IterativeSolvers.jl"}}
+REF_METHODS = [
+    ("fourier_accelerate!", "FourierAcceleration.jl", 91, "function fourier_accelerate!(v′::AbstractVector{Complex{T}}, fa::FourierAccelerator{T}, v::AbstractVector{Complex{T}}, power::T; use_mass::Bool=false) where {T<:AbstractFloat}"),
+    ("fourier_accelerate!", "FourierAcceleration.jl", 117, "function fourier_accelerate!(v′::AbstractVector{Complex{T}}, fa::FourierAccelerator{T}, v::AbstractVector{T}, power::T; use_mass::Bool=false) where {T<:AbstractFloat}"),
+    ("fourier_accelerate!", "FourierAcceleration.jl", 124, "function fourier_accelerate!(v′::AbstractVector{T}, fa::FourierAccelerator{T}, v::AbstractVector{Complex{T}}, power::T; use_mass::Bool=false) where {T<:AbstractFloat}"),
+    ("fourier_accelerate!", "FourierAcceleration.jl", 131, "function fourier_accelerate!(v′::AbstractVector{T}, fa::FourierAccelerator{T}, v::AbstractVector{T}, power::T; use_mass::Bool=false) where {T<:AbstractFloat}"),
+    ("fourier_accelerate!", "FourierAcceleration.jl", 139, "function fourier_accelerate!(v::AbstractVector, fa::FourierAccelerator{T}, power::T; use_mass::Bool=false) where {T<:AbstractFloat}"),
+    ("update!", "HMC.jl", 310, "function update!(model::AbstractModel{T1,T2}, hmc::HybridMonteCarlo{T1}, fa::FourierAccelerator{T1}, preconditioner=I)::Tuple{Bool,T1} where {T1,T2}"),
+    ("calc_O⁻¹Λϕ!", "HMC.jl", 820, "function calc_O⁻¹Λϕ!(hmc::HybridMonteCarlo{T1}, model::AbstractModel{T1,T2}, preconditioner=I, power::T1=1.0)::Tuple{Int,Int} where {T1,T2}"),
+    ("update_model!", "HolsteinModels.jl", 526, "function update_model!(holstein::HolsteinModel)"),
+    ("mulM!", "HolsteinModels.jl", 569, "function mulM!(y::AbstractVector{T2},holstein::HolsteinModel{T1,T3},v::AbstractVector{T2}) where {T1<:AbstractFloat,T2<:Number,T3<:Number}"),
+    ("mulMᵀ!", "HolsteinModels.jl", 631, "function mulMᵀ!(y::AbstractVector{T2},holstein::HolsteinModel{T1,T3},v::AbstractVector{T2}) where {T1<:AbstractFloat,T2<:Number,T3<:Number}"),
+    ("muldMdx!", "HolsteinModels.jl", 691, "function muldMdx!(dMdx::AbstractVector{T2},u::AbstractVector{T2},holstein::HolsteinModel{T1,T2,T3},v::AbstractVector{T2}) where {T1,T2,T3}"),
+    ("ldiv!", "IterativeSolvers.jl", 14, "function ldiv!(vout::AbstractVector,I::UniformScaling,vin::AbstractVector)"),
+    ("solve!", "IterativeSolvers.jl", 64, "function solve!(x::AbstractVector{Tdata},A,b::AbstractVector{Tdata},cg::ConjugateGradient{Ttol,Tdata},L,Lt; maxiter::Int=0,tol::Ttol=0.0,κmax::Ttol=0.0)::Int where {Ttol,Tdata}"),
+    ("solve!", "IterativeSolvers.jl", 153, "function solve!(x::AbstractVector{Tdata},A,b::AbstractVector{Tdata},cg::ConjugateGradient{Ttol,Tdata},P; maxiter::Int=0,tol::Ttol=0.0,κmax::Ttol=0.0)::Int where {Ttol,Tdata}"),
+    ("solve!", "IterativeSolvers.jl", 239, "function solve!(x::AbstractVector{Tdata},A,b::AbstractVector{Tdata},cg::ConjugateGradient{Ttol,Tdata}; maxiter::Int=0,tol::Ttol=0.0,κmax::Ttol=0.0)::Int where {Ttol,Tdata}"),
+    ("setup!", "KPMPreconditioners.jl", 259, "function setup!(op::KPMPreconditioner)"),
+    ("setup!", "KPMPreconditioners.jl", 269, "function setup!(op::KPMExpansion{T1,T2,T3}) where {T1,T2,T3}"),
+    ("setup!", "KPMPreconditioners.jl", 323, "function setup!(op)"),
+    ("ldiv!", "KPMPreconditioners.jl", 406, "function ldiv!(v′::AbstractVector{T4},op::KPMExpansion{T1,T2,T3},v::AbstractVector{T4}) where {T1,T2,T3,T4<:Continuous}"),
+    ("ldiv!", "KPMPreconditioners.jl", 426, "function ldiv!(vout::AbstractVector{T},P::KPMPreconditioner,vin::AbstractVector{T}) where {T<:AbstractFloat}"),
+    ("ldiv!", "KPMPreconditioners.jl", 484, "function ldiv!(op::KPMPreconditioner,v::AbstractVector)"),
+    ("ldiv!", "Models.jl", 74, "function ldiv!(x::AbstractVector, model::AbstractModel{T1,T2,T3}, b::AbstractVector, P; maxiter::Int=0)::Tuple{Int,T1,Int} where {T1,T2,T3}"),
+    ("ldiv!", "Models.jl", 139, "function ldiv!(x::AbstractVector, model::AbstractModel{T1,T2,T3}, b::AbstractVector; maxiter::Int=0)::Tuple{Int,T1,Int} where {T1,T2,T3}"),
+    ("mulMᵀM!", "Models.jl", 215, "function mulMᵀM!(y::AbstractVector{T2},model::AbstractModel{T1,T2},v::AbstractVector{T2}) where {T1,T2}"),
+    ("mulMMᵀ!", "Models.jl", 229, "function mulMMᵀ!(y::AbstractVector{T2},model::AbstractModel{T1,T2},v::AbstractVector{T2}) where {T1,T2}"),
+    ("update_model!", "SSHModels.jl", 510, "function update_model!(ssh::SSHModel{T1,T2}) where {T1,T2}"),
+    ("mulM!", "SSHModels.jl", 581, "function mulM!(Mv::AbstractVector{T2},ssh::SSHModel{T1,T2},v::AbstractVector{T2}) where {T1,T2}"),
+    ("mulMᵀ!", "SSHModels.jl", 646, "function mulMᵀ!(Mᵀv::AbstractVector{T2},ssh::SSHModel{T1,T2},v::AbstractVector{T2}) where {T1,T2}"),
+    ("muldMdx!", "SSHModels.jl", 707, "function muldMdx!(dMdx::AbstractVector{T2},u::AbstractVector{T2},ssh::SSHModel{T1,T2},v::AbstractVector{T2}) where {T1,T2}"),
+]
+# solvers the library does not replace: their `solve!` methods name types outside the table and can never cover a ConjugateGradient tuple
+SKIPPED_HEADERS = ("BiCGStab{", "GMRES{")
+
+
+def _headers_of(src):
+    """(name, line, header on one line) of every top-level `function name(…) [::Ret] [where …]` in a Julia source text."""
+    out = []
+    for m in re.finditer(r"^function\s+([^\s(]+)\(", src, re.M):
+        depth, j = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        k = src.find("\n", j)
+        hdr = re.sub(r"\s*\n\s*", " ", src[m.start():k]).strip()
+        out.append((m.group(1), src.count("\n", 0, m.start()) + 1, re.sub(r"\s+where", " where", hdr)))
+    return out
+
+
+def test_reference_method_table_is_current():
+    if not os.path.isdir(REF):
+        pytest.skip("reference sources not on this machine")
+    found = []
+    for f in sorted(os.listdir(REF)):
+        if not f.endswith(".jl"):
+            continue
+        for name, ln, hdr in _headers_of(open(os.path.join(REF, f), encoding="utf-8").read()):
+            if name in INVOKED and f in OWNER_FILES.get(name, {f}) and not any(k in hdr for k in SKIPPED_HEADERS):
+                found.append((name, f, ln, hdr))
+    assert sorted(found) == sorted(REF_METHODS)
+
+
+def test_declarations_are_the_reference():
+    """The struct / abstract-type headers tests/julia_types.py works from are the reference's (parameters, bounds, supertype)."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference sources not on this machine")
+    text = "".join(open(os.path.join(REF, f), encoding="utf-8").read() for f in sorted(os.listdir(REF)) if f.endswith(".jl"))
+    for name in ("IterativeSolver", "ConjugateGradient", "AbstractModel", "HolsteinModel", "SSHModel", "KPMPreconditioner",
+                 "SymmetricKPMPreconditioner", "KPMExpansion", "HybridMonteCarlo", "FourierAccelerator"):
+        m = re.search(r"^(?:mutable\s+)?(?:struct|abstract type)\s+" + name + r"\{([^}]*)\}(?:\s*<:\s*(\S+))?", text, re.M)
+        assert m, name
+        params = []
+        for p in JT.split_top(m.group(1)):
+            nm, _, b = p.partition("<:")
+            params.append((nm.strip(), b.strip() or None))
+        decl, sup = JT.DECLS[name]
+        assert [d[0] for d in decl] == [q[0] for q in params], (name, params)
+        for (dn, db), (pn, pb) in zip(decl, params):
+            if name == "FourierAccelerator" and pn != "T":
+                continue                 # FFT plan types: never constrained by a signature on the path
+            assert db == pb, (name, dn, db, pb)
+        assert (sup or "Any") == (m.group(2) or "Any"), (name, sup, m.group(2))
+    assert re.search(r"^Continuous = Union\{AbstractFloat,Complex\{<:AbstractFloat\}\}", text, re.M)
+
+
+def _binding_methods(code):
+    """{name: [(argument types, {tvar: bound}, [argument names], start offset, end offset)]} of the binding's long-form methods."""
+    out = {}
+    for m in re.finditer(r"^function\s+([^\s(]+)\(", code, re.M):
+        depth, j = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(code[j], 0)
+            j += 1
+        k = code.find("\n", j)
+        end = code.find("\nend\n", m.start())
+        hdr = re.sub(r"\s*\n\s*", " ", code[m.start():k])
+        try:
+            for name, types, tv, names in JT.parse_method(hdr):
+                out.setdefault(name, []).append((types, tv, names, m.start(), end))
+        except AssertionError:
+            continue                     # a helper whose signature uses types outside the table: never the target of an invoke
+    return out
+
+
+def _invokes(code):
+    """[(function, [tuple element texts], line, offset)] of every invoke( f, Tuple{…}, … ) in the binding."""
+    out = []
+    for m in re.finditer(r"\binvoke\(\s*([^\s,]+)\s*,\s*Tuple\{", code):
+        depth, j = 1, m.end()
+        while depth:
+            depth += {"{": 1, "}": -1}.get(code[j], 0)
+            j += 1
+        out.append((m.group(1), JT.split_top(code[m.end():j - 1]), code.count("\n", 0, m.start()) + 1, m.start()))
+    return out
+
+
+# the reference method each fall-back must reach: (function, arity) -> (file, line); Holstein / SSH decided by the model type in scope
+EXPECTED_TARGET = {
+    ("mulMᵀM!", 3): [("Models.jl", 215)], ("mulMMᵀ!", 3): [("Models.jl", 229)],
+    ("ldiv!", 3): [("Models.jl", 139), ("KPMPreconditioners.jl", 426)], ("ldiv!", 4): [("Models.jl", 74)],
+    ("solve!", 4): [("IterativeSolvers.jl", 239)], ("solve!", 5): [("IterativeSolvers.jl", 153)],
+    ("setup!", 1): [("KPMPreconditioners.jl", 259)], ("calc_O⁻¹Λϕ!", 4): [("HMC.jl", 820)], ("update!", 4): [("HMC.jl", 310)],
+    ("fourier_accelerate!", 4): [("FourierAcceleration.jl", 131)],
+    ("update_model!", 1): [("HolsteinModels.jl", 526), ("SSHModels.jl", 510)],
+    ("mulM!", 3): [("HolsteinModels.jl", 569), ("SSHModels.jl", 581)], ("mulMᵀ!", 3): [("HolsteinModels.jl", 631), ("SSHModels.jl", 646)],
+    ("muldMdx!", 4): [("HolsteinModels.jl", 691), ("SSHModels.jl", 707)],
+}
+
+
+def check_invokes(code):
+    """Every invoke of `code` against REF_METHODS and the binding's own methods -> [(line, function, problem)] (empty: all reach the
+    reference).  A tuple must (1) be covered by exactly one reference method for every concrete alternative of its `typeof`s, that
+    method being the one the fall-back is written for, and (2) NOT be covered by a method of the binding itself (that would be the
+    more specific one: the fall-back would call itself for ever)."""
+    own = _binding_methods(code)
+    problems, checked = [], 0
+    for fname, elems, line, off in _invokes(code):
+        encl = [(t, tv, n) for ms in own.values() for (t, tv, n, a, b) in ms if a <= off <= b]
+        declared = {}
+        for types, tv, names in encl:
+            for nm, ty in zip(names, types):
+                declared[nm] = JT.parse_type(ty, tuple(tv))
+        try:
+            parsed = [JT.resolve_typeof(JT.parse_type(e), declared) for e in elems]
+        except AssertionError as e:
+            problems.append((line, fname, f"unparsable tuple: {e}"))
+            continue
+        for alt in JT.expand_unions(parsed):
+            hits, why = [], []
+            for name, f, ln, hdr in REF_METHODS:
+                if name != fname:
+                    continue
+                for _, types, tv, _names in JT.parse_method(hdr):
+                    ok, reason = JT.Matcher(types, tv).covers(alt)
+                    if ok:
+                        hits.append((f, ln, types, tv))
+                    elif len(types) == len(alt):
+                        why.append(f"{f}:{ln}: {reason}")
+            shown = "Tuple{" + ",".join(JT.show(t) for t in alt) + "}"
+            if not hits:
+                problems.append((line, fname, f"{shown} is covered by NO reference method (MethodError at run time) — " + "; ".join(why)))
+                continue
+            if len(hits) > 1:
+                # the most specific one runs: the hit whose own signature every other hit covers (signatures without type variables only)
+                best = [h for h in hits if not h[3] and all(JT.Matcher(g[2], g[3]).covers([JT.parse_type(t) for t in h[2]])[0] for g in hits)]
+                if len(best) != 1:
+                    problems.append((line, fname, f"{shown} is covered by several reference methods {[h[:2] for h in hits]} and none is the most specific"))
+                    continue
+                hits = best
+            hits = [h[:2] for h in hits]
+            if hits[0] not in EXPECTED_TARGET.get((fname, len(alt)), []):
+                problems.append((line, fname, f"{shown} reaches {hits[0]}, not one of {EXPECTED_TARGET.get((fname, len(alt)))}"))
+            for types, tv, _n, _a, _b in own.get(fname, []):
+                ok, _ = JT.Matcher(types, tv).covers(alt)
+                if ok:
+                    problems.append((line, fname, f"{shown} is also covered by the binding's own method ({', '.join(types)}): the fall-back would recurse"))
+            checked += 1
+    return problems, checked
+
+
+def test_every_invoke_tuple_is_covered_by_the_reference_method_it_names(code):
+    problems, checked = check_invokes(code)
+    assert not problems, "\n".join(f"julia/ElPhGPU.jl:{ln} invoke({fn}, …): {p}" for ln, fn, p in problems)
+    assert checked >= 23                  # every invoke of the file was looked at (GPUModel alternatives count once each)
+    assert len(_invokes(code)) == 23
+
+
+# the eight tuples round 5 shipped (VERDICT r05 "What's weak" 2): each must be REJECTED by the check above, for the right reason
+ROUND5_BROKEN = [
+    ("mulM!", "HolsteinModel{Float64,Float64}", "invoke(mulM!, Tuple{AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, y, m, v)"),
+    ("mulM!", "SSHModel{Float64,Float64}", "invoke(mulM!, Tuple{AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, y, m, v)"),
+    ("mulMᵀ!", "HolsteinModel{Float64,Float64}", "invoke(mulMᵀ!, Tuple{AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, y, m, v)"),
+    ("mulMᵀ!", "SSHModel{Float64,Float64}", "invoke(mulMᵀ!, Tuple{AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, y, m, v)"),
+    ("mulMᵀM!", "GPUModel", "invoke(mulMᵀM!, Tuple{AbstractVector{Float64},AbstractModel,AbstractVector{Float64}}, y, m, v)"),
+    ("mulMMᵀ!", "GPUModel", "invoke(mulMMᵀ!, Tuple{AbstractVector{Float64},AbstractModel,AbstractVector{Float64}}, y, m, v)"),
+    ("muldMdx!", "HolsteinModel{Float64,Float64}", "invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},HolsteinModel,AbstractVector{Float64}}, y, u, m, v)"),
+    ("muldMdx!", "SSHModel{Float64,Float64}", "invoke(muldMdx!, Tuple{AbstractVector{Float64},AbstractVector{Float64},SSHModel,AbstractVector{Float64}}, y, u, m, v)"),
+]
+
+
+@pytest.mark.parametrize("fname,mtype,call", ROUND5_BROKEN, ids=[f"{a}-{b.split('{')[0]}" for a, b, _ in ROUND5_BROKEN])
+def test_the_round5_tuples_are_rejected(fname, mtype, call):
+    nargs = 4 if fname == "muldMdx!" else 3
+    args = ("y::Vector{Float64}, u::Vector{Float64}, " if nargs == 4 else "y::Vector{Float64}, ") + f"m::{mtype}, v::Vector{{Float64}}"
+    snippet = f"function {fname}({args})\n    return {call}\nend\n"
+    problems, checked = check_invokes(snippet)
+    assert problems and all("NO reference method" in p for _, _, p in problems), problems
+    assert any("ties `T2`" in p or "exceeds the bound" in p for _, _, p in problems), problems
+
+
+def test_reintroducing_a_bare_model_type_turns_the_check_red(code):
+    """Mutation check on the file itself: put a bare `SSHModel` (then `AbstractModel`) back into one fall-back — the check must flag
+    exactly that line; a tuple naming the binding's own signature must be flagged as self-recursion."""
+    good = "invoke(mulM!, Tuple{AbstractVector{Float64},typeof(m),AbstractVector{Float64}}, y, m, v)"
+    assert code.count(good) == 2
+    for bare in ("SSHModel", "AbstractModel", "HolsteinModel"):
+        i = code.rindex(good)            # the SSH method's fall-back
+        mutated = code[:i] + good.replace("typeof(m)", bare) + code[i + len(good):]
+        problems, _ = check_invokes(mutated)
+        assert len(problems) == 1 and problems[0][1] == "mulM!" and "NO reference method" in problems[0][2], (bare, problems)
+        assert problems[0][0] == code.count("\n", 0, i) + 1
+    i = code.index(good)
+    mutated = code[:i] + good.replace("AbstractVector{Float64}", "Vector{Float64}") + code[i + len(good):]
+    problems, _ = check_invokes(mutated)
+    assert any("recurse" in p for _, _, p in problems), problems
+    # update_model!(m) has the model as its only argument: typeof(m) there WOULD select the binding's own method
+    j = code.index("invoke(update_model!, Tuple{HolsteinModel}, m)")
+    mutated = code[:j] + "invoke(update_model!, Tuple{typeof(m)}, m)" + code[j + len("invoke(update_model!, Tuple{HolsteinModel}, m)"):]
+    problems, _ = check_invokes(mutated)
+    assert any("recurse" in p for _, _, p in problems), problems
+
+
+def test_subtype_model_knows_the_textbook_cases():
+    """The restated relation on cases whose answer is documented Julia behaviour."""
+    def covers(sig, tv, tup):
+        return JT.Matcher(sig, tv).covers([JT.parse_type(t) for t in tup])[0]
+    # Tuple{Vector} <: Tuple{Vector{T}} where T  (one occurrence: the where can be pushed inside)
+    assert covers(["Vector{T}"], {"T": None}, ["Vector"])
+    # Tuple{Vector,Vector} is NOT <: Tuple{Vector{T},Vector{T}} where T  (the two element types may differ)
+    assert not covers(["Vector{T}", "Vector{T}"], {"T": None}, ["Vector", "Vector"])
+    assert covers(["Vector{T}", "Vector{T}"], {"T": None}, ["Vector{Float64}", "Vector{Float64}"])
+    assert not covers(["Vector{T}", "Vector{T}"], {"T": None}, ["Vector{Float64}", "Vector{Int}"])
+    # invariance: Vector{Float64} is not a Vector{Real}; it is an AbstractVector{Float64}; bounds are honoured
+    assert not covers(["Vector{Real}"], {}, ["Vector{Float64}"])
+    assert covers(["AbstractVector{Float64}"], {}, ["Vector{Float64}"])
+    assert not covers(["Vector{T}"], {"T": "AbstractFloat"}, ["Vector{Int}"])
+    assert not covers(["Vector{T}"], {"T": "AbstractFloat"}, ["Vector"])           # unspecified T (bound Any) exceeds <:AbstractFloat
+    assert covers(["HybridMonteCarlo{T}"], {"T": "AbstractFloat"}, ["HybridMonteCarlo"])      # declared bound of the struct's own T
+    # the reference's case
+    sig, tv = ["AbstractVector{T2}", "AbstractModel{T1,T2}", "AbstractVector{T2}"], {"T1": None, "T2": None}
+    assert not covers(sig, tv, ["AbstractVector{Float64}", "AbstractModel", "AbstractVector{Float64}"])
+    assert covers(sig, tv, ["AbstractVector{Float64}", "AbstractModel{Float64,Float64}", "AbstractVector{Float64}"])
+    assert covers(sig, tv, ["Vector{Float64}", "SSHModel{Float64,Float64}", "Vector{Float64}"])
+    assert not covers(sig, tv, ["Vector{Float64}", "SSHModel{Float64,Complex{Float64}}", "Vector{Float64}"])
