@@ -1,6 +1,7 @@
 // cg_fast.hip — latency-tuned gfx950 kernels for lattices whose checkerboard has <= 6 colours
 // (every even-L square, honeycomb and triangular lattice of the reference's example decks).
-// The kernels live in cg_fast_impl.inc, compiled twice: lane programs of 4 colours (namespace lp4) and of 6 (lp6) —
+// The kernels live in cg_fast_impl.inc, compiled per lane-program width — 4 colours (namespace lp4) and 6 (lp6) — and per sites-per-lane
+// count (cg_fast_npl.hip, 8 translation units each; this file holds what is common to the counts: cg_fast_shared.inc) —
 // the colour count is a compile-time loop bound (bonds live in registers, the fused forward/reverse sweep pairs colour
 // cc with colour MC-1-cc), so a 4-colour lattice does not pay for the two stages only triangular lattices need.
 //
@@ -22,7 +23,7 @@
 
 #define ELPH_LP_MC 4
 #define LPNS lp4
-#include "cg_fast_impl.inc"
+#include "cg_fast_shared.inc"
 #undef ELPH_LP_MC
 #undef LPNS
 

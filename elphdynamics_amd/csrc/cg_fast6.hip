@@ -1,8 +1,8 @@
-// cg_fast6.hip — the 6-colour (triangular-lattice) instantiation of the lane-program kernels; see cg_fast.hip.
+// cg_fast6.hip — what the 6-colour (triangular-lattice) lane programs share across sites-per-lane counts (kernels: cg_fast_npl.hip, -DELPH_LP_MC=6); see cg_fast.hip.
 #include "cg_fast_common.h"
 
 #define ELPH_LP_MC 6
 #define LPNS lp6
-#include "cg_fast_impl.inc"
+#include "cg_fast_shared.inc"
 #undef ELPH_LP_MC
 #undef LPNS
