@@ -18,7 +18,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("ELPH_LIB") or os.path.join(HERE, "libelphgpu.so")
-SOURCES = ["kernels.hip", "cg_fast.hip", "cg_fast6.hip", "cg_wg.hip", "pcg_wg.hip", "shard.hip", "slabs.hip", "pgrid.hip", "kpm_dev.hip", "dft.hip", "dft_mfma.hip", "dft_big.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
+SOURCES = ["kernels.hip", "cg_fast.hip", "cg_fast6.hip", "cg_sq16.hip", "cg_wg.hip", "pcg_wg.hip", "shard.hip", "slabs.hip", "pgrid.hip", "kpm_dev.hip", "dft.hip", "dft_mfma.hip", "dft_big.hip", "elph_api.hip", "hmc.hip", "greens.hip", "kpm_host.cpp"]
 # The lane-program kernels (cg_fast_impl.inc) are one translation unit per (colours per lane program, sites per lane): 2 x 8 objects of
 # cg_fast_npl.hip.  As ONE unit they were 340 kernels and 5 min 42 s on one thread (VERDICT r05 "What's weak" 7); as sixteen they compile
 # side by side.  (object name, source, extra flags)

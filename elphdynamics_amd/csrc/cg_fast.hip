@@ -41,6 +41,9 @@ int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int
 int elph_choose_T(const elph_handle_s *h, int nrhs) { return lp4::elph_choose_T(h, nrhs); }
 int elph_choose_T_px(const elph_handle_s *h, int nrhs) { return lp4::elph_choose_T_px(h, nrhs); }
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool px) {
+    // the p/x-fused step of a preconditioned batch on the 16 x 16 square lattice: the checkerboard in registers (cg_sq16.hip)
+    h->sq16_ap_ran = px && B.npap > 0 && B.npap < (int)h->L && (int)h->L % B.npap == 0 && elph_sq16_ap_usable(h, (int)h->L / B.npap);
+    if (h->sq16_ap_ran) return elph_sq16_cg_ap_px(h, B, nrhs, parity);
     return h->lp_mc == 4 ? lp4::elph_fast_cg_ap(h, B, nrhs, parity, px) : lp6::elph_fast_cg_ap(h, B, nrhs, parity, px);
 }
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) {

@@ -321,6 +321,23 @@ __device__ __forceinline__ double reduce_partials_lane(const double *p, int n, i
 }
 __device__ __forceinline__ double reduce_partials2(const double *p, int n) { return reduce_partials_lane(p, n, threadIdx.x); }
 
+// Which (right-hand side, chunk) a block of the chunked kernel works on.  order 0: block = rhs * nch + chunk (consecutive blocks — which
+// the dispatcher deals round-robin over the 8 XCDs — are the chunks of one right-hand side).  order 1 (XCD-aware; observed placement,
+// correctness never depends on it): the blocks of one XCD (equal blockIdx % 8) walk a contiguous range of the order
+// [chain][chunk][copy], copy = the right-hand sides that share the chain's exp(-dtau V) (rhs = chain + copy * nchains: the two
+// pseudofermion solves of a force evaluation) — so the copies of a chain read the same slices of exp(-dtau V) at the same time on
+// the same L2 (one HBM read instead of one per right-hand side: 47 of 691 MB per launch at 144 chains x 2), and tau-neighbouring
+// chunks, which re-read each other's boundary slices of p and P^-1 r, follow each other on one XCD.
+__device__ __forceinline__ void chunk_block_map(int g, int nrhs, int nch, int nchains, int order, int &rhs, int &ch) {
+    const int nb = nrhs * nch;
+    if (order == 0 || (nb & 7) || nrhs % nchains) { rhs = g / nch; ch = g - rhs * nch; return; }
+    const int per = nrhs / nchains;
+    const int s = (g & 7) * (nb >> 3) + (g >> 3);
+    const int k = s / (per * nch), rem = s - k * (per * nch);
+    ch = rem / per;
+    rhs = k + (rem - ch * per) * nchains;
+}
+
 // Stop test of an iteration (IterativeSolvers.jl:212-219 / :286-295): eps = |r|/|b| < tol, kappa_min = max_j (2j/ln(2 eps0/eps_j))^2
 // > kappa_max, j = maxiter.  Two comparisons screen out the square root, the divisions and the logarithm (~150 dependent f64
 // instructions, half a microsecond on the critical path of every wave) while no decision is near: r.r well above (tol |b|)^2

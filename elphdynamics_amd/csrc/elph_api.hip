@@ -1987,7 +1987,7 @@ extern "C" int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, 
 extern "C" int elph_bench_px_info(elph_handle h, int *fused) {
     CHECK_H(h);
     if (!fused) { elph_set_error("bad argument"); return ELPH_E_ARG; }
-    *fused = h->px_solve ? 1 : 0;
+    *fused = h->px_solve ? (h->sq16_ap_ran ? 2 : 1) : 0;      // 2: with the register-exchange k_cg_ap of the 16 x 16 lattice (cg_sq16.hip)
     return ELPH_OK;
 }
 

@@ -205,6 +205,7 @@ struct elph_handle_s {
     int T_rhs_hint = 0;                    // > 0: right-hand sides in flight when the slices per wave are chosen (two-stream batches: both halves)
     bool ebar_external = false;            // kpm_setup_core: d_Ebar was filled by the caller (elph_i_kpm_setup_ebar)
     bool px_solve = false;                 // the current solve's preconditioned iteration is p/x-fused (kernels.hip: px_plan)
+    bool sq16_ap_ran = false;              // the latest p/x-fused k_cg_ap ran in the register-exchange form (cg_sq16.hip)
     // SSH update_model! on the device (elph_update_model_ssh_fields): staging of x, per-phonon tables, slot map
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;
     int *d_ssh_cb = nullptr, *d_ssh_slot = nullptr;
@@ -399,6 +400,9 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
 int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool px = false);
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
+// cg_sq16.hip: the p/x-fused k_cg_ap of the 16 x 16 square lattice with the checkerboard in registers (no LDS slabs)
+bool elph_sq16_ap_usable(const elph_handle_s *h, int T);
+int elph_sq16_cg_ap_px(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 // ---- one solve over several GPUs (cg_wg.hip, shard.hip): by-value description of this rank's shard for the resident kernel
 #define ELPH_SHARD_MAXREC 256      // records of a meeting: ranks x workgroups per rank (8 x 20 at Ltau = 160; polled as 8 x 64 granules)
 #define ELPH_SHARD_MAXRANKS 8

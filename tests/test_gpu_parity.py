@@ -1362,6 +1362,9 @@ def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, 
     from elphdynamics_amd import configs, models, preconditioners as pc, synth
     if chunk_T:
         monkeypatch.setenv("ELPH_CHUNK_T", chunk_T)
+    # (the statement is about WHERE the p- and x-update are evaluated: both forms with the lane-program k_cg_ap — the register-exchange k_cg_ap of
+    #  the 16 x 16 lattice rounds differently and has its own test below)
+    monkeypatch.setenv("ELPH_SQ16_AP", "0")
     m = configs.make_model(tag, tol=1e-8)
     nrhs = nchains * per
     if nchains > 1 and m.kind == models.SSH:      # bond phonons: the deck's field rescaled and roughened per chain (|alpha x| stays below t)
@@ -1383,6 +1386,48 @@ def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, 
     assert out["0"][2] is False and out["1"][2] is True, "the fused form was not taken: the A/B compares a kernel with itself"
     assert np.array_equal(out["0"][1], out["1"][1])
     assert rel(out["1"][0], out["0"][0]) < 1e-13
+    m.close()
+
+
+@pytest.mark.parametrize("nchains,per,chunk_T,disorder", [(16, 2, None, 0.0), (1, 48, None, 0.0), (64, 2, None, 0.0), (144, 2, None, 0.0), (20, 2, "5", 0.0), (24, 2, "2", 0.0),
+                                                          (24, 2, "20", 0.0), (16, 2, None, 0.1), (64, 2, "8", 0.1)])
+def test_register_exchange_k_cg_ap_of_the_fused_iteration(nchains, per, chunk_T, disorder, monkeypatch):
+    """cg_sq16.hip: the p/x-fused k_cg_ap of the 16 x 16 square lattice (BASELINE config C) with the checkerboard in registers (2 x 2 patch per
+    lane, DPP rotations + one ds_bpermute pair, uniform hopping as c^4 prod (I + th P)) against the lane-program kernel it stands in front of
+    (ELPH_SQ16_AP=0): same recurrences (HolsteinModels.jl:569-684, IterativeSolvers.jl:153-234), rounding differs — iteration counts within
+    one, solutions of two tol = 1e-8 solves to 1e-9 — and against the oracle's preconditioned solve on sampled right-hand sides (1e-7: two
+    solves stopped at 1e-8).  disorder > 0: hopping disorder, i.e. the per-site (cosh, sinh) variant of the kernel."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    if chunk_T:
+        monkeypatch.setenv("ELPH_CHUNK_T", chunk_T)
+    m = configs.make_model("C", tol=1e-8, t_stddev=disorder)
+    nrhs = nchains * per
+    if nchains > 1:
+        X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=8600 + c) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    (pc.setup_chains_ if nchains > 1 else pc.setup_)(P, rng=np.random.default_rng(13))
+    B = np.stack([synth.randn(8700 + r, m.Ndim) for r in range(nrhs)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_SQ16_AP", mode)
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any()
+        f = C.c_int()
+        from elphdynamics_amd import _lib
+        _lib.check(_lib.load().elph_bench_px_info(m._h, C.byref(f)))
+        out[mode] = (Xs, it, f.value)
+    assert out["0"][2] == 1 and out["1"][2] == 2, f"forms taken: {out['0'][2]}, {out['1'][2]} (1 = lane program, 2 = registers)"
+    assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
+    assert rel(out["1"][0], out["0"][0]) < 1e-9
+    # the post-solve residual of every right-hand side, computed by the un-fused mat-vec: |MtM x - b| / |b| <= a few tol
+    for r in range(0, nrhs, max(1, nrhs // 6)):
+        if nchains > 1:
+            continue                     # (chains: models.mulMtM_ applies chain 0's matrix)
+        y = np.empty(m.Ndim)
+        models.mulMtM_(y, m, np.ascontiguousarray(out["1"][0][r]))
+        assert np.linalg.norm(y - B[r]) / np.linalg.norm(B[r]) < 5e-8
     m.close()
 
 
