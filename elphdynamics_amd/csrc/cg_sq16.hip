@@ -233,7 +233,7 @@ int elph_sq16_cg_ap_px(elph_handle_s *h, const CgBufs &B, int nrhs, int parity) 
     const int po = parity | ((xcd_order && h->solo_chain < 0) ? 2 : 0);
     const dim3 grid((unsigned)(nrhs * B.npap));
     // (ring depth / waves per SIMD: ELPH_SQ16_SHAPE=<depth><waves>, e.g. 24 — measurement only)
-    static const int shape = []() { const char *e = getenv("ELPH_SQ16_SHAPE"); return e ? atoi(e) : 0; }();
+    const int shape = []() { const char *e = getenv("ELPH_SQ16_SHAPE"); return e ? atoi(e) : 0; }();      // (read per call: in-process A/B)
 #define SQ16_LAUNCH(TT)                                                                                                            \
     do {                                                                                                                            \
         if (!m.uniform) hipLaunchKernelGGL((sq16::k_cg_ap_sq16_px<TT, false, 2, 2>), grid, dim3(WAVE), 0, h->stream, B, m, po);     \

@@ -1670,6 +1670,21 @@ static hipError_t launch_npl(elph_handle_s *h, const Shape &sh, dim3 grid, const
 }  // namespace wg
 
 // Whether the workgroup-resident kernel can run this handle's un-preconditioned solves (and with which shape).
+// How many workgroups of the resident kernels may a launch count on being resident AT ONCE on this handle's device?  Their teams spin on
+// one another's records: a workgroup that is not resident is waited for until the time-out.  One workgroup per CU (the kernels run at 256
+// registers x 8 waves, or need most of the LDS), a sixteenth of the CUs left to whatever else the device runs: 240 on a whole MI355X
+// (256 CUs), proportionally fewer on a partitioned or CU-masked device (CPX: 32 CUs -> 30).  Queried once per device.
+int elph_i_resident_wg_limit(const elph_handle_s *h) {
+    static int cache[64] = {};
+    const int d = (h && h->device >= 0 && h->device < 64) ? h->device : 0;
+    if (cache[d] <= 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0) cus = 256;
+        cache[d] = std::max(1, cus - cus / 16);
+    }
+    return cache[d];
+}
+
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs) {
     const char *eo = getenv("ELPH_NO_WG");                 // read per call: the tests switch between the two forms
     const bool off = eo && eo[0] == '1';
@@ -1930,7 +1945,7 @@ int elph_wg_cg_ranks(elph_handle_s *const *hs, int P, const CgBufs *Bs, long lon
         A[(size_t)q].B = Bs[q];
         A[(size_t)q].Sh = ctls[q];
     }
-    if ((long long)P * sh0.G > 240) { elph_set_error("slabs on one device: %d x %d workgroups cannot all be resident", P, sh0.G); return ELPH_E_UNSUPPORTED; }
+    if ((long long)P * sh0.G > elph_i_resident_wg_limit(hs[0])) { elph_set_error("slabs on one device: %d x %d workgroups cannot all be resident", P, sh0.G); return ELPH_E_UNSUPPORTED; }
     HIPCHK(hipMemcpyAsync(d_args, A, (size_t)P * sizeof(wg::WgRankArgs), hipMemcpyHostToDevice, stream));
     wg::WgCtl R0 = A[0].R;
     R0.ranks = d_args;

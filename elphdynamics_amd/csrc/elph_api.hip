@@ -474,7 +474,8 @@ extern "C" int elph_destroy(elph_handle h) {
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    for (int k = 1; k < ELPH_SPLIT_MAX; ++k)
+        if (h->split_stream[k]) (void)hipStreamDestroy(h->split_stream[k]);
     if (h->split_ev) (void)hipEventDestroy(h->split_ev);
     delete h;
     return ELPH_OK;
@@ -793,18 +794,37 @@ static int get_chunk_graph(elph_handle_s *h, int nrhs, int use_prec, hipGraphExe
 // the batch size) and halves that hold whole groups of chains.  ELPH_SPLIT_STREAMS=0 off, =1 wherever legal; default from 192 right-hand sides.
 // ------------------------------------------------------------------------------------------
 struct SplitRun {
-    bool on = false;
-    int n1 = 0, n2 = 0;
-    elph_handle_s *main = nullptr, *view = nullptr;
-    ~SplitRun() { if (main) main->T_rhs_hint = 0; delete view; }
+    bool on = false, ok = false, px_before = false;
+    int ways = 0, n1 = 0;                                 // `ways` parts of n1 right-hand sides each; part 0 is the handle itself on its own stream
+    elph_handle_s *main = nullptr, *view[ELPH_SPLIT_MAX] = {};
+    // A solve that leaves through an error return must not leave kernels of the other streams in flight behind it (they write d_x, d_p, d_r,
+    // d_state of their parts while the caller's next step — ldiv's zero-fill, a retry, a new solve — runs on the main stream), nor the handle
+    // believing in a p/x-fused solve that never happened.
+    ~SplitRun() {
+        if (main) main->T_rhs_hint = 0;
+        for (int k = 1; k < ways; ++k)
+            if (view[k]) {
+                if (on) (void)hipStreamSynchronize(view[k]->stream);
+                delete view[k];
+            }
+        if (main && on && !ok) main->px_solve = px_before;
+    }
 };
 
+// parts of the split form: ELPH_SPLIT_WAYS (2 … 8) [2]
+static int split_ways() {
+    const char *e = getenv("ELPH_SPLIT_WAYS");
+    const int w = e ? atoi(e) : 2;
+    return w < 2 ? 2 : (w > ELPH_SPLIT_MAX ? ELPH_SPLIT_MAX : w);
+}
+
 static bool split_legal(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
-    if (!use_prec || hist || h->use_graph || nrhs < 4 || (nrhs & 1) || h->solo_chain >= 0 || h->dot_hi > 0) return false;
-    const int n1 = nrhs / 2;
+    const int ways = split_ways();
+    if (!use_prec || hist || h->use_graph || nrhs < 2 * ways || (nrhs % ways) || h->solo_chain >= 0 || h->dot_hi > 0) return false;
+    const int n1 = nrhs / ways;
     if (n1 % std::max(1, h->nchains) || n1 % std::max(1, h->kpm_nch)) return false;
     const int keep = h->T_rhs_hint;
-    h->T_rhs_hint = nrhs;                 // the halves choose their slices per wave for the whole batch in flight
+    h->T_rhs_hint = nrhs;                 // the parts choose their slices per wave for the whole batch in flight
     const bool ok = elph_px_plan(h, n1);
     h->T_rhs_hint = keep;
     return ok;
@@ -822,31 +842,46 @@ static bool split_wanted(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
 
 // after elph_launch_cg_init(h, nrhs, 1, …) on the main stream
 static int split_begin(elph_handle_s *h, int nrhs, SplitRun &S) {
-    if (!h->stream2) HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    if (!h->split_ev) HIPCHK(hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming));
-    S.n1 = nrhs / 2; S.n2 = nrhs - S.n1;
+    S.ways = split_ways();
+    S.n1 = nrhs / S.ways;
     S.main = h;
-    h->px_solve = true;                                   // (split_legal: the halves run p/x-fused whatever the whole batch would have run)
-    h->T_rhs_hint = nrhs;                                 // slices per wave for the right-hand sides in flight = both halves
-    S.view = new elph_handle_s(*h);
-    elph_handle_s *v = S.view;
-    const size_t r0 = (size_t)S.n1, nd = (size_t)h->ndim, Lo2 = (size_t)(h->L + 1) / 2, nrz = (size_t)h->L * (size_t)h->npl;
-    v->d_x += r0 * nd; v->d_r += r0 * nd; v->d_z += r0 * nd; v->d_zp += r0 * nd; v->d_b += r0 * nd; v->d_tmp += r0 * nd; v->d_p += r0 * nd;
-    v->d_nu += r0 * Lo2 * (size_t)h->N;
-    v->d_state += 2 * r0; v->h_state += 2 * r0; v->d_alpha += r0;
-    v->d_part += r0 * nrz;        // the three partial-sum arrays lie cap_rhs * nrz apart and are indexed [rhs][<= nrz]: one offset serves all
-    v->stream = h->stream2;
-    v->graphs.clear();
+    S.view[0] = h;
+    S.px_before = h->px_solve;
+    for (int k = 1; k < S.ways; ++k)
+        if (!h->split_stream[k]) HIPCHK(hipStreamCreateWithFlags(&h->split_stream[k], hipStreamNonBlocking));
+    if (!h->split_ev) HIPCHK(hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming));
+    h->px_solve = true;                                   // (split_legal: the parts run p/x-fused whatever the whole batch would have run)
+    h->T_rhs_hint = nrhs;                                 // slices per wave for the right-hand sides in flight = all parts
     HIPCHK(hipEventRecord(h->split_ev, h->stream));       // the start state (x0, r0, p0, rho0 of every right-hand side) is on the main stream
-    HIPCHK(hipStreamWaitEvent(h->stream2, h->split_ev, 0));
+    const size_t nd = (size_t)h->ndim, Lo2 = (size_t)(h->L + 1) / 2, nrz = (size_t)h->L * (size_t)h->npl;
+    for (int k = 1; k < S.ways; ++k) {
+        elph_handle_s *v = S.view[k] = new elph_handle_s(*h);
+        const size_t r0 = (size_t)k * (size_t)S.n1;
+        v->d_x += r0 * nd; v->d_r += r0 * nd; v->d_z += r0 * nd; v->d_zp += r0 * nd; v->d_b += r0 * nd; v->d_tmp += r0 * nd; v->d_p += r0 * nd;
+        v->d_nu += r0 * Lo2 * (size_t)h->N;
+        v->d_state += 2 * r0; v->h_state += 2 * r0; v->d_alpha += r0;
+        v->d_part += r0 * nrz;    // the three partial-sum arrays lie cap_rhs * nrz apart and are indexed [rhs][<= nrz]: one offset serves all
+        v->stream = h->split_stream[k];
+        v->graphs.clear();
+        HIPCHK(hipStreamWaitEvent(v->stream, h->split_ev, 0));
+    }
     S.on = true;
     return ELPH_OK;
 }
 
-// the main stream continues only after the second half has finished
-static int split_join(elph_handle_s *h) {
-    HIPCHK(hipEventRecord(h->split_ev, h->stream2));
-    HIPCHK(hipStreamWaitEvent(h->stream, h->split_ev, 0));
+// one iteration of every part, each on its stream
+static int split_iteration(SplitRun &S, int use_prec) {
+    for (int k = 0; k < S.ways; ++k) RC(elph_launch_cg_iteration(S.view[k], S.n1, use_prec));
+    return ELPH_OK;
+}
+
+// the main stream continues only after the other parts have finished
+static int split_join(SplitRun &S) {
+    elph_handle_s *h = S.main;
+    for (int k = 1; k < S.ways; ++k) {
+        HIPCHK(hipEventRecord(h->split_ev, S.view[k]->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->split_ev, 0));
+    }
     return ELPH_OK;
 }
 
@@ -966,14 +1001,10 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
         SplitRun S;
         RC(split_begin(h, nrhs, S));
         for (int64_t c = 0; c < max_chunks && !all_done; ++c) {
-            for (int it = 0; it < h->chunk; ++it) {
-                RC(elph_launch_cg_iteration(h, S.n1, use_prec));
-                RC(elph_launch_cg_iteration(S.view, S.n2, use_prec));
-            }
-            HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(CgState) * 2 * (size_t)S.n1, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(S.view->h_state, S.view->d_state, sizeof(CgState) * 2 * (size_t)S.n2, hipMemcpyDeviceToHost, S.view->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            HIPCHK(hipStreamSynchronize(S.view->stream));
+            for (int it = 0; it < h->chunk; ++it) RC(split_iteration(S, use_prec));
+            for (int k = 0; k < S.ways; ++k)
+                HIPCHK(hipMemcpyAsync(S.view[k]->h_state, S.view[k]->d_state, sizeof(CgState) * 2 * (size_t)S.n1, hipMemcpyDeviceToHost, S.view[k]->stream));
+            for (int k = 0; k < S.ways; ++k) HIPCHK(hipStreamSynchronize(S.view[k]->stream));
             all_done = true;
             for (int r = 0; r < nrhs; ++r) {
                 const CgState &a = h->h_state[2 * r], &b = h->h_state[2 * r + 1];
@@ -982,6 +1013,8 @@ static int run_cg(elph_handle_s *h, int nrhs, int use_prec, double tol, int64_t 
                 else iters[r] = s.iters;
             }
         }
+        h->ap_count = S.view[S.ways - 1]->ap_count;
+        S.ok = all_done;
         if (!all_done) { elph_set_error("CG chunk loop (two streams) ended without a terminal state (internal error)"); return ELPH_E_STATE; }
         return ELPH_OK;
     }
@@ -2042,12 +2075,10 @@ extern "C" int elph_bench_run(elph_handle h, int what, int nrhs, int reps, int u
         hipError_t er = hipStreamSynchronize(h->stream);
         if (er == hipSuccess) er = hipEventRecord(e0, h->stream);
         if (er == hipSuccess) rc = split_begin(h, nrhs, S);
-        for (int r = 0; r < reps && rc == ELPH_OK && er == hipSuccess; ++r) {
-            rc = elph_launch_cg_iteration(h, S.n1, 1);
-            if (rc == ELPH_OK) rc = elph_launch_cg_iteration(S.view, S.n2, 1);
-        }
-        if (rc == ELPH_OK && er == hipSuccess) rc = split_join(h);
-        if (S.on) h->ap_count = S.view->ap_count;
+        for (int r = 0; r < reps && rc == ELPH_OK && er == hipSuccess; ++r) rc = split_iteration(S, 1);
+        if (rc == ELPH_OK && er == hipSuccess) rc = split_join(S);
+        if (S.on) h->ap_count = S.view[S.ways - 1]->ap_count;
+        S.ok = (rc == ELPH_OK && er == hipSuccess);
         if (er == hipSuccess && rc == ELPH_OK) er = hipEventRecord(e1, h->stream);
         if (er == hipSuccess && rc == ELPH_OK) er = hipEventSynchronize(e1);
         float ms = 0.f;

@@ -81,7 +81,14 @@ __device__ __forceinline__ void ssh_chain_select(ModelDev &m, int rhs) {
 }
 #endif
 
+// internal only (never crosses the C ABI): a resident launch gave up at its time-out — the caller owns the fallback.  Distinct from ELPH_E_HIP so
+// that a real device error (event, copy, launch) is never mistaken for a time-out and hidden behind the streaming fallback.
+#define ELPH_I_ABORTED (-100)
+int elph_i_resident_wg_limit(const elph_handle_s *h);      // cg_wg.hip: workgroups of a resident kernel that can be co-resident on the handle's device
+
 // Solver parameters travel BY VALUE in the kernel arguments (never through a small H2D copy + scalar load).
+#define ELPH_SPLIT_MAX 8      // parts of a preconditioned batch on streams of their own (elph_api.hip: SplitRun)
+
 struct CgParams {
     double tol, kmax;
     long long maxiter;
@@ -200,7 +207,7 @@ struct elph_handle_s {
     bool fast_capable = false;             // lane-program kernels possible for this bond table (fast may be switched off)
     int solo_chain = -1;                   // >= 0: kernels see only this chain (single re-solve of one RHS of a chains batch)
     double *d_lam = nullptr;               // [3N] lambda, lambda2, mu staging
-    hipStream_t stream2 = nullptr;         // second stream + event of the two-half-batches form of a preconditioned batch (elph_api.hip: SplitRun)
+    hipStream_t split_stream[8] = {};      // streams 1 … ways-1 + event of the split form of a preconditioned batch (elph_api.hip: SplitRun; [0] unused: the handle's own stream)
     hipEvent_t split_ev = nullptr;
     int T_rhs_hint = 0;                    // > 0: right-hand sides in flight when the slices per wave are chosen (two-stream batches: both halves)
     bool ebar_external = false;            // kpm_setup_core: d_Ebar was filled by the caller (elph_i_kpm_setup_ebar)

@@ -351,7 +351,7 @@ int elph_i_shard_run_ranks(elph_handle_s *const *hs, int P, int nsets, void *h_a
         bool aborted = false;
         rc = elph_wg_aborted(hs[q], &aborted);
         if (rc) return rc;
-        if (aborted) { hs[q]->wg_broken = false; hs[q]->wg_cooldown = 0; return ELPH_E_HIP; }      // (the caller owns the fallback and its cool-down)
+        if (aborted) { hs[q]->wg_broken = false; hs[q]->wg_cooldown = 0; return ELPH_I_ABORTED; }      // (the caller owns the fallback and its cool-down; every OTHER failure keeps its own code)
     }
     if (state_out) for (int k = 0; k < nsets; ++k) state_out[k] = hs[k * P]->h_state[0];
     return ELPH_OK;
@@ -1000,20 +1000,19 @@ int elph_i_shard_solve_pair(elph_handle_s *h, elph_handle_s *hfull, int use_prec
     int rc = elph_i_shard_ldiv_dev(h, hfull, use_prec, 0, &it1, &res, &fl);
     int64_t tot = it1;
     if (rc == ELPH_OK && fl == 0) {
-        hipError_t e = hipMemcpyAsync(h->d_zp, h->d_x, bytes, hipMemcpyDeviceToDevice, h->stream);           // X₊ aside (d_zp: free outside a preconditioned streaming solve... kept until below)
+        // X₊ waits in slot 1 of d_x for the length of the second solve (a sharded solve carries ONE right-hand side: slot 0 of every per-right-hand-side
+        // array; the handle's capacity is two) — on the device, no host round trip; b₊ aside in the staging buffer, b₋ into slot 0
+        hipError_t e = hipMemcpyAsync(h->d_x + nd, h->d_x, bytes, hipMemcpyDeviceToDevice, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h->d_stage_out, h->d_b, bytes, hipMemcpyDeviceToDevice, h->stream);   // b₊ aside
         if (e == hipSuccess) e = hipMemcpyAsync(h->d_b, h->d_b + nd, bytes, hipMemcpyDeviceToDevice, h->stream);
-        if (e != hipSuccess) { h->tol = tol0; elph_set_error("sharded pair: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
-        std::vector<double> xp(nd);
-        // (a preconditioned sharded solve uses d_zp itself: X₊ waits on the host for the length of the second solve)
-        e = hipMemcpyAsync(xp.data(), h->d_x, bytes, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { h->tol = tol0; elph_set_error("sharded pair: %s", hipGetErrorString(e)); return ELPH_E_HIP; }
         rc = elph_i_shard_ldiv_dev(h, hfull, use_prec, 0, &it2, &res, &fl);
         if (rc == ELPH_OK) {
             tot += it2;
-            e = hipMemcpyAsync(h->d_x + nd, h->d_x, bytes, hipMemcpyDeviceToDevice, h->stream);                  // X₋ -> slot 1
-            if (e == hipSuccess) e = hipMemcpyAsync(h->d_x, xp.data(), bytes, hipMemcpyHostToDevice, h->stream);   // X₊ -> slot 0
+            // slot 0 holds X₋, slot 1 X₊: swap through slot 1 of d_z (free: the solves are over)
+            e = hipMemcpyAsync(h->d_z + nd, h->d_x, bytes, hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_x, h->d_x + nd, bytes, hipMemcpyDeviceToDevice, h->stream);           // X₊ -> slot 0
+            if (e == hipSuccess) e = hipMemcpyAsync(h->d_x + nd, h->d_z + nd, bytes, hipMemcpyDeviceToDevice, h->stream);      // X₋ -> slot 1
             if (e == hipSuccess) e = hipMemcpyAsync(h->d_b + nd, h->d_b, bytes, hipMemcpyDeviceToDevice, h->stream);   // b₋ back to slot 1
             if (e == hipSuccess) e = hipMemcpyAsync(h->d_b, h->d_stage_out, bytes, hipMemcpyDeviceToDevice, h->stream); // b₊ back to slot 0
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -249,7 +249,7 @@ bool elph_i_slabs_usable(elph_handle_s *h, int nrhs) {
         // two right-hand sides (the pseudofermion pair): only as ONE launch of two sets of slabs — all 2 P G workgroups resident at once;
         // one after the other they lose to the streaming pair
         const SlabSet *S = static_cast<const SlabSet *>(h->slabs);
-        return nrhs == 1 || force == 1 || 2LL * S->P * S->G <= 240;
+        return nrhs == 1 || force == 1 || 2LL * S->P * S->G <= elph_i_resident_wg_limit(h);
     }
     if (h->slabs_tried) return false;
     h->slabs_tried = true;
@@ -268,7 +268,7 @@ bool elph_i_slabs_usable(elph_handle_s *h, int nrhs) {
             const int nloc = lo + (int)h->N / P + hi;
             if (force != 1 && fp <= 0 && ((P & 1) || nloc > 4 * ELPH_WAVE)) continue;
             int W = 0, G = 0;
-            if (elph_shard_shape(h->L, P, &W, &G, nullptr, nullptr) != ELPH_OK || (long long)P * G > 240) { why = "the slabs' workgroups cannot all be resident"; continue; }
+            if (elph_shard_shape(h->L, P, &W, &G, nullptr, nullptr) != ELPH_OK || (long long)P * G > elph_i_resident_wg_limit(h)) { why = "the slabs' workgroups cannot all be resident"; continue; }
             cands.push_back({P, lo, hi, nloc});
         }
         std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.nloc < b.nloc; });
@@ -280,7 +280,7 @@ bool elph_i_slabs_usable(elph_handle_s *h, int nrhs) {
             // (that every slab takes the lane-program form of the sharded kernel is checked by the launch set-up of the first solve)
             h->slabs = S;
             if (getenv("ELPH_SLABS_DEBUG")) fprintf(stderr, "[slabs] N = %lld: %d slabs of %d own + %d / %d ghost sites, %d workgroups each\n", (long long)h->N, c.P, S->own_n, c.lo, c.hi, G);
-            return nrhs == 1 || force == 1 || 2LL * S->P * S->G <= 240;
+            return nrhs == 1 || force == 1 || 2LL * S->P * S->G <= elph_i_resident_wg_limit(h);
         }
     }
     if (getenv("ELPH_SLABS_DEBUG")) fprintf(stderr, "[slabs] N = %lld: not decomposed (%s)\n", (long long)h->N, why);
@@ -301,7 +301,7 @@ int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long 
     }
     const int N = (int)h->N, L = (int)h->L, Nloc = S->Nloc, Pq = S->P;
     // a pair of right-hand sides runs as two sets of slabs in ONE launch where all their workgroups are resident together
-    const bool pairs = nrhs >= 2 && 2LL * Pq * S->G <= 240;
+    const bool pairs = nrhs >= 2 && 2LL * Pq * S->G <= elph_i_resident_wg_limit(h);
     if (pairs && S->nsets < 2) {
         const int rc = add_set(h, S);
         if (rc) return rc;
@@ -328,16 +328,15 @@ int elph_i_slabs_solve(elph_handle_s *h, int nrhs, const CgParams &P, long long 
         if (P.record_hist) for (int k = 0; k < ns; ++k) hist[k] = h->d_hist + (size_t)(r + k) * (size_t)P.hist_stride;
         int rc = elph_i_shard_run_ranks(S->hs.data(), Pq, ns, S->h_args, S->d_args, P.tol, P.maxiter, P.kmax, fixed_iters, timeout_ms, st,
                                         ms_out ? &ms : nullptr, P.record_hist ? hist : nullptr, P.hist_stride);
-        if (test_give_up && rc == ELPH_OK) rc = ELPH_E_HIP;
+        if (test_give_up && rc == ELPH_OK) rc = ELPH_I_ABORTED;
         if (rc == ELPH_E_UNSUPPORTED) {                  // the slabs do not take the sharded kernel's lane-program form: never again
             elph_i_slabs_free(h);
             HIPCHK(hipMemsetAsync(h->d_x, 0, (size_t)nrhs * (size_t)h->ndim * sizeof(double), h->stream));
             return ELPH_OK;
         }
-        if (rc == ELPH_E_HIP) {
-            // a time-out inside the launch (the abort word was raised): cool down like the other resident kernels, streaming takes over
-            hipError_t le = hipGetLastError();
-            if (le != hipSuccess) return rc;
+        if (rc == ELPH_I_ABORTED) {
+            // a time-out inside the launch (the abort word was raised — and nothing else: an event, copy or launch failure comes back as
+            // ELPH_E_HIP and is returned below): cool down like the other resident kernels, streaming takes over
             h->wg_broken = true;
             const char *ec = getenv("ELPH_WG_COOLDOWN");
             h->wg_cooldown = ec ? std::max(1, atoi(ec)) : 16;

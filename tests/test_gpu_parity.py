@@ -1765,6 +1765,45 @@ def test_wg_resident_cg_bench_shape_vs_oracle(oracle):
     m.close()
 
 
+def test_exact_bench_batch_vs_oracle(oracle):
+    """The EXACT batch bench.py times by default — config C, 288 right-hand sides of 144 chains (right-hand side r on the matrix of chain
+    r % 144) — through both of its legs: the un-preconditioned resident kernel (k_cg_wg<T=4,W=8,G=5>: six rounds of 48) and the KPM-preconditioned
+    iteration (two half-batches of 144 on two streams, p/x-fused, the register-exchange k_cg_ap of cg_sq16.hip), each solved tightly, against the
+    ORACLE's solve of six sampled columns on that chain's matrix: the north_star's 1e-10 on the solution (the Green's-function elements are
+    products of its entries).  (Round 5 checked this shape at 52 right-hand sides and the 288 one only from a tool.)"""
+    from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth
+    m = configs.make_model("C", tol=1e-13, maxiter=20000)
+    nch, nrhs = 144, 288
+    Xc = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=100 + c) for c in range(nch)])      # (bench.py's fields)
+    models.update_model_chains_(m, Xc)
+    usable, T, W, G = _wg_info(m, nrhs)
+    assert usable == 1 and (T, W, G) == (4, 8, 5)
+    R = np.stack([synth.rhs(m.Ndim, seed=synth.SEED_RHS + 7919 * i) for i in range(nrhs)])
+    X = np.zeros_like(R)
+    it, res, fl = models.ldiv_batched_(X, m, R)
+    assert not fl.any() and (res < 1e-12).all()
+    # the preconditioned leg: every chain's own expansion (device Arnoldi), tolerance 1e-12 — the oracle below is the un-preconditioned
+    # solve: both are the solution of the same system
+    m.solver.tol = 1e-12
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_chains_(P, rng=np.random.default_rng(7))
+    Xp = np.zeros_like(R)
+    itp, resp, flp = models.ldiv_batched_(Xp, m, R, P=P)
+    f = C.c_int()
+    _lib.check(_lib.load().elph_bench_px_info(m._h, C.byref(f)))
+    assert f.value == 2, f"the preconditioned leg did not take the p/x-fused register-exchange form ({f.value})"
+    assert not flp.any() and (resp < 1e-11).all() and itp.max() < it.min()
+    for i in (0, 47, 143, 144, 200, 287):                        # first / last of a round, both copies of a chain, both half-batches
+        c = i % nch
+        E = oracle.update_model_holstein(m.Nsites, m.Ltau, m.dtau, Xc[c], m.lam, m.lam2, m.mu)
+        om = oracle.make_model(0, m.Nsites, m.Ltau, m.neighbor_table, m.cosht, m.sinht, E)
+        xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(R[i]), solver_tol=1e-13, solver_maxiter=20000)
+        assert flo == 0 and abs(int(it[i]) - ito) <= max(3, ito // 100), (i, int(it[i]), ito)
+        assert rel(X[i], xo) < 1e-10, ("plain", i, rel(X[i], xo))
+        assert rel(Xp[i], xo) < 1e-10, ("preconditioned", i, rel(Xp[i], xo))
+    m.close()
+
+
 def test_wg_resident_cg_honeycomb_and_ssh_batches_vs_oracle(oracle):
     """Configs D and E in the shape a batch of chains runs — 3 resp. 2 slices per wave, the register-exchange checkerboards (honeycomb: mirror
     lanes; bond phonons: one hopping-table set per time slice, one of three in LDS) — against the ORACLE directly: solved to 1e-13 on
