@@ -738,7 +738,14 @@ def order_roofline(roof):
 F64_FLOPS_PER_ITER = lambda ndim, ltau, nbonds: 2.0 * (2.0 * ndim + 6.0 * ltau * nbonds) + 10.0 * ndim     # noqa: E731  SURVEY §8(d)
 
 
-def spatial_record(tag, world, ranks_rccl, K, ms_dev_max, elapsed_max, N, Ltau, nbonds, slab, peer, selftest_us, backend):
+TRANSPORT_TEXT = {
+    "mailbox": "device-initiated stores into hipIpc / peer-mapped mailboxes, one inter-rank hop per iteration; no collective",
+    "collectives": "torch.distributed collectives (nccl = RCCL over xGMI; gloo: staged through the host): two all-reduces (p.z, r.r) + one grouped "
+                   "ghost-row send/recv per iteration, the library's streaming mat-vec on the slab (elphdynamics_amd/sharded_rccl.py)",
+}
+
+
+def spatial_record(tag, world, ranks_rccl, K, ms_dev_max, elapsed_max, N, Ltau, nbonds, slab, peer, selftest_us, backend, transport="mailbox", why=None):
     """The JSON sub-record of one sharded solve (pure arithmetic: the CPU test of the schema calls it at world 2 over gloo).
     ms_dev_max: MAX over ranks of the HIP-event time of the K-iteration launch; elapsed_max: MAX of the host time around it."""
     us_dev = 1e3 * ms_dev_max / K
@@ -753,7 +760,7 @@ def spatial_record(tag, world, ranks_rccl, K, ms_dev_max, elapsed_max, N, Ltau, 
         "frac": tfl / (F64_MFMA_PEAK_TFLOPS * world),
         "hbm_streaming_equivalent_frac": ALG_BYTES_PER_ELT["cg_iter"] * N * Ltau / (us_dev * 1e-6) / 1e9 / (HBM_PEAK_GBS * world),
         "peer_access": peer, "selftest_us_per_round": selftest_us,
-        "scaling": "strong", "transport": "device-initiated stores into hipIpc / peer-mapped mailboxes, one inter-rank hop per iteration; no collective",
+        "scaling": "strong", "transport": transport, "transport_detail": TRANSPORT_TEXT.get(transport, transport), "transport_chosen_because": why,
     }
 
 
@@ -779,8 +786,11 @@ def make_sharded(tag, comm):
     cb = lat.initialize_checkerboard(raw, np.ones(raw.shape[0]), dtau)
     N, Ltau = la.nsites, lat.ltau_from_beta(beta, dtau)
     b = synth.rhs(N * Ltau)
-    s = sharded.ShardedSolver(comm, norb, la.L1, la.L2, Ltau, cb["table"], kind=0 if kind == "holstein" else 1,
-                              cosht=cb["cosht"], sinht=cb["sinht"])
+    # ELPH_SHARD_TRANSPORT = mailbox | rccl | auto [auto: the in-library mailbox form when its preflight passes on every rank, else collectives]
+    from elphdynamics_amd import sharded_rccl
+    s, transport, why = sharded_rccl.make_solver(comm, norb, la.L1, la.L2, Ltau, cb["table"], cb["cosht"], cb["sinht"], kind=0 if kind == "holstein" else 1)
+    s.bench_transport, s.bench_why = transport, why
+    s.bench_geometry = (norb, la.L1, la.L2, Ltau, cb["table"], cb["cosht"], cb["sinht"], kind)
     if kind == "holstein":
         s.update_model(np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)))        # lambda = 1, mu = 0 (configs.py)
     else:
@@ -788,8 +798,10 @@ def make_sharded(tag, comm):
         xb = 0.25 * synth.phonon_field(nb, Ltau, beta, dtau, omega=0.1, lam=0.0).reshape(nb, Ltau)
         tp = 1.0 - 0.1 * xb
         s.update_model_ssh(np.cosh(dtau * tp), np.sinh(dtau * tp), np.ones(N))
-    slab = (f"slabs of rows of cells (+{s.sl['lo']}/{s.sl['hi']} ghost rows; {s.Nloc} of {N} sites on rank 0), resident CG kernel per rank, "
-            f"partial sums and boundary rows by device-initiated stores into mapped mailboxes")
+    slab = (f"slabs of rows of cells (+{s.sl['lo']}/{s.sl['hi']} ghost rows; {s.Nloc} of {N} sites on rank 0), " +
+            ("resident CG kernel per rank, partial sums and boundary rows by device-initiated stores into mapped mailboxes" if transport == "mailbox"
+             else "streaming mat-vec per rank, inner products by all-reduce, ghost rows by grouped send/recv"))
+    s.bench_expV = np.exp(-dtau * synth.phonon_field(N, Ltau, beta, dtau)) if kind == "holstein" else None
     return s, b, N, Ltau, raw.shape[0], slab
 
 
@@ -813,9 +825,33 @@ def measure_sharded(tag, comm, K, W, factory=None):
         rccl = int(dist.get_world_size())
     devs = sorted(set(comm.allgather_object(comm.device_index())))
     peer = peer_matrix(lib, max(devs) + 1) if lib.elph_device_count() > 0 else None
-    st = [float(x) for x in s.selftest_us] if s.selftest_us is not None else None
-    rec = spatial_record(tag, comm.world, rccl, K, ms_dev, elapsed, N, Ltau, nb, slab, peer, st, getattr(comm, "backend", None))
+    st = [float(x) for x in s.selftest_us] if getattr(s, "selftest_us", None) is not None else None
+    transport = getattr(s, "bench_transport", "mailbox")
+    rec = spatial_record(tag, comm.world, rccl, K, ms_dev, elapsed, N, Ltau, nb, slab, peer, st, getattr(comm, "backend", None),
+                         transport=transport, why=getattr(s, "bench_why", None))
     rec["devices"] = devs
+    # A/B of the two transports on the same slabs (Holstein, more than one rank, a torch.distributed communicator): the collective form for a
+    # tenth of the iterations — wall time per iteration (its host drives every iteration; the mailbox form's host only launches)
+    geo = getattr(s, "bench_geometry", None)
+    if transport == "mailbox" and comm.world > 1 and geo is not None and geo[7] == "holstein" and getattr(comm, "dist", None) is not None:
+        s2, err = None, None
+        try:
+            from elphdynamics_amd import sharded_rccl
+            s2 = sharded_rccl.CollectiveShardedSolver(comm, *geo[:7])
+            s2.update_model(s.bench_expV)
+        except Exception as e:      # noqa: BLE001 — agreed below: no rank enters the timed collectives alone
+            err = repr(e)
+        errs = comm.allgather_object(err)
+        if not any(errs):
+            k2 = max(16, K // 10)
+            s2.iterate(b, 8)
+            ms2 = comm.max(s2.iterate(b, k2))
+            rec["ab_collectives"] = {"us_per_iteration_wall": 1e3 * ms2 / k2, "iterations": k2, "backend": getattr(comm, "backend", None),
+                                     "collectives_per_iteration": 3, "note": TRANSPORT_TEXT["collectives"]}
+        else:
+            rec["ab_collectives"] = {"error": next(e for e in errs if e)}
+        if s2 is not None:
+            s2.close()
     s.close()
     return rec
 

@@ -22,7 +22,9 @@ class Comm:
         self.dist = None
         self.device = None
         self.backend = None
-        if self.world > 1:
+        # ELPH_DIST_FORCE_INIT=1: a process group even at world size 1 (the collective transport of the sharded solve then runs its all-reduces
+        # through RCCL on a one-GPU box: tests/test_gpu_shard.py)
+        if self.world > 1 or os.environ.get("ELPH_DIST_FORCE_INIT") == "1":
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist

@@ -180,7 +180,13 @@ class ShardedSolver:
         if self.P > 1:
             allh = b"".join(comm.allgather_object(bytes(hbuf)))
             self._allh = C.create_string_buffer(allh, len(allh))
-            _lib.check(self.lib.elph_shard_connect(self.h, C.cast(self._allh, C.c_void_p)))
+            # every rank learns of every rank's failure to map a peer's mailbox (hipIpcOpenMemHandle refused between two devices, say) and raises
+            # with it: nobody is left waiting in the barrier below, and sharded_rccl.make_solver can fall back to collectives on all ranks alike
+            rc = self.lib.elph_shard_connect(self.h, C.cast(self._allh, C.c_void_p))
+            err = self.lib.elph_last_error().decode() if rc else ""
+            failed = [(r, e) for r, c_, e in comm.allgather_object((self.rank, rc, err)) if c_]
+            if failed:
+                raise _lib.ElphError(-2, "mailbox mapping failed: " + "; ".join(f"rank {r}: {e}" for r, e in failed))
         comm.barrier()
         # preflight of the mailbox protocol between every pair of ranks: a broken peer mapping shows HERE, with the silent ranks named,
         # instead of as a time-out inside the first solve.  selftest_us[q]: mean time from this rank's store to the sight of rank q's.

@@ -35,9 +35,15 @@ def run_rank(comm, case, out, tol):
     cb = lat.initialize_checkerboard(raw, tvals * np.ones(nb), dtau)
     b = synth.randn(321, N * Ltau)
     res = dict(N=N, Ltau=Ltau, kind=kind, table=cb["table"], b=b)
-    solver = sharded.ShardedSolver(comm, norb, Ls, Ls, Ltau, cb["table"], kind=kind, cosht=cb["cosht"], sinht=cb["sinht"], device=0)
-    # the preflight of the mailbox protocol ran in the constructor (elph_shard_selftest): us per lock-step round, per peer
-    res.update(selftest_us=np.asarray(solver.selftest_us), selftest_slowest_us=solver.selftest_slowest_us)
+    if os.environ.get("ELPH_TEST_TRANSPORT") == "collectives":
+        # the same solve with torch.distributed collectives as the transport (sharded_rccl.py: RCCL between GPUs; gloo here when several ranks share the card)
+        from elphdynamics_amd import sharded_rccl
+        solver = sharded_rccl.CollectiveShardedSolver(comm, norb, Ls, Ls, Ltau, cb["table"], cb["cosht"], cb["sinht"], device=0)
+        res.update(selftest_us=np.zeros(comm.world), selftest_slowest_us=1.0, direct=int(solver.direct))
+    else:
+        solver = sharded.ShardedSolver(comm, norb, Ls, Ls, Ltau, cb["table"], kind=kind, cosht=cb["cosht"], sinht=cb["sinht"], device=0)
+        # the preflight of the mailbox protocol ran in the constructor (elph_shard_selftest): us per lock-step round, per peer
+        res.update(selftest_us=np.asarray(solver.selftest_us), selftest_slowest_us=solver.selftest_slowest_us)
     if kind == 0:
         x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
         E = np.exp(-dtau * x)
@@ -52,6 +58,7 @@ def run_rank(comm, case, out, tol):
         solver.update_model_ssh(c, s, emu)
         res.update(E=emu, c=c, s=s)
     xs, it, done = solver.solve(b, tol=tol, maxiter=20000)
+    res.update(collectives=getattr(solver, "collectives", 0))
     res.update(x=xs, it=it, done=done, eps=solver.eps, halo=np.array([solver.sl["lo"], solver.sl["hi"]]), rows=np.array([s_["R"] for s_ in solver.slabs.slabs]))
     # a second solve on the same handle (mailbox re-zeroed, new barrier): same bits
     xs2, it2, done2 = solver.solve(b, tol=tol, maxiter=20000)
@@ -80,7 +87,7 @@ def main():
     case, out = sys.argv[1], sys.argv[2]
     tol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-9
     per_proc = int(os.environ.get("ELPH_RANKS_PER_PROC", "1"))
-    comm = dist.Comm(backend="gloo")
+    comm = dist.Comm(backend=os.environ.get("ELPH_TEST_BACKEND", "gloo"))
     if per_proc == 1:
         run_rank(comm, case, out, tol)
     else:

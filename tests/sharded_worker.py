@@ -1,6 +1,6 @@
 """Worker of the 2-rank sharded-CG tests (launched once per rank by tests/test_sharded_*.py).
 
-usage: sharded_worker.py numpy[-spatial] <out.npz>
+usage: sharded_worker.py numpy[-spatial] | collectives <out.npz>
   numpy    : local compute by a numpy/oracle stand-in backend (CPU, gloo) — TEST-ONLY code path (tests/protocol_reference.py)
   -spatial : slabs of rows of cells (SpatialShardedCG) instead of tau-slabs (ShardedCG)
 """
@@ -145,9 +145,65 @@ def main_spatial(mode, out, comm):
     comm.close()
 
 
+class NumpyLocal:
+    """The slab's operator for elphdynamics_amd.sharded_rccl.CollectiveShardedSolver by the CPU oracle (CPU tensors): test infrastructure — the
+    product's local operator is LibraryLocal (the HIP library)."""
+
+    def __init__(self, torch, Nloc, ltau, ltab, cosht, sinht, device_index):
+        from oracle.oracle import Oracle
+        self.orc, self.torch = Oracle(), torch
+        self.N, self.L, self.table, self.c, self.s = int(Nloc), int(ltau), ltab, np.ascontiguousarray(cosht), np.ascontiguousarray(sinht)
+        self.device = torch.device("cpu")
+
+    def set_expV(self, E_loc):
+        self.m = self.orc.make_model(0, self.N, self.L, self.table, self.c, self.s, np.ascontiguousarray(E_loc).reshape(-1))
+
+    def mtm(self, z, p):
+        z.copy_(self.torch.from_numpy(self.orc.mulMTM(self.m, np.ascontiguousarray(p.numpy()))))
+
+    def close(self):
+        pass
+
+
+def main_collectives(out, comm):
+    """The COLLECTIVE transport of the sharded solve (sharded_rccl.CollectiveShardedSolver: all-reduces of p.z and r.r, one grouped ghost-row
+    exchange of p per iteration) on the two lattices of main_spatial, next to the host-spelled mailbox protocol on the same system."""
+    from elphdynamics_amd import sharded_rccl
+    res = {}
+    for tag, norb, Ls, bonds, Ltau in (("sq", 1, 8, lat.SQUARE_BONDS, 8), ("hc", 2, 4, lat.HONEYCOMB_BONDS, 6)):
+        dtau = 0.1
+        la = lat.Lattice(norb, Ls, Ls, 1)
+        raw = np.concatenate([la.calc_neighbor_table(o1, o2, d) for (o1, o2, d) in bonds], axis=0)
+        tvals = 1.0 + 0.1 * synth.randn(5, raw.shape[0])
+        cb = lat.initialize_checkerboard(raw, tvals, dtau)
+        N = la.nsites
+        x = synth.phonon_field(N, Ltau, Ltau * dtau, dtau, seed=123)
+        E = np.exp(-dtau * (1.0 * x - 0.0))
+        b = synth.randn(321, N * Ltau)
+        solver = sharded_rccl.CollectiveShardedSolver(comm, norb, Ls, Ls, Ltau, cb["table"], cb["cosht"], cb["sinht"], local_factory=NumpyLocal)
+        solver.update_model(E)
+        xs, it, done = solver.solve(b, tol=1e-9, maxiter=2000, check_every=4)
+        ncoll = solver.collectives
+        x5, it5, done5 = solver.solve(b, fixed_iters=5)                   # (the measurement form: exactly five iterations)
+        ref = sharded.SpatialShardedCG(comm, norb, Ls, Ls, Ltau, cb["table"], cb["cosht"], cb["sinht"],
+                                       backend_factory=lambda n, l, t, c, s_: NumpyBackend(n, l, t, c, s_))
+        ref.update_model(E)
+        xr, itr, doner = ref.solve(b, tol=1e-9, maxiter=2000, check_every=4)
+        res.update({f"{tag}_x": xs, f"{tag}_it": it, f"{tag}_done": done, f"{tag}_E": E, f"{tag}_b": b, f"{tag}_table": cb["table"],
+                    f"{tag}_c": cb["cosht"], f"{tag}_s": cb["sinht"], f"{tag}_N": N, f"{tag}_Ltau": Ltau,
+                    f"{tag}_halo": np.array([solver.sl["lo"], solver.sl["hi"]]), f"{tag}_ncoll": ncoll, f"{tag}_it5": it5, f"{tag}_x5": x5,
+                    f"{tag}_xref": xr, f"{tag}_itref": itr})
+        solver.close()
+        ref.close()
+    np.savez(out + f".rank{comm.rank}", **res)
+    comm.close()
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     comm = dist.Comm(backend="gloo")
+    if mode == "collectives":
+        return main_collectives(out, comm)
     if mode.endswith("-spatial"):
         return main_spatial(mode.split("-")[0], out, comm)
     # Holstein square lattice, small enough for the CPU backend: L = 4, Ltau = 16

@@ -87,6 +87,32 @@ def test_sharded_solve_small_lattices(tmp_path, oracle, case, world, halo):
     assert err < 1e-7 and rres < 1e-8
 
 
+@pytest.mark.parametrize("case,world,backend,tol", [("sq8", 2, "gloo", 1e-9), ("hc4", 2, "gloo", 1e-9), ("hc4", 4, "gloo", 1e-9), ("C", 2, "gloo", 1e-13), ("D", 4, "gloo", 1e-13),
+                                                    ("C", 1, "nccl", 1e-13)])
+def test_sharded_solve_with_collectives_as_transport(tmp_path, oracle, monkeypatch, case, world, backend, tol):
+    """sharded_rccl.CollectiveShardedSolver on the GPU: the library's un-modified mat-vec on the slab (device pointers, torch's stream), two
+    all-reduces and one grouped ghost-row exchange per iteration through torch.distributed — RCCL ("nccl") where every rank has a GPU of its
+    own, here gloo with the ranks sharing the box's one card (messages staged through the host; RCCL refuses two ranks on one device) and RCCL
+    itself at world size 1 (all-reduces of a one-rank group: ELPH_DIST_FORCE_INIT).  Against the oracle's un-sharded solve: iteration count,
+    solution (BASELINE configs C and D at tol 1e-13: the north_star's 1e-10), true residual; every rank the same bits; a repeated solve the
+    same bits.  UNMEASURED ON HARDWARE between two devices, like the mailbox transport."""
+    monkeypatch.setenv("ELPH_TEST_TRANSPORT", "collectives")
+    monkeypatch.setenv("ELPH_TEST_BACKEND", backend)
+    if world == 1:
+        monkeypatch.setenv("ELPH_DIST_FORCE_INIT", "1")
+    res = _run(case, tmp_path, world, tol=tol)
+    err, rres = _check(res, oracle, tol)
+    a = res[0]
+    assert int(a["direct"]) == (1 if backend == "nccl" else 0)
+    launched = (int(a["it"]) + 7) // 8 * 8                       # the host looks at the done flag every 8 iterations
+    per_it = 3 if world > 1 else 2                               # two all-reduces + one grouped exchange (no neighbours at world 1)
+    assert int(a["collectives"]) == 1 + per_it * launched
+    if tol < 1e-12:
+        assert err < 1e-10 and rres < 1e-11, (err, rres)
+    else:
+        assert err < 1e-7 and rres < 1e-8, (err, rres)
+
+
 @pytest.mark.parametrize("case,world", [("C", 2), ("C", 4), ("D", 2), ("D", 4), ("E", 2), ("E", 4), ("C", 8), ("D", 8), ("E", 8)])
 def test_sharded_solve_baseline_configs(tmp_path, oracle, case, world):
     """Configs D and E (and C) at full size, sharded over 2, 4 and 8 ranks (BASELINE.json: "1, 2, 4 and 8 GPUs"), solved to 1e-13 on

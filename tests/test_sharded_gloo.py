@@ -82,6 +82,23 @@ def test_spatial_sharded_protocol_two_ranks_cpu(tmp_path, oracle):
     _check_spatial(_run("numpy-spatial", tmp_path), oracle)
 
 
+def test_collective_transport_two_ranks_cpu(tmp_path, oracle):
+    """sharded_rccl.CollectiveShardedSolver — the sharded solve with torch.distributed collectives as its transport (RCCL on GPUs; gloo here):
+    two all-reduces (p.z, r.r) and one grouped ghost-row exchange of p per iteration, scalars and stop rule on every rank from the same
+    all-reduced numbers (IterativeSolvers.jl:239-314).  World 2, the CPU oracle as the slab operator: same solution on both ranks, the
+    un-sharded oracle solve's iteration count and solution, the true residual, and agreement with the host-spelled MAILBOX protocol
+    (tests/protocol_reference.py) on the same system — same iteration count, solutions to 1e-9 after ~100 iterations at tol 1e-9 (other summation order of the inner
+    products: partial sums per time slice there, one dot product per rank here)."""
+    res = _run("collectives", tmp_path)
+    _check_spatial(res, oracle)
+    a = res[0]
+    for tag in ("sq", "hc"):
+        assert int(a[f"{tag}_it"]) == int(a[f"{tag}_itref"])
+        assert np.linalg.norm(a[f"{tag}_x"] - a[f"{tag}_xref"]) / np.linalg.norm(a[f"{tag}_xref"]) < 1e-9
+        assert int(a[f"{tag}_ncoll"]) == 1 + 3 * ((int(a[f"{tag}_it"]) + 3) // 4 * 4)      # start-up all-reduce + 3 per launched iteration (checked every 4)
+        assert int(a[f"{tag}_it5"]) == 5 and np.array_equal(a[f"{tag}_x5"], res[1][f"{tag}_x5"])
+
+
 def test_spatial_slab_tables():
     """Integer set-up of the spatial decomposition on the BASELINE lattices: ghost rows from the dependency closure of
     the fused MᵀM (2+2 for the even-aligned square lattice — only the last colour crosses the slab boundary, SURVEY §8e;
