@@ -45,9 +45,17 @@ class LibraryLocal:
         _lib.check(self.lib.elph_create(C.byref(self.h), 0, int(Nloc), int(ltau), nb, _lib.iptr(np.ascontiguousarray(ltab, dtype=np.int64)) if nb else None,
                                         _lib.dptr(c) if nb else None, _lib.dptr(s) if nb else None, int(device_index)))
         self.device = torch.device("cuda", int(device_index))
-        # the library's launches join torch's stream: no synchronisation between a torch op and the mat-vec that follows it
+        # ONE stream for the torch ops of the iteration and the library's launches: no synchronisation between a torch op and the mat-vec that
+        # follows it.  A stream of our own, not torch's default one: the default stream's handle is NULL, which elph_set_stream reads as "keep
+        # your own (non-blocking) stream" — the mat-vec would then race with the torch ops around it.
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.elph_set_stream(self.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            self.stream = torch.cuda.Stream(device=self.device)
+        assert self.stream.cuda_stream != 0
+        _lib.check(self.lib.elph_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
+
+    def stream_ctx(self):
+        """Context in which the solver issues its torch ops (and its collectives): the stream the library launches on."""
+        return self.torch.cuda.stream(self.stream)
 
     def set_expV(self, E_loc):
         self._lm.check(self.lib.elph_set_expV(self.h, self._lm.dptr(np.ascontiguousarray(E_loc, dtype=np.float64).reshape(-1))))
@@ -168,6 +176,12 @@ class CollectiveShardedSolver:
     def solve(self, b_global, tol=1e-5, maxiter=10000, kmax=1e12, check_every=8, fixed_iters=0):
         """Returns (x_global (N·Ltau,), iterations, done) — identical on every rank.  done: 1 ε < tol, 2 κ > κmax, 3 maxiter (the library's
         codes).  fixed_iters > 0: exactly that many iterations, no stop test (measurement)."""
+        import contextlib
+        ctx = self.local.stream_ctx() if hasattr(self.local, "stream_ctx") else contextlib.nullcontext()
+        with ctx:
+            return self._solve(b_global, tol, maxiter, kmax, check_every, fixed_iters)
+
+    def _solve(self, b_global, tol, maxiter, kmax, check_every, fixed_iters):
         torch = self.torch
         f64 = torch.float64
         dev = self.device
@@ -192,6 +206,7 @@ class CollectiveShardedSolver:
         zero = torch.zeros((), dtype=f64, device=dev)
         tol_t, kmax_t = torch.tensor(float(tol), dtype=f64, device=dev), torch.tensor(float(kmax), dtype=f64, device=dev)
         s1 = torch.zeros(1, dtype=f64, device=dev)
+        eps_t = eps0.clone()
         j, limit = 0, (int(fixed_iters) if fixed_iters > 0 else int(maxiter))
         finished = False
         while j < limit and not finished:
@@ -208,6 +223,7 @@ class CollectiveShardedSolver:
                 self._allreduce(s1)                                        # r·r
                 rr = s1[0]
                 eps = torch.sqrt(rr) / normb
+                eps_t = torch.where(live, eps, eps_t)                      # ε of the last iteration that was taken
                 if fixed_iters <= 0:
                     q = (2.0 * j) / torch.log(2.0 * eps0 / eps)
                     kmin = torch.where(live, torch.maximum(kmin, q * q), kmin)
@@ -229,7 +245,7 @@ class CollectiveShardedSolver:
         it, dn = int(iters.item()), int(done.item())
         if fixed_iters <= 0 and dn == 0:
             dn = 3
-        self.eps = float((torch.sqrt(rho) / normb).item()) if dn != 0 else float("nan")
+        self.eps = float(eps_t.item())
         x_own = xo.detach().to("cpu").numpy().reshape(self.own_n, self.Ltau)
         parts = self.comm.allgather_object(x_own) if self.P > 1 else [x_own]
         return np.ascontiguousarray(np.concatenate(parts, axis=0)).reshape(-1), it, dn
