@@ -39,6 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_STREAM_CEILING_GBS = 5380.0   # MEASURED on this pool (round 6): read r, read z, write r of 288 x 40 960 doubles each, buffers rotating through more than the
+                                  # 256 MB Infinity Cache holds: 5.29-5.39 TB/s in three access patterns (tools/probes/access_pattern_probe.cpp; profiles/r06/)
 HMC_CHAINS = 64                # lockstep chains of the secondary whole-HMC-update measurement
 F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64, dense (same guide: f64 matrix = f64 vector peak)
 ALG_BYTES_PER_ELT = {          # the UNFUSED pass count of the algorithm, f64 (reported as algorithmic_GBs only)
@@ -320,7 +322,27 @@ def main():
         if traffic:      # what the memory-side counters saw per launch
             stream["traffic_frac"] = traffic / (ms_ap * 1e-3) / 1e9 / HBM_PEAK_GBS
             stream["traffic_over_bytes"] = traffic / built_ap
-        if not resident:
+        if not resident and args.precond and m.kind == 0:
+            # --precond: the timed region IS the preconditioned iteration (k_cg_ap + forward transform with the residual update + Chebyshev +
+            # inverse transform with the p/x-update; two half-batches on two streams from 192 right-hand sides): priced on the compulsory
+            # bytes of all its kernels as built against the HBM peak, and against the streaming rate a read-read-write mix reaches on this
+            # part once it is larger than the Infinity Cache (tools/probes/access_pattern_probe.cpp, profiles/r06/)
+            fz = C.c_int()
+            check(lib.elph_bench_px_info(m._h, C.byref(fz)))
+            it_bytes = ((2.0 * vec + tab) + 4.0 * vec + 2.0 * vec + 5.0 * vec) if fz.value else (built_ap + 4.0 * vec + 2.0 * vec + 2.0 * vec)
+            us_it = 1e3 * ms_events / K
+            achp = it_bytes / (us_it * 1e-6) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": ("k_cg_ap_sq16_px" if fz.value == 2 else ("k_cg_ap_chunk_px" if fz.value else kname)) +
+                                          " + k_dft_mfma_r2s(forward, residual update) + k_kpm_cheb_sq + k_dft_mfma_r2s(inverse, p/x update)",
+                "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": us_it, "bytes_per_launch": it_bytes, "px_fused": int(fz.value), "two_streams": bool(two_streams),
+                "hbm_streaming_ceiling_GBs": HBM_STREAM_CEILING_GBS, "frac_of_streaming_ceiling": achp / HBM_STREAM_CEILING_GBS,
+                "bytes_model": "p/x-fused: k_cg_ap reads p (+ tables), writes z (2 vectors + tables); forward transform reads r, z, writes r, nu (4); "
+                               "Chebyshev reads and writes nu (2); inverse reads nu, p, x, writes p, x (5) — 13 vectors x 8 B x Ndim x nrhs",
+            }
+            out["roofline_streaming_unpreconditioned"] = stream
+        elif not resident:
             out["roofline"] = stream
         else:
             # (2) the RESIDENT kernel — the timed region above is ONE launch of k_cg_wg (K iterations of all right-hand sides).  Its
@@ -405,6 +427,9 @@ def main():
                     rp["precond_two_streams_error"] = repr(e)
                 rp["precond_bytes"] = byts[3]
                 rp["precond_hbm_frac"] = rp["precond_iter_hbm_frac"]
+                rp["precond_hbm_streaming_ceiling_GBs"] = HBM_STREAM_CEILING_GBS      # measured: read-read-write beyond the Infinity Cache (profiles/r06)
+                rp["precond_frac_of_streaming_ceiling"] = byts[3] / (rp["precond_iter_us"] * 1e-6) / 1e9 / HBM_STREAM_CEILING_GBS
+                rp["precond_ap_kernel"] = {0: "k_cg_ap_chunk (unfused)", 1: "k_cg_ap_chunk_px (lane program)", 2: "k_cg_ap_sq16_px (checkerboard in registers)"}[int(fused.value)]
                 rp["precond_matvecs_per_sec"] = 2.0 * nrhs / (rp["precond_iter_us"] * 1e-6)
                 # co-headline: the PRODUCTION path (every deck has [solver.preconditioner]; BASELINE config 3 "with tau-FFT precond") — the
                 # same batch, one KPM-preconditioned CG iteration per step (k_cg_ap + forward transform with the residual update +
