@@ -405,7 +405,7 @@ int elph_launch_force_holstein(elph_handle_s *h, double *FS, const double *XS, c
 
 // ---- fast path (cg_fast.hip) ----------------------------------------------------------------
 int elph_fast_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec);
-int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool px = false);
+int elph_fast_cg_ap(elph_handle_s *h, const CgBufs &B, int nrhs, int parity, bool fused = false);      // fused: the p/x-fused iteration (reads the ready p)
 int elph_fast_cg_xr(elph_handle_s *h, const CgBufs &B, int nrhs, int parity);
 // cg_sq16.hip: the p/x-fused k_cg_ap of the 16 x 16 square lattice with the checkerboard in registers (no LDS slabs)
 bool elph_sq16_ap_usable(const elph_handle_s *h, int T);
@@ -441,11 +441,11 @@ bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs = 1
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream has drained
 bool elph_pg_cheb_usable(const elph_handle_s *h);                       // pgrid.hip
-int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st);
+int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part = nullptr, int nrz = 0, const double *rr_part = nullptr);
 bool elph_pg_ap_usable(const elph_handle_s *h);
 bool elph_pg_mul_usable(const elph_handle_s *h);
 int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, const double *vS, int nvec);
-int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity);
+int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity, bool fused = false);      // fused: the p/x-fused iteration (reads the ready p)
 int elph_wg_cooldown_step(elph_handle_s *h);                // one solve of the cool-down after a time-out (both resident kernels call it)
 long long elph_shard_timeout_ms();                          // wait bound of the sharded solves (shard.hip)
 // ---- workgroup-resident KPM-preconditioned CG (pcg_wg.hip): the whole preconditioned solve of 1..8 right-hand sides in one launch

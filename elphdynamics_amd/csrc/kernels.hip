@@ -1167,8 +1167,25 @@ static bool reg_cheb_form(const elph_handle_s *h) {      // a register-exchange 
            (h->hc_L > 0 && h->hc_uniform && h->kind == ELPH_MODEL_HOLSTEIN && (h->hc12 || h->hc_L * h->hc_L <= 64 || (h->hc_L % 2 == 0 && h->hc_L <= 16)));
 }
 
+// the patch-form lattices of the generic family (round 6): Holstein, uniform hopping, k_cg_ap_pg + k_kpm_cheb_pg (pgrid.hip) — their p/x-fused
+// iteration is the lane-program family's with those two kernels in its place (ELPH_PG_PX=0: the unfused form, A/B; read per call)
+static bool pg_px_form(const elph_handle_s *h) {
+    const char *e = getenv("ELPH_PG_PX");
+    if (e && e[0] == '0') return false;
+    return !h->fast && h->kind == ELPH_MODEL_HOLSTEIN && h->pg_uniform && elph_pg_ap_usable(h) && elph_pg_cheb_usable(h);
+}
+
 static bool px_plan(elph_handle_s *h, int nrhs) {
-    if (!h->fast || !h->kpm_active || h->lp_mc != 4) return false;      // (Holstein and bond-phonon models alike)
+    if (!h->kpm_active) return false;
+    if (pg_px_form(h)) {
+        const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+        CgBufs B = make_bufs(h, nrhs);
+        if (!(B.dot_lo == 0 && B.dot_hi == N) || B.npap != L || 2 * Lo2 > B.nrz) return false;
+        const char *ef = getenv("ELPH_FREQ_RZ");
+        if (ef && ef[0] == '0') return false;
+        return elph_dft_mfma_xr_usable(h, N, nrhs) && elph_dft_mfma_px_usable(h, N, nrhs);
+    }
+    if (!h->fast || h->lp_mc != 4) return false;      // (Holstein and bond-phonon models alike)
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     CgBufs B = make_bufs(h, nrhs);
     if (!(B.dot_lo == 0 && B.dot_hi == N) || !elph_dft_mfma_xr_usable(h, N, nrhs)) return false;      // the iteration takes cg_mode 2
@@ -1230,8 +1247,11 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
     } else if (elph_pg_cheb_usable(h)) {
         // an even-L square lattice beyond 16 x 16 (L = 18 ... 32), uniform hopping: the recursion in registers, a patch of sites per lane
         // (whether the lattice still fits the lane-program family — 18 x 18, 20 x 20 — or only the generic kernels)
-        int rcp = elph_pg_kpm_cheb(h, nrhs, st);
+        static const bool freq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
+        const bool want = cg_mode && freq_rz && 2 * Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N && h->px_solve;      // (r.z in frequency space: the p/x-fused iteration's)
+        int rcp = elph_pg_kpm_cheb(h, nrhs, st, want ? B.rz : nullptr, B.nrz, B.rr);
         if (rcp) return rcp;
+        rz_done = want;
     } else if (h->fast) {
         static const bool freq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
         const bool want = cg_mode && freq_rz && 2 * Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N;
@@ -1347,6 +1367,15 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
         dim3 grid((unsigned)L, (unsigned)nrhs, 1);
         const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
         const bool pg = elph_pg_ap_usable(h) && m.uniform && B.npap == L;      // a large even-L square lattice: the patch-layout kernel (pgrid.hip)
+        if (use_prec && h->px_solve) {
+            // the p/x-fused iteration of a patch-form lattice (px_plan): k_cg_ap_pg reads the ready p; the residual update rides on the forward
+            // transform, r.z comes from the Chebyshev kernel in frequency space, the p/x-update is the inverse transform's epilogue
+            if (!pg) { elph_set_error("p/x-fused iteration planned for a lattice without the patch-form k_cg_ap (internal error)"); return ELPH_E_STATE; }
+            rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1), true);
+            h->ap_count++;
+            if (rc) return rc;
+            return elph_launch_kpm_apply(h, h->d_zp, h->d_r, nrhs, 2);
+        }
         if (pg) { rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1)); if (rc) return rc; }
         DISPATCH_NPL(gen_npl(h), {
             if (!pg) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
@@ -1376,7 +1405,7 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     dim3 grid((unsigned)L, (unsigned)nrhs, 1);
     const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
     if (which == 0 && elph_pg_ap_usable(h) && m.uniform && B.npap == L) {
-        int rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1));
+        int rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1), B.params.use_prec && h->px_solve);
         h->ap_count++;
         return rc;
     }

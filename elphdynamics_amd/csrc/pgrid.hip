@@ -21,6 +21,12 @@ using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::
 using TR22 = pgrid::Tri<2, 2>; using TR24 = pgrid::Tri<2, 4>; using TR26 = pgrid::Tri<2, 6>; using TR44 = pgrid::Tri<4, 4>;
 using HC32 = pgrid::Hc<3, 2>; using HC42 = pgrid::Hc<4, 2>; using HC33 = pgrid::Hc<3, 3>;
 
+__device__ __forceinline__ double pg_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
 // sum_n c_n T_n(A') v  for one real vector in the patch layout: Pacc = sum Re(c_n) u_n, Qacc = sum Im(c_n) u_n with
 //   u_1 = v, u_2 = A' u_1 (shifted and scaled: A' = a A + b), u_{n+1} = 2 A' u_n - u_{n-1}
 //   A = CB diag(Ebar)  (TRANSPOSED: diag(Ebar) CB^T),  e1 = a c^4 Ebar (the scale of A' and the c^4 of the factored colours ride on it)
@@ -67,8 +73,14 @@ __device__ __forceinline__ void series_lean(double (&Pacc)[NS], double (&Qacc)[N
     }
 }
 
+// rz_part != nullptr (round 6, the p/x-fused iteration of the patch-form lattices): the partial sums of r.(P^-1 r) in frequency space —
+// Parseval for the twisted transform, a.b = (1/L) sum_k conj(a_k) b_k; a wave holds the real or the imaginary parts of one frequency, whose
+// mirror L-1-k contributes the same — in slot 2 y + wave of this right-hand side (y = the block's position in the longest-first schedule);
+// every block also clears the slots beyond 2 Lo2 that are its share.  A chain whose expansion is inactive hands over the r.r partials of the
+// residual update instead (kernels of cg_fast_shared.inc: the same contract).
 template <class LAT>
-__global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ nu, KpmDev K, int N, int Ls, int Lo2, const CgState *state) {
+__global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ nu, KpmDev K, int N, int Ls, int Lo2, const CgState *state,
+                                                          double *__restrict__ rz_part, int nrz, int Ltau, const double *__restrict__ rr_part) {
     constexpr int NS = LAT::NS;
     __shared__ double xch[2][NS * WAVE];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
@@ -78,6 +90,13 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
     const int w = V.wsched[blockIdx.y];
     const int order = V.order[w];
     const double2 *c = K.coeff + V.coff[w];
+    auto put_rz = [&](double dot_wave) {      // lane 0 of each wave: this block's two slots, and its share of the slots beyond the schedule
+        if (!rz_part || lane != 0) return;
+        const int bid = 2 * (int)blockIdx.y + wv, nb = 2 * (int)gridDim.y;
+        double *slots = rz_part + (size_t)rhs * nrz;
+        slots[bid] = V.active ? dot_wave / (double)Ltau : (bid < Ltau ? rr_part[(size_t)rhs * Ltau + bid] : 0.0);
+        for (int qq = nb + bid; qq < nrz; qq += nb) slots[qq] = 0.0;
+    };
     if (order == 1) {
         // A series of order 1 is its leading coefficient: z_w = c0 (conj(c0) r_w) — no checkerboard, no patch layout.  That is most
         // frequencies (order_w ~ 1 / phi_w: 45 of 80 at L_tau = 160), and a block of its own for each would hold a wave slot for a few
@@ -86,17 +105,24 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
         // general path)
         constexpr int ORD1_BLOCKS = 4;
         const int y = (int)blockIdx.y;
-        if (y >= ORD1_BLOCKS && V.order[V.wsched[y - ORD1_BLOCKS]] == 1) return;
+        if (y >= ORD1_BLOCKS && V.order[V.wsched[y - ORD1_BLOCKS]] == 1) { put_rz(0.0); return; }
+        double dot = 0.0;
         for (int yy = y; yy < Lo2; yy += ORD1_BLOCKS) {
             const int ww = V.wsched[yy];
             const double2 c0 = K.coeff[V.coff[ww]];
+            const double wgt = ((Ltau & 1) && ww == Lo2 - 1) ? 1.0 : 2.0;
             double2 *uc = nu + ((size_t)rhs * Lo2 + ww) * N;
+            double d1 = 0.0;
             for (int i = threadIdx.x; i < N; i += 2 * WAVE) {
                 const double2 v = uc[i];
                 const double mr = __dadd_rn(__dmul_rn(c0.x, v.x), __dmul_rn(c0.y, v.y)), mi = __dsub_rn(__dmul_rn(c0.x, v.y), __dmul_rn(c0.y, v.x));
-                uc[i] = make_double2(__dsub_rn(__dmul_rn(c0.x, mr), __dmul_rn(c0.y, mi)), __dadd_rn(__dmul_rn(c0.x, mi), __dmul_rn(c0.y, mr)));
+                const double zr = __dsub_rn(__dmul_rn(c0.x, mr), __dmul_rn(c0.y, mi)), zi = __dadd_rn(__dmul_rn(c0.x, mi), __dmul_rn(c0.y, mr));
+                uc[i] = make_double2(zr, zi);
+                d1 += v.x * zr + v.y * zi;
             }
+            dot += wgt * d1;
         }
+        if (rz_part) put_rz(pg_wave_sum(dot));
         return;
     }
     double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
@@ -127,18 +153,18 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
 #pragma unroll
     for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
     __syncthreads();
+    double dot = 0.0;
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
         const double Qo = xch[wv ^ 1][q * WAVE + lane];
         const double res = (wv == 0) ? Pa[q] - Qo : Pa[q] + Qo;
-        if (act) u[2 * site[q] + wv] = res;
+        if (act) {
+            // (the input r_w is read back from memory — it is overwritten only now; keeping it in registers through both series costs NS of them)
+            if (rz_part) dot += u[2 * site[q] + wv] * res;
+            u[2 * site[q] + wv] = res;
+        }
     }
-}
-
-__device__ __forceinline__ double pg_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    if (rz_part) put_rz((((Ltau & 1) && w == Lo2 - 1) ? 1.0 : 2.0) * pg_wave_sum(dot));
 }
 // every wave reduces ALL partials itself: same loads, same tree => the same bits in every wave (kernels.hip: reduce_partials)
 __device__ __forceinline__ double pg_reduce_partials(const double *p, int n, int lane) {
@@ -157,7 +183,10 @@ __device__ __forceinline__ double pg_reduce_partials(const double *p, int n, int
 // the bytes that must move take ~100).
 //   w(t)   = p(t) - sg(t) c^4 S(E(t) p(t-1))            sg(t) = -1 at t = 0 (antiperiodic), S / S^T: the sweep without its c^4
 //   z(t-1) = w(t-1) - sg(t) c^4 E(t) S^T(w(t))
-template <class LAT>
+// PX (round 6): the p/x-fused preconditioned iteration — the search direction arrives READY in B.p (slot 0: the inverse tau-transform of the
+// previous iteration formed p = P^-1 r + beta p and applied x += alpha p in its epilogue, dft_mfma.hip: PxFuse): this kernel reads p (own slices
+// + two halo slices) and exp(-dtau V), writes z and the p.z partials and keeps the scalar state machine; no P^-1 r, no p_old, no p_new.
+template <class LAT, bool PX>
 __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int parity, int Ls, int Tmax) {
     constexpr int NS = LAT::NS;
     const int N = m.N, L = m.L, lane = threadIdx.x;
@@ -201,7 +230,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
         rho = rho_new;
     }
     const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
-    const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
+    const double *pold = B.p + ((size_t)(PX ? 0 : parity) * B.nrhs + rhs) * ndim;
     double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
     double *z = B.z + (size_t)rhs * ndim;
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
@@ -218,7 +247,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
         for (int q = 0; q < NS; ++q) {
             const size_t i = (size_t)t * N + site[q];
             qv[q] = pold[i];
-            sv[q] = first ? 0.0 : src[i];
+            sv[q] = (PX || first) ? 0.0 : src[i];
         }
     };
     auto load_e = [&](int t, double (&ev)[NS]) {
@@ -231,7 +260,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
         double s0[NS], q0[NS];
         load_raw(wrap(t0 - 1), s0, q0);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) pprev[q] = first ? q0[q] : s0[q] + beta * q0[q];
+        for (int q = 0; q < NS; ++q) pprev[q] = (PX || first) ? q0[q] : s0[q] + beta * q0[q];
     }
     // the loads of slice t + 1 are issued before the sweeps of slice t: a wave is alone or nearly alone on its SIMD (a slice is 2 x NS
     // registers per vector), nothing else would hide the round trip
@@ -246,7 +275,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
         double pcur[NS], wcur[NS], Ecur[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            pcur[q] = first ? Qn[q] : Sn[q] + beta * Qn[q];
+            pcur[q] = (PX || first) ? Qn[q] : Sn[q] + beta * Qn[q];
             Ecur[q] = En[q];
             wcur[q] = Ecur[q] * pprev[q];
         }
@@ -254,7 +283,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
             const int tn = wrap(t0 + j + 1);
             load_raw(tn, Sn, Qn);
             load_e(tn, En);
-            if (act) {
+            if (act && !PX) {
 #pragma unroll
                 for (int q = 0; q < NS; ++q) pnew[(size_t)t * N + site[q]] = pcur[q];
             }
@@ -395,11 +424,12 @@ bool elph_pg_cheb_usable(const elph_handle_s *h) {
 }
 
 // nu (d_nu: [nrhs][Lo2][N] complex) <- P^-1 in frequency space, every (right-hand side, frequency) a block of two wavefronts
-int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st) {
+int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part, int nrz, const double *rr_part) {
     KpmDev K = elph_kpm_dev(h);
     const int Lo2 = (int)((h->L + 1) / 2), N = (int)h->N, Ls = h->pg_L;
+    if (rz_part && 2 * Lo2 > nrz) { elph_set_error("k_kpm_cheb_pg: %d r.z slots needed, %d available", 2 * Lo2, nrz); return ELPH_E_STATE; }
     const dim3 grid((unsigned)nrhs, (unsigned)Lo2), block(2 * WAVE);
-#define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st)
+#define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st, rz_part, nrz, (int)h->L, rr_part)
     const int px = h->pg_PX, py = h->pg_PY;
     if (h->pg_kind == 1 && px == 4 && py == 4) PG_CHEB(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_CHEB(SQ26);
@@ -423,7 +453,7 @@ bool elph_pg_ap_usable(const elph_handle_s *h) {
     return h->pg_L > 0 && !h->fast && h->kind == ELPH_MODEL_HOLSTEIN && !(e && e[0] == '1');
 }
 
-int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity) {
+int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity, bool fused) {
     if (!m.uniform) return ELPH_E_UNSUPPORTED;
     if (B.npap != (int)h->L) { elph_set_error("k_cg_ap_pg: one p.z slot per time slice expected"); return ELPH_E_UNSUPPORTED; }
     // slices per wave: the SHORTEST chunk whose waves still fit the chip in one round — 1024 SIMDs x the waves a SIMD holds of this
@@ -440,7 +470,11 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     const int nch = (L + T - 1) / T;
     const dim3 grid((unsigned)(nrhs * nch)), block(WAVE);
     const int Ls = h->pg_L;
-#define PG_AP(LAT) hipLaunchKernelGGL((k_cg_ap_pg<LAT>), grid, block, 0, h->stream, B, m, parity, Ls, T)
+#define PG_AP(LAT)                                                                                                        \
+    do {                                                                                                                  \
+        if (fused) hipLaunchKernelGGL((k_cg_ap_pg<LAT, true>), grid, block, 0, h->stream, B, m, parity, Ls, T);              \
+        else hipLaunchKernelGGL((k_cg_ap_pg<LAT, false>), grid, block, 0, h->stream, B, m, parity, Ls, T);                \
+    } while (0)
     const int px = h->pg_PX, py = h->pg_PY;
     if (h->pg_kind == 1 && px == 4 && py == 4) PG_AP(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_AP(SQ26);

@@ -1389,6 +1389,43 @@ def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, 
     m.close()
 
 
+@pytest.mark.parametrize("tag,nchains,per", [("K", 8, 2), ("K", 1, 24), ("X32", 4, 2), ("k", 12, 2), ("j", 8, 2)])
+def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, monkeypatch):
+    """Round 6: the p/x-fused preconditioned batch iteration on the patch-form lattices of the generic family (square L = 18 … 32: `k_cg_ap_pg<PX>`
+    reads the ready p, the residual update rides on the forward transform, r.z comes from `k_kpm_cheb_pg` in frequency space, the p/x-update is
+    the inverse transform's epilogue) against the unfused form (ELPH_PG_PX=0: `k_cg_xr`, time-domain r.z): the same recurrences
+    (IterativeSolvers.jl:153-234), another summation of r.z — iteration counts within one, solutions of two tol = 1e-8 solves to 1e-9 — and,
+    where the time axis admits the fused form, the form must actually be taken.  One right-hand side of K also against the oracle's own
+    preconditioned solve."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    m = configs.make_model(tag, tol=1e-8)
+    nrhs = nchains * per
+    if nchains > 1:
+        X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=8800 + c) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    (pc.setup_chains_ if nchains > 1 else pc.setup_)(P, rng=np.random.default_rng(15))
+    B = np.stack([synth.randn(8900 + r, m.Ndim) for r in range(nrhs)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_PG_PX", mode)
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any()
+        out[mode] = (Xs, it, _px_fused(m))
+    assert out["0"][2] is False
+    # the fused form needs the MFMA transforms with the residual update (N / 16 column tiles <= Ltau, enough waves): K (24 x 24, Ltau = 40) and X32 have it
+    if tag in ("K", "X32"):
+        assert out["1"][2] is True, "the p/x-fused form was not taken on a lattice that admits it"
+    assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
+    assert rel(out["1"][0], out["0"][0]) < 1e-9
+    if tag == "K" and nchains == 1:
+        om = _oracle_model(oracle, m)
+        xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(B[0]), solver_tol=1e-12, solver_maxiter=20000)
+        assert flo == 0 and rel(out["1"][0][0], xo) < 1e-6            # (a tol = 1e-8 solve against a tight one)
+    m.close()
+
+
 @pytest.mark.parametrize("nchains,per,chunk_T,disorder", [(16, 2, None, 0.0), (1, 48, None, 0.0), (64, 2, None, 0.0), (144, 2, None, 0.0), (20, 2, "5", 0.0), (24, 2, "2", 0.0),
                                                           (24, 2, "20", 0.0), (16, 2, None, 0.1), (64, 2, "8", 0.1)])
 def test_register_exchange_k_cg_ap_of_the_fused_iteration(nchains, per, chunk_T, disorder, monkeypatch):
