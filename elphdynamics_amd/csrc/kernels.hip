@@ -1169,9 +1169,12 @@ static bool reg_cheb_form(const elph_handle_s *h) {      // a register-exchange 
 
 // the patch-form lattices of the generic family (round 6): Holstein, uniform hopping, k_cg_ap_pg + k_kpm_cheb_pg (pgrid.hip) — their p/x-fused
 // iteration is the lane-program family's with those two kernels in its place (ELPH_PG_PX=0: the unfused form, A/B; read per call)
-static bool pg_px_form(const elph_handle_s *h) {
+static bool pg_px_allowed() {
     const char *e = getenv("ELPH_PG_PX");
-    if (e && e[0] == '0') return false;
+    return !(e && e[0] == '0');
+}
+static bool pg_px_form(const elph_handle_s *h) {
+    if (!pg_px_allowed()) return false;
     return !h->fast && h->kind == ELPH_MODEL_HOLSTEIN && h->pg_uniform && elph_pg_ap_usable(h) && elph_pg_cheb_usable(h);
 }
 
@@ -1191,7 +1194,8 @@ static bool px_plan(elph_handle_s *h, int nrhs) {
     if (!(B.dot_lo == 0 && B.dot_hi == N) || !elph_dft_mfma_xr_usable(h, N, nrhs)) return false;      // the iteration takes cg_mode 2
     const char *ef = getenv("ELPH_FREQ_RZ");
     if ((ef && ef[0] == '0') || 2 * Lo2 > B.nrz) return false;
-    if (!reg_cheb_form(h) || elph_pg_cheb_usable(h)) return false;
+    // (r.z in frequency space comes from a register-exchange Chebyshev kernel — or, round 6, from the patch-form one: square L = 18, 20 of this family)
+    if (!reg_cheb_form(h) && !(elph_pg_cheb_usable(h) && pg_px_allowed())) return false;
     { const char *ec = getenv("ELPH_CHEB_COMPLEX"); if (ec && ec[0] == '1') return false; }
     const int T = elph_choose_T_px(h, h->T_rhs_hint > 0 ? h->T_rhs_hint : nrhs);
     if (!(T > 1 && L % T == 0 && (T == 20 || T == 16 || T == 10 || T == 8 || T == 5 || T == 4 || T == 2))) return false;

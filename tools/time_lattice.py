@@ -30,5 +30,13 @@ for nrhs in [int(a) for a in sys.argv[3:]] or [1, 16]:
         check(lib.elph_bench_prepare(m._h, what, nrhs, None))
         check(lib.elph_bench_run(m._h, what, nrhs, 160, 0, C.byref(ms)))
         out[name] = ms.value * 1e3 / 160
-    print(f"nrhs={nrhs:3d} cg_iter {out['cg_iter']:.1f} us  kpm_apply {out['kpm_apply']:.1f} us  pcg_iter {out['pcg_iter']:.1f} us")
+    two = ""
+    try:      # the preconditioned iteration as two half-batches on two streams (what a solve runs from 64 / 192 right-hand sides, where the fused form exists)
+        check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
+        check(lib.elph_bench_run(m._h, 11, nrhs, 32, 0, C.byref(ms)))
+        check(lib.elph_bench_run(m._h, 11, nrhs, 160, 0, C.byref(ms)))
+        two = f"  pcg_iter on two streams {ms.value * 1e3 / 160:.1f} us"
+    except Exception:
+        pass
+    print(f"nrhs={nrhs:3d} cg_iter {out['cg_iter']:.1f} us  kpm_apply {out['kpm_apply']:.1f} us  pcg_iter {out['pcg_iter']:.1f} us{two}")
 m.close()
