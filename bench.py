@@ -517,6 +517,18 @@ def main():
                         check(lib.elph_bench_prepare(ml_._h, wh, 72, None))
                         check(lib.elph_bench_run(ml_._h, wh, 72, 160, 0, C.byref(msl)))
                         rec[nm] = 1e3 * msl.value / 160
+                    # (round 6) the preconditioned iteration as a solve of this batch runs it: p/x-fused, two half-batches on two streams
+                    try:
+                        fz_ = C.c_int()
+                        check(lib.elph_bench_prepare(ml_._h, 3, 72, None))
+                        check(lib.elph_bench_px_info(ml_._h, C.byref(fz_)))
+                        rec["preconditioned_px_fused"] = int(fz_.value)
+                        check(lib.elph_bench_run(ml_._h, 11, 72, 32, 0, C.byref(msl)))
+                        check(lib.elph_bench_run(ml_._h, 11, 72, 160, 0, C.byref(msl)))
+                        rec["preconditioned_cg_iter_us_one_stream"] = rec["preconditioned_cg_iter_us"]
+                        rec["preconditioned_cg_iter_us"] = rec["preconditioned_cg_iter_us_two_streams"] = 1e3 * msl.value / 160
+                    except _lib.ElphError:
+                        pass                             # (no two-stream form for this shape: the one-stream figure stands)
                     # one right-hand side (the reference's call shape): the streaming pair and — where the rule of slabs.hip takes it —
                     # the slab form (the resident kernel on slabs of rows of the lattice, all slabs one launch)
                     for wh, nm in ((1, "cg_iter_us_1rhs_streaming"), (12, "cg_iter_us_1rhs_slabs")):
