@@ -45,6 +45,8 @@ CONFIGS = {
     "j": ("holstein", 1, 28, lat.SQUARE_BONDS, 0.6, 0.1),           # N = 784: 4 x 4 patches on 7 x 7 lanes
     "i": ("holstein", 1, 18, lat.SQUARE_BONDS, 0.6, 0.1),           # N = 324: 2 x 6 patches on 9 x 3 lanes
     "K": ("holstein", 1, 24, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 576, Ltau = 40: long recursions (order ~ 50 at the lowest frequency)
+    "l22": ("holstein", 1, 22, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 484, Ltau = 40: 22 = 2 x 11 has no single-wave patch — the generic LDS kernels (round 6: p/x-fused)
+    "l26": ("holstein", 1, 26, lat.SQUARE_BONDS, 4.8, 0.1),         # N = 676, Ltau = 48
     "k40": ("holstein", 1, 20, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 400, Ltau = 40: the lane-program family WITH the patch-form Chebyshev kernel — its p/x-fused iteration (round 6)
     "l30": ("holstein", 1, 30, lat.SQUARE_BONDS, 0.6, 0.1),         # N = 900: 2 x 10 patches on 15 x 3 lanes (round 5)
     # honeycomb lattices beyond 16 x 16 cells with a PGRID cell patch (h above, 18 x 18 cells: 3 x 2 cells per lane, is one more)

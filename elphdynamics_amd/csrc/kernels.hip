@@ -264,7 +264,9 @@ __global__ void __launch_bounds__(1024) k_mul(double *__restrict__ y, const doub
 // ------------------------------------------------------------------------------------------
 
 
-template <int NPL>
+// PX (round 6: the p/x-fused preconditioned iteration for every lattice of the generic family): the search direction arrives READY in B.p slot 0
+// (the inverse tau-transform formed p = P^-1 r + beta p and applied x += alpha p in its epilogue, dft_mfma.hip: PxFuse) — no P^-1 r, no p_new.
+template <int NPL, bool PX = false>
 __global__ void __launch_bounds__(1024) k_cg_ap(CgBufs B, ModelDev m, int parity) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bufA = lds, *bufB = lds + m.N;
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(1024) k_cg_ap(CgBufs B, ModelDev m, int parity
     }
 
     const double *src = (P.use_prec ? B.zp : B.r) + (size_t)rhs * ndim;
-    const double *pold = B.p + ((size_t)parity * B.nrhs + rhs) * ndim;
+    const double *pold = B.p + ((size_t)(PX ? 0 : parity) * B.nrhs + rhs) * ndim;
     double *pnew = B.p + ((size_t)(parity ^ 1) * B.nrhs + rhs) * ndim;
     double *z = B.z + (size_t)rhs * ndim;
 
@@ -330,14 +332,14 @@ __global__ void __launch_bounds__(1024) k_cg_ap(CgBufs B, ModelDev m, int parity
         if (s < N) {
             const size_t im = (size_t)tm1 * N + s, i0 = (size_t)t * N + s, ip = (size_t)tp1 * N + s;
             double pm;
-            if (first) {                       // p0 = z0|r0 was stored by the init kernel
+            if (PX || first) {                 // p0 = z0|r0 was stored by the init kernel (PX: the ready p of every iteration)
                 pm = pold[im]; p0[q] = pold[i0]; pp[q] = pold[ip];
             } else {                           // p = (z|r) + beta p   (:229-230 / :309-310)
                 pm = src[im] + beta * pold[im];
                 p0[q] = src[i0] + beta * pold[i0];
                 pp[q] = src[ip] + beta * pold[ip];
             }
-            pnew[i0] = p0[q];
+            if (!PX) pnew[i0] = p0[q];
             e1[q] = E1[s];
             bufA[s] = E0[s] * pm;
             bufB[s] = e1[q] * p0[q];
@@ -604,8 +606,12 @@ __device__ __forceinline__ void kpm_series(double2 (&acc)[NPL], const double2 (&
 }
 
 template <int NPL>
+// rz_part != nullptr (round 6, the p/x-fused iteration): the block's share of r.(P^-1 r) in frequency space (Parseval for the twisted transform:
+// a.b = (1/L) sum_k conj(a_k) b_k, the mirror frequency L-1-k contributing the same) into slot blockIdx.y of this right-hand side, the slots
+// beyond Lo2 cleared by the blocks in turn; a chain whose expansion is inactive hands over the r.r partials of the residual update instead.
 __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, KpmDev K, ModelDev m, int Lo2,
-                                                   const CgState *state, int lds_tables) {
+                                                   const CgState *state, int lds_tables, double *__restrict__ rz_part, int nrz,
+                                                   const double *__restrict__ rr_part) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double2 *buf = reinterpret_cast<double2 *>(lds);
     const int rhs = blockIdx.x;   // x = right-hand side, y = frequency in longest-first order: ALL long recursions are dispatched first
@@ -639,10 +645,25 @@ __global__ void __launch_bounds__(1024) k_kpm_cheb(double2 *__restrict__ nu, Kpm
     }
     kpm_series<NPL, true, true>(mid, vin, buf, eb, c, order, K, m, V.a, V.b, lij, lc, ls);     // M^-T[w,w], conj coefficients (:621-648)
     kpm_series<NPL, false, false>(res, mid, buf, eb, c, order, K, m, V.a, V.b, lij, lc, ls);   // M^-1[w,w]                     (:650-677)
+    double dot = 0.0;
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int s = threadIdx.x + q * blockDim.x;
-        if (s < N) u[s] = res[q];
+        if (s < N) { u[s] = res[q]; dot += vin[q].x * res[q].x + vin[q].y * res[q].y; }
+    }
+    if (rz_part) {
+        dot = block_sum(dot, lds);           // (the slab is free: both series are done)
+        if (threadIdx.x == 0) {
+            const int Ltau = m.L, bid = (int)blockIdx.y;
+            double *slots = rz_part + (size_t)rhs * nrz;
+            const double wgt = ((Ltau & 1) && w == Lo2 - 1) ? 1.0 : 2.0;
+            if (V.active) {
+                slots[bid] = wgt * dot / (double)Ltau;
+                for (int qq = Lo2 + bid; qq < nrz; qq += Lo2) slots[qq] = 0.0;
+            } else {
+                for (int qq = bid; qq < nrz; qq += Lo2) slots[qq] = (qq < Ltau) ? rr_part[(size_t)rhs * Ltau + qq] : 0.0;
+            }
+        }
     }
 }
 
@@ -1188,14 +1209,31 @@ static bool px_plan(elph_handle_s *h, int nrhs) {
         if (ef && ef[0] == '0') return false;
         return elph_dft_mfma_xr_usable(h, N, nrhs) && elph_dft_mfma_px_usable(h, N, nrhs);
     }
-    if (!h->fast || h->lp_mc != 4) return false;      // (Holstein and bond-phonon models alike)
+    if (!h->fast) {
+        // (round 6) every other lattice of the generic family — ragged colours, more than six colours, hopping disorder, no patch form, bond
+        // phonons beyond the lane-program sizes: k_cg_ap<PX> + k_kpm_cheb with r.z in frequency space (ELPH_GEN_PX=0: the unfused form, A/B)
+        const char *eg = getenv("ELPH_GEN_PX");
+        if (eg && eg[0] == '0') return false;
+        const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+        CgBufs B = make_bufs(h, nrhs);
+        if (!(B.dot_lo == 0 && B.dot_hi == N) || B.npap != L || Lo2 > B.nrz || elph_pg_cheb_usable(h)) return false;
+        const char *ef = getenv("ELPH_FREQ_RZ");
+        if (ef && ef[0] == '0') return false;
+        return elph_dft_mfma_xr_usable(h, N, nrhs) && elph_dft_mfma_px_usable(h, N, nrhs);
+    }
+    if (h->lp_mc != 4) return false;      // (Holstein and bond-phonon models alike)
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     CgBufs B = make_bufs(h, nrhs);
     if (!(B.dot_lo == 0 && B.dot_hi == N) || !elph_dft_mfma_xr_usable(h, N, nrhs)) return false;      // the iteration takes cg_mode 2
     const char *ef = getenv("ELPH_FREQ_RZ");
     if ((ef && ef[0] == '0') || 2 * Lo2 > B.nrz) return false;
     // (r.z in frequency space comes from a register-exchange Chebyshev kernel — or, round 6, from the patch-form one: square L = 18, 20 of this family)
-    if (!reg_cheb_form(h) && !(elph_pg_cheb_usable(h) && pg_px_allowed())) return false;
+    // or from the Re / Im recursion through the LDS slab (k_kpm_cheb_ri: square L = 22, disordered honeycomb lattices, ...; ELPH_LDS_CHEB_PX=0 and
+    // ELPH_NO_SQ=1 — the A/B that forces that recursion on a lattice with a register form — keep the unfused iteration)
+    if (!reg_cheb_form(h) && !(elph_pg_cheb_usable(h) && pg_px_allowed())) {
+        const char *el = getenv("ELPH_LDS_CHEB_PX"), *ens = getenv("ELPH_NO_SQ");
+        if ((el && el[0] == '0') || (ens && ens[0] == '1') || elph_pg_cheb_usable(h)) return false;
+    }
     { const char *ec = getenv("ELPH_CHEB_COMPLEX"); if (ec && ec[0] == '1') return false; }
     const int T = elph_choose_T_px(h, h->T_rhs_hint > 0 ? h->T_rhs_hint : nrhs);
     if (!(T > 1 && L % T == 0 && (T == 20 || T == 16 || T == 10 || T == 8 || T == 5 || T == 4 || T == 2))) return false;
@@ -1262,6 +1300,8 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         int rcf = elph_fast_kpm_cheb(h, nrhs, st, want ? B.rz : nullptr, B.nrz, &rz_done, B.rr, (fold && want) ? nct : 0);
         if (rcf) return rcf;
     } else {
+        static const bool gfreq_rz = []() { const char *e = getenv("ELPH_FREQ_RZ"); return !(e && e[0] == '0'); }();
+        const bool gwant = cg_mode && gfreq_rz && Lo2 <= B.nrz && B.dot_lo == 0 && B.dot_hi == N && h->px_solve;      // (the p/x-fused iteration of the generic family)
         // one thread per bond of the largest colour (up to 1024): a colour is then one LDS round trip per thread; the bond
         // program rides in LDS when it fits next to the slab
         int maxcol = 1;
@@ -1272,8 +1312,9 @@ int elph_launch_kpm_apply(elph_handle_s *h, double *zS, const double *rS, int nr
         const int lds_tables = (N <= 65535 && shm + tab <= 64 * 1024) ? 1 : 0;
         DISPATCH_NPL(cnpl, {
             hipLaunchKernelGGL((k_kpm_cheb<NPL>), dim3((unsigned)nrhs, (unsigned)Lo2), dim3((unsigned)cbs), shm + (lds_tables ? tab : 0),
-                               h->stream, h->d_nu, K, m, Lo2, st, lds_tables);
+                               h->stream, h->d_nu, K, m, Lo2, st, lds_tables, gwant ? B.rz : nullptr, B.nrz, B.rr);
         });
+        rz_done = gwant;
     }
     // r.z partial slots: (blockIdx.y * gridDim.x + blockIdx.x) < ceil(L/TPT)*nst <= L*npl = nrz; the kernel clears the rest
     if ((parts & 4) && cg_mode == 2 && h->px_solve) {
@@ -1372,10 +1413,16 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
         const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
         const bool pg = elph_pg_ap_usable(h) && m.uniform && B.npap == L;      // a large even-L square lattice: the patch-layout kernel (pgrid.hip)
         if (use_prec && h->px_solve) {
-            // the p/x-fused iteration of a patch-form lattice (px_plan): k_cg_ap_pg reads the ready p; the residual update rides on the forward
-            // transform, r.z comes from the Chebyshev kernel in frequency space, the p/x-update is the inverse transform's epilogue
-            if (!pg) { elph_set_error("p/x-fused iteration planned for a lattice without the patch-form k_cg_ap (internal error)"); return ELPH_E_STATE; }
-            rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1), true);
+            // the p/x-fused iteration of the generic family (px_plan): k_cg_ap_pg (patch-form lattices) or k_cg_ap<PX> reads the ready p; the
+            // residual update rides on the forward transform, r.z comes from the Chebyshev kernel in frequency space, the p/x-update is the
+            // inverse transform's epilogue
+            if (pg) rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1), true);
+            else {
+                DISPATCH_NPL(gen_npl(h), {
+                    hipLaunchKernelGGL((k_cg_ap<NPL, true>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
+                });
+                rc = check_launch("k_cg_ap<PX>");
+            }
             h->ap_count++;
             if (rc) return rc;
             return elph_launch_kpm_apply(h, h->d_zp, h->d_r, nrhs, 2);
@@ -1413,8 +1460,10 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
         h->ap_count++;
         return rc;
     }
+    const bool gpx = B.params.use_prec && h->px_solve;
     DISPATCH_NPL(gen_npl(h), {
-        if (which == 0) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
+        if (which == 0 && gpx) hipLaunchKernelGGL((k_cg_ap<NPL, true>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
+        else if (which == 0) hipLaunchKernelGGL((k_cg_ap<NPL>), grid, dim3((unsigned)gen_bs(h)), shm, h->stream, B, m, (int)(h->ap_count & 1));
         else hipLaunchKernelGGL((k_cg_xr<NPL>), grid, dim3((unsigned)gen_bs(h)), 0, h->stream, B, N, L, (int)(h->ap_count & 1));
     });
     if (which == 0) h->ap_count++;

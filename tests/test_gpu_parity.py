@@ -271,7 +271,7 @@ def _oracle_model(orc, m):
                           np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
 
 
-@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "l30", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32"])
+@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "l30", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32", "l22", "l26"])      # l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_matvec_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models, synth
     m = configs.make_model(tag)
@@ -304,7 +304,7 @@ def test_matvec_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "l30", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32"])
+@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "l30", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32", "l22", "l26"])      # l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_cg_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models
     m = configs.make_model(tag, tol=1e-5)
@@ -376,7 +376,7 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32"])
+@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32", "l22", "l26"])      # l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_kpm_vs_oracle(oracle, tag):
     """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle.  e / E: bond phonons — the
     expansion is built on the tau-means of the per-(tau, bond) hopping tables (update_A!, KPMPreconditioners.jl:355-381)."""
@@ -1424,6 +1424,47 @@ def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, mo
         om = _oracle_model(oracle, m)
         xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(B[0]), solver_tol=1e-12, solver_maxiter=20000)
         assert flo == 0 and rel(out["1"][0][0], xo) < 1e-6            # (a tol = 1e-8 solve against a tight one)
+    m.close()
+
+
+@pytest.mark.parametrize("tag,nchains,per,no_fast,disorder", [("C", 32, 2, True, 0.0), ("E", 32, 2, True, 0.0), ("l22", 32, 2, False, 0.0), ("l22", 1, 64, False, 0.0),
+                                                              ("l26", 8, 2, False, 0.0), ("K", 8, 2, False, 0.1), ("D", 16, 2, True, 0.0)])
+def test_px_fused_iteration_generic_family(oracle, tag, nchains, per, no_fast, disorder, monkeypatch):
+    """Round 6: the p/x-fused preconditioned batch iteration for the lattices that run the GENERIC LDS kernels — no lane program, no patch form:
+    square L = 22, 26 (2 x 11, 2 x 13: no even patch fits a wavefront), hopping disorder on a lattice beyond 16 x 16 (K with a disordered
+    hopping table), and, forced with ELPH_NO_FAST=1, the generic kernels on configs C, D and E (bond phonons) — `k_cg_ap<PX>` reads the ready
+    p, `k_kpm_cheb` delivers r.z in frequency space, the transforms carry the residual and the p/x-update — against the unfused form
+    (ELPH_GEN_PX=0): iteration counts within one, solutions of two tol = 1e-8 solves to 1e-9, the fused form asserted taken; one right-hand
+    side of l22 against the oracle (IterativeSolvers.jl:153-234)."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    if no_fast:
+        monkeypatch.setenv("ELPH_NO_FAST", "1")
+    m = configs.make_model(tag, tol=1e-8, t_stddev=disorder)
+    nrhs = nchains * per
+    if nchains > 1 and m.kind == models.SSH:
+        X = np.stack([m.x * (0.55 + 0.9 * c / nchains) * (1.0 + 0.2 * synth.randn(9000 + c, m.Ndof)) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+    elif nchains > 1:
+        X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=9000 + c) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    (pc.setup_chains_ if nchains > 1 else pc.setup_)(P, rng=np.random.default_rng(16))
+    B = np.stack([synth.randn(9100 + r, m.Ndim) for r in range(nrhs)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_GEN_PX", mode)
+        monkeypatch.setenv("ELPH_LDS_CHEB_PX", mode)             # (l22 is a lane-program lattice whose recursion runs through the LDS slab: k_kpm_cheb_ri)
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any()
+        out[mode] = (Xs, it, _px_fused(m))
+    assert out["0"][2] is False and out["1"][2] is True, (out["0"][2], out["1"][2])
+    assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
+    assert rel(out["1"][0], out["0"][0]) < 1e-9
+    if tag == "l22" and nchains == 1:
+        om = _oracle_model(oracle, m)
+        xo, ito, reso, flo = oracle.ldiv(om, np.ascontiguousarray(B[0]), solver_tol=1e-12, solver_maxiter=20000)
+        assert flo == 0 and rel(out["1"][0][0], xo) < 1e-6
     m.close()
 
 
