@@ -45,6 +45,8 @@ CONFIGS = {
     "j": ("holstein", 1, 28, lat.SQUARE_BONDS, 0.6, 0.1),           # N = 784: 4 x 4 patches on 7 x 7 lanes
     "i": ("holstein", 1, 18, lat.SQUARE_BONDS, 0.6, 0.1),           # N = 324: 2 x 6 patches on 9 x 3 lanes
     "K": ("holstein", 1, 24, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 576, Ltau = 40: long recursions (order ~ 50 at the lowest frequency)
+    "l36": ("holstein", 1, 36, lat.SQUARE_BONDS, 0.6, 0.1),         # N = 1296: 4 x 6 patches on 9 x 6 lanes (round 6)
+    "L36": ("holstein", 1, 36, lat.SQUARE_BONDS, 8.8, 0.1),         # N = 1296, Ltau = 88: long recursions, the fused preconditioned iteration (81 column tiles <= 88 slices)
     "l22": ("holstein", 1, 22, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 484, Ltau = 40: 22 = 2 x 11 has no single-wave patch — the generic LDS kernels (round 6: p/x-fused)
     "l26": ("holstein", 1, 26, lat.SQUARE_BONDS, 4.8, 0.1),         # N = 676, Ltau = 48
     "k40": ("holstein", 1, 20, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 400, Ltau = 40: the lane-program family WITH the patch-form Chebyshev kernel — its p/x-fused iteration (round 6)

@@ -17,7 +17,7 @@
 
 namespace {
 
-using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>; using SQ2A = pgrid::Sq<2, 10>;
+using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>; using SQ2A = pgrid::Sq<2, 10>; using SQ46 = pgrid::Sq<4, 6>;
 using TR22 = pgrid::Tri<2, 2>; using TR24 = pgrid::Tri<2, 4>; using TR26 = pgrid::Tri<2, 6>; using TR44 = pgrid::Tri<4, 4>;
 using HC32 = pgrid::Hc<3, 2>; using HC42 = pgrid::Hc<4, 2>; using HC33 = pgrid::Hc<3, 3>;
 
@@ -435,6 +435,7 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_p
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_CHEB(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_CHEB(SQ24);
     else if (h->pg_kind == 1 && px == 2 && py == 10) PG_CHEB(SQ2A);
+    else if (h->pg_kind == 1 && px == 4 && py == 6) PG_CHEB(SQ46);
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_CHEB(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_CHEB(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_CHEB(HC33);
@@ -480,6 +481,7 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_AP(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_AP(SQ24);
     else if (h->pg_kind == 1 && px == 2 && py == 10) PG_AP(SQ2A);
+    else if (h->pg_kind == 1 && px == 4 && py == 6) PG_AP(SQ46);
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_AP(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_AP(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_AP(HC33);
@@ -513,6 +515,7 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_MUL(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_MUL(SQ24);
     else if (h->pg_kind == 1 && px == 2 && py == 10) PG_MUL(SQ2A);
+    else if (h->pg_kind == 1 && px == 4 && py == 6) PG_MUL(SQ46);
     else if (h->pg_kind == 2 && px == 3 && py == 2) PG_MUL(HC32);
     else if (h->pg_kind == 2 && px == 4 && py == 2) PG_MUL(HC42);
     else if (h->pg_kind == 2 && px == 3 && py == 3) PG_MUL(HC33);

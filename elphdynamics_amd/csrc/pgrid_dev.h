@@ -10,7 +10,7 @@
 // before the first is used.  A 4 x 4 patch does 16 fma per colour and moves 4 + 4 values in two of the four colours: a quarter of the
 // exchange per fma of the 2 x 2 patch, and no barrier anywhere.
 //   L = 32, 28: 4 x 4 patches (64 / 49 lanes, 16 registers per vector)      L = 24, 18: 2 x 6 (48 / 27 lanes, 12 registers)
-//   L = 20:     2 x 4 (50 lanes, 8 registers)
+//   L = 20:     2 x 4 (50 lanes, 8 registers)                               L = 30: 2 x 10 (45 lanes, 20), L = 36: 4 x 6 (54 lanes, 24)
 // Uniform hopping only (one (cosh, sinh) for every bond — the decks): a colour is c (I + th P) with th = sinh / cosh, the caller
 // scales by c^4 once.
 #pragma once
@@ -246,7 +246,8 @@ template <int PX_, int PY_> struct Tri {
 inline bool pick_tpatch(int L, int *PX, int *PY) {
     if (L < 4 || (L & 1)) return false;
     if (L <= 16) { *PX = 2; *PY = 2; return true; }
-    return pick_patch(L, PX, PY);
+    // (only the shapes pgrid.hip instantiates for the triangular sweep: 2 x 4, 2 x 6, 4 x 4 — a triangular 30 x 30 or 36 x 36 keeps the generic kernels)
+    return pick_patch(L, PX, PY) && ((*PX == 2 && (*PY == 4 || *PY == 6)) || (*PX == 4 && *PY == 4));
 }
 
 // The cell patch for an L x L honeycomb lattice beyond 16 x 16 cells (false: none).
@@ -266,6 +267,7 @@ inline bool pick_patch(int L, int *PX, int *PY) {
         case 24: case 18: *PX = 2; *PY = 6; return true;
         case 20: *PX = 2; *PY = 4; return true;
         case 30: *PX = 2; *PY = 10; return true;     // 15 x 3 lanes, 20 registers per vector (round 5)
+        case 36: *PX = 4; *PY = 6; return true;      // 9 x 6 lanes, 24 registers per vector (round 6: the largest patch a wavefront carries — 6 vectors of the recursion = 288 registers, the overflow in AGPRs)
         default: return false;
     }
 }
