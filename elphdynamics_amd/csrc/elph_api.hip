@@ -851,6 +851,7 @@ static int split_begin(elph_handle_s *h, int nrhs, SplitRun &S) {
         if (!h->split_stream[k]) HIPCHK(hipStreamCreateWithFlags(&h->split_stream[k], hipStreamNonBlocking));
     if (!h->split_ev) HIPCHK(hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming));
     h->px_solve = true;                                   // (split_legal: the parts run p/x-fused whatever the whole batch would have run)
+    h->px_via_pg = h->fast && h->lp_mc != 4;              // (six-colour lane programs: the patch-form pair, kernels.hip: px_plan)
     h->T_rhs_hint = nrhs;                                 // slices per wave for the right-hand sides in flight = all parts
     HIPCHK(hipEventRecord(h->split_ev, h->stream));       // the start state (x0, r0, p0, rho0 of every right-hand side) is on the main stream
     const size_t nd = (size_t)h->ndim, Lo2 = (size_t)(h->L + 1) / 2, nrz = (size_t)h->L * (size_t)h->npl;

@@ -212,6 +212,7 @@ struct elph_handle_s {
     int T_rhs_hint = 0;                    // > 0: right-hand sides in flight when the slices per wave are chosen (two-stream batches: both halves)
     bool ebar_external = false;            // kpm_setup_core: d_Ebar was filled by the caller (elph_i_kpm_setup_ebar)
     bool px_solve = false;                 // the current solve's preconditioned iteration is p/x-fused (kernels.hip: px_plan)
+    bool px_via_pg = false;                // this solve's p/x-fused iteration takes the patch-form k_cg_ap_pg although the handle is of the lane-program family (six-colour lane programs: triangular lattices up to 16 x 16)
     bool sq16_ap_ran = false;              // the latest p/x-fused k_cg_ap ran in the register-exchange form (cg_sq16.hip)
     // SSH update_model! on the device (elph_update_model_ssh_fields): staging of x, per-phonon tables, slot map
     double *d_ssh_x = nullptr, *d_ssh_par = nullptr, *d_ssh_tbare = nullptr, *d_ssh_bar = nullptr;

@@ -1125,7 +1125,8 @@ static CgBufs make_bufs(elph_handle_s *h, int nrhs) {
     B.dot_hi = h->dot_hi > 0 ? h->dot_hi : (int)h->N;
     B.nrz = (int)(h->L * h->npl);
     {   // slices per wave of k_cg_ap: the p/x-fused kernel of a preconditioned batch has its own rule
-        const int Tc = (h->px_solve && h->cur_params.use_prec) ? elph_choose_T_px(h, h->T_rhs_hint > 0 ? h->T_rhs_hint : nrhs) : elph_choose_T(h, nrhs);
+        const int Tc = (h->px_solve && h->cur_params.use_prec && h->px_via_pg) ? 1      // (k_cg_ap_pg: one p.z slot per time slice)
+                       : (h->px_solve && h->cur_params.use_prec) ? elph_choose_T_px(h, h->T_rhs_hint > 0 ? h->T_rhs_hint : nrhs) : elph_choose_T(h, nrhs);
         B.npap = (int)((h->L + Tc - 1) / Tc);      // (a ragged cut: ceil)
     }
     B.nrhs = nrhs;
@@ -1221,7 +1222,21 @@ static bool px_plan(elph_handle_s *h, int nrhs) {
         if (ef && ef[0] == '0') return false;
         return elph_dft_mfma_xr_usable(h, N, nrhs) && elph_dft_mfma_px_usable(h, N, nrhs);
     }
-    if (h->lp_mc != 4) return false;      // (Holstein and bond-phonon models alike)
+    if (h->lp_mc != 4) {
+        // six-colour lane programs (triangular lattices up to 16 x 16: the geometry of holstein_hmc_triangular.toml) have no fused chunk kernel of
+        // their own: their p/x-fused iteration takes the patch-form pair k_cg_ap_pg<PX> + k_kpm_cheb_pg (pgrid::Tri<2, 2>) — round 6
+        if (!(pg_px_allowed() && h->kind == ELPH_MODEL_HOLSTEIN && h->pg_L > 0 && h->pg_uniform && elph_pg_cheb_usable(h))) return false;
+        const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
+        const bool keep = h->px_via_pg, keeps = h->px_solve;
+        h->px_via_pg = true; h->px_solve = true;            // (make_bufs prices the partial-sum layout of the form being planned)
+        CgParams kp = h->cur_params; h->cur_params.use_prec = 1;
+        CgBufs B = make_bufs(h, nrhs);
+        h->cur_params = kp; h->px_via_pg = keep; h->px_solve = keeps;
+        if (!(B.dot_lo == 0 && B.dot_hi == N) || B.npap != L || 2 * Lo2 > B.nrz) return false;
+        const char *ef = getenv("ELPH_FREQ_RZ");
+        if (ef && ef[0] == '0') return false;
+        return elph_dft_mfma_xr_usable(h, N, nrhs) && elph_dft_mfma_px_usable(h, N, nrhs);
+    }
     const int N = (int)h->N, L = (int)h->L, Lo2 = (L + 1) / 2;
     CgBufs B = make_bufs(h, nrhs);
     if (!(B.dot_lo == 0 && B.dot_hi == N) || !elph_dft_mfma_xr_usable(h, N, nrhs)) return false;      // the iteration takes cg_mode 2
@@ -1342,6 +1357,7 @@ int elph_launch_cg_init(elph_handle_s *h, int nrhs, int use_prec, bool x_zero) {
         const bool px = use_prec && h->kpm_ready && px_plan(h, nrhs);
         if (px != h->px_solve) elph_i_drop_graphs(h);
         h->px_solve = px;
+        h->px_via_pg = px && h->fast && h->lp_mc != 4;
     }
     h->x_zero_seen = x_zero;
     if (h->x_zero_seen) {       // x0 = 0 (the library zeroed it for this solve): A x0 = 0 without the mat-vec
@@ -1398,7 +1414,8 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
     int rc;
     if (h->fast) {
         const bool px = use_prec && h->px_solve;
-        rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1), px);
+        if (px && h->px_via_pg) { ModelDev mp = elph_model_dev(h); rc = elph_pg_cg_ap(h, B, mp, nrhs, (int)(h->ap_count & 1), true); }
+        else rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1), px);
         h->ap_count++;
         if (rc) return rc;
         if (use_prec && h->kpm_active && B.dot_lo == 0 && B.dot_hi == (int)h->N && elph_dft_mfma_xr_usable(h, (int)h->N, nrhs))
@@ -1445,7 +1462,9 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     CgBufs B = make_bufs(h, nrhs);
     if (h->fast) {
         if (which == 0) {
-            int rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1), B.params.use_prec && h->px_solve);
+            int rc;
+            if (B.params.use_prec && h->px_solve && h->px_via_pg) { ModelDev mp = elph_model_dev(h); rc = elph_pg_cg_ap(h, B, mp, nrhs, (int)(h->ap_count & 1), true); }
+            else rc = elph_fast_cg_ap(h, B, nrhs, (int)(h->ap_count & 1), B.params.use_prec && h->px_solve);
             h->ap_count++;
             return rc;
         }

@@ -1390,7 +1390,7 @@ def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, 
 
 
 @pytest.mark.parametrize("tag,nchains,per", [("K", 8, 2), ("K", 1, 24), ("X32", 4, 2), ("k40", 32, 2), ("k", 12, 2), ("j", 8, 2),
-                                             ("X24", 4, 2), ("XT24", 8, 2), ("L36", 4, 2)])      # honeycomb 24 x 24 cells, triangular 24 x 24: the same pipeline around their patch sweeps
+                                             ("X24", 4, 2), ("XT24", 8, 2), ("L36", 4, 2), ("T", 32, 2)])      # honeycomb 24 x 24 cells, triangular 24 x 24: the same pipeline around their patch sweeps
 def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, monkeypatch):
     """Round 6: the p/x-fused preconditioned batch iteration on the patch-form lattices of the generic family (square L = 18 … 32: `k_cg_ap_pg<PX>`
     reads the ready p, the residual update rides on the forward transform, r.z comes from `k_kpm_cheb_pg` in frequency space, the p/x-update is
@@ -1416,7 +1416,7 @@ def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, mo
         out[mode] = (Xs, it, _px_fused(m))
     assert out["0"][2] is False
     # the fused form needs the MFMA transforms with the residual update (N / 16 column tiles <= Ltau, enough waves): K (24 x 24, Ltau = 40), X32 and k40 (20 x 20, Ltau = 40: lane-program family, patch-form Chebyshev) have it
-    if tag in ("K", "X32", "k40", "X24", "XT24", "L36"):
+    if tag in ("K", "X32", "k40", "X24", "XT24", "L36", "T"):      # (T: triangular 16 x 16 — a six-colour lane program riding on the patch-form pair)
         assert out["1"][2] is True, "the p/x-fused form was not taken on a lattice that admits it"
     assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
     assert rel(out["1"][0], out["0"][0]) < 1e-9
