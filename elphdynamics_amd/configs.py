@@ -47,6 +47,7 @@ CONFIGS = {
     "K": ("holstein", 1, 24, lat.SQUARE_BONDS, 4.0, 0.1),           # N = 576, Ltau = 40: long recursions (order ~ 50 at the lowest frequency)
     "l36": ("holstein", 1, 36, lat.SQUARE_BONDS, 0.6, 0.1),         # N = 1296: 4 x 6 patches on 9 x 6 lanes (round 6)
     "L36": ("holstein", 1, 36, lat.SQUARE_BONDS, 8.8, 0.1),         # N = 1296, Ltau = 88: long recursions, the fused preconditioned iteration (81 column tiles <= 88 slices)
+    "G40": ("holstein", 1, 32, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 1024, Ltau = 40: more column tiles (64) than time slices — the residual update's r.r slots per workgroup (round 6)
     "l22": ("holstein", 1, 22, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 484, Ltau = 40: 22 = 2 x 11 has no single-wave patch — the generic LDS kernels (round 6: p/x-fused)
     "l26": ("holstein", 1, 26, lat.SQUARE_BONDS, 4.8, 0.1),         # N = 676, Ltau = 48
     "k40": ("holstein", 1, 20, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 400, Ltau = 40: the lane-program family WITH the patch-form Chebyshev kernel — its p/x-fused iteration (round 6)

@@ -562,12 +562,30 @@ __global__ void __launch_bounds__(CW * WAVE) k_dft_mfma_r2s(double *__restrict__
         if (XR) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
-            if (lane == 0) {
-                const int nct = (N + 15) / 16;
-                double *slots = X.rr + (size_t)rhs * X.rr_slots;
-                slots[ctile] = acc;
-                for (int qq = nct + ctile; qq < X.rr_slots; qq += nct) slots[qq] = 0.0;
-                if (ctile == 0) X.alpha[rhs] = alpha;
+            const int nct = (N + 15) / 16;
+            if (nct <= X.rr_slots) {
+                if (lane == 0) {
+                    double *slots = X.rr + (size_t)rhs * X.rr_slots;
+                    slots[ctile] = acc;
+                    for (int qq = nct + ctile; qq < X.rr_slots; qq += nct) slots[qq] = 0.0;
+                    if (ctile == 0) X.alpha[rhs] = alpha;
+                }
+            } else {
+                // (round 6) more column tiles than r.r slots — a large lattice on a short time axis (32 x 32 at Ltau = 40: 64 tiles, 40 slots): ONE
+                // slot per workgroup, the waves' sums added in wave order through LDS.  (Waves without a column tile have left: a barrier
+                // waits for the surviving waves of the workgroup only; wave 0 always has a tile.)
+                __shared__ double wsum[CW];
+                if (lane == 0) wsum[wv] = acc;
+                __syncthreads();
+                if (wv == 0 && lane == 0) {
+                    const int nw = (nct - (int)blockIdx.x * CW < CW) ? nct - (int)blockIdx.x * CW : CW, nwg = (int)gridDim.x;
+                    double t = 0.0;
+                    for (int w2 = 0; w2 < nw; ++w2) t += wsum[w2];
+                    double *slots = X.rr + (size_t)rhs * X.rr_slots;
+                    slots[blockIdx.x] = t;
+                    for (int qq = nwg + (int)blockIdx.x; qq < X.rr_slots; qq += nwg) slots[qq] = 0.0;
+                    if (blockIdx.x == 0) X.alpha[rhs] = alpha;
+                }
             }
         }
         double facc = 0.0;
@@ -803,7 +821,14 @@ bool elph_dft_mfma_fold_usable(const elph_handle_s *h) {
 bool elph_dft_mfma_xr_usable(const elph_handle_s *h, int N, int nrhs) {
     const char *e = getenv("ELPH_FUSE_XR");
     if (e && atoi(e) == 0) return false;
-    return h->mf_r2[0].W && r2_enabled() && elph_dft_mfma_usable(h, 0, false, N, nrhs) && (N + 15) / 16 <= (int)h->L &&
+    // r.r partial slots: one per column tile where the time axis has that many (L slots per right-hand side), else — streaming form only —
+    // one per workgroup of CW tiles (round 6: large lattices on short time axes)
+    const int nct = (N + 15) / 16;
+    const size_t panel = (size_t)MG * h->mf_r2[0].nt * WAVE * sizeof(double);
+    const char *es = getenv("ELPH_DFT_STREAM");
+    const bool streaming = panel <= 144 * 1024 && !(es && atoi(es) == 0);
+    const bool slots_ok = nct <= (int)h->L || (streaming && (nct + CW - 1) / CW <= (int)h->L);
+    return h->mf_r2[0].W && r2_enabled() && elph_dft_mfma_usable(h, 0, false, N, nrhs) && slots_ok &&
            h->mf_r2[0].groups == 1;           // one row group: every element of r belongs to exactly one wave
 }
 

@@ -1389,8 +1389,39 @@ def test_px_fused_preconditioned_iteration_equals_the_unfused_one(tag, nchains, 
     m.close()
 
 
+@pytest.mark.parametrize("nchains,per,chunk_T", [(16, 2, None), (64, 2, None), (128, 2, None), (20, 2, "5"), (24, 2, "20")])
+def test_register_exchange_k_cg_ap_honeycomb12(nchains, per, chunk_T, monkeypatch):
+    """cg_sq16.hip: k_cg_ap_hc12_px — the p/x-fused k_cg_ap of BASELINE config D (honeycomb 12 x 12 cells, uniform hopping) with the checkerboard in
+    registers (the QUAD layout of the Chebyshev recursion: six consecutive sites per lane on 48 lanes, DPP quad rotations + one ds_bpermute round trip
+    per sweep) against the lane-program kernel it stands in front of (ELPH_SQ16_AP=0): iteration counts within one, solutions of two tol = 1e-8
+    solves to 1e-9, the post-solve residual."""
+    from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth
+    if chunk_T:
+        monkeypatch.setenv("ELPH_CHUNK_T", chunk_T)
+    m = configs.make_model("D", tol=1e-8)
+    nrhs = nchains * per
+    X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=9300 + c) for c in range(nchains)])
+    models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_chains_(P, rng=np.random.default_rng(17))
+    B = np.stack([synth.randn(9400 + r, m.Ndim) for r in range(nrhs)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_SQ16_AP", mode)
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any() and (res < 1e-6).all()
+        f = C.c_int()
+        _lib.check(_lib.load().elph_bench_px_info(m._h, C.byref(f)))
+        out[mode] = (Xs, it, f.value)
+    assert out["0"][2] == 1 and out["1"][2] == 2, f"forms taken: {out['0'][2]}, {out['1'][2]} (1 = lane program, 2 = registers)"
+    assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
+    assert rel(out["1"][0], out["0"][0]) < 1e-9
+    m.close()
+
+
 @pytest.mark.parametrize("tag,nchains,per", [("K", 8, 2), ("K", 1, 24), ("X32", 4, 2), ("k40", 32, 2), ("k", 12, 2), ("j", 8, 2),
-                                             ("X24", 4, 2), ("XT24", 8, 2), ("L36", 4, 2), ("T", 32, 2)])      # honeycomb 24 x 24 cells, triangular 24 x 24: the same pipeline around their patch sweeps
+                                             ("X24", 4, 2), ("XT24", 8, 2), ("L36", 4, 2), ("T", 32, 2), ("G40", 4, 2)])      # honeycomb 24 x 24 cells, triangular 24 x 24: the same pipeline around their patch sweeps
 def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, monkeypatch):
     """Round 6: the p/x-fused preconditioned batch iteration on the patch-form lattices of the generic family (square L = 18 … 32: `k_cg_ap_pg<PX>`
     reads the ready p, the residual update rides on the forward transform, r.z comes from `k_kpm_cheb_pg` in frequency space, the p/x-update is
@@ -1416,7 +1447,7 @@ def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, mo
         out[mode] = (Xs, it, _px_fused(m))
     assert out["0"][2] is False
     # the fused form needs the MFMA transforms with the residual update (N / 16 column tiles <= Ltau, enough waves): K (24 x 24, Ltau = 40), X32 and k40 (20 x 20, Ltau = 40: lane-program family, patch-form Chebyshev) have it
-    if tag in ("K", "X32", "k40", "X24", "XT24", "L36", "T"):      # (T: triangular 16 x 16 — a six-colour lane program riding on the patch-form pair)
+    if tag in ("K", "X32", "k40", "X24", "XT24", "L36", "T", "G40"):      # (T: triangular 16 x 16 — a six-colour lane program riding on the patch-form pair)
         assert out["1"][2] is True, "the p/x-fused form was not taken on a lattice that admits it"
     assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
     assert rel(out["1"][0], out["0"][0]) < 1e-9

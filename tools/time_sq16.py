@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elphdynamics_amd import _lib, configs, models, preconditioners as pc, synth  # noqa: E402
 
 lib = _lib.load()
-SETTINGS = [("0", "0"), ("1", "0"), ("1", "24"), ("1", "33"), ("1", "42")]
+SETTINGS = [("0", "0"), ("1", "0"), ("1", "24"), ("1", "33"), ("1", "42")] if os.environ.get("ELPH_TIME_TAG", "C") == "C" else [("0", "0"), ("1", "0"), ("1", "22"), ("1", "32")]      # (D: ring depth / waves of k_cg_ap_hc12_px; 0 = the default 2 / 3)
 ROUNDS = int(os.environ.get("ELPH_TIME_ROUNDS", "4"))
 for nrhs in [int(a) for a in sys.argv[1:]] or [288]:
     m = configs.make_model(os.environ.get("ELPH_TIME_TAG", "C"), tol=1e-5)
