@@ -396,6 +396,7 @@ def main():
                 # k_cg_ap 6 vectors + tables; forward transform with the residual update folded in: reads r, z, writes r, nu (4; the half
                 # spectrum nu is one vector of bytes); Chebyshev reads and writes nu (2); inverse reads nu, writes P^-1 r (2)
                 check(lib.elph_bench_prepare(m._h, 3, nrhs, None))
+                run(3, nrhs, 2)                               # (which k_cg_ap form runs is known once one has run)
                 fused = C.c_int()
                 check(lib.elph_bench_px_info(m._h, C.byref(fused)))
                 if fused.value:      # p/x-fused (round 5): k_cg_ap reads the ready p (+ tables), writes z; the inverse transform reads nu, p, x and

@@ -793,6 +793,60 @@ static int get_chunk_graph(elph_handle_s *h, int nrhs, int use_prec, hipGraphExe
 // layout per right-hand side).  Needs the p/x-fused iteration (the unfused one ping-pongs p between two slots whose distance depends on
 // the batch size) and halves that hold whole groups of chains.  ELPH_SPLIT_STREAMS=0 off, =1 wherever legal; default from 192 right-hand sides.
 // ------------------------------------------------------------------------------------------
+__global__ void k_spin_us(long long ticks, long long *sink) {      // wall_clock64: 100 MHz
+    const long long t0 = wall_clock64();
+    long long t = t0;
+    while (t - t0 < ticks) t = wall_clock64();
+    if (sink) *sink = t;
+}
+
+// do kernels on `a` and `b` run at the same time?  (two 40-us spins: together ~40 us, one after the other ~80)
+static int streams_overlap(hipStream_t a, hipStream_t b, bool *yes) {
+    hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    float best = 1e9f;
+    hipError_t er = hipSuccess;
+    for (int rep = 0; rep < 3 && er == hipSuccess; ++rep) {
+        er = hipStreamSynchronize(a);
+        if (er == hipSuccess) er = hipStreamSynchronize(b);
+        if (er == hipSuccess) er = hipEventRecord(e0, a);
+        if (er == hipSuccess) {
+            hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, a, 4000LL, (long long *)nullptr);
+            hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, b, 4000LL, (long long *)nullptr);
+            er = hipEventRecord(eb, b);
+        }
+        if (er == hipSuccess) er = hipStreamWaitEvent(a, eb, 0);
+        if (er == hipSuccess) er = hipEventRecord(e1, a);
+        if (er == hipSuccess) er = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (er == hipSuccess) er = hipEventElapsedTime(&ms, e0, e1);
+        if (er == hipSuccess && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eb);
+    if (er != hipSuccess) { elph_set_error("stream pairing probe: %s", hipGetErrorString(er)); return ELPH_E_HIP; }
+    *yes = best < 0.062f;      // (40 us each: < 62 us = they overlapped)
+    return ELPH_OK;
+}
+
+static int make_overlapping_stream(elph_handle_s *h, hipStream_t *out) {
+    const char *ep = getenv("ELPH_SPLIT_PROBE");      // (0: take the first stream HIP hands out — the A/B)
+    std::vector<hipStream_t> aside;
+    hipStream_t chosen = nullptr;
+    int rc = ELPH_OK;
+    for (int attempt = 0; attempt < 8 && !chosen && rc == ELPH_OK; ++attempt) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { elph_set_error("hipStreamCreate failed"); rc = ELPH_E_HIP; break; }
+        bool ok = true;
+        if (!(ep && ep[0] == '0')) rc = streams_overlap(h->stream, s, &ok);
+        if (rc == ELPH_OK && (ok || attempt == 7)) chosen = s;      // (eight in a row on the main stream's queue: take it, the form still works)
+        else aside.push_back(s);
+    }
+    for (hipStream_t s : aside) (void)hipStreamDestroy(s);
+    if (rc) { if (chosen) (void)hipStreamDestroy(chosen); return rc; }
+    *out = chosen;
+    return ELPH_OK;
+}
+
 struct SplitRun {
     bool on = false, ok = false, px_before = false;
     int ways = 0, n1 = 0;                                 // `ways` parts of n1 right-hand sides each; part 0 is the handle itself on its own stream
@@ -847,8 +901,14 @@ static int split_begin(elph_handle_s *h, int nrhs, SplitRun &S) {
     S.main = h;
     S.view[0] = h;
     S.px_before = h->px_solve;
+    // The parts must run on DIFFERENT hardware queues.  HIP maps its streams onto a few hardware queues per process (four by default,
+    // GPU_MAX_HW_QUEUES) by a rule of its own: in a process that holds several handles a part's stream can share the queue of the handle's main
+    // stream — the parts then run one after the other, slower than one stream (round 6: the second handle of a process, 32 x 32 at 72 right-hand
+    // sides: 437 us instead of 353; a stream priority of its own did not change the mapping).  So the pairing is MEASURED once per stream: a spin
+    // kernel on each of the two streams at the same time — two that overlap finish in the time of one; a candidate that does not is set aside
+    // (kept alive until the choice is made, so that the next candidate does not inherit its queue) and the next one is tried.
     for (int k = 1; k < S.ways; ++k)
-        if (!h->split_stream[k]) HIPCHK(hipStreamCreateWithFlags(&h->split_stream[k], hipStreamNonBlocking));
+        if (!h->split_stream[k]) RC(make_overlapping_stream(h, &h->split_stream[k]));
     if (!h->split_ev) HIPCHK(hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming));
     h->px_solve = true;                                   // (split_legal: the parts run p/x-fused whatever the whole batch would have run)
     h->px_via_pg = h->fast && h->lp_mc != 4;              // (six-colour lane programs: the patch-form pair, kernels.hip: px_plan)
