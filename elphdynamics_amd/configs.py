@@ -48,6 +48,13 @@ CONFIGS = {
     "l36": ("holstein", 1, 36, lat.SQUARE_BONDS, 0.6, 0.1),         # N = 1296: 4 x 6 patches on 9 x 6 lanes (round 6)
     "L36": ("holstein", 1, 36, lat.SQUARE_BONDS, 8.8, 0.1),         # N = 1296, Ltau = 88: long recursions, the fused preconditioned iteration (81 column tiles <= 88 slices)
     "G40": ("holstein", 1, 32, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 1024, Ltau = 40: more column tiles (64) than time slices — the residual update's r.r slots per workgroup (round 6)
+    # square lattices whose patches need several wavefronts per slice (round 6: pgrid_dev.h, pick_patch_mw) — l22 and l26 below are two more
+    "l34": ("holstein", 1, 34, lat.SQUARE_BONDS, 0.6, 0.1),         # N = 1156: 2 x 2 patches on 5 wavefronts
+    "l40": ("holstein", 1, 40, lat.SQUARE_BONDS, 0.6, 0.1),         # N = 1600: 4 x 4 patches on 2 wavefronts
+    "l48": ("holstein", 1, 48, lat.SQUARE_BONDS, 0.6, 0.1),         # N = 2304: 4 x 4 patches on 3
+    "l64": ("holstein", 1, 64, lat.SQUARE_BONDS, 0.4, 0.1),         # N = 4096: 4 x 4 patches on 4
+    "L26": ("holstein", 1, 26, lat.SQUARE_BONDS, 4.8, 0.1),         # N = 676, Ltau = 48: long recursions on 3 wavefronts per slice, the fused iteration
+    "L40": ("holstein", 1, 40, lat.SQUARE_BONDS, 10.0, 0.1),        # N = 1600, Ltau = 100
     "l22": ("holstein", 1, 22, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 484, Ltau = 40: 22 = 2 x 11 has no single-wave patch — the generic LDS kernels (round 6: p/x-fused)
     "l26": ("holstein", 1, 26, lat.SQUARE_BONDS, 4.8, 0.1),         # N = 676, Ltau = 48
     "k40": ("holstein", 1, 20, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 400, Ltau = 40: the lane-program family WITH the patch-form Chebyshev kernel — its p/x-fused iteration (round 6)

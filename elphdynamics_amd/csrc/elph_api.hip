@@ -223,10 +223,16 @@ static void detect_square(elph_handle_s *h) {
     }
     // a larger square lattice: PX x PY patches per lane (pgrid_dev.h) — the Chebyshev recursion of the preconditioner in registers
     h->pg_L = h->pg_PX = h->pg_PY = h->pg_kind = 0;
-    for (int l = 18; l <= 36; l += 2) {
-        int px = 0, py = 0;
-        if ((int64_t)l * l != h->N || !pgrid::pick_patch(l, &px, &py)) continue;
-        if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 1; }
+    h->pg_NW = 0;
+    for (int l = 18; l <= 64; l += 2) {
+        int px = 0, py = 0, nw = 1;
+        if ((int64_t)l * l != h->N) continue;
+        if (!pgrid::pick_patch(l, &px, &py)) {
+            // no patch that fits one wavefront: several wavefronts per slice, the patch edges through LDS (ELPH_PG_MW=0: the generic kernels, A/B)
+            const char *em = getenv("ELPH_PG_MW");
+            if ((em && em[0] == '0') || !pgrid::pick_patch_mw(l, &px, &py, &nw)) continue;
+        }
+        if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 1; h->pg_NW = nw; }
     }
     h->sq_bond.clear();
 }

@@ -239,6 +239,7 @@ struct elph_handle_s {
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
     bool hc_uniform = false;               // ... and its tau-averaged hopping tables are one (cosh, sinh) for every bond (the register-exchange Chebyshev recursion)
+    int pg_NW = 0;                         // wavefronts per time slice of the patch kernels (0 / 1: one; round 6: L = 22, 26, 34, 38 and 40 ... 64 take several)
     int pg_L = 0, pg_PX = 0, pg_PY = 0;    // even-L square lattice beyond 16 x 16 in the reference's colouring (detect_square): PX x PY sites per lane (pgrid_dev.h)
     int pg_kind = 0;                       // 1: that square lattice; 2: a honeycomb lattice beyond 16 x 16 cells, PX x PY CELLS per lane (detect_honeycomb);
                                            // 3: an even-L triangular lattice of any size (detect_triangular)

@@ -18,6 +18,9 @@
 namespace {
 
 using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>; using SQ2A = pgrid::Sq<2, 10>; using SQ46 = pgrid::Sq<4, 6>;
+// several wavefronts per slice (round 6): 2 x 2 patches on 2, 3, 5, 6 wavefronts (L = 22, 26, 34, 38), 4 x 4 patches on 2, 3, 4 (L = 40 ... 64)
+using M22_2 = pgrid::Sq<2, 2, 2>; using M22_3 = pgrid::Sq<2, 2, 3>; using M22_5 = pgrid::Sq<2, 2, 5>; using M22_6 = pgrid::Sq<2, 2, 6>;
+using M44_2 = pgrid::Sq<4, 4, 2>; using M44_3 = pgrid::Sq<4, 4, 3>; using M44_4 = pgrid::Sq<4, 4, 4>;
 using TR22 = pgrid::Tri<2, 2>; using TR24 = pgrid::Tri<2, 4>; using TR26 = pgrid::Tri<2, 6>; using TR44 = pgrid::Tri<4, 4>;
 using HC32 = pgrid::Hc<3, 2>; using HC42 = pgrid::Hc<4, 2>; using HC33 = pgrid::Hc<3, 3>;
 
@@ -25,6 +28,22 @@ __device__ __forceinline__ double pg_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
+}
+// the sum over the NW wavefronts of a slice (threads t0 ... t0 + 64 NW - 1 of the block; `red`: NW doubles of LDS of that group): wave sums, added
+// in wave order — the same value in every thread.  One wavefront: the wave sum.  (Every thread of the group must call it: two barriers.)
+template <int NW>
+__device__ __forceinline__ double pg_group_sum(double v, double *red, int ltid) {
+    v = pg_wave_sum(v);
+    if constexpr (NW == 1) return v;
+    else {
+        __syncthreads();
+        if ((ltid & (WAVE - 1)) == 0) red[ltid >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w];
+        return t;
+    }
 }
 
 // sum_n c_n T_n(A') v  for one real vector in the patch layout: Pacc = sum Re(c_n) u_n, Qacc = sum Im(c_n) u_n with
@@ -79,18 +98,20 @@ __device__ __forceinline__ void series_lean(double (&Pacc)[NS], double (&Qacc)[N
 // every block also clears the slots beyond 2 Lo2 that are its share.  A chain whose expansion is inactive hands over the r.r partials of the
 // residual update instead (kernels of cg_fast_shared.inc: the same contract).
 template <class LAT>
-__global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ nu, KpmDev K, int N, int Ls, int Lo2, const CgState *state,
+__global__ void __launch_bounds__(2 * LAT::NW * WAVE) k_kpm_cheb_pg(double2 *__restrict__ nu, KpmDev K, int N, int Ls, int Lo2, const CgState *state,
                                                           double *__restrict__ rz_part, int nrz, int Ltau, const double *__restrict__ rr_part) {
-    constexpr int NS = LAT::NS;
-    __shared__ double xch[2][NS * WAVE];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    constexpr int NS = LAT::NS, NW = LAT::NW, NT = NW * WAVE;      // NT threads hold the real parts, NT the imaginary parts (wv = 0 / 1)
+    __shared__ double xch[2][NS * NT];
+    __shared__ double xbuf[2][LAT::XB2_DOUBLES];                    // (several wavefronts per slice: the patch edges through LDS, pgrid_dev.h; two buffers per part: a series sweeps in ONE direction, a barrier separates the two series)
+    __shared__ double red[2][NW];
+    const int wv = threadIdx.x / NT, lane = threadIdx.x % NT;
     const int rhs = blockIdx.x;               // x = right-hand side, y = frequency in longest-first order
     if (state && state[2 * rhs].done) return;
     const KpmChainView V = kpm_chain_view(K, rhs, N);
     const int w = V.wsched[blockIdx.y];
     const int order = V.order[w];
     const double2 *c = K.coeff + V.coff[w];
-    auto put_rz = [&](double dot_wave) {      // lane 0 of each wave: this block's two slots, and its share of the slots beyond the schedule
+    auto put_rz = [&](double dot_wave) {      // thread 0 of each part: this block's two slots, and its share of the slots beyond the schedule
         if (!rz_part || lane != 0) return;
         const int bid = 2 * (int)blockIdx.y + wv, nb = 2 * (int)gridDim.y;
         double *slots = rz_part + (size_t)rhs * nrz;
@@ -113,7 +134,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
             const double wgt = ((Ltau & 1) && ww == Lo2 - 1) ? 1.0 : 2.0;
             double2 *uc = nu + ((size_t)rhs * Lo2 + ww) * N;
             double d1 = 0.0;
-            for (int i = threadIdx.x; i < N; i += 2 * WAVE) {
+            for (int i = threadIdx.x; i < N; i += 2 * NT) {
                 const double2 v = uc[i];
                 const double mr = __dadd_rn(__dmul_rn(c0.x, v.x), __dmul_rn(c0.y, v.y)), mi = __dsub_rn(__dmul_rn(c0.x, v.y), __dmul_rn(c0.y, v.x));
                 const double zr = __dsub_rn(__dmul_rn(c0.x, mr), __dmul_rn(c0.y, mi)), zi = __dadd_rn(__dmul_rn(c0.x, mi), __dmul_rn(c0.y, mr));
@@ -122,12 +143,12 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
             }
             dot += wgt * d1;
         }
-        if (rz_part) put_rz(pg_wave_sum(dot));
+        if (rz_part) put_rz(pg_group_sum<NW>(dot, red[wv], lane));      // (rz_part is uniform over the block)
         return;
     }
     double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
     const bool act = lane < LAT::lanes(Ls);
-    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, V.cbar[0], V.sbar[0]);
+    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, V.cbar[0], V.sbar[0], xbuf[wv], 1);
     const double a = V.a * X.ks, b = V.b;
     int site[NS];
     double e1[NS], vin[NS], Pa[NS], Qa[NS];
@@ -140,23 +161,23 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
     // M^-T[w,w]: conjugated coefficients, transposed A   (KPMPreconditioners.jl:621-648)
     series_lean<NS, true>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { LAT::template apply<true>(v, X); });
 #pragma unroll
-    for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
+    for (int q = 0; q < NS; ++q) xch[wv][q * NT + lane] = Qa[q];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-        const double Qo = xch[wv ^ 1][q * WAVE + lane];
+        const double Qo = xch[wv ^ 1][q * NT + lane];
         vin[q] = (wv == 0) ? Pa[q] + Qo : Pa[q] - Qo;          // (vin now holds the middle vector: the input of the second series)
     }
     __syncthreads();
     // M^-1[w,w]   (:650-677)
     series_lean<NS, false>(Pa, Qa, vin, e1, c, order, b, [&X](double (&v)[NS]) { LAT::template apply<false>(v, X); });
 #pragma unroll
-    for (int q = 0; q < NS; ++q) xch[wv][q * WAVE + lane] = Qa[q];
+    for (int q = 0; q < NS; ++q) xch[wv][q * NT + lane] = Qa[q];
     __syncthreads();
     double dot = 0.0;
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-        const double Qo = xch[wv ^ 1][q * WAVE + lane];
+        const double Qo = xch[wv ^ 1][q * NT + lane];
         const double res = (wv == 0) ? Pa[q] - Qo : Pa[q] + Qo;
         if (act) {
             // (the input r_w is read back from memory — it is overwritten only now; keeping it in registers through both series costs NS of them)
@@ -164,7 +185,7 @@ __global__ void __launch_bounds__(2 * WAVE) k_kpm_cheb_pg(double2 *__restrict__ 
             u[2 * site[q] + wv] = res;
         }
     }
-    if (rz_part) put_rz((((Ltau & 1) && w == Lo2 - 1) ? 1.0 : 2.0) * pg_wave_sum(dot));
+    if (rz_part) put_rz((((Ltau & 1) && w == Lo2 - 1) ? 1.0 : 2.0) * pg_group_sum<NW>(dot, red[wv], lane));
 }
 // every wave reduces ALL partials itself: same loads, same tree => the same bits in every wave (kernels.hip: reduce_partials)
 __device__ __forceinline__ double pg_reduce_partials(const double *p, int n, int lane) {
@@ -187,9 +208,11 @@ __device__ __forceinline__ double pg_reduce_partials(const double *p, int n, int
 // previous iteration formed p = P^-1 r + beta p and applied x += alpha p in its epilogue, dft_mfma.hip: PxFuse): this kernel reads p (own slices
 // + two halo slices) and exp(-dtau V), writes z and the p.z partials and keeps the scalar state machine; no P^-1 r, no p_old, no p_new.
 template <class LAT, bool PX>
-__global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int parity, int Ls, int Tmax) {
-    constexpr int NS = LAT::NS;
-    const int N = m.N, L = m.L, lane = threadIdx.x;
+__global__ void __launch_bounds__(LAT::NW * WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int parity, int Ls, int Tmax) {
+    constexpr int NS = LAT::NS, NW = LAT::NW;
+    __shared__ double xbuf[LAT::XB_DOUBLES];
+    __shared__ double red[NW];
+    const int N = m.N, L = m.L, lane = threadIdx.x;      // (several wavefronts per slice: the thread's index in the slice)
     const int nch = (L + Tmax - 1) / Tmax;
     const int rhs = blockIdx.x / nch, ch = blockIdx.x - rhs * nch;
     const int t0 = ch * Tmax, T = (L - t0 < Tmax) ? L - t0 : Tmax;
@@ -207,7 +230,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
     double beta = 0.0, rho = S.rho, kmin = S.kmin, eps = S.eps;
     if (!first) {
         // stop test of iteration `seq` (IterativeSolvers.jl:286-295 / :211-219)
-        const double rr = pg_reduce_partials(B.rr + (size_t)rhs * L, L, lane);
+        const double rr = pg_reduce_partials(B.rr + (size_t)rhs * L, L, lane & (WAVE - 1));
         eps = sqrt(rr) / S.normb;
         const double qq = 2.0 * (double)seq / log(2.0 * S.eps0 / eps);
         const double val = qq * qq;
@@ -225,7 +248,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
             }
             return;
         }
-        const double rho_new = P.use_prec ? pg_reduce_partials(B.rz + (size_t)rhs * B.nrz, B.nrz, lane) : rr;
+        const double rho_new = P.use_prec ? pg_reduce_partials(B.rz + (size_t)rhs * B.nrz, B.nrz, lane & (WAVE - 1)) : rr;
         beta = rho_new / S.rho;            // :222-223 / :303-304
         rho = rho_new;
     }
@@ -235,7 +258,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
     double *z = B.z + (size_t)rhs * ndim;
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
     const bool act = lane < LAT::lanes(Ls);
-    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni);
+    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni, xbuf);
     int site[NS];
     bool dot[NS];
 #pragma unroll
@@ -307,7 +330,7 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
 #pragma unroll
         for (int q = 0; q < NS; ++q) { pprev[q] = pcur[q]; wprev[q] = wcur[q]; }
     }
-    acc = pg_wave_sum(acc);
+    acc = pg_group_sum<NW>(acc, red, lane);
     if (lane == 0) {
         // one partial sum per chunk, in the slot of its first slice; the slots of its other slices are zero (npap = L: the generic family's layout)
         double *pap = B.pap + (size_t)rhs * B.npap;
@@ -325,8 +348,9 @@ __global__ void __launch_bounds__(WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int par
 // chunk of Tmax slices of a vector; the arithmetic of the generic k_mul (kernels.hip) with register sweeps:
 //   (M v)(t)   = v(t) - sg(t) c^k S(E(t) v(t-1))          (M^T v)(t) = v(t) - sg(t+1) c^k E(t+1) S^T(v(t+1))
 template <class LAT, int WHICH>
-__global__ void __launch_bounds__(WAVE) k_mul_pg(double *__restrict__ y, const double *__restrict__ v, ModelDev m, int Ls, int Tmax) {
+__global__ void __launch_bounds__(LAT::NW * WAVE) k_mul_pg(double *__restrict__ y, const double *__restrict__ v, ModelDev m, int Ls, int Tmax) {
     constexpr int NS = LAT::NS;
+    __shared__ double xbuf[LAT::XB_DOUBLES];
     const int N = m.N, L = m.L, lane = threadIdx.x;
     const int nch = (L + Tmax - 1) / Tmax;
     const int vecno = blockIdx.x / nch, ch = blockIdx.x - vecno * nch;
@@ -336,7 +360,7 @@ __global__ void __launch_bounds__(WAVE) k_mul_pg(double *__restrict__ y, const d
     double *yy = y + vec;
     const double *Ech = m.E + (size_t)(vecno % m.nchains) * m.E_chain_stride;
     const bool act = lane < LAT::lanes(Ls);
-    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni);
+    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni, xbuf);
     int site[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) site[q] = LAT::site_of(lane, q, Ls);
@@ -428,10 +452,21 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_p
     KpmDev K = elph_kpm_dev(h);
     const int Lo2 = (int)((h->L + 1) / 2), N = (int)h->N, Ls = h->pg_L;
     if (rz_part && 2 * Lo2 > nrz) { elph_set_error("k_kpm_cheb_pg: %d r.z slots needed, %d available", 2 * Lo2, nrz); return ELPH_E_STATE; }
-    const dim3 grid((unsigned)nrhs, (unsigned)Lo2), block(2 * WAVE);
-#define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, block, 0, h->stream, h->d_nu, K, N, Ls, Lo2, st, rz_part, nrz, (int)h->L, rr_part)
+    const dim3 grid((unsigned)nrhs, (unsigned)Lo2);
+#define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, dim3(2 * LAT::NW * WAVE), 0, h->stream, h->d_nu, K, N, Ls, Lo2, st, rz_part, nrz, (int)h->L, rr_part)
     const int px = h->pg_PX, py = h->pg_PY;
-    if (h->pg_kind == 1 && px == 4 && py == 4) PG_CHEB(SQ44);
+    const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
+    if (h->pg_kind == 1 && nw > 1) {
+        if (px == 2 && py == 2 && nw == 2) PG_CHEB(M22_2);
+        else if (px == 2 && py == 2 && nw == 3) PG_CHEB(M22_3);
+        else if (px == 2 && py == 2 && nw == 5) PG_CHEB(M22_5);
+        else if (px == 2 && py == 2 && nw == 6) PG_CHEB(M22_6);
+        else if (px == 4 && py == 4 && nw == 2) PG_CHEB(M44_2);
+        else if (px == 4 && py == 4 && nw == 3) PG_CHEB(M44_3);
+        else if (px == 4 && py == 4 && nw == 4) PG_CHEB(M44_4);
+        else { elph_set_error("patch kernels: no instantiation for %d x %d patches on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
+    }
+    else if (h->pg_kind == 1 && px == 4 && py == 4) PG_CHEB(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_CHEB(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_CHEB(SQ24);
     else if (h->pg_kind == 1 && px == 2 && py == 10) PG_CHEB(SQ2A);
@@ -463,21 +498,32 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     // waves 98 us, 10 = 1152 waves 140 us; profiles/r04/pgrid_large_lattices.log); beyond one round of 40-slice chunks: 20
     const int L = (int)h->L;
     static const int forceT = []() { const char *e = getenv("ELPH_PG_T"); return e ? atoi(e) : 0; }();
-    const long long slots = 1024LL * ((h->pg_kind != 2 && h->pg_PX * h->pg_PY <= 8) ? 2 : 1);
+    const long long slots = 1024LL * ((h->pg_kind != 2 && h->pg_PX * h->pg_PY <= 8) ? 2 : 1) / (h->pg_NW > 1 ? h->pg_NW : 1);      // (a slice of several wavefronts holds as many slots)
     int T = 20;
     for (int c : {1, 2, 4, 5, 8, 10, 16, 20, 32, 40}) { if ((long long)nrhs * ((L + c - 1) / c) <= slots) { T = c; break; } }
     if (forceT > 0) T = forceT;
     T = std::max(1, std::min(T, L));
     const int nch = (L + T - 1) / T;
-    const dim3 grid((unsigned)(nrhs * nch)), block(WAVE);
+    const dim3 grid((unsigned)(nrhs * nch));
     const int Ls = h->pg_L;
 #define PG_AP(LAT)                                                                                                        \
     do {                                                                                                                  \
-        if (fused) hipLaunchKernelGGL((k_cg_ap_pg<LAT, true>), grid, block, 0, h->stream, B, m, parity, Ls, T);              \
-        else hipLaunchKernelGGL((k_cg_ap_pg<LAT, false>), grid, block, 0, h->stream, B, m, parity, Ls, T);                \
+        if (fused) hipLaunchKernelGGL((k_cg_ap_pg<LAT, true>), grid, dim3(LAT::NW * WAVE), 0, h->stream, B, m, parity, Ls, T);              \
+        else hipLaunchKernelGGL((k_cg_ap_pg<LAT, false>), grid, dim3(LAT::NW * WAVE), 0, h->stream, B, m, parity, Ls, T);                \
     } while (0)
     const int px = h->pg_PX, py = h->pg_PY;
-    if (h->pg_kind == 1 && px == 4 && py == 4) PG_AP(SQ44);
+    const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
+    if (h->pg_kind == 1 && nw > 1) {
+        if (px == 2 && py == 2 && nw == 2) PG_AP(M22_2);
+        else if (px == 2 && py == 2 && nw == 3) PG_AP(M22_3);
+        else if (px == 2 && py == 2 && nw == 5) PG_AP(M22_5);
+        else if (px == 2 && py == 2 && nw == 6) PG_AP(M22_6);
+        else if (px == 4 && py == 4 && nw == 2) PG_AP(M44_2);
+        else if (px == 4 && py == 4 && nw == 3) PG_AP(M44_3);
+        else if (px == 4 && py == 4 && nw == 4) PG_AP(M44_4);
+        else { elph_set_error("patch kernels: no instantiation for %d x %d patches on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
+    }
+    else if (h->pg_kind == 1 && px == 4 && py == 4) PG_AP(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_AP(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_AP(SQ24);
     else if (h->pg_kind == 1 && px == 2 && py == 10) PG_AP(SQ2A);
@@ -503,15 +549,26 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
     int T = 20;
     for (int c : {1, 2, 4, 5, 8, 10, 16, 20}) { if ((long long)nvec * ((L + c - 1) / c) <= 2048) { T = c; break; } }
     T = std::max(1, std::min(T, L));
-    const dim3 grid((unsigned)(nvec * ((L + T - 1) / T))), block(WAVE);
+    const dim3 grid((unsigned)(nvec * ((L + T - 1) / T)));
 #define PG_MUL(LAT)                                                                                                       \
     do {                                                                                                                  \
-        if (which == 0) hipLaunchKernelGGL((k_mul_pg<LAT, 0>), grid, block, 0, h->stream, yS, vS, m, Ls, T);              \
-        else if (which == 1) hipLaunchKernelGGL((k_mul_pg<LAT, 1>), grid, block, 0, h->stream, yS, vS, m, Ls, T);         \
-        else hipLaunchKernelGGL((k_mul_pg<LAT, 2>), grid, block, 0, h->stream, yS, vS, m, Ls, T);                         \
+        if (which == 0) hipLaunchKernelGGL((k_mul_pg<LAT, 0>), grid, dim3(LAT::NW * WAVE), 0, h->stream, yS, vS, m, Ls, T);              \
+        else if (which == 1) hipLaunchKernelGGL((k_mul_pg<LAT, 1>), grid, dim3(LAT::NW * WAVE), 0, h->stream, yS, vS, m, Ls, T);         \
+        else hipLaunchKernelGGL((k_mul_pg<LAT, 2>), grid, dim3(LAT::NW * WAVE), 0, h->stream, yS, vS, m, Ls, T);                         \
     } while (0)
     const int px = h->pg_PX, py = h->pg_PY;
-    if (h->pg_kind == 1 && px == 4 && py == 4) PG_MUL(SQ44);
+    const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
+    if (h->pg_kind == 1 && nw > 1) {
+        if (px == 2 && py == 2 && nw == 2) PG_MUL(M22_2);
+        else if (px == 2 && py == 2 && nw == 3) PG_MUL(M22_3);
+        else if (px == 2 && py == 2 && nw == 5) PG_MUL(M22_5);
+        else if (px == 2 && py == 2 && nw == 6) PG_MUL(M22_6);
+        else if (px == 4 && py == 4 && nw == 2) PG_MUL(M44_2);
+        else if (px == 4 && py == 4 && nw == 3) PG_MUL(M44_3);
+        else if (px == 4 && py == 4 && nw == 4) PG_MUL(M44_4);
+        else { elph_set_error("patch kernels: no instantiation for %d x %d patches on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
+    }
+    else if (h->pg_kind == 1 && px == 4 && py == 4) PG_MUL(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_MUL(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_MUL(SQ24);
     else if (h->pg_kind == 1 && px == 2 && py == 10) PG_MUL(SQ2A);

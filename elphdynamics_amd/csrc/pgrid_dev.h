@@ -24,6 +24,13 @@ struct Ctx {
     double th, ks;           // tanh of the bond angle; the factor taken out of the colours: c^4 (square), c^3 (honeycomb)
     int xu, xd, yu, yd;      // lanes of the patches X + 1, X - 1, Y + 1, Y - 1 (cyclic); idle lanes: themselves
     int du, dd;              // lanes of the patches (X - 1, Y + 1) and (X + 1, Y - 1): the diagonal bonds of the triangular lattice
+    // MULTI-WAVE slices (round 6: square lattices whose patches need more than 64 lanes — L = 22, 26, 34, 38 as 2 x 2 patches on 2 ... 6 wavefronts,
+    // L = 40 ... 64 as 4 x 4 patches on 2 ... 4): the "lanes" above are thread indices of the slice's NT = 64 NW threads, and the patch edges
+    // cross through LDS instead of ds_bpermute — xb: four exchange buffers of 2 PBMAX x NT doubles (x-odd / y-odd colour x forward / reverse sweep:
+    // with a buffer of its own per colour and direction ONE barrier per crossing colour orders everything), nullptr for one wavefront
+    double *xb;
+    int nt, me;              // threads of the slice; this thread's index in it
+    int bmask;               // 3: four buffers; 1: the reverse sweeps share the forward sweeps' two (a kernel whose directions never alternate without a barrier: the Chebyshev series)
 };
 
 template <int PX, int PY>
@@ -38,6 +45,7 @@ template <int PX, int PY>
 __device__ __forceinline__ Ctx ctx(int lane, int L, double c, double s) {
     const int GX = L / PX, GY = L / PY;
     Ctx X;
+    X.xb = nullptr; X.nt = WAVE_; X.me = lane; X.bmask = 3;
     X.th = s / c; X.ks = (c * c) * (c * c);
     if (lane < GX * GY) {
         const int x = lane % GX, y = lane / GX;
@@ -51,7 +59,7 @@ __device__ __forceinline__ Ctx ctx(int lane, int L, double c, double s) {
 }
 
 // one colour of the checkerboard on the PX x PY values of a lane: v <- (I + th P_colour) v
-template <int PX, int PY, int COL>
+template <int PX, int PY, int COL, int BUF = 0>
 __device__ __forceinline__ void colour(double (&v)[PX * PY], const Ctx &X) {
     constexpr bool ALONG_X = (COL < 2), ODD = (COL & 1);
     constexpr int PA = ALONG_X ? PX : PY;        // patch extent along the colour's direction
@@ -63,10 +71,27 @@ __device__ __forceinline__ void colour(double (&v)[PX * PY], const Ctx &X) {
         // column with the last column of the patch below
         const int up = ALONG_X ? X.xu : X.yu, dn = ALONG_X ? X.xd : X.yd;
         double fu[PB], fd[PB];
+        if (X.xb) {
+            // several wavefronts per slice: the edges through LDS (buffer BUF of this colour and sweep direction), one barrier
+            constexpr int PBM = (PX > PY) ? PX : PY;
+            double *xb = X.xb + (size_t)(BUF & X.bmask) * 2 * PBM * X.nt;
 #pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            fu[b] = __shfl(v[0 * SA + b * SB], up, WAVE_);
-            fd[b] = __shfl(v[(PA - 1) * SA + b * SB], dn, WAVE_);
+            for (int b = 0; b < PB; ++b) {
+                xb[(2 * b) * X.nt + X.me] = v[0 * SA + b * SB];
+                xb[(2 * b + 1) * X.nt + X.me] = v[(PA - 1) * SA + b * SB];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                fu[b] = xb[(2 * b) * X.nt + up];
+                fd[b] = xb[(2 * b + 1) * X.nt + dn];
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                fu[b] = __shfl(v[0 * SA + b * SB], up, WAVE_);
+                fd[b] = __shfl(v[(PA - 1) * SA + b * SB], dn, WAVE_);
+            }
         }
         // the inner pairs (1,2), (3,4), ... while the crossings fly
 #pragma unroll
@@ -97,8 +122,8 @@ __device__ __forceinline__ void colour(double (&v)[PX * PY], const Ctx &X) {
 // the whole checkerboard (REVERSE: its transpose — the colours in reverse order; every colour is symmetric), WITHOUT the factor c^4
 template <int PX, int PY, bool REVERSE>
 __device__ __forceinline__ void sweep(double (&v)[PX * PY], const Ctx &X) {
-    if constexpr (!REVERSE) { colour<PX, PY, 0>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 3>(v, X); }
-    else                    { colour<PX, PY, 3>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 1>(v, X); colour<PX, PY, 0>(v, X); }
+    if constexpr (!REVERSE) { colour<PX, PY, 0>(v, X); colour<PX, PY, 1, 0>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 3, 1>(v, X); }
+    else                    { colour<PX, PY, 3, 3>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 1, 2>(v, X); colour<PX, PY, 0>(v, X); }
 }
 
 // ---- honeycomb: L x L two-site cells (site = 2 (x + L y) + orbital) in the reference's colouring [A-B of a cell | B(x,y)-A(x+1,y) |
@@ -202,18 +227,25 @@ __device__ __forceinline__ void tdiag(double (&v)[PX * PY], const Ctx &X) {
 }
 
 // ---- the two lattices behind one interface: NS registers per vector, site(), ctx(), sweep<REVERSE>() -----------------------------------
-template <int PX_, int PY_> struct Sq {
-    static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_;
+// NW: wavefronts per time slice (1: the whole slice in one wavefront, edges by ds_bpermute; > 1: NT = 64 NW threads, edges through LDS)
+template <int PX_, int PY_, int NW_ = 1> struct Sq {
+    static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_, NW = NW_;
+    static constexpr int XB_DOUBLES = (NW_ > 1) ? 4 * 2 * ((PX_ > PY_) ? PX_ : PY_) * NW_ * WAVE_ : 1;      // the four exchange buffers of one slice
     __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
     __host__ __device__ static int site_of(int lane, int q, int L) { return site<PX, PY>(lane, q, L); }
-    __device__ static Ctx make_ctx(int lane, int L, double c, double s) { return ctx<PX, PY>(lane, L, c, s); }
+    static constexpr int XB2_DOUBLES = (NW_ > 1) ? 2 * 2 * ((PX_ > PY_) ? PX_ : PY_) * NW_ * WAVE_ : 1;     // ... two of them (bmask = 1)
+    __device__ static Ctx make_ctx(int lane, int L, double c, double s, double *xb = nullptr, int bmask = 3) {
+        Ctx X = ctx<PX, PY>(lane, L, c, s);
+        if (NW > 1) { X.xb = xb; X.nt = NW * WAVE_; X.bmask = bmask; }
+        return X;
+    }
     template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) { sweep<PX, PY, REVERSE>(v, X); }
 };
 template <int PX_, int PY_> struct Hc {
-    static constexpr int PX = PX_, PY = PY_, NS = 2 * PX_ * PY_;
+    static constexpr int PX = PX_, PY = PY_, NS = 2 * PX_ * PY_, NW = 1, XB_DOUBLES = 1, XB2_DOUBLES = 1;
     __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
     __host__ __device__ static int site_of(int lane, int q, int L) { return hsite<PX, PY>(lane, q, L); }
-    __device__ static Ctx make_ctx(int lane, int L, double c, double s) {
+    __device__ static Ctx make_ctx(int lane, int L, double c, double s, double * = nullptr, int = 3) {
         Ctx X = ctx<PX, PY>(lane, L, c, s);
         X.ks = c * c * c;                      // three colours
         return X;
@@ -226,10 +258,10 @@ template <int PX_, int PY_> struct Hc {
 
 inline bool pick_patch(int L, int *PX, int *PY);
 template <int PX_, int PY_> struct Tri {
-    static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_;
+    static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_, NW = 1, XB_DOUBLES = 1, XB2_DOUBLES = 1;
     __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
     __host__ __device__ static int site_of(int lane, int q, int L) { return site<PX, PY>(lane, q, L); }
-    __device__ static Ctx make_ctx(int lane, int L, double c, double s) {
+    __device__ static Ctx make_ctx(int lane, int L, double c, double s, double * = nullptr, int = 3) {
         Ctx X = ctx<PX, PY>(lane, L, c, s);
         X.ks = (c * c * c) * (c * c * c);      // six colours
         return X;
@@ -258,6 +290,21 @@ inline bool pick_hpatch(int L, int *PX, int *PY) {
         case 21: case 24: *PX = 3; *PY = 3; return true;      // 7 x 7 / 8 x 8 lanes, 18
         default: return false;
     }
+}
+
+// The multi-wave patch for an even-L square lattice that has no single-wave one (round 6): 2 x 2 patches on 2, 3, 5 or 6 wavefronts (L = 22, 26, 34,
+// 38), 4 x 4 patches on 2, 3 or 4 (L = 40, 44, 48, 52, 56, 60, 64) — the shapes pgrid.hip instantiates.  *NW = wavefronts per slice.
+inline bool pick_patch_mw(int L, int *PX, int *PY, int *NW) {
+    if (L < 18 || (L & 1)) return false;
+    if (L % 4 == 0 && L >= 40 && L <= 64) {
+        const int lanes = (L / 4) * (L / 4), nw = (lanes + 63) / 64;
+        if (nw >= 2 && nw <= 4) { *PX = 4; *PY = 4; *NW = nw; return true; }
+    }
+    if (L == 22 || L == 26 || L == 34 || L == 38) {
+        const int lanes = (L / 2) * (L / 2), nw = (lanes + 63) / 64;      // 121, 169, 289, 361 -> 2, 3, 5, 6
+        *PX = 2; *PY = 2; *NW = nw; return true;
+    }
+    return false;
 }
 
 // The patch shape for an L x L lattice (0: none — the lattice keeps the generic kernels).
