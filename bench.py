@@ -231,6 +231,9 @@ def main():
     check(lib.elph_synchronize(m._h))
     elapsed, matvecs = edist.timed_steps(comm, run_steps, K)
     ms_events = ev["ms"]
+    fz_timed = C.c_int(0)                    # which form of the preconditioned iteration the timed region ran (0 unfused, 1 / 2 p/x-fused: lane program / registers)
+    if args.precond:
+        check(lib.elph_bench_px_info(m._h, C.byref(fz_timed)))
 
     out = None
     if rank == 0:
@@ -327,8 +330,7 @@ def main():
             # inverse transform with the p/x-update; two half-batches on two streams from 192 right-hand sides): priced on the compulsory
             # bytes of all its kernels as built against the HBM peak, and against the streaming rate a read-read-write mix reaches on this
             # part once it is larger than the Infinity Cache (tools/probes/access_pattern_probe.cpp, profiles/r06/)
-            fz = C.c_int()
-            check(lib.elph_bench_px_info(m._h, C.byref(fz)))
+            fz = fz_timed                    # (asked right after the timed region: the legs in between have re-planned the handle)
             it_bytes = ((2.0 * vec + tab) + 4.0 * vec + 2.0 * vec + 5.0 * vec) if fz.value else (built_ap + 4.0 * vec + 2.0 * vec + 2.0 * vec)
             us_it = 1e3 * ms_events / K
             achp = it_bytes / (us_it * 1e-6) / 1e9
