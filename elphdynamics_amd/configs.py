@@ -55,6 +55,9 @@ CONFIGS = {
     "l64": ("holstein", 1, 64, lat.SQUARE_BONDS, 0.4, 0.1),         # N = 4096: 4 x 4 patches on 4
     "L26": ("holstein", 1, 26, lat.SQUARE_BONDS, 4.8, 0.1),         # N = 676, Ltau = 48: long recursions on 3 wavefronts per slice, the fused iteration
     "L40": ("holstein", 1, 40, lat.SQUARE_BONDS, 10.0, 0.1),        # N = 1600, Ltau = 100
+    "h30": ("holstein", 2, 30, lat.HONEYCOMB_BONDS, 0.6, 0.1),      # honeycomb 30 x 30 cells (N = 1800): 3 x 3 cells per thread on 2 wavefronts (round 6)
+    "h22": ("holstein", 2, 22, lat.HONEYCOMB_BONDS, 0.6, 0.1),      # honeycomb 22 x 22 cells (N = 968): 2 x 2 cells on 2 wavefronts
+    "H27": ("holstein", 2, 27, lat.HONEYCOMB_BONDS, 9.6, 0.1),      # honeycomb 27 x 27 cells (N = 1458), Ltau = 96: long recursions, the fused iteration (92 column tiles <= 96)
     "l22": ("holstein", 1, 22, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 484, Ltau = 40: 22 = 2 x 11 has no single-wave patch — the generic LDS kernels (round 6: p/x-fused)
     "l26": ("holstein", 1, 26, lat.SQUARE_BONDS, 4.8, 0.1),         # N = 676, Ltau = 48
     "k40": ("holstein", 1, 20, lat.SQUARE_BONDS, 4.0, 0.1),         # N = 400, Ltau = 40: the lane-program family WITH the patch-form Chebyshev kernel — its p/x-fused iteration (round 6)

@@ -276,8 +276,10 @@ static void detect_honeycomb12(elph_handle_s *h) {
         h->hc_LX = c.first; h->hc_LY = c.second;
         if (c.first == c.second) {
             h->hc_L = c.first; h->hc12 = (c.first == 12);
-            int px = 0, py = 0;
-            if (c.first > 16 && pgrid::pick_hpatch(c.first, &px, &py)) { h->pg_L = c.first; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 2; }     // (pgrid.hip: PX x PY cells per lane)
+            int px = 0, py = 0, nw = 1;
+            const char *em = getenv("ELPH_PG_MW");
+            if (c.first > 16 && pgrid::pick_hpatch(c.first, &px, &py)) { h->pg_L = c.first; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 2; h->pg_NW = 1; }     // (pgrid.hip: PX x PY cells per lane)
+            else if (c.first > 16 && !(em && em[0] == '0') && pgrid::pick_hpatch_mw(c.first, &px, &py, &nw)) { h->pg_L = c.first; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 2; h->pg_NW = nw; }     // (several wavefronts per slice)
         }
         return;
     }

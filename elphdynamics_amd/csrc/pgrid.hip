@@ -21,6 +21,8 @@ using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::
 // several wavefronts per slice (round 6): 2 x 2 patches on 2, 3, 5, 6 wavefronts (L = 22, 26, 34, 38), 4 x 4 patches on 2, 3, 4 (L = 40 ... 64)
 using M22_2 = pgrid::Sq<2, 2, 2>; using M22_3 = pgrid::Sq<2, 2, 3>; using M22_5 = pgrid::Sq<2, 2, 5>; using M22_6 = pgrid::Sq<2, 2, 6>;
 using M44_2 = pgrid::Sq<4, 4, 2>; using M44_3 = pgrid::Sq<4, 4, 3>; using M44_4 = pgrid::Sq<4, 4, 4>;
+using H33_2 = pgrid::Hc<3, 3, 2>; using H33_3 = pgrid::Hc<3, 3, 3>; using H33_4 = pgrid::Hc<3, 3, 4>;      // honeycomb: 3 x 3 / 2 x 2 cells per thread
+using H22_2 = pgrid::Hc<2, 2, 2>; using H22_3 = pgrid::Hc<2, 2, 3>; using H22_4 = pgrid::Hc<2, 2, 4>;
 using TR22 = pgrid::Tri<2, 2>; using TR24 = pgrid::Tri<2, 4>; using TR26 = pgrid::Tri<2, 6>; using TR44 = pgrid::Tri<4, 4>;
 using HC32 = pgrid::Hc<3, 2>; using HC42 = pgrid::Hc<4, 2>; using HC33 = pgrid::Hc<3, 3>;
 
@@ -466,6 +468,15 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_p
         else if (px == 4 && py == 4 && nw == 4) PG_CHEB(M44_4);
         else { elph_set_error("patch kernels: no instantiation for %d x %d patches on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
     }
+    else if (h->pg_kind == 2 && nw > 1) {
+        if (px == 3 && nw == 2) PG_CHEB(H33_2);
+        else if (px == 3 && nw == 3) PG_CHEB(H33_3);
+        else if (px == 3 && nw == 4) PG_CHEB(H33_4);
+        else if (px == 2 && nw == 2) PG_CHEB(H22_2);
+        else if (px == 2 && nw == 3) PG_CHEB(H22_3);
+        else if (px == 2 && nw == 4) PG_CHEB(H22_4);
+        else { elph_set_error("patch kernels: no honeycomb instantiation for %d x %d cells on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
+    }
     else if (h->pg_kind == 1 && px == 4 && py == 4) PG_CHEB(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_CHEB(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_CHEB(SQ24);
@@ -523,6 +534,15 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
         else if (px == 4 && py == 4 && nw == 4) PG_AP(M44_4);
         else { elph_set_error("patch kernels: no instantiation for %d x %d patches on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
     }
+    else if (h->pg_kind == 2 && nw > 1) {
+        if (px == 3 && nw == 2) PG_AP(H33_2);
+        else if (px == 3 && nw == 3) PG_AP(H33_3);
+        else if (px == 3 && nw == 4) PG_AP(H33_4);
+        else if (px == 2 && nw == 2) PG_AP(H22_2);
+        else if (px == 2 && nw == 3) PG_AP(H22_3);
+        else if (px == 2 && nw == 4) PG_AP(H22_4);
+        else { elph_set_error("patch kernels: no honeycomb instantiation for %d x %d cells on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
+    }
     else if (h->pg_kind == 1 && px == 4 && py == 4) PG_AP(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_AP(SQ26);
     else if (h->pg_kind == 1 && px == 2 && py == 4) PG_AP(SQ24);
@@ -567,6 +587,15 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
         else if (px == 4 && py == 4 && nw == 3) PG_MUL(M44_3);
         else if (px == 4 && py == 4 && nw == 4) PG_MUL(M44_4);
         else { elph_set_error("patch kernels: no instantiation for %d x %d patches on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
+    }
+    else if (h->pg_kind == 2 && nw > 1) {
+        if (px == 3 && nw == 2) PG_MUL(H33_2);
+        else if (px == 3 && nw == 3) PG_MUL(H33_3);
+        else if (px == 3 && nw == 4) PG_MUL(H33_4);
+        else if (px == 2 && nw == 2) PG_MUL(H22_2);
+        else if (px == 2 && nw == 3) PG_MUL(H22_3);
+        else if (px == 2 && nw == 4) PG_MUL(H22_4);
+        else { elph_set_error("patch kernels: no honeycomb instantiation for %d x %d cells on %d wavefronts", px, py, nw); return ELPH_E_UNSUPPORTED; }
     }
     else if (h->pg_kind == 1 && px == 4 && py == 4) PG_MUL(SQ44);
     else if (h->pg_kind == 1 && px == 2 && py == 6) PG_MUL(SQ26);

@@ -137,7 +137,7 @@ __host__ __device__ __forceinline__ int hsite(int lane, int q, int L) {
     const int c = q >> 1, cx = c % PX, cy = c / PX;
     return 2 * ((PX * X + cx) + L * (PY * Y + cy)) + (q & 1);
 }
-template <int PX, int PY, int COL>
+template <int PX, int PY, int COL, int BUF = 0>
 __device__ __forceinline__ void hcolour(double (&v)[2 * PX * PY], const Ctx &X) {
     if constexpr (COL == 0) {
 #pragma unroll
@@ -151,10 +151,26 @@ __device__ __forceinline__ void hcolour(double (&v)[2 * PX * PY], const Ctx &X) 
         constexpr int SA = ALONG_X ? 1 : PX, SB = ALONG_X ? PX : 1;          // cell strides along / across
         const int up = ALONG_X ? X.xu : X.yu, dn = ALONG_X ? X.xd : X.yd;
         double fu[PB], fd[PB];
+        if (X.xb) {      // several wavefronts per slice: the edges through LDS (the square lattice's scheme, `colour` above)
+            constexpr int PBM = (PX > PY) ? PX : PY;
+            double *xb = X.xb + (size_t)(BUF & X.bmask) * 2 * PBM * X.nt;
 #pragma unroll
-        for (int b = 0; b < PB; ++b) {
-            fu[b] = __shfl(v[2 * (0 * SA + b * SB)], up, WAVE_);                    // the A site of the first cell of the patch above
-            fd[b] = __shfl(v[2 * ((PA - 1) * SA + b * SB) + 1], dn, WAVE_);         // the B site of the last cell of the patch below
+            for (int b = 0; b < PB; ++b) {
+                xb[(2 * b) * X.nt + X.me] = v[2 * (0 * SA + b * SB)];
+                xb[(2 * b + 1) * X.nt + X.me] = v[2 * ((PA - 1) * SA + b * SB) + 1];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                fu[b] = xb[(2 * b) * X.nt + up];
+                fd[b] = xb[(2 * b + 1) * X.nt + dn];
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                fu[b] = __shfl(v[2 * (0 * SA + b * SB)], up, WAVE_);                    // the A site of the first cell of the patch above
+                fd[b] = __shfl(v[2 * ((PA - 1) * SA + b * SB) + 1], dn, WAVE_);         // the B site of the last cell of the patch below
+            }
         }
 #pragma unroll
         for (int b = 0; b < PB; ++b)
@@ -241,18 +257,20 @@ template <int PX_, int PY_, int NW_ = 1> struct Sq {
     }
     template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) { sweep<PX, PY, REVERSE>(v, X); }
 };
-template <int PX_, int PY_> struct Hc {
-    static constexpr int PX = PX_, PY = PY_, NS = 2 * PX_ * PY_, NW = 1, XB_DOUBLES = 1, XB2_DOUBLES = 1;
+template <int PX_, int PY_, int NW_ = 1> struct Hc {
+    static constexpr int PX = PX_, PY = PY_, NS = 2 * PX_ * PY_, NW = NW_;
+    static constexpr int XB_DOUBLES = (NW_ > 1) ? 4 * 2 * ((PX_ > PY_) ? PX_ : PY_) * NW_ * WAVE_ : 1, XB2_DOUBLES = (NW_ > 1) ? XB_DOUBLES / 2 : 1;
     __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
     __host__ __device__ static int site_of(int lane, int q, int L) { return hsite<PX, PY>(lane, q, L); }
-    __device__ static Ctx make_ctx(int lane, int L, double c, double s, double * = nullptr, int = 3) {
+    __device__ static Ctx make_ctx(int lane, int L, double c, double s, double *xb = nullptr, int bmask = 3) {
         Ctx X = ctx<PX, PY>(lane, L, c, s);
         X.ks = c * c * c;                      // three colours
+        if (NW > 1) { X.xb = xb; X.nt = NW * WAVE_; X.bmask = bmask; }
         return X;
     }
     template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) {
-        if constexpr (!REVERSE) { hcolour<PX, PY, 0>(v, X); hcolour<PX, PY, 1>(v, X); hcolour<PX, PY, 2>(v, X); }
-        else                    { hcolour<PX, PY, 2>(v, X); hcolour<PX, PY, 1>(v, X); hcolour<PX, PY, 0>(v, X); }
+        if constexpr (!REVERSE) { hcolour<PX, PY, 0>(v, X); hcolour<PX, PY, 1, 0>(v, X); hcolour<PX, PY, 2, 1>(v, X); }
+        else                    { hcolour<PX, PY, 2, 3>(v, X); hcolour<PX, PY, 1, 2>(v, X); hcolour<PX, PY, 0>(v, X); }
     }
 };
 
@@ -280,6 +298,18 @@ inline bool pick_tpatch(int L, int *PX, int *PY) {
     if (L <= 16) { *PX = 2; *PY = 2; return true; }
     // (only the shapes pgrid.hip instantiates for the triangular sweep: 2 x 4, 2 x 6, 4 x 4 — a triangular 30 x 30 or 36 x 36 keeps the generic kernels)
     return pick_patch(L, PX, PY) && ((*PX == 2 && (*PY == 4 || *PY == 6)) || (*PX == 4 && *PY == 4));
+}
+
+// The multi-wave cell patch for an L x L honeycomb lattice that has no single-wave one (round 6): 3 x 3 cells per thread on 2, 3 or 4 wavefronts
+// (L = 27, 30, 33, 36, 39, 42, 45, 48), else 2 x 2 cells on 2, 3 or 4 (L = 22, 26, 28, 32) — the shapes pgrid.hip instantiates.
+inline bool pick_hpatch_mw(int L, int *PX, int *PY, int *NW) {
+    if (L <= 16) return false;
+    for (int P : {3, 2}) {
+        if (L % P) continue;
+        const int lanes = (L / P) * (L / P), nw = (lanes + 63) / 64;
+        if (nw >= 2 && nw <= 4) { *PX = P; *PY = P; *NW = nw; return true; }
+    }
+    return false;
 }
 
 // The cell patch for an L x L honeycomb lattice beyond 16 x 16 cells (false: none).

@@ -271,7 +271,7 @@ def _oracle_model(orc, m):
                           np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
 
 
-@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "l30", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64"])      # l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
+@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "l30", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_matvec_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models, synth
     m = configs.make_model(tag)
@@ -304,7 +304,7 @@ def test_matvec_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "l30", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64"])      # l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
+@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "l30", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_cg_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models
     m = configs.make_model(tag, tol=1e-5)
@@ -376,7 +376,7 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64"])      # l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
+@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_kpm_vs_oracle(oracle, tag):
     """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle.  e / E: bond phonons — the
     expansion is built on the tau-means of the per-(tau, bond) hopping tables (update_A!, KPMPreconditioners.jl:355-381)."""
@@ -1421,7 +1421,7 @@ def test_register_exchange_k_cg_ap_honeycomb12(nchains, per, chunk_T, monkeypatc
 
 
 @pytest.mark.parametrize("tag,nchains,per", [("K", 8, 2), ("K", 1, 24), ("X32", 4, 2), ("k40", 32, 2), ("k", 12, 2), ("j", 8, 2),
-                                             ("X24", 4, 2), ("XT24", 8, 2), ("L36", 4, 2), ("T", 32, 2), ("G40", 4, 2), ("L26", 8, 2), ("L40", 4, 2)])      # honeycomb 24 x 24 cells, triangular 24 x 24: the same pipeline around their patch sweeps
+                                             ("X24", 4, 2), ("XT24", 8, 2), ("L36", 4, 2), ("T", 32, 2), ("G40", 4, 2), ("L26", 8, 2), ("L40", 4, 2), ("H27", 4, 2)])      # honeycomb 24 x 24 cells, triangular 24 x 24: the same pipeline around their patch sweeps
 def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, monkeypatch):
     """Round 6: the p/x-fused preconditioned batch iteration on the patch-form lattices of the generic family (square L = 18 … 32: `k_cg_ap_pg<PX>`
     reads the ready p, the residual update rides on the forward transform, r.z comes from `k_kpm_cheb_pg` in frequency space, the p/x-update is
@@ -1447,7 +1447,7 @@ def test_px_fused_iteration_on_patch_form_lattices(oracle, tag, nchains, per, mo
         out[mode] = (Xs, it, _px_fused(m))
     assert out["0"][2] is False
     # the fused form needs the MFMA transforms with the residual update (N / 16 column tiles <= Ltau, enough waves): K (24 x 24, Ltau = 40), X32 and k40 (20 x 20, Ltau = 40: lane-program family, patch-form Chebyshev) have it
-    if tag in ("K", "X32", "k40", "X24", "XT24", "L36", "T", "G40", "L26", "L40"):      # (T: triangular 16 x 16 — a six-colour lane program riding on the patch-form pair)
+    if tag in ("K", "X32", "k40", "X24", "XT24", "L36", "T", "G40", "L26", "L40", "H27"):      # (T: triangular 16 x 16 — a six-colour lane program riding on the patch-form pair)
         assert out["1"][2] is True, "the p/x-fused form was not taken on a lattice that admits it"
     assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
     assert rel(out["1"][0], out["0"][0]) < 1e-9
