@@ -109,6 +109,8 @@ SIGNATURES = {
     "elph_shard_set_collectives": (c_int, [Handle, C.c_void_p, C.c_void_p, C.c_void_p]),
     "elph_shard_hmc_set_columns": (c_int, [Handle, P_i64, c_i64, P_dbl]),
     "elph_shard_set_full_lattice": (c_int, [Handle, Handle]),
+    "elph_shard_set_bonds": (c_int, [Handle, P_i64, c_i64, P_dbl]),
+    "elph_shard_ghost_stats": (c_int, [Handle, P_i64, P_i64]),
     "elph_shard_ldiv": (c_int, [Handle, Handle, P_dbl, P_dbl, c_int, c_i64, P_i64, P_dbl, P_int]),
     "elph_shard_fermion_force_holstein": (c_int, [Handle, Handle, P_dbl, P_dbl, P_dbl, P_dbl, c_dbl, P_dbl, P_dbl, c_int, c_dbl, P_dbl, P_dbl,
                                                   P_dbl, P_i64, P_int]),

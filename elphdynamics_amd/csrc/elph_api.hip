@@ -1729,7 +1729,11 @@ static int kpm_setup_core(elph_handle_s *h, const double *b_max, const double *b
         }
         h->h_cbar.resize((size_t)nch * h->nb);
         h->h_sbar.resize((size_t)nch * h->nb);
-        if (h->nb > 0) {   // tau-means of cosht, sinht from the device tables (they may have been produced there)
+        if (h->nb > 0 && h->csbar_external) {      // (the caller's: the full-lattice handle of a sharded update — elph_i_kpm_setup_csbar filled h_cbar / h_sbar)
+            HIPCHK(hipMemcpyAsync(h->d_cbar, h->h_cbar.data(), sizeof(double) * (size_t)nch * h->nb, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_sbar, h->h_sbar.data(), sizeof(double) * (size_t)nch * h->nb, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        } else if (h->nb > 0) {   // tau-means of cosht, sinht from the device tables (they may have been produced there)
             RC(elph_launch_cs_bar(h, h->d_cbar, h->d_sbar, nch));
             HIPCHK(hipMemcpyAsync(h->h_cbar.data(), h->d_cbar, sizeof(double) * (size_t)nch * h->nb, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipMemcpyAsync(h->h_sbar.data(), h->d_sbar, sizeof(double) * (size_t)nch * h->nb, hipMemcpyDeviceToHost, h->stream));
@@ -1891,6 +1895,23 @@ int elph_i_kpm_setup_ebar(elph_handle_s *h, const double *Ebar_host, const doubl
     const int rc = kpm_setup_core(h, b_max, b_min, nullptr, nullptr, nullptr, nullptr, nullptr);
     h->ebar_external = false;
     h->have_E = had_E;
+    return rc;
+}
+
+// setup!(P) of a bond-phonon handle whose τ-averaged hopping tables come from OUTSIDE (update_A!, KPMPreconditioners.jl:355-381): the
+// full-lattice handle of a sharded HMC update — the hoppings move on the ranks' slabs, every rank contributes the τ-means of the bonds it
+// owns and the sum is injected here (hmc.hip).  exp(Δτμ) is the handle's own (elph_update_model_ssh once; μ does not move).  One chain.
+int elph_i_kpm_setup_csbar(elph_handle_s *h, const double *cbar_host, const double *sbar_host, const double *b_max, const double *b_min) {
+    if (h->kind != ELPH_MODEL_SSH || !h->kpm_created || !h->have_E) {
+        elph_set_error("c̄ / s̄ injection: a bond-phonon handle with elph_kpm_create and one elph_update_model_ssh done");
+        return ELPH_E_STATE;
+    }
+    if (h->nchains != 1) { h->nchains = 1; drop_graphs(h); h->kpm_ready = false; }
+    h->h_cbar.assign(cbar_host, cbar_host + h->nb);
+    h->h_sbar.assign(sbar_host, sbar_host + h->nb);
+    h->csbar_external = true;
+    const int rc = kpm_setup_core(h, b_max, b_min, nullptr, nullptr, nullptr, nullptr, nullptr);
+    h->csbar_external = false;
     return rc;
 }
 

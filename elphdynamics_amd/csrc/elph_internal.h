@@ -210,6 +210,7 @@ struct elph_handle_s {
     hipStream_t split_stream[8] = {};      // streams 1 … ways-1 + event of the split form of a preconditioned batch (elph_api.hip: SplitRun; [0] unused: the handle's own stream)
     hipEvent_t split_ev = nullptr;
     int T_rhs_hint = 0;                    // > 0: right-hand sides in flight when the slices per wave are chosen (two-stream batches: both halves)
+    bool csbar_external = false;           // kpm_setup_core: h_cbar / h_sbar were filled by the caller (elph_i_kpm_setup_csbar)
     bool ebar_external = false;            // kpm_setup_core: d_Ebar was filled by the caller (elph_i_kpm_setup_ebar)
     bool px_solve = false;                 // the current solve's preconditioned iteration is p/x-fused (kernels.hip: px_plan)
     bool px_via_pg = false;                // this solve's p/x-fused iteration takes the patch-form k_cg_ap_pg although the handle is of the lane-program family (six-colour lane programs: triangular lattices up to 16 x 16)
@@ -371,6 +372,9 @@ int elph_i_shard_ldiv_dev(elph_handle_s *h, elph_handle_s *hfull, int use_prec, 
 int elph_i_kpm_setup_ebar(elph_handle_s *h, const double *Ebar_host, const double *b_max, const double *b_min);      // elph_api.hip
 elph_handle_s *elph_i_shard_full(const elph_handle_s *h);                  // the full-lattice handle registered with elph_shard_set_full_lattice (or nullptr)
 int elph_i_shard_global_ebar(elph_handle_s *h, std::vector<double> &Ebar_global);      // Ē of the whole lattice from every rank's own rows
+bool elph_i_shard_has_bonds(const elph_handle_s *h);                                    // elph_shard_set_bonds has been called for this slab's bonds
+int elph_i_shard_global_csbar(elph_handle_s *h, std::vector<double> &cs, int64_t *n_bonds);   // [c̄ | s̄] of every bond of the lattice from the owners' tables
+int elph_i_kpm_setup_csbar(elph_handle_s *h, const double *cbar_host, const double *sbar_host, const double *b_max, const double *b_min);      // elph_api.hip
 int elph_i_shard_solve_pair(elph_handle_s *h, elph_handle_s *hfull, int use_prec, double tol_power, int64_t *iters, int *flag);
 void elph_greens_free(elph_handle_s *h);
 int elph_launch_r2s(elph_handle_s *h, double *dstS, const double *srcR, int nvec, int ncols = 0);

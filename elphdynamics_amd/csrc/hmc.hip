@@ -319,10 +319,21 @@ int calc_OinvLphi(elph_handle_s *h, HmcState *st, int use_precond, double power,
         const size_t NG = (size_t)hf->N;
         const double *bmax = kpm_randn + (size_t)(2 * *kpm_calls) * NG, *bmin = bmax + NG;
         ++*kpm_calls;
-        std::vector<double> Eg;
-        RC(elph_i_shard_global_ebar(h, Eg));
-        RC(elph_i_kpm_setup_ebar(hf, Eg.data(), bmax, bmin));
-        RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
+        if (st->ssh) {
+            // bond phonons: the τ-means of cosh / sinh of every bond of the lattice, from the owners' slabs (update_A!, KPMPreconditioners.jl:355-381);
+            // Λ ≡ 1 (HMC.jl:943-946,970-973): the right-hand sides are ϕ± themselves
+            std::vector<double> cs;
+            int64_t nbg = 0;
+            RC(elph_i_shard_global_csbar(h, cs, &nbg));
+            if (nbg != hf->nb) { elph_set_error("the full-lattice handle has %lld bonds, elph_shard_set_bonds named %lld", (long long)hf->nb, (long long)nbg); return ELPH_E_ARG; }
+            RC(elph_i_kpm_setup_csbar(hf, cs.data(), cs.data() + nbg, bmax, bmin));
+            HIPCHK(hipMemcpyAsync(h->d_b, st->phi, 2 * (size_t)nch * nd * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        } else {
+            std::vector<double> Eg;
+            RC(elph_i_shard_global_ebar(h, Eg));
+            RC(elph_i_kpm_setup_ebar(hf, Eg.data(), bmax, bmin));
+            RC(elph_launch_lambda_rhs(h, h->d_b, st->phi, st->x, st->dtau, nch));
+        }
         HIPCHK(hipMemsetAsync(h->d_x, 0, 2 * (size_t)nch * nd * sizeof(double), h->stream));
         h->x_zero = false;
         return elph_i_shard_solve_pair(h, hf, 1, power, iters, flag);
@@ -768,11 +779,11 @@ extern "C" int elph_hmc_update_chains(elph_handle h, double dt, int64_t nt, int 
     if (sharded(h)) {
         // one lattice over several ranks: the trajectory runs on the slab (own + ghost rows); the random vectors must be the slab's part
         // of the GLOBAL vectors (ghost entries included) and the uniform of the Metropolis test the same number on every rank
-        const bool prec_ok = !use_precond || (!st->ssh && elph_i_shard_full(h) && elph_i_shard_full(h)->kpm_created && kpm_randn);
+        const bool prec_ok = !use_precond || (elph_i_shard_full(h) && elph_i_shard_full(h)->kpm_created && kpm_randn && (!st->ssh || elph_i_shard_has_bonds(h)));
         if ((st->ssh && (!st->wown || st->shared)) || nch != 1 || !prec_ok || st->rng_on || !R || !Rp || !Rm || !u_accept) {
             elph_set_error("HMC on a sharded lattice: one chain, with R, Rp, Rm and u_accept given (the slab's part of the global vectors); bond "
-                           "phonons after elph_shard_hmc_set_columns, without shared fields, un-preconditioned; a preconditioner (Holstein) needs "
-                           "elph_shard_set_full_lattice with elph_kpm_create done and kpm_randn = start vectors of the WHOLE lattice");
+                           "phonons after elph_shard_hmc_set_columns, without shared fields; a preconditioner needs elph_shard_set_full_lattice with "
+                           "elph_kpm_create done, kpm_randn = start vectors of the WHOLE lattice and — bond phonons — elph_shard_set_bonds");
             return ELPH_E_UNSUPPORTED;
         }
     }

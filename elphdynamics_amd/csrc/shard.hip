@@ -43,6 +43,15 @@ struct ShardState {
     elph_shard_allreduce_fn allreduce = nullptr;
     void *coll_ctx = nullptr;
     std::vector<int> gsites_host;             // [N_loc] global site of every slab site (host copy of d_gsites)
+    size_t xch_words = 0;                     // words of the spectrum area = the exchange area of the ghost-row pushes between solves
+    int *d_xcol = nullptr;                    // ghost exchange of vectors whose columns are not sites: global column, owner weight (device copies)
+    double *d_xown = nullptr;
+    size_t xcol_cap = 0;
+    std::vector<int> gbond;                   // bond phonons: global bond (checkerboard position on the whole lattice) of every slab bond, owner weight
+    std::vector<double> bown;
+    int64_t n_gbonds = 0;
+    double *d_csbar = nullptr;                // [2][slab bonds]: tau-means of the slab's hopping tables
+    uint64_t ghost_dev = 0, ghost_host = 0;   // ghost exchanges that went through the mailboxes / were staged through the host collectives
     elph_handle_s *full = nullptr;            // the full-lattice handle of the preconditioned callers (elph_shard_set_full_lattice; not owned)
 };
 
@@ -50,13 +59,17 @@ struct ShardState {
 //   [2][ELPH_SHARD_MAXREC][2]   records of the resident kernel's two meetings
 //   [2][2][Ltau][cap][2]        ghost rows from below / from above, once per parity of the iteration
 //   [8][8][2] + [8]             streaming form: records of up to 8 named all-sums (one 2-granule record per rank) + spectrum flags
-//   [Lo2][n_global][2]          spectrum nu of the whole lattice (16-byte complex), written by all ranks (KPM apply)
-static size_t mailbox_words(int64_t L, int cap, int64_t n_global, size_t *ext_off, size_t *nu_off) {
+//   [Lo2][n_global][2]          spectrum nu of the whole lattice (16-byte complex), written by all ranks (KPM apply) — and, BETWEEN solves,
+//                               the exchange area of the callers' ghost rows (elph_i_shard_ghost_sync: up to four vectors of the whole
+//                               lattice, [vector][tau][global column] doubles), hence at least 4 L n_global words
+static size_t mailbox_words(int64_t L, int cap, int64_t n_global, size_t *ext_off, size_t *nu_off, size_t *xch_words = nullptr) {
     size_t w = 2 * (size_t)ELPH_SHARD_MAXREC * 2 + 2 * 2 * (size_t)L * (size_t)cap * 2;      // (ghost regions twice: by the parity of the iteration)
     if (ext_off) *ext_off = w;
     w += 8 * 8 * 2 + 8;
     if (nu_off) *nu_off = w;
-    w += (size_t)((L + 1) / 2) * (size_t)n_global * 2;
+    const size_t area = std::max((size_t)((L + 1) / 2) * (size_t)n_global * 2, (size_t)4 * (size_t)L * (size_t)n_global);
+    if (xch_words) *xch_words = area;
+    w += area;
     return w;
 }
 
@@ -97,6 +110,9 @@ void elph_shard_free(elph_handle_s *h) {
     if (S->mail) (void)hipFree(S->mail);
     if (S->d_gsites) (void)hipFree(S->d_gsites);
     if (S->d_counter) (void)hipFree(S->d_counter);
+    if (S->d_xcol) (void)hipFree(S->d_xcol);
+    if (S->d_xown) (void)hipFree(S->d_xown);
+    if (S->d_csbar) (void)hipFree(S->d_csbar);
     delete S;
     h->shard = nullptr;
 }
@@ -164,7 +180,7 @@ static int shard_create(elph_handle_s *h, int rank, int world, int64_t own_lo, i
         return ELPH_E_ARG;
     }
     S->n_global = n_global; S->own_gstart = own_global_start;
-    S->mail_bytes = mailbox_words(h->L, (int)cap_ghost, n_global, &S->ext_off, &S->nu_off) * sizeof(unsigned long long);
+    S->mail_bytes = mailbox_words(h->L, (int)cap_ghost, n_global, &S->ext_off, &S->nu_off, &S->xch_words) * sizeof(unsigned long long);
     if (n_global > 0) {
         std::vector<int> gs((size_t)h->N);
         for (int64_t i = 0; i < h->N; ++i) {
@@ -820,14 +836,83 @@ static int shard_arm(elph_handle_s *h, ShardState *S) {      // mailbox zeroed o
     return ELPH_OK;
 }
 
-// Ghost rows of a site vector (layout S on the slab, nvec vectors) from their owners: every rank contributes its own rows to a vector on
-// the WHOLE lattice, the ranks sum it, and each takes its ghost rows from the sum.  Host-staged (once per force evaluation / refresh,
-// not per CG iteration); the own rows are not touched.
+// ---- ghost rows (ghost columns) of a slab vector from their owners, through the mailboxes ------------------------------------------
+// Between two solves the spectrum area of every mailbox is idle: it is the exchange area.  Every rank stores the columns it OWNS of
+// vec[vt][column] (vt = vector x time slice) into the area of every other rank at [vt][global column] (peer stores, 8 bytes each), the
+// ranks pass the caller's barrier, and every rank takes the columns it does NOT own out of its own area.  No host copy of the vector, no
+// all-reduce of a whole-lattice array: what crosses between the GPUs is what the owners hold, once.
+// own == nullptr: site vectors — column c is owned when lo <= c < hi.
+__global__ void __launch_bounds__(256) k_shard_push_cols(const double *__restrict__ vec, ElphShardCtl Sh, size_t area_off, int ncols, int ngcol,
+                                                         const int *__restrict__ gcol, const double *__restrict__ own, int lo, int hi) {
+    const size_t vt = blockIdx.x;
+    for (int c = threadIdx.x; c < ncols; c += 256) {
+        const bool mine = own ? own[c] != 0.0 : (c >= lo && c < hi);
+        if (!mine) continue;
+        const u64s bits = (u64s)__double_as_longlong(vec[vt * ncols + c]);
+        const size_t at = area_off + vt * ngcol + gcol[c];
+        for (int q = 0; q < Sh.P; ++q) if (q != Sh.rank) sst(Sh.mail[q] + at, bits);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_shard_pull_cols(double *__restrict__ vec, const u64s *__restrict__ area, int ncols, int ngcol,
+                                                         const int *__restrict__ gcol, const double *__restrict__ own, int lo, int hi) {
+    const size_t vt = blockIdx.x;
+    for (int c = threadIdx.x; c < ncols; c += 256) {
+        const bool mine = own ? own[c] != 0.0 : (c >= lo && c < hi);
+        if (mine) continue;
+        vec[vt * ncols + c] = __longlong_as_double((long long)sld(area + vt * ngcol + gcol[c]));
+    }
+}
+
+// *done = false: not taken (one rank, ELPH_SHARD_GHOST_HOST=1, a vector that does not fit the exchange area) — the caller stages through the host
+static int ghost_sync_dev(elph_handle_s *h, ShardState *S, double *vec, int nvec, int ncols, int ngcol, const int *d_gcol, const double *d_own,
+                          bool *done) {
+    *done = false;
+    const char *e = getenv("ELPH_SHARD_GHOST_HOST");
+    if ((e && e[0] == '1') || !S->connected || nvec < 1) return ELPH_OK;
+    const size_t rows = (size_t)nvec * (size_t)h->L;
+    if (rows * (size_t)ngcol > S->xch_words) return ELPH_OK;
+    // (1) nobody still reads this area — a spectrum of the last solve, the pull of an earlier exchange: those are stream-ordered on their rank
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (S->barrier(S->coll_ctx) != 0) { elph_set_error("the caller's barrier failed"); return ELPH_E_HIP; }
+    hipLaunchKernelGGL(k_shard_push_cols, dim3((unsigned)rows), dim3(256), 0, h->stream, (const double *)vec, S->ctl, S->nu_off, ncols, ngcol, d_gcol,
+                       d_own, S->ctl.own_lo, S->ctl.own_hi);
+    { const int rcl = launch_ok("k_shard_push_cols"); if (rcl) return rcl; }
+    // (2) every rank's stores have landed (a kernel's system-scope stores are visible once its stream has drained)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (S->barrier(S->coll_ctx) != 0) { elph_set_error("the caller's barrier failed"); return ELPH_E_HIP; }
+    hipLaunchKernelGGL(k_shard_pull_cols, dim3((unsigned)rows), dim3(256), 0, h->stream, vec, (const u64s *)(S->mail + S->nu_off), ncols, ngcol, d_gcol,
+                       d_own, S->ctl.own_lo, S->ctl.own_hi);
+    { const int rcl = launch_ok("k_shard_pull_cols"); if (rcl) return rcl; }
+    ++S->ghost_dev;
+    *done = true;
+    return ELPH_OK;
+}
+
+// how many ghost exchanges of this handle went through the mailboxes / through the host collectives (tests, bench)
+extern "C" int elph_shard_ghost_stats(elph_handle h, int64_t *through_mailboxes, int64_t *through_host) {
+    if (!h || !h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
+    const ShardState *S = static_cast<const ShardState *>(h->shard);
+    if (through_mailboxes) *through_mailboxes = (int64_t)S->ghost_dev;
+    if (through_host) *through_host = (int64_t)S->ghost_host;
+    return ELPH_OK;
+}
+
+// Ghost rows of a site vector (layout S on the slab, nvec vectors) from their owners; the own rows are not touched.  Through the mailboxes
+// (above); the fall-back stages through the host: every rank contributes its own rows to a vector on the WHOLE lattice, the ranks sum it,
+// and each takes its ghost rows from the sum.  Once per force evaluation / refresh, not per CG iteration.
 int elph_i_shard_ghost_sync(elph_handle_s *h, double *vecS, int nvec) {
     ShardState *S = shard_callers(h);
     if (!S) return ELPH_E_STATE;
     if (S->ctl.P == 1) return ELPH_OK;
     if (S->n_global <= 0 || S->gsites_host.empty()) { elph_set_error("the shard was created without its global geometry"); return ELPH_E_STATE; }
+    {
+        bool done = false;
+        const int rcd = ghost_sync_dev(h, S, vecS, nvec, (int)h->N, (int)S->n_global, S->d_gsites, nullptr, &done);
+        if (rcd) return rcd;
+        if (done) return ELPH_OK;
+        ++S->ghost_host;
+    }
     const size_t N = (size_t)h->N, L = (size_t)h->L, NG = (size_t)S->n_global;
     std::vector<double> loc(N * L * (size_t)nvec), glob(NG * L * (size_t)nvec, 0.0);
     HIPCHK(hipMemcpyAsync(loc.data(), vecS, loc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -873,12 +958,80 @@ int elph_i_shard_global_ebar(elph_handle_s *h, std::vector<double> &Eg) {
     return elph_i_shard_allreduce(h, Eg.data(), (int)Eg.size());
 }
 
+// Bond phonons under a preconditioner: the expansion on the full-lattice handle takes the tau-means of cosh / sinh of EVERY bond of the lattice
+// (update_A!, KPMPreconditioners.jl:355-381); a rank holds the tables of its slab's bonds.  global_bond[b] = the bond's position in the
+// checkerboard order of the whole lattice, own_weight[b] = 1 for the bonds this rank owns (every bond of the lattice has exactly one owner).
+extern "C" int elph_shard_set_bonds(elph_handle h, const int64_t *global_bond, int64_t n_global_bonds, const double *own_weight) {
+    if (!h || !h->shard) { elph_set_error("elph_shard_create has not been called"); return ELPH_E_STATE; }
+    ShardState *S = static_cast<ShardState *>(h->shard);
+    if (!global_bond || !own_weight || n_global_bonds < h->nb) { elph_set_error("bad argument"); return ELPH_E_ARG; }
+    std::vector<int> gb((size_t)h->nb);
+    std::vector<double> w((size_t)h->nb);
+    for (int64_t b = 0; b < h->nb; ++b) {
+        if (global_bond[b] < 0 || global_bond[b] >= n_global_bonds) { elph_set_error("global_bond[%lld] out of range", (long long)b); return ELPH_E_ARG; }
+        gb[(size_t)b] = (int)global_bond[b];
+        w[(size_t)b] = own_weight[b] != 0.0 ? 1.0 : 0.0;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (S->d_csbar) HIPCHK(hipFree(S->d_csbar));
+    S->d_csbar = nullptr;
+    if (h->nb > 0) HIPCHK(hipMalloc((void **)&S->d_csbar, 2 * (size_t)h->nb * sizeof(double)));
+    S->gbond.swap(gb); S->bown.swap(w); S->n_gbonds = n_global_bonds;
+    return ELPH_OK;
+}
+
+bool elph_i_shard_has_bonds(const elph_handle_s *h) {
+    const ShardState *S = h ? static_cast<const ShardState *>(h->shard) : nullptr;
+    return S && S->n_gbonds > 0 && (int64_t)S->gbond.size() == h->nb;
+}
+
+// cs = [c̄ of every bond of the lattice | s̄ of every bond]: every rank takes the tau-means of its slab's tables on the device, contributes
+// the bonds it owns, the ranks sum the disjoint pieces (2 x bonds doubles through the caller's all-reduce — no vector of the lattice)
+int elph_i_shard_global_csbar(elph_handle_s *h, std::vector<double> &cs, int64_t *n_bonds) {
+    ShardState *S = shard_callers(h);
+    if (!S) return ELPH_E_STATE;
+    if (!elph_i_shard_has_bonds(h)) { elph_set_error("elph_shard_set_bonds has not been called"); return ELPH_E_STATE; }
+    const size_t nb = (size_t)h->nb, NB = (size_t)S->n_gbonds;
+    if (h->kind != ELPH_MODEL_SSH || !h->have_E) { elph_set_error("the tau-means of the hopping tables: a bond-phonon handle after update_model"); return ELPH_E_STATE; }
+    int rc = elph_launch_cs_bar(h, S->d_csbar, S->d_csbar + nb, 1);
+    if (rc) return rc;
+    std::vector<double> cl(nb), sl(nb);
+    HIPCHK(hipMemcpyAsync(cl.data(), S->d_csbar, nb * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(sl.data(), S->d_csbar + nb, nb * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    cs.assign(2 * NB, 0.0);
+    for (size_t b = 0; b < nb; ++b)
+        if (S->bown[b] != 0.0) { cs[(size_t)S->gbond[b]] = cl[b]; cs[NB + (size_t)S->gbond[b]] = sl[b]; }
+    *n_bonds = S->n_gbonds;
+    return elph_i_shard_allreduce(h, cs.data(), (int)cs.size());
+}
+
 // The same for vectors whose columns are not sites (bond-phonon fields): gcol[c] = the column's number on the whole lattice, own[c] = 1 when
 // this rank owns it; owned columns are contributed, the others taken from the sum.
 int elph_i_shard_ghost_sync_cols(elph_handle_s *h, double *vecS, int nvec, int ncols, const int *gcol, int ngcol, const double *own) {
     ShardState *S = shard_callers(h);
     if (!S) return ELPH_E_STATE;
     if (S->ctl.P == 1) return ELPH_OK;
+    {
+        if ((size_t)ncols > S->xcol_cap) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (S->d_xcol) HIPCHK(hipFree(S->d_xcol));
+            if (S->d_xown) HIPCHK(hipFree(S->d_xown));
+            S->d_xcol = nullptr; S->d_xown = nullptr; S->xcol_cap = 0;
+            HIPCHK(hipMalloc((void **)&S->d_xcol, (size_t)ncols * sizeof(int)));
+            HIPCHK(hipMalloc((void **)&S->d_xown, (size_t)ncols * sizeof(double)));
+            S->xcol_cap = (size_t)ncols;
+        }
+        for (int c = 0; c < ncols; ++c)
+            if (gcol[c] < 0 || gcol[c] >= ngcol) { elph_set_error("ghost exchange: column %d maps to %d of %d", c, gcol[c], ngcol); return ELPH_E_ARG; }
+        HIPCHK(hipMemcpyAsync(S->d_xcol, gcol, (size_t)ncols * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(S->d_xown, own, (size_t)ncols * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        bool done = false;
+        const int rcd = ghost_sync_dev(h, S, vecS, nvec, ncols, ngcol, S->d_xcol, S->d_xown, &done);
+        if (rcd) return rcd;
+        if (done) return ELPH_OK;
+        ++S->ghost_host;
+    }
     const size_t N = (size_t)ncols, L = (size_t)h->L, NG = (size_t)ngcol;
     std::vector<double> loc(N * L * (size_t)nvec), glob(NG * L * (size_t)nvec, 0.0);
     HIPCHK(hipMemcpyAsync(loc.data(), vecS, loc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -391,6 +391,21 @@ class ShardedSolver:
                 gcol.append(int(ph)); cbl.append(k + 1); w.append(1.0 if own[k] else 0.0)
         return np.asarray(gcol, dtype=np.int64), np.asarray(cbl, dtype=np.int64), np.asarray(w, dtype=np.float64)
 
+    def set_bonds(self, nbonds_global):
+        """elph_shard_set_bonds: the slab's bonds in the checkerboard numbering of the whole lattice and which of them this rank owns — what a
+        KPM-preconditioned HMC update of a bond-phonon model needs to put the τ-means of every bond's hopping onto the full-lattice handle."""
+        lm = self._lib_mod
+        own = np.zeros(len(self.bonds))
+        own[self.owned_bonds()] = 1.0
+        gb = np.ascontiguousarray(np.asarray(self.bonds), dtype=np.int64)
+        lm.check(self.lib.elph_shard_set_bonds(self.h, lm.iptr(gb), int(nbonds_global), lm.dptr(own)))
+
+    def ghost_stats(self):
+        """(ghost exchanges through the mailboxes, through the host collectives) since the shard was created."""
+        a, b = C.c_int64(), C.c_int64()
+        self._lib_mod.check(self.lib.elph_shard_ghost_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def iterate(self, b_global, k):
         """Exactly k iterations (no stop test); returns this rank's HIP-event time of the launch in ms (bench.py)."""
         b = self._local(b_global)

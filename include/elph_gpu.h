@@ -495,7 +495,8 @@ int elph_shard_destroy(elph_handle h);
 /* The CALLERS of the solve on a sharded lattice (BASELINE configs "HMC ... spatial-sharded across 8 GPUs"): ldiv!'s wrapper, the fermion
  * force and — elph_hmc_update on a sharded handle — one HMC update.  Everything but the solve is pointwise in the site index or stays
  * inside the MᵀM closure the slab already holds; what crosses ranks besides the solve are a few scalars (true residual, energies) and,
- * once per force evaluation, the ghost rows of one vector.  Those go through two host collectives the caller registers once per handle
+ * once per force evaluation, the ghost rows of one vector (device to device through the mailboxes, see elph_shard_ghost_stats).  The
+ * scalars and the barriers go through two host collectives the caller registers once per handle
  * (MPI.Barrier / MPI.Allreduce!(SUM), torch.distributed, a thread barrier for ranks that share a process); the CG iteration itself
  * keeps its device-initiated mailbox stores.  The library arms the mailbox itself (elph_shard_prepare + the barrier) before every solve
  * of these calls.  All vectors are SLAB vectors (own + ghost rows, reference layout, ghost entries filled from the global arrays);
@@ -522,7 +523,7 @@ int elph_shard_fermion_force_ssh(elph_handle h, elph_handle hfull, const double 
                                  double tol_power, double *q_out, double *Xp_out, double *Xm_out, int64_t *iters, int *flag);
 
 /* elph_hmc_update on a SHARDED handle (elph_hmc_create / elph_hmc_create_ssh + elph_hmc_set_state on the slab handle, collectives set): one HMC
- * update of the whole lattice over the ranks — one chain, un-preconditioned; R, Rp, Rm and every per-site / per-phonon array are the slab's
+ * update of the whole lattice over the ranks — one chain; R, Rp, Rm and every per-site / per-phonon array are the slab's
  * part of the global ones (ghost entries included), u_accept the same number on every rank.  Bond phonons additionally need the slab's phonon
  * columns in the numbering of the whole lattice and their owners (the phonons of the slab's bonds; owner = the rank whose own rows hold the
  * bond's first site): global_column[nph_slab], own_weight[nph_slab] in {0, 1}; the state vectors of elph_hmc_set_state / _get_state are then
@@ -532,6 +533,17 @@ int elph_shard_hmc_set_columns(elph_handle h, const int64_t *global_column, int6
  * (it needs no field: every setup!(P) inside the update injects the τ-averaged exp(−ΔτV) of the whole lattice, summed over the ranks' own
  * rows); kpm_randn of elph_hmc_update then holds the (nt + 2) pairs of Arnoldi start vectors of the WHOLE lattice, the same on every rank. */
 int elph_shard_set_full_lattice(elph_handle h, elph_handle hfull);
+/* ... and on a sharded BOND-PHONON handle: hfull = a bond-phonon handle on the whole lattice with one elph_update_model_ssh (for exp(Δτμ), which does
+ * not move) and elph_kpm_create done; every setup!(P) inside the update injects the τ-means of cosh / sinh of every bond of the lattice
+ * (update_A!, KPMPreconditioners.jl:355-381), taken by each rank from its slab's tables for the bonds it owns and summed over the ranks.  For that
+ * the slab's bonds in the numbering of the whole lattice: global_bond[nbonds_slab] = checkerboard position on the whole lattice (0-based),
+ * own_weight[nbonds_slab] in {0, 1} — owner = the rank whose own rows hold the bond's first site, as for elph_shard_hmc_set_columns. */
+int elph_shard_set_bonds(elph_handle h, const int64_t *global_bond, int64_t n_global_bonds, const double *own_weight);
+/* The ghost rows of ϕ± (once per update) and of the fermion force (once per force evaluation) travel from their owners' devices into the
+ * holders' mailboxes by peer stores — the spectrum area of the mailbox is the exchange area between solves; two of the caller's barriers per
+ * exchange, no host copy of a vector.  ELPH_SHARD_GHOST_HOST=1 (A/B), or a vector that does not fit the area, stages through the caller's
+ * all-reduce instead.  Counts of both since elph_shard_create: */
+int elph_shard_ghost_stats(elph_handle h, int64_t *through_mailboxes, int64_t *through_host);
 
 /* ---------------------------------------------------------------- health of the resident kernels */
 

@@ -141,9 +141,13 @@ def run_rank(comm, what, tag, out):
                                            d(col(ssh["alpha2"])), d(t_bare_loc), d(np.ascontiguousarray(ssh["mu"][S.gsites])), dtau, d(fld(faM))))
         _lib.check(lib.elph_shard_hmc_set_columns(S.h, ip(np.ascontiguousarray(gcol)), ssh["Nph"], d(wown)))
         _lib.check(lib.elph_hmc_set_state(S.h, d(fld(x0)), d(np.zeros(nphl * Ltau))))
+        if with_kpm:      # the expansion on a bond-phonon handle of the whole lattice: exp(Δτμ) once, the τ-means of the hoppings injected at every setup!(P)
+            S.setup_kpm((c, s, emu), n=20, buf=0.05, c1=1.0, c2=1.0, seed=1)
+            _lib.check(lib.elph_shard_set_full_lattice(S.h, S.hf))
+            S.set_bonds(Nb)
         acc, fl, its, en = C.c_int(), C.c_int(), C.c_double(), np.zeros(5)
-        _lib.check(lib.elph_hmc_update(S.h, dt, nt, nb, 0.0, 0, d(fld(rnd["R"])), d(S._local(rnd["Rp"])), d(S._local(rnd["Rm"])), None, rnd["u"],
-                                       C.byref(acc), C.byref(its), d(en), C.byref(fl)))
+        _lib.check(lib.elph_hmc_update(S.h, dt, nt, nb, 0.0, 1 if with_kpm else 0, d(fld(rnd["R"])), d(S._local(rnd["Rp"])), d(S._local(rnd["Rm"])),
+                                       d(rnd["kpm_randn"]) if with_kpm else None, rnd["u"], C.byref(acc), C.byref(its), d(en), C.byref(fl)))
         xs, vs = np.zeros(nphl * Ltau), np.zeros(nphl * Ltau)
         _lib.check(lib.elph_hmc_get_state(S.h, d(xs), d(vs)))
         # the owned columns of every rank -> the field on the whole lattice
@@ -155,6 +159,9 @@ def run_rank(comm, what, tag, out):
             xg[g_], vg[g_] = x_, v_
         assert not np.isnan(xg).any(), "a phonon without an owner"
         res.update(accepted=acc.value, flag=fl.value, iters=its.value, energies=en, x=xg.reshape(-1), v=vg.reshape(-1))
+    if what == "hmc":
+        gd, gh = S.ghost_stats()
+        res.update(ghost_dev=gd, ghost_host=gh)
     S.close()
     np.savez(out + f".rank{comm.rank}", **res)
     comm.close()

@@ -336,6 +336,37 @@ def test_sharded_hmc_update_with_the_kpm_preconditioner(tmp_path, world):
     assert abs(float(a["iters"]) - float(a["iters_ref"])) <= 1 and float(a["iters"]) < 100     # (preconditioned at tol 1e-10: 61 iterations per solve; plain: several hundred)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hmc_update_bond_phonons_with_the_kpm_preconditioner(tmp_path, world):
+    """The production shape of BASELINE config 5: the sharded update of the optical SSH model with the KPM preconditioner — the expansion on a
+    bond-phonon handle of the whole lattice, its τ-averaged cosh / sinh of EVERY bond taken at each setup!(P) from the owners' slabs
+    (elph_shard_set_bonds; update_A!, KPMPreconditioners.jl:355-381) — against the preconditioned update of ONE handle."""
+    res = _run_callers("hmc", "E", tmp_path, world, extra_env={"ELPH_TEST_KPM": "1"})
+    a = res[0]
+    for b in res[1:]:
+        assert int(b["accepted"]) == int(a["accepted"]) and np.array_equal(a["energies"], b["energies"]) and np.array_equal(a["x"], b["x"])
+    assert int(a["accepted"]) == int(a["accepted_ref"]) == 1 and int(a["flag"]) == int(a["flag_ref"]) == 0
+    e, er = a["energies"], a["energies_ref"]
+    assert abs(e[0] - er[0]) < 1e-9 * abs(er[0]) and abs(e[1] - er[1]) < 1e-8 * abs(er[1])
+    assert _rel(a["x"], a["x_ref"]) < 1e-9 and _rel(a["v"], a["v_ref"]) < 1e-8
+    assert abs(float(a["iters"]) - float(a["iters_ref"])) <= 1 and float(a["iters"]) < 150     # (plain: several hundred per solve)
+    assert all(int(r["ghost_dev"]) > 0 and int(r["ghost_host"]) == 0 for r in res)
+
+
+@pytest.mark.parametrize("tag", ["D", "E"])
+def test_ghost_rows_through_the_mailboxes_equal_the_host_staged_exchange(tmp_path, tag):
+    """The ghost rows of ϕ± and of the fermion force travel device to device through the mailboxes (elph_shard_ghost_stats counts them); staged
+    through the caller's all-reduce instead (ELPH_SHARD_GHOST_HOST=1) the update ends on the same bits — the exchange moves values, it adds nothing."""
+    (tmp_path / "dev").mkdir()
+    (tmp_path / "host").mkdir()
+    dev = _run_callers("hmc", tag, tmp_path / "dev", 2)
+    host = _run_callers("hmc", tag, tmp_path / "host", 2, extra_env={"ELPH_SHARD_GHOST_HOST": "1"})
+    assert all(int(r["ghost_dev"]) >= 3 and int(r["ghost_host"]) == 0 for r in dev)           # ϕ± once, the force at every evaluation
+    assert all(int(r["ghost_dev"]) == 0 and int(r["ghost_host"]) >= 3 for r in host)
+    for a, b in zip(dev, host):
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["v"], b["v"]) and np.array_equal(a["energies"], b["energies"])
+
+
 @pytest.mark.parametrize("world,nb", [(2, 1), (4, 1), (2, 3), (8, 1)])
 def test_sharded_hmc_update_vs_one_handle(tmp_path, world, nb):
     """One HMC update of BASELINE config 4 (Holstein honeycomb L = 12, Ntau = 120) on a lattice sharded over 2 / 4 ranks —
