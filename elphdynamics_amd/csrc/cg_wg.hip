@@ -37,6 +37,12 @@ namespace wg {
 
 #ifdef ELPH_WG_ARRIVE
 __device__ unsigned long long g_wg_arrive[4096 * 4];
+// (tools/diag_wg_timeline.py) per workgroup: wall clock at the top of its first iteration, at the end of its first iteration, when it saw
+// `done`, and after its last stores — what a launch of few iterations spends outside them
+__device__ unsigned long long g_wg_timeline[4096 * 4];
+#define TL(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg_timeline[blockIdx.x * 4 + (k)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define TL(k) do { } while (0)
 #endif
 
 // SQ: the DPP form for the 16 x 16 square lattice in the reference's colouring (NPL = 4, no LDS slabs; Holstein: uniform hopping in
@@ -384,6 +390,8 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         u64 *const bnd = bnd0 + (size_t)par * G * 2 * HS * 2;
         const size_t ghp = SHARD ? (size_t)par * 2 * L * Sh.cap_ghost * 2 : 0;      // (a shard: the ghost rows of z in the mailboxes, by parity too)
         STAMP(9);
+        if (seq == 0) TL(0);
+        if (seq == 1) TL(1);
         // ---- z = M^T M p on the own slices:  w(t) = p(t) - sg(t) CB_t [E(t) p(t-1)]  for t = t0 .. t0+T  (T+1 forward sweeps at once),
         //      z(t) = w(t) - sg(t+1) E(t+1) CB_{t+1}^T w(t+1)  for t = t0 .. t0+T-1  (T reverse sweeps at once)
         // (w and z share registers: z(t0+j) overwrites w(t0+j) once the reverse sweep of w(t0+j+1) has been taken)
@@ -1027,6 +1035,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
         STAMP(7);
         if (done) {
             STAMP_OUT(it);
+            TL(2);
             // (the store addresses are made here, from a laundered lane number: computed before the loop they sit in 2 registers per
             //  value for the whole solve — in a kernel that has none to spare: 10 -> 2 spilled registers at 4 slices per wave)
             int lane2 = lane;
@@ -1049,6 +1058,7 @@ __global__ void __launch_bounds__(512) k_cg_wg(CgBufs B, ModelDev m, WgCtl R, Sh
                 st2[0] = o;
                 st2[1] = o;
             }
+            TL(3);
 #ifdef ELPH_WG_PERSISTENT
             break;
 #else
@@ -1828,6 +1838,11 @@ int elph_wg_aborted(elph_handle_s *h, bool *aborted) {
 extern "C" int elph_debug_wg_arrive(unsigned long long *out, int n_blocks, int clear) {
     if (clear) { static unsigned long long z[4096 * 4]; return hipMemcpyToSymbol(HIP_SYMBOL(wg::g_wg_arrive), z, sizeof(z)) == hipSuccess ? 0 : -1; }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(wg::g_wg_arrive), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef ELPH_WG_ARRIVE
+extern "C" int elph_debug_wg_timeline(unsigned long long *out, int n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(wg::g_wg_timeline), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef ELPH_WG_STAMPS
