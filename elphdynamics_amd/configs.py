@@ -18,6 +18,10 @@ CONFIGS = {
     "b": ("holstein", 1, 4, lat.SQUARE_BONDS, 2.0, 0.1),
     "d": ("holstein", 2, 3, lat.HONEYCOMB_BONDS, 1.2, 0.1),
     "e": ("ssh", 1, 4, lat.SQUARE_BONDS, 1.0, 0.05),
+    "e8": ("ssh", 1, 8, lat.SQUARE_BONDS, 1.0, 0.05),               # bond phonons beyond the two deck sizes (round 6): N = 64 — one site per lane
+    "e12": ("ssh", 1, 12, lat.SQUARE_BONDS, 1.0, 0.05),             # N = 144 — three sites per lane
+    "e20": ("ssh", 1, 20, lat.SQUARE_BONDS, 1.0, 0.05),             # N = 400 — seven sites per lane
+    "e24": ("ssh", 1, 24, lat.SQUARE_BONDS, 1.0, 0.05),             # N = 576 — beyond the lane program: the generic LDS kernels
     "t": ("holstein", 1, 3, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # odd L: 9 ragged colours (generic kernels)
     "u": ("holstein", 1, 4, lat.TRIANGULAR_BONDS, 1.0, 0.125),      # even-L triangular: 6 colours (lane program lp6)
     "T": ("holstein", 1, 16, lat.TRIANGULAR_BONDS, 16.0, 0.1),      # holstein_hmc_triangular.toml geometry at config-C size

@@ -345,7 +345,7 @@ def test_ssh_hmc_shared_fields_match_dense_golden(nb):
     m.close()
 
 
-@pytest.mark.parametrize("tag,with_kpm,nb", [("e", False, 1), ("e", True, 2), ("E", True, 1)])
+@pytest.mark.parametrize("tag,with_kpm,nb", [("e", False, 1), ("e", True, 2), ("E", True, 1), ("e12", True, 1), ("e24", True, 1)])
 def test_ssh_hmc_update_vs_oracle(oracle, tag, with_kpm, nb):
     """Configs e / E (optical SSH square L = 4 / 16): device trajectory vs the oracle's, with alpha2 != 0 and the KPM
     preconditioner (tau-averaged cosh/sinh from the device tables), accept and reject."""

@@ -271,7 +271,7 @@ def _oracle_model(orc, m):
                           np.ascontiguousarray(m.sinht).reshape(-1), m.expDtauMu)
 
 
-@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "l30", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
+@pytest.mark.parametrize("tag", ["A", "b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "G", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "k", "j", "i", "l30", "h20", "h21", "h24", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22", "e8", "e12", "e20", "e24"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_matvec_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models, synth
     m = configs.make_model(tag)
@@ -304,7 +304,7 @@ def test_matvec_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "l30", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
+@pytest.mark.parametrize("tag", ["b", "d", "t", "u", "e", "B", "C", "D", "E", "T", "g", "h", "s", "q", "Q", "S", "y", "z", "Y", "r", "R", "w", "W", "G", "k", "j", "i", "l30", "h20", "h21", "h24", "H18", "t6", "t12", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22", "e8", "e12", "e20", "e24"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_cg_vs_oracle(oracle, tag):
     from elphdynamics_amd import configs, models
     m = configs.make_model(tag, tol=1e-5)
@@ -376,7 +376,7 @@ def test_nonzero_initial_guess_and_kappa_bailout(oracle):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
+@pytest.mark.parametrize("tag", ["b", "u", "B", "C", "D", "T", "g", "e", "E", "s", "q", "Q", "S", "d", "y", "z", "Y", "r", "W", "G", "k", "j", "i", "l30", "K", "h", "h20", "h21", "h24", "H18", "t6", "t12", "t20", "t24", "t32", "l22", "l26", "l36", "l34", "l40", "l48", "l64", "h30", "h22", "e8", "e12", "e20", "e24"])      # h30, h22: honeycomb cells on two wavefronts; l36: 4 x 6 patches (round 6); l34 … l64: several wavefronts per slice; l22, l26: square 22 x 22 / 26 x 26 — no register form (2 x 11, 2 x 13), the LDS kernels
 def test_kpm_vs_oracle(oracle, tag):
     """setup!(P) with injected eigenvalue bounds, ldiv!(z,P,r) and the preconditioned CG vs the oracle.  e / E: bond phonons — the
     expansion is built on the tau-means of the per-(tau, bond) hopping tables (update_A!, KPMPreconditioners.jl:355-381)."""
