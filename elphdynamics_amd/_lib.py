@@ -125,6 +125,7 @@ BENCH_SIGNATURES = {
     "elph_bench_info": (c_int, [Handle, c_int, P_int]),
     "elph_bench_wg_info": (c_int, [Handle, c_int, P_int, P_int, P_int, P_int]),
     "elph_bench_px_info": (c_int, [Handle, P_int]),
+    "elph_bench_pg_info": (c_int, [Handle, P_int, P_int, P_int, P_int, P_int]),
     "elph_bench_slabs_info": (c_int, [Handle, c_int, P_int, P_int, P_int, P_int]),
 }
 

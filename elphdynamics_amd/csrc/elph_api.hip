@@ -137,6 +137,10 @@ static int build_lane_program(elph_handle_s *h) {
         RC(dev_alloc(&h->d_sq_bond, (size_t)4 * h->N));
         HIPCHK(hipMemcpy(h->d_sq_bond, h->sq_bond.data(), sizeof(int) * 4 * h->N, hipMemcpyHostToDevice));
     }
+    if (h->pg_kind == 1 && h->pg_bond.size() == (size_t)4 * h->N) {      // the site -> bond map of the colouring: hopping disorder in the patch layout (pgrid.hip)
+        RC(dev_alloc(&h->d_pg_bond, (size_t)4 * h->N));
+        HIPCHK(hipMemcpy(h->d_pg_bond, h->pg_bond.data(), sizeof(int) * 4 * h->N, hipMemcpyHostToDevice));
+    }
     return ELPH_OK;
 }
 
@@ -232,7 +236,16 @@ static void detect_square(elph_handle_s *h) {
             const char *em = getenv("ELPH_PG_MW");
             if ((em && em[0] == '0') || !pgrid::pick_patch_mw(l, &px, &py, &nw)) continue;
         }
-        if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 1; h->pg_NW = nw; }
+        {   // hopping disorder on 28 x 28 / 32 x 32: 2 x 2 patches on four wavefronts instead of 4 x 4 on one — 12 table entries per thread instead of 40
+            // (measured, profiles/r06/hopping_disorder_patch_kernels_with_tables.log); ELPH_PG_MW=0 keeps the one-wavefront shape
+            const char *em = getenv("ELPH_PG_MW");
+            bool uni = true;
+            if (h->kind == ELPH_MODEL_HOLSTEIN)
+                for (int64_t n = 1; n < h->nb && uni; ++n) uni = (h->h_c[(size_t)n] == h->h_c[0] && h->h_s[(size_t)n] == h->h_s[0]);
+            // (... and 30 x 30, whose 2 x 10 patches have no table variant: 15 x 15 threads on four wavefronts)
+            if (!uni && nw == 1 && ((px == 4 && py == 4) || (px == 2 && py == 10)) && !(em && em[0] == '0')) { px = 2; py = 2; nw = ((l / 2) * (l / 2) + 63) / 64; }
+        }
+        if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 1; h->pg_NW = nw; h->pg_bond = h->sq_bond; }
     }
     h->sq_bond.clear();
 }
@@ -477,7 +490,7 @@ extern "C" int elph_destroy(elph_handle h) {
                     h->d_b, h->d_x, h->d_r, h->d_z, h->d_zp, h->d_p, h->d_tmp, h->d_part, h->d_state, h->d_phi, h->d_xfield,
                     h->d_hist, h->d_scal, h->d_alpha, h->d_Ebar, h->d_cbar, h->d_sbar, h->d_order, h->d_coff, h->d_wsched, h->d_kdesc, h->d_kfold,
                     h->d_coeff, h->d_klam, h->d_ssh_x, h->d_ssh_par, h->d_ssh_tbare, h->d_ssh_bar, h->d_ssh_cb, h->d_ssh_slot, h->d_nu, h->d_tw, h->d_theta, h->d_diag, h->d_lp_ij, h->d_lp_c, h->d_lp_s, h->d_lp_cbar,
-                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_sq_bond, h->d_res, h->d_mu_ch, h->d_kpm_start};
+                    h->d_lp_sbar, h->d_Tk, h->d_Tt, h->d_Pk, h->d_Pt, h->d_sq_cbar, h->d_sq_sbar, h->d_sq_bond, h->d_pg_bond, h->d_res, h->d_mu_ch, h->d_kpm_start};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -899,6 +912,9 @@ static bool split_wanted(elph_handle_s *h, int nrhs, int use_prec, bool hist) {
     // (config C, 128 right-hand sides: 130 us either way, profiles/r05/px_chunk_T.log; five sites per lane — the honeycomb lattice of config D,
     //  whose fused kernel stays at two waves per SIMD — gains from 64 on: D 128: 131 -> 116 us, 256: 262 -> 230, profiles/r05/px_fused_five_sites_per_lane.log;
     //  honeycomb 16 x 16 cells, eight sites per lane: 64 right-hand sides 64 -> 55 us, 256: 159 -> 145; D at 64: 89 -> 87)
+    // (hopping disorder on 4 x 4 patches: the table variants of the patch kernels hold 40 KB of LDS per wavefront — two half-batches side by side lose to one
+    //  stream: 32 x 32 at 96 right-hand sides 763 against 732 us, 28 x 28 695 against 663; profiles/r06/hopping_disorder_patch_kernels_with_tables.log)
+    if (!(e && e[0] == '1') && h->pg_L > 0 && h->pg_PX * h->pg_PY >= 16 && !h->pg_uniform && elph_pg_disorder_ok(h)) return false;
     return (e && e[0] == '1') || nrhs >= (h->npl >= 5 ? 64 : 192);
 }
 
@@ -2111,6 +2127,19 @@ extern "C" int elph_bench_px_info(elph_handle h, int *fused) {
     CHECK_H(h);
     if (!fused) { elph_set_error("bad argument"); return ELPH_E_ARG; }
     *fused = h->px_solve ? (h->sq16_ap_ran ? 2 : 1) : 0;      // 2: with the register-exchange k_cg_ap of the 16 x 16 lattice (cg_sq16.hip)
+    return ELPH_OK;
+}
+
+extern "C" int elph_bench_pg_info(elph_handle h, int *kind, int *px, int *py, int *nw, int *tables) {
+    CHECK_H(h);
+    if (kind) *kind = h->pg_L > 0 ? h->pg_kind : 0;
+    if (px) *px = h->pg_PX;
+    if (py) *py = h->pg_PY;
+    if (nw) *nw = h->pg_NW > 1 ? h->pg_NW : 1;
+    if (tables) {
+        ModelDev m = elph_model_dev(h);
+        *tables = (h->pg_L > 0 && h->kind == ELPH_MODEL_HOLSTEIN && !m.uniform && elph_pg_disorder_ok(h)) ? 1 : 0;
+    }
     return ELPH_OK;
 }
 

@@ -37,6 +37,10 @@ int elph_bench_wg_info(elph_handle h, int nrhs, int *usable, int *T, int *W, int
  * in the epilogue of the inverse tau-transform, k_cg_ap_chunk<PX> reading the ready p; kernels.hip: px_plan). */
 int elph_bench_px_info(elph_handle h, int *fused);
 
+/* The patch layout of this handle (pgrid.hip), if any: *kind 0 none, 1 square, 2 honeycomb, 3 triangular; the patch shape and the wavefronts per time
+ * slice; *tables = 1 when the hopping is disordered and the mat-vec / Chebyshev kernels take the patch layout with a (cosh, sinh) table in LDS. */
+int elph_bench_pg_info(elph_handle h, int *kind, int *px, int *py, int *nw, int *tables);
+
 /* Whether an un-preconditioned solve of nrhs right-hand sides FROM x = 0 on this handle runs in the slab form (slabs.hip: lattices beyond
  * 320 sites as slabs of rows on the same device, the resident kernel per slab, one launch) and its shape. */
 int elph_bench_slabs_info(elph_handle h, int nrhs, int *usable, int *slabs, int *sites_per_slab, int *own_sites);

@@ -239,6 +239,7 @@ struct elph_handle_s {
     int sq_LX = 0, sq_LY = 0;              // periodic LX x LY square lattice (both even, LX LY / 4 <= 64 lanes) recognised: sq_L = LX when LX == LY
     bool sq_uniform = false;               // every bond has the same (cbar, sbar): the Chebyshev kernel keeps them in scalars
     std::vector<int> sq_bond;              // [4][N] bond index touching site s in colour c
+    std::vector<int> pg_bond;              // ... of a square lattice in the patch layout (pg_kind 1)
     bool hc_uniform = false;               // ... and its tau-averaged hopping tables are one (cosh, sinh) for every bond (the register-exchange Chebyshev recursion)
     int pg_NW = 0;                         // wavefronts per time slice of the patch kernels (0 / 1: one; round 6: L = 22, 26, 34, 38 and 40 ... 64 take several)
     int pg_L = 0, pg_PX = 0, pg_PY = 0;    // even-L square lattice beyond 16 x 16 in the reference's colouring (detect_square): PX x PY sites per lane (pgrid_dev.h)
@@ -249,6 +250,7 @@ struct elph_handle_s {
     int hc_LX = 0, hc_LY = 0;              // periodic honeycomb lattice of LX x LY cells recognised: hc_L = LX when LX == LY
     bool hc12 = false;                     // honeycomb lattice of 12 x 12 cells in the reference's colouring (detect_honeycomb12): the DPP form of k_cg_wg
     double *d_sq_cbar = nullptr, *d_sq_sbar = nullptr;   // [4][N]
+    int *d_pg_bond = nullptr;                            // [4][N] the same for a square lattice in the patch layout (pg_kind 1): hopping disorder there
     int *d_sq_bond = nullptr;                            // [4][N] device copy of sq_bond (sq_P > 0)
     void *shard = nullptr;                 // ShardState (shard.hip), owned
     void *slabs = nullptr;                 // SlabSet (slabs.hip), owned: slab handles of this lattice on the same device
@@ -446,7 +448,8 @@ void elph_i_slabs_free(elph_handle_s *h);
 bool elph_wg_usable(const elph_handle_s *h, int *T, int *W, int *G, int nrhs = 1);
 int elph_wg_cg(elph_handle_s *h, const CgBufs &B, int nrhs, long long fixed_iters, bool *ran);
 int elph_wg_aborted(elph_handle_s *h, bool *aborted);       // after the stream has drained
-bool elph_pg_cheb_usable(const elph_handle_s *h);                       // pgrid.hip
+bool elph_pg_cheb_usable(const elph_handle_s *h);
+bool elph_pg_disorder_ok(const elph_handle_s *h);      // hopping disorder on this handle's patch shape (pgrid.hip)                       // pgrid.hip
 int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_part = nullptr, int nrz = 0, const double *rr_part = nullptr);
 bool elph_pg_ap_usable(const elph_handle_s *h);
 bool elph_pg_mul_usable(const elph_handle_s *h);

@@ -1103,7 +1103,7 @@ int elph_launch_zero(elph_handle_s *h, double *p, int64_t n) {
 int elph_launch_mul(elph_handle_s *h, int which, double *yS, const double *vS, int nvec) {
     if (h->fast) return elph_fast_mul(h, which, yS, vS, nvec);
     ModelDev m = elph_model_dev(h);
-    if (which >= 0 && which <= 2 && elph_pg_mul_usable(h) && m.uniform) return elph_pg_mul(h, m, which, yS, vS, nvec);     // large square / honeycomb lattices: pgrid.hip
+    if (which >= 0 && which <= 2 && elph_pg_mul_usable(h) && (m.uniform || elph_pg_disorder_ok(h))) return elph_pg_mul(h, m, which, yS, vS, nvec);     // large square / honeycomb lattices: pgrid.hip
     dim3 grid((unsigned)h->L, (unsigned)nvec, 1);
     const size_t shm = (2 * (size_t)h->N + 16) * sizeof(double);
     DISPATCH_NPL(gen_npl(h), {
@@ -1197,7 +1197,7 @@ static bool pg_px_allowed() {
 }
 static bool pg_px_form(const elph_handle_s *h) {
     if (!pg_px_allowed()) return false;
-    return !h->fast && h->kind == ELPH_MODEL_HOLSTEIN && h->pg_uniform && elph_pg_ap_usable(h) && elph_pg_cheb_usable(h);
+    return !h->fast && h->kind == ELPH_MODEL_HOLSTEIN && (h->pg_uniform || elph_pg_disorder_ok(h)) && elph_pg_ap_usable(h) && elph_pg_cheb_usable(h);
 }
 
 static bool px_plan(elph_handle_s *h, int nrhs) {
@@ -1428,7 +1428,7 @@ int elph_launch_cg_iteration(elph_handle_s *h, int nrhs, int use_prec) {
         const int N = (int)h->N, L = (int)h->L;
         dim3 grid((unsigned)L, (unsigned)nrhs, 1);
         const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
-        const bool pg = elph_pg_ap_usable(h) && m.uniform && B.npap == L;      // a large even-L square lattice: the patch-layout kernel (pgrid.hip)
+        const bool pg = elph_pg_ap_usable(h) && (m.uniform || elph_pg_disorder_ok(h)) && B.npap == L;      // a large even-L square lattice: the patch-layout kernel (pgrid.hip)
         if (use_prec && h->px_solve) {
             // the p/x-fused iteration of the generic family (px_plan): k_cg_ap_pg (patch-form lattices) or k_cg_ap<PX> reads the ready p; the
             // residual update rides on the forward transform, r.z comes from the Chebyshev kernel in frequency space, the p/x-update is the
@@ -1474,7 +1474,7 @@ int elph_launch_cg_kernel(elph_handle_s *h, int nrhs, int which) {
     const int N = (int)h->N, L = (int)h->L;
     dim3 grid((unsigned)L, (unsigned)nrhs, 1);
     const size_t shm = (2 * (size_t)N + 16) * sizeof(double);
-    if (which == 0 && elph_pg_ap_usable(h) && m.uniform && B.npap == L) {
+    if (which == 0 && elph_pg_ap_usable(h) && (m.uniform || elph_pg_disorder_ok(h)) && B.npap == L) {
         int rc = elph_pg_cg_ap(h, B, m, nrhs, (int)(h->ap_count & 1), B.params.use_prec && h->px_solve);
         h->ap_count++;
         return rc;

@@ -21,6 +21,9 @@ using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::
 // several wavefronts per slice (round 6): 2 x 2 patches on 2, 3, 5, 6 wavefronts (L = 22, 26, 34, 38), 4 x 4 patches on 2, 3, 4 (L = 40 ... 64)
 using M22_2 = pgrid::Sq<2, 2, 2>; using M22_3 = pgrid::Sq<2, 2, 3>; using M22_5 = pgrid::Sq<2, 2, 5>; using M22_6 = pgrid::Sq<2, 2, 6>;
 using M44_2 = pgrid::Sq<4, 4, 2>; using M44_3 = pgrid::Sq<4, 4, 3>; using M44_4 = pgrid::Sq<4, 4, 4>;
+// hopping disorder (round 6): a (cosh, sinh) pair per bond from a table in LDS — the shapes of pgrid::patch_takes_disorder
+using SQ44D = pgrid::Sq<4, 4, 1, false>; using SQ26D = pgrid::Sq<2, 6, 1, false>; using SQ24D = pgrid::Sq<2, 4, 1, false>;
+using M22_2D = pgrid::Sq<2, 2, 2, false>; using M22_3D = pgrid::Sq<2, 2, 3, false>; using M22_4D = pgrid::Sq<2, 2, 4, false>; using M22_5D = pgrid::Sq<2, 2, 5, false>;
 using H33_2 = pgrid::Hc<3, 3, 2>; using H33_3 = pgrid::Hc<3, 3, 3>; using H33_4 = pgrid::Hc<3, 3, 4>;      // honeycomb: 3 x 3 / 2 x 2 cells per thread
 using H22_2 = pgrid::Hc<2, 2, 2>; using H22_3 = pgrid::Hc<2, 2, 3>; using H22_4 = pgrid::Hc<2, 2, 4>;
 using TR22 = pgrid::Tri<2, 2>; using TR24 = pgrid::Tri<2, 4>; using TR26 = pgrid::Tri<2, 6>; using TR44 = pgrid::Tri<4, 4>;
@@ -45,6 +48,40 @@ __device__ __forceinline__ double pg_group_sum(double v, double *red, int ltid) 
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += red[w];
         return t;
+    }
+}
+
+// hopping disorder: this thread's (cosh, sinh) pairs -> tab (LDS; pgrid::Ctx::tab), from the bond tables through the site -> bond map of the
+// colouring (pgb[colour][site]); every thread reads back only what it wrote (the two parts of the Chebyshev kernel write the same values to the
+// same words), so no barrier is needed
+extern __shared__ __attribute__((aligned(16))) double2 pg_dtab[];
+template <class LAT, int COL>
+__device__ __forceinline__ void pg_fill_col(int lane, int Ls, int N, const int *__restrict__ pgb, const double *__restrict__ cb, const double *__restrict__ sb) {
+    using D = pgrid::ColDims<LAT::PX, LAT::PY, COL>;
+    constexpr int NT = LAT::NW * WAVE, BASE = pgrid::col_base<LAT::PX, LAT::PY, COL>();
+    auto put = [&](int slot, int reg) {
+        const int b = pgb[(size_t)COL * N + LAT::site_of(lane, reg, Ls)];
+        pg_dtab[(size_t)(BASE + slot) * NT + lane] = make_double2(cb[b], sb[b]);
+    };
+#pragma unroll
+    for (int b = 0; b < D::PB; ++b) {
+#pragma unroll
+        for (int a = D::ODD ? 1 : 0; a + 1 < D::PA; a += 2) put(D::pair_slot(a, b), a * D::SA + b * D::SB);
+        if constexpr (D::ODD) {
+            put(D::edge_slot(true, b), (D::PA - 1) * D::SA + b * D::SB);
+            put(D::edge_slot(false, b), 0 * D::SA + b * D::SB);
+        }
+    }
+}
+template <class LAT>
+__device__ __forceinline__ void pg_fill_tab(pgrid::Ctx &X, int lane, int Ls, int N, const int *__restrict__ pgb, const double *__restrict__ cb,
+                                            const double *__restrict__ sb) {
+    if constexpr (LAT::DIS) {
+        pg_fill_col<LAT, 0>(lane, Ls, N, pgb, cb, sb);
+        pg_fill_col<LAT, 1>(lane, Ls, N, pgb, cb, sb);
+        pg_fill_col<LAT, 2>(lane, Ls, N, pgb, cb, sb);
+        pg_fill_col<LAT, 3>(lane, Ls, N, pgb, cb, sb);
+        X.tab = pg_dtab;
     }
 }
 
@@ -101,7 +138,8 @@ __device__ __forceinline__ void series_lean(double (&Pacc)[NS], double (&Qacc)[N
 // residual update instead (kernels of cg_fast_shared.inc: the same contract).
 template <class LAT>
 __global__ void __launch_bounds__(2 * LAT::NW * WAVE) k_kpm_cheb_pg(double2 *__restrict__ nu, KpmDev K, int N, int Ls, int Lo2, const CgState *state,
-                                                          double *__restrict__ rz_part, int nrz, int Ltau, const double *__restrict__ rr_part) {
+                                                          double *__restrict__ rz_part, int nrz, int Ltau, const double *__restrict__ rr_part,
+                                                          const int *__restrict__ pgb) {
     constexpr int NS = LAT::NS, NW = LAT::NW, NT = NW * WAVE;      // NT threads hold the real parts, NT the imaginary parts (wv = 0 / 1)
     __shared__ double xch[2][NS * NT];
     __shared__ double xbuf[2][LAT::XB2_DOUBLES];                    // (several wavefronts per slice: the patch edges through LDS, pgrid_dev.h; two buffers per part: a series sweeps in ONE direction, a barrier separates the two series)
@@ -150,7 +188,8 @@ __global__ void __launch_bounds__(2 * LAT::NW * WAVE) k_kpm_cheb_pg(double2 *__r
     }
     double *u = reinterpret_cast<double *>(nu + ((size_t)rhs * Lo2 + w) * N);
     const bool act = lane < LAT::lanes(Ls);
-    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, V.cbar[0], V.sbar[0], xbuf[wv], 1);
+    pgrid::Ctx X = LAT::make_ctx(lane, Ls, V.cbar[0], V.sbar[0], xbuf[wv], 1);
+    pg_fill_tab<LAT>(X, lane, Ls, N, pgb, V.cbar, V.sbar);
     const double a = V.a * X.ks, b = V.b;
     int site[NS];
     double e1[NS], vin[NS], Pa[NS], Qa[NS];
@@ -210,7 +249,7 @@ __device__ __forceinline__ double pg_reduce_partials(const double *p, int n, int
 // previous iteration formed p = P^-1 r + beta p and applied x += alpha p in its epilogue, dft_mfma.hip: PxFuse): this kernel reads p (own slices
 // + two halo slices) and exp(-dtau V), writes z and the p.z partials and keeps the scalar state machine; no P^-1 r, no p_old, no p_new.
 template <class LAT, bool PX>
-__global__ void __launch_bounds__(LAT::NW * WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int parity, int Ls, int Tmax) {
+__global__ void __launch_bounds__(LAT::NW * WAVE) k_cg_ap_pg(CgBufs B, ModelDev m, int parity, int Ls, int Tmax, const int *__restrict__ pgb) {
     constexpr int NS = LAT::NS, NW = LAT::NW;
     __shared__ double xbuf[LAT::XB_DOUBLES];
     __shared__ double red[NW];
@@ -260,7 +299,8 @@ __global__ void __launch_bounds__(LAT::NW * WAVE) k_cg_ap_pg(CgBufs B, ModelDev 
     double *z = B.z + (size_t)rhs * ndim;
     const double *Ech = m.E + (size_t)(rhs % m.nchains) * m.E_chain_stride;
     const bool act = lane < LAT::lanes(Ls);
-    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni, xbuf);
+    pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni, xbuf);
+    pg_fill_tab<LAT>(X, lane, Ls, N, pgb, m.c, m.s);
     int site[NS];
     bool dot[NS];
 #pragma unroll
@@ -350,7 +390,8 @@ __global__ void __launch_bounds__(LAT::NW * WAVE) k_cg_ap_pg(CgBufs B, ModelDev 
 // chunk of Tmax slices of a vector; the arithmetic of the generic k_mul (kernels.hip) with register sweeps:
 //   (M v)(t)   = v(t) - sg(t) c^k S(E(t) v(t-1))          (M^T v)(t) = v(t) - sg(t+1) c^k E(t+1) S^T(v(t+1))
 template <class LAT, int WHICH>
-__global__ void __launch_bounds__(LAT::NW * WAVE) k_mul_pg(double *__restrict__ y, const double *__restrict__ v, ModelDev m, int Ls, int Tmax) {
+__global__ void __launch_bounds__(LAT::NW * WAVE) k_mul_pg(double *__restrict__ y, const double *__restrict__ v, ModelDev m, int Ls, int Tmax,
+                                                           const int *__restrict__ pgb) {
     constexpr int NS = LAT::NS;
     __shared__ double xbuf[LAT::XB_DOUBLES];
     const int N = m.N, L = m.L, lane = threadIdx.x;
@@ -362,7 +403,8 @@ __global__ void __launch_bounds__(LAT::NW * WAVE) k_mul_pg(double *__restrict__ 
     double *yy = y + vec;
     const double *Ech = m.E + (size_t)(vecno % m.nchains) * m.E_chain_stride;
     const bool act = lane < LAT::lanes(Ls);
-    const pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni, xbuf);
+    pgrid::Ctx X = LAT::make_ctx(lane, Ls, m.c_uni, m.s_uni, xbuf);
+    pg_fill_tab<LAT>(X, lane, Ls, N, pgb, m.c, m.s);
     int site[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) site[q] = LAT::site_of(lane, q, Ls);
@@ -446,7 +488,17 @@ int pg_check(const char *what) {
 // Can the per-frequency recursion of this handle run in the patch layout?  (ELPH_NO_PG=1: the generic kernel, the A/B — read per call)
 bool elph_pg_cheb_usable(const elph_handle_s *h) {
     const char *e = getenv("ELPH_NO_PG");
-    return h->pg_L > 0 && h->pg_uniform && h->kind == ELPH_MODEL_HOLSTEIN && !(e && e[0] == '1');
+    return h->pg_L > 0 && (h->pg_uniform || elph_pg_disorder_ok(h)) && h->kind == ELPH_MODEL_HOLSTEIN && !(e && e[0] == '1');
+}
+
+// hopping disorder on this handle's patch shape (square lattices whose (cosh, sinh) table fits the LDS: pgrid::patch_takes_disorder; ELPH_PG_DIS=0:
+// the generic kernels — the A/B, read per call)
+bool elph_pg_disorder_ok(const elph_handle_s *h) {
+    const char *e = getenv("ELPH_PG_DIS");
+    // (measured, profiles/r06/hopping_disorder_patch_kernels_with_tables.log: 18 x 18 — lane-program mat-vec, only the recursion would move — loses to
+    //  the Re / Im recursion through the LDS slab, 214 -> 252 us at 96 right-hand sides; 20 x 20 and 22 x 22, the same family, gain: 241 -> 195, 313 -> 266)
+    if (h->fast && h->pg_L == 18) return false;
+    return h->pg_L > 0 && h->pg_kind == 1 && h->d_pg_bond && pgrid::patch_takes_disorder(h->pg_PX, h->pg_PY, h->pg_NW > 1 ? h->pg_NW : 1) && !(e && e[0] == '0');
 }
 
 // nu (d_nu: [nrhs][Lo2][N] complex) <- P^-1 in frequency space, every (right-hand side, frequency) a block of two wavefronts
@@ -455,10 +507,20 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_p
     const int Lo2 = (int)((h->L + 1) / 2), N = (int)h->N, Ls = h->pg_L;
     if (rz_part && 2 * Lo2 > nrz) { elph_set_error("k_kpm_cheb_pg: %d r.z slots needed, %d available", 2 * Lo2, nrz); return ELPH_E_STATE; }
     const dim3 grid((unsigned)nrhs, (unsigned)Lo2);
-#define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, dim3(2 * LAT::NW * WAVE), 0, h->stream, h->d_nu, K, N, Ls, Lo2, st, rz_part, nrz, (int)h->L, rr_part)
+#define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, dim3(2 * LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, h->d_nu, K, N, Ls, Lo2, st, rz_part, nrz, (int)h->L, rr_part, h->d_pg_bond)
     const int px = h->pg_PX, py = h->pg_PY;
     const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
-    if (h->pg_kind == 1 && nw > 1) {
+    if (!h->pg_uniform) {        // hopping disorder: the table variants (elph_pg_cheb_usable has checked the shape)
+        if (!elph_pg_disorder_ok(h)) { elph_set_error("k_kpm_cheb_pg: hopping disorder on a patch shape without a table variant"); return ELPH_E_UNSUPPORTED; }
+        if (nw == 2) PG_CHEB(M22_2D);
+        else if (nw == 3) PG_CHEB(M22_3D);
+        else if (nw == 4) PG_CHEB(M22_4D);
+        else if (nw == 5) PG_CHEB(M22_5D);
+        else if (px == 4) PG_CHEB(SQ44D);
+        else if (py == 6) PG_CHEB(SQ26D);
+        else PG_CHEB(SQ24D);
+    }
+    else if (h->pg_kind == 1 && nw > 1) {
         if (px == 2 && py == 2 && nw == 2) PG_CHEB(M22_2);
         else if (px == 2 && py == 2 && nw == 3) PG_CHEB(M22_3);
         else if (px == 2 && py == 2 && nw == 5) PG_CHEB(M22_5);
@@ -501,7 +563,7 @@ bool elph_pg_ap_usable(const elph_handle_s *h) {
 }
 
 int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs, int parity, bool fused) {
-    if (!m.uniform) return ELPH_E_UNSUPPORTED;
+    if (!m.uniform && !elph_pg_disorder_ok(h)) return ELPH_E_UNSUPPORTED;
     if (B.npap != (int)h->L) { elph_set_error("k_cg_ap_pg: one p.z slot per time slice expected"); return ELPH_E_UNSUPPORTED; }
     // slices per wave: the SHORTEST chunk whose waves still fit the chip in one round — 1024 SIMDs x the waves a SIMD holds of this
     // instantiation (one for 12 or 16 sites per lane: 256 + ~100 registers with the prefetched slice; two for 8) — a second, partly
@@ -519,12 +581,21 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     const int Ls = h->pg_L;
 #define PG_AP(LAT)                                                                                                        \
     do {                                                                                                                  \
-        if (fused) hipLaunchKernelGGL((k_cg_ap_pg<LAT, true>), grid, dim3(LAT::NW * WAVE), 0, h->stream, B, m, parity, Ls, T);              \
-        else hipLaunchKernelGGL((k_cg_ap_pg<LAT, false>), grid, dim3(LAT::NW * WAVE), 0, h->stream, B, m, parity, Ls, T);                \
+        if (fused) hipLaunchKernelGGL((k_cg_ap_pg<LAT, true>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, B, m, parity, Ls, T, h->d_pg_bond);              \
+        else hipLaunchKernelGGL((k_cg_ap_pg<LAT, false>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, B, m, parity, Ls, T, h->d_pg_bond);                \
     } while (0)
     const int px = h->pg_PX, py = h->pg_PY;
     const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
-    if (h->pg_kind == 1 && nw > 1) {
+    if (!m.uniform) {
+        if (nw == 2) PG_AP(M22_2D);
+        else if (nw == 3) PG_AP(M22_3D);
+        else if (nw == 4) PG_AP(M22_4D);
+        else if (nw == 5) PG_AP(M22_5D);
+        else if (px == 4) PG_AP(SQ44D);
+        else if (py == 6) PG_AP(SQ26D);
+        else PG_AP(SQ24D);
+    }
+    else if (h->pg_kind == 1 && nw > 1) {
         if (px == 2 && py == 2 && nw == 2) PG_AP(M22_2);
         else if (px == 2 && py == 2 && nw == 3) PG_AP(M22_3);
         else if (px == 2 && py == 2 && nw == 5) PG_AP(M22_5);
@@ -564,7 +635,7 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
 bool elph_pg_mul_usable(const elph_handle_s *h) { return elph_pg_ap_usable(h); }
 
 int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, const double *vS, int nvec) {
-    if (!m.uniform) return ELPH_E_UNSUPPORTED;
+    if (!m.uniform && !elph_pg_disorder_ok(h)) return ELPH_E_UNSUPPORTED;
     const int L = (int)h->L, Ls = h->pg_L;
     int T = 20;
     for (int c : {1, 2, 4, 5, 8, 10, 16, 20}) { if ((long long)nvec * ((L + c - 1) / c) <= 2048) { T = c; break; } }
@@ -572,13 +643,22 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
     const dim3 grid((unsigned)(nvec * ((L + T - 1) / T)));
 #define PG_MUL(LAT)                                                                                                       \
     do {                                                                                                                  \
-        if (which == 0) hipLaunchKernelGGL((k_mul_pg<LAT, 0>), grid, dim3(LAT::NW * WAVE), 0, h->stream, yS, vS, m, Ls, T);              \
-        else if (which == 1) hipLaunchKernelGGL((k_mul_pg<LAT, 1>), grid, dim3(LAT::NW * WAVE), 0, h->stream, yS, vS, m, Ls, T);         \
-        else hipLaunchKernelGGL((k_mul_pg<LAT, 2>), grid, dim3(LAT::NW * WAVE), 0, h->stream, yS, vS, m, Ls, T);                         \
+        if (which == 0) hipLaunchKernelGGL((k_mul_pg<LAT, 0>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, yS, vS, m, Ls, T, h->d_pg_bond);              \
+        else if (which == 1) hipLaunchKernelGGL((k_mul_pg<LAT, 1>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, yS, vS, m, Ls, T, h->d_pg_bond);         \
+        else hipLaunchKernelGGL((k_mul_pg<LAT, 2>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, yS, vS, m, Ls, T, h->d_pg_bond);                         \
     } while (0)
     const int px = h->pg_PX, py = h->pg_PY;
     const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
-    if (h->pg_kind == 1 && nw > 1) {
+    if (!m.uniform) {
+        if (nw == 2) PG_MUL(M22_2D);
+        else if (nw == 3) PG_MUL(M22_3D);
+        else if (nw == 4) PG_MUL(M22_4D);
+        else if (nw == 5) PG_MUL(M22_5D);
+        else if (px == 4) PG_MUL(SQ44D);
+        else if (py == 6) PG_MUL(SQ26D);
+        else PG_MUL(SQ24D);
+    }
+    else if (h->pg_kind == 1 && nw > 1) {
         if (px == 2 && py == 2 && nw == 2) PG_MUL(M22_2);
         else if (px == 2 && py == 2 && nw == 3) PG_MUL(M22_3);
         else if (px == 2 && py == 2 && nw == 5) PG_MUL(M22_5);

@@ -31,6 +31,10 @@ struct Ctx {
     double *xb;
     int nt, me;              // threads of the slice; this thread's index in it
     int bmask;               // 3: four buffers; 1: the reverse sweeps share the forward sweeps' two (a kernel whose directions never alternate without a barrier: the Chebyshev series)
+    // HOPPING DISORDER (round 6; square patches, Sq<..., UNI = false>): the (cosh, sinh) of the bonds this thread touches, one entry per bond, at
+    // tab[(col_base<COL> + slot) nt + me] (LDS, filled by the kernel from the bond tables through the site -> bond map of the colouring; ColDims); a
+    // colour is then v_i <- c v_i + s v_j with the bond's own pair, nothing is factored out (ks = 1).  nullptr: uniform hopping.
+    const double2 *tab;
 };
 
 template <int PX, int PY>
@@ -45,7 +49,7 @@ template <int PX, int PY>
 __device__ __forceinline__ Ctx ctx(int lane, int L, double c, double s) {
     const int GX = L / PX, GY = L / PY;
     Ctx X;
-    X.xb = nullptr; X.nt = WAVE_; X.me = lane; X.bmask = 3;
+    X.xb = nullptr; X.nt = WAVE_; X.me = lane; X.bmask = 3; X.tab = nullptr;
     X.th = s / c; X.ks = (c * c) * (c * c);
     if (lane < GX * GY) {
         const int x = lane % GX, y = lane / GX;
@@ -58,14 +62,34 @@ __device__ __forceinline__ Ctx ctx(int lane, int L, double c, double s) {
     return X;
 }
 
-// one colour of the checkerboard on the PX x PY values of a lane: v <- (I + th P_colour) v
-template <int PX, int PY, int COL, int BUF = 0>
+// The geometry of one colour on a PX x PY patch, and where its bonds sit in the (cosh, sinh) table of the disorder variant: ONE entry per bond a
+// thread touches — a pair inside the patch is one entry, an edge site has the entry of its crossing bond (4 x 4: 8 + 12 + 8 + 12 = 40 entries
+// where one per site and colour would be 64 — 40 KB per wavefront instead of 64: four blocks per CU again).
+template <int PX, int PY, int COL> struct ColDims {
+    static constexpr bool ALONG_X = (COL < 2), ODD = (COL & 1);
+    static constexpr int PA = ALONG_X ? PX : PY, PB = ALONG_X ? PY : PX, SA = ALONG_X ? 1 : PX, SB = ALONG_X ? PX : 1;
+    static constexpr int INNER = ODD ? PB * (PA / 2 - 1) : PB * (PA / 2);        // pairs inside the patch
+    static constexpr int ENTRIES = ODD ? INNER + 2 * PB : INNER;
+    __host__ __device__ static constexpr int pair_slot(int a, int b) { return ODD ? b * (PA / 2 - 1) + (a - 1) / 2 : b * (PA / 2) + a / 2; }
+    __host__ __device__ static constexpr int edge_slot(bool hi, int b) { return INNER + (hi ? 0 : PB) + b; }
+};
+template <int PX, int PY, int COL> __host__ __device__ constexpr int col_base() {
+    if constexpr (COL == 0) return 0;
+    else return col_base<PX, PY, COL - 1>() + ColDims<PX, PY, COL - 1>::ENTRIES;
+}
+template <int PX, int PY> __host__ __device__ constexpr int tab_entries() { return col_base<PX, PY, 3>() + ColDims<PX, PY, 3>::ENTRIES; }
+
+// one colour of the checkerboard on the PX x PY values of a lane: v <- (I + th P_colour) v   (UNI = false: v_i <- c v_i + s v_j per bond, Ctx::tab)
+template <int PX, int PY, int COL, int BUF = 0, bool UNI = true>
 __device__ __forceinline__ void colour(double (&v)[PX * PY], const Ctx &X) {
     constexpr bool ALONG_X = (COL < 2), ODD = (COL & 1);
     constexpr int PA = ALONG_X ? PX : PY;        // patch extent along the colour's direction
     constexpr int PB = ALONG_X ? PY : PX;        // ... and across it
     constexpr int SA = ALONG_X ? 1 : PX;         // register strides along / across
     constexpr int SB = ALONG_X ? PX : 1;
+    // (cosh, sinh) of the bond in table slot `slot` of this colour
+    using D = ColDims<PX, PY, COL>;
+    auto cs = [&X](int slot) { return UNI ? make_double2(1.0, X.th) : X.tab[(size_t)(col_base<PX, PY, COL>() + slot) * X.nt + X.me]; };
     if constexpr (ODD) {
         // the edge pairs cross to the neighbouring patches: my last column pairs with the first column of the patch above, my first
         // column with the last column of the patch below
@@ -99,13 +123,25 @@ __device__ __forceinline__ void colour(double (&v)[PX * PY], const Ctx &X) {
 #pragma unroll
             for (int a = 1; a + 1 < PA; a += 2) {
                 const int i = a * SA + b * SB, j = i + SA;
-                const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
-                v[i] = ni; v[j] = nj;
+                if constexpr (UNI) {
+                    const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
+                    v[i] = ni; v[j] = nj;
+                } else {
+                    const double2 t = cs(D::pair_slot(a, b));
+                    const double ni = t.x * v[i] + t.y * v[j], nj = t.x * v[j] + t.y * v[i];
+                    v[i] = ni; v[j] = nj;
+                }
             }
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
-            v[(PA - 1) * SA + b * SB] += X.th * fu[b];
-            v[0 * SA + b * SB] += X.th * fd[b];
+            if constexpr (UNI) {
+                v[(PA - 1) * SA + b * SB] += X.th * fu[b];
+                v[0 * SA + b * SB] += X.th * fd[b];
+            } else {
+                const double2 tu = cs(D::edge_slot(true, b)), td = cs(D::edge_slot(false, b));
+                v[(PA - 1) * SA + b * SB] = tu.x * v[(PA - 1) * SA + b * SB] + tu.y * fu[b];
+                v[0 * SA + b * SB] = td.x * v[0 * SA + b * SB] + td.y * fd[b];
+            }
         }
     } else {
 #pragma unroll
@@ -113,17 +149,23 @@ __device__ __forceinline__ void colour(double (&v)[PX * PY], const Ctx &X) {
 #pragma unroll
             for (int a = 0; a + 1 < PA; a += 2) {
                 const int i = a * SA + b * SB, j = i + SA;
-                const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
-                v[i] = ni; v[j] = nj;
+                if constexpr (UNI) {
+                    const double ni = v[i] + X.th * v[j], nj = v[j] + X.th * v[i];
+                    v[i] = ni; v[j] = nj;
+                } else {
+                    const double2 t = cs(D::pair_slot(a, b));
+                    const double ni = t.x * v[i] + t.y * v[j], nj = t.x * v[j] + t.y * v[i];
+                    v[i] = ni; v[j] = nj;
+                }
             }
     }
 }
 
 // the whole checkerboard (REVERSE: its transpose — the colours in reverse order; every colour is symmetric), WITHOUT the factor c^4
-template <int PX, int PY, bool REVERSE>
+template <int PX, int PY, bool REVERSE, bool UNI = true>
 __device__ __forceinline__ void sweep(double (&v)[PX * PY], const Ctx &X) {
-    if constexpr (!REVERSE) { colour<PX, PY, 0>(v, X); colour<PX, PY, 1, 0>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 3, 1>(v, X); }
-    else                    { colour<PX, PY, 3, 3>(v, X); colour<PX, PY, 2>(v, X); colour<PX, PY, 1, 2>(v, X); colour<PX, PY, 0>(v, X); }
+    if constexpr (!REVERSE) { colour<PX, PY, 0, 0, UNI>(v, X); colour<PX, PY, 1, 0, UNI>(v, X); colour<PX, PY, 2, 0, UNI>(v, X); colour<PX, PY, 3, 1, UNI>(v, X); }
+    else                    { colour<PX, PY, 3, 3, UNI>(v, X); colour<PX, PY, 2, 0, UNI>(v, X); colour<PX, PY, 1, 2, UNI>(v, X); colour<PX, PY, 0, 0, UNI>(v, X); }
 }
 
 // ---- honeycomb: L x L two-site cells (site = 2 (x + L y) + orbital) in the reference's colouring [A-B of a cell | B(x,y)-A(x+1,y) |
@@ -244,8 +286,12 @@ __device__ __forceinline__ void tdiag(double (&v)[PX * PY], const Ctx &X) {
 
 // ---- the two lattices behind one interface: NS registers per vector, site(), ctx(), sweep<REVERSE>() -----------------------------------
 // NW: wavefronts per time slice (1: the whole slice in one wavefront, edges by ds_bpermute; > 1: NT = 64 NW threads, edges through LDS)
-template <int PX_, int PY_, int NW_ = 1> struct Sq {
+// UNI_ = false: hopping disorder — a (cosh, sinh) pair per bond from a table in LDS (Ctx::tab; TAB_BYTES of dynamic LDS per block)
+template <int PX_, int PY_, int NW_ = 1, bool UNI_ = true> struct Sq {
     static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_, NW = NW_;
+    static constexpr bool DIS = !UNI_;
+    static constexpr int NCOL = 4;
+    static constexpr size_t TAB_BYTES = UNI_ ? 0 : (size_t)tab_entries<PX_, PY_>() * NW_ * WAVE_ * sizeof(double2);
     static constexpr int XB_DOUBLES = (NW_ > 1) ? 4 * 2 * ((PX_ > PY_) ? PX_ : PY_) * NW_ * WAVE_ : 1;      // the four exchange buffers of one slice
     __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
     __host__ __device__ static int site_of(int lane, int q, int L) { return site<PX, PY>(lane, q, L); }
@@ -253,12 +299,16 @@ template <int PX_, int PY_, int NW_ = 1> struct Sq {
     __device__ static Ctx make_ctx(int lane, int L, double c, double s, double *xb = nullptr, int bmask = 3) {
         Ctx X = ctx<PX, PY>(lane, L, c, s);
         if (NW > 1) { X.xb = xb; X.nt = NW * WAVE_; X.bmask = bmask; }
+        if (DIS) { X.ks = 1.0; X.th = 0.0; }
         return X;
     }
-    template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) { sweep<PX, PY, REVERSE>(v, X); }
+    template <bool REVERSE> __device__ static void apply(double (&v)[NS], const Ctx &X) { sweep<PX, PY, REVERSE, UNI_>(v, X); }
 };
 template <int PX_, int PY_, int NW_ = 1> struct Hc {
     static constexpr int PX = PX_, PY = PY_, NS = 2 * PX_ * PY_, NW = NW_;
+    static constexpr bool DIS = false;
+    static constexpr int NCOL = 3;
+    static constexpr size_t TAB_BYTES = 0;
     static constexpr int XB_DOUBLES = (NW_ > 1) ? 4 * 2 * ((PX_ > PY_) ? PX_ : PY_) * NW_ * WAVE_ : 1, XB2_DOUBLES = (NW_ > 1) ? XB_DOUBLES / 2 : 1;
     __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
     __host__ __device__ static int site_of(int lane, int q, int L) { return hsite<PX, PY>(lane, q, L); }
@@ -277,6 +327,9 @@ template <int PX_, int PY_, int NW_ = 1> struct Hc {
 inline bool pick_patch(int L, int *PX, int *PY);
 template <int PX_, int PY_> struct Tri {
     static constexpr int PX = PX_, PY = PY_, NS = PX_ * PY_, NW = 1, XB_DOUBLES = 1, XB2_DOUBLES = 1;
+    static constexpr bool DIS = false;
+    static constexpr int NCOL = 6;
+    static constexpr size_t TAB_BYTES = 0;
     __host__ __device__ static int lanes(int L) { return (L / PX) * (L / PY); }
     __host__ __device__ static int site_of(int lane, int q, int L) { return site<PX, PY>(lane, q, L); }
     __device__ static Ctx make_ctx(int lane, int L, double c, double s, double * = nullptr, int = 3) {
@@ -335,6 +388,14 @@ inline bool pick_patch_mw(int L, int *PX, int *PY, int *NW) {
         *PX = 2; *PY = 2; *NW = nw; return true;
     }
     return false;
+}
+
+// Hopping disorder in the patch layout: the shapes with a table variant — 2 x 6 and 2 x 4 patches on one wavefront (L = 24, 20; 4 x 4 exists for the
+// A/B), 2 x 2 patches on two to five (L = 22, 26, 34; disordered 28, 30 and 32); the others (L = 18, 36 and beyond) keep the generic kernels when the
+// hopping is disordered.
+inline bool patch_takes_disorder(int px, int py, int nw) {
+    if (nw <= 1) return (px == 4 && py == 4) || (px == 2 && (py == 6 || py == 4));
+    return px == 2 && py == 2 && nw >= 2 && nw <= 5;      // (12 entries per thread: 24 / 36 / 48 / 60 KB; four wavefronts: disordered 28 x 28, 30 x 30 and 32 x 32, elph_api.hip: detect_square; five: 34 x 34)
 }
 
 // The patch shape for an L x L lattice (0: none — the lattice keeps the generic kernels).

@@ -422,15 +422,35 @@ def test_kpm_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["B", "C", "g", "h"])
+def _pg_info(m):
+    from elphdynamics_amd import _lib
+    v = [C.c_int() for _ in range(5)]
+    _lib.check(_lib.load().elph_bench_pg_info(m._h, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)      # (kind, px, py, wavefronts per slice, disorder tables)
+
+
+@pytest.mark.parametrize("tag", ["B", "C", "g", "h", "G", "i", "k", "j", "l22", "l26", "l30", "l34", "l36"])
 def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
     """Hopping disorder (assign_t! with a standard deviation, HolsteinModels.jl:427-447): the register-exchange Chebyshev kernels
     carry one (cosh, sinh) per site and colour instead of two scalars — the row layout on 16 x 16, one site per lane on 8 x 8.
-    g, h (24 x 24 square, 18 x 18 honeycomb cells): the PGRID kernels know uniform hopping only — these lattices must fall back to the
-    generic kernels, and do."""
+    Square lattices in the patch layout (round 6): g, k (24, 20: 2 x 6, 2 x 4 patches on one wavefront), l22, l26, l34 (2 x 2 patches on two, three,
+    five) and G, j, l30 (32, 28, 30: as 2 x 2 patches on four wavefronts when the hopping is disordered) keep it — a (cosh, sinh) pair per bond from
+    a table in LDS (pgrid_dev.h: Sq<..., UNI = false>) — asserted taken; l36 (no table variant), i (18 x 18: measured slower) and h (honeycomb) keep
+    the other kernels."""
     from elphdynamics_amd import configs, models, preconditioners as pc
     m = configs.make_model(tag, tol=1e-5, t_stddev=0.1)
+    if tag in ("g", "G", "k", "j", "l22", "l26", "l30", "l34"):
+        assert _pg_info(m)[0] == 1 and _pg_info(m)[4] == 1, _pg_info(m)
+        if tag in ("G", "j", "l30"):
+            assert _pg_info(m)[1:4] == (2, 2, 4)        # (disordered 32 x 32, 28 x 28, 30 x 30: 2 x 2 patches on four wavefronts instead of the uniform lattice's one-wavefront shape)
+    elif tag in ("l36", "h", "i"):
+        assert _pg_info(m)[4] == 0, _pg_info(m)
     om = _oracle_model(oracle, m)
+    from elphdynamics_amd import synth
+    v, y = synth.randn(177, m.Ndim), np.empty(m.Ndim)
+    for fn, ofn in ((models.mulM_, oracle.mulM), (models.mulMt_, oracle.mulMT), (models.mulMtM_, oracle.mulMTM)):
+        fn(y, m, v)
+        assert rel(y, ofn(om, v)) < 1e-13
     P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
     oP = oracle.make_kpm(om, n=20, buf=0.05, c1=1.0, c2=1.0)
     rng = np.random.default_rng(13)
@@ -447,6 +467,33 @@ def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
     xo, ito, histo = oracle.cg_solve(om, b, tol=1e-5, maxiter=10000, P=oP, history=True)
     assert it == ito and rel(x, xo) < 1e-8
     m.close()
+
+
+@pytest.mark.parametrize("tag,nchains,per", [("K", 8, 2), ("G40", 4, 2), ("L26", 8, 2)])
+def test_hopping_disorder_in_the_patch_layout_batched(tag, nchains, per, monkeypatch):
+    """The preconditioned BATCH iteration on a disordered square lattice in the patch layout (24 x 24, 32 x 32, 26 x 26 on three wavefronts; tables of
+    (cosh, sinh) per bond in LDS): the p/x-fused pipeline around the table variants of k_cg_ap_pg / k_kpm_cheb_pg against the generic LDS kernels
+    (ELPH_PG_DIS=0) — iteration counts within one, solutions of two tol = 1e-8 solves to 1e-9, the patch form and the fused form asserted taken."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELPH_PG_DIS", mode)
+        m = configs.make_model(tag, tol=1e-8, t_stddev=0.1)
+        assert _pg_info(m)[4] == int(mode)
+        nrhs = nchains * per
+        X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=8800 + c) for c in range(nchains)])
+        models.update_model_chains_(m, X)
+        P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+        pc.setup_chains_(P, rng=np.random.default_rng(15))
+        B = np.stack([synth.randn(8900 + r, m.Ndim) for r in range(nrhs)])
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any()
+        out[mode] = (Xs, it, _px_fused(m))
+        m.close()
+    assert out["1"][2] is True, "the p/x-fused form was not taken"
+    assert np.abs(out["0"][1] - out["1"][1]).max() <= 1
+    assert rel(out["1"][0], out["0"][0]) < 1e-9
 
 
 @pytest.mark.parametrize("ltau", [160, 80])
@@ -1471,6 +1518,7 @@ def test_px_fused_iteration_generic_family(oracle, tag, nchains, per, no_fast, d
     if no_fast:
         monkeypatch.setenv("ELPH_NO_FAST", "1")
     monkeypatch.setenv("ELPH_PG_MW", "0")      # (l22, l26 have multi-wavefront patch kernels since later in round 6: this test is about the LDS kernels)
+    monkeypatch.setenv("ELPH_PG_DIS", "0")     # (... and a disordered 24 x 24 lattice the table variant of the patch kernels)
     m = configs.make_model(tag, tol=1e-8, t_stddev=disorder)
     nrhs = nchains * per
     if nchains > 1 and m.kind == models.SSH:
