@@ -83,6 +83,7 @@ CONFIGS = {
     "XT24": ("holstein", 1, 24, lat.TRIANGULAR_BONDS, 16.0, 0.1),   # triangular 24 x 24, Ltau = 160: 92 160 unknowns
     # a long time axis: 1280 slices (beyond the direct-DFT tables: dft_big.hip)
     "l": ("holstein", 1, 4, lat.SQUARE_BONDS, 128.0, 0.1),
+    "l800": ("holstein", 1, 4, lat.SQUARE_BONDS, 80.0, 0.1),        # 800 time slices: between the matrix-core transforms (<= 400) and 1024 — the Cooley-Tukey split since round 6
 }
 
 

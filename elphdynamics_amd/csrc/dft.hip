@@ -276,7 +276,20 @@ int elph_dft_inv_plain(elph_handle_s *h, double *outS, const double2 *nu, int N,
 
 // host: build the four twiddle tables with exact index reduction
 int elph_dft_build_tables(elph_handle_s *h) {
-    if (h->L > 1024) return elph_dft_big_build_tables(h);      // long axes: one Cooley-Tukey split instead of O(L^2) tables (dft_big.hip)
+    {   // long axes: one Cooley-Tukey split instead of O(L^2) tables (dft_big.hip) — always beyond 1024 slices; from 401 (where the matrix-core
+        // forms end) to 1024 when the length has a divisor >= 4 below its square root: measured (round 6, profiles/r06/long_time_axes_split_from_401.log,
+        // 16 x 16 sites, KPM apply of 16 right-hand sides): 480 slices 298 -> 219 us, 512: 350 -> 238, 800: 815 -> 394, 1000: 1328 -> 512 against the
+        // scalar-twiddle kernels.  ELPH_DFT_BIG_FROM=n: the split for every length beyond n instead (A/B)
+        const char *e = getenv("ELPH_DFT_BIG_FROM");
+        bool big = h->L > 1024;
+        if (e) big = h->L > atoll(e);
+        else if (h->L > 400 && !big) {
+            long long best = 0;
+            for (long long f = 2; f * f <= h->L; ++f) if (h->L % f == 0) best = f;
+            big = best >= 4;
+        }
+        if (big) return elph_dft_big_build_tables(h);
+    }
     const int L = (int)h->L, Lo2 = (L + 1) / 2, Lh = L / 2 + 1;
     const int Lp = dft_pad(L, 2 * DFT_TC), Kp2 = dft_pad(Lo2, 2 * DFT_KC), Kph = dft_pad(Lh, 2 * DFT_KC);
     const double2 zero = make_double2(0.0, 0.0);

@@ -16,6 +16,7 @@
 // L_tau <= ~200); it runs full complex transforms and takes the half spectrum afterwards.
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "elph_internal.h"
@@ -166,6 +167,118 @@ __global__ void __launch_bounds__(WAVE) k_big_store(double *__restrict__ out, co
     }
 }
 
+// ---- round 6: the two steps register-blocked and fused with their neighbours ---------------------------------------------------------------
+// The kernels above produce ONE output row per wave: every input row of a sub-transform is read L1 (L2) times, and the transform is four
+// kernels with full complex intermediates (load | step 1 | step 2 | take).  Here a wave produces BT output rows of its sub-transform at once —
+// the input row is loaded once per BT outputs and meets BT wave-uniform twiddles (32 fma per 16-byte load at BT = 8: arithmetic, not
+// re-reads, bounds the step) — and the neighbours ride along: step 1 takes its input straight from the caller's array (forward: the real
+// vector times Theta; inverse: the half spectrum with its mirror image), step 2 writes the caller's array (forward: the half spectrum only —
+// rows beyond it are not computed; inverse: Re(conj(Theta) y) and the r.out partials).  Two kernels and one complex intermediate per
+// transform.  Per output element the sums run in the same order with the same expressions as above.
+constexpr int BT = 8;
+
+// step 1:  Z[c][b] = TW[(c b) mod L]^(+-1) sum_a W1[c][a]^(+-1) u[L2 a + b]   for c = c0 .. c0 + BT - 1
+//   forward: u[t] = (TWISTED ? Theta_t : 1) v[t] (v real);  inverse: u[k] = the full spectrum out of the half one (nu[k], k < K; else conj of its mirror)
+// grid: x = site tile, y = (c group) * L2 + b, z = vector
+template <bool INV, bool TWISTED>
+__global__ void __launch_bounds__(WAVE) k_big_s1(double2 *__restrict__ Z, const double *__restrict__ vreal, const double2 *__restrict__ nu,
+                                                 const double2 *__restrict__ W1, const double2 *__restrict__ TW, const double2 *__restrict__ theta,
+                                                 int N, int L, int L1, int L2, int K) {
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int cg = blockIdx.y / L2, b = blockIdx.y - cg * L2, c0 = cg * BT;
+    const int sc = (s < N) ? s : N - 1;
+    double ax[BT], ay[BT];
+#pragma unroll
+    for (int j = 0; j < BT; ++j) { ax[j] = 0.0; ay[j] = 0.0; }
+    for (int a = 0; a < L1; ++a) {
+        const int t = L2 * a + b;
+        double2 x;
+        if (!INV) {
+            const double xr = vreal[((size_t)blockIdx.z * L + t) * N + sc];
+            if (TWISTED) { const double2 th = theta[t]; x = make_double2(th.x * xr, th.y * xr); }
+            else x = make_double2(xr, 0.0);
+        } else {
+            const double2 *h = nu + (size_t)blockIdx.z * K * N;
+            if (t < K) x = h[(size_t)t * N + sc];
+            else { const int km = TWISTED ? L - 1 - t : L - t; const double2 cc = h[(size_t)km * N + sc]; x = make_double2(cc.x, -cc.y); }
+        }
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            const int c = (c0 + j < L1) ? c0 + j : L1 - 1;
+            const double2 ww = W1[(size_t)c * L1 + a];
+            const double wy = INV ? -ww.y : ww.y;
+            ax[j] += ww.x * x.x - wy * x.y;
+            ay[j] += ww.x * x.y + wy * x.x;
+        }
+    }
+    const size_t base = (size_t)blockIdx.z * L * N;
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+        const int c = c0 + j;
+        if (c < L1 && s < N) {
+            const double2 tw = TW[(int)(((long long)c * b) % L)];
+            const double ty = INV ? -tw.y : tw.y;
+            Z[base + (size_t)(c * L2 + b) * N + s] = make_double2(tw.x * ax[j] - ty * ay[j], tw.x * ay[j] + ty * ax[j]);
+        }
+    }
+}
+
+// step 2:  X[c + L1 d] = scale sum_b W2[d][b]^(+-1) Z[c][b]   for d = d0 .. d0 + BT - 1
+//   forward: written to the half spectrum nu[k], k = c + L1 d < K (rows beyond it are skipped);  inverse: out[t] = Re((TWISTED ? conj(Theta_t) : 1) X[t]),
+//   t = c + L1 d, and — rz_part — the partial sums of rvec . out over this wave's sites in slot t * gridDim.x + site tile
+// grid: x = site tile, y = (d group) * L1 + c, z = vector
+template <bool INV, bool TWISTED>
+__global__ void __launch_bounds__(WAVE) k_big_s2(double2 *__restrict__ nu, double *__restrict__ out, const double2 *__restrict__ Z,
+                                                 const double2 *__restrict__ W2, const double2 *__restrict__ theta, int N, int L, int L1, int L2, int K,
+                                                 double scale, const double *__restrict__ rvec, double *__restrict__ rz_part, int nrz) {
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    const int dg = blockIdx.y / L1, c = blockIdx.y - dg * L1, d0 = dg * BT;
+    if (!INV && c + L1 * d0 >= K) return;                  // forward: the whole group lies beyond the half spectrum
+    const int sc = (s < N) ? s : N - 1;
+    const size_t base = (size_t)blockIdx.z * L * N;
+    double ax[BT], ay[BT];
+#pragma unroll
+    for (int j = 0; j < BT; ++j) { ax[j] = 0.0; ay[j] = 0.0; }
+    for (int b = 0; b < L2; ++b) {
+        const double2 x = Z[base + (size_t)(c * L2 + b) * N + sc];
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            const int d = (d0 + j < L2) ? d0 + j : L2 - 1;
+            const double2 ww = W2[(size_t)d * L2 + b];
+            const double wy = INV ? -ww.y : ww.y;
+            ax[j] += ww.x * x.x - wy * x.y;
+            ay[j] += ww.x * x.y + wy * x.x;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+        const int d = d0 + j, k = c + L1 * d;
+        if (d >= L2) continue;
+        if (!INV) {
+            if (k < K && s < N) nu[((size_t)blockIdx.z * K + k) * N + s] = make_double2(scale * ax[j], scale * ay[j]);
+        } else {
+            const double2 th = TWISTED ? theta[k] : make_double2(1.0, 0.0);
+            const double vx = scale * ax[j], vy = scale * ay[j];
+            const double o = th.x * vx + th.y * vy;        // Re(conj(theta) v)
+            double dot = 0.0;
+            if (s < N) {
+                out[base + (size_t)k * N + s] = o;
+                if (rz_part) dot = rvec[base + (size_t)k * N + s] * o;
+            }
+            if (rz_part) {
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) dot += __shfl_xor(dot, o2, WAVE);
+                if (threadIdx.x == 0) {
+                    const int nst = (int)gridDim.x, slot = k * nst + (int)blockIdx.x, used = L * nst;
+                    double *slots = rz_part + (size_t)blockIdx.z * nrz;
+                    slots[slot] = dot;
+                    for (int q = used + slot; q < nrz; q += used) slots[q] = 0.0;
+                }
+            }
+        }
+    }
+}
+
 int ensure_work(elph_handle_s *h, int N, int nvec) {
     const size_t need = (size_t)nvec * (size_t)h->L * (size_t)N;
     if (need <= h->big_cap) return ELPH_OK;
@@ -236,9 +349,31 @@ void elph_dft_big_free(elph_handle_s *h) {
 }
 
 // nu[vec][k][s], k < K: K = ceil(L/2) (twisted) or L/2 + 1 (plain)
+// Which form: the blocked pair has BT times fewer waves — a batch of one or two right-hand sides does not fill the chip with them and is latency-bound
+// (measured, profiles/r06/long_time_axes_blocked_transforms.log: 16 x 16 sites, 1000 slices, ONE right-hand side 29 -> 40 us per transform; 16: 224 -> 113;
+// 64: 1152 -> 358), so it runs from 16384 one-row waves on.  ELPH_DFT_BIG_BLOCKED=0 / 1: never / always (A/B, tests; read per call)
+static bool blocked_form(const elph_handle_s *h, int N, int nvec) {
+    if (h->big_L2 <= 1) return false;
+    const char *e = getenv("ELPH_DFT_BIG_BLOCKED");
+    if (e) return e[0] != '0';
+    return (long long)nvec * ((N + WAVE - 1) / WAVE) * h->L >= 16384;
+}
+
 int elph_dft_big_fwd(elph_handle_s *h, bool twisted, double2 *nu, const double *vS, int N, int nvec) {
     const int L = (int)h->L, K = twisted ? (L + 1) / 2 : L / 2 + 1;
     RC(ensure_work(h, N, nvec));
+    if (blocked_form(h, N, nvec)) {
+        const int L1 = h->big_L1, L2 = h->big_L2, nst = (N + WAVE - 1) / WAVE;
+        const dim3 g1((unsigned)nst, (unsigned)(((L1 + BT - 1) / BT) * L2), (unsigned)nvec), g2((unsigned)nst, (unsigned)(((L2 + BT - 1) / BT) * L1), (unsigned)nvec);
+        if (twisted) {
+            hipLaunchKernelGGL((k_big_s1<false, true>), g1, dim3(WAVE), 0, h->stream, h->d_big_b, vS, (const double2 *)nullptr, h->d_big_W1, h->d_big_TW, h->d_big_TH, N, L, L1, L2, K);
+            hipLaunchKernelGGL((k_big_s2<false, true>), g2, dim3(WAVE), 0, h->stream, nu, (double *)nullptr, h->d_big_b, h->d_big_W2, h->d_big_TH, N, L, L1, L2, K, 1.0, (const double *)nullptr, (double *)nullptr, 0);
+        } else {
+            hipLaunchKernelGGL((k_big_s1<false, false>), g1, dim3(WAVE), 0, h->stream, h->d_big_b, vS, (const double2 *)nullptr, h->d_big_W1, h->d_big_TW, h->d_big_TH, N, L, L1, L2, K);
+            hipLaunchKernelGGL((k_big_s2<false, false>), g2, dim3(WAVE), 0, h->stream, nu, (double *)nullptr, h->d_big_b, h->d_big_W2, h->d_big_TH, N, L, L1, L2, K, 1.0, (const double *)nullptr, (double *)nullptr, 0);
+        }
+        return big_check("k_big_s1/s2(forward)");
+    }
     const long long total = (long long)nvec * L * N;
     if (twisted) hipLaunchKernelGGL((k_big_load<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_big_a, vS, h->d_big_TH, N, L, total);
     else hipLaunchKernelGGL((k_big_load<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_big_a, vS, h->d_big_TH, N, L, total);
@@ -253,6 +388,22 @@ int elph_dft_big_inv(elph_handle_s *h, bool twisted, double *outS, const double2
     const int L = (int)h->L, K = twisted ? (L + 1) / 2 : L / 2 + 1;
     if (rz_part && nrz < L) { elph_set_error("dft_big: %d partial slots needed, %d available", L, nrz); return ELPH_E_STATE; }
     RC(ensure_work(h, N, nvec));
+    {
+        const int nst = (N + WAVE - 1) / WAVE;
+        if (blocked_form(h, N, nvec) && (!rz_part || nrz >= L * nst)) {
+            const int L1 = h->big_L1, L2 = h->big_L2;
+            const dim3 g1((unsigned)nst, (unsigned)(((L1 + BT - 1) / BT) * L2), (unsigned)nvec), g2((unsigned)nst, (unsigned)(((L2 + BT - 1) / BT) * L1), (unsigned)nvec);
+            const double scale = 1.0 / (double)L;
+            if (twisted) {
+                hipLaunchKernelGGL((k_big_s1<true, true>), g1, dim3(WAVE), 0, h->stream, h->d_big_b, (const double *)nullptr, nu, h->d_big_W1, h->d_big_TW, h->d_big_TH, N, L, L1, L2, K);
+                hipLaunchKernelGGL((k_big_s2<true, true>), g2, dim3(WAVE), 0, h->stream, (double2 *)nullptr, outS, h->d_big_b, h->d_big_W2, h->d_big_TH, N, L, L1, L2, K, scale, rvec, rz_part, nrz);
+            } else {
+                hipLaunchKernelGGL((k_big_s1<true, false>), g1, dim3(WAVE), 0, h->stream, h->d_big_b, (const double *)nullptr, nu, h->d_big_W1, h->d_big_TW, h->d_big_TH, N, L, L1, L2, K);
+                hipLaunchKernelGGL((k_big_s2<true, false>), g2, dim3(WAVE), 0, h->stream, (double2 *)nullptr, outS, h->d_big_b, h->d_big_W2, h->d_big_TH, N, L, L1, L2, K, scale, rvec, rz_part, nrz);
+            }
+            return big_check("k_big_s1/s2(inverse)");
+        }
+    }
     const long long total = (long long)nvec * L * N;
     if (twisted) hipLaunchKernelGGL((k_big_expand<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_big_a, nu, N, L, K, total);
     else hipLaunchKernelGGL((k_big_expand<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->d_big_a, nu, N, L, K, total);

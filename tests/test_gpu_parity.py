@@ -160,13 +160,17 @@ def test_fft_golden(lib, L):
         m.close()
 
 
-@pytest.mark.parametrize("L", [1280, 2048, 1155, 4096, 1031])
-def test_long_time_axis_transforms(lib, L):
+@pytest.mark.parametrize("blocked", ["0", "1"])
+@pytest.mark.parametrize("L", [1280, 2048, 1155, 4096, 1031, 480, 800, 1000, 404, 422, 409, 1024])
+def test_long_time_axis_transforms(lib, L, blocked, monkeypatch):
     """Time axes beyond 1024 slices (dft_big.hip: one Cooley-Tukey split, both factors <= 1024; a prime length — 1031 — runs a
     direct transform; the reference's FFTW plans take any length, TimeFreqFFTs.jl:32-45) against numpy's FFT: the twisted pair,
-    the round trip and fourier_accelerate!."""
+    the round trip and fourier_accelerate!.  Round 6: the split also serves 401 … 1024 slices where the length has a divisor >= 4 below
+    its square root (480, 800, 1000, 404 = 4 x 101, 1024); 422 = 2 x 211 and the prime 409 keep the scalar-twiddle kernels.  blocked: the
+    one-output-row-per-wave kernels of round 4 ("0") and the register-blocked, fused pair k_big_s1 / k_big_s2 ("1": what batches run)."""
     from elphdynamics_amd import _lib
-    N = 3
+    monkeypatch.setenv("ELPH_DFT_BIG_BLOCKED", blocked)
+    N = 3 if L != 800 else 70        # (800: two site tiles, the second ragged)
     rng = np.random.default_rng(L)
     m = RawModel(lib, 0, N, L, np.zeros((0, 2), dtype=np.int64))
     try:
@@ -189,12 +193,15 @@ def test_long_time_axis_transforms(lib, L):
         m.close()
 
 
-def test_long_time_axis_kpm_and_cg_vs_oracle(oracle):
-    """Config l: the 4 x 4 Holstein lattice with 1280 time slices — mat-vec, KPM apply (two-step transforms around the Chebyshev
+@pytest.mark.parametrize("blocked", ["0", "1"])
+@pytest.mark.parametrize("tag,ltau", [("l", 1280), ("l800", 800)])
+def test_long_time_axis_kpm_and_cg_vs_oracle(oracle, tag, ltau, blocked, monkeypatch):
+    """Configs l, l800: the 4 x 4 Holstein lattice with 1280 / 800 time slices — mat-vec, KPM apply (two-step transforms around the Chebyshev
     kernel) and the preconditioned solve against the oracle."""
     from elphdynamics_amd import configs, models, preconditioners as pc, synth
-    m = configs.make_model("l", tol=1e-5)
-    assert m.Ltau == 1280
+    monkeypatch.setenv("ELPH_DFT_BIG_BLOCKED", blocked)
+    m = configs.make_model(tag, tol=1e-5)
+    assert m.Ltau == ltau
     om = _oracle_model(oracle, m)
     v = synth.randn(77, m.Ndim)
     y = np.empty(m.Ndim)
