@@ -244,6 +244,7 @@ static void detect_square(elph_handle_s *h) {
                 for (int64_t n = 1; n < h->nb && uni; ++n) uni = (h->h_c[(size_t)n] == h->h_c[0] && h->h_s[(size_t)n] == h->h_s[0]);
             // (... and 30 x 30, whose 2 x 10 patches have no table variant: 15 x 15 threads on four wavefronts)
             if (!uni && nw == 1 && ((px == 4 && py == 4) || (px == 2 && py == 10)) && !(em && em[0] == '0')) { px = 2; py = 2; nw = ((l / 2) * (l / 2) + 63) / 64; }
+            h->pg_uniform_c = uni && h->kind == ELPH_MODEL_HOLSTEIN;
         }
         if (match_square(h, l, l)) { h->pg_L = l; h->pg_PX = px; h->pg_PY = py; h->pg_kind = 1; h->pg_NW = nw; h->pg_bond = h->sq_bond; }
     }

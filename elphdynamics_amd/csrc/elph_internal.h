@@ -245,6 +245,7 @@ struct elph_handle_s {
     int pg_L = 0, pg_PX = 0, pg_PY = 0;    // even-L square lattice beyond 16 x 16 in the reference's colouring (detect_square): PX x PY sites per lane (pgrid_dev.h)
     int pg_kind = 0;                       // 1: that square lattice; 2: a honeycomb lattice beyond 16 x 16 cells, PX x PY CELLS per lane (detect_honeycomb);
                                            // 3: an even-L triangular lattice of any size (detect_triangular)
+    bool pg_uniform_c = false;             // the model's own hopping table is uniform (known at elph_create; pg_uniform: the averaged one of the KPM set-up)
     bool pg_uniform = false;               // ... and one (cbar, sbar) for every bond
     int hc_L = 0;                          // honeycomb lattice of hc_L x hc_L cells in the reference's colouring (detect_honeycomb); hc12: hc_L == 12
     int hc_LX = 0, hc_LY = 0;              // periodic honeycomb lattice of LX x LY cells recognised: hc_L = LX when LX == LY

@@ -19,7 +19,7 @@ namespace {
 
 using SQ44 = pgrid::Sq<4, 4>; using SQ26 = pgrid::Sq<2, 6>; using SQ24 = pgrid::Sq<2, 4>; using SQ2A = pgrid::Sq<2, 10>; using SQ46 = pgrid::Sq<4, 6>;
 // several wavefronts per slice (round 6): 2 x 2 patches on 2, 3, 5, 6 wavefronts (L = 22, 26, 34, 38), 4 x 4 patches on 2, 3, 4 (L = 40 ... 64)
-using M22_2 = pgrid::Sq<2, 2, 2>; using M22_3 = pgrid::Sq<2, 2, 3>; using M22_5 = pgrid::Sq<2, 2, 5>; using M22_6 = pgrid::Sq<2, 2, 6>;
+using M22_2 = pgrid::Sq<2, 2, 2>; using M22_3 = pgrid::Sq<2, 2, 3>; using M22_4 = pgrid::Sq<2, 2, 4>; using M22_5 = pgrid::Sq<2, 2, 5>; using M22_6 = pgrid::Sq<2, 2, 6>;
 using M44_2 = pgrid::Sq<4, 4, 2>; using M44_3 = pgrid::Sq<4, 4, 3>; using M44_4 = pgrid::Sq<4, 4, 4>;
 // hopping disorder (round 6): a (cosh, sinh) pair per bond from a table in LDS — the shapes of pgrid::patch_takes_disorder
 using SQ44D = pgrid::Sq<4, 4, 1, false>; using SQ26D = pgrid::Sq<2, 6, 1, false>; using SQ24D = pgrid::Sq<2, 4, 1, false>;
@@ -485,6 +485,23 @@ int pg_check(const char *what) {
 
 }   // namespace
 
+// The patch shape of ONE launch.  The memory layout of a vector does not depend on it (a shape only says which thread holds which sites), so a launch may
+// take another shape than the handle's: 4 x 4 patches on one wavefront (28 x 28, 32 x 32) have the fewest instructions per site and the shortest
+// dependent chain — one right-hand side: 89 us per preconditioned iteration against 96 as 2 x 2 patches on four wavefronts — but hold ONE wave per
+// SIMD (16 registers per vector), and a large batch is then latency-bound.  Measured (profiles/r06/patch_shape_by_batch_size.log, 32 x 32): the
+// recursion 79 -> 71 us at 48 right-hand sides, 96 -> 76 at 64, 133 -> 113 at 96, 176 -> 151 at 128 (24, 32: 63 -> 68, 66 -> 71: the other way); the
+// p/x-fused k_cg_ap_pg 70 -> 61, 100 -> 92, 157 -> 139; the iteration 250 -> 233, 318 -> 291, 477 -> 443, 589 -> 546; 28 x 28 at 64: 281 -> 261.  The
+// UNFUSED k_cg_ap_pg and k_mul_pg keep the handle's shape (72 right-hand sides: 184 -> 203 us the wrong way, 96: 273 -> 252).
+// `big`: a launch that may switch (the recursion, the fused k_cg_ap).  ELPH_PG_2X2_FROM=n: from n right-hand sides [48] (A/B; 0: never).
+static void pg_launch_shape(const elph_handle_s *h, int nrhs, bool big, int *px, int *py, int *nw) {
+    *px = h->pg_PX; *py = h->pg_PY; *nw = h->pg_NW > 1 ? h->pg_NW : 1;
+    if (!big || h->pg_kind != 1 || *nw != 1 || *px != 4 || *py != 4 || !h->pg_uniform_c) return;
+    const char *e = getenv("ELPH_PG_2X2_FROM"), *em = getenv("ELPH_PG_MW");
+    const int from = e ? atoi(e) : 48;
+    if (from <= 0 || nrhs < from || (em && em[0] == '0')) return;
+    *px = 2; *py = 2; *nw = ((h->pg_L / 2) * (h->pg_L / 2) + 63) / 64;      // 28: 196 threads, 32: 256 — four wavefronts
+}
+
 // Can the per-frequency recursion of this handle run in the patch layout?  (ELPH_NO_PG=1: the generic kernel, the A/B — read per call)
 bool elph_pg_cheb_usable(const elph_handle_s *h) {
     const char *e = getenv("ELPH_NO_PG");
@@ -508,8 +525,8 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_p
     if (rz_part && 2 * Lo2 > nrz) { elph_set_error("k_kpm_cheb_pg: %d r.z slots needed, %d available", 2 * Lo2, nrz); return ELPH_E_STATE; }
     const dim3 grid((unsigned)nrhs, (unsigned)Lo2);
 #define PG_CHEB(LAT) hipLaunchKernelGGL((k_kpm_cheb_pg<LAT>), grid, dim3(2 * LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, h->d_nu, K, N, Ls, Lo2, st, rz_part, nrz, (int)h->L, rr_part, h->d_pg_bond)
-    const int px = h->pg_PX, py = h->pg_PY;
-    const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
+    int px, py, nw;
+    pg_launch_shape(h, nrhs, true, &px, &py, &nw);
     if (!h->pg_uniform) {        // hopping disorder: the table variants (elph_pg_cheb_usable has checked the shape)
         if (!elph_pg_disorder_ok(h)) { elph_set_error("k_kpm_cheb_pg: hopping disorder on a patch shape without a table variant"); return ELPH_E_UNSUPPORTED; }
         if (nw == 2) PG_CHEB(M22_2D);
@@ -523,6 +540,7 @@ int elph_pg_kpm_cheb(elph_handle_s *h, int nrhs, const CgState *st, double *rz_p
     else if (h->pg_kind == 1 && nw > 1) {
         if (px == 2 && py == 2 && nw == 2) PG_CHEB(M22_2);
         else if (px == 2 && py == 2 && nw == 3) PG_CHEB(M22_3);
+        else if (px == 2 && py == 2 && nw == 4) PG_CHEB(M22_4);
         else if (px == 2 && py == 2 && nw == 5) PG_CHEB(M22_5);
         else if (px == 2 && py == 2 && nw == 6) PG_CHEB(M22_6);
         else if (px == 4 && py == 4 && nw == 2) PG_CHEB(M44_2);
@@ -571,7 +589,9 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     // waves 98 us, 10 = 1152 waves 140 us; profiles/r04/pgrid_large_lattices.log); beyond one round of 40-slice chunks: 20
     const int L = (int)h->L;
     static const int forceT = []() { const char *e = getenv("ELPH_PG_T"); return e ? atoi(e) : 0; }();
-    const long long slots = 1024LL * ((h->pg_kind != 2 && h->pg_PX * h->pg_PY <= 8) ? 2 : 1) / (h->pg_NW > 1 ? h->pg_NW : 1);      // (a slice of several wavefronts holds as many slots)
+    int px, py, nw;
+    pg_launch_shape(h, nrhs, fused, &px, &py, &nw);
+    const long long slots = 1024LL * ((h->pg_kind != 2 && px * py <= 8) ? 2 : 1) / nw;      // (a slice of several wavefronts holds as many slots)
     int T = 20;
     for (int c : {1, 2, 4, 5, 8, 10, 16, 20, 32, 40}) { if ((long long)nrhs * ((L + c - 1) / c) <= slots) { T = c; break; } }
     if (forceT > 0) T = forceT;
@@ -584,8 +604,6 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
         if (fused) hipLaunchKernelGGL((k_cg_ap_pg<LAT, true>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, B, m, parity, Ls, T, h->d_pg_bond);              \
         else hipLaunchKernelGGL((k_cg_ap_pg<LAT, false>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, B, m, parity, Ls, T, h->d_pg_bond);                \
     } while (0)
-    const int px = h->pg_PX, py = h->pg_PY;
-    const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
     if (!m.uniform) {
         if (nw == 2) PG_AP(M22_2D);
         else if (nw == 3) PG_AP(M22_3D);
@@ -598,6 +616,7 @@ int elph_pg_cg_ap(elph_handle_s *h, const CgBufs &B, const ModelDev &m, int nrhs
     else if (h->pg_kind == 1 && nw > 1) {
         if (px == 2 && py == 2 && nw == 2) PG_AP(M22_2);
         else if (px == 2 && py == 2 && nw == 3) PG_AP(M22_3);
+        else if (px == 2 && py == 2 && nw == 4) PG_AP(M22_4);
         else if (px == 2 && py == 2 && nw == 5) PG_AP(M22_5);
         else if (px == 2 && py == 2 && nw == 6) PG_AP(M22_6);
         else if (px == 4 && py == 4 && nw == 2) PG_AP(M44_2);
@@ -647,8 +666,8 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
         else if (which == 1) hipLaunchKernelGGL((k_mul_pg<LAT, 1>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, yS, vS, m, Ls, T, h->d_pg_bond);         \
         else hipLaunchKernelGGL((k_mul_pg<LAT, 2>), grid, dim3(LAT::NW * WAVE), LAT::TAB_BYTES, h->stream, yS, vS, m, Ls, T, h->d_pg_bond);                         \
     } while (0)
-    const int px = h->pg_PX, py = h->pg_PY;
-    const int nw = h->pg_NW > 1 ? h->pg_NW : 1;
+    int px, py, nw;
+    pg_launch_shape(h, nvec, false, &px, &py, &nw);
     if (!m.uniform) {
         if (nw == 2) PG_MUL(M22_2D);
         else if (nw == 3) PG_MUL(M22_3D);
@@ -661,6 +680,7 @@ int elph_pg_mul(elph_handle_s *h, const ModelDev &m, int which, double *yS, cons
     else if (h->pg_kind == 1 && nw > 1) {
         if (px == 2 && py == 2 && nw == 2) PG_MUL(M22_2);
         else if (px == 2 && py == 2 && nw == 3) PG_MUL(M22_3);
+        else if (px == 2 && py == 2 && nw == 4) PG_MUL(M22_4);
         else if (px == 2 && py == 2 && nw == 5) PG_MUL(M22_5);
         else if (px == 2 && py == 2 && nw == 6) PG_MUL(M22_6);
         else if (px == 4 && py == 4 && nw == 2) PG_MUL(M44_2);

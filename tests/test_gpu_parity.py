@@ -476,6 +476,32 @@ def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
     m.close()
 
 
+@pytest.mark.parametrize("tag", ["G40", "j"])
+def test_patch_shape_chosen_per_launch(tag, monkeypatch):
+    """32 x 32 and 28 x 28 lattices: from 48 right-hand sides a launch of the Chebyshev kernel / the p/x-fused k_cg_ap_pg takes 2 x 2 patches on four
+    wavefronts instead of the handle's 4 x 4 on one (pgrid.hip: pg_launch_shape) — the memory layout does not depend on the shape and every site sees the
+    same operations in the same order, so the solve must agree with the one-shape solve (ELPH_PG_2X2_FROM=0) to rounding of the inner products: equal
+    iteration counts up to the knife edge, solutions 1e-10."""
+    from elphdynamics_amd import configs, models, preconditioners as pc, synth
+    m = configs.make_model(tag, tol=1e-8)
+    nchains, per = 24, 2
+    X = np.stack([synth.phonon_field(m.Nph, m.Ltau, m.beta, m.dtau, seed=7700 + c) for c in range(nchains)])
+    models.update_model_chains_(m, X)
+    P = pc.SymmetricKPMPreconditioner(m, 20, 0.05, 1.0, 1.0)
+    pc.setup_chains_(P, rng=np.random.default_rng(25))
+    B = np.stack([synth.randn(7800 + r, m.Ndim) for r in range(nchains * per)])
+    out = {}
+    for mode in ("0", "48"):
+        monkeypatch.setenv("ELPH_PG_2X2_FROM", mode)
+        Xs = np.zeros_like(B)
+        it, res, fl = models.ldiv_batched_(Xs, m, B, P=P)
+        assert not fl.any()
+        out[mode] = (Xs, it)
+    assert np.abs(out["0"][1] - out["48"][1]).max() <= 1
+    assert rel(out["48"][0], out["0"][0]) < 1e-10
+    m.close()
+
+
 @pytest.mark.parametrize("tag,nchains,per", [("K", 8, 2), ("G40", 4, 2), ("L26", 8, 2)])
 def test_hopping_disorder_in_the_patch_layout_batched(tag, nchains, per, monkeypatch):
     """The preconditioned BATCH iteration on a disordered square lattice in the patch layout (24 x 24, 32 x 32, 26 x 26 on three wavefronts; tables of
