@@ -495,11 +495,18 @@ int pg_check(const char *what) {
 // `big`: a launch that may switch (the recursion, the fused k_cg_ap).  ELPH_PG_2X2_FROM=n: from n right-hand sides [48] (A/B; 0: never).
 static void pg_launch_shape(const elph_handle_s *h, int nrhs, bool big, int *px, int *py, int *nw) {
     *px = h->pg_PX; *py = h->pg_PY; *nw = h->pg_NW > 1 ? h->pg_NW : 1;
-    if (!big || h->pg_kind != 1 || *nw != 1 || *px != 4 || *py != 4 || !h->pg_uniform_c) return;
+    if (!big || *nw != 1) return;
     const char *e = getenv("ELPH_PG_2X2_FROM"), *em = getenv("ELPH_PG_MW");
     const int from = e ? atoi(e) : 48;
     if (from <= 0 || nrhs < from || (em && em[0] == '0')) return;
-    *px = 2; *py = 2; *nw = ((h->pg_L / 2) * (h->pg_L / 2) + 63) / 64;      // 28: 196 threads, 32: 256 — four wavefronts
+    if (h->pg_kind == 1 && *px == 4 && *py == 4 && h->pg_uniform_c) {
+        *px = 2; *py = 2; *nw = ((h->pg_L / 2) * (h->pg_L / 2) + 63) / 64;      // 28: 196 threads, 32: 256 — four wavefronts
+    } else if (h->pg_kind == 2 && *px == 4 && *py == 2) {
+        // honeycomb 20 x 20 cells (4 x 2 cells per lane: the other 16-register shape) as 2 x 2 cells on two wavefronts: 96 right-hand sides 315 -> 292 us per
+        // iteration, on two streams 295 -> 247; 18 x 18 (3 x 2 cells) is indifferent, 24 x 24 (3 x 3) LOSES as 2 x 2 cells on three (538 -> 590 at 128) and
+        // keeps its shape (profiles/r06/patch_shape_by_batch_size.log)
+        *px = 2; *py = 2; *nw = ((h->pg_L / 2) * (h->pg_L / 2) + 63) / 64;
+    }
 }
 
 // Can the per-frequency recursion of this handle run in the patch layout?  (ELPH_NO_PG=1: the generic kernel, the A/B — read per call)
