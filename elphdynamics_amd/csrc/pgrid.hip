@@ -499,8 +499,8 @@ static void pg_launch_shape(const elph_handle_s *h, int nrhs, bool big, int *px,
     const char *e = getenv("ELPH_PG_2X2_FROM"), *em = getenv("ELPH_PG_MW");
     const int from = e ? atoi(e) : 48;
     if (from <= 0 || nrhs < from || (em && em[0] == '0')) return;
-    if (h->pg_kind == 1 && *px == 4 && *py == 4 && h->pg_uniform_c) {
-        *px = 2; *py = 2; *nw = ((h->pg_L / 2) * (h->pg_L / 2) + 63) / 64;      // 28: 196 threads, 32: 256 — four wavefronts
+    if (h->pg_kind == 1 && *px * *py >= 16 && ((h->pg_L / 2) * (h->pg_L / 2) + 63) / 64 <= 6 && h->pg_uniform_c) {      // 4 x 4 (28, 32), 2 x 10 (30: 96 right-hand sides on two streams 477 -> 415 us), 4 x 6 (36: 472 -> 459 at 64)
+        *px = 2; *py = 2; *nw = ((h->pg_L / 2) * (h->pg_L / 2) + 63) / 64;      // 28: 196 threads, 32: 256 — four wavefronts; 30: 225 — four; 36: 324 — six
     } else if (h->pg_kind == 2 && *px == 4 && *py == 2) {
         // honeycomb 20 x 20 cells (4 x 2 cells per lane: the other 16-register shape) as 2 x 2 cells on two wavefronts: 96 right-hand sides 315 -> 292 us per
         // iteration, on two streams 295 -> 247; 18 x 18 (3 x 2 cells) is indifferent, 24 x 24 (3 x 3) LOSES as 2 x 2 cells on three (538 -> 590 at 128) and

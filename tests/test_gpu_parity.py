@@ -476,7 +476,7 @@ def test_kpm_with_hopping_disorder_vs_oracle(oracle, tag):
     m.close()
 
 
-@pytest.mark.parametrize("tag", ["G40", "j", "h20"])
+@pytest.mark.parametrize("tag", ["G40", "j", "h20", "l30", "l36"])
 def test_patch_shape_chosen_per_launch(tag, monkeypatch):
     """32 x 32 and 28 x 28 lattices (and the honeycomb lattice of 20 x 20 cells, 4 x 2 cells per lane): from 48 right-hand sides a launch of the
     Chebyshev kernel / the p/x-fused k_cg_ap_pg takes 2 x 2 patches on four (two) wavefronts instead of the handle's 4 x 4 on one (pgrid.hip: pg_launch_shape) — the memory layout does not depend on the shape and every site sees the
